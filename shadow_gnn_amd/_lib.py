@@ -1,0 +1,113 @@
+"""ctypes binding of libshadow_hip.so (the C ABI declared in include/shadow_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).
+There is NO CPU fallback: if the shared object is missing, or a call returns a
+non-zero status, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshadow_hip.so")
+
+SG_OK, SG_ERR_INVALID, SG_ERR_HIP, SG_ERR_CAPACITY, SG_ERR_IO, SG_ERR_STATE = 0, 1, 2, 3, 4, 5
+SG_METHOD = {"khop": 0, "ppr": 1, "nodeIID": 2}
+SG_AUG = {"hops": 1, "pprs": 2, "drnls": 4}
+
+
+class ShadowHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libshadow_hip status {code}: {msg}")
+        self.code = code
+
+
+class CapacityError(ShadowHipError):
+    """SG_ERR_CAPACITY -- grow the named capacity and call again."""
+
+
+class SgConfig(C.Structure):
+    _fields_ = [
+        ("method", C.c_int32), ("num_roots", C.c_int32), ("depth", C.c_int32),
+        ("budget", C.c_int32), ("k", C.c_int32), ("threshold", C.c_float),
+        ("add_self_edge", C.c_int32), ("include_target_conn", C.c_int32),
+        ("compat_overread", C.c_int32), ("aug_flags", C.c_int32),
+    ]
+
+
+class SgBatchOut(C.Structure):
+    _fields_ = [
+        ("d_node", C.c_void_p), ("d_indptr", C.c_void_p), ("d_indices", C.c_void_p),
+        ("d_edge_id", C.c_void_p), ("d_target", C.c_void_p), ("d_subg_nodes", C.c_void_p),
+        ("d_subg_edges", C.c_void_p), ("d_hop", C.c_void_p), ("d_ppr", C.c_void_p),
+        ("d_drnl", C.c_void_p), ("cap_nodes", C.c_uint64), ("cap_edges", C.c_uint64),
+    ]
+
+
+class SgBatchCounts(C.Structure):
+    _fields_ = [
+        ("n_tot", C.c_uint64), ("e_tot", C.c_uint64), ("num_subgraphs", C.c_uint32),
+        ("max_subg_nodes", C.c_uint32), ("max_subg_edges", C.c_uint32), ("overflow", C.c_uint32),
+        ("slots_scanned", C.c_uint64), ("frontier_reads", C.c_uint64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/shadow_hip.h
+_P = C.c_void_p
+SIGNATURES = {
+    "sg_last_error": (C.c_char_p, []),
+    "sg_abi_version": (C.c_int, []),
+    "sg_create": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "sg_create_from_bin": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "sg_destroy": (None, [_P]),
+    "sg_num_nodes": (C.c_uint32, [_P]),
+    "sg_num_edges": (C.c_uint64, [_P]),
+    "sg_num_nodes_target": (C.c_uint64, [_P]),
+    "sg_get_idx_root": (C.c_uint64, [_P]),
+    "sg_device_indptr": (_P, [_P]),
+    "sg_device_indices": (_P, [_P]),
+    "sg_shuffle_targets": (C.c_int, [_P, _P, C.c_uint64]),
+    "sg_next_roots": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "sg_set_caps": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "sg_get_caps": (C.c_int, [_P, C.POINTER(SgConfig), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "sg_set_ppr": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _P, C.c_uint32]),
+    "sg_load_ppr_bin": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_float]),
+    "sg_save_ppr_bin": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_float]),
+    "sg_drop_full_graph_info": (C.c_int, [_P]),
+    "sg_sample": (C.c_int, [_P, C.POINTER(SgConfig), C.c_uint64, C.c_uint32, C.c_uint64, _P,
+                             C.POINTER(SgBatchOut), _P]),
+    "sg_sample_finish": (C.c_int, [_P, C.POINTER(SgBatchCounts)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libshadow_hip.so.  torch is imported first so that the HIP runtime
+    torch ships (same SONAME libamdhip64.so.7) is the one the library binds to:
+    one runtime per process, torch's streams and allocations are directly usable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root. "
+            "shadow_gnn_amd has no CPU fallback.")
+    import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code == SG_OK:
+        return
+    msg = load().sg_last_error().decode(errors="replace")
+    if code == SG_ERR_CAPACITY:
+        raise CapacityError(code, msg)
+    raise ShadowHipError(code, msg)

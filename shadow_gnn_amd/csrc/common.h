@@ -1,0 +1,86 @@
+// Shared host/device helpers for libshadow_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "shadow_hip.h"
+
+namespace shadow {
+
+// thread-local last-error string behind sg_last_error()
+std::string &last_error();
+int set_error(int code, const char *fmt, ...);
+
+#define SHD_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return shadow::set_error(SG_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                               hipGetErrorString(_e), __FILE__, __LINE__);                 \
+  } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+// lanes below the calling lane
+__device__ __forceinline__ uint64_t lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(v, off, 64);
+    if (lane >= (uint32_t)off) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_reduce_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint32_t t = __shfl_xor(v, off, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread.  `wsum` is LDS scratch of
+// at least blockDim.x/64 + 1 words.  Returns the exclusive prefix; *total gets
+// the block sum.  Contains two __syncthreads().
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
+  const uint32_t lane = lane_id(), wave = wave_id();
+  const uint32_t nw = (blockDim.x + 63) >> 6;
+  uint32_t incl = wave_incl_scan(v);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < nw; w++) {
+    uint32_t x = wsum[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+}  // namespace shadow

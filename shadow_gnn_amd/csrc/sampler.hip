@@ -1,0 +1,1204 @@
+// sampler.hip -- MI355X (gfx950) subgraph sampler behind the sg_* C ABI.
+//
+// Replaces the reference's C++/OpenMP backend
+// (para_graph_sampler/graph_engine/backend/ParallelSampler.cpp) -- it is a new
+// design, not a translation:
+//
+//   * the full-graph CSR lives in HBM; one WORKGROUP samples one subgraph;
+//   * node selection (k-hop frontier expansion .cpp:510-547, PPR top-k
+//     .cpp:565-590, nodeIID .cpp:498-505) dedupes through an LDS-resident
+//     open-addressing hash set; frontiers are LDS lists;
+//   * the selected ids are bitonic-sorted in LDS (== std::sort, .cpp:362) and
+//     the hash value of each id becomes its rank (orig2subID, .cpp:369-372);
+//   * node-induced slicing (.cpp:378-431) is ONE ordered streaming pass over
+//     the concatenated full-graph rows of the subgraph's nodes: every stream
+//     slot is a coalesced uint32 load from HBM + an LDS hash probe; wavefront
+//     ballots + a tiny LDS scan give every surviving edge its output rank, so
+//     the emitted CSR is in exactly the reference's order with no atomics;
+//   * a second, light kernel relocates the per-subgraph results into the
+//     block-diagonal batch layout (frontend/graph.py:280-320), and runs the
+//     hop BFS / DRNL labels (Graph.cpp:32-73) on the emitted CSR.
+//
+// Subgraphs whose node set does not fit the LDS tables are re-sampled by the
+// same code instantiated over global-memory tables (sg_sample_big_kernel).
+//
+// Budgeted k-hop draws come from Philox4x32-10 keyed on
+// (seed, subgraph serial, level, node, draw) -- see DESIGN.md "RNG contract".
+#include <fcntl.h>
+#include <stdarg.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace shadow {
+
+std::string &last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+int set_error(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kItems = 4;            // stream slots per thread per chunk
+constexpr uint32_t kLdsCapNodes = 2560;   // largest node set handled by the LDS kernel
+constexpr uint32_t kMaxRoots = 8;
+
+// control words (LDS)
+enum { C_NNODES = 0, C_NF0 = 1, C_NF1 = 2, C_OVF = 3, C_MFAIL = 4, C_FRONT_NODES = 5,
+       C_FRONT_READS = 6, C_CHANGED = 7, C_WORDS = 16 };
+
+// per-subgraph result words in scratch (s_cnt)
+enum { R_N = 0, R_E = 1, R_FLAGS = 2, R_SLOTS = 3, R_FNODES = 4, R_FREADS = 5, R_WORDS = 8 };
+
+struct SampleParams {
+  const uint32_t *indptr;
+  const uint32_t *indices;
+  uint32_t N;
+  uint64_t nnz;
+  const uint32_t *roots;  // [P*R]
+  uint32_t P;
+  int R;
+  int method, depth, budget, k;
+  float threshold;
+  int include_self, include_target_conn, compat;
+  uint64_t seed, serial_base;
+  const int32_t *ppr_row;
+  const uint32_t *ppr_len;
+  const uint32_t *ppr_neigh;
+  const float *ppr_score;
+  uint32_t ppr_stride;
+  // table geometry
+  uint32_t capn;      // node capacity of the tables used by this launch
+  uint32_t capf;      // frontier list capacity
+  uint32_t H;         // hash slots (power of two)
+  uint32_t hshift;    // 32 - log2(H)
+  // per-subgraph scratch (stride = cap_nodes_scr / cap_edges_scr)
+  uint32_t cap_nodes_scr, cap_edges_scr;
+  uint32_t *s_nodes;   // [P*cap_nodes_scr]
+  float *s_ppr;        // [P*cap_nodes_scr]
+  uint32_t *s_rowptr;  // [P*(cap_nodes_scr+1)]
+  uint32_t *s_col;     // [P*cap_edges_scr]
+  uint32_t *s_eid;     // [P*cap_edges_scr]
+  uint32_t *s_tgt;     // [P*kMaxRoots]
+  uint32_t *s_cnt;     // [P*R_WORDS]
+  // global tables for the big path
+  uint32_t *g_tables;        // [n_big_slots * g_stride]
+  uint64_t g_stride;         // words per slot
+  uint32_t *g_ticket;        // work queue head for the big path
+};
+
+struct Tables {
+  uint32_t *hkey;    // [H]
+  uint32_t *hval;    // [H] level mask, later the sub id
+  float *pprv;       // [H] (ppr method) or nullptr
+  uint32_t *nodes;   // [capn]
+  uint32_t *rowptr;  // [capn+1]
+  uint32_t *front0;  // [capf]
+  uint32_t *front1;  // [capf]
+};
+
+// ---------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------- hash set
+__device__ __forceinline__ uint32_t hash_slot(uint32_t key, uint32_t hshift) {
+  return (key * 0x9E3779B1u) >> hshift;
+}
+
+// insert `key`; returns its slot.  New keys are appended to t.nodes.
+__device__ __forceinline__ uint32_t tab_insert(const Tables &t, uint32_t *ctrl, uint32_t key,
+                                               uint32_t hmask, uint32_t hshift, uint32_t capn) {
+  uint32_t slot = hash_slot(key, hshift);
+  for (;;) {
+    uint32_t old = atomicCAS(&t.hkey[slot], kEmpty, key);
+    if (old == kEmpty) {
+      uint32_t idx = atomicAdd(&ctrl[C_NNODES], 1u);
+      if (idx < capn) t.nodes[idx] = key;
+      else atomicOr(&ctrl[C_OVF], 1u);
+      return slot;
+    }
+    if (old == key) return slot;
+    slot = (slot + 1) & hmask;
+  }
+}
+
+__device__ __forceinline__ int32_t tab_find(const uint32_t *hkey, uint32_t key, uint32_t hmask,
+                                            uint32_t hshift) {
+  uint32_t slot = hash_slot(key, hshift);
+  for (;;) {
+    uint32_t k = hkey[slot];
+    if (k == key) return (int32_t)slot;
+    if (k == kEmpty) return -1;
+    slot = (slot + 1) & hmask;
+  }
+}
+
+__device__ __forceinline__ bool overflowed(uint32_t *ctrl) {
+  return __hip_atomic_load(&ctrl[C_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+}
+
+// add `u` to the touched set and (unless this is the last level) to the next frontier
+__device__ __forceinline__ void touch(const Tables &t, uint32_t *ctrl, uint32_t u, uint32_t hmask,
+                                      uint32_t hshift, uint32_t capn, uint32_t capf, bool last,
+                                      uint32_t bit_next, uint32_t *nxt, int nxt_cnt_idx) {
+  if (overflowed(ctrl)) return;
+  uint32_t slot = tab_insert(t, ctrl, u, hmask, hshift, capn);
+  if (!last) {
+    uint32_t old = atomicOr(&t.hval[slot], bit_next);
+    if (!(old & bit_next)) {
+      uint32_t idx = atomicAdd(&ctrl[nxt_cnt_idx], 1u);
+      if (idx < capf) nxt[idx] = u;
+      else atomicOr(&ctrl[C_OVF], 4u);
+    }
+  }
+}
+
+// All-ascending bitonic sort of a[0..n) with virtual +inf padding (no storage
+// for the padding: a compare-exchange whose upper partner is >= n is a no-op).
+__device__ __forceinline__ void block_sort_u32(uint32_t *a, uint32_t n) {
+  if (n < 2) { __syncthreads(); return; }
+  uint32_t p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  const uint32_t half = p2 >> 1;
+  for (uint32_t k = 2; k <= p2; k <<= 1) {
+    const uint32_t hk = k >> 1;
+    for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+      uint32_t i = (t / hk) * k + (t % hk);
+      uint32_t j = i ^ (k - 1);
+      if (j < n) {
+        uint32_t x = a[i], y = a[j];
+        if (x > y) { a[i] = y; a[j] = x; }
+      }
+    }
+    __syncthreads();
+    for (uint32_t s = hk >> 1; s >= 1; s >>= 1) {
+      for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+        uint32_t i = (t / s) * (2 * s) + (t % s);
+        uint32_t j = i + s;
+        if (j < n) {
+          uint32_t x = a[i], y = a[j];
+          if (x > y) { a[i] = y; a[j] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ bool is_root(const uint32_t *roots, int R, uint32_t v) {
+  bool r = false;
+  for (int i = 0; i < R; i++) r |= (roots[i] == v);
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// Sample ONE subgraph `s` with the calling workgroup.  `t` points at LDS (fast
+// kernel) or at a global-memory table slot (big kernel); ctrl/wsum/wcnt are LDS.
+// Writes the subgraph-local result into the scratch arrays of subgraph s.
+// ---------------------------------------------------------------------------
+template <bool kGlobalTables>
+__device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t s, const Tables &t,
+                                                uint32_t *ctrl, uint32_t *wsum, uint32_t *wcnt) {
+  const uint32_t tid = threadIdx.x, T = blockDim.x;
+  const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
+  const uint32_t H = p.H, hmask = H - 1, hshift = p.hshift;
+  const uint32_t capn = p.capn, capf = p.capf;
+  const int R = p.R;
+  const uint32_t *roots = p.roots + (size_t)s * R;
+  const uint64_t serial = p.serial_base + s;
+
+  // ---- phase 0: clear tables
+  for (uint32_t i = tid; i < H; i += T) { t.hkey[i] = kEmpty; t.hval[i] = 0; }
+  if (tid < C_WORDS) ctrl[tid] = 0;
+  __syncthreads();
+
+  // ---- phase 1: node selection
+  if (p.method == SG_METHOD_PPR) {
+    // ParallelSampler::ppr, .cpp:572-590 (write order: later writes win)
+    for (int r = 0; r < R; r++) {
+      const uint32_t root = roots[r];
+      const int32_t row = p.ppr_row[root];
+      const uint32_t size_all = row < 0 ? 0u : p.ppr_len[row];
+      const uint32_t size_neigh = min((uint32_t)p.k, size_all);
+      const uint32_t *nb = p.ppr_neigh + (size_t)(row < 0 ? 0 : row) * p.ppr_stride;
+      const float *sc = p.ppr_score + (size_t)(row < 0 ? 0 : row) * p.ppr_stride;
+      const float max_ppr = size_neigh > 1 ? sc[1] : 0.0f;
+      if (tid == 0) {
+        uint32_t slot = tab_insert(t, ctrl, root, hmask, hshift, capn);
+        t.pprv[slot] = (size_neigh <= 1 && size_all > 0) ? sc[0] : -1.0f;   // :574, :581
+        ctrl[C_MFAIL] = size_neigh;
+      }
+      __syncthreads();
+      // first index failing the threshold test (:584); scores are non-increasing
+      for (uint32_t i = tid; i < size_neigh; i += T) {
+        bool fail = (max_ppr == 0.0f) || (sc[i] / max_ppr < p.threshold);
+        if (fail) atomicMin(&ctrl[C_MFAIL], i);
+      }
+      __syncthreads();
+      const uint32_t m = ctrl[C_MFAIL];
+      for (uint32_t i = tid; i < m; i += T) {
+        uint32_t slot = tab_insert(t, ctrl, nb[i], hmask, hshift, capn);
+        t.pprv[slot] = sc[i];                                                // :587
+      }
+      __syncthreads();
+    }
+  } else {
+    // roots: level 0 (.cpp:519-522), nodeIID: roots only (.cpp:502-505)
+    if (tid < (uint32_t)R) {
+      uint32_t slot = tab_insert(t, ctrl, roots[tid], hmask, hshift, capn);
+      uint32_t old = atomicOr(&t.hval[slot], 1u);
+      if (!(old & 1u)) {
+        uint32_t idx = atomicAdd(&ctrl[C_NF0], 1u);
+        t.front0[idx] = roots[tid];
+      }
+    }
+    __syncthreads();
+    const int depth = p.method == SG_METHOD_KHOP ? p.depth : 0;
+    const int budget = p.budget;
+    uint32_t fr_nodes = 0, fr_reads = 0;
+    for (int lvl = 0; lvl < depth; lvl++) {
+      const uint32_t *cur = (lvl & 1) ? t.front1 : t.front0;
+      uint32_t *nxt = (lvl & 1) ? t.front0 : t.front1;
+      const int cur_idx = (lvl & 1) ? C_NF1 : C_NF0, nxt_idx = (lvl & 1) ? C_NF0 : C_NF1;
+      const uint32_t nf = min(ctrl[cur_idx], capf);
+      __syncthreads();
+      if (tid == 0) ctrl[nxt_idx] = 0;
+      __syncthreads();
+      const bool last = (lvl + 1 == depth);
+      const uint32_t bit_next = 1u << (lvl + 1);
+      if (budget >= 0) {
+        // one work item = (frontier node, group of 4 draws)
+        const uint32_t groups = ((uint32_t)budget + 3u) >> 2;
+        const uint32_t items = nf * groups;
+        for (uint32_t q = tid; q < items; q += T) {
+          const uint32_t fi = q / groups, g = q - fi * groups;
+          const uint32_t v = cur[fi];
+          const uint32_t e0 = p.indptr[v], deg = p.indptr[v + 1] - e0;
+          const uint32_t d0 = g * 4;
+          if (g == 0) { fr_nodes++; fr_reads += min(deg, (uint32_t)budget); }
+          if (deg <= (uint32_t)budget) {                               // .cpp:528-531
+            const uint32_t d1 = min(d0 + 4, deg);
+            for (uint32_t d = d0; d < d1; d++)
+              touch(t, ctrl, p.indices[e0 + d], hmask, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
+          } else {                                                     // .cpp:533-536
+            uint32_t rnd[4];
+            philox4x32_10(v, (uint32_t)lvl * 65536u + g, (uint32_t)serial, (uint32_t)(serial >> 32),
+                          (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+            const uint32_t d1 = min(d0 + 4, (uint32_t)budget);
+            for (uint32_t d = d0; d < d1; d++) {
+              const uint32_t off = __umulhi(rnd[d & 3], deg);
+              touch(t, ctrl, p.indices[e0 + off], hmask, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
+            }
+          }
+        }
+      } else {
+        // full expansion: one wavefront streams one frontier row (coalesced)
+        for (uint32_t fi = wave; fi < nf; fi += nw) {
+          const uint32_t v = cur[fi];
+          const uint32_t e0 = p.indptr[v], deg = p.indptr[v + 1] - e0;
+          if (lane == 0) { fr_nodes++; fr_reads += deg; }
+          for (uint32_t d = lane; d < deg; d += 64)
+            touch(t, ctrl, p.indices[e0 + d], hmask, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
+        }
+      }
+      __syncthreads();
+      if (overflowed(ctrl)) break;
+    }
+    fr_nodes = wave_reduce_sum(fr_nodes);
+    fr_reads = wave_reduce_sum(fr_reads);
+    if (lane == 0) { atomicAdd(&ctrl[C_FRONT_NODES], fr_nodes); atomicAdd(&ctrl[C_FRONT_READS], fr_reads); }
+    __syncthreads();
+  }
+
+  // Global-memory tables: the hash set was built with L2 atomics, the phases
+  // below read it with plain loads -> drop this CU's possibly stale L1 lines.
+  if (kGlobalTables) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
+
+  uint32_t *cnt = p.s_cnt + (size_t)s * R_WORDS;
+  const uint32_t n_all = ctrl[C_NNODES];
+  if (overflowed(ctrl) || n_all > capn || n_all > p.cap_nodes_scr) {
+    if (tid == 0) {
+      cnt[R_N] = n_all; cnt[R_E] = 0; cnt[R_FLAGS] = 1u; cnt[R_SLOTS] = 0;
+      cnt[R_FNODES] = ctrl[C_FRONT_NODES]; cnt[R_FREADS] = ctrl[C_FRONT_READS];
+    }
+    __syncthreads();
+    return;
+  }
+  const uint32_t n = n_all;
+
+  // ---- phase 2: sort ids ascending (.cpp:362) and rank them (.cpp:369-372)
+  block_sort_u32(t.nodes, n);
+  uint32_t *g_nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
+  float *g_ppr = p.s_ppr + (size_t)s * p.cap_nodes_scr;
+  for (uint32_t i = tid; i < n; i += T) {
+    const uint32_t v = t.nodes[i];
+    const int32_t slot = tab_find(t.hkey, v, hmask, hshift);
+    t.hval[slot] = i;
+    g_nodes[i] = v;
+    g_ppr[i] = (p.method == SG_METHOD_PPR) ? t.pprv[slot] : -1.0f;     // .cpp:365, :545
+  }
+  __syncthreads();
+  if (tid < (uint32_t)R) {                                             // .cpp:373-377
+    const int32_t slot = tab_find(t.hkey, roots[tid], hmask, hshift);
+    p.s_tgt[(size_t)s * kMaxRoots + tid] = t.hval[slot];
+  }
+
+  // ---- phase 3: stream-slot prefix per row: deg(v)+1 slots (last = sentinel)
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += T) {
+    const uint32_t i = base + tid;
+    uint32_t val = 0;
+    if (i < n) { const uint32_t v = t.nodes[i]; val = p.indptr[v + 1] - p.indptr[v] + 1u; }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(val, wsum, &total);
+    if (i < n) t.rowptr[i] = carry + ex;
+    carry += total;
+  }
+  if (tid == 0) t.rowptr[n] = carry;
+  __syncthreads();
+  const uint32_t S = carry;
+
+  // ---- phase 4: ordered streaming induction (.cpp:381-427)
+  const bool incl_self = p.include_self != 0;
+  const bool itc = (p.include_target_conn != 0) || (R == 1);          // .cpp:356-358
+  const bool compat = p.compat != 0;
+  const uint32_t cape = p.cap_edges_scr;
+  uint32_t *g_rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
+  uint32_t *g_col = p.s_col + (size_t)s * cape;
+  uint32_t *g_eid = p.s_eid + (size_t)s * cape;
+  uint32_t e_run = 0;
+  const uint32_t chunk = T * kItems;
+  for (uint32_t base = 0; base < S; base += chunk) {
+    uint32_t o_col[kItems], o_eid[kItems], o_row[kItems], o_rank[kItems];
+    uint32_t o_flags[kItems];   // bit0 self edge, bit1 own edge, bit2 first slot of its row
+#pragma unroll
+    for (int kk = 0; kk < kItems; kk++) {
+      const uint32_t slot = base + kk * T + tid;
+      uint32_t flags = 0, col = 0, eid = 0, row = 0;
+      if (slot < S) {
+        // largest row with rowptr[row] <= slot
+        uint32_t lo = 0, hi = n;
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (t.rowptr[mid] <= slot) lo = mid; else hi = mid;
+        }
+        row = lo;
+        const uint32_t rs = t.rowptr[row];
+        const uint32_t j = slot - rs;
+        const uint32_t deg = t.rowptr[row + 1] - rs - 1u;
+        const uint32_t v = t.nodes[row];
+        const uint32_t e0 = p.indptr[v];
+        if (j == 0) flags |= 4u;
+        uint32_t cand = kEmpty;   // neighbour id to test for membership
+        if (j < deg) {
+          cand = p.indices[e0 + j];
+          eid = e0 + j;
+          if (incl_self) {
+            // self edge goes right before the first neighbour > v (.cpp:387-400)
+            const bool prev_lt = (j == 0) || (p.indices[e0 + j - 1] < v);
+            if (prev_lt && v < cand) flags |= 1u;
+          }
+        } else {
+          // sentinel slot: self edge after the last neighbour, or the compat over-read
+          bool inserted_here = false;
+          if (incl_self) {
+            inserted_here = (deg == 0) || (p.indices[e0 + deg - 1] < v);
+            if (inserted_here) flags |= 1u;
+          }
+          if (compat && !inserted_here) {
+            bool inserted = false;
+            if (incl_self) {
+              // was the self edge inserted earlier in this row?  <=> v not in the row
+              uint32_t l2 = 0, h2 = deg;
+              while (l2 < h2) { const uint32_t m2 = (l2 + h2) >> 1; if (p.indices[e0 + m2] < v) l2 = m2 + 1; else h2 = m2; }
+              inserted = !(l2 < deg && p.indices[e0 + l2] == v);
+            }
+            if (!inserted && (uint64_t)e0 + deg < p.nnz) { cand = p.indices[e0 + deg]; eid = e0 + deg; }
+          }
+        }
+        if (cand != kEmpty) {
+          const int32_t hs = tab_find(t.hkey, cand, hmask, hshift);
+          if (hs >= 0) {
+            bool keep = true;
+            if (!itc) keep = !(is_root(roots, R, v) && is_root(roots, R, cand));   // .cpp:414-418
+            if (keep) { flags |= 2u; col = t.hval[hs]; }
+          }
+        }
+      }
+      const uint64_t m_self = __ballot(flags & 1u), m_own = __ballot(flags & 2u);
+      const uint64_t lt = lanemask_lt();
+      o_rank[kk] = __popcll(m_self & lt) + __popcll(m_own & lt);
+      if (lane == 0) wcnt[kk * nw + wave] = __popcll(m_self) + __popcll(m_own);
+      o_flags[kk] = flags; o_col[kk] = col; o_eid[kk] = eid; o_row[kk] = row;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const uint32_t cntw = kItems * nw;
+      const uint32_t x = tid < cntw ? wcnt[tid] : 0u;
+      const uint32_t incl = wave_incl_scan(x);
+      if (tid < cntw) wcnt[tid] = incl - x;
+      if (tid == 63) wcnt[64] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kItems; kk++) {
+      const uint32_t flags = o_flags[kk];
+      uint32_t pos = e_run + wcnt[kk * nw + wave] + o_rank[kk];
+      if (flags & 4u) g_rowptr[o_row[kk]] = pos;
+      if (flags & 1u) {
+        if (pos < cape) { g_col[pos] = o_row[kk]; g_eid[pos] = 0xFFFFFFFFu; }   // .cpp:408-410
+        pos++;
+      }
+      if (flags & 2u) {
+        if (pos < cape) { g_col[pos] = o_col[kk]; g_eid[pos] = o_eid[kk]; }     // .cpp:420-422
+      }
+    }
+    e_run += wcnt[64];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    g_rowptr[n] = e_run;
+    cnt[R_N] = n; cnt[R_E] = e_run; cnt[R_FLAGS] = (e_run > cape) ? 2u : 0u; cnt[R_SLOTS] = S;
+    cnt[R_FNODES] = ctrl[C_FRONT_NODES]; cnt[R_FREADS] = ctrl[C_FRONT_READS];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// LDS carve shared by host (size computation) and device
+struct LdsLayout {
+  size_t hkey, hval, pprv, nodes, rowptr, front0, front1, ctrl, wsum, wcnt, total;
+};
+
+__host__ __device__ inline LdsLayout lds_layout(uint32_t H, uint32_t capn, uint32_t capf, bool ppr, uint32_t T) {
+  LdsLayout L;
+  size_t o = 0;
+  L.hkey = o; o += (size_t)H * 4;
+  L.hval = o; o += (size_t)H * 4;
+  L.pprv = o; o += ppr ? (size_t)H * 4 : 0;
+  L.nodes = o; o += (((size_t)capn * 4) + 15) & ~(size_t)15;
+  L.rowptr = o; o += (((size_t)(capn + 1) * 4) + 15) & ~(size_t)15;
+  L.front0 = o; o += (((size_t)capf * 4) + 15) & ~(size_t)15;
+  L.front1 = o; o += (((size_t)capf * 4) + 15) & ~(size_t)15;
+  L.ctrl = o; o += C_WORDS * 4;
+  L.wsum = o; o += 32 * 4;
+  L.wcnt = o; o += (((size_t)(kItems * (T / 64)) + 1 + 64) * 4 + 15) & ~(size_t)15;
+  L.total = o;
+  return L;
+}
+
+__global__ void sg_sample_lds_kernel(SampleParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const LdsLayout L = lds_layout(p.H, p.capn, p.capf, p.method == SG_METHOD_PPR, blockDim.x);
+  Tables t;
+  t.hkey = (uint32_t *)(smem + L.hkey);
+  t.hval = (uint32_t *)(smem + L.hval);
+  t.pprv = (float *)(smem + L.pprv);
+  t.nodes = (uint32_t *)(smem + L.nodes);
+  t.rowptr = (uint32_t *)(smem + L.rowptr);
+  t.front0 = (uint32_t *)(smem + L.front0);
+  t.front1 = (uint32_t *)(smem + L.front1);
+  uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
+  uint32_t *wsum = (uint32_t *)(smem + L.wsum);
+  uint32_t *wcnt = (uint32_t *)(smem + L.wcnt);
+  sample_subgraph<false>(p, blockIdx.x, t, ctrl, wsum, wcnt);
+}
+
+// Big path: persistent workgroups pull overflowed subgraphs (flag bit0 from the
+// LDS kernel) from a ticket counter and redo them over global-memory tables.
+__global__ void sg_sample_big_kernel(SampleParams p) {
+  __shared__ uint32_t ctrl[C_WORDS];
+  __shared__ uint32_t wsum[32];
+  __shared__ uint32_t wcnt[kItems * 16 + 1 + 64];
+  __shared__ uint32_t s_next;
+  uint32_t *base = p.g_tables + (size_t)blockIdx.x * p.g_stride;
+  Tables t;
+  size_t o = 0;
+  t.hkey = base + o; o += p.H;
+  t.hval = base + o; o += p.H;
+  t.pprv = (float *)(base + o); o += p.H;
+  t.nodes = base + o; o += p.capn;
+  t.rowptr = base + o; o += (size_t)p.capn + 1;
+  t.front0 = base + o; o += p.capf;
+  t.front1 = base + o; o += p.capf;
+  for (;;) {
+    if (threadIdx.x == 0) s_next = atomicAdd(p.g_ticket, 1u);
+    __syncthreads();
+    const uint32_t s = s_next;
+    __syncthreads();
+    if (s >= p.P) return;
+    const uint32_t flags = p.s_cnt[(size_t)s * R_WORDS + R_FLAGS];
+    if (!(flags & 1u)) continue;
+    sample_subgraph<true>(p, s, t, ctrl, wsum, wcnt);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Relocation into the block-diagonal batch (frontend/graph.py:280-320), hop
+// BFS (Graph.cpp:32-64) and DRNL (Graph.cpp:66-73, .cpp:438-451).
+// ---------------------------------------------------------------------------
+struct RelocParams {
+  uint32_t P;
+  int R;
+  int aug_flags;
+  uint32_t cap_nodes_scr, cap_edges_scr;
+  const uint32_t *s_nodes;
+  const float *s_ppr;
+  const uint32_t *s_rowptr;
+  const uint32_t *s_col;
+  const uint32_t *s_eid;
+  const uint32_t *s_tgt;
+  const uint32_t *s_cnt;
+  uint32_t *s_tmp;       // [P*cap_nodes_scr] BFS scratch (drnl)
+  sg_batch_out out;
+  uint64_t *d_counts;    // [8] n_tot, e_tot, max_n, max_e, overflow, slots, fnodes, freads
+};
+
+__device__ __forceinline__ void bfs_local(const uint32_t *rowptr, const uint32_t *col, uint32_t n,
+                                          uint32_t src, uint32_t *hop, uint32_t *changed) {
+  const uint32_t tid = threadIdx.x, T = blockDim.x;
+  for (uint32_t i = tid; i < n; i += T) hop[i] = (i == src) ? 0u : 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t cur = 0;; cur++) {
+    if (tid == 0) *changed = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += T) {
+      if (hop[i] == cur) {
+        for (uint32_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+          const uint32_t u = col[e];
+          if (hop[u] == 0xFFFFFFFFu) { hop[u] = cur + 1; *changed = 1; }
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t ch = *changed;
+    __syncthreads();
+    if (!ch) break;
+  }
+}
+
+__global__ void sg_relocate_kernel(RelocParams p) {
+  __shared__ uint64_t red[4 * 16];
+  __shared__ uint64_t offs[2];
+  __shared__ uint32_t changed;
+  const uint32_t s = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
+  // exclusive prefix of (nodes, edges) over the preceding subgraphs
+  uint64_t pn = 0, pe = 0;
+  for (uint32_t q = tid; q < s; q += T) {
+    const uint32_t *c = p.s_cnt + (size_t)q * R_WORDS;
+    pn += c[R_N];
+    pe += c[R_E];
+  }
+  for (int off = 32; off >= 1; off >>= 1) { pn += __shfl_xor(pn, off, 64); pe += __shfl_xor(pe, off, 64); }
+  if (lane == 0) { red[wave] = pn; red[16 + wave] = pe; }
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t a = 0, b = 0;
+    for (uint32_t w = 0; w < nw; w++) { a += red[w]; b += red[16 + w]; }
+    offs[0] = a; offs[1] = b;
+  }
+  __syncthreads();
+  const uint64_t noff = offs[0], eoff = offs[1];
+  const uint32_t *c = p.s_cnt + (size_t)s * R_WORDS;
+  const uint32_t n = c[R_N], e = c[R_E], flags = c[R_FLAGS];
+  const sg_batch_out &o = p.out;
+  if (tid == 0) {
+    o.d_subg_nodes[s] = (uint32_t)noff;
+    o.d_subg_edges[s] = (uint32_t)eoff;
+    if (s + 1 == p.P) { o.d_subg_nodes[p.P] = (uint32_t)(noff + n); o.d_subg_edges[p.P] = (uint32_t)(eoff + e); }
+    atomicMax((unsigned long long *)&p.d_counts[2], (unsigned long long)n);
+    atomicMax((unsigned long long *)&p.d_counts[3], (unsigned long long)e);
+    atomicAdd((unsigned long long *)&p.d_counts[5], (unsigned long long)c[R_SLOTS]);
+    atomicAdd((unsigned long long *)&p.d_counts[6], (unsigned long long)c[R_FNODES]);
+    atomicAdd((unsigned long long *)&p.d_counts[7], (unsigned long long)c[R_FREADS]);
+    if (s + 1 == p.P) { p.d_counts[0] = noff + n; p.d_counts[1] = eoff + e; }
+  }
+  uint32_t ovf = flags & 3u;
+  if (noff + n > o.cap_nodes) ovf |= 4u;
+  if (eoff + e > o.cap_edges) ovf |= 8u;
+  if (ovf) {
+    if (tid == 0) atomicOr((unsigned long long *)&p.d_counts[4], (unsigned long long)ovf);
+    return;
+  }
+  const uint32_t *nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
+  const float *ppr = p.s_ppr + (size_t)s * p.cap_nodes_scr;
+  const uint32_t *rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
+  const uint32_t *col = p.s_col + (size_t)s * p.cap_edges_scr;
+  const uint32_t *eid = p.s_eid + (size_t)s * p.cap_edges_scr;
+  for (uint32_t i = tid; i < n; i += T) {
+    o.d_node[noff + i] = nodes[i];
+    o.d_indptr[noff + i] = (uint32_t)(eoff + rowptr[i]);
+    if (o.d_ppr) o.d_ppr[noff + i] = ppr[i];
+  }
+  if (s + 1 == p.P && tid == 0) o.d_indptr[noff + n] = (uint32_t)(eoff + e);
+  for (uint32_t j = tid; j < e; j += T) {
+    o.d_indices[eoff + j] = (uint32_t)(noff + col[j]);
+    o.d_edge_id[eoff + j] = eid[j];
+  }
+  const uint32_t *tgt = p.s_tgt + (size_t)s * kMaxRoots;
+  if (tid < (uint32_t)p.R) o.d_target[(size_t)s * p.R + tid] = (uint32_t)(noff + tgt[tid]);
+  if ((p.aug_flags & SG_AUG_HOPS) && o.d_hop) {
+    bfs_local(rowptr, col, n, tgt[0], o.d_hop + noff, &changed);            // .cpp:433-436
+  }
+  if ((p.aug_flags & SG_AUG_DRNLS) && o.d_drnl && p.R >= 2) {               // .cpp:438-451
+    uint32_t *dx = p.s_tmp + (size_t)s * p.cap_nodes_scr;
+    uint32_t *dy = o.d_drnl + noff;
+    bfs_local(rowptr, col, n, tgt[0], dx, &changed);
+    bfs_local(rowptr, col, n, tgt[1], dy, &changed);
+    for (uint32_t i = tid; i < n; i += T) {
+      const uint32_t a = dx[i], b = dy[i];
+      uint32_t r;
+      if (a >= 255u || b >= 255u) r = 255u;
+      else { const uint32_t d = a + b, mn = a < b ? a : b; r = 1u + mn + (d / 2) * ((d / 2) + (d % 2) - 1u); }
+      dy[i] = r;
+    }
+  }
+}
+
+}  // namespace shadow
+
+// ===========================================================================
+// Host side
+// ===========================================================================
+using namespace shadow;
+
+struct sg_sampler {
+  int device = 0;
+  uint32_t N = 0;
+  uint64_t nnz = 0;
+  uint32_t *d_indptr = nullptr;
+  uint32_t *d_indices = nullptr;
+  bool owns_graph = false;
+  bool graph_dropped = false;
+  uint32_t *d_targets = nullptr;
+  uint64_t num_targets = 0, cap_targets = 0;
+  uint64_t idx_root = 0;
+  uint64_t seed = 0, serial_next = 0;
+  // ppr table (device) + host mirror for sg_save_ppr_bin
+  int32_t *d_ppr_row = nullptr;
+  uint32_t *d_ppr_len = nullptr, *d_ppr_neigh = nullptr;
+  float *d_ppr_score = nullptr;
+  uint32_t ppr_stride = 0, ppr_rows = 0;
+  std::vector<uint32_t> h_ppr_targets, h_ppr_len, h_ppr_neigh;
+  std::vector<float> h_ppr_score;
+  // scratch
+  void *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void *d_big = nullptr;
+  size_t big_bytes = 0;
+  uint32_t user_cap_nodes = 0, user_cap_edges = 0;
+  uint64_t *d_counts = nullptr;   // [8] + ticket
+  uint64_t *h_counts = nullptr;   // pinned
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+  uint32_t pending_P = 0;
+};
+
+static uint32_t next_pow2(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return (uint32_t)p;
+}
+
+static int ensure(void **ptr, size_t *have, size_t need) {
+  if (*have >= need) return SG_OK;
+  if (*ptr) (void)hipFree(*ptr);
+  *ptr = nullptr; *have = 0;
+  size_t want = need + need / 4;
+  hipError_t e = hipMalloc(ptr, want);
+  if (e != hipSuccess) return set_error(SG_ERR_HIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  *have = want;
+  return SG_OK;
+}
+
+static int upload_chunked(void *dst, const void *src, size_t bytes) {
+  // pageable host memory -> HBM through a double-buffered pinned staging area
+  const size_t CH = (size_t)64 << 20;
+  if (bytes == 0) return SG_OK;
+  if (bytes <= CH) { SHD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return SG_OK; }
+  void *pin[2] = {nullptr, nullptr};
+  hipStream_t st;
+  SHD_HIP(hipStreamCreate(&st));
+  SHD_HIP(hipHostMalloc(&pin[0], CH, hipHostMallocDefault));
+  SHD_HIP(hipHostMalloc(&pin[1], CH, hipHostMallocDefault));
+  hipEvent_t ev[2];
+  SHD_HIP(hipEventCreate(&ev[0])); SHD_HIP(hipEventCreate(&ev[1]));
+  int b = 0;
+  for (size_t off = 0; off < bytes; off += CH, b ^= 1) {
+    size_t len = std::min(CH, bytes - off);
+    SHD_HIP(hipEventSynchronize(ev[b]));
+    memcpy(pin[b], (const char *)src + off, len);
+    SHD_HIP(hipMemcpyAsync((char *)dst + off, pin[b], len, hipMemcpyHostToDevice, st));
+    SHD_HIP(hipEventRecord(ev[b], st));
+  }
+  SHD_HIP(hipStreamSynchronize(st));
+  (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+  (void)hipHostFree(pin[0]); (void)hipHostFree(pin[1]);
+  (void)hipStreamDestroy(st);
+  return SG_OK;
+}
+
+extern "C" const char *sg_last_error(void) { return last_error().c_str(); }
+extern "C" int sg_abi_version(void) { return 1; }
+
+static int create_common(sg_sampler *s, int device_id, int64_t seed) {
+  s->device = device_id;
+  s->seed = seed < 0 ? (uint64_t)time(nullptr) : (uint64_t)seed;
+  SHD_HIP(hipMalloc((void **)&s->d_counts, 16 * sizeof(uint64_t)));
+  SHD_HIP(hipHostMalloc((void **)&s->h_counts, 16 * sizeof(uint64_t), hipHostMallocDefault));
+  SHD_HIP(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
+  return SG_OK;
+}
+
+extern "C" int sg_create(const uint32_t *indptr, const uint32_t *indices, uint32_t num_nodes,
+                         uint64_t num_edges, int on_device, int device_id, int64_t seed,
+                         sg_sampler **out) {
+  if (!indptr || (!indices && num_edges) || !out) return set_error(SG_ERR_INVALID, "sg_create: null argument");
+  if (num_edges > 0xFFFFFFFFull) return set_error(SG_ERR_INVALID, "sg_create: nnz exceeds uint32 edge ids");
+  SHD_HIP(hipSetDevice(device_id));
+  sg_sampler *s = new sg_sampler();
+  s->N = num_nodes; s->nnz = num_edges;
+  int rc;
+  if (on_device) {
+    s->d_indptr = const_cast<uint32_t *>(indptr);
+    s->d_indices = const_cast<uint32_t *>(indices);
+    s->owns_graph = false;
+  } else {
+    if (indptr[0] != 0 || indptr[num_nodes] != num_edges) {     // Graph.h:29-30
+      delete s;
+      return set_error(SG_ERR_INVALID, "sg_create: indptr[0]=%u indptr[N]=%u but nnz=%llu", indptr[0],
+                       indptr[num_nodes], (unsigned long long)num_edges);
+    }
+    hipError_t e1 = hipMalloc((void **)&s->d_indptr, ((size_t)num_nodes + 1) * 4);
+    hipError_t e2 = hipMalloc((void **)&s->d_indices, std::max<size_t>(1, num_edges) * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess) { delete s; return set_error(SG_ERR_HIP, "sg_create: hipMalloc of the CSR failed"); }
+    s->owns_graph = true;
+    if ((rc = upload_chunked(s->d_indptr, indptr, ((size_t)num_nodes + 1) * 4)) != SG_OK) { sg_destroy(s); return rc; }
+    if ((rc = upload_chunked(s->d_indices, indices, (size_t)num_edges * 4)) != SG_OK) { sg_destroy(s); return rc; }
+  }
+  if ((rc = create_common(s, device_id, seed)) != SG_OK) { sg_destroy(s); return rc; }
+  *out = s;
+  return SG_OK;
+}
+
+static int read_bin_u32(const char *path, std::vector<uint32_t> &v) {
+  // raw little-endian uint32, element count = file size / 4 (.cpp:81)
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return set_error(SG_ERR_IO, "cannot open %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return set_error(SG_ERR_IO, "cannot stat %s", path); }
+  size_t n = (size_t)st.st_size / 4;
+  v.resize(n);
+  size_t got = 0, want = n * 4;
+  while (got < want) {
+    ssize_t r = read(fd, (char *)v.data() + got, want - got);
+    if (r <= 0) { close(fd); return set_error(SG_ERR_IO, "short read on %s", path); }
+    got += (size_t)r;
+  }
+  close(fd);
+  return SG_OK;
+}
+
+extern "C" int sg_create_from_bin(const char *path_indptr, const char *path_indices, int device_id,
+                                  int64_t seed, sg_sampler **out) {
+  if (!path_indptr || !path_indices || !out) return set_error(SG_ERR_INVALID, "sg_create_from_bin: null argument");
+  std::vector<uint32_t> ip, ix;
+  int rc;
+  if ((rc = read_bin_u32(path_indptr, ip)) != SG_OK) return rc;
+  if ((rc = read_bin_u32(path_indices, ix)) != SG_OK) return rc;
+  if (ip.empty()) return set_error(SG_ERR_IO, "%s is empty", path_indptr);
+  return sg_create(ip.data(), ix.data(), (uint32_t)(ip.size() - 1), ix.size(), 0, device_id, seed, out);
+}
+
+static void free_ppr(sg_sampler *s) {
+  if (s->d_ppr_row) (void)hipFree(s->d_ppr_row);
+  if (s->d_ppr_len) (void)hipFree(s->d_ppr_len);
+  if (s->d_ppr_neigh) (void)hipFree(s->d_ppr_neigh);
+  if (s->d_ppr_score) (void)hipFree(s->d_ppr_score);
+  s->d_ppr_row = nullptr; s->d_ppr_len = nullptr; s->d_ppr_neigh = nullptr; s->d_ppr_score = nullptr;
+  s->ppr_rows = 0; s->ppr_stride = 0;
+}
+
+extern "C" void sg_destroy(sg_sampler *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->pending && s->ev) (void)hipEventSynchronize(s->ev);
+  if (s->owns_graph) { if (s->d_indptr) (void)hipFree(s->d_indptr); if (s->d_indices) (void)hipFree(s->d_indices); }
+  if (s->d_targets) (void)hipFree(s->d_targets);
+  free_ppr(s);
+  if (s->d_scratch) (void)hipFree(s->d_scratch);
+  if (s->d_big) (void)hipFree(s->d_big);
+  if (s->d_counts) (void)hipFree(s->d_counts);
+  if (s->h_counts) (void)hipHostFree(s->h_counts);
+  if (s->ev) (void)hipEventDestroy(s->ev);
+  delete s;
+}
+
+extern "C" uint32_t sg_num_nodes(const sg_sampler *s) { return s ? s->N : 0; }
+extern "C" uint64_t sg_num_edges(const sg_sampler *s) { return s ? (s->graph_dropped ? 0 : s->nnz) : 0; }
+extern "C" uint64_t sg_num_nodes_target(const sg_sampler *s) { return s ? s->num_targets : 0; }
+extern "C" uint64_t sg_get_idx_root(const sg_sampler *s) { return s ? s->idx_root : 0; }
+extern "C" const uint32_t *sg_device_indptr(const sg_sampler *s) { return s ? s->d_indptr : nullptr; }
+extern "C" const uint32_t *sg_device_indices(const sg_sampler *s) { return s ? s->d_indices : nullptr; }
+
+extern "C" int sg_shuffle_targets(sg_sampler *s, const uint32_t *h_targets, uint64_t count) {
+  if (!s || (!h_targets && count)) return set_error(SG_ERR_INVALID, "sg_shuffle_targets: null argument");
+  SHD_HIP(hipSetDevice(s->device));
+  for (uint64_t i = 0; i < count; i++)
+    if (h_targets[i] >= s->N) return set_error(SG_ERR_INVALID, "sg_shuffle_targets: target %u >= num_nodes %u", h_targets[i], s->N);
+  if (s->pending) SHD_HIP(hipEventSynchronize(s->ev));
+  if (count > s->cap_targets) {
+    if (s->d_targets) (void)hipFree(s->d_targets);
+    s->d_targets = nullptr; s->cap_targets = 0;
+    SHD_HIP(hipMalloc((void **)&s->d_targets, std::max<uint64_t>(1, count) * 4));
+    s->cap_targets = count;
+  }
+  if (count) SHD_HIP(hipMemcpy(s->d_targets, h_targets, count * 4, hipMemcpyHostToDevice));
+  s->num_targets = count;
+  return SG_OK;
+}
+
+extern "C" int sg_next_roots(sg_sampler *s, uint32_t num_roots, uint32_t max_subgraphs,
+                             uint64_t *root_start, uint32_t *num_subgraphs, uint64_t *serial_base) {
+  if (!s || !root_start || !num_subgraphs || !serial_base || num_roots == 0)
+    return set_error(SG_ERR_INVALID, "sg_next_roots: bad argument");
+  if (s->num_targets == 0) return set_error(SG_ERR_STATE, "sg_next_roots: no targets (call sg_shuffle_targets)");
+  // _get_roots_p, .cpp:459-468
+  const uint64_t start = s->idx_root;
+  const uint64_t end = std::min<uint64_t>(s->num_targets, start + (uint64_t)num_roots * max_subgraphs);
+  s->idx_root = (end == s->num_targets) ? 0 : end;
+  const uint64_t groups = (end - start + num_roots - 1) / num_roots;
+  if ((end - start) % num_roots != 0)
+    return set_error(SG_ERR_STATE, "sg_next_roots: %llu remaining targets not divisible by num_roots=%u",
+                     (unsigned long long)(end - start), num_roots);
+  *root_start = start;
+  *num_subgraphs = (uint32_t)groups;
+  *serial_base = s->serial_next;
+  s->serial_next += groups;
+  return SG_OK;
+}
+
+extern "C" int sg_set_caps(sg_sampler *s, uint32_t cap_subg_nodes, uint32_t cap_subg_edges) {
+  if (!s) return set_error(SG_ERR_INVALID, "sg_set_caps: null sampler");
+  s->user_cap_nodes = std::max(s->user_cap_nodes, cap_subg_nodes);
+  s->user_cap_edges = std::max(s->user_cap_edges, cap_subg_edges);
+  return SG_OK;
+}
+
+static void derive_caps(const sg_sampler *s, const sg_config *cfg, uint32_t *capn, uint32_t *cape,
+                        uint32_t *capf) {
+  const uint64_t N = std::max<uint32_t>(1, s->N);
+  uint64_t n = 1, f = 1;
+  const uint64_t R = (uint64_t)std::max(1, cfg->num_roots);
+  if (cfg->method == SG_METHOD_KHOP) {
+    if (cfg->budget >= 0) {
+      uint64_t lvl = R; n = R; f = R;
+      for (int d = 0; d < cfg->depth; d++) {
+        lvl = std::min<uint64_t>(N, lvl * (uint64_t)cfg->budget);
+        if (d + 1 < cfg->depth) f = std::max(f, lvl);
+        n = std::min<uint64_t>(N, n + lvl);
+      }
+    } else {
+      n = std::min<uint64_t>(N, 4096);   // grown on demand (SG_ERR_CAPACITY)
+      f = n;
+    }
+  } else if (cfg->method == SG_METHOD_PPR) {
+    n = std::min<uint64_t>(N, R * ((uint64_t)std::max(0, cfg->k) + 1)); f = 1;
+  } else {
+    n = R; f = R;
+  }
+  n = std::max<uint64_t>(n, s->user_cap_nodes);
+  n = std::min<uint64_t>(n, N);
+  n = std::max<uint64_t>(n, R);
+  if (cfg->method == SG_METHOD_KHOP && cfg->budget < 0) f = n;
+  f = std::min<uint64_t>(std::max<uint64_t>(f, R), n);
+  uint64_t e = std::min<uint64_t>(n * n + n, std::max<uint64_t>(4096, 16 * n));
+  e = std::max<uint64_t>(e, s->user_cap_edges);
+  e = std::min<uint64_t>(e, 0x7FFFFFFFull);
+  *capn = (uint32_t)n; *cape = (uint32_t)e; *capf = (uint32_t)f;
+}
+
+extern "C" int sg_get_caps(const sg_sampler *s, const sg_config *cfg, uint32_t *cap_subg_nodes,
+                           uint32_t *cap_subg_edges) {
+  if (!s || !cfg || !cap_subg_nodes || !cap_subg_edges) return set_error(SG_ERR_INVALID, "sg_get_caps: null argument");
+  uint32_t f;
+  derive_caps(s, cfg, cap_subg_nodes, cap_subg_edges, &f);
+  return SG_OK;
+}
+
+extern "C" int sg_set_ppr(sg_sampler *s, const uint32_t *h_targets, uint32_t num_rows,
+                          const uint32_t *h_len, const uint32_t *h_neigh, const float *h_score,
+                          uint32_t stride) {
+  if (!s || (num_rows && (!h_targets || !h_len || !h_neigh || !h_score)) || stride == 0)
+    return set_error(SG_ERR_INVALID, "sg_set_ppr: bad argument");
+  SHD_HIP(hipSetDevice(s->device));
+  if (s->pending) SHD_HIP(hipEventSynchronize(s->ev));
+  free_ppr(s);
+  std::vector<int32_t> row((size_t)s->N, -1);
+  for (uint32_t r = 0; r < num_rows; r++) {
+    if (h_targets[r] >= s->N) return set_error(SG_ERR_INVALID, "sg_set_ppr: target %u out of range", h_targets[r]);
+    if (h_len[r] > stride) return set_error(SG_ERR_INVALID, "sg_set_ppr: row %u longer than stride", r);
+    row[h_targets[r]] = (int32_t)r;
+  }
+  const size_t cells = std::max<size_t>(1, (size_t)num_rows * stride);
+  SHD_HIP(hipMalloc((void **)&s->d_ppr_row, std::max<size_t>(1, s->N) * 4));
+  SHD_HIP(hipMalloc((void **)&s->d_ppr_len, std::max<size_t>(1, num_rows) * 4));
+  SHD_HIP(hipMalloc((void **)&s->d_ppr_neigh, cells * 4));
+  SHD_HIP(hipMalloc((void **)&s->d_ppr_score, cells * 4));
+  int rc;
+  if ((rc = upload_chunked(s->d_ppr_row, row.data(), (size_t)s->N * 4)) != SG_OK) return rc;
+  if (num_rows) {
+    if ((rc = upload_chunked(s->d_ppr_len, h_len, (size_t)num_rows * 4)) != SG_OK) return rc;
+    if ((rc = upload_chunked(s->d_ppr_neigh, h_neigh, (size_t)num_rows * stride * 4)) != SG_OK) return rc;
+    if ((rc = upload_chunked(s->d_ppr_score, h_score, (size_t)num_rows * stride * 4)) != SG_OK) return rc;
+  }
+  s->ppr_rows = num_rows; s->ppr_stride = stride;
+  s->h_ppr_targets.assign(h_targets, h_targets + num_rows);
+  s->h_ppr_len.assign(h_len, h_len + num_rows);
+  s->h_ppr_neigh.assign(h_neigh, h_neigh + (size_t)num_rows * stride);
+  s->h_ppr_score.assign(h_score, h_score + (size_t)num_rows * stride);
+  return SG_OK;
+}
+
+// PPR cache files: header {float alpha'(=1-alpha), float epsilon, int32 k, uint32 num_records},
+// then per node {uint32 len, len * (uint32 | float)}  (.cpp:105-137).
+extern "C" int sg_save_ppr_bin(const sg_sampler *s, const char *path_neighs, const char *path_scores,
+                               int k, float alpha, float epsilon) {
+  if (!s || !path_neighs || !path_scores) return set_error(SG_ERR_INVALID, "sg_save_ppr_bin: null argument");
+  if (!s->ppr_rows) return set_error(SG_ERR_STATE, "sg_save_ppr_bin: no PPR table set");
+  const float a1 = 1 - alpha;
+  std::vector<int32_t> row((size_t)s->N, -1);
+  for (uint32_t r = 0; r < s->ppr_rows; r++) row[s->h_ppr_targets[r]] = (int32_t)r;
+  for (int which = 0; which < 2; which++) {
+    FILE *f = fopen(which ? path_scores : path_neighs, "wb");
+    if (!f) return set_error(SG_ERR_IO, "cannot write %s", which ? path_scores : path_neighs);
+    uint32_t cnt = s->N;
+    fwrite(&a1, 4, 1, f); fwrite(&epsilon, 4, 1, f); fwrite(&k, 4, 1, f); fwrite(&cnt, 4, 1, f);
+    for (uint32_t v = 0; v < s->N; v++) {
+      uint32_t len = row[v] < 0 ? 0u : s->h_ppr_len[row[v]];
+      fwrite(&len, 4, 1, f);
+      if (len) {
+        const size_t off = (size_t)row[v] * s->ppr_stride;
+        if (which) fwrite(s->h_ppr_score.data() + off, 4, len, f);
+        else fwrite(s->h_ppr_neigh.data() + off, 4, len, f);
+      }
+    }
+    fclose(f);
+  }
+  return SG_OK;
+}
+
+extern "C" int sg_load_ppr_bin(sg_sampler *s, const char *path_neighs, const char *path_scores, int k,
+                               float alpha, float epsilon) {
+  if (!s || !path_neighs || !path_scores || k <= 0) return set_error(SG_ERR_INVALID, "sg_load_ppr_bin: bad argument");
+  const float a1 = 1 - alpha;
+  std::vector<uint32_t> raw[2];
+  int rc;
+  if ((rc = read_bin_u32(path_neighs, raw[0])) != SG_OK) return rc;
+  if ((rc = read_bin_u32(path_scores, raw[1])) != SG_OK) return rc;
+  for (int w = 0; w < 2; w++) {
+    if (raw[w].size() < 4) return set_error(SG_ERR_IO, "PPR file too short");
+    float a_, e_; int32_t k_;
+    memcpy(&a_, &raw[w][0], 4); memcpy(&e_, &raw[w][1], 4); memcpy(&k_, &raw[w][2], 4);
+    // acceptance rule of read_PPR_from_binary_file, .cpp:166
+    if (a_ != a1 || e_ > 1.1 * epsilon || e_ < 0.9 * epsilon || k_ < k)
+      return set_error(SG_ERR_IO, "PPR file header mismatch (alpha'=%g eps=%g k=%d)", a_, e_, k_);
+    if (raw[w][3] != s->N) return set_error(SG_ERR_IO, "PPR file has %u records, graph has %u nodes", raw[w][3], s->N);
+  }
+  std::vector<uint32_t> targets, len, neigh;
+  std::vector<float> score;
+  size_t o0 = 4, o1 = 4;
+  for (uint32_t v = 0; v < s->N; v++) {
+    if (o0 >= raw[0].size() || o1 >= raw[1].size()) return set_error(SG_ERR_IO, "PPR file truncated");
+    const uint32_t l0 = raw[0][o0++], l1 = raw[1][o1++];
+    if (l0 != l1 || o0 + l0 > raw[0].size() || o1 + l1 > raw[1].size()) return set_error(SG_ERR_IO, "PPR files inconsistent");
+    if (l0) {
+      const uint32_t clip = std::min<uint32_t>(l0, (uint32_t)k);      // .cpp:176-183
+      targets.push_back(v); len.push_back(clip);
+      const size_t base = neigh.size();
+      neigh.resize(base + k, 0xFFFFFFFFu); score.resize(base + k, 0.0f);
+      for (uint32_t j = 0; j < clip; j++) { neigh[base + j] = raw[0][o0 + j]; memcpy(&score[base + j], &raw[1][o1 + j], 4); }
+    }
+    o0 += l0; o1 += l1;
+  }
+  return sg_set_ppr(s, targets.data(), (uint32_t)targets.size(), len.data(), neigh.data(), score.data(), (uint32_t)k);
+}
+
+extern "C" int sg_drop_full_graph_info(sg_sampler *s) {
+  if (!s) return set_error(SG_ERR_INVALID, "sg_drop_full_graph_info: null sampler");
+  SHD_HIP(hipSetDevice(s->device));
+  if (s->pending) SHD_HIP(hipEventSynchronize(s->ev));
+  if (s->owns_graph && s->d_indices) { (void)hipFree(s->d_indices); s->d_indices = nullptr; }
+  free_ppr(s);
+  s->graph_dropped = true;
+  return SG_OK;
+}
+
+extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
+                         uint32_t num_subgraphs, uint64_t serial_base,
+                         const uint32_t *d_roots_override, const sg_batch_out *out, void *stream_) {
+  if (!s || !cfg || !out) return set_error(SG_ERR_INVALID, "sg_sample: null argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint32_t P = num_subgraphs;
+  const int R = cfg->num_roots;
+  if (s->graph_dropped) return set_error(SG_ERR_STATE, "sg_sample: full graph was dropped");
+  if (R < 1 || R > (int)kMaxRoots) return set_error(SG_ERR_INVALID, "sg_sample: num_roots=%d unsupported (1..%u)", R, kMaxRoots);
+  if (cfg->method < 0 || cfg->method > SG_METHOD_NODEIID) return set_error(SG_ERR_INVALID, "sg_sample: unknown method %d", cfg->method);
+  if (cfg->method == SG_METHOD_KHOP && (cfg->depth < 0 || cfg->depth > 30)) return set_error(SG_ERR_INVALID, "sg_sample: depth=%d unsupported (0..30)", cfg->depth);
+  if (cfg->method == SG_METHOD_KHOP && cfg->budget > 262144) return set_error(SG_ERR_INVALID, "sg_sample: budget too large");
+  if (cfg->method == SG_METHOD_PPR && !s->d_ppr_row) return set_error(SG_ERR_STATE, "sg_sample: PPR table not set (sg_set_ppr / sg_load_ppr_bin)");
+  if (cfg->method == SG_METHOD_PPR && cfg->k < 0) return set_error(SG_ERR_INVALID, "sg_sample: k<0");
+  if ((cfg->aug_flags & SG_AUG_DRNLS) && R < 2) return set_error(SG_ERR_INVALID, "sg_sample: drnl needs two roots");
+  if (!d_roots_override) {
+    if (root_start + (uint64_t)P * R > s->num_targets)
+      return set_error(SG_ERR_INVALID, "sg_sample: roots [%llu, +%u*%d) outside the %llu targets",
+                       (unsigned long long)root_start, P, R, (unsigned long long)s->num_targets);
+  }
+  if (!out->d_node || !out->d_indptr || !out->d_indices || !out->d_edge_id || !out->d_target ||
+      !out->d_subg_nodes || !out->d_subg_edges)
+    return set_error(SG_ERR_INVALID, "sg_sample: missing output buffer");
+  SHD_HIP(hipSetDevice(s->device));
+  if (s->pending) { SHD_HIP(hipEventSynchronize(s->ev)); s->pending = false; }
+
+  uint32_t capn, cape, capf;
+  derive_caps(s, cfg, &capn, &cape, &capf);
+  // scratch carve
+  const size_t Pz = std::max<uint32_t>(1, P);
+  size_t o = 0;
+  auto carve = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+  const size_t o_nodes = carve(Pz * capn * 4), o_ppr = carve(Pz * capn * 4), o_rowptr = carve(Pz * ((size_t)capn + 1) * 4);
+  const size_t o_tmp = carve(Pz * capn * 4);
+  const size_t o_col = carve(Pz * (size_t)cape * 4), o_eid = carve(Pz * (size_t)cape * 4);
+  const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
+  int rc;
+  if ((rc = ensure(&s->d_scratch, &s->scratch_bytes, o)) != SG_OK) return rc;
+  char *sc = (char *)s->d_scratch;
+
+  SHD_HIP(hipMemsetAsync(s->d_counts, 0, 16 * sizeof(uint64_t), stream));
+  if (P == 0) {
+    SHD_HIP(hipMemsetAsync(out->d_indptr, 0, 4, stream));
+    SHD_HIP(hipMemsetAsync(out->d_subg_nodes, 0, 4, stream));
+    SHD_HIP(hipMemsetAsync(out->d_subg_edges, 0, 4, stream));
+  } else {
+    SampleParams p;
+    memset(&p, 0, sizeof(p));
+    p.indptr = s->d_indptr; p.indices = s->d_indices; p.N = s->N; p.nnz = s->nnz;
+    p.roots = d_roots_override ? d_roots_override : s->d_targets + root_start;
+    p.P = P; p.R = R;
+    p.method = cfg->method; p.depth = cfg->depth; p.budget = cfg->budget; p.k = cfg->k;
+    p.threshold = cfg->threshold;
+    p.include_self = (cfg->method == SG_METHOD_NODEIID) ? 0 : cfg->add_self_edge;   // .cpp:506
+    p.include_target_conn = (cfg->method == SG_METHOD_NODEIID) ? 0 : cfg->include_target_conn;
+    p.compat = cfg->compat_overread;
+    p.seed = s->seed; p.serial_base = serial_base;
+    p.ppr_row = s->d_ppr_row; p.ppr_len = s->d_ppr_len; p.ppr_neigh = s->d_ppr_neigh;
+    p.ppr_score = s->d_ppr_score; p.ppr_stride = s->ppr_stride;
+    p.cap_nodes_scr = capn; p.cap_edges_scr = cape;
+    p.s_nodes = (uint32_t *)(sc + o_nodes); p.s_ppr = (float *)(sc + o_ppr);
+    p.s_rowptr = (uint32_t *)(sc + o_rowptr); p.s_col = (uint32_t *)(sc + o_col);
+    p.s_eid = (uint32_t *)(sc + o_eid); p.s_tgt = (uint32_t *)(sc + o_tgt);
+    p.s_cnt = (uint32_t *)(sc + o_cnt);
+    // ---- LDS kernel
+    const uint32_t capn_lds = std::min(capn, kLdsCapNodes);
+    const uint32_t capf_lds = std::min(capf, capn_lds);
+    const uint32_t T = (capn_lds > 1024 || P < 512) ? 512 : 256;
+    // sparse table (most probes are misses): 4x the capacity while the two
+    // tables stay within 32 KiB, never below 1.5x
+    uint32_t H = next_pow2((uint64_t)capn_lds * 4);
+    while ((size_t)H * 8 > 32 * 1024 && (H >> 1) >= capn_lds + capn_lds / 2) H >>= 1;
+    while (H < capn_lds + T + 1) H <<= 1;
+    H = std::max<uint32_t>(H, 64);
+    p.capn = capn_lds; p.capf = capf_lds; p.H = H;
+    p.hshift = 32; for (uint32_t h = H; h > 1; h >>= 1) p.hshift--;
+    const LdsLayout L = lds_layout(H, capn_lds, capf_lds, cfg->method == SG_METHOD_PPR, T);
+    if (L.total > 160 * 1024) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
+    if (L.total > 64 * 1024)
+      SHD_HIP(hipFuncSetAttribute((const void *)sg_sample_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(sg_sample_lds_kernel, dim3(P), dim3(T), L.total, stream, p);
+    SHD_HIP(hipGetLastError());
+    // ---- big path for subgraphs that overflowed the LDS tables
+    if (capn > capn_lds) {
+      SampleParams q = p;
+      q.capn = capn; q.capf = capf;
+      uint32_t Hb = next_pow2((uint64_t)capn * 2);
+      const uint32_t Tb = 1024;
+      while (Hb < capn + Tb + 1) Hb <<= 1;
+      q.H = Hb; q.hshift = 32; for (uint32_t h = Hb; h > 1; h >>= 1) q.hshift--;
+      const uint64_t stride = (uint64_t)Hb * 3 + (uint64_t)capn * 2 + 1 + (uint64_t)capf * 2 + 64;
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
+      uint32_t nslots = std::min<uint32_t>(P, (uint32_t)ncu);
+      // keep the table arena below 4 GiB
+      while (nslots > 1 && (uint64_t)nslots * stride * 4 > ((uint64_t)4 << 30)) nslots >>= 1;
+      if ((rc = ensure(&s->d_big, &s->big_bytes, (size_t)nslots * stride * 4)) != SG_OK) return rc;
+      q.g_tables = (uint32_t *)s->d_big; q.g_stride = stride;
+      q.g_ticket = (uint32_t *)(s->d_counts + 8);
+      hipLaunchKernelGGL(sg_sample_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
+      SHD_HIP(hipGetLastError());
+    }
+    RelocParams r;
+    memset(&r, 0, sizeof(r));
+    r.P = P; r.R = R; r.aug_flags = cfg->aug_flags;
+    r.cap_nodes_scr = capn; r.cap_edges_scr = cape;
+    r.s_nodes = p.s_nodes; r.s_ppr = p.s_ppr; r.s_rowptr = p.s_rowptr; r.s_col = p.s_col;
+    r.s_eid = p.s_eid; r.s_tgt = p.s_tgt; r.s_cnt = p.s_cnt; r.s_tmp = (uint32_t *)(sc + o_tmp);
+    r.out = *out; r.d_counts = s->d_counts;
+    hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(256), 0, stream, r);
+    SHD_HIP(hipGetLastError());
+  }
+  SHD_HIP(hipMemcpyAsync(s->h_counts, s->d_counts, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  SHD_HIP(hipEventRecord(s->ev, stream));
+  s->pending = true;
+  s->pending_P = P;
+  return SG_OK;
+}
+
+extern "C" int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts) {
+  if (!s || !counts) return set_error(SG_ERR_INVALID, "sg_sample_finish: null argument");
+  if (!s->pending) return set_error(SG_ERR_STATE, "sg_sample_finish: no sample in flight");
+  SHD_HIP(hipSetDevice(s->device));
+  SHD_HIP(hipEventSynchronize(s->ev));
+  s->pending = false;
+  const uint64_t *h = s->h_counts;
+  counts->n_tot = h[0]; counts->e_tot = h[1];
+  counts->num_subgraphs = s->pending_P;
+  counts->max_subg_nodes = (uint32_t)h[2]; counts->max_subg_edges = (uint32_t)h[3];
+  counts->overflow = (uint32_t)h[4];
+  counts->slots_scanned = h[5]; counts->frontier_reads = h[7];
+  if (counts->overflow)
+    return set_error(SG_ERR_CAPACITY,
+                     "sg_sample: capacity exceeded (flags=0x%x: 1=subgraph nodes 2=subgraph edges 4=out nodes 8=out edges); "
+                     "largest subgraph %u nodes / %u edges, batch %llu nodes / %llu edges",
+                     counts->overflow, counts->max_subg_nodes, counts->max_subg_edges,
+                     (unsigned long long)counts->n_tot, (unsigned long long)counts->e_tot);
+  return SG_OK;
+}

@@ -1,0 +1,66 @@
+"""Seeded synthetic graphs of the benchmark shapes:
+uint32 CSR, symmetric, deduplicated, sorted rows, no self-loops, heavy-tailed
+degrees (one endpoint uniform, the other Pareto(1.5)-weighted)."""
+import numpy as np
+
+SHAPES = {
+    # name: (num_nodes, target nnz (directed entries), feature width, classes)
+    "arxiv": (169_343, 2_331_418, 128, 40),
+    "products": (2_449_029, 123_718_280, 100, 47),
+    "papers100M": (111_059_956, 3_231_371_744, 128, 172),
+}
+
+
+def make_graph_numpy(n, avg_deg, seed=0):
+    """Small/medium graphs on the host (tests, smoke)."""
+    rng = np.random.default_rng(seed)
+    m = int(n * avg_deg // 2)
+    w = rng.pareto(1.5, n) + 1.0
+    w /= w.sum()
+    a = rng.integers(0, n, m)
+    b = rng.choice(n, size=m, p=w)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = np.concatenate([a * n + b, b * n + a])
+    key = np.unique(key)
+    rows = key // n
+    cols = (key % n).astype(np.uint32)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(indptr, rows + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.uint32)
+    return indptr, cols
+
+
+def make_graph_torch(n, nnz_target, seed=0, device="cuda"):
+    """Benchmark-scale graphs generated on the GPU (sort-based symmetrise +
+    dedupe).  Returns int32 tensors (uint32 bit patterns) indptr[n+1], indices[nnz]."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    m = nnz_target // 2
+    # Pareto(1.5)+1 weights via inverse CDF; weighted endpoint via searchsorted on the CDF
+    u = torch.rand(n, generator=g, device=device, dtype=torch.float64).clamp_(min=1e-12)
+    w = u.pow_(-1.0 / 1.5)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    a = torch.randint(0, n, (m,), generator=g, device=device, dtype=torch.int64)
+    r = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+    b = torch.searchsorted(cdf, r).clamp_(max=n - 1)
+    del r, cdf, w, u
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.cat([a * n + b, b * n + a])
+    del a, b, keep
+    key = torch.unique(key)          # sorted + deduplicated
+    rows = torch.div(key, n, rounding_mode="floor")
+    cols = (key - rows * n).to(torch.int32)
+    del key
+    counts = torch.bincount(rows, minlength=n)
+    del rows
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    assert int(indptr[-1]) < 2 ** 32
+    # uint32 bit pattern in an int32 tensor
+    indptr32 = (indptr & 0xFFFFFFFF).to(torch.int64)
+    indptr32 = torch.where(indptr32 >= 2 ** 31, indptr32 - 2 ** 32, indptr32).to(torch.int32)
+    return indptr32, cols

@@ -1,0 +1,236 @@
+"""GPU parity tests of the HIP sampler (through the C ABI) against
+(a) the reference's golden vectors and (b) the CPU oracle on seeded inputs.
+Bit-exact on every integer field and on the fp32 ppr scores."""
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import (SAMPLER_FIXTURES, Fixture, has_self_loops, sampler_kwargs,
+                           touches_end_of_indices)
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ["node", "indptr", "indices", "edge_id", "target"]
+
+
+def _cfg(kw, compat=False):
+    from shadow_gnn_amd.sampler import SamplerConfig
+    return SamplerConfig(method=kw["method"], num_roots=kw["num_roots"], depth=kw.get("depth", 0),
+                         budget=kw.get("budget", -1), k=kw.get("k", 0),
+                         threshold=kw.get("threshold", 0.0), add_self_edge=kw["add_self_edge"],
+                         include_target_conn=kw["include_target_conn"], compat_overread=compat,
+                         aug=tuple(kw["aug"]))
+
+
+def _make(indptr, indices, seed=0):
+    from shadow_gnn_amd.sampler import HipSampler
+    return HipSampler(indptr, indices, device=torch.device("cuda:0"), seed=seed)
+
+
+def _cmp_local(ref, got, fields, ctx):
+    for f in fields:
+        a, b = ref[f], got[f]
+        if f == "ppr":
+            assert a.size == b.size and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (ctx, f)
+        else:
+            assert np.array_equal(a, b), (ctx, f, a[:16], b[:16])
+
+
+@pytest.mark.parametrize("name", SAMPLER_FIXTURES)
+def test_hip_matches_reference_golden(name):
+    fx = Fixture(name)
+    loops = has_self_loops(fx.indptr, fx.indices)
+    hs = _make(fx.indptr, fx.indices)
+    n_compat = n_exact = 0
+    for case in fx.cases:
+        ci = case["idx"]
+        kw = sampler_kwargs(case)
+        tab = fx.ppr_table(ci)
+        if tab is not None:
+            hs.set_ppr(*tab)
+        roots = fx.roots(ci)
+        refs = fx.ref_subgraphs(ci)
+        aug_fields = [f[:-1] for f in case["aug"] if f != "pprs"]
+        got = hs.sample(_cfg(kw, compat=True), roots=roots).split_host()
+        assert len(got) == len(refs)
+        for p, (r, g) in enumerate(zip(refs, got)):
+            fields = ["node", "target", "ppr"]
+            if not touches_end_of_indices(fx.indptr, r["node"]):
+                fields += ["indptr", "indices", "edge_index"] + aug_fields
+                n_compat += 1
+            _cmp_local(r, g, fields, (name, ci, p, "compat"))
+        got = hs.sample(_cfg(kw, compat=False), roots=roots).split_host()
+        exact = kw["add_self_edge"] and not loops and kw["method"] != "nodeIID"
+        for p, (r, g) in enumerate(zip(refs, got)):
+            fields = ["node", "target", "ppr"]
+            if exact:
+                fields += ["indptr", "indices", "edge_index"] + aug_fields
+                n_exact += 1
+            _cmp_local(r, g, fields, (name, ci, p, "correct"))
+    assert n_compat > 0
+    if not loops:
+        assert n_exact > 0
+
+
+def _cmp_batch(ref, b, aug, ctx):
+    h = b.to_host()
+    for f in INT_FIELDS:
+        assert np.array_equal(h[f], getattr(ref, f)), (ctx, f)
+    assert np.array_equal(np.diff(h["subg_node_off"].astype(np.int64)), ref.subg_nodes)
+    assert np.array_equal(np.diff(h["subg_edge_off"].astype(np.int64)), ref.subg_edges)
+    assert np.array_equal(h["ppr"].view(np.uint32), ref.ppr.view(np.uint32)), (ctx, "ppr")
+    if "hops" in aug:
+        assert np.array_equal(h["hop"], ref.hop), (ctx, "hop")
+    if "drnls" in aug:
+        assert np.array_equal(h["drnl"], ref.drnl), (ctx, "drnl")
+
+
+@pytest.mark.parametrize("depth,budget,self_e,aug", [
+    (2, 20, False, ("hops",)), (2, 20, True, ("hops",)), (2, 3, True, ()), (3, 4, True, ("hops",)),
+    (1, -1, False, ()), (2, -1, True, ("hops",)), (0, 5, True, ("hops",)), (2, 0, True, ()),
+])
+def test_khop_matches_oracle(depth, budget, self_e, aug):
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(20000, 14, seed=5)
+    rng = np.random.default_rng(9)
+    roots = rng.permutation(20000)[:700].astype(np.uint32)
+    hs = _make(indptr, indices, seed=1234)
+    hs.shuffle_targets(roots)
+    from shadow_gnn_amd.sampler import SamplerConfig
+    cfg = SamplerConfig(method="khop", depth=depth, budget=budget, add_self_edge=self_e, aug=aug)
+    # three consecutive calls through the sequential cursor: 300 + 300 + 100 roots
+    serial = 0
+    for call, P in enumerate((300, 300, 100)):
+        b = hs.sample(cfg, 300)
+        assert b.num_subgraphs == P
+        ref = so.sample_batch(indptr, indices, roots[call * 300:call * 300 + P], method="khop",
+                              depth=depth, budget=budget, add_self_edge=self_e, aug=aug, seed=1234,
+                              serial_base=serial, num_threads=8)
+        _cmp_batch(ref, b, aug, (depth, budget, self_e, call))
+        serial += P
+    assert hs.get_idx_root() == 0          # cursor wrapped (ParallelSampler.cpp:462)
+
+
+def test_link_task_two_roots_drnl():
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(5000, 10, seed=2)
+    rng = np.random.default_rng(3)
+    roots = rng.integers(0, 5000, 2 * 128).astype(np.uint32)
+    roots[10] = roots[11]                      # degenerate pair: both roots equal
+    hs = _make(indptr, indices, seed=7)
+    for itc in (False, True):
+        cfg = SamplerConfig(method="khop", num_roots=2, depth=2, budget=6, add_self_edge=True,
+                            include_target_conn=itc, aug=("drnls",))
+        b = hs.sample(cfg, roots=roots, serial_base=5)
+        ref = so.sample_batch(indptr, indices, roots, method="khop", num_roots=2, depth=2, budget=6,
+                              add_self_edge=True, include_target_conn=itc, aug=("drnls",), seed=7,
+                              serial_base=5)
+        _cmp_batch(ref, b, ("drnls",), ("link", itc))
+
+
+def test_ppr_matches_oracle():
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(8000, 12, seed=8)
+    rng = np.random.default_rng(4)
+    targets = rng.permutation(8000)[:256].astype(np.uint32)
+    tab = so.ppr_approximate(indptr, indices, targets, k=50, alpha=0.85, epsilon=1e-5, num_threads=8)
+    hs = _make(indptr, indices)
+    hs.set_ppr(targets, tab.len, tab.neigh, tab.score)
+    hs.shuffle_targets(targets)
+    for k, thr, self_e in ((50, 0.0, False), (20, 0.02, True), (1, 0.0, True)):
+        cfg = SamplerConfig(method="ppr", k=k, threshold=thr, add_self_edge=self_e, aug=("hops", "pprs"))
+        b = hs.sample(cfg, 256)
+        ref = so.sample_batch(indptr, indices, targets, method="ppr", k=k, threshold=thr,
+                              add_self_edge=self_e, aug=("hops", "pprs"), ppr=tab)
+        _cmp_batch(ref, b, ("hops",), ("ppr", k, thr))
+    # a root without a table row: just the root, ppr = -1
+    other = np.setdiff1d(np.arange(8000, dtype=np.uint32), targets)[:4]
+    b = hs.sample(SamplerConfig(method="ppr", k=10), roots=other)
+    h = b.to_host()
+    assert np.array_equal(h["node"], other) and np.all(h["ppr"] == -1.0)
+
+
+def test_big_subgraphs_take_the_global_table_path():
+    """Full 2-hop around hubs: node sets far beyond the LDS tables (2560)."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(30000, 16, seed=12)
+    deg = np.diff(indptr.astype(np.int64))
+    hubs = np.argsort(-deg)[:6].astype(np.uint32)
+    small = np.argsort(deg)[:10].astype(np.uint32)
+    roots = np.concatenate([hubs, small])
+    hs = _make(indptr, indices)
+    cfg = SamplerConfig(method="khop", depth=2, budget=-1, add_self_edge=True, aug=("hops",))
+    b = hs.sample(cfg, roots=roots)
+    ref = so.sample_batch(indptr, indices, roots, method="khop", depth=2, budget=-1,
+                          add_self_edge=True, aug=("hops",), num_threads=8)
+    assert ref.subg_nodes.max() > 2560
+    _cmp_batch(ref, b, ("hops",), "big")
+
+
+def test_edge_cases_empty_isolated_and_last_batch():
+    from shadow_gnn_amd.sampler import SamplerConfig
+    # graph with isolated nodes: 0-1, 2 isolated, 3-4
+    indptr = np.array([0, 1, 2, 2, 3, 4], dtype=np.uint32)
+    indices = np.array([1, 0, 4, 3], dtype=np.uint32)
+    hs = _make(indptr, indices)
+    cfg = SamplerConfig(method="khop", depth=2, budget=-1, add_self_edge=True, aug=("hops",))
+    b = hs.sample(cfg, roots=np.array([2, 0], dtype=np.uint32))
+    subs = b.split_host()
+    assert subs[0]["node"].tolist() == [2] and subs[0]["indices"].tolist() == [0]
+    assert subs[0]["edge_index"].tolist() == [0xFFFFFFFF] and subs[0]["hop"].tolist() == [0]
+    assert subs[1]["node"].tolist() == [0, 1] and subs[1]["indices"].tolist() == [0, 1, 0, 1]
+    # without self edges the isolated root has an empty CSR row
+    b = hs.sample(SamplerConfig(method="khop", depth=1, budget=-1), roots=np.array([2], dtype=np.uint32))
+    s = b.split_host()[0]
+    assert s["indptr"].tolist() == [0, 0] and s["indices"].size == 0
+    # zero subgraphs
+    hs.shuffle_targets(np.array([1, 3, 4], dtype=np.uint32))
+    b = hs.sample(SamplerConfig(method="nodeIID"), 2)
+    assert b.num_subgraphs == 2 and b.to_host()["node"].tolist() == [1, 3]
+    b = hs.sample(SamplerConfig(method="nodeIID"), 2)
+    assert b.num_subgraphs == 1 and hs.get_idx_root() == 0
+
+
+def test_reference_compatible_surface():
+    """ParallelSampler / SubgraphStructVec mirror: same ctor order, config keys and getters."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import ParallelSampler
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(3000, 10, seed=21)
+    data = np.ones(indices.size, dtype=np.float32)
+    ps = ParallelSampler(indptr, indices, data, 100, 4, True, True, [], 2, "", "", "", 11)
+    assert ps.num_nodes() == 3000 and ps.num_edges() == indices.size and ps.is_seq_root_traversal()
+    roots = np.arange(0, 250, dtype=np.uint32)
+    ps.shuffle_targets(roots)
+    assert ps.num_nodes_target() == 250
+    cfgs = [{"method": "khop", "depth": "2", "budget": "-1", "num_roots": "1", "add_self_edge": "true",
+             "include_target_conn": "false", "return_target_only": "false"},
+            {"method": "nodeIID", "num_roots": "1", "add_self_edge": "false",
+             "include_target_conn": "false", "return_target_only": "true"}]
+    seen = 0
+    for call in range(3):
+        ret = ps.parallel_sampler_ensemble(cfgs, [{"hops"}, set()])
+        assert len(ret) == 2
+        clip = ret[0].get_num_valid_subg()
+        assert clip == (100 if call < 2 else 50) and ret[1].get_num_valid_subg() == clip
+        ref = so.sample_batch(indptr, indices, roots[seen:seen + clip], method="khop", depth=2,
+                              budget=-1, add_self_edge=True, aug=("hops",)).split()
+        for p in range(clip):
+            for getter, key in (("indptr", "indptr"), ("indices", "indices"), ("node", "node"),
+                                ("edge_index", "edge_index"), ("target", "target"), ("hop", "hop")):
+                got = np.asarray(getattr(ret[0], f"get_subgraph_{getter}")()[p])
+                assert np.array_equal(got, ref[p][key]), (call, p, getter)
+            assert np.all(np.asarray(ret[0].get_subgraph_data()[p]) == 1.0)
+            assert np.asarray(ret[1].get_subgraph_node()[p]).tolist() == [roots[seen + p]]
+        assert len(ret[0].get_subgraph_node()) == 100      # vectors keep their full length
+        seen += clip
+    assert ps.get_idx_root() == 0
+    with pytest.raises(KeyError):
+        ps.parallel_sampler_ensemble([{"num_roots": "1"}, cfgs[1]], [set(), set()])
