@@ -163,6 +163,12 @@ int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t
               void *stream);
 int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts);
 
+/* Development aid: per-subgraph result words of the last sg_sample call,
+ * 16 uint32 per subgraph: {nodes, edges, flags, stream slots, frontier nodes,
+ * frontier reads, -, -, 8 x phase cycle stamps (only when the library was
+ * built with -DSHADOW_SG_TIMING)}.  Synchronises the device.                  */
+int sg_debug_subgraph_stats(sg_sampler *s, uint32_t *h_out, uint32_t max_subgraphs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,7 @@ SIGNATURES = {
     "sg_sample": (C.c_int, [_P, C.POINTER(SgConfig), C.c_uint64, C.c_uint32, C.c_uint64, _P,
                              C.POINTER(SgBatchOut), _P]),
     "sg_sample_finish": (C.c_int, [_P, C.POINTER(SgBatchCounts)]),
+    "sg_debug_subgraph_stats": (C.c_int, [_P, _P, C.c_uint32]),
 }
 
 _lib = None

@@ -26,6 +26,7 @@
 // (seed, subgraph serial, level, node, draw) -- see DESIGN.md "RNG contract".
 #include <fcntl.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -53,513 +54,11 @@ int set_error(int code, const char *fmt, ...) {
   return code;
 }
 
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kItems = 4;            // stream slots per thread per chunk
-constexpr uint32_t kLdsCapNodes = 2560;   // largest node set handled by the LDS kernel
-constexpr uint32_t kMaxRoots = 8;
+}  // namespace shadow
 
-// control words (LDS)
-enum { C_NNODES = 0, C_NF0 = 1, C_NF1 = 2, C_OVF = 3, C_MFAIL = 4, C_FRONT_NODES = 5,
-       C_FRONT_READS = 6, C_CHANGED = 7, C_WORDS = 16 };
+#include "sampler_device.h"
 
-// per-subgraph result words in scratch (s_cnt)
-enum { R_N = 0, R_E = 1, R_FLAGS = 2, R_SLOTS = 3, R_FNODES = 4, R_FREADS = 5, R_WORDS = 8 };
-
-struct SampleParams {
-  const uint32_t *indptr;
-  const uint32_t *indices;
-  uint32_t N;
-  uint64_t nnz;
-  const uint32_t *roots;  // [P*R]
-  uint32_t P;
-  int R;
-  int method, depth, budget, k;
-  float threshold;
-  int include_self, include_target_conn, compat;
-  uint64_t seed, serial_base;
-  const int32_t *ppr_row;
-  const uint32_t *ppr_len;
-  const uint32_t *ppr_neigh;
-  const float *ppr_score;
-  uint32_t ppr_stride;
-  // table geometry
-  uint32_t capn;      // node capacity of the tables used by this launch
-  uint32_t capf;      // frontier list capacity
-  uint32_t H;         // hash slots (power of two)
-  uint32_t hshift;    // 32 - log2(H)
-  // per-subgraph scratch (stride = cap_nodes_scr / cap_edges_scr)
-  uint32_t cap_nodes_scr, cap_edges_scr;
-  uint32_t *s_nodes;   // [P*cap_nodes_scr]
-  float *s_ppr;        // [P*cap_nodes_scr]
-  uint32_t *s_rowptr;  // [P*(cap_nodes_scr+1)]
-  uint32_t *s_col;     // [P*cap_edges_scr]
-  uint32_t *s_eid;     // [P*cap_edges_scr]
-  uint32_t *s_tgt;     // [P*kMaxRoots]
-  uint32_t *s_cnt;     // [P*R_WORDS]
-  // global tables for the big path
-  uint32_t *g_tables;        // [n_big_slots * g_stride]
-  uint64_t g_stride;         // words per slot
-  uint32_t *g_ticket;        // work queue head for the big path
-};
-
-struct Tables {
-  uint32_t *hkey;    // [H]
-  uint32_t *hval;    // [H] level mask, later the sub id
-  float *pprv;       // [H] (ppr method) or nullptr
-  uint32_t *nodes;   // [capn]
-  uint32_t *rowptr;  // [capn+1]
-  uint32_t *front0;  // [capf]
-  uint32_t *front1;  // [capf]
-};
-
-// ---------------------------------------------------------------- Philox4x32-10
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// ---------------------------------------------------------------- hash set
-__device__ __forceinline__ uint32_t hash_slot(uint32_t key, uint32_t hshift) {
-  return (key * 0x9E3779B1u) >> hshift;
-}
-
-// insert `key`; returns its slot.  New keys are appended to t.nodes.
-__device__ __forceinline__ uint32_t tab_insert(const Tables &t, uint32_t *ctrl, uint32_t key,
-                                               uint32_t hmask, uint32_t hshift, uint32_t capn) {
-  uint32_t slot = hash_slot(key, hshift);
-  for (;;) {
-    uint32_t old = atomicCAS(&t.hkey[slot], kEmpty, key);
-    if (old == kEmpty) {
-      uint32_t idx = atomicAdd(&ctrl[C_NNODES], 1u);
-      if (idx < capn) t.nodes[idx] = key;
-      else atomicOr(&ctrl[C_OVF], 1u);
-      return slot;
-    }
-    if (old == key) return slot;
-    slot = (slot + 1) & hmask;
-  }
-}
-
-__device__ __forceinline__ int32_t tab_find(const uint32_t *hkey, uint32_t key, uint32_t hmask,
-                                            uint32_t hshift) {
-  uint32_t slot = hash_slot(key, hshift);
-  for (;;) {
-    uint32_t k = hkey[slot];
-    if (k == key) return (int32_t)slot;
-    if (k == kEmpty) return -1;
-    slot = (slot + 1) & hmask;
-  }
-}
-
-__device__ __forceinline__ bool overflowed(uint32_t *ctrl) {
-  return __hip_atomic_load(&ctrl[C_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
-}
-
-// add `u` to the touched set and (unless this is the last level) to the next frontier
-__device__ __forceinline__ void touch(const Tables &t, uint32_t *ctrl, uint32_t u, uint32_t hmask,
-                                      uint32_t hshift, uint32_t capn, uint32_t capf, bool last,
-                                      uint32_t bit_next, uint32_t *nxt, int nxt_cnt_idx) {
-  if (overflowed(ctrl)) return;
-  uint32_t slot = tab_insert(t, ctrl, u, hmask, hshift, capn);
-  if (!last) {
-    uint32_t old = atomicOr(&t.hval[slot], bit_next);
-    if (!(old & bit_next)) {
-      uint32_t idx = atomicAdd(&ctrl[nxt_cnt_idx], 1u);
-      if (idx < capf) nxt[idx] = u;
-      else atomicOr(&ctrl[C_OVF], 4u);
-    }
-  }
-}
-
-// All-ascending bitonic sort of a[0..n) with virtual +inf padding (no storage
-// for the padding: a compare-exchange whose upper partner is >= n is a no-op).
-__device__ __forceinline__ void block_sort_u32(uint32_t *a, uint32_t n) {
-  if (n < 2) { __syncthreads(); return; }
-  uint32_t p2 = 1;
-  while (p2 < n) p2 <<= 1;
-  const uint32_t half = p2 >> 1;
-  for (uint32_t k = 2; k <= p2; k <<= 1) {
-    const uint32_t hk = k >> 1;
-    for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-      uint32_t i = (t / hk) * k + (t % hk);
-      uint32_t j = i ^ (k - 1);
-      if (j < n) {
-        uint32_t x = a[i], y = a[j];
-        if (x > y) { a[i] = y; a[j] = x; }
-      }
-    }
-    __syncthreads();
-    for (uint32_t s = hk >> 1; s >= 1; s >>= 1) {
-      for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-        uint32_t i = (t / s) * (2 * s) + (t % s);
-        uint32_t j = i + s;
-        if (j < n) {
-          uint32_t x = a[i], y = a[j];
-          if (x > y) { a[i] = y; a[j] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-__device__ __forceinline__ bool is_root(const uint32_t *roots, int R, uint32_t v) {
-  bool r = false;
-  for (int i = 0; i < R; i++) r |= (roots[i] == v);
-  return r;
-}
-
-// ---------------------------------------------------------------------------
-// Sample ONE subgraph `s` with the calling workgroup.  `t` points at LDS (fast
-// kernel) or at a global-memory table slot (big kernel); ctrl/wsum/wcnt are LDS.
-// Writes the subgraph-local result into the scratch arrays of subgraph s.
-// ---------------------------------------------------------------------------
-template <bool kGlobalTables>
-__device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t s, const Tables &t,
-                                                uint32_t *ctrl, uint32_t *wsum, uint32_t *wcnt) {
-  const uint32_t tid = threadIdx.x, T = blockDim.x;
-  const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
-  const uint32_t H = p.H, hmask = H - 1, hshift = p.hshift;
-  const uint32_t capn = p.capn, capf = p.capf;
-  const int R = p.R;
-  const uint32_t *roots = p.roots + (size_t)s * R;
-  const uint64_t serial = p.serial_base + s;
-
-  // ---- phase 0: clear tables
-  for (uint32_t i = tid; i < H; i += T) { t.hkey[i] = kEmpty; t.hval[i] = 0; }
-  if (tid < C_WORDS) ctrl[tid] = 0;
-  __syncthreads();
-
-  // ---- phase 1: node selection
-  if (p.method == SG_METHOD_PPR) {
-    // ParallelSampler::ppr, .cpp:572-590 (write order: later writes win)
-    for (int r = 0; r < R; r++) {
-      const uint32_t root = roots[r];
-      const int32_t row = p.ppr_row[root];
-      const uint32_t size_all = row < 0 ? 0u : p.ppr_len[row];
-      const uint32_t size_neigh = min((uint32_t)p.k, size_all);
-      const uint32_t *nb = p.ppr_neigh + (size_t)(row < 0 ? 0 : row) * p.ppr_stride;
-      const float *sc = p.ppr_score + (size_t)(row < 0 ? 0 : row) * p.ppr_stride;
-      const float max_ppr = size_neigh > 1 ? sc[1] : 0.0f;
-      if (tid == 0) {
-        uint32_t slot = tab_insert(t, ctrl, root, hmask, hshift, capn);
-        t.pprv[slot] = (size_neigh <= 1 && size_all > 0) ? sc[0] : -1.0f;   // :574, :581
-        ctrl[C_MFAIL] = size_neigh;
-      }
-      __syncthreads();
-      // first index failing the threshold test (:584); scores are non-increasing
-      for (uint32_t i = tid; i < size_neigh; i += T) {
-        bool fail = (max_ppr == 0.0f) || (sc[i] / max_ppr < p.threshold);
-        if (fail) atomicMin(&ctrl[C_MFAIL], i);
-      }
-      __syncthreads();
-      const uint32_t m = ctrl[C_MFAIL];
-      for (uint32_t i = tid; i < m; i += T) {
-        uint32_t slot = tab_insert(t, ctrl, nb[i], hmask, hshift, capn);
-        t.pprv[slot] = sc[i];                                                // :587
-      }
-      __syncthreads();
-    }
-  } else {
-    // roots: level 0 (.cpp:519-522), nodeIID: roots only (.cpp:502-505)
-    if (tid < (uint32_t)R) {
-      uint32_t slot = tab_insert(t, ctrl, roots[tid], hmask, hshift, capn);
-      uint32_t old = atomicOr(&t.hval[slot], 1u);
-      if (!(old & 1u)) {
-        uint32_t idx = atomicAdd(&ctrl[C_NF0], 1u);
-        t.front0[idx] = roots[tid];
-      }
-    }
-    __syncthreads();
-    const int depth = p.method == SG_METHOD_KHOP ? p.depth : 0;
-    const int budget = p.budget;
-    uint32_t fr_nodes = 0, fr_reads = 0;
-    for (int lvl = 0; lvl < depth; lvl++) {
-      const uint32_t *cur = (lvl & 1) ? t.front1 : t.front0;
-      uint32_t *nxt = (lvl & 1) ? t.front0 : t.front1;
-      const int cur_idx = (lvl & 1) ? C_NF1 : C_NF0, nxt_idx = (lvl & 1) ? C_NF0 : C_NF1;
-      const uint32_t nf = min(ctrl[cur_idx], capf);
-      __syncthreads();
-      if (tid == 0) ctrl[nxt_idx] = 0;
-      __syncthreads();
-      const bool last = (lvl + 1 == depth);
-      const uint32_t bit_next = 1u << (lvl + 1);
-      if (budget >= 0) {
-        // one work item = (frontier node, group of 4 draws)
-        const uint32_t groups = ((uint32_t)budget + 3u) >> 2;
-        const uint32_t items = nf * groups;
-        for (uint32_t q = tid; q < items; q += T) {
-          const uint32_t fi = q / groups, g = q - fi * groups;
-          const uint32_t v = cur[fi];
-          const uint32_t e0 = p.indptr[v], deg = p.indptr[v + 1] - e0;
-          const uint32_t d0 = g * 4;
-          if (g == 0) { fr_nodes++; fr_reads += min(deg, (uint32_t)budget); }
-          if (deg <= (uint32_t)budget) {                               // .cpp:528-531
-            const uint32_t d1 = min(d0 + 4, deg);
-            for (uint32_t d = d0; d < d1; d++)
-              touch(t, ctrl, p.indices[e0 + d], hmask, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
-          } else {                                                     // .cpp:533-536
-            uint32_t rnd[4];
-            philox4x32_10(v, (uint32_t)lvl * 65536u + g, (uint32_t)serial, (uint32_t)(serial >> 32),
-                          (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
-            const uint32_t d1 = min(d0 + 4, (uint32_t)budget);
-            for (uint32_t d = d0; d < d1; d++) {
-              const uint32_t off = __umulhi(rnd[d & 3], deg);
-              touch(t, ctrl, p.indices[e0 + off], hmask, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
-            }
-          }
-        }
-      } else {
-        // full expansion: one wavefront streams one frontier row (coalesced)
-        for (uint32_t fi = wave; fi < nf; fi += nw) {
-          const uint32_t v = cur[fi];
-          const uint32_t e0 = p.indptr[v], deg = p.indptr[v + 1] - e0;
-          if (lane == 0) { fr_nodes++; fr_reads += deg; }
-          for (uint32_t d = lane; d < deg; d += 64)
-            touch(t, ctrl, p.indices[e0 + d], hmask, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
-        }
-      }
-      __syncthreads();
-      if (overflowed(ctrl)) break;
-    }
-    fr_nodes = wave_reduce_sum(fr_nodes);
-    fr_reads = wave_reduce_sum(fr_reads);
-    if (lane == 0) { atomicAdd(&ctrl[C_FRONT_NODES], fr_nodes); atomicAdd(&ctrl[C_FRONT_READS], fr_reads); }
-    __syncthreads();
-  }
-
-  // Global-memory tables: the hash set was built with L2 atomics, the phases
-  // below read it with plain loads -> drop this CU's possibly stale L1 lines.
-  if (kGlobalTables) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
-
-  uint32_t *cnt = p.s_cnt + (size_t)s * R_WORDS;
-  const uint32_t n_all = ctrl[C_NNODES];
-  if (overflowed(ctrl) || n_all > capn || n_all > p.cap_nodes_scr) {
-    if (tid == 0) {
-      cnt[R_N] = n_all; cnt[R_E] = 0; cnt[R_FLAGS] = 1u; cnt[R_SLOTS] = 0;
-      cnt[R_FNODES] = ctrl[C_FRONT_NODES]; cnt[R_FREADS] = ctrl[C_FRONT_READS];
-    }
-    __syncthreads();
-    return;
-  }
-  const uint32_t n = n_all;
-
-  // ---- phase 2: sort ids ascending (.cpp:362) and rank them (.cpp:369-372)
-  block_sort_u32(t.nodes, n);
-  uint32_t *g_nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
-  float *g_ppr = p.s_ppr + (size_t)s * p.cap_nodes_scr;
-  for (uint32_t i = tid; i < n; i += T) {
-    const uint32_t v = t.nodes[i];
-    const int32_t slot = tab_find(t.hkey, v, hmask, hshift);
-    t.hval[slot] = i;
-    g_nodes[i] = v;
-    g_ppr[i] = (p.method == SG_METHOD_PPR) ? t.pprv[slot] : -1.0f;     // .cpp:365, :545
-  }
-  __syncthreads();
-  if (tid < (uint32_t)R) {                                             // .cpp:373-377
-    const int32_t slot = tab_find(t.hkey, roots[tid], hmask, hshift);
-    p.s_tgt[(size_t)s * kMaxRoots + tid] = t.hval[slot];
-  }
-
-  // ---- phase 3: stream-slot prefix per row: deg(v)+1 slots (last = sentinel)
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < n; base += T) {
-    const uint32_t i = base + tid;
-    uint32_t val = 0;
-    if (i < n) { const uint32_t v = t.nodes[i]; val = p.indptr[v + 1] - p.indptr[v] + 1u; }
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(val, wsum, &total);
-    if (i < n) t.rowptr[i] = carry + ex;
-    carry += total;
-  }
-  if (tid == 0) t.rowptr[n] = carry;
-  __syncthreads();
-  const uint32_t S = carry;
-
-  // ---- phase 4: ordered streaming induction (.cpp:381-427)
-  const bool incl_self = p.include_self != 0;
-  const bool itc = (p.include_target_conn != 0) || (R == 1);          // .cpp:356-358
-  const bool compat = p.compat != 0;
-  const uint32_t cape = p.cap_edges_scr;
-  uint32_t *g_rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
-  uint32_t *g_col = p.s_col + (size_t)s * cape;
-  uint32_t *g_eid = p.s_eid + (size_t)s * cape;
-  uint32_t e_run = 0;
-  const uint32_t chunk = T * kItems;
-  for (uint32_t base = 0; base < S; base += chunk) {
-    uint32_t o_col[kItems], o_eid[kItems], o_row[kItems], o_rank[kItems];
-    uint32_t o_flags[kItems];   // bit0 self edge, bit1 own edge, bit2 first slot of its row
-#pragma unroll
-    for (int kk = 0; kk < kItems; kk++) {
-      const uint32_t slot = base + kk * T + tid;
-      uint32_t flags = 0, col = 0, eid = 0, row = 0;
-      if (slot < S) {
-        // largest row with rowptr[row] <= slot
-        uint32_t lo = 0, hi = n;
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (t.rowptr[mid] <= slot) lo = mid; else hi = mid;
-        }
-        row = lo;
-        const uint32_t rs = t.rowptr[row];
-        const uint32_t j = slot - rs;
-        const uint32_t deg = t.rowptr[row + 1] - rs - 1u;
-        const uint32_t v = t.nodes[row];
-        const uint32_t e0 = p.indptr[v];
-        if (j == 0) flags |= 4u;
-        uint32_t cand = kEmpty;   // neighbour id to test for membership
-        if (j < deg) {
-          cand = p.indices[e0 + j];
-          eid = e0 + j;
-          if (incl_self) {
-            // self edge goes right before the first neighbour > v (.cpp:387-400)
-            const bool prev_lt = (j == 0) || (p.indices[e0 + j - 1] < v);
-            if (prev_lt && v < cand) flags |= 1u;
-          }
-        } else {
-          // sentinel slot: self edge after the last neighbour, or the compat over-read
-          bool inserted_here = false;
-          if (incl_self) {
-            inserted_here = (deg == 0) || (p.indices[e0 + deg - 1] < v);
-            if (inserted_here) flags |= 1u;
-          }
-          if (compat && !inserted_here) {
-            bool inserted = false;
-            if (incl_self) {
-              // was the self edge inserted earlier in this row?  <=> v not in the row
-              uint32_t l2 = 0, h2 = deg;
-              while (l2 < h2) { const uint32_t m2 = (l2 + h2) >> 1; if (p.indices[e0 + m2] < v) l2 = m2 + 1; else h2 = m2; }
-              inserted = !(l2 < deg && p.indices[e0 + l2] == v);
-            }
-            if (!inserted && (uint64_t)e0 + deg < p.nnz) { cand = p.indices[e0 + deg]; eid = e0 + deg; }
-          }
-        }
-        if (cand != kEmpty) {
-          const int32_t hs = tab_find(t.hkey, cand, hmask, hshift);
-          if (hs >= 0) {
-            bool keep = true;
-            if (!itc) keep = !(is_root(roots, R, v) && is_root(roots, R, cand));   // .cpp:414-418
-            if (keep) { flags |= 2u; col = t.hval[hs]; }
-          }
-        }
-      }
-      const uint64_t m_self = __ballot(flags & 1u), m_own = __ballot(flags & 2u);
-      const uint64_t lt = lanemask_lt();
-      o_rank[kk] = __popcll(m_self & lt) + __popcll(m_own & lt);
-      if (lane == 0) wcnt[kk * nw + wave] = __popcll(m_self) + __popcll(m_own);
-      o_flags[kk] = flags; o_col[kk] = col; o_eid[kk] = eid; o_row[kk] = row;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const uint32_t cntw = kItems * nw;
-      const uint32_t x = tid < cntw ? wcnt[tid] : 0u;
-      const uint32_t incl = wave_incl_scan(x);
-      if (tid < cntw) wcnt[tid] = incl - x;
-      if (tid == 63) wcnt[64] = incl;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < kItems; kk++) {
-      const uint32_t flags = o_flags[kk];
-      uint32_t pos = e_run + wcnt[kk * nw + wave] + o_rank[kk];
-      if (flags & 4u) g_rowptr[o_row[kk]] = pos;
-      if (flags & 1u) {
-        if (pos < cape) { g_col[pos] = o_row[kk]; g_eid[pos] = 0xFFFFFFFFu; }   // .cpp:408-410
-        pos++;
-      }
-      if (flags & 2u) {
-        if (pos < cape) { g_col[pos] = o_col[kk]; g_eid[pos] = o_eid[kk]; }     // .cpp:420-422
-      }
-    }
-    e_run += wcnt[64];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    g_rowptr[n] = e_run;
-    cnt[R_N] = n; cnt[R_E] = e_run; cnt[R_FLAGS] = (e_run > cape) ? 2u : 0u; cnt[R_SLOTS] = S;
-    cnt[R_FNODES] = ctrl[C_FRONT_NODES]; cnt[R_FREADS] = ctrl[C_FRONT_READS];
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-
-// LDS carve shared by host (size computation) and device
-struct LdsLayout {
-  size_t hkey, hval, pprv, nodes, rowptr, front0, front1, ctrl, wsum, wcnt, total;
-};
-
-__host__ __device__ inline LdsLayout lds_layout(uint32_t H, uint32_t capn, uint32_t capf, bool ppr, uint32_t T) {
-  LdsLayout L;
-  size_t o = 0;
-  L.hkey = o; o += (size_t)H * 4;
-  L.hval = o; o += (size_t)H * 4;
-  L.pprv = o; o += ppr ? (size_t)H * 4 : 0;
-  L.nodes = o; o += (((size_t)capn * 4) + 15) & ~(size_t)15;
-  L.rowptr = o; o += (((size_t)(capn + 1) * 4) + 15) & ~(size_t)15;
-  L.front0 = o; o += (((size_t)capf * 4) + 15) & ~(size_t)15;
-  L.front1 = o; o += (((size_t)capf * 4) + 15) & ~(size_t)15;
-  L.ctrl = o; o += C_WORDS * 4;
-  L.wsum = o; o += 32 * 4;
-  L.wcnt = o; o += (((size_t)(kItems * (T / 64)) + 1 + 64) * 4 + 15) & ~(size_t)15;
-  L.total = o;
-  return L;
-}
-
-__global__ void sg_sample_lds_kernel(SampleParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const LdsLayout L = lds_layout(p.H, p.capn, p.capf, p.method == SG_METHOD_PPR, blockDim.x);
-  Tables t;
-  t.hkey = (uint32_t *)(smem + L.hkey);
-  t.hval = (uint32_t *)(smem + L.hval);
-  t.pprv = (float *)(smem + L.pprv);
-  t.nodes = (uint32_t *)(smem + L.nodes);
-  t.rowptr = (uint32_t *)(smem + L.rowptr);
-  t.front0 = (uint32_t *)(smem + L.front0);
-  t.front1 = (uint32_t *)(smem + L.front1);
-  uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
-  uint32_t *wsum = (uint32_t *)(smem + L.wsum);
-  uint32_t *wcnt = (uint32_t *)(smem + L.wcnt);
-  sample_subgraph<false>(p, blockIdx.x, t, ctrl, wsum, wcnt);
-}
-
-// Big path: persistent workgroups pull overflowed subgraphs (flag bit0 from the
-// LDS kernel) from a ticket counter and redo them over global-memory tables.
-__global__ void sg_sample_big_kernel(SampleParams p) {
-  __shared__ uint32_t ctrl[C_WORDS];
-  __shared__ uint32_t wsum[32];
-  __shared__ uint32_t wcnt[kItems * 16 + 1 + 64];
-  __shared__ uint32_t s_next;
-  uint32_t *base = p.g_tables + (size_t)blockIdx.x * p.g_stride;
-  Tables t;
-  size_t o = 0;
-  t.hkey = base + o; o += p.H;
-  t.hval = base + o; o += p.H;
-  t.pprv = (float *)(base + o); o += p.H;
-  t.nodes = base + o; o += p.capn;
-  t.rowptr = base + o; o += (size_t)p.capn + 1;
-  t.front0 = base + o; o += p.capf;
-  t.front1 = base + o; o += p.capf;
-  for (;;) {
-    if (threadIdx.x == 0) s_next = atomicAdd(p.g_ticket, 1u);
-    __syncthreads();
-    const uint32_t s = s_next;
-    __syncthreads();
-    if (s >= p.P) return;
-    const uint32_t flags = p.s_cnt[(size_t)s * R_WORDS + R_FLAGS];
-    if (!(flags & 1u)) continue;
-    sample_subgraph<true>(p, s, t, ctrl, wsum, wcnt);
-  }
-}
+namespace shadow {
 
 // ---------------------------------------------------------------------------
 // Relocation into the block-diagonal batch (frontend/graph.py:280-320), hop
@@ -572,7 +71,8 @@ struct RelocParams {
   uint32_t cap_nodes_scr, cap_edges_scr;
   const uint32_t *s_nodes;
   const float *s_ppr;
-  const uint32_t *s_rowptr;
+  uint32_t *s_rowptr;     // [P*(cap_nodes_scr+1)] written here (lower_bound over s_row)
+  const uint32_t *s_row;
   const uint32_t *s_col;
   const uint32_t *s_eid;
   const uint32_t *s_tgt;
@@ -651,8 +151,16 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   }
   const uint32_t *nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
   const float *ppr = p.s_ppr + (size_t)s * p.cap_nodes_scr;
-  const uint32_t *rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
+  uint32_t *rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
+  const uint32_t *erow = p.s_row + (size_t)s * p.cap_edges_scr;
   const uint32_t *col = p.s_col + (size_t)s * p.cap_edges_scr;
+  // local CSR row pointers: edges are ordered by row -> rowptr[i] = lower_bound(erow, i)
+  for (uint32_t i = tid; i <= n; i += T) {
+    uint32_t lo = 0, hi = e;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (erow[mid] < i) lo = mid + 1; else hi = mid; }
+    rowptr[i] = lo;
+  }
+  __syncthreads();
   const uint32_t *eid = p.s_eid + (size_t)s * p.cap_edges_scr;
   for (uint32_t i = tid; i < n; i += T) {
     o.d_node[noff + i] = nodes[i];
@@ -721,6 +229,7 @@ struct sg_sampler {
   hipEvent_t ev = nullptr;
   bool pending = false;
   uint32_t pending_P = 0;
+  const uint32_t *last_cnt = nullptr;   // per-subgraph result words of the last call
 };
 
 static uint32_t next_pow2(uint64_t x) {
@@ -1097,6 +606,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
   auto carve = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
   const size_t o_nodes = carve(Pz * capn * 4), o_ppr = carve(Pz * capn * 4), o_rowptr = carve(Pz * ((size_t)capn + 1) * 4);
   const size_t o_tmp = carve(Pz * capn * 4);
+  const size_t o_row = carve(Pz * (size_t)cape * 4);
   const size_t o_col = carve(Pz * (size_t)cape * 4), o_eid = carve(Pz * (size_t)cape * 4);
   const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
   int rc;
@@ -1124,44 +634,54 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     p.ppr_score = s->d_ppr_score; p.ppr_stride = s->ppr_stride;
     p.cap_nodes_scr = capn; p.cap_edges_scr = cape;
     p.s_nodes = (uint32_t *)(sc + o_nodes); p.s_ppr = (float *)(sc + o_ppr);
-    p.s_rowptr = (uint32_t *)(sc + o_rowptr); p.s_col = (uint32_t *)(sc + o_col);
+    p.s_row = (uint32_t *)(sc + o_row); p.s_col = (uint32_t *)(sc + o_col);
     p.s_eid = (uint32_t *)(sc + o_eid); p.s_tgt = (uint32_t *)(sc + o_tgt);
     p.s_cnt = (uint32_t *)(sc + o_cnt);
-    // ---- LDS kernel
+    s->last_cnt = p.s_cnt;
+    // ---- LDS kernel (persistent workgroups, one subgraph at a time)
     const uint32_t capn_lds = std::min(capn, kLdsCapNodes);
     const uint32_t capf_lds = std::min(capf, capn_lds);
-    const uint32_t T = (capn_lds > 1024 || P < 512) ? 512 : 256;
-    // sparse table (most probes are misses): 4x the capacity while the two
-    // tables stay within 32 KiB, never below 1.5x
-    uint32_t H = next_pow2((uint64_t)capn_lds * 4);
-    while ((size_t)H * 8 > 32 * 1024 && (H >> 1) >= capn_lds + capn_lds / 2) H >>= 1;
-    while (H < capn_lds + T + 1) H <<= 1;
-    H = std::max<uint32_t>(H, 64);
+    uint32_t T = 512;
+    if (const char *e = getenv("SHADOW_SG_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = (uint32_t)v; }
+    // bucketised table: ~4 key slots per possible node (power-of-two bucket count)
+    uint32_t H = std::max<uint32_t>(64, next_pow2((uint64_t)capn_lds * 4));
+    while ((size_t)H * 8 > 16 * 1024 && (H >> 1) >= capn_lds * 2) H >>= 1;
     p.capn = capn_lds; p.capf = capf_lds; p.H = H;
-    p.hshift = 32; for (uint32_t h = H; h > 1; h >>= 1) p.hshift--;
-    const LdsLayout L = lds_layout(H, capn_lds, capf_lds, cfg->method == SG_METHOD_PPR, T);
-    if (L.total > 160 * 1024) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
+    p.hshift = 32; for (uint32_t h = H / 4; h > 1; h >>= 1) p.hshift--;
+    p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, ((capn_lds * 7 / 2) + 255) & ~255u));
+    if (const char *e = getenv("SHADOW_SG_CAPM")) { const int v = atoi(e); if (v >= 256) p.capm = (uint32_t)v; }
+    p.g_ticket = (uint32_t *)(s->d_counts + 8);
+    const LdsLayout L = lds_layout(H, capn_lds, capf_lds, p.capm, cfg->method == SG_METHOD_PPR);
+    if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
+    const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
+    const void *kfn = plain ? (const void *)sg_sample_lds_kernel<true> : (const void *)sg_sample_lds_kernel<false>;
     if (L.total > 64 * 1024)
-      SHD_HIP(hipFuncSetAttribute((const void *)sg_sample_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(sg_sample_lds_kernel, dim3(P), dim3(T), L.total, stream, p);
+      SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((L.total + 255) & ~(size_t)255)));
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
+    uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));
+    per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 7));
+    const uint32_t grid = std::min<uint32_t>(P, (uint32_t)ncu * per_cu);
+    if (plain) hipLaunchKernelGGL(sg_sample_lds_kernel<true>, dim3(grid), dim3(T), L.total, stream, p);
+    else hipLaunchKernelGGL(sg_sample_lds_kernel<false>, dim3(grid), dim3(T), L.total, stream, p);
     SHD_HIP(hipGetLastError());
     // ---- big path for subgraphs that overflowed the LDS tables
     if (capn > capn_lds) {
       SampleParams q = p;
       q.capn = capn; q.capf = capf;
-      uint32_t Hb = next_pow2((uint64_t)capn * 2);
       const uint32_t Tb = 1024;
-      while (Hb < capn + Tb + 1) Hb <<= 1;
-      q.H = Hb; q.hshift = 32; for (uint32_t h = Hb; h > 1; h >>= 1) q.hshift--;
-      const uint64_t stride = (uint64_t)Hb * 3 + (uint64_t)capn * 2 + 1 + (uint64_t)capf * 2 + 64;
-      int ncu = 256;
-      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
+      uint32_t Hb = std::max<uint32_t>(64, next_pow2((uint64_t)capn * 4));
+      q.H = Hb; q.hshift = 32; for (uint32_t h = Hb / 4; h > 1; h >>= 1) q.hshift--;
+      q.capm = std::max<uint32_t>(8192, next_pow2((uint64_t)capn * 4));
+      uint64_t stride = ((uint64_t)Hb + kStash) * 3 + ((uint64_t)capn + 8) * 4 + ((uint64_t)capf + 4) * 2 +
+                        (uint64_t)q.capm * 3 + 64;
+      stride = (stride + 63) & ~(uint64_t)63;
       uint32_t nslots = std::min<uint32_t>(P, (uint32_t)ncu);
       // keep the table arena below 4 GiB
       while (nslots > 1 && (uint64_t)nslots * stride * 4 > ((uint64_t)4 << 30)) nslots >>= 1;
       if ((rc = ensure(&s->d_big, &s->big_bytes, (size_t)nslots * stride * 4)) != SG_OK) return rc;
       q.g_tables = (uint32_t *)s->d_big; q.g_stride = stride;
-      q.g_ticket = (uint32_t *)(s->d_counts + 8);
+      q.g_ticket = (uint32_t *)(s->d_counts + 8) + 1;
       hipLaunchKernelGGL(sg_sample_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
       SHD_HIP(hipGetLastError());
     }
@@ -1169,7 +689,8 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     memset(&r, 0, sizeof(r));
     r.P = P; r.R = R; r.aug_flags = cfg->aug_flags;
     r.cap_nodes_scr = capn; r.cap_edges_scr = cape;
-    r.s_nodes = p.s_nodes; r.s_ppr = p.s_ppr; r.s_rowptr = p.s_rowptr; r.s_col = p.s_col;
+    r.s_nodes = p.s_nodes; r.s_ppr = p.s_ppr; r.s_rowptr = (uint32_t *)(sc + o_rowptr);
+    r.s_row = p.s_row; r.s_col = p.s_col;
     r.s_eid = p.s_eid; r.s_tgt = p.s_tgt; r.s_cnt = p.s_cnt; r.s_tmp = (uint32_t *)(sc + o_tmp);
     r.out = *out; r.d_counts = s->d_counts;
     hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(256), 0, stream, r);
@@ -1200,5 +721,15 @@ extern "C" int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts) {
                      "largest subgraph %u nodes / %u edges, batch %llu nodes / %llu edges",
                      counts->overflow, counts->max_subg_nodes, counts->max_subg_edges,
                      (unsigned long long)counts->n_tot, (unsigned long long)counts->e_tot);
+  return SG_OK;
+}
+
+extern "C" int sg_debug_subgraph_stats(sg_sampler *s, uint32_t *h_out, uint32_t max_subgraphs) {
+  if (!s || !h_out) return set_error(SG_ERR_INVALID, "sg_debug_subgraph_stats: null argument");
+  if (!s->last_cnt) return set_error(SG_ERR_STATE, "sg_debug_subgraph_stats: nothing sampled yet");
+  SHD_HIP(hipSetDevice(s->device));
+  SHD_HIP(hipDeviceSynchronize());
+  const uint32_t P = std::min(max_subgraphs, s->pending_P);
+  SHD_HIP(hipMemcpy(h_out, s->last_cnt, (size_t)P * R_WORDS * 4, hipMemcpyDeviceToHost));
   return SG_OK;
 }

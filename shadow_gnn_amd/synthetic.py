@@ -10,6 +10,13 @@ SHAPES = {
     "papers100M": (111_059_956, 3_231_371_744, 128, 172),
 }
 
+# Largest node degree of the real (undirected) OGB graphs.  An uncapped
+# Pareto(1.5) weight vector over 2.4 M nodes puts >1 M edges on a single node
+# (60x the real products maximum) and the benchmark degenerates into scanning
+# four rows; the generators clip the weights so that the expected maximum
+# degree matches the dataset the shape is named after.
+MAX_DEGREE = {"arxiv": 13_161, "products": 17_481, "papers100M": 250_000}
+
 
 def make_graph_numpy(n, avg_deg, seed=0):
     """Small/medium graphs on the host (tests, smoke)."""
@@ -31,7 +38,7 @@ def make_graph_numpy(n, avg_deg, seed=0):
     return indptr, cols
 
 
-def make_graph_torch(n, nnz_target, seed=0, device="cuda"):
+def make_graph_torch(n, nnz_target, seed=0, device="cuda", max_degree=None):
     """Benchmark-scale graphs generated on the GPU (sort-based symmetrise +
     dedupe).  Returns int32 tensors (uint32 bit patterns) indptr[n+1], indices[nnz]."""
     import torch
@@ -41,6 +48,9 @@ def make_graph_torch(n, nnz_target, seed=0, device="cuda"):
     # Pareto(1.5)+1 weights via inverse CDF; weighted endpoint via searchsorted on the CDF
     u = torch.rand(n, generator=g, device=device, dtype=torch.float64).clamp_(min=1e-12)
     w = u.pow_(-1.0 / 1.5)
+    if max_degree is not None:
+        for _ in range(3):      # clip so that E[deg] of the heaviest node ~ max_degree
+            w.clamp_(max=float(max_degree) * float(w.sum()) / m)
     cdf = torch.cumsum(w, 0)
     cdf /= cdf[-1].clone()
     a = torch.randint(0, n, (m,), generator=g, device=device, dtype=torch.int64)
