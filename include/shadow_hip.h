@@ -163,6 +163,83 @@ int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t
               void *stream);
 int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts);
 
+/* ------------------------------------------------------------ layer ops
+ * Aggregation / normalisation kernels over a batch CSR (uint32 indptr[n+1],
+ * indices[e], block diagonal as produced by sg_sample).  All pointers are
+ * DEVICE pointers; features are row-major fp32 with a leading dimension in
+ * elements.  These replace the torch.sparse.mm / torch_scatter / scipy call
+ * sites of shaDow/layers.py and frontend/graph_utils.py listed per function.  */
+
+/* out[i,:] = table[idx[i],:]      (feat_full[subgs.node], shaDow/minibatch.py:469) */
+int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n,
+                       uint32_t F, float *d_out, int64_t ld_out, void *stream);
+
+/* edge_row[p] = row of edge p (the COO row index adj._indices()[0] of
+ * frontend/graph_utils.py:48-56, without the host round trip).               */
+int sl_csr_edge_rows(const uint32_t *d_indptr, uint32_t n, uint32_t e, uint32_t *d_edge_row,
+                     void *stream);
+
+/* Transposed CSR for the backward pass (dX = A^T dY): t_indptr[n+1],
+ * t_indices[e] (source rows, ascending) and t_perm[e] (position of the same
+ * edge in the original CSR).  d_work: uint32[n + 2*e + 16] scratch.           */
+int sl_csr_transpose(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_edge_row,
+                     uint32_t n, uint32_t e, uint32_t *d_t_indptr, uint32_t *d_t_indices,
+                     uint32_t *d_t_perm, uint32_t *d_work, void *stream);
+
+/* Degree scales of the adjacency normalisations (edge_w = drop-edge mask or
+ * NULL for all ones):  mode 0 "rw":  1/max(1,sum_j w_ij)     (adj_norm_rw,
+ * frontend/graph_utils.py:84-94);  mode 1 "sym": max(1,sum_j w_ij)^-1/2
+ * (adj_norm_sym, frontend/graph_utils.py:140-142).                            */
+int sl_degree_scales(const uint32_t *d_indptr, const float *d_edge_w, uint32_t n, int mode,
+                     float *d_row_scale, void *stream);
+
+/* Y[i,:] = row_scale[i] * sum_{p in row i} edge_w[edge_perm[p]] * col_scale[col_p] * X[col_p,:]
+ * Any of edge_w / edge_perm / row_scale / col_scale may be NULL (= 1 / identity).
+ * Replaces torch.sparse.mm(adj_norm, X) (shaDow/layers.py:326-327,433,475,580). */
+int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                    const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                    const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
+                    void *stream);
+
+/* Fused activation + feature normalisation + branch sum:
+ *   out = out_scale * sum_{b<nb} ( (h_b - mean) * scale[b] * rsqrt(var + 1e-9) + offset[b] ),
+ *   h_b = act_b(Z_b), mean/var (biased) over segments of `seg` features
+ * (shaDowLayer._f_norm_feat, shaDow/layers.py:329-338; GCN :435, GraphSAGE
+ * :476-483, GAT :620-625 with seg = head slice and out_scale = 0.5).
+ * act codes: 0 identity("I"), 1 relu, 2 elu, 3 tanh, 4 leakyrelu(0.2).
+ * d_Z / ldz / act are HOST arrays of nb entries; scale / offset are [nb, F].   */
+int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
+                    const float *d_scale, const float *d_offset, uint32_t n, uint32_t F, uint32_t seg,
+                    float out_scale, float *d_out, int64_t ldo, void *stream);
+/* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F]
+ * (overwritten).                                                              */
+int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
+                    const float *d_scale, const float *d_offset, uint32_t n, uint32_t F, uint32_t seg,
+                    float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
+                    const int64_t *lddz, float *d_dscale, float *d_doffset, void *stream);
+
+/* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
+ * heads, shaDow/layers.py:560-582,612-619):
+ *   hn = act(z_neigh);  u_s = att[0,h]·act(z_self)_h;  u_n = att[1,h]·hn_h
+ *   e_ij = lrelu0.2(u_s[i]) + lrelu0.2(u_n[j]);  row softmax with max
+ *   subtraction, numerator * edge_w (drop-edge mask), denominator >= 1e-10
+ *   nagg_i = sum_j p_ij hn_j / den_i
+ * F = heads*D <= 256, D = 4*2^k.  Outputs hn[n,F], u_s/u_n/mx/den[n,heads]
+ * are kept for the backward pass.                                             */
+int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+               const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
+               uint32_t F, uint32_t heads, float *d_hn, float *d_u_s, float *d_u_n, float *d_mx,
+               float *d_den, float *d_nagg, void *stream);
+/* Backward: dz_self (attention part only), dz_neigh, datt[2,heads,D].
+ * d_work: float[2*e*heads + n*heads].                                         */
+int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
+               const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
+               const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
+               uint32_t e, uint32_t F, uint32_t heads, const float *d_hn, const float *d_u_s,
+               const float *d_u_n, const float *d_mx, const float *d_den, const float *d_nagg,
+               const float *d_dnagg, float *d_work, float *d_dz_self, float *d_dz_neigh, float *d_datt,
+               void *stream);
+
 /* Development aid: per-subgraph result words of the last sg_sample call,
  * 16 uint32 per subgraph: {nodes, edges, flags, stream slots, frontier nodes,
  * frontier reads, -, -, 8 x phase cycle stamps (only when the library was

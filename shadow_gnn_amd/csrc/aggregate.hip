@@ -1,0 +1,658 @@
+// aggregate.hip -- per-subgraph aggregation ops of the shaDow layers behind the
+// sl_* C ABI (MI355X / gfx950).  All of them are HBM-bound gather / streaming
+// kernels over the block-diagonal batch CSR produced by the sampler:
+//
+//   sl_gather_rows_f32   feat_full[subgs.node]               shaDow/minibatch.py:469
+//   sl_csr_transpose     structure for the backward SpMM (A^T dY)
+//   sl_degree_scales     D^-1 / D^-1/2 of adj_norm_rw / adj_norm_sym
+//                        (frontend/graph_utils.py:67-145), optionally with a drop-edge mask
+//   sl_spmm_csr_f32      Y = diag(rs) (A o W) diag(cs) X     shaDow/layers.py:326-327,433,475
+//   sl_act_norm_fwd/bwd  sum_b norm_b(act(Z_b))              shaDow/layers.py:329-338,476-483
+//
+// Layout: rows are feature vectors of F fp32; one wavefront owns 64/LPR rows at a
+// time, LPR = lanes per row (power of two), each lane moving float4 (16 B) so a
+// 256-feature row is exactly one 1-KiB wave access.  MFMA is not used here: the
+// dense feature x weight GEMMs stay on rocBLAS/hipBLASLt through torch.
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace shadow {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ---------------------------------------------------------------- gather
+// out[i, :] = table[idx[i], :]; F % 4 == 0, rows 16-B aligned.
+template <int LPR>
+__global__ void gather_rows_kernel(const float *__restrict__ table, int64_t ld_table,
+                                   const uint32_t *__restrict__ idx, float *__restrict__ out,
+                                   int64_t ld_out, uint32_t n, uint32_t F) {
+  const uint32_t rows_per_block = kBlock / LPR;
+  const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  for (uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub; r < n;
+       r += (uint64_t)gridDim.x * rows_per_block) {
+    const float *src = table + (int64_t)idx[r] * ld_table;
+    float *dst = out + (int64_t)r * ld_out;
+    for (uint32_t c = l * 4; c < F; c += LPR * 4) st4(dst + c, ld4(src + c));
+  }
+}
+
+__global__ void gather_rows_scalar_kernel(const float *__restrict__ table, int64_t ld_table,
+                                          const uint32_t *__restrict__ idx, float *__restrict__ out,
+                                          int64_t ld_out, uint32_t n, uint32_t F) {
+  const uint64_t total = (uint64_t)n * F;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = t / F, c = t % F;
+    out[r * ld_out + c] = table[(int64_t)idx[r] * ld_table + c];
+  }
+}
+
+// ---------------------------------------------------------------- transpose
+// Batch CSR -> transposed CSR (+ permutation into the original edge order), all
+// edge-parallel.  Fast path: the structure is symmetric (undirected graphs with
+// sorted rows, the normal case) => A^T has the same indptr/indices and the
+// permutation is "position of the mate edge", found by binary search.  A
+// device-side flag switches to the general counting path when a mate is missing.
+
+// row of every edge (lower_bound over indptr)
+__global__ void edge_rows_kernel(const uint32_t *__restrict__ indptr, uint32_t n, uint32_t e,
+                                 uint32_t *__restrict__ edge_row) {
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t lo = 0, hi = n;           // largest i with indptr[i] <= p
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (indptr[mid] <= p) lo = mid; else hi = mid; }
+    edge_row[p] = lo;
+  }
+}
+
+__global__ void tr_sym_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                              const uint32_t *__restrict__ edge_row, uint32_t n, uint32_t e,
+                              uint32_t *__restrict__ t_indptr, uint32_t *__restrict__ t_indices,
+                              uint32_t *__restrict__ t_perm, uint32_t *__restrict__ flag) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = tid; i <= n; i += nt) t_indptr[i] = indptr[i];
+  for (uint64_t p = tid; p < e; p += nt) {
+    const uint32_t i = edge_row[p], j = indices[p];
+    t_indices[p] = j;
+    uint32_t lo = indptr[j], hi = indptr[j + 1];
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (indices[mid] < i) lo = mid + 1; else hi = mid; }
+    if (lo < indptr[j + 1] && indices[lo] == i) t_perm[lo] = (uint32_t)p;   // entry (j, i) of A^T comes from edge p
+    else atomicOr(flag, 1u);
+  }
+}
+
+// every slot of t_perm must have been claimed exactly once
+__global__ void tr_check_kernel(const uint32_t *__restrict__ t_perm, uint32_t e, uint32_t *__restrict__ flag) {
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (uint64_t)gridDim.x * blockDim.x)
+    if (t_perm[p] == 0xFFFFFFFFu) atomicOr(flag, 1u);
+}
+
+// ---- general path (runs only when *flag != 0)
+__global__ void tr_count_kernel(const uint32_t *__restrict__ indices, uint32_t n, uint32_t e,
+                                uint32_t *__restrict__ cnt, const uint32_t *__restrict__ flag) {
+  if (*flag == 0) return;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = tid; t < e; t += nt) atomicAdd(&cnt[indices[t] + 1], 1u);
+}
+
+__global__ void tr_zero_kernel(uint32_t *__restrict__ a, uint32_t n1, const uint32_t *__restrict__ flag) {
+  if (*flag == 0) return;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n1; t += (uint64_t)gridDim.x * blockDim.x) a[t] = 0;
+}
+
+// single-workgroup inclusive scan in place over a[0..n1) (a[i+1] = count of row i, a[0] = 0)
+__global__ void tr_scan_kernel(uint32_t *__restrict__ a, uint32_t n1, uint32_t *__restrict__ cursor,
+                               const uint32_t *__restrict__ flag) {
+  if (*flag == 0) return;
+  __shared__ uint32_t wsum[32];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n1; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n1 ? a[i] : 0u;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) { const uint32_t x = wsum[w]; if (w < wave_id()) pre += x; tot += x; }
+    const uint32_t c = carry_s;
+    if (i < n1) { a[i] = c + pre + incl; cursor[i] = c + pre + incl; }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = c + tot;
+    __syncthreads();
+  }
+}
+
+__global__ void tr_fill_kernel(const uint32_t *__restrict__ indices, const uint32_t *__restrict__ edge_row,
+                               uint32_t e, uint32_t *__restrict__ cursor, uint32_t *__restrict__ t_indices,
+                               uint32_t *__restrict__ t_perm, const uint32_t *__restrict__ flag) {
+  if (*flag == 0) return;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t q = atomicAdd(&cursor[indices[p]], 1u);
+    t_indices[q] = edge_row[p];
+    t_perm[q] = (uint32_t)p;
+  }
+}
+
+// Order every transposed row by edge position (== by source row): one wavefront
+// per row, rank sort through registers (rows are short; a hub row costs k^2/64).
+__global__ void tr_sort_rows_kernel(const uint32_t *__restrict__ t_indptr, uint32_t n,
+                                    uint32_t *__restrict__ t_indices, uint32_t *__restrict__ t_perm,
+                                    uint32_t *__restrict__ tmp_idx, uint32_t *__restrict__ tmp_perm,
+                                    const uint32_t *__restrict__ flag) {
+  if (*flag == 0) return;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint64_t j = wave; j < n; j += nwaves) {
+    const uint32_t a = t_indptr[j], b = t_indptr[j + 1];
+    if (b - a < 2) continue;
+    for (uint32_t x = a + lane; x < b; x += 64) {
+      const uint32_t kp = t_perm[x];
+      uint32_t r = 0;
+      for (uint32_t y = a; y < b; y++) r += (t_perm[y] < kp) ? 1u : 0u;
+      tmp_perm[a + r] = kp; tmp_idx[a + r] = t_indices[x];
+    }
+  }
+}
+
+__global__ void tr_copy_back_kernel(const uint32_t *__restrict__ t_indptr, uint32_t n, uint32_t e,
+                                    uint32_t *__restrict__ t_indices, uint32_t *__restrict__ t_perm,
+                                    const uint32_t *__restrict__ tmp_idx, const uint32_t *__restrict__ tmp_perm,
+                                    const uint32_t *__restrict__ flag) {
+  if (*flag == 0) return;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < e; p += (uint64_t)gridDim.x * blockDim.x) {
+    // rows with a single entry were not touched by the sort
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (t_indptr[mid] <= p) lo = mid; else hi = mid; }
+    if (t_indptr[lo + 1] - t_indptr[lo] >= 2) { t_indices[p] = tmp_idx[p]; t_perm[p] = tmp_perm[p]; }
+  }
+}
+
+// ---------------------------------------------------------------- degree scales
+// mode 0 (rw):  row_scale[i] = 1 / max(1, sum_j w_ij)          graph_utils.py:84-94
+// mode 1 (sym): row_scale[i] = max(1, sum_j w_ij)^-1/2         graph_utils.py:140-142
+__global__ void degree_scales_kernel(const uint32_t *__restrict__ indptr, const float *__restrict__ edge_w,
+                                     uint32_t n, int mode, float *__restrict__ row_scale) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t a = indptr[i], b = indptr[i + 1];
+    float d;
+    if (edge_w) { d = 0.f; for (uint32_t p = a; p < b; p++) d += edge_w[p]; }
+    else d = (float)(b - a);
+    d = fmaxf(d, 1.0f);
+    row_scale[i] = mode == 0 ? 1.0f / d : 1.0f / sqrtf(d);
+  }
+}
+
+// ---------------------------------------------------------------- SpMM
+// Y[i,:] = rs[i] * sum_{p in row i} w[perm[p]] * cs[col_p] * X[col_p,:]
+// LPR lanes per row (F/4 <= LPR*CH), each lane CH float4 chunks.
+template <int LPR, int CH>
+__global__ void spmm_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                            const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
+                            const float *__restrict__ row_scale, const float *__restrict__ col_scale,
+                            const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
+                            uint32_t n, uint32_t F) {
+  const uint32_t rows_per_block = kBlock / LPR;
+  const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  // XCD-aware order: consecutive logical blocks (rows of the same subgraphs) share an XCD's L2
+  const uint32_t nb = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t per = nb >> 3;          // the grid is a multiple of 8 blocks
+  const uint32_t lb = xcd * per + slot;
+  const uint64_t r = (uint64_t)lb * rows_per_block + sub;
+  if (r >= n) return;
+  float4 acc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t a = indptr[r], b = indptr[r + 1];
+  uint32_t p = a;
+  // two edges per iteration: both gathers in flight
+  for (; p + 1 < b; p += 2) {
+    const uint32_t c0 = indices[p], c1 = indices[p + 1];
+    float w0 = 1.f, w1 = 1.f;
+    if (edge_w) { w0 = edge_w[edge_perm ? edge_perm[p] : p]; w1 = edge_w[edge_perm ? edge_perm[p + 1] : p + 1]; }
+    if (col_scale) { w0 *= col_scale[c0]; w1 *= col_scale[c1]; }
+    const float *x0 = X + (int64_t)c0 * ldx, *x1 = X + (int64_t)c1 * ldx;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const uint32_t f = (l + c * LPR) * 4;
+      if (f < F) {
+        const float4 v0 = ld4(x0 + f), v1 = ld4(x1 + f);
+        acc[c].x += w0 * v0.x; acc[c].y += w0 * v0.y; acc[c].z += w0 * v0.z; acc[c].w += w0 * v0.w;
+        acc[c].x += w1 * v1.x; acc[c].y += w1 * v1.y; acc[c].z += w1 * v1.z; acc[c].w += w1 * v1.w;
+      }
+    }
+  }
+  if (p < b) {
+    const uint32_t c0 = indices[p];
+    float w0 = 1.f;
+    if (edge_w) w0 = edge_w[edge_perm ? edge_perm[p] : p];
+    if (col_scale) w0 *= col_scale[c0];
+    const float *x0 = X + (int64_t)c0 * ldx;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const uint32_t f = (l + c * LPR) * 4;
+      if (f < F) {
+        const float4 v0 = ld4(x0 + f);
+        acc[c].x += w0 * v0.x; acc[c].y += w0 * v0.y; acc[c].z += w0 * v0.z; acc[c].w += w0 * v0.w;
+      }
+    }
+  }
+  const float rs = row_scale ? row_scale[r] : 1.0f;
+  float *y = Y + (int64_t)r * ldy;
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const uint32_t f = (l + c * LPR) * 4;
+    if (f < F) st4(y + f, make_float4(acc[c].x * rs, acc[c].y * rs, acc[c].z * rs, acc[c].w * rs));
+  }
+}
+
+// scalar fallback for F % 4 != 0
+__global__ void spmm_scalar_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                   const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
+                                   const float *__restrict__ row_scale, const float *__restrict__ col_scale,
+                                   const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
+                                   uint32_t n, uint32_t F) {
+  const uint64_t total = (uint64_t)n * F;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = t / F, f = t % F;
+    float acc = 0.f;
+    for (uint32_t p = indptr[r]; p < indptr[r + 1]; p++) {
+      const uint32_t c = indices[p];
+      float w = edge_w ? edge_w[edge_perm ? edge_perm[p] : p] : 1.0f;
+      if (col_scale) w *= col_scale[c];
+      acc += w * X[(int64_t)c * ldx + f];
+    }
+    Y[r * ldy + f] = acc * (row_scale ? row_scale[r] : 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------- act + row norm
+// F_ACT of shaDow/layers.py:26-34 (prelu variants carry parameters and stay in torch)
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case 1: return x > 0.f ? x : 0.f;                       // relu
+    case 2: return x > 0.f ? x : expm1f(x);                 // elu (alpha = 1)
+    case 3: return tanhf(x);                                // tanh
+    case 4: return x > 0.f ? x : 0.2f * x;                  // leakyrelu(0.2)
+    default: return x;                                      // 0: identity ("I")
+  }
+}
+// derivative given the input x and the output h = act(x)
+__device__ __forceinline__ float act_bwd(int act, float x, float h) {
+  switch (act) {
+    case 1: return x > 0.f ? 1.f : 0.f;
+    case 2: return x > 0.f ? 1.f : h + 1.0f;                // d/dx expm1(x) = exp(x) = h + 1
+    case 3: return 1.f - h * h;
+    case 4: return x > 0.f ? 1.f : 0.2f;
+    default: return 1.f;
+  }
+}
+
+struct ActNormParams {
+  const float *Z[2];       // branch inputs [n, F]
+  int64_t ldz[2];
+  int act[2];              // activation applied to the branch input
+  const float *scale;      // [nb, F]
+  const float *offset;     // [nb, F]
+  int nb;                  // 1 or 2 branches
+  uint32_t n, F, seg;      // seg = normalisation segment (F, or the head slice for GAT)
+  float out_scale;         // 1 (GCN/SAGE: sum), 0.5 (GAT: (self+neigh)/2)
+  float eps;               // 1e-9
+  float *out; int64_t ldo; // forward output
+  // backward
+  const float *dout; int64_t lddo;
+  float *dZ[2]; int64_t lddz[2];
+  float *dscale;           // [nb, F] (+=, atomics)
+  float *doffset;          // [nb, F]
+};
+
+// sum over the lanes of one segment group (LS lanes, power of two)
+template <int LS>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+  for (int off = LS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One row per LPR lanes, one float4 per lane; LS = lanes per normalisation segment.
+// (F/4 == number of active lanes per row <= LPR; seg/4 == LS)
+template <int LPR, int LS, bool BWD>
+__global__ void act_norm_kernel(ActNormParams p) {
+  const uint32_t rows_per_block = kBlock / LPR;
+  const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t f = l * 4;
+  const bool lane_on = f < p.F;
+  const float inv_seg = 1.0f / (float)p.seg;
+  float4 gs[2], go[2];   // per-thread partial sums of dscale / doffset over its rows
+  gs[0] = gs[1] = go[0] = go[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub; r < p.n; r += (uint64_t)gridDim.x * rows_per_block) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BWD && lane_on) {
+      dy = ld4(p.dout + (int64_t)r * p.lddo + f);
+      dy.x *= p.out_scale; dy.y *= p.out_scale; dy.z *= p.out_scale; dy.w *= p.out_scale;
+    }
+    for (int b = 0; b < p.nb; b++) {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
+      if (lane_on) {
+        z = ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f);
+        h = make_float4(act_fwd(p.act[b], z.x), act_fwd(p.act[b], z.y), act_fwd(p.act[b], z.z), act_fwd(p.act[b], z.w));
+      }
+      // biased mean / variance over the segment (layers.py:334-335)
+      const float mean = seg_sum<LS>(h.x + h.y + h.z + h.w) * inv_seg;
+      float4 d = make_float4(h.x - mean, h.y - mean, h.z - mean, h.w - mean);
+      if (!lane_on) d = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float var = seg_sum<LS>(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * inv_seg + p.eps;
+      const float rstd = rsqrtf(var);
+      const float4 xh = make_float4(d.x * rstd, d.y * rstd, d.z * rstd, d.w * rstd);
+      float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), of = sc;
+      if (lane_on) { sc = ld4(p.scale + (size_t)b * p.F + f); of = ld4(p.offset + (size_t)b * p.F + f); }
+      if (!BWD) {
+        // (x - mean) * scale * rsqrt(var) + offset   (layers.py:336)
+        acc.x += d.x * sc.x * rstd + of.x; acc.y += d.y * sc.y * rstd + of.y;
+        acc.z += d.z * sc.z * rstd + of.z; acc.w += d.w * sc.w * rstd + of.w;
+      } else {
+        gs[b].x += dy.x * xh.x; gs[b].y += dy.y * xh.y; gs[b].z += dy.z * xh.z; gs[b].w += dy.w * xh.w;
+        go[b].x += dy.x; go[b].y += dy.y; go[b].z += dy.z; go[b].w += dy.w;
+        const float4 dxh = make_float4(dy.x * sc.x, dy.y * sc.y, dy.z * sc.z, dy.w * sc.w);
+        const float m1 = seg_sum<LS>(dxh.x + dxh.y + dxh.z + dxh.w) * inv_seg;
+        const float m2 = seg_sum<LS>(dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w) * inv_seg;
+        float4 dh = make_float4(rstd * (dxh.x - m1 - xh.x * m2), rstd * (dxh.y - m1 - xh.y * m2),
+                                rstd * (dxh.z - m1 - xh.z * m2), rstd * (dxh.w - m1 - xh.w * m2));
+        if (lane_on && p.dZ[b]) {
+          dh.x *= act_bwd(p.act[b], z.x, h.x); dh.y *= act_bwd(p.act[b], z.y, h.y);
+          dh.z *= act_bwd(p.act[b], z.z, h.z); dh.w *= act_bwd(p.act[b], z.w, h.w);
+          st4(p.dZ[b] + (int64_t)r * p.lddz[b] + f, dh);
+        }
+      }
+    }
+    if (!BWD && lane_on) {
+      acc.x *= p.out_scale; acc.y *= p.out_scale; acc.z *= p.out_scale; acc.w *= p.out_scale;
+      st4(p.out + (int64_t)r * p.ldo + f, acc);
+    }
+  }
+  if (BWD) {
+    // block reduction of the parameter gradients over the row sub-groups, then one atomic per feature
+    __shared__ float red[2][2][kBlock * 4];
+    for (int b = 0; b < p.nb; b++) {
+      float *rs = &red[b][0][threadIdx.x * 4], *ro = &red[b][1][threadIdx.x * 4];
+      rs[0] = gs[b].x; rs[1] = gs[b].y; rs[2] = gs[b].z; rs[3] = gs[b].w;
+      ro[0] = go[b].x; ro[1] = go[b].y; ro[2] = go[b].z; ro[3] = go[b].w;
+    }
+    __syncthreads();
+    if (sub == 0 && lane_on) {
+      for (int b = 0; b < p.nb; b++) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t q = 0; q < rows_per_block; q++) {
+          const float *rs = &red[b][0][(q * LPR + l) * 4], *ro = &red[b][1][(q * LPR + l) * 4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { s4[k] += rs[k]; o4[k] += ro[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          atomicAdd(p.dscale + (size_t)b * p.F + f + k, s4[k]);
+          atomicAdd(p.doffset + (size_t)b * p.F + f + k, o4[k]);
+        }
+      }
+    }
+  }
+}
+
+// generic fallback: one wavefront per row, any F / seg (seg divides F), scalar accesses
+template <bool BWD>
+__global__ void act_norm_generic_kernel(ActNormParams p) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float inv_seg = 1.0f / (float)p.seg;
+  for (uint64_t r = wave; r < p.n; r += nwaves) {
+    for (uint32_t s0 = 0; s0 < p.F; s0 += p.seg) {
+      for (int b = 0; b < p.nb; b++) {
+        const float *z = p.Z[b] + (int64_t)r * p.ldz[b] + s0;
+        float sum = 0.f;
+        for (uint32_t k = lane; k < p.seg; k += 64) sum += act_fwd(p.act[b], z[k]);
+        const float mean = wave_reduce_sum_f(sum) * inv_seg;
+        float sq = 0.f;
+        for (uint32_t k = lane; k < p.seg; k += 64) { const float d = act_fwd(p.act[b], z[k]) - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_reduce_sum_f(sq) * inv_seg + p.eps);
+        const float *sc = p.scale + (size_t)b * p.F + s0, *of = p.offset + (size_t)b * p.F + s0;
+        if (!BWD) {
+          float *o = p.out + (int64_t)r * p.ldo + s0;
+          for (uint32_t k = lane; k < p.seg; k += 64) {
+            const float y = ((act_fwd(p.act[b], z[k]) - mean) * sc[k] * rstd + of[k]) * p.out_scale;
+            o[k] = (b == 0) ? y : o[k] + y;
+          }
+        } else {
+          const float *dy = p.dout + (int64_t)r * p.lddo + s0;
+          float a1 = 0.f, a2 = 0.f;
+          for (uint32_t k = lane; k < p.seg; k += 64) {
+            const float xh = (act_fwd(p.act[b], z[k]) - mean) * rstd;
+            const float g = dy[k] * p.out_scale;
+            atomicAdd(p.dscale + (size_t)b * p.F + s0 + k, g * xh);
+            atomicAdd(p.doffset + (size_t)b * p.F + s0 + k, g);
+            a1 += g * sc[k]; a2 += g * sc[k] * xh;
+          }
+          const float m1 = wave_reduce_sum_f(a1) * inv_seg, m2 = wave_reduce_sum_f(a2) * inv_seg;
+          if (p.dZ[b]) {
+            float *dz = p.dZ[b] + (int64_t)r * p.lddz[b] + s0;
+            for (uint32_t k = lane; k < p.seg; k += 64) {
+              const float h = act_fwd(p.act[b], z[k]);
+              const float xh = (h - mean) * rstd;
+              dz[k] = rstd * (dy[k] * p.out_scale * sc[k] - m1 - xh * m2) * act_bwd(p.act[b], z[k], h);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+static inline uint32_t grid_for(uint64_t work_items, uint32_t per_block, uint32_t cap = 256 * 16) {
+  uint64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (uint32_t)g;
+}
+
+}  // namespace shadow
+
+using namespace shadow;
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx,
+                                  uint32_t n, uint32_t F, float *d_out, int64_t ld_out, void *stream_) {
+  if (!d_table || !d_idx || !d_out) return set_error(SG_ERR_INVALID, "sl_gather_rows_f32: null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  if (n == 0 || F == 0) return SG_OK;
+  const bool vec = (F % 4 == 0) && (ld_table % 4 == 0) && (ld_out % 4 == 0) && aligned16(d_table) && aligned16(d_out);
+  if (!vec) {
+    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(grid_for((uint64_t)n * F, kBlock)), dim3(kBlock), 0, st,
+                       d_table, ld_table, d_idx, d_out, ld_out, n, F);
+  } else if (F <= 64) {
+    hipLaunchKernelGGL(gather_rows_kernel<16>, dim3(grid_for(n, kBlock / 16)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F);
+  } else if (F <= 128) {
+    hipLaunchKernelGGL(gather_rows_kernel<32>, dim3(grid_for(n, kBlock / 32)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F);
+  } else {
+    hipLaunchKernelGGL(gather_rows_kernel<64>, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F);
+  }
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_csr_edge_rows(const uint32_t *d_indptr, uint32_t n, uint32_t e, uint32_t *d_edge_row,
+                                void *stream_) {
+  if (!d_indptr || (e && !d_edge_row)) return set_error(SG_ERR_INVALID, "sl_csr_edge_rows: null argument");
+  if (e == 0) return SG_OK;
+  hipLaunchKernelGGL(edge_rows_kernel, dim3(grid_for(e, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_, d_indptr, n, e, d_edge_row);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_csr_transpose(const uint32_t *d_indptr, const uint32_t *d_indices,
+                                const uint32_t *d_edge_row, uint32_t n, uint32_t e,
+                                uint32_t *d_t_indptr, uint32_t *d_t_indices, uint32_t *d_t_perm,
+                                uint32_t *d_work, void *stream_) {
+  if (!d_indptr || !d_t_indptr || !d_work || (e && (!d_indices || !d_edge_row || !d_t_indices || !d_t_perm)))
+    return set_error(SG_ERR_INVALID, "sl_csr_transpose: null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  // work: [0] flag, [4 .. 4+n+1) cursors, then 2*e sort scratch
+  uint32_t *flag = d_work, *cursor = d_work + 4, *tmp_idx = cursor + (size_t)n + 4, *tmp_perm = tmp_idx + e;
+  SHD_HIP(hipMemsetAsync(flag, 0, 16, st));
+  if (e) SHD_HIP(hipMemsetAsync(d_t_perm, 0xFF, (size_t)e * 4, st));
+  const uint32_t ge = grid_for(std::max<uint64_t>(e, (uint64_t)n + 1), kBlock);
+  hipLaunchKernelGGL(tr_sym_kernel, dim3(ge), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_row, n, e,
+                     d_t_indptr, d_t_indices, d_t_perm, flag);
+  if (e) {
+    hipLaunchKernelGGL(tr_check_kernel, dim3(ge), dim3(kBlock), 0, st, d_t_perm, e, flag);
+    // general path, skipped on the device when the structure was symmetric
+    hipLaunchKernelGGL(tr_zero_kernel, dim3(grid_for((uint64_t)n + 1, kBlock)), dim3(kBlock), 0, st, d_t_indptr, n + 1, flag);
+    hipLaunchKernelGGL(tr_count_kernel, dim3(ge), dim3(kBlock), 0, st, d_indices, n, e, d_t_indptr, flag);
+    hipLaunchKernelGGL(tr_scan_kernel, dim3(1), dim3(1024), 0, st, d_t_indptr, n + 1, cursor, flag);
+    hipLaunchKernelGGL(tr_fill_kernel, dim3(ge), dim3(kBlock), 0, st, d_indices, d_edge_row, e, cursor, d_t_indices, d_t_perm, flag);
+    hipLaunchKernelGGL(tr_sort_rows_kernel, dim3(grid_for((uint64_t)n * 64, kBlock)), dim3(kBlock), 0, st, d_t_indptr, n,
+                       d_t_indices, d_t_perm, tmp_idx, tmp_perm, flag);
+    hipLaunchKernelGGL(tr_copy_back_kernel, dim3(ge), dim3(kBlock), 0, st, d_t_indptr, n, e, d_t_indices, d_t_perm, tmp_idx, tmp_perm, flag);
+  }
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_degree_scales(const uint32_t *d_indptr, const float *d_edge_w, uint32_t n, int mode,
+                                float *d_row_scale, void *stream_) {
+  if (!d_indptr || !d_row_scale || mode < 0 || mode > 1) return set_error(SG_ERR_INVALID, "sl_degree_scales: bad argument");
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(degree_scales_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
+                     d_indptr, d_edge_w, n, mode, d_row_scale);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                               const uint32_t *d_edge_perm, const float *d_row_scale,
+                               const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
+                               int64_t ldy, uint32_t n, uint32_t F, void *stream_) {
+  if (!d_indptr || !d_X || !d_Y) return set_error(SG_ERR_INVALID, "sl_spmm_csr_f32: null argument");
+  if (n == 0 || F == 0) return SG_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y) && F <= 1024;
+#define SHD_SPMM(LPR, CH)                                                                          \
+  hipLaunchKernelGGL((spmm_kernel<LPR, CH>), dim3((((n + (kBlock / LPR) - 1) / (kBlock / LPR)) + 7u) & ~7u), dim3(kBlock), 0, st, \
+                     d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F)
+  if (!vec) {
+    hipLaunchKernelGGL(spmm_scalar_kernel, dim3(grid_for((uint64_t)n * F, kBlock)), dim3(kBlock), 0, st, d_indptr,
+                       d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F);
+  } else if (F <= 32) { SHD_SPMM(8, 1); }
+  else if (F <= 64) { SHD_SPMM(16, 1); }
+  else if (F <= 128) { SHD_SPMM(32, 1); }
+  else if (F <= 256) { SHD_SPMM(64, 1); }
+  else if (F <= 512) { SHD_SPMM(64, 2); }
+  else { SHD_SPMM(64, 4); }
+#undef SHD_SPMM
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+static int act_norm_launch(const ActNormParams &p, bool bwd, hipStream_t st) {
+  const uint32_t F = p.F, seg = p.seg;
+  bool vec = (F % 4 == 0) && (seg % 4 == 0) && F <= 256 && (F % seg == 0);
+  // lanes per segment must be a power of two; when seg == F and F/4 is not a
+  // power of two the idle lanes of the row group contribute zeros
+  uint32_t lpr = 1; while (lpr * 4 < F) lpr <<= 1;
+  uint32_t ls = seg == F ? lpr : seg / 4;
+  if (seg != F && (ls & (ls - 1))) vec = false;
+  for (int b = 0; b < p.nb; b++) {
+    vec = vec && aligned16(p.Z[b]) && (p.ldz[b] % 4 == 0);
+    if (bwd && p.dZ[b]) vec = vec && aligned16(p.dZ[b]) && (p.lddz[b] % 4 == 0);
+  }
+  vec = vec && aligned16(p.scale) && aligned16(p.offset);
+  if (!bwd) vec = vec && aligned16(p.out) && (p.ldo % 4 == 0);
+  else vec = vec && aligned16(p.dout) && (p.lddo % 4 == 0);
+  if (lpr < 4) vec = false;
+#define SHD_AN(LPR, LS)                                                                                    \
+  do {                                                                                                     \
+    const uint32_t g = grid_for(p.n, kBlock / LPR, 256 * 8);                                               \
+    if (bwd) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true>), dim3(g), dim3(kBlock), 0, st, p);        \
+    else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false>), dim3(g), dim3(kBlock), 0, st, p);           \
+  } while (0)
+  bool done = false;
+  if (vec) {
+    done = true;
+    if (lpr == 64 && ls == 64) SHD_AN(64, 64);
+    else if (lpr == 64 && ls == 32) SHD_AN(64, 32);
+    else if (lpr == 64 && ls == 16) SHD_AN(64, 16);
+    else if (lpr == 64 && ls == 8) SHD_AN(64, 8);
+    else if (lpr == 32 && ls == 32) SHD_AN(32, 32);
+    else if (lpr == 32 && ls == 16) SHD_AN(32, 16);
+    else if (lpr == 32 && ls == 8) SHD_AN(32, 8);
+    else if (lpr == 16 && ls == 16) SHD_AN(16, 16);
+    else if (lpr == 16 && ls == 8) SHD_AN(16, 8);
+    else if (lpr == 8 && ls == 8) SHD_AN(8, 8);
+    else if (lpr == 4 && ls == 4) SHD_AN(4, 4);
+    else done = false;
+  }
+#undef SHD_AN
+  if (!done) {
+    const uint32_t g = grid_for((uint64_t)p.n * 64, kBlock, 256 * 8);
+    if (bwd) hipLaunchKernelGGL(act_norm_generic_kernel<true>, dim3(g), dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL(act_norm_generic_kernel<false>, dim3(g), dim3(kBlock), 0, st, p);
+  }
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+static int act_norm_check(int nb, uint32_t F, uint32_t seg, const float *const *Z, const int *act) {
+  if (nb < 1 || nb > 2) return set_error(SG_ERR_INVALID, "sl_act_norm: nb must be 1 or 2");
+  if (seg == 0 || F % seg != 0) return set_error(SG_ERR_INVALID, "sl_act_norm: seg=%u must divide F=%u", seg, F);
+  for (int b = 0; b < nb; b++) {
+    if (!Z[b]) return set_error(SG_ERR_INVALID, "sl_act_norm: null branch input");
+    if (act[b] < 0 || act[b] > 4) return set_error(SG_ERR_INVALID, "sl_act_norm: unknown activation %d", act[b]);
+  }
+  return SG_OK;
+}
+
+extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
+                               const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                               uint32_t seg, float out_scale, float *d_out, int64_t ldo, void *stream_) {
+  int rc = act_norm_check(nb, F, seg, d_Z, act);
+  if (rc) return rc;
+  if (!d_scale || !d_offset || !d_out) return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: null argument");
+  if (n == 0) return SG_OK;
+  ActNormParams p;
+  memset(&p, 0, sizeof(p));
+  for (int b = 0; b < nb; b++) { p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; }
+  p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
+  p.out_scale = out_scale; p.eps = 1e-9f; p.out = d_out; p.ldo = ldo;
+  return act_norm_launch(p, false, (hipStream_t)stream_);
+}
+
+extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
+                               const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                               uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                               float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                               float *d_doffset, void *stream_) {
+  int rc = act_norm_check(nb, F, seg, d_Z, act);
+  if (rc) return rc;
+  if (!d_scale || !d_offset || !d_dout || !d_dscale || !d_doffset || !d_dZ)
+    return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  SHD_HIP(hipMemsetAsync(d_dscale, 0, (size_t)nb * F * 4, st));
+  SHD_HIP(hipMemsetAsync(d_doffset, 0, (size_t)nb * F * 4, st));
+  if (n == 0) return SG_OK;
+  ActNormParams p;
+  memset(&p, 0, sizeof(p));
+  for (int b = 0; b < nb; b++) {
+    p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b];
+    p.dZ[b] = d_dZ[b]; p.lddz[b] = lddz ? lddz[b] : 0;
+  }
+  p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
+  p.out_scale = out_scale; p.eps = 1e-9f; p.dout = d_dout; p.lddo = lddo;
+  p.dscale = d_dscale; p.doffset = d_doffset;
+  return act_norm_launch(p, true, st);
+}

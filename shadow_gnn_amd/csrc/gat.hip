@@ -1,0 +1,317 @@
+// gat.hip -- fused GAT attention for the shaDow GAT layer (shaDow/layers.py:560-626)
+// behind the sl_gat_* C ABI.  All heads are processed together; a row of
+// F = heads*D features is owned by LPR lanes (float4 each), a head slice by LS
+// = D/4 lanes, so per-head reductions are LS-lane shuffles.
+//
+// forward  (per node)  hn = act(z_neigh), u_s = att[0]·act(z_self), u_n = att[1]·hn  per head
+//          (per row)   e_ij = lrelu(u_s[i]) + lrelu(u_n[j])          layers.py:568-570
+//                      softmax over the row with max subtraction,    layers.py:572-578
+//                      numerator * drop-edge mask, denominator clamp 1e-10
+//                      N_i = sum_j p_ij hn_j / den_i                 layers.py:580-581
+// backward (per row)   t = dN_i·N_i ; d e_ij = alpha_ij (dN_i·hn_j - t) ; du_s ; dz_self (attention part)
+//          (per col)   d hn_j = sum_i alpha_ij dN_i + du_n att[1] ; dz_neigh ; datt
+// The reference runs ~10 torch/scatter kernels per head per layer for this.
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace shadow {
+
+constexpr int kGatBlock = 256;
+
+__device__ __forceinline__ float4 gld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void gst4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
+__device__ __forceinline__ float dlrelu02(float x) { return x > 0.f ? 1.f : 0.2f; }
+
+__device__ __forceinline__ float g_act_fwd(int act, float x) {
+  switch (act) {
+    case 1: return x > 0.f ? x : 0.f;
+    case 2: return x > 0.f ? x : expm1f(x);
+    case 3: return tanhf(x);
+    case 4: return x > 0.f ? x : 0.2f * x;
+    default: return x;
+  }
+}
+__device__ __forceinline__ float g_act_bwd(int act, float x, float h) {
+  switch (act) {
+    case 1: return x > 0.f ? 1.f : 0.f;
+    case 2: return x > 0.f ? 1.f : h + 1.0f;
+    case 3: return 1.f - h * h;
+    case 4: return x > 0.f ? 1.f : 0.2f;
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ float4 act4(int act, float4 z) {
+  return make_float4(g_act_fwd(act, z.x), g_act_fwd(act, z.y), g_act_fwd(act, z.z), g_act_fwd(act, z.w));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// sum over the ls lanes of a head slice (ls power of two, runtime)
+__device__ __forceinline__ float slice_sum(float v, uint32_t ls) {
+  for (uint32_t off = ls >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct GatParams {
+  const uint32_t *indptr, *indices;       // CSR of the batch
+  const uint32_t *t_indptr, *t_indices, *t_perm;
+  const float *edge_w;                    // drop-edge mask or NULL
+  const float *z_self, *z_neigh;          // [n, F] pre-activation
+  const float *att;                       // [2, H, D]
+  int act;
+  uint32_t n, F, H, D;
+  float *hn;                              // [n, F]  act(z_neigh)
+  float *u_s, *u_n;                       // [n, H]  pre-leakyrelu scores
+  float *mx, *den;                        // [n, H]
+  float *nagg;                            // [n, F]  output
+  // backward
+  const float *dnagg;                     // [n, F]
+  float *alpha, *de;                      // [e, H]
+  float *du_s;                            // [n, H]
+  float *dz_self, *dz_neigh;              // [n, F]
+  float *datt;                            // [2, H, D] (+=)
+};
+
+template <int LPR>
+__global__ void gat_node_fwd_kernel(GatParams p) {
+  const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t f = l * 4, ls = p.D / 4;
+  const bool on = f < p.F;
+  const uint32_t h = on ? f / p.D : 0;
+  float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
+  if (on) { a0 = gld4(p.att + f); a1 = gld4(p.att + p.F + f); }
+  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+    float4 hs = make_float4(0, 0, 0, 0), hn = hs;
+    if (on) {
+      hs = act4(p.act, gld4(p.z_self + r * p.F + f));
+      hn = act4(p.act, gld4(p.z_neigh + r * p.F + f));
+      gst4(p.hn + r * p.F + f, hn);
+    }
+    const float us = slice_sum(dot4(a0, hs), ls), un = slice_sum(dot4(a1, hn), ls);
+    if (on && (l % ls) == 0) { p.u_s[r * p.H + h] = us; p.u_n[r * p.H + h] = un; }
+  }
+}
+
+template <int LPR>
+__global__ void gat_row_fwd_kernel(GatParams p) {
+  const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t f = l * 4, ls = p.D / 4;
+  const bool on = f < p.F;
+  const uint32_t h = on ? f / p.D : 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+    const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
+    const float as = lrelu02(p.u_s[r * p.H + h]);
+    float mx = -INFINITY;
+    for (uint32_t q = a; q < b; q++) mx = fmaxf(mx, as + lrelu02(p.u_n[(uint64_t)p.indices[q] * p.H + h]));
+    if (a == b) mx = 0.f;
+    float den = 0.f;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (uint32_t q = a; q < b; q++) {
+      const uint32_t c = p.indices[q];
+      float pe = expf(as + lrelu02(p.u_n[(uint64_t)c * p.H + h]) - mx);
+      if (p.edge_w) pe *= p.edge_w[q];
+      den += pe;
+      if (on) {
+        const float4 v = gld4(p.hn + (uint64_t)c * p.F + f);
+        acc.x += pe * v.x; acc.y += pe * v.y; acc.z += pe * v.z; acc.w += pe * v.w;
+      }
+    }
+    den = fmaxf(den, 1e-10f);
+    const float inv = 1.0f / den;
+    if (on) {
+      gst4(p.nagg + r * p.F + f, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+      if ((l % ls) == 0) { p.mx[r * p.H + h] = mx; p.den[r * p.H + h] = den; }
+    }
+  }
+}
+
+// backward, row side: alpha / de per edge, du_s, attention part of dz_self, datt[0]
+template <int LPR>
+__global__ void gat_row_bwd_kernel(GatParams p) {
+  const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t f = l * 4, ls = p.D / 4;
+  const bool on = f < p.F;
+  const uint32_t h = on ? f / p.D : 0;
+  float4 a0 = make_float4(0, 0, 0, 0), g0 = a0;
+  if (on) a0 = gld4(p.att + f);
+  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+    const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
+    float4 dn = make_float4(0, 0, 0, 0), ng = dn;
+    if (on) { dn = gld4(p.dnagg + r * p.F + f); ng = gld4(p.nagg + r * p.F + f); }
+    const float t = slice_sum(dot4(dn, ng), ls);          // dN_i . N_i per head
+    const float usr = p.u_s[r * p.H + h];
+    const float as = lrelu02(usr);
+    const float mx = p.mx[r * p.H + h], inv = 1.0f / p.den[r * p.H + h];
+    float das = 0.f;
+    for (uint32_t q = a; q < b; q++) {
+      const uint32_t c = p.indices[q];
+      float pe = expf(as + lrelu02(p.u_n[(uint64_t)c * p.H + h]) - mx);
+      if (p.edge_w) pe *= p.edge_w[q];
+      const float alpha = pe * inv;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (on) v = gld4(p.hn + (uint64_t)c * p.F + f);
+      const float dal = slice_sum(dot4(dn, v), ls);
+      const float de = alpha * (dal - t);
+      das += de;
+      if (on && (l % ls) == 0) { p.alpha[(uint64_t)q * p.H + h] = alpha; p.de[(uint64_t)q * p.H + h] = de; }
+    }
+    const float dus = das * dlrelu02(usr);
+    if (on) {
+      if ((l % ls) == 0) p.du_s[r * p.H + h] = dus;
+      const float4 z = gld4(p.z_self + r * p.F + f);
+      const float4 hs = act4(p.act, z);
+      gst4(p.dz_self + r * p.F + f,
+           make_float4(dus * a0.x * g_act_bwd(p.act, z.x, hs.x), dus * a0.y * g_act_bwd(p.act, z.y, hs.y),
+                       dus * a0.z * g_act_bwd(p.act, z.z, hs.z), dus * a0.w * g_act_bwd(p.act, z.w, hs.w)));
+      g0.x += dus * hs.x; g0.y += dus * hs.y; g0.z += dus * hs.z; g0.w += dus * hs.w;
+    }
+  }
+  // datt[0] += sum over this block's rows
+  __shared__ float red[kGatBlock * 4];
+  red[threadIdx.x * 4 + 0] = g0.x; red[threadIdx.x * 4 + 1] = g0.y; red[threadIdx.x * 4 + 2] = g0.z; red[threadIdx.x * 4 + 3] = g0.w;
+  __syncthreads();
+  if (sub == 0 && on) {
+    float s4[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < rpb; q++)
+      for (int k = 0; k < 4; k++) s4[k] += red[(q * LPR + l) * 4 + k];
+    for (int k = 0; k < 4; k++) atomicAdd(p.datt + f + k, s4[k]);
+  }
+}
+
+// backward, column side (transposed CSR): d hn, du_n, dz_neigh, datt[1]
+template <int LPR>
+__global__ void gat_col_bwd_kernel(GatParams p) {
+  const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t f = l * 4, ls = p.D / 4;
+  const bool on = f < p.F;
+  const uint32_t h = on ? f / p.D : 0;
+  float4 a1 = make_float4(0, 0, 0, 0), g1 = a1;
+  if (on) a1 = gld4(p.att + p.F + f);
+  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+    const uint32_t a = p.t_indptr[r], b = p.t_indptr[r + 1];
+    float4 acc = make_float4(0, 0, 0, 0);
+    float dan = 0.f;
+    for (uint32_t q = a; q < b; q++) {
+      const uint32_t src = p.t_indices[q], pe = p.t_perm[q];
+      const float alpha = p.alpha[(uint64_t)pe * p.H + h];
+      dan += p.de[(uint64_t)pe * p.H + h];
+      if (on) {
+        const float4 v = gld4(p.dnagg + (uint64_t)src * p.F + f);
+        acc.x += alpha * v.x; acc.y += alpha * v.y; acc.z += alpha * v.z; acc.w += alpha * v.w;
+      }
+    }
+    if (on) {
+      const float dun = dan * dlrelu02(p.u_n[r * p.H + h]);
+      const float4 z = gld4(p.z_neigh + r * p.F + f);
+      const float4 hn = gld4(p.hn + r * p.F + f);
+      acc.x += dun * a1.x; acc.y += dun * a1.y; acc.z += dun * a1.z; acc.w += dun * a1.w;
+      gst4(p.dz_neigh + r * p.F + f,
+           make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
+                       acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w)));
+      g1.x += dun * hn.x; g1.y += dun * hn.y; g1.z += dun * hn.z; g1.w += dun * hn.w;
+    }
+  }
+  __shared__ float red[kGatBlock * 4];
+  red[threadIdx.x * 4 + 0] = g1.x; red[threadIdx.x * 4 + 1] = g1.y; red[threadIdx.x * 4 + 2] = g1.z; red[threadIdx.x * 4 + 3] = g1.w;
+  __syncthreads();
+  if (sub == 0 && on) {
+    float s4[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < rpb; q++)
+      for (int k = 0; k < 4; k++) s4[k] += red[(q * LPR + l) * 4 + k];
+    for (int k = 0; k < 4; k++) atomicAdd(p.datt + p.F + f + k, s4[k]);
+  }
+}
+
+static uint32_t gat_grid(uint32_t n, uint32_t lpr) {
+  const uint32_t rpb = kGatBlock / lpr;
+  uint64_t g = ((uint64_t)n + rpb - 1) / rpb;
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, 256 * 8));
+}
+
+static int gat_check(uint32_t F, uint32_t H, uint32_t *lpr_out) {
+  if (H == 0 || F == 0 || F % H != 0) return set_error(SG_ERR_INVALID, "sl_gat: F=%u not divisible by heads=%u", F, H);
+  const uint32_t D = F / H;
+  if (D % 4 != 0 || ((D / 4) & (D / 4 - 1)) != 0 || F > 256)
+    return set_error(SG_ERR_INVALID, "sl_gat: head slice D=%u must be 4*2^k and F=%u <= 256", D, F);
+  uint32_t lpr = 4;
+  while (lpr * 4 < F) lpr <<= 1;
+  if (D / 4 > lpr) return set_error(SG_ERR_INVALID, "sl_gat: bad geometry");
+  *lpr_out = lpr;
+  return SG_OK;
+}
+
+#define SHD_GAT_LAUNCH(KERN, lpr, grid, st, p)                                            \
+  do {                                                                                    \
+    switch (lpr) {                                                                        \
+      case 4: hipLaunchKernelGGL(KERN<4>, dim3(grid), dim3(kGatBlock), 0, st, p); break;  \
+      case 8: hipLaunchKernelGGL(KERN<8>, dim3(grid), dim3(kGatBlock), 0, st, p); break;  \
+      case 16: hipLaunchKernelGGL(KERN<16>, dim3(grid), dim3(kGatBlock), 0, st, p); break; \
+      case 32: hipLaunchKernelGGL(KERN<32>, dim3(grid), dim3(kGatBlock), 0, st, p); break; \
+      default: hipLaunchKernelGGL(KERN<64>, dim3(grid), dim3(kGatBlock), 0, st, p); break; \
+    }                                                                                     \
+  } while (0)
+
+}  // namespace shadow
+
+using namespace shadow;
+
+extern "C" int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                          const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
+                          uint32_t n, uint32_t F, uint32_t heads, float *d_hn, float *d_u_s,
+                          float *d_u_n, float *d_mx, float *d_den, float *d_nagg, void *stream_) {
+  if (!d_indptr || !d_z_self || !d_z_neigh || !d_att || !d_hn || !d_u_s || !d_u_n || !d_mx || !d_den || !d_nagg)
+    return set_error(SG_ERR_INVALID, "sl_gat_fwd: null argument");
+  if (act < 0 || act > 4) return set_error(SG_ERR_INVALID, "sl_gat_fwd: unknown activation %d", act);
+  uint32_t lpr;
+  int rc = gat_check(F, heads, &lpr);
+  if (rc) return rc;
+  if (n == 0) return SG_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  GatParams p;
+  memset(&p, 0, sizeof(p));
+  p.indptr = d_indptr; p.indices = d_indices; p.edge_w = d_edge_w; p.z_self = d_z_self; p.z_neigh = d_z_neigh;
+  p.att = d_att; p.act = act; p.n = n; p.F = F; p.H = heads; p.D = F / heads;
+  p.hn = d_hn; p.u_s = d_u_s; p.u_n = d_u_n; p.mx = d_mx; p.den = d_den; p.nagg = d_nagg;
+  const uint32_t g = gat_grid(n, lpr);
+  SHD_GAT_LAUNCH(gat_node_fwd_kernel, lpr, g, st, p);
+  SHD_GAT_LAUNCH(gat_row_fwd_kernel, lpr, g, st, p);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
+                          const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
+                          const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
+                          uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
+                          const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
+                          const float *d_nagg, const float *d_dnagg, float *d_work, float *d_dz_self,
+                          float *d_dz_neigh, float *d_datt, void *stream_) {
+  if (!d_indptr || !d_t_indptr || !d_z_self || !d_z_neigh || !d_att || !d_hn || !d_u_s || !d_u_n || !d_mx ||
+      !d_den || !d_nagg || !d_dnagg || !d_work || !d_dz_self || !d_dz_neigh || !d_datt)
+    return set_error(SG_ERR_INVALID, "sl_gat_bwd: null argument");
+  uint32_t lpr;
+  int rc = gat_check(F, heads, &lpr);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  SHD_HIP(hipMemsetAsync(d_datt, 0, (size_t)2 * F * 4, st));
+  if (n == 0) return SG_OK;
+  GatParams p;
+  memset(&p, 0, sizeof(p));
+  p.indptr = d_indptr; p.indices = d_indices; p.t_indptr = d_t_indptr; p.t_indices = d_t_indices; p.t_perm = d_t_perm;
+  p.edge_w = d_edge_w; p.z_self = d_z_self; p.z_neigh = d_z_neigh; p.att = d_att; p.act = act;
+  p.n = n; p.F = F; p.H = heads; p.D = F / heads;
+  p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
+  p.mx = const_cast<float *>(d_mx); p.den = const_cast<float *>(d_den); p.nagg = const_cast<float *>(d_nagg);
+  p.dnagg = d_dnagg;
+  // work: alpha[e*H], de[e*H], du_s[n*H]
+  p.alpha = d_work; p.de = d_work + (size_t)e * heads; p.du_s = p.de + (size_t)e * heads;
+  p.dz_self = d_dz_self; p.dz_neigh = d_dz_neigh; p.datt = d_datt;
+  const uint32_t g = gat_grid(n, lpr);
+  SHD_GAT_LAUNCH(gat_row_bwd_kernel, lpr, g, st, p);
+  SHD_GAT_LAUNCH(gat_col_bwd_kernel, lpr, g, st, p);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}

@@ -1,0 +1,312 @@
+"""GNN layers with the reference's plugin protocol (shaDow/layers.py), computing
+on the MI355X through libshadow_hip.so.
+
+Same class names, constructor arguments, parameter names/shapes (the checkpoint
+contract: f_lin, f_lin_self, f_lin_neigh, f_lin.{0,1}, attention, scale, offset)
+and the same layer protocol as the reference:
+
+    forward((feat_in, adj, is_normed, dropedge), sizes_subg)
+        -> (feat_out, adj_norm, True, 0.)
+
+Layer 0 receives the batch adjacency un-normalised -- a scipy CSR (as in the
+reference) or a device-resident ``ops.DeviceCSR`` (fast path) -- normalises it
+once, and threads the ``ops.NormAdj`` through the later layers.
+
+Aggregation (SpMM), activation + feature normalisation and the GAT edge softmax
+are hand-written HIP kernels; the dense feature x weight products stay on
+rocBLAS / hipBLASLt through ``torch.nn.functional.linear``.
+"""
+from collections import namedtuple
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+Dims_X = namedtuple('Dims_X', ['num_nodes', 'num_feats'])
+Dims_adj = namedtuple('Dims_adj', ['num_nodes', 'num_edges'])
+
+# activations of the reference's F_ACT table (shaDow/layers.py:26-34) that the
+# fused kernels implement; 'prelu'/'prelu+' carry parameters and are not offered
+SUPPORTED_ACT = ("relu", "I", "elu", "tanh", "leakyrelu")
+
+
+def _check_act(act):
+    if act not in SUPPORTED_ACT:
+        raise NotImplementedError(f"activation {act!r} is not provided by the HIP layers {SUPPORTED_ACT}")
+    return act
+
+
+def _as_device_csr(adj, device):
+    if isinstance(adj, ops.DeviceCSR):
+        return adj
+    if isinstance(adj, sp.csr_matrix):
+        return ops.DeviceCSR.from_scipy(adj, device)
+    raise TypeError(f"layer 0 expects a scipy CSR or a DeviceCSR adjacency, got {type(adj)}")
+
+
+class EnsembleDummy(nn.Module):
+    """used when there is only one branch of subgraph (shaDow/layers.py:42-53)"""
+    def __init__(self, dim_in=0, dim_out=0, **kwargs):
+        super().__init__()
+
+    def forward(self, Xi):
+        assert len(Xi) == 1, "ONLY USE DUMMY ENSEMBLER WITH ONE BRANCH!"
+        return Xi[0]
+
+    def complexity(self, dims):
+        assert len(dims) == 1, "ONLY USE DUMMY ENSEMBLER WITH ONE BRANCH!"
+        return dims[0], 0
+
+
+class shaDowLayer(nn.Module):
+    """Parent of the message-passing layers (shaDow/layers.py:299-373)."""
+    def __init__(self, dim_in, dim_out, dropout=0.0, act='relu', norm='norm_feat', **kwargs):
+        super().__init__()
+        self.dropout = dropout
+        self.dim_in, self.dim_out = dim_in, dim_out
+        self.act_name = _check_act(act)
+        self.f_dropout = nn.Dropout(p=self.dropout)
+        if norm not in ('norm_feat', 'none'):
+            raise NotImplementedError("only norm in {'norm_feat', 'none'} (the reference's pairnorm path is unfinished, layers.py:358)")
+        self.norm = norm
+        self.norm_dim = (1, dim_out) if 'norm_dim' not in kwargs else kwargs['norm_dim']
+        if norm == 'norm_feat':
+            self.offset = nn.Parameter(torch.zeros(self.norm_dim))
+            self.scale = nn.Parameter(torch.ones(self.norm_dim))
+
+    def spmm(self, adj, X):
+        return ops.spmm(adj, X)
+
+    def f_act_norm(self, Zs, acts, seg=None, out_scale=1.0):
+        """sum_b norm_b(act_b(Z_b)) * out_scale -- the reference's act + f_norm + add
+        sequence (layers.py:435, :476-483, :620-625) in one kernel."""
+        if self.norm == 'norm_feat':
+            return ops.act_norm(Zs, acts, self.scale, self.offset, seg=seg, out_scale=out_scale)
+        out = None
+        for z, a in zip(Zs, acts):
+            h = _torch_act(a, z)
+            out = h if out is None else out + h
+        return out * out_scale
+
+
+def _torch_act(act, x):
+    if act == 'I':
+        return x
+    if act == 'relu':
+        return F.relu(x)
+    if act == 'elu':
+        return F.elu(x)
+    if act == 'tanh':
+        return torch.tanh(x)
+    if act == 'leakyrelu':
+        return F.leaky_relu(x, 0.2)
+    raise NotImplementedError(act)
+
+
+class MLP(shaDowLayer):
+    """shaDow/layers.py:376-400"""
+    def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', **kwargs):
+        assert norm in ['norm_feat', 'none']
+        kwargs['norm_dim'] = (1, dim_out)
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
+        self.f_lin = nn.Linear(dim_in, dim_out)
+
+    def forward(self, feat_in):
+        feat_in = self.f_dropout(feat_in)
+        return self.f_act_norm([self.f_lin(feat_in)], [self.act_name])
+
+    def complexity(self, dims_x):
+        assert dims_x.num_feats == self.f_lin.weight.shape[1]
+        ops_ = dims_x.num_nodes * int(np.prod(self.f_lin.weight.shape))
+        return Dims_X(dims_x.num_nodes, self.f_lin.weight.shape[0]), ops_
+
+
+class GCN(shaDowLayer):
+    """shaDow/layers.py:417-444 -- aggregate first, then Linear."""
+    def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', **kwargs):
+        kwargs['norm_dim'] = (1, dim_out)
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
+        self.f_lin = nn.Linear(dim_in, dim_out, bias=True)
+
+    def forward(self, inputs, sizes_subg):
+        feat_in, adj, is_normed, dropedge = inputs
+        feat_in = self.f_dropout(feat_in)
+        if not is_normed and adj is not None:
+            # self-edges are already added by the sampler (shaDow/utils.py:126-131)
+            adj_norm = ops.adj_norm_sym(_as_device_csr(adj, feat_in.device), dropedge=dropedge)
+        else:
+            assert adj is None or isinstance(adj, ops.NormAdj)
+            adj_norm = adj
+        feat_aggr = self.spmm(adj_norm, feat_in)
+        feat_trans = self.f_lin(feat_aggr)
+        feat_out = self.f_act_norm([feat_trans], [self.act_name])
+        return feat_out, adj_norm, True, 0.
+
+    def complexity(self, dims_x, dims_adj):
+        ops_ = dims_adj.num_edges * dims_x.num_feats + dims_x.num_nodes * int(np.prod(self.f_lin.weight.shape))
+        return (Dims_X(dims_x.num_nodes, self.f_lin.weight.shape[0]),
+                Dims_adj(dims_adj.num_nodes, dims_adj.num_edges)), ops_
+
+
+class GraphSAGE(shaDowLayer):
+    """shaDow/layers.py:447-494"""
+    def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', **kwargs):
+        kwargs['norm_dim'] = (2, dim_out)   # 2 for self + neigh
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
+        self.f_lin_self = nn.Linear(dim_in, dim_out)
+        self.f_lin_neigh = nn.Linear(dim_in, dim_out)
+
+    def forward(self, inputs, sizes_subg):
+        feat_in, adj, is_normed, dropedge = inputs
+        if not is_normed and adj is not None:
+            adj_norm = ops.adj_norm_rw(_as_device_csr(adj, feat_in.device), dropedge=dropedge)
+        else:
+            assert adj is None or isinstance(adj, ops.NormAdj)
+            adj_norm = adj
+        feat_in = self.f_dropout(feat_in)
+        feat_neigh = self.spmm(adj_norm, feat_in)
+        feat_out = self.f_act_norm(
+            [self.f_lin_self(feat_in), self.f_lin_neigh(feat_neigh)], [self.act_name, self.act_name])
+        return feat_out, adj_norm, True, 0.
+
+    def complexity(self, dims_x, dims_adj):
+        assert dims_x.num_nodes == dims_adj.num_nodes
+        ops_ = dims_x.num_nodes * int(np.prod(self.f_lin_self.weight.shape)) \
+            + dims_adj.num_edges * dims_x.num_feats \
+            + dims_x.num_nodes * int(np.prod(self.f_lin_neigh.weight.shape))
+        return (Dims_X(dims_x.num_nodes, self.f_lin_self.weight.shape[0]),
+                Dims_adj(dims_adj.num_nodes, dims_adj.num_edges)), ops_
+
+
+class ResPool(nn.Module):
+    """Residue + pooling head (shaDow/layers.py:57-233).  'center' pooling is an
+    index select; max/mean/sum pooling uses segment reductions over the subgraph
+    offsets.  Sort pooling (PyG global_sort_pool) is not provided."""
+    def __init__(self, dim_in, dim_out, num_layers, type_res, type_pool, dropout, act,
+                 args_pool=None, prediction_task='node'):
+        super().__init__()
+        self.dim_out = dim_out
+        self.type_pool = type_pool
+        self.type_res = type_res
+        self.prediction_task = prediction_task
+        self.act_name = _check_act(act)
+        if type_pool == 'center':
+            if type_res == 'none':
+                if self.prediction_task == 'node':
+                    self.dim_in = self.dim_out = 0
+                else:
+                    self.dim_in = dim_in
+            elif type_res in ['cat', 'concat']:
+                self.dim_in = num_layers * dim_in
+            else:
+                self.dim_in = dim_in
+        elif type_pool in ('max', 'mean', 'sum'):
+            self.dim_in = 2 * dim_in * num_layers if type_res in ['cat', 'concat'] else 2 * dim_in
+        else:
+            raise NotImplementedError(f"pooling {type_pool!r} is not provided (sort pooling needs PyG)")
+        if self.dim_in > 0 and self.dim_out > 0:
+            _f_lin = nn.Linear(self.dim_in, self.dim_out, bias=True)
+            _f_dropout = nn.Dropout(p=dropout)
+            # same child indices as the reference's nn.Sequential(dropout, lin, act): "nn.1" is the Linear
+            self.nn = nn.Sequential(_f_dropout, _f_lin, nn.Identity())
+            self.offset = nn.Parameter(torch.zeros(self.dim_out))
+            self.scale = nn.Parameter(torch.ones(self.dim_out))
+
+    def f_residue(self, feat_l):
+        if self.type_res in ['cat', 'concat']:
+            return torch.cat(feat_l, dim=1)
+        if self.type_res == 'sum':
+            return torch.stack(feat_l, dim=0).sum(dim=0)
+        if self.type_res == 'max':
+            return torch.max(torch.stack(feat_l, dim=0), dim=0).values
+        raise NotImplementedError
+
+    def aggr_target_emb(self, feat_src_dst):
+        if self.prediction_task == 'node':
+            return feat_src_dst
+        b, f = feat_src_dst.shape
+        feat_ret = feat_src_dst.reshape(b // 2, 2, f)
+        return feat_ret[:, 0] * feat_ret[:, 1]
+
+    def _pool(self, feat, sizes_subg):
+        offsets = torch.cumsum(sizes_subg, dim=0) - sizes_subg
+        idx = torch.arange(feat.shape[0], device=feat.device)
+        return F.embedding_bag(idx, feat, offsets.long(), mode=self.type_pool)   # layers.py:175,180
+
+    def forward(self, feats_in_l, idx_targets, sizes_subg):
+        idx_targets = torch.as_tensor(idx_targets, device=feats_in_l[-1].device).long()
+        if self.type_pool == 'center':
+            if self.type_res == 'none':
+                feat_in = feats_in_l[-1][idx_targets]
+                if self.prediction_task == 'node':
+                    return feat_in
+            else:
+                feat_in = self.f_residue([f[idx_targets] for f in feats_in_l])
+            feat_in = self.aggr_target_emb(feat_in)
+        else:
+            if self.type_res == 'none':
+                feat_pool = self._pool(feats_in_l[-1], sizes_subg)
+                feat_root = feats_in_l[-1][idx_targets]
+            else:
+                feat_pool = self.f_residue([self._pool(f, sizes_subg) for f in feats_in_l])
+                feat_root = self.f_residue([f[idx_targets] for f in feats_in_l])
+            feat_in = torch.cat([self.aggr_target_emb(feat_root), feat_pool], dim=1)
+        z = self.nn(feat_in)                                   # dropout -> Linear (act fused below)
+        return ops.act_norm([z], [self.act_name], self.scale, self.offset)   # layers.py:114-118,199
+
+
+class GAT(shaDowLayer):
+    """shaDow/layers.py:539-645.  Attention scores, edge softmax and the weighted
+    aggregation of all heads run in fused HIP kernels (ops_gat)."""
+    def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', mulhead=1, **kwargs):
+        self.mulhead = mulhead
+        assert dim_out % self.mulhead == 0, "invalid output dimension: need to be divisible by mulhead"
+        self.dim_slice = int(dim_out / self.mulhead)
+        kwargs['norm_dim'] = (2, self.mulhead, self.dim_slice)
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
+        self.f_lin = nn.ModuleList(nn.Linear(dim_in, dim_out, bias=True) for i in range(2))   # self + neigh
+        self.attention = nn.Parameter(torch.ones(2, self.mulhead, self.dim_slice))
+        nn.init.xavier_uniform_(self.attention)
+
+    def _adj_norm(self, adj, is_normed, device, dropedge=0):
+        if not is_normed:
+            csr = _as_device_csr(adj, device)
+            # not normalised (data = 1,1,1...), only edge dropout (layers.py:590-596)
+            return ops.NormAdj(csr, edge_w=ops.dropedge_mask(csr, dropedge))
+        assert isinstance(adj, ops.NormAdj)
+        return adj
+
+    def forward(self, inputs, sizes_subg):
+        from . import ops_gat
+        feat_in, adj, is_normed, dropedge = inputs
+        adj_norm = self._adj_norm(adj, is_normed, feat_in.device, dropedge=dropedge)
+        feat_in = self.f_dropout(feat_in)
+        z_self = self.f_lin[0](feat_in)
+        z_neigh = self.f_lin[1](feat_in)
+        # neigh branch: act -> per-head attention aggregate; both branches normalised per head slice
+        feat_neigh = ops_gat.gat_aggregate(adj_norm, z_self, z_neigh, self.attention, self.act_name,
+                                           self.mulhead)
+        if self.norm == 'norm_feat':
+            # reference order: f_norm([neigh, self]) -> scale[0]=neigh, scale[1]=self (layers.py:620-622)
+            feat_out = ops.act_norm([feat_neigh, z_self], ['I', self.act_name], self.scale, self.offset,
+                                    seg=self.dim_slice, out_scale=0.5)
+        else:
+            feat_out = (feat_neigh + _torch_act(self.act_name, z_self)) / 2
+        return feat_out, adj_norm, True, 0.
+
+    def complexity(self, dims_X, dims_adj):
+        ops_ = 0
+        ops_ += dims_X.num_nodes * int(np.prod(self.f_lin[0].weight.shape))
+        ops_ += dims_X.num_nodes * int(np.prod(self.f_lin[1].weight.shape))
+        ops_ += dims_X.num_nodes * self.f_lin[0].weight.shape[0]
+        ops_ += dims_X.num_nodes * self.f_lin[1].weight.shape[0]
+        for _h in range(self.mulhead):
+            ops_ += dims_adj.num_edges * 2
+            ops_ += dims_adj.num_edges * 20
+        ops_ += dims_adj.num_edges * self.f_lin[1].weight.shape[0]
+        return (Dims_X(dims_X.num_nodes, self.f_lin[1].weight.shape[0]),
+                Dims_adj(dims_adj.num_nodes, dims_adj.num_edges)), ops_

@@ -1,0 +1,207 @@
+"""Minibatch orchestration with the reference's API surface
+(shaDow/minibatch.py:94-495): ``OneBatchSubgraph`` record and
+``MinibatchShallowExtractor`` with epoch_start_reset / shuffle_entity /
+one_batch / is_end_epoch / epoch_end_reset.
+
+Fast path: one sampler call returns the whole batch in block-diagonal form in
+HBM (no host pool of per-subgraph objects, no scipy, no host<->device copies):
+features are gathered by a HIP kernel from the device-resident feature matrix,
+the adjacency is an ``ops.DeviceCSR`` that layer 0 recognises.  The next batch
+is sampled on a side stream while the current one trains."""
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .sampler import DeviceBatch, HipSampler, SamplerConfig
+
+TRAIN, VALID, TEST = 0, 1, 2          # graph_engine.frontend mode constants
+STR2MODE = {"train": TRAIN, "valid": VALID, "test": TEST}
+MODE2STR = {TRAIN: "train", VALID: "valid", TEST: "test"}
+
+
+@dataclass
+class OneBatchSubgraph:
+    """data returned by one minibatch (shaDow/minibatch.py:94-140)"""
+    adj_ens: List[Any]
+    feat_ens: List[torch.Tensor]
+    label: torch.Tensor
+    size_subg_ens: Optional[torch.Tensor]
+    target_ens: List[Any]
+    feat_aug_ens: Optional[List[Dict[str, Any]]]
+    idx_raw: Optional[List[Any]] = None
+
+    @property
+    def num_ens(self):
+        return len(self.adj_ens)
+
+    @property
+    def batch_size(self):
+        return int(self.target_ens[0].numel() if torch.is_tensor(self.target_ens[0]) else self.target_ens[0].size)
+
+    def __post_init__(self):
+        assert len(self.feat_ens) == self.num_ens and len(self.target_ens) == self.num_ens
+        if self.size_subg_ens is not None:
+            assert self.size_subg_ens.shape[0] == self.num_ens
+        if self.feat_aug_ens is not None:
+            assert len(self.feat_aug_ens) == self.num_ens
+
+    def pop_idx_raw(self):
+        ret, self.idx_raw = self.idx_raw, None
+        return ret
+
+    def to_dict(self, keys=None):
+        if keys is None:
+            keys = self.__dataclass_fields__
+        return {k: getattr(self, k) for k in keys}
+
+
+def hop2onehot(hop: torch.Tensor, dim_1hot_vec: int) -> torch.Tensor:
+    """EntityEncoding.hop2onehot_vec (frontend/graph.py:134-147) on the device:
+    hop h in [0, dim-2] -> column h+1, unreachable (0xFFFFFFFF, i.e. -1 as int32)
+    and hops >= 255 -> column 0, other hops -> all-zero row."""
+    h = hop.long()
+    n = h.numel()
+    col = torch.where((h >= 0) & (h <= dim_1hot_vec - 2), h + 1, torch.full_like(h, -1))
+    col = torch.where((h < 0) | (h >= 255), torch.zeros_like(h), col)
+    out = torch.zeros(n, dim_1hot_vec, dtype=torch.float32, device=hop.device)
+    valid = col >= 0
+    out[torch.nonzero(valid).squeeze(1), col[valid]] = 1.0
+    return out
+
+
+class MinibatchShallowExtractor:
+    """Node-task minibatch loop over a device-resident graph (fast path of
+    shaDow/minibatch.py:143-495).
+
+    adjs:        {mode: (indptr, indices)} uint32 CSR per mode (numpy, or int32 torch tensors on the device)
+    entity_set:  {mode: array of root node ids}
+    sampler_config: dict like one entry of the reference's sampler section, e.g.
+                 {"method": "khop", "depth": 2, "budget": 20, "add_self_edge": False}
+    """
+    def __init__(self, adjs, entity_set, sampler_config: Dict[str, Any], aug_feats, feat_full: torch.Tensor,
+                 label_full: torch.Tensor, batch_size: int, device, seed_cpp: int = -1,
+                 rank: int = 0, world_size: int = 1, prefetch: bool = True):
+        self.device = torch.device(device)
+        self.aug_feats = set(aug_feats)
+        self.raw_entity_set = {m: np.asarray(v) for m, v in entity_set.items()}
+        self.feat_full = feat_full.to(self.device)
+        self.label_full = label_full.to(self.device)
+        self.batch_size_global = int(batch_size)
+        self.rank, self.world_size = rank, world_size
+        assert batch_size % world_size == 0, "global batch must divide evenly over the ranks"
+        self.batch_size = {m: batch_size // world_size for m in (TRAIN, VALID, TEST)}
+        cfg = dict(sampler_config)
+        method = cfg.pop("method")
+        self.sampler_cfg = SamplerConfig(
+            method=method, num_roots=1, depth=int(cfg.get("depth", 2)), budget=int(cfg.get("budget", -1)),
+            k=int(cfg.get("k", 0)), threshold=float(cfg.get("threshold", 0.0)),
+            add_self_edge=bool(cfg.get("add_self_edge", False)),
+            aug=tuple(sorted(self.aug_feats & {"hops", "pprs", "drnls"})))
+        self.graph_sampler = {}
+        self._adjs = adjs
+        self._seed = seed_cpp
+        self.entity_epoch = {m: None for m in (TRAIN, VALID, TEST)}
+        self.label_epoch = {m: None for m in (TRAIN, VALID, TEST)}
+        self.idx_entity_evaluated = {m: 0 for m in (TRAIN, VALID, TEST)}
+        self.end_epoch = {m: False for m in (TRAIN, VALID, TEST)}
+        self.batch_num = -1
+        self.dim_1hot_hop, self.dim_1hot_ppr, self.dim_1hot_drnl = 5 + 2, 1, 25 + 1   # minibatch.py:246-248
+        self.prefetch = prefetch
+        self._side = torch.cuda.Stream(device=self.device) if prefetch else None
+        self._inflight = {}
+
+    # ------------------------------------------------------------------ API
+    def get_aug_dim(self, aug_type):
+        return getattr(self, f'dim_1hot_{aug_type[:-1]}')
+
+    def epoch_start_reset(self, epoch, mode):
+        self.batch_num = -1
+        if mode not in self.graph_sampler:
+            ip, ix = self._adjs[mode]
+            self.graph_sampler[mode] = HipSampler(ip, ix, device=self.device, seed=self._seed)
+
+    def shuffle_entity(self, mode, perm=None):
+        """YOU MUST CALL THIS BEFORE STARTING ANY EPOCH (minibatch.py:269-280).  Every
+        rank draws the same permutation and keeps its own slice of each global batch."""
+        ent = self.raw_entity_set[mode]
+        if perm is None:
+            perm = np.random.permutation(ent.size)
+        ent = ent[perm]
+        B, G, r = self.batch_size_global, self.world_size, self.rank
+        nfull = (ent.size // B) * B
+        body = ent[:nfull].reshape(-1, G, B // G)[:, r, :].reshape(-1)
+        tail = ent[nfull:]
+        per = -(-tail.size // G)                      # ceil: the last, smaller global batch
+        mine = np.concatenate([body, tail[r * per:(r + 1) * per]])
+        self.entity_epoch[mode] = mine
+        self.label_epoch[mode] = self.label_full[torch.as_tensor(mine.astype(np.int64), device=self.device)]
+        self.graph_sampler[mode].shuffle_targets(mine.astype(np.uint32))
+        self.idx_entity_evaluated[mode] = 0
+        self.end_epoch[mode] = False
+        self._inflight.pop(mode, None)
+
+    def is_end_epoch(self, mode):
+        return self.end_epoch[mode]
+
+    def epoch_end_reset(self, mode):
+        self.end_epoch[mode] = False
+
+    def drop_full_graph_info(self, mode):
+        self.graph_sampler[mode].drop_full_graph_info()
+
+    def disable_cache(self, mode):
+        pass      # the fast path re-samples every epoch (no subgraph cache yet)
+
+    # ------------------------------------------------------------- batching
+    def _launch(self, mode):
+        hs = self.graph_sampler[mode]
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                hs.sample_async(self.sampler_cfg, self.batch_size[mode])
+        else:
+            hs.sample_async(self.sampler_cfg, self.batch_size[mode])
+        self._inflight[mode] = True
+
+    def _collect(self, mode) -> DeviceBatch:
+        hs = self.graph_sampler[mode]
+        if self._side is not None:
+            with torch.cuda.stream(self._side):
+                b = hs.finish()
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        else:
+            b = hs.finish()
+        self._inflight.pop(mode, None)
+        return b
+
+    def one_batch(self, mode=TRAIN, ret_raw_idx=False) -> OneBatchSubgraph:
+        remaining = self.entity_epoch[mode].shape[0] - self.idx_entity_evaluated[mode]
+        batch_size_ = min(remaining, self.batch_size[mode])
+        if mode not in self._inflight:
+            self._launch(mode)
+        subgs = self._collect(mode)
+        assert subgs.num_subgraphs == batch_size_, (subgs.num_subgraphs, batch_size_)
+        i0 = self.idx_entity_evaluated[mode]
+        self.idx_entity_evaluated[mode] += batch_size_
+        self.batch_num += 1
+        if self.idx_entity_evaluated[mode] >= self.entity_epoch[mode].shape[0]:
+            self.idx_entity_evaluated[mode] = 0
+            self.end_epoch[mode] = True
+            assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
+        elif self.prefetch:
+            self._launch(mode)        # overlap the next sampler call with this batch's training
+        adj = ops.DeviceCSR(subgs.indptr, subgs.indices)
+        feat = ops.gather_rows(self.feat_full, subgs.node)           # minibatch.py:469
+        label = self.label_epoch[mode][i0:i0 + batch_size_]
+        feat_aug = {}
+        if "hops" in self.aug_feats:
+            feat_aug["hops"] = hop2onehot(subgs.hop, self.dim_1hot_hop)
+        size_subg = subgs.size_subg.unsqueeze(0)
+        ret = OneBatchSubgraph([adj], [feat], label, size_subg, [subgs.target], [feat_aug])
+        ret.device_batch = subgs
+        if ret_raw_idx:
+            ret.idx_raw = [subgs.node]
+        return ret

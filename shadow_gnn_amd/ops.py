@@ -1,0 +1,271 @@
+"""torch front-end of the sl_* layer kernels (libshadow_hip.so).
+
+``DeviceCSR`` is the device-resident stand-in for the scipy CSR matrix the
+reference hands to layer 0 (shaDow/minibatch.py:468, shaDow/layers.py:427,467);
+``NormAdj`` is what layer 0 returns as ``adj_norm`` and later layers receive
+(the reference threads a torch sparse COO tensor, layers.py:436,484,626).
+
+Every op launches hand-written HIP kernels through the C ABI on the current
+torch stream.  No CPU / torch fallback: tensors must live on a ROCm device.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT_CODE = {"I": 0, "relu": 1, "elu": 2, "tanh": 3, "leakyrelu": 4}
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("shadow_gnn_amd ops need tensors on a ROCm device (no CPU fallback)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.stride(-1) != 1 or (t.dim() == 2 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+class DeviceCSR:
+    """Square batch adjacency (block diagonal) in HBM: int32 tensors holding
+    uint32 values, all-ones data (the sampler emits data = 1., .cpp:411,423)."""
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor):
+        _need_cuda(indptr, indices)
+        assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
+        self.indptr = indptr.contiguous()
+        self.indices = indices.contiguous()
+        self.n = int(indptr.numel()) - 1
+        self.e = int(indices.numel())
+        self._edge_row = None
+        self._t = None
+
+    @property
+    def shape(self):
+        return (self.n, self.n)
+
+    @property
+    def size(self):          # scipy's nnz-like attribute used by calc_complexity_step
+        return self.e
+
+    @property
+    def device(self):
+        return self.indptr.device
+
+    @classmethod
+    def from_scipy(cls, adj, device):
+        """Upload a scipy CSR (the reference's layer-0 input type)."""
+        ip = torch.from_numpy(np.ascontiguousarray(adj.indptr, dtype=np.int64).astype(np.int32))
+        ix = torch.from_numpy(np.ascontiguousarray(adj.indices, dtype=np.int64).astype(np.int32))
+        if adj.data.size and not np.all(adj.data == 1):
+            raise ValueError("DeviceCSR carries binary adjacencies only (graph_utils.py:83,111)")
+        return cls(ip.to(device), ix.to(device))
+
+    @property
+    def edge_row(self) -> torch.Tensor:
+        if self._edge_row is None:
+            er = torch.empty(max(1, self.e), dtype=torch.int32, device=self.device)[:self.e]
+            check(_lib.load().sl_csr_edge_rows(self.indptr.data_ptr(), self.n, self.e, er.data_ptr(),
+                                               _stream(er)))
+            self._edge_row = er
+        return self._edge_row
+
+    @property
+    def transposed(self):
+        """(t_indptr, t_indices, t_perm) of A^T, built once per batch."""
+        if self._t is None:
+            dev = self.device
+            ti = torch.empty(self.n + 1, dtype=torch.int32, device=dev)
+            tx = torch.empty(max(1, self.e), dtype=torch.int32, device=dev)[:self.e]
+            tp = torch.empty(max(1, self.e), dtype=torch.int32, device=dev)[:self.e]
+            work = torch.empty(self.n + 2 * self.e + 16, dtype=torch.int32, device=dev)
+            check(_lib.load().sl_csr_transpose(self.indptr.data_ptr(), self.indices.data_ptr(),
+                                               self.edge_row.data_ptr(), self.n, self.e, ti.data_ptr(),
+                                               tx.data_ptr(), tp.data_ptr(), work.data_ptr(), _stream(ti)))
+            self._t = (ti, tx, tp)
+        return self._t
+
+
+class NormAdj:
+    """Normalised adjacency  diag(row_scale) (A o edge_w) diag(col_scale)."""
+
+    def __init__(self, csr: DeviceCSR, edge_w: Optional[torch.Tensor] = None,
+                 row_scale: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None):
+        self.csr = csr
+        self.edge_w = edge_w
+        self.row_scale = row_scale
+        self.col_scale = col_scale
+
+    @property
+    def shape(self):
+        return self.csr.shape
+
+    def to_dense(self) -> torch.Tensor:
+        """Dense fp32 copy (tests / debugging only)."""
+        n = self.csr.n
+        rows = self.csr.edge_row.long()
+        cols = self.csr.indices.long()
+        w = torch.ones(self.csr.e, device=self.csr.device) if self.edge_w is None else self.edge_w.clone()
+        if self.row_scale is not None:
+            w = w * self.row_scale[rows]
+        if self.col_scale is not None:
+            w = w * self.col_scale[cols]
+        d = torch.zeros(n, n, device=self.csr.device)
+        d.index_put_((rows, cols), w, accumulate=True)
+        return d
+
+
+def degree_scales(csr: DeviceCSR, edge_w: Optional[torch.Tensor], mode: str) -> torch.Tensor:
+    out = torch.empty(max(1, csr.n), dtype=torch.float32, device=csr.device)[:csr.n]
+    check(_lib.load().sl_degree_scales(csr.indptr.data_ptr(), edge_w.data_ptr() if edge_w is not None else None,
+                                       csr.n, {"rw": 0, "sym": 1}[mode], out.data_ptr(), _stream(out)))
+    return out
+
+
+def dropedge_mask(csr: DeviceCSR, dropedge: float, symmetric: bool = False) -> Optional[torch.Tensor]:
+    """Edge keep-mask of the reference's drop-edge: int(nnz*p) positions drawn WITH
+    replacement are zeroed (graph_utils.py:85-88, layers.py:592-596); the symmetric
+    variant keeps an edge only when its mate survived too (graph_utils.py:114-123)."""
+    if dropedge <= 0 or csr.e == 0:
+        return None
+    num = int(csr.e * dropedge)
+    m = torch.ones(csr.e, dtype=torch.float32, device=csr.device)
+    if num > 0:
+        idx = torch.floor(torch.rand(num, device=csr.device) * csr.e).long().clamp_(max=csr.e - 1)
+        m[idx] = 0
+    if symmetric:
+        _ti, _tx, tp = csr.transposed
+        m = m * m[tp.long()]
+    return m
+
+
+def adj_norm_rw(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
+    """D^-1 A with drop-edge (frontend/graph_utils.py:67-95, torch-sparse branch)."""
+    m = dropedge_mask(csr, dropedge)
+    return NormAdj(csr, edge_w=m, row_scale=degree_scales(csr, m, "rw"))
+
+
+def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
+    """D^-1/2 A D^-1/2 with symmetric drop-edge (frontend/graph_utils.py:109-145)."""
+    m = dropedge_mask(csr, dropedge, symmetric=True)
+    s = degree_scales(csr, m, "sym")
+    return NormAdj(csr, edge_w=m, row_scale=s, col_scale=s)
+
+
+def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n):
+    X = _f32c(X)
+    F = X.shape[1]
+    Y = torch.empty(n, F, dtype=torch.float32, device=X.device)
+    check(_lib.load().sl_spmm_csr_f32(
+        indptr.data_ptr(), indices.data_ptr(), edge_w.data_ptr() if edge_w is not None else None,
+        edge_perm.data_ptr() if edge_perm is not None else None,
+        row_scale.data_ptr() if row_scale is not None else None,
+        col_scale.data_ptr() if col_scale is not None else None,
+        X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), n, F, _stream(X)))
+    return Y
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, adj: NormAdj):
+        _need_cuda(X)
+        ctx.adj = adj
+        c = adj.csr
+        return _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n)
+
+    @staticmethod
+    def backward(ctx, dY):
+        adj = ctx.adj
+        ti, tx, tp = adj.csr.transposed
+        # (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
+        dX = _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale,
+                       adj.row_scale, dY, adj.csr.n)
+        return dX, None
+
+
+def spmm(adj: NormAdj, X: torch.Tensor) -> torch.Tensor:
+    """adj @ X  (torch.sparse.mm(adj_norm, X), shaDow/layers.py:326-327)."""
+    return _SpMM.apply(X, adj)
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """table[idx]  (feat_full[subgs.node], shaDow/minibatch.py:469)."""
+    _need_cuda(table, idx)
+    assert table.dim() == 2 and idx.dtype == torch.int32 and table.dtype == torch.float32
+    n, F = int(idx.numel()), int(table.shape[1])
+    out = torch.empty(n, F, dtype=torch.float32, device=table.device)
+    check(_lib.load().sl_gather_rows_f32(table.data_ptr(), table.stride(0), idx.data_ptr(), n, F,
+                                         out.data_ptr(), out.stride(0), _stream(out)))
+    return out
+
+
+def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+class _ActNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, offset, acts, seg, out_scale, *Zs):
+        Zs = [_f32c(z) for z in Zs]
+        _need_cuda(scale, offset, *Zs)
+        nb = len(Zs)
+        n, F = Zs[0].shape
+        sc = scale.reshape(nb, F).contiguous().float()
+        of = offset.reshape(nb, F).contiguous().float()
+        out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
+        ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
+        ac = (C.c_int * nb)(*acts)
+        check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
+                                          seg, out_scale, out.data_ptr(), out.stride(0), _stream(out)))
+        ctx.save_for_backward(sc, of, *Zs)
+        ctx.meta = (acts, seg, out_scale, scale.shape, offset.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sc, of, *Zs = ctx.saved_tensors
+        acts, seg, out_scale, sshape, oshape = ctx.meta
+        nb = len(Zs)
+        n, F = Zs[0].shape
+        dout = _f32c(dout)
+        need = ctx.needs_input_grad[5:5 + nb]
+        dZs = [torch.empty_like(z) if nd else None for z, nd in zip(Zs, need)]
+        dsc = torch.empty(nb, F, dtype=torch.float32, device=sc.device)
+        dof = torch.empty(nb, F, dtype=torch.float32, device=sc.device)
+        ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
+        ldd = (C.c_int64 * nb)(*[(d.stride(0) if d is not None else 0) for d in dZs])
+        ac = (C.c_int * nb)(*acts)
+        check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
+                                          seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs),
+                                          ldd, dsc.data_ptr(), dof.data_ptr(), _stream(dout)))
+        return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, *dZs)
+
+
+def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, offset: torch.Tensor,
+             seg: Optional[int] = None, out_scale: float = 1.0) -> torch.Tensor:
+    """out_scale * sum_b norm_b(act_b(Z_b)) with the reference's 'norm_feat'
+    (shaDowLayer._f_norm_feat, shaDow/layers.py:329-338).  scale/offset hold one
+    row of F features per branch (any shape with nb*F elements)."""
+    F = Zs[0].shape[1]
+    codes = []
+    for a in acts:
+        if a not in ACT_CODE:
+            raise NotImplementedError(f"activation {a!r} is not available in the fused HIP kernel "
+                                      f"(supported: {sorted(ACT_CODE)})")
+        codes.append(ACT_CODE[a])
+    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), *Zs)

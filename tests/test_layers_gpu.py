@@ -1,0 +1,205 @@
+"""GPU parity of the HIP layer kernels / layers / DeepGNN (through the C ABI)
+against (a) the reference's golden outputs and gradients and (b) the CPU layer
+oracle on seeded inputs at benchmark feature widths.  fp32 tolerance 1e-4
+(BASELINE.json north_star); gradients of reduced parameters 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from tests._golden_layers import LayerGolden, ModelGolden
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+DEV = "cuda:0"
+
+
+def _csr(indptr, indices):
+    from shadow_gnn_amd import ops
+    return ops.DeviceCSR(torch.tensor(np.asarray(indptr).astype(np.int64).astype(np.int32)).to(DEV),
+                         torch.tensor(np.asarray(indices).astype(np.int64).astype(np.int32)).to(DEV))
+
+
+def _mk_layer(case, dim_in, dim_out, params):
+    from shadow_gnn_amd import layers
+    cls = {"gcn": layers.GCN, "sage": layers.GraphSAGE, "gat": layers.GAT}[case["layer"]]
+    layer = cls(dim_in, dim_out, dropout=0.0, act=case["act"], norm="norm_feat", mulhead=case.get("mulhead", 1))
+    layer.load_state_dict({k: torch.tensor(v) for k, v in params.items()})     # same names / shapes as the reference
+    return layer.to(DEV)
+
+
+def test_layers_match_reference_golden():
+    g = LayerGolden()
+    for case in g.cases:
+        ci = case["idx"]
+        layer = _mk_layer(case, case["dim_in"], case["dim_out"], g.params(ci))
+        layer.train()
+        x = torch.tensor(g.get(ci, "X"), device=DEV, requires_grad=True)
+        csr = _csr(g.get(ci, "indptr"), g.get(ci, "indices"))
+        sizes = torch.tensor(g.get(ci, "sizes").astype(np.int64), device=DEV)
+        out, adj_norm, flag, de = layer((x, csr, False, 0.0), sizes)
+        assert flag is True and de == 0.0
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g.get(ci, "out"), err_msg=str(case), **TOL)
+        (out * torch.tensor(g.get(ci, "wout"), device=DEV)).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g.get(ci, "dX"), err_msg=str(case), **TOL)
+        for k, gr in g.grads(ci).items():
+            got = dict(layer.named_parameters())[k].grad.cpu().numpy()
+            np.testing.assert_allclose(got, gr, err_msg=f"{case} {k}", rtol=1e-3, atol=2e-4)
+        # later layers get the threaded normalised adjacency
+        layer2 = _mk_layer(case, case["dim_out"], case["dim_out"], g.params(ci, "p2"))
+        out2, _, _, _ = layer2((torch.tensor(g.get(ci, "out"), device=DEV), adj_norm, True, 0.0), sizes)
+        np.testing.assert_allclose(out2.detach().cpu().numpy(), g.get(ci, "out2"), err_msg=str(case), **TOL)
+
+
+def test_scipy_csr_input_like_the_reference():
+    """Layer 0 also accepts the scipy CSR the reference passes (layers.py:427,467)."""
+    import scipy.sparse as sp
+    g = LayerGolden()
+    case = g.cases[2]
+    ci = case["idx"]
+    layer = _mk_layer(case, case["dim_in"], case["dim_out"], g.params(ci))
+    ip, ix = g.get(ci, "indptr").astype(np.int64), g.get(ci, "indices").astype(np.int64)
+    adj = sp.csr_matrix((np.ones(ix.size, dtype=np.float32), ix, ip), shape=(ip.size - 1, ip.size - 1))
+    out, _, _, _ = layer((torch.tensor(g.get(ci, "X"), device=DEV), adj, False, 0.0), None)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g.get(ci, "out"), **TOL)
+
+
+def _model_from_case(case, g, ci):
+    from shadow_gnn_amd.models import DeepGNN
+    aug_feat = [("hops", 7)] if case["aug"] else []
+    model = DeepGNN(case["dim_feat"], case["dim_feat"], case["num_classes"], 0, case["arch"], aug_feat, 1,
+                    case["train_params"], "node")
+    sd = {k: torch.tensor(v) for k, v in g.group(ci, "p").items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return model.to(DEV)
+
+
+def test_model_step_matches_reference_golden():
+    """One full DeepGNN.step (fwd, CE loss, bwd, clip 5, Adam) vs the reference's."""
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN, hop2onehot
+    g = ModelGolden()
+    for case in g.cases:
+        ci = case["idx"]
+        model = _model_from_case(case, g, ci)
+        model.optimizer = torch.optim.Adam(model.parameters(), lr=case["train_params"]["lr"])
+        feat_aug = {}
+        if case["aug"]:
+            hop = torch.tensor(g.get(ci, "hop").astype(np.int64).astype(np.int32), device=DEV)
+            feat_aug["hops"] = hop2onehot(hop, 7)
+            np.testing.assert_array_equal(feat_aug["hops"].cpu().numpy(), g.get(ci, "hop1hot"))
+        batch = OneBatchSubgraph(
+            [_csr(g.get(ci, "indptr"), g.get(ci, "indices"))], [torch.tensor(g.get(ci, "X"), device=DEV)],
+            torch.tensor(g.get(ci, "labels"), device=DEV),
+            torch.tensor(g.get(ci, "sizes").astype(np.int64), device=DEV).unsqueeze(0),
+            [torch.tensor(g.get(ci, "target").astype(np.int64), device=DEV)], [feat_aug])
+        ret = model.step(TRAIN, "running", batch)
+        assert abs(float(ret["loss"]) - float(g.get(ci, "loss"))) < 1e-4, case["arch"]["aggr"]
+        ref_preds = torch.softmax(torch.tensor(g.get(ci, "preds")), dim=1).numpy()
+        np.testing.assert_allclose(ret["preds"].detach().cpu().numpy(), ref_preds, **TOL)
+        np.testing.assert_allclose(ret["emb_ens"][0].detach().cpu().numpy(), g.get(ci, "emb"), **TOL)
+        for k, gr in g.group(ci, "g").items():
+            got = dict(model.named_parameters())[k].grad.cpu().numpy()
+            np.testing.assert_allclose(got, gr, err_msg=f"{case['arch']['aggr']} {k}", rtol=2e-3, atol=2e-4)
+        # parameters after the Adam update.  The first Adam step moves a weight by
+        # lr*g/(|g|+1e-8): only entries whose gradient is well above the fp32 noise
+        # floor are comparable at 1e-4; the rest must still move by at most lr.
+        grads = g.group(ci, "g")
+        for k, q in g.group(ci, "q").items():
+            got = model.state_dict()[k].cpu().numpy()
+            lr = case["train_params"]["lr"]
+            assert np.all(np.abs(got - q) <= 2 * lr + 1e-6), k
+            if k in grads:
+                solid = np.abs(grads[k]) > 1e-4
+                np.testing.assert_allclose(got[solid], q[solid], err_msg=k, rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("kind,F_in,F_out,heads", [("sage", 128, 256, 1), ("sage", 100, 256, 1), ("gcn", 256, 256, 1),
+                                                    ("gat", 256, 256, 4), ("gat", 100, 256, 4), ("sage", 47, 36, 1)])
+def test_layers_match_oracle_at_benchmark_widths(kind, F_in, F_out, heads):
+    """Seeded sampler batch, hidden width 256: HIP layer vs the dense CPU oracle."""
+    from oracle import layers_oracle as lo
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd import layers
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(3000, 10, seed=3)
+    roots = np.random.default_rng(1).permutation(3000)[:24].astype(np.uint32)
+    b = so.sample_batch(indptr, indices, roots, method="khop", depth=2, budget=6, add_self_edge=(kind != "sage"), seed=5)
+    n = b.node.size
+    torch.manual_seed(0)
+    cls = {"gcn": layers.GCN, "sage": layers.GraphSAGE, "gat": layers.GAT}[kind]
+    layer = cls(F_in, F_out, dropout=0.0, act="elu", norm="norm_feat", mulhead=heads)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    X = torch.randn(n, F_in)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    Xo = X.clone().requires_grad_(True)
+    ref = lo.layer_forward(kind, params, Xo, b.indptr, b.indices, "elu", heads=heads)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    layer = layer.to(DEV)
+    x = X.to(DEV).requires_grad_(True)
+    out, _, _, _ = layer((x, _csr(b.indptr, b.indices), False, 0.0), None)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), Xo.grad.numpy(), rtol=1e-3, atol=3e-4)
+    for k, p in layer.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), params[k].grad.numpy(), err_msg=k, rtol=2e-3, atol=2e-3)
+
+
+def test_gather_spmm_transpose_primitives():
+    from shadow_gnn_amd import ops
+    rng = np.random.default_rng(0)
+    # directed (asymmetric) CSR with duplicate-free rows: exercises the general transpose path
+    n = 500
+    dense = (rng.random((n, n)) < 0.01).astype(np.float32)
+    import scipy.sparse as sp
+    A = sp.csr_matrix(dense)
+    A.sort_indices()
+    csr = _csr(A.indptr, A.indices)
+    ti, tx, tp = csr.transposed
+    At = sp.csr_matrix(dense.T)
+    At.sort_indices()
+    assert np.array_equal(ti.cpu().numpy(), At.indptr) and np.array_equal(tx.cpu().numpy(), At.indices)
+    # t_perm maps transposed entries back to original edge positions
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    tpn = tp.cpu().numpy()
+    assert np.array_equal(rows[tpn], At.indices) and np.array_equal(A.indices[tpn], np.repeat(np.arange(n), np.diff(At.indptr)))
+    X = torch.randn(n, 100, device=DEV, requires_grad=True)
+    w = torch.rand(A.nnz, device=DEV)
+    rs = torch.rand(n, device=DEV) + 0.5
+    adj = ops.NormAdj(csr, edge_w=w, row_scale=rs, col_scale=rs)
+    Y = ops.spmm(adj, X)
+    D = adj.to_dense()
+    np.testing.assert_allclose(Y.detach().cpu().numpy(), (D @ X.detach()).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    G = torch.randn_like(Y)
+    (Y * G).sum().backward()
+    np.testing.assert_allclose(X.grad.cpu().numpy(), (D.t() @ G).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # feature gather
+    table = torch.randn(1000, 100, device=DEV)
+    idx = torch.randint(0, 1000, (777,), device=DEV, dtype=torch.int32)
+    assert torch.equal(ops.gather_rows(table, idx), table[idx.long()])
+    table2 = torch.randn(1000, 47, device=DEV)
+    assert torch.equal(ops.gather_rows(table2, idx), table2[idx.long()])
+    # empty inputs
+    e0 = _csr(np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    assert ops.spmm(ops.adj_norm_rw(e0), torch.ones(3, 8, device=DEV)).abs().sum().item() == 0.0
+
+
+def test_dropedge_semantics():
+    """int(nnz*p) positions zeroed (with replacement); row scale follows the masked degree;
+    the symmetric variant keeps an edge only if its mate survived (graph_utils.py:85-94,114-123)."""
+    from shadow_gnn_amd import ops
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(2000, 8, seed=1)
+    b = so.sample_batch(indptr, indices, np.arange(40, dtype=np.uint32), method="khop", depth=2, budget=5, add_self_edge=True)
+    csr = _csr(b.indptr, b.indices)
+    torch.manual_seed(0)
+    adj = ops.adj_norm_rw(csr, dropedge=0.3)
+    m = adj.edge_w.cpu().numpy()
+    assert set(np.unique(m)) <= {0.0, 1.0} and (m == 0).sum() <= int(csr.e * 0.3) and (m == 0).sum() > 0.2 * csr.e * 0.3
+    deg = np.add.reduceat(np.concatenate([m, [0]]), b.indptr[:-1].astype(np.int64))[:csr.n] * (np.diff(b.indptr.astype(np.int64)) > 0)
+    np.testing.assert_allclose(adj.row_scale.cpu().numpy(), 1.0 / np.maximum(deg, 1), rtol=1e-6)
+    adj = ops.adj_norm_sym(csr, dropedge=0.3)
+    D = adj.to_dense().cpu().numpy()
+    assert np.allclose(D, D.T, atol=1e-6)
