@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+  sample B subgraphs (HIP sampler) -> gather features (HIP) -> L-layer SAGE forward
+  (HIP SpMM + fused act/norm, rocBLAS GEMMs) -> CE loss -> backward -> [RCCL gradient
+  all-reduce] -> clip -> Adam.
+The full graph CSR, the feature matrix and the root list are resident in HBM
+before the timed region.  Batches are sharded over the ranks (weak scaling: B per
+GPU is fixed); there is no collective on the data path, only the gradient
+all-reduce.
+
+Rank 0 prints ONE JSON line.  metric/unit follow BASELINE.json:
+  value               sampled nodes/s through the full train step, summed over ranks
+  train_steps_per_sec optimizer steps/s
+  roofline            the dominant hand-written (HBM-bound) kernel, timed live with HIP
+                      events on its launch stream: algorithmic bytes / duration vs 8 TB/s
+  cpu_baseline        the reference's own C++/OpenMP sampler (oracle/_ref) timed on this
+                      box's host cores on a bounded sample of the same roots
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # BASELINE.json north_star: "k-hop-sample + SAGE-aggregate step for ogbn-products-shape batches"
+    # sampler / architecture / hyper-parameters: config_train/products/vanilla/sage_5_khop.yml
+    "products-khop-sage5": dict(shape="products", sampler=dict(method="khop", depth=2, budget=20, add_self_edge=False),
+                                aggr="sage", layers=5, dim=256, act="relu", heads=1, aug=(), batch=1024,
+                                dropout=0.4, dropedge=0.05, lr=0.002),
+    # BASELINE.json configs[1]: config_train/arxiv/vanilla/sage_5_khop.yml
+    "arxiv-khop-sage5": dict(shape="arxiv", sampler=dict(method="khop", depth=2, budget=20, add_self_edge=False),
+                             aggr="sage", layers=5, dim=256, act="elu", heads=1, aug=("hops",), batch=256,
+                             dropout=0.25, dropedge=0.15, lr=2e-5),
+    # BASELINE.json configs[0] shape on the GPU (reference case is CPU only)
+    "arxiv-khop-gcn3": dict(shape="arxiv", sampler=dict(method="khop", depth=2, budget=20, add_self_edge=True),
+                            aggr="gcn", layers=3, dim=256, act="elu", heads=1, aug=("hops",), batch=32,
+                            dropout=0.25, dropedge=0.15, lr=2e-5),
+    # BASELINE.json configs[3] shape (k-hop depth 3, GAT-5, 4 heads)
+    "products-khop3-gat5": dict(shape="products", sampler=dict(method="khop", depth=3, budget=20, add_self_edge=True),
+                                aggr="gat", layers=5, dim=256, act="elu", heads=4, aug=(), batch=64,
+                                dropout=0.35, dropedge=0.1, lr=0.001),
+}
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def sampler_alg_bytes(c, with_hop):
+    """SURVEY.md 8(d) Bytes_S from the counters of one call: frontier (8 B of indptr per
+    expanded node + 4 B per neighbour id read), induction (8 n indptr + 4 D neighbour ids),
+    outputs (node 4n, indptr 4(n+1), indices + edge id 8e, hop 4n)."""
+    n, e = c["n_tot"], c["e_tot"]
+    D = c["slots_scanned"] - n
+    return (8 * c["frontier_nodes"] + 4 * c["frontier_reads"] + 8 * n + 4 * D + 4 * n + 4 * (n + 1) + 8 * e
+            + (4 * n if with_hop else 0))
+
+
+def cpu_baseline(indptr_host, indices_host, roots, scfg, seed, budget_s=20.0):
+    """The reference's own sampler on the host cores (kind 'reference'), or the C port."""
+    cores = os.cpu_count() or 1
+    P = 500                                             # the reference's num_subg_per_batch (minibatch.py:397)
+    roots = np.ascontiguousarray(roots[:4 * P], dtype=np.uint32)
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    try:
+        sys.path.insert(0, ref_dir)
+        import tempfile
+        import ParallelSampler as ref
+        with tempfile.TemporaryDirectory() as td:
+            f_ip, f_ix = os.path.join(td, "indptr.bin"), os.path.join(td, "indices.bin")
+            indptr_host.tofile(f_ip); indices_host.tofile(f_ix)       # raw uint32 .bin, read by the C++ side
+            ps = ref.ParallelSampler([], [], [], P, cores, True, True, [], 1, f_ip, f_ix, "", seed)
+        ps.shuffle_targets(roots)
+        cfg = {"method": "khop", "depth": str(scfg["depth"]), "budget": str(scfg["budget"]), "num_roots": "1",
+               "add_self_edge": "true" if scfg.get("add_self_edge") else "false", "include_target_conn": "false",
+               "return_target_only": "false"}
+        nodes, t = 0, 0.0
+        calls = 0
+        while calls < roots.size // P and t < budget_s:
+            t0 = time.perf_counter()
+            out = ps.parallel_sampler_ensemble([cfg], [set()])[0]
+            t += time.perf_counter() - t0
+            nodes += sum(len(v) for v in out.get_subgraph_node()[:out.get_num_valid_subg()])
+            calls += 1
+        return dict(value=nodes / t, unit="sampled-nodes/s", cores=cores, kind="reference",
+                    sample=f"reference C++/OpenMP ParallelSampler (oracle/_ref), {calls} calls x {P} subgraphs, "
+                           f"sampler only (no model), {cores} threads")
+    except Exception as ex:                              # oracle/_ref missing: time the C restatement instead
+        from oracle import sampler_oracle as so
+        t0 = time.perf_counter()
+        b = so.sample_batch(indptr_host, indices_host, roots[:P], method="khop", depth=scfg["depth"],
+                            budget=scfg["budget"], add_self_edge=bool(scfg.get("add_self_edge")), seed=seed,
+                            num_threads=cores)
+        t = time.perf_counter() - t0
+        return dict(value=b.node.size / t, unit="sampled-nodes/s", cores=cores, kind="port",
+                    sample=f"oracle/sampler_oracle.c (OpenMP), 1 call x {P} subgraphs ({type(ex).__name__}: reference build unavailable)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="products-khop-sage5", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="roots per GPU per step (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true")
+    args = ap.parse_args()
+
+    from shadow_gnn_amd import dist as sdist
+    rank, local_rank, world = sdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from shadow_gnn_amd import ops
+    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.synthetic import MAX_DEGREE, SHAPES, make_graph_torch
+
+    wl = WORKLOADS[args.workload]
+    N, nnz, F0, C = SHAPES[wl["shape"]]
+    B = args.batch or wl["batch"]
+    K, W = args.steps, args.warmup
+    # ---- synthetic inputs, resident in HBM before the timed region (seeds: SURVEY.md 8(d))
+    indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE[wl["shape"]])
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    feat_full = torch.randn(N, F0, generator=g, device=dev)
+    label_full = torch.randint(0, C, (N,), generator=g, device=dev)
+    need = B * world * (K + W + 2)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy()
+    roots_all = np.resize(perm, need).astype(np.int64)
+    aug = tuple(wl["aug"])
+    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots_all}, dict(wl["sampler"]), aug, feat_full,
+                                   label_full, batch_size=B * world, device=dev, seed_cpp=3, rank=rank,
+                                   world_size=world, prefetch=not args.no_prefetch)
+    mb.epoch_start_reset(0, TRAIN)
+    mb.shuffle_entity(TRAIN, perm=np.arange(roots_all.size))
+    hs = mb.graph_sampler[TRAIN]
+    torch.manual_seed(4)
+    arch = dict(num_layers=wl["layers"], num_cls_layers=1, heads=wl["heads"], dim=wl["dim"], act=wl["act"],
+                layer_norm="norm_feat", feature_augment_ops="sum", aggr=wl["aggr"], residue="none",
+                pooling="center", loss="softmax")
+    aug_feat = [(a, mb.get_aug_dim(a)) for a in aug]
+    model = DeepGNN(F0, F0, C, 0, arch, aug_feat, 1, dict(dropout=wl["dropout"], dropedge=wl["dropedge"], lr=wl["lr"]),
+                    "node").to(dev)
+    sdist.broadcast_parameters(model)
+    model.grad_sync = sdist.GradSync(model.parameters(), world_size=world)
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=wl["lr"])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    def one_step():
+        batch = mb.one_batch(TRAIN)
+        ret = model.step(TRAIN, "running", batch)
+        return batch.device_batch.counts, ret
+
+    for _ in range(W):
+        one_step()
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides
+    hs.set_profiling(True)
+    barrier()
+    timer = ops.KernelTimer()
+    counts = []
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(K):
+            c, ret = one_step()
+            counts.append(c)
+    barrier()
+    dt = time.perf_counter() - t0
+    hs.set_profiling(False)
+    loss = float(ret["loss"])
+    nodes = float(sum(c["n_tot"] for c in counts))
+    edges = float(sum(c["e_tot"] for c in counts))
+    stats = torch.tensor([dt, nodes, edges], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone(); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tot = stats[1:].clone(); torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+        dt, nodes, edges = float(tmax[0]), float(tot[0]), float(tot[1])
+
+    # ---- sampler-only rate (same kernels, no model), a few calls
+    scfg = mb.sampler_cfg
+    if TRAIN in mb._inflight:            # drain the prefetched batch
+        mb._collect(TRAIN)
+    torch.cuda.synchronize(dev)
+    ts0 = time.perf_counter(); sn = 0
+    for _ in range(10):
+        sb = hs.sample(scfg, B)
+        sn += sb.num_nodes
+    torch.cuda.synchronize(dev)
+    sampler_rate = sn / (time.perf_counter() - ts0) * world
+
+    if rank != 0:
+        return
+    # ---- roofline of the hand-written kernels (live HIP-event timings of the timed region)
+    kern = timer.summary()
+    with_hop = "hops" in aug
+    s_ms = [c["sample_kernel_ms"] for c in counts if c["sample_kernel_ms"] > 0]
+    s_bytes = [sampler_alg_bytes(c, with_hop) for c in counts]
+    if s_ms:
+        kern["sg_sample_lds_kernel"] = dict(launches=len(s_ms), total_ms=float(sum(s_ms)), avg_ms=float(np.mean(s_ms)),
+                                            bytes_per_launch=float(np.mean(s_bytes)),
+                                            gbps=float(np.mean(s_bytes)) / 1e9 / (float(np.mean(s_ms)) / 1e3))
+        r_ms = [c["relocate_kernel_ms"] for c in counts]
+        kern["sg_relocate_kernel"] = dict(launches=len(r_ms), total_ms=float(sum(r_ms)), avg_ms=float(np.mean(r_ms)),
+                                          bytes_per_launch=float(np.mean([16 * c["n_tot"] + 16 * c["e_tot"] for c in counts])),
+                                          gbps=0.0)
+    dom = max((k for k in kern if k != "sg_relocate_kernel"), key=lambda k: kern[k]["total_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if collected
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=dom, achieved=round(kern[dom]["gbps"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(kern[dom]["gbps"] / HBM_PEAK_GBS, 4), traffic=traffic,
+                    avg_ms=round(kern[dom]["avg_ms"], 4), bytes_per_launch=int(kern[dom]["bytes_per_launch"]))
+    kernels = {k: dict(launches=v["launches"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
+                       alg_GBps=round(v["gbps"], 1), frac=round(v["gbps"] / HBM_PEAK_GBS, 4)) for k, v in kern.items()}
+    # north-star aggregate: k-hop sample + feature gather + SAGE aggregates (forward), bytes / time
+    ns_keys = [k for k in kern if k.startswith(("sg_sample", "gather", "spmm"))]
+    ns_ms = sum(kern[k]["total_ms"] for k in ns_keys)
+    ns_by = sum(kern[k]["bytes_per_launch"] * kern[k]["launches"] for k in ns_keys)
+    cb = None
+    if not args.no_cpu_baseline and world == 1:
+        ip = indptr.cpu().numpy().view(np.uint32); ix = indices.cpu().numpy().view(np.uint32)
+        cb = cpu_baseline(ip, ix, roots_all, wl["sampler"], seed=3)
+    line = {
+        "metric": "sampled-nodes/sec", "value": round(nodes / dt, 1), "unit": "sampled-nodes/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "train_steps_per_sec": round(K / dt, 3),
+        "sampler_only_nodes_per_sec": round(sampler_rate, 1),
+        "config": {"workload": f"{args.workload}: {wl['shape']}-shape synthetic CSR (N={N}, nnz={int(indices.numel())}, "
+                               f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
+                               f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",
+                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4)},
+        "roofline": roofline,
+        "north_star_sample_gather_aggregate": {"achieved": round(ns_by / 1e9 / (ns_ms / 1e3), 1) if ns_ms else 0.0,
+                                               "unit": "GB/s", "frac": round(ns_by / 1e9 / (ns_ms / 1e3) / HBM_PEAK_GBS, 4) if ns_ms else 0.0,
+                                               "kernels": ns_keys},
+        "kernels": kernels,
+        "cpu_baseline": cb,
+    }
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,11 @@ typedef struct sg_batch_counts {
                                cap_edges                                        */
   uint64_t slots_scanned;   /* full-graph neighbour ids examined (= D + n)      */
   uint64_t frontier_reads;  /* neighbour ids read by the k-hop expansion        */
+  uint64_t frontier_nodes;  /* frontier nodes expanded (2 indptr reads each)    */
+  float sample_kernel_ms;   /* duration of the sampling kernel(s) of this call,
+                               HIP events on the launch stream; 0 unless
+                               sg_set_profiling(s, 1)                           */
+  float relocate_kernel_ms; /* same for the relocation kernel                   */
 } sg_batch_counts;
 
 /* Create a sampler over a full-graph CSR (uint32 indptr[N+1], indices[nnz]).
@@ -162,6 +167,9 @@ int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t
               uint64_t serial_base, const uint32_t *d_roots_override, const sg_batch_out *out,
               void *stream);
 int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts);
+/* Bracket the kernels of every sg_sample call with timing events (bench.py's
+ * live roofline measurement).                                                 */
+int sg_set_profiling(sg_sampler *s, int enable);
 
 /* ------------------------------------------------------------ layer ops
  * Aggregation / normalisation kernels over a batch CSR (uint32 indptr[n+1],
@@ -212,11 +220,13 @@ int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const i
                     const float *d_scale, const float *d_offset, uint32_t n, uint32_t F, uint32_t seg,
                     float out_scale, float *d_out, int64_t ldo, void *stream);
 /* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F]
- * (overwritten).                                                              */
+ * (overwritten; reduced over the rows in a fixed order).
+ * d_partial: float[2048 * nb * 2 * F] scratch for the two-stage reduction.     */
 int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
                     const float *d_scale, const float *d_offset, uint32_t n, uint32_t F, uint32_t seg,
                     float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
-                    const int64_t *lddz, float *d_dscale, float *d_doffset, void *stream);
+                    const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_partial,
+                    void *stream);
 
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):

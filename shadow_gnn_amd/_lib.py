@@ -47,7 +47,8 @@ class SgBatchCounts(C.Structure):
     _fields_ = [
         ("n_tot", C.c_uint64), ("e_tot", C.c_uint64), ("num_subgraphs", C.c_uint32),
         ("max_subg_nodes", C.c_uint32), ("max_subg_edges", C.c_uint32), ("overflow", C.c_uint32),
-        ("slots_scanned", C.c_uint64), ("frontier_reads", C.c_uint64),
+        ("slots_scanned", C.c_uint64), ("frontier_reads", C.c_uint64), ("frontier_nodes", C.c_uint64),
+        ("sample_kernel_ms", C.c_float), ("relocate_kernel_ms", C.c_float),
     ]
 
 
@@ -77,6 +78,7 @@ SIGNATURES = {
     "sg_sample": (C.c_int, [_P, C.POINTER(SgConfig), C.c_uint64, C.c_uint32, C.c_uint64, _P,
                              C.POINTER(SgBatchOut), _P]),
     "sg_sample_finish": (C.c_int, [_P, C.POINTER(SgBatchCounts)]),
+    "sg_set_profiling": (C.c_int, [_P, C.c_int]),
     "sg_debug_subgraph_stats": (C.c_int, [_P, _P, C.c_uint32]),
     "sl_gather_rows_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_csr_edge_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
@@ -92,7 +94,7 @@ SIGNATURES = {
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sl_act_norm_bwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
-                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P]),
+                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -309,8 +309,9 @@ struct ActNormParams {
   // backward
   const float *dout; int64_t lddo;
   float *dZ[2]; int64_t lddz[2];
-  float *dscale;           // [nb, F] (+=, atomics)
+  float *dscale;           // [nb, F]
   float *doffset;          // [nb, F]
+  float *partial;          // [grid, nb, 2, F] per-block partial sums of dscale / doffset
 };
 
 // sum over the lanes of one segment group (LS lanes, power of two)
@@ -323,7 +324,7 @@ __device__ __forceinline__ float seg_sum(float v) {
 
 // One row per LPR lanes, one float4 per lane; LS = lanes per normalisation segment.
 // (F/4 == number of active lanes per row <= LPR; seg/4 == LS)
-template <int LPR, int LS, bool BWD>
+template <int LPR, int LS, bool BWD, int NB>
 __global__ void act_norm_kernel(ActNormParams p) {
   const uint32_t rows_per_block = kBlock / LPR;
   const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
@@ -339,7 +340,8 @@ __global__ void act_norm_kernel(ActNormParams p) {
       dy = ld4(p.dout + (int64_t)r * p.lddo + f);
       dy.x *= p.out_scale; dy.y *= p.out_scale; dy.z *= p.out_scale; dy.w *= p.out_scale;
     }
-    for (int b = 0; b < p.nb; b++) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
       if (lane_on) {
         z = ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f);
@@ -380,28 +382,52 @@ __global__ void act_norm_kernel(ActNormParams p) {
   }
   if (BWD) {
     // block reduction of the parameter gradients over the row sub-groups, then one atomic per feature
-    __shared__ float red[2][2][kBlock * 4];
-    for (int b = 0; b < p.nb; b++) {
+    __shared__ float red[NB][2][kBlock * 4];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
       float *rs = &red[b][0][threadIdx.x * 4], *ro = &red[b][1][threadIdx.x * 4];
       rs[0] = gs[b].x; rs[1] = gs[b].y; rs[2] = gs[b].z; rs[3] = gs[b].w;
       ro[0] = go[b].x; ro[1] = go[b].y; ro[2] = go[b].z; ro[3] = go[b].w;
     }
     __syncthreads();
     if (sub == 0 && lane_on) {
-      for (int b = 0; b < p.nb; b++) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
         float s4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
         for (uint32_t q = 0; q < rows_per_block; q++) {
           const float *rs = &red[b][0][(q * LPR + l) * 4], *ro = &red[b][1][(q * LPR + l) * 4];
 #pragma unroll
           for (int k = 0; k < 4; k++) { s4[k] += rs[k]; o4[k] += ro[k]; }
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          atomicAdd(p.dscale + (size_t)b * p.F + f + k, s4[k]);
-          atomicAdd(p.doffset + (size_t)b * p.F + f + k, o4[k]);
-        }
+        // deterministic two-stage reduction: this block's partial row, summed by act_norm_finish_kernel
+        float *ps = p.partial + (((size_t)blockIdx.x * NB + b) * 2 + 0) * p.F + f;
+        float *po = p.partial + (((size_t)blockIdx.x * NB + b) * 2 + 1) * p.F + f;
+        st4(ps, make_float4(s4[0], s4[1], s4[2], s4[3]));
+        st4(po, make_float4(o4[0], o4[1], o4[2], o4[3]));
       }
     }
+  }
+}
+
+// dscale[b,f] = sum over blocks of partial[blk,b,0,f]; doffset likewise (fixed order).
+// grid (ceil(F/64), nb*2), 1024 threads = 16 groups x 64 features: each group sums a
+// strided subset of the partial rows, LDS combines the groups in a fixed order.
+__global__ void act_norm_finish_kernel(const float *__restrict__ partial, uint32_t nblocks, int nb, uint32_t F,
+                                       float *__restrict__ dscale, float *__restrict__ doffset) {
+  __shared__ float red[16][64];
+  const uint32_t fl = threadIdx.x & 63u, g = threadIdx.x >> 6;
+  const uint32_t f = blockIdx.x * 64 + fl;
+  const uint32_t b = blockIdx.y >> 1, kind = blockIdx.y & 1u;
+  float acc = 0.f;
+  if (f < F)
+    for (uint32_t k = g; k < nblocks; k += 16) acc += partial[(((size_t)k * nb + b) * 2 + kind) * F + f];
+  red[g][fl] = acc;
+  __syncthreads();
+  if (g == 0 && f < F) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += red[q][fl];
+    (kind ? doffset : dscale)[(size_t)b * F + f] = s;
   }
 }
 
@@ -559,7 +585,9 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
   return SG_OK;
 }
 
-static int act_norm_launch(const ActNormParams &p, bool bwd, hipStream_t st) {
+constexpr uint32_t kActNormBwdBlocks = 2048;  // == rows of the partial buffer
+
+static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
   const uint32_t F = p.F, seg = p.seg;
   bool vec = (F % 4 == 0) && (seg % 4 == 0) && F <= 256 && (F % seg == 0);
   // lanes per segment must be a power of two; when seg == F and F/4 is not a
@@ -577,9 +605,14 @@ static int act_norm_launch(const ActNormParams &p, bool bwd, hipStream_t st) {
   if (lpr < 4) vec = false;
 #define SHD_AN(LPR, LS)                                                                                    \
   do {                                                                                                     \
-    const uint32_t g = grid_for(p.n, kBlock / LPR, 256 * 8);                                               \
-    if (bwd) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true>), dim3(g), dim3(kBlock), 0, st, p);        \
-    else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false>), dim3(g), dim3(kBlock), 0, st, p);           \
+    const uint32_t g = grid_for(p.n, kBlock / LPR, bwd ? kActNormBwdBlocks : 256 * 8);                     \
+    if (bwd) {                                                                                             \
+      if (p.nb == 1) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true, 1>), dim3(g), dim3(kBlock), 0, st, p); \
+      else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true, 2>), dim3(g), dim3(kBlock), 0, st, p);       \
+      hipLaunchKernelGGL(act_norm_finish_kernel, dim3((p.F + 63) / 64, p.nb * 2), dim3(1024), 0, st,       \
+                         p.partial, g, p.nb, p.F, p.dscale, p.doffset);                                    \
+    } else if (p.nb == 1) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false, 1>), dim3(g), dim3(kBlock), 0, st, p); \
+    else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false, 2>), dim3(g), dim3(kBlock), 0, st, p);        \
   } while (0)
   bool done = false;
   if (vec) {
@@ -600,6 +633,10 @@ static int act_norm_launch(const ActNormParams &p, bool bwd, hipStream_t st) {
 #undef SHD_AN
   if (!done) {
     const uint32_t g = grid_for((uint64_t)p.n * 64, kBlock, 256 * 8);
+    if (bwd) {
+      SHD_HIP(hipMemsetAsync(p.dscale, 0, (size_t)p.nb * p.F * 4, st));
+      SHD_HIP(hipMemsetAsync(p.doffset, 0, (size_t)p.nb * p.F * 4, st));
+    }
     if (bwd) hipLaunchKernelGGL(act_norm_generic_kernel<true>, dim3(g), dim3(kBlock), 0, st, p);
     else hipLaunchKernelGGL(act_norm_generic_kernel<false>, dim3(g), dim3(kBlock), 0, st, p);
   }
@@ -636,15 +673,18 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
-                               float *d_doffset, void *stream_) {
+                               float *d_doffset, float *d_partial, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
   if (!d_scale || !d_offset || !d_dout || !d_dscale || !d_doffset || !d_dZ)
     return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: null argument");
   hipStream_t st = (hipStream_t)stream_;
-  SHD_HIP(hipMemsetAsync(d_dscale, 0, (size_t)nb * F * 4, st));
-  SHD_HIP(hipMemsetAsync(d_doffset, 0, (size_t)nb * F * 4, st));
-  if (n == 0) return SG_OK;
+  if (n == 0) {
+    SHD_HIP(hipMemsetAsync(d_dscale, 0, (size_t)nb * F * 4, st));
+    SHD_HIP(hipMemsetAsync(d_doffset, 0, (size_t)nb * F * 4, st));
+    return SG_OK;
+  }
+  if (!d_partial) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: null partial buffer");
   ActNormParams p;
   memset(&p, 0, sizeof(p));
   for (int b = 0; b < nb; b++) {
@@ -653,6 +693,6 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
   }
   p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
   p.out_scale = out_scale; p.eps = 1e-9f; p.dout = d_dout; p.lddo = lddo;
-  p.dscale = d_dscale; p.doffset = d_doffset;
+  p.dscale = d_dscale; p.doffset = d_doffset; p.partial = d_partial;
   return act_norm_launch(p, true, st);
 }

@@ -230,6 +230,9 @@ struct sg_sampler {
   bool pending = false;
   uint32_t pending_P = 0;
   const uint32_t *last_cnt = nullptr;   // per-subgraph result words of the last call
+  bool profiling = false;
+  hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};
+  bool timed = false;
 };
 
 static uint32_t next_pow2(uint64_t x) {
@@ -369,6 +372,7 @@ extern "C" void sg_destroy(sg_sampler *s) {
   if (s->d_counts) (void)hipFree(s->d_counts);
   if (s->h_counts) (void)hipHostFree(s->h_counts);
   if (s->ev) (void)hipEventDestroy(s->ev);
+  for (int i = 0; i < 3; i++) if (s->ev_t[i]) (void)hipEventDestroy(s->ev_t[i]);
   delete s;
 }
 
@@ -613,12 +617,14 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
   if ((rc = ensure(&s->d_scratch, &s->scratch_bytes, o)) != SG_OK) return rc;
   char *sc = (char *)s->d_scratch;
 
+  s->timed = false;
   SHD_HIP(hipMemsetAsync(s->d_counts, 0, 16 * sizeof(uint64_t), stream));
   if (P == 0) {
     SHD_HIP(hipMemsetAsync(out->d_indptr, 0, 4, stream));
     SHD_HIP(hipMemsetAsync(out->d_subg_nodes, 0, 4, stream));
     SHD_HIP(hipMemsetAsync(out->d_subg_edges, 0, 4, stream));
   } else {
+    if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[0], stream));
     SampleParams p;
     memset(&p, 0, sizeof(p));
     p.indptr = s->d_indptr; p.indices = s->d_indices; p.N = s->N; p.nnz = s->nnz;
@@ -685,6 +691,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       hipLaunchKernelGGL(sg_sample_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
       SHD_HIP(hipGetLastError());
     }
+    if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[1], stream));
     RelocParams r;
     memset(&r, 0, sizeof(r));
     r.P = P; r.R = R; r.aug_flags = cfg->aug_flags;
@@ -695,6 +702,8 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     r.out = *out; r.d_counts = s->d_counts;
     hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(256), 0, stream, r);
     SHD_HIP(hipGetLastError());
+    if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[2], stream));
+    s->timed = s->profiling;
   }
   SHD_HIP(hipMemcpyAsync(s->h_counts, s->d_counts, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   SHD_HIP(hipEventRecord(s->ev, stream));
@@ -714,13 +723,27 @@ extern "C" int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts) {
   counts->num_subgraphs = s->pending_P;
   counts->max_subg_nodes = (uint32_t)h[2]; counts->max_subg_edges = (uint32_t)h[3];
   counts->overflow = (uint32_t)h[4];
-  counts->slots_scanned = h[5]; counts->frontier_reads = h[7];
+  counts->slots_scanned = h[5]; counts->frontier_reads = h[7]; counts->frontier_nodes = h[6];
+  counts->sample_kernel_ms = 0.f; counts->relocate_kernel_ms = 0.f;
+  if (s->timed) {
+    (void)hipEventElapsedTime(&counts->sample_kernel_ms, s->ev_t[0], s->ev_t[1]);
+    (void)hipEventElapsedTime(&counts->relocate_kernel_ms, s->ev_t[1], s->ev_t[2]);
+  }
   if (counts->overflow)
     return set_error(SG_ERR_CAPACITY,
                      "sg_sample: capacity exceeded (flags=0x%x: 1=subgraph nodes 2=subgraph edges 4=out nodes 8=out edges); "
                      "largest subgraph %u nodes / %u edges, batch %llu nodes / %llu edges",
                      counts->overflow, counts->max_subg_nodes, counts->max_subg_edges,
                      (unsigned long long)counts->n_tot, (unsigned long long)counts->e_tot);
+  return SG_OK;
+}
+
+extern "C" int sg_set_profiling(sg_sampler *s, int enable) {
+  if (!s) return set_error(SG_ERR_INVALID, "sg_set_profiling: null sampler");
+  SHD_HIP(hipSetDevice(s->device));
+  if (enable && !s->ev_t[0])
+    for (int i = 0; i < 3; i++) SHD_HIP(hipEventCreate(&s->ev_t[i]));
+  s->profiling = enable != 0;
   return SG_OK;
 }
 

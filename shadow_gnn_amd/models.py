@@ -142,7 +142,10 @@ class DeepGNN(nn.Module):
             label_targets = F.one_hot(label_targets.to(torch.int64), num_classes=self.num_classes)
         if mode == TRAIN and status == 'running':
             self.train()
-            self.optimizer.zero_grad(set_to_none=True)
+            if self.grad_sync is not None:
+                self.grad_sync.zero()
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
             preds, emb_ens = self(mode, dropedge=self.dropedge, **args_forward_common)
             loss = self._loss(preds, label_targets)
             (loss * loss_scale if loss_scale != 1.0 else loss).backward()

@@ -20,6 +20,51 @@ from ._lib import check
 ACT_CODE = {"I": 0, "relu": 1, "elu": 2, "tanh": 3, "leakyrelu": 4}
 
 
+class KernelTimer:
+    """Optional live timing of the hand-written kernels with HIP events on the
+    stream they are launched on (bench.py's roofline measurement).  Each record:
+    kernel class -> [events..., algorithmic bytes]."""
+    active = None
+
+    def __init__(self):
+        self.rec = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def summary(self):
+        out = {}
+        for name, items in self.rec.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _b in items)
+            by = sum(b for _e0, _e1, b in items)
+            out[name] = dict(launches=len(items), total_ms=ms, avg_ms=ms / max(1, len(items)),
+                             bytes_per_launch=by / max(1, len(items)), gbps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0)
+        return out
+
+
+class _timed:
+    def __init__(self, name, nbytes, device):
+        self.t = KernelTimer.active
+        if self.t is not None:
+            self.name, self.nbytes = name, nbytes
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.t is not None:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.t is not None:
+            self.e1.record()
+            self.t.rec.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes))
+
+
 def _stream(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -168,7 +213,11 @@ def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n):
     X = _f32c(X)
     F = X.shape[1]
     Y = torch.empty(n, F, dtype=torch.float32, device=X.device)
-    check(_lib.load().sl_spmm_csr_f32(
+    e = int(indices.numel())
+    # algorithmic bytes: indptr + indices (+ edge values) + read X + write A.X
+    nbytes = 4 * (n + 1) + 4 * e + (4 * e if edge_w is not None else 0) + 8 * n * F
+    with _timed(f"spmm_F{F}", nbytes, X.device):
+      check(_lib.load().sl_spmm_csr_f32(
         indptr.data_ptr(), indices.data_ptr(), edge_w.data_ptr() if edge_w is not None else None,
         edge_perm.data_ptr() if edge_perm is not None else None,
         row_scale.data_ptr() if row_scale is not None else None,
@@ -206,8 +255,9 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     assert table.dim() == 2 and idx.dtype == torch.int32 and table.dtype == torch.float32
     n, F = int(idx.numel()), int(table.shape[1])
     out = torch.empty(n, F, dtype=torch.float32, device=table.device)
-    check(_lib.load().sl_gather_rows_f32(table.data_ptr(), table.stride(0), idx.data_ptr(), n, F,
-                                         out.data_ptr(), out.stride(0), _stream(out)))
+    with _timed(f"gather_F{F}", 8 * n * F + 4 * n, table.device):
+        check(_lib.load().sl_gather_rows_f32(table.data_ptr(), table.stride(0), idx.data_ptr(), n, F,
+                                             out.data_ptr(), out.stride(0), _stream(out)))
     return out
 
 
@@ -230,8 +280,9 @@ class _ActNorm(torch.autograd.Function):
         out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
         ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
         ac = (C.c_int * nb)(*acts)
-        check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
-                                          seg, out_scale, out.data_ptr(), out.stride(0), _stream(out)))
+        with _timed(f"act_norm_fwd_nb{nb}_F{F}", (nb + 1) * 4 * n * F, out.device):
+            check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
+                                              seg, out_scale, out.data_ptr(), out.stride(0), _stream(out)))
         ctx.save_for_backward(sc, of, *Zs)
         ctx.meta = (acts, seg, out_scale, scale.shape, offset.shape)
         return out
@@ -247,12 +298,15 @@ class _ActNorm(torch.autograd.Function):
         dZs = [torch.empty_like(z) if nd else None for z, nd in zip(Zs, need)]
         dsc = torch.empty(nb, F, dtype=torch.float32, device=sc.device)
         dof = torch.empty(nb, F, dtype=torch.float32, device=sc.device)
+        partial = torch.empty(2048 * nb * 2 * F, dtype=torch.float32, device=sc.device)
         ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
         ldd = (C.c_int64 * nb)(*[(d.stride(0) if d is not None else 0) for d in dZs])
         ac = (C.c_int * nb)(*acts)
-        check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
-                                          seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs),
-                                          ldd, dsc.data_ptr(), dof.data_ptr(), _stream(dout)))
+        with _timed(f"act_norm_bwd_nb{nb}_F{F}", (2 * nb + 1) * 4 * n * F, dout.device):
+            check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
+                                              seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs),
+                                              ldd, dsc.data_ptr(), dof.data_ptr(), partial.data_ptr(),
+                                              _stream(dout)))
         return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, *dZs)
 
 

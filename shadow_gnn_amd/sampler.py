@@ -242,6 +242,9 @@ class HipSampler:
     def drop_full_graph_info(self):
         check(self._lib.sg_drop_full_graph_info(self._h))
 
+    def set_profiling(self, enable: bool):
+        check(self._lib.sg_set_profiling(self._h, int(bool(enable))))
+
     def set_caps(self, cap_subg_nodes=0, cap_subg_edges=0):
         check(self._lib.sg_set_caps(self._h, cap_subg_nodes, cap_subg_edges))
 
@@ -353,7 +356,9 @@ class HipSampler:
             num_subgraphs=P, num_roots=pend.cfg.num_roots,
             counts=dict(n_tot=n, e_tot=e, max_subg_nodes=cnt.max_subg_nodes,
                         max_subg_edges=cnt.max_subg_edges, slots_scanned=int(cnt.slots_scanned),
-                        frontier_reads=int(cnt.frontier_reads)))
+                        frontier_reads=int(cnt.frontier_reads), frontier_nodes=int(cnt.frontier_nodes),
+                        sample_kernel_ms=float(cnt.sample_kernel_ms),
+                        relocate_kernel_ms=float(cnt.relocate_kernel_ms)))
 
     def sample(self, cfg: SamplerConfig, max_subgraphs: int = 0, *, roots=None,
                serial_base: Optional[int] = None) -> DeviceBatch:
