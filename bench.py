@@ -121,7 +121,7 @@ def main():
     from shadow_gnn_amd import dist as sdist
     rank, local_rank, world = sdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
 
     from shadow_gnn_amd import ops

@@ -22,7 +22,8 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SHADOW_DIST_BACKEND=gloo lets several ranks share one GPU (functional tests only)
+            backend = os.environ.get("SHADOW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

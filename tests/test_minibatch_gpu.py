@@ -1,0 +1,141 @@
+"""GPU: the minibatch loop (epoch bookkeeping, prefetch, rank sharding) and a
+two-process data-parallel train step (gloo transport, both ranks on cuda:0)
+against the single-process step on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(prefetch, rank=0, world=1, batch=16, aug=("hops",), budget=4):
+    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(4000, 10, seed=4)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(4000, 20, generator=g)
+    label = torch.randint(0, 7, (4000,), generator=g)
+    roots = np.random.default_rng(3).permutation(4000)[:103]
+    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+                                   dict(method="khop", depth=2, budget=budget, add_self_edge=True), aug, feat, label,
+                                   batch_size=batch, device=DEV, seed_cpp=11, rank=rank, world_size=world, prefetch=prefetch)
+    mb.epoch_start_reset(0, TRAIN)
+    mb.shuffle_entity(TRAIN, perm=np.arange(103))
+    return mb, indptr, indices, feat, label, roots
+
+
+def _epoch(mb):
+    from shadow_gnn_amd.minibatch import TRAIN
+    out = []
+    while not mb.is_end_epoch(TRAIN):
+        out.append(mb.one_batch(TRAIN, ret_raw_idx=True))
+    mb.epoch_end_reset(TRAIN)
+    return out
+
+
+def test_epoch_loop_matches_oracle_batches():
+    from oracle import layers_oracle as lo
+    from oracle import sampler_oracle as so
+    mb, indptr, indices, feat, label, roots = _setup(prefetch=True)
+    batches = _epoch(mb)
+    assert [b.batch_size for b in batches] == [16] * 6 + [7]          # last, smaller batch (minibatch.py:452-454)
+    serial = 0
+    for t, b in enumerate(batches):
+        r = roots[t * 16:t * 16 + b.batch_size].astype(np.uint32)
+        ref = so.sample_batch(indptr, indices, r, method="khop", depth=2, budget=4, add_self_edge=True,
+                              aug=("hops",), seed=11, serial_base=serial)
+        serial += b.batch_size
+        adj = b.adj_ens[0]
+        assert np.array_equal(adj.indptr.cpu().numpy().view(np.uint32), ref.indptr)
+        assert np.array_equal(adj.indices.cpu().numpy().view(np.uint32), ref.indices)
+        assert np.array_equal(b.idx_raw[0].cpu().numpy().view(np.uint32), ref.node)
+        assert np.array_equal(b.target_ens[0].cpu().numpy().view(np.uint32), ref.target)
+        assert np.array_equal(b.size_subg_ens[0].cpu().numpy(), ref.subg_nodes.astype(np.int32))
+        # features are feat_full[node] (minibatch.py:469), labels follow the roots, hops are one-hot encoded
+        assert torch.equal(b.feat_ens[0].cpu(), feat[torch.as_tensor(ref.node.astype(np.int64))])
+        assert torch.equal(b.label.cpu(), label[torch.as_tensor(r.astype(np.int64))])
+        np.testing.assert_array_equal(b.feat_aug_ens[0]["hops"].cpu().numpy(), lo.hop2onehot(ref.hop, 7))
+    # a second epoch works and re-samples (stochastic sampler: new serials)
+    mb.shuffle_entity(0, perm=np.arange(103))
+    again = _epoch(mb)
+    assert [b.batch_size for b in again] == [16] * 6 + [7]
+
+
+def test_prefetch_does_not_change_batches():
+    a = _epoch(_setup(prefetch=True)[0])
+    b = _epoch(_setup(prefetch=False)[0])
+    for x, y in zip(a, b):
+        assert torch.equal(x.adj_ens[0].indices, y.adj_ens[0].indices) and torch.equal(x.feat_ens[0], y.feat_ens[0])
+
+
+def test_rank_sharding_covers_the_global_batches():
+    full = _epoch(_setup(prefetch=False, batch=16)[0])
+    r0 = _epoch(_setup(prefetch=False, rank=0, world=2, batch=16)[0])
+    r1 = _epoch(_setup(prefetch=False, rank=1, world=2, batch=16)[0])
+    assert len(r0) == len(r1) == len(full)
+    for t in range(len(full)):
+        roots_full = full[t].idx_raw[0][full[t].target_ens[0].long()].cpu().numpy()
+        roots_dp = np.concatenate([r0[t].idx_raw[0][r0[t].target_ens[0].long()].cpu().numpy(),
+                                   r1[t].idx_raw[0][r1[t].target_ens[0].long()].cpu().numpy()])
+        assert np.array_equal(roots_full, roots_dp)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from shadow_gnn_amd import dist as sdist
+    from shadow_gnn_amd.minibatch import TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    sdist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    mb = _setup(prefetch=True, rank=rank, world=world, batch=16, aug=(), budget=-1)[0]   # deterministic sampler
+    torch.manual_seed(5 + rank)
+    arch = dict(num_layers=2, heads=1, dim=32, act="elu", aggr="sage", residue="none", pooling="center")
+    model = DeepGNN(20, 20, 7, 0, arch, [], 1, dict(dropout=0.0, dropedge=0.0, lr=1e-2), "node").to(DEV)
+    sdist.broadcast_parameters(model)
+    model.grad_sync = sdist.GradSync(model.parameters())
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for _ in range(3):
+        model.step(TRAIN, "running", mb.one_batch(TRAIN))
+    q.put((rank, {k: v.cpu().numpy() for k, v in model.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_single_process():
+    import torch.multiprocessing as mp
+    from shadow_gnn_amd.minibatch import TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # both ranks end with identical parameters
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    # single process, global batch 16, same initial parameters (rank 0's seed), deterministic
+    # (full 2-hop) sampler -> the same three optimizer steps up to fp32 summation order
+    mb = _setup(prefetch=False, batch=16, aug=(), budget=-1)[0]
+    torch.manual_seed(5)
+    arch = dict(num_layers=2, heads=1, dim=32, act="elu", aggr="sage", residue="none", pooling="center")
+    model = DeepGNN(20, 20, 7, 0, arch, [], 1, dict(dropout=0.0, dropedge=0.0, lr=1e-2), "node").to(DEV)
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for _ in range(3):
+        model.step(TRAIN, "running", mb.one_batch(TRAIN))
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(res[0][k], v.cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=k)
