@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs (kernel stats + FETCH_SIZE / WRITE_SIZE counter
+passes) into a small markdown table and a traffic JSON.
+
+HBM bytes per launch, per MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE
+are reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
+coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024 (upper estimate for
+kernels that are not purely wide streams); write bytes = WRITE_SIZE * 1024."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("shadow::", "")
+    return n[:60]
+
+
+stats = {}
+f = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if f:
+    for r in csv.DictReader(open(f[0])):
+        stats[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+
+
+def counters(sub, cname):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != cname:
+                continue
+            a = acc[r["Kernel_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return {k: v[0] / max(1, v[1]) for k, v in acc.items()}
+
+
+fetch = counters("pmc_fetch", "FETCH_SIZE")
+write = counters("pmc_write", "WRITE_SIZE")
+total = sum(v[1] for v in stats.values())
+print(f"# rocprofv3 summary {tag}\n")
+print(f"total kernel time {total:.1f} ms over the run (bench.py --steps 10 --warmup 3)\n")
+print("| kernel | calls | total ms | avg us | % | HBM read MB/launch (2*FETCH_SIZE) | HBM write MB/launch |")
+print("|---|---|---|---|---|---|---|")
+traffic = {}
+for name, (calls, tot, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][1])[:24]:
+    rd = 2 * fetch.get(name, 0.0) * 1024 / 1e6 if name in fetch else None
+    wr = write.get(name, 0.0) * 1024 / 1e6 if name in write else None
+    print(f"| {short(name)} | {calls} | {tot:.2f} | {avg:.1f} | {pct:.2f} | {'' if rd is None else f'{rd:.1f}'} | {'' if wr is None else f'{wr:.1f}'} |")
+    if "shadow::" in name and rd is not None:
+        traffic[short(name)] = dict(read_bytes=rd * 1e6, write_bytes=(wr or 0.0) * 1e6, avg_us=avg, calls=calls)
+json.dump(traffic, open(os.path.join(out, f"traffic_{tag}.json"), "w"), indent=1)
