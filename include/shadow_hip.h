@@ -209,24 +209,26 @@ int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const f
                     const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                     void *stream);
 
-/* Fused activation + feature normalisation + branch sum:
+/* Fused (bias +) activation + feature normalisation + branch sum:
  *   out = out_scale * sum_{b<nb} ( (h_b - mean) * scale[b] * rsqrt(var + 1e-9) + offset[b] ),
- *   h_b = act_b(Z_b), mean/var (biased) over segments of `seg` features
- * (shaDowLayer._f_norm_feat, shaDow/layers.py:329-338; GCN :435, GraphSAGE
- * :476-483, GAT :620-625 with seg = head slice and out_scale = 0.5).
+ *   h_b = act_b(Z_b + bias_b), mean/var (biased) over segments of `seg` features
+ * (nn.Linear bias + act + shaDowLayer._f_norm_feat, shaDow/layers.py:329-338; GCN
+ * :434-435, GraphSAGE :476-483, GAT :620-625 with seg = head slice, out_scale 0.5).
  * act codes: 0 identity("I"), 1 relu, 2 elu, 3 tanh, 4 leakyrelu(0.2).
- * d_Z / ldz / act are HOST arrays of nb entries; scale / offset are [nb, F].   */
-int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
-                    const float *d_scale, const float *d_offset, uint32_t n, uint32_t F, uint32_t seg,
-                    float out_scale, float *d_out, int64_t ldo, void *stream);
-/* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F]
- * (overwritten; reduced over the rows in a fixed order).
- * d_partial: float[2048 * nb * 2 * F] scratch for the two-stage reduction.     */
-int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
-                    const float *d_scale, const float *d_offset, uint32_t n, uint32_t F, uint32_t seg,
-                    float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
-                    const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_partial,
-                    void *stream);
+ * d_Z / ldz / d_bias / act are HOST arrays of nb entries (d_bias or its entries
+ * may be NULL); scale / offset are [nb, F].                                    */
+int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                    const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                    uint32_t seg, float out_scale, float *d_out, int64_t ldo, void *stream);
+/* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
+ * when d_dbias != NULL, dbias [nb, F] = column sums of dZ_b (all overwritten,
+ * reduced over the rows in a fixed order).
+ * d_partial: float[2048 * nb * 3 * F] scratch for the two-stage reduction.     */
+int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                    const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                    uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
+                    const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
+                    float *d_partial, void *stream);
 
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):

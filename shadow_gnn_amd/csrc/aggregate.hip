@@ -296,6 +296,8 @@ __device__ __forceinline__ float act_bwd(int act, float x, float h) {
 }
 
 struct ActNormParams {
+  const float *bias[2];    // optional per-branch bias [F] added to Z before the activation (fused Linear bias)
+  float *dbias;            // [nb, F] bias gradients (backward, optional)
   const float *Z[2];       // branch inputs [n, F]
   int64_t ldz[2];
   int act[2];              // activation applied to the branch input
@@ -311,7 +313,7 @@ struct ActNormParams {
   float *dZ[2]; int64_t lddz[2];
   float *dscale;           // [nb, F]
   float *doffset;          // [nb, F]
-  float *partial;          // [grid, nb, 2, F] per-block partial sums of dscale / doffset
+  float *partial;          // [grid, nb, 3, F] per-block partial sums of dscale / doffset / dbias
 };
 
 // sum over the lanes of one segment group (LS lanes, power of two)
@@ -331,8 +333,8 @@ __global__ void act_norm_kernel(ActNormParams p) {
   const uint32_t f = l * 4;
   const bool lane_on = f < p.F;
   const float inv_seg = 1.0f / (float)p.seg;
-  float4 gs[2], go[2];   // per-thread partial sums of dscale / doffset over its rows
-  gs[0] = gs[1] = go[0] = go[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gs[2], go[2], gb[2];   // per-thread partial sums of dscale / doffset / dbias over its rows
+  gs[0] = gs[1] = go[0] = go[1] = gb[0] = gb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub; r < p.n; r += (uint64_t)gridDim.x * rows_per_block) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -345,6 +347,7 @@ __global__ void act_norm_kernel(ActNormParams p) {
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
       if (lane_on) {
         z = ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f);
+        if (p.bias[b]) { const float4 bb = ld4(p.bias[b] + f); z.x += bb.x; z.y += bb.y; z.z += bb.z; z.w += bb.w; }
         h = make_float4(act_fwd(p.act[b], z.x), act_fwd(p.act[b], z.y), act_fwd(p.act[b], z.z), act_fwd(p.act[b], z.w));
       }
       // biased mean / variance over the segment (layers.py:334-335)
@@ -368,10 +371,11 @@ __global__ void act_norm_kernel(ActNormParams p) {
         const float m2 = seg_sum<LS>(dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w) * inv_seg;
         float4 dh = make_float4(rstd * (dxh.x - m1 - xh.x * m2), rstd * (dxh.y - m1 - xh.y * m2),
                                 rstd * (dxh.z - m1 - xh.z * m2), rstd * (dxh.w - m1 - xh.w * m2));
-        if (lane_on && p.dZ[b]) {
+        if (lane_on && (p.dZ[b] || p.dbias)) {
           dh.x *= act_bwd(p.act[b], z.x, h.x); dh.y *= act_bwd(p.act[b], z.y, h.y);
           dh.z *= act_bwd(p.act[b], z.z, h.z); dh.w *= act_bwd(p.act[b], z.w, h.w);
-          st4(p.dZ[b] + (int64_t)r * p.lddz[b] + f, dh);
+          if (p.dZ[b]) st4(p.dZ[b] + (int64_t)r * p.lddz[b] + f, dh);
+          gb[b].x += dh.x; gb[b].y += dh.y; gb[b].z += dh.z; gb[b].w += dh.w;
         }
       }
     }
@@ -382,52 +386,58 @@ __global__ void act_norm_kernel(ActNormParams p) {
   }
   if (BWD) {
     // block reduction of the parameter gradients over the row sub-groups, then one atomic per feature
-    __shared__ float red[NB][2][kBlock * 4];
+    __shared__ float red[NB][3][kBlock * 4];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      float *rs = &red[b][0][threadIdx.x * 4], *ro = &red[b][1][threadIdx.x * 4];
+      float *rs = &red[b][0][threadIdx.x * 4], *ro = &red[b][1][threadIdx.x * 4], *rb = &red[b][2][threadIdx.x * 4];
       rs[0] = gs[b].x; rs[1] = gs[b].y; rs[2] = gs[b].z; rs[3] = gs[b].w;
       ro[0] = go[b].x; ro[1] = go[b].y; ro[2] = go[b].z; ro[3] = go[b].w;
+      rb[0] = gb[b].x; rb[1] = gb[b].y; rb[2] = gb[b].z; rb[3] = gb[b].w;
     }
     __syncthreads();
     if (sub == 0 && lane_on) {
 #pragma unroll
       for (int b = 0; b < NB; b++) {
-        float s4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
+        float s4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
         for (uint32_t q = 0; q < rows_per_block; q++) {
-          const float *rs = &red[b][0][(q * LPR + l) * 4], *ro = &red[b][1][(q * LPR + l) * 4];
+          const float *rs = &red[b][0][(q * LPR + l) * 4], *ro = &red[b][1][(q * LPR + l) * 4], *rb = &red[b][2][(q * LPR + l) * 4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) { s4[k] += rs[k]; o4[k] += ro[k]; }
+          for (int k = 0; k < 4; k++) { s4[k] += rs[k]; o4[k] += ro[k]; b4[k] += rb[k]; }
         }
         // deterministic two-stage reduction: this block's partial row, summed by act_norm_finish_kernel
-        float *ps = p.partial + (((size_t)blockIdx.x * NB + b) * 2 + 0) * p.F + f;
-        float *po = p.partial + (((size_t)blockIdx.x * NB + b) * 2 + 1) * p.F + f;
+        float *ps = p.partial + (((size_t)blockIdx.x * NB + b) * 3 + 0) * p.F + f;
+        float *po = p.partial + (((size_t)blockIdx.x * NB + b) * 3 + 1) * p.F + f;
+        float *pb = p.partial + (((size_t)blockIdx.x * NB + b) * 3 + 2) * p.F + f;
         st4(ps, make_float4(s4[0], s4[1], s4[2], s4[3]));
         st4(po, make_float4(o4[0], o4[1], o4[2], o4[3]));
+        st4(pb, make_float4(b4[0], b4[1], b4[2], b4[3]));
       }
     }
   }
 }
 
-// dscale[b,f] = sum over blocks of partial[blk,b,0,f]; doffset likewise (fixed order).
-// grid (ceil(F/64), nb*2), 1024 threads = 16 groups x 64 features: each group sums a
-// strided subset of the partial rows, LDS combines the groups in a fixed order.
+// dscale[b,f] = sum over blocks of partial[blk,b,0,f]; doffset (kind 1) and dbias (kind 2)
+// likewise, in a fixed order.  grid (ceil(F/64), nb*3), 1024 threads = 16 groups x 64
+// features: each group sums a strided subset of the partial rows, LDS combines the groups.
 __global__ void act_norm_finish_kernel(const float *__restrict__ partial, uint32_t nblocks, int nb, uint32_t F,
-                                       float *__restrict__ dscale, float *__restrict__ doffset) {
+                                       float *__restrict__ dscale, float *__restrict__ doffset,
+                                       float *__restrict__ dbias) {
   __shared__ float red[16][64];
   const uint32_t fl = threadIdx.x & 63u, g = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * 64 + fl;
-  const uint32_t b = blockIdx.y >> 1, kind = blockIdx.y & 1u;
+  const uint32_t b = blockIdx.y / 3, kind = blockIdx.y % 3;
+  float *dst = kind == 0 ? dscale : (kind == 1 ? doffset : dbias);
+  if (!dst) return;
   float acc = 0.f;
   if (f < F)
-    for (uint32_t k = g; k < nblocks; k += 16) acc += partial[(((size_t)k * nb + b) * 2 + kind) * F + f];
+    for (uint32_t k = g; k < nblocks; k += 16) acc += partial[(((size_t)k * nb + b) * 3 + kind) * F + f];
   red[g][fl] = acc;
   __syncthreads();
   if (g == 0 && f < F) {
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; q++) s += red[q][fl];
-    (kind ? doffset : dscale)[(size_t)b * F + f] = s;
+    dst[(size_t)b * F + f] = s;
   }
 }
 
@@ -441,38 +451,44 @@ __global__ void act_norm_generic_kernel(ActNormParams p) {
     for (uint32_t s0 = 0; s0 < p.F; s0 += p.seg) {
       for (int b = 0; b < p.nb; b++) {
         const float *z = p.Z[b] + (int64_t)r * p.ldz[b] + s0;
+        const float *bi = p.bias[b] ? p.bias[b] + s0 : nullptr;
+#define SHD_ZB(k) (z[k] + (bi ? bi[k] : 0.f))
         float sum = 0.f;
-        for (uint32_t k = lane; k < p.seg; k += 64) sum += act_fwd(p.act[b], z[k]);
+        for (uint32_t k = lane; k < p.seg; k += 64) sum += act_fwd(p.act[b], SHD_ZB(k));
         const float mean = wave_reduce_sum_f(sum) * inv_seg;
         float sq = 0.f;
-        for (uint32_t k = lane; k < p.seg; k += 64) { const float d = act_fwd(p.act[b], z[k]) - mean; sq += d * d; }
+        for (uint32_t k = lane; k < p.seg; k += 64) { const float d = act_fwd(p.act[b], SHD_ZB(k)) - mean; sq += d * d; }
         const float rstd = rsqrtf(wave_reduce_sum_f(sq) * inv_seg + p.eps);
         const float *sc = p.scale + (size_t)b * p.F + s0, *of = p.offset + (size_t)b * p.F + s0;
         if (!BWD) {
           float *o = p.out + (int64_t)r * p.ldo + s0;
           for (uint32_t k = lane; k < p.seg; k += 64) {
-            const float y = ((act_fwd(p.act[b], z[k]) - mean) * sc[k] * rstd + of[k]) * p.out_scale;
+            const float y = ((act_fwd(p.act[b], SHD_ZB(k)) - mean) * sc[k] * rstd + of[k]) * p.out_scale;
             o[k] = (b == 0) ? y : o[k] + y;
           }
         } else {
           const float *dy = p.dout + (int64_t)r * p.lddo + s0;
           float a1 = 0.f, a2 = 0.f;
           for (uint32_t k = lane; k < p.seg; k += 64) {
-            const float xh = (act_fwd(p.act[b], z[k]) - mean) * rstd;
+            const float xh = (act_fwd(p.act[b], SHD_ZB(k)) - mean) * rstd;
             const float g = dy[k] * p.out_scale;
             atomicAdd(p.dscale + (size_t)b * p.F + s0 + k, g * xh);
             atomicAdd(p.doffset + (size_t)b * p.F + s0 + k, g);
             a1 += g * sc[k]; a2 += g * sc[k] * xh;
           }
           const float m1 = wave_reduce_sum_f(a1) * inv_seg, m2 = wave_reduce_sum_f(a2) * inv_seg;
-          if (p.dZ[b]) {
-            float *dz = p.dZ[b] + (int64_t)r * p.lddz[b] + s0;
+          if (p.dZ[b] || p.dbias) {
+            float *dz = p.dZ[b] ? p.dZ[b] + (int64_t)r * p.lddz[b] + s0 : nullptr;
             for (uint32_t k = lane; k < p.seg; k += 64) {
-              const float h = act_fwd(p.act[b], z[k]);
+              const float zz = SHD_ZB(k);
+              const float h = act_fwd(p.act[b], zz);
               const float xh = (h - mean) * rstd;
-              dz[k] = rstd * (dy[k] * p.out_scale * sc[k] - m1 - xh * m2) * act_bwd(p.act[b], z[k], h);
+              const float v = rstd * (dy[k] * p.out_scale * sc[k] - m1 - xh * m2) * act_bwd(p.act[b], zz, h);
+              if (dz) dz[k] = v;
+              if (p.dbias) atomicAdd(p.dbias + (size_t)b * p.F + s0 + k, v);
             }
           }
+#undef SHD_ZB
         }
       }
     }
@@ -600,6 +616,7 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
     if (bwd && p.dZ[b]) vec = vec && aligned16(p.dZ[b]) && (p.lddz[b] % 4 == 0);
   }
   vec = vec && aligned16(p.scale) && aligned16(p.offset);
+  for (int b = 0; b < p.nb; b++) if (p.bias[b]) vec = vec && aligned16(p.bias[b]);
   if (!bwd) vec = vec && aligned16(p.out) && (p.ldo % 4 == 0);
   else vec = vec && aligned16(p.dout) && (p.lddo % 4 == 0);
   if (lpr < 4) vec = false;
@@ -609,8 +626,8 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
     if (bwd) {                                                                                             \
       if (p.nb == 1) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true, 1>), dim3(g), dim3(kBlock), 0, st, p); \
       else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true, 2>), dim3(g), dim3(kBlock), 0, st, p);       \
-      hipLaunchKernelGGL(act_norm_finish_kernel, dim3((p.F + 63) / 64, p.nb * 2), dim3(1024), 0, st,       \
-                         p.partial, g, p.nb, p.F, p.dscale, p.doffset);                                    \
+      hipLaunchKernelGGL(act_norm_finish_kernel, dim3((p.F + 63) / 64, p.nb * 3), dim3(1024), 0, st,       \
+                         p.partial, g, p.nb, p.F, p.dscale, p.doffset, p.dbias);                           \
     } else if (p.nb == 1) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false, 1>), dim3(g), dim3(kBlock), 0, st, p); \
     else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false, 2>), dim3(g), dim3(kBlock), 0, st, p);        \
   } while (0)
@@ -636,6 +653,7 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
     if (bwd) {
       SHD_HIP(hipMemsetAsync(p.dscale, 0, (size_t)p.nb * p.F * 4, st));
       SHD_HIP(hipMemsetAsync(p.doffset, 0, (size_t)p.nb * p.F * 4, st));
+      if (p.dbias) SHD_HIP(hipMemsetAsync(p.dbias, 0, (size_t)p.nb * p.F * 4, st));
     }
     if (bwd) hipLaunchKernelGGL(act_norm_generic_kernel<true>, dim3(g), dim3(kBlock), 0, st, p);
     else hipLaunchKernelGGL(act_norm_generic_kernel<false>, dim3(g), dim3(kBlock), 0, st, p);
@@ -654,8 +672,8 @@ static int act_norm_check(int nb, uint32_t F, uint32_t seg, const float *const *
   return SG_OK;
 }
 
-extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
-                               const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                               const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, float *d_out, int64_t ldo, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
@@ -663,17 +681,17 @@ extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *l
   if (n == 0) return SG_OK;
   ActNormParams p;
   memset(&p, 0, sizeof(p));
-  for (int b = 0; b < nb; b++) { p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; }
+  for (int b = 0; b < nb; b++) { p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.bias[b] = d_bias ? d_bias[b] : nullptr; }
   p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
   p.out_scale = out_scale; p.eps = 1e-9f; p.out = d_out; p.ldo = ldo;
   return act_norm_launch(p, false, (hipStream_t)stream_);
 }
 
-extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const int *act,
-                               const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                               const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
-                               float *d_doffset, float *d_partial, void *stream_) {
+                               float *d_doffset, float *d_dbias, float *d_partial, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
   if (!d_scale || !d_offset || !d_dout || !d_dscale || !d_doffset || !d_dZ)
@@ -682,15 +700,17 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
   if (n == 0) {
     SHD_HIP(hipMemsetAsync(d_dscale, 0, (size_t)nb * F * 4, st));
     SHD_HIP(hipMemsetAsync(d_doffset, 0, (size_t)nb * F * 4, st));
+    if (d_dbias) SHD_HIP(hipMemsetAsync(d_dbias, 0, (size_t)nb * F * 4, st));
     return SG_OK;
   }
   if (!d_partial) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: null partial buffer");
   ActNormParams p;
   memset(&p, 0, sizeof(p));
   for (int b = 0; b < nb; b++) {
-    p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b];
+    p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.bias[b] = d_bias ? d_bias[b] : nullptr;
     p.dZ[b] = d_dZ[b]; p.lddz[b] = lddz ? lddz[b] : 0;
   }
+  p.dbias = d_dbias;
   p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
   p.out_scale = out_scale; p.eps = 1e-9f; p.dout = d_dout; p.lddo = lddo;
   p.dscale = d_dscale; p.doffset = d_doffset; p.partial = d_partial;

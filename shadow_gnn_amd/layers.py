@@ -81,6 +81,13 @@ class shaDowLayer(nn.Module):
     def spmm(self, adj, X):
         return ops.spmm(adj, X)
 
+    def f_lin_act_norm(self, Xs, lins, acts):
+        """sum_b norm_b(act_b(lin_b(X_b))): Linear (rocBLAS) + bias/act/norm/add (one HIP kernel),
+        one autograd node with fused bias / scale / offset gradients."""
+        if self.norm == 'norm_feat':
+            return ops.linear_act_norm(Xs, lins, acts, self.scale, self.offset)
+        return self.f_act_norm([ops.linear(x, l) for x, l in zip(Xs, lins)], acts)
+
     def f_act_norm(self, Zs, acts, seg=None, out_scale=1.0):
         """sum_b norm_b(act_b(Z_b)) * out_scale -- the reference's act + f_norm + add
         sequence (layers.py:435, :476-483, :620-625) in one kernel."""
@@ -117,7 +124,7 @@ class MLP(shaDowLayer):
 
     def forward(self, feat_in):
         feat_in = self.f_dropout(feat_in)
-        return self.f_act_norm([self.f_lin(feat_in)], [self.act_name])
+        return self.f_lin_act_norm([feat_in], [self.f_lin], [self.act_name])
 
     def complexity(self, dims_x):
         assert dims_x.num_feats == self.f_lin.weight.shape[1]
@@ -142,8 +149,7 @@ class GCN(shaDowLayer):
             assert adj is None or isinstance(adj, ops.NormAdj)
             adj_norm = adj
         feat_aggr = self.spmm(adj_norm, feat_in)
-        feat_trans = self.f_lin(feat_aggr)
-        feat_out = self.f_act_norm([feat_trans], [self.act_name])
+        feat_out = self.f_lin_act_norm([feat_aggr], [self.f_lin], [self.act_name])
         return feat_out, adj_norm, True, 0.
 
     def complexity(self, dims_x, dims_adj):
@@ -169,8 +175,8 @@ class GraphSAGE(shaDowLayer):
             adj_norm = adj
         feat_in = self.f_dropout(feat_in)
         feat_neigh = self.spmm(adj_norm, feat_in)
-        feat_out = self.f_act_norm(
-            [self.f_lin_self(feat_in), self.f_lin_neigh(feat_neigh)], [self.act_name, self.act_name])
+        feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],
+                                       [self.act_name, self.act_name])
         return feat_out, adj_norm, True, 0.
 
     def complexity(self, dims_x, dims_adj):
@@ -255,8 +261,8 @@ class ResPool(nn.Module):
                 feat_pool = self.f_residue([self._pool(f, sizes_subg) for f in feats_in_l])
                 feat_root = self.f_residue([f[idx_targets] for f in feats_in_l])
             feat_in = torch.cat([self.aggr_target_emb(feat_root), feat_pool], dim=1)
-        z = self.nn(feat_in)                                   # dropout -> Linear (act fused below)
-        return ops.act_norm([z], [self.act_name], self.scale, self.offset)   # layers.py:114-118,199
+        # dropout -> Linear -> act -> norm (layers.py:110,114-118,199)
+        return ops.linear_act_norm([self.nn[0](feat_in)], [self.nn[1]], [self.act_name], self.scale, self.offset)
 
 
 class GAT(shaDowLayer):
@@ -285,8 +291,8 @@ class GAT(shaDowLayer):
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self._adj_norm(adj, is_normed, feat_in.device, dropedge=dropedge)
         feat_in = self.f_dropout(feat_in)
-        z_self = self.f_lin[0](feat_in)
-        z_neigh = self.f_lin[1](feat_in)
+        z_self = ops.linear(feat_in, self.f_lin[0])
+        z_neigh = ops.linear(feat_in, self.f_lin[1])
         # neigh branch: act -> per-head attention aggregate; both branches normalised per head slice
         feat_neigh = ops_gat.gat_aggregate(adj_norm, z_self, z_neigh, self.attention, self.act_name,
                                            self.mulhead)

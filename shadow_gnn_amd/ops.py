@@ -268,6 +268,39 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
+def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale):
+    nb = len(Zs)
+    n, F = Zs[0].shape
+    out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
+    ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
+    ac = (C.c_int * nb)(*codes)
+    with _timed(f"act_norm_fwd_nb{nb}_F{F}", (nb + 1) * 4 * n * F, out.device):
+        check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
+                                          n, F, seg, out_scale, out.data_ptr(), out.stride(0), _stream(out)))
+    return out
+
+
+def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias):
+    nb = len(Zs)
+    n, F = Zs[0].shape
+    dev = sc.device
+    dout = _f32c(dout)
+    dZs = [torch.empty_like(z) if nd else None for z, nd in zip(Zs, need_dz)]
+    dsc = torch.empty(nb, F, dtype=torch.float32, device=dev)
+    dof = torch.empty(nb, F, dtype=torch.float32, device=dev)
+    dbi = torch.empty(nb, F, dtype=torch.float32, device=dev) if want_dbias else None
+    partial = torch.empty(2048 * nb * 3 * F, dtype=torch.float32, device=dev)
+    ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
+    ldd = (C.c_int64 * nb)(*[(d.stride(0) if d is not None else 0) for d in dZs])
+    ac = (C.c_int * nb)(*codes)
+    with _timed(f"act_norm_bwd_nb{nb}_F{F}", (2 * nb + 1) * 4 * n * F, dev):
+        check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
+                                          n, F, seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs), ldd,
+                                          dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
+                                          partial.data_ptr(), _stream(dout)))
+    return dZs, dsc, dof, dbi
+
+
 class _ActNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scale, offset, acts, seg, out_scale, *Zs):
@@ -277,12 +310,7 @@ class _ActNorm(torch.autograd.Function):
         n, F = Zs[0].shape
         sc = scale.reshape(nb, F).contiguous().float()
         of = offset.reshape(nb, F).contiguous().float()
-        out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
-        ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
-        ac = (C.c_int * nb)(*acts)
-        with _timed(f"act_norm_fwd_nb{nb}_F{F}", (nb + 1) * 4 * n * F, out.device):
-            check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
-                                              seg, out_scale, out.data_ptr(), out.stride(0), _stream(out)))
+        out = _an_fwd(Zs, [None] * nb, acts, sc, of, seg, out_scale)
         ctx.save_for_backward(sc, of, *Zs)
         ctx.meta = (acts, seg, out_scale, scale.shape, offset.shape)
         return out
@@ -292,22 +320,101 @@ class _ActNorm(torch.autograd.Function):
         sc, of, *Zs = ctx.saved_tensors
         acts, seg, out_scale, sshape, oshape = ctx.meta
         nb = len(Zs)
-        n, F = Zs[0].shape
-        dout = _f32c(dout)
         need = ctx.needs_input_grad[5:5 + nb]
-        dZs = [torch.empty_like(z) if nd else None for z, nd in zip(Zs, need)]
-        dsc = torch.empty(nb, F, dtype=torch.float32, device=sc.device)
-        dof = torch.empty(nb, F, dtype=torch.float32, device=sc.device)
-        partial = torch.empty(2048 * nb * 2 * F, dtype=torch.float32, device=sc.device)
-        ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
-        ldd = (C.c_int64 * nb)(*[(d.stride(0) if d is not None else 0) for d in dZs])
-        ac = (C.c_int * nb)(*acts)
-        with _timed(f"act_norm_bwd_nb{nb}_F{F}", (2 * nb + 1) * 4 * n * F, dout.device):
-            check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, ac, sc.data_ptr(), of.data_ptr(), n, F,
-                                              seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs),
-                                              ldd, dsc.data_ptr(), dof.data_ptr(), partial.data_ptr(),
-                                              _stream(dout)))
+        dZs, dsc, dof, _ = _an_bwd(Zs, [None] * nb, acts, sc, of, seg, out_scale, dout, need, False)
         return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, *dZs)
+
+
+def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
+    """dW = dZ^T X for tall inputs (K = number of batch nodes, hundreds of thousands).
+    rocBLAS picks a 32-workgroup kernel for a plain 256 x n x 256 product; splitting n
+    into a batched GEMM fills the chip (2x faster on MI355X) and the partial sums add
+    in a fixed order."""
+    n, Fo = dZ.shape
+    Fi = X.shape[1]
+    if n < 32768:
+        return dZ.t() @ X
+    S = min(256, max(2, n // 2048))
+    c = n // S
+    dW = torch.bmm(dZ[:S * c].view(S, c, Fo).transpose(1, 2), X[:S * c].view(S, c, Fi)).sum(0)
+    if S * c < n:
+        dW += dZ[S * c:].t() @ X[S * c:]
+    return dW
+
+
+class _Linear(torch.autograd.Function):
+    """nn.Linear with the split-K weight gradient."""
+    @staticmethod
+    def forward(ctx, X, W, b):
+        X = _f32c(X).contiguous()
+        ctx.save_for_backward(X, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, X, W.t()) if b is not None else X @ W.t()
+
+    @staticmethod
+    def backward(ctx, dZ):
+        X, W = ctx.saved_tensors
+        dZ = _f32c(dZ).contiguous()
+        dX = dZ @ W if ctx.needs_input_grad[0] else None
+        dW = weight_grad(dZ, X) if ctx.needs_input_grad[1] else None
+        db = dZ.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dX, dW, db
+
+
+def linear(X, lin: "torch.nn.Linear"):
+    return _Linear.apply(X, lin.weight, lin.bias)
+
+
+class _LinearActNorm(torch.autograd.Function):
+    """out = out_scale * sum_b norm_b(act_b(X_b W_b^T + bias_b)): the dense tail of a
+    GCN / GraphSAGE / MLP layer as ONE autograd node.  GEMMs on rocBLAS (MFMA); bias add,
+    activation, normalisation, branch sum and -- in backward -- dZ, dscale, doffset AND the
+    bias gradients come from one HIP kernel pass each."""
+    @staticmethod
+    def forward(ctx, scale, offset, acts, seg, out_scale, nb, *t):
+        Xs = [_f32c(x).contiguous() for x in t[:nb]]
+        Ws = list(t[nb:2 * nb])
+        bs = list(t[2 * nb:3 * nb])
+        _need_cuda(scale, offset, *Xs, *Ws)
+        F = Ws[0].shape[0]
+        sc = scale.reshape(nb, F).contiguous().float()
+        of = offset.reshape(nb, F).contiguous().float()
+        Zs = [x @ w.t() for x, w in zip(Xs, Ws)]
+        bsc = [b.detach().contiguous() if b is not None else None for b in bs]
+        out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale)
+        ctx.save_for_backward(sc, of, *Xs, *Ws, *Zs, *[b if b is not None else sc.new_empty(0) for b in bsc])
+        ctx.meta = (acts, seg, out_scale, nb, scale.shape, offset.shape, [b is not None for b in bs])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        acts, seg, out_scale, nb, sshape, oshape, has_b = ctx.meta
+        sv = ctx.saved_tensors
+        sc, of = sv[0], sv[1]
+        Xs, Ws, Zs, bs = sv[2:2 + nb], sv[2 + nb:2 + 2 * nb], sv[2 + 2 * nb:2 + 3 * nb], sv[2 + 3 * nb:2 + 4 * nb]
+        biases = [b if hb else None for b, hb in zip(bs, has_b)]
+        dZs, dsc, dof, dbi = _an_bwd(list(Zs), biases, acts, sc, of, seg, out_scale, dout, [True] * nb, any(has_b))
+        ng = ctx.needs_input_grad
+        dXs = [dz @ w if ng[6 + i] else None for i, (dz, w) in enumerate(zip(dZs, Ws))]
+        dWs = [weight_grad(dz, x) if ng[6 + nb + i] else None for i, (dz, x) in enumerate(zip(dZs, Xs))]
+        dbs = [dbi[i] if (has_b[i] and ng[6 + 2 * nb + i]) else None for i in range(nb)]
+        return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, *dXs, *dWs, *dbs)
+
+
+def linear_act_norm(Xs: List[torch.Tensor], lins: Sequence["torch.nn.Linear"], acts: Sequence[str],
+                    scale: torch.Tensor, offset: torch.Tensor, seg: Optional[int] = None,
+                    out_scale: float = 1.0) -> torch.Tensor:
+    """Fused dense tail of a layer: sum_b norm_b(act_b(lin_b(X_b))) * out_scale
+    (nn.Linear + act + _f_norm_feat + add; shaDow/layers.py:434-435, :476-483, :393-394)."""
+    codes = []
+    for a in acts:
+        if a not in ACT_CODE:
+            raise NotImplementedError(f"activation {a!r} is not available in the fused HIP kernel")
+        codes.append(ACT_CODE[a])
+    F = lins[0].weight.shape[0]
+    nb = len(Xs)
+    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, *Xs,
+                                *[l.weight for l in lins], *[l.bias for l in lins])
 
 
 def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, offset: torch.Tensor,
