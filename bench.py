@@ -48,6 +48,13 @@ WORKLOADS = {
     "arxiv-khop-gcn3": dict(shape="arxiv", sampler=dict(method="khop", depth=2, budget=20, add_self_edge=True),
                             aggr="gcn", layers=3, dim=256, act="elu", heads=1, aug=("hops",), batch=32,
                             dropout=0.25, dropedge=0.15, lr=2e-5),
+    # BASELINE.json configs[2]: products, PPR top-k=200, SAGE-5 + mean pool (config_train/products/vanilla/sage_5_ppr.yml;
+    # residue max + pooling mean per SURVEY.md 8(d)); the PPR table of the benchmark roots is built on the GPU
+    # (sg_ppr_push) before the timed region, as the reference builds it once per run
+    "products-ppr-sage5": dict(shape="products", sampler=dict(method="ppr", k=200, threshold=0.0, add_self_edge=False),
+                               aggr="sage", layers=5, dim=256, act="relu", heads=1, aug=(), batch=1024,
+                               dropout=0.4, dropedge=0.05, lr=0.002, residue="max", pooling="mean",
+                               ppr=dict(alpha=0.85, epsilon=1e-5)),
     # BASELINE.json configs[3] shape (k-hop depth 3, GAT-5, 4 heads)
     "products-khop3-gat5": dict(shape="products", sampler=dict(method="khop", depth=3, budget=20, add_self_edge=True),
                                 aggr="gat", layers=5, dim=256, act="elu", heads=4, aug=(), batch=64,
@@ -63,8 +70,8 @@ def sampler_alg_bytes(c, with_hop):
     outputs (node 4n, indptr 4(n+1), indices + edge id 8e, hop 4n)."""
     n, e = c["n_tot"], c["e_tot"]
     D = c["slots_scanned"] - n
-    return (8 * c["frontier_nodes"] + 4 * c["frontier_reads"] + 8 * n + 4 * D + 4 * n + 4 * (n + 1) + 8 * e
-            + (4 * n if with_hop else 0))
+    return (8 * c["frontier_nodes"] + 4 * c["frontier_reads"] + 8 * c.get("ppr_reads", 0) + 8 * n + 4 * D + 4 * n
+            + 4 * (n + 1) + 8 * e + (4 * n if with_hop else 0))
 
 
 def cpu_baseline(indptr_host, indices_host, roots, scfg, seed, budget_s=20.0):
@@ -148,10 +155,19 @@ def main():
     mb.epoch_start_reset(0, TRAIN)
     mb.shuffle_entity(TRAIN, perm=np.arange(roots_all.size))
     hs = mb.graph_sampler[TRAIN]
+    ppr_info = None
+    if wl["sampler"]["method"] == "ppr":
+        from shadow_gnn_amd.ppr import ppr_approximate_device
+        uniq = np.unique(mb.entity_epoch[TRAIN]).astype(np.uint32)
+        torch.cuda.synchronize(dev); tp0 = time.perf_counter()
+        ln, nb, sc = ppr_approximate_device(hs, uniq, wl["sampler"]["k"], wl["ppr"]["alpha"], wl["ppr"]["epsilon"])
+        torch.cuda.synchronize(dev); tp = time.perf_counter() - tp0
+        hs.set_ppr(uniq, ln, nb, sc)
+        ppr_info = dict(targets=int(uniq.size), seconds=round(tp, 3), targets_per_sec=round(uniq.size / tp, 1))
     torch.manual_seed(4)
     arch = dict(num_layers=wl["layers"], num_cls_layers=1, heads=wl["heads"], dim=wl["dim"], act=wl["act"],
-                layer_norm="norm_feat", feature_augment_ops="sum", aggr=wl["aggr"], residue="none",
-                pooling="center", loss="softmax")
+                layer_norm="norm_feat", feature_augment_ops="sum", aggr=wl["aggr"], residue=wl.get("residue", "none"),
+                pooling=wl.get("pooling", "center"), loss="softmax")
     aug_feat = [(a, mb.get_aug_dim(a)) for a in aug]
     model = DeepGNN(F0, F0, C, 0, arch, aug_feat, 1, dict(dropout=wl["dropout"], dropedge=wl["dropedge"], lr=wl["lr"]),
                     "node").to(dev)
@@ -211,6 +227,9 @@ def main():
     kern = timer.summary()
     with_hop = "hops" in aug
     s_ms = [c["sample_kernel_ms"] for c in counts if c["sample_kernel_ms"] > 0]
+    if wl["sampler"]["method"] == "ppr":       # 8 B (neighbour id + score) per selected table entry
+        for c in counts:
+            c["ppr_reads"] = c["n_tot"]
     s_bytes = [sampler_alg_bytes(c, with_hop) for c in counts]
     if s_ms:
         kern["sg_sample_lds_kernel"] = dict(launches=len(s_ms), total_ms=float(sum(s_ms)), avg_ms=float(np.mean(s_ms)),
@@ -238,7 +257,7 @@ def main():
     ns_ms = sum(kern[k]["total_ms"] for k in ns_keys)
     ns_by = sum(kern[k]["bytes_per_launch"] * kern[k]["launches"] for k in ns_keys)
     cb = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and wl["sampler"]["method"] == "khop":
         ip = indptr.cpu().numpy().view(np.uint32); ix = indices.cpu().numpy().view(np.uint32)
         cb = cpu_baseline(ip, ix, roots_all, wl["sampler"], seed=3)
     line = {
@@ -251,7 +270,8 @@ def main():
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
                                f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",
                    "global_batch": B * world, "parallelism": f"dp{world}",
-                   "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4)},
+                   "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4),
+                   "ppr_preproc": ppr_info},
         "roofline": roofline,
         "north_star_sample_gather_aggregate": {"achieved": round(ns_by / 1e9 / (ns_ms / 1e3), 1) if ns_ms else 0.0,
                                                "unit": "GB/s", "frac": round(ns_by / 1e9 / (ns_ms / 1e3) / HBM_PEAK_GBS, 4) if ns_ms else 0.0,

@@ -153,6 +153,20 @@ int sg_load_ppr_bin(sg_sampler *s, const char *path_neighs, const char *path_sco
                     float alpha, float epsilon);
 int sg_save_ppr_bin(const sg_sampler *s, const char *path_neighs, const char *path_scores, int k,
                     float alpha, float epsilon);
+/* Approximate PPR by lazy-walk push, one wavefront per target, bit-exact with
+ * ParallelSampler::preproc_ppr_approximate (.cpp:237-318): for every target the
+ * touched set {(node, pi)} is appended to out_node / out_score at
+ * out_offset[t] (out_count[t] entries, unordered); the caller orders them by
+ * (-score, id) and keeps k (.cpp:320-339).  `alpha` is the user-facing value
+ * (flipped to 1-alpha inside, .cpp:242).  hash_slots = per-target table size
+ * (power of two), num_waves = targets in flight (multiple of 4), d_work >=
+ * num_waves*hash_slots*21 + 256 bytes.  Synchronises the stream; SG_ERR_CAPACITY
+ * when a table or the output list is too small (*h_total = entries needed).   */
+int sg_ppr_push(const uint32_t *d_indptr, const uint32_t *d_indices, uint32_t num_nodes,
+                const uint32_t *d_targets, uint32_t num_targets, float alpha, float epsilon,
+                uint32_t hash_slots, uint32_t num_waves, void *d_work, uint64_t work_bytes,
+                uint32_t *d_out_count, uint64_t *d_out_offset, uint32_t *d_out_node, float *d_out_score,
+                uint64_t cap_out, uint64_t *h_total, uint32_t *h_flags, void *stream);
 /* ParallelSampler::drop_full_graph_info (.cpp:22-34). */
 int sg_drop_full_graph_info(sg_sampler *s);
 

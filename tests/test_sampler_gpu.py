@@ -234,3 +234,55 @@ def test_reference_compatible_surface():
     assert ps.get_idx_root() == 0
     with pytest.raises(KeyError):
         ps.parallel_sampler_ensemble([{"num_roots": "1"}, cfgs[1]], [set(), set()])
+
+
+def test_ppr_push_kernel_matches_reference_tables_and_oracle():
+    """sg_ppr_push (one wavefront per target) vs (a) the reference's own cache-file contents in the
+    golden fixtures and (b) the CPU oracle on a larger graph: neighbours exact, scores bit-exact."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.ppr import ppr_approximate_device
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    n_rows = 0
+    for name in SAMPLER_FIXTURES:
+        fx = Fixture(name)
+        hs = _make(fx.indptr, fx.indices)
+        for case in fx.cases:
+            if case["cfg"]["method"] != "ppr":
+                continue
+            targets, ln, nb, sc = fx.ppr_table(case["idx"])
+            p = case["ppr"]
+            gl, gn, gs = ppr_approximate_device(hs, targets, p["k"], p["alpha"], p["epsilon"], hash_slots=1 << 10, num_waves=64)
+            assert np.array_equal(gl, ln), (name, case["idx"])
+            for i in range(targets.size):
+                L = int(ln[i])
+                assert np.array_equal(gn[i, :L], nb[i, :L]), (name, case["idx"], i)
+                assert np.array_equal(gs[i, :L].view(np.uint32), sc[i, :L].view(np.uint32)), (name, case["idx"], i)
+                n_rows += 1
+    assert n_rows > 50
+    indptr, indices = make_graph_numpy(20000, 14, seed=5)
+    targets = np.random.default_rng(0).permutation(20000)[:300].astype(np.uint32)
+    ref = so.ppr_approximate(indptr, indices, targets, k=100, alpha=0.85, epsilon=1e-5, num_threads=8)
+    hs = _make(indptr, indices)
+    gl, gn, gs = ppr_approximate_device(hs, targets, 100, 0.85, 1e-5, hash_slots=1 << 12, num_waves=256)   # small table: exercises the grow path
+    assert np.array_equal(gl, ref.len)
+    for i in range(targets.size):
+        L = int(gl[i])
+        assert np.array_equal(gn[i, :L], ref.neigh[i, :L]) and np.array_equal(gs[i, :L].view(np.uint32), ref.score[i, :L].view(np.uint32)), i
+    # end to end through the reference-compatible surface: compute, write cache files, reload, sample
+    import tempfile, os
+    from shadow_gnn_amd.sampler import ParallelSampler
+    with tempfile.TemporaryDirectory() as td:
+        fn, fs = os.path.join(td, "neighs.bin"), os.path.join(td, "scores.bin")
+        ps = ParallelSampler(indptr, indices, [], 100, 4, True, True, [], 1, "", "", "", 0)
+        ps.preproc_ppr_approximate(targets, 100, 0.85, 1e-5, fn, fs)
+        assert os.path.getsize(fn) > 16 and os.path.getsize(fs) > 16
+        ps2 = ParallelSampler(indptr, indices, [], 100, 4, True, True, [], 1, "", "", "", 0)
+        ps2.preproc_ppr_approximate(targets, 50, 0.85, 1e-5, fn, fs)       # k_file >= k: loaded, clipped to 50
+        ps2.shuffle_targets(targets[:100])
+        cfg = {"method": "ppr", "k": "50", "threshold": "0.0", "num_roots": "1", "add_self_edge": "true",
+               "include_target_conn": "false", "return_target_only": "false"}
+        out = ps2.parallel_sampler_ensemble([cfg], [{"pprs"}])[0]
+        refb = so.sample_batch(indptr, indices, targets[:100], method="ppr", k=50, add_self_edge=True, ppr=ref).split()
+        for p_ in range(100):
+            assert np.array_equal(np.asarray(out.get_subgraph_node()[p_]), refb[p_]["node"])
+            assert np.array_equal(np.asarray(out.get_subgraph_indices()[p_]), refb[p_]["indices"])
