@@ -23,3 +23,5 @@ print("per-subgraph cycles (mean / p50 / max):  n=%.0f slots=%.0f e=%.0f" % (buf
 for i, nm in enumerate(names):
     print("  %-16s %9.0f %9.0f %9.0f" % (nm, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
 print("  %-16s %9.0f %9.0f %9.0f" % ("total", st[:, 3].mean(), np.median(st[:, 3]), st[:, 3].max()))
+ft = buf[:, 12:16].astype(np.float64)
+print("  wave0 bulk-path buckets (mean cycles): other/build %.0f  load-wait %.0f  lookup %.0f  emit %.0f" % tuple(ft.mean(0)))

@@ -41,3 +41,23 @@ n, e, sl = tot_n / a.iters, tot_e / a.iters, tot_slots / a.iters
 byt = 4 * sl + 8 * n + 4 * n + 4 * (n + 1) + 8 * e + 4 * tot_fr / a.iters
 print(f"per call: {ms:.3f} ms (wall {dt/a.iters*1e3:.3f} ms)  n={n:.0f} e={e:.0f} slots={sl:.0f}  "
       f"nodes/s={n/(dt/a.iters):.3e}  alg GB/s={byt/(ms*1e-3)/1e9:.1f}  max_n={b.counts['max_subg_nodes']} max_e={b.counts['max_subg_edges']}")
+
+# ---- steady state: two sampler handles alternate so the GPU always has the next call queued
+# (a lone synchronous call per iteration leaves idle gaps and the clocks sag)
+hs2 = HipSampler(indptr, indices, device=dev, seed=3)
+hs2.shuffle_targets(roots)
+for h in (hs, hs2):
+    h.set_profiling(True)
+hs.sample_async(cfg, a.batch); hs2.sample_async(cfg, a.batch)
+ks, kr = [], []
+torch.cuda.synchronize(); t0 = time.time()
+for it in range(a.iters):
+    for h in (hs, hs2):
+        b = h.finish()
+        ks.append(b.counts["sample_kernel_ms"]); kr.append(b.counts["relocate_kernel_ms"])
+        h.sample_async(cfg, a.batch)
+torch.cuda.synchronize(); dt = time.time() - t0
+hs.finish(); hs2.finish()
+ks, kr = np.array(ks[4:]), np.array(kr[4:])
+print(f"pipelined: {dt/(2*a.iters)*1e3:.3f} ms/call wall; sample kernel {ks.mean():.3f} ms (min {ks.min():.3f}), relocate {kr.mean():.3f} ms "
+      f"-> sample-kernel alg GB/s {byt/(ks.mean()*1e-3)/1e9:.1f}")

@@ -253,6 +253,113 @@ __global__ void spmm_kernel(const uint32_t *__restrict__ indptr, const uint32_t 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Multi-row SpMM for F <= 256 (the hidden width of every config): one wavefront owns
+// R consecutive rows.  Subgraph rows are tiny (~2 edges), so a row-at-a-time kernel is a
+// chain of three dependent HBM round trips (indptr -> indices -> X rows) per row.  Here
+// the wave reads the R+1 row pointers and ALL edge ids of its rows with two coalesced
+// loads, moves the column ids to scalar registers (v_readlane) and issues up to KMAX
+// feature-row gathers (1 KiB each) back to back -- three round trips per R rows, KMAX KiB in
+// flight per wave.  Rows with more edges fall back to a streaming loop.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ float rl_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+template <int R, int KMAX>
+__global__ void spmm_rows_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                 const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
+                                 const float *__restrict__ row_scale, const float *__restrict__ col_scale,
+                                 const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
+                                 uint32_t n, uint32_t F) {
+  const uint32_t lane = lane_id();
+  // XCD-aware block order (the grid is a multiple of 8 blocks)
+  const uint32_t nb = gridDim.x, per = nb >> 3;
+  const uint32_t lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  const uint64_t gw = (uint64_t)lb * (kBlock / 64) + wave_id();
+  const uint64_t r0 = gw * R;
+  if (r0 >= n) return;
+  const uint32_t rows = (uint32_t)min((uint64_t)R, (uint64_t)n - r0);
+  const uint32_t f = lane * 4;
+  const bool on = f < F;
+  const uint32_t ipl = indptr[min(r0 + lane, (uint64_t)n)];        // lanes 0..R hold the row pointers
+  uint32_t ip[R + 1];
+#pragma unroll
+  for (int q = 0; q <= R; q++) ip[q] = rl_u32(ipl, q < (int)rows ? q : (int)rows);
+  const uint32_t e0 = ip[0], E = ip[R] - e0;
+  float4 acc[R];
+#pragma unroll
+  for (int q = 0; q < R; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (E <= (uint32_t)KMAX) {
+    uint32_t col = 0;
+    float wv = 0.f;
+    if (lane < E) {
+      col = indices[e0 + lane];
+      wv = 1.0f;
+      if (edge_w) wv = edge_w[edge_perm ? edge_perm[e0 + lane] : e0 + lane];
+      if (col_scale) wv *= col_scale[col];
+    }
+    float4 x[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((uint32_t)k < E) {                                        // uniform
+        const uint32_t c = rl_u32(col, k);
+        if (on) x[k] = ld4(X + (int64_t)c * ldx + f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      if ((uint32_t)k < E) {
+        const float wk = rl_f32(wv, k);
+        const uint32_t ek = e0 + k;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          if (ek >= ip[q] && ek < ip[q + 1]) {                      // uniform: edge k belongs to row q
+            acc[q].x += wk * x[k].x; acc[q].y += wk * x[k].y; acc[q].z += wk * x[k].z; acc[q].w += wk * x[k].w;
+          }
+        }
+      }
+    }
+  } else {
+    // long rows (hubs): stream the edges of each row, two gathers in flight
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      uint32_t p = ip[q];
+      const uint32_t b = ip[q + 1];
+      for (; p + 1 < b; p += 2) {
+        const uint32_t c0 = indices[p], c1 = indices[p + 1];
+        float w0 = 1.f, w1 = 1.f;
+        if (edge_w) { w0 = edge_w[edge_perm ? edge_perm[p] : p]; w1 = edge_w[edge_perm ? edge_perm[p + 1] : p + 1]; }
+        if (col_scale) { w0 *= col_scale[c0]; w1 *= col_scale[c1]; }
+        if (on) {
+          const float4 v0 = ld4(X + (int64_t)c0 * ldx + f), v1 = ld4(X + (int64_t)c1 * ldx + f);
+          acc[q].x += w0 * v0.x; acc[q].y += w0 * v0.y; acc[q].z += w0 * v0.z; acc[q].w += w0 * v0.w;
+          acc[q].x += w1 * v1.x; acc[q].y += w1 * v1.y; acc[q].z += w1 * v1.z; acc[q].w += w1 * v1.w;
+        }
+      }
+      if (p < b) {
+        const uint32_t c0 = indices[p];
+        float w0 = 1.f;
+        if (edge_w) w0 = edge_w[edge_perm ? edge_perm[p] : p];
+        if (col_scale) w0 *= col_scale[c0];
+        if (on) {
+          const float4 v0 = ld4(X + (int64_t)c0 * ldx + f);
+          acc[q].x += w0 * v0.x; acc[q].y += w0 * v0.y; acc[q].z += w0 * v0.z; acc[q].w += w0 * v0.w;
+        }
+      }
+    }
+  }
+  float rsl = 1.0f;
+  if (row_scale && lane < rows) rsl = row_scale[r0 + lane];
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    if ((uint32_t)q < rows && on) {
+      const float rs = row_scale ? rl_f32(rsl, q) : 1.0f;
+      st4(Y + (int64_t)(r0 + q) * ldy + f, make_float4(acc[q].x * rs, acc[q].y * rs, acc[q].z * rs, acc[q].w * rs));
+    }
+  }
+}
+
 // scalar fallback for F % 4 != 0
 __global__ void spmm_scalar_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                    const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
@@ -592,8 +699,13 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
                        d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F);
   } else if (F <= 32) { SHD_SPMM(8, 1); }
   else if (F <= 64) { SHD_SPMM(16, 1); }
-  else if (F <= 128) { SHD_SPMM(32, 1); }
-  else if (F <= 256) { SHD_SPMM(64, 1); }
+  else if (F <= 256) {
+    constexpr int R = 4, KMAX = 16;
+    const uint32_t waves = (n + R - 1) / R;
+    const uint32_t blocks = (((waves + (kBlock / 64) - 1) / (kBlock / 64)) + 7u) & ~7u;
+    hipLaunchKernelGGL((spmm_rows_kernel<R, KMAX>), dim3(blocks), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_w,
+                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F);
+  }
   else if (F <= 512) { SHD_SPMM(64, 2); }
   else { SHD_SPMM(64, 4); }
 #undef SHD_SPMM

@@ -661,15 +661,31 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
     const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
     const void *kfn = plain ? (const void *)sg_sample_lds_kernel<true> : (const void *)sg_sample_lds_kernel<false>;
-    if (L.total > 64 * 1024)
-      SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((L.total + 255) & ~(size_t)255)));
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
     uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));
     per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 7));
+    // Fewer resident workgroups run each subgraph faster (they share the CU's LDS pipe and issue
+    // slots): take the smallest residency that does not add a round of subgraphs.
+    {
+      uint32_t best = per_cu;
+      double best_cost = 1e30;
+      for (uint32_t pc = 1; pc <= per_cu; pc++) {
+        const uint32_t rounds = (P + (uint32_t)ncu * pc - 1) / ((uint32_t)ncu * pc);
+        const double cost = rounds * (1.0 + 0.11 * (pc - 1));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = pc; }
+      }
+      if (const char *e = getenv("SHADOW_SG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 7) best = std::min<uint32_t>(per_cu, (uint32_t)v); }
+      per_cu = best;
+    }
     const uint32_t grid = std::min<uint32_t>(P, (uint32_t)ncu * per_cu);
-    if (plain) hipLaunchKernelGGL(sg_sample_lds_kernel<true>, dim3(grid), dim3(T), L.total, stream, p);
-    else hipLaunchKernelGGL(sg_sample_lds_kernel<false>, dim3(grid), dim3(T), L.total, stream, p);
+    // ask for 1/per_cu of the CU's LDS so the dispatcher cannot pack more workgroups on one CU
+    // than intended (and leave other CUs short)
+    size_t lds_req = std::max<size_t>(L.total, ((size_t)(160 * 1024) / per_cu - 512) & ~(size_t)255);
+    if (lds_req > 64 * 1024)
+      SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req));
+    if (plain) hipLaunchKernelGGL(sg_sample_lds_kernel<true>, dim3(grid), dim3(T), lds_req, stream, p);
+    else hipLaunchKernelGGL(sg_sample_lds_kernel<false>, dim3(grid), dim3(T), lds_req, stream, p);
     SHD_HIP(hipGetLastError());
     // ---- big path for subgraphs that overflowed the LDS tables
     if (capn > capn_lds) {

@@ -36,17 +36,29 @@ constexpr uint32_t kLdsCapNodes = 2048;  // largest node set handled by the LDS 
 constexpr uint32_t kMaxRoots = 8;
 constexpr uint32_t kStash = 64;          // overflow entries behind the bucket array
 constexpr uint32_t kSortBuckets = 256;
+constexpr uint32_t kBitWords = 2048;     // membership filter: 64 Ki bits indexed by the low id bits
 
 // control words (LDS)
 enum { C_NNODES = 0, C_NF0 = 1, C_NF1 = 2, C_OVF = 3, C_MFAIL = 4, C_FRONT_NODES = 5,
-       C_FRONT_READS = 6, C_CHANGED = 7, C_M = 8, C_TICKET = 9, C_NSTASH = 10, C_WORDS = 16 };
+       C_FRONT_READS = 6, C_CHANGED = 7, C_M = 8, C_TICKET = 9, C_NSTASH = 10, C_MV = 11, C_WORDS = 16 };
 
 // per-subgraph result words in scratch (s_cnt)
 enum { R_N = 0, R_E = 1, R_FLAGS = 2, R_SLOTS = 3, R_FNODES = 4, R_FREADS = 5, R_T0 = 8, R_WORDS = 16 };
 #ifdef SHADOW_SG_TIMING
 #define SHD_STAMP(i) do { if (threadIdx.x == 0) res[R_T0 + (i)] = (uint32_t)(clock64() - t_begin); } while (0)
+// fine-grained scan timers (wave 0 only): SHD_T(k) adds the cycles since the previous stamp to bucket k
+#define SHD_TT(k) do { if (threadIdx.x == 0) { const uint64_t now_ = clock64(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+#if SHADOW_SG_TIMING == 2      // buckets over the generic path instead of the bulk path
+#define SHD_T(k) do {} while (0)
+#define SHD_G(k) SHD_TT(k)
+#else
+#define SHD_T(k) SHD_TT(k)
+#define SHD_G(k) do {} while (0)
+#endif
 #else
 #define SHD_STAMP(i) do {} while (0)
+#define SHD_T(k) do {} while (0)
+#define SHD_G(k) do {} while (0)
 #endif
 
 struct SampleParams {
@@ -102,6 +114,8 @@ struct Tables {
   uint32_t *lnext;   // [capm] bucket chains of the final sort
   uint32_t *bhead;   // [kSortBuckets]
   uint32_t *bcnt;    // [kSortBuckets]
+  unsigned char *wtmp;  // [waves * 128] wave-private scratch of the scan (LDS)
+  uint32_t *bits;    // [kBitWords] membership filter over the node set (LDS; aliases the frontiers)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -226,6 +240,18 @@ __device__ __forceinline__ void block_sort_u32(uint32_t *a, uint32_t n) {
   }
 }
 
+// membership-filter probe of one aligned quad: bit c = component c may be in the node set
+__device__ __forceinline__ uint32_t probe_quad(const uint32_t *bits, const uint4 c) {
+  const uint32_t w0 = bits[(c.x >> 5) & (kBitWords - 1u)];
+  const uint32_t w1 = bits[(c.y >> 5) & (kBitWords - 1u)];
+  const uint32_t w2 = bits[(c.z >> 5) & (kBitWords - 1u)];
+  const uint32_t w3 = bits[(c.w >> 5) & (kBitWords - 1u)];
+  return ((w0 >> (c.x & 31u)) & 1u) | (((w1 >> (c.y & 31u)) & 1u) << 1) |
+         (((w2 >> (c.z & 31u)) & 1u) << 2) | (((w3 >> (c.w & 31u)) & 1u) << 3);
+}
+
+__device__ __forceinline__ uint32_t rl_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __device__ __forceinline__ bool is_root(const uint32_t *roots, int R, uint32_t v) {
   bool r = false;
   for (int i = 0; i < R; i++) r |= (roots[i] == v);
@@ -265,11 +291,10 @@ __device__ __forceinline__ void emit_list(const Tables &t, uint32_t *ctrl, uint3
 }
 
 // Scan variant: entry q of a lane has key keybase+q (q even: self edge before
-// component q/2, q odd: regular edge of component q/2); the value (column sub
-// id) is only resolved here, inside the rarely taken branch.
+// component q/2 -> value myrow, q odd: regular edge of component q/2 -> value cols[q/2]).
 __device__ __forceinline__ void emit_scan(const Tables &t, uint32_t *ctrl, uint32_t capm,
                                           uint32_t mask, uint32_t keybase, uint32_t myrow,
-                                          const uint32_t (&sidx)[4]) {
+                                          const uint32_t (&cols)[4]) {
   const uint64_t any = __ballot(mask != 0);
   if (any == 0) return;
   const uint64_t lt = lanemask_lt();
@@ -287,7 +312,7 @@ __device__ __forceinline__ void emit_scan(const Tables &t, uint32_t *ctrl, uint3
   for (int q = 0; q < 8; q++) {
     if ((mask >> q) & 1u) {
       const uint32_t r = r0 + __popc(mask & ((1u << q) - 1u));
-      if (r < capm) { t.lkey[r] = keybase + q; t.lval[r] = (q & 1) ? t.hval[sidx[q >> 1]] : myrow; }
+      if (r < capm) { t.lkey[r] = keybase + q; t.lval[r] = (q & 1) ? cols[q >> 1] : myrow; }
     }
   }
 }
@@ -310,6 +335,8 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
   uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
 #ifdef SHADOW_SG_TIMING
   const uint64_t t_begin = clock64();
+  uint64_t tlast = t_begin;
+  uint32_t tacc[4] = {0, 0, 0, 0};
 #endif
 
   // ---- phase 0: clear tables
@@ -471,9 +498,21 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
     p.s_tgt[(size_t)s * kMaxRoots + tid] = t.hval[slot];
   }
   const uint32_t S = carry_s, Q = carry_q;
+  // membership filter for the streaming scan: bit (id mod 2^16) of every node.  A set bit is only a
+  // candidate (resolved exactly against the hash table after the scan); a clear bit is a definite miss.
+  for (uint32_t w = tid; w < kBitWords; w += T) t.bits[w] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += T) {
+    const uint32_t v = t.nodes[i];
+    atomicOr(&t.bits[(v >> 5) & (kBitWords - 1u)], 1u << (v & 31u));
+  }
+  __syncthreads();
   SHD_STAMP(1);   // sort + rank + prefixes done
 
   // ---- phase 4: streaming induction (.cpp:381-427)
+  unsigned char *wflag = t.wtmp + wave * 128u;      // wave-private: start flags per position
+  unsigned char *wsel = wflag + 64;                 //               k-th starting row -> lane
+  for (uint32_t i = tid; i < nw * 32u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
   const bool incl_self = !kPlain && (p.include_self != 0);
   const bool itc = kPlain || (p.include_target_conn != 0) || (R == 1);   // .cpp:356-358
   const bool compat = !kPlain && (p.compat != 0);
@@ -522,10 +561,10 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
               inserted = !(l3 < deg && p.indices[e0 + l3] == v);
             }
             if (!inserted && (uint64_t)e0 + deg < p.nnz) {              // .cpp:401-405
+              // (a neighbour candidate like any other: resolved and root-filtered after the scan)
               const uint32_t c = p.indices[e0 + deg];
-              const int32_t hs = tab_find(t.hkey, c, H, hshift, nstash);
-              if (hs >= 0 && (itc || !(is_root(roots, R, v) && is_root(roots, R, c)))) {
-                keys[1] = 2u * (rs + deg) + 1u; vals[1] = t.hval[hs]; mask |= 2u;
+              if ((t.bits[(c >> 5) & (kBitWords - 1u)] >> (c & 31u)) & 1u) {
+                keys[1] = 2u * (rs + deg) + 1u; vals[1] = c; mask |= 2u;
               }
             }
           }
@@ -533,7 +572,10 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
         emit_list<2>(t, ctrl, capm, mask, keys, vals);
       }
     }
-    // ---- the quad scan
+    // ---- the quad scan: stream every row's aligned 16-B quads, test each id against the membership
+    //      filter (one LDS dword per id, no branches) and append the rare candidates to the list:
+    //      key = 2*slot + kind; kind 1: neighbour candidate (value = its global id, resolved after the
+    //      scan), kind 0: inserted self edge (value = row).
     for (;;) {
       uint32_t tk = 0;
       if (lane == 0) tk = atomicAdd(&ctrl[C_TICKET], 1u);
@@ -549,6 +591,65 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
       }
       uint32_t row = lo, qpos = qa;   // wave-uniform walk state
       while (qpos < qb) {
+        // ---------------------------------------------------------------
+        // bulk path (plain variant): >= kUnroll*64 INTERIOR quads of one long row -- every
+        // component valid, one set of row scalars for the whole run, kUnroll 1-KiB loads in flight.
+        // ---------------------------------------------------------------
+        if (kPlain) {
+          const uint32_t qs_row = __builtin_amdgcn_readfirstlane(t.qptr[row]);
+          const uint32_t qe_row = __builtin_amdgcn_readfirstlane(t.qptr[row + 1]);
+          const uint32_t e0 = __builtin_amdgcn_readfirstlane(t.rowe0[row]);
+          const uint32_t rs = __builtin_amdgcn_readfirstlane(t.rowptr[row]);
+          const uint32_t deg = __builtin_amdgcn_readfirstlane(t.rowptr[row + 1]) - rs - 1u;
+          // interior quads: all four ids inside [e0, e0+deg)
+          const uint32_t q_first = qs_row + ((e0 & 3u) ? 1u : 0u);
+          const uint32_t q_last = qe_row - ((((e0 + deg) & 3u) && qe_row > qs_row) ? 1u : 0u);   // exclusive
+          const uint32_t lo_q = max(qpos, q_first), hi_q = min(min(q_last, qe_row), qb);
+          if (lo_q == qpos && hi_q > lo_q && hi_q - lo_q >= 64u * kUnroll) {
+            const uint32_t nrun = (hi_q - lo_q) / (64u * kUnroll);
+            for (uint32_t it = 0; it < nrun; it++) {
+              const uint32_t qbase = qpos + it * 64u * kUnroll;
+              uint4 c4[kUnroll];
+              SHD_T(0);
+#pragma unroll
+              for (int u = 0; u < kUnroll; u++) {
+                const uint32_t q = qbase + u * 64u + lane;
+                const uint32_t addr4 = ((e0 >> 2) + (q - qs_row)) << 2;
+                c4[u] = *reinterpret_cast<const uint4 *>(p.indices + addr4);
+              }
+#ifdef SHADOW_SG_TIMING
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+              SHD_T(1);
+              uint32_t hit = 0;        // bit (4u + c): component c of group u is a candidate
+#pragma unroll
+              for (int u = 0; u < kUnroll; u++) hit |= probe_quad(t.bits, c4[u]) << (4 * u);
+              SHD_T(2);
+              if (hit) {
+                uint32_t r = atomicAdd(&ctrl[C_M], (uint32_t)__popc(hit));
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+                  const uint32_t cc[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
+                  const uint32_t q = qbase + u * 64u + lane;
+                  const uint32_t j0 = (((e0 >> 2) + (q - qs_row)) << 2) - e0;
+#pragma unroll
+                  for (int c = 0; c < 4; c++) {
+                    if ((hit >> (4 * u + c)) & 1u) {
+                      if (r < capm) { t.lkey[r] = 2u * (rs + j0 + c) + 1u; t.lval[r] = cc[c]; }   // .cpp:420-422
+                      r++;
+                    }
+                  }
+                }
+              }
+              SHD_T(3);
+            }
+            qpos += nrun * 64u * kUnroll;
+            // (usually the row is not finished: its last quads go through the generic path)
+            while (row < n && __builtin_amdgcn_readfirstlane(t.qptr[row + 1]) <= qpos) row++;
+            continue;
+          }
+        }
+        SHD_G(0);
         uint32_t d_take[kUnroll], l_row[kUnroll], l_addr[kUnroll], l_e0[kUnroll], l_rs[kUnroll],
             l_deg[kUnroll], prevv[kUnroll];
         uint4 cand[kUnroll];
@@ -558,24 +659,29 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
           d_take[u] = 0; l_row[u] = 0; l_addr[u] = 0; l_e0[u] = 0; l_rs[u] = 0; l_deg[u] = 0; prevv[u] = 0;
           cand[u] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
           if (qpos < qb) {
-            const uint32_t qe_row = __builtin_amdgcn_readfirstlane(t.qptr[row + 1]);
-            const uint32_t lim = min(qe_row, qb);
-            const uint32_t rem = lim - qpos;
-            uint32_t take, myrow = row;
-            if (rem >= 48u || lim == qb) {
-              take = min(rem, 64u);                     // one row
-            } else {
-              // several short rows: per-lane search (empty rows have no quads)
-              take = min(64u, qb - qpos);
-              const uint32_t q = qpos + min(lane, take - 1u);
-              uint32_t l2 = row, h2 = n;
-              while (l2 < h2) {
-                const uint32_t mid = (l2 + h2) >> 1;
-                if (t.qptr[mid + 1] > q) h2 = mid; else l2 = mid + 1;
-              }
-              myrow = l2;
-            }
-            const uint32_t q = qpos + min(lane, take - 1u);        // lanes >= take mirror the last quad
+            // Position -> row for the next <=64 quads without a search: lane l looks at row
+            // `row + l`; non-empty rows flag the position their first quad lands on; the flags
+            // read back as one ballot give every position the count of rows starting at or
+            // before it; a wave-private byte table turns that count into the lane (= row offset).
+            const uint32_t r_l = min(row + lane, n);                   // qptr[n] = Q
+            const uint32_t qs_l = t.qptr[r_l];
+            const uint32_t qe_l = t.qptr[min(r_l + 1u, n)];
+            const uint32_t wend = __builtin_amdgcn_readlane(qe_l, 63);
+            const uint32_t take = min(min(64u, qb - qpos), wend - qpos);
+            const uint32_t rel = (lane == 0) ? 0u : qs_l - qpos;       // row `row` holds qpos
+            const bool instart = (qe_l > qs_l) && (lane == 0 || rel < take);
+            const uint64_t nb = __ballot(instart);
+            if (instart) { wflag[rel] = 1; wsel[__popcll(nb & lanemask_lt())] = (unsigned char)lane; }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t fl = wflag[lane];
+            __builtin_amdgcn_wave_barrier();
+            wflag[lane] = 0;
+            const uint64_t m64 = __ballot(fl != 0);
+            const uint32_t ppos = min(lane, take - 1u);                 // lanes >= take mirror the last quad
+            const uint32_t cnt = __popcll(m64 & (~0ull >> (63u - ppos)));   // >= 1: bit 0 is always set
+            const uint32_t myrow = row + wsel[cnt - 1u];
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t q = qpos + ppos;
             const uint32_t e0 = t.rowe0[myrow];
             const uint32_t rs = t.rowptr[myrow];
             const uint32_t addr4 = ((e0 >> 2) + (q - t.qptr[myrow])) << 2;   // aligned quad
@@ -584,68 +690,63 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
             cand[u] = *reinterpret_cast<const uint4 *>(p.indices + addr4);
             if (!kPlain && incl_self && addr4 > e0) prevv[u] = p.indices[addr4 - 1];
             qpos += take;
-            row = __builtin_amdgcn_readlane(myrow, take - 1);
-            while (row < n && __builtin_amdgcn_readfirstlane(t.qptr[row + 1]) <= qpos) row++;   // skips empty rows too
+            if (qpos < qb) {
+              const uint64_t cont = __ballot(r_l < n && qe_l > qpos);   // rows ending after the new position
+              row = cont ? row + (uint32_t)__ffsll((unsigned long long)cont) - 1u : row + 64u;
+              while (row < n && __builtin_amdgcn_readfirstlane(t.qptr[row + 1]) <= qpos) row++;   // (only after a run of empty rows)
+            }
           }
         }
-        // ---- look the ids up (straight-line, predicated) and append the rare matches
-        const uint32_t nstash_s = __builtin_amdgcn_readfirstlane(nstash);
+        SHD_G(1);
+#if SHADOW_SG_TIMING == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        SHD_G(2);
+        // ---- filter probes (branch-free, all LDS reads of the kUnroll groups in flight together)
+        uint32_t hit = 0;              // bit (4u + c): neighbour candidate
+        uint32_t selfm = 0;            // bit (4u + c): self edge goes right before component c
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-          const uint32_t take = d_take[u];
-          if (take == 0) break;
-          const bool act = lane < take;
-          const uint32_t myrow = l_row[u], e0 = l_e0[u], rs = l_rs[u], deg = l_deg[u];
-          const uint32_t j0 = l_addr[u] - e0;                          // wraps when the quad starts before the row
-          const uint32_t cc[4] = {cand[u].x, cand[u].y, cand[u].z, cand[u].w};
-          uint32_t sidx[4], mask = 0, full = 0;
+          const uint32_t deg = l_deg[u];
+          const uint32_t j0 = l_addr[u] - l_e0[u];                 // wraps when the quad starts before the row
+          uint32_t vmask = 0;
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const bool valid = act && (j0 + c < deg);
-            const uint32_t base = bucket_base(cc[c], hshift);
-            const uint4 k4 = *reinterpret_cast<const uint4 *>(t.hkey + base);
-            uint32_t off = 4;
-            off = (k4.w == cc[c]) ? 3u : off;
-            off = (k4.z == cc[c]) ? 2u : off;
-            off = (k4.y == cc[c]) ? 1u : off;
-            off = (k4.x == cc[c]) ? 0u : off;
-            sidx[c] = base + off;
-            if (valid && off < 4u) mask |= 2u << (2 * c);              // .cpp:412-413
-            if (valid && off == 4u && k4.w != kEmpty) full |= 1u << c;
-          }
-          if (nstash_s != 0 && __ballot(full != 0) != 0) {
-            // overflow stash (a handful of entries at most)
+          for (int c = 0; c < 4; c++)
+            if (lane < d_take[u] && (j0 + c < deg)) vmask |= 1u << c;
+          hit |= (probe_quad(t.bits, cand[u]) & vmask) << (4 * u);
+          if (!kPlain && incl_self) {
+            // the self edge goes right before the first neighbour > v (.cpp:387-400, :408-410)
+            const uint32_t v = t.nodes[l_row[u]];
+            const uint32_t cc[4] = {cand[u].x, cand[u].y, cand[u].z, cand[u].w};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-              if ((full >> c) & 1u) {
-                for (uint32_t i = 0; i < nstash_s; i++)
-                  if (t.hkey[H + i] == cc[c]) { sidx[c] = H + i; mask |= 2u << (2 * c); break; }
-              }
+              const uint32_t j = j0 + c;
+              const uint32_t pv = (c == 0) ? prevv[u] : cc[c > 0 ? c - 1 : 0];
+              const bool prev_lt = (j == 0) || (pv < v);
+              if (((vmask >> c) & 1u) && prev_lt && v < cc[c]) selfm |= 1u << (4 * u + c);
             }
           }
-          if (!kPlain) {
-            const uint32_t v = t.nodes[myrow];
-            if (!itc) {
-              // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
-              if (is_root(roots, R, v)) {
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                  if (((mask >> (2 * c + 1)) & 1u) && is_root(roots, R, cc[c])) mask &= ~(2u << (2 * c));
-              }
-            }
-            if (incl_self) {
-              // the self edge goes right before the first neighbour > v (.cpp:387-400, :408-410)
-#pragma unroll
-              for (int c = 0; c < 4; c++) {
-                const uint32_t j = j0 + c;
-                const uint32_t pv = (c == 0) ? prevv[u] : cc[c > 0 ? c - 1 : 0];
-                const bool prev_lt = (j == 0) || (pv < v);
-                if (act && j < deg && prev_lt && v < cc[c]) mask |= 1u << (2 * c);
-              }
-            }
-          }
-          emit_scan(t, ctrl, capm, mask, 2u * (rs + j0), myrow, sidx);   // key = 2*slot + kind
         }
+        if (hit | selfm) {
+          uint32_t r = atomicAdd(&ctrl[C_M], (uint32_t)(__popc(hit) + __popc(selfm)));
+#pragma unroll
+          for (int u = 0; u < kUnroll; u++) {
+            const uint32_t cc[4] = {cand[u].x, cand[u].y, cand[u].z, cand[u].w};
+            const uint32_t keybase = 2u * (l_rs[u] + (l_addr[u] - l_e0[u]));
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              if (!kPlain && ((selfm >> (4 * u + c)) & 1u)) {
+                if (r < capm) { t.lkey[r] = keybase + 2u * c; t.lval[r] = l_row[u]; }       // .cpp:408-410
+                r++;
+              }
+              if ((hit >> (4 * u + c)) & 1u) {
+                if (r < capm) { t.lkey[r] = keybase + 2u * c + 1u; t.lval[r] = cc[c]; }      // .cpp:420-422
+                r++;
+              }
+            }
+          }
+        }
+        SHD_G(3);
       }
     }
     __syncthreads();
@@ -671,10 +772,28 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
       const uint32_t bshift = kbits > 8 ? kbits - 8 : 0;
       for (uint32_t i = tid; i < kSortBuckets; i += T) { t.bhead[i] = kEmpty; t.bcnt[i] = 0; }
       __syncthreads();
+      // resolve the neighbour candidates exactly (.cpp:412-413) and chain the survivors
       for (uint32_t i = tid; i < m; i += T) {
-        const uint32_t b = min(t.lkey[i] >> bshift, kSortBuckets - 1);
-        atomicAdd(&t.bcnt[b], 1u);
-        t.lnext[i] = atomicExch(&t.bhead[b], i);
+        uint32_t key = t.lkey[i];
+        if (key & 1u) {
+          const uint32_t c = t.lval[i];
+          const int32_t hs = tab_find(t.hkey, c, H, hshift, nstash);
+          bool keep = hs >= 0;
+          if (keep && !itc && is_root(roots, R, c)) {
+            // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
+            const uint32_t slot = key >> 1;
+            uint32_t lo = 0, hi = n;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (t.rowptr[mid] <= slot) lo = mid; else hi = mid; }
+            keep = !is_root(roots, R, t.nodes[lo]);
+          }
+          if (keep) t.lval[i] = t.hval[hs];
+          else { key = kEmpty; t.lkey[i] = kEmpty; }
+        }
+        if (key != kEmpty) {
+          const uint32_t b = min(key >> bshift, kSortBuckets - 1);
+          atomicAdd(&t.bcnt[b], 1u);
+          t.lnext[i] = atomicExch(&t.bhead[b], i);
+        }
       }
       __syncthreads();
       // exclusive scan of the bucket counts (kSortBuckets = 256 = 4 per lane of wave 0)
@@ -686,10 +805,12 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
         uint32_t run = incl - sum;
 #pragma unroll
         for (int q = 0; q < 4; q++) { t.bcnt[lane * 4 + q] = run; run += c4[q]; }
+        if (lane == 63) ctrl[C_MV] = run;          // surviving entries
       }
       __syncthreads();
       for (uint32_t i = tid; i < m; i += T) {
         const uint32_t key = t.lkey[i];
+        if (key == kEmpty) continue;
         const uint32_t b = min(key >> bshift, kSortBuckets - 1);
         uint32_t r = t.bcnt[b];
         for (uint32_t j = t.bhead[b]; j != kEmpty; j = t.lnext[j]) r += (t.lkey[j] < key) ? 1u : 0u;
@@ -707,12 +828,15 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
         }
       }
     }
-    e_run += m;
+    e_run += ctrl[C_MV];
     rq0 = rq1;
     __syncthreads();
     if (rq0 >= Q) break;
   }
   SHD_STAMP(3);   // match sort + write-out done
+#ifdef SHADOW_SG_TIMING
+  if (threadIdx.x == 0) { res[R_T0 + 4] = tacc[0]; res[R_T0 + 5] = tacc[1]; res[R_T0 + 6] = tacc[2]; res[R_T0 + 7] = tacc[3]; }
+#endif
   if (tid == 0) {
     res[R_N] = n; res[R_E] = e_run; res[R_FLAGS] = (e_run > cape) ? 2u : 0u; res[R_SLOTS] = S;
     res[R_FNODES] = ctrl[C_FRONT_NODES]; res[R_FREADS] = ctrl[C_FRONT_READS];
@@ -723,7 +847,7 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
 // LDS carve shared by host (size computation) and device
 struct LdsLayout {
   size_t hkey, hval, pprv, nodes, rowptr, qptr, rowe0, front0, front1, lkey, lval, lnext, bhead,
-      bcnt, ctrl, wsum, total;
+      bcnt, bits, wtmp, ctrl, wsum, total;
 };
 
 __host__ __device__ inline size_t r16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -739,13 +863,16 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t H, uint32_t capn, uint3
   L.rowptr = o; o += r16((size_t)(capn + 1) * 4);
   L.qptr = o; o += r16((size_t)(capn + 1) * 4);
   L.rowe0 = o; o += r16((size_t)capn * 4);
-  L.front0 = o; o += r16((size_t)capf * 4);
-  L.front1 = o; o += r16((size_t)capf * 4);
+  L.front0 = o;                                     // the frontiers are dead once the node set is
+  L.front1 = o + r16((size_t)capf * 4);             // final: the scan's filter reuses their space
+  L.bits = o;
+  o += (2 * r16((size_t)capf * 4) > (size_t)kBitWords * 4) ? 2 * r16((size_t)capf * 4) : (size_t)kBitWords * 4;
   L.lkey = o; o += r16((size_t)capm * 4);
   L.lval = o; o += r16((size_t)capm * 4);
   L.lnext = o; o += r16((size_t)capm * 4);
   L.bhead = o; o += kSortBuckets * 4;
   L.bcnt = o; o += kSortBuckets * 4;
+  L.wtmp = o; o += 16 * 128;
   L.ctrl = o; o += C_WORDS * 4;
   L.wsum = o; o += 32 * 4;
   L.total = o;
@@ -772,6 +899,8 @@ __global__ void sg_sample_lds_kernel(SampleParams p) {
   t.lnext = (uint32_t *)(smem + L.lnext);
   t.bhead = (uint32_t *)(smem + L.bhead);
   t.bcnt = (uint32_t *)(smem + L.bcnt);
+  t.bits = (uint32_t *)(smem + L.bits);
+  t.wtmp = smem + L.wtmp;
   uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
   uint32_t *wsum = (uint32_t *)(smem + L.wsum);
   // persistent workgroups: subgraph ids come from a global ticket
@@ -792,6 +921,8 @@ __global__ void sg_sample_big_kernel(SampleParams p) {
   __shared__ uint32_t wsum[32];
   __shared__ uint32_t bhead[kSortBuckets];
   __shared__ uint32_t bcnt[kSortBuckets];
+  __shared__ uint32_t bits[kBitWords];
+  __shared__ __attribute__((aligned(16))) unsigned char wtmp[16 * 128];
   __shared__ uint32_t s_next;
   uint32_t *base = p.g_tables + (size_t)blockIdx.x * p.g_stride;
   Tables t;
@@ -811,6 +942,8 @@ __global__ void sg_sample_big_kernel(SampleParams p) {
   t.lnext = base + o; o += p.capm;
   t.bhead = bhead;
   t.bcnt = bcnt;
+  t.bits = bits;
+  t.wtmp = wtmp;
   for (;;) {
     if (threadIdx.x == 0) s_next = atomicAdd(p.g_ticket, 1u);
     __syncthreads();

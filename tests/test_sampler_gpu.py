@@ -286,3 +286,30 @@ def test_ppr_push_kernel_matches_reference_tables_and_oracle():
         for p_ in range(100):
             assert np.array_equal(np.asarray(out.get_subgraph_node()[p_]), refb[p_]["node"])
             assert np.array_equal(np.asarray(out.get_subgraph_indices()[p_]), refb[p_]["indices"])
+
+
+@pytest.mark.parametrize("shape,batch,depth,self_e", [
+    ("products", 1024, 2, False),      # BASELINE configs[1]-style k-hop batch at the full products shape
+    ("products", 512, 2, True),
+    ("products", 128, 3, False),       # depth 3: node sets beyond the LDS tables (global-table path)
+    ("arxiv", 2048, 2, True),
+])
+def test_full_size_shapes_match_oracle(shape, batch, depth, self_e):
+    """BASELINE-size synthetic graphs (long hub rows, 16-B-aligned row tails, rows that end exactly on
+    a streaming-run boundary): every integer field equals the oracle's."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+    from shadow_gnn_amd.synthetic import MAX_DEGREE, SHAPES, make_graph_torch
+    dev = torch.device("cuda:0")
+    N, nnz, _, _ = SHAPES[shape]
+    indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE[shape])
+    ip, ix = indptr.cpu().numpy(), indices.cpu().numpy()
+    roots = torch.randperm(N, generator=torch.Generator().manual_seed(2))[:batch].numpy().astype(np.uint32)
+    hs = HipSampler(indptr, indices, device=dev, seed=3)
+    hs.shuffle_targets(roots)
+    cfg = SamplerConfig(method="khop", depth=depth, budget=20, add_self_edge=self_e, aug=("hops",))
+    got = hs.sample(cfg, batch).to_host()
+    ref = so.sample_batch(ip, ix, roots, method="khop", depth=depth, budget=20, add_self_edge=self_e,
+                          aug=("hops",), seed=3, serial_base=0, num_threads=16)
+    for f in INT_FIELDS + ["hop"]:
+        assert np.array_equal(got[f], getattr(ref, f)), (shape, batch, depth, self_e, f)
