@@ -223,6 +223,18 @@ int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const f
                     const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                     void *stream);
 
+/* Same product for a BLOCK-DIAGONAL adjacency (a collated minibatch, graph.py:280-330): rows
+ * [node_off[s], node_off[s+1]) only reference columns of the same range and own the edges
+ * [edge_off[s], edge_off[s+1]) (sg_batch_out.d_subg_nodes / d_subg_edges; the transpose of such a
+ * matrix has the same offsets).  Each subgraph's feature tile is staged in LDS once instead of being
+ * gathered per edge; subgraphs beyond the LDS tile (384 rows / 1024 edges) gather from HBM.
+ * max_subg_nodes (sg_batch_counts) sizes the tile. */
+int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                          const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                          const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
+                          const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off,
+                          uint32_t num_subg, uint32_t max_subg_nodes, void *stream);
+
 /* Fused (bias +) activation + feature normalisation + branch sum:
  *   out = out_scale * sum_{b<nb} ( (h_b - mean) * scale[b] * rsqrt(var + 1e-9) + offset[b] ),
  *   h_b = act_b(Z_b + bias_b), mean/var (biased) over segments of `seg` features

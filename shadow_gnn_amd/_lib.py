@@ -88,6 +88,8 @@ SIGNATURES = {
     "sl_degree_scales": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
     "sl_spmm_csr_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                    C.c_uint32, _P]),
+    "sl_spmm_blockdiag_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
+                                         C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P]),
     "sl_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, _P]),
     "sl_gat_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,

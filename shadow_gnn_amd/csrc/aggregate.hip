@@ -253,110 +253,309 @@ __global__ void spmm_kernel(const uint32_t *__restrict__ indptr, const uint32_t 
   }
 }
 
-// ---------------------------------------------------------------------------
-// Multi-row SpMM for F <= 256 (the hidden width of every config): one wavefront owns
-// R consecutive rows.  Subgraph rows are tiny (~2 edges), so a row-at-a-time kernel is a
-// chain of three dependent HBM round trips (indptr -> indices -> X rows) per row.  Here
-// the wave reads the R+1 row pointers and ALL edge ids of its rows with two coalesced
-// loads, moves the column ids to scalar registers (v_readlane) and issues up to KMAX
-// feature-row gathers (1 KiB each) back to back -- three round trips per R rows, KMAX KiB in
-// flight per wave.  Rows with more edges fall back to a streaming loop.
-// ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ float rl_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
-template <int R, int KMAX>
-__global__ void spmm_rows_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                 const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
-                                 const float *__restrict__ row_scale, const float *__restrict__ col_scale,
-                                 const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
-                                 uint32_t n, uint32_t F) {
+// ---------------------------------------------------------------------------
+// Persistent, software-pipelined multi-row SpMM.  A "unit" = LPG lanes (a whole wavefront for
+// 128 < F <= 256) walks a contiguous chunk of row groups (R rows each).  The
+// three dependent HBM round trips of a group (row pointers -> edge ids [-> edge weights /
+// column scales] -> feature rows) are spread over the pipeline stages of four consecutive
+// groups, so each loop iteration waits for exactly one round trip -- the feature-row gathers
+// of the current group -- while the pointer / id loads of the next three groups ride along.
+// Subgraph rows are tiny (~2 edges): the R+1 row pointers and all edge ids of a group sit one
+// per lane, column ids move to scalar registers (v_readlane) and up to KMAX 1-KiB feature-row
+// gathers are issued back to back; groups with more edges fall back to a streaming loop.
+// Contiguous chunks keep a subgraph's rows (which gather each other's features) on one CU.
+// ---------------------------------------------------------------------------
+template <int LPG>
+__device__ __forceinline__ uint32_t grp_u32(uint32_t v, int k, int gb) {
+  if constexpr (LPG == 64) return rl_u32(v, k);
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute((gb + k) << 2, (int)v);
+}
+template <int LPG>
+__device__ __forceinline__ float grp_f32(float v, int k, int gb) {
+  return __int_as_float((int)grp_u32<LPG>((uint32_t)__float_as_int(v), k, gb));
+}
+
+template <int R, int KMAX, int LPG>
+__global__ void __launch_bounds__(kBlock)
+spmm_pipe_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                 const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
+                 const float *__restrict__ row_scale, const float *__restrict__ col_scale,
+                 const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
+                 uint32_t n, uint32_t F, uint32_t chunk) {
+  static_assert(KMAX <= LPG && R + 1 <= LPG, "edge ids / row pointers live one per lane");
   const uint32_t lane = lane_id();
+  const uint32_t sl = lane & (LPG - 1);              // lane inside the unit
+  const int gb = (int)(lane - sl);                   // first lane of the unit
   // XCD-aware block order (the grid is a multiple of 8 blocks)
   const uint32_t nb = gridDim.x, per = nb >> 3;
   const uint32_t lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-  const uint64_t gw = (uint64_t)lb * (kBlock / 64) + wave_id();
-  const uint64_t r0 = gw * R;
-  if (r0 >= n) return;
-  const uint32_t rows = (uint32_t)min((uint64_t)R, (uint64_t)n - r0);
-  const uint32_t f = lane * 4;
+  uint64_t unit = ((uint64_t)lb * (kBlock / 64) + wave_id()) * (64 / LPG) + lane / LPG;
+  if (LPG == 64) unit = (uint64_t)__builtin_amdgcn_readfirstlane((int)unit);      // (units < 2^31)
+  const uint64_t G = ((uint64_t)n + R - 1) / R;
+  const uint64_t g0 = unit * chunk;
+  if (__ballot(g0 < G) == 0) return;
+  const uint64_t g1 = min(G, g0 + chunk);
+  const uint32_t f = sl * 4;
   const bool on = f < F;
-  const uint32_t ipl = indptr[min(r0 + lane, (uint64_t)n)];        // lanes 0..R hold the row pointers
-  uint32_t ip[R + 1];
-#pragma unroll
-  for (int q = 0; q <= R; q++) ip[q] = rl_u32(ipl, q < (int)rows ? q : (int)rows);
-  const uint32_t e0 = ip[0], E = ip[R] - e0;
-  float4 acc[R];
-#pragma unroll
-  for (int q = 0; q < R; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (E <= (uint32_t)KMAX) {
-    uint32_t col = 0;
-    float wv = 0.f;
-    if (lane < E) {
-      col = indices[e0 + lane];
-      wv = 1.0f;
-      if (edge_w) wv = edge_w[edge_perm ? edge_perm[e0 + lane] : e0 + lane];
-      if (col_scale) wv *= col_scale[col];
+  const uint32_t ipn = indptr[n];
+  uint32_t ipl_b = ipn, ipl_c = ipn, ipl_d = ipn;    // row pointers of groups it+2, it+1, it
+  uint32_t col_c = 0, pe_c = 0, col_d = 0;
+  float w_d = 1.0f;
+  for (int64_t it = -3; it < (int64_t)chunk; it++) {
+    // ---- stage A: row pointers of group it+3
+    uint32_t ipl_a;
+    {
+      const uint64_t g = g0 + (uint64_t)(it + 3);
+      const uint64_t ra = (g < g1) ? g * R : (uint64_t)n;
+      ipl_a = indptr[min(ra + sl, (uint64_t)n)];     // lanes past the last row hold indptr[n]
     }
-    float4 x[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-      x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((uint32_t)k < E) {                                        // uniform
-        const uint32_t c = rl_u32(col, k);
-        if (on) x[k] = ld4(X + (int64_t)c * ldx + f);
+    // ---- stage B1: edge ids (and permuted edge positions) of group it+2
+    uint32_t col_b = 0, pe_b = 0;
+    {
+      const uint32_t e0 = grp_u32<LPG>(ipl_b, 0, gb), E = grp_u32<LPG>(ipl_b, R, gb) - e0;
+      if (sl < min(E, (uint32_t)KMAX)) {
+        col_b = indices[e0 + sl];
+        pe_b = edge_perm ? edge_perm[e0 + sl] : e0 + sl;
       }
     }
+    // ---- stage B2: edge weights / column scales of group it+1
+    float w_c = 1.0f;
+    if (edge_w || col_scale) {
+      const uint32_t e0 = grp_u32<LPG>(ipl_c, 0, gb), E = grp_u32<LPG>(ipl_c, R, gb) - e0;
+      if (sl < min(E, (uint32_t)KMAX)) {
+        if (edge_w) w_c = edge_w[pe_c];
+        if (col_scale) w_c *= col_scale[col_c];
+      }
+    }
+    // ---- stage C: gather, accumulate and store group it
+    {
+      const uint64_t g = g0 + (uint64_t)(it < 0 ? 0 : it);
+      const uint64_t r0 = (it >= 0 && g < g1) ? g * R : (uint64_t)n;
+      uint32_t ip[R + 1];
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-      if ((uint32_t)k < E) {
-        const float wk = rl_f32(wv, k);
-        const uint32_t ek = e0 + k;
+      for (int q = 0; q <= R; q++) ip[q] = grp_u32<LPG>(ipl_d, q, gb);
+      const uint32_t e0 = ip[0], E = ip[R] - e0;
+      float rsl = 1.0f;
+      if (row_scale && r0 + sl < n && sl < R) rsl = row_scale[r0 + sl];
+      float4 acc[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (E <= (uint32_t)KMAX) {
+        float4 x[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+          x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((uint32_t)k < E) {
+            const uint32_t c = grp_u32<LPG>(col_d, k, gb);
+            if (on) x[k] = ld4(X + (int64_t)c * ldx + f);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+          if ((uint32_t)k < E) {
+            const float wk = grp_f32<LPG>(w_d, k, gb);
+            const uint32_t ek = e0 + k;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+              if (ek >= ip[q] && ek < ip[q + 1]) {
+                acc[q].x += wk * x[k].x; acc[q].y += wk * x[k].y; acc[q].z += wk * x[k].z; acc[q].w += wk * x[k].w;
+              }
+            }
+          }
+        }
+      } else {
+        // long rows (hubs): stream the edges of each row, two gathers in flight
 #pragma unroll
         for (int q = 0; q < R; q++) {
-          if (ek >= ip[q] && ek < ip[q + 1]) {                      // uniform: edge k belongs to row q
-            acc[q].x += wk * x[k].x; acc[q].y += wk * x[k].y; acc[q].z += wk * x[k].z; acc[q].w += wk * x[k].w;
+          uint32_t p = ip[q];
+          const uint32_t b = ip[q + 1];
+          for (; p + 1 < b; p += 2) {
+            const uint32_t c0 = indices[p], c1 = indices[p + 1];
+            float w0 = 1.f, w1 = 1.f;
+            if (edge_w) { w0 = edge_w[edge_perm ? edge_perm[p] : p]; w1 = edge_w[edge_perm ? edge_perm[p + 1] : p + 1]; }
+            if (col_scale) { w0 *= col_scale[c0]; w1 *= col_scale[c1]; }
+            if (on) {
+              const float4 v0 = ld4(X + (int64_t)c0 * ldx + f), v1 = ld4(X + (int64_t)c1 * ldx + f);
+              acc[q].x += w0 * v0.x; acc[q].y += w0 * v0.y; acc[q].z += w0 * v0.z; acc[q].w += w0 * v0.w;
+              acc[q].x += w1 * v1.x; acc[q].y += w1 * v1.y; acc[q].z += w1 * v1.z; acc[q].w += w1 * v1.w;
+            }
+          }
+          if (p < b) {
+            const uint32_t c0 = indices[p];
+            float w0 = 1.f;
+            if (edge_w) w0 = edge_w[edge_perm ? edge_perm[p] : p];
+            if (col_scale) w0 *= col_scale[c0];
+            if (on) {
+              const float4 v0 = ld4(X + (int64_t)c0 * ldx + f);
+              acc[q].x += w0 * v0.x; acc[q].y += w0 * v0.y; acc[q].z += w0 * v0.z; acc[q].w += w0 * v0.w;
+            }
           }
         }
       }
-    }
-  } else {
-    // long rows (hubs): stream the edges of each row, two gathers in flight
 #pragma unroll
-    for (int q = 0; q < R; q++) {
-      uint32_t p = ip[q];
-      const uint32_t b = ip[q + 1];
-      for (; p + 1 < b; p += 2) {
-        const uint32_t c0 = indices[p], c1 = indices[p + 1];
-        float w0 = 1.f, w1 = 1.f;
-        if (edge_w) { w0 = edge_w[edge_perm ? edge_perm[p] : p]; w1 = edge_w[edge_perm ? edge_perm[p + 1] : p + 1]; }
-        if (col_scale) { w0 *= col_scale[c0]; w1 *= col_scale[c1]; }
-        if (on) {
-          const float4 v0 = ld4(X + (int64_t)c0 * ldx + f), v1 = ld4(X + (int64_t)c1 * ldx + f);
-          acc[q].x += w0 * v0.x; acc[q].y += w0 * v0.y; acc[q].z += w0 * v0.z; acc[q].w += w0 * v0.w;
-          acc[q].x += w1 * v1.x; acc[q].y += w1 * v1.y; acc[q].z += w1 * v1.z; acc[q].w += w1 * v1.w;
-        }
-      }
-      if (p < b) {
-        const uint32_t c0 = indices[p];
-        float w0 = 1.f;
-        if (edge_w) w0 = edge_w[edge_perm ? edge_perm[p] : p];
-        if (col_scale) w0 *= col_scale[c0];
-        if (on) {
-          const float4 v0 = ld4(X + (int64_t)c0 * ldx + f);
-          acc[q].x += w0 * v0.x; acc[q].y += w0 * v0.y; acc[q].z += w0 * v0.z; acc[q].w += w0 * v0.w;
-        }
+      for (int q = 0; q < R; q++) {
+        const float rs = grp_f32<LPG>(rsl, q, gb);
+        if (r0 + q < n && on)
+          st4(Y + (int64_t)(r0 + q) * ldy + f, make_float4(acc[q].x * rs, acc[q].y * rs, acc[q].z * rs, acc[q].w * rs));
       }
     }
+    ipl_d = ipl_c; ipl_c = ipl_b; ipl_b = ipl_a;
+    col_d = col_c; w_d = w_c; col_c = col_b; pe_c = pe_b;
   }
-  float rsl = 1.0f;
-  if (row_scale && lane < rows) rsl = row_scale[r0 + lane];
+}
+
+// ---------------------------------------------------------------------------
+// Block-diagonal SpMM with the subgraph's feature tile staged in LDS.  A minibatch adjacency is
+// block diagonal (graph.py:280-330): the rows of subgraph s only gather feature rows of subgraph s,
+// each ~2x.  One workgroup takes (subgraph, 32-float column tile): the tile of X (n_s x 128 B), the
+// subgraph's row pointers, its column ids and final edge weights are loaded with coalesced,
+// mutually independent loads (one HBM round trip), then every edge is an LDS read.  Traffic
+// through L2 drops from (e + n) to 2n feature rows.  Subgraphs that do not fit the LDS budget
+// gather from global memory in the same kernel.
+// ---------------------------------------------------------------------------
+constexpr int kBdTile = 32;            // floats per column tile (8 lanes x float4)
+constexpr int kBdBlock = 1024;         // threads per workgroup (128 row groups of 8 lanes)
+constexpr int kBdRowPad = kBdTile + 4; // LDS row stride in floats (16 B pad rotates the banks)
+constexpr int kBdMaxRows = 384;        // rows of one subgraph tile held in LDS (12 per 8-lane group)
+constexpr int kBdMaxEdges = 1024;      // edges of one subgraph held in LDS (4 per thread)
+constexpr int kBdKX = kBdMaxRows / (kBdBlock / 8);
+constexpr int kBdKE = kBdMaxEdges / kBdBlock;
+
+struct BdItem { uint32_t a, ns, e0, es; };
+
+// Work item w = (subgraph, column tile).  Headers are wave-uniform (scalar loads).
+__device__ __forceinline__ BdItem bd_header(uint32_t w, uint32_t total, uint32_t tiles,
+                                            const uint32_t *__restrict__ node_off,
+                                            const uint32_t *__restrict__ edge_off) {
+  BdItem h; h.a = 0; h.ns = 0; h.e0 = 0; h.es = 0;
+  if (w < total) {
+    const uint32_t s = w / tiles;
+    h.a = node_off[s]; h.ns = node_off[s + 1] - h.a;
+    h.e0 = edge_off[s]; h.es = edge_off[s + 1] - h.e0;
+  }
+  return h;
+}
+
+__global__ void __launch_bounds__(kBdBlock)
+spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                      const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
+                      const float *__restrict__ row_scale, const float *__restrict__ col_scale,
+                      const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
+                      uint32_t F, const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ edge_off,
+                      uint32_t P, uint32_t tiles, uint32_t cap_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem[];
+  float *xs = reinterpret_cast<float *>(bd_smem);                        // [cap_rows][kBdRowPad]
+  uint32_t *ips = reinterpret_cast<uint32_t *>(xs + (size_t)cap_rows * kBdRowPad);   // [cap_rows + 4]
+  uint32_t *cols = ips + cap_rows + 4;                                   // [kBdMaxEdges] local column ids
+  float *ws = reinterpret_cast<float *>(cols + kBdMaxEdges);             // [kBdMaxEdges] final edge weights
+  const uint32_t tid = threadIdx.x;
+  const uint32_t l8 = tid & 7u, rg = tid >> 3;                           // 8 lanes per row, 32 rows per pass
+  const bool weighted = (edge_w != nullptr) || (col_scale != nullptr);
+  const uint32_t total = P * tiles;          // (host checks the product fits 32 bits)
+  // ---- software pipeline over this workgroup's items: the global loads of item k+1 are issued
+  //      into registers before item k is computed out of LDS
+  float4 xv[kBdKX];
+  float rsv[kBdKX], rsc[kBdKX];      // row scales of the prefetched / current item
+  uint32_t iv[2], cv[kBdKE];
+  float wv[kBdKE];
+  auto fits = [&](const BdItem &h) { return h.ns != 0 && h.ns <= cap_rows && h.es <= (uint32_t)kBdMaxEdges; };
+  auto prefetch = [&](const BdItem &h, uint32_t w) {
+    if (!fits(h)) return;
+    const uint32_t f = (w % tiles) * kBdTile + l8 * 4;
 #pragma unroll
-  for (int q = 0; q < R; q++) {
-    if ((uint32_t)q < rows && on) {
-      const float rs = row_scale ? rl_f32(rsl, q) : 1.0f;
-      st4(Y + (int64_t)(r0 + q) * ldy + f, make_float4(acc[q].x * rs, acc[q].y * rs, acc[q].z * rs, acc[q].w * rs));
+    for (int k = 0; k < kBdKX; k++) {
+      const uint32_t i = rg + k * (kBdBlock / 8);
+      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rsv[k] = 1.0f;
+      if (i < h.ns && f < F) xv[k] = ld4(X + (int64_t)(h.a + i) * ldx + f);
+      if (i < h.ns && row_scale) rsv[k] = row_scale[h.a + i];
     }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t i = tid + k * kBdBlock;
+      iv[k] = (i <= h.ns) ? indptr[h.a + i] - h.e0 : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kBdKE; k++) {
+      const uint32_t p = tid + k * kBdBlock;
+      cv[k] = 0; wv[k] = 1.0f;
+      if (p < h.es) {
+        const uint32_t c = indices[h.e0 + p];
+        cv[k] = c - h.a;
+        if (edge_w) wv[k] = edge_w[edge_perm ? edge_perm[h.e0 + p] : h.e0 + p];
+        if (col_scale) wv[k] *= col_scale[c];
+      }
+    }
+  };
+  uint32_t w = blockIdx.x;
+  BdItem cur = bd_header(w, total, tiles, node_off, edge_off);
+  BdItem nxt = bd_header(w + gridDim.x, total, tiles, node_off, edge_off);
+  prefetch(cur, w);
+  for (; w < total; w += gridDim.x) {
+    const uint32_t f = (w % tiles) * kBdTile + l8 * 4;
+    const bool on = f < F;
+    const bool in_lds = fits(cur);
+    __syncthreads();                                                     // the previous item's readers are done
+    if (in_lds) {
+#pragma unroll
+      for (int k = 0; k < kBdKX; k++) {
+        const uint32_t i = rg + k * (kBdBlock / 8);
+        if (i < cur.ns) *reinterpret_cast<float4 *>(xs + (size_t)i * kBdRowPad + l8 * 4) = xv[k];
+        rsc[k] = rsv[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint32_t i = tid + k * kBdBlock;
+        if (i <= cur.ns) ips[i] = iv[k];
+      }
+#pragma unroll
+      for (int k = 0; k < kBdKE; k++) {
+        const uint32_t p = tid + k * kBdBlock;
+        if (p < cur.es) { cols[p] = cv[k]; if (weighted) ws[p] = wv[k]; }
+      }
+    }
+    __syncthreads();
+    const BdItem nn = bd_header(w + 2 * gridDim.x, total, tiles, node_off, edge_off);
+    prefetch(nxt, w + gridDim.x);
+    if (in_lds) {
+#pragma unroll
+      for (int k = 0; k < kBdKX; k++) {
+        const uint32_t i = rg + k * (kBdBlock / 8);
+        if (i < cur.ns) {
+          const uint32_t p0 = ips[i], p1 = ips[i + 1];
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (uint32_t p = p0; p < p1; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + (size_t)cols[p] * kBdRowPad + l8 * 4);
+            const float we = weighted ? ws[p] : 1.0f;
+            acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
+          }
+          const float rs = rsc[k];
+          if (on) st4(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
+        }
+      }
+    } else {
+      // oversize subgraph: gather the feature rows from global memory
+      for (uint32_t i = rg; i < cur.ns; i += kBdBlock / 8) {
+        const uint32_t p0 = indptr[cur.a + i], p1 = indptr[cur.a + i + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t p = p0; p < p1; p++) {
+          const uint32_t c = indices[p];
+          float we = 1.0f;
+          if (edge_w) we = edge_w[edge_perm ? edge_perm[p] : p];
+          if (col_scale) we *= col_scale[c];
+          if (on) {
+            const float4 v = ld4(X + (int64_t)c * ldx + f);
+            acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
+          }
+        }
+        const float rs = row_scale ? row_scale[cur.a + i] : 1.0f;
+        if (on) st4(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
+      }
+    }
+    cur = nxt; nxt = nn;
   }
 }
 
@@ -442,18 +641,42 @@ __global__ void act_norm_kernel(ActNormParams p) {
   const float inv_seg = 1.0f / (float)p.seg;
   float4 gs[2], go[2], gb[2];   // per-thread partial sums of dscale / doffset / dbias over its rows
   gs[0] = gs[1] = go[0] = go[1] = gb[0] = gb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub; r < p.n; r += (uint64_t)gridDim.x * rows_per_block) {
+  // register double buffering: the loads of this thread's NEXT row are issued before the
+  // reductions of the current one, so two rows per wavefront are in flight
+  const uint64_t rstep = (uint64_t)gridDim.x * rows_per_block;
+  uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub;
+  float4 zn[NB], dyn = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int b = 0; b < NB; b++) zn[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (backward only: the forward kernel runs at full occupancy and measured slower with it)
+  constexpr bool kPrefetch = BWD;
+  if (kPrefetch && r < p.n && lane_on) {
+    if (BWD) dyn = ld4(p.dout + (int64_t)r * p.lddo + f);
+#pragma unroll
+    for (int b = 0; b < NB; b++) zn[b] = ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f);
+  }
+  for (; r < p.n; r += rstep) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (BWD && lane_on) {
-      dy = ld4(p.dout + (int64_t)r * p.lddo + f);
-      dy.x *= p.out_scale; dy.y *= p.out_scale; dy.z *= p.out_scale; dy.w *= p.out_scale;
+    float4 dy = dyn;
+    float4 zc[NB];
+    if (kPrefetch) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) zc[b] = zn[b];
+      if (r + rstep < p.n && lane_on) {
+        if (BWD) dyn = ld4(p.dout + (int64_t)(r + rstep) * p.lddo + f);
+#pragma unroll
+        for (int b = 0; b < NB; b++) zn[b] = ld4(p.Z[b] + (int64_t)(r + rstep) * p.ldz[b] + f);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; b++) zc[b] = lane_on ? ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (BWD) { dy.x *= p.out_scale; dy.y *= p.out_scale; dy.z *= p.out_scale; dy.w *= p.out_scale; }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
       if (lane_on) {
-        z = ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f);
+        z = zc[b];
         if (p.bias[b]) { const float4 bb = ld4(p.bias[b] + f); z.x += bb.x; z.y += bb.y; z.z += bb.z; z.w += bb.w; }
         h = make_float4(act_fwd(p.act[b], z.x), act_fwd(p.act[b], z.y), act_fwd(p.act[b], z.z), act_fwd(p.act[b], z.w));
       }
@@ -699,16 +922,61 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
                        d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F);
   } else if (F <= 32) { SHD_SPMM(8, 1); }
   else if (F <= 64) { SHD_SPMM(16, 1); }
+  else if (F <= 128) { SHD_SPMM(32, 1); }       // (measured faster than half-wave units of the pipelined kernel)
   else if (F <= 256) {
+    // persistent pipelined kernel: ~4 blocks (16 waves) per CU, contiguous chunks of row groups
     constexpr int R = 4, KMAX = 16;
-    const uint32_t waves = (n + R - 1) / R;
-    const uint32_t blocks = (((waves + (kBlock / 64) - 1) / (kBlock / 64)) + 7u) & ~7u;
-    hipLaunchKernelGGL((spmm_rows_kernel<R, KMAX>), dim3(blocks), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_w,
-                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F);
+    int ncu = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t upb = kBlock / 64;                                          // units (wavefronts) per block
+    const uint64_t G = ((uint64_t)n + R - 1) / R;
+    const uint64_t max_units = (uint64_t)ncu * 4 * upb;                        // 4 resident blocks per CU (VGPR-bound)
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(6, (G + max_units - 1) / max_units);
+    const uint64_t units = (G + chunk - 1) / chunk;
+    const uint32_t blocks = (uint32_t)((((units + upb - 1) / upb) + 7u) & ~(uint64_t)7u);
+    hipLaunchKernelGGL((spmm_pipe_kernel<R, KMAX, 64>), dim3(blocks), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_w,
+                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, chunk);
   }
   else if (F <= 512) { SHD_SPMM(64, 2); }
   else { SHD_SPMM(64, 4); }
 #undef SHD_SPMM
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                     const uint32_t *d_edge_perm, const float *d_row_scale,
+                                     const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
+                                     int64_t ldy, uint32_t n, uint32_t F, const uint32_t *d_subg_node_off,
+                                     const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                                     uint32_t max_subg_nodes, void *stream_) {
+  if (!d_indptr || !d_X || !d_Y || !d_subg_node_off || !d_subg_edge_off)
+    return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: null argument");
+  if (n == 0 || F == 0 || num_subg == 0) return SG_OK;
+  const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y);
+  if (!vec)   // unaligned layouts: the general kernel handles them
+    return sl_spmm_csr_f32(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy,
+                           n, F, stream_);
+  hipStream_t st = (hipStream_t)stream_;
+  int ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  // rows of the LDS tile: the batch's largest subgraph, at most kBdMaxRows (bigger ones gather from HBM)
+  uint32_t cap_rows = std::min<uint32_t>(std::max<uint32_t>(max_subg_nodes, 32), (uint32_t)kBdMaxRows);
+  cap_rows = (cap_rows + 31u) & ~31u;
+  const size_t lds = (size_t)cap_rows * kBdRowPad * 4 + ((size_t)cap_rows + 4) * 4 + (size_t)kBdMaxEdges * 8;
+  if (lds > 64 * 1024)
+    SHD_HIP(hipFuncSetAttribute((const void *)spmm_blockdiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const uint32_t tiles = (F + kBdTile - 1) / kBdTile;
+  const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 256)));
+  const uint64_t total = (uint64_t)num_subg * tiles;
+  if (total + 2 * (uint64_t)ncu * per_cu >= ((uint64_t)1 << 32))
+    return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: too many (subgraph, tile) items");
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(total, (uint64_t)ncu * per_cu);
+  hipLaunchKernelGGL(spmm_blockdiag_kernel, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
+                     d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
+                     cap_rows);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

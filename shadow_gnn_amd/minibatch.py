@@ -193,7 +193,8 @@ class MinibatchShallowExtractor:
             assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
         elif self.prefetch:
             self._launch(mode)        # overlap the next sampler call with this batch's training
-        adj = ops.DeviceCSR(subgs.indptr, subgs.indices)
+        adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
+                            subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
         feat = ops.gather_rows(self.feat_full, subgs.node)           # minibatch.py:469
         label = self.label_epoch[mode][i0:i0 + batch_size_]
         feat_aug = {}

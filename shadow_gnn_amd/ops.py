@@ -87,7 +87,11 @@ class DeviceCSR:
     """Square batch adjacency (block diagonal) in HBM: int32 tensors holding
     uint32 values, all-ones data (the sampler emits data = 1., .cpp:411,423)."""
 
-    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor):
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, subg_off: Optional[torch.Tensor] = None,
+                 subg_edge_off: Optional[torch.Tensor] = None, max_subg_nodes: int = 0):
+        """``subg_off`` / ``subg_edge_off`` ([P+1] int32 node / edge offsets of the diagonal blocks, as
+        the sampler returns them) let SpMM stage each subgraph's features in LDS
+        (sl_spmm_blockdiag_f32)."""
         _need_cuda(indptr, indices)
         assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
         self.indptr = indptr.contiguous()
@@ -96,6 +100,13 @@ class DeviceCSR:
         self.e = int(indices.numel())
         self._edge_row = None
         self._t = None
+        self.subg_off = subg_off.contiguous() if subg_off is not None else None
+        self.subg_edge_off = subg_edge_off.contiguous() if subg_edge_off is not None else None
+        self.max_subg_nodes = int(max_subg_nodes)
+        if self.subg_off is not None:
+            assert self.subg_edge_off is not None and self.subg_edge_off.numel() == self.subg_off.numel()
+            assert self.subg_off.dtype == torch.int32 and self.subg_off.is_cuda
+            assert self.subg_edge_off.dtype == torch.int32 and self.subg_edge_off.is_cuda
 
     @property
     def shape(self):
@@ -209,20 +220,30 @@ def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
     return NormAdj(csr, edge_w=m, row_scale=s, col_scale=s)
 
 
-def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n):
+BLOCKDIAG_MIN_F = 128     # below this width the per-edge gather kernels are faster (measured)
+
+
+def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None):
+    """``blocks`` = (subg_off, subg_edge_off, max_subg_nodes) of a block-diagonal adjacency."""
     X = _f32c(X)
     F = X.shape[1]
     Y = torch.empty(n, F, dtype=torch.float32, device=X.device)
     e = int(indices.numel())
     # algorithmic bytes (SURVEY.md 8(d)): indptr + indices (+ edge values) + read X + write A.X
     nbytes = 4 * (n + 1) + 4 * e + (4 * e if edge_w is not None else 0) + 8 * n * F
+    lib = _lib.load()
+    opt = lambda t: t.data_ptr() if t is not None else None
     with _timed(f"spmm_F{F}", nbytes, X.device):
-      check(_lib.load().sl_spmm_csr_f32(
-        indptr.data_ptr(), indices.data_ptr(), edge_w.data_ptr() if edge_w is not None else None,
-        edge_perm.data_ptr() if edge_perm is not None else None,
-        row_scale.data_ptr() if row_scale is not None else None,
-        col_scale.data_ptr() if col_scale is not None else None,
-        X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), n, F, _stream(X)))
+        if blocks is not None and blocks[0] is not None and F >= BLOCKDIAG_MIN_F:
+            off, eoff, mn = blocks
+            check(lib.sl_spmm_blockdiag_f32(
+                indptr.data_ptr(), indices.data_ptr(), opt(edge_w), opt(edge_perm), opt(row_scale), opt(col_scale),
+                X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), n, F, off.data_ptr(), eoff.data_ptr(),
+                int(off.numel()) - 1, mn, _stream(X)))
+        else:
+            check(lib.sl_spmm_csr_f32(
+                indptr.data_ptr(), indices.data_ptr(), opt(edge_w), opt(edge_perm), opt(row_scale), opt(col_scale),
+                X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), n, F, _stream(X)))
     return Y
 
 
@@ -232,15 +253,17 @@ class _SpMM(torch.autograd.Function):
         _need_cuda(X)
         ctx.adj = adj
         c = adj.csr
-        return _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n)
+        return _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
+                         (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
 
     @staticmethod
     def backward(ctx, dY):
         adj = ctx.adj
         ti, tx, tp = adj.csr.transposed
         # (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
+        c = adj.csr          # the transpose of a block-diagonal matrix has the same blocks
         dX = _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale,
-                       adj.row_scale, dY, adj.csr.n)
+                       adj.row_scale, dY, c.n, (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
         return dX, None
 
 

@@ -185,6 +185,88 @@ def test_gather_spmm_transpose_primitives():
     assert ops.spmm(ops.adj_norm_rw(e0), torch.ones(3, 8, device=DEV)).abs().sum().item() == 0.0
 
 
+@pytest.mark.parametrize("F", [68, 100, 128, 132, 200, 256])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_pipelined_kernel_shapes(F, weighted):
+    """The persistent multi-row SpMM (whole-wave units for F<=256, half-wave units for F<=128):
+    tiny rows, empty rows, hub rows beyond the in-register edge budget, ragged last group,
+    forward and transpose (permuted edge weights), against dense fp32."""
+    import scipy.sparse as sp
+    from shadow_gnn_amd import ops
+    rng = np.random.default_rng(F + int(weighted))
+    n = 1237                                             # not a multiple of the 4-row groups
+    dense = (rng.random((n, n)) < 0.002).astype(np.float32)
+    dense[17, rng.choice(n, 300, replace=False)] = 1.0   # hub rows (> 16 edges in one group)
+    dense[600, rng.choice(n, 40, replace=False)] = 1.0
+    dense[100:140, :] = 0.0                              # a run of empty rows
+    A = sp.csr_matrix(dense)
+    A.sort_indices()
+    csr = _csr(A.indptr, A.indices)
+    X = torch.randn(n, F, device=DEV, requires_grad=True)
+    if weighted:
+        w = torch.rand(A.nnz, device=DEV)
+        rs = torch.rand(n, device=DEV) + 0.5
+        adj = ops.NormAdj(csr, edge_w=w, row_scale=rs, col_scale=rs)
+    else:
+        adj = ops.adj_norm_rw(csr)
+    Y = ops.spmm(adj, X)
+    D = adj.to_dense()
+    np.testing.assert_allclose(Y.detach().cpu().numpy(), (D @ X.detach()).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    G = torch.randn_like(Y)
+    (Y * G).sum().backward()
+    np.testing.assert_allclose(X.grad.cpu().numpy(), (D.t() @ G).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("F", [100, 128, 256, 260])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_blockdiag_lds_kernel(F, weighted):
+    """Block-diagonal SpMM (features of each subgraph staged in LDS): ragged subgraph sizes, an
+    empty subgraph, one subgraph larger than the LDS tile (global-gather path), forward and
+    transpose, against dense fp32 and against the general CSR kernel (bit-equal sums are not
+    required: the accumulation order per row is the same edge order, so they are equal anyway)."""
+    import scipy.sparse as sp
+    from shadow_gnn_amd import ops
+    rng = np.random.default_rng(F * 2 + int(weighted))
+    sizes = [1, 7, 0, 300, 64, 1500, 33, 2, 380]         # 1500 rows > LDS tile; 380 rows: > 1024 edges
+    blocks = []
+    for m in sizes:
+        d = (rng.random((m, m)) < min(1.0, 3.0 / max(m, 1))).astype(np.float32)
+        if m > 10:
+            d[3, :] = (rng.random(m) < 0.5)              # a dense-ish row
+            d[5, :] = 0                                  # an empty row
+        blocks.append(sp.csr_matrix(d))
+    A = sp.block_diag(blocks, format="csr")
+    A.sort_indices()
+    n = A.shape[0]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=DEV)
+    eoff = torch.tensor(np.concatenate([[0], np.cumsum([b.nnz for b in blocks])]), dtype=torch.int32, device=DEV)
+    ip = torch.from_numpy(A.indptr.astype(np.int32)).to(DEV)
+    ix = torch.from_numpy(A.indices.astype(np.int32)).to(DEV)
+    csr_bd = ops.DeviceCSR(ip, ix, subg_off=off, subg_edge_off=eoff, max_subg_nodes=max(sizes))
+    csr_pl = ops.DeviceCSR(ip, ix)
+    X = torch.randn(n, F, device=DEV)
+    outs = []
+    for csr in (csr_bd, csr_pl):
+        x = X.clone().requires_grad_(True)
+        if weighted:
+            g = torch.Generator(device=DEV).manual_seed(1)
+            w = torch.rand(A.nnz, device=DEV, generator=g)
+            rs = torch.rand(n, device=DEV, generator=g) + 0.5
+            adj = ops.NormAdj(csr, edge_w=w, row_scale=rs, col_scale=rs)
+        else:
+            adj = ops.adj_norm_rw(csr)
+        Y = ops.spmm(adj, x)
+        G = torch.randn(n, F, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+        (Y * G).sum().backward()
+        outs.append((Y.detach(), x.grad.detach(), adj, G))
+    (Yb, gb, adj, G), (Yp, gp, _, _) = outs
+    D = adj.to_dense()
+    np.testing.assert_allclose(Yb.cpu().numpy(), (D @ X).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gb.cpu().numpy(), (D.t() @ G).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(Yb.cpu().numpy(), Yp.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), gp.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def test_dropedge_semantics():
     """int(nnz*p) positions zeroed (with replacement); row scale follows the masked degree;
     the symmetric variant keeps an edge only if its mate survived (graph_utils.py:85-94,114-123)."""
