@@ -235,6 +235,32 @@ int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off,
                           uint32_t num_subg, uint32_t max_subg_nodes, void *stream);
 
+/* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
+ * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)
+ * in ResPool (shaDow/layers.py:166-183).  d_argmax [num_subg, F] (max mode; may be NULL otherwise) receives
+ * the winning row id for the backward pass: dX[i,f] = dout[s,f] / n_s | dout[s,f]*(argmax[s,f]==i) | dout[s,f]. */
+int sl_segment_pool_fwd(const float *d_X, int64_t ldx, const uint32_t *d_node_off, uint32_t num_subg, uint32_t F,
+                        int mode, float *d_out, int64_t ldo, uint32_t *d_argmax, void *stream);
+int sl_segment_pool_bwd(const float *d_dout, int64_t lddo, const uint32_t *d_node_off, uint32_t num_subg,
+                        uint32_t F, int mode, const uint32_t *d_argmax, float *d_dX, int64_t lddx, void *stream);
+
+/* Entity encodings as bit masks of the active one-hot columns (frontend/graph.py:134-172):
+ * kind 0 hops (uint32, 0xFFFFFFFF unreachable -> column 0, hop h <= dim-2 -> column h+1, h >= 255 -> column 0),
+ * kind 1 pprs (float; column c iff 0.25^c >= ppr >= 0.25^(c+1), last bin down to 0 -- edges belong to both bins),
+ * kind 2 drnls (uint32; values >= 255 or > dim-1 -> column 0).  dim <= 32. */
+int sl_encode_codes(int kind, const void *d_src, uint32_t n, uint32_t dim, uint32_t *d_codes, void *stream);
+
+/* out = X + onehot(codes) @ W^T + bias without materialising the one-hot matrix (the feature-augmentation
+ * Linear of DeepGNN.forward, shaDow/models.py:178-191, 'sum' mode).  d_Wt = W^T, [dim, F] row-major; d_X and
+ * d_bias may be NULL; dim <= 16.  Backward: d_dWt [dim, F] and d_dbias [F] (may be NULL) from dout, through
+ * d_partial [partial_blocks * (dim+1) * F] (deterministic two-stage sum); dX = dout. */
+int sl_onehot_linear_fwd(const float *d_X, int64_t ldx, const uint32_t *d_codes, const float *d_Wt,
+                         const float *d_bias, uint32_t n, uint32_t F, uint32_t dim, float *d_out, int64_t ldo,
+                         void *stream);
+int sl_onehot_linear_bwd(const float *d_dout, int64_t lddo, const uint32_t *d_codes, uint32_t n, uint32_t F,
+                         uint32_t dim, float *d_dWt, float *d_dbias, float *d_partial, uint32_t partial_blocks,
+                         void *stream);
+
 /* Fused (bias +) activation + feature normalisation + branch sum:
  *   out = out_scale * sum_{b<nb} ( (h_b - mean) * scale[b] * rsqrt(var + 1e-9) + offset[b] ),
  *   h_b = act_b(Z_b + bias_b), mean/var (biased) over segments of `seg` features

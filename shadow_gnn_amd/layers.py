@@ -239,9 +239,12 @@ class ResPool(nn.Module):
         return feat_ret[:, 0] * feat_ret[:, 1]
 
     def _pool(self, feat, sizes_subg):
-        offsets = torch.cumsum(sizes_subg, dim=0) - sizes_subg
-        idx = torch.arange(feat.shape[0], device=feat.device)
-        return F.embedding_bag(idx, feat, offsets.long(), mode=self.type_pool)   # layers.py:175,180
+        # F.embedding_bag(arange(n), feat, offsets, mode) of the reference (layers.py:175,180) as one
+        # segment-reduction kernel over the subgraph row ranges
+        sizes = torch.as_tensor(sizes_subg, device=feat.device).reshape(-1)
+        off = torch.zeros(sizes.numel() + 1, dtype=torch.int32, device=feat.device)
+        off[1:] = torch.cumsum(sizes, dim=0)
+        return ops.segment_pool(feat, off, self.type_pool)
 
     def forward(self, feats_in_l, idx_targets, sizes_subg):
         idx_targets = torch.as_tensor(idx_targets, device=feats_in_l[-1].device).long()

@@ -198,8 +198,14 @@ class MinibatchShallowExtractor:
         feat = ops.gather_rows(self.feat_full, subgs.node)           # minibatch.py:469
         label = self.label_epoch[mode][i0:i0 + batch_size_]
         feat_aug = {}
+        # entity encodings (frontend/graph.py:134-172) as per-node bit masks; the model's augmentation
+        # Linear consumes them fused (ops.onehot_linear_add), .dense() gives the reference's matrix
         if "hops" in self.aug_feats:
-            feat_aug["hops"] = hop2onehot(subgs.hop, self.dim_1hot_hop)
+            feat_aug["hops"] = ops.OneHotCodes(ops.encode_codes("hops", subgs.hop, self.dim_1hot_hop), self.dim_1hot_hop)
+        if "pprs" in self.aug_feats:
+            feat_aug["pprs"] = ops.OneHotCodes(ops.encode_codes("pprs", subgs.ppr, self.dim_1hot_ppr), self.dim_1hot_ppr)
+        if "drnls" in self.aug_feats:
+            feat_aug["drnls"] = ops.OneHotCodes(ops.encode_codes("drnls", subgs.drnl, self.dim_1hot_drnl), self.dim_1hot_drnl)
         size_subg = subgs.size_subg.unsqueeze(0)
         ret = OneBatchSubgraph([adj], [feat], label, size_subg, [subgs.target], [feat_aug])
         ret.device_batch = subgs

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import layers
+from . import layers, ops
 from .minibatch import TRAIN, OneBatchSubgraph
 
 
@@ -106,7 +106,15 @@ class DeepGNN(nn.Module):
                 feat_ens[i][tgt, -self.dim_label_in:] = 0
             if len(self.type_feature_augment) > 0:
                 for ia, (ta, _dim) in enumerate(self.type_feature_augment):
-                    feat_aug_emb = self.aug_layers[i][ia](feat_aug_ens[i][ta])
+                    enc = feat_aug_ens[i][ta]
+                    if isinstance(enc, ops.OneHotCodes):
+                        if (self.feat_aug_ops == 'sum' and enc.dim <= 16
+                                and self.dim_feat_in == feat_ens[i].shape[1]):
+                            # fused one-hot + Linear + add: no [n, dim] matrix, one pass over the features
+                            feat_ens[i] = ops.onehot_linear_add(feat_ens[i], enc.codes, self.aug_layers[i][ia])
+                            continue
+                        enc = enc.dense()
+                    feat_aug_emb = self.aug_layers[i][ia](enc)
                     if self.feat_aug_ops == 'sum':
                         # (the reference adds in place into the gathered features, models.py:189)
                         if self.dim_feat_in == feat_ens[i].shape[1]:

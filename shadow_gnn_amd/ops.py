@@ -453,3 +453,117 @@ def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, o
                                       f"(supported: {sorted(ACT_CODE)})")
         codes.append(ACT_CODE[a])
     return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), *Zs)
+
+
+# ----------------------------------------------------------------------------- readout / encodings
+POOL_MODE = {"mean": 0, "max": 1, "sum": 2}
+
+
+class _SegmentPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, node_off, mode):
+        X = _f32c(X)
+        _need_cuda(X, node_off)
+        P, F = int(node_off.numel()) - 1, int(X.shape[1])
+        out = torch.empty(P, F, dtype=torch.float32, device=X.device)
+        am = torch.empty(P, F, dtype=torch.int32, device=X.device) if mode == 1 else None
+        with _timed(f"segment_pool_F{F}", 4 * X.shape[0] * F + 4 * P * F, X.device):
+            check(_lib.load().sl_segment_pool_fwd(X.data_ptr(), X.stride(0), node_off.data_ptr(), P, F, mode,
+                                                  out.data_ptr(), out.stride(0),
+                                                  am.data_ptr() if am is not None else None, _stream(X)))
+        ctx.mode, ctx.n = mode, int(X.shape[0])
+        ctx.save_for_backward(node_off, am if am is not None else node_off)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        node_off, am = ctx.saved_tensors
+        dout = _f32c(dout)
+        P, F = dout.shape
+        dX = torch.empty(ctx.n, F, dtype=torch.float32, device=dout.device)
+        check(_lib.load().sl_segment_pool_bwd(dout.data_ptr(), dout.stride(0), node_off.data_ptr(), P, F, ctx.mode,
+                                              am.data_ptr() if ctx.mode == 1 else None, dX.data_ptr(), dX.stride(0),
+                                              _stream(dout)))
+        return dX, None, None
+
+
+def segment_pool(X: torch.Tensor, node_off: torch.Tensor, mode: str) -> torch.Tensor:
+    """mean / max / sum of X over the rows of each subgraph; node_off = [P+1] int32 row offsets
+    (F.embedding_bag over the subgraph offsets, shaDow/layers.py:166-183).  Rows must tile
+    [0, n): every row belongs to exactly one subgraph (true for a collated batch)."""
+    assert node_off.dtype == torch.int32
+    return _SegmentPool.apply(X, node_off, POOL_MODE[mode])
+
+
+ENC_KIND = {"hops": 0, "pprs": 1, "drnls": 2}
+
+
+def encode_codes(kind: str, src: torch.Tensor, dim: int) -> torch.Tensor:
+    """Bit mask of the active one-hot columns per node (frontend/graph.py:134-172)."""
+    _need_cuda(src)
+    assert src.dtype in (torch.int32, torch.float32) and src.dim() == 1
+    src = src.contiguous()
+    codes = torch.empty(max(1, src.numel()), dtype=torch.int32, device=src.device)[:src.numel()]
+    check(_lib.load().sl_encode_codes(ENC_KIND[kind], src.data_ptr(), src.numel(), dim, codes.data_ptr(), _stream(src)))
+    return codes
+
+
+class OneHotCodes:
+    """A one-hot (multi-hot at ppr bin edges) encoding kept as one bit mask per node; what the fast
+    minibatch path puts into ``feat_aug_ens`` instead of the dense [n, dim] matrix."""
+
+    def __init__(self, codes: torch.Tensor, dim: int):
+        self.codes, self.dim = codes, int(dim)
+
+    @property
+    def shape(self):
+        return (int(self.codes.numel()), self.dim)
+
+    def dense(self) -> torch.Tensor:
+        return codes_to_dense(self.codes, self.dim)
+
+
+def codes_to_dense(codes: torch.Tensor, dim: int) -> torch.Tensor:
+    """The [n, dim] fp32 one-hot matrix the reference materialises (tests / generic consumers)."""
+    bits = torch.arange(dim, device=codes.device, dtype=torch.int32)
+    return ((codes.unsqueeze(1) >> bits) & 1).to(torch.float32)
+
+
+class _OnehotLinear(torch.autograd.Function):
+    PARTIAL_BLOCKS = 512
+
+    @staticmethod
+    def forward(ctx, X, codes, weight, bias):
+        X = _f32c(X)
+        _need_cuda(X, codes, weight)
+        n, F = X.shape
+        dim = int(weight.shape[1])
+        Wt = weight.detach().t().contiguous()                       # [dim, F]
+        out = torch.empty(n, F, dtype=torch.float32, device=X.device)
+        check(_lib.load().sl_onehot_linear_fwd(X.data_ptr(), X.stride(0), codes.data_ptr(), Wt.data_ptr(),
+                                               bias.data_ptr() if bias is not None else None, n, F, dim,
+                                               out.data_ptr(), out.stride(0), _stream(X)))
+        ctx.save_for_backward(codes)
+        ctx.dim, ctx.has_bias = dim, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (codes,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        n, F = dout.shape
+        dim = ctx.dim
+        dWt = torch.empty(dim, F, dtype=torch.float32, device=dout.device)
+        db = torch.empty(F, dtype=torch.float32, device=dout.device) if ctx.has_bias else None
+        nblk = _OnehotLinear.PARTIAL_BLOCKS
+        partial = torch.empty(nblk * (dim + 1) * F, dtype=torch.float32, device=dout.device)
+        check(_lib.load().sl_onehot_linear_bwd(dout.data_ptr(), dout.stride(0), codes.data_ptr(), n, F, dim,
+                                               dWt.data_ptr(), db.data_ptr() if db is not None else None,
+                                               partial.data_ptr(), nblk, _stream(dout)))
+        return dout, None, dWt.t(), db
+
+
+def onehot_linear_add(X: torch.Tensor, codes: torch.Tensor, lin: "torch.nn.Linear") -> torch.Tensor:
+    """X + lin(onehot(codes))  (the 'sum' feature augmentation of DeepGNN.forward) in one pass,
+    without the [n, dim] one-hot matrix; lin.weight is [F, dim]."""
+    return _OnehotLinear.apply(X, codes, lin.weight, lin.bias)

@@ -267,6 +267,80 @@ def test_spmm_blockdiag_lds_kernel(F, weighted):
     np.testing.assert_allclose(gb.cpu().numpy(), gp.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["mean", "max", "sum"])
+@pytest.mark.parametrize("F", [47, 256, 300])
+def test_segment_pool_matches_embedding_bag(mode, F):
+    """ResPool's readout (F.embedding_bag over subgraph offsets, layers.py:166-183): forward and
+    backward against torch on the same device, ragged sizes incl. single-row subgraphs."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(F)
+    sizes = torch.tensor([1, 5, 283, 64, 2, 9, 130, 1], device=DEV)
+    n = int(sizes.sum())
+    off = torch.zeros(sizes.numel() + 1, dtype=torch.int32, device=DEV)
+    off[1:] = torch.cumsum(sizes, 0)
+    X = torch.randn(n, F, device=DEV, generator=g)
+    x1 = X.clone().requires_grad_(True)
+    x2 = X.clone().requires_grad_(True)
+    got = ops.segment_pool(x1, off, mode)
+    ref = torch.nn.functional.embedding_bag(torch.arange(n, device=DEV), x2, off[:-1].long(), mode=mode)
+    # (sums of up to 283 terms in a different order than torch: the stated fp32 tolerance, 1e-4)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    G = torch.randn(got.shape, device=DEV, generator=g)
+    (got * G).sum().backward()
+    (ref * G).sum().backward()
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_encodings_match_reference_rules():
+    """hop / ppr / drnl one-hot rules of frontend/graph.py:134-172, restated in numpy here."""
+    from shadow_gnn_amd import ops
+    from oracle import layers_oracle as lo
+    hop = np.array([0, 1, 2, 5, 6, 7, 254, 255, 300, 0xFFFFFFFF], dtype=np.uint32)
+    got = ops.OneHotCodes(ops.encode_codes("hops", torch.from_numpy(hop.view(np.int32)).to(DEV), 7), 7).dense()
+    np.testing.assert_array_equal(got.cpu().numpy(), lo.hop2onehot(hop, 7))
+    # ppr: bins [0.25^(c+1), 0.25^c], closed on both sides, last bin down to 0
+    for dim in (1, 4):
+        ppr = np.array([1.0, 0.7, 0.25, 0.2, 0.0625, 0.01, 0.0, 0.015625, -1.0], dtype=np.float32)
+        cond = [0.25 ** i for i in range(dim)] + [0]
+        ref = np.zeros((ppr.size, dim))
+        for i in range(dim):
+            ref[np.where(np.logical_and(ppr <= cond[i], ppr >= cond[i + 1])), i] = 1
+        got = ops.OneHotCodes(ops.encode_codes("pprs", torch.from_numpy(ppr).to(DEV), dim), dim).dense()
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    drnl = np.array([0, 1, 25, 26, 100, 255, 300], dtype=np.uint32)
+    d = drnl.astype(np.int64).copy()
+    d[d >= 255] = 0; d[d > 25] = 0
+    ref = np.zeros((d.size, 26)); ref[np.arange(d.size), d] = 1
+    got = ops.OneHotCodes(ops.encode_codes("drnls", torch.from_numpy(drnl.view(np.int32)).to(DEV), 26), 26).dense()
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("F", [100, 128, 256])
+def test_onehot_linear_add_fused(F):
+    """X + Linear(onehot) fused (models.py feature augmentation, 'sum'): forward and all gradients
+    against the dense formulation."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(F)
+    n, dim = 3001, 7
+    hop = torch.randint(-1, 9, (n,), device=DEV, generator=g, dtype=torch.int32)
+    codes = ops.encode_codes("hops", hop, dim)
+    lin1 = torch.nn.Linear(dim, F).to(DEV)
+    lin2 = torch.nn.Linear(dim, F).to(DEV)
+    lin2.load_state_dict(lin1.state_dict())
+    X = torch.randn(n, F, device=DEV, generator=g)
+    x1 = X.clone().requires_grad_(True)
+    x2 = X.clone().requires_grad_(True)
+    got = ops.onehot_linear_add(x1, codes, lin1)
+    ref = x2 + lin2(ops.codes_to_dense(codes, dim))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    G = torch.randn(n, F, device=DEV, generator=g)
+    (got * G).sum().backward()
+    (ref * G).sum().backward()
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lin1.weight.grad.cpu().numpy(), lin2.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(lin1.bias.grad.cpu().numpy(), lin2.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
 def test_dropedge_semantics():
     """int(nnz*p) positions zeroed (with replacement); row scale follows the masked degree;
     the symmetric variant keeps an edge only if its mate survived (graph_utils.py:85-94,114-123)."""

@@ -58,7 +58,7 @@ def test_epoch_loop_matches_oracle_batches():
         # features are feat_full[node] (minibatch.py:469), labels follow the roots, hops are one-hot encoded
         assert torch.equal(b.feat_ens[0].cpu(), feat[torch.as_tensor(ref.node.astype(np.int64))])
         assert torch.equal(b.label.cpu(), label[torch.as_tensor(r.astype(np.int64))])
-        np.testing.assert_array_equal(b.feat_aug_ens[0]["hops"].cpu().numpy(), lo.hop2onehot(ref.hop, 7))
+        np.testing.assert_array_equal(b.feat_aug_ens[0]["hops"].dense().cpu().numpy(), lo.hop2onehot(ref.hop, 7))
     # a second epoch works and re-samples (stochastic sampler: new serials)
     mb.shuffle_entity(0, perm=np.arange(103))
     again = _epoch(mb)
