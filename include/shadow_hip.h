@@ -215,6 +215,30 @@ int sl_csr_transpose(const uint32_t *d_indptr, const uint32_t *d_indices, const 
 int sl_degree_scales(const uint32_t *d_indptr, const float *d_edge_w, uint32_t n, int mode,
                      float *d_row_scale, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Device-side subgraph cache: the reference's record -> reuse loop for deterministic samplers
+ * (CachedSubgraph / PoolSubgraph, shaDow/minibatch.py:21-91; par_graph_sample :403-426;
+ * REUSABLE_SAMPLER = {ppr}, CONFIG_TEMPLATE.yml:16-17).  Epoch 1 records every sampled
+ * single-root subgraph under its root id; later epochs rebuild any batch of roots from the arena
+ * in block-diagonal form (cat_to_block_diagonal, frontend/graph.py:280-330) without sampling --
+ * the full graph may then be dropped (sg_drop_full_graph_info), as the reference does at
+ * optm_level 'high' (minibatch.py:336-341).
+ * ------------------------------------------------------------------------- */
+typedef struct sg_cache sg_cache;
+int sg_cache_create(uint32_t num_nodes, int device_id, sg_cache **out);
+void sg_cache_destroy(sg_cache *c);
+int sg_cache_clear(sg_cache *c);
+int sg_cache_stats(const sg_cache *c, uint64_t *num_recorded, uint64_t *nodes, uint64_t *edges);
+/* Append a finished sg_sample batch (num_roots = 1) to the arena; n_tot / e_tot from sg_batch_counts.
+ * Asynchronous on `stream` (the batch buffers must stay alive until the stream passes this point). */
+int sg_cache_record(sg_cache *c, const sg_batch_out *batch, uint32_t num_subg, uint64_t n_tot, uint64_t e_tot,
+                    void *stream);
+/* Rebuild the batch of `d_roots[num_subg]` (device array of root ids) into `out` (same layout and
+ * capacity contract as sg_sample; d_drnl is not written).  sg_cache_collate_finish waits and returns
+ * the sizes; SG_ERR_STATE if a root was never recorded, SG_ERR_CAPACITY if `out` is too small. */
+int sg_cache_collate(sg_cache *c, const uint32_t *d_roots, uint32_t num_subg, sg_batch_out *out, void *stream);
+int sg_cache_collate_finish(sg_cache *c, sg_batch_counts *counts);
+
 /* Y[i,:] = row_scale[i] * sum_{p in row i} edge_w[edge_perm[p]] * col_scale[col_p] * X[col_p,:]
  * Any of edge_w / edge_perm / row_scale / col_scale may be NULL (= 1 / identity).
  * Replaces torch.sparse.mm(adj_norm, X) (shaDow/layers.py:326-327,433,475,580). */

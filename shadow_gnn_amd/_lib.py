@@ -90,6 +90,13 @@ SIGNATURES = {
                                    C.c_uint32, _P]),
     "sl_spmm_blockdiag_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                          C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P]),
+    "sg_cache_create": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "sg_cache_destroy": (None, [_P]),
+    "sg_cache_clear": (C.c_int, [_P]),
+    "sg_cache_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sg_cache_record": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, _P]),
+    "sg_cache_collate": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
+    "sg_cache_collate_finish": (C.c_int, [_P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
     "sl_segment_pool_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, _P, C.c_int64, _P]),
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),

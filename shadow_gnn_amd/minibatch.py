@@ -15,7 +15,9 @@ import numpy as np
 import torch
 
 from . import ops
-from .sampler import DeviceBatch, HipSampler, SamplerConfig
+from .sampler import DeviceBatch, HipSampler, SamplerConfig, SubgraphCache
+
+REUSABLE_SAMPLER = {"ppr"}          # CONFIG_TEMPLATE.yml:16-17 (algorithm.sampler.deterministic)
 
 TRAIN, VALID, TEST = 0, 1, 2          # graph_engine.frontend mode constants
 STR2MODE = {"train": TRAIN, "valid": VALID, "test": TEST}
@@ -83,7 +85,7 @@ class MinibatchShallowExtractor:
     """
     def __init__(self, adjs, entity_set, sampler_config: Dict[str, Any], aug_feats, feat_full: torch.Tensor,
                  label_full: torch.Tensor, batch_size: int, device, seed_cpp: int = -1,
-                 rank: int = 0, world_size: int = 1, prefetch: bool = True):
+                 rank: int = 0, world_size: int = 1, prefetch: bool = True, nocache_modes=()):
         self.device = torch.device(device)
         self.aug_feats = set(aug_feats)
         self.raw_entity_set = {m: np.asarray(v) for m, v in entity_set.items()}
@@ -112,6 +114,13 @@ class MinibatchShallowExtractor:
         self.prefetch = prefetch
         self._side = torch.cuda.Stream(device=self.device) if prefetch else None
         self._inflight = {}
+        # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
+        self.nocache_modes = set(nocache_modes)
+        self.record_subgraphs = {}
+        self.cache_subg = {}
+        self._roots_dev = {}
+        self._cursor = {m: 0 for m in (TRAIN, VALID, TEST)}
+        self._hwm = {m: [1, 1] for m in (TRAIN, VALID, TEST)}       # largest batch seen (nodes, edges)
 
     # ------------------------------------------------------------------ API
     def get_aug_dim(self, aug_type):
@@ -121,7 +130,11 @@ class MinibatchShallowExtractor:
         self.batch_num = -1
         if mode not in self.graph_sampler:
             ip, ix = self._adjs[mode]
-            self.graph_sampler[mode] = HipSampler(ip, ix, device=self.device, seed=self._seed)
+            self.graph_sampler[mode] = hs = HipSampler(ip, ix, device=self.device, seed=self._seed)
+            reusable = self.sampler_cfg.method in REUSABLE_SAMPLER and mode not in self.nocache_modes
+            self.record_subgraphs[mode] = "record" if reusable else ("noncache" if mode in self.nocache_modes else "none")
+            if reusable:
+                self.cache_subg[mode] = SubgraphCache(hs.num_nodes(), self.device)
 
     def shuffle_entity(self, mode, perm=None):
         """YOU MUST CALL THIS BEFORE STARTING ANY EPOCH (minibatch.py:269-280).  Every
@@ -139,6 +152,8 @@ class MinibatchShallowExtractor:
         self.entity_epoch[mode] = mine
         self.label_epoch[mode] = self.label_full[torch.as_tensor(mine.astype(np.int64), device=self.device)]
         self.graph_sampler[mode].shuffle_targets(mine.astype(np.uint32))
+        self._roots_dev[mode] = torch.as_tensor(mine.astype(np.uint32).view(np.int32)).to(self.device)
+        self._cursor[mode] = 0
         self.idx_entity_evaluated[mode] = 0
         self.end_epoch[mode] = False
         self._inflight.pop(mode, None)
@@ -146,35 +161,68 @@ class MinibatchShallowExtractor:
     def is_end_epoch(self, mode):
         return self.end_epoch[mode]
 
-    def epoch_end_reset(self, mode):
+    def epoch_end_reset(self, mode, drop_full_graph: bool = False):
+        """After the first full epoch of a deterministic sampler the recorded subgraphs are
+        reused (minibatch.py:326-334); ``drop_full_graph`` is the reference's optm_level 'high'
+        (:335-341): the full CSR is freed once nothing samples from it any more."""
         self.end_epoch[mode] = False
+        if self.record_subgraphs.get(mode) == "record" and not self.cache_subg[mode].is_empty():
+            self.record_subgraphs[mode] = "reuse"
+            if drop_full_graph:
+                self.drop_full_graph_info(mode)
 
     def drop_full_graph_info(self, mode):
         self.graph_sampler[mode].drop_full_graph_info()
 
     def disable_cache(self, mode):
-        pass      # the fast path re-samples every epoch (no subgraph cache yet)
+        """minibatch.py:490-492: stop recording / reusing subgraphs of this mode."""
+        self.nocache_modes.add(mode)
+        if mode in self.record_subgraphs:
+            self.record_subgraphs[mode] = "noncache"
+            self._inflight.pop(mode, None)
 
     # ------------------------------------------------------------- batching
     def _launch(self, mode):
         hs = self.graph_sampler[mode]
+        reuse = self.record_subgraphs.get(mode) == "reuse"
+        bs = min(self.batch_size[mode], self._roots_dev[mode].numel() - self._cursor[mode])
+
+        def go():
+            if reuse:
+                roots = self._roots_dev[mode][self._cursor[mode]:self._cursor[mode] + bs]
+                hn, he = self._hwm[mode]
+                self.cache_subg[mode].collate_async(roots, hn + hn // 8 + 64, he + he // 8 + 64,
+                                                    want_hop="hops" in self.aug_feats)
+            else:
+                hs.sample_async(self.sampler_cfg, self.batch_size[mode])
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
-                hs.sample_async(self.sampler_cfg, self.batch_size[mode])
+                go()
         else:
-            hs.sample_async(self.sampler_cfg, self.batch_size[mode])
-        self._inflight[mode] = True
+            go()
+        self._cursor[mode] += bs
+        self._inflight[mode] = "reuse" if reuse else "sample"
 
     def _collect(self, mode) -> DeviceBatch:
         hs = self.graph_sampler[mode]
+        kind = self._inflight[mode]
+
+        def go():
+            if kind == "reuse":
+                return self.cache_subg[mode].finish()
+            b = hs.finish()
+            if self.record_subgraphs.get(mode) == "record":
+                self.cache_subg[mode].record(b)                      # minibatch.py:407-412
+            return b
         if self._side is not None:
             with torch.cuda.stream(self._side):
-                b = hs.finish()
+                b = go()
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         else:
-            b = hs.finish()
+            b = go()
         self._inflight.pop(mode, None)
+        self._hwm[mode] = [max(self._hwm[mode][0], b.num_nodes), max(self._hwm[mode][1], b.num_edges)]
         return b
 
     def one_batch(self, mode=TRAIN, ret_raw_idx=False) -> OneBatchSubgraph:
@@ -190,7 +238,8 @@ class MinibatchShallowExtractor:
         if self.idx_entity_evaluated[mode] >= self.entity_epoch[mode].shape[0]:
             self.idx_entity_evaluated[mode] = 0
             self.end_epoch[mode] = True
-            assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
+            if self.record_subgraphs.get(mode) != "reuse":
+                assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
         elif self.prefetch:
             self._launch(mode)        # overlap the next sampler call with this batch's training
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,

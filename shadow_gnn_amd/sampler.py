@@ -366,6 +366,104 @@ class HipSampler:
         return self.finish()
 
 
+class SubgraphCache:
+    """Device-resident record -> reuse cache of sampled subgraphs keyed by root id: the
+    reference's CachedSubgraph + PoolSubgraph.collate for deterministic samplers
+    (shaDow/minibatch.py:21-91, :403-426) without leaving HBM."""
+
+    def __init__(self, num_nodes: int, device: torch.device):
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        check(self._lib.sg_cache_create(num_nodes, self.device.index or 0, C.byref(h)))
+        self._h = h
+        self._pend = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sg_cache_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(self._lib.sg_cache_clear(self._h))
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._lib.sg_cache_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(num_recorded=a.value, nodes=b.value, edges=c.value)
+
+    def is_empty(self):
+        return self.stats()["num_recorded"] == 0
+
+    def record(self, batch: DeviceBatch):
+        """File every (single-root) subgraph of a sampled batch under its root id."""
+        assert batch.num_roots == 1, "the cache holds node-task subgraphs (minibatch.py:410)"
+        out = SgBatchOut(batch.node.data_ptr(), batch.indptr.data_ptr(), batch.indices.data_ptr(),
+                         batch.edge_id.data_ptr(), batch.target.data_ptr(), batch.subg_node_off.data_ptr(),
+                         batch.subg_edge_off.data_ptr(), batch.hop.data_ptr() if batch.hop is not None else None,
+                         batch.ppr.data_ptr(), None, batch.num_nodes, batch.num_edges)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            check(self._lib.sg_cache_record(self._h, C.byref(out), batch.num_subgraphs, batch.num_nodes,
+                                            batch.num_edges, stream))
+
+    def _alloc(self, P, cap_nodes, cap_edges, want_hop):
+        i32 = dict(dtype=torch.int32, device=self.device)
+        b = dict(node=torch.empty(cap_nodes, **i32), indptr=torch.empty(cap_nodes + 1, **i32),
+                 indices=torch.empty(cap_edges, **i32), edge_id=torch.empty(cap_edges, **i32),
+                 target=torch.empty(max(1, P), **i32), subg_node_off=torch.empty(P + 1, **i32),
+                 subg_edge_off=torch.empty(P + 1, **i32),
+                 ppr=torch.empty(cap_nodes, dtype=torch.float32, device=self.device),
+                 hop=torch.empty(cap_nodes, **i32) if want_hop else None)
+        out = SgBatchOut(b["node"].data_ptr(), b["indptr"].data_ptr(), b["indices"].data_ptr(),
+                         b["edge_id"].data_ptr(), b["target"].data_ptr(), b["subg_node_off"].data_ptr(),
+                         b["subg_edge_off"].data_ptr(), b["hop"].data_ptr() if want_hop else None,
+                         b["ppr"].data_ptr(), None, cap_nodes, cap_edges)
+        return b, out
+
+    def collate_async(self, roots, cap_nodes: int, cap_edges: int, want_hop: bool = False):
+        """Start rebuilding the block-diagonal batch of ``roots`` (device int32 tensor or array)."""
+        if self._pend is not None:
+            raise RuntimeError("a collate is already in flight; call finish() first")
+        if not (isinstance(roots, torch.Tensor) and roots.is_cuda):
+            roots = torch.as_tensor(np.ascontiguousarray(np.asarray(roots).reshape(-1), dtype=np.uint32).view(np.int32)).to(self.device)
+        roots = roots.contiguous()
+        P = int(roots.numel())
+        bufs, out = self._alloc(P, max(1, cap_nodes), max(1, cap_edges), want_hop)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            check(self._lib.sg_cache_collate(self._h, roots.data_ptr(), P, C.byref(out), stream))
+        self._pend = (roots, bufs, out, P, want_hop)
+
+    def finish(self) -> DeviceBatch:
+        roots, b, out, P, want_hop = self._pend
+        cnt = SgBatchCounts()
+        rc = self._lib.sg_cache_collate_finish(self._h, C.byref(cnt))
+        self._pend = None
+        if rc == _lib.SG_ERR_CAPACITY:          # sizes are known now: run again with exact buffers
+            self.collate_async(roots, int(cnt.n_tot), int(cnt.e_tot), want_hop)
+            return self.finish()
+        check(rc)
+        n, e = int(cnt.n_tot), int(cnt.e_tot)
+        return DeviceBatch(node=b["node"][:n], indptr=b["indptr"][:n + 1], indices=b["indices"][:e],
+                           edge_id=b["edge_id"][:e], target=b["target"][:P], subg_node_off=b["subg_node_off"],
+                           subg_edge_off=b["subg_edge_off"], ppr=b["ppr"][:n],
+                           hop=b["hop"][:n] if want_hop else None, drnl=None, num_subgraphs=P, num_roots=1,
+                           counts=dict(n_tot=n, e_tot=e, max_subg_nodes=cnt.max_subg_nodes,
+                                       max_subg_edges=cnt.max_subg_edges, slots_scanned=0, frontier_reads=0,
+                                       frontier_nodes=0, sample_kernel_ms=0.0, relocate_kernel_ms=0.0))
+
+    def collate(self, roots, cap_nodes: int, cap_edges: int, want_hop: bool = False) -> DeviceBatch:
+        self.collate_async(roots, cap_nodes, cap_edges, want_hop)
+        return self.finish()
+
+
 # ===========================================================================
 # Reference-compatible surface (pybind11 module `ParallelSampler`)
 # ===========================================================================

@@ -73,8 +73,11 @@ def _model_from_case(case, g, ci):
     return model.to(DEV)
 
 
-def test_model_step_matches_reference_golden():
-    """One full DeepGNN.step (fwd, CE loss, bwd, clip 5, Adam) vs the reference's."""
+@pytest.mark.parametrize("fused_encoding", [False, True])
+def test_model_step_matches_reference_golden(fused_encoding):
+    """One full DeepGNN.step (fwd, CE loss, bwd, clip 5, Adam) vs the reference's.  The hop encoding
+    is passed either as the reference's dense one-hot matrix or as per-node codes (fused one-hot Linear)."""
+    from shadow_gnn_amd import ops
     from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN, hop2onehot
     g = ModelGolden()
     for case in g.cases:
@@ -86,6 +89,9 @@ def test_model_step_matches_reference_golden():
             hop = torch.tensor(g.get(ci, "hop").astype(np.int64).astype(np.int32), device=DEV)
             feat_aug["hops"] = hop2onehot(hop, 7)
             np.testing.assert_array_equal(feat_aug["hops"].cpu().numpy(), g.get(ci, "hop1hot"))
+            if fused_encoding:
+                feat_aug["hops"] = ops.OneHotCodes(ops.encode_codes("hops", hop, 7), 7)
+                np.testing.assert_array_equal(feat_aug["hops"].dense().cpu().numpy(), g.get(ci, "hop1hot"))
         batch = OneBatchSubgraph(
             [_csr(g.get(ci, "indptr"), g.get(ci, "indices"))], [torch.tensor(g.get(ci, "X"), device=DEV)],
             torch.tensor(g.get(ci, "labels"), device=DEV),

@@ -139,3 +139,82 @@ def test_two_rank_data_parallel_step_equals_single_process():
         model.step(TRAIN, "running", mb.one_batch(TRAIN))
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(res[0][k], v.cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_subgraph_cache_record_then_reuse(prefetch):
+    """Deterministic (PPR) sampler: epoch 1 records every subgraph on the device, later epochs are
+    rebuilt from the cache for a DIFFERENT root order and equal a fresh sample of the same roots
+    (CachedSubgraph / PoolSubgraph.collate, shaDow/minibatch.py:21-91, :403-426); the full graph can be
+    dropped afterwards (:336-341); disable_cache goes back to sampling (:490-492)."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    N = 3000
+    indptr, indices = make_graph_numpy(N, 8, seed=5)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(N, 12, generator=g)
+    label = torch.randint(0, 5, (N,), generator=g)
+    roots = np.random.default_rng(1).permutation(N)[:70].astype(np.uint32)
+    table = so.ppr_approximate(indptr, indices, roots, k=12, alpha=0.85, epsilon=1e-4, num_threads=4)
+    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+                                   dict(method="ppr", k=12, threshold=0.0, add_self_edge=True), ("hops",), feat, label,
+                                   batch_size=16, device=DEV, seed_cpp=2, prefetch=prefetch)
+    mb.epoch_start_reset(0, TRAIN)
+    hs = mb.graph_sampler[TRAIN]
+    hs.set_ppr(roots, table.len, table.neigh, table.score)
+    assert mb.record_subgraphs[TRAIN] == "record"
+    mb.shuffle_entity(TRAIN, perm=np.arange(70))
+    ep1 = _epoch(mb)
+    assert mb.record_subgraphs[TRAIN] == "reuse"
+    assert mb.cache_subg[TRAIN].stats()["num_recorded"] == 70
+    perm2 = np.random.default_rng(9).permutation(70)
+    mb.epoch_start_reset(1, TRAIN)
+    mb.shuffle_entity(TRAIN, perm=perm2)
+    mb.drop_full_graph_info(TRAIN)                     # nothing samples from the CSR any more
+    ep2 = _epoch(mb)
+    assert [b.device_batch.num_subgraphs for b in ep2] == [16, 16, 16, 16, 6]
+    r2 = roots[perm2]
+    for bi, b in enumerate(ep2):
+        rb = r2[bi * 16:(bi + 1) * 16]
+        ref = so.sample_batch(indptr, indices, rb, method="ppr", k=12, threshold=0.0, add_self_edge=True,
+                              aug=("hops",), ppr=table, seed=2, serial_base=0)
+        h = b.device_batch.to_host()
+        for f in ("node", "indptr", "indices", "edge_id", "target", "hop"):
+            assert np.array_equal(h[f], getattr(ref, f)), (bi, f)
+        assert np.array_equal(h["ppr"].view(np.uint32), ref.ppr.view(np.uint32))
+        assert torch.equal(b.feat_ens[0].cpu(), feat[torch.as_tensor(ref.node.astype(np.int64))])
+        assert torch.equal(b.label.cpu(), label[torch.as_tensor(rb.astype(np.int64))])
+    # epoch-1 batches were plain samples of the original order
+    h0 = ep1[0].device_batch.to_host()
+    ref0 = so.sample_batch(indptr, indices, roots[:16], method="ppr", k=12, threshold=0.0, add_self_edge=True,
+                           aug=("hops",), ppr=table, seed=2, serial_base=0)
+    assert np.array_equal(h0["node"], ref0.node) and np.array_equal(h0["indices"], ref0.indices)
+
+
+def test_subgraph_cache_api_errors_and_growth():
+    from shadow_gnn_amd._lib import ShadowHipError
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig, SubgraphCache
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(5000, 10, seed=7)
+    hs = HipSampler(indptr, indices, device=torch.device(DEV), seed=1)
+    roots = np.arange(0, 600, dtype=np.uint32)
+    hs.shuffle_targets(roots)
+    cfg = SamplerConfig(method="khop", depth=2, budget=-1, add_self_edge=False, aug=("hops",))   # full 2-hop: deterministic
+    cache = SubgraphCache(5000, torch.device(DEV))
+    assert cache.is_empty()
+    batches = [hs.sample(cfg, 200) for _ in range(3)]      # three appends: the arena grows
+    for b in batches:
+        cache.record(b)
+    st = cache.stats()
+    assert st["num_recorded"] == 600 and st["nodes"] == sum(b.num_nodes for b in batches)
+    # any subset, any order; deliberately tiny output buffers: finish() re-runs with the exact sizes
+    pick = np.array([599, 0, 250, 3, 401], dtype=np.uint32)
+    got = cache.collate(pick, 1, 1, want_hop=True).to_host()
+    ref = hs.sample(cfg, roots=pick).to_host()
+    for f in ("node", "indptr", "indices", "edge_id", "target", "hop", "subg_node_off", "subg_edge_off"):
+        assert np.array_equal(got[f], ref[f]), f
+    with pytest.raises(ShadowHipError):
+        cache.collate(np.array([4999], dtype=np.uint32), 64, 64)          # never recorded
+    cache.clear()
+    assert cache.is_empty()
