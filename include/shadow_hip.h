@@ -285,6 +285,18 @@ int sl_onehot_linear_bwd(const float *d_dout, int64_t lddo, const uint32_t *d_co
                          uint32_t dim, float *d_dWt, float *d_dbias, float *d_partial, uint32_t partial_blocks,
                          void *stream);
 
+/* Dense feature x weight product of nn.Linear (shaDow/layers.py:433-435, :474-483, :604-611) on the bf16
+ * matrix cores with fp32-level accuracy ("split-bf16": each fp32 operand is split exactly into three bf16
+ * pieces and the six largest cross products are accumulated in fp32; error <= 2^-21 |a||b| per product):
+ *     C[M,N] = A[M,K] . B[N,K]^T,   fp32 row-major in and out, N <= 256.
+ * sl_gemm_pack_b converts B (the Linear weight, [out, in]) once per call into the per-lane MFMA fragment
+ * image (sl_gemm_pack_bytes(N, K) bytes); sl_gemm_nt_f32 streams A and writes C.  A must be 16-byte
+ * aligned with lda % 4 == 0. */
+size_t sl_gemm_pack_bytes(uint32_t N, uint32_t K);
+int sl_gemm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream);
+int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packed_B, float *d_C, int64_t ldc, uint32_t M,
+                   uint32_t N, uint32_t K, void *stream);
+
 /* Fused (bias +) activation + feature normalisation + branch sum:
  *   out = out_scale * sum_{b<nb} ( (h_b - mean) * scale[b] * rsqrt(var + 1e-9) + offset[b] ),
  *   h_b = act_b(Z_b + bias_b), mean/var (biased) over segments of `seg` features

@@ -1,0 +1,322 @@
+// Dense feature x weight GEMMs of the layers (nn.Linear, shaDow/layers.py:433-435, :474-483, :604-611)
+// on the bf16 matrix cores with fp32-level accuracy: the "split-bf16" scheme.
+//
+//   C[M,N] = A[M,K] . B[N,K]^T          A, B, C fp32 row-major (B = nn.Linear.weight, [out, in])
+//
+// Every fp32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 mantissa bits):
+//   x = x_h + x_m + x_l.
+// The product keeps the six largest cross terms
+//   a.b ~= a_h b_h + a_h b_m + a_m b_h + a_m b_m + a_h b_l + a_l b_h        (dropped: <= 2^-21 |a||b|)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The fp32 MFMA
+// path runs at 1/16 of the bf16 rate on gfx950 (157 vs 2500 TFLOP/s), so six bf16 MFMAs are still
+// ~2.7x faster than one fp32 MFMA pass, and for these skinny shapes (M ~ 3e5, N, K <= 256) the kernel
+// ends up bound by streaming A in and C out of HBM (2 x 4 x M x 256 bytes) rather than by the matrix cores.
+//
+// Tiling (wave64, 32x32x16 MFMA):
+//   workgroup = 4 wavefronts; a wavefront owns 32 rows x all N columns (N/32 MFMA tiles).
+//   A is read straight from HBM into registers: lane (row r = lane & 31, half g = lane >> 5) loads the
+//   16 contiguous floats A[row][32u + 16g .. +15] of "unit" u -- a wavefront load covers whole 128-byte
+//   lines -- and splits them in registers.  The two MFMA k-steps of a unit therefore use the physical
+//   columns  k = 32u + 16g + 8h + j  (h = step, j = 0..7); B is packed with the same permutation.
+//   B is pre-split and pre-permuted once per call into the exact per-lane fragment image
+//   [unit][step][piece][column tile][lane][8 x bf16] (sl_gemm_pack_b) and streamed through LDS one unit
+//   (2 steps x 3 pieces x N/32 tiles x 1 KiB) at a time.
+#include <algorithm>
+
+#include "common.h"
+
+namespace shadow {
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmThreads = 256;        // 4 wavefronts per workgroup, two workgroups per CU
+constexpr int kGemmWaves = kGemmThreads / 64;
+
+#ifdef GEMM_TIMING
+__device__ unsigned long long gemm_dbg[16];
+#define GT_STAMP(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) { const unsigned long long n_ = clock64(); gemm_dbg[i] += n_ - tl_; tl_ = n_; } } while (0)
+#else
+#define GT_STAMP(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t lo_src, uint32_t hi_src) {
+  // [hi_src.b3, hi_src.b2, lo_src.b3, lo_src.b2]: two truncated-bf16 values in one dword
+  return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u);
+}
+
+// exact 3-way split of 8 floats into bf16 pieces (truncation: every piece is a prefix of the
+// remaining mantissa, so h + m + l == x bit for bit)
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+  uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t xb = __float_as_uint(x[j]);
+    hb[j] = xb & 0xFFFF0000u;
+    const float r1 = x[j] - __uint_as_float(hb[j]);
+    mb[j] = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mb[j]);
+    lb[j] = __float_as_uint(r2);                 // <= 8 significant bits left: the top half holds them all
+  }
+  union { uint32_t u[4]; bf16x8 v; } H, Mm, L;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    H.u[j] = pack_hi16(hb[2 * j], hb[2 * j + 1]);
+    Mm.u[j] = pack_hi16(mb[2 * j], mb[2 * j + 1]);
+    L.u[j] = pack_hi16(lb[2 * j], lb[2 * j + 1]);
+  }
+  h = H.v; m = Mm.v; l = L.v;
+}
+
+// ---------------------------------------------------------------------------
+// B [N, K] fp32 -> fragment image: for unit u, step h, piece p, tile t, lane l: 8 bf16 =
+// piece_p( B[32t + (l & 31)][32u + 16 (l >> 5) + 8h + j] ), j = 0..7.  Rows >= N and columns >= K are zero.
+// One thread per (u, h, t, l).
+// ---------------------------------------------------------------------------
+__global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t ldb, uint32_t N, uint32_t K, uint32_t units,
+                                   uint32_t tiles, bf16x8 *__restrict__ out) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = units * 2 * tiles * 64;
+  if (idx >= total) return;
+  const uint32_t l = idx & 63, t = (idx >> 6) % tiles, h = ((idx >> 6) / tiles) & 1, u = (idx >> 6) / tiles / 2;
+  const uint32_t col = 32 * t + (l & 31);
+  const uint32_t k0 = 32 * u + 16 * (l >> 5) + 8 * h;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) x[j] = (col < N && k0 + j < K) ? B[(int64_t)col * ldb + k0 + j] : 0.f;
+  bf16x8 hh, mm, ll;
+  split8(x, hh, mm, ll);
+  // image index: ((u*2 + h)*3 + p)*tiles + t, then lane
+  const size_t base = ((size_t)(u * 2 + h) * 3) * tiles;
+  out[(base + 0 * tiles + t) * 64 + l] = hh;
+  out[(base + 1 * tiles + t) * 64 + l] = mm;
+  out[(base + 2 * tiles + t) * 64 + l] = ll;
+}
+
+// ---------------------------------------------------------------------------
+// Main kernel.  A wavefront owns RB x 32 rows and ALL NT column tiles (every A element is loaded by
+// exactly one wavefront); a workgroup = 4 wavefronts.  The B image is streamed one k-step (16 columns)
+// at a time, global -> LDS directly (global_load_lds, no VGPRs), double buffered.  Measured on MI355X:
+// the CU's vector-memory path (64 B/clk), not the matrix cores, is the scarce resource of this kernel, and
+// a burst of loads right after a barrier stalls every wavefront on issue -- so the copies of the next
+// step and the A registers of the next unit are issued one by one between the MFMA groups.  Two
+// workgroups are resident per CU (register-bound): one keeps the matrix cores busy while the other sits
+// in a barrier or in its epilogue.
+// ---------------------------------------------------------------------------
+template <int RB, int NT, bool kTail>     // kTail: K is not a multiple of 32 (the last unit is zero-padded)
+__global__ void __launch_bounds__(kGemmThreads, 2)
+gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__restrict__ Bimg, float *__restrict__ C,
+                     int64_t ldc, uint32_t M, uint32_t N, uint32_t K, uint32_t units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  constexpr int kRowsWG = 32 * RB * kGemmWaves;
+  constexpr int kPieces = 4 * RB;                        // 16-byte A pieces per lane per unit
+  constexpr int kPPS = (kPieces + 2 * NT - 1) / (2 * NT);   // A pieces issued per (step, tile) slot
+  constexpr int kStepVecs = 3 * NT * 64;                 // bf16x8 vectors of one k-step's B image
+  constexpr int kFill = (kStepVecs + kGemmThreads - 1) / kGemmThreads;     // copies per thread per step
+  constexpr int kFillPerSlot = (kFill + NT - 1) / NT;
+  bf16x8 *lbuf = reinterpret_cast<bf16x8 *>(gsm);       // [2][kStepVecs]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t r = lane & 31u, g = lane >> 5;
+  const uint64_t m0 = (uint64_t)blockIdx.x * kRowsWG + wv * (32u * RB);
+  const float *arow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; rb++) {
+    const uint64_t row = min(m0 + 32u * rb + r, (uint64_t)M - 1);   // rows past the end repeat the last row (never stored)
+    arow[rb] = A + row * lda + 16 * g;
+  }
+
+  f32x16 acc[RB][NT];
+#pragma unroll
+  for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[rb][t][i] = 0.f;
+
+  float4 an[RB][4];                                      // A of the next unit
+  // piece p = (row block p / 4, quarter p % 4) of unit u
+  auto load_a_piece = [&](uint32_t u, int p) {
+    const int rb = p >> 2, q = p & 3;
+    const float *ptr = arow[rb] + 32 * u + 4 * q;
+    if (!kTail || 32 * u + 32 <= K) {
+      an[rb][q] = *reinterpret_cast<const float4 *>(ptr);
+    } else {
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { const uint32_t k = 32 * u + 16 * g + 4 * q + c; v[c] = k < K ? ptr[c] : 0.f; }
+      an[rb][q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  // copies `slot` (of NT) of the B image of k-step s into LDS buffer s & 1
+  auto fill_b = [&](uint32_t s, int slot) {
+    const bf16x8 *src = Bimg + (size_t)s * kStepVecs;
+    bf16x8 *dst = lbuf + (size_t)(s & 1) * kStepVecs;
+#pragma unroll
+    for (int q = slot * kFillPerSlot; q < (slot + 1) * kFillPerSlot && q < kFill; q++) {
+      const uint32_t base = q * kGemmThreads + wv * 64u;               // wave-uniform
+      if (base < (uint32_t)kStepVecs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + base + lane),
+                                         (__attribute__((address_space(3))) void *)(dst + base), 16, 0, 0);
+    }
+  };
+
+#ifdef GEMM_TIMING
+  unsigned long long tl_ = clock64();
+  const unsigned long long t0_ = tl_, w0_ = wall_clock64();
+#endif
+#pragma unroll
+  for (int slot = 0; slot < NT; slot++) fill_b(0, slot);
+#pragma unroll
+  for (int p = 0; p < kPieces; p++) load_a_piece(0, p);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  GT_STAMP(0);
+  float4 ac[RB][4];
+  const uint32_t steps = 2 * units;
+  for (uint32_t u = 0; u < units; u++) {
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) ac[rb][q] = an[rb][q];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t st = 2 * u + h;
+      const bf16x8 *lb = lbuf + (size_t)(st & 1) * kStepVecs;
+      bf16x8 ah[RB], am[RB], al[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) {
+        const float x[8] = {ac[rb][2 * h].x, ac[rb][2 * h].y, ac[rb][2 * h].z, ac[rb][2 * h].w,
+                            ac[rb][2 * h + 1].x, ac[rb][2 * h + 1].y, ac[rb][2 * h + 1].z, ac[rb][2 * h + 1].w};
+        split8(x, ah[rb], am[rb], al[rb]);
+      }
+      GT_STAMP(1);
+      // B fragments are read one tile ahead of the MFMAs that consume them
+      bf16x8 fb[2][3];
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) fb[0][pc] = lb[(pc * NT) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        if (t + 1 < NT) {
+#pragma unroll
+          for (int pc = 0; pc < 3; pc++) fb[(t + 1) & 1][pc] = lb[(pc * NT + t + 1) * 64 + lane];
+        }
+        if (st + 1 < steps) fill_b(st + 1, t);
+        if (u + 1 < units) {
+#pragma unroll
+          for (int p = (h * NT + t) * kPPS; p < (h * NT + t + 1) * kPPS && p < kPieces; p++) load_a_piece(u + 1, p);
+        }
+        const bf16x8 bh = fb[t & 1][0], bm = fb[t & 1][1], bl = fb[t & 1][2];
+        // small terms first, the dominant product last; row blocks alternate
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rb], bh, acc[rb][t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rb], bl, acc[rb][t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rb], bm, acc[rb][t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rb], bh, acc[rb][t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rb], bm, acc[rb][t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rb], bh, acc[rb][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      GT_STAMP(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next image (and A pieces) landed
+      GT_STAMP(3);
+      __syncthreads();                                   // ... for every wavefront; this buffer may be refilled
+      GT_STAMP(4);
+    }
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int rb = 0; rb < RB; rb++) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const uint32_t col = 32 * t + r;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const uint64_t rr = m0 + 32u * rb + (i & 3) + 8 * (i >> 2) + 4 * g;
+        if (rr < M && col < N) C[rr * ldc + col] = acc[rb][t][i];
+      }
+    }
+  }
+  GT_STAMP(5);
+#ifdef GEMM_TIMING
+  if (blockIdx.x == 7 && threadIdx.x == 0) { gemm_dbg[6] += clock64() - t0_; gemm_dbg[7] += wall_clock64() - w0_; gemm_dbg[8] += 1; }
+#endif
+}
+
+}  // namespace
+}  // namespace shadow
+
+using namespace shadow;
+
+// row blocks per wavefront for a given number of 32-column tiles (narrow outputs: two row blocks)
+static int gemm_rb(uint32_t tiles) { return tiles <= 4 ? 2 : 1; }
+
+extern "C" size_t sl_gemm_pack_bytes(uint32_t N, uint32_t K) {
+  const size_t units = (K + 31) / 32, tiles = (N + 31) / 32;
+  return units * 6 * tiles * 64 * 16;
+}
+
+extern "C" int sl_gemm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream) {
+  if (!d_B || !d_packed) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b: null argument");
+  if (N == 0 || K == 0) return SG_OK;
+  if (N > 256) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b: N = %u (at most 256 output columns)", N);
+  const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
+  const uint32_t total = units * 2 * tiles * 64;
+  hipLaunchKernelGGL(gemm_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_B, ldb, N, K,
+                     units, tiles, reinterpret_cast<bf16x8 *>(d_packed));
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packed_B, float *d_C, int64_t ldc,
+                              uint32_t M, uint32_t N, uint32_t K, void *stream) {
+  if (!d_A || !d_packed_B || !d_C) return set_error(SG_ERR_INVALID, "sl_gemm_nt_f32: null argument");
+  if (M == 0 || N == 0) return SG_OK;
+  if (K == 0) return set_error(SG_ERR_INVALID, "sl_gemm_nt_f32: K == 0");
+  if (N > 256) return set_error(SG_ERR_INVALID, "sl_gemm_nt_f32: N = %u (at most 256 output columns)", N);
+  if ((lda & 3) || (reinterpret_cast<uintptr_t>(d_A) & 15))
+    return set_error(SG_ERR_INVALID, "sl_gemm_nt_f32: A must be 16-byte aligned with lda %% 4 == 0");
+  const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
+  const int rb = gemm_rb(tiles);
+  const uint32_t rows_wg = 32u * (uint32_t)rb * (uint32_t)kGemmWaves;
+  const uint32_t grid = (M + rows_wg - 1) / rows_wg;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16x8 *img = reinterpret_cast<const bf16x8 *>(d_packed_B);
+  const size_t lds = (size_t)2 * 3 * tiles * 64 * 16;
+#define SHD_GEMM(RB, NT)                                                                                     \
+  {                                                                                                          \
+    if (K % 32 == 0)                                                                                         \
+      hipLaunchKernelGGL((gemm_nt_split_kernel<RB, NT, false>), dim3(grid), dim3(kGemmThreads), lds, st, d_A, lda, img, \
+                         d_C, ldc, M, N, K, units);                                                          \
+    else                                                                                                     \
+      hipLaunchKernelGGL((gemm_nt_split_kernel<RB, NT, true>), dim3(grid), dim3(kGemmThreads), lds, st, d_A, lda, img, \
+                         d_C, ldc, M, N, K, units);                                                          \
+  }
+  switch (tiles) {
+    case 1: SHD_GEMM(2, 1) break;
+    case 2: SHD_GEMM(2, 2) break;
+    case 3: SHD_GEMM(2, 3) break;
+    case 4: SHD_GEMM(2, 4) break;
+    case 5: SHD_GEMM(1, 5) break;
+    case 6: SHD_GEMM(1, 6) break;
+    case 7: SHD_GEMM(1, 7) break;
+    default: SHD_GEMM(1, 8) break;
+  }
+#undef SHD_GEMM
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+#ifdef GEMM_TIMING
+extern "C" int sl_gemm_debug_read(unsigned long long *out, int reset) {
+  SHD_HIP(hipDeviceSynchronize());
+  SHD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(shadow::gemm_dbg), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; SHD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(shadow::gemm_dbg), z, sizeof(z))); }
+  return SG_OK;
+}
+#endif

@@ -9,6 +9,7 @@ Every op launches hand-written HIP kernels through the C ABI on the current
 torch stream.  No CPU / torch fallback: tensors must live on a ROCm device.
 """
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -348,6 +349,33 @@ class _ActNorm(torch.autograd.Function):
         return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, *dZs)
 
 
+# split-bf16 MFMA GEMM (csrc/gemm.hip) for the tall feature x weight products; rocBLAS fp32 otherwise
+GEMM_SPLIT_MIN_ROWS = 8192
+GEMM_SPLIT = os.environ.get("SHADOW_GEMM_SPLIT", "1") != "0"
+
+
+def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A[M,K] @ B[N,K]^T in fp32.  Tall products (M >= 8192, N <= 256) run on the bf16 matrix cores
+    with the exact three-way operand split (fp32-level accuracy, see csrc/gemm.hip); the rest goes to
+    rocBLAS."""
+    M, K = A.shape
+    N = B.shape[0]
+    if not (GEMM_SPLIT and A.is_cuda and M >= GEMM_SPLIT_MIN_ROWS and N <= 256 and A.dtype == torch.float32
+            and A.stride(1) == 1 and A.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0):
+        return A @ B.t()
+    lib = _lib.load()
+    Bc = B.detach()
+    if Bc.stride(1) != 1:
+        Bc = Bc.contiguous()
+    packed = torch.empty(lib.sl_gemm_pack_bytes(N, K), dtype=torch.uint8, device=A.device)
+    Cm = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    st = _stream(A)
+    check(lib.sl_gemm_pack_b(Bc.data_ptr(), Bc.stride(0), N, K, packed.data_ptr(), st))
+    with _timed(f"gemm_nt_N{N}_K{K}", 4 * M * (K + N), A.device):
+        check(lib.sl_gemm_nt_f32(A.data_ptr(), A.stride(0), packed.data_ptr(), Cm.data_ptr(), Cm.stride(0), M, N, K, st))
+    return Cm
+
+
 def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
     """dW = dZ^T X for tall inputs (K = number of batch nodes, hundreds of thousands).
     rocBLAS picks a 32-workgroup kernel for a plain 256 x n x 256 product; splitting n
@@ -372,13 +400,14 @@ class _Linear(torch.autograd.Function):
         X = _f32c(X).contiguous()
         ctx.save_for_backward(X, W)
         ctx.has_bias = b is not None
-        return torch.addmm(b, X, W.t()) if b is not None else X @ W.t()
+        Z = mm_nt(X, W)
+        return Z + b if b is not None else Z
 
     @staticmethod
     def backward(ctx, dZ):
         X, W = ctx.saved_tensors
         dZ = _f32c(dZ).contiguous()
-        dX = dZ @ W if ctx.needs_input_grad[0] else None
+        dX = mm_nt(dZ, W.t()) if ctx.needs_input_grad[0] else None
         dW = weight_grad(dZ, X) if ctx.needs_input_grad[1] else None
         db = dZ.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dX, dW, db
@@ -390,7 +419,8 @@ def linear(X, lin: "torch.nn.Linear"):
 
 class _LinearActNorm(torch.autograd.Function):
     """out = out_scale * sum_b norm_b(act_b(X_b W_b^T + bias_b)): the dense tail of a
-    GCN / GraphSAGE / MLP layer as ONE autograd node.  GEMMs on rocBLAS (MFMA); bias add,
+    GCN / GraphSAGE / MLP layer as ONE autograd node.  GEMMs through mm_nt (split-bf16 MFMA kernel for
+    the tall products, rocBLAS otherwise); bias add,
     activation, normalisation, branch sum and -- in backward -- dZ, dscale, doffset AND the
     bias gradients come from one HIP kernel pass each."""
     @staticmethod
@@ -402,7 +432,7 @@ class _LinearActNorm(torch.autograd.Function):
         F = Ws[0].shape[0]
         sc = scale.reshape(nb, F).contiguous().float()
         of = offset.reshape(nb, F).contiguous().float()
-        Zs = [x @ w.t() for x, w in zip(Xs, Ws)]
+        Zs = [mm_nt(x, w) for x, w in zip(Xs, Ws)]
         bsc = [b.detach().contiguous() if b is not None else None for b in bs]
         out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale)
         ctx.save_for_backward(sc, of, *Xs, *Ws, *Zs, *[b if b is not None else sc.new_empty(0) for b in bsc])
@@ -418,7 +448,7 @@ class _LinearActNorm(torch.autograd.Function):
         biases = [b if hb else None for b, hb in zip(bs, has_b)]
         dZs, dsc, dof, dbi = _an_bwd(list(Zs), biases, acts, sc, of, seg, out_scale, dout, [True] * nb, any(has_b))
         ng = ctx.needs_input_grad
-        dXs = [dz @ w if ng[6 + i] else None for i, (dz, w) in enumerate(zip(dZs, Ws))]
+        dXs = [mm_nt(dz, w.t()) if ng[6 + i] else None for i, (dz, w) in enumerate(zip(dZs, Ws))]
         dWs = [weight_grad(dz, x) if ng[6 + nb + i] else None for i, (dz, x) in enumerate(zip(dZs, Xs))]
         dbs = [dbi[i] if (has_b[i] and ng[6 + 2 * nb + i]) else None for i in range(nb)]
         return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, *dXs, *dWs, *dbs)
