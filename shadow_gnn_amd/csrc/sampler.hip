@@ -704,7 +704,9 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       if ((rc = ensure(&s->d_big, &s->big_bytes, (size_t)nslots * stride * 4)) != SG_OK) return rc;
       q.g_tables = (uint32_t *)s->d_big; q.g_stride = stride;
       q.g_ticket = (uint32_t *)(s->d_counts + 8) + 1;
-      hipLaunchKernelGGL(sg_sample_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
+      const size_t big_lds = (size_t)kBitWordsBig * 4;
+      SHD_HIP(hipFuncSetAttribute((const void *)sg_sample_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+      hipLaunchKernelGGL(sg_sample_big_kernel, dim3(nslots), dim3(Tb), big_lds, stream, q);
       SHD_HIP(hipGetLastError());
     }
     if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[1], stream));

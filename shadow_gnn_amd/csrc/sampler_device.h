@@ -37,6 +37,7 @@ constexpr uint32_t kMaxRoots = 8;
 constexpr uint32_t kStash = 64;          // overflow entries behind the bucket array
 constexpr uint32_t kSortBuckets = 256;
 constexpr uint32_t kBitWords = 2048;     // membership filter: 64 Ki bits indexed by the low id bits
+constexpr uint32_t kBitWordsBig = 32768; // same for the global-table path (node sets of 10^3..10^5): 1 Mi bits
 
 // control words (LDS)
 enum { C_NNODES = 0, C_NF0 = 1, C_NF1 = 2, C_OVF = 3, C_MFAIL = 4, C_FRONT_NODES = 5,
@@ -115,7 +116,7 @@ struct Tables {
   uint32_t *bhead;   // [kSortBuckets]
   uint32_t *bcnt;    // [kSortBuckets]
   unsigned char *wtmp;  // [waves * 128] wave-private scratch of the scan (LDS)
-  uint32_t *bits;    // [kBitWords] membership filter over the node set (LDS; aliases the frontiers)
+  uint32_t *bits;    // [kBitWords / kBitWordsBig] membership filter over the node set (LDS; aliases the frontiers)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -241,11 +242,12 @@ __device__ __forceinline__ void block_sort_u32(uint32_t *a, uint32_t n) {
 }
 
 // membership-filter probe of one aligned quad: bit c = component c may be in the node set
+template <uint32_t kBW>
 __device__ __forceinline__ uint32_t probe_quad(const uint32_t *bits, const uint4 c) {
-  const uint32_t w0 = bits[(c.x >> 5) & (kBitWords - 1u)];
-  const uint32_t w1 = bits[(c.y >> 5) & (kBitWords - 1u)];
-  const uint32_t w2 = bits[(c.z >> 5) & (kBitWords - 1u)];
-  const uint32_t w3 = bits[(c.w >> 5) & (kBitWords - 1u)];
+  const uint32_t w0 = bits[(c.x >> 5) & (kBW - 1u)];
+  const uint32_t w1 = bits[(c.y >> 5) & (kBW - 1u)];
+  const uint32_t w2 = bits[(c.z >> 5) & (kBW - 1u)];
+  const uint32_t w3 = bits[(c.w >> 5) & (kBW - 1u)];
   return ((w0 >> (c.x & 31u)) & 1u) | (((w1 >> (c.y & 31u)) & 1u) << 1) |
          (((w2 >> (c.z & 31u)) & 1u) << 2) | (((w3 >> (c.w & 31u)) & 1u) << 3);
 }
@@ -500,11 +502,12 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
   const uint32_t S = carry_s, Q = carry_q;
   // membership filter for the streaming scan: bit (id mod 2^16) of every node.  A set bit is only a
   // candidate (resolved exactly against the hash table after the scan); a clear bit is a definite miss.
-  for (uint32_t w = tid; w < kBitWords; w += T) t.bits[w] = 0;
+  constexpr uint32_t kBW = kGlobalTables ? kBitWordsBig : kBitWords;
+  for (uint32_t w = tid; w < kBW; w += T) t.bits[w] = 0;
   __syncthreads();
   for (uint32_t i = tid; i < n; i += T) {
     const uint32_t v = t.nodes[i];
-    atomicOr(&t.bits[(v >> 5) & (kBitWords - 1u)], 1u << (v & 31u));
+    atomicOr(&t.bits[(v >> 5) & (kBW - 1u)], 1u << (v & 31u));
   }
   __syncthreads();
   SHD_STAMP(1);   // sort + rank + prefixes done
@@ -563,7 +566,7 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
             if (!inserted && (uint64_t)e0 + deg < p.nnz) {              // .cpp:401-405
               // (a neighbour candidate like any other: resolved and root-filtered after the scan)
               const uint32_t c = p.indices[e0 + deg];
-              if ((t.bits[(c >> 5) & (kBitWords - 1u)] >> (c & 31u)) & 1u) {
+              if ((t.bits[(c >> 5) & (kBW - 1u)] >> (c & 31u)) & 1u) {
                 keys[1] = 2u * (rs + deg) + 1u; vals[1] = c; mask |= 2u;
               }
             }
@@ -623,7 +626,7 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
               SHD_T(1);
               uint32_t hit = 0;        // bit (4u + c): component c of group u is a candidate
 #pragma unroll
-              for (int u = 0; u < kUnroll; u++) hit |= probe_quad(t.bits, c4[u]) << (4 * u);
+              for (int u = 0; u < kUnroll; u++) hit |= probe_quad<kBW>(t.bits, c4[u]) << (4 * u);
               SHD_T(2);
               if (hit) {
                 uint32_t r = atomicAdd(&ctrl[C_M], (uint32_t)__popc(hit));
@@ -713,7 +716,7 @@ __device__ __forceinline__ void sample_subgraph(const SampleParams &p, uint32_t 
 #pragma unroll
           for (int c = 0; c < 4; c++)
             if (lane < d_take[u] && (j0 + c < deg)) vmask |= 1u << c;
-          hit |= (probe_quad(t.bits, cand[u]) & vmask) << (4 * u);
+          hit |= (probe_quad<kBW>(t.bits, cand[u]) & vmask) << (4 * u);
           if (!kPlain && incl_self) {
             // the self edge goes right before the first neighbour > v (.cpp:387-400, :408-410)
             const uint32_t v = t.nodes[l_row[u]];
@@ -921,7 +924,8 @@ __global__ void sg_sample_big_kernel(SampleParams p) {
   __shared__ uint32_t wsum[32];
   __shared__ uint32_t bhead[kSortBuckets];
   __shared__ uint32_t bcnt[kSortBuckets];
-  __shared__ uint32_t bits[kBitWords];
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];     // [kBitWordsBig] words
+  uint32_t *bits = reinterpret_cast<uint32_t *>(big_smem);
   __shared__ __attribute__((aligned(16))) unsigned char wtmp[16 * 128];
   __shared__ uint32_t s_next;
   uint32_t *base = p.g_tables + (size_t)blockIdx.x * p.g_stride;

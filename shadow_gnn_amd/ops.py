@@ -40,18 +40,20 @@ class KernelTimer:
     def summary(self):
         out = {}
         for name, items in self.rec.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _b in items)
-            by = sum(b for _e0, _e1, b in items)
+            ms = sum(it[0].elapsed_time(it[1]) for it in items)
+            by = sum(it[2] for it in items)
+            fl = sum(it[3] for it in items)
             out[name] = dict(launches=len(items), total_ms=ms, avg_ms=ms / max(1, len(items)),
-                             bytes_per_launch=by / max(1, len(items)), gbps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0)
+                             bytes_per_launch=by / max(1, len(items)), gbps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0,
+                             flops_per_launch=fl / max(1, len(items)))
         return out
 
 
 class _timed:
-    def __init__(self, name, nbytes, device):
+    def __init__(self, name, nbytes, device, flops=0):
         self.t = KernelTimer.active
         if self.t is not None:
-            self.name, self.nbytes = name, nbytes
+            self.name, self.nbytes, self.flops = name, nbytes, flops
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
 
@@ -63,7 +65,7 @@ class _timed:
     def __exit__(self, *a):
         if self.t is not None:
             self.e1.record()
-            self.t.rec.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes))
+            self.t.rec.setdefault(self.name, []).append((self.e0, self.e1, self.nbytes, self.flops))
 
 
 def _stream(t: torch.Tensor):
@@ -371,7 +373,7 @@ def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     Cm = torch.empty(M, N, dtype=torch.float32, device=A.device)
     st = _stream(A)
     check(lib.sl_gemm_pack_b(Bc.data_ptr(), Bc.stride(0), N, K, packed.data_ptr(), st))
-    with _timed(f"gemm_nt_N{N}_K{K}", 4 * M * (K + N), A.device):
+    with _timed(f"gemm_nt_N{N}_K{K}", 4 * M * (K + N), A.device, flops=2 * M * K * N):
         check(lib.sl_gemm_nt_f32(A.data_ptr(), A.stride(0), packed.data_ptr(), Cm.data_ptr(), Cm.stride(0), M, N, K, st))
     return Cm
 
