@@ -107,19 +107,30 @@ __device__ __forceinline__ void bfs_local(const uint32_t *rowptr, const uint32_t
 
 __global__ void sg_relocate_kernel(RelocParams p) {
   __shared__ uint64_t red[4 * 16];
+  __shared__ uint64_t stat[16][5];
   __shared__ uint64_t offs[2];
   __shared__ uint32_t changed;
   const uint32_t s = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
-  // exclusive prefix of (nodes, edges) over the preceding subgraphs
-  uint64_t pn = 0, pe = 0;
-  for (uint32_t q = tid; q < s; q += T) {
+  // exclusive prefix of (nodes, edges) over the preceding subgraphs; the LAST workgroup also folds
+  // the batch statistics of every subgraph (same pass, no contended global atomics)
+  const bool last = (s + 1 == p.P);
+  uint64_t pn = 0, pe = 0, sl = 0, fn = 0, fr = 0;
+  uint32_t mxn = 0, mxe = 0;
+  for (uint32_t q = tid; q < s + (last ? 1u : 0u); q += T) {
     const uint32_t *c = p.s_cnt + (size_t)q * R_WORDS;
-    pn += c[R_N];
-    pe += c[R_E];
+    if (q < s) { pn += c[R_N]; pe += c[R_E]; }
+    if (last) { sl += c[R_SLOTS]; fn += c[R_FNODES]; fr += c[R_FREADS]; mxn = max(mxn, c[R_N]); mxe = max(mxe, c[R_E]); }
   }
   for (int off = 32; off >= 1; off >>= 1) { pn += __shfl_xor(pn, off, 64); pe += __shfl_xor(pe, off, 64); }
   if (lane == 0) { red[wave] = pn; red[16 + wave] = pe; }
+  if (last) {
+    for (int off = 32; off >= 1; off >>= 1) {
+      sl += __shfl_xor(sl, off, 64); fn += __shfl_xor(fn, off, 64); fr += __shfl_xor(fr, off, 64);
+      mxn = max(mxn, (uint32_t)__shfl_xor((int)mxn, off, 64)); mxe = max(mxe, (uint32_t)__shfl_xor((int)mxe, off, 64));
+    }
+    if (lane == 0) { stat[wave][0] = sl; stat[wave][1] = fn; stat[wave][2] = fr; stat[wave][3] = mxn; stat[wave][4] = mxe; }
+  }
   __syncthreads();
   if (tid == 0) {
     uint64_t a = 0, b = 0;
@@ -134,13 +145,15 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   if (tid == 0) {
     o.d_subg_nodes[s] = (uint32_t)noff;
     o.d_subg_edges[s] = (uint32_t)eoff;
-    if (s + 1 == p.P) { o.d_subg_nodes[p.P] = (uint32_t)(noff + n); o.d_subg_edges[p.P] = (uint32_t)(eoff + e); }
-    atomicMax((unsigned long long *)&p.d_counts[2], (unsigned long long)n);
-    atomicMax((unsigned long long *)&p.d_counts[3], (unsigned long long)e);
-    atomicAdd((unsigned long long *)&p.d_counts[5], (unsigned long long)c[R_SLOTS]);
-    atomicAdd((unsigned long long *)&p.d_counts[6], (unsigned long long)c[R_FNODES]);
-    atomicAdd((unsigned long long *)&p.d_counts[7], (unsigned long long)c[R_FREADS]);
-    if (s + 1 == p.P) { p.d_counts[0] = noff + n; p.d_counts[1] = eoff + e; }
+    if (last) {
+      o.d_subg_nodes[p.P] = (uint32_t)(noff + n); o.d_subg_edges[p.P] = (uint32_t)(eoff + e);
+      uint64_t t0 = 0, t1 = 0, t2 = 0, m0 = 0, m1 = 0;
+      for (uint32_t w = 0; w < nw; w++) {
+        t0 += stat[w][0]; t1 += stat[w][1]; t2 += stat[w][2]; m0 = max(m0, stat[w][3]); m1 = max(m1, stat[w][4]);
+      }
+      p.d_counts[0] = noff + n; p.d_counts[1] = eoff + e;
+      p.d_counts[2] = m0; p.d_counts[3] = m1; p.d_counts[5] = t0; p.d_counts[6] = t1; p.d_counts[7] = t2;
+    }
   }
   uint32_t ovf = flags & 3u;
   if (noff + n > o.cap_nodes) ovf |= 4u;
@@ -154,11 +167,13 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   uint32_t *rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
   const uint32_t *erow = p.s_row + (size_t)s * p.cap_edges_scr;
   const uint32_t *col = p.s_col + (size_t)s * p.cap_edges_scr;
-  // local CSR row pointers: edges are ordered by row -> rowptr[i] = lower_bound(erow, i)
-  for (uint32_t i = tid; i <= n; i += T) {
-    uint32_t lo = 0, hi = e;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (erow[mid] < i) lo = mid + 1; else hi = mid; }
-    rowptr[i] = lo;
+  // local CSR row pointers: edges are ordered by row, so rowptr[i] = first edge j with erow[j] >= i.
+  // Every edge that starts a new row fills the pointers of the rows since the previous edge's row
+  // (two coalesced reads per edge instead of a binary search per node).
+  for (uint32_t j = tid; j <= e; j += T) {
+    const uint32_t r_hi = (j < e) ? erow[j] : n;                 // rows (r_lo, r_hi] start at edge j
+    const uint32_t r_lo = (j > 0) ? erow[j - 1] + 1u : 0u;
+    for (uint32_t i = r_lo; i <= r_hi && i <= n; i++) rowptr[i] = j;
   }
   __syncthreads();
   const uint32_t *eid = p.s_eid + (size_t)s * p.cap_edges_scr;
