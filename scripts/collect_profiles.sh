@@ -6,7 +6,7 @@
 set -uo pipefail
 TAG="${1:-r01}"; shift || true
 R="${GRAFT_REPO_ROOT:-$PWD}"
-OUT="$R/gpurun_out/prof_$TAG"
+OUT="$R/gpurun_out/prof_$TAG"   # (clear the local copy too before a re-run: gpurun merges, it does not mirror)
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"

@@ -17,7 +17,7 @@ out, tag = sys.argv[1], sys.argv[2]
 
 
 def short(name):
-    n = name.split("(")[0].replace("void ", "").replace("shadow::", "")
+    n = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("shadow::", "")
     return n[:60]
 
 
