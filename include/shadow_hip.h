@@ -259,6 +259,14 @@ int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off,
                           uint32_t num_subg, uint32_t max_subg_nodes, void *stream);
 
+/* Weight gradient of nn.Linear with the same split-bf16 arithmetic:  C[N,K] = A[M,N]^T . B[M,K]
+ * (A = dZ, B = the layer input; N, K <= 256 and multiples of 4; operands 16-byte aligned, ld % 4 == 0).
+ * The rows are cut into sl_gemm_tn_slices(M) slices, one workgroup each; d_partial holds the per-slice
+ * products ([slices, N, K] floats) that a second kernel adds in a fixed order (deterministic). */
+uint32_t sl_gemm_tn_slices(uint32_t M);
+int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb, float *d_C, uint32_t M, uint32_t N,
+                   uint32_t K, float *d_partial, void *stream);
+
 /* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
  * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)
  * in ResPool (shaDow/layers.py:166-183).  d_argmax [num_subg, F] (max mode; may be NULL otherwise) receives

@@ -24,3 +24,11 @@ for (M, K, N) in [(289252, 256, 256), (289252, 100, 256), (289252, 256, 47), (40
     fl = 2.0 * M * K * N
     print(f"M={M} K={K} N={N}: split {ms_s:.3f} ms ({fl/ms_s/1e9:.0f} TF-equiv, {4*M*(K+N)/ms_s/1e6:.0f} GB/s)  rocBLAS {ms_b:.3f} ms ({fl/ms_b/1e9:.0f} TF)  "
           f"max err/|a||b|: split {e_split:.2e} rocBLAS {e_blas:.2e}  maxabs diff {float((got-blas).abs().max()):.3e}")
+print("--- weight gradient dW = dZ^T X")
+for (M, N, K) in [(289252, 256, 256), (289252, 256, 100)]:
+    dZ = torch.randn(M, N, device=dev); X = torch.randn(M, K, device=dev)
+    ops.GEMM_SPLIT = True;  ms_s = t(lambda: ops.weight_grad(dZ, X)); a = ops.weight_grad(dZ, X)
+    ops.GEMM_SPLIT = False; ms_b = t(lambda: ops.weight_grad(dZ, X)); b = ops.weight_grad(dZ, X)
+    ops.GEMM_SPLIT = True
+    ref = dZ.double().t() @ X.double(); den = dZ.abs().double().t() @ X.abs().double()
+    print(f"M={M} N={N} K={K}: split {ms_s:.3f} ms  rocBLAS split-K {ms_b:.3f} ms  err split {float(((a.double()-ref).abs()/den).max()):.2e} rocBLAS {float(((b.double()-ref).abs()/den).max()):.2e}")

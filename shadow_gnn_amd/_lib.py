@@ -100,6 +100,8 @@ SIGNATURES = {
     "sl_gemm_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_gemm_pack_b": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_gemm_nt_f32": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
+    "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
     "sl_segment_pool_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, _P, C.c_int64, _P]),
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),

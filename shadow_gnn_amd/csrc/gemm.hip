@@ -320,3 +320,176 @@ extern "C" int sl_gemm_debug_read(unsigned long long *out, int reset) {
   return SG_OK;
 }
 #endif
+
+// ===========================================================================
+// Weight gradient  dW[N,K] = A[M,N]^T . B[M,K]   (A = dZ, B = layer input; M = batch nodes)
+// ===========================================================================
+// Same split-bf16 arithmetic; the reduction runs over the ROWS, so both operands are needed "k-major".
+// Each workgroup owns a slice of the rows and walks it 16 rows (one MFMA k-step) at a time: the 16 x N
+// and 16 x K fp32 row tiles go global -> LDS with global_load_lds (whole rows, lane-linear, double
+// buffered, trickled between the MFMA groups); a fragment is eight ds_read_b32 down a column (one per
+// row of the lane's half of the step), split into its three bf16 pieces in registers.  The 8 wavefronts
+// form a 4 (N) x 2 (K) grid, each holding 2 x TK accumulator tiles.  Every workgroup writes its partial
+// [N, K] product; gemm_tn_reduce_kernel adds the partials in a fixed order (deterministic).
+namespace shadow {
+namespace {
+
+constexpr int kTnThreads = 512;
+constexpr int kTnRowFloats = 256;                 // LDS row stride of both tiles (N, K <= 256)
+constexpr int kTnStepFloats = 2 * 16 * kTnRowFloats;   // A tile + B tile of one k-step
+
+__device__ __forceinline__ void lds_frag8(const float *tile, uint32_t col, uint32_t kg, float (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) x[j] = tile[(8 * kg + j) * kTnRowFloats + col];
+}
+
+template <int TK>
+__global__ void __launch_bounds__(kTnThreads)
+gemm_tn_split_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+                     float *__restrict__ partial, uint32_t M, uint32_t N, uint32_t K, uint32_t rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  float *lbuf = reinterpret_cast<float *>(tsm);              // [2][kTnStepFloats]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t r = lane & 31u, kg = lane >> 5;
+  const uint32_t wn = wv >> 1, wk = wv & 1u;                  // 4 x 2 wavefront grid
+  const uint64_t m_begin = (uint64_t)blockIdx.x * rows_per_wg;
+  const uint64_t m_end = min((uint64_t)M, m_begin + rows_per_wg);
+  const uint32_t steps = m_end > m_begin ? (uint32_t)((m_end - m_begin + 15) / 16) : 0u;   // (slices past M write zeros)
+
+  // zero both buffers once: columns >= N / K and rows >= M are never written by the copies
+  for (uint32_t i = tid; i < 2 * kTnStepFloats / 4; i += kTnThreads)
+    reinterpret_cast<float4 *>(lbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  f32x16 acc[2][TK];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int t = 0; t < TK; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[a][t][i] = 0.f;
+
+  // copy `part` (0..3) of k-step s: this wavefront moves rows {2 wv, 2 wv + 1} of the A tile and of the B tile
+  auto fill = [&](uint32_t s, int part) {
+    const uint32_t lr = 2 * wv + (part & 1);                 // row inside the 16-row tile
+    const uint64_t row = m_begin + (uint64_t)s * 16 + lr;
+    const bool isb = part >= 2;
+    float *dst = lbuf + (size_t)(s & 1) * kTnStepFloats + (isb ? 16 * kTnRowFloats : 0) + lr * kTnRowFloats;
+    const uint32_t width = isb ? K : N;
+    if (row < m_end) {
+      const float *src = (isb ? B + row * ldb : A + row * lda);
+      if (lane * 4 < width)     // (width % 4 == 0: whole 16-byte pieces)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane * 4),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    } else if (lane * 4 < width) {
+      *reinterpret_cast<float4 *>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (steps > 0) {
+#pragma unroll
+    for (int part = 0; part < 4; part++) fill(0, part);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (uint32_t s = 0; s < steps; s++) {
+    const float *at = lbuf + (size_t)(s & 1) * kTnStepFloats;
+    const float *bt = at + 16 * kTnRowFloats;
+    bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      float x[8];
+      lds_frag8(at, 32 * (2 * wn + a) + r, kg, x);
+      split8(x, ah[a], am[a], al[a]);
+    }
+#pragma unroll
+    for (int t = 0; t < TK; t++) {
+      if (s + 1 < steps && t < 4) fill(s + 1, t);            // next step's rows trickle out between the MFMA groups
+      if (TK < 4 && s + 1 < steps && t == TK - 1) {
+#pragma unroll
+        for (int part = TK; part < 4; part++) fill(s + 1, part);
+      }
+      float x[8];
+      lds_frag8(bt, 32 * (TK * wk + t) + r, kg, x);
+      bf16x8 bh, bm, bl;
+      split8(x, bh, bm, bl);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // partial[g][n][k]; C/D layout: col (k) = lane & 31, row (n) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  float *out = partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+#pragma unroll
+    for (int t = 0; t < TK; t++) {
+      const uint32_t kc = 32 * (TK * wk + t) + r;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const uint32_t nr = 32 * (2 * wn + a) + (i & 3) + 8 * (i >> 2) + 4 * kg;
+        if (nr < N && kc < K) out[(size_t)nr * K + kc] = acc[a][t][i];
+      }
+    }
+  }
+}
+
+__global__ void gemm_tn_reduce_kernel(const float *__restrict__ partial, uint32_t G, uint32_t NK, float *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NK) return;
+  float s = 0.f;
+  for (uint32_t g = 0; g < G; g++) s += partial[(size_t)g * NK + i];
+  out[i] = s;
+}
+
+}  // namespace
+}  // namespace shadow
+
+// number of row slices (= partial products) sl_gemm_tn_f32 uses for M rows
+extern "C" uint32_t sl_gemm_tn_slices(uint32_t M) {
+  int ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const uint32_t min_rows = 256;                                   // at least 16 k-steps per workgroup
+  return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ncu, (M + min_rows - 1) / min_rows));
+}
+
+extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb, float *d_C, uint32_t M,
+                              uint32_t N, uint32_t K, float *d_partial, void *stream) {
+  if (!d_A || !d_B || !d_C || !d_partial) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f32: null argument");
+  if (N == 0 || K == 0) return SG_OK;
+  if (N > 256 || K > 256 || (N & 3) || (K & 3))
+    return set_error(SG_ERR_INVALID, "sl_gemm_tn_f32: N = %u, K = %u (multiples of 4, at most 256)", N, K);
+  if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(d_A) & 15) || (reinterpret_cast<uintptr_t>(d_B) & 15))
+    return set_error(SG_ERR_INVALID, "sl_gemm_tn_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t G = sl_gemm_tn_slices(M);
+  uint32_t rows_per_wg = (M + G - 1) / G;
+  rows_per_wg = (rows_per_wg + 15u) & ~15u;
+  const size_t lds = (size_t)2 * kTnStepFloats * 4;
+  if (K <= 128) {
+    SHD_HIP(hipFuncSetAttribute((const void *)gemm_tn_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gemm_tn_split_kernel<2>), dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_B, ldb, d_partial, M, N, K,
+                       rows_per_wg);
+  } else {
+    SHD_HIP(hipFuncSetAttribute((const void *)gemm_tn_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gemm_tn_split_kernel<4>), dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_B, ldb, d_partial, M, N, K,
+                       rows_per_wg);
+  }
+  SHD_HIP(hipGetLastError());
+  const uint32_t NK = N * K;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 255) / 256), dim3(256), 0, st, d_partial, G, NK, d_C);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}

@@ -385,6 +385,17 @@ def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
     in a fixed order."""
     n, Fo = dZ.shape
     Fi = X.shape[1]
+    if (GEMM_SPLIT and dZ.is_cuda and n >= GEMM_SPLIT_MIN_ROWS and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
+            and dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.stride(1) == 1 and X.stride(1) == 1
+            and dZ.stride(0) % 4 == 0 and X.stride(0) % 4 == 0 and dZ.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0):
+        lib = _lib.load()
+        G = lib.sl_gemm_tn_slices(n)
+        partial = torch.empty(G * Fo * Fi, dtype=torch.float32, device=dZ.device)
+        dW = torch.empty(Fo, Fi, dtype=torch.float32, device=dZ.device)
+        with _timed(f"gemm_tn_N{Fo}_K{Fi}", 4 * n * (Fo + Fi), dZ.device, flops=2 * n * Fo * Fi):
+            check(lib.sl_gemm_tn_f32(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), n, Fo, Fi,
+                                     partial.data_ptr(), _stream(dZ)))
+        return dW
     if n < 32768:
         return dZ.t() @ X
     S = min(256, max(2, n // 2048))

@@ -402,3 +402,21 @@ def test_split_bf16_gemm_exact_cases():
     W = torch.zeros(37, K, device=DEV); W[5, 100] = -3.0
     out = ops.mm_nt(A, W)
     assert torch.equal(out[:, 5], A[:, 100] * -3.0) and out[:, :5].abs().sum() == 0 and out[:, 6:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (10007, 256, 100), (9001, 64, 256), (300000, 256, 256), (8200, 36, 132)])
+def test_split_bf16_weight_gradient_gemm_matches_fp64(M, N, K):
+    """dW = dZ^T X on the split-bf16 kernel (sl_gemm_tn_f32): fp32-level accuracy vs fp64, asymmetric
+    operands, ragged row slices (M not a multiple of 16), narrow N / K."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dZ = torch.randn(M, N, device=DEV, generator=g) * (torch.rand(M, 1, device=DEV, generator=g) + 0.01)
+    X = torch.randn(M, K, device=DEV, generator=g) * (torch.arange(K, device=DEV).float() / K + 0.1)
+    got = ops.weight_grad(dZ, X)
+    assert got.shape == (N, K)
+    ref = dZ.double().t() @ X.double()
+    den = dZ.abs().double().t() @ X.abs().double()
+    err = ((got.double() - ref).abs() / den).max().item()
+    assert err < 1.5e-6, err
+    # deterministic: the partial products are added in a fixed order
+    assert torch.equal(got, ops.weight_grad(dZ, X))
