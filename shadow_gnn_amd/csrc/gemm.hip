@@ -97,7 +97,9 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t ldb, uin
 // ---------------------------------------------------------------------------
 // Main kernel.  A wavefront owns RB x 32 rows and ALL NT column tiles (every A element is loaded by
 // exactly one wavefront); a workgroup = 4 wavefronts.  The B image is streamed one k-step (16 columns)
-// at a time, global -> LDS directly (global_load_lds, no VGPRs), double buffered.  Measured on MI355X:
+// at a time, global -> LDS directly (global_load_lds, no VGPRs), into a ring of three buffers: the
+// copies of step s+2 are issued during step s and only the OLDER ones are waited for (counted vmcnt +
+// bare s_barrier), so no step ever waits for a copy it has just issued.  Measured on MI355X:
 // the CU's vector-memory path (64 B/clk), not the matrix cores, is the scarce resource of this kernel, and
 // a burst of loads right after a barrier stalls every wavefront on issue -- so the copies of the next
 // step and the A registers of the next unit are issued one by one between the MFMA groups.  Two
@@ -115,7 +117,9 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
   constexpr int kStepVecs = 3 * NT * 64;                 // bf16x8 vectors of one k-step's B image
   constexpr int kFill = (kStepVecs + kGemmThreads - 1) / kGemmThreads;     // copies per thread per step
   constexpr int kFillPerSlot = (kFill + NT - 1) / NT;
-  bf16x8 *lbuf = reinterpret_cast<bf16x8 *>(gsm);       // [2][kStepVecs]
+  bf16x8 *lbuf = reinterpret_cast<bf16x8 *>(gsm);       // [3][kStepVecs]: ring of k-step images
+  constexpr int kPieces0 = (kPieces < NT * kPPS) ? kPieces : NT * kPPS;   // A pieces issued during step h = 0 / h = 1
+  constexpr int kPieces1 = kPieces - kPieces0;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t r = lane & 31u, g = lane >> 5;
   const uint64_t m0 = (uint64_t)blockIdx.x * kRowsWG + wv * (32u * RB);
@@ -151,7 +155,7 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
   // copies `slot` (of NT) of the B image of k-step s into LDS buffer s & 1
   auto fill_b = [&](uint32_t s, int slot) {
     const bf16x8 *src = Bimg + (size_t)s * kStepVecs;
-    bf16x8 *dst = lbuf + (size_t)(s & 1) * kStepVecs;
+    bf16x8 *dst = lbuf + (size_t)(s % 3u) * kStepVecs;
 #pragma unroll
     for (int q = slot * kFillPerSlot; q < (slot + 1) * kFillPerSlot && q < kFill; q++) {
       const uint32_t base = q * kGemmThreads + wv * 64u;               // wave-uniform
@@ -167,6 +171,10 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
 #endif
 #pragma unroll
   for (int slot = 0; slot < NT; slot++) fill_b(0, slot);
+  if (units * 2 > 1) {
+#pragma unroll
+    for (int slot = 0; slot < NT; slot++) fill_b(1, slot);
+  }
 #pragma unroll
   for (int p = 0; p < kPieces; p++) load_a_piece(0, p);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -182,7 +190,7 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const uint32_t st = 2 * u + h;
-      const bf16x8 *lb = lbuf + (size_t)(st & 1) * kStepVecs;
+      const bf16x8 *lb = lbuf + (size_t)(st % 3u) * kStepVecs;
       bf16x8 ah[RB], am[RB], al[RB];
 #pragma unroll
       for (int rb = 0; rb < RB; rb++) {
@@ -190,6 +198,9 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
                             ac[rb][2 * h + 1].x, ac[rb][2 * h + 1].y, ac[rb][2 * h + 1].z, ac[rb][2 * h + 1].w};
         split8(x, ah[rb], am[rb], al[rb]);
       }
+      // (pin: the A registers are consumed -- and waited for -- BEFORE this step issues new copies; hipcc
+      //  waits vmcnt(0) for an ordinary load while LDS-DMA copies are in flight)
+      __builtin_amdgcn_sched_barrier(0);
       GT_STAMP(1);
       // B fragments are read one tile ahead of the MFMAs that consume them
       bf16x8 fb[2][3];
@@ -201,7 +212,7 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
 #pragma unroll
           for (int pc = 0; pc < 3; pc++) fb[(t + 1) & 1][pc] = lb[(pc * NT + t + 1) * 64 + lane];
         }
-        if (st + 1 < steps) fill_b(st + 1, t);
+        if (st + 2 < steps) fill_b(st + 2, t);              // two steps ahead: never waited for in this step
         if (u + 1 < units) {
 #pragma unroll
           for (int p = (h * NT + t) * kPPS; p < (h * NT + t + 1) * kPPS && p < kPieces; p++) load_a_piece(u + 1, p);
@@ -223,9 +234,17 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
         __builtin_amdgcn_sched_barrier(0);
       }
       GT_STAMP(2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next image (and A pieces) landed
+      // The next step's image was issued one step ago: wait only for what is OLDER than this step's own
+      // copies (the vector-memory counter retires in order), then a bare barrier -- __syncthreads() would
+      // drain the copies that are meant to stay in flight.
+      if (u + 1 < units) {
+        if (h == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kFill + kPieces0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kFill + kPieces1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
       GT_STAMP(3);
-      __syncthreads();                                   // ... for every wavefront; this buffer may be refilled
+      __builtin_amdgcn_s_barrier();                      // every wavefront is done with this step's buffer
       GT_STAMP(4);
     }
   }
@@ -287,9 +306,15 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
   const uint32_t grid = (M + rows_wg - 1) / rows_wg;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8 *img = reinterpret_cast<const bf16x8 *>(d_packed_B);
-  const size_t lds = (size_t)2 * 3 * tiles * 64 * 16;
+  const size_t lds = (size_t)3 * 3 * tiles * 64 * 16;
 #define SHD_GEMM(RB, NT)                                                                                     \
   {                                                                                                          \
+    if (lds > 64 * 1024) {                                                                                   \
+      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, NT, false>,                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, NT, true>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+    }                                                                                                        \
     if (K % 32 == 0)                                                                                         \
       hipLaunchKernelGGL((gemm_nt_split_kernel<RB, NT, false>), dim3(grid), dim3(kGemmThreads), lds, st, d_A, lda, img, \
                          d_C, ldc, M, N, K, units);                                                          \
