@@ -312,10 +312,17 @@ int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packed_B, float 
  * :434-435, GraphSAGE :476-483, GAT :620-625 with seg = head slice, out_scale 0.5).
  * act codes: 0 identity("I"), 1 relu, 2 elu, 3 tanh, 4 leakyrelu(0.2).
  * d_Z / ldz / d_bias / act are HOST arrays of nb entries (d_bias or its entries
- * may be NULL); scale / offset are [nb, F].                                    */
+ * may be NULL); scale / offset are [nb, F].
+ * drop_p > 0 fuses the dropout the NEXT layer applies to its input (nn.Dropout at layers.py:430,471,601)
+ * into this output: element (row r, column c) is kept iff
+ *   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= drop_p * 2^32      (32-bit wrap-around),
+ * mix32 = the murmur3 finaliser (h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16);
+ * kept values are scaled by 1 / (1 - drop_p); the backward entry regenerates the same mask from
+ * (drop_p, drop_seed), no mask tensor exists.  Vector layout only (F % 4 == 0, F <= 256, 16-byte aligned operands).      */
 int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
-                    uint32_t seg, float out_scale, float *d_out, int64_t ldo, void *stream);
+                    uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p, uint64_t drop_seed,
+                    void *stream);
 /* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
  * when d_dbias != NULL, dbias [nb, F] = column sums of dZ_b (all overwritten,
  * reduced over the rows in a fixed order).
@@ -324,7 +331,7 @@ int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
                     const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
-                    float *d_partial, void *stream);
+                    float *d_partial, float drop_p, uint64_t drop_seed, void *stream);
 
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):

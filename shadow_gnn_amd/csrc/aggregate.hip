@@ -620,7 +620,25 @@ struct ActNormParams {
   float *dscale;           // [nb, F]
   float *doffset;          // [nb, F]
   float *partial;          // [grid, nb, 3, F] per-block partial sums of dscale / doffset / dbias
+  // fused dropout of the OUTPUT (= the next layer's input dropout, layers.py:430,471,601): element
+  // (row r, column c) is kept iff  mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= drop_thr,
+  // mix32 = the murmur3 finaliser; kept values are scaled by drop_scale = 1 / (1 - p).  drop_thr == 0: none.
+  uint32_t drop_thr;
+  float drop_scale;
+  uint32_t seed_lo, seed_hi;
 };
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+// keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
+__device__ __forceinline__ uint32_t drop_keep4(const ActNormParams &p, uint64_t r, uint32_t f) {
+  const uint32_t base = mix32((uint32_t)r ^ p.seed_lo) + (uint32_t)(r >> 32) + p.seed_hi + f * 0x9E3779B1u;
+  return (mix32(base) >= p.drop_thr ? 1u : 0u) | (mix32(base + 0x9E3779B1u) >= p.drop_thr ? 2u : 0u) |
+         (mix32(base + 2u * 0x9E3779B1u) >= p.drop_thr ? 4u : 0u) | (mix32(base + 3u * 0x9E3779B1u) >= p.drop_thr ? 8u : 0u);
+}
 
 // sum over the lanes of one segment group (LS lanes, power of two)
 template <int LS>
@@ -671,7 +689,15 @@ __global__ void act_norm_kernel(ActNormParams p) {
 #pragma unroll
       for (int b = 0; b < NB; b++) zc[b] = lane_on ? ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (BWD) { dy.x *= p.out_scale; dy.y *= p.out_scale; dy.z *= p.out_scale; dy.w *= p.out_scale; }
+    if (BWD) {
+      float4 ds = make_float4(p.out_scale, p.out_scale, p.out_scale, p.out_scale);
+      if (p.drop_thr) {            // gradient of the fused output dropout: same mask, same 1/(1-p)
+        const uint32_t keep = drop_keep4(p, r, f);
+        const float ks = p.out_scale * p.drop_scale;
+        ds = make_float4((keep & 1u) ? ks : 0.f, (keep & 2u) ? ks : 0.f, (keep & 4u) ? ks : 0.f, (keep & 8u) ? ks : 0.f);
+      }
+      dy.x *= ds.x; dy.y *= ds.y; dy.z *= ds.z; dy.w *= ds.w;
+    }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
@@ -711,6 +737,11 @@ __global__ void act_norm_kernel(ActNormParams p) {
     }
     if (!BWD && lane_on) {
       acc.x *= p.out_scale; acc.y *= p.out_scale; acc.z *= p.out_scale; acc.w *= p.out_scale;
+      if (p.drop_thr) {
+        const uint32_t keep = drop_keep4(p, r, f);
+        acc.x = (keep & 1u) ? acc.x * p.drop_scale : 0.f; acc.y = (keep & 2u) ? acc.y * p.drop_scale : 0.f;
+        acc.z = (keep & 4u) ? acc.z * p.drop_scale : 0.f; acc.w = (keep & 8u) ? acc.w * p.drop_scale : 0.f;
+      }
       st4(p.out + (int64_t)r * p.ldo + f, acc);
     }
   }
@@ -983,6 +1014,15 @@ extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d
 
 constexpr uint32_t kActNormBwdBlocks = 2048;  // == rows of the partial buffer
 
+// blocks of `kernel` (kBlock threads, no dynamic LDS) that fit on the device at once
+static uint32_t resident_blocks(const void *kernel) {
+  int per_cu = 0, ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  return (uint32_t)per_cu * (uint32_t)ncu;
+}
+
 static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
   const uint32_t F = p.F, seg = p.seg;
   bool vec = (F % 4 == 0) && (seg % 4 == 0) && F <= 256 && (F % seg == 0);
@@ -1000,16 +1040,24 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
   if (!bwd) vec = vec && aligned16(p.out) && (p.ldo % 4 == 0);
   else vec = vec && aligned16(p.dout) && (p.lddo % 4 == 0);
   if (lpr < 4) vec = false;
+  // the kernels are grid-stride loops: launch exactly the resident number of blocks (a partial second
+  // round of blocks costs as much as a full one -- measured 0.19 -> 0.27 ms when one VGPR too many
+  // dropped the occupancy below the old fixed grid)
+#define SHD_AN_LAUNCH(KERNEL, CAP)                                                                         \
+  do {                                                                                                     \
+    g = grid_for(p.n, kBlock / lpr, std::min<uint32_t>(CAP, resident_blocks((const void *)KERNEL)));       \
+    hipLaunchKernelGGL(KERNEL, dim3(g), dim3(kBlock), 0, st, p);                                           \
+  } while (0)
 #define SHD_AN(LPR, LS)                                                                                    \
   do {                                                                                                     \
-    const uint32_t g = grid_for(p.n, kBlock / LPR, bwd ? kActNormBwdBlocks : 256 * 8);                     \
+    uint32_t g = 1;                                                                                        \
     if (bwd) {                                                                                             \
-      if (p.nb == 1) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true, 1>), dim3(g), dim3(kBlock), 0, st, p); \
-      else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, true, 2>), dim3(g), dim3(kBlock), 0, st, p);       \
+      if (p.nb == 1) SHD_AN_LAUNCH((act_norm_kernel<LPR, LS, true, 1>), kActNormBwdBlocks);                \
+      else SHD_AN_LAUNCH((act_norm_kernel<LPR, LS, true, 2>), kActNormBwdBlocks);                          \
       hipLaunchKernelGGL(act_norm_finish_kernel, dim3((p.F + 63) / 64, p.nb * 3), dim3(1024), 0, st,       \
                          p.partial, g, p.nb, p.F, p.dscale, p.doffset, p.dbias);                           \
-    } else if (p.nb == 1) hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false, 1>), dim3(g), dim3(kBlock), 0, st, p); \
-    else hipLaunchKernelGGL((act_norm_kernel<LPR, LS, false, 2>), dim3(g), dim3(kBlock), 0, st, p);        \
+    } else if (p.nb == 1) SHD_AN_LAUNCH((act_norm_kernel<LPR, LS, false, 1>), 256 * 8);                    \
+    else SHD_AN_LAUNCH((act_norm_kernel<LPR, LS, false, 2>), 256 * 8);                                     \
   } while (0)
   bool done = false;
   if (vec) {
@@ -1028,6 +1076,10 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
     else done = false;
   }
 #undef SHD_AN
+#undef SHD_AN_LAUNCH
+  if (!done && p.drop_thr)
+    return set_error(SG_ERR_INVALID, "sl_act_norm: fused output dropout needs the vector layout (F %% 4 == 0, F <= 256, "
+                                     "16-byte aligned operands); apply dropout separately for this shape");
   if (!done) {
     const uint32_t g = grid_for((uint64_t)p.n * 64, kBlock, 256 * 8);
     if (bwd) {
@@ -1052,9 +1104,20 @@ static int act_norm_check(int nb, uint32_t F, uint32_t seg, const float *const *
   return SG_OK;
 }
 
+static int set_dropout(ActNormParams &p, float drop_p, uint64_t drop_seed, const char *who) {
+  p.drop_thr = 0; p.drop_scale = 1.0f; p.seed_lo = (uint32_t)drop_seed; p.seed_hi = (uint32_t)(drop_seed >> 32);
+  if (drop_p <= 0.f) return SG_OK;
+  if (!(drop_p < 1.f)) return set_error(SG_ERR_INVALID, "%s: dropout probability %g", who, drop_p);
+  const double t = (double)drop_p * 4294967296.0;
+  p.drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+  p.drop_scale = 1.0f / (1.0f - drop_p);
+  return SG_OK;
+}
+
 extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
-                               uint32_t seg, float out_scale, float *d_out, int64_t ldo, void *stream_) {
+                               uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p,
+                               uint64_t drop_seed, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
   if (!d_scale || !d_offset || !d_out) return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: null argument");
@@ -1064,6 +1127,7 @@ extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *l
   for (int b = 0; b < nb; b++) { p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.bias[b] = d_bias ? d_bias[b] : nullptr; }
   p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
   p.out_scale = out_scale; p.eps = 1e-9f; p.out = d_out; p.ldo = ldo;
+  if ((rc = set_dropout(p, drop_p, drop_seed, "sl_act_norm_fwd")) != SG_OK) return rc;
   return act_norm_launch(p, false, (hipStream_t)stream_);
 }
 
@@ -1071,7 +1135,8 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
-                               float *d_doffset, float *d_dbias, float *d_partial, void *stream_) {
+                               float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                               void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
   if (!d_scale || !d_offset || !d_dout || !d_dscale || !d_doffset || !d_dZ)
@@ -1094,5 +1159,6 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
   p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
   p.out_scale = out_scale; p.eps = 1e-9f; p.dout = d_dout; p.lddo = lddo;
   p.dscale = d_dscale; p.doffset = d_doffset; p.partial = d_partial;
+  if ((rc = set_dropout(p, drop_p, drop_seed, "sl_act_norm_bwd")) != SG_OK) return rc;
   return act_norm_launch(p, true, st);
 }

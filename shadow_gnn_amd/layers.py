@@ -70,6 +70,11 @@ class shaDowLayer(nn.Module):
         self.dim_in, self.dim_out = dim_in, dim_out
         self.act_name = _check_act(act)
         self.f_dropout = nn.Dropout(p=self.dropout)
+        # Dropout fusion (set per step by DeepGNN.forward while training): the layer BEFORE this one may
+        # already have applied this layer's input dropout inside its act_norm kernel (input_pre_dropped),
+        # and this layer may apply the NEXT layer's input dropout to its own output (out_dropout).
+        self.input_pre_dropped = False
+        self.out_dropout = 0.0
         if norm not in ('norm_feat', 'none'):
             raise NotImplementedError("only norm in {'norm_feat', 'none'} (the reference's pairnorm path is unfinished, layers.py:358)")
         self.norm = norm
@@ -81,18 +86,29 @@ class shaDowLayer(nn.Module):
     def spmm(self, adj, X):
         return ops.spmm(adj, X)
 
+    def in_dropout(self, feat_in):
+        """nn.Dropout on the layer input (layers.py:430,471,601) unless the producer fused it."""
+        return feat_in if (self.input_pre_dropped and self.training) else self.f_dropout(feat_in)
+
+    def can_fuse_out_dropout(self):
+        return self.norm == 'norm_feat' and ops.can_fuse_out_dropout(self.dim_out)
+
+    def _out_p(self):
+        return self.out_dropout if self.training else 0.0
+
     def f_lin_act_norm(self, Xs, lins, acts):
         """sum_b norm_b(act_b(lin_b(X_b))): Linear (rocBLAS) + bias/act/norm/add (one HIP kernel),
         one autograd node with fused bias / scale / offset gradients."""
         if self.norm == 'norm_feat':
-            return ops.linear_act_norm(Xs, lins, acts, self.scale, self.offset)
+            return ops.linear_act_norm(Xs, lins, acts, self.scale, self.offset, out_dropout=self._out_p())
         return self.f_act_norm([ops.linear(x, l) for x, l in zip(Xs, lins)], acts)
 
     def f_act_norm(self, Zs, acts, seg=None, out_scale=1.0):
         """sum_b norm_b(act_b(Z_b)) * out_scale -- the reference's act + f_norm + add
         sequence (layers.py:435, :476-483, :620-625) in one kernel."""
         if self.norm == 'norm_feat':
-            return ops.act_norm(Zs, acts, self.scale, self.offset, seg=seg, out_scale=out_scale)
+            return ops.act_norm(Zs, acts, self.scale, self.offset, seg=seg, out_scale=out_scale,
+                                out_dropout=self._out_p())
         out = None
         for z, a in zip(Zs, acts):
             h = _torch_act(a, z)
@@ -123,7 +139,7 @@ class MLP(shaDowLayer):
         self.f_lin = nn.Linear(dim_in, dim_out)
 
     def forward(self, feat_in):
-        feat_in = self.f_dropout(feat_in)
+        feat_in = self.in_dropout(feat_in)
         return self.f_lin_act_norm([feat_in], [self.f_lin], [self.act_name])
 
     def complexity(self, dims_x):
@@ -141,7 +157,7 @@ class GCN(shaDowLayer):
 
     def forward(self, inputs, sizes_subg):
         feat_in, adj, is_normed, dropedge = inputs
-        feat_in = self.f_dropout(feat_in)
+        feat_in = self.in_dropout(feat_in)
         if not is_normed and adj is not None:
             # self-edges are already added by the sampler (shaDow/utils.py:126-131)
             adj_norm = ops.adj_norm_sym(_as_device_csr(adj, feat_in.device), dropedge=dropedge)
@@ -173,7 +189,7 @@ class GraphSAGE(shaDowLayer):
         else:
             assert adj is None or isinstance(adj, ops.NormAdj)
             adj_norm = adj
-        feat_in = self.f_dropout(feat_in)
+        feat_in = self.in_dropout(feat_in)
         feat_neigh = self.spmm(adj_norm, feat_in)
         feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],
                                        [self.act_name, self.act_name])
@@ -293,7 +309,7 @@ class GAT(shaDowLayer):
         from . import ops_gat
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self._adj_norm(adj, is_normed, feat_in.device, dropedge=dropedge)
-        feat_in = self.f_dropout(feat_in)
+        feat_in = self.in_dropout(feat_in)
         z_self = ops.linear(feat_in, self.f_lin[0])
         z_neigh = ops.linear(feat_in, self.f_lin[1])
         # neigh branch: act -> per-head attention aggregate; both branches normalised per head slice
@@ -302,7 +318,7 @@ class GAT(shaDowLayer):
         if self.norm == 'norm_feat':
             # reference order: f_norm([neigh, self]) -> scale[0]=neigh, scale[1]=self (layers.py:620-622)
             feat_out = ops.act_norm([feat_neigh, z_self], ['I', self.act_name], self.scale, self.offset,
-                                    seg=self.dim_slice, out_scale=0.5)
+                                    seg=self.dim_slice, out_scale=0.5, out_dropout=self._out_p())
         else:
             feat_out = (feat_neigh + _torch_act(self.act_name, z_self)) / 2
         return feat_out, adj_norm, True, 0.

@@ -86,6 +86,7 @@ class DeepGNN(nn.Module):
         self.lr = train_params["lr"]
         self.sigmoid_loss = arch_gnn.get("loss", "softmax") == "sigmoid"
         self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr)
+        self.fuse_dropout = True       # fold each layer's input dropout into the producing kernel where possible
         self.num_ensemble = num_ensemble
         self.grad_sync = grad_sync
 
@@ -126,6 +127,7 @@ class DeepGNN(nn.Module):
                         feat_ens[i] = torch.cat([feat_ens[i], feat_aug_emb], dim=1)
             xjk = []
             xmd = (feat_ens[i], adj_ens[i], False, dropedge)
+            self._plan_dropout_fusion(i)
             for md in self.conv_layers[i]:
                 xmd = md(xmd, sizes_subg=size_subg_ens[i])
                 xjk.append(xmd[0])
@@ -135,6 +137,26 @@ class DeepGNN(nn.Module):
         emb_ensemble = self.ensembler(emb_subg_ens)
         pred_subg = self.classifier(emb_ensemble)
         return pred_subg, emb_subg_ens
+
+    def _plan_dropout_fusion(self, i):
+        """Layer l+1's input dropout (shaDow/layers.py:430,471,601) is applied by layer l's own act_norm
+        kernel when nothing else reads layer l's un-dropped output: residue 'none' with centre pooling only
+        consumes the LAST layer's output (layers.py:159-163).  Same distribution, no [n, F] mask tensor, one
+        pass less per layer; evaluation and other read-out configurations keep nn.Dropout."""
+        layers_i = list(self.conv_layers[i])
+        rp = self.res_pool_layers[i]
+        fuse_ok = (self.training and self.fuse_dropout and rp.type_res == 'none' and rp.type_pool == 'center')
+        for l, md in enumerate(layers_i):
+            if not hasattr(md, 'out_dropout'):
+                continue
+            nxt = layers_i[l + 1] if l + 1 < len(layers_i) else None
+            fuse = (fuse_ok and nxt is not None and hasattr(nxt, 'input_pre_dropped') and nxt.dropout > 0
+                    and md.can_fuse_out_dropout())
+            md.out_dropout = nxt.dropout if fuse else 0.0
+            if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
+                nxt.input_pre_dropped = bool(fuse)
+        if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):
+            layers_i[0].input_pre_dropped = False
 
     def predict(self, preds):
         return torch.sigmoid(preds) if self.sigmoid_loss else F.softmax(preds, dim=1)

@@ -294,7 +294,45 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
-def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale):
+def can_fuse_out_dropout(F: int) -> bool:
+    """Shapes whose act_norm runs on the vector kernels (the fused output dropout lives there)."""
+    return F % 4 == 0 and 16 <= F <= 256
+
+
+def new_dropout_seed() -> int:
+    """64-bit seed from torch's CPU generator (reproducible under torch.manual_seed, no device sync)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _mix32(h: torch.Tensor) -> torch.Tensor:
+    """murmur3 finaliser on int64 tensors holding 32-bit values."""
+    M32 = 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    h = _mul32(h, 0x85EBCA6B)
+    h = h ^ (h >> 13)
+    h = _mul32(h, 0xC2B2AE35)
+    return (h ^ (h >> 16)) & M32
+
+
+def _mul32(b: torch.Tensor, a: int) -> torch.Tensor:
+    """(a * b) mod 2^32 without int64 overflow (a, b < 2^32)."""
+    M32 = 0xFFFFFFFF
+    return (((b & 0xFFFF) * a) + ((((b >> 16) * (a & 0xFFFF)) & 0xFFFF) << 16)) & M32
+
+
+def dropout_keep_mask(n: int, F: int, p: float, seed: int, device) -> torch.Tensor:
+    """The keep mask the kernels generate for (p, seed) -- the rule documented in include/shadow_hip.h,
+    restated in torch for the tests."""
+    M32 = 0xFFFFFFFF
+    r = torch.arange(n, device=device, dtype=torch.int64).unsqueeze(1)
+    c = torch.arange(F, device=device, dtype=torch.int64).unsqueeze(0)
+    row = (_mix32((r & M32) ^ (seed & M32)) + (r >> 32) + ((seed >> 32) & M32)) & M32
+    h = _mix32((row + _mul32(c, 0x9E3779B1)) & M32)
+    thr = int(min(max(p * 4294967296.0, 1.0), 4294967295.0))
+    return h >= thr
+
+
+def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
     nb = len(Zs)
     n, F = Zs[0].shape
     out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
@@ -302,11 +340,12 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale):
     ac = (C.c_int * nb)(*codes)
     with _timed(f"act_norm_fwd_nb{nb}_F{F}", (nb + 1) * 4 * n * F, out.device):
         check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
-                                          n, F, seg, out_scale, out.data_ptr(), out.stride(0), _stream(out)))
+                                          n, F, seg, out_scale, out.data_ptr(), out.stride(0), float(drop[0]),
+                                          int(drop[1]), _stream(out)))
     return out
 
 
-def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias):
+def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias, drop=(0.0, 0)):
     nb = len(Zs)
     n, F = Zs[0].shape
     dev = sc.device
@@ -323,32 +362,32 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias
         check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
                                           n, F, seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs), ldd,
                                           dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
-                                          partial.data_ptr(), _stream(dout)))
+                                          partial.data_ptr(), float(drop[0]), int(drop[1]), _stream(dout)))
     return dZs, dsc, dof, dbi
 
 
 class _ActNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scale, offset, acts, seg, out_scale, *Zs):
+    def forward(ctx, scale, offset, acts, seg, out_scale, drop, *Zs):
         Zs = [_f32c(z) for z in Zs]
         _need_cuda(scale, offset, *Zs)
         nb = len(Zs)
         n, F = Zs[0].shape
         sc = scale.reshape(nb, F).contiguous().float()
         of = offset.reshape(nb, F).contiguous().float()
-        out = _an_fwd(Zs, [None] * nb, acts, sc, of, seg, out_scale)
+        out = _an_fwd(Zs, [None] * nb, acts, sc, of, seg, out_scale, drop)
         ctx.save_for_backward(sc, of, *Zs)
-        ctx.meta = (acts, seg, out_scale, scale.shape, offset.shape)
+        ctx.meta = (acts, seg, out_scale, scale.shape, offset.shape, drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         sc, of, *Zs = ctx.saved_tensors
-        acts, seg, out_scale, sshape, oshape = ctx.meta
+        acts, seg, out_scale, sshape, oshape, drop = ctx.meta
         nb = len(Zs)
-        need = ctx.needs_input_grad[5:5 + nb]
-        dZs, dsc, dof, _ = _an_bwd(Zs, [None] * nb, acts, sc, of, seg, out_scale, dout, need, False)
-        return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, *dZs)
+        need = ctx.needs_input_grad[6:6 + nb]
+        dZs, dsc, dof, _ = _an_bwd(Zs, [None] * nb, acts, sc, of, seg, out_scale, dout, need, False, drop)
+        return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, *dZs)
 
 
 # split-bf16 MFMA GEMM (csrc/gemm.hip) for the tall feature x weight products; rocBLAS fp32 otherwise
@@ -437,7 +476,7 @@ class _LinearActNorm(torch.autograd.Function):
     activation, normalisation, branch sum and -- in backward -- dZ, dscale, doffset AND the
     bias gradients come from one HIP kernel pass each."""
     @staticmethod
-    def forward(ctx, scale, offset, acts, seg, out_scale, nb, *t):
+    def forward(ctx, scale, offset, acts, seg, out_scale, nb, drop, *t):
         Xs = [_f32c(x).contiguous() for x in t[:nb]]
         Ws = list(t[nb:2 * nb])
         bs = list(t[2 * nb:3 * nb])
@@ -447,29 +486,38 @@ class _LinearActNorm(torch.autograd.Function):
         of = offset.reshape(nb, F).contiguous().float()
         Zs = [mm_nt(x, w) for x, w in zip(Xs, Ws)]
         bsc = [b.detach().contiguous() if b is not None else None for b in bs]
-        out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale)
+        out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale, drop)
         ctx.save_for_backward(sc, of, *Xs, *Ws, *Zs, *[b if b is not None else sc.new_empty(0) for b in bsc])
-        ctx.meta = (acts, seg, out_scale, nb, scale.shape, offset.shape, [b is not None for b in bs])
+        ctx.meta = (acts, seg, out_scale, nb, scale.shape, offset.shape, [b is not None for b in bs], drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        acts, seg, out_scale, nb, sshape, oshape, has_b = ctx.meta
+        acts, seg, out_scale, nb, sshape, oshape, has_b, drop = ctx.meta
         sv = ctx.saved_tensors
         sc, of = sv[0], sv[1]
         Xs, Ws, Zs, bs = sv[2:2 + nb], sv[2 + nb:2 + 2 * nb], sv[2 + 2 * nb:2 + 3 * nb], sv[2 + 3 * nb:2 + 4 * nb]
         biases = [b if hb else None for b, hb in zip(bs, has_b)]
-        dZs, dsc, dof, dbi = _an_bwd(list(Zs), biases, acts, sc, of, seg, out_scale, dout, [True] * nb, any(has_b))
+        dZs, dsc, dof, dbi = _an_bwd(list(Zs), biases, acts, sc, of, seg, out_scale, dout, [True] * nb, any(has_b), drop)
         ng = ctx.needs_input_grad
-        dXs = [mm_nt(dz, w.t()) if ng[6 + i] else None for i, (dz, w) in enumerate(zip(dZs, Ws))]
-        dWs = [weight_grad(dz, x) if ng[6 + nb + i] else None for i, (dz, x) in enumerate(zip(dZs, Xs))]
-        dbs = [dbi[i] if (has_b[i] and ng[6 + 2 * nb + i]) else None for i in range(nb)]
-        return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, *dXs, *dWs, *dbs)
+        dXs = [mm_nt(dz, w.t()) if ng[7 + i] else None for i, (dz, w) in enumerate(zip(dZs, Ws))]
+        dWs = [weight_grad(dz, x) if ng[7 + nb + i] else None for i, (dz, x) in enumerate(zip(dZs, Xs))]
+        dbs = [dbi[i] if (has_b[i] and ng[7 + 2 * nb + i]) else None for i in range(nb)]
+        return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, *dXs, *dWs, *dbs)
+
+
+def _drop_arg(out_dropout: float, F: int):
+    """(p, seed) of the fused output dropout, or (0, 0)."""
+    if out_dropout and out_dropout > 0.0:
+        if not can_fuse_out_dropout(F):
+            raise ValueError(f"fused output dropout is not available for width {F}")
+        return (float(out_dropout), new_dropout_seed())
+    return (0.0, 0)
 
 
 def linear_act_norm(Xs: List[torch.Tensor], lins: Sequence["torch.nn.Linear"], acts: Sequence[str],
                     scale: torch.Tensor, offset: torch.Tensor, seg: Optional[int] = None,
-                    out_scale: float = 1.0) -> torch.Tensor:
+                    out_scale: float = 1.0, out_dropout: float = 0.0) -> torch.Tensor:
     """Fused dense tail of a layer: sum_b norm_b(act_b(lin_b(X_b))) * out_scale
     (nn.Linear + act + _f_norm_feat + add; shaDow/layers.py:434-435, :476-483, :393-394)."""
     codes = []
@@ -479,12 +527,12 @@ def linear_act_norm(Xs: List[torch.Tensor], lins: Sequence["torch.nn.Linear"], a
         codes.append(ACT_CODE[a])
     F = lins[0].weight.shape[0]
     nb = len(Xs)
-    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, *Xs,
-                                *[l.weight for l in lins], *[l.bias for l in lins])
+    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, _drop_arg(out_dropout, F),
+                                *Xs, *[l.weight for l in lins], *[l.bias for l in lins])
 
 
 def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, offset: torch.Tensor,
-             seg: Optional[int] = None, out_scale: float = 1.0) -> torch.Tensor:
+             seg: Optional[int] = None, out_scale: float = 1.0, out_dropout: float = 0.0) -> torch.Tensor:
     """out_scale * sum_b norm_b(act_b(Z_b)) with the reference's 'norm_feat'
     (shaDowLayer._f_norm_feat, shaDow/layers.py:329-338).  scale/offset hold one
     row of F features per branch (any shape with nb*F elements)."""
@@ -495,7 +543,7 @@ def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, o
             raise NotImplementedError(f"activation {a!r} is not available in the fused HIP kernel "
                                       f"(supported: {sorted(ACT_CODE)})")
         codes.append(ACT_CODE[a])
-    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), *Zs)
+    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), _drop_arg(out_dropout, F), *Zs)
 
 
 # ----------------------------------------------------------------------------- readout / encodings

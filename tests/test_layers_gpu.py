@@ -420,3 +420,84 @@ def test_split_bf16_weight_gradient_gemm_matches_fp64(M, N, K):
     assert err < 1.5e-6, err
     # deterministic: the partial products are added in a fixed order
     assert torch.equal(got, ops.weight_grad(dZ, X))
+
+
+@pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
+def test_act_norm_fused_output_dropout(nb, F, seg):
+    """The next layer's input dropout folded into act_norm's output: the kernel's mask equals the documented
+    hash rule (restated in torch, ops.dropout_keep_mask) bit for bit, kept values are scaled by 1/(1-p),
+    and the backward pass applies the same mask (it is regenerated, never stored)."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(nb * 1000 + F + seg)
+    n, p, seed = 3001, 0.4, 0x1234_5678_9ABC_DEF
+    Zs = [torch.randn(n, F, device=DEV, generator=g) for _ in range(nb)]
+    scale = torch.rand(nb, F, device=DEV, generator=g) + 0.5
+    offset = torch.randn(nb, F, device=DEV, generator=g) * 0.1 + 0.3      # (outputs are never exactly 0)
+    acts = tuple([ops.ACT_CODE["relu"], ops.ACT_CODE["elu"]][:nb])
+
+    def run(drop, dout=None):
+        zs = [z.clone().requires_grad_(True) for z in Zs]
+        sc = scale.clone().requires_grad_(True); of = offset.clone().requires_grad_(True)
+        out = ops._ActNorm.apply(sc, of, acts, seg, 1.0, drop, *zs)
+        if dout is not None:
+            (out * dout).sum().backward()
+        return out.detach(), [z.grad for z in zs], sc.grad, of.grad
+
+    base, _, _, _ = run((0.0, 0))
+    dropped, _, _, _ = run((p, seed))
+    keep = ops.dropout_keep_mask(n, F, p, seed, DEV)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    assert torch.equal(dropped != 0, keep & (base != 0))
+    np.testing.assert_allclose(dropped.cpu().numpy(), (base * keep / (1 - p)).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    # a different seed gives a different mask
+    other, _, _, _ = run((p, seed + 1))
+    assert not torch.equal(other != 0, dropped != 0)
+    # backward: same as pushing G * mask / (1-p) through the op without dropout
+    G = torch.randn(n, F, device=DEV, generator=g)
+    _, gz_d, gs_d, go_d = run((p, seed), G)
+    _, gz_r, gs_r, go_r = run((0.0, 0), G * keep / (1 - p))
+    for a, b in zip(gz_d, gz_r):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gs_d.cpu().numpy(), gs_r.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(go_d.cpu().numpy(), go_r.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_model_dropout_fusion_plan_and_training_step():
+    """DeepGNN folds layer l+1's input dropout into layer l's kernel only when nothing else reads layer l's
+    un-dropped output (residue none + centre pooling) and only in training; evaluation is unaffected."""
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN, VALID
+    from shadow_gnn_amd.models import DeepGNN
+    torch.manual_seed(0)
+    n, F0, C, B = 9000, 32, 5, 300
+    sizes = torch.full((B,), n // B, dtype=torch.int64)
+    import scipy.sparse as sp
+    blocks = [sp.random(n // B, n // B, density=0.1, format="csr", random_state=i % 7, dtype=np.float32) for i in range(B)]
+    A = sp.block_diag(blocks, format="csr"); A.data[:] = 1.0; A.sort_indices()
+    tgt = torch.arange(B) * (n // B)
+
+    def make(residue, pooling):
+        arch = dict(num_layers=3, num_cls_layers=1, heads=1, branch_sharing=False, dim=64, act="relu",
+                    layer_norm="norm_feat", feature_augment_ops="sum", aggr="sage", residue=residue, pooling=pooling,
+                    loss="softmax", ensemble_act="relu")
+        m = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(lr=0.01, dropout=0.3, dropedge=0.0), "node").to(DEV)
+        m.optimizer = torch.optim.Adam(m.parameters(), lr=0.01)
+        return m
+
+    def batch():
+        return OneBatchSubgraph([_csr(A.indptr, A.indices)], [torch.randn(n, F0, device=DEV)],
+                                torch.randint(0, C, (B,), device=DEV), sizes.to(DEV).unsqueeze(0), [tgt.to(DEV)], [{}])
+
+    m = make("none", "center")
+    losses = [float(m.step(TRAIN, "running", batch())["loss"]) for _ in range(3)]
+    assert all(np.isfinite(losses))
+    L = list(m.conv_layers[0])
+    assert [l.out_dropout for l in L] == [0.3, 0.3, 0.0] and [l.input_pre_dropped for l in L] == [False, True, True]
+    # evaluation: deterministic, no dropout anywhere
+    b = batch()
+    e1 = m.step(VALID, "running", OneBatchSubgraph(b.adj_ens, [b.feat_ens[0].clone()], b.label, b.size_subg_ens, b.target_ens, [{}]))
+    e2 = m.step(VALID, "running", OneBatchSubgraph(b.adj_ens, [b.feat_ens[0].clone()], b.label, b.size_subg_ens, b.target_ens, [{}]))
+    assert torch.equal(e1["preds"], e2["preds"])
+    # a read-out that consumes every layer's output keeps nn.Dropout
+    m2 = make("max", "mean")
+    m2.step(TRAIN, "running", batch())
+    assert all(l.out_dropout == 0.0 and not l.input_pre_dropped for l in m2.conv_layers[0])
