@@ -190,9 +190,14 @@ class GraphSAGE(shaDowLayer):
             assert adj is None or isinstance(adj, ops.NormAdj)
             adj_norm = adj
         feat_in = self.in_dropout(feat_in)
-        feat_neigh = self.spmm(adj_norm, feat_in)
-        feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],
-                                       [self.act_name, self.act_name])
+        if self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0:
+            # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)
+            feat_out = ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
+                                      self.scale, self.offset, out_dropout=self._out_p())
+        else:
+            feat_neigh = self.spmm(adj_norm, feat_in)
+            feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],
+                                           [self.act_name, self.act_name])
         return feat_out, adj_norm, True, 0.
 
     def complexity(self, dims_x, dims_adj):

@@ -226,11 +226,12 @@ def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
 BLOCKDIAG_MIN_F = 128     # below this width the per-edge gather kernels are faster (measured)
 
 
-def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None):
-    """``blocks`` = (subg_off, subg_edge_off, max_subg_nodes) of a block-diagonal adjacency."""
+def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None, out=None):
+    """``blocks`` = (subg_off, subg_edge_off, max_subg_nodes) of a block-diagonal adjacency.
+    ``out``: optional [n, F] destination (may be a column slice of a wider buffer)."""
     X = _f32c(X)
     F = X.shape[1]
-    Y = torch.empty(n, F, dtype=torch.float32, device=X.device)
+    Y = out if out is not None else torch.empty(n, F, dtype=torch.float32, device=X.device)
     e = int(indices.numel())
     # algorithmic bytes (SURVEY.md 8(d)): indptr + indices (+ edge values) + read X + write A.X
     nbytes = 4 * (n + 1) + 4 * e + (4 * e if edge_w is not None else 0) + 8 * n * F
@@ -345,12 +346,14 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
     return out
 
 
-def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias, drop=(0.0, 0)):
+def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias, drop=(0.0, 0), dz_out=None):
+    """``dz_out``: optional preallocated dZ destinations (column slices of a wider buffer are fine)."""
     nb = len(Zs)
     n, F = Zs[0].shape
     dev = sc.device
     dout = _f32c(dout)
-    dZs = [torch.empty_like(z) if nd else None for z, nd in zip(Zs, need_dz)]
+    dZs = [((dz_out[i] if dz_out is not None and dz_out[i] is not None else torch.empty_like(z)) if nd else None)
+           for i, (z, nd) in enumerate(zip(Zs, need_dz))]
     dsc = torch.empty(nb, F, dtype=torch.float32, device=dev)
     dof = torch.empty(nb, F, dtype=torch.float32, device=dev)
     dbi = torch.empty(nb, F, dtype=torch.float32, device=dev) if want_dbias else None
@@ -437,6 +440,7 @@ def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
         return dW
     if n < 32768:
         return dZ.t() @ X
+    dZ, X = dZ.contiguous(), X.contiguous()          # (column-slice views reach here from the fused SAGE node)
     S = min(256, max(2, n // 2048))
     c = n // S
     dW = torch.bmm(dZ[:S * c].view(S, c, Fo).transpose(1, 2), X[:S * c].view(S, c, Fi)).sum(0)
@@ -504,6 +508,67 @@ class _LinearActNorm(torch.autograd.Function):
         dWs = [weight_grad(dz, x) if ng[7 + nb + i] else None for i, (dz, x) in enumerate(zip(dZs, Xs))]
         dbs = [dbi[i] if (has_b[i] and ng[7 + 2 * nb + i]) else None for i in range(nb)]
         return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, *dXs, *dWs, *dbs)
+
+
+class _SageDense(torch.autograd.Function):
+    """The whole dense part of a GraphSAGE layer (shaDow/layers.py:471-483) as ONE autograd node:
+        out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn))
+    so that the backward pass can use  dX = [dZs | A^T dZn] . [Ws ; Wn]  -- one GEMM with K = 2F that writes
+    dX once -- instead of two GEMMs, a transposed SpMM on the product and an add."""
+    @staticmethod
+    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop):
+        X = _f32c(X).contiguous()
+        _need_cuda(X, Ws, Wn, scale, offset)
+        c = adj.csr
+        F = Ws.shape[0]
+        AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
+                       (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
+        Zs, Zn = mm_nt(X, Ws), mm_nt(AX, Wn)
+        sc = scale.reshape(2, F).contiguous().float()
+        of = offset.reshape(2, F).contiguous().float()
+        bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
+        out = _an_fwd([Zs, Zn], bsc, acts, sc, of, F, 1.0, drop)
+        ctx.save_for_backward(X, AX, Ws, Wn, Zs, Zn, sc, of, *[b if b is not None else sc.new_empty(0) for b in bsc])
+        ctx.adj = adj
+        ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        X, AX, Ws, Wn, Zs, Zn, sc, of, b0, b1 = ctx.saved_tensors
+        acts, drop, sshape, oshape, has_b = ctx.meta
+        adj = ctx.adj
+        n, F = Zs.shape
+        ng = ctx.needs_input_grad
+        biases = [b if hb else None for b, hb in zip((b0, b1), has_b)]
+        # dZs lands in the left half of one [n, 2F] buffer; A^T dZn goes into the right half
+        buf = torch.empty(n, 2 * F, dtype=torch.float32, device=dout.device) if ng[0] else None
+        dz_out = [buf[:, :F], None] if buf is not None else None
+        (dZs, dZn), dsc, dof, dbi = _an_bwd([Zs, Zn], biases, acts, sc, of, F, 1.0, dout, [True, True], any(has_b),
+                                            drop, dz_out)
+        dX = None
+        if ng[0]:
+            c = adj.csr
+            ti, tx, tp = c.transposed
+            _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale, adj.row_scale, dZn,
+                      c.n, (c.subg_off, c.subg_edge_off, c.max_subg_nodes), out=buf[:, F:])
+            dX = mm_nt(buf, torch.cat([Ws.t(), Wn.t()], dim=1))
+        dWs = weight_grad(dZs, X) if ng[2] else None
+        dWn = weight_grad(dZn, AX) if ng[4] else None
+        dbs = dbi[0] if (has_b[0] and ng[3]) else None
+        dbn = dbi[1] if (has_b[1] and ng[5]) else None
+        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None
+
+
+def sage_dense(X: torch.Tensor, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
+               offset: torch.Tensor, out_dropout: float = 0.0) -> torch.Tensor:
+    """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483)."""
+    if act not in ACT_CODE:
+        raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
+    F = lin_self.weight.shape[0]
+    code = ACT_CODE[act]
+    return _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
+                            (code, code), _drop_arg(out_dropout, F))
 
 
 def _drop_arg(out_dropout: float, F: int):
