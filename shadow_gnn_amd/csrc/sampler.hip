@@ -421,7 +421,9 @@ extern "C" int sg_next_roots(sg_sampler *s, uint32_t num_roots, uint32_t max_sub
     return set_error(SG_ERR_INVALID, "sg_next_roots: bad argument");
   if (s->num_targets == 0) return set_error(SG_ERR_STATE, "sg_next_roots: no targets (call sg_shuffle_targets)");
   // _get_roots_p, .cpp:459-468
-  const uint64_t start = s->idx_root;
+  // (a shorter target list installed mid-epoch leaves the cursor past its end: wrap, as at an epoch end --
+  //  the reference would index past `targets` there)
+  const uint64_t start = s->idx_root < s->num_targets ? s->idx_root : 0;
   const uint64_t end = std::min<uint64_t>(s->num_targets, start + (uint64_t)num_roots * max_subgraphs);
   s->idx_root = (end == s->num_targets) ? 0 : end;
   const uint64_t groups = (end - start + num_roots - 1) / num_roots;
@@ -464,13 +466,14 @@ static void derive_caps(const sg_sampler *s, const sg_config *cfg, uint32_t *cap
   } else {
     n = R; f = R;
   }
-  n = std::max<uint64_t>(n, s->user_cap_nodes);
+  // grown capacities (sg_set_caps after SG_ERR_CAPACITY) only concern k-hop: the other methods are bounded
+  if (cfg->method == SG_METHOD_KHOP) n = std::max<uint64_t>(n, s->user_cap_nodes);
   n = std::min<uint64_t>(n, N);
   n = std::max<uint64_t>(n, R);
   if (cfg->method == SG_METHOD_KHOP && cfg->budget < 0) f = n;
   f = std::min<uint64_t>(std::max<uint64_t>(f, R), n);
   uint64_t e = std::min<uint64_t>(n * n + n, std::max<uint64_t>(4096, 16 * n));
-  e = std::max<uint64_t>(e, s->user_cap_edges);
+  if (cfg->method == SG_METHOD_KHOP) e = std::max<uint64_t>(e, s->user_cap_edges);
   e = std::min<uint64_t>(e, 0x7FFFFFFFull);
   *capn = (uint32_t)n; *cape = (uint32_t)e; *capf = (uint32_t)f;
 }

@@ -184,7 +184,7 @@ class HipSampler:
                                       self.device.index, seed, C.byref(h)))
         self._h = h
         self._pending: Optional[_Pending] = None
-        self._edge_hwm = 0   # high-water mark of batch edges per subgraph, for output sizing
+        self._hwm = {}       # per sampler config: high-water marks of (edges, nodes) per subgraph, for output sizing
 
     # ------------------------------------------------------------------ info
     def close(self):
@@ -258,6 +258,9 @@ class HipSampler:
     def _alloc(self, cfg: SamplerConfig, P: int, cap_nodes: int, cap_edges: int):
         dev = self.device
         i32 = dict(dtype=torch.int32, device=dev)
+        if cap_nodes >= (1 << 32) or cap_edges >= (1 << 32):
+            raise CapacityError(_lib.SG_ERR_CAPACITY, f"output buffers of {cap_nodes} nodes / {cap_edges} edges for {P} "
+                                f"subgraphs exceed the uint32 batch index space; use smaller sampler calls")
         b = dict(node=torch.empty(cap_nodes, **i32), indptr=torch.empty(cap_nodes + 1, **i32),
                  indices=torch.empty(cap_edges, **i32), edge_id=torch.empty(cap_edges, **i32),
                  target=torch.empty(max(1, P * cfg.num_roots), **i32),
@@ -274,12 +277,22 @@ class HipSampler:
                          cap_nodes, cap_edges)
         return b, out
 
-    def _launch(self, pend: _Pending, cap_edges_out: Optional[int] = None):
+    @staticmethod
+    def _cfg_key(cfg: SamplerConfig):
+        return (cfg.method, cfg.num_roots, cfg.depth, cfg.budget, cfg.k, cfg.add_self_edge)
+
+    def _launch(self, pend: _Pending, cap_edges_out: Optional[int] = None, cap_nodes_out: Optional[int] = None):
         cfg, P = pend.cfg, pend.P
         capn, cape = self.get_caps(cfg)
-        cap_nodes_out = max(1, P * capn)
+        if cap_nodes_out is None:
+            # worst case P * capn when that is small; otherwise (hub-heavy graphs, grown caps) the running
+            # high-water mark with head room -- finish() re-runs with the exact size on overflow
+            cap_nodes_out = P * capn
+            if cap_nodes_out > (1 << 24):
+                cap_nodes_out = min(cap_nodes_out, max(1 << 24, P * (self._hwm.get(self._cfg_key(cfg), (0, 0))[1] * 3 // 2 + 64)))
+        cap_nodes_out = max(1, cap_nodes_out)
         if cap_edges_out is None:
-            per = max(self._edge_hwm * 3 // 2, min(cape, 8 * capn), 64)
+            per = max(self._hwm.get(self._cfg_key(cfg), (0, 0))[0] * 3 // 2, min(cape, 8 * capn), 64)
             cap_edges_out = max(1, P * per)
         cap_edges_out = min(cap_edges_out, max(1, P * cape))
         pend.bufs, pend.out = self._alloc(cfg, P, cap_nodes_out, cap_edges_out)
@@ -334,18 +347,22 @@ class HipSampler:
                 self.set_caps(cap_subg_nodes=min(self.num_nodes(), max(2 * cnt.max_subg_nodes, 1024)))
             if ov & 2:
                 self.set_caps(cap_subg_edges=cnt.max_subg_edges + cnt.max_subg_edges // 4 + 64)
-            cap_e = None
+            cap_e = cap_n = None
             if (ov & 8) and not (ov & 3):
                 cap_e = int(cnt.e_tot) + int(cnt.e_tot) // 8 + 64
+            if (ov & 4) and not (ov & 3):
+                cap_n = int(cnt.n_tot) + int(cnt.n_tot) // 8 + 64
             with torch.cuda.device(self.device):
-                self._launch(pend, cap_e)
+                self._launch(pend, cap_e, cap_n)
         else:
             self._pending = None
             raise CapacityError(_lib.SG_ERR_CAPACITY, "sampler capacity did not converge")
         self._pending = None
         n, e, P = int(cnt.n_tot), int(cnt.e_tot), pend.P
         if P:
-            self._edge_hwm = max(self._edge_hwm, -(-e // P))
+            k = self._cfg_key(pend.cfg)
+            he, hn = self._hwm.get(k, (0, 0))
+            self._hwm[k] = (max(he, -(-e // P)), max(hn, -(-n // P)))
         b = pend.bufs
         return DeviceBatch(
             node=b["node"][:n], indptr=b["indptr"][:n + 1], indices=b["indices"][:e],

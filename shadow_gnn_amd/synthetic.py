@@ -59,9 +59,24 @@ def make_graph_torch(n, nnz_target, seed=0, device="cuda", max_degree=None):
     del r, cdf, w, u
     keep = a != b
     a, b = a[keep], b[keep]
-    key = torch.cat([a * n + b, b * n + a])
+    k1, k2 = a * n + b, b * n + a
     del a, b, keep
-    key = torch.unique(key)          # sorted + deduplicated
+    if 2 * k1.numel() < (1 << 30):
+        key = torch.unique(torch.cat([k1, k2]))      # sorted + deduplicated
+        del k1, k2
+    else:
+        # torch's sort / boolean indexing take < 2^31 elements: de-duplicate row ranges separately (keys are
+        # row-major, so the sorted pieces concatenate into the sorted whole)
+        parts = -(-2 * k1.numel() // (1 << 29))
+        pieces = []
+        for i in range(parts):
+            lo, hi = (i * n // parts) * n, (((i + 1) * n // parts) * n if i + 1 < parts else (n + 1) * n)
+            sel = torch.cat([k1[(k1 >= lo) & (k1 < hi)], k2[(k2 >= lo) & (k2 < hi)]])
+            pieces.append(torch.unique(sel))
+            del sel
+        del k1, k2
+        key = torch.cat(pieces)
+        del pieces
     rows = torch.div(key, n, rounding_mode="floor")
     cols = (key - rows * n).to(torch.int32)
     del key

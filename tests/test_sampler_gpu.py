@@ -198,6 +198,20 @@ def test_edge_cases_empty_isolated_and_last_batch():
     assert b.num_subgraphs == 1 and hs.get_idx_root() == 0
 
 
+def test_root_cursor_wraps_when_a_shorter_target_list_is_installed():
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(500, 6, seed=1)
+    hs = _make(indptr, indices)
+    hs.shuffle_targets(np.arange(100, dtype=np.uint32))
+    cfg = SamplerConfig(method="nodeIID")
+    assert hs.sample(cfg, 60).num_subgraphs == 60          # cursor at 60
+    hs.shuffle_targets(np.arange(10, dtype=np.uint32))      # shorter list, cursor beyond its end
+    b = hs.sample(cfg, 60)
+    assert b.num_subgraphs == 10 and np.array_equal(b.to_host()["node"], np.arange(10, dtype=np.uint32))
+    assert hs.get_idx_root() == 0
+
+
 def test_reference_compatible_surface():
     """ParallelSampler / SubgraphStructVec mirror: same ctor order, config keys and getters."""
     from oracle import sampler_oracle as so
