@@ -31,8 +31,6 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kGemmThreads = 256;        // 4 wavefronts per workgroup, two workgroups per CU
-constexpr int kGemmWaves = kGemmThreads / 64;
 
 #ifdef GEMM_TIMING
 __device__ unsigned long long gemm_dbg[16];
@@ -106,23 +104,30 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t ldb, uin
 // workgroups are resident per CU (register-bound): one keeps the matrix cores busy while the other sits
 // in a barrier or in its epilogue.
 // ---------------------------------------------------------------------------
-template <int RB, int NT, bool kTail>     // kTail: K is not a multiple of 32 (the last unit is zero-padded)
-__global__ void __launch_bounds__(kGemmThreads, 2)
+// RB x 32 rows and TW column tiles per wavefront; the WAVES wavefronts of a workgroup form
+// (WAVES / CS) row groups x CS column groups and share one B image ring (NT = TW * CS tiles).
+// <1, 8, 1, 4>: 217 registers, 2 wavefronts per SIMD;  <1, 4, 2, 6>: half the accumulators per wavefront,
+// 3 wavefronts per SIMD (A is then loaded by both column groups).
+template <int RB, int TW, int CS, int WAVES, bool kTail>     // kTail: K % 32 != 0 (the last unit is zero-padded)
+__global__ void __launch_bounds__(WAVES * 64, 2)
 gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__restrict__ Bimg, float *__restrict__ C,
                      int64_t ldc, uint32_t M, uint32_t N, uint32_t K, uint32_t units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-  constexpr int kRowsWG = 32 * RB * kGemmWaves;
+  constexpr int NT = TW * CS;                            // column tiles of the B image
+  constexpr int kGemmThreads = WAVES * 64;
+  constexpr int kRowsWG = 32 * RB * (WAVES / CS);
   constexpr int kPieces = 4 * RB;                        // 16-byte A pieces per lane per unit
-  constexpr int kPPS = (kPieces + 2 * NT - 1) / (2 * NT);   // A pieces issued per (step, tile) slot
+  constexpr int kPPS = (kPieces + 2 * TW - 1) / (2 * TW);   // A pieces issued per (step, tile) slot
   constexpr int kStepVecs = 3 * NT * 64;                 // bf16x8 vectors of one k-step's B image
   constexpr int kFill = (kStepVecs + kGemmThreads - 1) / kGemmThreads;     // copies per thread per step
-  constexpr int kFillPerSlot = (kFill + NT - 1) / NT;
+  constexpr int kFillPerSlot = (kFill + TW - 1) / TW;
   bf16x8 *lbuf = reinterpret_cast<bf16x8 *>(gsm);       // [3][kStepVecs]: ring of k-step images
-  constexpr int kPieces0 = (kPieces < NT * kPPS) ? kPieces : NT * kPPS;   // A pieces issued during step h = 0 / h = 1
+  constexpr int kPieces0 = (kPieces < TW * kPPS) ? kPieces : TW * kPPS;   // A pieces issued during step h = 0 / h = 1
   constexpr int kPieces1 = kPieces - kPieces0;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t r = lane & 31u, g = lane >> 5;
-  const uint64_t m0 = (uint64_t)blockIdx.x * kRowsWG + wv * (32u * RB);
+  const uint32_t wrow = wv / CS, wcol = wv % CS;
+  const uint64_t m0 = (uint64_t)blockIdx.x * kRowsWG + wrow * (32u * RB);
   const float *arow[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; rb++) {
@@ -130,11 +135,11 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
     arow[rb] = A + row * lda + 16 * g;
   }
 
-  f32x16 acc[RB][NT];
+  f32x16 acc[RB][TW];
 #pragma unroll
   for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+    for (int t = 0; t < TW; t++)
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[rb][t][i] = 0.f;
 
@@ -152,7 +157,7 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
       an[rb][q] = make_float4(v[0], v[1], v[2], v[3]);
     }
   };
-  // copies `slot` (of NT) of the B image of k-step s into LDS buffer s & 1
+  // copies `slot` (of TW) of the B image of k-step s into its ring buffer
   auto fill_b = [&](uint32_t s, int slot) {
     const bf16x8 *src = Bimg + (size_t)s * kStepVecs;
     bf16x8 *dst = lbuf + (size_t)(s % 3u) * kStepVecs;
@@ -170,10 +175,10 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
   const unsigned long long t0_ = tl_, w0_ = wall_clock64();
 #endif
 #pragma unroll
-  for (int slot = 0; slot < NT; slot++) fill_b(0, slot);
+  for (int slot = 0; slot < TW; slot++) fill_b(0, slot);
   if (units * 2 > 1) {
 #pragma unroll
-    for (int slot = 0; slot < NT; slot++) fill_b(1, slot);
+    for (int slot = 0; slot < TW; slot++) fill_b(1, slot);
   }
 #pragma unroll
   for (int p = 0; p < kPieces; p++) load_a_piece(0, p);
@@ -205,17 +210,17 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
       // B fragments are read one tile ahead of the MFMAs that consume them
       bf16x8 fb[2][3];
 #pragma unroll
-      for (int pc = 0; pc < 3; pc++) fb[0][pc] = lb[(pc * NT) * 64 + lane];
+      for (int pc = 0; pc < 3; pc++) fb[0][pc] = lb[(pc * NT + wcol * TW) * 64 + lane];
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        if (t + 1 < NT) {
+      for (int t = 0; t < TW; t++) {
+        if (t + 1 < TW) {
 #pragma unroll
-          for (int pc = 0; pc < 3; pc++) fb[(t + 1) & 1][pc] = lb[(pc * NT + t + 1) * 64 + lane];
+          for (int pc = 0; pc < 3; pc++) fb[(t + 1) & 1][pc] = lb[(pc * NT + wcol * TW + t + 1) * 64 + lane];
         }
         if (st + 2 < steps) fill_b(st + 2, t);              // two steps ahead: never waited for in this step
         if (u + 1 < units) {
 #pragma unroll
-          for (int p = (h * NT + t) * kPPS; p < (h * NT + t + 1) * kPPS && p < kPieces; p++) load_a_piece(u + 1, p);
+          for (int p = (h * TW + t) * kPPS; p < (h * TW + t + 1) * kPPS && p < kPieces; p++) load_a_piece(u + 1, p);
         }
         const bf16x8 bh = fb[t & 1][0], bm = fb[t & 1][1], bl = fb[t & 1][2];
         // small terms first, the dominant product last; row blocks alternate
@@ -252,8 +257,8 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
 #pragma unroll
   for (int rb = 0; rb < RB; rb++) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-      const uint32_t col = 32 * t + r;
+    for (int t = 0; t < TW; t++) {
+      const uint32_t col = 32 * (wcol * TW + t) + r;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const uint64_t rr = m0 + 32u * rb + (i & 3) + 8 * (i >> 2) + 4 * g;
@@ -272,8 +277,6 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
 
 using namespace shadow;
 
-// row blocks per wavefront for a given number of 32-column tiles (narrow outputs: two row blocks)
-static int gemm_rb(uint32_t tiles) { return tiles <= 4 ? 2 : 1; }
 
 extern "C" size_t sl_gemm_pack_bytes(uint32_t N, uint32_t K) {
   const size_t units = (K + 31) / 32, tiles = (N + 31) / 32;
@@ -301,36 +304,37 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
   if ((lda & 3) || (reinterpret_cast<uintptr_t>(d_A) & 15))
     return set_error(SG_ERR_INVALID, "sl_gemm_nt_f32: A must be 16-byte aligned with lda %% 4 == 0");
   const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
-  const int rb = gemm_rb(tiles);
-  const uint32_t rows_wg = 32u * (uint32_t)rb * (uint32_t)kGemmWaves;
-  const uint32_t grid = (M + rows_wg - 1) / rows_wg;
   hipStream_t st = (hipStream_t)stream;
   const bf16x8 *img = reinterpret_cast<const bf16x8 *>(d_packed_B);
   const size_t lds = (size_t)3 * 3 * tiles * 64 * 16;
-#define SHD_GEMM(RB, NT)                                                                                     \
+#define SHD_GEMM(RB, TW, CS, WAVES)                                                                          \
   {                                                                                                          \
+    const uint32_t rows_wg = 32u * RB * (WAVES / CS);                                                        \
+    const uint32_t grid = (M + rows_wg - 1) / rows_wg;                                                       \
     if (lds > 64 * 1024) {                                                                                   \
-      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, NT, false>,                         \
+      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, TW, CS, WAVES, false>,              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, NT, true>,                          \
+      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, TW, CS, WAVES, true>,               \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
     }                                                                                                        \
     if (K % 32 == 0)                                                                                         \
-      hipLaunchKernelGGL((gemm_nt_split_kernel<RB, NT, false>), dim3(grid), dim3(kGemmThreads), lds, st, d_A, lda, img, \
-                         d_C, ldc, M, N, K, units);                                                          \
+      hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,  \
+                         lda, img, d_C, ldc, M, N, K, units);                                                \
     else                                                                                                     \
-      hipLaunchKernelGGL((gemm_nt_split_kernel<RB, NT, true>), dim3(grid), dim3(kGemmThreads), lds, st, d_A, lda, img, \
-                         d_C, ldc, M, N, K, units);                                                          \
+      hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, true>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,   \
+                         lda, img, d_C, ldc, M, N, K, units);                                                \
   }
+  // (a column-split variant <1, 4, 2, 6> reaches 3 wavefronts per SIMD but measured slower: 0.35 vs 0.29 ms --
+  //  A is loaded by both column groups and the vector-memory path is the scarce resource)
   switch (tiles) {
-    case 1: SHD_GEMM(2, 1) break;
-    case 2: SHD_GEMM(2, 2) break;
-    case 3: SHD_GEMM(2, 3) break;
-    case 4: SHD_GEMM(2, 4) break;
-    case 5: SHD_GEMM(1, 5) break;
-    case 6: SHD_GEMM(1, 6) break;
-    case 7: SHD_GEMM(1, 7) break;
-    default: SHD_GEMM(1, 8) break;
+    case 1: SHD_GEMM(2, 1, 1, 4) break;
+    case 2: SHD_GEMM(2, 2, 1, 4) break;
+    case 3: SHD_GEMM(2, 3, 1, 4) break;
+    case 4: SHD_GEMM(2, 4, 1, 4) break;
+    case 5: SHD_GEMM(1, 5, 1, 4) break;
+    case 6: SHD_GEMM(1, 6, 1, 4) break;
+    case 7: SHD_GEMM(1, 7, 1, 4) break;
+    default: SHD_GEMM(1, 8, 1, 4) break;
   }
 #undef SHD_GEMM
   SHD_HIP(hipGetLastError());
