@@ -223,7 +223,7 @@ def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
     return NormAdj(csr, edge_w=m, row_scale=s, col_scale=s)
 
 
-BLOCKDIAG_MIN_F = 128     # below this width the per-edge gather kernels are faster (measured)
+BLOCKDIAG_MIN_F = 96      # below this width the per-edge gather kernels are faster (measured)
 
 
 def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None, out=None):
