@@ -121,6 +121,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 2      # sg_abi_version() of the library these signatures describe
+
+
 def load():
     """Load libshadow_hip.so.  torch is imported first so that the HIP runtime
     torch ships (same SONAME libamdhip64.so.7) is the one the library binds to:
@@ -139,6 +142,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.sg_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.sg_abi_version()}, this package needs {ABI_VERSION}: "
+                          "rebuild it (python -c 'import __graft_entry__ as g; g.build(force=True)')")
     _lib = lib
     return lib
 
