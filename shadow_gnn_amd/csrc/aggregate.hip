@@ -651,14 +651,16 @@ __device__ __forceinline__ float seg_sum(float v) {
 // One row per LPR lanes, one float4 per lane; LS = lanes per normalisation segment.
 // (F/4 == number of active lanes per row <= LPR; seg/4 == LS)
 template <int LPR, int LS, bool BWD, int NB>
-__global__ void act_norm_kernel(ActNormParams p) {
+__global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_kernel(ActNormParams p) {
   const uint32_t rows_per_block = kBlock / LPR;
   const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const uint32_t f = l * 4;
   const bool lane_on = f < p.F;
   const float inv_seg = 1.0f / (float)p.seg;
-  float4 gs[2], go[2], gb[2];   // per-thread partial sums of dscale / doffset / dbias over its rows
-  gs[0] = gs[1] = go[0] = go[1] = gb[0] = gb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // per-thread partial sums of dscale / doffset / dbias over its rows (doffset = sum of dy is the same for
+  // every branch: one accumulator)
+  float4 gs[2], go, gb[2];
+  gs[0] = gs[1] = go = gb[0] = gb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   // register double buffering: the loads of this thread's NEXT row are issued before the
   // reductions of the current one, so two rows per wavefront are in flight
   const uint64_t rstep = (uint64_t)gridDim.x * rows_per_block;
@@ -721,7 +723,7 @@ __global__ void act_norm_kernel(ActNormParams p) {
         acc.z += d.z * sc.z * rstd + of.z; acc.w += d.w * sc.w * rstd + of.w;
       } else {
         gs[b].x += dy.x * xh.x; gs[b].y += dy.y * xh.y; gs[b].z += dy.z * xh.z; gs[b].w += dy.w * xh.w;
-        go[b].x += dy.x; go[b].y += dy.y; go[b].z += dy.z; go[b].w += dy.w;
+        if (b == 0) { go.x += dy.x; go.y += dy.y; go.z += dy.z; go.w += dy.w; }
         const float4 dxh = make_float4(dy.x * sc.x, dy.y * sc.y, dy.z * sc.z, dy.w * sc.w);
         const float m1 = seg_sum<LS>(dxh.x + dxh.y + dxh.z + dxh.w) * inv_seg;
         const float m2 = seg_sum<LS>(dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w) * inv_seg;
@@ -752,7 +754,7 @@ __global__ void act_norm_kernel(ActNormParams p) {
     for (int b = 0; b < NB; b++) {
       float *rs = &red[b][0][threadIdx.x * 4], *ro = &red[b][1][threadIdx.x * 4], *rb = &red[b][2][threadIdx.x * 4];
       rs[0] = gs[b].x; rs[1] = gs[b].y; rs[2] = gs[b].z; rs[3] = gs[b].w;
-      ro[0] = go[b].x; ro[1] = go[b].y; ro[2] = go[b].z; ro[3] = go[b].w;
+      ro[0] = go.x; ro[1] = go.y; ro[2] = go.z; ro[3] = go.w;
       rb[0] = gb[b].x; rb[1] = gb[b].y; rb[2] = gb[b].z; rb[3] = gb[b].w;
     }
     __syncthreads();
