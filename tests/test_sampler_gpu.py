@@ -327,3 +327,41 @@ def test_full_size_shapes_match_oracle(shape, batch, depth, self_e):
                           aug=("hops",), seed=3, serial_base=0, num_threads=16)
     for f in INT_FIELDS + ["hop"]:
         assert np.array_equal(got[f], getattr(ref, f)), (shape, batch, depth, self_e, f)
+
+
+def test_seeded_fuzz_against_oracle():
+    """40 seeded random (graph, sampler config) draws -- directed and undirected graphs, isolated nodes,
+    self loops, hubs, 1- and 2-root subgraphs, every flag combination -- HIP vs oracle, every field."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import SamplerConfig
+    rng = np.random.default_rng(20240917)
+    for trial in range(40):
+        n = int(rng.integers(30, 3000))
+        deg = float(rng.choice([0.5, 2, 6, 25]))
+        m = int(n * deg)
+        a = rng.integers(0, n, m); b = rng.integers(0, n, m)
+        if rng.random() < 0.5:                               # a hub
+            hub = int(rng.integers(0, n)); k = int(min(n - 1, rng.integers(50, 800)))
+            a = np.concatenate([a, np.full(k, hub)]); b = np.concatenate([b, rng.choice(n, k, replace=False)])
+        if rng.random() < 0.6:                               # symmetric
+            a, b = np.concatenate([a, b]), np.concatenate([b, a])
+        if rng.random() < 0.5:                               # no self loops
+            keep = a != b; a, b = a[keep], b[keep]
+        key = np.unique(a.astype(np.int64) * n + b)
+        rows, cols = key // n, (key % n).astype(np.uint32)
+        indptr = np.zeros(n + 1, dtype=np.int64); np.add.at(indptr, rows + 1, 1)
+        indptr = np.cumsum(indptr).astype(np.uint32)
+        num_roots = int(rng.choice([1, 1, 2]))
+        P = int(rng.integers(1, 60))
+        roots = rng.integers(0, n, P * num_roots).astype(np.uint32)
+        method = str(rng.choice(["khop", "khop", "khop", "nodeIID"]))
+        kw = dict(method=method, num_roots=num_roots, depth=int(rng.integers(0, 4)), budget=int(rng.choice([-1, 0, 1, 3, 10])),
+                  add_self_edge=bool(rng.random() < 0.5), include_target_conn=bool(rng.random() < 0.5),
+                  compat_overread=bool(rng.random() < 0.3))
+        aug = tuple(x for x in ("hops", "drnls") if rng.random() < 0.5 and (x == "hops" or num_roots == 2))
+        seed = int(rng.integers(0, 2 ** 31))
+        hs = _make(indptr, cols, seed=seed)
+        got = hs.sample(SamplerConfig(aug=aug, **kw), roots=roots, serial_base=7)
+        ref = so.sample_batch(indptr, cols, roots, aug=aug, seed=seed, serial_base=7, num_threads=4, **kw)
+        _cmp_batch(ref, got, aug, (trial, n, m, kw, aug))
+        hs.close()
