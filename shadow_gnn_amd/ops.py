@@ -415,7 +415,8 @@ def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     Cm = torch.empty(M, N, dtype=torch.float32, device=A.device)
     st = _stream(A)
     check(lib.sl_gemm_pack_b(Bc.data_ptr(), Bc.stride(0), N, K, packed.data_ptr(), st))
-    with _timed(f"gemm_nt_N{N}_K{K}", 4 * M * (K + N), A.device, flops=2 * M * K * N):
+    # (keyed like the kernel instantiation rocprofv3 reports: one name per N and per "K % 32" variant)
+    with _timed(f"gemm_nt_split_N{N}" + ("" if K % 32 == 0 else "_Ktail"), 4 * M * (K + N), A.device, flops=2 * M * K * N):
         check(lib.sl_gemm_nt_f32(A.data_ptr(), A.stride(0), packed.data_ptr(), Cm.data_ptr(), Cm.stride(0), M, N, K, st))
     return Cm
 
@@ -434,7 +435,7 @@ def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
         G = lib.sl_gemm_tn_slices(n)
         partial = torch.empty(G * Fo * Fi, dtype=torch.float32, device=dZ.device)
         dW = torch.empty(Fo, Fi, dtype=torch.float32, device=dZ.device)
-        with _timed(f"gemm_tn_N{Fo}_K{Fi}", 4 * n * (Fo + Fi), dZ.device, flops=2 * n * Fo * Fi):
+        with _timed(f"gemm_tn_split_N{Fo}" + ("_K128" if Fi <= 128 else ""), 4 * n * (Fo + Fi), dZ.device, flops=2 * n * Fo * Fi):
             check(lib.sl_gemm_tn_f32(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), n, Fo, Fi,
                                      partial.data_ptr(), _stream(dZ)))
         return dW
