@@ -91,7 +91,7 @@ class shaDowLayer(nn.Module):
         return feat_in if (self.input_pre_dropped and self.training) else self.f_dropout(feat_in)
 
     def can_fuse_out_dropout(self):
-        return self.norm == 'norm_feat' and ops.can_fuse_out_dropout(self.dim_out)
+        return self.norm == 'norm_feat' and ops.can_fuse_out_dropout(self.dim_out, getattr(self, 'dim_slice', None))
 
     def _out_p(self):
         return self.out_dropout if self.training else 0.0

@@ -295,9 +295,14 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
-def can_fuse_out_dropout(F: int) -> bool:
-    """Shapes whose act_norm runs on the vector kernels (the fused output dropout lives there)."""
-    return F % 4 == 0 and 16 <= F <= 256
+def can_fuse_out_dropout(F: int, seg: Optional[int] = None) -> bool:
+    """Shapes whose act_norm runs on the vector kernels (the fused output dropout lives there):
+    F a multiple of 4 up to 256, normalisation segments of a power-of-two number of float4 lanes."""
+    seg = F if seg is None else seg
+    if not (F % 4 == 0 and 16 <= F <= 256 and seg % 4 == 0 and F % seg == 0):
+        return False
+    ls = seg // 4
+    return seg == F or (ls & (ls - 1)) == 0
 
 
 def new_dropout_seed() -> int:
@@ -572,10 +577,10 @@ def sage_dense(X: torch.Tensor, adj: "NormAdj", lin_self, lin_neigh, act: str, s
                             (code, code), _drop_arg(out_dropout, F))
 
 
-def _drop_arg(out_dropout: float, F: int):
+def _drop_arg(out_dropout: float, F: int, seg: Optional[int] = None):
     """(p, seed) of the fused output dropout, or (0, 0)."""
     if out_dropout and out_dropout > 0.0:
-        if not can_fuse_out_dropout(F):
+        if not can_fuse_out_dropout(F, seg):
             raise ValueError(f"fused output dropout is not available for width {F}")
         return (float(out_dropout), new_dropout_seed())
     return (0.0, 0)
@@ -593,7 +598,7 @@ def linear_act_norm(Xs: List[torch.Tensor], lins: Sequence["torch.nn.Linear"], a
         codes.append(ACT_CODE[a])
     F = lins[0].weight.shape[0]
     nb = len(Xs)
-    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, _drop_arg(out_dropout, F),
+    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, _drop_arg(out_dropout, F, seg),
                                 *Xs, *[l.weight for l in lins], *[l.bias for l in lins])
 
 
@@ -609,7 +614,7 @@ def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, o
             raise NotImplementedError(f"activation {a!r} is not available in the fused HIP kernel "
                                       f"(supported: {sorted(ACT_CODE)})")
         codes.append(ACT_CODE[a])
-    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), _drop_arg(out_dropout, F), *Zs)
+    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), _drop_arg(out_dropout, F, seg), *Zs)
 
 
 # ----------------------------------------------------------------------------- readout / encodings
