@@ -29,6 +29,7 @@ class KernelTimer:
 
     def __init__(self):
         self.rec = {}
+        self.count = {}       # launches per kernel class (all of them; only the first MAX_PER_KERNEL carry events)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -43,15 +44,22 @@ class KernelTimer:
             ms = sum(it[0].elapsed_time(it[1]) for it in items)
             by = sum(it[2] for it in items)
             fl = sum(it[3] for it in items)
-            out[name] = dict(launches=len(items), total_ms=ms, avg_ms=ms / max(1, len(items)),
-                             bytes_per_launch=by / max(1, len(items)), gbps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0,
-                             flops_per_launch=fl / max(1, len(items)))
+            k, n = max(1, len(items)), max(len(items), self.count.get(name, 0))
+            out[name] = dict(launches=n, timed_launches=len(items), total_ms=ms / k * n, avg_ms=ms / k,
+                             bytes_per_launch=by / k, gbps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0,
+                             flops_per_launch=fl / k)
         return out
 
 
 class _timed:
+    MAX_PER_KERNEL = 512          # long runs: keep the number of live HIP events bounded
+
     def __init__(self, name, nbytes, device, flops=0):
         self.t = KernelTimer.active
+        if self.t is not None:
+            self.t.count[name] = self.t.count.get(name, 0) + 1
+            if len(self.t.rec.get(name, ())) >= _timed.MAX_PER_KERNEL:
+                self.t = None
         if self.t is not None:
             self.name, self.nbytes, self.flops = name, nbytes, flops
             self.e0 = torch.cuda.Event(enable_timing=True)
