@@ -318,20 +318,26 @@ int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packed_B, float 
  *   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= drop_p * 2^32      (32-bit wrap-around),
  * mix32 = the murmur3 finaliser (h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16);
  * kept values are scaled by 1 / (1 - drop_p); the backward entry regenerates the same mask from
- * (drop_p, drop_seed), no mask tensor exists.  Vector layout only (F % 4 == 0, F <= 256, 16-byte aligned operands).      */
+ * (drop_p, drop_seed), no mask tensor exists.  Vector layout only (F % 4 == 0, F <= 256, 16-byte aligned operands).
+ * d_out_dropped != NULL (needs drop_p > 0) is the dual mode for architectures where something besides the next
+ * layer reads this output (the residue / ResPool read-outs, shaDow/models.py:176-185): d_out receives the plain
+ * value and d_out_dropped the dropped one, from one pass over Z.                                                      */
 int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p, uint64_t drop_seed,
-                    void *stream);
+                    float *d_out_dropped, int64_t ldo_dropped, void *stream);
 /* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
  * when d_dbias != NULL, dbias [nb, F] = column sums of dZ_b (all overwritten,
  * reduced over the rows in a fixed order).
- * d_partial: float[2048 * nb * 3 * F] scratch for the two-stage reduction.     */
+ * d_partial: float[2048 * nb * 3 * F] scratch for the two-stage reduction.
+ * Dual mode: d_dout_dropped != NULL is the gradient of d_out_dropped (goes through the mask), d_dout the gradient
+ * of the plain output and may then be NULL (= zero).                            */
 int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
                     const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
-                    float *d_partial, float drop_p, uint64_t drop_seed, void *stream);
+                    float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped,
+                    int64_t lddo_dropped, void *stream);
 
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):

@@ -626,6 +626,11 @@ struct ActNormParams {
   uint32_t drop_thr;
   float drop_scale;
   uint32_t seed_lo, seed_hi;
+  // dual mode (something else reads the un-dropped output too, e.g. a residue / pooling read-out):
+  // forward writes out (plain) AND out2 (dropped); backward adds the two incoming gradients,
+  // dout (may be NULL) for the plain output and dout2 through the dropout mask
+  float *out2; int64_t ldo2;
+  const float *dout2; int64_t lddo2;
 };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
@@ -671,7 +676,7 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
   // (backward only: the forward kernel runs at full occupancy and measured slower with it)
   constexpr bool kPrefetch = BWD;
   if (kPrefetch && r < p.n && lane_on) {
-    if (BWD) dyn = ld4(p.dout + (int64_t)r * p.lddo + f);
+    if (BWD && p.dout) dyn = ld4(p.dout + (int64_t)r * p.lddo + f);
 #pragma unroll
     for (int b = 0; b < NB; b++) zn[b] = ld4(p.Z[b] + (int64_t)r * p.ldz[b] + f);
   }
@@ -683,7 +688,7 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
 #pragma unroll
       for (int b = 0; b < NB; b++) zc[b] = zn[b];
       if (r + rstep < p.n && lane_on) {
-        if (BWD) dyn = ld4(p.dout + (int64_t)(r + rstep) * p.lddo + f);
+        if (BWD && p.dout) dyn = ld4(p.dout + (int64_t)(r + rstep) * p.lddo + f);
 #pragma unroll
         for (int b = 0; b < NB; b++) zn[b] = ld4(p.Z[b] + (int64_t)(r + rstep) * p.ldz[b] + f);
       }
@@ -693,12 +698,20 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
     }
     if (BWD) {
       float4 ds = make_float4(p.out_scale, p.out_scale, p.out_scale, p.out_scale);
+      float4 dm = ds;                      // factors of the gradient that came through the dropout mask
       if (p.drop_thr) {            // gradient of the fused output dropout: same mask, same 1/(1-p)
         const uint32_t keep = drop_keep4(p, r, f);
         const float ks = p.out_scale * p.drop_scale;
-        ds = make_float4((keep & 1u) ? ks : 0.f, (keep & 2u) ? ks : 0.f, (keep & 4u) ? ks : 0.f, (keep & 8u) ? ks : 0.f);
+        dm = make_float4((keep & 1u) ? ks : 0.f, (keep & 2u) ? ks : 0.f, (keep & 4u) ? ks : 0.f, (keep & 8u) ? ks : 0.f);
       }
-      dy.x *= ds.x; dy.y *= ds.y; dy.z *= ds.z; dy.w *= ds.w;
+      if (p.dout2) {               // dual mode: plain gradient (if any) + masked gradient
+        float4 d2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_on) d2 = ld4(p.dout2 + (int64_t)r * p.lddo2 + f);
+        dy.x = dy.x * ds.x + d2.x * dm.x; dy.y = dy.y * ds.y + d2.y * dm.y;
+        dy.z = dy.z * ds.z + d2.z * dm.z; dy.w = dy.w * ds.w + d2.w * dm.w;
+      } else {
+        dy.x *= dm.x; dy.y *= dm.y; dy.z *= dm.z; dy.w *= dm.w;
+      }
     }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -741,8 +754,10 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
       acc.x *= p.out_scale; acc.y *= p.out_scale; acc.z *= p.out_scale; acc.w *= p.out_scale;
       if (p.drop_thr) {
         const uint32_t keep = drop_keep4(p, r, f);
-        acc.x = (keep & 1u) ? acc.x * p.drop_scale : 0.f; acc.y = (keep & 2u) ? acc.y * p.drop_scale : 0.f;
-        acc.z = (keep & 4u) ? acc.z * p.drop_scale : 0.f; acc.w = (keep & 8u) ? acc.w * p.drop_scale : 0.f;
+        const float4 dr = make_float4((keep & 1u) ? acc.x * p.drop_scale : 0.f, (keep & 2u) ? acc.y * p.drop_scale : 0.f,
+                                      (keep & 4u) ? acc.z * p.drop_scale : 0.f, (keep & 8u) ? acc.w * p.drop_scale : 0.f);
+        if (p.out2) st4(p.out2 + (int64_t)r * p.ldo2 + f, dr);      // dual mode: out stays un-dropped
+        else acc = dr;
       }
       st4(p.out + (int64_t)r * p.ldo + f, acc);
     }
@@ -1040,7 +1055,7 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
   vec = vec && aligned16(p.scale) && aligned16(p.offset);
   for (int b = 0; b < p.nb; b++) if (p.bias[b]) vec = vec && aligned16(p.bias[b]);
   if (!bwd) vec = vec && aligned16(p.out) && (p.ldo % 4 == 0);
-  else vec = vec && aligned16(p.dout) && (p.lddo % 4 == 0);
+  else if (p.dout) vec = vec && aligned16(p.dout) && (p.lddo % 4 == 0);
   if (lpr < 4) vec = false;
   // the kernels are grid-stride loops: launch exactly the resident number of blocks (a partial second
   // round of blocks costs as much as a full one -- measured 0.19 -> 0.27 ms when one VGPR too many
@@ -1119,7 +1134,7 @@ static int set_dropout(ActNormParams &p, float drop_p, uint64_t drop_seed, const
 extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p,
-                               uint64_t drop_seed, void *stream_) {
+                               uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
   if (!d_scale || !d_offset || !d_out) return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: null argument");
@@ -1130,6 +1145,12 @@ extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *l
   p.scale = d_scale; p.offset = d_offset; p.nb = nb; p.n = n; p.F = F; p.seg = seg;
   p.out_scale = out_scale; p.eps = 1e-9f; p.out = d_out; p.ldo = ldo;
   if ((rc = set_dropout(p, drop_p, drop_seed, "sl_act_norm_fwd")) != SG_OK) return rc;
+  if (d_out_dropped) {
+    if (!p.drop_thr) return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: a dropped output needs drop_p > 0");
+    if ((ldo_dropped & 3) || !aligned16(d_out_dropped))
+      return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: the dropped output must be 16-byte aligned, ld %% 4 == 0");
+    p.out2 = d_out_dropped; p.ldo2 = ldo_dropped;
+  }
   return act_norm_launch(p, false, (hipStream_t)stream_);
 }
 
@@ -1138,10 +1159,10 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                                float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
-                               void *stream_) {
+                               const float *d_dout_dropped, int64_t lddo_dropped, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act);
   if (rc) return rc;
-  if (!d_scale || !d_offset || !d_dout || !d_dscale || !d_doffset || !d_dZ)
+  if (!d_scale || !d_offset || (!d_dout && !d_dout_dropped) || !d_dscale || !d_doffset || !d_dZ)
     return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: null argument");
   hipStream_t st = (hipStream_t)stream_;
   if (n == 0) {
@@ -1162,5 +1183,11 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
   p.out_scale = out_scale; p.eps = 1e-9f; p.dout = d_dout; p.lddo = lddo;
   p.dscale = d_dscale; p.doffset = d_doffset; p.partial = d_partial;
   if ((rc = set_dropout(p, drop_p, drop_seed, "sl_act_norm_bwd")) != SG_OK) return rc;
+  if (d_dout_dropped) {
+    if (!p.drop_thr) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: a dropped-output gradient needs drop_p > 0");
+    if ((lddo_dropped & 3) || !aligned16(d_dout_dropped))
+      return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: the dropped-output gradient must be 16-byte aligned, ld %% 4 == 0");
+    p.dout2 = d_dout_dropped; p.lddo2 = lddo_dropped;
+  }
   return act_norm_launch(p, true, st);
 }

@@ -73,8 +73,12 @@ class shaDowLayer(nn.Module):
         # Dropout fusion (set per step by DeepGNN.forward while training): the layer BEFORE this one may
         # already have applied this layer's input dropout inside its act_norm kernel (input_pre_dropped),
         # and this layer may apply the NEXT layer's input dropout to its own output (out_dropout).
+        # out_dual: something else reads this layer's un-dropped output too (residue / pooling read-outs), so the
+        # kernel writes both; the dropped tensor waits in `dropped_out` for the model loop to hand it on.
         self.input_pre_dropped = False
         self.out_dropout = 0.0
+        self.out_dual = False
+        self.dropped_out = None
         if norm not in ('norm_feat', 'none'):
             raise NotImplementedError("only norm in {'norm_feat', 'none'} (the reference's pairnorm path is unfinished, layers.py:358)")
         self.norm = norm
@@ -96,19 +100,34 @@ class shaDowLayer(nn.Module):
     def _out_p(self):
         return self.out_dropout if self.training else 0.0
 
+    def _drop_kw(self):
+        p = self._out_p()
+        return {'out_dropout': p, 'dual': bool(self.out_dual and p > 0.0)}
+
+    def _emit(self, res):
+        """Fused kernels return out, or (out, dropout(out)) in dual mode: keep the second for the next layer."""
+        if isinstance(res, tuple):
+            self.dropped_out = res[1]
+            return res[0]
+        return res
+
+    def take_dropped_out(self):
+        d, self.dropped_out = self.dropped_out, None
+        return d
+
     def f_lin_act_norm(self, Xs, lins, acts):
         """sum_b norm_b(act_b(lin_b(X_b))): Linear (rocBLAS) + bias/act/norm/add (one HIP kernel),
         one autograd node with fused bias / scale / offset gradients."""
         if self.norm == 'norm_feat':
-            return ops.linear_act_norm(Xs, lins, acts, self.scale, self.offset, out_dropout=self._out_p())
+            return self._emit(ops.linear_act_norm(Xs, lins, acts, self.scale, self.offset, **self._drop_kw()))
         return self.f_act_norm([ops.linear(x, l) for x, l in zip(Xs, lins)], acts)
 
     def f_act_norm(self, Zs, acts, seg=None, out_scale=1.0):
         """sum_b norm_b(act_b(Z_b)) * out_scale -- the reference's act + f_norm + add
         sequence (layers.py:435, :476-483, :620-625) in one kernel."""
         if self.norm == 'norm_feat':
-            return ops.act_norm(Zs, acts, self.scale, self.offset, seg=seg, out_scale=out_scale,
-                                out_dropout=self._out_p())
+            return self._emit(ops.act_norm(Zs, acts, self.scale, self.offset, seg=seg, out_scale=out_scale,
+                                           **self._drop_kw()))
         out = None
         for z, a in zip(Zs, acts):
             h = _torch_act(a, z)
@@ -192,8 +211,8 @@ class GraphSAGE(shaDowLayer):
         feat_in = self.in_dropout(feat_in)
         if self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0:
             # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)
-            feat_out = ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
-                                      self.scale, self.offset, out_dropout=self._out_p())
+            feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
+                                                 self.scale, self.offset, **self._drop_kw()))
         else:
             feat_neigh = self.spmm(adj_norm, feat_in)
             feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],
@@ -322,8 +341,8 @@ class GAT(shaDowLayer):
                                            self.mulhead)
         if self.norm == 'norm_feat':
             # reference order: f_norm([neigh, self]) -> scale[0]=neigh, scale[1]=self (layers.py:620-622)
-            feat_out = ops.act_norm([feat_neigh, z_self], ['I', self.act_name], self.scale, self.offset,
-                                    seg=self.dim_slice, out_scale=0.5, out_dropout=self._out_p())
+            feat_out = self._emit(ops.act_norm([feat_neigh, z_self], ['I', self.act_name], self.scale, self.offset,
+                                               seg=self.dim_slice, out_scale=0.5, **self._drop_kw()))
         else:
             feat_out = (feat_neigh + _torch_act(self.act_name, z_self)) / 2
         return feat_out, adj_norm, True, 0.

@@ -131,6 +131,9 @@ class DeepGNN(nn.Module):
             for md in self.conv_layers[i]:
                 xmd = md(xmd, sizes_subg=size_subg_ens[i])
                 xjk.append(xmd[0])
+                dropped = md.take_dropped_out() if hasattr(md, 'take_dropped_out') else None
+                if dropped is not None:       # dual mode: the read-out keeps the plain output, the next layer
+                    xmd = (dropped,) + tuple(xmd[1:])     # gets the one its input dropout was applied to
             emb_subg_i = self.res_pool_layers[i](xjk, tgt, size_subg_ens[i])
             emb_subg_i = F.normalize(emb_subg_i, p=2, dim=1)
             emb_subg_ens.append(emb_subg_i)
@@ -140,12 +143,15 @@ class DeepGNN(nn.Module):
 
     def _plan_dropout_fusion(self, i):
         """Layer l+1's input dropout (shaDow/layers.py:430,471,601) is applied by layer l's own act_norm
-        kernel when nothing else reads layer l's un-dropped output: residue 'none' with centre pooling only
-        consumes the LAST layer's output (layers.py:159-163).  Same distribution, no [n, F] mask tensor, one
-        pass less per layer; evaluation and other read-out configurations keep nn.Dropout."""
+        kernel.  Residue 'none' with centre pooling only consumes the LAST layer's output (layers.py:159-163),
+        so the kernel writes the dropped tensor alone; every other read-out (residue 'concat' / 'max', the
+        mean / max / sort poolings) also reads the plain output of every layer, and the kernel then writes both
+        from the same pass (dual mode).  Same distribution, no [n, F] mask tensor, no separate dropout pass;
+        evaluation keeps nn.Dropout (identity)."""
         layers_i = list(self.conv_layers[i])
         rp = self.res_pool_layers[i]
-        fuse_ok = (self.training and self.fuse_dropout and rp.type_res == 'none' and rp.type_pool == 'center')
+        fuse_ok = self.training and self.fuse_dropout
+        dual = not (rp.type_res == 'none' and rp.type_pool == 'center')
         for l, md in enumerate(layers_i):
             if not hasattr(md, 'out_dropout'):
                 continue
@@ -153,6 +159,7 @@ class DeepGNN(nn.Module):
             fuse = (fuse_ok and nxt is not None and hasattr(nxt, 'input_pre_dropped') and nxt.dropout > 0
                     and md.can_fuse_out_dropout())
             md.out_dropout = nxt.dropout if fuse else 0.0
+            md.out_dual = bool(fuse and dual)
             if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):

@@ -346,25 +346,47 @@ def dropout_keep_mask(n: int, F: int, p: float, seed: int, device) -> torch.Tens
     return h >= thr
 
 
+def _is_dual(drop) -> bool:
+    return len(drop) > 2 and bool(drop[2])
+
+
 def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
+    """Returns out, or (out, out_dropped) when ``drop`` is (p, seed, True) -- the dual mode of sl_act_norm_fwd."""
     nb = len(Zs)
     n, F = Zs[0].shape
     out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
+    out2 = torch.empty_like(out) if _is_dual(drop) else None
     ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
     ac = (C.c_int * nb)(*codes)
     with _timed(f"act_norm_fwd_nb{nb}_F{F}", (nb + 1) * 4 * n * F, out.device):
         check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
                                           n, F, seg, out_scale, out.data_ptr(), out.stride(0), float(drop[0]),
-                                          int(drop[1]), _stream(out)))
-    return out
+                                          int(drop[1]), out2.data_ptr() if out2 is not None else None,
+                                          out2.stride(0) if out2 is not None else 0, _stream(out)))
+    return out if out2 is None else (out, out2)
 
 
-def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias, drop=(0.0, 0), dz_out=None):
-    """``dz_out``: optional preallocated dZ destinations (column slices of a wider buffer are fine)."""
+def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None):
+    """``douts``: the gradient(s) autograd handed over -- (dout,) or, in dual mode, (dout_plain, dout_dropped) with
+    None for an output nothing consumed.  ``dz_out``: optional preallocated dZ destinations (column slices of a
+    wider buffer are fine)."""
     nb = len(Zs)
     n, F = Zs[0].shape
     dev = sc.device
-    dout = _f32c(dout)
+    if not isinstance(douts, (tuple, list)):
+        douts = (douts,)
+    dout = _f32c(douts[0]) if douts[0] is not None else None
+    dout2 = None
+    if _is_dual(drop):
+        dout2 = _f32c(douts[1]) if douts[1] is not None else None
+        if dout2 is None:                   # only the plain output was used: no mask on the way back
+            drop = (0.0, 0)
+        elif dout2.stride(1) != 1:
+            dout2 = dout2.contiguous()
+    if dout is None and dout2 is None:
+        dout = torch.zeros(n, F, dtype=torch.float32, device=dev)
+    if dout is not None and dout.stride(1) != 1:
+        dout = dout.contiguous()
     dZs = [((dz_out[i] if dz_out is not None and dz_out[i] is not None else torch.empty_like(z)) if nd else None)
            for i, (z, nd) in enumerate(zip(Zs, need_dz))]
     dsc = torch.empty(nb, F, dtype=torch.float32, device=dev)
@@ -376,9 +398,12 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, dout, need_dz, want_dbias
     ac = (C.c_int * nb)(*codes)
     with _timed(f"act_norm_bwd_nb{nb}_F{F}", (2 * nb + 1) * 4 * n * F, dev):
         check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
-                                          n, F, seg, out_scale, dout.data_ptr(), dout.stride(0), _ptr_array(dZs), ldd,
+                                          n, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
+                                          dout.stride(0) if dout is not None else 0, _ptr_array(dZs), ldd,
                                           dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
-                                          partial.data_ptr(), float(drop[0]), int(drop[1]), _stream(dout)))
+                                          partial.data_ptr(), float(drop[0]), int(drop[1]),
+                                          dout2.data_ptr() if dout2 is not None else None,
+                                          dout2.stride(0) if dout2 is not None else 0, _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 
@@ -394,10 +419,11 @@ class _ActNorm(torch.autograd.Function):
         out = _an_fwd(Zs, [None] * nb, acts, sc, of, seg, out_scale, drop)
         ctx.save_for_backward(sc, of, *Zs)
         ctx.meta = (acts, seg, out_scale, scale.shape, offset.shape, drop)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *dout):
         sc, of, *Zs = ctx.saved_tensors
         acts, seg, out_scale, sshape, oshape, drop = ctx.meta
         nb = len(Zs)
@@ -507,10 +533,11 @@ class _LinearActNorm(torch.autograd.Function):
         out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale, drop)
         ctx.save_for_backward(sc, of, *Xs, *Ws, *Zs, *[b if b is not None else sc.new_empty(0) for b in bsc])
         ctx.meta = (acts, seg, out_scale, nb, scale.shape, offset.shape, [b is not None for b in bs], drop)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *dout):
         acts, seg, out_scale, nb, sshape, oshape, has_b, drop = ctx.meta
         sv = ctx.saved_tensors
         sc, of = sv[0], sv[1]
@@ -545,10 +572,11 @@ class _SageDense(torch.autograd.Function):
         ctx.save_for_backward(X, AX, Ws, Wn, Zs, Zn, sc, of, *[b if b is not None else sc.new_empty(0) for b in bsc])
         ctx.adj = adj
         ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)])
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *dout):
         X, AX, Ws, Wn, Zs, Zn, sc, of, b0, b1 = ctx.saved_tensors
         acts, drop, sshape, oshape, has_b = ctx.meta
         adj = ctx.adj
@@ -556,7 +584,7 @@ class _SageDense(torch.autograd.Function):
         ng = ctx.needs_input_grad
         biases = [b if hb else None for b, hb in zip((b0, b1), has_b)]
         # dZs lands in the left half of one [n, 2F] buffer; A^T dZn goes into the right half
-        buf = torch.empty(n, 2 * F, dtype=torch.float32, device=dout.device) if ng[0] else None
+        buf = torch.empty(n, 2 * F, dtype=torch.float32, device=Zs.device) if ng[0] else None
         dz_out = [buf[:, :F], None] if buf is not None else None
         (dZs, dZn), dsc, dof, dbi = _an_bwd([Zs, Zn], biases, acts, sc, of, F, 1.0, dout, [True, True], any(has_b),
                                             drop, dz_out)
@@ -575,28 +603,31 @@ class _SageDense(torch.autograd.Function):
 
 
 def sage_dense(X: torch.Tensor, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
-               offset: torch.Tensor, out_dropout: float = 0.0) -> torch.Tensor:
-    """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483)."""
+               offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False):
+    """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483).
+    ``dual`` (with out_dropout > 0): returns (out, dropout(out)) from one kernel pass."""
     if act not in ACT_CODE:
         raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
     F = lin_self.weight.shape[0]
     code = ACT_CODE[act]
     return _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
-                            (code, code), _drop_arg(out_dropout, F))
+                            (code, code), _drop_arg(out_dropout, F, None, dual))
 
 
-def _drop_arg(out_dropout: float, F: int, seg: Optional[int] = None):
-    """(p, seed) of the fused output dropout, or (0, 0)."""
+def _drop_arg(out_dropout: float, F: int, seg: Optional[int] = None, dual: bool = False):
+    """(p, seed[, True]) of the fused output dropout, or (0, 0)."""
     if out_dropout and out_dropout > 0.0:
         if not can_fuse_out_dropout(F, seg):
             raise ValueError(f"fused output dropout is not available for width {F}")
-        return (float(out_dropout), new_dropout_seed())
+        return (float(out_dropout), new_dropout_seed(), True) if dual else (float(out_dropout), new_dropout_seed())
+    if dual:
+        raise ValueError("dual output needs out_dropout > 0")
     return (0.0, 0)
 
 
 def linear_act_norm(Xs: List[torch.Tensor], lins: Sequence["torch.nn.Linear"], acts: Sequence[str],
                     scale: torch.Tensor, offset: torch.Tensor, seg: Optional[int] = None,
-                    out_scale: float = 1.0, out_dropout: float = 0.0) -> torch.Tensor:
+                    out_scale: float = 1.0, out_dropout: float = 0.0, dual: bool = False):
     """Fused dense tail of a layer: sum_b norm_b(act_b(lin_b(X_b))) * out_scale
     (nn.Linear + act + _f_norm_feat + add; shaDow/layers.py:434-435, :476-483, :393-394)."""
     codes = []
@@ -606,12 +637,12 @@ def linear_act_norm(Xs: List[torch.Tensor], lins: Sequence["torch.nn.Linear"], a
         codes.append(ACT_CODE[a])
     F = lins[0].weight.shape[0]
     nb = len(Xs)
-    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, _drop_arg(out_dropout, F, seg),
+    return _LinearActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), nb, _drop_arg(out_dropout, F, seg, dual),
                                 *Xs, *[l.weight for l in lins], *[l.bias for l in lins])
 
 
 def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, offset: torch.Tensor,
-             seg: Optional[int] = None, out_scale: float = 1.0, out_dropout: float = 0.0) -> torch.Tensor:
+             seg: Optional[int] = None, out_scale: float = 1.0, out_dropout: float = 0.0, dual: bool = False):
     """out_scale * sum_b norm_b(act_b(Z_b)) with the reference's 'norm_feat'
     (shaDowLayer._f_norm_feat, shaDow/layers.py:329-338).  scale/offset hold one
     row of F features per branch (any shape with nb*F elements)."""
@@ -622,7 +653,7 @@ def act_norm(Zs: List[torch.Tensor], acts: Sequence[str], scale: torch.Tensor, o
             raise NotImplementedError(f"activation {a!r} is not available in the fused HIP kernel "
                                       f"(supported: {sorted(ACT_CODE)})")
         codes.append(ACT_CODE[a])
-    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), _drop_arg(out_dropout, F, seg), *Zs)
+    return _ActNorm.apply(scale, offset, tuple(codes), int(seg or F), float(out_scale), _drop_arg(out_dropout, F, seg, dual), *Zs)
 
 
 # ----------------------------------------------------------------------------- readout / encodings

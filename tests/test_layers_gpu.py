@@ -461,6 +461,27 @@ def test_act_norm_fused_output_dropout(nb, F, seg):
     np.testing.assert_allclose(gs_d.cpu().numpy(), gs_r.cpu().numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(go_d.cpu().numpy(), go_r.cpu().numpy(), rtol=1e-4, atol=1e-3)
 
+    # dual mode: one pass writes the plain output AND the dropped one; the two incoming gradients add up
+    def run_dual(G1, G2):
+        zs = [z.clone().requires_grad_(True) for z in Zs]
+        sc = scale.clone().requires_grad_(True); of = offset.clone().requires_grad_(True)
+        o1, o2 = ops._ActNorm.apply(sc, of, acts, seg, 1.0, (p, seed, True), *zs)
+        loss = 0.0
+        if G1 is not None: loss = loss + (o1 * G1).sum()
+        if G2 is not None: loss = loss + (o2 * G2).sum()
+        loss.backward()
+        return o1.detach(), o2.detach(), [z.grad for z in zs], sc.grad, of.grad
+    G2 = torch.randn(n, F, device=DEV, generator=g)
+    for g1, g2 in ((G, G2), (None, G2), (G, None)):
+        o1, o2, gz_d, gs_d, go_d = run_dual(g1, g2)
+        assert torch.equal(o1, base) and torch.equal(o2, dropped)
+        tot = (g1 if g1 is not None else 0) + (g2 * keep / (1 - p) if g2 is not None else 0)
+        _, gz_r, gs_r, go_r = run((0.0, 0), tot)
+        for a_, b_ in zip(gz_d, gz_r):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(gs_d.cpu().numpy(), gs_r.cpu().numpy(), rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(go_d.cpu().numpy(), go_r.cpu().numpy(), rtol=1e-4, atol=2e-3)
+
 
 def test_model_dropout_fusion_plan_and_training_step():
     """DeepGNN folds layer l+1's input dropout into layer l's kernel only when nothing else reads layer l's
@@ -497,7 +518,41 @@ def test_model_dropout_fusion_plan_and_training_step():
     e1 = m.step(VALID, "running", OneBatchSubgraph(b.adj_ens, [b.feat_ens[0].clone()], b.label, b.size_subg_ens, b.target_ens, [{}]))
     e2 = m.step(VALID, "running", OneBatchSubgraph(b.adj_ens, [b.feat_ens[0].clone()], b.label, b.size_subg_ens, b.target_ens, [{}]))
     assert torch.equal(e1["preds"], e2["preds"])
-    # a read-out that consumes every layer's output keeps nn.Dropout
-    m2 = make("max", "mean")
-    m2.step(TRAIN, "running", batch())
-    assert all(l.out_dropout == 0.0 and not l.input_pre_dropped for l in m2.conv_layers[0])
+    assert not any(l.out_dual for l in L)
+    # a read-out that consumes every layer's plain output: the kernels write both tensors (dual mode)
+    for residue, pooling in (("max", "mean"), ("concat", "center"), ("none", "max")):
+        m2 = make(residue, pooling)
+        losses = [float(m2.step(TRAIN, "running", batch())["loss"]) for _ in range(2)]
+        assert all(np.isfinite(losses))
+        L2 = list(m2.conv_layers[0])
+        assert [l.out_dropout for l in L2] == [0.3, 0.3, 0.0] and [l.out_dual for l in L2] == [True, True, False]
+        assert [l.input_pre_dropped for l in L2] == [False, True, True] and all(l.dropped_out is None for l in L2)
+        assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m2.parameters())
+    # plumbing: with residue none + centre pooling the read-out ignores the plain copies, so forcing the dual
+    # mode must reproduce the single-output run exactly (same seeds -> same masks, same loss, same gradients)
+    def one_step(force_dual):
+        torch.manual_seed(7)
+        mm = make("none", "center")
+        if force_dual:
+            plan = mm._plan_dropout_fusion
+            def plan_dual(i):
+                plan(i)
+                for l in mm.conv_layers[i]:
+                    l.out_dual = l.out_dropout > 0
+            mm._plan_dropout_fusion = plan_dual
+        torch.manual_seed(11)
+        bt = batch()
+        torch.manual_seed(13)
+        mm.train()
+        preds, _ = mm(TRAIN, dropedge=0.0, **bt.to_dict({"feat_ens", "adj_ens", "target_ens", "size_subg_ens", "feat_aug_ens"}))
+        preds.square().sum().backward()
+        return preds.detach(), [q.grad.clone() for q in mm.parameters() if q.grad is not None]
+    p1, g1 = one_step(False)
+    p2, g2 = one_step(True)
+    assert torch.equal(p1, p2) and len(g1) == len(g2)
+    for a_, b_ in zip(g1, g2):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # switching the fusion off restores nn.Dropout everywhere
+    m3 = make("max", "mean"); m3.fuse_dropout = False
+    m3.step(TRAIN, "running", batch())
+    assert all(l.out_dropout == 0.0 and not l.input_pre_dropped for l in m3.conv_layers[0])
