@@ -124,6 +124,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="roots per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--prune-tail", action="store_true",
+                    help="run the WHOLE benchmark with the exact target-only tail (shadow_gnn_amd/tail.py); without the "
+                         "flag the timed region computes every row of every layer like the reference, and the pruned "
+                         "variant is timed separately afterwards and reported as 'target_only_tail'")
     args = ap.parse_args()
 
     from shadow_gnn_amd import dist as sdist
@@ -146,7 +150,8 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(1)
     feat_full = torch.randn(N, F0, generator=g, device=dev)
     label_full = torch.randint(0, C, (N,), generator=g, device=dev)
-    need = B * world * (K + W + 2)
+    TAIL_STEPS, TAIL_WARMUP = 10, 3      # extra steps for the separately reported target-only-tail variant
+    need = B * world * (K + W + 2 + TAIL_STEPS + TAIL_WARMUP)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy()
     roots_all = np.resize(perm, need).astype(np.int64)
     aug = tuple(wl["aug"])
@@ -175,6 +180,9 @@ def main():
     sdist.broadcast_parameters(model)
     model.grad_sync = sdist.GradSync(model.parameters(), world_size=world)
     model.optimizer = torch.optim.Adam(model.parameters(), lr=wl["lr"])
+    model.prune_tail = bool(args.prune_tail)
+    if args.prune_tail and model._tail_prunable(0):
+        mb.tail_plan_layers = wl["layers"]
 
     def barrier():
         if world > 1:
@@ -211,6 +219,34 @@ def main():
         tmax = stats[0:1].clone(); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         tot = stats[1:].clone(); torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
         dt, nodes, edges = float(tmax[0]), float(tot[0]), float(tot[1])
+
+    # ---- the same training step with the exact target-only tail (dead rows of the last layers not computed);
+    #      reported separately, never part of `value`
+    tail_info = None
+    if not args.prune_tail and model._tail_prunable(0):
+        model.prune_tail = True
+        mb.tail_plan_layers = wl["layers"]
+        for _ in range(TAIL_WARMUP):
+            one_step()
+        barrier()
+        tt0 = time.perf_counter()
+        tn = 0.0
+        for _ in range(TAIL_STEPS):
+            c, _r = one_step()
+            tn += c["n_tot"]
+        barrier()
+        tdt = time.perf_counter() - tt0
+        model.prune_tail = False
+        mb.tail_plan_layers = 0
+        tstats = torch.tensor([tdt, tn], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmx = tstats[0:1].clone(); torch.distributed.all_reduce(tmx, op=torch.distributed.ReduceOp.MAX)
+            tsm = tstats[1:].clone(); torch.distributed.all_reduce(tsm, op=torch.distributed.ReduceOp.SUM)
+            tdt, tn = float(tmx[0]), float(tsm[0])
+        tail_info = dict(steps=TAIL_STEPS, ms_per_step=round(tdt / TAIL_STEPS * 1e3, 4),
+                         train_steps_per_sec=round(TAIL_STEPS / tdt, 3), sampled_nodes_per_sec=round(tn / tdt, 1),
+                         note="exact dead-row elimination (residue none + centre pooling): identical predictions and "
+                              "gradients, tests/test_tail_gpu.py; NOT included in `value`")
 
     # ---- sampler-only rate (same kernels, no model), a few calls
     scfg = mb.sampler_cfg
@@ -289,11 +325,12 @@ def main():
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "train_steps_per_sec": round(K / dt, 3),
+        "target_only_tail": tail_info,
         "sampler_only_nodes_per_sec": round(sampler_rate, 1),
         "config": {"workload": f"{args.workload}: {wl['shape']}-shape synthetic CSR (N={N}, nnz={int(indices.numel())}, "
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
                                f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",
-                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "prune_tail": bool(args.prune_tail),
                    "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4),
                    "ppr_preproc": ppr_info},
         "roofline": roofline, "roofline_hbm": roofline_hbm,

@@ -174,18 +174,27 @@ class GCN(shaDowLayer):
         super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
         self.f_lin = nn.Linear(dim_in, dim_out, bias=True)
 
+    def norm_adj(self, adj, is_normed, dropedge, device):
+        if not is_normed and adj is not None:
+            # self-edges are already added by the sampler (shaDow/utils.py:126-131)
+            return ops.adj_norm_sym(_as_device_csr(adj, device), dropedge=dropedge)
+        assert adj is None or isinstance(adj, ops.NormAdj)
+        return adj
+
     def forward(self, inputs, sizes_subg):
         feat_in, adj, is_normed, dropedge = inputs
         feat_in = self.in_dropout(feat_in)
-        if not is_normed and adj is not None:
-            # self-edges are already added by the sampler (shaDow/utils.py:126-131)
-            adj_norm = ops.adj_norm_sym(_as_device_csr(adj, feat_in.device), dropedge=dropedge)
-        else:
-            assert adj is None or isinstance(adj, ops.NormAdj)
-            adj_norm = adj
+        adj_norm = self.norm_adj(adj, is_normed, dropedge, feat_in.device)
         feat_aggr = self.spmm(adj_norm, feat_in)
         feat_out = self.f_lin_act_norm([feat_aggr], [self.f_lin], [self.act_name])
         return feat_out, adj_norm, True, 0.
+
+    def forward_rows(self, feat_in, adj_norm, level):
+        """The layer on the output rows of ``level`` only (tail.py): same arithmetic per row."""
+        from . import tail
+        feat_in = self.in_dropout(feat_in)
+        _, feat_aggr = tail.rect_gather_spmm(feat_in, level, adj_norm)
+        return self.f_lin_act_norm([feat_aggr], [self.f_lin], [self.act_name])
 
     def complexity(self, dims_x, dims_adj):
         ops_ = dims_adj.num_edges * dims_x.num_feats + dims_x.num_nodes * int(np.prod(self.f_lin.weight.shape))
@@ -201,13 +210,23 @@ class GraphSAGE(shaDowLayer):
         self.f_lin_self = nn.Linear(dim_in, dim_out)
         self.f_lin_neigh = nn.Linear(dim_in, dim_out)
 
+    def norm_adj(self, adj, is_normed, dropedge, device):
+        if not is_normed and adj is not None:
+            return ops.adj_norm_rw(_as_device_csr(adj, device), dropedge=dropedge)
+        assert adj is None or isinstance(adj, ops.NormAdj)
+        return adj
+
+    def forward_rows(self, feat_in, adj_norm, level):
+        """The layer on the output rows of ``level`` only (tail.py): same arithmetic per row."""
+        from . import tail
+        feat_in = self.in_dropout(feat_in)
+        feat_self, feat_neigh = tail.rect_gather_spmm(feat_in, level, adj_norm)
+        return self.f_lin_act_norm([feat_self, feat_neigh], [self.f_lin_self, self.f_lin_neigh],
+                                   [self.act_name, self.act_name])
+
     def forward(self, inputs, sizes_subg):
         feat_in, adj, is_normed, dropedge = inputs
-        if not is_normed and adj is not None:
-            adj_norm = ops.adj_norm_rw(_as_device_csr(adj, feat_in.device), dropedge=dropedge)
-        else:
-            assert adj is None or isinstance(adj, ops.NormAdj)
-            adj_norm = adj
+        adj_norm = self.norm_adj(adj, is_normed, dropedge, feat_in.device)
         feat_in = self.in_dropout(feat_in)
         if self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0:
             # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)

@@ -34,6 +34,7 @@ class OneBatchSubgraph:
     target_ens: List[Any]
     feat_aug_ens: Optional[List[Dict[str, Any]]]
     idx_raw: Optional[List[Any]] = None
+    tail_ens: Optional[List[Any]] = None      # per-branch target-only-tail plan (tail.py), built while prefetching
 
     @property
     def num_ens(self):
@@ -112,6 +113,8 @@ class MinibatchShallowExtractor:
         self.batch_num = -1
         self.dim_1hot_hop, self.dim_1hot_ppr, self.dim_1hot_drnl = 5 + 2, 1, 25 + 1   # minibatch.py:246-248
         self.prefetch = prefetch
+        # > 0: every batch carries a target-only-tail plan for a model of that many layers (DeepGNN.prune_tail)
+        self.tail_plan_layers = 0
         self._side = torch.cuda.Stream(device=self.device) if prefetch else None
         self._inflight = {}
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
@@ -182,6 +185,29 @@ class MinibatchShallowExtractor:
             self._inflight.pop(mode, None)
 
     # ------------------------------------------------------------- batching
+    def _tail_plan(self, subgs, adj, targets):
+        """Target-only-tail plan of this batch (tail.py) on the prefetch stream: its host syncs wait for the
+        side stream only, the training stream keeps running the previous step.
+        Stream-ordered allocation: without this, blocks of the side-stream pool are only reused after _launch's
+        side.wait_stream(main), i.e. after every consumer on the training stream.  The plan allocates on the
+        side stream BEFORE that point, so the sampler outputs (and the plan) are recorded on the training
+        stream: the allocator then defers their reuse until the training stream is done with them."""
+        from . import tail
+        if self._side is None:
+            return tail.build_tail_plan(adj, targets, self.tail_plan_layers, eager_transpose=True)
+        main = torch.cuda.current_stream(self.device)
+        for t in (subgs.node, subgs.indptr, subgs.indices, subgs.edge_id, subgs.target, subgs.subg_node_off,
+                  subgs.subg_edge_off, subgs.ppr, subgs.hop, subgs.drnl):
+            if t is not None and t.is_cuda:
+                t.record_stream(main)
+        with torch.cuda.stream(self._side):
+            levels = tail.build_tail_plan(adj, targets, self.tail_plan_layers, eager_transpose=True)
+        main.wait_stream(self._side)
+        for lv in levels:
+            for t in lv.tensors():
+                t.record_stream(main)
+        return levels
+
     def _launch(self, mode):
         hs = self.graph_sampler[mode]
         reuse = self.record_subgraphs.get(mode) == "reuse"
@@ -228,6 +254,7 @@ class MinibatchShallowExtractor:
     def one_batch(self, mode=TRAIN, ret_raw_idx=False) -> OneBatchSubgraph:
         remaining = self.entity_epoch[mode].shape[0] - self.idx_entity_evaluated[mode]
         batch_size_ = min(remaining, self.batch_size[mode])
+        launch_next = False
         if mode not in self._inflight:
             self._launch(mode)
         subgs = self._collect(mode)
@@ -241,9 +268,12 @@ class MinibatchShallowExtractor:
             if self.record_subgraphs.get(mode) != "reuse":
                 assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
         elif self.prefetch:
-            self._launch(mode)        # overlap the next sampler call with this batch's training
+            launch_next = True
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
                             subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
+        tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
+        if launch_next:
+            self._launch(mode)        # overlap the next sampler call with this batch's training
         feat = ops.gather_rows(self.feat_full, subgs.node)           # minibatch.py:469
         label = self.label_epoch[mode][i0:i0 + batch_size_]
         feat_aug = {}
@@ -257,6 +287,8 @@ class MinibatchShallowExtractor:
             feat_aug["drnls"] = ops.OneHotCodes(ops.encode_codes("drnls", subgs.drnl, self.dim_1hot_drnl), self.dim_1hot_drnl)
         size_subg = subgs.size_subg.unsqueeze(0)
         ret = OneBatchSubgraph([adj], [feat], label, size_subg, [subgs.target], [feat_aug])
+        if tail_plan is not None:
+            ret.tail_ens = [tail_plan]
         ret.device_batch = subgs
         if ret_raw_idx:
             ret.idx_raw = [subgs.node]

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import layers, ops
+from . import layers, ops, tail
 from .minibatch import TRAIN, OneBatchSubgraph
 
 
@@ -87,6 +87,9 @@ class DeepGNN(nn.Module):
         self.sigmoid_loss = arch_gnn.get("loss", "softmax") == "sigmoid"
         self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr)
         self.fuse_dropout = True       # fold each layer's input dropout into the producing kernel where possible
+        # Exact dead-row elimination for residue 'none' + centre pooling (tail.py): the last layers are computed
+        # only on the rows the roots depend on.  Off by default: the reference computes every row.
+        self.prune_tail = False
         self.num_ensemble = num_ensemble
         self.grad_sync = grad_sync
 
@@ -98,7 +101,7 @@ class DeepGNN(nn.Module):
             labels = torch.max(labels, dim=1)[1]
         return torch.nn.CrossEntropyLoss()(preds, labels)
 
-    def forward(self, mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge):
+    def forward(self, mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge, tail_ens=None):
         num_ensemble = len(feat_ens)
         emb_subg_ens = []
         for i in range(num_ensemble):
@@ -126,20 +129,46 @@ class DeepGNN(nn.Module):
                     else:
                         feat_ens[i] = torch.cat([feat_ens[i], feat_aug_emb], dim=1)
             xjk = []
-            xmd = (feat_ens[i], adj_ens[i], False, dropedge)
+            convs = list(self.conv_layers[i])
+            adj_i = adj_ens[i]
+            levels = []
+            if self.prune_tail and self._tail_prunable(i):
+                adj_i = layers._as_device_csr(adj_i, feat_ens[i].device)
+                if tail_ens is not None and tail_ens[i] is not None:
+                    levels = tail_ens[i]             # built by the minibatch on its prefetch stream
+                    assert len(levels) <= len(convs)
+                else:
+                    levels = tail.build_tail_plan(adj_i, tgt, len(convs))
+            num_full = len(convs) - len(levels)
+            xmd = (feat_ens[i], adj_i, False, dropedge)
             self._plan_dropout_fusion(i)
-            for md in self.conv_layers[i]:
+            for md in convs[:num_full]:
                 xmd = md(xmd, sizes_subg=size_subg_ens[i])
                 xjk.append(xmd[0])
                 dropped = md.take_dropped_out() if hasattr(md, 'take_dropped_out') else None
                 if dropped is not None:       # dual mode: the read-out keeps the plain output, the next layer
                     xmd = (dropped,) + tuple(xmd[1:])     # gets the one its input dropout was applied to
-            emb_subg_i = self.res_pool_layers[i](xjk, tgt, size_subg_ens[i])
+            if levels:
+                # target-only tail: each remaining layer on the rows the roots depend on; the last one yields the
+                # root rows in target order, which is all that residue 'none' + centre pooling reads
+                x, adj_norm = xmd[0], xmd[1]
+                if num_full == 0:
+                    adj_norm = convs[0].norm_adj(adj_i, False, dropedge, x.device)
+                for md, level in zip(convs[num_full:], levels):
+                    x = md.forward_rows(x, adj_norm, level)
+                emb_subg_i = x
+            else:
+                emb_subg_i = self.res_pool_layers[i](xjk, tgt, size_subg_ens[i])
             emb_subg_i = F.normalize(emb_subg_i, p=2, dim=1)
             emb_subg_ens.append(emb_subg_i)
         emb_ensemble = self.ensembler(emb_subg_ens)
         pred_subg = self.classifier(emb_ensemble)
         return pred_subg, emb_subg_ens
+
+    def _tail_prunable(self, i):
+        rp = self.res_pool_layers[i]
+        return (rp.type_res == 'none' and rp.type_pool == 'center' and self.prediction_task == 'node'
+                and all(hasattr(md, 'forward_rows') for md in self.conv_layers[i]))
 
     def _plan_dropout_fusion(self, i):
         """Layer l+1's input dropout (shaDow/layers.py:430,471,601) is applied by layer l's own act_norm
@@ -174,6 +203,7 @@ class DeepGNN(nn.Module):
             {"feat_ens", "adj_ens", "target_ens", "size_subg_ens", "feat_aug_ens"})
         # the step consumes the batch record (features are augmented in place in the reference)
         args_forward_common["feat_ens"] = list(args_forward_common["feat_ens"])
+        args_forward_common["tail_ens"] = getattr(batch_data, "tail_ens", None)
         label_targets = batch_data.label
         if len(label_targets.shape) == 1 and self.num_classes > 1:
             label_targets = F.one_hot(label_targets.to(torch.int64), num_classes=self.num_classes)

@@ -1,0 +1,154 @@
+"""Target-only tail of the layer stack (an exact optimisation, off by default).
+
+With residue 'none' and 'center' pooling on a node task the model reads ONE row per subgraph from the last
+layer: the root's (shaDow/layers.py:159-163 -- ``feats_in_l[-1][idx_targets]``).  Row i of a GCN / GraphSAGE
+layer depends on row i and on the in-subgraph neighbours of i of the layer below, nothing else (the feature
+normalisation is per row, layers.py:329-338).  So the last layer is needed on the roots only, the layer below
+on roots + their neighbours, ... until the needed set covers most of the batch (k-hop depth-2 subgraphs: after
+two layers).  The reference computes every row of every layer; the rows dropped here never reach the loss, so
+predictions and all parameter gradients are unchanged -- tests/test_tail_gpu.py checks both against the full
+stack.
+
+A pruned layer is a *rectangular* layer: r output rows, m_in input rows,
+
+    out[k] = norm(act(lin_self(X[self_idx[k]]))) + norm(act(lin_neigh(sum_j A[rows[k], j] X[j])))      (SAGE)
+
+on the rows of the batch adjacency selected by ``rows`` (same normalisation scales and drop-edge mask as the
+full matrix: the scales are gathered, not recomputed).  The SpMM kernels are the ordinary CSR ones
+(sl_spmm_csr_f32 takes any row count); the transposed matrix for the backward pass is built with a stable sort.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+class RectLevel:
+    """One pruned layer: CSR of the selected rows with column ids in the numbering of its input."""
+
+    def __init__(self, indptr, indices, edge_row, edge_pos, rows_full, in_ids_full, self_idx, m_in):
+        self.indptr = indptr            # int32 [r + 1]
+        self.indices = indices          # int32 [E], positions in the input tensor
+        self.edge_row = edge_row        # int64 [E], local row of every edge
+        self.edge_pos = edge_pos        # int64 [E], position of every edge in the full batch CSR
+        self.rows_full = rows_full      # int64 [r], batch-level ids of the output rows
+        self.in_ids_full = in_ids_full  # int64 [m_in] batch-level ids of the input rows, None = the whole batch
+        self.self_idx = self_idx        # int64 [r], position of every output row in the input tensor
+        self.m_in = int(m_in)
+        self.r = int(rows_full.numel())
+        self._t = None
+
+    @property
+    def transposed(self):
+        """(t_indptr, t_indices, t_perm) of the m_in x r transpose (stable sort by column)."""
+        if self._t is None:
+            cols = self.indices.long()
+            perm = torch.argsort(cols, stable=True)
+            t_indices = self.edge_row[perm].to(torch.int32)
+            t_indptr = torch.zeros(self.m_in + 1, dtype=torch.int64, device=cols.device)
+            if cols.numel():
+                torch.cumsum(torch.bincount(cols, minlength=self.m_in), 0, out=t_indptr[1:])
+            self._t = (t_indptr.to(torch.int32), t_indices, perm.to(torch.int32))
+        return self._t
+
+    def tensors(self):
+        ts = [self.indptr, self.indices, self.edge_row, self.edge_pos, self.rows_full, self.self_idx]
+        if self.in_ids_full is not None:
+            ts.append(self.in_ids_full)
+        if self._t is not None:
+            ts.extend(self._t)
+        return ts
+
+    def norm(self, full: "ops.NormAdj"):
+        """(edge_w, row_scale, col_scale) of this level, gathered from the normalised full adjacency."""
+        ew = full.edge_w[self.edge_pos] if full.edge_w is not None else None
+        rs = full.row_scale[self.rows_full] if full.row_scale is not None else None
+        cs = full.col_scale
+        if cs is not None and self.in_ids_full is not None:
+            cs = cs[self.in_ids_full]
+        return ew, rs, cs
+
+
+def _select_rows(indptr: torch.Tensor, rows: torch.Tensor):
+    """CSR row selection: local indptr (int64), local row of every edge, position of every edge in the source."""
+    dev = indptr.device
+    start = indptr[rows].long()
+    lens = indptr[rows + 1].long() - start
+    ip = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=ip[1:])
+    E = int(ip[-1])                                    # (host sync: the edge count sizes the arrays below)
+    er = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), lens, output_size=E)
+    pos = start[er] + (torch.arange(E, device=dev) - ip[er])
+    return ip, er, pos
+
+
+def build_tail_plan(csr: "ops.DeviceCSR", targets: torch.Tensor, num_layers: int, frac: float = 0.5,
+                    eager_transpose: bool = False) -> List[RectLevel]:
+    """Levels for the LAST len(result) layers, bottom (first to run) first.  Empty: nothing worth pruning.
+    A level is kept only while its output rows are at most ``frac`` of the batch; the lowest level always reads
+    the full-size tensor of the layer below (or the input features).
+    Two host syncs per level (array sizes): MinibatchShallowExtractor builds the plan on its prefetch stream,
+    next to the sampler's own sync, so the training stream never waits for it."""
+    n = csr.n
+    dev = csr.device
+    rows = torch.as_tensor(targets, device=dev).long().reshape(-1)
+    levels: List[RectLevel] = []
+    for layer in reversed(range(num_layers)):
+        if rows.numel() > frac * n:
+            break
+        ip, er, pos = _select_rows(csr.indptr, rows)
+        cols = csr.indices[pos].long()
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        mask[rows] = True
+        mask[cols] = True
+        cnt = int(mask.sum())                          # (host sync)
+        if layer == 0 or cnt > frac * n:               # input = the whole batch, batch numbering
+            levels.append(RectLevel(ip.to(torch.int32), cols.to(torch.int32), er, pos, rows, None, rows, n))
+            break
+        in_ids = mask.nonzero().reshape(-1)
+        newid = torch.cumsum(mask, 0) - 1
+        levels.append(RectLevel(ip.to(torch.int32), newid[cols].to(torch.int32), er, pos, rows, in_ids, newid[rows], cnt))
+        rows = in_ids
+    levels.reverse()
+    if eager_transpose:
+        for lv in levels:
+            lv.transposed
+    return levels
+
+
+class _RectGatherSpMM(torch.autograd.Function):
+    """(X[self_idx], A_rect X) with one dense input gradient: dX = A_rect^T dAX, then += dXs at self_idx."""
+
+    @staticmethod
+    def forward(ctx, X, level: RectLevel, ew, rs, cs):
+        X = X.contiguous().float()
+        ctx.level, ctx.norm = level, (ew, rs, cs)
+        ctx.set_materialize_grads(False)       # (GCN never uses the self rows: their gradient stays None)
+        ctx.m_in = X.shape[0]
+        assert X.shape[0] == level.m_in, (X.shape, level.m_in)
+        AX = ops._spmm_raw(level.indptr, level.indices, ew, None, rs, cs, X, level.r)
+        Xs = X.index_select(0, level.self_idx)
+        return Xs, AX
+
+    @staticmethod
+    def backward(ctx, dXs, dAX):
+        level = ctx.level
+        ew, rs, cs = ctx.norm
+        ti, tx, tp = level.transposed
+        if dAX is None and dXs is None:
+            return None, None, None, None, None
+        if dAX is None:
+            dX = torch.zeros(ctx.m_in, dXs.shape[1], dtype=torch.float32, device=dXs.device)
+        else:
+            # (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
+            dX = ops._spmm_raw(ti, tx, ew, tp if ew is not None else None, cs, rs, dAX.contiguous().float(), level.m_in)
+        if dXs is not None:
+            dX.index_add_(0, level.self_idx, dXs.float())
+        return dX, None, None, None, None
+
+
+def rect_gather_spmm(X: torch.Tensor, level: RectLevel, full_adj: "ops.NormAdj"):
+    """Returns (X[level.self_idx], A[level rows, :] @ X) under the normalisation of ``full_adj``."""
+    ew, rs, cs = level.norm(full_adj)
+    return _RectGatherSpMM.apply(X, level, ew, rs, cs)
