@@ -1,0 +1,23 @@
+"""Sampler kernel time vs roots per call (products shape, k-hop depth 2 budget 20): how much of the per-call
+time is per-subgraph latency (1024 subgraphs = exactly two rounds of 512 resident workgroups) and how much is
+throughput."""
+import sys, numpy as np, torch
+from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+from shadow_gnn_amd.synthetic import SHAPES, MAX_DEGREE, make_graph_torch
+dev = torch.device("cuda:0")
+N, nnz, F, C = SHAPES["products"]
+indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE["products"])
+hs = HipSampler(indptr, indices, device=dev, seed=3)
+roots = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy().astype(np.uint32)
+hs.shuffle_targets(roots)
+hs.set_profiling(True)
+cfg = SamplerConfig(method="khop", depth=2, budget=20)
+for B in (256, 512, 768, 1024, 1536, 2048, 4096, 8192):
+    ms, nn, slots = [], 0, 0
+    for it in range(6):
+        b = hs.sample(cfg, B)
+        if it >= 2:
+            ms.append(b.counts["sample_kernel_ms"]); nn += b.num_nodes; slots += b.counts["slots_scanned"]
+    m = float(np.mean(ms))
+    print(f"B={B:5d}: sample kernel {m:.3f} ms  {nn / 4 / m / 1e3:.0f} M nodes/s  neighbour ids scanned {slots / 4 * 4 / m / 1e6:.0f} GB/s  "
+          f"({m / B * 1e3:.3f} us per subgraph)")
