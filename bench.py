@@ -6,7 +6,7 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input:
   sample B subgraphs (HIP sampler) -> gather features (HIP) -> L-layer SAGE forward
-  (HIP SpMM + fused act/norm, rocBLAS GEMMs) -> CE loss -> backward -> [RCCL gradient
+  (HIP SpMM + fused act/norm, split-bf16 MFMA GEMMs) -> CE loss -> backward -> [RCCL gradient
   all-reduce] -> clip -> Adam.
 The full graph CSR, the feature matrix and the root list are resident in HBM
 before the timed region.  Batches are sharded over the ranks (weak scaling: B per
@@ -16,10 +16,15 @@ all-reduce.
 Rank 0 prints ONE JSON line.  metric/unit follow BASELINE.json:
   value               sampled nodes/s through the full train step, summed over ranks
   train_steps_per_sec optimizer steps/s
-  roofline            the dominant hand-written (HBM-bound) kernel, timed live with HIP
-                      events on its launch stream: algorithmic bytes / duration vs 8 TB/s
+  roofline            the hand-written kernel with the largest total time, timed live with HIP
+                      events on its launch stream (algorithmic flops or bytes / duration against the
+                      MFMA or HBM peak); roofline_hbm: the dominant HBM-bound kernel, always reported
   cpu_baseline        the reference's own C++/OpenMP sampler (oracle/_ref) timed on this
                       box's host cores on a bounded sample of the same roots
+  cpu_baseline_train_step  the other half of the reference's CPU path: the training step in CPU
+                      PyTorch (oracle/cpu_train_step.py) on 1/8 of one benchmark batch, scaled to steps/s
+  target_only_tail    the same step with the opt-in exact dead-row elimination (shadow_gnn_amd/tail.py),
+                      10 extra steps after the timed region; never part of `value`
 """
 import argparse
 import json
@@ -189,9 +194,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    last = {}
+
     def one_step():
         batch = mb.one_batch(TRAIN)
         ret = model.step(TRAIN, "running", batch)
+        last["batch"] = batch
         return batch.device_batch.counts, ret
 
     for _ in range(W):
@@ -320,12 +328,47 @@ def main():
     if not args.no_cpu_baseline and world == 1 and wl["sampler"]["method"] == "khop":
         ip = indptr.cpu().numpy().view(np.uint32); ix = indices.cpu().numpy().view(np.uint32)
         cb = cpu_baseline(ip, ix, roots_all, wl["sampler"], seed=3)
+    cb_step = None
+    if (not args.no_cpu_baseline and world == 1 and wl["aggr"] in ("sage", "gcn") and model._tail_prunable(0)
+            and not wl["aug"]):
+        # the other half of the reference's CPU path: the training step in CPU PyTorch (torch.sparse.mm + nn.Linear),
+        # one batch of the same shape on the host cores
+        from oracle import cpu_train_step as cts
+        bt = last["batch"]
+        cores = os.cpu_count() or 1
+        sizes = bt.size_subg_ens[0].cpu().numpy().astype(np.int64)
+        ip_all = bt.adj_ens[0].indptr.cpu().numpy().astype(np.int64)
+        ix_all = bt.adj_ens[0].indices.cpu().numpy().astype(np.int64)
+        feat_all, tgt_all, lab_all = bt.feat_ens[0].detach().cpu(), bt.target_ens[0].cpu(), bt.label.cpu()
+
+        def run(P_, threads, budget):
+            # the first P_ subgraphs of the batch (block-diagonal: a prefix of the rows and of the edges)
+            n_ = int(sizes[:P_].sum()); e_ = int(ip_all[n_])
+            return cts.time_train_steps(ip_all[:n_ + 1], ix_all[:e_], feat_all[:n_], tgt_all[:P_], lab_all[:P_], wl["aggr"],
+                                        wl["layers"], wl["dim"], C, wl["act"], wl["dropout"], wl["dropedge"], wl["lr"],
+                                        threads=threads, budget_s=budget, max_steps=2)
+        # torch's CPU kernels do not always get faster with every hardware thread: pick the best of a few counts
+        # on a small slice, then time 1/8 of the batch with it and scale to whole steps
+        P_cal, P_run = max(1, B // 64), max(1, B // 8)
+        best_t, best_th = None, cores
+        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 32)}, reverse=True):
+            nst, tsec, _w = run(P_cal, th, 3.0)
+            if best_t is None or tsec / nst < best_t:
+                best_t, best_th = tsec / nst, th
+        nst, tsec, warm = run(P_run, best_th, 25.0)
+        frac = P_run / B
+        cb_step = dict(value=round(nst / tsec * frac, 5), unit="train-steps/s", cores=best_th, kind="port",
+                       sample=f"oracle/cpu_train_step.py (CPU PyTorch fp32: torch.sparse.mm + nn.Linear + norm, Adam), "
+                              f"{nst} step(s) on the first {P_run} of the {B} subgraphs of one benchmark batch "
+                              f"({int(sizes[:P_run].sum())} nodes), scaled by {frac:g} to whole steps; model only (no sampler); "
+                              f"{best_th} of {cores} threads (fastest of a 4-way sweep on {P_cal} subgraphs)")
     line = {
         "metric": "sampled-nodes/sec", "value": round(nodes / dt, 1), "unit": "sampled-nodes/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "train_steps_per_sec": round(K / dt, 3),
         "target_only_tail": tail_info,
+        "cpu_baseline_train_step": cb_step,
         "sampler_only_nodes_per_sec": round(sampler_rate, 1),
         "config": {"workload": f"{args.workload}: {wl['shape']}-shape synthetic CSR (N={N}, nnz={int(indices.numel())}, "
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
