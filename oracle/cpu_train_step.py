@@ -2,10 +2,10 @@
 stack, residue 'none', centre pooling, node task) at full batch size.
 
 TEST INFRASTRUCTURE ONLY -- never imported by the product path; bench.py's ``cpu_baseline`` leg times it on
-the GPU box's host cores ("the reference's ... CPU PyTorch path", BASELINE.json north_star).  parity unpinned:
-it is a timing stand-in, not a checker -- the layer arithmetic it repeats is pinned in oracle/layers_oracle.py
-(dense adjacency, golden vectors); this file only swaps the dense matrix for torch.sparse so that a
-300 k-node batch fits.
+the GPU box's host cores ("the reference's ... CPU PyTorch path", BASELINE.json north_star).  It is a timing
+stand-in, not a checker; its forward pass is pinned against oracle/layers_oracle.py (dense adjacency, itself
+pinned on the reference's golden vectors) in tests/test_layers_oracle_golden.py -- this file only swaps the
+dense matrix for torch.sparse so that a 300 k-node batch fits.
 
 What it follows (line numbers: /root/reference):
   adjacency   D^-1 A / D^-1/2 A D^-1/2 as a torch sparse COO tensor, drop-edge on the values

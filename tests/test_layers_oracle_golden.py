@@ -2,6 +2,7 @@
 (golden fixtures).  CPU only.  fp32 tolerance 1e-4 (absolute + relative), as
 BASELINE.json's north_star states for floating point."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import layers_oracle as lo
@@ -57,3 +58,47 @@ def test_model_step_matches_reference():
         assert abs(float(gn) - float(g.get(ci, "gnorm"))) < 1e-3 * max(1.0, float(gn))
         for k, gr in g.group(ci, "g").items():
             np.testing.assert_allclose(p[k].grad.numpy(), gr, err_msg=f"{case['arch']['aggr']} {k}", rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["sage", "gcn"])
+def test_cpu_train_step_port_matches_layer_oracle(kind):
+    """oracle/cpu_train_step.py (the sparse-matrix CPU model bench.py times as ``cpu_baseline_train_step``)
+    computes what the golden-pinned dense layer oracle computes."""
+    from oracle import cpu_train_step as cts
+    from oracle import layers_oracle as lo
+    rng = np.random.default_rng(5)
+    blocks, n_per, B = [], 12, 5
+    import scipy.sparse as sp
+    for b in range(B):
+        a = (rng.random((n_per, n_per)) < 0.3).astype(np.float32)
+        a = np.maximum(a, a.T); np.fill_diagonal(a, 1.0)
+        blocks.append(sp.csr_matrix(a))
+    A = sp.block_diag(blocks, format="csr"); A.sort_indices()
+    n, F0, dim, C, L = A.shape[0], 7, 16, 4, 3
+    torch.manual_seed(1)
+    X = torch.randn(n, F0)
+    target = np.arange(B) * n_per
+    m = cts.CpuModel(kind, L, F0, dim, C, "relu", dropout=0.0).eval()
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(0.1 * torch.randn_like(q))          # (scale / offset away from their 1 / 0 initial values)
+    p = {}
+    for l, layer in enumerate(m.layers):
+        pre = f"conv_layers.0.{l}."
+        if kind == "gcn":
+            p[pre + "f_lin.weight"], p[pre + "f_lin.bias"] = layer.lins[0].weight, layer.lins[0].bias
+        else:
+            p[pre + "f_lin_self.weight"], p[pre + "f_lin_self.bias"] = layer.lins[0].weight, layer.lins[0].bias
+            p[pre + "f_lin_neigh.weight"], p[pre + "f_lin_neigh.bias"] = layer.lins[1].weight, layer.lins[1].bias
+        p[pre + "scale"], p[pre + "offset"] = layer.scale, layer.offset
+    p["classifier.0.f_lin.weight"], p["classifier.0.f_lin.bias"] = m.cls.weight, m.cls.bias
+    p["classifier.0.scale"], p["classifier.0.offset"] = m.cls_scale.unsqueeze(0), m.cls_offset.unsqueeze(0)
+    arch = dict(aggr=kind, num_layers=L, heads=1, act="relu", residue="none", pooling="center")
+    ref, _ = lo.model_forward(p, arch, X, A.indptr, A.indices, [n_per] * B, target)
+    adj = cts.norm_adj(A.indptr, A.indices, kind, 0.0, torch.Generator().manual_seed(0))
+    got = m(X, adj, torch.as_tensor(target))
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    # and a whole optimisation step runs
+    steps, sec, warm = cts.time_train_steps(A.indptr, A.indices, X, torch.as_tensor(target), torch.arange(B) % C, kind, L, dim, C,
+                                            "relu", 0.3, 0.1, 0.01, threads=2, budget_s=5.0, max_steps=1)
+    assert steps == 1 and sec > 0
