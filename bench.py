@@ -188,6 +188,7 @@ def main():
     model.prune_tail = bool(args.prune_tail)
     if args.prune_tail and model._tail_prunable(0):
         mb.tail_plan_layers = wl["layers"]
+        mb.tail_plan_square = wl["aggr"] == "gat"
 
     def barrier():
         if world > 1:
@@ -234,6 +235,7 @@ def main():
     if not args.prune_tail and model._tail_prunable(0):
         model.prune_tail = True
         mb.tail_plan_layers = wl["layers"]
+        mb.tail_plan_square = wl["aggr"] == "gat"
         for _ in range(TAIL_WARMUP):
             one_step()
         barrier()

@@ -115,6 +115,7 @@ class MinibatchShallowExtractor:
         self.prefetch = prefetch
         # > 0: every batch carries a target-only-tail plan for a model of that many layers (DeepGNN.prune_tail)
         self.tail_plan_layers = 0
+        self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
         self._side = torch.cuda.Stream(device=self.device) if prefetch else None
         self._inflight = {}
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
@@ -194,14 +195,14 @@ class MinibatchShallowExtractor:
         stream: the allocator then defers their reuse until the training stream is done with them."""
         from . import tail
         if self._side is None:
-            return tail.build_tail_plan(adj, targets, self.tail_plan_layers, eager_transpose=True)
+            return tail.build_tail_plan(adj, targets, self.tail_plan_layers, eager_transpose=("square" if self.tail_plan_square else True))
         main = torch.cuda.current_stream(self.device)
         for t in (subgs.node, subgs.indptr, subgs.indices, subgs.edge_id, subgs.target, subgs.subg_node_off,
                   subgs.subg_edge_off, subgs.ppr, subgs.hop, subgs.drnl):
             if t is not None and t.is_cuda:
                 t.record_stream(main)
         with torch.cuda.stream(self._side):
-            levels = tail.build_tail_plan(adj, targets, self.tail_plan_layers, eager_transpose=True)
+            levels = tail.build_tail_plan(adj, targets, self.tail_plan_layers, eager_transpose=("square" if self.tail_plan_square else True))
         main.wait_stream(self._side)
         for lv in levels:
             for t in lv.tensors():

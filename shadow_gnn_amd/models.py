@@ -153,9 +153,13 @@ class DeepGNN(nn.Module):
                 # root rows in target order, which is all that residue 'none' + centre pooling reads
                 x, adj_norm = xmd[0], xmd[1]
                 if num_full == 0:
-                    adj_norm = convs[0].norm_adj(adj_i, False, dropedge, x.device)
+                    adj_norm = (convs[0].norm_adj(adj_i, False, dropedge, x.device) if hasattr(convs[0], 'norm_adj')
+                                else convs[0]._adj_norm(adj_i, False, x.device, dropedge=dropedge))
                 for md, level in zip(convs[num_full:], levels):
-                    x = md.forward_rows(x, adj_norm, level)
+                    if hasattr(md, 'forward_rows'):
+                        x = md.forward_rows(x, adj_norm, level)
+                    else:                 # GAT: ordinary kernels on the level's input rows, other rows unconnected
+                        x = tail.square_layer(md, x, level, adj_norm)
                 emb_subg_i = x
             else:
                 emb_subg_i = self.res_pool_layers[i](xjk, tgt, size_subg_ens[i])
@@ -168,7 +172,7 @@ class DeepGNN(nn.Module):
     def _tail_prunable(self, i):
         rp = self.res_pool_layers[i]
         return (rp.type_res == 'none' and rp.type_pool == 'center' and self.prediction_task == 'node'
-                and all(hasattr(md, 'forward_rows') for md in self.conv_layers[i]))
+                and all(isinstance(md, (layers.GCN, layers.GraphSAGE, layers.GAT)) for md in self.conv_layers[i]))
 
     def _plan_dropout_fusion(self, i):
         """Layer l+1's input dropout (shaDow/layers.py:430,471,601) is applied by layer l's own act_norm

@@ -16,6 +16,10 @@ A pruned layer is a *rectangular* layer: r output rows, m_in input rows,
 on the rows of the batch adjacency selected by ``rows`` (same normalisation scales and drop-edge mask as the
 full matrix: the scales are gathered, not recomputed).  The SpMM kernels are the ordinary CSR ones
 (sl_spmm_csr_f32 takes any row count); the transposed matrix for the backward pass is built with a stable sort.
+
+GAT transforms the neighbours before it aggregates (layers.py:604-611), so its pruned layers run the ordinary
+square kernels on the level's INPUT rows with only the level's rows connected (``RectLevel.square``): the
+attention / softmax / aggregation kernels see the few needed edges, the dense part shrinks with the input set.
 """
 from typing import List, Optional
 
@@ -38,6 +42,7 @@ class RectLevel:
         self.m_in = int(m_in)
         self.r = int(rows_full.numel())
         self._t = None
+        self._sq = None
 
     @property
     def transposed(self):
@@ -58,7 +63,40 @@ class RectLevel:
             ts.append(self.in_ids_full)
         if self._t is not None:
             ts.extend(self._t)
+        if self._sq is not None:
+            csr, order = self._sq
+            ts.extend([csr.indptr, csr.indices, order])
+            if csr._t is not None:
+                ts.extend(csr._t)
+            if csr._edge_row is not None:
+                ts.append(csr._edge_row)
         return ts
+
+    @property
+    def square(self):
+        """(DeviceCSR, edge order) of the m_in x m_in matrix that keeps the edges of this level's rows and
+        leaves every other row empty: layers without a rectangular form (GAT: the neighbour transform runs on
+        the input rows anyway) run their ordinary kernels on it; rows outside the level produce values nobody
+        reads."""
+        if self._sq is None:
+            srow = self.self_idx[self.edge_row]                 # row of every edge in the input numbering
+            order = torch.argsort(srow, stable=True)
+            ip = torch.zeros(self.m_in + 1, dtype=torch.int64, device=srow.device)
+            if srow.numel():
+                torch.cumsum(torch.bincount(srow, minlength=self.m_in), 0, out=ip[1:])
+            self._sq = (ops.DeviceCSR(ip.to(torch.int32), self.indices[order].contiguous()), order)
+        return self._sq
+
+    def square_adj(self, full: "ops.NormAdj") -> "ops.NormAdj":
+        csr, order = self.square
+        ew = full.edge_w[self.edge_pos[order]] if full.edge_w is not None else None
+        rs = cs = None
+        ids = self.in_ids_full
+        if full.row_scale is not None:
+            rs = full.row_scale if ids is None else full.row_scale[ids]
+        if full.col_scale is not None:
+            cs = full.col_scale if ids is None else full.col_scale[ids]
+        return ops.NormAdj(csr, edge_w=ew, row_scale=rs, col_scale=cs)
 
     def norm(self, full: "ops.NormAdj"):
         """(edge_w, row_scale, col_scale) of this level, gathered from the normalised full adjacency."""
@@ -113,7 +151,10 @@ def build_tail_plan(csr: "ops.DeviceCSR", targets: torch.Tensor, num_layers: int
     levels.reverse()
     if eager_transpose:
         for lv in levels:
-            lv.transposed
+            if eager_transpose == "square":
+                lv.square[0].transposed
+            else:
+                lv.transposed
     return levels
 
 
@@ -146,6 +187,15 @@ class _RectGatherSpMM(torch.autograd.Function):
         if dXs is not None:
             dX.index_add_(0, level.self_idx, dXs.float())
         return dX, None, None, None, None
+
+
+def square_layer(md, X: torch.Tensor, level: RectLevel, full_adj: "ops.NormAdj") -> torch.Tensor:
+    """A layer without a rectangular form (GAT) on the input rows of ``level`` with only the level's rows
+    connected; returns the level's output rows."""
+    out = md((X, level.square_adj(full_adj), True, 0.), sizes_subg=None)[0]
+    dropped = md.take_dropped_out() if hasattr(md, 'take_dropped_out') else None
+    assert dropped is None
+    return out.index_select(0, level.self_idx)
 
 
 def rect_gather_spmm(X: torch.Tensor, level: RectLevel, full_adj: "ops.NormAdj"):

@@ -38,7 +38,7 @@ def _batch(B, nodes_per, F0, C, seed, deg=3):
 
 def _model(aggr, num_layers, F0, C, dropedge=0.0, dim=64):
     from shadow_gnn_amd.models import DeepGNN
-    arch = dict(num_layers=num_layers, num_cls_layers=1, heads=1, branch_sharing=False, dim=dim, act="relu",
+    arch = dict(num_layers=num_layers, num_cls_layers=1, heads=(2 if aggr == "gat" else 1), branch_sharing=False, dim=dim, act="relu",
                 layer_norm="norm_feat", feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center",
                 loss="softmax", ensemble_act="relu")
     torch.manual_seed(3)
@@ -46,7 +46,7 @@ def _model(aggr, num_layers, F0, C, dropedge=0.0, dim=64):
 
 
 @pytest.mark.parametrize("aggr,num_layers,dropedge", [("sage", 5, 0.0), ("gcn", 3, 0.0), ("sage", 3, 0.1), ("gcn", 5, 0.1),
-                                                      ("sage", 1, 0.0)])
+                                                      ("sage", 1, 0.0), ("gat", 3, 0.0), ("gat", 5, 0.1), ("gat", 1, 0.0)])
 def test_pruned_tail_matches_full_stack(aggr, num_layers, dropedge):
     from shadow_gnn_amd.minibatch import TRAIN, VALID
     B, nodes_per, F0, C = 40, 300, 32, 6
