@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="roots per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--no-tail", action="store_true", help="skip the separately reported target-only-tail steps "
+                    "(profiling runs: keeps the kernel trace to the timed configuration)")
     ap.add_argument("--prune-tail", action="store_true",
                     help="run the WHOLE benchmark with the exact target-only tail (shadow_gnn_amd/tail.py); without the "
                          "flag the timed region computes every row of every layer like the reference, and the pruned "
@@ -232,7 +234,7 @@ def main():
     # ---- the same training step with the exact target-only tail (dead rows of the last layers not computed);
     #      reported separately, never part of `value`
     tail_info = None
-    if not args.prune_tail and model._tail_prunable(0):
+    if not args.prune_tail and not args.no_tail and model._tail_prunable(0):
         model.prune_tail = True
         mb.tail_plan_layers = wl["layers"]
         mb.tail_plan_square = wl["aggr"] == "gat"
