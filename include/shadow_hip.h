@@ -161,12 +161,15 @@ int sg_save_ppr_bin(const sg_sampler *s, const char *path_neighs, const char *pa
  * (flipped to 1-alpha inside, .cpp:242).  hash_slots = per-target table size
  * (power of two), num_waves = targets in flight (multiple of 4), d_work >=
  * num_waves*hash_slots*21 + 256 bytes.  Synchronises the stream; SG_ERR_CAPACITY
- * when a table or the output list is too small (*h_total = entries needed).   */
+ * when a table or the output list is too small (*h_total = entries needed).
+ * mode 0 = "ordered": smallest pending id first, as the reference's std::set (bit-exact tables);
+ * mode 1 = "fifo": same push arithmetic in discovery order (ring queue filled by all lanes), several
+ * times faster; every residue still ends <= epsilon * degree, scores agree within that bound.      */
 int sg_ppr_push(const uint32_t *d_indptr, const uint32_t *d_indices, uint32_t num_nodes,
                 const uint32_t *d_targets, uint32_t num_targets, float alpha, float epsilon,
                 uint32_t hash_slots, uint32_t num_waves, void *d_work, uint64_t work_bytes,
                 uint32_t *d_out_count, uint64_t *d_out_offset, uint32_t *d_out_node, float *d_out_score,
-                uint64_t cap_out, uint64_t *h_total, uint32_t *h_flags, void *stream);
+                uint64_t cap_out, uint64_t *h_total, uint32_t *h_flags, uint32_t mode, void *stream);
 /* ParallelSampler::drop_full_graph_info (.cpp:22-34). */
 int sg_drop_full_graph_info(sg_sampler *s);
 

@@ -76,7 +76,7 @@ SIGNATURES = {
     "sg_save_ppr_bin": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_float]),
     "sg_drop_full_graph_info": (C.c_int, [_P]),
     "sg_ppr_push": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _P,
-                               C.c_uint64, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _P]),
+                               C.c_uint64, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, _P]),
     "sg_sample": (C.c_int, [_P, C.POINTER(SgConfig), C.c_uint64, C.c_uint32, C.c_uint64, _P,
                              C.POINTER(SgBatchOut), _P]),
     "sg_sample_finish": (C.c_int, [_P, C.POINTER(SgBatchCounts)]),
@@ -121,7 +121,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 4      # sg_abi_version() of the library these signatures describe
 
 
 def load():

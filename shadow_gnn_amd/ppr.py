@@ -14,10 +14,18 @@ from . import _lib
 from ._lib import check
 
 
+PUSH_MODE = {"ordered": 0, "fifo": 1}
+
+
 def ppr_approximate_device(hs, targets, k: int, alpha: float = 0.85, epsilon: float = 1e-5,
-                           hash_slots: int = 1 << 15, num_waves: int = 2048, chunk: int = 1 << 16):
+                           hash_slots: int = 1 << 15, num_waves: int = 2048, chunk: int = 1 << 16,
+                           order: str = "ordered"):
     """Returns (len[T] uint32, neigh[T,k] uint32, score[T,k] float32) for `targets`
-    (numpy), computed on hs.device.  `hs` is a HipSampler (owner of the CSR in HBM)."""
+    (numpy), computed on hs.device.  `hs` is a HipSampler (owner of the CSR in HBM).
+    ``order``: "ordered" reproduces the reference's tables bit for bit (smallest pending id first);
+    "fifo" pushes in discovery order -- same error bound, several times faster, tables agree with the
+    reference's within the approximation error (use it when the cache files need not be interchangeable)."""
+    mode = PUSH_MODE[order]
     lib = _lib.load()
     dev = hs.device
     targets = np.ascontiguousarray(np.asarray(targets).reshape(-1), dtype=np.uint32)
@@ -44,7 +52,8 @@ def ppr_approximate_device(hs, targets, k: int, alpha: float = 0.85, epsilon: fl
                 total, flags = C.c_uint64(), C.c_uint32()
                 rc = lib.sg_ppr_push(d_ip, d_ix, N, d_t.data_ptr(), Tc, alpha, epsilon, hash_slots, waves,
                                      work.data_ptr(), work.numel(), cnt.data_ptr(), off.data_ptr(),
-                                     o_node.data_ptr(), o_score.data_ptr(), cap, C.byref(total), C.byref(flags), stream)
+                                     o_node.data_ptr(), o_score.data_ptr(), cap, C.byref(total), C.byref(flags), mode,
+                                     stream)
                 if rc == _lib.SG_ERR_CAPACITY:
                     if flags.value & 1:
                         hash_slots *= 4
@@ -66,8 +75,8 @@ def ppr_approximate_device(hs, targets, k: int, alpha: float = 0.85, epsilon: fl
             o2 = torch.sort(score[o1], descending=True, stable=True).indices
             o12 = o1[o2]
             o3 = torch.sort(seg[o12], stable=True).indices
-            order = o12[o3]
-            seg_s, node_s, score_s = seg[order], node[order], score[order]
+            perm = o12[o3]
+            seg_s, node_s, score_s = seg[perm], node[perm], score[perm]
             start = torch.cumsum(cnt64, 0) - cnt64                   # per target, in target order (segments sorted by id)
             rank = torch.arange(n_ent, device=dev) - start[seg_s]
             keep = rank < k
