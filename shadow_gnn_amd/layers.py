@@ -348,6 +348,24 @@ class GAT(shaDowLayer):
         assert isinstance(adj, ops.NormAdj)
         return adj
 
+    def forward_rows(self, feat_in, adj_norm, level):
+        """The layer on the output rows of ``level`` only (tail.py).  The neighbour transform runs on every
+        input row (attention reads it at the sources); the self transform, the normalisation and the edge
+        kernels only see the level's rows (a square matrix with the other rows unconnected)."""
+        from . import ops_gat
+        feat_in = self.in_dropout(feat_in)
+        adj_sq = level.square_adj(adj_norm)
+        z_neigh = ops.linear(feat_in, self.f_lin[1])
+        z_self_r = ops.linear(feat_in.index_select(0, level.self_idx), self.f_lin[0])
+        z_self = torch.zeros(feat_in.shape[0], z_self_r.shape[1], dtype=z_self_r.dtype,
+                             device=z_self_r.device).index_copy(0, level.self_idx, z_self_r)
+        feat_neigh = ops_gat.gat_aggregate(adj_sq, z_self, z_neigh, self.attention, self.act_name, self.mulhead)
+        feat_neigh_r = feat_neigh.index_select(0, level.self_idx)
+        if self.norm == 'norm_feat':
+            return self._emit(ops.act_norm([feat_neigh_r, z_self_r], ['I', self.act_name], self.scale, self.offset,
+                                           seg=self.dim_slice, out_scale=0.5, **self._drop_kw()))
+        return (feat_neigh_r + _torch_act(self.act_name, z_self_r)) / 2
+
     def forward(self, inputs, sizes_subg):
         from . import ops_gat
         feat_in, adj, is_normed, dropedge = inputs

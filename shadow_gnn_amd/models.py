@@ -156,10 +156,7 @@ class DeepGNN(nn.Module):
                     adj_norm = (convs[0].norm_adj(adj_i, False, dropedge, x.device) if hasattr(convs[0], 'norm_adj')
                                 else convs[0]._adj_norm(adj_i, False, x.device, dropedge=dropedge))
                 for md, level in zip(convs[num_full:], levels):
-                    if hasattr(md, 'forward_rows'):
-                        x = md.forward_rows(x, adj_norm, level)
-                    else:                 # GAT: ordinary kernels on the level's input rows, other rows unconnected
-                        x = tail.square_layer(md, x, level, adj_norm)
+                    x = md.forward_rows(x, adj_norm, level)
                 emb_subg_i = x
             else:
                 emb_subg_i = self.res_pool_layers[i](xjk, tgt, size_subg_ens[i])

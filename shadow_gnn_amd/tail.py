@@ -17,9 +17,10 @@ on the rows of the batch adjacency selected by ``rows`` (same normalisation scal
 full matrix: the scales are gathered, not recomputed).  The SpMM kernels are the ordinary CSR ones
 (sl_spmm_csr_f32 takes any row count); the transposed matrix for the backward pass is built with a stable sort.
 
-GAT transforms the neighbours before it aggregates (layers.py:604-611), so its pruned layers run the ordinary
-square kernels on the level's INPUT rows with only the level's rows connected (``RectLevel.square``): the
-attention / softmax / aggregation kernels see the few needed edges, the dense part shrinks with the input set.
+GAT transforms the neighbours before it aggregates (layers.py:604-611): its neighbour Linear runs on every input
+row of the level, the attention / softmax / aggregation kernels on a square matrix over the input rows with only
+the level's rows connected (``RectLevel.square``), and the self Linear and the normalisation on the level's
+rows alone (GAT.forward_rows).
 """
 from typing import List, Optional
 
@@ -187,15 +188,6 @@ class _RectGatherSpMM(torch.autograd.Function):
         if dXs is not None:
             dX.index_add_(0, level.self_idx, dXs.float())
         return dX, None, None, None, None
-
-
-def square_layer(md, X: torch.Tensor, level: RectLevel, full_adj: "ops.NormAdj") -> torch.Tensor:
-    """A layer without a rectangular form (GAT) on the input rows of ``level`` with only the level's rows
-    connected; returns the level's output rows."""
-    out = md((X, level.square_adj(full_adj), True, 0.), sizes_subg=None)[0]
-    dropped = md.take_dropped_out() if hasattr(md, 'take_dropped_out') else None
-    assert dropped is None
-    return out.index_select(0, level.self_idx)
 
 
 def rect_gather_spmm(X: torch.Tensor, level: RectLevel, full_adj: "ops.NormAdj"):
