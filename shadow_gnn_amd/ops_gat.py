@@ -50,6 +50,38 @@ class _GatAggregate(torch.autograd.Function):
         return dzs, dzn, datt.reshape(att_shape), None, None, None
 
 
+def _fused_slice(D: int) -> bool:
+    """Head widths the fused kernels take: 4 * 2^k floats."""
+    return D >= 4 and D % 4 == 0 and ((D // 4) & (D // 4 - 1)) == 0
+
+
 def gat_aggregate(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: int):
-    """N = softmax_row(lrelu(a_s.act(z_self)) + lrelu(a_n.act(z_neigh))) @ act(z_neigh), per head."""
-    return _GatAggregate.apply(z_self, z_neigh, attention, adj, ops.ACT_CODE[act], int(heads))
+    """N = softmax_row(lrelu(a_s.act(z_self)) + lrelu(a_n.act(z_neigh))) @ act(z_neigh), per head.
+
+    The fused kernels take up to 256 columns of heads that are 4 * 2^k wide (the reference's dim 256 / 4 heads).
+    Other shapes -- dim 512 / 4 heads and dim 800 / 4 heads in config_train/{products,papers100M}/leaderboard --
+    run as several launches over groups of heads, each head zero-padded to the next such width: heads are
+    independent, and a zero column contributes nothing (act(0) = 0 for every supported activation, its attention
+    weight is padded with 0)."""
+    code, heads = ops.ACT_CODE[act], int(heads)
+    n, F = z_self.shape
+    D = F // heads
+    assert D * heads == F
+    if F <= 256 and _fused_slice(D):
+        return _GatAggregate.apply(z_self, z_neigh, attention, adj, code, heads)
+    Dp = 4
+    while Dp < D:
+        Dp *= 2
+    if Dp > 256:
+        raise NotImplementedError(f"GAT head width {D} > 256 is not provided")
+    per = max(1, 256 // Dp)                                   # heads per launch
+    att = attention.reshape(2, heads, D)
+    zs, zn = z_self.reshape(n, heads, D), z_neigh.reshape(n, heads, D)
+    pad = (lambda t: torch.nn.functional.pad(t, (0, Dp - D))) if Dp != D else (lambda t: t)
+    outs = []
+    for h0 in range(0, heads, per):
+        h1 = min(heads, h0 + per)
+        o = _GatAggregate.apply(pad(zs[:, h0:h1]).reshape(n, (h1 - h0) * Dp), pad(zn[:, h0:h1]).reshape(n, (h1 - h0) * Dp),
+                                pad(att[:, h0:h1]).contiguous(), adj, code, h1 - h0)
+        outs.append(o.reshape(n, h1 - h0, Dp)[:, :, :D])
+    return torch.cat(outs, dim=1).reshape(n, F)

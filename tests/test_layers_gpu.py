@@ -556,3 +556,36 @@ def test_model_dropout_fusion_plan_and_training_step():
     m3 = make("max", "mean"); m3.fuse_dropout = False
     m3.step(TRAIN, "running", batch())
     assert all(l.out_dropout == 0.0 and not l.input_pre_dropped for l in m3.conv_layers[0])
+
+
+@pytest.mark.parametrize("dim,heads,act", [(512, 4, "elu"), (800, 4, "relu"), (130, 2, "relu"), (36, 3, "tanh")])
+def test_gat_layer_any_head_width_matches_layer_oracle(dim, heads, act):
+    """GAT with the widths of the reference's leaderboard configs (dim 512 and 800 with 4 heads,
+    config_train/{products,papers100M}/leaderboard) and odd ones: the fused kernels take 4 * 2^k-wide heads in
+    groups of <= 256 columns, ops_gat pads / groups the rest.  Outputs and all gradients vs the golden-pinned
+    dense layer oracle."""
+    from oracle import layers_oracle as lo
+    from shadow_gnn_amd import layers
+    rng = np.random.default_rng(dim)
+    n, F_in = 500, 40
+    import scipy.sparse as sp
+    a = (rng.random((n, n)) < 0.02).astype(np.float32); a = np.maximum(a, a.T); np.fill_diagonal(a, 1.0)
+    A = sp.csr_matrix(a); A.sort_indices()
+    torch.manual_seed(dim + heads)
+    layer = layers.GAT(F_in, dim, dropout=0.0, act=act, norm="norm_feat", mulhead=heads).to(DEV)
+    with torch.no_grad():
+        for q in layer.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    X = torch.randn(n, F_in)
+    G = torch.randn(n, dim)
+    x = X.to(DEV).requires_grad_(True)
+    out, _, _, _ = layer((x, _csr(A.indptr, A.indices), False, 0.0), None)
+    (out * G.to(DEV)).sum().backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xr = X.clone().requires_grad_(True)
+    ref = lo.gat_forward(p, xr, lo.dense_adj(A.indptr, A.indices), act, heads)
+    (ref * G).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), **TOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-4)
+    for k, q in layer.named_parameters():
+        np.testing.assert_allclose(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=2e-3, atol=1e-3, err_msg=k)
