@@ -1,6 +1,6 @@
 """cProfile of the host side of the train step (development aid): where the Python time of a step goes."""
 import cProfile, pstats, io, sys, os, runpy
-sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--steps", "60", "--warmup", "5", "--no-cpu-baseline", "--no-tail"] + sys.argv[1:]
 pr = cProfile.Profile()
 pr.enable()
 try:
