@@ -96,18 +96,27 @@ def tnp(t):
     return t.detach().cpu().numpy()
 
 
-def gen_layers(L):
+LAYER_CASES = lambda L: (
+    ("gcn", L.GCN, True, dict(act="elu")), ("gcn", L.GCN, True, dict(act="relu")),
+    ("sage", L.GraphSAGE, False, dict(act="elu")), ("sage", L.GraphSAGE, False, dict(act="relu")),
+    ("sage", L.GraphSAGE, True, dict(act="tanh")),
+    ("gat", L.GAT, True, dict(act="elu", mulhead=4)), ("gat", L.GAT, True, dict(act="relu", mulhead=2)),
+    ("gat", L.GAT, False, dict(act="elu", mulhead=1)),
+)
+# learnable activations (nn.PReLU: one slope per layer; "prelu+": one per output channel; layers.py:26-39)
+LAYER_CASES_PRELU = lambda L: (
+    ("gcn", L.GCN, True, dict(act="prelu")), ("sage", L.GraphSAGE, False, dict(act="prelu")),
+    ("sage", L.GraphSAGE, True, dict(act="prelu+")), ("gat", L.GAT, True, dict(act="prelu", mulhead=2)),
+    ("gat", L.GAT, False, dict(act="prelu+", mulhead=4)),
+)
+
+
+def gen_layers(L, case_list=None, fname="layers_fwd_bwd.npz", seed=0):
     store = {}
     cases = []
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     ci = 0
-    for (name, cls, self_edge, kw) in (
-        ("gcn", L.GCN, True, dict(act="elu")), ("gcn", L.GCN, True, dict(act="relu")),
-        ("sage", L.GraphSAGE, False, dict(act="elu")), ("sage", L.GraphSAGE, False, dict(act="relu")),
-        ("sage", L.GraphSAGE, True, dict(act="tanh")),
-        ("gat", L.GAT, True, dict(act="elu", mulhead=4)), ("gat", L.GAT, True, dict(act="relu", mulhead=2)),
-        ("gat", L.GAT, False, dict(act="elu", mulhead=1)),
-    ):
+    for (name, cls, self_edge, kw) in (case_list or LAYER_CASES(L)):
         b, X = make_batch(seed=10 + ci, self_edge=self_edge, feat=12)
         dim_in, dim_out = 12, 16
         layer = cls(dim_in, dim_out, dropout=0.0, norm="norm_feat", **kw)
@@ -142,22 +151,29 @@ def gen_layers(L):
         ci += 1
     import json
     store["cases"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
-    path = os.path.join(ROOT, "tests", "golden", "layers_fwd_bwd.npz")
+    path = os.path.join(ROOT, "tests", "golden", fname)
     np.savez_compressed(path, **store)
     print(f"wrote {path}: {len(cases)} cases, {os.path.getsize(path)/1024:.1f} KiB")
 
 
-def gen_models(L, M, MB):
+MODEL_CASES = (
+    ("sage", False, 1, "none", "center", "elu", True, 3),
+    ("gcn", True, 1, "none", "center", "elu", True, 3),
+    ("gat", True, 4, "none", "center", "elu", False, 2),
+    ("sage", False, 1, "max", "mean", "relu", False, 3),
+)
+MODEL_CASES_PRELU = (
+    ("gat", True, 4, "max", "max", "prelu", False, 2),       # the leaderboard GAT read-out with the ResPool PReLU
+    ("sage", False, 1, "none", "center", "prelu", True, 3),
+)
+
+
+def gen_models(L, M, MB, case_list=MODEL_CASES, fname="models_step.npz", seed_base=100):
     import json
     store, cases = {}, []
     ci = 0
-    for (aggr, self_edge, heads, residue, pooling, act, aug, nl) in (
-        ("sage", False, 1, "none", "center", "elu", True, 3),
-        ("gcn", True, 1, "none", "center", "elu", True, 3),
-        ("gat", True, 4, "none", "center", "elu", False, 2),
-        ("sage", False, 1, "max", "mean", "relu", False, 3),
-    ):
-        torch.manual_seed(100 + ci)
+    for (aggr, self_edge, heads, residue, pooling, act, aug, nl) in case_list:
+        torch.manual_seed(seed_base + ci)
         b, X = make_batch(seed=50 + ci, P=8, self_edge=self_edge, feat=10)
         num_classes = 5
         arch = dict(num_layers=nl, num_cls_layers=1, heads=heads, branch_sharing=False, dim=16, act=act,
@@ -207,13 +223,17 @@ def gen_models(L, M, MB):
         cases.append(dict(idx=ci, arch=arch, train_params=tp, aug=aug, num_classes=num_classes, dim_feat=10))
         ci += 1
     store["cases"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
-    path = os.path.join(ROOT, "tests", "golden", "models_step.npz")
+    path = os.path.join(ROOT, "tests", "golden", fname)
     np.savez_compressed(path, **store)
     print(f"wrote {path}: {len(cases)} cases, {os.path.getsize(path)/1024:.1f} KiB")
 
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    prelu_only = "--prelu-only" in sys.argv          # (import_reference() replaces sys.argv)
     L, M, MB = import_reference()
-    gen_layers(L)
-    gen_models(L, M, MB)
+    if not prelu_only:
+        gen_layers(L)
+        gen_models(L, M, MB)
+    gen_layers(L, LAYER_CASES_PRELU(L), "layers_prelu.npz", seed=7)
+    gen_models(L, M, MB, MODEL_CASES_PRELU, "models_prelu.npz", seed_base=300)

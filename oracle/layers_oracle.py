@@ -19,6 +19,14 @@ ACT = {
 }
 
 
+def act_fn(act, p, key="act.weight"):
+    """The layer's activation module (layers.py:26-39): fixed functions, or nn.PReLU with its learnable slope
+    ("prelu": one per layer, "prelu+": one per output channel) stored in the layer's state_dict as `key`."""
+    if act in ("prelu", "prelu+"):
+        return lambda x: F.prelu(x, p[key])
+    return ACT[act]
+
+
 def dense_adj(indptr, indices, edge_w=None):
     indptr = np.asarray(indptr, dtype=np.int64)
     indices = np.asarray(indices, dtype=np.int64)
@@ -52,13 +60,13 @@ def gcn_forward(p, X, A_norm, act):
     """GCN.forward, layers.py:433-435: aggregate, Linear, act, norm"""
     h = A_norm @ X
     z = F.linear(h, p["f_lin.weight"], p["f_lin.bias"])
-    return f_norm(ACT[act](z), p["scale"][0], p["offset"][0])
+    return f_norm(act_fn(act, p)(z), p["scale"][0], p["offset"][0])
 
 
 def sage_forward(p, X, A_norm, act):
     """GraphSAGE.forward, layers.py:473-483"""
-    hs = ACT[act](F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"]))
-    hn = ACT[act](F.linear(A_norm @ X, p["f_lin_neigh.weight"], p["f_lin_neigh.bias"]))
+    hs = act_fn(act, p)(F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"]))
+    hn = act_fn(act, p)(F.linear(A_norm @ X, p["f_lin_neigh.weight"], p["f_lin_neigh.bias"]))
     return f_norm(hs, p["scale"][0], p["offset"][0]) + f_norm(hn, p["scale"][1], p["offset"][1])
 
 
@@ -66,8 +74,8 @@ def gat_forward(p, X, A_mask, act, heads):
     """GAT.forward + _aggregate_attention, layers.py:560-626.  A_mask: dense 0/1
     (multiplicities for duplicate edges) adjacency, un-normalised (:591)."""
     n = X.shape[0]
-    hs = ACT[act](F.linear(X, p["f_lin.0.weight"], p["f_lin.0.bias"])).view(n, heads, -1)
-    hn = ACT[act](F.linear(X, p["f_lin.1.weight"], p["f_lin.1.bias"])).view(n, heads, -1)
+    hs = act_fn(act, p)(F.linear(X, p["f_lin.0.weight"], p["f_lin.0.bias"])).view(n, heads, -1)
+    hn = act_fn(act, p)(F.linear(X, p["f_lin.1.weight"], p["f_lin.1.bias"])).view(n, heads, -1)
     att = p["attention"]
     outs_n, outs_s = [], []
     present = A_mask > 0
@@ -152,7 +160,8 @@ def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None):
             feat_in = torch.cat([feats[-1][tgt], pool(feats[-1])], 1)
         else:
             feat_in = torch.cat([residue([f[tgt] for f in feats]), residue([pool(f) for f in feats])], 1)
-        z = ACT[act](F.linear(feat_in, p["res_pool_layers.0.nn.1.weight"], p["res_pool_layers.0.nn.1.bias"]))
+        z = act_fn(act, p, "res_pool_layers.0.nn.2.weight")(
+            F.linear(feat_in, p["res_pool_layers.0.nn.1.weight"], p["res_pool_layers.0.nn.1.bias"]))
         emb = f_norm(z, p["res_pool_layers.0.scale"], p["res_pool_layers.0.offset"])    # layers.py:114-118,199
     emb = F.normalize(emb, p=2, dim=1)                           # models.py:200
     z = F.linear(emb, p["classifier.0.f_lin.weight"], p["classifier.0.f_lin.bias"])

@@ -29,15 +29,27 @@ from . import ops
 Dims_X = namedtuple('Dims_X', ['num_nodes', 'num_feats'])
 Dims_adj = namedtuple('Dims_adj', ['num_nodes', 'num_edges'])
 
-# activations of the reference's F_ACT table (shaDow/layers.py:26-34) that the
-# fused kernels implement; 'prelu'/'prelu+' carry parameters and are not offered
-SUPPORTED_ACT = ("relu", "I", "elu", "tanh", "leakyrelu")
+# activations of the reference's F_ACT table (shaDow/layers.py:26-34).  The parameter-free ones run inside the
+# fused kernels.  'prelu' (nn.PReLU(): one learnable slope per layer) and 'prelu+' (one per output channel) are
+# applied by torch between the Linear and the fused normalisation -- the kernels then see the identity -- so the
+# slope's gradient comes from autograd and the module keeps the reference's state_dict key ("act.weight").
+SUPPORTED_ACT = ("relu", "I", "elu", "tanh", "leakyrelu", "prelu", "prelu+")
+LEARNED_ACT = ("prelu", "prelu+")
 
 
 def _check_act(act):
     if act not in SUPPORTED_ACT:
         raise NotImplementedError(f"activation {act!r} is not provided by the HIP layers {SUPPORTED_ACT}")
     return act
+
+
+def _learned_act(act, dim_out):
+    """nn.PReLU for the learnable activations (get_torch_act, layers.py:37-39), None otherwise."""
+    if act == "prelu":
+        return nn.PReLU()
+    if act == "prelu+":
+        return nn.PReLU(num_parameters=dim_out)
+    return None
 
 
 def _as_device_csr(adj, device):
@@ -69,6 +81,8 @@ class shaDowLayer(nn.Module):
         self.dropout = dropout
         self.dim_in, self.dim_out = dim_in, dim_out
         self.act_name = _check_act(act)
+        self.act = _learned_act(act, dim_out)        # registered only when it has parameters ("act.weight")
+        self.kact = 'I' if self.act is not None else self.act_name      # what the fused kernels apply
         self.f_dropout = nn.Dropout(p=self.dropout)
         # Dropout fusion (set per step by DeepGNN.forward while training): the layer BEFORE this one may
         # already have applied this layer's input dropout inside its act_norm kernel (input_pre_dropped),
@@ -118,6 +132,8 @@ class shaDowLayer(nn.Module):
     def f_lin_act_norm(self, Xs, lins, acts):
         """sum_b norm_b(act_b(lin_b(X_b))): Linear (rocBLAS) + bias/act/norm/add (one HIP kernel),
         one autograd node with fused bias / scale / offset gradients."""
+        if self.act is not None:              # learnable activation: Linear, PReLU (torch), fused norm of the result
+            return self.f_act_norm([self.act(ops.linear(x, l)) for x, l in zip(Xs, lins)], ['I'] * len(Xs))
         if self.norm == 'norm_feat':
             return self._emit(ops.linear_act_norm(Xs, lins, acts, self.scale, self.offset, **self._drop_kw()))
         return self.f_act_norm([ops.linear(x, l) for x, l in zip(Xs, lins)], acts)
@@ -228,7 +244,7 @@ class GraphSAGE(shaDowLayer):
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self.norm_adj(adj, is_normed, dropedge, feat_in.device)
         feat_in = self.in_dropout(feat_in)
-        if self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0:
+        if self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0 and self.act is None:
             # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)
             feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
                                                  self.scale, self.offset, **self._drop_kw()))
@@ -276,8 +292,9 @@ class ResPool(nn.Module):
         if self.dim_in > 0 and self.dim_out > 0:
             _f_lin = nn.Linear(self.dim_in, self.dim_out, bias=True)
             _f_dropout = nn.Dropout(p=dropout)
-            # same child indices as the reference's nn.Sequential(dropout, lin, act): "nn.1" is the Linear
-            self.nn = nn.Sequential(_f_dropout, _f_lin, nn.Identity())
+            # same child indices as the reference's nn.Sequential(dropout, lin, act): "nn.1" is the Linear, "nn.2"
+            # the activation module (it has a parameter only for PReLU: "nn.2.weight")
+            self.nn = nn.Sequential(_f_dropout, _f_lin, _learned_act(act, self.dim_out) or nn.Identity())
             self.offset = nn.Parameter(torch.zeros(self.dim_out))
             self.scale = nn.Parameter(torch.ones(self.dim_out))
 
@@ -324,6 +341,8 @@ class ResPool(nn.Module):
                 feat_root = self.f_residue([f[idx_targets] for f in feats_in_l])
             feat_in = torch.cat([self.aggr_target_emb(feat_root), feat_pool], dim=1)
         # dropout -> Linear -> act -> norm (layers.py:110,114-118,199)
+        if self.act_name in LEARNED_ACT:
+            return ops.act_norm([self.nn[2](ops.linear(self.nn[0](feat_in), self.nn[1]))], ['I'], self.scale, self.offset)
         return ops.linear_act_norm([self.nn[0](feat_in)], [self.nn[1]], [self.act_name], self.scale, self.offset)
 
 
@@ -357,14 +376,16 @@ class GAT(shaDowLayer):
         adj_sq = level.square_adj(adj_norm)
         z_neigh = ops.linear(feat_in, self.f_lin[1])
         z_self_r = ops.linear(feat_in.index_select(0, level.self_idx), self.f_lin[0])
+        if self.act is not None:
+            z_neigh, z_self_r = self.act(z_neigh), self.act(z_self_r)
         z_self = torch.zeros(feat_in.shape[0], z_self_r.shape[1], dtype=z_self_r.dtype,
                              device=z_self_r.device).index_copy(0, level.self_idx, z_self_r)
-        feat_neigh = ops_gat.gat_aggregate(adj_sq, z_self, z_neigh, self.attention, self.act_name, self.mulhead)
+        feat_neigh = ops_gat.gat_aggregate(adj_sq, z_self, z_neigh, self.attention, self.kact, self.mulhead)
         feat_neigh_r = feat_neigh.index_select(0, level.self_idx)
         if self.norm == 'norm_feat':
-            return self._emit(ops.act_norm([feat_neigh_r, z_self_r], ['I', self.act_name], self.scale, self.offset,
+            return self._emit(ops.act_norm([feat_neigh_r, z_self_r], ['I', self.kact], self.scale, self.offset,
                                            seg=self.dim_slice, out_scale=0.5, **self._drop_kw()))
-        return (feat_neigh_r + _torch_act(self.act_name, z_self_r)) / 2
+        return (feat_neigh_r + _torch_act(self.kact, z_self_r)) / 2
 
     def forward(self, inputs, sizes_subg):
         from . import ops_gat
@@ -373,15 +394,17 @@ class GAT(shaDowLayer):
         feat_in = self.in_dropout(feat_in)
         z_self = ops.linear(feat_in, self.f_lin[0])
         z_neigh = ops.linear(feat_in, self.f_lin[1])
+        if self.act is not None:
+            z_self, z_neigh = self.act(z_self), self.act(z_neigh)
         # neigh branch: act -> per-head attention aggregate; both branches normalised per head slice
-        feat_neigh = ops_gat.gat_aggregate(adj_norm, z_self, z_neigh, self.attention, self.act_name,
+        feat_neigh = ops_gat.gat_aggregate(adj_norm, z_self, z_neigh, self.attention, self.kact,
                                            self.mulhead)
         if self.norm == 'norm_feat':
             # reference order: f_norm([neigh, self]) -> scale[0]=neigh, scale[1]=self (layers.py:620-622)
-            feat_out = self._emit(ops.act_norm([feat_neigh, z_self], ['I', self.act_name], self.scale, self.offset,
+            feat_out = self._emit(ops.act_norm([feat_neigh, z_self], ['I', self.kact], self.scale, self.offset,
                                                seg=self.dim_slice, out_scale=0.5, **self._drop_kw()))
         else:
-            feat_out = (feat_neigh + _torch_act(self.act_name, z_self)) / 2
+            feat_out = (feat_neigh + _torch_act(self.kact, z_self)) / 2
         return feat_out, adj_norm, True, 0.
 
     def complexity(self, dims_X, dims_adj):

@@ -9,8 +9,8 @@ from tests._golden import GOLDEN
 
 
 class LayerGolden:
-    def __init__(self):
-        self.z = np.load(os.path.join(GOLDEN, "layers_fwd_bwd.npz"))
+    def __init__(self, fname="layers_fwd_bwd.npz"):
+        self.z = np.load(os.path.join(GOLDEN, fname))
         self.cases = json.loads(bytes(self.z["cases"]).decode())
 
     def get(self, ci, name):
@@ -25,8 +25,8 @@ class LayerGolden:
 
 
 class ModelGolden:
-    def __init__(self):
-        self.z = np.load(os.path.join(GOLDEN, "models_step.npz"))
+    def __init__(self, fname="models_step.npz"):
+        self.z = np.load(os.path.join(GOLDEN, fname))
         self.cases = json.loads(bytes(self.z["cases"]).decode())
 
     def get(self, ci, name):

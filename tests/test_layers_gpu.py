@@ -27,8 +27,9 @@ def _mk_layer(case, dim_in, dim_out, params):
     return layer.to(DEV)
 
 
-def test_layers_match_reference_golden():
-    g = LayerGolden()
+@pytest.mark.parametrize("fname", ["layers_fwd_bwd.npz", "layers_prelu.npz"])
+def test_layers_match_reference_golden(fname):
+    g = LayerGolden(fname)
     for case in g.cases:
         ci = case["idx"]
         layer = _mk_layer(case, case["dim_in"], case["dim_out"], g.params(ci))
@@ -73,13 +74,14 @@ def _model_from_case(case, g, ci):
     return model.to(DEV)
 
 
+@pytest.mark.parametrize("fname", ["models_step.npz", "models_prelu.npz"])
 @pytest.mark.parametrize("fused_encoding", [False, True])
-def test_model_step_matches_reference_golden(fused_encoding):
+def test_model_step_matches_reference_golden(fused_encoding, fname):
     """One full DeepGNN.step (fwd, CE loss, bwd, clip 5, Adam) vs the reference's.  The hop encoding
     is passed either as the reference's dense one-hot matrix or as per-node codes (fused one-hot Linear)."""
     from shadow_gnn_amd import ops
     from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN, hop2onehot
-    g = ModelGolden()
+    g = ModelGolden(fname)
     for case in g.cases:
         ci = case["idx"]
         model = _model_from_case(case, g, ci)

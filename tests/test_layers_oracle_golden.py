@@ -15,9 +15,10 @@ def _t(d):
     return {k: torch.tensor(v) for k, v in d.items()}
 
 
-def test_layer_forward_and_gradients_match_reference():
-    g = LayerGolden()
-    assert len(g.cases) == 8
+@pytest.mark.parametrize("fname,ncases", [("layers_fwd_bwd.npz", 8), ("layers_prelu.npz", 5)])
+def test_layer_forward_and_gradients_match_reference(fname, ncases):
+    g = LayerGolden(fname)
+    assert len(g.cases) == ncases
     for case in g.cases:
         ci = case["idx"]
         p = {k: v.clone().requires_grad_(True) for k, v in _t(g.params(ci)).items()}
@@ -36,9 +37,10 @@ def test_layer_forward_and_gradients_match_reference():
         np.testing.assert_allclose(out2.detach().numpy(), g.get(ci, "out2"), err_msg=str(case), **TOL)
 
 
-def test_model_step_matches_reference():
-    g = ModelGolden()
-    assert len(g.cases) == 4
+@pytest.mark.parametrize("fname,ncases", [("models_step.npz", 4), ("models_prelu.npz", 2)])
+def test_model_step_matches_reference(fname, ncases):
+    g = ModelGolden(fname)
+    assert len(g.cases) == ncases
     for case in g.cases:
         ci = case["idx"]
         p = {k: v.clone().requires_grad_(True) for k, v in _t(g.group(ci, "p")).items()}

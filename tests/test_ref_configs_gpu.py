@@ -1,6 +1,6 @@
 """Every training configuration the reference ships (config_train/*/*/*.yml; the architecture / hyper-parameter
 sections are kept as data in tests/golden/ref_config_archs.json) either builds and trains on the HIP path, or is
-refused loudly for one of the documented out-of-scope features (PReLU, sort pooling) -- never silently wrong."""
+refused loudly for the documented out-of-scope feature (sort pooling, needs PyG) -- never silently wrong."""
 import json
 import os
 
@@ -46,7 +46,7 @@ def test_reference_config_builds_and_trains(cfg):
     from shadow_gnn_amd.models import DeepGNN
     arch = dict(cfg["architecture"])
     aug = [] if arch.get("feature_augment", "none") in ("none", None) else str(arch["feature_augment"]).split("-")
-    unsupported = arch["act"] == "prelu" or str(arch.get("pooling", "center")).startswith("sort")
+    unsupported = str(arch.get("pooling", "center")).startswith("sort")
     F0, C, B, n_per = 24, 6, 12, 40
     aug_feat = [(a, DIM_AUG[a]) for a in aug]
     dim_in = F0
