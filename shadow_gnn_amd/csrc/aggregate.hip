@@ -888,9 +888,9 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx,
                                   uint32_t n, uint32_t F, float *d_out, int64_t ld_out, void *stream_) {
+  if (n == 0 || F == 0) return SG_OK;             // (empty tensors may come with null pointers)
   if (!d_table || !d_idx || !d_out) return set_error(SG_ERR_INVALID, "sl_gather_rows_f32: null argument");
   hipStream_t st = (hipStream_t)stream_;
-  if (n == 0 || F == 0) return SG_OK;
   const bool vec = (F % 4 == 0) && (ld_table % 4 == 0) && (ld_out % 4 == 0) && aligned16(d_table) && aligned16(d_out);
   if (!vec) {
     hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(grid_for((uint64_t)n * F, kBlock)), dim3(kBlock), 0, st,
@@ -946,8 +946,9 @@ extern "C" int sl_csr_transpose(const uint32_t *d_indptr, const uint32_t *d_indi
 
 extern "C" int sl_degree_scales(const uint32_t *d_indptr, const float *d_edge_w, uint32_t n, int mode,
                                 float *d_row_scale, void *stream_) {
-  if (!d_indptr || !d_row_scale || mode < 0 || mode > 1) return set_error(SG_ERR_INVALID, "sl_degree_scales: bad argument");
+  if (mode < 0 || mode > 1) return set_error(SG_ERR_INVALID, "sl_degree_scales: mode %d (0 rw, 1 sym)", mode);
   if (n == 0) return SG_OK;
+  if (!d_indptr || !d_row_scale) return set_error(SG_ERR_INVALID, "sl_degree_scales: null argument");
   hipLaunchKernelGGL(degree_scales_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
                      d_indptr, d_edge_w, n, mode, d_row_scale);
   SHD_HIP(hipGetLastError());
@@ -958,8 +959,8 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
                                const uint32_t *d_edge_perm, const float *d_row_scale,
                                const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
                                int64_t ldy, uint32_t n, uint32_t F, void *stream_) {
-  if (!d_indptr || !d_X || !d_Y) return set_error(SG_ERR_INVALID, "sl_spmm_csr_f32: null argument");
   if (n == 0 || F == 0) return SG_OK;
+  if (!d_indptr || !d_X || !d_Y) return set_error(SG_ERR_INVALID, "sl_spmm_csr_f32: null argument");
   hipStream_t st = (hipStream_t)stream_;
   const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y) && F <= 1024;
 #define SHD_SPMM(LPR, CH)                                                                          \
@@ -1111,11 +1112,11 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
   return SG_OK;
 }
 
-static int act_norm_check(int nb, uint32_t F, uint32_t seg, const float *const *Z, const int *act) {
+static int act_norm_check(int nb, uint32_t F, uint32_t seg, const float *const *Z, const int *act, uint32_t n) {
   if (nb < 1 || nb > 2) return set_error(SG_ERR_INVALID, "sl_act_norm: nb must be 1 or 2");
   if (seg == 0 || F % seg != 0) return set_error(SG_ERR_INVALID, "sl_act_norm: seg=%u must divide F=%u", seg, F);
   for (int b = 0; b < nb; b++) {
-    if (!Z[b]) return set_error(SG_ERR_INVALID, "sl_act_norm: null branch input");
+    if (n && !Z[b]) return set_error(SG_ERR_INVALID, "sl_act_norm: null branch input");
     if (act[b] < 0 || act[b] > 4) return set_error(SG_ERR_INVALID, "sl_act_norm: unknown activation %d", act[b]);
   }
   return SG_OK;
@@ -1135,10 +1136,10 @@ extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *l
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p,
                                uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, void *stream_) {
-  int rc = act_norm_check(nb, F, seg, d_Z, act);
+  int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
-  if (!d_scale || !d_offset || !d_out) return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: null argument");
   if (n == 0) return SG_OK;
+  if (!d_scale || !d_offset || !d_out) return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: null argument");
   ActNormParams p;
   memset(&p, 0, sizeof(p));
   for (int b = 0; b < nb; b++) { p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.bias[b] = d_bias ? d_bias[b] : nullptr; }
@@ -1160,7 +1161,7 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                                float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                                const float *d_dout_dropped, int64_t lddo_dropped, void *stream_) {
-  int rc = act_norm_check(nb, F, seg, d_Z, act);
+  int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
   if (!d_scale || !d_offset || (!d_dout && !d_dout_dropped) || !d_dscale || !d_doffset || !d_dZ)
     return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: null argument");

@@ -309,8 +309,12 @@ def can_fuse_out_dropout(F: int, seg: Optional[int] = None) -> bool:
     seg = F if seg is None else seg
     if not (F % 4 == 0 and 16 <= F <= 256 and seg % 4 == 0 and F % seg == 0):
         return False
-    ls = seg // 4
-    return seg == F or (ls & (ls - 1)) == 0
+    lpr = 4                                  # lanes per row: the power of two covering F / 4 float4 lanes
+    while lpr * 4 < F:
+        lpr *= 2
+    ls = lpr if seg == F else seg // 4       # lanes per normalisation segment
+    # the instantiations of act_norm_launch (csrc/aggregate.hip)
+    return (lpr, ls) in {(64, 64), (64, 32), (64, 16), (64, 8), (32, 32), (32, 16), (32, 8), (16, 16), (16, 8), (8, 8), (4, 4)}
 
 
 def new_dropout_seed() -> int:

@@ -591,3 +591,57 @@ def test_gat_layer_any_head_width_matches_layer_oracle(dim, heads, act):
     np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-4)
     for k, q in layer.named_parameters():
         np.testing.assert_allclose(q.grad.cpu().numpy(), p[k].grad.numpy(), rtol=2e-3, atol=1e-3, err_msg=k)
+
+
+def test_degenerate_batches_and_empty_inputs():
+    """Single-node subgraphs, subgraphs without edges, one root, zero-row operands: every layer family trains
+    (full stack and target-only tail) and the kernels accept empty inputs."""
+    import scipy.sparse as sp
+    from shadow_gnn_amd import ops
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    for aggr in ("sage", "gcn", "gat"):
+        for B, n_per, selfloop in ((1, 1, False), (5, 1, True), (3, 2, False)):
+            blocks = [sp.csr_matrix(np.eye(n_per, dtype=np.float32) if selfloop else np.zeros((n_per, n_per), dtype=np.float32))
+                      for _ in range(B)]
+            A = sp.block_diag(blocks, format="csr"); n = A.shape[0]
+            arch = dict(num_layers=2, num_cls_layers=1, heads=2 if aggr == "gat" else 1, branch_sharing=False, dim=16,
+                        act="relu", layer_norm="norm_feat", feature_augment_ops="sum", aggr=aggr, residue="none",
+                        pooling="center", loss="softmax", ensemble_act="relu")
+            torch.manual_seed(0)
+            m = DeepGNN(8, 8, 3, 0, arch, [], 1, dict(lr=0.01, dropout=0.1, dropedge=0.1), "node").to(DEV)
+            for prune in (False, True):
+                m.prune_tail = prune
+                bt = OneBatchSubgraph([_csr(A.indptr, A.indices)], [torch.randn(n, 8, device=DEV)],
+                                      torch.randint(0, 3, (B,), device=DEV), torch.full((1, B), n_per, dtype=torch.int64, device=DEV),
+                                      [(torch.arange(B) * n_per).to(DEV)], [{}])
+                assert np.isfinite(float(m.step(TRAIN, "running", bt)["loss"].detach())), (aggr, B, n_per, prune)
+    X = torch.zeros(0, 64, device=DEV)
+    c = ops.DeviceCSR(torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV))
+    assert ops.spmm(ops.adj_norm_rw(c), X).shape == (0, 64)
+    assert ops.act_norm([X], ["relu"], torch.ones(1, 64, device=DEV), torch.zeros(1, 64, device=DEV)).shape == (0, 64)
+    assert ops.gather_rows(torch.randn(10, 64, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV)).shape == (0, 64)
+
+
+def test_dropout_fusion_eligibility_matches_the_kernel_dispatch():
+    """ops.can_fuse_out_dropout must say yes exactly for the (F, segment) layouts sl_act_norm_fwd runs on its
+    vector kernels: a yes the library refuses would abort training (found with dim 16 / 2 heads)."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    yes = no = 0
+    for F in range(4, 264, 4):
+        for seg in sorted({F, F // 2, F // 4, 8, 4, 16, 64}):
+            if seg <= 0 or F % seg or seg % 4:
+                continue
+            Z = torch.randn(37, F, device=DEV, generator=g)
+            sc, of = torch.ones(1, F, device=DEV), torch.zeros(1, F, device=DEV)
+            if ops.can_fuse_out_dropout(F, seg):
+                out = ops.act_norm([Z], ["relu"], sc, of, seg=seg, out_dropout=0.5)     # must not raise
+                assert out.shape == Z.shape and bool((out == 0).any())
+                yes += 1
+            else:
+                with pytest.raises(ValueError):
+                    ops.act_norm([Z], ["relu"], sc, of, seg=seg, out_dropout=0.5)
+                ops.act_norm([Z], ["relu"], sc, of, seg=seg)                              # without dropout: any layout
+                no += 1
+    assert yes > 20 and no > 20
