@@ -645,3 +645,14 @@ def test_dropout_fusion_eligibility_matches_the_kernel_dispatch():
                 ops.act_norm([Z], ["relu"], sc, of, seg=seg)                              # without dropout: any layout
                 no += 1
     assert yes > 20 and no > 20
+
+
+def test_layer_fuzz_against_oracle():
+    """60 seeded draws of (layer family, widths incl. odd and > 256, activation incl. PReLU, heads, graph with isolated
+    rows / hubs / directed edges): outputs and every gradient vs the dense layer oracle (scripts/fuzz_layers.py)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_layers", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_layers.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    failures = mod.run(2, 60, verbose=False)
+    assert not failures, failures[:3]
