@@ -656,3 +656,15 @@ def test_layer_fuzz_against_oracle():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     failures = mod.run(2, 60, verbose=False)
     assert not failures, failures[:3]
+
+
+def test_model_fuzz_against_oracle():
+    """40 seeded random architectures (family, depth, width, heads, activation, residue, pooling, hop augmentation) on
+    ragged block-diagonal batches: predictions, loss and every parameter gradient vs the layer oracle, and the
+    target-only tail vs the full stack where it applies (scripts/fuzz_models.py)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_models", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_models.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    failures = mod.run(1, 40, verbose=False)
+    assert not failures, failures[:3]
