@@ -819,12 +819,22 @@ __global__ void act_norm_finish_kernel(const float *__restrict__ partial, uint32
   }
 }
 
-// generic fallback: one wavefront per row, any F / seg (seg divides F), scalar accesses
-template <bool BWD>
+// generic fallback: one wavefront per row, any F / seg (seg divides F), scalar accesses.
+// kLds (backward): the scale / offset / bias gradients are accumulated per wavefront in LDS ([wave][nb][3][F], every
+// column belongs to one lane, rows go in order), combined per block in wavefront order and left in p.partial for
+// act_norm_finish_kernel -- the same fixed-order reduction as the vector kernels, bit-reproducible.  Without it
+// (F too wide for the LDS) the sums use float atomics.
+template <bool BWD, bool kLds>
 __global__ void act_norm_generic_kernel(ActNormParams p) {
+  extern __shared__ float an_sm[];
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const float inv_seg = 1.0f / (float)p.seg;
+  const uint32_t region = (uint32_t)p.nb * 3u * p.F;
+  float *my = an_sm + (size_t)(threadIdx.x >> 6) * region;
+  if (BWD && kLds) {
+    for (uint32_t i = lane; i < region; i += 64) my[i] = 0.f;
+  }
   for (uint64_t r = wave; r < p.n; r += nwaves) {
     for (uint32_t s0 = 0; s0 < p.F; s0 += p.seg) {
       for (int b = 0; b < p.nb; b++) {
@@ -850,8 +860,13 @@ __global__ void act_norm_generic_kernel(ActNormParams p) {
           for (uint32_t k = lane; k < p.seg; k += 64) {
             const float xh = (act_fwd(p.act[b], SHD_ZB(k)) - mean) * rstd;
             const float g = dy[k] * p.out_scale;
-            atomicAdd(p.dscale + (size_t)b * p.F + s0 + k, g * xh);
-            atomicAdd(p.doffset + (size_t)b * p.F + s0 + k, g);
+            if (kLds) {
+              my[((size_t)b * 3 + 0) * p.F + s0 + k] += g * xh;
+              my[((size_t)b * 3 + 1) * p.F + s0 + k] += g;
+            } else {
+              atomicAdd(p.dscale + (size_t)b * p.F + s0 + k, g * xh);
+              atomicAdd(p.doffset + (size_t)b * p.F + s0 + k, g);
+            }
             a1 += g * sc[k]; a2 += g * sc[k] * xh;
           }
           const float m1 = wave_reduce_sum_f(a1) * inv_seg, m2 = wave_reduce_sum_f(a2) * inv_seg;
@@ -863,12 +878,24 @@ __global__ void act_norm_generic_kernel(ActNormParams p) {
               const float xh = (h - mean) * rstd;
               const float v = rstd * (dy[k] * p.out_scale * sc[k] - m1 - xh * m2) * act_bwd(p.act[b], zz, h);
               if (dz) dz[k] = v;
-              if (p.dbias) atomicAdd(p.dbias + (size_t)b * p.F + s0 + k, v);
+              if (p.dbias) {
+                if (kLds) my[((size_t)b * 3 + 2) * p.F + s0 + k] += v;
+                else atomicAdd(p.dbias + (size_t)b * p.F + s0 + k, v);
+              }
             }
           }
 #undef SHD_ZB
         }
       }
+    }
+  }
+  if (BWD && kLds) {
+    __syncthreads();
+    const uint32_t nw = blockDim.x >> 6;
+    for (uint32_t i = threadIdx.x; i < region; i += blockDim.x) {
+      float acc = 0.f;
+      for (uint32_t w = 0; w < nw; w++) acc += an_sm[(size_t)w * region + i];
+      p.partial[(size_t)blockIdx.x * region + i] = acc;
     }
   }
 }
@@ -1100,13 +1127,22 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
                                      "16-byte aligned operands); apply dropout separately for this shape");
   if (!done) {
     const uint32_t g = grid_for((uint64_t)p.n * 64, kBlock, 256 * 8);
-    if (bwd) {
+    const size_t lds = (size_t)(kBlock / 64) * p.nb * 3 * p.F * sizeof(float);
+    if (bwd && lds <= 144 * 1024) {
+      // deterministic: per-wavefront LDS partials -> per-block partials -> fixed-order finish
+      if (lds > 64 * 1024)
+        SHD_HIP(hipFuncSetAttribute((const void *)act_norm_generic_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((act_norm_generic_kernel<true, true>), dim3(g), dim3(kBlock), lds, st, p);
+      hipLaunchKernelGGL(act_norm_finish_kernel, dim3((p.F + 63) / 64, p.nb * 3), dim3(1024), 0, st, p.partial, g, p.nb, p.F,
+                         p.dscale, p.doffset, p.dbias);
+    } else if (bwd) {
       SHD_HIP(hipMemsetAsync(p.dscale, 0, (size_t)p.nb * p.F * 4, st));
       SHD_HIP(hipMemsetAsync(p.doffset, 0, (size_t)p.nb * p.F * 4, st));
       if (p.dbias) SHD_HIP(hipMemsetAsync(p.dbias, 0, (size_t)p.nb * p.F * 4, st));
+      hipLaunchKernelGGL((act_norm_generic_kernel<true, false>), dim3(g), dim3(kBlock), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((act_norm_generic_kernel<false, false>), dim3(g), dim3(kBlock), 0, st, p);
     }
-    if (bwd) hipLaunchKernelGGL(act_norm_generic_kernel<true>, dim3(g), dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL(act_norm_generic_kernel<false>, dim3(g), dim3(kBlock), 0, st, p);
   }
   SHD_HIP(hipGetLastError());
   return SG_OK;
