@@ -355,7 +355,8 @@ int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float 
                uint32_t F, uint32_t heads, float *d_hn, float *d_u_s, float *d_u_n, float *d_mx,
                float *d_den, float *d_nagg, void *stream);
 /* Backward: dz_self (attention part only), dz_neigh, datt[2,heads,D].
- * d_work: float[2*e*heads + n*heads].                                         */
+ * d_work: float[2*e*heads + n*heads + 4096*F] (per-edge alpha / de, du_s, and the per-block partial sums of
+ * datt, which are added in block order: no float atomics, bit-reproducible).                */
 int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
                const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
                const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,

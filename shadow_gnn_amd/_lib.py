@@ -121,7 +121,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 5      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -72,7 +72,8 @@ struct GatParams {
   float *alpha, *de;                      // [e, H]
   float *du_s;                            // [n, H]
   float *dz_self, *dz_neigh;              // [n, F]
-  float *datt;                            // [2, H, D] (+=)
+  float *datt;                            // [2, H, D]
+  float *datt_part;                       // [gridDim.x][2][F] per-block sums, reduced in block order (gat_datt_finish_kernel)
 };
 
 template <int LPR>
@@ -177,7 +178,7 @@ __global__ void gat_row_bwd_kernel(GatParams p) {
     float s4[4] = {0, 0, 0, 0};
     for (uint32_t q = 0; q < rpb; q++)
       for (int k = 0; k < 4; k++) s4[k] += red[(q * LPR + l) * 4 + k];
-    for (int k = 0; k < 4; k++) atomicAdd(p.datt + f + k, s4[k]);
+    for (int k = 0; k < 4; k++) p.datt_part[((size_t)blockIdx.x * 2 + 0) * p.F + f + k] = s4[k];
   }
 }
 
@@ -221,8 +222,22 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
     float s4[4] = {0, 0, 0, 0};
     for (uint32_t q = 0; q < rpb; q++)
       for (int k = 0; k < 4; k++) s4[k] += red[(q * LPR + l) * 4 + k];
-    for (int k = 0; k < 4; k++) atomicAdd(p.datt + p.F + f + k, s4[k]);
+    for (int k = 0; k < 4; k++) p.datt_part[((size_t)blockIdx.x * 2 + 1) * p.F + f + k] = s4[k];
   }
+}
+
+// datt[j] = sum over blocks of datt_part[block][j], fixed order (bit-reproducible; no float atomics)
+__global__ void gat_datt_finish_kernel(const float *__restrict__ part, uint32_t nblocks, uint32_t len, float *__restrict__ datt) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t b = 0;
+  for (; b + 4 <= nblocks; b += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] += part[(size_t)(b + k) * len + j];
+  }
+  for (int k = 0; b < nblocks; b++, k++) acc[k] += part[(size_t)b * len + j];
+  datt[j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 static uint32_t gat_grid(uint32_t n, uint32_t lpr) {
@@ -296,8 +311,7 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   int rc = gat_check(F, heads, &lpr);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream_;
-  SHD_HIP(hipMemsetAsync(d_datt, 0, (size_t)2 * F * 4, st));
-  if (n == 0) return SG_OK;
+  if (n == 0) { SHD_HIP(hipMemsetAsync(d_datt, 0, (size_t)2 * F * 4, st)); return SG_OK; }
   GatParams p;
   memset(&p, 0, sizeof(p));
   p.indptr = d_indptr; p.indices = d_indices; p.t_indptr = d_t_indptr; p.t_indices = d_t_indices; p.t_perm = d_t_perm;
@@ -306,12 +320,14 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
   p.mx = const_cast<float *>(d_mx); p.den = const_cast<float *>(d_den); p.nagg = const_cast<float *>(d_nagg);
   p.dnagg = d_dnagg;
-  // work: alpha[e*H], de[e*H], du_s[n*H]
+  // work: alpha[e*H], de[e*H], du_s[n*H], datt_part[2048][2][F]
   p.alpha = d_work; p.de = d_work + (size_t)e * heads; p.du_s = p.de + (size_t)e * heads;
+  p.datt_part = p.du_s + (size_t)n * heads;
   p.dz_self = d_dz_self; p.dz_neigh = d_dz_neigh; p.datt = d_datt;
   const uint32_t g = gat_grid(n, lpr);
   SHD_GAT_LAUNCH(gat_row_bwd_kernel, lpr, g, st, p);
   SHD_GAT_LAUNCH(gat_col_bwd_kernel, lpr, g, st, p);
+  hipLaunchKernelGGL(gat_datt_finish_kernel, dim3((2 * F + 255) / 256), dim3(256), 0, st, p.datt_part, g, 2 * F, d_datt);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -38,7 +38,7 @@ class _GatAggregate(torch.autograd.Function):
         dev = z_self.device
         dnagg = ops._f32c(dnagg).contiguous()
         ti, tx, tp = c.transposed
-        work = torch.empty(2 * c.e * heads + n * heads + 4, device=dev)
+        work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
         dzs = torch.empty_like(z_self); dzn = torch.empty_like(z_neigh)
         datt = torch.empty(2, F, device=dev)
         w = adj.edge_w

@@ -220,8 +220,8 @@ def test_subgraph_cache_api_errors_and_growth():
     assert cache.is_empty()
 
 
-@pytest.mark.parametrize("prune_tail", [False, True])
-def test_training_is_bit_reproducible_with_and_without_prefetch(prune_tail):
+@pytest.mark.parametrize("aggr,prune_tail", [("sage", False), ("sage", True), ("gat", False), ("gcn", True)])
+def test_training_is_bit_reproducible_with_and_without_prefetch(aggr, prune_tail):
     """Same seeds -> the same loss sequence and the same parameters bit for bit, run to run and with the sampler
     prefetching on its side stream or not: no float atomics on the path (47 classes exercise the generic
     normalisation kernel, whose parameter gradients go through fixed-order partial sums) and no stream race."""
@@ -236,14 +236,16 @@ def test_training_is_bit_reproducible_with_and_without_prefetch(prune_tail):
     roots = np.random.default_rng(2).permutation(N)[:B * (steps + 1)]
 
     def run(prefetch):
-        mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots}, dict(method="khop", depth=2, budget=10, add_self_edge=False),
+        mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+                                       dict(method="khop", depth=2, budget=10, add_self_edge=(aggr != "sage")),
                                        (), feat, label, batch_size=B, device=DEV, seed_cpp=3, prefetch=prefetch)
         mb.epoch_start_reset(0, TRAIN); mb.shuffle_entity(TRAIN, perm=np.arange(roots.size))
         if prune_tail:
             mb.tail_plan_layers = 3
+            mb.tail_plan_square = aggr == "gat"
         torch.manual_seed(4)
-        arch = dict(num_layers=3, num_cls_layers=1, heads=1, dim=64, act="relu", layer_norm="norm_feat", feature_augment_ops="sum",
-                    aggr="sage", residue="none", pooling="center", loss="softmax")
+        arch = dict(num_layers=3, num_cls_layers=1, heads=(4 if aggr == "gat" else 1), dim=64, act="relu", layer_norm="norm_feat",
+                    feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
         m = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=0.3, dropedge=0.1, lr=0.01), "node").to(DEV)
         m.prune_tail = prune_tail
         losses = [m.step(TRAIN, "running", mb.one_batch(TRAIN))["loss"].detach() for _ in range(steps)]
