@@ -60,6 +60,11 @@ WORKLOADS = {
                                aggr="sage", layers=5, dim=256, act="relu", heads=1, aug=(), batch=1024,
                                dropout=0.4, dropedge=0.05, lr=0.002, residue="max", pooling="mean",
                                ppr=dict(alpha=0.85, epsilon=1e-5)),
+    # BASELINE.json configs[4] shape: papers100M (111 M nodes, 3.2 G directed edges: 13.4 GB CSR + 57 GB features resident
+    # in one GPU's 288 GB), PPR top-k = 200, SAGE-5; 256 roots per GPU = the configuration's global batch of 2048 on 8 GPUs
+    "papers100M-ppr-sage5": dict(shape="papers100M", sampler=dict(method="ppr", k=200, threshold=0.0, add_self_edge=False),
+                                 aggr="sage", layers=5, dim=256, act="relu", heads=1, aug=(), batch=256,
+                                 dropout=0.4, dropedge=0.05, lr=0.002, ppr=dict(alpha=0.85, epsilon=1e-5)),
     # BASELINE.json configs[3] shape (k-hop depth 3, GAT-5, 4 heads)
     "products-khop3-gat5": dict(shape="products", sampler=dict(method="khop", depth=3, budget=20, add_self_edge=True),
                                 aggr="gat", layers=5, dim=256, act="elu", heads=4, aug=(), batch=64,
