@@ -24,7 +24,7 @@ Rank 0 prints ONE JSON line.  metric/unit follow BASELINE.json:
   cpu_baseline_train_step  the other half of the reference's CPU path: the training step in CPU
                       PyTorch (oracle/cpu_train_step.py) on 1/8 of one benchmark batch, scaled to steps/s
   target_only_tail    the same step with the opt-in exact dead-row elimination (shadow_gnn_amd/tail.py),
-                      10 extra steps after the timed region; never part of `value`
+                      10 extra steps after the timed region (single-GPU runs); never part of `value`
 """
 import argparse
 import json
