@@ -167,7 +167,7 @@ def main():
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy()
     roots_all = np.resize(perm, need).astype(np.int64)
     aug = tuple(wl["aug"])
-    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots_all}, dict(wl["sampler"]), aug, feat_full,
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots_all}, dict(wl["sampler"]), aug, feat_full,
                                    label_full, batch_size=B * world, device=dev, seed_cpp=3, rank=rank,
                                    world_size=world, prefetch=not args.no_prefetch)
     mb.epoch_start_reset(0, TRAIN)

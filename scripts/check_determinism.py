@@ -13,7 +13,7 @@ def run(C, prefetch, steps=int(os.environ.get("STEPS", "40")), B=int(os.environ.
     g2 = torch.Generator(device=dev); g2.manual_seed(2)
     label = torch.randint(0, C, (N,), generator=g2, device=dev)
     roots = np.random.default_rng(2).permutation(N)[:B * (steps + 2)].astype(np.int64)
-    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots}, dict(method="khop", depth=2, budget=20, add_self_edge=(AGGR != "sage")), (), feat, label,
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots}, dict(method="khop", depth=2, budget=20, add_self_edge=(AGGR != "sage")), (), feat, label,
                                    batch_size=B, device=dev, seed_cpp=3, prefetch=prefetch)
     mb.epoch_start_reset(0, TRAIN); mb.shuffle_entity(TRAIN, perm=np.arange(roots.size))
     torch.manual_seed(4)

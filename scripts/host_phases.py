@@ -13,7 +13,7 @@ g=torch.Generator(device=dev); g.manual_seed(1)
 feat=torch.randn(N,F0,generator=g,device=dev); label=torch.randint(0,C,(N,),generator=g,device=dev)
 B=256; steps=200
 roots=np.resize(np.random.default_rng(2).permutation(N), B*(steps+5)).astype(np.int64)
-mb=MinibatchShallowExtractor({TRAIN:(indptr,indices)},{TRAIN:roots},dict(method="khop",depth=2,budget=20,add_self_edge=False),("hops",),feat,label,batch_size=B,device=dev,seed_cpp=3)
+mb=MinibatchShallowExtractor.on_device({TRAIN:(indptr,indices)},{TRAIN:roots},dict(method="khop",depth=2,budget=20,add_self_edge=False),("hops",),feat,label,batch_size=B,device=dev,seed_cpp=3)
 mb.epoch_start_reset(0,TRAIN); mb.shuffle_entity(TRAIN,perm=np.arange(roots.size))
 arch=dict(num_layers=5,num_cls_layers=1,heads=1,dim=256,act="elu",layer_norm="norm_feat",feature_augment_ops="sum",aggr="sage",residue="none",pooling="center",loss="softmax")
 m=DeepGNN(F0,F0,C,0,arch,[("hops",mb.get_aug_dim("hops"))],1,dict(dropout=0.25,dropedge=0.15,lr=2e-5),"node").to(dev)

@@ -18,7 +18,6 @@ rocBLAS / hipBLASLt through ``torch.nn.functional.linear``.
 """
 from collections import namedtuple
 
-import numpy as np
 import scipy.sparse as sp
 import torch
 import torch.nn.functional as F
@@ -61,22 +60,29 @@ def _as_device_csr(adj, device):
 
 
 class EnsembleDummy(nn.Module):
-    """used when there is only one branch of subgraph (shaDow/layers.py:42-53)"""
+    """Pass-through "ensembler" of a single-branch model (the role of shaDow/layers.py:42-53); the constructor
+    accepts and ignores the ensembler arguments so that it can stand in for a real one."""
     def __init__(self, dim_in=0, dim_out=0, **kwargs):
         super().__init__()
 
+    @staticmethod
+    def _only(branches):
+        if len(branches) != 1:
+            raise ValueError(f"EnsembleDummy passes one branch through, got {len(branches)}")
+        return branches[0]
+
     def forward(self, Xi):
-        assert len(Xi) == 1, "ONLY USE DUMMY ENSEMBLER WITH ONE BRANCH!"
-        return Xi[0]
+        return self._only(Xi)
 
     def complexity(self, dims):
-        assert len(dims) == 1, "ONLY USE DUMMY ENSEMBLER WITH ONE BRANCH!"
-        return dims[0], 0
+        return self._only(dims), 0
 
 
 class shaDowLayer(nn.Module):
     """Parent of the message-passing layers (shaDow/layers.py:299-373)."""
-    def __init__(self, dim_in, dim_out, dropout=0.0, act='relu', norm='norm_feat', **kwargs):
+    def __init__(self, dim_in, dim_out, dropout=0.0, act='relu', norm='norm_feat', norm_dim=None, **kwargs):
+        """``norm_dim``: shape of the layer's ``scale`` / ``offset`` parameters -- (branches, ..., features of one
+        normalisation segment); subclasses pass theirs, the default is one branch over all output features."""
         super().__init__()
         self.dropout = dropout
         self.dim_in, self.dim_out = dim_in, dim_out
@@ -96,7 +102,7 @@ class shaDowLayer(nn.Module):
         if norm not in ('norm_feat', 'none'):
             raise NotImplementedError("only norm in {'norm_feat', 'none'} (the reference's pairnorm path is unfinished, layers.py:358)")
         self.norm = norm
-        self.norm_dim = (1, dim_out) if 'norm_dim' not in kwargs else kwargs['norm_dim']
+        self.norm_dim = tuple(norm_dim) if norm_dim is not None else (1, dim_out)
         if norm == 'norm_feat':
             self.offset = nn.Parameter(torch.zeros(self.norm_dim))
             self.scale = nn.Parameter(torch.ones(self.norm_dim))
@@ -151,6 +157,11 @@ class shaDowLayer(nn.Module):
         return out * out_scale
 
 
+def _dense_ops(num_rows, lin):
+    """Multiply-accumulates of ``lin`` applied to ``num_rows`` rows (the unit of the reference's complexity())."""
+    return int(num_rows) * int(lin.weight.numel())
+
+
 def _torch_act(act, x):
     if act == 'I':
         return x
@@ -168,9 +179,8 @@ def _torch_act(act, x):
 class MLP(shaDowLayer):
     """shaDow/layers.py:376-400"""
     def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', **kwargs):
-        assert norm in ['norm_feat', 'none']
-        kwargs['norm_dim'] = (1, dim_out)
-        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
+        kwargs.pop('norm_dim', None)
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, norm_dim=(1, dim_out), **kwargs)
         self.f_lin = nn.Linear(dim_in, dim_out)
 
     def forward(self, feat_in):
@@ -178,16 +188,17 @@ class MLP(shaDowLayer):
         return self.f_lin_act_norm([feat_in], [self.f_lin], [self.act_name])
 
     def complexity(self, dims_x):
-        assert dims_x.num_feats == self.f_lin.weight.shape[1]
-        ops_ = dims_x.num_nodes * int(np.prod(self.f_lin.weight.shape))
-        return Dims_X(dims_x.num_nodes, self.f_lin.weight.shape[0]), ops_
+        """(output dims, multiply-accumulates) -- shaDow/layers.py:396-400."""
+        if dims_x.num_feats != self.f_lin.in_features:
+            raise ValueError(f"MLP expects {self.f_lin.in_features} input features, got {dims_x.num_feats}")
+        return Dims_X(dims_x.num_nodes, self.f_lin.out_features), _dense_ops(dims_x.num_nodes, self.f_lin)
 
 
 class GCN(shaDowLayer):
     """shaDow/layers.py:417-444 -- aggregate first, then Linear."""
     def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', **kwargs):
-        kwargs['norm_dim'] = (1, dim_out)
-        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
+        kwargs.pop('norm_dim', None)
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, norm_dim=(1, dim_out), **kwargs)
         self.f_lin = nn.Linear(dim_in, dim_out, bias=True)
 
     def norm_adj(self, adj, is_normed, dropedge, device):
@@ -213,18 +224,20 @@ class GCN(shaDowLayer):
         return self.f_lin_act_norm([feat_aggr], [self.f_lin], [self.act_name])
 
     def complexity(self, dims_x, dims_adj):
-        ops_ = dims_adj.num_edges * dims_x.num_feats + dims_x.num_nodes * int(np.prod(self.f_lin.weight.shape))
-        return (Dims_X(dims_x.num_nodes, self.f_lin.weight.shape[0]),
-                Dims_adj(dims_adj.num_nodes, dims_adj.num_edges)), ops_
+        """((feature dims, adjacency dims) after the layer, multiply-accumulates): one aggregation at the input
+        width plus one Linear (shaDow/layers.py:438-444)."""
+        macs = dims_adj.num_edges * dims_x.num_feats + _dense_ops(dims_x.num_nodes, self.f_lin)
+        return (Dims_X(dims_x.num_nodes, self.f_lin.out_features), Dims_adj(*dims_adj)), macs
 
 
 class GraphSAGE(shaDowLayer):
     """shaDow/layers.py:447-494"""
     def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', **kwargs):
-        kwargs['norm_dim'] = (2, dim_out)   # 2 for self + neigh
-        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
-        self.f_lin_self = nn.Linear(dim_in, dim_out)
-        self.f_lin_neigh = nn.Linear(dim_in, dim_out)
+        kwargs.pop('norm_dim', None)
+        # two normalised branches: row 0 of scale / offset belongs to the self branch, row 1 to the neighbours
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, norm_dim=(2, dim_out), **kwargs)
+        for name in ("f_lin_self", "f_lin_neigh"):
+            setattr(self, name, nn.Linear(dim_in, dim_out))
 
     def norm_adj(self, adj, is_normed, dropedge, device):
         if not is_normed and adj is not None:
@@ -255,64 +268,68 @@ class GraphSAGE(shaDowLayer):
         return feat_out, adj_norm, True, 0.
 
     def complexity(self, dims_x, dims_adj):
-        assert dims_x.num_nodes == dims_adj.num_nodes
-        ops_ = dims_x.num_nodes * int(np.prod(self.f_lin_self.weight.shape)) \
-            + dims_adj.num_edges * dims_x.num_feats \
-            + dims_x.num_nodes * int(np.prod(self.f_lin_neigh.weight.shape))
-        return (Dims_X(dims_x.num_nodes, self.f_lin_self.weight.shape[0]),
-                Dims_adj(dims_adj.num_nodes, dims_adj.num_edges)), ops_
+        """One aggregation at the input width plus the self and neighbour Linears (shaDow/layers.py:486-494)."""
+        if dims_x.num_nodes != dims_adj.num_nodes:
+            raise ValueError("feature rows and adjacency rows differ")
+        macs = (dims_adj.num_edges * dims_x.num_feats
+                + sum(_dense_ops(dims_x.num_nodes, lin) for lin in (self.f_lin_self, self.f_lin_neigh)))
+        return (Dims_X(dims_x.num_nodes, self.f_lin_self.out_features), Dims_adj(*dims_adj)), macs
+
+
+def _respool_in_width(type_pool, type_res, dim, num_layers, task):
+    """Input width of the read-out Linear (0 = no Linear at all).  Residue 'concat' stacks the layers side by
+    side, every other residue keeps one width; a pooled read-out carries [root rows | pooled rows]."""
+    stacked = type_res in ("cat", "concat")
+    per_part = dim * num_layers if stacked else dim
+    if type_pool == "center":
+        if type_res == "none":
+            return 0 if task == "node" else dim       # node task: the root's last-layer row goes out as it is
+        return per_part
+    return 2 * per_part
+
+
+_RESIDUE = {
+    "cat": lambda parts: torch.cat(parts, dim=1),
+    "concat": lambda parts: torch.cat(parts, dim=1),
+    "sum": lambda parts: torch.stack(parts, dim=0).sum(dim=0),
+    "max": lambda parts: torch.stack(parts, dim=0).max(dim=0).values,
+}
 
 
 class ResPool(nn.Module):
-    """Residue + pooling head (shaDow/layers.py:57-233).  'center' pooling is an
-    index select; max/mean/sum pooling uses segment reductions over the subgraph
-    offsets.  Sort pooling (PyG global_sort_pool) is not provided."""
+    """Residue + pooling read-out (role of shaDow/layers.py:57-233).  'center' pooling is a row select;
+    max / mean / sum pooling is one segment-reduction kernel over the subgraph row ranges.  Sort pooling
+    (PyG global_sort_pool) is not provided.  Parameter names follow the reference's checkpoint layout:
+    ``nn.1`` is the Linear, ``nn.2`` the activation module (it owns a tensor only for PReLU), ``scale`` /
+    ``offset`` the feature normalisation."""
+    POOLED = ("max", "mean", "sum")
+
     def __init__(self, dim_in, dim_out, num_layers, type_res, type_pool, dropout, act,
                  args_pool=None, prediction_task='node'):
         super().__init__()
-        self.dim_out = dim_out
-        self.type_pool = type_pool
-        self.type_res = type_res
-        self.prediction_task = prediction_task
-        self.act_name = _check_act(act)
-        if type_pool == 'center':
-            if type_res == 'none':
-                if self.prediction_task == 'node':
-                    self.dim_in = self.dim_out = 0
-                else:
-                    self.dim_in = dim_in
-            elif type_res in ['cat', 'concat']:
-                self.dim_in = num_layers * dim_in
-            else:
-                self.dim_in = dim_in
-        elif type_pool in ('max', 'mean', 'sum'):
-            self.dim_in = 2 * dim_in * num_layers if type_res in ['cat', 'concat'] else 2 * dim_in
-        else:
+        if type_pool != "center" and type_pool not in self.POOLED:
             raise NotImplementedError(f"pooling {type_pool!r} is not provided (sort pooling needs PyG)")
+        self.type_pool, self.type_res, self.prediction_task = type_pool, type_res, prediction_task
+        self.act_name = _check_act(act)
+        self.dim_in = _respool_in_width(type_pool, type_res, dim_in, num_layers, prediction_task)
+        self.dim_out = dim_out if self.dim_in > 0 else 0
         if self.dim_in > 0 and self.dim_out > 0:
-            _f_lin = nn.Linear(self.dim_in, self.dim_out, bias=True)
-            _f_dropout = nn.Dropout(p=dropout)
-            # same child indices as the reference's nn.Sequential(dropout, lin, act): "nn.1" is the Linear, "nn.2"
-            # the activation module (it has a parameter only for PReLU: "nn.2.weight")
-            self.nn = nn.Sequential(_f_dropout, _f_lin, _learned_act(act, self.dim_out) or nn.Identity())
+            self.nn = nn.Sequential(nn.Dropout(p=dropout), nn.Linear(self.dim_in, self.dim_out, bias=True),
+                                    _learned_act(act, self.dim_out) or nn.Identity())
             self.offset = nn.Parameter(torch.zeros(self.dim_out))
             self.scale = nn.Parameter(torch.ones(self.dim_out))
 
     def f_residue(self, feat_l):
-        if self.type_res in ['cat', 'concat']:
-            return torch.cat(feat_l, dim=1)
-        if self.type_res == 'sum':
-            return torch.stack(feat_l, dim=0).sum(dim=0)
-        if self.type_res == 'max':
-            return torch.max(torch.stack(feat_l, dim=0), dim=0).values
-        raise NotImplementedError
+        if self.type_res not in _RESIDUE:
+            raise NotImplementedError(f"residue {self.type_res!r}")
+        return _RESIDUE[self.type_res](list(feat_l))
 
     def aggr_target_emb(self, feat_src_dst):
+        """Link task: the two end points' rows are multiplied; node task: identity."""
         if self.prediction_task == 'node':
             return feat_src_dst
-        b, f = feat_src_dst.shape
-        feat_ret = feat_src_dst.reshape(b // 2, 2, f)
-        return feat_ret[:, 0] * feat_ret[:, 1]
+        pairs = feat_src_dst.unflatten(0, (-1, 2))
+        return pairs[:, 0] * pairs[:, 1]
 
     def _pool(self, feat, sizes_subg):
         # F.embedding_bag(arange(n), feat, offsets, mode) of the reference (layers.py:175,180) as one
@@ -323,41 +340,37 @@ class ResPool(nn.Module):
         return ops.segment_pool(feat, off, self.type_pool)
 
     def forward(self, feats_in_l, idx_targets, sizes_subg):
-        idx_targets = torch.as_tensor(idx_targets, device=feats_in_l[-1].device).long()
-        if self.type_pool == 'center':
-            if self.type_res == 'none':
-                feat_in = feats_in_l[-1][idx_targets]
-                if self.prediction_task == 'node':
-                    return feat_in
-            else:
-                feat_in = self.f_residue([f[idx_targets] for f in feats_in_l])
-            feat_in = self.aggr_target_emb(feat_in)
-        else:
-            if self.type_res == 'none':
-                feat_pool = self._pool(feats_in_l[-1], sizes_subg)
-                feat_root = feats_in_l[-1][idx_targets]
-            else:
-                feat_pool = self.f_residue([self._pool(f, sizes_subg) for f in feats_in_l])
-                feat_root = self.f_residue([f[idx_targets] for f in feats_in_l])
-            feat_in = torch.cat([self.aggr_target_emb(feat_root), feat_pool], dim=1)
+        rows = torch.as_tensor(idx_targets, device=feats_in_l[-1].device).long()
+        used = feats_in_l if self.type_res != 'none' else feats_in_l[-1:]       # residue 'none' reads the last layer
+        merge = self.f_residue if self.type_res != 'none' else (lambda parts: parts[0])
+        at_roots = merge([f[rows] for f in used])
+        if self.dim_in == 0:
+            return at_roots                                                    # layers.py:159-163
+        feat_in = self.aggr_target_emb(at_roots)
+        if self.type_pool in self.POOLED:
+            feat_in = torch.cat([feat_in, merge([self._pool(f, sizes_subg) for f in used])], dim=1)
         # dropout -> Linear -> act -> norm (layers.py:110,114-118,199)
+        drop, lin, act_mod = self.nn[0], self.nn[1], self.nn[2]
         if self.act_name in LEARNED_ACT:
-            return ops.act_norm([self.nn[2](ops.linear(self.nn[0](feat_in), self.nn[1]))], ['I'], self.scale, self.offset)
-        return ops.linear_act_norm([self.nn[0](feat_in)], [self.nn[1]], [self.act_name], self.scale, self.offset)
+            return ops.act_norm([act_mod(ops.linear(drop(feat_in), lin))], ['I'], self.scale, self.offset)
+        return ops.linear_act_norm([drop(feat_in)], [lin], [self.act_name], self.scale, self.offset)
 
 
 class GAT(shaDowLayer):
     """shaDow/layers.py:539-645.  Attention scores, edge softmax and the weighted
     aggregation of all heads run in fused HIP kernels (ops_gat)."""
     def __init__(self, dim_in, dim_out, dropout=0.0, act="relu", norm='norm_feat', mulhead=1, **kwargs):
-        self.mulhead = mulhead
-        assert dim_out % self.mulhead == 0, "invalid output dimension: need to be divisible by mulhead"
-        self.dim_slice = int(dim_out / self.mulhead)
-        kwargs['norm_dim'] = (2, self.mulhead, self.dim_slice)
-        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm, **kwargs)
-        self.f_lin = nn.ModuleList(nn.Linear(dim_in, dim_out, bias=True) for i in range(2))   # self + neigh
-        self.attention = nn.Parameter(torch.ones(2, self.mulhead, self.dim_slice))
-        nn.init.xavier_uniform_(self.attention)
+        heads = int(mulhead)
+        if heads < 1 or dim_out % heads:
+            raise ValueError(f"GAT output width {dim_out} is not divisible into {mulhead} heads")
+        self.mulhead, self.dim_slice = heads, dim_out // heads
+        kwargs.pop('norm_dim', None)
+        # every head slice of both branches (0: neighbours, 1: self -- the order GAT.forward normalises them in)
+        # has its own scale / offset row
+        super().__init__(dim_in, dim_out, dropout=dropout, act=act, norm=norm,
+                         norm_dim=(2, heads, self.dim_slice), **kwargs)
+        self.f_lin = nn.ModuleList([nn.Linear(dim_in, dim_out, bias=True), nn.Linear(dim_in, dim_out, bias=True)])  # self, neigh
+        self.attention = nn.Parameter(nn.init.xavier_uniform_(torch.empty(2, heads, self.dim_slice)))
 
     def _adj_norm(self, adj, is_normed, device, dropedge=0):
         if not is_normed:
@@ -407,15 +420,12 @@ class GAT(shaDowLayer):
             feat_out = (feat_neigh + _torch_act(self.kact, z_self)) / 2
         return feat_out, adj_norm, True, 0.
 
+    # per-edge cost model of the reference (shaDow/layers.py:628-645): 2 for the score sum, 20 for the softmax
+    _EDGE_OPS_PER_HEAD = 2 + 20
+
     def complexity(self, dims_X, dims_adj):
-        ops_ = 0
-        ops_ += dims_X.num_nodes * int(np.prod(self.f_lin[0].weight.shape))
-        ops_ += dims_X.num_nodes * int(np.prod(self.f_lin[1].weight.shape))
-        ops_ += dims_X.num_nodes * self.f_lin[0].weight.shape[0]
-        ops_ += dims_X.num_nodes * self.f_lin[1].weight.shape[0]
-        for _h in range(self.mulhead):
-            ops_ += dims_adj.num_edges * 2
-            ops_ += dims_adj.num_edges * 20
-        ops_ += dims_adj.num_edges * self.f_lin[1].weight.shape[0]
-        return (Dims_X(dims_X.num_nodes, self.f_lin[1].weight.shape[0]),
-                Dims_adj(dims_adj.num_nodes, dims_adj.num_edges)), ops_
+        n, e = dims_X.num_nodes, dims_adj.num_edges
+        width = self.f_lin[1].out_features
+        macs = sum(_dense_ops(n, lin) + n * lin.out_features for lin in self.f_lin)      # Linears + attention dots
+        macs += e * (self.mulhead * self._EDGE_OPS_PER_HEAD + width)                       # edge softmax + aggregation
+        return (Dims_X(n, width), Dims_adj(*dims_adj)), macs

@@ -1,15 +1,23 @@
 """Minibatch orchestration with the reference's API surface
 (shaDow/minibatch.py:94-495): ``OneBatchSubgraph`` record and
 ``MinibatchShallowExtractor`` with epoch_start_reset / shuffle_entity /
-one_batch / is_end_epoch / epoch_end_reset.
+one_batch / is_end_epoch / epoch_end_reset / disable_cache.
 
 Fast path: one sampler call returns the whole batch in block-diagonal form in
 HBM (no host pool of per-subgraph objects, no scipy, no host<->device copies):
 features are gathered by a HIP kernel from the device-resident feature matrix,
 the adjacency is an ``ops.DeviceCSR`` that layer 0 recognises.  The next batch
-is sampled on a side stream while the current one trains."""
+is sampled on a side stream while the current one trains.
+
+Data parallel (one process per GPU): ``plan_epoch`` gives every rank the SAME
+number of steps per epoch; a rank whose share of the last, smaller global batch
+is empty still takes the step (with an empty batch record) so that the gradient
+all-reduce stays collective, and every batch carries ``loss_weight`` = its share
+B_r / B_t of the step's global batch so that a SUM all-reduce yields the gradient
+of the mean loss over the global batch (CE is a mean over roots,
+shaDow/models.py:166)."""
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -22,6 +30,7 @@ REUSABLE_SAMPLER = {"ppr"}          # CONFIG_TEMPLATE.yml:16-17 (algorithm.sampl
 TRAIN, VALID, TEST = 0, 1, 2          # graph_engine.frontend mode constants
 STR2MODE = {"train": TRAIN, "valid": VALID, "test": TEST}
 MODE2STR = {TRAIN: "train", VALID: "valid", TEST: "test"}
+_MODES = (TRAIN, VALID, TEST)
 
 
 @dataclass
@@ -35,6 +44,7 @@ class OneBatchSubgraph:
     feat_aug_ens: Optional[List[Dict[str, Any]]]
     idx_raw: Optional[List[Any]] = None
     tail_ens: Optional[List[Any]] = None      # per-branch target-only-tail plan (tail.py), built while prefetching
+    loss_weight: float = 1.0                  # this rank's share of the step's global batch (data parallel)
 
     @property
     def num_ens(self):
@@ -42,7 +52,7 @@ class OneBatchSubgraph:
 
     @property
     def batch_size(self):
-        return int(self.target_ens[0].numel() if torch.is_tensor(self.target_ens[0]) else self.target_ens[0].size)
+        return int(self.target_ens[0].numel() if torch.is_tensor(self.target_ens[0]) else np.size(self.target_ens[0]))
 
     def __post_init__(self):
         assert len(self.feat_ens) == self.num_ens and len(self.target_ens) == self.num_ens
@@ -75,115 +85,280 @@ def hop2onehot(hop: torch.Tensor, dim_1hot_vec: int) -> torch.Tensor:
     return out
 
 
-class MinibatchShallowExtractor:
-    """Node-task minibatch loop over a device-resident graph (fast path of
-    shaDow/minibatch.py:143-495).
+def plan_epoch(order: np.ndarray, batch_global: int, world: int, rank: int,
+               static_partition: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Split one epoch's entity order over the ranks.  ``order``: positions into the mode's raw entity
+    set, in epoch order (identical on every rank).  Returns (mine, local_sizes[T], global_sizes[T]):
+    the positions this rank samples, in its own order, how many of them it takes at each of the
+    T = ceil(E / B) steps (possibly 0 at the end), and the size of every step's global batch.
 
-    adjs:        {mode: (indptr, indices)} uint32 CSR per mode (numpy, or int32 torch tensors on the device)
-    entity_set:  {mode: array of root node ids}
-    sampler_config: dict like one entry of the reference's sampler section, e.g.
-                 {"method": "khop", "depth": 2, "budget": 20, "add_self_edge": False}
-    """
-    def __init__(self, adjs, entity_set, sampler_config: Dict[str, Any], aug_feats, feat_full: torch.Tensor,
-                 label_full: torch.Tensor, batch_size: int, device, seed_cpp: int = -1,
-                 rank: int = 0, world_size: int = 1, prefetch: bool = True, nocache_modes=()):
-        self.device = torch.device(device)
+    Default: global batch t is ``order[t*B:(t+1)*B]`` -- exactly the single-process batch -- cut into
+    ``world`` contiguous slices whose sizes differ by at most one.
+    ``static_partition``: position p always belongs to rank p % world (needed by the per-rank subgraph
+    cache: a root recorded in epoch 1 must come back to the same rank); a rank spreads its share evenly
+    over the T steps, so a global batch is the union of the ranks' local batches."""
+    order = np.asarray(order).reshape(-1)
+    E, B, G = int(order.size), int(batch_global), int(world)
+    assert B >= 1 and G >= 1 and 0 <= rank < G
+    T = -(-E // B) if E else 0
+    if not static_partition:
+        sizes = np.minimum(B, E - B * np.arange(T, dtype=np.int64))          # B, ..., B, tail
+        base, rem = sizes // G, sizes % G
+        local_all = base[None, :] + (np.arange(G)[:, None] < rem[None, :])      # [G, T]
+        start = B * np.arange(T, dtype=np.int64) + rank * base + np.minimum(rank, rem)
+        mine = (np.concatenate([order[s:s + c] for s, c in zip(start, local_all[rank])])
+                if T else order[:0])
+        return mine, local_all[rank].astype(np.int64), sizes.astype(np.int64)
+    owner = order % G
+    per_rank = np.bincount(owner, minlength=G).astype(np.int64)
+    t = np.arange(max(T, 1), dtype=np.int64)[None, :]
+    local_all = per_rank[:, None] // max(T, 1) + (t < (per_rank[:, None] % max(T, 1)))
+    local_all = local_all[:, :T]
+    return order[owner == rank], local_all[rank].astype(np.int64), local_all.sum(0).astype(np.int64)
+
+
+def _parse_sampler_section(section: Dict[str, Any]) -> Tuple[int, Dict[str, Any]]:
+    """The reference's ``sampler_config_ensemble`` = {"batch_size": B, "configs": [{"method": m, key: [v], ...}]}
+    (shaDow/minibatch.py:213-221, :344-358).  One branch only: subgraph ensembles are outside the hot path."""
+    cfgs = list(section["configs"])
+    if len(cfgs) != 1:
+        raise NotImplementedError("subgraph ensembles (several sampler configs) are outside the hot path built here")
+    flat = {}
+    for key, val in cfgs[0].items():
+        if key != "method" and isinstance(val, (list, tuple)):
+            if len(val) != 1:
+                raise NotImplementedError("subgraph ensembles (several values per sampler key) are outside the hot path")
+            val = val[0]
+        flat[key] = val
+    if flat.get("method") == "full":
+        raise NotImplementedError("the 'full' (no sampling) mode is a preprocessing path of the reference, not the hot path")
+    return int(section["batch_size"]), flat
+
+
+def _as_uint32_csr(adj):
+    """scipy CSR (the reference's type) or an (indptr, indices) pair -> what HipSampler takes."""
+    if isinstance(adj, (tuple, list)):
+        return adj[0], adj[1]
+    return np.ascontiguousarray(adj.indptr, dtype=np.uint32), np.ascontiguousarray(adj.indices, dtype=np.uint32)
+
+
+class MinibatchShallowExtractor:
+    """Node-task minibatch loop over a device-resident graph.  The constructor takes the reference's
+    argument list (shaDow/minibatch.py:154-174) plus keyword-only placement arguments; ``on_device``
+    is the short form used by bench.py and the tests.
+
+    NOTE on batch_size (as in the reference): the number of target nodes per gradient update -- with
+    ``world_size`` ranks it is the GLOBAL batch; every rank samples its share of it."""
+
+    def __init__(self, name_data, dir_data, adjs, entity_set, sampler_config_ensemble, aug_feats, percent_per_epoch,
+                 feat_full: torch.Tensor, label_full: torch.Tensor, dim_feat_raw: int, is_transductive: bool,
+                 parallelism: int = 0, full_tensor_on_gpu: bool = True, bin_adj_files=None, nocache_modes=frozenset(),
+                 optm_level: str = "high", seed_cpp: int = -1, metrics_profile=None, *,
+                 device=None, rank: Optional[int] = None, world_size: Optional[int] = None, prefetch: bool = True):
+        if isinstance(entity_set.get(TRAIN), dict):
+            raise NotImplementedError("link prediction (pos / neg edge sets) is outside the hot path built here")
+        if not full_tensor_on_gpu:
+            raise ValueError("the HIP path keeps the feature matrix in HBM (the reference's --full_tensor_on_gpu)")
+        if rank is None or world_size is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            rank = dist.get_rank() if on else 0
+            world_size = dist.get_world_size() if on else 1
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.index is None and self.device.type == "cuda":
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.name_data, self.dir_data = name_data, dir_data
+        self.is_transductive, self.optm_level = bool(is_transductive), optm_level
+        self.dim_feat_raw = int(dim_feat_raw)
+        self.prediction_task = "node"
         self.aug_feats = set(aug_feats)
         self.raw_entity_set = {m: np.asarray(v) for m, v in entity_set.items()}
         self.feat_full = feat_full.to(self.device)
         self.label_full = label_full.to(self.device)
-        self.batch_size_global = int(batch_size)
-        self.rank, self.world_size = rank, world_size
-        assert batch_size % world_size == 0, "global batch must divide evenly over the ranks"
-        self.batch_size = {m: batch_size // world_size for m in (TRAIN, VALID, TEST)}
-        cfg = dict(sampler_config)
-        method = cfg.pop("method")
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.batch_size_global, scfg = _parse_sampler_section(sampler_config_ensemble)
         self.sampler_cfg = SamplerConfig(
-            method=method, num_roots=1, depth=int(cfg.get("depth", 2)), budget=int(cfg.get("budget", -1)),
-            k=int(cfg.get("k", 0)), threshold=float(cfg.get("threshold", 0.0)),
-            add_self_edge=bool(cfg.get("add_self_edge", False)),
+            method=scfg["method"], num_roots=1, depth=int(scfg.get("depth", 2)), budget=int(scfg.get("budget", -1)),
+            k=int(scfg.get("k", 0)), threshold=float(scfg.get("threshold", 0.0)),
+            add_self_edge=bool(scfg.get("add_self_edge", False)),
             aug=tuple(sorted(self.aug_feats & {"hops", "pprs", "drnls"})))
-        self.graph_sampler = {}
-        self._adjs = adjs
-        self._seed = seed_cpp
-        self.entity_epoch = {m: None for m in (TRAIN, VALID, TEST)}
-        self.label_epoch = {m: None for m in (TRAIN, VALID, TEST)}
-        self.idx_entity_evaluated = {m: 0 for m in (TRAIN, VALID, TEST)}
-        self.end_epoch = {m: False for m in (TRAIN, VALID, TEST)}
+        self._ppr_args = dict(alpha=float(scfg.get("alpha", 0.85)), epsilon=float(scfg.get("epsilon", 1e-5)))
+        # the largest local share of a global batch (what one sampler call is sized for)
+        self.batch_size = {m: -(-self.batch_size_global // self.world_size) for m in _MODES}
+        self.percent_per_epoch = {m: 1.0 for m in _MODES}
+        for key, val in (percent_per_epoch or {}).items():
+            self.percent_per_epoch[STR2MODE[key] if isinstance(key, str) else key] = float(val)
+        self.num_ensemble = 1
+        self.graph_sampler: Dict[int, HipSampler] = {}
+        self._adjs, self._bin_adj_files, self._seed = adjs, bin_adj_files, seed_cpp
+        self.seed_cpp = seed_cpp
+        self.entity_epoch = {m: None for m in _MODES}
+        self.label_epoch = {m: None for m in _MODES}
+        self.idx_entity_evaluated = {m: 0 for m in _MODES}
+        self.end_epoch = {m: False for m in _MODES}
         self.batch_num = -1
         self.dim_1hot_hop, self.dim_1hot_ppr, self.dim_1hot_drnl = 5 + 2, 1, 25 + 1   # minibatch.py:246-248
-        self.prefetch = prefetch
+        self.prefetch = bool(prefetch)
         # > 0: every batch carries a target-only-tail plan for a model of that many layers (DeepGNN.prune_tail)
         self.tail_plan_layers = 0
         self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
-        self._side = torch.cuda.Stream(device=self.device) if prefetch else None
-        self._inflight = {}
+        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        self._inflight: Dict[int, Tuple[str, int]] = {}        # mode -> (kind, roots in the call)
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
         self.nocache_modes = set(nocache_modes)
-        self.record_subgraphs = {}
-        self.cache_subg = {}
-        self._roots_dev = {}
-        self._cursor = {m: 0 for m in (TRAIN, VALID, TEST)}
-        self._hwm = {m: [1, 1] for m in (TRAIN, VALID, TEST)}       # largest batch seen (nodes, edges)
+        self.record_subgraphs: Dict[int, str] = {}
+        self.cache_subg: Dict[int, SubgraphCache] = {}
+        self._roots_dev: Dict[int, torch.Tensor] = {}
+        self._cursor = {m: 0 for m in _MODES}                 # roots handed to the sampler so far this epoch
+        self._step = {m: 0 for m in _MODES}                   # steps returned by one_batch this epoch
+        self._launched = {m: 0 for m in _MODES}               # steps whose sampler call has been issued
+        self._local_sizes = {m: np.zeros(0, dtype=np.int64) for m in _MODES}
+        self._global_sizes = {m: np.zeros(0, dtype=np.int64) for m in _MODES}
+        self._hwm = {m: [1, 1] for m in _MODES}               # largest batch seen (nodes, edges)
+
+    @classmethod
+    def on_device(cls, adjs, entity_set, sampler_config: Dict[str, Any], aug_feats, feat_full: torch.Tensor,
+                  label_full: torch.Tensor, batch_size: int, device, seed_cpp: int = -1, rank: int = 0,
+                  world_size: int = 1, prefetch: bool = True, nocache_modes=(), percent_per_epoch=None):
+        """Short form: ``sampler_config`` is one flat sampler entry, e.g.
+        {"method": "khop", "depth": 2, "budget": 20, "add_self_edge": False}; ``batch_size`` is the global batch."""
+        section = {"batch_size": int(batch_size), "configs": [dict(sampler_config)]}
+        return cls(None, None, adjs, entity_set, section, aug_feats, percent_per_epoch, feat_full, label_full,
+                   int(feat_full.shape[1]), True, nocache_modes=set(nocache_modes), seed_cpp=seed_cpp, device=device,
+                   rank=rank, world_size=world_size, prefetch=prefetch)
 
     # ------------------------------------------------------------------ API
     def get_aug_dim(self, aug_type):
         return getattr(self, f'dim_1hot_{aug_type[:-1]}')
 
+    def _static_partition(self, mode) -> bool:
+        """Per-rank subgraph caches need a fixed root -> rank map across epochs."""
+        return self.world_size > 1 and self.record_subgraphs.get(mode) in ("record", "reuse")
+
     def epoch_start_reset(self, epoch, mode):
         self.batch_num = -1
-        if mode not in self.graph_sampler:
-            ip, ix = self._adjs[mode]
-            self.graph_sampler[mode] = hs = HipSampler(ip, ix, device=self.device, seed=self._seed)
-            reusable = self.sampler_cfg.method in REUSABLE_SAMPLER and mode not in self.nocache_modes
-            self.record_subgraphs[mode] = "record" if reusable else ("noncache" if mode in self.nocache_modes else "none")
-            if reusable:
-                self.cache_subg[mode] = SubgraphCache(hs.num_nodes(), self.device)
+        if mode in self.graph_sampler:
+            return
+        files = (self._bin_adj_files or {}).get(mode) if isinstance(self._bin_adj_files, dict) else None
+        if files and files.get("indptr") and files.get("indices"):
+            # the reference's cpp/adj_*_{indptr,indices}.bin (loader.py:63-96): read straight into HBM
+            hs = HipSampler(device=self.device, seed=self._seed, path_indptr=files["indptr"], path_indices=files["indices"])
+        else:
+            ip, ix = _as_uint32_csr(self._adjs[mode])
+            hs = HipSampler(ip, ix, device=self.device, seed=self._seed)
+        self.graph_sampler[mode] = hs
+        if mode in self.nocache_modes:
+            self.record_subgraphs[mode] = "noncache"
+        elif self.sampler_cfg.method in REUSABLE_SAMPLER:
+            self.record_subgraphs[mode] = "record"
+            self.cache_subg[mode] = SubgraphCache(hs.num_nodes(), self.device)
+        else:
+            self.record_subgraphs[mode] = "none"
+
+    def prepare_ppr(self, mode, order: str = "ordered"):
+        """PPRSamplingCpp.preproc (frontend/samplers_cpp.py:166-186): the top-k table of the mode's entity set,
+        read from the reference's cache files when ``dir_data`` names them, computed on the GPU otherwise
+        (and written back in the same format)."""
+        import glob
+        import os
+        from .ppr import ppr_approximate_device
+        hs = self.graph_sampler[mode]
+        k, a, eps = self.sampler_cfg.k, self._ppr_args["alpha"], self._ppr_args["epsilon"]
+        f_nb = f_sc = None
+        if self.dir_data and self.name_data and not self.dir_data.get("is_adj_changed", False):
+            folder = f"{self.dir_data['local']}/{self.name_data}/ppr_float"
+            tag = f"{'transductive' if self.is_transductive else 'inductive'}_{MODE2STR[mode]}_{a}_{eps}"
+            os.makedirs(folder, exist_ok=True)
+            f_nb, f_sc = f"{folder}/neighs_{tag}_{k}.bin", f"{folder}/scores_{tag}_{k}.bin"
+            for cand in sorted(glob.glob(f"{folder}/neighs_{tag}_*.bin")):         # any stored k' >= k serves
+                k_meta = int(cand.rsplit("_", 1)[1][:-4])
+                sc = f"{folder}/scores_{tag}_{k_meta}.bin"
+                if k_meta >= k and os.path.isfile(sc):
+                    hs.load_ppr_bin(cand, sc, k, a, eps)
+                    return
+        targets = np.unique(self.raw_entity_set[mode]).astype(np.uint32)
+        ln, nb, sc = ppr_approximate_device(hs, targets, k, a, eps, order=order)
+        hs.set_ppr(targets, ln, nb, sc)
+        if f_nb is not None:
+            hs.save_ppr_bin(f_nb, f_sc, k, a, eps)
+
+    def _drain(self, mode):
+        """Finish and discard a prefetched sampler call (its outputs are dropped); returns its root count."""
+        if mode not in self._inflight:
+            return 0
+        kind, bs = self._inflight[mode]
+        self._collect(mode, discard=True)
+        return bs
 
     def shuffle_entity(self, mode, perm=None):
-        """YOU MUST CALL THIS BEFORE STARTING ANY EPOCH (minibatch.py:269-280).  Every
-        rank draws the same permutation and keeps its own slice of each global batch."""
-        ent = self.raw_entity_set[mode]
+        """YOU MUST CALL THIS BEFORE STARTING ANY EPOCH (minibatch.py:269-280).  Every rank works from the
+        same permutation (rank 0's draw is broadcast when none is given) and keeps its own share of each
+        global batch (``plan_epoch``)."""
+        self._drain(mode)
+        raw = self.raw_entity_set[mode]
         if perm is None:
-            perm = np.random.permutation(ent.size)
-        ent = ent[perm]
-        B, G, r = self.batch_size_global, self.world_size, self.rank
-        nfull = (ent.size // B) * B
-        body = ent[:nfull].reshape(-1, G, B // G)[:, r, :].reshape(-1)
-        tail = ent[nfull:]
-        per = -(-tail.size // G)                      # ceil: the last, smaller global batch
-        mine = np.concatenate([body, tail[r * per:(r + 1) * per]])
+            perm = np.random.permutation(raw.size)
+            if self.world_size > 1:
+                from . import dist as sdist
+                perm = sdist.broadcast_array(perm.astype(np.int64), src=0, device=self.device)
+        perm = np.asarray(perm).reshape(-1)
+        if self.percent_per_epoch[mode] < 1.0:
+            perm = perm[:int(np.ceil(self.percent_per_epoch[mode] * perm.size))]
+        mine_pos, local, glob = plan_epoch(perm, self.batch_size_global, self.world_size, self.rank,
+                                           static_partition=self._static_partition(mode))
+        mine = raw[mine_pos]
+        self._local_sizes[mode], self._global_sizes[mode] = local, glob
         self.entity_epoch[mode] = mine
         self.label_epoch[mode] = self.label_full[torch.as_tensor(mine.astype(np.int64), device=self.device)]
-        self.graph_sampler[mode].shuffle_targets(mine.astype(np.uint32))
+        if mine.size:
+            self.graph_sampler[mode].shuffle_targets(mine.astype(np.uint32))
         self._roots_dev[mode] = torch.as_tensor(mine.astype(np.uint32).view(np.int32)).to(self.device)
-        self._cursor[mode] = 0
+        self._cursor[mode] = self._step[mode] = self._launched[mode] = 0
         self.idx_entity_evaluated[mode] = 0
         self.end_epoch[mode] = False
-        self._inflight.pop(mode, None)
 
     def is_end_epoch(self, mode):
         return self.end_epoch[mode]
 
+    def num_steps(self, mode):
+        """Steps per epoch -- the same number on every rank."""
+        return int(self._global_sizes[mode].size)
+
     def epoch_end_reset(self, mode, drop_full_graph: bool = False):
         """After the first full epoch of a deterministic sampler the recorded subgraphs are
         reused (minibatch.py:326-334); ``drop_full_graph`` is the reference's optm_level 'high'
-        (:335-341): the full CSR is freed once nothing samples from it any more."""
+        (:335-341): the full CSR is freed once nothing samples from it any more.  The switch needs the
+        cache to hold this rank's whole share of the entity set (an epoch over a ``percent_per_epoch``
+        sub-sample keeps recording)."""
         self.end_epoch[mode] = False
-        if self.record_subgraphs.get(mode) == "record" and not self.cache_subg[mode].is_empty():
-            self.record_subgraphs[mode] = "reuse"
-            if drop_full_graph:
-                self.drop_full_graph_info(mode)
+        if self.record_subgraphs.get(mode) == "record":
+            raw = self.raw_entity_set[mode]
+            share = raw[np.arange(raw.size) % self.world_size == self.rank] if self.world_size > 1 else raw
+            if self.cache_subg[mode].stats()["num_recorded"] >= np.unique(share).size > 0:
+                self.record_subgraphs[mode] = "reuse"
+                if drop_full_graph:
+                    self.drop_full_graph_info(mode)
 
     def drop_full_graph_info(self, mode):
         self.graph_sampler[mode].drop_full_graph_info()
 
     def disable_cache(self, mode):
-        """minibatch.py:490-492: stop recording / reusing subgraphs of this mode."""
+        """minibatch.py:490-492: stop recording / reusing subgraphs of this mode.  A prefetched call is
+        finished and dropped, and the sampler's root cursor is put back where the epoch stands."""
         self.nocache_modes.add(mode)
-        if mode in self.record_subgraphs:
-            self.record_subgraphs[mode] = "noncache"
-            self._inflight.pop(mode, None)
+        if mode not in self.record_subgraphs:
+            return
+        dropped = self._drain(mode)
+        if dropped or self.record_subgraphs[mode] == "reuse":
+            self._cursor[mode] -= dropped
+            self._launched[mode] = self._step[mode]
+            mine = self.entity_epoch[mode]
+            if mine is not None and mine.size:
+                hs = self.graph_sampler[mode]
+                hs.shuffle_targets(mine.astype(np.uint32))
+                if self._cursor[mode] > 0:
+                    hs.next_roots(1, self._cursor[mode])       # cursor := roots already consumed this epoch
+        self.record_subgraphs[mode] = "noncache"
 
     # ------------------------------------------------------------- batching
     def _tail_plan(self, subgs, adj, targets):
@@ -210,84 +385,114 @@ class MinibatchShallowExtractor:
         return levels
 
     def _launch(self, mode):
+        """Issue the sampler call of the next un-launched step (nothing to issue for an empty share)."""
+        t = self._launched[mode]
+        bs = int(self._local_sizes[mode][t])
+        self._launched[mode] = t + 1
+        if bs == 0:
+            return
         hs = self.graph_sampler[mode]
         reuse = self.record_subgraphs.get(mode) == "reuse"
-        bs = min(self.batch_size[mode], self._roots_dev[mode].numel() - self._cursor[mode])
+        c0 = self._cursor[mode]
 
         def go():
             if reuse:
-                roots = self._roots_dev[mode][self._cursor[mode]:self._cursor[mode] + bs]
                 hn, he = self._hwm[mode]
-                self.cache_subg[mode].collate_async(roots, hn + hn // 8 + 64, he + he // 8 + 64,
+                self.cache_subg[mode].collate_async(self._roots_dev[mode][c0:c0 + bs], hn + hn // 8 + 64, he + he // 8 + 64,
                                                     want_hop="hops" in self.aug_feats)
             else:
-                hs.sample_async(self.sampler_cfg, self.batch_size[mode])
+                hs.sample_async(self.sampler_cfg, bs)
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
                 go()
         else:
             go()
-        self._cursor[mode] += bs
-        self._inflight[mode] = "reuse" if reuse else "sample"
+        self._cursor[mode] = c0 + bs
+        self._inflight[mode] = ("reuse" if reuse else "sample", bs)
 
-    def _collect(self, mode) -> DeviceBatch:
+    def _collect(self, mode, discard: bool = False) -> Optional[DeviceBatch]:
         hs = self.graph_sampler[mode]
-        kind = self._inflight[mode]
+        kind, _bs = self._inflight[mode]
+        main = torch.cuda.current_stream(self.device)
+
+        def before_rerun():
+            # a capacity re-run allocates new outputs on the prefetch stream: blocks freed by the previous
+            # batch may still be read by the training stream, so order the re-run behind it
+            if self._side is not None:
+                self._side.wait_stream(main)
 
         def go():
             if kind == "reuse":
-                return self.cache_subg[mode].finish()
-            b = hs.finish()
-            if self.record_subgraphs.get(mode) == "record":
+                return self.cache_subg[mode].finish(on_retry=before_rerun)
+            b = hs.finish(on_retry=before_rerun)
+            if not discard and self.record_subgraphs.get(mode) == "record":
                 self.cache_subg[mode].record(b)                      # minibatch.py:407-412
             return b
-        if self._side is not None:
-            with torch.cuda.stream(self._side):
+        try:
+            if self._side is not None:
+                with torch.cuda.stream(self._side):
+                    b = go()
+                main.wait_stream(self._side)
+            else:
                 b = go()
-            torch.cuda.current_stream(self.device).wait_stream(self._side)
-        else:
-            b = go()
-        self._inflight.pop(mode, None)
+        finally:
+            self._inflight.pop(mode, None)
+        if discard:
+            return None
         self._hwm[mode] = [max(self._hwm[mode][0], b.num_nodes), max(self._hwm[mode][1], b.num_edges)]
         return b
 
+    def _empty_batch(self, mode) -> OneBatchSubgraph:
+        """This rank has no root in the step's global batch: an empty record the model still steps on
+        (zero gradient into the all-reduce)."""
+        dev = self.device
+        z32 = torch.zeros(0, dtype=torch.int32, device=dev)
+        ret = OneBatchSubgraph([None], [self.feat_full[:0]], self.label_full[:0],
+                               torch.zeros(1, 0, dtype=torch.int32, device=dev), [z32], [{}], loss_weight=0.0)
+        ret.device_batch = None
+        return ret
+
     def one_batch(self, mode=TRAIN, ret_raw_idx=False) -> OneBatchSubgraph:
-        remaining = self.entity_epoch[mode].shape[0] - self.idx_entity_evaluated[mode]
-        batch_size_ = min(remaining, self.batch_size[mode])
-        launch_next = False
-        if mode not in self._inflight:
+        t = self._step[mode]
+        assert t < self._local_sizes[mode].size, "epoch exhausted: call shuffle_entity before the next epoch"
+        batch_size_ = int(self._local_sizes[mode][t])
+        if self._launched[mode] <= t:
             self._launch(mode)
-        subgs = self._collect(mode)
-        assert subgs.num_subgraphs == batch_size_, (subgs.num_subgraphs, batch_size_)
+        subgs = self._collect(mode) if batch_size_ > 0 else None
+        assert subgs is None or subgs.num_subgraphs == batch_size_, (subgs.num_subgraphs, batch_size_)
         i0 = self.idx_entity_evaluated[mode]
         self.idx_entity_evaluated[mode] += batch_size_
+        self._step[mode] = t + 1
         self.batch_num += 1
-        if self.idx_entity_evaluated[mode] >= self.entity_epoch[mode].shape[0]:
+        last = self._step[mode] >= self._local_sizes[mode].size
+        if last:
+            assert self.idx_entity_evaluated[mode] == self.entity_epoch[mode].shape[0]
             self.idx_entity_evaluated[mode] = 0
             self.end_epoch[mode] = True
-            if self.record_subgraphs.get(mode) != "reuse":
+            if self.record_subgraphs.get(mode) != "reuse" and self.entity_epoch[mode].size:
                 assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
-        elif self.prefetch:
-            launch_next = True
+        weight = batch_size_ / float(self._global_sizes[mode][t])
+        if subgs is None:
+            if not last and self.prefetch:
+                self._launch(mode)
+            return self._empty_batch(mode)
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
                             subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
-        if launch_next:
+        if not last and self.prefetch:
             self._launch(mode)        # overlap the next sampler call with this batch's training
         feat = ops.gather_rows(self.feat_full, subgs.node)           # minibatch.py:469
         label = self.label_epoch[mode][i0:i0 + batch_size_]
         feat_aug = {}
         # entity encodings (frontend/graph.py:134-172) as per-node bit masks; the model's augmentation
         # Linear consumes them fused (ops.onehot_linear_add), .dense() gives the reference's matrix
-        if "hops" in self.aug_feats:
-            feat_aug["hops"] = ops.OneHotCodes(ops.encode_codes("hops", subgs.hop, self.dim_1hot_hop), self.dim_1hot_hop)
-        if "pprs" in self.aug_feats:
-            feat_aug["pprs"] = ops.OneHotCodes(ops.encode_codes("pprs", subgs.ppr, self.dim_1hot_ppr), self.dim_1hot_ppr)
-        if "drnls" in self.aug_feats:
-            feat_aug["drnls"] = ops.OneHotCodes(ops.encode_codes("drnls", subgs.drnl, self.dim_1hot_drnl), self.dim_1hot_drnl)
+        for name, src, dim in (("hops", subgs.hop, self.dim_1hot_hop), ("pprs", subgs.ppr, self.dim_1hot_ppr),
+                               ("drnls", subgs.drnl, self.dim_1hot_drnl)):
+            if name in self.aug_feats:
+                feat_aug[name] = ops.OneHotCodes(ops.encode_codes(name, src, dim), dim)
         size_subg = subgs.size_subg.unsqueeze(0)
-        ret = OneBatchSubgraph([adj], [feat], label, size_subg, [subgs.target], [feat_aug])
+        ret = OneBatchSubgraph([adj], [feat], label, size_subg, [subgs.target], [feat_aug], loss_weight=weight)
         if tail_plan is not None:
             ret.tail_ens = [tail_plan]
         ret.device_batch = subgs

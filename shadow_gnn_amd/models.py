@@ -3,10 +3,13 @@ constructor arguments, layer registry keys, parameter names (the checkpoint
 contract), ``forward`` signature and ``step`` return dict -- running on the
 HIP layers of ``shadow_gnn_amd.layers``.
 
-Data parallel use: construct with ``grad_sync=dist.GradSync(...)`` and every
-``step`` all-reduces ONE flattened fp32 gradient bucket over RCCL before the
-clip + Adam update (DESIGN.md section "multi-GPU")."""
-from typing import Any, Dict, Optional
+Data parallel use: construct with ``grad_sync=dist.GradSync(...)``; every
+``step`` then scales its loss by the batch's share of the global batch
+(``OneBatchSubgraph.loss_weight``), sums the flat fp32 gradient buffer over the
+ranks (RCCL, overlapped with backward) and runs clip + Adam on identical values
+(DESIGN.md section "multi-GPU")."""
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -14,6 +17,35 @@ from torch import nn
 
 from . import layers, ops, tail
 from .minibatch import TRAIN, OneBatchSubgraph
+
+_FORWARD_FIELDS = ("feat_ens", "adj_ens", "target_ens", "size_subg_ens", "feat_aug_ens")
+GRAD_CLIP_NORM = 5.0                       # shaDow/models.py:225
+
+
+@dataclass(frozen=True)
+class _Arch:
+    """The architecture section of a training configuration (config_train/**.yml, 'architecture'), parsed once."""
+    aggr: str
+    num_gnn_layers: int
+    num_cls_layers: int
+    dim_hid: int
+    heads: int
+    act: str
+    layer_norm: str
+    aug_ops: str
+    residue: str
+    pooling: str
+    sigmoid_loss: bool
+    branch_sharing: bool
+
+    @classmethod
+    def parse(cls, cfg: Dict[str, Any]) -> "_Arch":
+        return cls(aggr=cfg["aggr"], num_gnn_layers=int(cfg["num_layers"]), num_cls_layers=int(cfg.get("num_cls_layers", 1)),
+                   dim_hid=int(cfg["dim"]), heads=int(cfg.get("heads", 1)), act=cfg["act"],
+                   layer_norm=cfg.get("layer_norm", "norm_feat"), aug_ops=cfg.get("feature_augment_ops", "sum"),
+                   residue=str(cfg.get("residue", "none")).lower(),
+                   pooling=str(cfg.get("pooling", "center")).split("-")[0].lower(),
+                   sigmoid_loss=cfg.get("loss", "softmax") == "sigmoid", branch_sharing=bool(cfg.get("branch_sharing", False)))
 
 
 class DeepGNN(nn.Module):
@@ -28,142 +60,139 @@ class DeepGNN(nn.Module):
                  arch_gnn: Dict[str, Any], aug_feat, num_ensemble: int, train_params: Dict[str, Any],
                  prediction_task: str, grad_sync=None):
         super().__init__()
-        assert prediction_task in {'link', 'node'}
+        if prediction_task not in ("link", "node"):
+            raise ValueError(f"prediction_task {prediction_task!r}")
         if num_ensemble != 1:
             raise NotImplementedError("subgraph ensembles (EnsembleAggregator) are outside the hot path built here")
-        self.prediction_task = prediction_task
-        self.num_gnn_layers = arch_gnn["num_layers"]
-        self.num_cls_layers = arch_gnn.get("num_cls_layers", 1)
-        self.dropout, self.dropedge = train_params["dropout"], train_params['dropedge']
-        self.mulhead = int(arch_gnn.get("heads", 1))
-        self.branch_sharing = arch_gnn.get('branch_sharing', False)
+        if dim_feat_raw > dim_feat_smooth:
+            raise ValueError("smoothed feature width below the raw width")
+        spec = _Arch.parse(arch_gnn)
+        if spec.aggr not in self.NAME2CLS:
+            raise NotImplementedError(f"aggr {spec.aggr!r} not provided (have {sorted(self.NAME2CLS)})")
+        self._spec = spec
+        # public attributes of the reference's model object
+        self.prediction_task, self.num_ensemble = prediction_task, num_ensemble
+        self.num_gnn_layers, self.num_cls_layers = spec.num_gnn_layers, spec.num_cls_layers
+        self.dim_hid, self.mulhead, self.branch_sharing = spec.dim_hid, spec.heads, spec.branch_sharing
+        self.feat_aug_ops, self.sigmoid_loss = spec.aug_ops, spec.sigmoid_loss
+        self.dropout, self.dropedge, self.lr = train_params["dropout"], train_params["dropedge"], train_params["lr"]
         self.type_feature_augment = aug_feat
-        assert dim_feat_raw <= dim_feat_smooth
-        self.num_classes = dim_label_raw
-        self.dim_label_in = dim_label_smooth
-        self.dim_feat_in = dim_feat_smooth
-        self.dim_hid = arch_gnn['dim']
-        act, layer_norm = arch_gnn['act'], arch_gnn.get('layer_norm', 'norm_feat')
-        self.feat_aug_ops = arch_gnn.get('feature_augment_ops', 'sum')
-        aug_layers, conv_layers, res_pool_layers = [], [], []
-        for i in range(num_ensemble):
-            dim_aug_add = 0
-            if len(self.type_feature_augment) > 0:
-                _dim_aug_out = self.dim_feat_in if self.feat_aug_ops == 'sum' else self.dim_hid
-                dim_aug_add += 0 if self.feat_aug_ops == 'sum' else _dim_aug_out
-                aug_layers.append(nn.ModuleList(
-                    nn.Linear(_dim, _dim_aug_out) for _, _dim in self.type_feature_augment))
-            convs = []
-            for j in range(self.num_gnn_layers):
-                dim_in = (self.dim_feat_in + self.dim_label_in + dim_aug_add) if j == 0 else self.dim_hid
-                if arch_gnn['aggr'] not in DeepGNN.NAME2CLS:
-                    raise NotImplementedError(f"aggr {arch_gnn['aggr']!r} not provided (have {sorted(DeepGNN.NAME2CLS)})")
-                convs.append(DeepGNN.NAME2CLS[arch_gnn['aggr']](
-                    dim_in, self.dim_hid, dropout=self.dropout, act=act, norm=layer_norm, mulhead=self.mulhead))
-            conv_layers.append(nn.Sequential(*convs))
-            type_res = arch_gnn.get('residue', 'none').lower()
-            type_pool = arch_gnn.get('pooling', 'center').split('-')[0].lower()
-            res_pool_layers.append(layers.ResPool(
-                self.dim_hid, self.dim_hid, self.num_gnn_layers, type_res, type_pool, dropout=self.dropout,
-                act=act, args_pool={}, prediction_task=self.prediction_task))
-        if len(aug_layers) > 0:
-            self.aug_layers = nn.ModuleList(aug_layers)
-        else:
-            self.aug_layers = []
-        self.conv_layers = nn.ModuleList(conv_layers)
-        self.res_pool_layers = nn.ModuleList(res_pool_layers)
+        self.num_classes, self.dim_label_in, self.dim_feat_in = dim_label_raw, dim_label_smooth, dim_feat_smooth
+        # modules; the attribute names below are the checkpoint's key prefixes
+        branches = [self._build_branch(spec) for _ in range(num_ensemble)]
+        aug = [b[0] for b in branches if b[0] is not None]
+        self.aug_layers = nn.ModuleList(aug) if aug else []
+        self.conv_layers = nn.ModuleList(b[1] for b in branches)
+        self.res_pool_layers = nn.ModuleList(b[2] for b in branches)
         self.ensembler = layers.EnsembleDummy()
-        _norm_type = 'norm_feat' if self.prediction_task == 'node' else 'none'
-        classifier = []
-        for i in range(self.num_cls_layers):
-            if i < self.num_cls_layers - 1:
-                _kwargs = {'dim_out': self.dim_hid, 'act': act, 'dropout': self.dropout}
-            else:
-                _kwargs = {'dim_out': self.num_classes, 'act': 'I', 'dropout': 0.}
-            _kwargs.update({'dim_in': self.dim_hid, 'norm': _norm_type})
-            classifier.append(DeepGNN.NAME2CLS['mlp'](**_kwargs))
-        self.classifier = nn.Sequential(*classifier)
-        self.lr = train_params["lr"]
-        self.sigmoid_loss = arch_gnn.get("loss", "softmax") == "sigmoid"
+        self.classifier = self._build_classifier(spec)
         self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr)
         self.fuse_dropout = True       # fold each layer's input dropout into the producing kernel where possible
         # Exact dead-row elimination for residue 'none' + centre pooling (tail.py): the last layers are computed
         # only on the rows the roots depend on.  Off by default: the reference computes every row.
         self.prune_tail = False
-        self.num_ensemble = num_ensemble
         self.grad_sync = grad_sync
 
+    # ------------------------------------------------------------ construction
+    def _build_branch(self, spec: _Arch):
+        """(augmentation Linears | None, conv stack, read-out) of one subgraph branch."""
+        aug, widen = None, 0
+        if len(self.type_feature_augment) > 0:
+            # 'sum' adds the encoding into the raw features; anything else appends dim_hid columns
+            out = self.dim_feat_in if spec.aug_ops == "sum" else spec.dim_hid
+            widen = 0 if spec.aug_ops == "sum" else out
+            aug = nn.ModuleList(nn.Linear(width, out) for _name, width in self.type_feature_augment)
+        widths = [self.dim_feat_in + self.dim_label_in + widen] + [spec.dim_hid] * (spec.num_gnn_layers - 1)
+        layer_cls = self.NAME2CLS[spec.aggr]
+        convs = nn.Sequential(*[layer_cls(w, spec.dim_hid, dropout=self.dropout, act=spec.act, norm=spec.layer_norm,
+                                          mulhead=spec.heads) for w in widths])
+        readout = layers.ResPool(spec.dim_hid, spec.dim_hid, spec.num_gnn_layers, spec.residue, spec.pooling,
+                                 dropout=self.dropout, act=spec.act, args_pool={}, prediction_task=self.prediction_task)
+        return aug, convs, readout
+
+    def _build_classifier(self, spec: _Arch):
+        """MLP head: hidden layers keep the model's activation / dropout, the last one maps to the classes with
+        the identity; feature normalisation only for the node task."""
+        norm = "norm_feat" if self.prediction_task == "node" else "none"
+        hidden = [dict(dim_out=spec.dim_hid, act=spec.act, dropout=self.dropout)] * (spec.num_cls_layers - 1)
+        heads = hidden + [dict(dim_out=self.num_classes, act="I", dropout=0.0)]
+        return nn.Sequential(*[self.NAME2CLS["mlp"](dim_in=spec.dim_hid, norm=norm, **kw) for kw in heads])
+
+    # ------------------------------------------------------------------ loss
     def _loss(self, preds, labels):
+        """Mean CE over the roots on class indices (one-hot label rows are arg-maxed), or the reference's
+        class-summed BCE for multi-label data (shaDow/models.py:151-166)."""
         if self.sigmoid_loss:
-            assert preds.shape == labels.shape
-            return torch.nn.BCEWithLogitsLoss()(preds, labels.type(preds.dtype)) * preds.shape[1]
-        if len(labels.shape) == 2:
-            labels = torch.max(labels, dim=1)[1]
-        return torch.nn.CrossEntropyLoss()(preds, labels)
+            if preds.shape != labels.shape:
+                raise ValueError(f"sigmoid loss needs label rows of {preds.shape[1]} classes")
+            return F.binary_cross_entropy_with_logits(preds, labels.to(preds.dtype)) * preds.shape[1]
+        index = labels.argmax(dim=1) if labels.dim() == 2 else labels
+        return F.cross_entropy(preds, index)
+
+    # --------------------------------------------------------------- forward
+    def _augment(self, i, feat, encodings):
+        """Entity encodings -> Linear -> added to / appended to the features (shaDow/models.py:183-192)."""
+        for ia, (kind, _width) in enumerate(self.type_feature_augment):
+            enc, lin = encodings[kind], self.aug_layers[i][ia]
+            whole = self.dim_feat_in == feat.shape[1]
+            if isinstance(enc, ops.OneHotCodes):
+                if self.feat_aug_ops == "sum" and enc.dim <= 16 and whole:
+                    # fused one-hot + Linear + add: no [n, dim] matrix, one pass over the features
+                    feat = ops.onehot_linear_add(feat, enc.codes, lin)
+                    continue
+                enc = enc.dense()
+            emb = lin(enc)
+            if self.feat_aug_ops != "sum":
+                feat = torch.cat([feat, emb], dim=1)
+            elif whole:
+                feat = feat + emb
+            else:           # smoothed-label columns ride behind the features and are not augmented
+                feat = torch.cat([feat[:, :self.dim_feat_in] + emb, feat[:, self.dim_feat_in:]], dim=1)
+        return feat
+
+    def _run_branch(self, i, feat, adj, tgt, sizes, dropedge, levels):
+        """Conv stack + read-out of branch i; ``levels``: target-only-tail plan (possibly empty)."""
+        convs = list(self.conv_layers[i])
+        num_full = len(convs) - len(levels)
+        state = (feat, adj, False, dropedge)
+        outs = []
+        self._plan_dropout_fusion(i)
+        for md in convs[:num_full]:
+            state = md(state, sizes_subg=sizes)
+            outs.append(state[0])
+            dropped = md.take_dropped_out() if hasattr(md, 'take_dropped_out') else None
+            if dropped is not None:       # dual mode: the read-out keeps the plain output, the next layer
+                state = (dropped,) + tuple(state[1:])     # gets the one its input dropout was applied to
+        if not levels:
+            return self.res_pool_layers[i](outs, tgt, sizes)
+        # target-only tail: each remaining layer on the rows the roots depend on; the last one yields the
+        # root rows in target order, which is all that residue 'none' + centre pooling reads
+        x, adj_norm = state[0], state[1]
+        if num_full == 0:
+            first = convs[0]
+            adj_norm = (first.norm_adj(adj, False, dropedge, x.device) if hasattr(first, 'norm_adj')
+                        else first._adj_norm(adj, False, x.device, dropedge=dropedge))
+        for md, level in zip(convs[num_full:], levels):
+            x = md.forward_rows(x, adj_norm, level)
+        return x
 
     def forward(self, mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge, tail_ens=None):
-        num_ensemble = len(feat_ens)
         emb_subg_ens = []
-        for i in range(num_ensemble):
-            tgt = torch.as_tensor(target_ens[i], device=feat_ens[i].device).long()
+        for i, feat in enumerate(feat_ens):
+            tgt = torch.as_tensor(target_ens[i], device=feat.device).long()
             if self.dim_label_in > 0 and mode == TRAIN:
-                feat_ens[i][tgt, -self.dim_label_in:] = 0
+                feat[tgt, -self.dim_label_in:] = 0            # a root never sees its own label (models.py:181-182)
             if len(self.type_feature_augment) > 0:
-                for ia, (ta, _dim) in enumerate(self.type_feature_augment):
-                    enc = feat_aug_ens[i][ta]
-                    if isinstance(enc, ops.OneHotCodes):
-                        if (self.feat_aug_ops == 'sum' and enc.dim <= 16
-                                and self.dim_feat_in == feat_ens[i].shape[1]):
-                            # fused one-hot + Linear + add: no [n, dim] matrix, one pass over the features
-                            feat_ens[i] = ops.onehot_linear_add(feat_ens[i], enc.codes, self.aug_layers[i][ia])
-                            continue
-                        enc = enc.dense()
-                    feat_aug_emb = self.aug_layers[i][ia](enc)
-                    if self.feat_aug_ops == 'sum':
-                        # (the reference adds in place into the gathered features, models.py:189)
-                        if self.dim_feat_in == feat_ens[i].shape[1]:
-                            feat_ens[i] = feat_ens[i] + feat_aug_emb
-                        else:
-                            feat_ens[i] = torch.cat([feat_ens[i][:, :self.dim_feat_in] + feat_aug_emb,
-                                                     feat_ens[i][:, self.dim_feat_in:]], dim=1)
-                    else:
-                        feat_ens[i] = torch.cat([feat_ens[i], feat_aug_emb], dim=1)
-            xjk = []
-            convs = list(self.conv_layers[i])
-            adj_i = adj_ens[i]
-            levels = []
+                feat = self._augment(i, feat, feat_aug_ens[i])
+            adj_i, levels = adj_ens[i], []
             if self.prune_tail and self._tail_prunable(i):
-                adj_i = layers._as_device_csr(adj_i, feat_ens[i].device)
-                if tail_ens is not None and tail_ens[i] is not None:
-                    levels = tail_ens[i]             # built by the minibatch on its prefetch stream
-                    assert len(levels) <= len(convs)
-                else:
-                    levels = tail.build_tail_plan(adj_i, tgt, len(convs))
-            num_full = len(convs) - len(levels)
-            xmd = (feat_ens[i], adj_i, False, dropedge)
-            self._plan_dropout_fusion(i)
-            for md in convs[:num_full]:
-                xmd = md(xmd, sizes_subg=size_subg_ens[i])
-                xjk.append(xmd[0])
-                dropped = md.take_dropped_out() if hasattr(md, 'take_dropped_out') else None
-                if dropped is not None:       # dual mode: the read-out keeps the plain output, the next layer
-                    xmd = (dropped,) + tuple(xmd[1:])     # gets the one its input dropout was applied to
-            if levels:
-                # target-only tail: each remaining layer on the rows the roots depend on; the last one yields the
-                # root rows in target order, which is all that residue 'none' + centre pooling reads
-                x, adj_norm = xmd[0], xmd[1]
-                if num_full == 0:
-                    adj_norm = (convs[0].norm_adj(adj_i, False, dropedge, x.device) if hasattr(convs[0], 'norm_adj')
-                                else convs[0]._adj_norm(adj_i, False, x.device, dropedge=dropedge))
-                for md, level in zip(convs[num_full:], levels):
-                    x = md.forward_rows(x, adj_norm, level)
-                emb_subg_i = x
-            else:
-                emb_subg_i = self.res_pool_layers[i](xjk, tgt, size_subg_ens[i])
-            emb_subg_i = F.normalize(emb_subg_i, p=2, dim=1)
-            emb_subg_ens.append(emb_subg_i)
-        emb_ensemble = self.ensembler(emb_subg_ens)
-        pred_subg = self.classifier(emb_ensemble)
+                adj_i = layers._as_device_csr(adj_i, feat.device)
+                planned = tail_ens[i] if tail_ens is not None else None      # built by the minibatch while prefetching
+                levels = planned if planned is not None else tail.build_tail_plan(adj_i, tgt, len(self.conv_layers[i]))
+                assert len(levels) <= len(self.conv_layers[i])
+            emb = self._run_branch(i, feat, adj_i, tgt, size_subg_ens[i], dropedge, levels)
+            emb_subg_ens.append(F.normalize(emb, p=2, dim=1))
+        pred_subg = self.classifier(self.ensembler(emb_subg_ens))
         return pred_subg, emb_subg_ens
 
     def _tail_prunable(self, i):
@@ -198,36 +227,59 @@ class DeepGNN(nn.Module):
     def predict(self, preds):
         return torch.sigmoid(preds) if self.sigmoid_loss else F.softmax(preds, dim=1)
 
+    # ------------------------------------------------------------------ step
+    def _begin_update(self):
+        self.train()
+        if self.grad_sync is not None:
+            self.grad_sync.zero()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+
+    def _finish_update(self):
+        """Gradient exchange (data parallel), clip by global norm, Adam -- on every rank, also one whose share of
+        the global batch was empty: the parameters stay identical everywhere."""
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(self.parameters())
+        torch.nn.utils.clip_grad_norm_(self.parameters(), GRAD_CLIP_NORM)
+        self.optimizer.step()
+
+    def _empty_result(self, batch_data):
+        dev = batch_data.feat_ens[0].device
+        preds = torch.zeros(0, self.num_classes, device=dev)
+        return {'batch_size': 0, 'loss': torch.zeros((), device=dev), 'labels': preds.long(), 'preds': preds,
+                'emb_ens': [torch.zeros(0, self.dim_hid, device=dev)]}
+
     def step(self, mode, status, batch_data: OneBatchSubgraph, loss_scale: float = 1.0):
-        assert status in ['running', 'final']
-        args_forward_common = batch_data.to_dict(
-            {"feat_ens", "adj_ens", "target_ens", "size_subg_ens", "feat_aug_ens"})
-        # the step consumes the batch record (features are augmented in place in the reference)
-        args_forward_common["feat_ens"] = list(args_forward_common["feat_ens"])
-        args_forward_common["tail_ens"] = getattr(batch_data, "tail_ens", None)
-        label_targets = batch_data.label
-        if len(label_targets.shape) == 1 and self.num_classes > 1:
-            label_targets = F.one_hot(label_targets.to(torch.int64), num_classes=self.num_classes)
-        if mode == TRAIN and status == 'running':
-            self.train()
-            if self.grad_sync is not None:
-                self.grad_sync.zero()
-            else:
-                self.optimizer.zero_grad(set_to_none=True)
-            preds, emb_ens = self(mode, dropedge=self.dropedge, **args_forward_common)
-            loss = self._loss(preds, label_targets)
-            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
-            if self.grad_sync is not None:
-                self.grad_sync.all_reduce(self.parameters())
-            torch.nn.utils.clip_grad_norm_(self.parameters(), 5)
-            self.optimizer.step()
+        """One training step (mode TRAIN, status 'running': forward, loss, backward, [all-reduce,] clip, Adam)
+        or one evaluation pass; returns the reference's result dict (shaDow/models.py:209-237)."""
+        if status not in ('running', 'final'):
+            raise ValueError(f"status {status!r}")
+        training = mode == TRAIN and status == 'running'
+        if batch_data.batch_size == 0:          # a rank without roots in this global batch (minibatch.plan_epoch)
+            if training:
+                self._begin_update()
+                self._finish_update()
+            return self._empty_result(batch_data)
+        fwd = {k: getattr(batch_data, k) for k in _FORWARD_FIELDS}
+        fwd["feat_ens"] = list(fwd["feat_ens"])          # the step consumes the record (features are augmented)
+        fwd["tail_ens"] = getattr(batch_data, "tail_ens", None)
+        labels = batch_data.label
+        if labels.dim() == 1 and self.num_classes > 1:
+            labels = F.one_hot(labels.to(torch.int64), num_classes=self.num_classes)
+        if training:
+            self._begin_update()
+            preds, emb_ens = self(mode, dropedge=self.dropedge, **fwd)
+            loss = self._loss(preds, labels)
+            weight = loss_scale * (getattr(batch_data, "loss_weight", 1.0) if self.grad_sync is not None else 1.0)
+            (loss if weight == 1.0 else loss * weight).backward()
+            self._finish_update()
         else:
             self.eval()
             with torch.no_grad():
-                preds, emb_ens = self(mode, dropedge=0., **args_forward_common)
-                loss = self._loss(preds, label_targets)
-        assert preds.shape[0] == label_targets.shape[0]
-        return {'batch_size': preds.shape[0], 'loss': loss, 'labels': label_targets,
+                preds, emb_ens = self(mode, dropedge=0., **fwd)
+                loss = self._loss(preds, labels)
+        assert preds.shape[0] == labels.shape[0]
+        return {'batch_size': preds.shape[0], 'loss': loss, 'labels': labels,
                 'preds': self.predict(preds), 'emb_ens': emb_ens}
 
     def __str__(self):

@@ -328,9 +328,12 @@ class HipSampler:
         self._pending = pend
         return pend
 
-    def finish(self) -> DeviceBatch:
+    def finish(self, on_retry=None) -> DeviceBatch:
         """Wait for the in-flight call and wrap the outputs.  Capacity overflows
-        are handled here by growing and re-running the same roots / serials."""
+        are handled here by growing and re-running the same roots / serials;
+        ``on_retry()`` is called before such a re-run allocates and launches again
+        (a caller that prefetches on a side stream orders it behind the consumers
+        of the blocks the allocator may hand back)."""
         pend = self._pending
         if pend is None:
             raise RuntimeError("no sample in flight")
@@ -352,6 +355,8 @@ class HipSampler:
                 cap_e = int(cnt.e_tot) + int(cnt.e_tot) // 8 + 64
             if (ov & 4) and not (ov & 3):
                 cap_n = int(cnt.n_tot) + int(cnt.n_tot) // 8 + 64
+            if on_retry is not None:
+                on_retry()
             with torch.cuda.device(self.device):
                 self._launch(pend, cap_e, cap_n)
         else:
@@ -391,8 +396,12 @@ class SubgraphCache:
     def __init__(self, num_nodes: int, device: torch.device):
         self._lib = _lib.load()
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("SubgraphCache needs a ROCm device (torch device type 'cuda')")
+        if self.device.index is None:            # 'cuda' means the CURRENT device, as for HipSampler
+            self.device = torch.device("cuda", torch.cuda.current_device())
         h = C.c_void_p()
-        check(self._lib.sg_cache_create(num_nodes, self.device.index or 0, C.byref(h)))
+        check(self._lib.sg_cache_create(num_nodes, self.device.index, C.byref(h)))
         self._h = h
         self._pend = None
 
@@ -421,6 +430,8 @@ class SubgraphCache:
     def record(self, batch: DeviceBatch):
         """File every (single-root) subgraph of a sampled batch under its root id."""
         assert batch.num_roots == 1, "the cache holds node-task subgraphs (minibatch.py:410)"
+        if batch.node.device != self.device:
+            raise ValueError(f"batch lives on {batch.node.device}, the cache on {self.device}")
         out = SgBatchOut(batch.node.data_ptr(), batch.indptr.data_ptr(), batch.indices.data_ptr(),
                          batch.edge_id.data_ptr(), batch.target.data_ptr(), batch.subg_node_off.data_ptr(),
                          batch.subg_edge_off.data_ptr(), batch.hop.data_ptr() if batch.hop is not None else None,
@@ -458,12 +469,16 @@ class SubgraphCache:
             check(self._lib.sg_cache_collate(self._h, roots.data_ptr(), P, C.byref(out), stream))
         self._pend = (roots, bufs, out, P, want_hop)
 
-    def finish(self) -> DeviceBatch:
+    def finish(self, on_retry=None) -> DeviceBatch:
+        if self._pend is None:
+            raise RuntimeError("no collate in flight")
         roots, b, out, P, want_hop = self._pend
         cnt = SgBatchCounts()
         rc = self._lib.sg_cache_collate_finish(self._h, C.byref(cnt))
         self._pend = None
         if rc == _lib.SG_ERR_CAPACITY:          # sizes are known now: run again with exact buffers
+            if on_retry is not None:
+                on_retry()
             self.collate_async(roots, int(cnt.n_tot), int(cnt.e_tot), want_hop)
             return self.finish()
         check(rc)

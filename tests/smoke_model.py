@@ -1,14 +1,15 @@
-"""smoke(): one tiny sample -> gather -> SAGE-3 train step on cuda:0, forward
-checked against the CPU oracle (tolerance 1e-4)."""
+"""__graft_entry__.smoke(): one tiny sample -> gather -> SAGE-3 train step on cuda:0, forward
+checked against the CPU oracle (tolerance 1e-4).  Test infrastructure (it imports oracle/): lives
+under tests/, not in the product package."""
 import numpy as np
 import torch
 
 
 def run(hs, cfg):
     from oracle import layers_oracle as lo
-    from .minibatch import OneBatchSubgraph, TRAIN, hop2onehot
-    from .models import DeepGNN
-    from . import ops
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN, hop2onehot
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd import ops
     dev = hs.device
     torch.manual_seed(0)
     N, F0, C = hs.num_nodes(), 16, 5

@@ -1,10 +1,12 @@
-"""CPU, world_size 2, gloo: the data-parallel pieces that do not need a GPU --
-root sharding of the shared permutation and the single-bucket gradient
-all-reduce (equivalence with the single-process gradient on the full batch)."""
+"""CPU, gloo, world_size 2 and 3: the data-parallel pieces that do not need a GPU -- the epoch plan
+(every rank takes the same number of steps, ragged last global batch, a rank whose share is empty) and
+the bucketed gradient all-reduce (SUM of loss-weighted gradients == the single-process gradient on the
+whole global batch, also with unequal / empty shares and with the overlap hooks armed)."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -18,69 +20,107 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _toy_model():
+    return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ELU(), torch.nn.Linear(16, 16), torch.nn.ELU(),
+                               torch.nn.Linear(16, 3))
+
+
+def _worker(rank, world, port, q, shares, num_buckets):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    from shadow_gnn_amd.dist import GradSync, broadcast_parameters, init_from_env
+    from shadow_gnn_amd.dist import GradSync, broadcast_array, broadcast_parameters, init_from_env
     r, _l, w = init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     torch.manual_seed(1234 + rank)                 # different init per rank ...
-    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ELU(), torch.nn.Linear(16, 3))
+    model = _toy_model()
     broadcast_parameters(model)                    # ... made identical here
-    sync = GradSync(model.parameters())
+    sync = GradSync(model.parameters(), num_buckets=num_buckets)
     g = torch.Generator().manual_seed(7)
-    X = torch.randn(12, 8, generator=g)
-    y = torch.randint(0, 3, (12,), generator=g)
-    B = 12 // world
-    xs, ys = X[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
-    sync.zero()
-    torch.nn.functional.cross_entropy(model(xs), ys).backward()
-    sync.all_reduce()
-    flat = sync.flat.clone()
-    # single-process reference on the whole batch
-    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ELU(), torch.nn.Linear(16, 3))
-    ref.load_state_dict(model.state_dict())
-    torch.nn.functional.cross_entropy(ref(X), y).backward()
-    ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    total = sum(shares)
+    X = torch.randn(total, 8, generator=g)
+    y = torch.randint(0, 3, (total,), generator=g)
+    lo = sum(shares[:rank])
+    xs, ys = X[lo:lo + shares[rank]], y[lo:lo + shares[rank]]
+    errs = []
+    for _step in range(2):                         # twice: zero() re-arms the hooks
+        sync.zero()
+        if shares[rank] > 0:                       # a rank with an empty share skips forward / backward ...
+            (torch.nn.functional.cross_entropy(model(xs), ys) * (shares[rank] / total)).backward()
+            assert sync._next == len(sync._slices)     # the hooks issued every slice during backward (overlap)
+        sync.all_reduce()                          # ... but still enters every collective
+        flat = sync.flat.clone()
+        # single-process reference on the whole batch
+        ref = _toy_model()
+        ref.load_state_dict(model.state_dict())
+        torch.nn.functional.cross_entropy(ref(X), y).backward()
+        ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        errs.append(float((flat - ref_flat).abs().max()))
     # param.grad stayed views of the bucket
-    views_ok = all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in model.parameters())
-    q.put((rank, float((flat - ref_flat).abs().max()), views_ok))
+    views_ok = all(sync.flat.data_ptr() <= p.grad.data_ptr() < sync.flat.data_ptr() + 4 * sync.flat.numel()
+                   for p in model.parameters())
+    perm = broadcast_array(np.random.default_rng(100 + rank).permutation(50).astype(np.int64))
+    q.put((rank, max(errs), views_ok, len(sync._slices), perm.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_grad_allreduce_equals_full_batch_gradient():
+@pytest.mark.parametrize("shares,num_buckets", [((6, 6), 1), ((6, 6), 2), ((5, 4, 3), 3), ((2, 2, 0), 2), ((1, 0, 0), 2)])
+def test_grad_allreduce_equals_full_batch_gradient(shares, num_buckets):
+    world = len(shares)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, shares, num_buckets)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, views_ok in res:
+    for rank, err, views_ok, nslices, perm in res:
         assert err < 1e-6 and views_ok, (rank, err)
+        assert 1 <= nslices <= num_buckets
+        assert perm == res[0][4]                   # every rank ends up with rank 0's permutation
 
 
-def test_root_sharding_partitions_every_global_batch():
-    """Every global batch of B roots is split into disjoint equal rank slices, in order."""
-    ent = np.arange(1000, 1103)
-    perm = np.random.default_rng(0).permutation(ent.size)
-    B, G = 16, 4
-    slices = []
-    for r in range(G):
-        e = ent[perm]
-        nfull = (e.size // B) * B
-        body = e[:nfull].reshape(-1, G, B // G)[:, r, :].reshape(-1)
-        tail = e[nfull:]
-        per = -(-tail.size // G)
-        slices.append(np.concatenate([body, tail[r * per:(r + 1) * per]]))
-    allr = np.concatenate(slices)
-    assert np.array_equal(np.sort(allr), np.sort(ent))
-    # step t of every rank together == global batch t of the permutation
-    e = ent[perm]
-    for t in range(e.size // B):
-        got = np.concatenate([s[t * (B // G):(t + 1) * (B // G)] for s in slices])
-        assert np.array_equal(got, e[t * B:(t + 1) * B])
+@pytest.mark.parametrize("E,B,G", [(103, 16, 4), (101, 16, 8), (5, 16, 8), (64, 16, 4), (7, 3, 2), (1, 8, 3), (0, 8, 2)])
+def test_epoch_plan_same_steps_on_every_rank_and_exact_global_batches(E, B, G):
+    """Default plan: step t of all ranks together == global batch t of the permutation, in order; shares differ by
+    at most one; every rank has ceil(E / B) steps (a share may be empty: E = 101, B = 16, G = 8 leaves a tail of 5)."""
+    from shadow_gnn_amd.minibatch import plan_epoch
+    order = np.random.default_rng(E + B + G).permutation(E)
+    plans = [plan_epoch(order, B, G, r) for r in range(G)]
+    T = -(-E // B)
+    for mine, local, glob in plans:
+        assert local.size == glob.size == T and mine.size == local.sum()
+        assert np.array_equal(glob, plans[0][2])
+    assert np.array_equal(np.sort(np.concatenate([p[0] for p in plans])), np.sort(order))
+    cursors = [0] * G
+    for t in range(T):
+        parts = []
+        for r, (mine, local, glob) in enumerate(plans):
+            parts.append(mine[cursors[r]:cursors[r] + local[t]])
+            cursors[r] += local[t]
+        got = np.concatenate(parts)
+        assert np.array_equal(got, order[t * B:(t + 1) * B])
+        sizes = [p[1][t] for p in plans]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == plans[0][2][t]
+    if (E, B, G) == (101, 16, 8):
+        assert [int(p[1][-1]) for p in plans] == [1, 1, 1, 1, 1, 0, 0, 0]      # three ranks idle in the last step
+
+
+@pytest.mark.parametrize("E,B,G", [(103, 16, 4), (70, 16, 3), (5, 16, 8), (9, 4, 2)])
+def test_epoch_plan_static_partition_keeps_roots_on_their_rank(E, B, G):
+    """Cache mode: position p of the entity set always lands on rank p % G, whatever the permutation; the
+    per-step sizes are known to every rank (their sum is the step's global batch)."""
+    from shadow_gnn_amd.minibatch import plan_epoch
+    T = -(-E // B)
+    for seed in (0, 1):
+        order = np.random.default_rng(seed).permutation(E)
+        plans = [plan_epoch(order, B, G, r, static_partition=True) for r in range(G)]
+        for r, (mine, local, glob) in enumerate(plans):
+            assert np.all(mine % G == r) and mine.size == local.sum() == np.sum(np.arange(E) % G == r)
+            assert local.size == glob.size == T
+            assert np.array_equal(mine, order[order % G == r])               # epoch order preserved inside the share
+            assert local.max() - local.min() <= 1
+        assert np.array_equal(sum(p[1] for p in plans), plans[0][2]) and plans[0][2].sum() == E

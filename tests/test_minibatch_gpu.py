@@ -20,7 +20,7 @@ def _setup(prefetch, rank=0, world=1, batch=16, aug=("hops",), budget=4):
     feat = torch.randn(4000, 20, generator=g)
     label = torch.randint(0, 7, (4000,), generator=g)
     roots = np.random.default_rng(3).permutation(4000)[:103]
-    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
                                    dict(method="khop", depth=2, budget=budget, add_self_edge=True), aug, feat, label,
                                    batch_size=batch, device=DEV, seed_cpp=11, rank=rank, world_size=world, prefetch=prefetch)
     mb.epoch_start_reset(0, TRAIN)
@@ -157,7 +157,7 @@ def test_subgraph_cache_record_then_reuse(prefetch):
     label = torch.randint(0, 5, (N,), generator=g)
     roots = np.random.default_rng(1).permutation(N)[:70].astype(np.uint32)
     table = so.ppr_approximate(indptr, indices, roots, k=12, alpha=0.85, epsilon=1e-4, num_threads=4)
-    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
                                    dict(method="ppr", k=12, threshold=0.0, add_self_edge=True), ("hops",), feat, label,
                                    batch_size=16, device=DEV, seed_cpp=2, prefetch=prefetch)
     mb.epoch_start_reset(0, TRAIN)
@@ -236,7 +236,7 @@ def test_training_is_bit_reproducible_with_and_without_prefetch(aggr, prune_tail
     roots = np.random.default_rng(2).permutation(N)[:B * (steps + 1)]
 
     def run(prefetch):
-        mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+        mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
                                        dict(method="khop", depth=2, budget=10, add_self_edge=(aggr != "sage")),
                                        (), feat, label, batch_size=B, device=DEV, seed_cpp=3, prefetch=prefetch)
         mb.epoch_start_reset(0, TRAIN); mb.shuffle_entity(TRAIN, perm=np.arange(roots.size))

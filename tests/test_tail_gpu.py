@@ -143,7 +143,7 @@ def test_minibatch_builds_the_plan_on_its_prefetch_stream(prefetch):
     feat = torch.randn(N, F0, generator=g)
     label = torch.randint(0, C, (N,), generator=g)
     roots = np.random.default_rng(3).permutation(N)[:96]
-    mb = MinibatchShallowExtractor({TRAIN: (indptr, indices)}, {TRAIN: roots},
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
                                    dict(method="khop", depth=2, budget=6, add_self_edge=True), (), feat, label,
                                    batch_size=32, device=DEV, seed_cpp=11, prefetch=prefetch)
     mb.tail_plan_layers = 4
