@@ -17,6 +17,8 @@ Fixture layout (one .npz per graph; cases are prefixed c<idx>_):
     c<i>_{..}_off                     offsets of each subgraph in the above
     ppr_{targets,len,neigh,score}     PPR table as written by the reference's
                                       cache files (decoded), when present
+tests/golden/ppr_cache_files.npz: the two cache files' raw bytes (gen_ppr_cache_files;
+    `python oracle/gen_golden.py --ppr-files-only` rewrites only this one).
 """
 import io
 import json
@@ -218,8 +220,44 @@ def gen_budget_stats():
     print(f"wrote {path}")
 
 
+def gen_ppr_cache_files():
+    """The reference's two PPR cache files as RAW BYTES (ParallelSampler.cpp:94-137, written by
+    preproc_ppr_approximate :344) for a small graph: the byte-compatibility fixture of sg_load_ppr_bin /
+    sg_save_ppr_bin.  Data only: graph, targets, parameters, file contents."""
+    import ParallelSampler as ref  # oracle/_ref
+    indptr, indices = make_graph(120, 6, seed=13)
+    rng = np.random.default_rng(17)
+    targets = np.sort(rng.choice(120, size=20, replace=False)).astype(np.uint32)
+    k, alpha, eps = 12, 0.85, 1e-4
+    ps = ref.ParallelSampler(indptr, indices, np.ones(indices.size, dtype=np.float32), 20, 1, True, True, [], 1, "", "", "", 0)
+    with tempfile.TemporaryDirectory() as td:
+        fn, fs = os.path.join(td, "neighs.bin"), os.path.join(td, "scores.bin")
+        ps.preproc_ppr_approximate(targets, k, alpha, eps, fn, fs)
+        bn, bs = open(fn, "rb").read(), open(fs, "rb").read()
+        # a second sampler object accepts its own files (the reader's acceptance rule, .cpp:166) ...
+        ps2 = ref.ParallelSampler(indptr, indices, np.ones(indices.size, dtype=np.float32), 20, 1, True, True, [], 1, "", "", "", 0)
+        ps2.preproc_ppr_approximate(targets, 8, alpha, eps * 1.05, fn, fs)         # smaller k, eps within 10 %: loaded, clipped
+        ps2.shuffle_targets(targets)
+        cfg = {"method": "ppr", "k": "8", "num_roots": "1", "threshold": "0.0", "add_self_edge": "true",
+               "include_target_conn": "false"}
+        out = ps2.parallel_sampler_ensemble([cfg], [{"pprs"}])[0]
+        nodes = out.get_subgraph_node()[:out.get_num_valid_subg()]
+        pprs = out.get_subgraph_ppr()[:out.get_num_valid_subg()]
+        assert open(fn, "rb").read() == bn                                          # a successful load does not rewrite
+    off = np.concatenate([[0], np.cumsum([len(v) for v in nodes])]).astype(np.int64)
+    path = os.path.join(ROOT, "tests", "golden", "ppr_cache_files.npz")
+    np.savez_compressed(path, indptr=indptr, indices=indices, targets=targets, k=k, alpha=alpha, epsilon=eps,
+                        neighs_bytes=np.frombuffer(bn, dtype=np.uint8), scores_bytes=np.frombuffer(bs, dtype=np.uint8),
+                        clip_k=8, clip_node=np.concatenate([np.asarray(v, dtype=np.uint32) for v in nodes]),
+                        clip_ppr=np.concatenate([np.asarray(v, dtype=np.float32) for v in pprs]), clip_off=off)
+    print(f"wrote {path}: {len(bn)} + {len(bs)} file bytes")
+
+
 def main():
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    if "--ppr-files-only" in sys.argv:
+        gen_ppr_cache_files()
+        return
     ip, ix = path_graph()
     gen_graph_fixture("path6", ip, ix, seed=1, n_roots=6, with_ppr=True, link=True)
     ip, ix = make_graph(300, 8, seed=3)
@@ -229,6 +267,7 @@ def main():
     ip, ix = make_graph(400, 6, seed=9, directed=True)
     gen_graph_fixture("directed400", ip, ix, seed=6, link=False)
     gen_budget_stats()
+    gen_ppr_cache_files()
 
 
 if __name__ == "__main__":

@@ -133,6 +133,13 @@ def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None):
         else:
             x = gat_forward(lp, x, A_n, act, heads)
         feats.append(x)
+    return readout_and_classify(p, arch, feats, sizes, target)
+
+
+def readout_and_classify(p, arch, feats, sizes, target):
+    """ResPool + L2 normalisation + classifier on the per-layer outputs ``feats`` (layers.py:154-199,
+    models.py:198-204); shared by the dense model above and oracle/model_oracle_sparse.py."""
+    act = arch["act"]
     tgt = torch.as_tensor(np.asarray(target, dtype=np.int64))
     type_res, type_pool = arch["residue"], arch["pooling"]
     if type_pool == "center" and type_res == "none":             # layers.py:159-163

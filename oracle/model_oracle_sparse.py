@@ -1,0 +1,106 @@
+"""Edge-list (sparse) restatement of the shaDow model forward for batches too large for the dense
+oracle, in a chosen dtype (fp64 by default: the comparison then measures the HIP path's error, not the
+checker's).
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product path.  It is pinned twice in the CPU suite
+(tests/test_layers_oracle_golden.py): against the reference's golden model steps (tests/golden/
+models_step.npz, produced by shaDow/models.py itself) and against the dense oracle/layers_oracle.py on
+random batches.  The layer arithmetic is layers_oracle's with the n x n matrix replaced by per-edge
+index_add / scatter_reduce; read-out and classifier are shared code (layers_oracle.readout_and_classify).
+Line numbers refer to /root/reference.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import layers_oracle as lo
+
+
+class EdgeList:
+    """rows / cols of the batch CSR (duplicates kept: an un-coalesced COO adds them up, as torch.sparse does)."""
+
+    def __init__(self, indptr, indices, dtype=torch.float64):
+        indptr = np.asarray(indptr, dtype=np.int64)
+        self.n = indptr.size - 1
+        self.rows = torch.from_numpy(np.repeat(np.arange(self.n), np.diff(indptr)))
+        self.cols = torch.from_numpy(np.asarray(indices, dtype=np.int64).copy())
+        self.dtype = dtype
+        self.w = torch.ones(self.cols.numel(), dtype=dtype)
+
+    def degree(self):
+        return torch.zeros(self.n, dtype=self.dtype).index_add_(0, self.rows, self.w)
+
+    def normalised(self, kind):
+        """adj_norm_rw: D^-1 A with D = clamp(row sum, 1) (frontend/graph_utils.py:84-94);
+        adj_norm_sym: D^-1/2 A D^-1/2 with D = clip(row sum, 1) (:140-142); GAT keeps the 0/1 values (layers.py:591)."""
+        out = EdgeList.__new__(EdgeList)
+        out.n, out.rows, out.cols, out.dtype = self.n, self.rows, self.cols, self.dtype
+        d = torch.clamp(self.degree(), min=1)
+        if kind == "sage":
+            out.w = self.w / d[self.rows]
+        elif kind == "gcn":
+            s = d.pow(-0.5)
+            out.w = self.w * s[self.rows] * s[self.cols]
+        else:
+            out.w = self.w
+        return out
+
+    def matmul(self, X):
+        """A @ X (torch.sparse.mm, layers.py:326-327,433)"""
+        return torch.zeros(self.n, X.shape[1], dtype=X.dtype).index_add_(0, self.rows, X[self.cols] * self.w[:, None])
+
+
+def gcn_forward(p, X, A, act):
+    z = F.linear(A.matmul(X), p["f_lin.weight"], p["f_lin.bias"])                       # layers.py:433-435
+    return lo.f_norm(lo.act_fn(act, p)(z), p["scale"][0], p["offset"][0])
+
+
+def sage_forward(p, X, A, act):
+    hs = lo.act_fn(act, p)(F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"]))   # layers.py:473-483
+    hn = lo.act_fn(act, p)(F.linear(A.matmul(X), p["f_lin_neigh.weight"], p["f_lin_neigh.bias"]))
+    return lo.f_norm(hs, p["scale"][0], p["offset"][0]) + lo.f_norm(hn, p["scale"][1], p["offset"][1])
+
+
+def gat_forward(p, X, A, act, heads):
+    """GAT.forward + _aggregate_attention (layers.py:560-626) on the edge list."""
+    n = X.shape[0]
+    hs = lo.act_fn(act, p)(F.linear(X, p["f_lin.0.weight"], p["f_lin.0.bias"])).view(n, heads, -1)
+    hn = lo.act_fn(act, p)(F.linear(X, p["f_lin.1.weight"], p["f_lin.1.bias"])).view(n, heads, -1)
+    att = p["attention"]
+    rows, cols = A.rows, A.cols
+    outs_n, outs_s = [], []
+    for k in range(heads):
+        a_s = F.leaky_relu(hs[:, k] @ att[0, k], 0.2)                                   # :568
+        a_n = F.leaky_relu(hn[:, k] @ att[1, k], 0.2)                                   # :569
+        e = a_s[rows] + a_n[cols]                                                       # :570
+        mx = torch.full((n,), float("-inf"), dtype=e.dtype).scatter_reduce(0, rows, e, "amax", include_self=True)   # :572
+        mx = torch.where(torch.isfinite(mx), mx, torch.zeros_like(mx)).detach()
+        pexp = torch.exp(e - mx[rows]) * A.w                                            # :574-575
+        denom = torch.clamp(torch.zeros(n, dtype=e.dtype).index_add_(0, rows, pexp), min=1e-10)   # :578
+        agg = torch.zeros(n, hn.shape[2], dtype=e.dtype).index_add_(0, rows, hn[cols, k] * pexp[:, None]) / denom[:, None]
+        outs_n.append(lo.f_norm(agg, p["scale"][0, k], p["offset"][0, k]))              # :620-622 (index 0 = neigh)
+        outs_s.append(lo.f_norm(hs[:, k], p["scale"][1, k], p["offset"][1, k]))
+    return (torch.cat(outs_s, 1) + torch.cat(outs_n, 1)) / 2                            # :623-625
+
+
+def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtype=torch.float64):
+    """DeepGNN.forward (models.py:169-204, one branch).  ``p``: state_dict tensors (any float dtype; cast to
+    ``dtype`` here -- pass leaves of that dtype with requires_grad to get gradients)."""
+    kind, L, heads, act = arch["aggr"], arch["num_layers"], int(arch.get("heads", 1)), arch["act"]
+    p = {k: (v if v.dtype == dtype else v.to(dtype)) for k, v in p.items()}
+    x = X.to(dtype)
+    if hop1hot is not None:                                                              # models.py:185-189
+        x = x + F.linear(hop1hot.to(dtype), p["aug_layers.0.0.weight"], p["aug_layers.0.0.bias"])
+    A = EdgeList(indptr, indices, dtype).normalised(kind)
+    feats = []
+    for l in range(L):
+        pre = f"conv_layers.0.{l}."
+        lp = {k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}
+        if kind == "gcn":
+            x = gcn_forward(lp, x, A, act)
+        elif kind == "sage":
+            x = sage_forward(lp, x, A, act)
+        else:
+            x = gat_forward(lp, x, A, act, heads)
+        feats.append(x)
+    return lo.readout_and_classify(p, arch, feats, sizes, target)

@@ -203,12 +203,14 @@ class MinibatchShallowExtractor:
         self.tail_plan_layers = 0
         self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
         self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
-        self._inflight: Dict[int, Tuple[str, int]] = {}        # mode -> (kind, roots in the call)
+        self._inflight: Dict[int, Tuple[str, int, int]] = {}   # mode -> (kind, roots in the call, epoch cursor at its start)
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
         self.nocache_modes = set(nocache_modes)
         self.record_subgraphs: Dict[int, str] = {}
         self.cache_subg: Dict[int, SubgraphCache] = {}
         self._roots_dev: Dict[int, torch.Tensor] = {}
+        self._mine_pos: Dict[int, np.ndarray] = {}            # this rank's positions into the raw entity set, epoch order
+        self._recorded: Dict[int, np.ndarray] = {}            # per position of the raw entity set: subgraph is in the cache
         self._cursor = {m: 0 for m in _MODES}                 # roots handed to the sampler so far this epoch
         self._step = {m: 0 for m in _MODES}                   # steps returned by one_batch this epoch
         self._launched = {m: 0 for m in _MODES}               # steps whose sampler call has been issued
@@ -286,7 +288,7 @@ class MinibatchShallowExtractor:
         """Finish and discard a prefetched sampler call (its outputs are dropped); returns its root count."""
         if mode not in self._inflight:
             return 0
-        kind, bs = self._inflight[mode]
+        bs = self._inflight[mode][1]
         self._collect(mode, discard=True)
         return bs
 
@@ -307,6 +309,7 @@ class MinibatchShallowExtractor:
         mine_pos, local, glob = plan_epoch(perm, self.batch_size_global, self.world_size, self.rank,
                                            static_partition=self._static_partition(mode))
         mine = raw[mine_pos]
+        self._mine_pos[mode] = mine_pos
         self._local_sizes[mode], self._global_sizes[mode] = local, glob
         self.entity_epoch[mode] = mine
         self.label_epoch[mode] = self.label_full[torch.as_tensor(mine.astype(np.int64), device=self.device)]
@@ -332,9 +335,9 @@ class MinibatchShallowExtractor:
         sub-sample keeps recording)."""
         self.end_epoch[mode] = False
         if self.record_subgraphs.get(mode) == "record":
-            raw = self.raw_entity_set[mode]
-            share = raw[np.arange(raw.size) % self.world_size == self.rank] if self.world_size > 1 else raw
-            if self.cache_subg[mode].stats()["num_recorded"] >= np.unique(share).size > 0:
+            done = self._recorded.get(mode)
+            share = np.arange(self.raw_entity_set[mode].size) % self.world_size == self.rank
+            if done is not None and share.any() and bool(done[share].all()):
                 self.record_subgraphs[mode] = "reuse"
                 if drop_full_graph:
                     self.drop_full_graph_info(mode)
@@ -409,11 +412,11 @@ class MinibatchShallowExtractor:
         else:
             go()
         self._cursor[mode] = c0 + bs
-        self._inflight[mode] = ("reuse" if reuse else "sample", bs)
+        self._inflight[mode] = ("reuse" if reuse else "sample", bs, c0)
 
     def _collect(self, mode, discard: bool = False) -> Optional[DeviceBatch]:
         hs = self.graph_sampler[mode]
-        kind, _bs = self._inflight[mode]
+        kind, bs, c0 = self._inflight[mode]
         main = torch.cuda.current_stream(self.device)
 
         def before_rerun():
@@ -428,6 +431,9 @@ class MinibatchShallowExtractor:
             b = hs.finish(on_retry=before_rerun)
             if not discard and self.record_subgraphs.get(mode) == "record":
                 self.cache_subg[mode].record(b)                      # minibatch.py:407-412
+                if mode not in self._recorded:
+                    self._recorded[mode] = np.zeros(self.raw_entity_set[mode].size, dtype=bool)
+                self._recorded[mode][self._mine_pos[mode][c0:c0 + bs]] = True
             return b
         try:
             if self._side is not None:

@@ -104,3 +104,78 @@ def test_cpu_train_step_port_matches_layer_oracle(kind):
     steps, sec, warm = cts.time_train_steps(A.indptr, A.indices, X, torch.as_tensor(target), torch.arange(B) % C, kind, L, dim, C,
                                             "relu", 0.3, 0.1, 0.01, threads=2, budget_s=5.0, max_steps=1)
     assert steps == 1 and sec > 0
+
+
+@pytest.mark.parametrize("fname", ["models_step.npz", "models_prelu.npz"])
+def test_sparse_model_oracle_matches_reference_golden(fname):
+    """oracle/model_oracle_sparse.py (the fp64 edge-list checker of the benchmark-scale GPU parity tests) reproduces
+    the reference's own DeepGNN.step vectors: predictions, embeddings, loss and every parameter gradient."""
+    from oracle import model_oracle_sparse as mos
+    g = ModelGolden(fname)
+    for case in g.cases:
+        ci = case["idx"]
+        p = {k: v.double().requires_grad_(True) for k, v in _t(g.group(ci, "p")).items()}
+        hop1hot = torch.tensor(lo.hop2onehot(g.get(ci, "hop"), 7)) if case["aug"] else None
+        preds, emb = mos.model_forward(p, case["arch"], torch.tensor(g.get(ci, "X")), g.get(ci, "indptr"),
+                                       g.get(ci, "indices"), g.get(ci, "sizes"), g.get(ci, "target"), hop1hot)
+        assert preds.dtype == torch.float64
+        np.testing.assert_allclose(preds.detach().numpy(), g.get(ci, "preds"), err_msg=str(case["arch"]), **TOL)
+        np.testing.assert_allclose(emb.detach().numpy(), g.get(ci, "emb"), **TOL)
+        loss = lo.model_loss(preds, g.get(ci, "labels"))
+        assert abs(float(loss) - float(g.get(ci, "loss"))) < 1e-4
+        loss.backward()
+        for k, gr in g.group(ci, "g").items():
+            np.testing.assert_allclose(p[k].grad.numpy(), gr, err_msg=f"{case['arch']['aggr']} {k}", rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind,heads", [("sage", 1), ("gcn", 1), ("gat", 2)])
+def test_sparse_model_oracle_matches_dense_oracle(kind, heads):
+    """Same arithmetic as the golden-pinned dense oracle on a ragged random batch with isolated rows (fp32 both)."""
+    import scipy.sparse as sp
+    from oracle import model_oracle_sparse as mos
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(1, 30, 9)
+    blocks = []
+    for s_ in sizes:
+        a = (rng.random((s_, s_)) < 0.2).astype(np.float32)
+        a = np.maximum(a, a.T)
+        if kind != "sage":
+            np.fill_diagonal(a, 1.0)
+        blocks.append(sp.csr_matrix(a))
+    A = sp.block_diag(blocks, format="csr"); A.sort_indices()
+    n, F0, dim, C, L = A.shape[0], 9, 8 * heads, 4, 3
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    target = off[:-1] + rng.integers(0, sizes)
+    torch.manual_seed(3)
+    p = {}
+    for l in range(L):
+        pre, fi = f"conv_layers.0.{l}.", (F0 if l == 0 else dim)
+        if kind == "gcn":
+            p[pre + "f_lin.weight"], p[pre + "f_lin.bias"] = torch.randn(dim, fi) * 0.3, torch.randn(dim) * 0.1
+            nb = (1, dim)
+        elif kind == "sage":
+            for nm in ("f_lin_self", "f_lin_neigh"):
+                p[pre + nm + ".weight"], p[pre + nm + ".bias"] = torch.randn(dim, fi) * 0.3, torch.randn(dim) * 0.1
+            nb = (2, dim)
+        else:
+            for j in range(2):
+                p[pre + f"f_lin.{j}.weight"], p[pre + f"f_lin.{j}.bias"] = torch.randn(dim, fi) * 0.3, torch.randn(dim) * 0.1
+            p[pre + "attention"] = torch.randn(2, heads, dim // heads) * 0.5
+            nb = (2, heads, dim // heads)
+        p[pre + "scale"], p[pre + "offset"] = torch.rand(nb) + 0.5, torch.randn(nb) * 0.1
+    p["res_pool_layers.0.nn.1.weight"], p["res_pool_layers.0.nn.1.bias"] = torch.randn(dim, 2 * dim) * 0.3, torch.randn(dim) * 0.1
+    p["res_pool_layers.0.scale"], p["res_pool_layers.0.offset"] = torch.rand(dim) + 0.5, torch.randn(dim) * 0.1
+    p["classifier.0.f_lin.weight"], p["classifier.0.f_lin.bias"] = torch.randn(C, dim) * 0.3, torch.randn(C) * 0.1
+    p["classifier.0.scale"], p["classifier.0.offset"] = torch.rand(1, C) + 0.5, torch.randn(1, C) * 0.1
+    arch = dict(aggr=kind, num_layers=L, heads=heads, act="elu", residue="max", pooling="mean")
+    X = torch.randn(n, F0)
+    labels = rng.integers(0, C, sizes.size)
+    pd = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref, ref_emb = lo.model_forward(pd, arch, X, A.indptr, A.indices, sizes, target)
+    got, got_emb = mos.model_forward(ps, arch, X, A.indptr, A.indices, sizes, target, dtype=torch.float32)
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got_emb.detach().numpy(), ref_emb.detach().numpy(), rtol=1e-4, atol=1e-5)
+    lo.model_loss(ref, labels).backward(); lo.model_loss(got, labels).backward()
+    for k in p:
+        np.testing.assert_allclose(ps[k].grad.numpy(), pd[k].grad.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)

@@ -254,3 +254,214 @@ def test_training_is_bit_reproducible_with_and_without_prefetch(aggr, prune_tail
     a, b, c = run(True), run(True), run(False)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ragged / empty data-parallel shares, reference constructor, mid-epoch resets (round 2)
+# --------------------------------------------------------------------------------------------------------------
+def _ragged_worker(rank, world, port, q, nroots, ppr_epochs):
+    """3 ranks on cuda:0 over gloo.  103 roots, global batch 16 -> 7 steps, the last one of 7 roots (3/2/2);
+    with nroots = 97 the tail is ONE root: ranks 1 and 2 step on an empty share."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from shadow_gnn_amd import dist as sdist
+    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    sdist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    indptr, indices = make_graph_numpy(4000, 10, seed=4)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(4000, 20, generator=g)
+    label = torch.randint(0, 7, (4000,), generator=g)
+    roots = np.random.default_rng(3).permutation(4000)[:nroots]
+    if ppr_epochs:
+        from oracle import sampler_oracle as so
+        scfg = dict(method="ppr", k=10, threshold=0.0, add_self_edge=True)
+    else:
+        scfg = dict(method="khop", depth=2, budget=-1, add_self_edge=True)        # deterministic (full 2-hop)
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots}, scfg, (), feat, label,
+                                             batch_size=16, device=DEV, seed_cpp=11, rank=rank, world_size=world, prefetch=True)
+    mb.epoch_start_reset(0, TRAIN)
+    if ppr_epochs:
+        table = so.ppr_approximate(indptr, indices, roots.astype(np.uint32), k=10, alpha=0.85, epsilon=1e-4, num_threads=2)
+        mb.graph_sampler[TRAIN].set_ppr(roots.astype(np.uint32), table.len, table.neigh, table.score)
+    torch.manual_seed(5 + rank)
+    arch = dict(num_layers=2, heads=1, dim=32, act="elu", aggr="sage", residue="none", pooling="center")
+    model = DeepGNN(20, 20, 7, 0, arch, [], 1, dict(dropout=0.0, dropedge=0.0, lr=1e-2), "node").to(DEV)
+    sdist.broadcast_parameters(model)
+    model.grad_sync = sdist.GradSync(model.parameters())
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    sizes, modes = [], []
+    for ep in range(max(1, ppr_epochs)):
+        mb.epoch_start_reset(ep, TRAIN)
+        mb.shuffle_entity(TRAIN, perm=(np.arange(nroots) if ep == 0 else None))     # None: rank 0's draw is broadcast
+        modes.append(mb.record_subgraphs[TRAIN])
+        while not mb.is_end_epoch(TRAIN):
+            b = mb.one_batch(TRAIN)
+            sizes.append((b.batch_size, round(b.loss_weight, 6)))
+            model.step(TRAIN, "running", b)
+        mb.epoch_end_reset(TRAIN)
+    q.put((rank, sizes, modes, {k: v.cpu().numpy() for k, v in model.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ranks(target, world, *args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        item = q.get(timeout=600)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("nroots", [103, 97])
+def test_three_rank_ragged_epoch_equals_single_process(nroots):
+    """A whole epoch whose last global batch is ragged (7 roots over 3 ranks) or leaves two ranks EMPTY (1 root):
+    nobody hangs in the all-reduce, every rank takes ceil(E / B) steps, all ranks end with identical parameters, and
+    those equal the single-process run over the same global batches (loss-weighted SUM all-reduce)."""
+    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    res = _run_ranks(_ragged_worker, 3, nroots, 0)
+    T = -(-nroots // 16)
+    tail = nroots - 16 * (T - 1)
+    for r in range(3):
+        sizes = res[r][0]
+        assert len(sizes) == T
+        assert [s for s, _w in sizes[:-1]] == [6 - (r > 0)] * (T - 1)            # 16 = 6 + 5 + 5
+        assert sizes[-1][0] == tail // 3 + (r < tail % 3)
+        assert abs(sizes[-1][1] - sizes[-1][0] / tail) < 1e-6
+    if nroots == 97:
+        assert [res[r][0][-1][0] for r in range(3)] == [1, 0, 0]
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k]) and np.array_equal(res[0][2][k], res[2][2][k]), k
+    indptr, indices = make_graph_numpy(4000, 10, seed=4)
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(4000, 20, generator=g)
+    label = torch.randint(0, 7, (4000,), generator=g)
+    roots = np.random.default_rng(3).permutation(4000)[:nroots]
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
+                                             dict(method="khop", depth=2, budget=-1, add_self_edge=True), (), feat, label,
+                                             batch_size=16, device=DEV, seed_cpp=11, prefetch=False)
+    mb.epoch_start_reset(0, TRAIN)
+    mb.shuffle_entity(TRAIN, perm=np.arange(nroots))
+    torch.manual_seed(5)
+    arch = dict(num_layers=2, heads=1, dim=32, act="elu", aggr="sage", residue="none", pooling="center")
+    model = DeepGNN(20, 20, 7, 0, arch, [], 1, dict(dropout=0.0, dropedge=0.0, lr=1e-2), "node").to(DEV)
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    while not mb.is_end_epoch(TRAIN):
+        model.step(TRAIN, "running", mb.one_batch(TRAIN))
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(res[0][2][k], v.cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=k)
+
+
+def test_two_rank_ppr_cache_survives_reshuffled_epochs():
+    """Per-rank record -> reuse caches with a NEW permutation every epoch: the static root -> rank map keeps
+    every reused root on the rank that recorded it; three epochs, no 'never recorded' error, ranks stay in step."""
+    res = _run_ranks(_ragged_worker, 2, 70, 3)
+    for r in range(2):
+        sizes, modes, _sd = res[r]
+        assert modes == ["record", "reuse", "reuse"]
+        assert len(sizes) == 3 * 5 and sum(s for s, _w in sizes) == 3 * 35
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+
+
+def test_reference_constructor_signature_and_bin_files(tmp_path):
+    """MinibatchShallowExtractor takes the reference's argument list (shaDow/minibatch.py:154-174): scipy CSR
+    adjacencies per mode, the {'batch_size', 'configs': [{key: [value]}]} sampler section, percent_per_epoch, and --
+    when given -- the cpp/adj_*_{indptr,indices}.bin files instead of the in-memory arrays.  Batches equal the short
+    form's."""
+    import scipy.sparse as sp
+    from shadow_gnn_amd.minibatch import TEST, TRAIN, VALID, MinibatchShallowExtractor
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    N = 3000
+    indptr, indices = make_graph_numpy(N, 8, seed=6)
+    adj = sp.csr_matrix((np.ones(indices.size, dtype=np.float32), indices.astype(np.int64), indptr.astype(np.int64)), shape=(N, N))
+    g = torch.Generator().manual_seed(0)
+    feat, label = torch.randn(N, 12, generator=g), torch.randint(0, 5, (N,), generator=g)
+    ent = {TRAIN: np.arange(0, 200), VALID: np.arange(200, 260), TEST: np.arange(260, 300)}
+    section = {"batch_size": 32, "configs": [{"method": "khop", "depth": [2], "budget": [5], "add_self_edge": [True]}]}
+    f_ip, f_ix = str(tmp_path / "adj_full_raw_indptr.bin"), str(tmp_path / "adj_full_raw_indices.bin")
+    indptr.astype(np.uint32).tofile(f_ip); indices.astype(np.uint32).tofile(f_ix)          # data_converter.py:462-468
+    bins = {m: {"indptr": f_ip, "indices": f_ix, "data": ""} for m in (TRAIN, VALID, TEST)}
+
+    def epoch(mb, mode):
+        mb.epoch_start_reset(0, mode)
+        mb.shuffle_entity(mode, perm=np.arange(ent[mode].size))
+        out = []
+        while not mb.is_end_epoch(mode):
+            out.append(mb.one_batch(mode, ret_raw_idx=True))
+        mb.epoch_end_reset(mode)
+        return out
+    a = MinibatchShallowExtractor("toy", None, {m: adj for m in ent}, ent, section, {"hops"}, {"train": 0.5}, feat, label,
+                                  12, True, 4, True, None, set(), "high", 9, device=DEV)
+    b = MinibatchShallowExtractor("toy", None, {m: None for m in ent}, ent, section, {"hops"}, {"train": 0.5}, feat, label,
+                                  12, True, 4, True, bins, set(), "high", 9, device=DEV)
+    c = MinibatchShallowExtractor.on_device({m: (indptr, indices) for m in ent}, ent,
+                                            dict(method="khop", depth=2, budget=5, add_self_edge=True), ("hops",), feat, label,
+                                            batch_size=32, device=DEV, seed_cpp=9, percent_per_epoch={"train": 0.5})
+    for mode, nb in ((TRAIN, 4), (VALID, 2)):                       # 50 % of 200 train roots -> 100 = 3 x 32 + 4
+        ea, eb, ec = epoch(a, mode), epoch(b, mode), epoch(c, mode)
+        assert len(ea) == len(eb) == len(ec) == nb
+        for x, y, z in zip(ea, eb, ec):
+            for u in (y, z):
+                assert torch.equal(x.adj_ens[0].indptr, u.adj_ens[0].indptr) and torch.equal(x.adj_ens[0].indices, u.adj_ens[0].indices)
+                assert torch.equal(x.idx_raw[0], u.idx_raw[0]) and torch.equal(x.feat_ens[0], u.feat_ens[0]) and torch.equal(x.label, u.label)
+    with pytest.raises(NotImplementedError):
+        MinibatchShallowExtractor("toy", None, {m: adj for m in ent}, ent,
+                                  {"batch_size": 8, "configs": [{"method": "khop", "depth": [2, 1], "budget": [5, 5]}]}, set(), None,
+                                  feat, label, 12, True, 4, device=DEV)
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_mid_epoch_reshuffle_and_disable_cache(prefetch):
+    """shuffle_entity / disable_cache with a prefetched call in flight finish and drop it instead of leaving
+    the sampler 'already in flight'; after disable_cache the epoch continues from where it stood, sampling again."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    N = 3000
+    indptr, indices = make_graph_numpy(N, 8, seed=5)
+    g = torch.Generator().manual_seed(0)
+    feat, label = torch.randn(N, 12, generator=g), torch.randint(0, 5, (N,), generator=g)
+    roots = np.random.default_rng(1).permutation(N)[:70].astype(np.uint32)
+    table = so.ppr_approximate(indptr, indices, roots, k=12, alpha=0.85, epsilon=1e-4, num_threads=4)
+    mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
+                                             dict(method="ppr", k=12, threshold=0.0, add_self_edge=True), (), feat, label,
+                                             batch_size=16, device=DEV, seed_cpp=2, prefetch=prefetch)
+    mb.epoch_start_reset(0, TRAIN)
+    mb.graph_sampler[TRAIN].set_ppr(roots, table.len, table.neigh, table.score)
+    mb.shuffle_entity(TRAIN, perm=np.arange(70))
+    mb.one_batch(TRAIN)                                   # (with prefetch the next call is now in flight)
+    mb.shuffle_entity(TRAIN, perm=np.arange(70)[::-1].copy())    # restart the epoch early
+    first = mb.one_batch(TRAIN, ret_raw_idx=True)
+    got = first.idx_raw[0][first.target_ens[0].long()].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, roots[::-1][:16])
+    while not mb.is_end_epoch(TRAIN):
+        mb.one_batch(TRAIN)
+    mb.epoch_end_reset(TRAIN)
+    assert mb.record_subgraphs[TRAIN] == "reuse"
+    mb.shuffle_entity(TRAIN, perm=np.arange(70))
+    b0 = mb.one_batch(TRAIN, ret_raw_idx=True)             # served by the cache (and the next one prefetched from it)
+    mb.disable_cache(TRAIN)                                # mid-epoch: back to sampling, from root 16 on
+    assert mb.record_subgraphs[TRAIN] == "noncache"
+    rest = []
+    while not mb.is_end_epoch(TRAIN):
+        rest.append(mb.one_batch(TRAIN, ret_raw_idx=True))
+    assert [b.batch_size for b in rest] == [16, 16, 16, 6]
+    seen = np.concatenate([b.idx_raw[0][b.target_ens[0].long()].cpu().numpy().view(np.uint32) for b in [b0] + rest])
+    assert np.array_equal(seen, roots)
+    ref = so.sample_batch(indptr, indices, roots[16:32], method="ppr", k=12, threshold=0.0, add_self_edge=True, ppr=table, seed=2)
+    assert np.array_equal(rest[0].device_batch.to_host()["indices"], ref.indices)

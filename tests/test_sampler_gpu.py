@@ -473,3 +473,40 @@ def test_extreme_structures_fuzz_against_oracle():
             _cmp_batch(ref, got, aug, (trial, kind, n, kw, aug))
             hs.close()
 
+
+
+def test_ppr_cache_files_byte_compatible_with_the_reference(tmp_path):
+    """Both directions against the reference's OWN cache files (tests/golden/ppr_cache_files.npz: raw bytes written by
+    ParallelSampler::write_PPR_to_binary_file, .cpp:94-137): (1) sg_load_ppr_bin reads them, with the reader's
+    acceptance rule (.cpp:166: same alpha, epsilon within +-10 %, k_file >= k -> rows clipped to k) and samples what
+    the reference sampled after ITS reload; (2) the table sg_ppr_push computes, written by sg_save_ppr_bin, is the
+    same two files byte for byte."""
+    import os
+    from shadow_gnn_amd._lib import ShadowHipError
+    from shadow_gnn_amd.ppr import ppr_approximate_device
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from tests._golden import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "ppr_cache_files.npz"))
+    indptr, indices, targets = z["indptr"], z["indices"], z["targets"]
+    k, alpha, eps, ck = int(z["k"]), float(z["alpha"]), float(z["epsilon"]), int(z["clip_k"])
+    fn, fs = str(tmp_path / "neighs.bin"), str(tmp_path / "scores.bin")
+    open(fn, "wb").write(z["neighs_bytes"].tobytes()); open(fs, "wb").write(z["scores_bytes"].tobytes())
+    # (1) read the reference's files
+    hs = _make(indptr, indices)
+    hs.load_ppr_bin(fn, fs, ck, alpha, eps * 1.05)                     # smaller k, epsilon inside the 10 % window
+    got = hs.sample(SamplerConfig(method="ppr", k=ck, threshold=0.0, add_self_edge=True, aug=("pprs",)), roots=targets).to_host()
+    assert np.array_equal(got["node"], z["clip_node"])
+    assert np.array_equal(got["ppr"].view(np.uint32), z["clip_ppr"].view(np.uint32))
+    assert np.array_equal(got["subg_node_off"], z["clip_off"].astype(np.uint32))
+    for bad in (dict(k=k + 1), dict(alpha=0.8), dict(epsilon=eps * 1.2), dict(epsilon=eps * 0.8)):
+        kw = dict(k=ck, alpha=alpha, epsilon=eps); kw.update(bad)
+        with pytest.raises(ShadowHipError):
+            _make(indptr, indices).load_ppr_bin(fn, fs, kw["k"], kw["alpha"], kw["epsilon"])
+    # (2) write our own
+    hs2 = _make(indptr, indices)
+    ln, nb, sc = ppr_approximate_device(hs2, targets, k, alpha, eps)
+    hs2.set_ppr(targets, ln, nb, sc)
+    gn, gs = str(tmp_path / "n2.bin"), str(tmp_path / "s2.bin")
+    hs2.save_ppr_bin(gn, gs, k, alpha, eps)
+    assert open(gn, "rb").read() == z["neighs_bytes"].tobytes()
+    assert open(gs, "rb").read() == z["scores_bytes"].tobytes()
