@@ -115,6 +115,13 @@ int sg_create(const uint32_t *indptr, const uint32_t *indices, uint32_t num_node
  * (ParallelSampler::read_array_from_bin, .cpp:70-86).                        */
 int sg_create_from_bin(const char *path_indptr, const char *path_indices, int device_id,
                        int64_t seed, sg_sampler **out);
+/* Same with the files' element widths stated (4 = the reference's uint32; 8 = uint64 / int64 as numpy / scipy
+ * hold index arrays of graphs with more than 2^31 entries, frontend/loader.py:63-96).  Both files stream
+ * through a double-buffered pinned staging area into HBM -- the whole array is never held on the host
+ * (papers100M: 13.4 GB).  64-bit elements are narrowed with a range check: a graph with >= 2^32 nodes or
+ * edges does not fit the sampler's uint32 ids (Graph.h:16) and is refused with SG_ERR_INVALID.             */
+int sg_create_from_bin_ex(const char *path_indptr, const char *path_indices, int indptr_bytes, int indices_bytes,
+                          int device_id, int64_t seed, sg_sampler **out);
 void sg_destroy(sg_sampler *s);
 
 uint32_t sg_num_nodes(const sg_sampler *s);        /* .cpp:49 */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sg_abi_version": (C.c_int, []),
     "sg_create": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.POINTER(_P)]),
     "sg_create_from_bin": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "sg_create_from_bin_ex": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(_P)]),
     "sg_destroy": (None, [_P]),
     "sg_num_nodes": (C.c_uint32, [_P]),
     "sg_num_edges": (C.c_uint64, [_P]),
@@ -121,7 +122,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 5      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 6      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -296,8 +296,8 @@ static int upload_chunked(void *dst, const void *src, size_t bytes) {
 
 extern "C" const char *sg_last_error(void) { return last_error().c_str(); }
 // 2: sl_act_norm_* carry (drop_p, drop_seed); gemm / cache / pooling entries.  3: sl_act_norm_* dual (plain + dropped) output
-// 4: sg_ppr_push(mode).  5: sl_gat_bwd work buffer holds the datt partial sums
-extern "C" int sg_abi_version(void) { return 5; }
+// 4: sg_ppr_push(mode).  5: sl_gat_bwd work buffer holds the datt partial sums.  6: sg_create_from_bin_ex
+extern "C" int sg_abi_version(void) { return 6; }
 
 static int create_common(sg_sampler *s, int device_id, int64_t seed) {
   s->device = device_id;
@@ -357,15 +357,106 @@ static int read_bin_u32(const char *path, std::vector<uint32_t> &v) {
   return SG_OK;
 }
 
+// File -> HBM through the double-buffered pinned staging area, never holding the whole array on the host
+// (papers100M: 13.4 GB of CSR).  width = 4: raw uint32 as the reference writes them (ndarray.tofile,
+// data_converter.py:462-468, read by .cpp:70-86); width = 8: uint64 / int64 elements (what numpy / scipy hold for
+// graphs with more than 2^31 edges when nobody narrowed them), narrowed to uint32 on the way with a range check.
+static int stream_file_to_device(uint32_t *dst, int fd, const char *path, size_t count, int width) {
+  const size_t CH_ELEMS = (size_t)16 << 20;                       // 64 MiB of uint32 per chunk
+  if (count == 0) return SG_OK;
+  void *pin[2] = {nullptr, nullptr};
+  hipStream_t st;
+  hipEvent_t ev[2];
+  std::vector<uint64_t> wide;
+  if (width == 8) wide.resize(std::min(count, CH_ELEMS));
+  SHD_HIP(hipStreamCreate(&st));
+  SHD_HIP(hipHostMalloc(&pin[0], std::min(count, CH_ELEMS) * 4, hipHostMallocDefault));
+  SHD_HIP(hipHostMalloc(&pin[1], std::min(count, CH_ELEMS) * 4, hipHostMallocDefault));
+  SHD_HIP(hipEventCreate(&ev[0])); SHD_HIP(hipEventCreate(&ev[1]));
+  int rc = SG_OK, b = 0;
+  for (size_t off = 0; off < count && rc == SG_OK; off += CH_ELEMS, b ^= 1) {
+    const size_t len = std::min(CH_ELEMS, count - off);
+    SHD_HIP(hipEventSynchronize(ev[b]));
+    char *to = width == 8 ? (char *)wide.data() : (char *)pin[b];
+    size_t got = 0, want = len * (size_t)width;
+    while (got < want) {
+      ssize_t r = pread(fd, to + got, want - got, (off_t)(off * (size_t)width + got));
+      if (r <= 0) { rc = set_error(SG_ERR_IO, "short read on %s", path); break; }
+      got += (size_t)r;
+    }
+    if (rc != SG_OK) break;
+    if (width == 8) {
+      uint32_t *narrow = (uint32_t *)pin[b];
+      uint64_t over = 0;
+      for (size_t i = 0; i < len; i++) { over |= wide[i] >> 32; narrow[i] = (uint32_t)wide[i]; }
+      if (over) { rc = set_error(SG_ERR_INVALID, "%s holds values >= 2^32: not representable in the uint32 node / edge ids "
+                                 "of the sampler (Graph.h:16)", path); break; }
+    }
+    SHD_HIP(hipMemcpyAsync(dst + off, pin[b], len * 4, hipMemcpyHostToDevice, st));
+    SHD_HIP(hipEventRecord(ev[b], st));
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+  (void)hipHostFree(pin[0]); (void)hipHostFree(pin[1]);
+  (void)hipStreamDestroy(st);
+  return rc;
+}
+
+static int file_elems(const char *path, int width, int *fd_out, size_t *count) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return set_error(SG_ERR_IO, "cannot open %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return set_error(SG_ERR_IO, "cannot stat %s", path); }
+  *count = (size_t)st.st_size / (size_t)width;                    // element count = file size / element size (.cpp:81)
+  *fd_out = fd;
+  return SG_OK;
+}
+
+static int read_elem(int fd, const char *path, size_t index, int width, uint64_t *v) {
+  uint64_t x = 0;
+  if (pread(fd, &x, (size_t)width, (off_t)(index * (size_t)width)) != (ssize_t)width) return set_error(SG_ERR_IO, "short read on %s", path);
+  *v = width == 8 ? x : (uint64_t)(uint32_t)x;
+  return SG_OK;
+}
+
+extern "C" int sg_create_from_bin_ex(const char *path_indptr, const char *path_indices, int indptr_bytes, int indices_bytes,
+                                     int device_id, int64_t seed, sg_sampler **out) {
+  if (!path_indptr || !path_indices || !out) return set_error(SG_ERR_INVALID, "sg_create_from_bin: null argument");
+  if ((indptr_bytes != 4 && indptr_bytes != 8) || (indices_bytes != 4 && indices_bytes != 8))
+    return set_error(SG_ERR_INVALID, "sg_create_from_bin: element widths must be 4 or 8 bytes");
+  int fd_p = -1, fd_x = -1, rc;
+  size_t np = 0, nx = 0;
+  if ((rc = file_elems(path_indptr, indptr_bytes, &fd_p, &np)) != SG_OK) return rc;
+  if ((rc = file_elems(path_indices, indices_bytes, &fd_x, &nx)) != SG_OK) { close(fd_p); return rc; }
+  auto fail = [&](int code) { close(fd_p); close(fd_x); return code; };
+  if (np == 0) return fail(set_error(SG_ERR_IO, "%s is empty", path_indptr));
+  if (np - 1 > 0xFFFFFFFFull) return fail(set_error(SG_ERR_INVALID, "%s: more than 2^32 nodes", path_indptr));
+  uint64_t first = 0, last = 0;
+  if ((rc = read_elem(fd_p, path_indptr, 0, indptr_bytes, &first)) != SG_OK) return fail(rc);
+  if ((rc = read_elem(fd_p, path_indptr, np - 1, indptr_bytes, &last)) != SG_OK) return fail(rc);
+  if (nx > 0xFFFFFFFFull || last > 0xFFFFFFFFull)
+    return fail(set_error(SG_ERR_INVALID, "%s: %llu edges do not fit the sampler's uint32 edge ids (Graph.h:16, "
+                          "ParallelSampler.h: vector<NodeType> origEdgeID)", path_indices, (unsigned long long)std::max<uint64_t>(nx, last)));
+  if (first != 0 || last != nx)                                    // Graph.h:29-30
+    return fail(set_error(SG_ERR_INVALID, "sg_create_from_bin: indptr[0]=%llu indptr[N]=%llu but %s holds %llu ids",
+                          (unsigned long long)first, (unsigned long long)last, path_indices, (unsigned long long)nx));
+  SHD_HIP(hipSetDevice(device_id));
+  sg_sampler *s = new sg_sampler();
+  s->N = (uint32_t)(np - 1); s->nnz = nx; s->owns_graph = true;
+  hipError_t e1 = hipMalloc((void **)&s->d_indptr, np * 4);
+  hipError_t e2 = hipMalloc((void **)&s->d_indices, std::max<size_t>(1, nx) * 4);
+  if (e1 != hipSuccess || e2 != hipSuccess) { sg_destroy(s); return fail(set_error(SG_ERR_HIP, "sg_create_from_bin: hipMalloc of the CSR failed")); }
+  if ((rc = stream_file_to_device(s->d_indptr, fd_p, path_indptr, np, indptr_bytes)) != SG_OK) { sg_destroy(s); return fail(rc); }
+  if ((rc = stream_file_to_device(s->d_indices, fd_x, path_indices, nx, indices_bytes)) != SG_OK) { sg_destroy(s); return fail(rc); }
+  close(fd_p); close(fd_x);
+  if ((rc = create_common(s, device_id, seed)) != SG_OK) { sg_destroy(s); return rc; }
+  *out = s;
+  return SG_OK;
+}
+
 extern "C" int sg_create_from_bin(const char *path_indptr, const char *path_indices, int device_id,
                                   int64_t seed, sg_sampler **out) {
-  if (!path_indptr || !path_indices || !out) return set_error(SG_ERR_INVALID, "sg_create_from_bin: null argument");
-  std::vector<uint32_t> ip, ix;
-  int rc;
-  if ((rc = read_bin_u32(path_indptr, ip)) != SG_OK) return rc;
-  if ((rc = read_bin_u32(path_indices, ix)) != SG_OK) return rc;
-  if (ip.empty()) return set_error(SG_ERR_IO, "%s is empty", path_indptr);
-  return sg_create(ip.data(), ix.data(), (uint32_t)(ip.size() - 1), ix.size(), 0, device_id, seed, out);
+  return sg_create_from_bin_ex(path_indptr, path_indices, 4, 4, device_id, seed, out);
 }
 
 static void free_ppr(sg_sampler *s) {

@@ -157,7 +157,9 @@ class HipSampler:
     scratch memory and the RNG serial counter."""
 
     def __init__(self, indptr=None, indices=None, *, device: Optional[torch.device] = None,
-                 seed: int = -1, path_indptr: str = "", path_indices: str = ""):
+                 seed: int = -1, path_indptr: str = "", path_indices: str = "", bin_dtype=("uint32", "uint32")):
+        """``bin_dtype``: element types of the two .bin files (uint32 as the reference writes them; 'int64' /
+        'uint64' files are narrowed on the way in, values >= 2^32 are refused)."""
         self._lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
@@ -169,8 +171,9 @@ class HipSampler:
         n_ptr = 0 if indptr is None else len(indptr)
         if n_ptr == 0:
             # empty arrays + paths => read the raw uint32 .bin files (ParallelSampler.h:41-46)
-            check(self._lib.sg_create_from_bin(path_indptr.encode(), path_indices.encode(),
-                                               self.device.index, seed, C.byref(h)))
+            wp, wx = (np.dtype(d).itemsize for d in bin_dtype)
+            check(self._lib.sg_create_from_bin_ex(path_indptr.encode(), path_indices.encode(), wp, wx,
+                                                  self.device.index, seed, C.byref(h)))
         elif isinstance(indptr, torch.Tensor) and indptr.is_cuda:
             assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
             self._keep = (indptr.contiguous(), indices.contiguous())

@@ -510,3 +510,143 @@ def test_ppr_cache_files_byte_compatible_with_the_reference(tmp_path):
     hs2.save_ppr_bin(gn, gs, k, alpha, eps)
     assert open(gn, "rb").read() == z["neighs_bytes"].tobytes()
     assert open(gs, "rb").read() == z["scores_bytes"].tobytes()
+
+
+def _lattice_graph(n, half):
+    """Ring lattice: node i -- i +- 1..half (sorted rows, symmetric, no self loops); cheap at millions of nodes."""
+    offs = np.concatenate([np.arange(-half, 0), np.arange(1, half + 1)])
+    cols = (np.arange(n, dtype=np.int64)[:, None] + offs[None, :]) % n
+    cols.sort(axis=1)
+    indptr = (np.arange(n + 1, dtype=np.int64) * (2 * half))
+    return indptr, cols.reshape(-1)
+
+
+def test_create_from_bin_files_like_the_reference(tmp_path):
+    """f4: the sampler built from the reference's cpp/adj_*_{indptr,indices}.bin files -- raw ndarray.tofile dumps,
+    uint32 (data_converter.py:462-468, read by ParallelSampler::read_array_from_bin, .cpp:70-86) -- equals the one
+    built from the in-memory arrays; int64 dumps (what scipy holds for big graphs) are narrowed on the way in;
+    inconsistent, truncated and out-of-range files are refused with a status, not a crash."""
+    from shadow_gnn_amd._lib import ShadowHipError
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    dev = torch.device("cuda:0")
+    indptr, indices = make_graph_numpy(30000, 12, seed=9)
+    f_ip, f_ix = str(tmp_path / "adj_full_raw_indptr.bin"), str(tmp_path / "adj_full_raw_indices.bin")
+    indptr.astype(np.uint32).tofile(f_ip); indices.astype(np.uint32).tofile(f_ix)
+    g_ip, g_ix = str(tmp_path / "ip64.bin"), str(tmp_path / "ix64.bin")
+    indptr.astype(np.int64).tofile(g_ip); indices.astype(np.int64).tofile(g_ix)
+    mem = HipSampler(indptr, indices, device=dev, seed=5)
+    f32 = HipSampler(device=dev, seed=5, path_indptr=f_ip, path_indices=f_ix)
+    f64 = HipSampler(device=dev, seed=5, path_indptr=g_ip, path_indices=g_ix, bin_dtype=("int64", "int64"))
+    mix = HipSampler(device=dev, seed=5, path_indptr=g_ip, path_indices=f_ix, bin_dtype=("uint64", "uint32"))
+    roots = np.random.default_rng(0).permutation(30000)[:200].astype(np.uint32)
+    for cfg in (SamplerConfig(method="khop", depth=2, budget=5, add_self_edge=True, aug=("hops",)),
+                SamplerConfig(method="khop", depth=1, budget=-1), SamplerConfig(method="nodeIID")):
+        want = mem.sample(cfg, roots=roots, serial_base=7).to_host()
+        for other in (f32, f64, mix):
+            assert (other.num_nodes(), other.num_edges()) == (mem.num_nodes(), mem.num_edges()) == (30000, indices.size)
+            got = other.sample(cfg, roots=roots, serial_base=7).to_host()
+            for f in INT_FIELDS + ["subg_node_off", "subg_edge_off"]:
+                assert np.array_equal(got[f], want[f]), f
+    # indptr[N] != number of ids (Graph.h:29-30), truncated file, missing file
+    indices[:-3].astype(np.uint32).tofile(str(tmp_path / "short.bin"))
+    for bad_ip, bad_ix in ((f_ip, str(tmp_path / "short.bin")), (f_ip, str(tmp_path / "nope.bin")), (f_ix, f_ix)):
+        with pytest.raises(ShadowHipError):
+            HipSampler(device=dev, path_indptr=bad_ip, path_indices=bad_ix)
+    # 64-bit ids that do not fit uint32 are an explicit error (Graph.h:16: NodeType = uint32)
+    big = indices.astype(np.int64); big[100] = 1 << 32
+    big.tofile(str(tmp_path / "big.bin"))
+    with pytest.raises(ShadowHipError, match="2\\^32"):
+        HipSampler(device=dev, path_indptr=g_ip, path_indices=str(tmp_path / "big.bin"), bin_dtype=("int64", "int64"))
+    ip_big = indptr.astype(np.int64); ip_big[-1] = (1 << 32) + 5
+    ip_big.tofile(str(tmp_path / "ipbig.bin"))
+    with pytest.raises(ShadowHipError, match="uint32 edge ids"):
+        HipSampler(device=dev, path_indptr=str(tmp_path / "ipbig.bin"), path_indices=g_ix, bin_dtype=("int64", "int64"))
+
+
+def test_create_from_bin_streams_multi_chunk_files(tmp_path):
+    """A 24 M-entry index file (96 MB: more than one 64 MiB staging chunk, odd tail) streamed file -> pinned -> HBM,
+    as uint32 and as int64: the device copy is the file."""
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+    dev = torch.device("cuda:0")
+    n, half = 2_000_003, 6
+    indptr, indices = _lattice_graph(n, half)
+    f_ip, f_ix = str(tmp_path / "ip.bin"), str(tmp_path / "ix.bin")
+    indptr.astype(np.uint32).tofile(f_ip); indices.astype(np.uint32).tofile(f_ix)
+    g_ix = str(tmp_path / "ix64.bin")
+    indices.astype(np.int64).tofile(g_ix)
+    for kw in (dict(path_indices=f_ix), dict(path_indices=g_ix, bin_dtype=("uint32", "int64"))):
+        hs = HipSampler(device=dev, seed=1, path_indptr=f_ip, **kw)
+        assert hs.num_nodes() == n and hs.num_edges() == indices.size
+        # every id of a row lands in a 1-hop subgraph: rows all over the file, and the rows that straddle the
+        # 16 Mi-element staging-chunk boundaries of the index file
+        cut = [(c << 24) // (2 * half) for c in (1,)]
+        roots = np.unique(np.concatenate([np.random.default_rng(3).integers(0, n, 3000), [0, 1, n - 1, n // 2],
+                                          np.arange(cut[0] - 3, cut[0] + 4)])).astype(np.uint32)
+        got = hs.sample(SamplerConfig(method="khop", depth=1, budget=-1), roots=roots).to_host()
+        off = got["subg_node_off"].astype(np.int64)
+        assert np.array_equal(np.diff(off), np.full(roots.size, 2 * half + 1))
+        want = np.sort((roots.astype(np.int64)[:, None] + np.arange(-half, half + 1)[None, :]) % n, axis=1)
+        assert np.array_equal(got["node"].reshape(roots.size, 2 * half + 1).astype(np.int64), want)
+        del hs
+
+
+def _free_hbm_gb():
+    free, _total = torch.cuda.mem_get_info(0)
+    return free / 2 ** 30
+
+
+def _host_ram_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        return 0.0
+
+
+@pytest.mark.parametrize("method", ["khop", "ppr"])
+def test_papers100m_shape_matches_oracle(method):
+    """BASELINE configs[4]: the papers100M-shape CSR (N = 111 M, 3.2 G directed entries = 13.4 GB, edge ids beyond
+    2^31) resident in one GPU's HBM: k-hop (depth 2, budget 20, self edges) and PPR top-k batches of 256 roots equal
+    the oracle's on the same graph copied to the host -- node, indptr, indices, edge_id (> 2^31), target, hop; the
+    PPR table of the roots is built on the GPU (sg_ppr_push) and compared with the oracle's for a subset.
+    Skipped when the box cannot hold it (needs ~80 GB free HBM while generating, ~40 GB host RAM for the oracle)."""
+    if _free_hbm_gb() < 80 or _host_ram_gb() < 40:
+        pytest.skip(f"papers100M shape needs 80 GB free HBM / 40 GB host RAM (have {_free_hbm_gb():.0f} / {_host_ram_gb():.0f})")
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.ppr import ppr_approximate_device
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+    from shadow_gnn_amd.synthetic import MAX_DEGREE, SHAPES, make_graph_torch
+    dev = torch.device("cuda:0")
+    N, nnz, _, _ = SHAPES["papers100M"]
+    indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE["papers100M"])
+    assert indices.numel() > 2 ** 31
+    ip, ix = indptr.cpu().numpy().view(np.uint32), indices.cpu().numpy().view(np.uint32)
+    B = 256
+    roots = torch.randperm(N, generator=torch.Generator().manual_seed(2))[:B].numpy().astype(np.uint32)
+    hs = HipSampler(indptr, indices, device=dev, seed=3)
+    hs.shuffle_targets(roots)
+    if method == "khop":
+        cfg = SamplerConfig(method="khop", depth=2, budget=20, add_self_edge=True, aug=("hops",))
+        got = hs.sample(cfg, B).to_host()
+        ref = so.sample_batch(ip, ix, roots, method="khop", depth=2, budget=20, add_self_edge=True, aug=("hops",),
+                              seed=3, serial_base=0, num_threads=32)
+    else:
+        k = 200
+        ln, nb, sc = ppr_approximate_device(hs, roots, k, 0.85, 1e-5)
+        sub = roots[:32]
+        tab = so.ppr_approximate(ip, ix, sub, k=k, alpha=0.85, epsilon=1e-5, num_threads=32)
+        assert np.array_equal(ln[:32], tab.len)
+        for i in range(32):
+            L = int(ln[i])
+            assert np.array_equal(nb[i, :L], tab.neigh[i, :L]) and np.array_equal(sc[i, :L].view(np.uint32), tab.score[i, :L].view(np.uint32)), i
+        hs.set_ppr(roots, ln, nb, sc)
+        cfg = SamplerConfig(method="ppr", k=k, threshold=0.0, add_self_edge=True, aug=("hops",))
+        got = hs.sample(cfg, B).to_host()
+        row = np.full(N, -1, dtype=np.int32); row[roots] = np.arange(B, dtype=np.int32)
+        ref = so.sample_batch(ip, ix, roots, method="ppr", k=k, threshold=0.0, add_self_edge=True, aug=("hops",),
+                              ppr=so.PprTable(row_of_node=row, len=ln, neigh=nb, score=sc), seed=3, num_threads=32)
+    for f in INT_FIELDS + ["hop"]:
+        assert np.array_equal(got[f], getattr(ref, f)), (method, f)
+    eid = got["edge_id"][got["edge_id"] != 0xFFFFFFFF]
+    assert eid.size and int(eid.max()) > 2 ** 31                     # ids the int32 view would call negative
