@@ -56,7 +56,7 @@ int set_error(int code, const char *fmt, ...) {
 
 }  // namespace shadow
 
-#include "sampler_device.h"
+#include "sampler_scan.h"
 
 namespace shadow {
 
@@ -77,7 +77,11 @@ struct RelocParams {
   const uint32_t *s_eid;
   const uint32_t *s_tgt;
   const uint32_t *s_cnt;
+  const uint32_t *itemptr;   // [P+1] scan items of every subgraph
+  const RoundRec *recs;      // round records: where each item's ordered survivors sit in the edge scratch
+  const uint32_t *plan;
   uint32_t *s_tmp;       // [P*cap_nodes_scr] BFS scratch (drnl)
+  uint32_t *s_lcol;      // [P*cap_edges_scr] local column ids in final order (hop / drnl BFS)
   sg_batch_out out;
   uint64_t *d_counts;    // [8] n_tot, e_tot, max_n, max_e, overflow, slots, fnodes, freads
 };
@@ -156,6 +160,8 @@ __global__ void sg_relocate_kernel(RelocParams p) {
     }
   }
   uint32_t ovf = flags & 3u;
+  if (e > p.cap_edges_scr) ovf |= 2u;                       // the scan ran out of per-subgraph edge scratch
+  if (p.plan[PL_FLAGS] & 16u) ovf |= 16u;                   // ... or of round records
   if (noff + n > o.cap_nodes) ovf |= 4u;
   if (eoff + e > o.cap_edges) ovf |= 8u;
   if (ovf) {
@@ -167,36 +173,52 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   uint32_t *rowptr = p.s_rowptr + (size_t)s * (p.cap_nodes_scr + 1);
   const uint32_t *erow = p.s_row + (size_t)s * p.cap_edges_scr;
   const uint32_t *col = p.s_col + (size_t)s * p.cap_edges_scr;
-  // local CSR row pointers: edges are ordered by row, so rowptr[i] = first edge j with erow[j] >= i.
-  // Every edge that starts a new row fills the pointers of the rows since the previous edge's row
-  // (two coalesced reads per edge instead of a binary search per node).
-  for (uint32_t j = tid; j <= e; j += T) {
-    const uint32_t r_hi = (j < e) ? erow[j] : n;                 // rows (r_lo, r_hi] start at edge j
-    const uint32_t r_lo = (j > 0) ? erow[j - 1] + 1u : 0u;
-    for (uint32_t i = r_lo; i <= r_hi && i <= n; i++) rowptr[i] = j;
-  }
-  __syncthreads();
   const uint32_t *eid = p.s_eid + (size_t)s * p.cap_edges_scr;
   for (uint32_t i = tid; i < n; i += T) {
     o.d_node[noff + i] = nodes[i];
-    o.d_indptr[noff + i] = (uint32_t)(eoff + rowptr[i]);
     if (o.d_ppr) o.d_ppr[noff + i] = ppr[i];
   }
-  if (s + 1 == p.P && tid == 0) o.d_indptr[noff + n] = (uint32_t)(eoff + e);
-  for (uint32_t j = tid; j < e; j += T) {
-    o.d_indices[eoff + j] = (uint32_t)(noff + col[j]);
-    o.d_edge_id[eoff + j] = eid[j];
+  // The scan left the subgraph's edges as a chain of rounds per item, every round in the reference's edge order
+  // and the rounds / items ordered by quad position: concatenating them in item order is the ordered edge list.
+  // Row pointers come from the same pass: edges are ordered by row, so rowptr[i] = first edge j with row(j) >= i --
+  // every edge that starts a new row fills the pointers of the rows since the previous edge's row.
+  // hop BFS / DRNL run on the subgraph's own CSR: local column ids in final order
+  uint32_t *lcol = p.s_lcol + (size_t)s * p.cap_edges_scr;
+  const bool want_lcol = (p.aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) != 0;
+  uint32_t dst = 0, prev_row = 0xFFFFFFFFu;                  // uniform walk state
+  for (uint32_t it = p.itemptr[s]; it < p.itemptr[s + 1]; it++) {
+    for (uint32_t rc = it; rc != 0xFFFFFFFFu;) {
+      const RoundRec rr = p.recs[rc];
+      for (uint32_t k = tid; k < rr.cnt; k += T) {
+        const uint32_t src = rr.src_off + k, j = dst + k;
+        const uint32_t r_hi = erow[src];
+        const uint32_t r_before = (k > 0) ? erow[src - 1] : prev_row;
+        const uint32_t r_lo = (j > 0) ? r_before + 1u : 0u;
+        for (uint32_t i = r_lo; i <= r_hi && i <= n; i++) rowptr[i] = j;
+        const uint32_t cj = col[src];
+        o.d_indices[eoff + j] = (uint32_t)(noff + cj);
+        o.d_edge_id[eoff + j] = eid[src];
+        if (want_lcol) lcol[j] = cj;
+      }
+      if (rr.cnt) prev_row = erow[rr.src_off + rr.cnt - 1u];
+      dst += rr.cnt;
+      rc = rr.next;
+    }
   }
+  for (uint32_t i = (e > 0 ? prev_row + 1u : 0u) + tid; i <= n; i += T) rowptr[i] = e;   // rows behind the last edge
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += T) o.d_indptr[noff + i] = (uint32_t)(eoff + rowptr[i]);
+  if (s + 1 == p.P && tid == 0) o.d_indptr[noff + n] = (uint32_t)(eoff + e);
   const uint32_t *tgt = p.s_tgt + (size_t)s * kMaxRoots;
   if (tid < (uint32_t)p.R) o.d_target[(size_t)s * p.R + tid] = (uint32_t)(noff + tgt[tid]);
   if ((p.aug_flags & SG_AUG_HOPS) && o.d_hop) {
-    bfs_local(rowptr, col, n, tgt[0], o.d_hop + noff, &changed);            // .cpp:433-436
+    bfs_local(rowptr, lcol, n, tgt[0], o.d_hop + noff, &changed);           // .cpp:433-436
   }
   if ((p.aug_flags & SG_AUG_DRNLS) && o.d_drnl && p.R >= 2) {               // .cpp:438-451
     uint32_t *dx = p.s_tmp + (size_t)s * p.cap_nodes_scr;
     uint32_t *dy = o.d_drnl + noff;
-    bfs_local(rowptr, col, n, tgt[0], dx, &changed);
-    bfs_local(rowptr, col, n, tgt[1], dy, &changed);
+    bfs_local(rowptr, lcol, n, tgt[0], dx, &changed);
+    bfs_local(rowptr, lcol, n, tgt[1], dy, &changed);
     for (uint32_t i = tid; i < n; i += T) {
       const uint32_t a = dx[i], b = dy[i];
       uint32_t r;
@@ -724,6 +746,10 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
   const size_t o_row = carve(Pz * (size_t)cape * 4);
   const size_t o_col = carve(Pz * (size_t)cape * 4), o_eid = carve(Pz * (size_t)cape * 4);
   const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
+  const size_t o_info = carve(Pz * capn * sizeof(RowInfo)), o_rowq = carve(Pz * ((size_t)capn + 1) * 4);
+  const size_t o_lcol = carve((cfg->aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) ? Pz * (size_t)cape * 4 : 16);
+  const uint32_t rec_cap = 2u * ((uint32_t)Pz + kPlanItems);
+  const size_t o_itemptr = carve((Pz + 1) * 4), o_plan = carve(PL_WORDS * 4), o_recs = carve((size_t)rec_cap * sizeof(RoundRec));
   int rc;
   if ((rc = ensure(&s->d_scratch, &s->scratch_bytes, o)) != SG_OK) return rc;
   char *sc = (char *)s->d_scratch;
@@ -754,60 +780,43 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     p.s_row = (uint32_t *)(sc + o_row); p.s_col = (uint32_t *)(sc + o_col);
     p.s_eid = (uint32_t *)(sc + o_eid); p.s_tgt = (uint32_t *)(sc + o_tgt);
     p.s_cnt = (uint32_t *)(sc + o_cnt);
+    p.s_rowinfo = (RowInfo *)(sc + o_info); p.s_rowq = (uint32_t *)(sc + o_rowq);
+    p.itemptr = (uint32_t *)(sc + o_itemptr); p.plan = (uint32_t *)(sc + o_plan);
+    p.recs = (RoundRec *)(sc + o_recs); p.rec_cap = rec_cap;
     s->last_cnt = p.s_cnt;
-    // ---- LDS kernel (persistent workgroups, one subgraph at a time)
-    const uint32_t capn_lds = std::min(capn, kLdsCapNodes);
-    const uint32_t capf_lds = std::min(capf, capn_lds);
-    uint32_t T = 512;
-    if (const char *e = getenv("SHADOW_SG_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = (uint32_t)v; }
-    // bucketised table: ~4 key slots per possible node (power-of-two bucket count)
-    uint32_t H = std::max<uint32_t>(64, next_pow2((uint64_t)capn_lds * 4));
-    while ((size_t)H * 8 > 16 * 1024 && (H >> 1) >= capn_lds * 2) H >>= 1;
-    p.capn = capn_lds; p.capf = capf_lds; p.H = H;
-    p.hshift = 32; for (uint32_t h = H / 4; h > 1; h >>= 1) p.hshift--;
-    p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, ((capn_lds * 7 / 2) + 255) & ~255u));
-    if (const char *e = getenv("SHADOW_SG_CAPM")) { const int v = atoi(e); if (v >= 256) p.capm = (uint32_t)v; }
-    p.g_ticket = (uint32_t *)(s->d_counts + 8);
-    const LdsLayout L = lds_layout(H, capn_lds, capf_lds, p.capm, cfg->method == SG_METHOD_PPR);
-    if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
-    const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
-    const void *kfn = plain ? (const void *)sg_sample_lds_kernel<true> : (const void *)sg_sample_lds_kernel<false>;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
-    uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));
-    per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 7));
-    // Fewer resident workgroups run each subgraph faster (they share the CU's LDS pipe and issue
-    // slots): take the smallest residency that does not add a round of subgraphs.
+    auto env_u32 = [](const char *name, uint32_t dflt) { const char *e = getenv(name); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt; };
+    // ---- 1. selection (one workgroup per subgraph, persistent over a ticket; tables in LDS)
+    const uint32_t capn_lds = std::min(capn, kLdsCapNodes);
+    const uint32_t capf_lds = std::min(capf, capn_lds);
     {
-      uint32_t best = per_cu;
-      double best_cost = 1e30;
-      for (uint32_t pc = 1; pc <= per_cu; pc++) {
-        const uint32_t rounds = (P + (uint32_t)ncu * pc - 1) / ((uint32_t)ncu * pc);
-        const double cost = rounds * (1.0 + 0.11 * (pc - 1));
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = pc; }
-      }
-      if (const char *e = getenv("SHADOW_SG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 7) best = std::min<uint32_t>(per_cu, (uint32_t)v); }
-      per_cu = best;
+      uint32_t T = env_u32("SHADOW_SG_THREADS", 256);
+      if (T != 256 && T != 512 && T != 1024) T = 256;
+      // bucketised table: ~4 key slots per possible node (power-of-two bucket count)
+      uint32_t H = std::max<uint32_t>(64, next_pow2((uint64_t)capn_lds * 4));
+      while ((size_t)H * 8 > 16 * 1024 && (H >> 1) >= capn_lds * 2) H >>= 1;
+      p.capn = capn_lds; p.capf = capf_lds; p.H = H;
+      p.hshift = 32; for (uint32_t h = H / 4; h > 1; h >>= 1) p.hshift--;
+      p.g_ticket = (uint32_t *)(s->d_counts + 8);
+      const LdsLayout L = lds_layout(H, capn_lds, capf_lds, cfg->method == SG_METHOD_PPR);
+      if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
+      uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));
+      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_PER_CU", 8)));
+      const uint32_t grid = std::min<uint32_t>(P, (uint32_t)ncu * per_cu);
+      if (L.total > 64 * 1024)
+        SHD_HIP(hipFuncSetAttribute((const void *)sg_select_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+      hipLaunchKernelGGL(sg_select_lds_kernel, dim3(grid), dim3(T), L.total, stream, p);
+      SHD_HIP(hipGetLastError());
     }
-    const uint32_t grid = std::min<uint32_t>(P, (uint32_t)ncu * per_cu);
-    // ask for 1/per_cu of the CU's LDS so the dispatcher cannot pack more workgroups on one CU
-    // than intended (and leave other CUs short)
-    size_t lds_req = std::max<size_t>(L.total, ((size_t)(160 * 1024) / per_cu - 512) & ~(size_t)255);
-    if (lds_req > 64 * 1024)
-      SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req));
-    if (plain) hipLaunchKernelGGL(sg_sample_lds_kernel<true>, dim3(grid), dim3(T), lds_req, stream, p);
-    else hipLaunchKernelGGL(sg_sample_lds_kernel<false>, dim3(grid), dim3(T), lds_req, stream, p);
-    SHD_HIP(hipGetLastError());
-    // ---- big path for subgraphs that overflowed the LDS tables
+    // ---- 1b. node sets beyond the LDS tables: the same selection over global-memory tables
     if (capn > capn_lds) {
       SampleParams q = p;
       q.capn = capn; q.capf = capf;
       const uint32_t Tb = 1024;
       uint32_t Hb = std::max<uint32_t>(64, next_pow2((uint64_t)capn * 4));
       q.H = Hb; q.hshift = 32; for (uint32_t h = Hb / 4; h > 1; h >>= 1) q.hshift--;
-      q.capm = std::max<uint32_t>(8192, next_pow2((uint64_t)capn * 4));
-      uint64_t stride = ((uint64_t)Hb + kStash) * 3 + ((uint64_t)capn + 8) * 4 + ((uint64_t)capf + 4) * 2 +
-                        (uint64_t)q.capm * 3 + 64;
+      uint64_t stride = ((uint64_t)Hb + kStash) * 3 + ((uint64_t)capn + 8) + ((uint64_t)capf + 4) * 2 + 64;
       stride = (stride + 63) & ~(uint64_t)63;
       uint32_t nslots = std::min<uint32_t>(P, (uint32_t)ncu);
       // keep the table arena below 4 GiB
@@ -815,9 +824,32 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       if ((rc = ensure(&s->d_big, &s->big_bytes, (size_t)nslots * stride * 4)) != SG_OK) return rc;
       q.g_tables = (uint32_t *)s->d_big; q.g_stride = stride;
       q.g_ticket = (uint32_t *)(s->d_counts + 8) + 1;
-      const size_t big_lds = (size_t)kBitWordsBig * 4;
-      SHD_HIP(hipFuncSetAttribute((const void *)sg_sample_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
-      hipLaunchKernelGGL(sg_sample_big_kernel, dim3(nslots), dim3(Tb), big_lds, stream, q);
+      hipLaunchKernelGGL(sg_select_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
+      SHD_HIP(hipGetLastError());
+    }
+    // ---- 2. plan: cut the subgraphs' quad streams into work items
+    hipLaunchKernelGGL(sg_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
+    SHD_HIP(hipGetLastError());
+    // ---- 3. scan: persistent workgroups over the items
+    {
+      const bool big = capn > kLdsCapNodes;
+      p.bit_words = env_u32("SHADOW_SG_BITWORDS", big ? kBitWordsBig : kBitWords);
+      if (p.bit_words & (p.bit_words - 1)) p.bit_words = big ? kBitWordsBig : kBitWords;
+      p.capm = std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : 2048));
+      p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
+      const ScanLayout SL = scan_layout(p.bit_words, p.capm, p.nodes_lds);
+      if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
+      uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", 512);
+      if (T != 256 && T != 512 && T != 1024) T = 512;
+      uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));
+      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_SCAN_PER_CU", 8)));
+      const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
+      const void *kfn = plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
+      if (SL.total > 64 * 1024)
+        SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL.total));
+      const uint32_t grid = (uint32_t)ncu * per_cu;
+      if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(grid), dim3(T), SL.total, stream, p);
+      else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(grid), dim3(T), SL.total, stream, p);
       SHD_HIP(hipGetLastError());
     }
     if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[1], stream));
@@ -828,6 +860,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     r.s_nodes = p.s_nodes; r.s_ppr = p.s_ppr; r.s_rowptr = (uint32_t *)(sc + o_rowptr);
     r.s_row = p.s_row; r.s_col = p.s_col;
     r.s_eid = p.s_eid; r.s_tgt = p.s_tgt; r.s_cnt = p.s_cnt; r.s_tmp = (uint32_t *)(sc + o_tmp);
+    r.itemptr = p.itemptr; r.recs = p.recs; r.plan = p.plan; r.s_lcol = (uint32_t *)(sc + o_lcol);
     r.out = *out; r.d_counts = s->d_counts;
     hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(256), 0, stream, r);
     SHD_HIP(hipGetLastError());
