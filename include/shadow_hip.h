@@ -377,6 +377,15 @@ int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32
  * frontier reads, -, -, 8 x phase cycle stamps (only when the library was
  * built with -DSHADOW_SG_TIMING)}.  Synchronises the device.                  */
 int sg_debug_subgraph_stats(sg_sampler *s, uint32_t *h_out, uint32_t max_subgraphs);
+/* Debug: the 16 plan words of the last sg_sample call -- [0] scan work items, [1] chunks per item, [8..12] cycles/16
+ * the scan workgroups' leaders spent in (item setup, chunk start rows, scan, candidate resolution, sort + write),
+ * [13] items, [14] rounds.  Synchronises the device.                                                          */
+int sg_debug_scan_phases(sg_sampler *s, uint32_t *h_out16);
+/* Calibration: stream the full-graph rows of `n` nodes (device array d_nodes) as the scan does (aligned 16-byte quads,
+ * one wavefront per row, `depth` in {1, 2, 4} 1-KiB loads in flight, `blocks` workgroups of 256 threads) and fold each
+ * row into d_out[i]: the memory system's ceiling for the sampler's access pattern (scripts/probe_row_stream.py).   */
+int sg_debug_stream_rows(sg_sampler *s, const uint32_t *d_nodes, uint32_t n, uint32_t *d_out, int depth, int blocks,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,12 +12,21 @@ roots = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy().as
 hs.shuffle_targets(roots)
 hs.set_profiling(True)
 cfg = SamplerConfig(method="khop", depth=2, budget=20)
-for B in (256, 512, 768, 1024, 1536, 2048, 4096, 8192):
+Bs = [int(a) for a in sys.argv[1:]] or [256, 512, 768, 1024, 1536, 2048, 4096, 8192]
+for B in Bs:
     ms, nn, slots = [], 0, 0
     for it in range(6):
         b = hs.sample(cfg, B)
         if it >= 2:
             ms.append(b.counts["sample_kernel_ms"]); nn += b.num_nodes; slots += b.counts["slots_scanned"]
     m = float(np.mean(ms))
+    import ctypes as C
+    ph = (C.c_uint32 * 24)()
+    hs._lib.sg_debug_scan_phases(hs._h, ph)
+    tot = sum(ph[8:13]) or 1
+    print(f"   scan: chunks {ph[0]} per workgroup {ph[1]} segments {ph[13]} rounds {ph[14]}  phases setup/startrows/scan/resolve/sortwrite = "
+          + " / ".join(f"{100 * ph[8 + i] / tot:.0f}%" for i in range(5)) + f"   avg cycles per segment {16 * tot / max(1, ph[13]):.0f}"
+          + f"\n         wave 0 inside the scan (cycles per segment): window setup {16 * ph[15] / max(1, ph[13]):.0f}, map + issue {16 * ph[16] / max(1, ph[13]):.0f}, "
+          f"wait {16 * ph[17] / max(1, ph[13]):.0f}, probe + emit {16 * ph[18] / max(1, ph[13]):.0f}; scan phase total {16 * ph[10] / max(1, ph[13]):.0f}")
     print(f"B={B:5d}: sample kernel {m:.3f} ms  {nn / 4 / m / 1e3:.0f} M nodes/s  neighbour ids scanned {slots / 4 * 4 / m / 1e6:.0f} GB/s  "
           f"({m / B * 1e3:.3f} us per subgraph)")

@@ -83,6 +83,8 @@ SIGNATURES = {
     "sg_sample_finish": (C.c_int, [_P, C.POINTER(SgBatchCounts)]),
     "sg_set_profiling": (C.c_int, [_P, C.c_int]),
     "sg_debug_subgraph_stats": (C.c_int, [_P, _P, C.c_uint32]),
+    "sg_debug_scan_phases": (C.c_int, [_P, _P]),
+    "sg_debug_stream_rows": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_int, C.c_int, _P]),
     "sl_gather_rows_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_csr_edge_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_csr_transpose": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P]),

@@ -31,16 +31,26 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
 
-// inclusive scan across the 64 lanes of a wave
+// Inclusive scans across the 64 lanes of a wave on the DPP network (no LDS crossbar round trips): row_shr 1/2/4/8
+// inside the 16-lane rows, then row_bcast:15 (lane 15 of a row into the next row) and row_bcast:31 (lane 31 into
+// the upper half).  Lanes without a source keep the identity passed as `old`.
+#define SHD_DPP_STEP(OP, CTRL, ROWMASK) v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ uint32_t dpp_add_(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_max_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  const uint32_t lane = lane_id();
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(v, off, 64);
-    if (lane >= (uint32_t)off) v += t;
-  }
+  SHD_DPP_STEP(dpp_add_, 0x111, 0xf); SHD_DPP_STEP(dpp_add_, 0x112, 0xf); SHD_DPP_STEP(dpp_add_, 0x114, 0xf);
+  SHD_DPP_STEP(dpp_add_, 0x118, 0xf); SHD_DPP_STEP(dpp_add_, 0x142, 0xa); SHD_DPP_STEP(dpp_add_, 0x143, 0xc);
   return v;
 }
+
+// inclusive max-scan of unsigned values (identity 0)
+__device__ __forceinline__ uint32_t wave_incl_max_scan(uint32_t v) {
+  SHD_DPP_STEP(dpp_max_, 0x111, 0xf); SHD_DPP_STEP(dpp_max_, 0x112, 0xf); SHD_DPP_STEP(dpp_max_, 0x114, 0xf);
+  SHD_DPP_STEP(dpp_max_, 0x118, 0xf); SHD_DPP_STEP(dpp_max_, 0x142, 0xa); SHD_DPP_STEP(dpp_max_, 0x143, 0xc);
+  return v;
+}
+#undef SHD_DPP_STEP
 
 // ---------------------------------------------------------------- Philox4x32-10
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

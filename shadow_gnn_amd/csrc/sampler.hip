@@ -77,8 +77,9 @@ struct RelocParams {
   const uint32_t *s_eid;
   const uint32_t *s_tgt;
   const uint32_t *s_cnt;
-  const uint32_t *itemptr;   // [P+1] scan items of every subgraph
-  const RoundRec *recs;      // round records: where each item's ordered survivors sit in the edge scratch
+  const uint32_t *cstart;    // [P+1] chunk prefix of the subgraphs
+  const RoundRec *recs;      // round records: where each round's ordered survivors sit in the edge scratch
+  const uint2 *blkinfo;
   const uint32_t *plan;
   uint32_t *s_tmp;       // [P*cap_nodes_scr] BFS scratch (drnl)
   uint32_t *s_lcol;      // [P*cap_edges_scr] local column ids in final order (hop / drnl BFS)
@@ -178,31 +179,38 @@ __global__ void sg_relocate_kernel(RelocParams p) {
     o.d_node[noff + i] = nodes[i];
     if (o.d_ppr) o.d_ppr[noff + i] = ppr[i];
   }
-  // The scan left the subgraph's edges as a chain of rounds per item, every round in the reference's edge order
-  // and the rounds / items ordered by quad position: concatenating them in item order is the ordered edge list.
+  // The scan left the subgraph's edges as round records, every round in the reference's edge order and the rounds
+  // ordered by quad position (workgroup by workgroup, in filing order): concatenating them is the ordered edge list.
   // Row pointers come from the same pass: edges are ordered by row, so rowptr[i] = first edge j with row(j) >= i --
   // every edge that starts a new row fills the pointers of the rows since the previous edge's row.
   // hop BFS / DRNL run on the subgraph's own CSR: local column ids in final order
   uint32_t *lcol = p.s_lcol + (size_t)s * p.cap_edges_scr;
   const bool want_lcol = (p.aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) != 0;
   uint32_t dst = 0, prev_row = 0xFFFFFFFFu;                  // uniform walk state
-  for (uint32_t it = p.itemptr[s]; it < p.itemptr[s + 1]; it++) {
-    for (uint32_t rc = it; rc != 0xFFFFFFFFu;) {
-      const RoundRec rr = p.recs[rc];
-      for (uint32_t k = tid; k < rr.cnt; k += T) {
-        const uint32_t src = rr.src_off + k, j = dst + k;
-        const uint32_t r_hi = erow[src];
-        const uint32_t r_before = (k > 0) ? erow[src - 1] : prev_row;
-        const uint32_t r_lo = (j > 0) ? r_before + 1u : 0u;
-        for (uint32_t i = r_lo; i <= r_hi && i <= n; i++) rowptr[i] = j;
-        const uint32_t cj = col[src];
-        o.d_indices[eoff + j] = (uint32_t)(noff + cj);
-        o.d_edge_id[eoff + j] = eid[src];
-        if (want_lcol) lcol[j] = cj;
+  const uint32_t ch0 = p.cstart[s], ch1 = p.cstart[s + 1], cpw = p.plan[PL_CPW];
+  if (ch1 > ch0) {
+    for (uint32_t w = ch0 / cpw; w <= (ch1 - 1u) / cpw; w++) {          // the scan workgroups that held chunks of s
+      for (uint32_t blk = w; blk != 0xFFFFFFFFu;) {
+        const uint2 bi = p.blkinfo[blk];
+        for (uint32_t q = 0; q < bi.x; q++) {
+          const RoundRec rr = p.recs[(size_t)blk * kRecPerBlock + q];
+          if (rr.s != s) continue;
+          for (uint32_t k = tid; k < rr.cnt; k += T) {
+            const uint32_t src = rr.src_off + k, j = dst + k;
+            const uint32_t r_hi = erow[src];
+            const uint32_t r_before = (k > 0) ? erow[src - 1] : prev_row;
+            const uint32_t r_lo = (j > 0) ? r_before + 1u : 0u;
+            for (uint32_t i = r_lo; i <= r_hi && i <= n; i++) rowptr[i] = j;
+            const uint32_t cj = col[src];
+            o.d_indices[eoff + j] = (uint32_t)(noff + cj);
+            o.d_edge_id[eoff + j] = eid[src];
+            if (want_lcol) lcol[j] = cj;
+          }
+          if (rr.cnt) prev_row = erow[rr.src_off + rr.cnt - 1u];
+          dst += rr.cnt;
+        }
+        blk = bi.y;
       }
-      if (rr.cnt) prev_row = erow[rr.src_off + rr.cnt - 1u];
-      dst += rr.cnt;
-      rc = rr.next;
     }
   }
   for (uint32_t i = (e > 0 ? prev_row + 1u : 0u) + tid; i <= n; i += T) rowptr[i] = e;   // rows behind the last edge
@@ -267,6 +275,7 @@ struct sg_sampler {
   bool pending = false;
   uint32_t pending_P = 0;
   const uint32_t *last_cnt = nullptr;   // per-subgraph result words of the last call
+  const uint32_t *last_plan = nullptr;  // plan words of the last call (item count, phase cycles of the scan)
   bool profiling = false;
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};
   bool timed = false;
@@ -748,8 +757,10 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
   const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
   const size_t o_info = carve(Pz * capn * sizeof(RowInfo)), o_rowq = carve(Pz * ((size_t)capn + 1) * 4);
   const size_t o_lcol = carve((cfg->aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) ? Pz * (size_t)cape * 4 : 16);
-  const uint32_t rec_cap = 2u * ((uint32_t)Pz + kPlanItems);
-  const size_t o_itemptr = carve((Pz + 1) * 4), o_plan = carve(PL_WORDS * 4), o_recs = carve((size_t)rec_cap * sizeof(RoundRec));
+  const uint32_t kScanGridMax = 8u * 256u;
+  const uint32_t rec_blocks = 2u * kScanGridMax + (uint32_t)Pz / 4u;
+  const size_t o_cstart = carve((Pz + 1) * 4), o_plan = carve(PL_WORDS * 4);
+  const size_t o_recs = carve((size_t)rec_blocks * kRecPerBlock * sizeof(RoundRec)), o_blkinfo = carve((size_t)rec_blocks * sizeof(uint2));
   int rc;
   if ((rc = ensure(&s->d_scratch, &s->scratch_bytes, o)) != SG_OK) return rc;
   char *sc = (char *)s->d_scratch;
@@ -781,9 +792,9 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     p.s_eid = (uint32_t *)(sc + o_eid); p.s_tgt = (uint32_t *)(sc + o_tgt);
     p.s_cnt = (uint32_t *)(sc + o_cnt);
     p.s_rowinfo = (RowInfo *)(sc + o_info); p.s_rowq = (uint32_t *)(sc + o_rowq);
-    p.itemptr = (uint32_t *)(sc + o_itemptr); p.plan = (uint32_t *)(sc + o_plan);
-    p.recs = (RoundRec *)(sc + o_recs); p.rec_cap = rec_cap;
-    s->last_cnt = p.s_cnt;
+    p.cstart = (uint32_t *)(sc + o_cstart); p.plan = (uint32_t *)(sc + o_plan);
+    p.recs = (RoundRec *)(sc + o_recs); p.blkinfo = (uint2 *)(sc + o_blkinfo); p.rec_blocks = rec_blocks;
+    s->last_cnt = p.s_cnt; s->last_plan = p.plan;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
     auto env_u32 = [](const char *name, uint32_t dflt) { const char *e = getenv(name); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt; };
@@ -827,15 +838,13 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       hipLaunchKernelGGL(sg_select_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
       SHD_HIP(hipGetLastError());
     }
-    // ---- 2. plan: cut the subgraphs' quad streams into work items
-    hipLaunchKernelGGL(sg_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
-    SHD_HIP(hipGetLastError());
-    // ---- 3. scan: persistent workgroups over the items
+    // ---- 2. plan (chunk prefix, chunks per scan workgroup) + 3. scan: one equal span of the chunk sequence per workgroup
     {
       const bool big = capn > kLdsCapNodes;
+      if (capn >= (1u << kRankShift)) return set_error(SG_ERR_INVALID, "sg_sample: subgraphs of %u nodes exceed the scan's row field", capn);
       p.bit_words = env_u32("SHADOW_SG_BITWORDS", big ? kBitWordsBig : kBitWords);
       if (p.bit_words & (p.bit_words - 1)) p.bit_words = big ? kBitWordsBig : kBitWords;
-      p.capm = std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : 2048));
+      p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : 2048)));
       p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
       const ScanLayout SL = scan_layout(p.bit_words, p.capm, p.nodes_lds);
       if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
@@ -843,13 +852,15 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       if (T != 256 && T != 512 && T != 1024) T = 512;
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));
       per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_SCAN_PER_CU", 8)));
+      p.scan_grid = std::min<uint32_t>((uint32_t)ncu * per_cu, kScanGridMax);
+      hipLaunchKernelGGL(sg_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
+      SHD_HIP(hipGetLastError());
       const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
       const void *kfn = plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
       if (SL.total > 64 * 1024)
         SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL.total));
-      const uint32_t grid = (uint32_t)ncu * per_cu;
-      if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(grid), dim3(T), SL.total, stream, p);
-      else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(grid), dim3(T), SL.total, stream, p);
+      if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       SHD_HIP(hipGetLastError());
     }
     if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[1], stream));
@@ -860,7 +871,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     r.s_nodes = p.s_nodes; r.s_ppr = p.s_ppr; r.s_rowptr = (uint32_t *)(sc + o_rowptr);
     r.s_row = p.s_row; r.s_col = p.s_col;
     r.s_eid = p.s_eid; r.s_tgt = p.s_tgt; r.s_cnt = p.s_cnt; r.s_tmp = (uint32_t *)(sc + o_tmp);
-    r.itemptr = p.itemptr; r.recs = p.recs; r.plan = p.plan; r.s_lcol = (uint32_t *)(sc + o_lcol);
+    r.cstart = p.cstart; r.recs = p.recs; r.blkinfo = p.blkinfo; r.plan = p.plan; r.s_lcol = (uint32_t *)(sc + o_lcol);
     r.out = *out; r.d_counts = s->d_counts;
     hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(256), 0, stream, r);
     SHD_HIP(hipGetLastError());
@@ -906,6 +917,57 @@ extern "C" int sg_set_profiling(sg_sampler *s, int enable) {
   if (enable && !s->ev_t[0])
     for (int i = 0; i < 3; i++) SHD_HIP(hipEventCreate(&s->ev_t[i]));
   s->profiling = enable != 0;
+  return SG_OK;
+}
+
+// Debug / calibration: stream the full-graph rows of `n` nodes (device array) exactly like the scan does -- aligned
+// 16-byte quads, one wavefront per row, `depth` 1-KiB loads in flight -- and fold them into one word per row.  No
+// filter, no LDS: the rate this reaches is the memory system's ceiling for the sampler's access pattern.
+namespace shadow {
+template <int kDepth>
+__global__ void __launch_bounds__(256) stream_rows_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                          const uint32_t *__restrict__ nodes, uint32_t n, uint32_t *__restrict__ out) {
+  const uint32_t lane = lane_id();
+  const uint32_t wpb = blockDim.x >> 6;
+  for (uint32_t r = blockIdx.x * wpb + wave_id(); r < n; r += gridDim.x * wpb) {
+    const uint32_t v = nodes[r];
+    const uint32_t e0 = indptr[v], e1 = indptr[v + 1];
+    const uint32_t q0 = e0 >> 2, q1 = e1 > e0 ? ((e1 - 1u) >> 2) + 1u : q0;
+    uint32_t acc = 0;
+    for (uint32_t q = q0; q < q1; q += 64u * kDepth) {
+      uint4 c[kDepth];
+#pragma unroll
+      for (int u = 0; u < kDepth; u++) {
+        const uint32_t qq = q + 64u * u + lane;
+        c[u] = qq < q1 ? *reinterpret_cast<const uint4 *>(indices + 4ull * qq) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < kDepth; u++) acc ^= c[u].x ^ c[u].y ^ c[u].z ^ c[u].w;
+    }
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) out[r] = acc;
+  }
+}
+}  // namespace shadow
+
+extern "C" int sg_debug_stream_rows(sg_sampler *s, const uint32_t *d_nodes, uint32_t n, uint32_t *d_out, int depth, int blocks,
+                                    void *stream) {
+  if (!s || !d_nodes || !d_out) return set_error(SG_ERR_INVALID, "sg_debug_stream_rows: null argument");
+  SHD_HIP(hipSetDevice(s->device));
+  const dim3 grid((unsigned)std::max(1, blocks)), block(256);
+  if (depth >= 4) hipLaunchKernelGGL(stream_rows_kernel<4>, grid, block, 0, (hipStream_t)stream, s->d_indptr, s->d_indices, d_nodes, n, d_out);
+  else if (depth >= 2) hipLaunchKernelGGL(stream_rows_kernel<2>, grid, block, 0, (hipStream_t)stream, s->d_indptr, s->d_indices, d_nodes, n, d_out);
+  else hipLaunchKernelGGL(stream_rows_kernel<1>, grid, block, 0, (hipStream_t)stream, s->d_indptr, s->d_indices, d_nodes, n, d_out);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sg_debug_scan_phases(sg_sampler *s, uint32_t *h_out16) {
+  if (!s || !h_out16) return set_error(SG_ERR_INVALID, "sg_debug_scan_phases: null argument");
+  if (!s->last_plan) return set_error(SG_ERR_STATE, "sg_debug_scan_phases: nothing sampled yet");
+  SHD_HIP(hipSetDevice(s->device));
+  SHD_HIP(hipDeviceSynchronize());
+  SHD_HIP(hipMemcpy(h_out16, s->last_plan, PL_WORDS * 4, hipMemcpyDeviceToHost));
   return SG_OK;
 }
 

@@ -51,14 +51,16 @@ struct RowInfo {
   uint32_t v;     // original node id
 };
 
-// Work-item record of the scan kernel: the survivors of one round, in key order, live at
-// [src_off, src_off + cnt) of the subgraph's edge scratch; `next` chains the rounds of an item.
+// Round record of the scan kernel: the survivors of one round of subgraph `s`, in key order, live at
+// [src_off, src_off + cnt) of that subgraph's edge scratch.  Records are filed in blocks of kRecPerBlock: scan
+// workgroup w owns block w and chains further blocks from a pool (blkinfo[b] = {records in block b, next block}).
 struct RoundRec {
-  uint32_t src_off, cnt, next, pad;
+  uint32_t s, src_off, cnt, pad;
 };
 
 // plan words (global): written by sg_plan_kernel
-enum { PL_NITEMS = 0, PL_CPI = 1, PL_POOL = 2, PL_FLAGS = 3, PL_TICKET = 4, PL_WORDS = 8 };
+// (PL_T0..: cycles workgroup leaders spent per scan phase -- setup, start rows, scan, resolve, sort + write, items, rounds)
+enum { PL_NCHUNKS = 0, PL_CPW = 1, PL_POOL = 2, PL_FLAGS = 3, PL_T0 = 8, PL_WORDS = 24 };
 
 struct SampleParams {
   const uint32_t *indptr;
@@ -97,11 +99,13 @@ struct SampleParams {
   uint32_t *s_eid;     // [P*cap_edges_scr]
   uint32_t *s_tgt;     // [P*kMaxRoots]
   uint32_t *s_cnt;     // [P*R_WORDS]
-  // work items of the scan
-  uint32_t *itemptr;   // [P+1] first item of every subgraph
+  // work partition of the scan
+  uint32_t *cstart;    // [P+1] first chunk of every subgraph in the global chunk sequence
   uint32_t *plan;      // [PL_WORDS]
-  RoundRec *recs;      // [rec_cap] item heads (index = item id) followed by the pool of extra rounds
-  uint32_t rec_cap;
+  RoundRec *recs;      // [rec_blocks * kRecPerBlock] round records
+  uint2 *blkinfo;      // [rec_blocks] {records filed in the block, next block of the same workgroup}
+  uint32_t rec_blocks;
+  uint32_t scan_grid;  // workgroups of the scan kernel
   // global tables for the big selection path
   uint32_t *g_tables;        // [n_slots * g_stride]
   uint64_t g_stride;         // words per slot

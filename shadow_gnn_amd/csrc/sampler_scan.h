@@ -5,21 +5,21 @@
 // row {e0, deg, slot prefix, id} plus the prefix of the rows' aligned 16-byte QUADS in the full graph's indices
 // array.  The concatenated quads of all rows of all subgraphs are the stream this kernel reads exactly once:
 //
-//   sg_plan_kernel   (one workgroup) cuts every subgraph's quad range into work ITEMS of `cpi` chunks of kQChunk
-//                    quads (cpi grows with the batch so that the item count stays bounded) and writes the item
-//                    prefix.
-//   sg_scan_kernel   persistent workgroups pull items from a global ticket -- no workgroup is tied to a subgraph,
-//                    so every CU streams ids for the whole duration and one heavy subgraph spreads over the chip.
-//                    Per item: rebuild the subgraph's membership filter in LDS (bit = id mod 2^k; a clear bit is a
-//                    definite miss), then every WAVEFRONT walks one chunk ROW BY ROW with wave-uniform row scalars:
-//                    a row's quads are covered by coalesced 16-byte-per-lane loads (<= 64 quads = 1 KiB per
-//                    instruction, all of a chunk's loads in flight before the first is consumed), each id costs one
-//                    LDS dword probe, and the rare candidates (~1 % of the ids) go to an LDS list keyed by
-//                    2*slot+kind.  At the end of the round the candidates are resolved exactly (binary search in
-//                    the sorted node list = the sub id), bucket-sorted by key -- which restores the reference's
-//                    edge order -- and appended to the subgraph's edge scratch; a round record remembers where.
-//                    Key ranges of different items / rounds of a subgraph are disjoint and ordered by quad position,
-//                    so the relocation kernel only concatenates the records in item order.
+//   sg_plan_kernel   (one workgroup) prefix of the subgraphs' CHUNKS (kQChunk quads = 8 KB of ids); the global chunk
+//                    sequence is cut into equal spans, one per scan workgroup: perfectly balanced in bytes, no
+//                    work queue, and a heavy subgraph simply spreads over several workgroups.
+//   sg_scan_kernel   workgroup w owns chunks [w * cpw, (w + 1) * cpw) -- usually the tail of one subgraph, a few
+//                    whole ones and the head of another.  Per subgraph segment: rebuild that subgraph's membership
+//                    filter in LDS (bit = id mod 2^k; a clear bit is a definite miss), then rounds of <= 64 chunks:
+//                    every WAVEFRONT streams whole chunks with coalesced 16-byte-per-lane loads (64 quads = 1 KiB per
+//                    instruction, a batch of four in flight); the quads of consecutive short rows are packed into the
+//                    same instruction (row WINDOW: 64 rows held one per lane; position -> row by one byte scatter and
+//                    a DPP fill-forward); each id costs one LDS dword probe, and the rare candidates (~1 % of the ids)
+//                    go to an LDS list keyed by 2*slot+kind.  At the end of a round the candidates are resolved exactly
+//                    (binary search in the sorted node list = the sub id), bucket-sorted by key -- which restores the
+//                    reference's edge order -- and appended to the subgraph's edge scratch; a round record remembers
+//                    where.  Key ranges of different rounds / workgroups of a subgraph are disjoint and ordered by quad
+//                    position, so the relocation kernel only concatenates the records in workgroup order.
 //
 // Self-edge insertion (.cpp:386-400), the reference's over-read (compat) and the root<->root exclusion of
 // multi-root subgraphs (.cpp:414-418) ride along: the lane that holds a row's last neighbour decides the trailing
@@ -30,50 +30,36 @@
 namespace shadow {
 
 constexpr uint32_t kMaxRoundChunks = 64;     // chunks a round may span (start-row table in LDS)
-constexpr uint32_t kPlanItems = 8192;        // item budget the plan aims at (beyond one item per subgraph)
+constexpr uint32_t kRecPerBlock = 32;        // round records per block (every scan workgroup owns block w; more come from a pool)
+constexpr uint32_t kRankShift = 20;          // rank of a list entry rides in the upper bits of its row word
 
 // ---------------------------------------------------------------------------------------------------------------
-// plan: item prefix over the subgraphs
+// plan: chunk prefix over the subgraphs, chunks per scan workgroup
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) sg_plan_kernel(SampleParams p) {
   __shared__ uint32_t wsum[32];
-  __shared__ uint32_t s_cpi;
   const uint32_t tid = threadIdx.x, T = blockDim.x;
-  uint32_t chunks = 0;
-  for (uint32_t s = tid; s < p.P; s += T) {
-    const uint32_t *c = p.s_cnt + (size_t)s * R_WORDS;
-    if (!(c[R_FLAGS] & 1u)) chunks += (c[R_Q] + kQChunk - 1u) / kQChunk;
-  }
-  uint32_t total;
-  (void)block_excl_scan(chunks, wsum, &total);
-  if (tid == 0) {
-    uint32_t cpi = 16;
-    const uint32_t need = (total + kPlanItems - 1u) / kPlanItems;
-    if (need > cpi) cpi = need;
-    s_cpi = cpi;
-  }
-  __syncthreads();
-  const uint32_t cpi = s_cpi;
   uint32_t carry = 0;
   for (uint32_t base = 0; base < p.P; base += T) {
     const uint32_t s = base + tid;
-    uint32_t items = 0;
+    uint32_t ch = 0;
     if (s < p.P) {
       const uint32_t *c = p.s_cnt + (size_t)s * R_WORDS;
-      if (!(c[R_FLAGS] & 1u)) {
-        const uint32_t ch = (c[R_Q] + kQChunk - 1u) / kQChunk;
-        items = ch ? (ch + cpi - 1u) / cpi : 1u;         // a subgraph without neighbours still owns one item
-      }
+      // (a subgraph without any neighbour still owns one chunk: its rows' sentinel slots are handled there)
+      if (!(c[R_FLAGS] & 1u)) ch = max(1u, (c[R_Q] + kQChunk - 1u) / kQChunk);
     }
     uint32_t tot;
-    const uint32_t ex = block_excl_scan(items, wsum, &tot);
-    if (s < p.P) p.itemptr[s] = carry + ex;
+    const uint32_t ex = block_excl_scan(ch, wsum, &tot);
+    if (s < p.P) p.cstart[s] = carry + ex;
     carry += tot;
   }
   if (tid == 0) {
-    p.itemptr[p.P] = carry;
-    p.plan[PL_NITEMS] = carry; p.plan[PL_CPI] = cpi; p.plan[PL_POOL] = carry; p.plan[PL_FLAGS] = 0;
-    p.plan[PL_TICKET] = 0;
+    p.cstart[p.P] = carry;
+    p.plan[PL_NCHUNKS] = carry;
+    p.plan[PL_CPW] = max(1u, (carry + p.scan_grid - 1u) / p.scan_grid);
+    p.plan[PL_POOL] = p.scan_grid;                         // blocks [0, scan_grid) belong to the workgroups
+    p.plan[PL_FLAGS] = 0;
+    for (int i = PL_T0; i < PL_WORDS; i++) p.plan[i] = 0;
   }
 }
 
@@ -83,14 +69,14 @@ __global__ void __launch_bounds__(1024) sg_plan_kernel(SampleParams p) {
 struct ScanLds {
   uint32_t *bits;    // [bit_words]
   uint32_t *lkey;    // [capm] candidate list: 2*slot+kind
-  uint32_t *lval;    // [capm] neighbour's global id (kind 1) / unused (kind 0)
-  uint32_t *lrow;    // [capm] row of the entry
+  uint32_t *lval;    // [capm] neighbour's global id (kind 1), later the column sub id
+  uint32_t *lrow;    // [capm] row of the entry (+ its rank in the upper bits during the write-out)
   uint32_t *lnext;   // [capm] bucket chains of the final sort
   uint32_t *bhead;   // [kSortBuckets]
   uint32_t *bcnt;    // [kSortBuckets]
   uint32_t *nodes;   // [nodes_lds] sorted node ids of the subgraph (when they fit)
   uint32_t *crow;    // [kMaxRoundChunks] first row of every chunk of the round
-  unsigned char *wtmp;  // [waves * 64] wave-private start-position flags
+  unsigned char *wtmp;  // [waves * 4 * 64] wave-private start-position flags
   uint32_t *ctrl;    // [C_WORDS]
 };
 
@@ -110,30 +96,29 @@ __host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t c
   L.bcnt = o; o += kSortBuckets * 4;
   L.nodes = o; o += r16((size_t)nodes_lds * 4);
   L.crow = o; o += kMaxRoundChunks * 4;
-  L.wtmp = o; o += 16 * 64;
+  L.wtmp = o; o += 16 * 64 * 4;
   L.ctrl = o; o += C_WORDS * 4;
   L.total = o;
   return L;
 }
 
-// one list entry per set bit of `mask` (bit q -> key keys[q], value vals[q]); per-lane LDS append
 __device__ __forceinline__ void list_put(const ScanLds &t, uint32_t capm, uint32_t &r, uint32_t key, uint32_t val,
                                          uint32_t row) {
   if (r < capm) { t.lkey[r] = key; t.lval[r] = val; t.lrow[r] = row; }
   r++;
 }
 
-// wave-uniform 64-way search: largest s in [0, P) with itemptr[s] <= item (itemptr non-decreasing, itemptr[P] > item)
-__device__ __forceinline__ uint32_t find_subgraph(const uint32_t *itemptr, uint32_t P, uint32_t item) {
+// wave-uniform 64-way search: largest s in [0, P) with a[s] <= x (a non-decreasing, a[0] <= x < a[P])
+__device__ __forceinline__ uint32_t find_span(const uint32_t *a, uint32_t P, uint32_t x) {
   uint32_t lo = 0, hi = P;          // answer in [lo, hi)
   const uint32_t lane = lane_id();
   while (hi - lo > 1) {
     const uint32_t span = hi - lo;
     const uint32_t step = (span + 63u) / 64u;
     const uint32_t probe = lo + min(span, (lane + 1u) * step);          // candidates lo+step, lo+2 step, ... (<= hi)
-    const bool le = (probe < hi) && (itemptr[probe] <= item);
+    const bool le = (probe < hi) && (a[probe] <= x);
     const uint64_t m = __ballot(le);
-    const uint32_t k = (uint32_t)__popcll(m);                          // monotone: the first k probes are <= item
+    const uint32_t k = (uint32_t)__popcll(m);                          // monotone: the first k probes are <= x
     const uint32_t nlo = lo + min(span, k * step);
     const uint32_t nhi = min(hi, lo + (k + 1u) * step);
     lo = (k == 0) ? lo : nlo;
@@ -192,6 +177,90 @@ __device__ __forceinline__ void emit_empty_row(const SampleParams &p, const Scan
   }
 }
 
+constexpr uint32_t kLongRow = 24;            // rows with at least this many quads left in the chunk are streamed alone
+
+// Everything the scan knows about the subgraph / round it works on (uniform), bundled for the group helpers.
+struct ScanCtx {
+  const uint32_t *indices;
+  uint64_t nnz;
+  uint32_t *ctrl;
+  uint32_t bw_mask, capm;
+  bool incl_self, compat;
+};
+
+// Probe the four ids of my quad against the membership filter, decide self-edge insertion, append what was found
+// to the candidate list.  j0 = (index of my quad's first id) - (row start): wraps when the quad starts in front
+// of the row; `edge` (wave-uniform) = 0 promises that every component of every lane is a neighbour of `row`.
+template <bool kPlain>
+__device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t, const uint4 q, uint32_t j0, uint32_t deg,
+                                              uint32_t rs, uint32_t row, uint32_t v, uint32_t e0, uint32_t prev, bool need_prev,
+                                              uint32_t edge) {
+  const uint32_t cc[4] = {q.x, q.y, q.z, q.w};
+  uint32_t h = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint32_t w = t.bits[(cc[c] >> 5) & x.bw_mask];
+    h |= ((w >> (cc[c] & 31u)) & 1u) << c;
+  }
+  uint32_t vmask = 0xFu;
+  if (edge) {
+    vmask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (j0 + c < deg) vmask |= 1u << c;
+  }
+  const uint32_t hit = h & vmask;
+  uint32_t selfm = 0, trail = 0;
+  if (!kPlain && x.incl_self) {
+    // the self edge goes right before the first neighbour > v (.cpp:387-400, :408-410), or after the last one
+    const uint32_t up = (uint32_t)__shfl_up((int)cc[3], 1, 64);
+    const uint32_t pv0 = need_prev ? prev : up;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t j = j0 + c;
+      const uint32_t pv = (c == 0) ? pv0 : cc[c > 0 ? c - 1 : 0];
+      const bool prev_lt = (j == 0) || (pv < v);
+      if (((vmask >> c) & 1u) && prev_lt && v < cc[c]) selfm |= 1u << c;
+      if (((vmask >> c) & 1u) && j + 1u == deg && cc[c] < v) trail = 1;        // last neighbour < v
+    }
+  }
+  const uint32_t cnt = (uint32_t)(__popc(hit) + __popc(selfm)) + trail;
+  if (__ballot(cnt != 0)) {
+    uint32_t r = 0;
+    if (cnt) r = atomicAdd(&x.ctrl[C_M], cnt);
+    const uint32_t keybase = 2u * (rs + j0);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (!kPlain && ((selfm >> c) & 1u)) list_put(t, x.capm, r, keybase + 2u * c, 0u, row);     // .cpp:408-410
+      if ((hit >> c) & 1u) list_put(t, x.capm, r, keybase + 2u * c + 1u, cc[c], row);         // .cpp:420-422
+    }
+    if (!kPlain && trail) list_put(t, x.capm, r, 2u * (rs + deg), 0u, row);
+  }
+  if (!kPlain && x.compat) {
+    // reference over-read (.cpp:401-405): when no self edge was inserted INSIDE the row (and none trails),
+    // the element right behind the row is examined like a neighbour
+    bool fin = false;                          // this lane holds the row's last neighbour
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (((vmask >> c) & 1u) && j0 + c + 1u == deg) fin = true;
+    if (fin && !trail) {
+      bool inserted = false;
+      if (x.incl_self) {
+        uint32_t l3 = 0, h3 = deg;
+        while (l3 < h3) { const uint32_t m3 = (l3 + h3) >> 1; if (x.indices[e0 + m3] < v) l3 = m3 + 1; else h3 = m3; }
+        inserted = !(l3 < deg && x.indices[e0 + l3] == v);
+      }
+      if (!inserted && (uint64_t)e0 + deg < x.nnz) {
+        const uint32_t c = x.indices[e0 + deg];
+        if ((t.bits[(c >> 5) & x.bw_mask] >> (c & 31u)) & 1u) {
+          uint32_t r = atomicAdd(&x.ctrl[C_M], 1u);
+          list_put(t, x.capm, r, 2u * (rs + deg) + 1u, c, row);
+        }
+      }
+    }
+  }
+}
+
 template <bool kPlain>
 __global__ void sg_scan_kernel(SampleParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -208,7 +277,6 @@ __global__ void sg_scan_kernel(SampleParams p) {
   t.crow = (uint32_t *)(smem + L.crow);
   t.wtmp = smem + L.wtmp;
   uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
-  __shared__ uint32_t s_item;
 
   const uint32_t tid = threadIdx.x, T = blockDim.x;
   const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
@@ -219,18 +287,25 @@ __global__ void sg_scan_kernel(SampleParams p) {
   const bool itc = kPlain || (p.include_target_conn != 0) || (R == 1);   // .cpp:356-358
   const bool compat = !kPlain && (p.compat != 0);
   const bool sentinel = incl_self || compat;
-  const uint32_t nitems = p.plan[PL_NITEMS], cpi = p.plan[PL_CPI];
-  unsigned char *wflag = t.wtmp + wave * 64u;            // wave-private, all zero between uses
-  for (uint32_t i = tid; i < 16u * 16u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
+  const uint32_t C = p.plan[PL_NCHUNKS], cpw = p.plan[PL_CPW];
+  unsigned char *wflag = t.wtmp + wave * 256u;           // wave-private (one 64-byte table per group of a batch), all zero between uses
+  for (uint32_t i = tid; i < 16u * 64u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
 
-  for (;;) {
-    if (tid == 0) s_item = atomicAdd(&p.plan[PL_TICKET], 1u);
-    __syncthreads();
-    const uint32_t item = s_item;
-    __syncthreads();
-    if (item >= nitems) return;
-    const uint32_t s = find_subgraph(p.itemptr, p.P, item);
-    const uint32_t li = item - p.itemptr[s];
+  uint32_t tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // phase cycles of this workgroup (thread 0)
+  uint64_t tlast = clock64();
+#define SCAN_T(k) do { if (tid == 0) { const uint64_t now_ = clock64(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+  // round records of this workgroup (thread 0 files them): block `blockIdx.x`, further blocks from the pool
+  uint32_t rec_blk = blockIdx.x, rec_cnt = 0;
+
+  uint32_t g = blockIdx.x * cpw;
+  const uint32_t gend = min(C, g + cpw);
+  uint32_t s = (g < gend) ? find_span(p.cstart, p.P, g) : 0u;
+  while (g < gend) {
+    const uint32_t c0 = p.cstart[s], c1 = p.cstart[s + 1];
+    if (c1 <= g) { s++; continue; }                       // (subgraphs the selection flagged own no chunk)
+    const uint32_t lc0 = g - c0, lc1 = min(c1, gend) - c0;   // this workgroup's chunks of subgraph s
+    g = c0 + lc1;
+    tacc[5]++;
     uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
     const uint32_t n = res[R_N], Q = res[R_Q];
     const uint32_t *roots = p.roots + (size_t)s * R;
@@ -241,10 +316,11 @@ __global__ void sg_scan_kernel(SampleParams p) {
     uint32_t *g_col = p.s_col + (size_t)s * cape;
     uint32_t *g_eid = p.s_eid + (size_t)s * cape;
     const bool nodes_in_lds = n <= p.nodes_lds;
-    const uint32_t iq0 = min(Q, li * cpi * kQChunk);
-    const uint32_t iq1 = min(Q, iq0 + cpi * kQChunk);
+    const uint32_t iq0 = min(Q, lc0 * kQChunk);
+    const uint32_t iq1 = min(Q, lc1 * kQChunk);
 
-    // ---- per item: the subgraph's membership filter (+ its sorted node list when it fits)
+    // ---- per segment: the subgraph's membership filter (+ its sorted node list when it fits)
+    __syncthreads();                                       // (the previous segment's last readers are done)
     for (uint32_t w = tid; w < p.bit_words; w += T) t.bits[w] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
@@ -254,13 +330,13 @@ __global__ void sg_scan_kernel(SampleParams p) {
     }
     // (the first barrier of the round loop orders these writes before the scan)
 
-    uint32_t rec_prev = 0xFFFFFFFFu;           // last round record of this item (thread 0)
     uint32_t rq0 = iq0;
     uint32_t rquads = min(iq1 - iq0, kMaxRoundChunks * kQChunk);
-    bool first_round = true;
     for (;;) {
       const uint32_t rq1 = min(iq1, rq0 + max(rquads, 1u));
       const uint32_t rchunks = (rq1 - rq0 + kQChunk - 1u) / kQChunk;
+      tacc[6]++;
+      SCAN_T(0);
       if (tid == 0) ctrl[C_M] = 0;
       // ---- first row of every chunk of the round: the row that holds the chunk's first quad
       for (uint32_t base = 0; base < n; base += T) {
@@ -274,173 +350,136 @@ __global__ void sg_scan_kernel(SampleParams p) {
         }
       }
       __syncthreads();
+      SCAN_T(1);
 
       // ---- the scan: wave w takes chunks w, w + nw, ... of the round
       for (uint32_t k = wave; k < max(rchunks, 1u); k += nw) {
         const uint32_t qa = rq0 + k * kQChunk, qb = min(qa + kQChunk, rq1);
         // rows without neighbours in front of the subgraph's first quad (or a subgraph without any quad):
         // their sentinel slots belong to the very first chunk of the subgraph
-        if (!kPlain && sentinel && qa == 0 && k == 0 && li == 0) {
+        if (!kPlain && sentinel && qa == 0 && k == 0 && lc0 == 0) {
           const uint32_t stop = (Q == 0) ? n : rl_first(t.crow[0]);
           for (uint32_t r0 = 0; r0 < stop; r0 += 64)
             if (r0 + lane < stop) emit_empty_row<kPlain>(p, t, ctrl, g_info, r0 + lane, incl_self, compat, bw_mask, capm);
         }
         if (rchunks == 0) break;
-        // ---- window of 64 rows starting at the row that holds the chunk's first quad
+        // ---- rows are taken 64 at a time (one per lane: the WINDOW), starting at the row that holds the chunk's
+        //      first quad.  Every row's quads are clipped to the chunk.  Rows with >= kLongRow quads left are streamed
+        //      one row at a time with wave-uniform row scalars -- no position -> row mapping at all, four 1-KiB loads
+        //      in flight while a row lasts; the short ones are packed into shared 64-quad groups.
+        ScanCtx cx;
+        cx.indices = p.indices; cx.nnz = p.nnz; cx.ctrl = ctrl; cx.bw_mask = bw_mask; cx.capm = capm;
+        cx.incl_self = incl_self; cx.compat = compat;
         uint32_t wb = rl_first(t.crow[k]);
-        uint32_t W;
-        RowWin win = win_make(win_fetch(g_info, wb, n), &W);
-        uint4 wnext = win_fetch(g_info, wb + 64u, n);                  // prefetched
-        uint32_t P0 = qa - rl_first(g_rowq[wb]);                       // window-local position of the next quad
-        uint32_t qpos = qa;
-        bool at_window_end = false;
-        while (qpos < qb) {
-          uint4 c4[kBatch];
-          uint32_t m_j0[kBatch], m_deg[kBatch], m_rs[kBatch], m_row[kBatch], m_v[kBatch], m_prev[kBatch], m_act[kBatch];
-          uint32_t m_e0[kBatch], m_take[kBatch];
+        uint32_t wbase = rl_first(g_rowq[wb]);                         // quad position of the window's first row
+        uint4 wcur = win_fetch(g_info, wb, n);
+        for (;;) {
+          const uint4 wnext = win_fetch(g_info, wb + 64u, n);          // prefetch
+          const uint32_t w_e0 = wcur.x, w_deg = wcur.y, w_rs = wcur.z, w_v = wcur.w;
+          const uint32_t w_nq = w_deg ? (((w_e0 + w_deg - 1u) >> 2) - (w_e0 >> 2) + 1u) : 0u;
+          const uint32_t incl = wave_incl_scan(w_nq);
+          const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          const uint32_t w_pos = wbase + incl - w_nq;                  // quad position of my row
+          const uint32_t lo = max(w_pos, qa), hi = min(w_pos + w_nq, qb);
+          const uint32_t w_len = hi > lo ? hi - lo : 0u;               // my row's quads inside the chunk
+          const uint32_t w_k0 = lo - w_pos;                            // ... starting at this quad of the row
+          // rows without neighbours behind a row that ends inside the chunk: their sentinel slots are this chunk's
+          if (!kPlain && sentinel && wb + lane < n && w_nq == 0 && w_pos > qa && w_pos <= qb)
+            emit_empty_row<kPlain>(p, t, ctrl, g_info, wb + lane, incl_self, compat, bw_mask, capm);
+          // ---- long rows, one at a time
+          uint64_t long_mask = __ballot(w_len >= kLongRow);
+          while (long_mask) {
+            const uint32_t cl = (uint32_t)__ffsll((unsigned long long)long_mask) - 1u;
+            long_mask &= long_mask - 1ull;
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)w_e0, cl);
+            const uint32_t deg = (uint32_t)__builtin_amdgcn_readlane((int)w_deg, cl);
+            const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)w_rs, cl);
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)w_v, cl);
+            const uint32_t nq = (uint32_t)__builtin_amdgcn_readlane((int)w_nq, cl);
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)w_k0, cl);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w_len, cl);
+            const uint32_t row = wb + cl;
+            const uint32_t abase = ((e0 >> 2) + k0 + lane) << 2;          // my quad of the row's first run
+            uint32_t g0 = 0;
+            // a run that holds the row's first or last quad may contain ids of the neighbouring rows
+            if (k0 == 0 && (e0 & 3u) && len >= 64u) {
+              const uint4 q = *reinterpret_cast<const uint4 *>(p.indices + abase);
+              process_group<kPlain>(cx, t, q, abase - e0, deg, rs, row, v, e0, 0u, false, 1u);
+              g0 = 64;
+            }
+            // interior runs, four in flight
+            const uint32_t interior_end = (k0 + len == nq && ((e0 + deg) & 3u)) ? len - 1u : len;
+            for (; g0 + 256u <= interior_end; g0 += 256u) {
+              uint4 q[4];
+              uint32_t pv = 0;
 #pragma unroll
-          for (int u = 0; u < kBatch; u++) {
-            m_act[u] = 0; m_j0[u] = 0; m_deg[u] = 0; m_rs[u] = 0; m_row[u] = 0; m_v[u] = 0; m_prev[u] = 0;
-            m_e0[u] = 0; m_take[u] = 0;
-            c4[u] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-            if (qpos < qb) {
-              if (P0 >= W) {
-                // window consumed: the next 64 rows.  Rows without neighbours at the head of the new window sit at
-                // the position the previous group ended on: their sentinel slots are this wavefront's.  (A window
-                // can consist of such rows only: W == 0 -> keep advancing.)
-                do {
-                  wb += 64u;
-                  win = win_make(wnext, &W);
-                  wnext = win_fetch(g_info, wb + 64u, n);
-                  if (!kPlain && sentinel && wb + lane < n && win.nq == 0 && win.wq == 0)
-                    emit_empty_row<kPlain>(p, t, ctrl, g_info, wb + lane, incl_self, compat, bw_mask, capm);
-                } while (W == 0 && wb + 64u < n);
-                P0 = 0;
+              for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint4 *>(p.indices + abase + 4u * (g0 + 64u * u));
+              if (!kPlain && incl_self && lane == 0 && k0 + g0 > 0) pv = p.indices[abase + 4u * g0 - 1u];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const uint32_t a = abase + 4u * (g0 + 64u * u);
+                uint32_t pvu = pv;
+                if (!kPlain && incl_self && u > 0) pvu = (uint32_t)__builtin_amdgcn_readlane((int)q[u > 0 ? u - 1 : 0].w, 63);
+                process_group<kPlain>(cx, t, q[u], a - e0, deg, rs, row, v, e0, pvu, lane == 0 && (k0 + g0 + 64u * u) > 0, 0u);
               }
-              const uint32_t take = min(min(64u, W - P0), qb - qpos);
-              // position -> row: rows that start inside (P0, P0 + take) flag their start position; fill forward
-              const bool nonempty = win.nq != 0;
-              const uint64_t before = __ballot(nonempty && win.wq <= P0);
-              const uint32_t f0 = 63u - (uint32_t)__builtin_clzll((unsigned long long)before);   // row that holds P0
-              const bool starts = nonempty && win.wq > P0 && win.wq < P0 + take;
-              if (starts) wflag[win.wq - P0] = (unsigned char)(lane + 1u);
+            }
+            // the rest of the row, one run at a time
+            for (; g0 < len; g0 += 64u) {
+              const uint32_t take = min(64u, len - g0);
+              const uint32_t a = abase + 4u * g0;
+              uint4 q = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+              uint32_t pv = 0;
+              if (lane < take) q = *reinterpret_cast<const uint4 *>(p.indices + a);
+              const bool np = lane == 0 && (k0 + g0) > 0;
+              if (!kPlain && incl_self && np) pv = p.indices[a - 1u];
+              process_group<kPlain>(cx, t, q, a - e0, lane < take ? deg : 0u, rs, row, v, e0, pv, np, 1u);
+            }
+          }
+          // ---- short rows, packed: the rows flag the packed position they start on, the positions read the flags
+          //      back and fill forward (DPP max-scan), lane gathers fetch the row's scalars
+          {
+            const bool shortrow = w_len != 0 && w_len < kLongRow;
+            const uint32_t tl = shortrow ? w_len : 0u;
+            const uint32_t tincl = wave_incl_scan(tl);
+            const uint32_t tq = tincl - tl;
+            const uint32_t ttot = (uint32_t)__builtin_amdgcn_readlane((int)tincl, 63);
+            for (uint32_t p0 = 0; p0 < ttot; p0 += 64u) {
+              const uint32_t take = min(64u, ttot - p0);
+              const bool starts = shortrow && tq > p0 && tq < p0 + take;
+              if (starts) wflag[tq - p0] = (unsigned char)(lane + 1u);
               __builtin_amdgcn_wave_barrier();
               uint32_t rl = wflag[lane];
               __builtin_amdgcn_wave_barrier();
-              if (starts) wflag[win.wq - P0] = 0;
+              if (starts) wflag[tq - p0] = 0;
+              const uint64_t before = __ballot(shortrow && tq <= p0);
+              const uint32_t f0 = 63u - (uint32_t)__builtin_clzll((unsigned long long)(before | 1ull));   // row that holds p0
               if (lane == 0) rl = f0 + 1u;
-#pragma unroll
-              for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)rl, off, 64);
-                if (lane >= (uint32_t)off) rl = max(rl, o);
-              }
-              rl -= 1u;                                                     // lane of the window that owns my position
-              const uint32_t e0 = lane_get(win.e0, rl), wq = lane_get(win.wq, rl);
-              const uint32_t deg = lane_get(win.deg, rl), rs = lane_get(win.rs, rl);
-              const uint32_t kq = P0 + lane - wq;                            // quad index inside the row
-              const uint32_t addr = ((e0 >> 2) + kq) << 2;
-              const bool act = lane < take;
-              m_act[u] = act ? 1u : 0u;
-              m_j0[u] = addr - e0;                                          // wraps when the quad starts before the row
-              m_deg[u] = deg; m_rs[u] = rs; m_row[u] = wb + rl;
-              if (act) c4[u] = *reinterpret_cast<const uint4 *>(p.indices + addr);
-              if (!kPlain) {
-                m_e0[u] = e0;
-                m_v[u] = lane_get(win.v, rl);
-                if (incl_self && lane == 0 && kq > 0) m_prev[u] = p.indices[addr - 1u];   // previous quad of the row is not in this group
-                // rows without neighbours whose position lies in (P0, P0 + take]: their sentinel slots go with this group
-                if (sentinel && wb + lane < n && win.nq == 0 && win.wq > P0 && win.wq <= P0 + take)
-                  emit_empty_row<kPlain>(p, t, ctrl, g_info, wb + lane, incl_self, compat, bw_mask, capm);
-              }
-              m_take[u] = take;
-              P0 += take; qpos += take;
-              at_window_end = (P0 >= W);
+              rl = wave_incl_max_scan(rl) - 1u;                              // lane of the window that owns my position
+              const uint32_t e0 = lane_get(w_e0, rl), rtq = lane_get(tq, rl), rk0 = lane_get(w_k0, rl);
+              const uint32_t deg = lane_get(w_deg, rl), rs = lane_get(w_rs, rl);
+              const uint32_t v = kPlain ? 0u : lane_get(w_v, rl);
+              const uint32_t kq = rk0 + (p0 + lane - rtq);                   // quad index inside the row
+              const uint32_t a = ((e0 >> 2) + kq) << 2;
+              uint4 q = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+              uint32_t pv = 0;
+              if (lane < take) q = *reinterpret_cast<const uint4 *>(p.indices + a);
+              // lane - 1 holds the previous quad of my row unless my quad opens the row's run in this group
+              const bool np = lane < take && kq > 0 && (lane == 0 || p0 + lane == rtq);
+              if (!kPlain && incl_self && np) pv = p.indices[a - 1u];
+              process_group<kPlain>(cx, t, q, a - e0, lane < take ? deg : 0u, rs, wb + rl, v, e0, pv, np, 1u);
             }
           }
-          // ---- probe + emit
-#pragma unroll
-          for (int u = 0; u < kBatch; u++) {
-            if (m_take[u] == 0) continue;                                   // wave-uniform
-            const uint32_t deg = m_deg[u], rs = m_rs[u], j0 = m_j0[u];
-            const uint32_t cc[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
-            uint32_t vmask = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-              if (m_act[u] && (j0 + c < deg)) vmask |= 1u << c;
-            uint32_t hit = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-              const uint32_t w = t.bits[(cc[c] >> 5) & bw_mask];
-              hit |= ((w >> (cc[c] & 31u)) & 1u) << c;
-            }
-            hit &= vmask;
-            uint32_t selfm = 0, trail = 0, last_c = 0;
-            bool fin = false;                          // this lane holds the row's last neighbour
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-              if (((vmask >> c) & 1u) && j0 + c + 1u == deg) { fin = true; last_c = cc[c]; }
-            if (!kPlain && incl_self) {
-              // the self edge goes right before the first neighbour > v (.cpp:387-400, :408-410), or after the last one
-              const uint32_t v = m_v[u];
-              const uint32_t up = (uint32_t)__shfl_up((int)cc[3], 1, 64);
-              const uint32_t pv0 = (lane == 0) ? m_prev[u] : up;
-#pragma unroll
-              for (int c = 0; c < 4; c++) {
-                const uint32_t j = j0 + c;
-                const uint32_t pv = (c == 0) ? pv0 : cc[c > 0 ? c - 1 : 0];
-                const bool prev_lt = (j == 0) || (pv < v);
-                if (((vmask >> c) & 1u) && prev_lt && v < cc[c]) selfm |= 1u << c;
-              }
-              if (fin && last_c < v) trail = 1;
-            }
-            const uint32_t cnt = (uint32_t)(__popc(hit) + __popc(selfm)) + trail;
-            if (cnt) {
-              uint32_t r = atomicAdd(&ctrl[C_M], cnt);
-              const uint32_t keybase = 2u * (rs + j0);
-#pragma unroll
-              for (int c = 0; c < 4; c++) {
-                if (!kPlain && ((selfm >> c) & 1u)) list_put(t, capm, r, keybase + 2u * c, 0u, m_row[u]);   // .cpp:408-410
-                if ((hit >> c) & 1u) list_put(t, capm, r, keybase + 2u * c + 1u, cc[c], m_row[u]);       // .cpp:420-422
-              }
-              if (!kPlain && trail) list_put(t, capm, r, 2u * (rs + deg), 0u, m_row[u]);
-            }
-            if (!kPlain && compat && fin && !trail) {
-              // reference over-read (.cpp:401-405): when no self edge was inserted INSIDE the row (and none trails),
-              // the element right behind the row is examined like a neighbour
-              const uint32_t row_e0 = m_e0[u];
-              bool inserted = false;
-              if (incl_self) {
-                uint32_t l3 = 0, h3 = deg;
-                while (l3 < h3) { const uint32_t m3 = (l3 + h3) >> 1; if (p.indices[row_e0 + m3] < m_v[u]) l3 = m3 + 1; else h3 = m3; }
-                inserted = !(l3 < deg && p.indices[row_e0 + l3] == m_v[u]);
-              }
-              if (!inserted && (uint64_t)row_e0 + deg < p.nnz) {
-                const uint32_t c = p.indices[row_e0 + deg];
-                if ((t.bits[(c >> 5) & bw_mask] >> (c & 31u)) & 1u) {
-                  uint32_t r = atomicAdd(&ctrl[C_M], 1u);
-                  list_put(t, capm, r, 2u * (rs + deg) + 1u, c, m_row[u]);
-                }
-              }
-            }
-          }
-        }
-        // the chunk's last group ended exactly at the end of its window: rows without neighbours may follow in the
-        // next window(s) -- they belong to this chunk
-        if (!kPlain && sentinel && at_window_end) {
-          uint32_t nb = wb + 64u;
-          uint4 w4 = wnext;
-          while (nb < n) {
-            const uint32_t r2 = nb + lane;
-            const uint64_t ne = __ballot(r2 < n && w4.y != 0);
-            const uint32_t first_ne = ne ? (uint32_t)__ffsll((unsigned long long)ne) - 1u : 64u;
-            if (r2 < n && lane < first_ne) emit_empty_row<kPlain>(p, t, ctrl, g_info, r2, incl_self, compat, bw_mask, capm);
-            if (ne) break;
-            nb += 64u;
-            w4 = win_fetch(g_info, nb, n);
-          }
+          // ---- next window?  Done when a row with neighbours starts at or behind the chunk's end (rows without
+          //      neighbours sitting exactly on the chunk's end still belong to it, wherever their window is)
+          const uint64_t stop = __ballot(wb + lane < n && w_nq != 0 && w_pos >= qb);
+          if (stop || wb + 64u >= n || wbase + W > qb) break;
+          wb += 64u;
+          wbase += W;
+          wcur = wnext;
         }
       }
       __syncthreads();
+      SCAN_T(2);
       const uint32_t m = ctrl[C_M];
       if (m > capm) {
         // too many candidates for the list: redo this round on half the quads
@@ -458,6 +497,7 @@ __global__ void sg_scan_kernel(SampleParams p) {
       for (uint32_t i = tid; i < kSortBuckets; i += T) { t.bhead[i] = kEmpty; t.bcnt[i] = 0; }
       if (tid == 0) { ctrl[C_MV] = 0; ctrl[C_CHANGED] = 0xFFFFFFFFu; ctrl[C_MFAIL] = 0; }
       __syncthreads();
+      uint32_t kmin_l = kEmpty, kmax_l = 0;
       for (uint32_t i = tid; i < m; i += T) {
         uint32_t key = t.lkey[i];
         if (key & 1u) {
@@ -479,7 +519,17 @@ __global__ void sg_scan_kernel(SampleParams p) {
         } else {
           t.lval[i] = t.lrow[i];                        // self edge: column = the row itself
         }
-        if (key != kEmpty) { atomicMin(&ctrl[C_CHANGED], key); atomicMax(&ctrl[C_MFAIL], key); }
+        kmin_l = min(kmin_l, key);                      // (kEmpty is the largest value)
+        if (key != kEmpty) kmax_l = max(kmax_l, key);
+      }
+      {
+        // one LDS atomic per wavefront, not per candidate
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          kmin_l = min(kmin_l, (uint32_t)__shfl_xor((int)kmin_l, off, 64));
+          kmax_l = max(kmax_l, (uint32_t)__shfl_xor((int)kmax_l, off, 64));
+        }
+        if (lane == 0 && kmin_l != kEmpty) { atomicMin(&ctrl[C_CHANGED], kmin_l); atomicMax(&ctrl[C_MFAIL], kmax_l); }
       }
       __syncthreads();
       const uint32_t kmin = ctrl[C_CHANGED], kmax = ctrl[C_MFAIL];
@@ -494,7 +544,10 @@ __global__ void sg_scan_kernel(SampleParams p) {
         }
       }
       __syncthreads();
-      // exclusive scan of the bucket counts (kSortBuckets = 256 = 4 per lane of wave 0)
+      SCAN_T(3);
+      // exclusive scan of the bucket counts (kSortBuckets = 256 = 4 per lane of wave 0); the survivors' place in the
+      // subgraph's edge scratch is reserved by ONE global atomic whose round trip overlaps the rank computation
+      uint32_t e_base_pending = 0;
       if (wave == 0) {
         uint32_t b4[4], sum = 0;
 #pragma unroll
@@ -504,36 +557,43 @@ __global__ void sg_scan_kernel(SampleParams p) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { t.bcnt[lane * 4 + q] = run; run += b4[q]; }
         if (lane == 63) {
-          // reserve the survivors' place in the subgraph's edge scratch and file the round record
-          const uint32_t mv = run;
-          const uint32_t off = atomicAdd(&res[R_E], mv);
-          ctrl[C_MV] = mv; ctrl[C_TICKET] = off;
-          uint32_t rec = item;
-          if (!first_round) {
-            rec = atomicAdd(&p.plan[PL_POOL], 1u);
-            if (rec >= p.rec_cap) { atomicOr(&p.plan[PL_FLAGS], 16u); rec = 0xFFFFFFFFu; }
-          }
-          ctrl[C_NF0] = rec;
+          ctrl[C_MV] = run;
+          e_base_pending = atomicAdd(&res[R_E], run);
         }
       }
       __syncthreads();
-      const uint32_t mv = ctrl[C_MV], e_base = ctrl[C_TICKET], rec = ctrl[C_NF0];
-      if (tid == 0 && rec != 0xFFFFFFFFu) {
-        RoundRec rr;
-        rr.src_off = e_base; rr.cnt = mv; rr.next = 0xFFFFFFFFu; rr.pad = 0;
-        p.recs[rec] = rr;
-        if (rec_prev != 0xFFFFFFFFu) p.recs[rec_prev].next = rec;
-        rec_prev = rec;
-      }
       for (uint32_t i = tid; i < m; i += T) {
         const uint32_t key = t.lkey[i];
         if (key == kEmpty) continue;
         const uint32_t b = (key - kmin) >> bshift;
         uint32_t r = t.bcnt[b];
         for (uint32_t j = t.bhead[b]; j != kEmpty; j = t.lnext[j]) r += (t.lkey[j] < key) ? 1u : 0u;
-        const uint32_t o = e_base + r;
+        t.lrow[i] |= r << kRankShift;
+      }
+      if (wave == 0 && lane == 63) ctrl[C_TICKET] = e_base_pending;
+      __syncthreads();
+      const uint32_t mv = ctrl[C_MV], e_base = ctrl[C_TICKET];
+      if (tid == 0) {
+        // file the round record
+        if (rec_cnt == kRecPerBlock) {
+          const uint32_t nb = atomicAdd(&p.plan[PL_POOL], 1u);
+          if (nb >= p.rec_blocks) { atomicOr(&p.plan[PL_FLAGS], 16u); }
+          else { p.blkinfo[rec_blk] = make_uint2(kRecPerBlock, nb); rec_blk = nb; rec_cnt = 0; }
+        }
+        if (rec_cnt < kRecPerBlock) {
+          RoundRec rr;
+          rr.s = s; rr.src_off = e_base; rr.cnt = mv; rr.pad = 0;
+          p.recs[(size_t)rec_blk * kRecPerBlock + rec_cnt] = rr;
+          rec_cnt++;
+        }
+      }
+      for (uint32_t i = tid; i < m; i += T) {
+        const uint32_t key = t.lkey[i];
+        if (key == kEmpty) continue;
+        const uint32_t rw_r = t.lrow[i];
+        const uint32_t rw = rw_r & ((1u << kRankShift) - 1u);
+        const uint32_t o = e_base + (rw_r >> kRankShift);
         if (o < cape) {
-          const uint32_t rw = t.lrow[i];
           g_row[o] = rw;
           g_col[o] = t.lval[i];
           uint32_t eid = 0xFFFFFFFFu;                                             // inserted self edge (.cpp:410)
@@ -541,13 +601,18 @@ __global__ void sg_scan_kernel(SampleParams p) {
           g_eid[o] = eid;
         }
       }
-      first_round = false;
       rq0 = rq1;
       __syncthreads();
+      SCAN_T(4);
       if (rq0 >= iq1) break;
     }
-    __syncthreads();
+    s++;
   }
+  if (tid == 0) {
+    p.blkinfo[rec_blk] = make_uint2(rec_cnt, 0xFFFFFFFFu);
+    for (int i = 0; i < 12; i++) atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
+  }
+#undef SCAN_T
 }
 
 }  // namespace shadow

@@ -751,6 +751,7 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
     batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
     with timer:
         ret = model.step(TRAIN, "running", batch)
+    torch.cuda.synchronize()
     ran = set(timer.summary())
     assert any(k.startswith("gemm_nt_split") for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
     # ---- fp64 oracle, same parameters
