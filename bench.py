@@ -170,6 +170,7 @@ def main():
     mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots_all}, dict(wl["sampler"]), aug, feat_full,
                                    label_full, batch_size=B * world, device=dev, seed_cpp=3, rank=rank,
                                    world_size=world, prefetch=not args.no_prefetch)
+    mb.lazy_features = True            # layer 0 gathers feat_full[node] inside its aggregation kernel
     mb.epoch_start_reset(0, TRAIN)
     mb.shuffle_entity(TRAIN, perm=np.arange(roots_all.size))
     hs = mb.graph_sampler[TRAIN]
@@ -330,7 +331,7 @@ def main():
                        **({"alg_TFLOPs": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                           if v.get("flops_per_launch") else {})) for k, v in kern.items()}
     # north-star aggregate: k-hop sample + feature gather + SAGE aggregates (forward), bytes / time
-    ns_keys = [k for k in kern if k.startswith(("sg_sample", "gather", "spmm"))]
+    ns_keys = [k for k in kern if k.startswith(("sg_sample", "gather", "spmm"))]      # (incl. the fused spmm_gather_F*)
     ns_ms = sum(kern[k]["total_ms"] for k in ns_keys)
     ns_by = sum(kern[k]["bytes_per_launch"] * kern[k]["launches"] for k in ns_keys)
     cb = None

@@ -205,6 +205,11 @@ int sg_set_profiling(sg_sampler *s, int enable);
 /* out[i,:] = table[idx[i],:]      (feat_full[subgs.node], shaDow/minibatch.py:469) */
 int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n,
                        uint32_t F, float *d_out, int64_t ld_out, void *stream);
+/* The same gather with layer 0's input dropout in the same pass (nn.Dropout at layers.py:430,471; the counter-hash
+ * mask rule of sl_act_norm_fwd with (drop_p, drop_seed), row = batch row i), written into rows padded with zeros up
+ * to F_pad columns (whole 128-byte lines: F = 100 -> F_pad = 128), ld_out >= F_pad.  F % 4 == 0, aligned rows.     */
+int sl_gather_rows_drop_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n, uint32_t F,
+                            float drop_p, uint64_t drop_seed, float *d_out, int64_t ld_out, uint32_t F_pad, void *stream);
 
 /* edge_row[p] = row of edge p (the COO row index adj._indices()[0] of
  * frontend/graph_utils.py:48-56, without the host round trip).               */
@@ -268,6 +273,18 @@ int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                           const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off,
                           uint32_t num_subg, uint32_t max_subg_nodes, void *stream);
+/* Layer-0 form of the same product: the input matrix is never materialised by a separate pass -- row i of X is
+ * table[ids[i]] (the feature gather feat_full[subgs.node], shaDow/minibatch.py:469), optionally with the layer's
+ * input dropout applied (nn.Dropout at layers.py:430,471; the counter-hash mask rule of sl_act_norm_fwd below with
+ * (drop_p, drop_seed), row = batch row i) -- read ONCE while the subgraph tile is staged in LDS.  d_Xout (optional,
+ * [n, F]) receives the gathered (+ dropped) rows for the layer's other consumers (the self Linear of GraphSAGE, the
+ * weight gradients).  Y = diag(row_scale) (A o w) diag(col_scale) X as above.  F % 4 == 0, 16-byte aligned rows.   */
+int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                 const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                                 const float *d_table, int64_t ldt, const uint32_t *d_ids, float drop_p,
+                                 uint64_t drop_seed, float *d_Xout, int64_t ldxo, float *d_Y, int64_t ldy, uint32_t n,
+                                 uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off,
+                                 uint32_t num_subg, uint32_t max_subg_nodes, void *stream);
 
 /* Weight gradient of nn.Linear with the same split-bf16 arithmetic:  C[N,K] = A[M,N]^T . B[M,K]
  * (A = dZ, B = the layer input; N, K <= 256 and multiples of 4; operands 16-byte aligned, ld % 4 == 0).

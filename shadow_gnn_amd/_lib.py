@@ -86,6 +86,8 @@ SIGNATURES = {
     "sg_debug_scan_phases": (C.c_int, [_P, _P]),
     "sg_debug_stream_rows": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_int, C.c_int, _P]),
     "sl_gather_rows_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
+    "sl_gather_rows_drop_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, _P, C.c_int64,
+                                           C.c_uint32, _P]),
     "sl_csr_edge_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_csr_transpose": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P]),
     "sl_degree_scales": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
@@ -93,6 +95,8 @@ SIGNATURES = {
                                    C.c_uint32, _P]),
     "sl_spmm_blockdiag_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                          C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P]),
+    "sl_spmm_blockdiag_gather_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_uint64, _P, C.c_int64,
+                                                _P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P]),
     "sg_cache_create": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(_P)]),
     "sg_cache_destroy": (None, [_P]),
     "sg_cache_clear": (C.c_int, [_P]),
@@ -124,7 +128,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 6      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 7      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -424,28 +424,100 @@ constexpr int kBdMaxEdges = 1024;      // edges of one subgraph held in LDS (4 p
 constexpr int kBdKX = kBdMaxRows / (kBdBlock / 8);
 constexpr int kBdKE = kBdMaxEdges / kBdBlock;
 
-struct BdItem { uint32_t a, ns, e0, es; };
+struct BdItem { uint32_t a, ns, e0, es, t, first, valid; };
 
-// Work item w = (subgraph, column tile).  Headers are wave-uniform (scalar loads).
-__device__ __forceinline__ BdItem bd_header(uint32_t w, uint32_t total, uint32_t tiles,
-                                            const uint32_t *__restrict__ node_off,
-                                            const uint32_t *__restrict__ edge_off) {
-  BdItem h; h.a = 0; h.ns = 0; h.e0 = 0; h.es = 0;
-  if (w < total) {
-    const uint32_t s = w / tiles;
+// Layer-0 fusion (shaDow/minibatch.py:469 + the layer's input nn.Dropout, layers.py:430,471): row i of X is
+// table[ids[i]] (the feature gather), optionally dropped out with the counter-hash mask of act_norm (same rule:
+// include/shadow_hip.h), and the staged rows are also written out densely (xout) for the layer's other consumers.
+struct BdGather {
+  const float *table;       // nullptr: X is dense
+  int64_t ldt;
+  const uint32_t *ids;
+  float *xout;              // [n, F] gathered (+ dropped) copy, or nullptr
+  int64_t ldxo;
+  uint32_t drop_thr;        // 0: no dropout
+  float drop_scale;
+  uint32_t seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ uint32_t bd_mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+// the four features f..f+3 of batch row r after the input dropout
+__device__ __forceinline__ float4 bd_drop4(const BdGather &g, float4 v, uint64_t r, uint32_t f) {
+  if (!g.drop_thr) return v;
+  const uint32_t base = bd_mix32((uint32_t)r ^ g.seed_lo) + (uint32_t)(r >> 32) + g.seed_hi + f * 0x9E3779B1u;
+  v.x = bd_mix32(base) >= g.drop_thr ? v.x * g.drop_scale : 0.f;
+  v.y = bd_mix32(base + 0x9E3779B1u) >= g.drop_thr ? v.y * g.drop_scale : 0.f;
+  v.z = bd_mix32(base + 2u * 0x9E3779B1u) >= g.drop_thr ? v.z * g.drop_scale : 0.f;
+  v.w = bd_mix32(base + 3u * 0x9E3779B1u) >= g.drop_thr ? v.w * g.drop_scale : 0.f;
+  return v;
+}
+
+// row r of the (virtual) input matrix: dense X or the gathered, dropped table row
+template <bool kGather>
+__device__ __forceinline__ float4 bd_load4(const BdGather &g, const float *__restrict__ X, int64_t ldx, uint64_t r, uint32_t f) {
+  if (!kGather) return ld4(X + (int64_t)r * ldx + f);
+  return bd_drop4(g, ld4(g.table + (int64_t)g.ids[r] * g.ldt + f), r, f);
+}
+
+// out[i, 0:F] = dropout(table[idx[i], :]), out[i, F:Fpad] = 0: the feature gather of a batch (shaDow/minibatch.py:469)
+// with layer 0's input dropout (layers.py:430,471) in the same pass, written into rows padded to whole 128-byte
+// lines so that every later reader (SpMM tiles, GEMM operand loads) works on aligned rows.
+template <int LPR>
+__global__ void gather_rows_drop_kernel(const float *__restrict__ table, int64_t ld_table, const uint32_t *__restrict__ idx,
+                                        float *__restrict__ out, int64_t ld_out, uint32_t n, uint32_t F, uint32_t Fpad,
+                                        BdGather g) {
+  const uint32_t rows_per_block = kBlock / LPR;
+  const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  for (uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub; r < n; r += (uint64_t)gridDim.x * rows_per_block) {
+    const float *src = table + (int64_t)idx[r] * ld_table;
+    float *dst = out + (int64_t)r * ld_out;
+    for (uint32_t c = l * 4; c < Fpad; c += LPR * 4)
+      st4(dst + c, c < F ? bd_drop4(g, ld4(src + c), r, c) : make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+
+// float4 column of lane l8 in tile t: the F/4 float4 columns are split evenly over the tiles (F = 100: 7+6+6+6
+// instead of 8+8+8+1), every tile at most 8 wide
+__device__ __forceinline__ uint32_t bd_col4(uint32_t t, uint32_t tiles, uint32_t nf4, uint32_t l8, bool *on) {
+  const uint32_t c0 = t * nf4 / tiles, c1 = (t + 1u) * nf4 / tiles;
+  *on = c0 + l8 < c1;
+  return (c0 + l8) * 4u;
+}
+
+// Work items: (subgraph, column tile).  A workgroup takes the tiles of a tile GROUP (tg consecutive tiles of one
+// subgraph) back to back: the subgraph's row pointers / column ids / weights are staged once per group, and the
+// slices of a feature row that the group's tiles read follow each other on the same CU (rows of 100 floats are not
+// line aligned: neighbouring tiles share sectors, which now hit L1 / L2 instead of being fetched again).
+// k-th item of workgroup b: group gi = b + (k / tg) * gridDim.x, tile (gi % groups) * tg + k % tg of subgraph gi / groups.
+// Headers are wave-uniform (scalar loads).
+__device__ __forceinline__ BdItem bd_item(uint32_t k, uint32_t tg, uint32_t groups, uint32_t tiles, uint32_t P,
+                                          const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ edge_off) {
+  BdItem h; h.a = 0; h.ns = 0; h.e0 = 0; h.es = 0; h.t = 0; h.first = 0; h.valid = 0;
+  const uint64_t gi = (uint64_t)blockIdx.x + (uint64_t)(k / tg) * gridDim.x;
+  if (gi < (uint64_t)P * groups) {
+    const uint32_t s = (uint32_t)(gi / groups);
+    h.t = (uint32_t)(gi % groups) * tg + k % tg;
+    h.first = (k % tg) == 0;
+    h.valid = h.t < tiles;
     h.a = node_off[s]; h.ns = node_off[s + 1] - h.a;
     h.e0 = edge_off[s]; h.es = edge_off[s + 1] - h.e0;
   }
   return h;
 }
 
-__global__ void __launch_bounds__(kBdBlock)
+// (two 1024-thread workgroups per CU = 8 wavefronts per SIMD: at most 64 VGPRs)
+template <bool kGather>
+__global__ void __launch_bounds__(kBdBlock, 8)
 spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                       const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
                       const float *__restrict__ row_scale, const float *__restrict__ col_scale,
                       const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
                       uint32_t F, const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ edge_off,
-                      uint32_t P, uint32_t tiles, uint32_t cap_rows) {
+                      uint32_t P, uint32_t tiles, uint32_t tg, uint32_t cap_rows, BdGather g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem[];
   float *xs = reinterpret_cast<float *>(bd_smem);                        // [cap_rows][kBdRowPad]
   uint32_t *ips = reinterpret_cast<uint32_t *>(xs + (size_t)cap_rows * kBdRowPad);   // [cap_rows + 4]
@@ -454,7 +526,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
   const uint32_t tid = threadIdx.x;
   const uint32_t l8 = tid & 7u, rg = tid >> 3;                           // 8 lanes per row, 32 rows per pass
   const bool weighted = (edge_w != nullptr) || (col_scale != nullptr);
-  const uint32_t total = P * tiles;          // (host checks the product fits 32 bits)
+  const uint32_t groups = (tiles + tg - 1) / tg;
   // ---- software pipeline over this workgroup's items: the global loads of item k+1 are issued
   //      into registers before item k is computed out of LDS
   float4 xv[kBdKX];
@@ -462,17 +534,22 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
   uint32_t iv[2], cv[kBdKE];
   float wv[kBdKE];
   auto fits = [&](const BdItem &h) { return h.ns != 0 && h.ns <= cap_rows && h.es <= (uint32_t)kBdMaxEdges; };
-  auto prefetch = [&](const BdItem &h, uint32_t w) {
-    if (!fits(h)) return;
-    const uint32_t f = (w % tiles) * kBdTile + l8 * 4;
+  auto prefetch = [&](const BdItem &h) {
+    if (!h.valid || !fits(h)) return;
+    bool pon;
+    const uint32_t f = bd_col4(h.t, tiles, F >> 2, l8, &pon);
 #pragma unroll
     for (int k = 0; k < kBdKX; k++) {
       const uint32_t i = rg + k * (kBdBlock / 8);
       xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       rsv[k] = 1.0f;
-      if (i < h.ns && f < F) xv[k] = ld4(X + (int64_t)(h.a + i) * ldx + f);
+      if (i < h.ns && pon) {
+        xv[k] = bd_load4<kGather>(g, X, ldx, (uint64_t)h.a + i, f);
+        if (kGather && g.xout) st4(g.xout + (int64_t)(h.a + i) * g.ldxo + f, xv[k]);       // the dense copy of the staged rows
+      }
       if (i < h.ns && row_scale) rsv[k] = row_scale[h.a + i];
     }
+    if (!h.first) return;                 // the group's first tile staged the subgraph's structure already
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const uint32_t i = tid + k * kBdBlock;
@@ -490,14 +567,16 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
       }
     }
   };
-  uint32_t w = blockIdx.x;
-  BdItem cur = bd_header(w, total, tiles, node_off, edge_off);
-  BdItem nxt = bd_header(w + gridDim.x, total, tiles, node_off, edge_off);
-  prefetch(cur, w);
-  for (; w < total; w += gridDim.x) {
-    const uint32_t f = (w % tiles) * kBdTile + l8 * 4;
-    const bool on = f < F;
-    const bool in_lds = fits(cur);
+  uint32_t kq = 0;
+  BdItem cur = bd_item(0, tg, groups, tiles, P, node_off, edge_off);
+  BdItem nxt = bd_item(1, tg, groups, tiles, P, node_off, edge_off);
+  prefetch(cur);
+  for (;; kq++) {
+    if ((uint64_t)blockIdx.x + (uint64_t)(kq / tg) * gridDim.x >= (uint64_t)P * groups) break;   // (wave-uniform)
+    bool on;
+    const uint32_t f = bd_col4(cur.t, tiles, F >> 2, l8, &on);
+    on = on && cur.valid;
+    const bool in_lds = cur.valid && fits(cur);
     __syncthreads();                                                     // the previous item's readers are done
     if (in_lds) {
 #pragma unroll
@@ -506,20 +585,22 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
         if (i < cur.ns) *reinterpret_cast<float4 *>(xs + (size_t)i * kBdRowPad + l8 * 4) = xv[k];
         rsc[k] = rsv[k];
       }
+      if (cur.first) {
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const uint32_t i = tid + k * kBdBlock;
-        if (i <= cur.ns) ips[i] = iv[k];
-      }
+        for (int k = 0; k < 2; k++) {
+          const uint32_t i = tid + k * kBdBlock;
+          if (i <= cur.ns) ips[i] = iv[k];
+        }
 #pragma unroll
-      for (int k = 0; k < kBdKE; k++) {
-        const uint32_t p = tid + k * kBdBlock;
-        if (p < cur.es) { cols[p] = cv[k]; if (weighted) ws[p] = wv[k]; }
+        for (int k = 0; k < kBdKE; k++) {
+          const uint32_t p = tid + k * kBdBlock;
+          if (p < cur.es) { cols[p] = cv[k]; if (weighted) ws[p] = wv[k]; }
+        }
       }
     }
     __syncthreads();
-    const BdItem nn = bd_header(w + 2 * gridDim.x, total, tiles, node_off, edge_off);
-    prefetch(nxt, w + gridDim.x);
+    const BdItem nn = bd_item(kq + 2, tg, groups, tiles, P, node_off, edge_off);
+    prefetch(nxt);
     if (in_lds) {
 #pragma unroll
       for (int k = 0; k < kBdKX; k++) {
@@ -536,9 +617,10 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
           if (on) st4(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
         }
       }
-    } else {
+    } else if (cur.valid) {
       // oversize subgraph: gather the feature rows from global memory
       for (uint32_t i = rg; i < cur.ns; i += kBdBlock / 8) {
+        if (kGather && g.xout && on) st4(g.xout + (int64_t)(cur.a + i) * g.ldxo + f, bd_load4<kGather>(g, X, ldx, (uint64_t)cur.a + i, f));
         const uint32_t p0 = indptr[cur.a + i], p1 = indptr[cur.a + i + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t p = p0; p < p1; p++) {
@@ -547,7 +629,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
           if (edge_w) we = edge_w[edge_perm ? edge_perm[p] : p];
           if (col_scale) we *= col_scale[c];
           if (on) {
-            const float4 v = ld4(X + (int64_t)c * ldx + f);
+            const float4 v = bd_load4<kGather>(g, X, ldx, (uint64_t)c, f);
             acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
           }
         }
@@ -1021,6 +1103,45 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
   return SG_OK;
 }
 
+static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                 const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                                 const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
+                                 const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                                 uint32_t max_subg_nodes, const BdGather &bg, void *stream_);
+
+static int make_drop(BdGather *bg, float drop_p, uint64_t drop_seed, const char *who) {
+  memset(bg, 0, sizeof(*bg));
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return set_error(SG_ERR_INVALID, "%s: drop_p = %g", who, drop_p);
+  bg->drop_scale = 1.0f; bg->seed_lo = (uint32_t)drop_seed; bg->seed_hi = (uint32_t)(drop_seed >> 32);
+  if (drop_p > 0.f) {
+    const double t = (double)drop_p * 4294967296.0;
+    bg->drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+    bg->drop_scale = 1.0f / (1.0f - drop_p);
+  }
+  return SG_OK;
+}
+
+extern "C" int sl_gather_rows_drop_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n, uint32_t F,
+                                       float drop_p, uint64_t drop_seed, float *d_out, int64_t ld_out, uint32_t F_pad,
+                                       void *stream_) {
+  if (n == 0 || F == 0) return SG_OK;
+  if (!d_table || !d_idx || !d_out) return set_error(SG_ERR_INVALID, "sl_gather_rows_drop_f32: null argument");
+  if ((F % 4) || (F_pad % 4) || F_pad < F || (ld_table % 4) || (ld_out % 4) || ld_out < (int64_t)F_pad || !aligned16(d_table) || !aligned16(d_out))
+    return set_error(SG_ERR_INVALID, "sl_gather_rows_drop_f32: needs F %% 4 == 0, F <= F_pad <= ld_out and 16-byte aligned rows");
+  BdGather bg;
+  int rc;
+  if ((rc = make_drop(&bg, drop_p, drop_seed, "sl_gather_rows_drop_f32")) != SG_OK) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  if (F_pad <= 64)
+    hipLaunchKernelGGL(gather_rows_drop_kernel<16>, dim3(grid_for(n, kBlock / 16)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg);
+  else if (F_pad <= 128)
+    hipLaunchKernelGGL(gather_rows_drop_kernel<32>, dim3(grid_for(n, kBlock / 32)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg);
+  else
+    hipLaunchKernelGGL(gather_rows_drop_kernel<64>, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
 extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                      const uint32_t *d_edge_perm, const float *d_row_scale,
                                      const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
@@ -1034,6 +1155,37 @@ extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d
   if (!vec)   // unaligned layouts: the general kernel handles them
     return sl_spmm_csr_f32(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy,
                            n, F, stream_);
+  BdGather bg;
+  memset(&bg, 0, sizeof(bg));
+  return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F,
+                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, stream_);
+}
+
+extern "C" int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                            const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                                            const float *d_table, int64_t ldt, const uint32_t *d_ids, float drop_p,
+                                            uint64_t drop_seed, float *d_Xout, int64_t ldxo, float *d_Y, int64_t ldy,
+                                            uint32_t n, uint32_t F, const uint32_t *d_subg_node_off,
+                                            const uint32_t *d_subg_edge_off, uint32_t num_subg, uint32_t max_subg_nodes,
+                                            void *stream_) {
+  if (!d_indptr || !d_table || !d_ids || !d_Y || !d_subg_node_off || !d_subg_edge_off)
+    return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_gather_f32: null argument");
+  if (n == 0 || F == 0 || num_subg == 0) return SG_OK;
+  if ((F % 4) || (ldt % 4) || (ldy % 4) || !aligned16(d_table) || !aligned16(d_Y) || (d_Xout && ((ldxo % 4) || !aligned16(d_Xout))))
+    return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_gather_f32: needs F %% 4 == 0 and 16-byte aligned rows");
+  BdGather bg;
+  int rc;
+  if ((rc = make_drop(&bg, drop_p, drop_seed, "sl_spmm_blockdiag_gather_f32")) != SG_OK) return rc;
+  bg.table = d_table; bg.ldt = ldt; bg.ids = d_ids; bg.xout = d_Xout; bg.ldxo = ldxo;
+  return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_table, ldt, d_Y, ldy, n, F,
+                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, stream_);
+}
+
+static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                 const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                                 const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
+                                 const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                                 uint32_t max_subg_nodes, const BdGather &bg, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
@@ -1042,17 +1194,29 @@ extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d
   uint32_t cap_rows = std::min<uint32_t>(std::max<uint32_t>(max_subg_nodes, 32), (uint32_t)kBdMaxRows);
   cap_rows = (cap_rows + 31u) & ~31u;
   const size_t lds = (size_t)cap_rows * kBdRowPad * 4 + ((size_t)cap_rows + 4) * 4 + (size_t)kBdMaxEdges * 8;
-  if (lds > 64 * 1024)
-    SHD_HIP(hipFuncSetAttribute((const void *)spmm_blockdiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint32_t tiles = (F + kBdTile - 1) / kBdTile;
+  if (lds > 64 * 1024) {
+    SHD_HIP(hipFuncSetAttribute((const void *)spmm_blockdiag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SHD_HIP(hipFuncSetAttribute((const void *)spmm_blockdiag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  const uint32_t tiles = (F / 4 + 7) / 8;            // float4 columns split evenly over the tiles, <= 8 per tile
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 256)));
-  const uint64_t total = (uint64_t)num_subg * tiles;
+  // tiles a workgroup takes back to back: all of a narrow row (F <= 128), otherwise as many as keep >= ~4 groups
+  // per resident workgroup (load balance over ragged subgraphs)
+  uint32_t tg = tiles;
+  if (const char *e = getenv("SHADOW_SPMM_TG")) { const int v = atoi(e); if (v >= 1) tg = std::min<uint32_t>(tiles, (uint32_t)v); }
+  else while (tg > 4 && (uint64_t)num_subg * ((tiles + tg - 1) / tg) < (uint64_t)4 * ncu * per_cu) tg = (tg + 1) / 2;
+  const uint64_t total = (uint64_t)num_subg * ((tiles + tg - 1) / tg);
   if (total + 2 * (uint64_t)ncu * per_cu >= ((uint64_t)1 << 32))
     return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: too many (subgraph, tile) items");
   const uint32_t grid = (uint32_t)std::min<uint64_t>(total, (uint64_t)ncu * per_cu);
-  hipLaunchKernelGGL(spmm_blockdiag_kernel, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
-                     d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
-                     cap_rows);
+  if (bg.table)
+    hipLaunchKernelGGL(spmm_blockdiag_kernel<true>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
+                       d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
+                       tg, cap_rows, bg);
+  else
+    hipLaunchKernelGGL(spmm_blockdiag_kernel<false>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
+                       d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
+                       tg, cap_rows, bg);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

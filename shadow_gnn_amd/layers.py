@@ -112,7 +112,12 @@ class shaDowLayer(nn.Module):
 
     def in_dropout(self, feat_in):
         """nn.Dropout on the layer input (layers.py:430,471,601) unless the producer fused it."""
+        feat_in = ops.dense_rows(feat_in)
         return feat_in if (self.input_pre_dropped and self.training) else self.f_dropout(feat_in)
+
+    def _in_p(self):
+        """Probability of the input dropout still to be applied (0 in evaluation / when the producer fused it)."""
+        return float(self.dropout) if (self.training and not self.input_pre_dropped) else 0.0
 
     def can_fuse_out_dropout(self):
         return self.norm == 'norm_feat' and ops.can_fuse_out_dropout(self.dim_out, getattr(self, 'dim_slice', None))
@@ -210,9 +215,15 @@ class GCN(shaDowLayer):
 
     def forward(self, inputs, sizes_subg):
         feat_in, adj, is_normed, dropedge = inputs
-        feat_in = self.in_dropout(feat_in)
         adj_norm = self.norm_adj(adj, is_normed, dropedge, feat_in.device)
-        feat_aggr = self.spmm(adj_norm, feat_in)
+        if isinstance(feat_in, ops.LazyRows) and ops.FUSE_GATHER_INTO_SPMM and ops.can_fuse_gather(adj_norm, feat_in):
+            # layer 0 of the fast path: feature gather + input dropout inside the aggregation kernel
+            feat_aggr, _x, _seed = ops.spmm_gather(adj_norm, feat_in, drop_p=self._in_p(), want_dense=False)
+        elif isinstance(feat_in, ops.LazyRows):
+            # ... or gather + input dropout in one pass into line-padded rows (the measured faster form)
+            feat_aggr = self.spmm(adj_norm, feat_in.gather_dropped(self._in_p())[0])
+        else:
+            feat_aggr = self.spmm(adj_norm, self.in_dropout(feat_in))
         feat_out = self.f_lin_act_norm([feat_aggr], [self.f_lin], [self.act_name])
         return feat_out, adj_norm, True, 0.
 
@@ -256,8 +267,14 @@ class GraphSAGE(shaDowLayer):
     def forward(self, inputs, sizes_subg):
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self.norm_adj(adj, is_normed, dropedge, feat_in.device)
+        fused = self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0 and self.act is None
+        if fused and isinstance(feat_in, ops.LazyRows):
+            # layer 0 of the fast path: gather + input dropout in one pass (or inside the aggregation kernel)
+            feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
+                                                 self.scale, self.offset, in_dropout=self._in_p(), **self._drop_kw()))
+            return feat_out, adj_norm, True, 0.
         feat_in = self.in_dropout(feat_in)
-        if self.norm == 'norm_feat' and self.f_lin_self.weight.shape[0] % 4 == 0 and self.act is None:
+        if fused:
             # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)
             feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
                                                  self.scale, self.offset, **self._drop_kw()))

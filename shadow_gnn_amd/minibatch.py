@@ -199,6 +199,9 @@ class MinibatchShallowExtractor:
         self.batch_num = -1
         self.dim_1hot_hop, self.dim_1hot_ppr, self.dim_1hot_drnl = 5 + 2, 1, 25 + 1   # minibatch.py:246-248
         self.prefetch = bool(prefetch)
+        # True: batches carry ops.LazyRows(feat_full, node) instead of the gathered matrix -- layer 0 of GCN / GraphSAGE
+        # then reads feat_full[node] inside its aggregation kernel (everything else materialises it on first use)
+        self.lazy_features = False
         # > 0: every batch carries a target-only-tail plan for a model of that many layers (DeepGNN.prune_tail)
         self.tail_plan_layers = 0
         self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
@@ -315,10 +318,23 @@ class MinibatchShallowExtractor:
         self.label_epoch[mode] = self.label_full[torch.as_tensor(mine.astype(np.int64), device=self.device)]
         if mine.size:
             self.graph_sampler[mode].shuffle_targets(mine.astype(np.uint32))
+            self._set_root_cursor(mode, 0)               # (an epoch abandoned half-way leaves the cursor mid-list)
         self._roots_dev[mode] = torch.as_tensor(mine.astype(np.uint32).view(np.int32)).to(self.device)
         self._cursor[mode] = self._step[mode] = self._launched[mode] = 0
         self.idx_entity_evaluated[mode] = 0
         self.end_epoch[mode] = False
+
+    def _set_root_cursor(self, mode, pos: int):
+        """Put the sampler's sequential root cursor (ParallelSampler::_get_roots_p, .cpp:456-468) at ``pos`` of the
+        installed target list: hand out (and drop) root ranges until it stands there.  Only the RNG serial moves on."""
+        hs = self.graph_sampler[mode]
+        total, cur = hs.num_nodes_target(), hs.get_idx_root()
+        if cur > pos:                                    # run to the end of the list: the cursor wraps to 0
+            hs.next_roots(1, total - cur)
+            cur = 0
+        if pos > cur:
+            hs.next_roots(1, pos - cur)
+        assert hs.get_idx_root() == pos % max(total, 1)
 
     def is_end_epoch(self, mode):
         return self.end_epoch[mode]
@@ -357,10 +373,8 @@ class MinibatchShallowExtractor:
             self._launched[mode] = self._step[mode]
             mine = self.entity_epoch[mode]
             if mine is not None and mine.size:
-                hs = self.graph_sampler[mode]
-                hs.shuffle_targets(mine.astype(np.uint32))
-                if self._cursor[mode] > 0:
-                    hs.next_roots(1, self._cursor[mode])       # cursor := roots already consumed this epoch
+                self.graph_sampler[mode].shuffle_targets(mine.astype(np.uint32))
+                self._set_root_cursor(mode, self._cursor[mode])    # cursor := roots already consumed this epoch
         self.record_subgraphs[mode] = "noncache"
 
     # ------------------------------------------------------------- batching
@@ -488,7 +502,8 @@ class MinibatchShallowExtractor:
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
         if not last and self.prefetch:
             self._launch(mode)        # overlap the next sampler call with this batch's training
-        feat = ops.gather_rows(self.feat_full, subgs.node)           # minibatch.py:469
+        feat = (ops.LazyRows(self.feat_full, subgs.node) if self.lazy_features
+                else ops.gather_rows(self.feat_full, subgs.node))    # minibatch.py:469
         label = self.label_epoch[mode][i0:i0 + batch_size_]
         feat_aug = {}
         # entity encodings (frontend/graph.py:134-172) as per-node bit masks; the model's augmentation

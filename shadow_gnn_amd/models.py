@@ -167,7 +167,7 @@ class DeepGNN(nn.Module):
             return self.res_pool_layers[i](outs, tgt, sizes)
         # target-only tail: each remaining layer on the rows the roots depend on; the last one yields the
         # root rows in target order, which is all that residue 'none' + centre pooling reads
-        x, adj_norm = state[0], state[1]
+        x, adj_norm = ops.dense_rows(state[0]), state[1]
         if num_full == 0:
             first = convs[0]
             adj_norm = (first.norm_adj(adj, False, dropedge, x.device) if hasattr(first, 'norm_adj')
@@ -181,9 +181,10 @@ class DeepGNN(nn.Module):
         for i, feat in enumerate(feat_ens):
             tgt = torch.as_tensor(target_ens[i], device=feat.device).long()
             if self.dim_label_in > 0 and mode == TRAIN:
+                feat = ops.dense_rows(feat)
                 feat[tgt, -self.dim_label_in:] = 0            # a root never sees its own label (models.py:181-182)
             if len(self.type_feature_augment) > 0:
-                feat = self._augment(i, feat, feat_aug_ens[i])
+                feat = self._augment(i, ops.dense_rows(feat), feat_aug_ens[i])
             adj_i, levels = adj_ens[i], []
             if self.prune_tail and self._tail_prunable(i):
                 adj_i = layers._as_device_csr(adj_i, feat.device)
@@ -244,7 +245,7 @@ class DeepGNN(nn.Module):
         self.optimizer.step()
 
     def _empty_result(self, batch_data):
-        dev = batch_data.feat_ens[0].device
+        dev = self.classifier[0].f_lin.weight.device
         preds = torch.zeros(0, self.num_classes, device=dev)
         return {'batch_size': 0, 'loss': torch.zeros((), device=dev), 'labels': preds.long(), 'preds': preds,
                 'emb_ens': [torch.zeros(0, self.dim_hid, device=dev)]}

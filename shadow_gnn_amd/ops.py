@@ -239,7 +239,13 @@ def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, bl
     ``out``: optional [n, F] destination (may be a column slice of a wider buffer)."""
     X = _f32c(X)
     F = X.shape[1]
-    Y = out if out is not None else torch.empty(n, F, dtype=torch.float32, device=X.device)
+    if out is not None:
+        Y = out
+    elif X.stride(0) != F and X.stride(0) % 32 == 0:
+        # line-padded input rows (LazyRows.gather_dropped): keep the product's rows on the same aligned pitch
+        Y = torch.empty(n, X.stride(0), dtype=torch.float32, device=X.device)[:, :F]
+    else:
+        Y = torch.empty(n, F, dtype=torch.float32, device=X.device)
     e = int(indices.numel())
     # algorithmic bytes (SURVEY.md 8(d)): indptr + indices (+ edge values) + read X + write A.X
     nbytes = 4 * (n + 1) + 4 * e + (4 * e if edge_w is not None else 0) + 8 * n * F
@@ -294,6 +300,95 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         check(_lib.load().sl_gather_rows_f32(table.data_ptr(), table.stride(0), idx.data_ptr(), n, F,
                                              out.data_ptr(), out.stride(0), _stream(out)))
     return out
+
+
+# Layer 0 of the fast path reads its input as LazyRows.  Two ways to do that were built and measured (MI355X, products
+# shape, 1024 roots, F0 = 100; scripts/probe_spmm_gather.py): the gather (+ input dropout) INSIDE the block-diagonal
+# SpMM (sl_spmm_blockdiag_gather_f32: 152 us incl. the dense copy the self Linear needs) and ONE gather + dropout pass
+# into 128-byte-padded rows followed by the dense SpMM (43 + 81 us).  The dependent id -> row loads inside the SpMM's
+# software pipeline cost more than the extra pass saves, so the second is the default.
+FUSE_GATHER_INTO_SPMM = os.environ.get("SHADOW_FUSE_GATHER_SPMM", "0") == "1"
+
+
+class LazyRows:
+    """table[idx] that has not been gathered yet: the fast minibatch path hands the model this instead of the
+    gathered feature matrix, so that layer 0 reads ``feat_full[subgs.node]`` (shaDow/minibatch.py:469) directly
+    inside its aggregation kernel (sl_spmm_blockdiag_gather_f32).  ``materialize()`` is the plain gather for every
+    other consumer."""
+
+    def __init__(self, table: torch.Tensor, idx: torch.Tensor):
+        _need_cuda(table, idx)
+        assert table.dim() == 2 and table.dtype == torch.float32 and idx.dtype == torch.int32
+        self.table, self.idx = table, idx.contiguous()
+        self._dense = None
+
+    @property
+    def shape(self):
+        return (int(self.idx.numel()), int(self.table.shape[1]))
+
+    @property
+    def device(self):
+        return self.table.device
+
+    @property
+    def is_cuda(self):
+        return True
+
+    def materialize(self) -> torch.Tensor:
+        if self._dense is None:
+            self._dense = gather_rows(self.table, self.idx)
+        return self._dense
+
+    def gather_dropped(self, drop_p: float = 0.0):
+        """dropout(table[idx]) in ONE pass, in rows padded with zeros to whole 128-byte lines: returns the [n, F] view
+        of an [n, F_pad] buffer (F = 100 -> F_pad = 128; aligned rows for the SpMM tiles and the GEMM operand loads)
+        and the dropout seed.  Falls back to gather + nn.functional.dropout for layouts the kernel does not take."""
+        n, F = self.shape
+        t = self.table
+        if not (F % 4 == 0 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+            x = self.materialize()
+            return (torch.nn.functional.dropout(x, drop_p, True) if drop_p > 0 else x), 0
+        Fp = (F + 31) // 32 * 32
+        buf = torch.empty(n, Fp, dtype=torch.float32, device=t.device)
+        seed = new_dropout_seed() if drop_p > 0 else 0
+        with _timed(f"gather_F{F}", 8 * n * F + 4 * n, t.device):
+            check(_lib.load().sl_gather_rows_drop_f32(t.data_ptr(), t.stride(0), self.idx.data_ptr(), n, F, float(drop_p), int(seed),
+                                                      buf.data_ptr(), buf.stride(0), Fp, _stream(buf)))
+        return buf[:, :F], seed
+
+
+def dense_rows(x):
+    """The feature matrix itself, or the gathered rows of a LazyRows."""
+    return x.materialize() if isinstance(x, LazyRows) else x
+
+
+def can_fuse_gather(adj: "NormAdj", x) -> bool:
+    """Layer 0 can read a LazyRows inside the block-diagonal SpMM: the adjacency must carry its block offsets and the
+    rows must be float4-addressable."""
+    c = adj.csr
+    return (isinstance(x, LazyRows) and c.subg_off is not None and x._dense is None
+            and x.shape[1] % 4 == 0 and x.shape[1] >= BLOCKDIAG_MIN_F and x.table.stride(0) % 4 == 0
+            and x.table.stride(1) == 1 and x.table.data_ptr() % 16 == 0)
+
+
+def spmm_gather(adj: "NormAdj", x: LazyRows, drop_p: float = 0.0, want_dense: bool = True):
+    """(adj @ dropout(table[idx]), dropout(table[idx]) or None) in one kernel -- no autograd (layer-0 inputs carry no
+    gradient; the fused layer nodes call this from their forward)."""
+    c = adj.csr
+    n, F = x.shape
+    Y = torch.empty(n, F, dtype=torch.float32, device=x.device)
+    Xo = torch.empty(n, F, dtype=torch.float32, device=x.device) if want_dense else None
+    seed = new_dropout_seed() if drop_p > 0 else 0
+    e = c.e
+    nbytes = 4 * (n + 1) + 4 * e + (4 * e if adj.edge_w is not None else 0) + 4 * n + 4 * n * F * (2 + (1 if want_dense else 0))
+    opt = lambda t: t.data_ptr() if t is not None else None
+    with _timed(f"spmm_gather_F{F}", nbytes, x.device):
+        check(_lib.load().sl_spmm_blockdiag_gather_f32(
+            c.indptr.data_ptr(), c.indices.data_ptr(), opt(adj.edge_w), None, opt(adj.row_scale), opt(adj.col_scale),
+            x.table.data_ptr(), x.table.stride(0), x.idx.data_ptr(), float(drop_p), int(seed), opt(Xo),
+            Xo.stride(0) if Xo is not None else 0, Y.data_ptr(), Y.stride(0), n, F, c.subg_off.data_ptr(),
+            c.subg_edge_off.data_ptr(), int(c.subg_off.numel()) - 1, c.max_subg_nodes, _stream(Y)))
+    return Y, Xo, seed
 
 
 def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
@@ -563,13 +658,19 @@ class _SageDense(torch.autograd.Function):
     so that the backward pass can use  dX = [dZs | A^T dZn] . [Ws ; Wn]  -- one GEMM with K = 2F that writes
     dX once -- instead of two GEMMs, a transposed SpMM on the product and an add."""
     @staticmethod
-    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop):
-        X = _f32c(X).contiguous()
-        _need_cuda(X, Ws, Wn, scale, offset)
+    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop, lazy=None, in_drop=0.0):
+        """``lazy`` (a LazyRows; X is then a dummy): layer 0 -- the aggregation kernel gathers the features, applies the
+        layer's input dropout ``in_drop`` and leaves the dense copy the self Linear and the weight gradients read."""
+        _need_cuda(Ws, Wn, scale, offset)
         c = adj.csr
         F = Ws.shape[0]
-        AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
-                       (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
+        if lazy is not None:
+            AX, X, _seed = spmm_gather(adj, lazy, drop_p=in_drop, want_dense=True)
+        else:
+            X = _f32c(X)                   # (may be the [n, F] view of line-padded rows: every consumer takes a row pitch)
+            _need_cuda(X)
+            AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
+                           (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
         Zs, Zn = mm_nt(X, Ws), mm_nt(AX, Wn)
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
@@ -605,19 +706,26 @@ class _SageDense(torch.autograd.Function):
         dWn = weight_grad(dZn, AX) if ng[4] else None
         dbs = dbi[0] if (has_b[0] and ng[3]) else None
         dbn = dbi[1] if (has_b[1] and ng[5]) else None
-        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None
+        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None
 
 
-def sage_dense(X: torch.Tensor, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
-               offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False):
+def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
+               offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False, in_dropout: float = 0.0):
     """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483).
-    ``dual`` (with out_dropout > 0): returns (out, dropout(out)) from one kernel pass."""
+    ``dual`` (with out_dropout > 0): returns (out, dropout(out)) from one kernel pass.  ``X`` may be a LazyRows
+    (layer 0 of the fast path): gather and input dropout ``in_dropout`` then happen inside the aggregation kernel."""
     if act not in ACT_CODE:
         raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
     F = lin_self.weight.shape[0]
     code = ACT_CODE[act]
+    lazy = None
+    if isinstance(X, LazyRows):
+        if FUSE_GATHER_INTO_SPMM and can_fuse_gather(adj, X):
+            lazy, X = X, X.table.new_empty(0)
+        else:
+            X, _seed = X.gather_dropped(in_dropout)
     return _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
-                            (code, code), _drop_arg(out_dropout, F, None, dual))
+                            (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout))
 
 
 def _drop_arg(out_dropout: float, F: int, seg: Optional[int] = None, dual: bool = False):

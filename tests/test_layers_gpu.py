@@ -790,3 +790,114 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         solid = gref.abs() > 1e-3 * gref.abs().max()
         moved_ok = (got[solid] - want[solid]).abs() <= 1e-4 * want[solid].abs() + 2e-5
         assert float(moved_ok.double().mean()) >= (0.99 if act == "relu" else 1.0), k
+
+
+# --------------------------------------------------------------------------------------------------------------
+# layer-0 fusion: feature gather (+ input dropout) inside the block-diagonal SpMM (round 2)
+# --------------------------------------------------------------------------------------------------------------
+def _blockdiag_batch(sizes, density, seed):
+    import scipy.sparse as sp
+    from shadow_gnn_amd import ops
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for s_ in sizes:
+        a = (rng.random((s_, s_)) < density).astype(np.float32)
+        a = np.maximum(a, a.T)
+        blocks.append(sp.csr_matrix(a))
+    A = sp.block_diag(blocks, format="csr"); A.sort_indices()
+    noff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    eoff = A.indptr[noff].astype(np.int32)
+    csr = ops.DeviceCSR(torch.from_numpy(A.indptr.astype(np.int32)).to(DEV), torch.from_numpy(A.indices.astype(np.int32)).to(DEV),
+                        subg_off=torch.from_numpy(noff).to(DEV), subg_edge_off=torch.from_numpy(eoff).to(DEV),
+                        max_subg_nodes=int(max(sizes)))
+    return csr, A
+
+
+@pytest.mark.parametrize("F", [100, 128, 256, 96, 132])
+@pytest.mark.parametrize("p", [0.0, 0.4])
+def test_spmm_gather_equals_gather_then_spmm(F, p):
+    """sl_spmm_blockdiag_gather_f32: Y = A_norm . dropout(table[ids]) with the gather (shaDow/minibatch.py:469) and the
+    layer's input dropout done while the subgraph tile is staged -- equal, bit for bit, to gather -> mask -> SpMM through
+    the separate kernels; the dense copy it leaves equals table[ids] * mask / (1 - p) under the documented hash rule.
+    Ragged subgraphs incl. one beyond the LDS tile (400 rows: HBM fall-back path) and single-node ones."""
+    from shadow_gnn_amd import ops
+    sizes = [37, 1, 250, 400, 3, 64, 1, 129]
+    csr, A = _blockdiag_batch(sizes, 0.05, seed=F)
+    n = csr.n
+    g = torch.Generator(device=DEV).manual_seed(F + int(p * 10))
+    table = torch.randn(5000, F, device=DEV, generator=g)
+    ids = torch.randint(0, 5000, (n,), device=DEV, dtype=torch.int32, generator=g)
+    adj = ops.adj_norm_rw(csr, dropedge=0.2 if F == 128 else 0.0)
+    lazy = ops.LazyRows(table, ids)
+    assert ops.can_fuse_gather(adj, lazy)
+    torch.manual_seed(77)                                    # (the dropout seed comes from torch's CPU generator)
+    Y, Xo, seed = ops.spmm_gather(adj, lazy, drop_p=p, want_dense=True)
+    X = table[ids.long()]
+    if p > 0:
+        keep = ops.dropout_keep_mask(n, F, p, seed, DEV)
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+        X = torch.where(keep, X * (1.0 / (1.0 - p)), torch.zeros_like(X))
+    assert torch.equal(Xo, X)
+    assert torch.equal(Y, ops.spmm(adj, X))
+    Y2, none, _ = ops.spmm_gather(adj, lazy, drop_p=0.0, want_dense=False)
+    assert none is None and torch.equal(Y2, ops.spmm(adj, table[ids.long()]))
+
+
+@pytest.mark.parametrize("aggr", ["sage", "gcn"])
+def test_lazy_feature_batches_train_like_gathered_ones(aggr):
+    """MinibatchShallowExtractor.lazy_features: batches carry LazyRows and layer 0 gathers inside its aggregation kernel.
+    With dropout = 0 three training steps end in bit-identical parameters; with dropout on, training still runs and the
+    evaluation pass (no dropout) is bit-identical too."""
+    from shadow_gnn_amd import ops
+    from shadow_gnn_amd.minibatch import TRAIN, VALID, MinibatchShallowExtractor
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    N, F0, C, B = 20000, 100, 11, 64
+    indptr, indices = make_graph_numpy(N, 12, seed=8)
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(N, F0, generator=g)
+    label = torch.randint(0, C, (N,), generator=g)
+    roots = np.random.default_rng(2).permutation(N)[:B * 4]
+
+    def run(lazy, dropout):
+        mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices), VALID: (indptr, indices)}, {TRAIN: roots, VALID: roots[:B]},
+                                                 dict(method="khop", depth=2, budget=8, add_self_edge=(aggr == "gcn")),
+                                                 (), feat, label, batch_size=B, device=DEV, seed_cpp=3, prefetch=False)
+        mb.lazy_features = lazy
+        mb.epoch_start_reset(0, TRAIN); mb.shuffle_entity(TRAIN, perm=np.arange(roots.size))
+        torch.manual_seed(4)
+        arch = dict(num_layers=3, num_cls_layers=1, heads=1, dim=64, act="relu", layer_norm="norm_feat",
+                    feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
+        m = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=dropout, dropedge=0.0, lr=0.01), "node").to(DEV)
+        losses = []
+        for _ in range(3):
+            b = mb.one_batch(TRAIN)
+            assert isinstance(b.feat_ens[0], ops.LazyRows) == lazy
+            losses.append(float(m.step(TRAIN, "running", b)["loss"].detach()))
+        mb.epoch_start_reset(0, VALID); mb.shuffle_entity(VALID, perm=np.arange(B))
+        ev = m.step(VALID, "running", mb.one_batch(VALID))["preds"].detach().clone()
+        return losses, torch.cat([q.detach().flatten() for q in m.parameters()]).clone(), ev
+    l0, p0, e0 = run(False, 0.0)
+    l1, p1, e1 = run(True, 0.0)
+    assert l0 == l1 and torch.equal(p0, p1) and torch.equal(e0, e1)
+    l2, p2, e2 = run(True, 0.3)
+    assert all(np.isfinite(l2)) and torch.isfinite(p2).all() and torch.isfinite(e2).all()
+
+
+@pytest.mark.parametrize("F,p", [(100, 0.0), (100, 0.4), (128, 0.25), (36, 0.5), (200, 0.1)])
+def test_gather_dropped_rows(F, p):
+    """sl_gather_rows_drop_f32: table[ids] with the input dropout in the same pass (mask = the documented hash rule,
+    kept values scaled by 1/(1-p)), rows padded with zeros to whole 128-byte lines."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(F)
+    table = torch.randn(3000, F, device=DEV, generator=g)
+    ids = torch.randint(0, 3000, (2111,), device=DEV, dtype=torch.int32, generator=g)
+    x, seed = ops.LazyRows(table, ids).gather_dropped(p)
+    assert x.shape == (2111, F) and x.stride(0) == (F + 31) // 32 * 32 and x.data_ptr() % 128 == 0
+    want = table[ids.long()]
+    if p > 0:
+        keep = ops.dropout_keep_mask(2111, F, p, seed, DEV)
+        want = torch.where(keep, want * (1.0 / (1.0 - p)), torch.zeros_like(want))
+    assert torch.equal(x, want)
+    pad = torch.as_strided(x, (2111, x.stride(0)), (x.stride(0), 1))[:, F:]
+    assert pad.numel() == 0 or float(pad.abs().max()) == 0.0
