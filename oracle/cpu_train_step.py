@@ -51,14 +51,18 @@ class _Layer(nn.Module):
 
 
 class CpuModel(nn.Module):
-    def __init__(self, kind, num_layers, dim_in, dim, num_classes, act, dropout):
+    def __init__(self, kind, num_layers, dim_in, dim, num_classes, act, dropout, aug_dim=0):
         super().__init__()
         self.layers = nn.ModuleList(_Layer(kind, dim_in if i == 0 else dim, dim, act, dropout) for i in range(num_layers))
         self.cls = nn.Linear(dim, num_classes)
         self.cls_scale = nn.Parameter(torch.ones(num_classes))
         self.cls_offset = nn.Parameter(torch.zeros(num_classes))
+        # 'sum' feature augmentation: Linear(one-hot hop encoding) added into the raw features (models.py:183-189)
+        self.aug = nn.Linear(aug_dim, dim_in) if aug_dim else None
 
-    def forward(self, x, adj, target):
+    def forward(self, x, adj, target, enc=None):
+        if self.aug is not None:
+            x = x + self.aug(enc)
         for l in self.layers:
             x = l(x, adj)
         emb = F.normalize(x[target], p=2, dim=1)
@@ -87,13 +91,14 @@ def norm_adj(indptr, indices, kind, dropedge, gen):
 
 
 def time_train_steps(indptr, indices, feat, target, label, kind, num_layers, dim, num_classes, act, dropout, dropedge,
-                     lr, threads, budget_s=25.0, max_steps=3):
+                     lr, threads, budget_s=25.0, max_steps=3, enc=None):
     """Runs whole training steps on the CPU until ``budget_s`` is spent (at least one, at most ``max_steps``
     after one untimed warm-up if the budget allows).  Returns (steps, seconds, warmup_seconds)."""
     torch.set_num_threads(int(threads))
     gen = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
-    model = CpuModel(kind, num_layers, feat.shape[1], dim, num_classes, act, dropout)
+    model = CpuModel(kind, num_layers, feat.shape[1], dim, num_classes, act, dropout,
+                     aug_dim=(enc.shape[1] if enc is not None else 0))
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     feat, target, label = feat.float(), target.long(), label.long()
 
@@ -101,7 +106,7 @@ def time_train_steps(indptr, indices, feat, target, label, kind, num_layers, dim
         model.train()
         adj = norm_adj(indptr, indices, kind, dropedge, gen)
         opt.zero_grad(set_to_none=True)
-        loss = F.cross_entropy(model(feat, adj, target), label)
+        loss = F.cross_entropy(model(feat, adj, target, enc), label)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
         opt.step()

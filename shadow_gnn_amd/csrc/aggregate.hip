@@ -1195,8 +1195,8 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   cap_rows = (cap_rows + 31u) & ~31u;
   const size_t lds = (size_t)cap_rows * kBdRowPad * 4 + ((size_t)cap_rows + 4) * 4 + (size_t)kBdMaxEdges * 8;
   if (lds > 64 * 1024) {
-    SHD_HIP(hipFuncSetAttribute((const void *)spmm_blockdiag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SHD_HIP(hipFuncSetAttribute((const void *)spmm_blockdiag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<false>, lds));
+    SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<true>, lds));
   }
   const uint32_t tiles = (F / 4 + 7) / 8;            // float4 columns split evenly over the tiles, <= 8 per tile
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 256)));
@@ -1295,7 +1295,7 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
     if (bwd && lds <= 144 * 1024) {
       // deterministic: per-wavefront LDS partials -> per-block partials -> fixed-order finish
       if (lds > 64 * 1024)
-        SHD_HIP(hipFuncSetAttribute((const void *)act_norm_generic_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SHD_HIP(ensure_dynamic_lds((const void *)act_norm_generic_kernel<true, true>, lds));
       hipLaunchKernelGGL((act_norm_generic_kernel<true, true>), dim3(g), dim3(kBlock), lds, st, p);
       hipLaunchKernelGGL(act_norm_finish_kernel, dim3((p.F + 63) / 64, p.nb * 3), dim3(1024), 0, st, p.partial, g, p.nb, p.F,
                          p.dscale, p.doffset, p.dbias);

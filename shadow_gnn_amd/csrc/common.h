@@ -21,6 +21,10 @@ int set_error(int code, const char *fmt, ...);
                                hipGetErrorString(_e), __FILE__, __LINE__);                 \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver round trip: remember the largest size granted per
+// (kernel, device) and only ask again for more (the hot launches of a training step call it thousands of times otherwise)
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

@@ -312,10 +312,8 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
     const uint32_t rows_wg = 32u * RB * (WAVES / CS);                                                        \
     const uint32_t grid = (M + rows_wg - 1) / rows_wg;                                                       \
     if (lds > 64 * 1024) {                                                                                   \
-      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, TW, CS, WAVES, false>,              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-      SHD_HIP(hipFuncSetAttribute((const void *)gemm_nt_split_kernel<RB, TW, CS, WAVES, true>,               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+      SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_split_kernel<RB, TW, CS, WAVES, false>, lds));        \
+      SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_split_kernel<RB, TW, CS, WAVES, true>, lds));         \
     }                                                                                                        \
     if (K % 32 == 0)                                                                                         \
       hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,  \
@@ -522,11 +520,11 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
   rows_per_wg = (rows_per_wg + 15u) & ~15u;
   const size_t lds = (size_t)2 * kTnStepFloats * 4;
   if (K <= 128) {
-    SHD_HIP(hipFuncSetAttribute((const void *)gemm_tn_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_split_kernel<2>, lds));
     hipLaunchKernelGGL((gemm_tn_split_kernel<2>), dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_B, ldb, d_partial, M, N, K,
                        rows_per_wg);
   } else {
-    SHD_HIP(hipFuncSetAttribute((const void *)gemm_tn_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_split_kernel<4>, lds));
     hipLaunchKernelGGL((gemm_tn_split_kernel<4>), dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_B, ldb, d_partial, M, N, K,
                        rows_per_wg);
   }

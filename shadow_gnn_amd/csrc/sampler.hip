@@ -33,6 +33,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -52,6 +54,19 @@ int set_error(int code, const char *fmt, ...) {
   va_end(ap);
   last_error() = buf;
   return code;
+}
+
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &have = granted[std::make_pair(kernel, dev)];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
 }
 
 }  // namespace shadow
@@ -817,7 +832,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_PER_CU", 8)));
       const uint32_t grid = std::min<uint32_t>(P, (uint32_t)ncu * per_cu);
       if (L.total > 64 * 1024)
-        SHD_HIP(hipFuncSetAttribute((const void *)sg_select_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+        SHD_HIP(ensure_dynamic_lds((const void *)sg_select_lds_kernel, L.total));
       hipLaunchKernelGGL(sg_select_lds_kernel, dim3(grid), dim3(T), L.total, stream, p);
       SHD_HIP(hipGetLastError());
     }
@@ -859,7 +874,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
       const void *kfn = plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
       if (SL.total > 64 * 1024)
-        SHD_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL.total));
+        SHD_HIP(ensure_dynamic_lds(kfn, SL.total));
       if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       SHD_HIP(hipGetLastError());

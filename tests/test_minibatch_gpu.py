@@ -465,3 +465,28 @@ def test_mid_epoch_reshuffle_and_disable_cache(prefetch):
     assert np.array_equal(seen, roots)
     ref = so.sample_batch(indptr, indices, roots[16:32], method="ppr", k=12, threshold=0.0, add_self_edge=True, ppr=table, seed=2)
     assert np.array_equal(rest[0].device_batch.to_host()["indices"], ref.indices)
+
+
+def test_flat_adam_equals_torch_adam():
+    """optim.FlatAdam (clip-by-global-norm + Adam on the flat gradient / parameter buffers) takes the same steps as
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam: five training steps from the same seeds end in the same
+    parameters (same arithmetic; only the reduction order of the gradient norm differs)."""
+    from shadow_gnn_amd import dist as sdist
+    from shadow_gnn_amd.minibatch import TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.optim import FlatAdam
+
+    def run(flat):
+        mb = _setup(prefetch=False, batch=16, aug=("hops",), budget=-1)[0]
+        torch.manual_seed(5)
+        arch = dict(num_layers=3, heads=1, dim=32, act="elu", aggr="sage", residue="max", pooling="mean")
+        model = DeepGNN(20, 20, 7, 0, arch, [("hops", 7)], 1, dict(dropout=0.0, dropedge=0.0, lr=1e-2), "node").to(DEV)
+        model.grad_sync = sdist.GradSync(model.parameters(), world_size=1)
+        model.optimizer = FlatAdam(model.grad_sync, lr=1e-2) if flat else torch.optim.Adam(model.parameters(), lr=1e-2)
+        losses = [float(model.step(TRAIN, "running", mb.one_batch(TRAIN))["loss"].detach()) for _ in range(5)]
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    la, pa = run(False)
+    lb, pb = run(True)
+    np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)
+    for k in pa:
+        np.testing.assert_allclose(pb[k].numpy(), pa[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
