@@ -331,6 +331,11 @@ size_t sl_gemm_pack_bytes(uint32_t N, uint32_t K);
 int sl_gemm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream);
 int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packed_B, float *d_C, int64_t ldc, uint32_t M,
                    uint32_t N, uint32_t K, void *stream);
+/* The same image from strided sources: B element (j, k) = B1[j * s1j + k * s1k] for k < K1 and
+ * B2[j * s2j + (k - K1) * s2k] for K1 <= k < K -- a weight packed transposed (s1j = 1, s1k = ld), or the
+ * concatenation [Ws^T | Wn^T] of the GraphSAGE input gradient without materialising it.                      */
+int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k,
+                    uint32_t N, uint32_t K, void *d_packed, void *stream);
 
 /* Fused (bias +) activation + feature normalisation + branch sum:
  *   out = out_scale * sum_{b<nb} ( (h_b - mean) * scale[b] * rsqrt(var + 1e-9) + offset[b] ),
@@ -365,6 +370,39 @@ int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
                     const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
                     float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped,
                     int64_t lddo_dropped, void *stream);
+
+/* A normalised batch adjacency  diag(row_scale) (A o edge_w) diag(col_scale)  as the layer entries below take it
+ * (what ops.NormAdj holds): any of edge_w / row_scale / col_scale may be NULL (= ones); t_* = the transposed CSR
+ * with the permutation into the original edge order (sl_csr_transpose), needed by the backward entries when the
+ * input gradient is wanted; subg_* = the block offsets of a collated batch (NULL: plain CSR kernels).          */
+typedef struct {
+  const uint32_t *indptr, *indices;
+  const float *edge_w, *row_scale, *col_scale;
+  const uint32_t *t_indptr, *t_indices, *t_perm;
+  const uint32_t *subg_node_off, *subg_edge_off;
+  uint32_t num_subg, max_subg_nodes, n, e;
+} sl_norm_adj;
+
+/* One GraphSAGE layer pass per call (shaDow/layers.py:471-483 and its autograd):
+ *     out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn))      [+ the next layer's input dropout, as
+ *     sl_act_norm_fwd does it; d_out_dropped != NULL: dual mode]
+ * forward: SpMM -> weight packs -> two split-bf16 GEMMs -> fused bias / act / norm, enqueued by ONE call; the caller
+ * provides AX [n, Fin] (ldax), Zs, Zn, out [n, Fout] and d_pack (sl_sage_pack_bytes(Fin, Fout) bytes).
+ * backward: act_norm backward -> A^T dZn -> dX = [dZs | A^T dZn] . [Ws ; Wn] (one K = 2 Fout product; d_dX NULL: not
+ * wanted) -> the two weight gradients; d_buf is [n, 3 Fout] scratch, d_an_partial as for sl_act_norm_bwd (nb = 2),
+ * d_tn_partial as for sl_gemm_tn_f32; d_dbias [2, Fout] or NULL.  Fout % 4 == 0, <= 256 (input gradient: Fout % 32
+ * == 0, Fin <= 256); the same kernels in the same order as the separate entries: identical results.             */
+size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout);
+int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_Ws,
+                int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
+                const float *d_offset, int act, float drop_p, uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs,
+                float *d_Zn, float *d_out, float *d_out_dropped, void *d_pack, void *stream);
+int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
+                const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws, const float *d_bs,
+                const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale, const float *d_offset, int act,
+                float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
+                float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
+                float *d_an_partial, float *d_tn_partial, void *d_pack, void *stream);
 
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):

@@ -52,6 +52,15 @@ class SgBatchCounts(C.Structure):
     ]
 
 
+class SlNormAdj(C.Structure):
+    _fields_ = [
+        ("indptr", C.c_void_p), ("indices", C.c_void_p), ("edge_w", C.c_void_p), ("row_scale", C.c_void_p),
+        ("col_scale", C.c_void_p), ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("t_perm", C.c_void_p),
+        ("subg_node_off", C.c_void_p), ("subg_edge_off", C.c_void_p), ("num_subg", C.c_uint32),
+        ("max_subg_nodes", C.c_uint32), ("n", C.c_uint32), ("e", C.c_uint32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/shadow_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -107,6 +116,13 @@ SIGNATURES = {
     "sl_gemm_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_gemm_pack_b": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_gemm_nt_f32": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    "sl_gemm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_sage_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "sl_sage_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P,
+                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "sl_sage_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
+                               _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                               _P, _P]),
     "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
@@ -128,7 +144,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 7      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 8      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -72,8 +72,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m
 // piece_p( B[32t + (l & 31)][32u + 16 (l >> 5) + 8h + j] ), j = 0..7.  Rows >= N and columns >= K are zero.
 // One thread per (u, h, t, l).
 // ---------------------------------------------------------------------------
-__global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t ldb, uint32_t N, uint32_t K, uint32_t units,
-                                   uint32_t tiles, bf16x8 *__restrict__ out) {
+// (B element (j, k) = B1[j * s1j + k * s1k] for k < K1, B2[j * s2j + (k - K1) * s2k] behind: a weight can be packed
+//  transposed, and [Ws^T | Wn^T] without materialising the concatenation)
+__global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t s1j, int64_t s1k, uint32_t K1,
+                                   const float *__restrict__ B2, int64_t s2j, int64_t s2k, uint32_t N, uint32_t K,
+                                   uint32_t units, uint32_t tiles, bf16x8 *__restrict__ out) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = units * 2 * tiles * 64;
   if (idx >= total) return;
@@ -82,7 +85,10 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t ldb, uin
   const uint32_t k0 = 32 * u + 16 * (l >> 5) + 8 * h;
   float x[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) x[j] = (col < N && k0 + j < K) ? B[(int64_t)col * ldb + k0 + j] : 0.f;
+  for (int j = 0; j < 8; j++) {
+    const uint32_t k = k0 + j;
+    x[j] = (col < N && k < K) ? (k < K1 ? B[(int64_t)col * s1j + (int64_t)k * s1k] : B2[(int64_t)col * s2j + (int64_t)(k - K1) * s2k]) : 0.f;
+  }
   bf16x8 hh, mm, ll;
   split8(x, hh, mm, ll);
   // image index: ((u*2 + h)*3 + p)*tiles + t, then lane
@@ -289,8 +295,21 @@ extern "C" int sl_gemm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_
   if (N > 256) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b: N = %u (at most 256 output columns)", N);
   const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
   const uint32_t total = units * 2 * tiles * 64;
-  hipLaunchKernelGGL(gemm_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_B, ldb, N, K,
-                     units, tiles, reinterpret_cast<bf16x8 *>(d_packed));
+  hipLaunchKernelGGL(gemm_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_B, ldb, (int64_t)1, K,
+                     d_B, ldb, (int64_t)1, N, K, units, tiles, reinterpret_cast<bf16x8 *>(d_packed));
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j,
+                               int64_t s2k, uint32_t N, uint32_t K, void *d_packed, void *stream) {
+  if (!d_B1 || !d_packed || (K1 < K && !d_B2)) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: null argument");
+  if (N == 0 || K == 0) return SG_OK;
+  if (N > 256) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: N = %u (at most 256 output columns)", N);
+  const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
+  const uint32_t total = units * 2 * tiles * 64;
+  hipLaunchKernelGGL(gemm_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_B1, s1j, s1k,
+                     std::min(K1, K), d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, units, tiles, reinterpret_cast<bf16x8 *>(d_packed));
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

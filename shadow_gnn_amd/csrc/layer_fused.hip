@@ -1,0 +1,100 @@
+// layer_fused.hip -- one C entry per GraphSAGE layer pass.
+//
+// The dense part of a GraphSAGE layer (shaDow/layers.py:471-483),
+//     out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn)),
+// is six kernels forward (SpMM, two weight packs, two split-bf16 GEMMs, fused bias/act/norm) and about ten backward.
+// Launched one by one from Python through ctypes they cost more host time than GPU time at the reference's own batch
+// sizes (16-256 roots per step).  These entries enqueue the whole pass with ONE call; they own no kernel, only the
+// order of the existing ones (the same order ops._SageDense used), so results are identical.
+#include <string.h>
+
+#include "common.h"
+
+using namespace shadow;
+
+namespace {
+
+int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx, float *Y, int64_t ldy, uint32_t F, void *st) {
+  const uint32_t *ip = transposed ? a->t_indptr : a->indptr, *ix = transposed ? a->t_indices : a->indices;
+  const uint32_t *perm = (transposed && a->edge_w) ? a->t_perm : nullptr;
+  // (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
+  const float *rs = transposed ? a->col_scale : a->row_scale, *cs = transposed ? a->row_scale : a->col_scale;
+  if (a->subg_node_off && F >= 96)
+    return sl_spmm_blockdiag_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
+                                 a->num_subg, a->max_subg_nodes, st);
+  return sl_spmm_csr_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, st);
+}
+
+}  // namespace
+
+extern "C" size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout) {
+  // forward: Ws and Wn images ([Fout, Fin] each); backward: the [Fin, 2 Fout] image of [Ws^T | Wn^T]
+  const size_t fwd = 2 * sl_gemm_pack_bytes(Fout, Fin), bwd = sl_gemm_pack_bytes(Fin, 2 * Fout);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout,
+                           const float *d_Ws, int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn,
+                           const float *d_bn, const float *d_scale, const float *d_offset, int act, float drop_p,
+                           uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs, float *d_Zn, float *d_out,
+                           float *d_out_dropped, void *d_pack, void *stream) {
+  if (!adj || !d_X || !d_Ws || !d_Wn || !d_scale || !d_offset || !d_AX || !d_Zs || !d_Zn || !d_out || !d_pack)
+    return set_error(SG_ERR_INVALID, "sl_sage_fwd: null argument");
+  if (Fout > 256 || (Fout & 3) || Fin == 0) return set_error(SG_ERR_INVALID, "sl_sage_fwd: Fout = %u (multiple of 4, at most 256)", Fout);
+  const uint32_t n = adj->n;
+  if (n == 0) return SG_OK;
+  int rc;
+  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
+  char *pk = (char *)d_pack;
+  const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
+  if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pb, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_nt_f32(d_X, ldx, pk, d_Zs, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_nt_f32(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  const float *Z[2] = {d_Zs, d_Zn};
+  const int64_t ldz[2] = {Fout, Fout};
+  const float *bias[2] = {d_bs, d_bn};
+  const int acts[2] = {act, act};
+  return sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
+                         d_out_dropped, Fout, stream);
+}
+
+extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax,
+                           const float *d_Zs, const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws,
+                           const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
+                           const float *d_offset, int act, float drop_p, uint64_t drop_seed, const float *d_dout,
+                           const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
+                           float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
+                           void *d_pack, void *stream) {
+  if (!adj || !d_X || !d_AX || !d_Zs || !d_Zn || !d_Ws || !d_Wn || !d_scale || !d_offset || !d_dWs || !d_dWn || !d_dscale ||
+      !d_doffset || !d_buf || !d_an_partial || !d_tn_partial || !d_pack || (!d_dout && !d_dout_dropped))
+    return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
+  if (Fout > 256 || (Fout & 3) || Fin > 256 || (Fin & 3)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: widths %u -> %u unsupported", Fin, Fout);
+  if (d_dX && ((2 * Fout) % 32 || Fout % 32)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs Fout %% 32 == 0");
+  const uint32_t n = adj->n;
+  if (n == 0) return SG_OK;
+  int rc;
+  // act_norm backward: dZs into the left half of buf [n, 2 Fout], dZn into the right half (in place of A^T dZn later)
+  const float *Z[2] = {d_Zs, d_Zn};
+  const int64_t ldz[2] = {Fout, Fout};
+  const float *bias[2] = {d_bs, d_bn};
+  const int acts[2] = {act, act};
+  // dZn needs its own dense [n, Fout] home: the transposed SpMM reads it and writes the right half of buf.  The
+  // caller's buf is [n, 3 Fout]: [dZs | A^T dZn | dZn].
+  float *dZs = d_buf, *dZn = d_buf + 2 * (size_t)Fout;
+  float *dZ[2] = {dZs, dZn};
+  const int64_t ld3 = 3 * (int64_t)Fout;
+  const int64_t lddz[2] = {ld3, ld3};
+  if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
+                            d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
+    return rc;
+  if (d_dX) {
+    if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
+    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream)) != SG_OK) return rc;
+    // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
+    if ((rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream)) != SG_OK) return rc;
+    if ((rc = sl_gemm_nt_f32(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) return rc;
+  }
+  if ((rc = sl_gemm_tn_f32(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
+  return sl_gemm_tn_f32(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+}

@@ -110,11 +110,12 @@ class GradSync:
     def zero(self):
         """Start of a step: clear the buffer and arm the hooks."""
         self.flat.zero_()
-        # autograd may have replaced .grad (e.g. after zero_grad(set_to_none=True)); re-attach
-        for i, p in enumerate(self.params):
-            view = self.flat[self._off[i]:self._off[i + 1]].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                p.grad = view
+        # something may have dropped a .grad (zero_grad(set_to_none=True)): re-attach the views.  (A .grad that is set
+        # stays the view: autograd accumulates into it in place.)
+        if any(p.grad is None for p in self.params):
+            for i, p in enumerate(self.params):
+                if p.grad is None:
+                    p.grad = self.flat[self._off[i]:self._off[i + 1]].view_as(p)
         self._left = [hi - lo for lo, hi in self._slices]
         self._next = 0
         self._works = []

@@ -230,7 +230,8 @@ class DeepGNN(nn.Module):
 
     # ------------------------------------------------------------------ step
     def _begin_update(self):
-        self.train()
+        if not self.training:                     # (nn.Module.train() walks the whole module tree: only on a mode change)
+            self.train()
         if self.grad_sync is not None:
             self.grad_sync.zero()
         else:
@@ -278,7 +279,8 @@ class DeepGNN(nn.Module):
             (loss if weight == 1.0 else loss * weight).backward()
             self._finish_update()
         else:
-            self.eval()
+            if self.training:
+                self.eval()
             with torch.no_grad():
                 preds, emb_ens = self(mode, dropedge=0., **fwd)
                 loss = self._loss(preds, labels)

@@ -77,7 +77,9 @@ class _timed:
 
 
 def _stream(t: torch.Tensor):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    # (the raw handle of torch's current stream on t's device: ~20x cheaper than building a torch.cuda.Stream object,
+    #  and every op launch needs it)
+    return torch._C._cuda_getCurrentRawStream(t.device.index if t.device.index is not None else torch.cuda.current_device())
 
 
 def _need_cuda(*ts):
@@ -210,8 +212,7 @@ def dropedge_mask(csr: DeviceCSR, dropedge: float, symmetric: bool = False) -> O
     num = int(csr.e * dropedge)
     m = torch.ones(csr.e, dtype=torch.float32, device=csr.device)
     if num > 0:
-        idx = torch.floor(torch.rand(num, device=csr.device) * csr.e).long().clamp_(max=csr.e - 1)
-        m[idx] = 0
+        m[torch.randint(0, csr.e, (num,), device=csr.device)] = 0
     if symmetric:
         _ti, _tx, tp = csr.transposed
         m = m * m[tp.long()]
@@ -232,6 +233,23 @@ def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
 
 
 BLOCKDIAG_MIN_F = 96      # below this width the per-edge gather kernels are faster (measured)
+
+
+def _adj_struct(adj: "NormAdj", need_transpose: bool):
+    """The ctypes image of a NormAdj for the one-call layer entries (the tensors stay owned by ``adj``)."""
+    c = adj.csr
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    ti = tx = tp = None
+    if need_transpose:
+        ti, tx, tp = c.transposed
+    return _lib.SlNormAdj(c.indptr.data_ptr(), c.indices.data_ptr(), ptr(adj.edge_w), ptr(adj.row_scale), ptr(adj.col_scale),
+                          ptr(ti), ptr(tx), ptr(tp), ptr(c.subg_off), ptr(c.subg_edge_off),
+                          (int(c.subg_off.numel()) - 1) if c.subg_off is not None else 0, c.max_subg_nodes, c.n, c.e)
+
+
+# One C call per GraphSAGE layer pass (sl_sage_fwd / sl_sage_bwd) instead of one per kernel: the same kernels in the
+# same order.  Off while a KernelTimer is collecting per-kernel HIP-event timings (bench.py's roofline measurement).
+FUSED_LAYER_CALLS = os.environ.get("SHADOW_FUSED_LAYER_CALLS", "1") != "0"
 
 
 def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None, out=None):
@@ -669,18 +687,85 @@ class _SageDense(torch.autograd.Function):
         else:
             X = _f32c(X)                   # (may be the [n, F] view of line-padded rows: every consumer takes a row pitch)
             _need_cuda(X)
-            AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
-                           (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
-        Zs, Zn = mm_nt(X, Ws), mm_nt(AX, Wn)
+            if _SageDense._fusable(X, Ws, Wn):
+                AX = None                  # the one-call entry below computes it
+            else:
+                AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
+                               (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
         bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
-        out = _an_fwd([Zs, Zn], bsc, acts, sc, of, F, 1.0, drop)
+        if AX is None:
+            AX, Zs, Zn, out = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop)
+        else:
+            Zs, Zn = mm_nt(X, Ws), mm_nt(AX, Wn)
+            out = _an_fwd([Zs, Zn], bsc, acts, sc, of, F, 1.0, drop)
         ctx.save_for_backward(X, AX, Ws, Wn, Zs, Zn, sc, of, *[b if b is not None else sc.new_empty(0) for b in bsc])
         ctx.adj = adj
         ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)])
         ctx.set_materialize_grads(False)
         return out
+
+    @staticmethod
+    def _fusable(X, Ws, Wn):
+        Fo, Fi = Ws.shape
+        return (FUSED_LAYER_CALLS and GEMM_SPLIT and KernelTimer.active is None and X.shape[0] > 0 and Fo % 4 == 0 and Fo <= 256
+                and Fi % 4 == 0 and X.dtype == torch.float32 and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+                and Ws.stride(1) == 1 and Wn.stride(1) == 1 and Ws.dtype == torch.float32 and Wn.shape == Ws.shape)
+
+    @staticmethod
+    def _fused_forward(X, adj, Ws, Wn, biases, sc, of, acts, drop):
+        lib = _lib.load()
+        n, Fi = X.shape
+        Fo = Ws.shape[0]
+        dev = X.device
+        pitch = X.stride(0) if (X.stride(0) != Fi and X.stride(0) % 32 == 0) else Fi
+        AX = torch.empty(n, pitch, dtype=torch.float32, device=dev)[:, :Fi]
+        Zs = torch.empty(n, Fo, dtype=torch.float32, device=dev)
+        Zn = torch.empty(n, Fo, dtype=torch.float32, device=dev)
+        out = torch.empty(n, Fo, dtype=torch.float32, device=dev)
+        out2 = torch.empty(n, Fo, dtype=torch.float32, device=dev) if _is_dual(drop) else None
+        pack = torch.empty(lib.sl_sage_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        a = _adj_struct(adj, False)
+        opt = lambda t: t.data_ptr() if t is not None else None
+        check(lib.sl_sage_fwd(C.byref(a), X.data_ptr(), X.stride(0), Fi, Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]),
+                              Wn.data_ptr(), Wn.stride(0), opt(biases[1]), sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]),
+                              int(drop[1]), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), out.data_ptr(), opt(out2),
+                              pack.data_ptr(), _stream(X)))
+        return AX, Zs, Zn, (out if out2 is None else (out, out2))
+
+    @staticmethod
+    def _fused_backward(ctx, dout, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, drop, has_b, want_dx):
+        lib = _lib.load()
+        n, Fo = Zs.shape
+        Fi = X.shape[1]
+        dev = Zs.device
+        douts = dout if isinstance(dout, (tuple, list)) else (dout,)
+        d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
+        d1 = None
+        if _is_dual(drop):
+            d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
+            if d1 is None:
+                drop = (0.0, 0)
+        if d0 is None and d1 is None:
+            d0 = torch.zeros(n, Fo, dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dX = torch.empty(n, Fi, **f32) if want_dx else None
+        dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
+        dbi = torch.empty(2, Fo, **f32) if any(has_b) else None
+        dsc, dof = torch.empty(2, Fo, **f32), torch.empty(2, Fo, **f32)
+        buf = torch.empty(n, 3 * Fo, **f32)
+        an_partial = torch.empty(2048 * 2 * 3 * Fo, **f32)
+        tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)
+        pack = torch.empty(lib.sl_sage_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        a = _adj_struct(ctx.adj, want_dx)
+        opt = lambda t: t.data_ptr() if t is not None else None
+        check(lib.sl_sage_bwd(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi, Fo,
+                              Ws.data_ptr(), Ws.stride(0), opt(biases[0]), Wn.data_ptr(), Wn.stride(0), opt(biases[1]), sc.data_ptr(),
+                              of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX), dWs.data_ptr(),
+                              dWn.data_ptr(), opt(dbi), dsc.data_ptr(), dof.data_ptr(), buf.data_ptr(), an_partial.data_ptr(),
+                              tn_partial.data_ptr(), pack.data_ptr(), _stream(Zs)))
+        return dX, dWs, dWn, dbi, dsc, dof
 
     @staticmethod
     def backward(ctx, *dout):
@@ -690,6 +775,14 @@ class _SageDense(torch.autograd.Function):
         n, F = Zs.shape
         ng = ctx.needs_input_grad
         biases = [b if hb else None for b, hb in zip((b0, b1), has_b)]
+        Fi = X.shape[1]
+        if (_SageDense._fusable(X, Ws, Wn) and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
+                and (not ng[0] or F % 32 == 0)):
+            dX, dWs, dWn, dbi, dsc, dof = _SageDense._fused_backward(ctx, dout, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, drop,
+                                                                     has_b, bool(ng[0]))
+            dbs = dbi[0] if (has_b[0] and ng[3]) else None
+            dbn = dbi[1] if (has_b[1] and ng[5]) else None
+            return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None
         # dZs lands in the left half of one [n, 2F] buffer; A^T dZn goes into the right half
         buf = torch.empty(n, 2 * F, dtype=torch.float32, device=Zs.device) if ng[0] else None
         dz_out = [buf[:, :F], None] if buf is not None else None

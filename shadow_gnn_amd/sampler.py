@@ -300,7 +300,7 @@ class HipSampler:
         cap_edges_out = min(cap_edges_out, max(1, P * cape))
         pend.bufs, pend.out = self._alloc(cfg, P, cap_nodes_out, cap_edges_out)
         c = cfg.to_c()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
         roots_ptr = pend.roots_dev.data_ptr() if pend.roots_dev is not None else None
         check(self._lib.sg_sample(self._h, C.byref(c), pend.root_start, P, pend.serial, roots_ptr,
                                   C.byref(pend.out), stream))
@@ -439,7 +439,7 @@ class SubgraphCache:
                          batch.edge_id.data_ptr(), batch.target.data_ptr(), batch.subg_node_off.data_ptr(),
                          batch.subg_edge_off.data_ptr(), batch.hop.data_ptr() if batch.hop is not None else None,
                          batch.ppr.data_ptr(), None, batch.num_nodes, batch.num_edges)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
         with torch.cuda.device(self.device):
             check(self._lib.sg_cache_record(self._h, C.byref(out), batch.num_subgraphs, batch.num_nodes,
                                             batch.num_edges, stream))
@@ -467,7 +467,7 @@ class SubgraphCache:
         roots = roots.contiguous()
         P = int(roots.numel())
         bufs, out = self._alloc(P, max(1, cap_nodes), max(1, cap_edges), want_hop)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = torch._C._cuda_getCurrentRawStream(self.device.index)
         with torch.cuda.device(self.device):
             check(self._lib.sg_cache_collate(self._h, roots.data_ptr(), P, C.byref(out), stream))
         self._pend = (roots, bufs, out, P, want_hop)
