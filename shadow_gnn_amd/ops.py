@@ -552,12 +552,15 @@ class _ActNorm(torch.autograd.Function):
 # split-bf16 MFMA GEMM (csrc/gemm.hip) for the tall feature x weight products; rocBLAS fp32 otherwise
 # (SHADOW_GEMM_SPLIT_MIN_ROWS=1 sends every product the kernels can take through them -- the parity suite replays
 #  the reference's small golden fixtures that way)
-GEMM_SPLIT_MIN_ROWS = int(os.environ.get("SHADOW_GEMM_SPLIT_MIN_ROWS", "8192"))
+# (default 1024 rows: below that rocBLAS wins on GPU time; between 1 k and 8 k rows it is the HOST time of a rocBLAS
+#  launch -- ~65 us of heuristics per call against ~10 us for the two ctypes calls -- that decides, measured on the
+#  arxiv-shape GCN-3 / 32-root configuration: 2.42 -> 1.95 ms per step)
+GEMM_SPLIT_MIN_ROWS = int(os.environ.get("SHADOW_GEMM_SPLIT_MIN_ROWS", "1024"))
 GEMM_SPLIT = os.environ.get("SHADOW_GEMM_SPLIT", "1") != "0"
 
 
 def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """A[M,K] @ B[N,K]^T in fp32.  Tall products (M >= 8192, N <= 256) run on the bf16 matrix cores
+    """A[M,K] @ B[N,K]^T in fp32.  Tall products (M >= GEMM_SPLIT_MIN_ROWS, N <= 256) run on the bf16 matrix cores
     with the exact three-way operand split (fp32-level accuracy, see csrc/gemm.hip); the rest goes to
     rocBLAS."""
     M, K = A.shape
