@@ -862,10 +862,10 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       if (p.bit_words & (p.bit_words - 1)) p.bit_words = big ? kBitWordsBig : kBitWords;
       p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : 2048)));
       p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
-      const ScanLayout SL = scan_layout(p.bit_words, p.capm, p.nodes_lds);
-      if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
       uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", 512);
       if (T != 256 && T != 512 && T != 1024) T = 512;
+      const ScanLayout SL = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);
+      if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));
       per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_SCAN_PER_CU", 8)));
       p.scan_grid = std::min<uint32_t>((uint32_t)ncu * per_cu, kScanGridMax);

@@ -69,22 +69,23 @@ __global__ void __launch_bounds__(1024) sg_plan_kernel(SampleParams p) {
 struct ScanLds {
   uint32_t *bits;    // [bit_words]
   uint32_t *lkey;    // [capm] candidate list: 2*slot+kind
-  uint32_t *lval;    // [capm] neighbour's global id (kind 1), later the column sub id
+  uint32_t *lval;    // [capm] position of the neighbour in `indices` (kind 1: its id is fetched when the round resolves), later the column sub id
   uint32_t *lrow;    // [capm] row of the entry (+ its rank in the upper bits during the write-out)
   uint32_t *lnext;   // [capm] bucket chains of the final sort
   uint32_t *bhead;   // [kSortBuckets]
   uint32_t *bcnt;    // [kSortBuckets]
   uint32_t *nodes;   // [nodes_lds] sorted node ids of the subgraph (when they fit)
   uint32_t *crow;    // [kMaxRoundChunks] first row of every chunk of the round
-  unsigned char *wtmp;  // [waves * 4 * 64] wave-private start-position flags
+  unsigned char *wtmp;  // [waves * 512] wave-private: start-position flags + records of the runs in flight
   uint32_t *ctrl;    // [C_WORDS]
 };
 
+constexpr uint32_t kWavePriv = 640;          // wave-private LDS: 64 start-position flags + 36 run records
 struct ScanLayout {
   size_t bits, lkey, lval, lrow, lnext, bhead, bcnt, nodes, crow, wtmp, ctrl, total;
 };
 
-__host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t capm, uint32_t nodes_lds) {
+__host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t capm, uint32_t nodes_lds, uint32_t waves) {
   ScanLayout L;
   size_t o = 0;
   L.bits = o; o += (size_t)bit_words * 4;
@@ -96,7 +97,7 @@ __host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t c
   L.bcnt = o; o += kSortBuckets * 4;
   L.nodes = o; o += r16((size_t)nodes_lds * 4);
   L.crow = o; o += kMaxRoundChunks * 4;
-  L.wtmp = o; o += 16 * 64 * 4;
+  L.wtmp = o; o += (size_t)waves * kWavePriv;
   L.ctrl = o; o += C_WORDS * 4;
   L.total = o;
   return L;
@@ -173,11 +174,21 @@ __device__ __forceinline__ void emit_empty_row(const SampleParams &p, const Scan
   if (cnt) {
     uint32_t rr = atomicAdd(&ctrl[C_M], cnt);
     if (incl_self) list_put(t, capm, rr, 2u * w.z, 0u, r);
-    if (put_over) list_put(t, capm, rr, 2u * w.z + 1u, over, r);
+    if (put_over) list_put(t, capm, rr, 2u * w.z + 1u, w.x, r);
   }
 }
 
+// membership-filter bit of one id / of the four ids of a quad (bit c = component c); bm4 = (bit_words - 1) * 4
+__device__ __forceinline__ uint32_t probe1(const ScanLds &t, uint32_t id, uint32_t bm4) {
+  const uint32_t w = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(t.bits) + ((id >> 3) & bm4));
+  return __builtin_amdgcn_ubfe(w, id, 1u);
+}
+__device__ __forceinline__ uint32_t probe4(const ScanLds &t, const uint4 q, uint32_t bm4) {
+  return probe1(t, q.x, bm4) | (probe1(t, q.y, bm4) << 1) | (probe1(t, q.z, bm4) << 2) | (probe1(t, q.w, bm4) << 3);
+}
+
 constexpr uint32_t kLongRow = 24;            // rows with at least this many quads left in the chunk are streamed alone
+constexpr int kRuns = 8;                     // runs (1-KiB loads) a wavefront issues before it consumes the first
 
 // Everything the scan knows about the subgraph / round it works on (uniform), bundled for the group helpers.
 struct ScanCtx {
@@ -196,12 +207,7 @@ __device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t
                                               uint32_t rs, uint32_t row, uint32_t v, uint32_t e0, uint32_t prev, bool need_prev,
                                               uint32_t edge) {
   const uint32_t cc[4] = {q.x, q.y, q.z, q.w};
-  uint32_t h = 0;
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const uint32_t w = t.bits[(cc[c] >> 5) & x.bw_mask];
-    h |= ((w >> (cc[c] & 31u)) & 1u) << c;
-  }
+  const uint32_t h = probe4(t, q, x.bw_mask << 2);
   uint32_t vmask = 0xFu;
   if (edge) {
     vmask = 0;
@@ -224,15 +230,19 @@ __device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t
       if (((vmask >> c) & 1u) && j + 1u == deg && cc[c] < v) trail = 1;        // last neighbour < v
     }
   }
-  const uint32_t cnt = (uint32_t)(__popc(hit) + __popc(selfm)) + trail;
+  // the found ids are few (about one in a hundred): one list reservation per lane, then one entry per set bit
+  uint32_t todo = hit | (selfm << 4);
+  const uint32_t cnt = (uint32_t)__popc(todo) + trail;
   if (__ballot(cnt != 0)) {
     uint32_t r = 0;
     if (cnt) r = atomicAdd(&x.ctrl[C_M], cnt);
     const uint32_t keybase = 2u * (rs + j0);
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      if (!kPlain && ((selfm >> c) & 1u)) list_put(t, x.capm, r, keybase + 2u * c, 0u, row);     // .cpp:408-410
-      if ((hit >> c) & 1u) list_put(t, x.capm, r, keybase + 2u * c + 1u, cc[c], row);         // .cpp:420-422
+    while (todo) {
+      const uint32_t b = (uint32_t)__ffs((int)todo) - 1u;
+      todo &= todo - 1u;
+      const uint32_t c = b & 3u;
+      const bool nb = b < 4u;                                                                    // neighbour (.cpp:420-422) / self edge (.cpp:408-410)
+      list_put(t, x.capm, r, keybase + 2u * c + (nb ? 1u : 0u), e0 + j0 + c, row);
     }
     if (!kPlain && trail) list_put(t, x.capm, r, 2u * (rs + deg), 0u, row);
   }
@@ -254,7 +264,7 @@ __device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t
         const uint32_t c = x.indices[e0 + deg];
         if ((t.bits[(c >> 5) & x.bw_mask] >> (c & 31u)) & 1u) {
           uint32_t r = atomicAdd(&x.ctrl[C_M], 1u);
-          list_put(t, x.capm, r, 2u * (rs + deg) + 1u, c, row);
+          list_put(t, x.capm, r, 2u * (rs + deg) + 1u, e0 + deg, row);
         }
       }
     }
@@ -264,7 +274,7 @@ __device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t
 template <bool kPlain>
 __global__ void sg_scan_kernel(SampleParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const ScanLayout L = scan_layout(p.bit_words, p.capm, p.nodes_lds);
+  const ScanLayout L = scan_layout(p.bit_words, p.capm, p.nodes_lds, blockDim.x >> 6);
   ScanLds t;
   t.bits = (uint32_t *)(smem + L.bits);
   t.lkey = (uint32_t *)(smem + L.lkey);
@@ -288,8 +298,9 @@ __global__ void sg_scan_kernel(SampleParams p) {
   const bool compat = !kPlain && (p.compat != 0);
   const bool sentinel = incl_self || compat;
   const uint32_t C = p.plan[PL_NCHUNKS], cpw = p.plan[PL_CPW];
-  unsigned char *wflag = t.wtmp + wave * 256u;           // wave-private (one 64-byte table per group of a batch), all zero between uses
-  for (uint32_t i = tid; i < 16u * 64u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
+  unsigned char *wflag = t.wtmp + wave * kWavePriv;           // wave-private: 64 start-position flags (all zero between uses) ...
+  uint4 *wrun = reinterpret_cast<uint4 *>(wflag + 64);   // ... and the run list of the row window (at most 28 entries, see below)
+  for (uint32_t i = tid; i < (T >> 6) * kWavePriv / 4u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
 
   uint32_t tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // phase cycles of this workgroup (thread 0)
   uint64_t tlast = clock64();
@@ -353,6 +364,9 @@ __global__ void sg_scan_kernel(SampleParams p) {
       SCAN_T(1);
 
       // ---- the scan: wave w takes chunks w, w + nw, ... of the round
+      uint32_t nx_wb = (wave < rchunks) ? t.crow[wave] : 0u;
+      uint32_t nx_base = g_rowq[nx_wb];
+      uint4 nx_win = win_fetch(g_info, nx_wb, n);
       for (uint32_t k = wave; k < max(rchunks, 1u); k += nw) {
         const uint32_t qa = rq0 + k * kQChunk, qb = min(qa + kQChunk, rq1);
         // rows without neighbours in front of the subgraph's first quad (or a subgraph without any quad):
@@ -370,9 +384,14 @@ __global__ void sg_scan_kernel(SampleParams p) {
         ScanCtx cx;
         cx.indices = p.indices; cx.nnz = p.nnz; cx.ctrl = ctrl; cx.bw_mask = bw_mask; cx.capm = capm;
         cx.incl_self = incl_self; cx.compat = compat;
-        uint32_t wb = rl_first(t.crow[k]);
-        uint32_t wbase = rl_first(g_rowq[wb]);                         // quad position of the window's first row
-        uint4 wcur = win_fetch(g_info, wb, n);
+        uint32_t wb = rl_first(nx_wb);
+        uint32_t wbase = rl_first(nx_base);                            // quad position of the window's first row
+        uint4 wcur = nx_win;
+        if (k + nw < rchunks) {                                        // the next chunk's first window: loads in flight meanwhile
+          nx_wb = t.crow[k + nw];
+          nx_base = g_rowq[nx_wb];
+          nx_win = win_fetch(g_info, nx_wb, n);
+        }
         for (;;) {
           const uint4 wnext = win_fetch(g_info, wb + 64u, n);          // prefetch
           const uint32_t w_e0 = wcur.x, w_deg = wcur.y, w_rs = wcur.z, w_v = wcur.w;
@@ -386,53 +405,99 @@ __global__ void sg_scan_kernel(SampleParams p) {
           // rows without neighbours behind a row that ends inside the chunk: their sentinel slots are this chunk's
           if (!kPlain && sentinel && wb + lane < n && w_nq == 0 && w_pos > qa && w_pos <= qb)
             emit_empty_row<kPlain>(p, t, ctrl, g_info, wb + lane, incl_self, compat, bw_mask, capm);
-          // ---- long rows, one at a time
-          uint64_t long_mask = __ballot(w_len >= kLongRow);
-          while (long_mask) {
-            const uint32_t cl = (uint32_t)__ffsll((unsigned long long)long_mask) - 1u;
-            long_mask &= long_mask - 1ull;
-            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)w_e0, cl);
-            const uint32_t deg = (uint32_t)__builtin_amdgcn_readlane((int)w_deg, cl);
-            const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)w_rs, cl);
-            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)w_v, cl);
-            const uint32_t nq = (uint32_t)__builtin_amdgcn_readlane((int)w_nq, cl);
-            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)w_k0, cl);
-            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w_len, cl);
-            const uint32_t row = wb + cl;
-            const uint32_t abase = ((e0 >> 2) + k0 + lane) << 2;          // my quad of the row's first run
-            uint32_t g0 = 0;
-            // a run that holds the row's first or last quad may contain ids of the neighbouring rows
-            if (k0 == 0 && (e0 & 3u) && len >= 64u) {
-              const uint4 q = *reinterpret_cast<const uint4 *>(p.indices + abase);
-              process_group<kPlain>(cx, t, q, abase - e0, deg, rs, row, v, e0, 0u, false, 1u);
-              g0 = 64;
-            }
-            // interior runs, four in flight
-            const uint32_t interior_end = (k0 + len == nq && ((e0 + deg) & 3u)) ? len - 1u : len;
-            for (; g0 + 256u <= interior_end; g0 += 256u) {
-              uint4 q[4];
-              uint32_t pv = 0;
-#pragma unroll
-              for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint4 *>(p.indices + abase + 4u * (g0 + 64u * u));
-              if (!kPlain && incl_self && lane == 0 && k0 + g0 > 0) pv = p.indices[abase + 4u * g0 - 1u];
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const uint32_t a = abase + 4u * (g0 + 64u * u);
-                uint32_t pvu = pv;
-                if (!kPlain && incl_self && u > 0) pvu = (uint32_t)__builtin_amdgcn_readlane((int)q[u > 0 ? u - 1 : 0].w, 63);
-                process_group<kPlain>(cx, t, q[u], a - e0, deg, rs, row, v, e0, pvu, lane == 0 && (k0 + g0 + 64u * u) > 0, 0u);
+          // ---- long rows: a flat list of RUNS (<= 64 quads of one row).  The rows write their runs' records to a
+          //      wave-private LDS list in parallel (sum of ceil(len / 64) over rows of >= kLongRow quads in 512: at most 28); it then issues
+          //      up to kRuns 1-KiB loads back to back -- across rows -- before it consumes the first: with 16 wavefronts
+          //      per CU that keeps the ~64 KiB in flight this access pattern needs (scripts/probe_row_stream.py).
+          {
+            const bool is_long = w_len >= kLongRow;
+            const uint32_t nr = is_long ? (w_len + 63u) >> 6 : 0u;
+            const uint32_t rincl = wave_incl_scan(nr);
+            const uint32_t nruns = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
+            if (nruns) {
+              uint32_t ri = rincl - nr;
+              for (uint32_t g0 = 0; g0 < (is_long ? w_len : 0u); g0 += 64u, ri++) {
+                const uint32_t take = min(64u, w_len - g0);
+                const uint32_t kq = w_k0 + g0;
+                // every component is a neighbour unless the run holds the row's first / last quad or is not full
+                const uint32_t edge = ((kq == 0 && (w_e0 & 3u)) || (kq + take == w_nq && ((w_e0 + w_deg) & 3u)) || take < 64u) ? 1u : 0u;
+                // record: first id of the run, (row lane | quads - 1 | edge | not the row's first quad), key of id 0
+                wrun[ri] = make_uint4(((w_e0 >> 2) + kq) << 2, lane | ((take - 1u) << 6) | (edge << 12) | (kq > 0 ? 1u << 13 : 0u),
+                                      2u * (w_rs - w_e0) + 1u, 0u);
               }
-            }
-            // the rest of the row, one run at a time
-            for (; g0 < len; g0 += 64u) {
-              const uint32_t take = min(64u, len - g0);
-              const uint32_t a = abase + 4u * g0;
-              uint4 q = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
-              uint32_t pv = 0;
-              if (lane < take) q = *reinterpret_cast<const uint4 *>(p.indices + a);
-              const bool np = lane == 0 && (k0 + g0) > 0;
-              if (!kPlain && incl_self && np) pv = p.indices[a - 1u];
-              process_group<kPlain>(cx, t, q, a - e0, lane < take ? deg : 0u, rs, row, v, e0, pv, np, 1u);
+              __builtin_amdgcn_wave_barrier();
+              for (uint32_t i0 = 0; i0 < nruns; i0 += kRuns) {
+                const uint32_t nfill = min((uint32_t)kRuns, nruns - i0);
+                const uint4 dl = wrun[i0 + (lane & (kRuns - 1))];          // lane u holds run i0 + u
+                uint4 q[kRuns];
+                uint32_t pv[kRuns];
+#pragma unroll
+                for (int u = 0; u < kRuns; u++) {
+                  q[u] = make_uint4(kEmpty, kEmpty, kEmpty, kEmpty);
+                  pv[u] = 0;
+                  if ((uint32_t)u < nfill) {                                // wave-uniform
+                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)dl.x, u);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)dl.y, u);
+                    if (lane <= ((m >> 6) & 63u)) q[u] = *reinterpret_cast<const uint4 *>(p.indices + a0 + 4u * lane);
+                    if (!kPlain && incl_self && lane == 0 && (m & (1u << 13))) pv[u] = p.indices[a0 - 1u];
+                  }
+                }
+                if (kPlain) {
+                  // probe all runs first (4 bits per run and lane), then file what was found -- about one id in a
+                  // hundred -- in one go: one list reservation per batch, the ids noted by position
+                  uint32_t hm = 0;
+#pragma unroll
+                  for (int u = 0; u < kRuns; u++) {
+                    if ((uint32_t)u < nfill) {
+                      const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)dl.y, u);
+                      uint32_t h = probe4(t, q[u], bw_mask << 2);
+                      if (m & (1u << 12)) {                                  // the run holds an end of its row / is not full
+                        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)dl.x, u);
+                        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)w_e0, m & 63u);
+                        const uint32_t deg = (uint32_t)__builtin_amdgcn_readlane((int)w_deg, m & 63u);
+                        const uint32_t j0 = a0 + 4u * lane - e0;            // wraps in front of the row
+                        const uint32_t dq = lane <= ((m >> 6) & 63u) ? deg : 0u;
+                        uint32_t vmask = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+                          if (j0 + c < dq) vmask |= 1u << c;
+                        h &= vmask;
+                      }
+                      hm |= h << (4 * u);
+                    }
+                  }
+                  const uint32_t cnt = (uint32_t)__popc(hm);
+                  if (__ballot(cnt != 0)) {
+                    const uint32_t incl = wave_incl_scan(cnt);
+                    uint32_t base = 0;
+                    if (lane == 63) base = atomicAdd(&ctrl[C_M], incl);
+                    uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + incl - cnt;
+                    while (hm) {
+                      const uint32_t b = (uint32_t)__ffs((int)hm) - 1u;
+                      hm &= hm - 1u;
+                      const uint4 d = wrun[i0 + (b >> 2)];
+                      const uint32_t idx = d.x + 4u * lane + (b & 3u);
+                      list_put(t, capm, r, d.z + 2u * idx, idx, wb + (d.y & 63u));        // .cpp:420-422
+                    }
+                  }
+                } else {
+#pragma unroll
+                  for (int u = 0; u < kRuns; u++) {
+                    if ((uint32_t)u < nfill) {
+                      const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)dl.x, u);
+                      const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)dl.y, u);
+                      const uint32_t rl = m & 63u;
+                      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)w_e0, rl);
+                      const uint32_t deg = (uint32_t)__builtin_amdgcn_readlane((int)w_deg, rl);
+                      const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)w_rs, rl);
+                      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)w_v, rl);
+                      process_group<kPlain>(cx, t, q[u], a0 + 4u * lane - e0, lane <= ((m >> 6) & 63u) ? deg : 0u, rs, wb + rl, v, e0,
+                                            pv[u], lane == 0 && (m & (1u << 13)), (m >> 12) & 1u);
+                    }
+                  }
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
             }
           }
           // ---- short rows, packed: the rows flag the packed position they start on, the positions read the flags
@@ -501,7 +566,7 @@ __global__ void sg_scan_kernel(SampleParams p) {
       for (uint32_t i = tid; i < m; i += T) {
         uint32_t key = t.lkey[i];
         if (key & 1u) {
-          const uint32_t c = t.lval[i];
+          const uint32_t c = p.indices[t.lval[i]];
           uint32_t lo = 0, hi = n;
           if (nodes_in_lds) {
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < c) lo = mid + 1; else hi = mid; }
