@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC passes of scripts/collect_profiles.sh: HBM bytes per launch (read + write) under
+the kernel labels bench.py uses.
+
+    python scripts/make_traffic.py gpurun_out/prof_r02 r02 products-khop-sage5
+
+Read bytes = 2 * FETCH_SIZE * 1024, write bytes = WRITE_SIZE * 1024 (MI355X_MICROARCH.md: the counters are in KiB and
+on gfx950 FETCH_SIZE counts a 128-byte request of a wide coalesced read as 64 bytes).  rocprofv3 only knows kernel
+names; launches of one kernel that differ in shape (the block-diagonal SpMM at F = 100 / F = 256, the nt GEMM at
+K = 256 / K = 512) are told apart by their counter value: the sorted per-dispatch values are cut where they jump by
+more than 15 %."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def per_dispatch(sub, cname):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == cname and "shadow::" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def clusters(vals):
+    """[(mean, count)] of the value groups, ascending."""
+    v = sorted(vals)
+    groups, cur = [], [v[0]]
+    for x in v[1:]:
+        if x > 1.15 * cur[-1] and x - cur[-1] > 1024:
+            groups.append(cur); cur = [x]
+        else:
+            cur.append(x)
+    groups.append(cur)
+    return [(sum(g) / len(g), len(g)) for g in groups]
+
+
+fetch = per_dispatch("pmc_fetch", "FETCH_SIZE")
+write = per_dispatch("pmc_write", "WRITE_SIZE")
+
+
+def find(sub):
+    ks = [k for k in fetch if sub in k]
+    assert len(ks) == 1, (sub, ks)
+    return ks[0]
+
+
+def rw(sub, which=None, of=None):
+    """read+write bytes per launch of the kernel whose name contains `sub`; `which`/`of`: cluster index / expected
+    cluster count when its launches mix shapes (None = mean over all launches)."""
+    k = find(sub)
+    res = []
+    for acc, scale in ((fetch, 2 * 1024.0), (write, 1024.0)):
+        cl = clusters(acc[k])
+        if which is None:
+            res.append(scale * sum(acc[k]) / len(acc[k]))
+        else:
+            if len(cl) != of:
+                # small kernels' counters are noisy: merge to the expected count by taking the heaviest clusters
+                cl = sorted(sorted(cl, key=lambda c: -c[1])[:of])
+            res.append(scale * cl[which][0])
+    return res
+
+
+t = {}
+notes = {}
+sel, plan, scan = rw("sg_select_lds_kernel"), rw("sg_plan_kernel"), rw("sg_scan_kernel<true>")
+t["sg_sample_pipeline"] = sum(sel) + sum(plan) + sum(scan)
+notes["sg_sample_pipeline"] = dict(select=sel, plan=plan, scan=scan)
+t["sg_relocate_kernel"] = sum(rw("sg_relocate_kernel"))
+t["gather_F100"] = sum(rw("gather_rows_drop_kernel"))
+t["spmm_F100"] = sum(rw("spmm_blockdiag_kernel<false>", 0, 2))
+t["spmm_F256"] = sum(rw("spmm_blockdiag_kernel<false>", 1, 2))
+t["act_norm_fwd_nb2_F256"] = sum(rw("act_norm_kernel<64, 64, false, 2>"))
+t["act_norm_bwd_nb2_F256"] = sum(rw("act_norm_kernel<64, 64, true, 2>"))
+t["gemm_nt_split_N256"] = sum(rw("gemm_nt_split_kernel<1, 8, 1, 4, false>"))
+t["gemm_nt_split_N256_Ktail"] = sum(rw("gemm_nt_split_kernel<1, 8, 1, 4, true>"))
+t["gemm_tn_split_N256"] = sum(rw("gemm_tn_split_kernel<4>"))
+t["gemm_tn_split_N256_K128"] = sum(rw("gemm_tn_split_kernel<2>"))
+t = {k: int(v) for k, v in t.items()}
+
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+cur = {}
+if os.path.exists(path):
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        cur = {}
+cur[workload] = t
+cur["_source"] = (f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv (separate rocprofv3 --pmc passes of bench.py --steps 10 "
+                  "--warmup 3, scripts/collect_profiles.sh); read bytes = 2*FETCH_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md), "
+                  "write bytes = WRITE_SIZE*1024; per-launch means by kernel; launches of one kernel that differ in shape (SpMM F = 100 / 256) "
+                  "are separated by counter value (scripts/make_traffic.py); the nt GEMM figure averages its K = 256 and K = 512 launches; "
+                  "sg_sample_pipeline = select + plan + scan kernels of one call")
+json.dump(cur, open(path, "w"), indent=1)
+print(json.dumps(t, indent=1))
+print(json.dumps(notes, indent=1))
