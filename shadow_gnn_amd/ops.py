@@ -212,7 +212,8 @@ def dropedge_mask(csr: DeviceCSR, dropedge: float, symmetric: bool = False) -> O
     num = int(csr.e * dropedge)
     m = torch.ones(csr.e, dtype=torch.float32, device=csr.device)
     if num > 0:
-        m[torch.randint(0, csr.e, (num,), device=csr.device)] = 0
+        # (index_fill_ with a scalar: `m[idx] = 0` would stage a host scalar through a blocking H2D copy every step)
+        m.index_fill_(0, torch.randint(0, csr.e, (num,), device=csr.device), 0.0)
     if symmetric:
         _ti, _tx, tp = csr.transposed
         m = m * m[tp.long()]
