@@ -5,8 +5,10 @@ import sys, numpy as np, torch
 from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
 from shadow_gnn_amd.synthetic import SHAPES, MAX_DEGREE, make_graph_torch
 dev = torch.device("cuda:0")
-N, nnz, F, C = SHAPES["products"]
-indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE["products"])
+import os
+SHAPE = os.environ.get("SHAPE", "products")
+N, nnz, F, C = SHAPES[SHAPE]
+indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE[SHAPE])
 hs = HipSampler(indptr, indices, device=dev, seed=3)
 roots = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy().astype(np.uint32)
 hs.shuffle_targets(roots)
@@ -26,7 +28,8 @@ for B in Bs:
     tot = sum(ph[8:13]) or 1
     print(f"   scan: chunks {ph[0]} per workgroup {ph[1]} segments {ph[13]} rounds {ph[14]}  phases setup/startrows/scan/resolve/sortwrite = "
           + " / ".join(f"{100 * ph[8 + i] / tot:.0f}%" for i in range(5)) + f"   avg cycles per segment {16 * tot / max(1, ph[13]):.0f}"
-          + f"\n         wave 0 inside the scan (cycles per segment): window setup {16 * ph[15] / max(1, ph[13]):.0f}, map + issue {16 * ph[16] / max(1, ph[13]):.0f}, "
-          f"wait {16 * ph[17] / max(1, ph[13]):.0f}, probe + emit {16 * ph[18] / max(1, ph[13]):.0f}; scan phase total {16 * ph[10] / max(1, ph[13]):.0f}")
+          + f"\n         wave 0 (cycles per segment): run streaming {16 * ph[15] / max(1, ph[13]):.0f}, short rows {16 * ph[16] / max(1, ph[13]):.0f}, "
+          f"barrier wait {16 * ph[10] / max(1, ph[13]):.0f}; bucket scan {16 * ph[17] / max(1, ph[13]):.0f}, rank {16 * ph[18] / max(1, ph[13]):.0f}, "
+          f"ticket wait {16 * ph[19] / max(1, ph[13]):.0f}, write-out {16 * ph[12] / max(1, ph[13]):.0f}")
     print(f"B={B:5d}: sample kernel {m:.3f} ms  {nn / 4 / m / 1e3:.0f} M nodes/s  neighbour ids scanned {slots / 4 * 4 / m / 1e6:.0f} GB/s  "
           f"({m / B * 1e3:.3f} us per subgraph)")

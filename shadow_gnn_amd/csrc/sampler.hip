@@ -864,18 +864,34 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
       uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", 512);
       if (T != 256 && T != 512 && T != 1024) T = 512;
-      const ScanLayout SL = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);
+      const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
+      // SHADOW_SG_SCAN_IMPL=window: the general (row-window) kernel for plain calls too (A/B measurements, tests)
+      const char *impl_env = getenv("SHADOW_SG_SCAN_IMPL");
+      const bool flat = plain && !(impl_env && !strcmp(impl_env, "window"));
+      p.run_cap = 0;
+      if (flat) {
+        // the run list takes what two workgroups per CU leave (one per CU when the filter alone is larger)
+        const size_t base = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 64u, 0).total + kHubCap * 32;
+        const size_t lim2 = (size_t)(160 * 1024) / 2 - 64;
+        const size_t lim = base + 128 * 16 <= lim2 ? lim2 : (size_t)160 * 1024 - 256;
+        if (base + 64 * 16 > lim) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", base);
+        p.run_cap = (uint32_t)std::min<size_t>(1024, (lim - base) / 16) & ~31u;
+        p.run_cap = std::max<uint32_t>(64, std::min<uint32_t>(p.run_cap, env_u32("SHADOW_SG_RUNCAP", 1024)));
+      }
+      const ScanLayout SL = flat ? scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 64u, p.run_cap)
+                                  : scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);
       if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));
       per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_SCAN_PER_CU", 8)));
       p.scan_grid = std::min<uint32_t>((uint32_t)ncu * per_cu, kScanGridMax);
       hipLaunchKernelGGL(sg_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
       SHD_HIP(hipGetLastError());
-      const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
-      const void *kfn = plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
+      const void *kfn = flat ? (const void *)sg_scan_plain_kernel
+                             : plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
       if (SL.total > 64 * 1024)
         SHD_HIP(ensure_dynamic_lds(kfn, SL.total));
-      if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      if (flat) hipLaunchKernelGGL(sg_scan_plain_kernel, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      else if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       SHD_HIP(hipGetLastError());
     }

@@ -68,10 +68,9 @@ __global__ void __launch_bounds__(1024) sg_plan_kernel(SampleParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 struct ScanLds {
   uint32_t *bits;    // [bit_words]
-  uint32_t *lkey;    // [capm] candidate list: 2*slot+kind
+  uint2 *lkn;        // [capm] candidate list: {key = 2*slot+kind, next entry of its bucket chain in the final sort} (one ds_read_b64 per chain step)
   uint32_t *lval;    // [capm] position of the neighbour in `indices` (kind 1: its id is fetched when the round resolves), later the column sub id
   uint32_t *lrow;    // [capm] row of the entry (+ its rank in the upper bits during the write-out)
-  uint32_t *lnext;   // [capm] bucket chains of the final sort
   uint32_t *bhead;   // [kSortBuckets]
   uint32_t *bcnt;    // [kSortBuckets]
   uint32_t *nodes;   // [nodes_lds] sorted node ids of the subgraph (when they fit)
@@ -82,22 +81,26 @@ struct ScanLds {
 
 constexpr uint32_t kWavePriv = 640;          // wave-private LDS: 64 start-position flags + 36 run records
 struct ScanLayout {
-  size_t bits, lkey, lval, lrow, lnext, bhead, bcnt, nodes, crow, wtmp, ctrl, total;
+  size_t bits, lkn, lval, lrow, bhead, bcnt, nodes, crow, wtmp, runs, hub, ctrl, total;
 };
 
-__host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t capm, uint32_t nodes_lds, uint32_t waves) {
+constexpr uint32_t kHubCap = 64;             // rows of a round whose runs are written by a whole wavefront
+// `wave_priv`: wave-private bytes per wavefront; `run_cap`: entries of the plain kernel's run list (0: none)
+__host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t capm, uint32_t nodes_lds, uint32_t waves,
+                                                  uint32_t wave_priv = kWavePriv, uint32_t run_cap = 0) {
   ScanLayout L;
   size_t o = 0;
   L.bits = o; o += (size_t)bit_words * 4;
-  L.lkey = o; o += r16((size_t)capm * 4);
+  L.lkn = o; o += r16((size_t)capm * 8);
   L.lval = o; o += r16((size_t)capm * 4);
   L.lrow = o; o += r16((size_t)capm * 4);
-  L.lnext = o; o += r16((size_t)capm * 4);
   L.bhead = o; o += kSortBuckets * 4;
   L.bcnt = o; o += kSortBuckets * 4;
   L.nodes = o; o += r16((size_t)nodes_lds * 4);
   L.crow = o; o += kMaxRoundChunks * 4;
-  L.wtmp = o; o += (size_t)waves * kWavePriv;
+  L.wtmp = o; o += (size_t)waves * wave_priv;
+  L.runs = o; o += (size_t)run_cap * 16;
+  L.hub = o; o += run_cap ? kHubCap * 32 : 0;
   L.ctrl = o; o += C_WORDS * 4;
   L.total = o;
   return L;
@@ -105,7 +108,7 @@ __host__ __device__ inline ScanLayout scan_layout(uint32_t bit_words, uint32_t c
 
 __device__ __forceinline__ void list_put(const ScanLds &t, uint32_t capm, uint32_t &r, uint32_t key, uint32_t val,
                                          uint32_t row) {
-  if (r < capm) { t.lkey[r] = key; t.lval[r] = val; t.lrow[r] = row; }
+  if (r < capm) { t.lkn[r].x = key; t.lval[r] = val; t.lrow[r] = row; }
   r++;
 }
 
@@ -184,7 +187,17 @@ __device__ __forceinline__ uint32_t probe1(const ScanLds &t, uint32_t id, uint32
   return __builtin_amdgcn_ubfe(w, id, 1u);
 }
 __device__ __forceinline__ uint32_t probe4(const ScanLds &t, const uint4 q, uint32_t bm4) {
-  return probe1(t, q.x, bm4) | (probe1(t, q.y, bm4) << 1) | (probe1(t, q.z, bm4) << 2) | (probe1(t, q.w, bm4) << 3);
+  // the four reads go out back to back, one wait (left to itself hipcc serialises them: read, wait, read, wait ...)
+  const uint32_t base = (uint32_t)(uintptr_t)t.bits;         // LDS byte offset of the filter (low half of the flat address)
+  // (the filter sits at LDS offset 0 -- first member of the layout, no static LDS in the scan kernels -- so `| base` = `+ base`
+  //  and the address is one v_and_or_b32)
+  const uint32_t a0 = ((q.x >> 3) & bm4) | base, a1 = ((q.y >> 3) & bm4) | base;
+  const uint32_t a2 = ((q.z >> 3) & bm4) | base, a3 = ((q.w >> 3) & bm4) | base;
+  uint32_t w0, w1, w2, w3;
+  asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+  return __builtin_amdgcn_ubfe(w0, q.x, 1u) | (__builtin_amdgcn_ubfe(w1, q.y, 1u) << 1) | (__builtin_amdgcn_ubfe(w2, q.z, 1u) << 2) |
+         (__builtin_amdgcn_ubfe(w3, q.w, 1u) << 3);
 }
 
 constexpr uint32_t kLongRow = 24;            // rows with at least this many quads left in the chunk are streamed alone
@@ -271,16 +284,154 @@ __device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// end of a round (both scan kernels): resolve the m candidates of the LDS list exactly, order the survivors by key,
+// append them to the subgraph's edge scratch, file the round record.  kFromPos: the list holds (position, row)
+// only and the key is derived here.
+// ---------------------------------------------------------------------------------------------------------------
+#define SCAN_T(k) do { if (threadIdx.x == 0) { const uint64_t now_ = clock64(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+template <bool kFromPos>
+__device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLds &t, uint32_t *ctrl, uint32_t m, uint32_t n,
+                                             bool nodes_in_lds, const uint32_t *g_nodes, const RowInfo *g_info,
+                                             const uint32_t *roots, bool itc, uint32_t *res, uint32_t *g_row, uint32_t *g_col,
+                                             uint32_t *g_eid, uint32_t s, uint32_t &rec_blk, uint32_t &rec_cnt, uint32_t *tacc,
+                                             uint64_t &tlast) {
+  const uint32_t tid = threadIdx.x, T = blockDim.x;
+  const uint32_t lane = lane_id(), wave = wave_id();
+  const uint32_t cape = p.cap_edges_scr;
+  const int R = p.R;
+  // ---- resolve the neighbour candidates exactly (.cpp:412-413), order the survivors by key
+  // (the keys of a round cover a narrow range: bucket on the offset from the round's smallest key, so that the
+  //  256 buckets spread over the round only)
+  for (uint32_t i = tid; i < kSortBuckets; i += T) { t.bhead[i] = kEmpty; t.bcnt[i] = 0; }
+  if (tid == 0) { ctrl[C_MV] = 0; ctrl[C_CHANGED] = 0xFFFFFFFFu; ctrl[C_MFAIL] = 0; }
+  __syncthreads();
+  uint32_t kmin_l = kEmpty, kmax_l = 0;
+  for (uint32_t i = tid; i < m; i += T) {
+    uint32_t key = kFromPos ? 1u : t.lkn[i].x;
+    if (key & 1u) {
+      const uint32_t pos = t.lval[i];
+      const uint32_t c = p.indices[pos];
+      uint4 riw = make_uint4(0u, 0u, 0u, 0u);
+      if (kFromPos) riw = *reinterpret_cast<const uint4 *>(g_info + t.lrow[i]);   // (issued with the id's load: one round trip)
+      uint32_t lo = 0, hi = n;
+      if (nodes_in_lds) {
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < c) lo = mid + 1; else hi = mid; }
+      } else {
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g_nodes[mid] < c) lo = mid + 1; else hi = mid; }
+      }
+      bool keep = lo < n && (nodes_in_lds ? t.nodes[lo] : g_nodes[lo]) == c;
+      if (keep && !itc && is_root(roots, R, c)) {
+        // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
+        const uint32_t rr = t.lrow[i];
+        keep = !is_root(roots, R, nodes_in_lds ? t.nodes[rr] : g_nodes[rr]);
+      }
+      if (keep && kFromPos) {
+        // the scan noted (position, row) only: key = 2 * slot + 1, slot = the row's slot prefix + offset in the row
+        key = 2u * (riw.z + (pos - riw.x)) + 1u;                   // RowInfo {e0, deg, rs, v}
+        t.lkn[i].x = key;
+      }
+      if (keep) t.lval[i] = lo;
+      else { key = kEmpty; t.lkn[i].x = kEmpty; }
+    } else {
+      t.lval[i] = t.lrow[i];                        // self edge: column = the row itself
+    }
+    kmin_l = min(kmin_l, key);                      // (kEmpty is the largest value)
+    if (key != kEmpty) kmax_l = max(kmax_l, key);
+  }
+  {
+    // one LDS atomic per wavefront, not per candidate
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      kmin_l = min(kmin_l, (uint32_t)__shfl_xor((int)kmin_l, off, 64));
+      kmax_l = max(kmax_l, (uint32_t)__shfl_xor((int)kmax_l, off, 64));
+    }
+    if (lane == 0 && kmin_l != kEmpty) { atomicMin(&ctrl[C_CHANGED], kmin_l); atomicMax(&ctrl[C_MFAIL], kmax_l); }
+  }
+  __syncthreads();
+  const uint32_t kmin = ctrl[C_CHANGED], kmax = ctrl[C_MFAIL];
+  uint32_t bshift = 0;
+  if (kmin != 0xFFFFFFFFu) { while (((kmax - kmin) >> bshift) >= kSortBuckets) bshift++; }
+  for (uint32_t i = tid; i < m; i += T) {
+    const uint32_t key = t.lkn[i].x;
+    if (key != kEmpty) {
+      const uint32_t b = (key - kmin) >> bshift;
+      atomicAdd(&t.bcnt[b], 1u);
+      t.lkn[i].y = atomicExch(&t.bhead[b], i);
+    }
+  }
+  __syncthreads();
+  SCAN_T(3);
+  // exclusive scan of the bucket counts (kSortBuckets = 256 = 4 per lane of wave 0); the survivors' place in the
+  // subgraph's edge scratch is reserved by ONE global atomic whose round trip overlaps the rank computation
+  uint32_t e_base_pending = 0;
+  if (wave == 0) {
+    uint32_t b4[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { b4[q] = t.bcnt[lane * 4 + q]; sum += b4[q]; }
+    const uint32_t incl = wave_incl_scan(sum);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { t.bcnt[lane * 4 + q] = run; run += b4[q]; }
+    if (lane == 63) {
+      ctrl[C_MV] = run;
+      e_base_pending = atomicAdd(&res[R_E], run);
+    }
+  }
+  __syncthreads();
+  SCAN_T(9);
+  for (uint32_t i = tid; i < m; i += T) {
+    const uint32_t key = t.lkn[i].x;
+    if (key == kEmpty) continue;
+    const uint32_t b = (key - kmin) >> bshift;
+    uint32_t r = t.bcnt[b];
+    for (uint32_t j = t.bhead[b]; j != kEmpty;) { const uint2 kn = t.lkn[j]; r += (kn.x < key) ? 1u : 0u; j = kn.y; }
+    t.lrow[i] |= r << kRankShift;
+  }
+  SCAN_T(10);
+  if (wave == 0 && lane == 63) ctrl[C_TICKET] = e_base_pending;
+  __syncthreads();
+  SCAN_T(11);
+  const uint32_t mv = ctrl[C_MV], e_base = ctrl[C_TICKET];
+  if (tid == 0) {
+    // file the round record
+    if (rec_cnt == kRecPerBlock) {
+      const uint32_t nb = atomicAdd(&p.plan[PL_POOL], 1u);
+      if (nb >= p.rec_blocks) { atomicOr(&p.plan[PL_FLAGS], 16u); }
+      else { p.blkinfo[rec_blk] = make_uint2(kRecPerBlock, nb); rec_blk = nb; rec_cnt = 0; }
+    }
+    if (rec_cnt < kRecPerBlock) {
+      RoundRec rr;
+      rr.s = s; rr.src_off = e_base; rr.cnt = mv; rr.pad = 0;
+      p.recs[(size_t)rec_blk * kRecPerBlock + rec_cnt] = rr;
+      rec_cnt++;
+    }
+  }
+  for (uint32_t i = tid; i < m; i += T) {
+    const uint32_t key = t.lkn[i].x;
+    if (key == kEmpty) continue;
+    const uint32_t rw_r = t.lrow[i];
+    const uint32_t rw = rw_r & ((1u << kRankShift) - 1u);
+    const uint32_t o = e_base + (rw_r >> kRankShift);
+    if (o < cape) {
+      g_row[o] = rw;
+      g_col[o] = t.lval[i];
+      uint32_t eid = 0xFFFFFFFFu;                                             // inserted self edge (.cpp:410)
+      if (key & 1u) { const RowInfo ri = g_info[rw]; eid = ri.e0 + ((key >> 1) - ri.rs); }   // .cpp:422
+      g_eid[o] = eid;
+    }
+  }
+}
+
 template <bool kPlain>
 __global__ void sg_scan_kernel(SampleParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ScanLayout L = scan_layout(p.bit_words, p.capm, p.nodes_lds, blockDim.x >> 6);
   ScanLds t;
   t.bits = (uint32_t *)(smem + L.bits);
-  t.lkey = (uint32_t *)(smem + L.lkey);
+  t.lkn = (uint2 *)(smem + L.lkn);
   t.lval = (uint32_t *)(smem + L.lval);
   t.lrow = (uint32_t *)(smem + L.lrow);
-  t.lnext = (uint32_t *)(smem + L.lnext);
   t.bhead = (uint32_t *)(smem + L.bhead);
   t.bcnt = (uint32_t *)(smem + L.bcnt);
   t.nodes = (uint32_t *)(smem + L.nodes);
@@ -304,7 +455,6 @@ __global__ void sg_scan_kernel(SampleParams p) {
 
   uint32_t tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // phase cycles of this workgroup (thread 0)
   uint64_t tlast = clock64();
-#define SCAN_T(k) do { if (tid == 0) { const uint64_t now_ = clock64(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
   // round records of this workgroup (thread 0 files them): block `blockIdx.x`, further blocks from the pool
   uint32_t rec_blk = blockIdx.x, rec_cnt = 0;
 
@@ -556,116 +706,8 @@ __global__ void sg_scan_kernel(SampleParams p) {
         __syncthreads();
         continue;
       }
-      // ---- resolve the neighbour candidates exactly (.cpp:412-413), order the survivors by key
-      // (the keys of a round cover a narrow range: bucket on the offset from the round's smallest key, so that the
-      //  256 buckets spread over the round only)
-      for (uint32_t i = tid; i < kSortBuckets; i += T) { t.bhead[i] = kEmpty; t.bcnt[i] = 0; }
-      if (tid == 0) { ctrl[C_MV] = 0; ctrl[C_CHANGED] = 0xFFFFFFFFu; ctrl[C_MFAIL] = 0; }
-      __syncthreads();
-      uint32_t kmin_l = kEmpty, kmax_l = 0;
-      for (uint32_t i = tid; i < m; i += T) {
-        uint32_t key = t.lkey[i];
-        if (key & 1u) {
-          const uint32_t c = p.indices[t.lval[i]];
-          uint32_t lo = 0, hi = n;
-          if (nodes_in_lds) {
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < c) lo = mid + 1; else hi = mid; }
-          } else {
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g_nodes[mid] < c) lo = mid + 1; else hi = mid; }
-          }
-          bool keep = lo < n && (nodes_in_lds ? t.nodes[lo] : g_nodes[lo]) == c;
-          if (keep && !itc && is_root(roots, R, c)) {
-            // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
-            const uint32_t rr = t.lrow[i];
-            keep = !is_root(roots, R, nodes_in_lds ? t.nodes[rr] : g_nodes[rr]);
-          }
-          if (keep) t.lval[i] = lo;
-          else { key = kEmpty; t.lkey[i] = kEmpty; }
-        } else {
-          t.lval[i] = t.lrow[i];                        // self edge: column = the row itself
-        }
-        kmin_l = min(kmin_l, key);                      // (kEmpty is the largest value)
-        if (key != kEmpty) kmax_l = max(kmax_l, key);
-      }
-      {
-        // one LDS atomic per wavefront, not per candidate
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          kmin_l = min(kmin_l, (uint32_t)__shfl_xor((int)kmin_l, off, 64));
-          kmax_l = max(kmax_l, (uint32_t)__shfl_xor((int)kmax_l, off, 64));
-        }
-        if (lane == 0 && kmin_l != kEmpty) { atomicMin(&ctrl[C_CHANGED], kmin_l); atomicMax(&ctrl[C_MFAIL], kmax_l); }
-      }
-      __syncthreads();
-      const uint32_t kmin = ctrl[C_CHANGED], kmax = ctrl[C_MFAIL];
-      uint32_t bshift = 0;
-      if (kmin != 0xFFFFFFFFu) { while (((kmax - kmin) >> bshift) >= kSortBuckets) bshift++; }
-      for (uint32_t i = tid; i < m; i += T) {
-        const uint32_t key = t.lkey[i];
-        if (key != kEmpty) {
-          const uint32_t b = (key - kmin) >> bshift;
-          atomicAdd(&t.bcnt[b], 1u);
-          t.lnext[i] = atomicExch(&t.bhead[b], i);
-        }
-      }
-      __syncthreads();
-      SCAN_T(3);
-      // exclusive scan of the bucket counts (kSortBuckets = 256 = 4 per lane of wave 0); the survivors' place in the
-      // subgraph's edge scratch is reserved by ONE global atomic whose round trip overlaps the rank computation
-      uint32_t e_base_pending = 0;
-      if (wave == 0) {
-        uint32_t b4[4], sum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { b4[q] = t.bcnt[lane * 4 + q]; sum += b4[q]; }
-        const uint32_t incl = wave_incl_scan(sum);
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { t.bcnt[lane * 4 + q] = run; run += b4[q]; }
-        if (lane == 63) {
-          ctrl[C_MV] = run;
-          e_base_pending = atomicAdd(&res[R_E], run);
-        }
-      }
-      __syncthreads();
-      for (uint32_t i = tid; i < m; i += T) {
-        const uint32_t key = t.lkey[i];
-        if (key == kEmpty) continue;
-        const uint32_t b = (key - kmin) >> bshift;
-        uint32_t r = t.bcnt[b];
-        for (uint32_t j = t.bhead[b]; j != kEmpty; j = t.lnext[j]) r += (t.lkey[j] < key) ? 1u : 0u;
-        t.lrow[i] |= r << kRankShift;
-      }
-      if (wave == 0 && lane == 63) ctrl[C_TICKET] = e_base_pending;
-      __syncthreads();
-      const uint32_t mv = ctrl[C_MV], e_base = ctrl[C_TICKET];
-      if (tid == 0) {
-        // file the round record
-        if (rec_cnt == kRecPerBlock) {
-          const uint32_t nb = atomicAdd(&p.plan[PL_POOL], 1u);
-          if (nb >= p.rec_blocks) { atomicOr(&p.plan[PL_FLAGS], 16u); }
-          else { p.blkinfo[rec_blk] = make_uint2(kRecPerBlock, nb); rec_blk = nb; rec_cnt = 0; }
-        }
-        if (rec_cnt < kRecPerBlock) {
-          RoundRec rr;
-          rr.s = s; rr.src_off = e_base; rr.cnt = mv; rr.pad = 0;
-          p.recs[(size_t)rec_blk * kRecPerBlock + rec_cnt] = rr;
-          rec_cnt++;
-        }
-      }
-      for (uint32_t i = tid; i < m; i += T) {
-        const uint32_t key = t.lkey[i];
-        if (key == kEmpty) continue;
-        const uint32_t rw_r = t.lrow[i];
-        const uint32_t rw = rw_r & ((1u << kRankShift) - 1u);
-        const uint32_t o = e_base + (rw_r >> kRankShift);
-        if (o < cape) {
-          g_row[o] = rw;
-          g_col[o] = t.lval[i];
-          uint32_t eid = 0xFFFFFFFFu;                                             // inserted self edge (.cpp:410)
-          if (key & 1u) { const RowInfo ri = g_info[rw]; eid = ri.e0 + ((key >> 1) - ri.rs); }   // .cpp:422
-          g_eid[o] = eid;
-        }
-      }
+      finish_round<false>(p, t, ctrl, m, n, nodes_in_lds, g_nodes, g_info, roots, itc, res, g_row, g_col, g_eid, s, rec_blk, rec_cnt,
+                          tacc, tlast);
       rq0 = rq1;
       __syncthreads();
       SCAN_T(4);
@@ -677,7 +719,304 @@ __global__ void sg_scan_kernel(SampleParams p) {
     p.blkinfo[rec_blk] = make_uint2(rec_cnt, 0xFFFFFFFFu);
     for (int i = 0; i < 12; i++) atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
   }
-#undef SCAN_T
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The plain scan (no self-edge insertion, no compat over-read, single root or include_target_conn): the benchmark's
+// case, built around ONE flat run list per round so that the streaming loop has no row logic in it.
+//
+//   A. one thread per row of the subgraph clips its quads to the round and counts its RUNS (<= 64 quads of one row;
+//      rows with fewer than kLongRow quads in the round are left to C); a block scan places them; every row writes
+//      its 16-byte run records {first id position, row | quads | edge flag, row begin, row end} into the LDS list
+//      (rows with many runs hand them to a whole wavefront).
+//   B. wavefront w streams runs w, w + nw, ...: eight 1-KiB loads are always in flight -- the loop is software
+//      pipelined in straight-line code (the load of run j + 8 is issued right after run j was probed; loads are never
+//      predicated or branched around, so the counted `s_waitcnt vmcnt(7)` the compiler derives is exact).  Lanes beyond
+//      a run's length re-read its first quad and are masked.  Found ids -- about one in a hundred -- are filed once
+//      per eight runs: one DPP scan + one LDS atomic per wavefront, entries (position, row).
+//   C. the rows with few quads: windows of 64 rows, their quads packed into shared 64-quad groups (as in the general
+//      kernel).
+//   D. finish_round<true>: ids fetched by position, exact membership, keys derived, bucket sort, write-out.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int C_NRUN = C_NNODES, C_NHUB = C_NF0;
+constexpr uint32_t kHubRuns = 8;             // rows with at least this many runs in the round are expanded by a wavefront
+#ifndef SHADOW_PLAIN_LONGROW
+#define SHADOW_PLAIN_LONGROW 24
+#endif
+constexpr uint32_t kPlainLongRow = SHADOW_PLAIN_LONGROW;   // rows with fewer quads in the round go to the packed pass
+constexpr int kDepth = 8;                    // 1-KiB loads a wavefront keeps in flight
+
+__device__ __forceinline__ uint4 make_run(const RowInfo ri, uint32_t row, uint32_t nq, uint32_t k0, uint32_t len, uint32_t g0) {
+  const uint32_t take = min(64u, len - g0);
+  const uint32_t kq = k0 + g0;
+  // every component is a neighbour unless the run holds the row's first / last quad
+  const uint32_t edge = ((kq == 0 && (ri.e0 & 3u)) || (kq + take == nq && ((ri.e0 + ri.deg) & 3u))) ? 1u : 0u;
+  return make_uint4(((ri.e0 >> 2) + kq) << 2, row | ((take - 1u) << 20) | (edge << 26), ri.e0, ri.e0 + ri.deg);
+}
+
+__global__ void sg_scan_plain_kernel(SampleParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ScanLayout L = scan_layout(p.bit_words, p.capm, p.nodes_lds, blockDim.x >> 6, 64u, p.run_cap);
+  ScanLds t;
+  t.bits = (uint32_t *)(smem + L.bits);
+  t.lkn = (uint2 *)(smem + L.lkn);
+  t.lval = (uint32_t *)(smem + L.lval);
+  t.lrow = (uint32_t *)(smem + L.lrow);
+  t.bhead = (uint32_t *)(smem + L.bhead);
+  t.bcnt = (uint32_t *)(smem + L.bcnt);
+  t.nodes = (uint32_t *)(smem + L.nodes);
+  t.crow = (uint32_t *)(smem + L.crow);
+  t.wtmp = smem + L.wtmp;
+  uint4 *runs = (uint4 *)(smem + L.runs);
+  uint4 *hub = (uint4 *)(smem + L.hub);
+  uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
+
+  const uint32_t tid = threadIdx.x, T = blockDim.x;
+  const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
+  const uint32_t bw_mask = p.bit_words - 1u, bm4 = bw_mask << 2;
+  const uint32_t capm = p.capm, cape = p.cap_edges_scr, run_cap = p.run_cap;
+  const int R = p.R;
+  const uint32_t C = p.plan[PL_NCHUNKS], cpw = p.plan[PL_CPW];
+  unsigned char *wflag = t.wtmp + wave * 64u;             // wave-private: 64 start-position flags (all zero between uses)
+  for (uint32_t i = tid; i < (T >> 6) * 16u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
+
+  uint32_t tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tlast = clock64();
+  uint32_t rec_blk = blockIdx.x, rec_cnt = 0;
+  ScanCtx cx;
+  cx.indices = p.indices; cx.nnz = p.nnz; cx.ctrl = ctrl; cx.bw_mask = bw_mask; cx.capm = capm;
+  cx.incl_self = false; cx.compat = false;
+
+  uint32_t g = blockIdx.x * cpw;
+  const uint32_t gend = min(C, g + cpw);
+  uint32_t s = (g < gend) ? find_span(p.cstart, p.P, g) : 0u;
+  while (g < gend) {
+    const uint32_t c0 = p.cstart[s], c1 = p.cstart[s + 1];
+    if (c1 <= g) { s++; continue; }
+    const uint32_t lc0 = g - c0, lc1 = min(c1, gend) - c0;
+    g = c0 + lc1;
+    tacc[5]++;
+    uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
+    const uint32_t n = res[R_N], Q = res[R_Q];
+    const uint32_t *roots = p.roots + (size_t)s * R;
+    const uint32_t *g_nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
+    const RowInfo *g_info = p.s_rowinfo + (size_t)s * p.cap_nodes_scr;
+    const uint32_t *g_rowq = p.s_rowq + (size_t)s * (p.cap_nodes_scr + 1);
+    uint32_t *g_row = p.s_row + (size_t)s * cape;
+    uint32_t *g_col = p.s_col + (size_t)s * cape;
+    uint32_t *g_eid = p.s_eid + (size_t)s * cape;
+    const bool nodes_in_lds = n <= p.nodes_lds;
+    const uint32_t iq0 = min(Q, lc0 * kQChunk);
+    const uint32_t iq1 = min(Q, lc1 * kQChunk);
+
+    // ---- per segment: the subgraph's membership filter (+ its sorted node list when it fits)
+    __syncthreads();
+    for (uint32_t w = tid; w < p.bit_words; w += T) t.bits[w] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += T) {
+      const uint32_t v = g_nodes[i];
+      atomicOr(&t.bits[(v >> 5) & bw_mask], 1u << (v & 31u));
+      if (nodes_in_lds) t.nodes[i] = v;
+    }
+
+    // runs of a round <= quads / 64 + rows with >= kLongRow quads: start with a round that fits for sure
+    uint32_t rq0 = iq0;
+    uint32_t rquads = min(kMaxRoundChunks, max(1u, (run_cap - min(n, run_cap / 2u)) / (kQChunk / 64u))) * kQChunk;
+    for (;;) {
+      const uint32_t rq1 = min(iq1, rq0 + rquads);
+      tacc[6]++;
+      SCAN_T(0);
+      if (tid == 0) { ctrl[C_M] = 0; ctrl[C_NHUB] = 0; }
+      __syncthreads();
+      // ---- A. the round's run list
+      uint32_t nrun = 0;
+      for (uint32_t base = 0; base < n; base += T) {
+        const uint32_t r = base + tid;
+        uint32_t nr = 0, len = 0, k0 = 0, nq = 0;
+        RowInfo ri;
+        ri.e0 = ri.deg = ri.rs = ri.v = 0;
+        if (r < n) {
+          const uint32_t qs = g_rowq[r], qe = g_rowq[r + 1];
+          ri = g_info[r];                                   // (with the two loads above: one round trip)
+          const uint32_t lo = max(qs, rq0), hi = min(qe, rq1);
+          if (hi > lo) { len = hi - lo; k0 = lo - qs; nq = qe - qs; if (len >= kPlainLongRow) nr = (len + 63u) >> 6; }
+        }
+        uint32_t tot;
+        const uint32_t first = nrun + block_excl_scan(nr, t.bhead, &tot);
+        nrun += tot;
+        if (nr && first + nr <= run_cap) {
+          uint32_t h = kHubCap;
+          if (nr >= kHubRuns) h = atomicAdd(&ctrl[C_NHUB], 1u);
+          if (h < kHubCap) { hub[2 * h] = make_uint4(r, first, k0, len); hub[2 * h + 1] = make_uint4(ri.e0, ri.deg, nq, 0u); }
+          else {
+            for (uint32_t g0 = 0, i = first; g0 < len; g0 += 64u, i++) runs[i] = make_run(ri, r, nq, k0, len, g0);
+          }
+        }
+      }
+      __syncthreads();
+      if (nrun > run_cap) {
+        // (cannot happen for a single chunk: 8 + 512 / kLongRow runs at most)
+        rquads = max((rq1 - rq0) / 2u, kQChunk);
+        __syncthreads();
+        continue;
+      }
+      {
+        const uint32_t nhub = min(ctrl[C_NHUB], kHubCap);
+        for (uint32_t h = wave; h < nhub; h += nw) {
+          const uint4 hb = hub[2 * h], hr = hub[2 * h + 1];
+          RowInfo ri;
+          ri.e0 = hr.x; ri.deg = hr.y; ri.rs = 0; ri.v = 0;
+          const uint32_t nq = hr.z;
+          for (uint32_t j = lane; j * 64u < hb.w; j += 64u) runs[hb.y + j] = make_run(ri, hb.x, nq, hb.z, hb.w, j * 64u);
+        }
+      }
+      __syncthreads();
+      SCAN_T(1);
+
+      // ---- B. stream the runs: wavefront w takes runs w, w + nw, ...
+      if (wave < nrun) {
+        const uint32_t J = (nrun - wave + nw - 1u) / nw;
+        uint4 q[kDepth];
+        uint32_t r_meta[kDepth], r_e0[kDepth], r_e1[kDepth], r_a0[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; u++) {
+          const uint32_t i = wave + (uint32_t)u * nw;
+          const uint4 rc = runs[min(i, nrun - 1u)];
+          r_a0[u] = rl_first(rc.x); r_e0[u] = rl_first(rc.z); r_e1[u] = rl_first(rc.w);
+          r_meta[u] = rl_first(i < nrun ? rc.y : 0xFFFFFFFFu);                        // (all ones: no such run)
+          const uint32_t tk = r_meta[u] == 0xFFFFFFFFu ? 0u : (r_meta[u] >> 20) & 63u;
+          q[u] = *reinterpret_cast<const uint4 *>(p.indices + r_a0[u] + 4u * min(lane, tk));
+          __builtin_amdgcn_sched_barrier(0);                  // (keep the slots in issue order: the counted waits below rely on it)
+        }
+        for (uint32_t j0 = 0; j0 < J; j0 += kDepth) {
+          uint32_t hm = 0;
+#pragma unroll
+          for (int u = 0; u < kDepth; u++) {
+            // consume run j0 + u ...
+            const uint32_t meta = r_meta[u];
+            uint32_t h = probe4(t, q[u], bm4);
+            const uint32_t tk = (meta >> 20) & 63u;
+            if (meta == 0xFFFFFFFFu) h = 0;
+            else if (tk != 63u || (meta & (1u << 26))) {
+              // an end of the row inside the run, or lanes beyond its length: components [lo, hi) of my quad are the row's
+              const uint32_t i0 = r_a0[u] + 4u * min(lane, tk);
+              const int lo = min(max((int)(r_e0[u] - i0), 0), 4), hi = min(max((int)(r_e1[u] - i0), 0), 4);
+              uint32_t vm = (0xFu << lo) & ~(0xFu << hi) & 0xFu;
+              if (lane > tk) vm = 0;
+              h &= vm;
+            }
+            hm |= h << (4 * u);
+            // ... and put run j0 + u + kDepth in its place
+            const uint32_t i2 = wave + (j0 + (uint32_t)u + kDepth) * nw;
+            const uint4 rc = runs[min(i2, nrun - 1u)];
+            r_a0[u] = rl_first(rc.x); r_e0[u] = rl_first(rc.z); r_e1[u] = rl_first(rc.w);
+            r_meta[u] = rl_first(i2 < nrun ? rc.y : 0xFFFFFFFFu);
+            const uint32_t tk2 = r_meta[u] == 0xFFFFFFFFu ? 0u : (r_meta[u] >> 20) & 63u;
+            q[u] = *reinterpret_cast<const uint4 *>(p.indices + r_a0[u] + 4u * min(lane, tk2));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const uint32_t cnt = (uint32_t)__popc(hm);
+          if (__ballot(cnt != 0)) {
+            const uint32_t incl = wave_incl_scan(cnt);
+            uint32_t basev = 0;
+            if (lane == 63) basev = atomicAdd(&ctrl[C_M], incl);
+            uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)basev, 63) + incl - cnt;
+            while (hm) {
+              const uint32_t b = (uint32_t)__ffs((int)hm) - 1u;
+              hm &= hm - 1u;
+              const uint4 d = runs[wave + (j0 + (b >> 2)) * nw];
+              if (r < capm) { t.lval[r] = d.x + 4u * lane + (b & 3u); t.lrow[r] = d.y & ((1u << kRankShift) - 1u); }   // .cpp:420-422
+              r++;
+            }
+          }
+        }
+      }
+      SCAN_T(7);
+      // ---- C. rows with few quads in the round, packed: the rows flag the packed position they start on, the positions
+      //      read the flags back and fill forward (DPP max-scan), lane gathers fetch the row's scalars
+      for (uint32_t wb = wave * 64u; wb < n; wb += nw * 64u) {
+        const uint32_t r = wb + lane;
+        uint32_t w_len = 0, w_k0 = 0;
+        if (r < n) {
+          const uint32_t qs = g_rowq[r], qe = g_rowq[r + 1];
+          const uint32_t lo = max(qs, rq0), hi = min(qe, rq1);
+          if (hi > lo && hi - lo < kPlainLongRow) { w_len = hi - lo; w_k0 = lo - qs; }
+        }
+        if (!__ballot(w_len != 0)) continue;
+        const uint4 wcur = win_fetch(g_info, wb, n);
+        const uint32_t w_e0 = wcur.x, w_deg = wcur.y, w_rs = wcur.z;
+        const bool shortrow = w_len != 0;
+        const uint32_t tincl = wave_incl_scan(w_len);
+        const uint32_t tq = tincl - w_len;
+        const uint32_t ttot = (uint32_t)__builtin_amdgcn_readlane((int)tincl, 63);
+        // groups of 64 packed quads, kPack loads in flight (same straight-line pipelining as B; a lane without a quad
+        // re-reads the window's first quad with degree 0, i.e. fully masked)
+        constexpr int kPack = 4;
+        uint4 q[kPack];
+        uint32_t g_a[kPack], g_e0[kPack], g_deg[kPack], g_rs[kPack], g_rl[kPack];
+        const uint32_t a_dummy = (rl_first(w_e0) >> 2) << 2;
+        auto issue = [&](int u, uint32_t p0) {
+          const uint32_t take = p0 < ttot ? min(64u, ttot - p0) : 0u;
+          const bool starts = shortrow && tq > p0 && tq < p0 + take;
+          if (starts) wflag[tq - p0] = (unsigned char)(lane + 1u);
+          __builtin_amdgcn_wave_barrier();
+          uint32_t rl = wflag[lane];
+          __builtin_amdgcn_wave_barrier();
+          if (starts) wflag[tq - p0] = 0;
+          const uint64_t before = __ballot(shortrow && tq <= p0);
+          const uint32_t f0 = 63u - (uint32_t)__builtin_clzll((unsigned long long)(before | 1ull));   // row that holds p0
+          if (lane == 0) rl = f0 + 1u;
+          rl = wave_incl_max_scan(rl) - 1u;                              // lane of the window that owns my position
+          const uint32_t e0 = lane_get(w_e0, rl), rtq = lane_get(tq, rl), rk0 = lane_get(w_k0, rl);
+          const uint32_t kq = rk0 + (p0 + lane - rtq);                   // quad index inside the row
+          const bool have = lane < take;
+          g_a[u] = have ? ((e0 >> 2) + kq) << 2 : a_dummy;
+          g_e0[u] = e0; g_rl[u] = rl;
+          const uint32_t dg = lane_get(w_deg, rl);                        // (all lanes take part: the owner lane may hold no quad)
+          g_deg[u] = have ? dg : 0u;
+          g_rs[u] = lane_get(w_rs, rl);
+          q[u] = *reinterpret_cast<const uint4 *>(p.indices + g_a[u]);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int u = 0; u < kPack; u++) issue(u, (uint32_t)u * 64u);
+        for (uint32_t p0 = 0; p0 < ttot; p0 += kPack * 64u) {
+#pragma unroll
+          for (int u = 0; u < kPack; u++) {
+            process_group<true>(cx, t, q[u], g_a[u] - g_e0[u], g_deg[u], g_rs[u], wb + g_rl[u], 0u, g_e0[u], 0u, false, 1u);
+            issue(u, p0 + (uint32_t)(u + kPack) * 64u);
+          }
+        }
+      }
+      SCAN_T(8);
+      __syncthreads();
+      SCAN_T(2);
+      const uint32_t m = ctrl[C_M];
+      if (m > capm) {
+        // too many candidates for the list: redo this round on half the quads
+        if (rq1 - rq0 <= 64u) {
+          if (tid == 0) atomicOr(&res[R_FLAGS], 2u);
+          break;
+        }
+        rquads = max((rq1 - rq0) / 2u, 64u);
+        __syncthreads();
+        continue;
+      }
+      finish_round<true>(p, t, ctrl, m, n, nodes_in_lds, g_nodes, g_info, roots, true, res, g_row, g_col, g_eid, s, rec_blk, rec_cnt,
+                         tacc, tlast);
+      rq0 = rq1;
+      __syncthreads();
+      SCAN_T(4);
+      if (rq0 >= iq1) break;
+    }
+    s++;
+  }
+  if (tid == 0) {
+    p.blkinfo[rec_blk] = make_uint2(rec_cnt, 0xFFFFFFFFu);
+    for (int i = 0; i < 12; i++) atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
+  }
+}
+
+#undef SCAN_T
 
 }  // namespace shadow
