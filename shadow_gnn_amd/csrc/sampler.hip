@@ -869,16 +869,17 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       const char *impl_env = getenv("SHADOW_SG_SCAN_IMPL");
       const bool flat = plain && !(impl_env && !strcmp(impl_env, "window"));
       p.run_cap = 0;
+      p.seg_pad = std::min<uint32_t>(256, env_u32("SHADOW_SG_SEG_PAD", 25) - 1);   // (env value = pad + 1: 1 means none; default 24, scripts/sweep_seg_pad.sh)
       if (flat) {
         // the run list takes what two workgroups per CU leave (one per CU when the filter alone is larger)
-        const size_t base = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 64u, 0).total + kHubCap * 32;
+        const size_t base = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, 0).total + kHubCap * 32;
         const size_t lim2 = (size_t)(160 * 1024) / 2 - 64;
         const size_t lim = base + 128 * 16 <= lim2 ? lim2 : (size_t)160 * 1024 - 256;
         if (base + 64 * 16 > lim) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", base);
         p.run_cap = (uint32_t)std::min<size_t>(1024, (lim - base) / 16) & ~31u;
         p.run_cap = std::max<uint32_t>(64, std::min<uint32_t>(p.run_cap, env_u32("SHADOW_SG_RUNCAP", 1024)));
       }
-      const ScanLayout SL = flat ? scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 64u, p.run_cap)
+      const ScanLayout SL = flat ? scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, p.run_cap)
                                   : scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);
       if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));

@@ -89,6 +89,7 @@ struct SampleParams {
   uint32_t bit_words; // membership filter size in words (power of two)
   uint32_t nodes_lds; // node ids of subgraphs up to this size are kept in LDS for the candidate resolution
   uint32_t run_cap;   // entries of the plain scan kernel's LDS run list
+  uint32_t seg_pad;   // chunks' worth of work a subgraph segment costs a scan workgroup before it streams anything
   // per-subgraph scratch (stride = cap_nodes_scr / cap_edges_scr)
   uint32_t cap_nodes_scr, cap_edges_scr;
   uint32_t *s_nodes;   // [P*cap_nodes_scr] sorted node ids

@@ -46,7 +46,9 @@ __global__ void __launch_bounds__(1024) sg_plan_kernel(SampleParams p) {
     if (s < p.P) {
       const uint32_t *c = p.s_cnt + (size_t)s * R_WORDS;
       // (a subgraph without any neighbour still owns one chunk: its rows' sentinel slots are handled there)
-      if (!(c[R_FLAGS] & 1u)) ch = max(1u, (c[R_Q] + kQChunk - 1u) / kQChunk);
+      // + seg_pad virtual chunks in front: the span partition then balances bytes AND the per-segment fixed work
+      // (filter build, run list, candidate sort -- worth about as much as streaming two dozen chunks)
+      if (!(c[R_FLAGS] & 1u)) ch = max(1u, (c[R_Q] + kQChunk - 1u) / kQChunk) + p.seg_pad;
     }
     uint32_t tot;
     const uint32_t ex = block_excl_scan(ch, wsum, &tot);
@@ -303,41 +305,60 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
   // ---- resolve the neighbour candidates exactly (.cpp:412-413), order the survivors by key
   // (the keys of a round cover a narrow range: bucket on the offset from the round's smallest key, so that the
   //  256 buckets spread over the round only)
-  for (uint32_t i = tid; i < kSortBuckets; i += T) { t.bhead[i] = kEmpty; t.bcnt[i] = 0; }
+  for (uint32_t i = tid; i < kSortBuckets; i += T) { t.bhead[i] = 0; t.bcnt[i] = 0; }
   if (tid == 0) { ctrl[C_MV] = 0; ctrl[C_CHANGED] = 0xFFFFFFFFu; ctrl[C_MFAIL] = 0; }
   __syncthreads();
-  uint32_t kmin_l = kEmpty, kmax_l = 0;
-  for (uint32_t i = tid; i < m; i += T) {
-    uint32_t key = kFromPos ? 1u : t.lkn[i].x;
-    if (key & 1u) {
-      const uint32_t pos = t.lval[i];
-      const uint32_t c = p.indices[pos];
-      uint4 riw = make_uint4(0u, 0u, 0u, 0u);
-      if (kFromPos) riw = *reinterpret_cast<const uint4 *>(g_info + t.lrow[i]);   // (issued with the id's load: one round trip)
-      uint32_t lo = 0, hi = n;
-      if (nodes_in_lds) {
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < c) lo = mid + 1; else hi = mid; }
-      } else {
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g_nodes[mid] < c) lo = mid + 1; else hi = mid; }
+  uint32_t kmin_l = kEmpty, kmax_l = 0, alive = 0;
+  for (uint32_t i0 = tid; i0 < m; i0 += 2u * T) {
+    // two entries per pass: their global loads (the id at its position, the row record) share one round trip
+    const uint32_t idx[2] = {i0, i0 + T};
+    const bool ok[2] = {true, i0 + T < m};
+    uint32_t key[2], pos[2] = {0, 0}, c[2] = {0, 0};
+    uint4 riw[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      key[e] = 0; riw[e] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok[e]) {
+        key[e] = kFromPos ? 1u : t.lkn[idx[e]].x;
+        if (key[e] & 1u) {
+          pos[e] = t.lval[idx[e]];
+          c[e] = p.indices[pos[e]];
+          if (kFromPos) riw[e] = *reinterpret_cast<const uint4 *>(g_info + t.lrow[idx[e]]);
+        }
       }
-      bool keep = lo < n && (nodes_in_lds ? t.nodes[lo] : g_nodes[lo]) == c;
-      if (keep && !itc && is_root(roots, R, c)) {
-        // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
-        const uint32_t rr = t.lrow[i];
-        keep = !is_root(roots, R, nodes_in_lds ? t.nodes[rr] : g_nodes[rr]);
-      }
-      if (keep && kFromPos) {
-        // the scan noted (position, row) only: key = 2 * slot + 1, slot = the row's slot prefix + offset in the row
-        key = 2u * (riw.z + (pos - riw.x)) + 1u;                   // RowInfo {e0, deg, rs, v}
-        t.lkn[i].x = key;
-      }
-      if (keep) t.lval[i] = lo;
-      else { key = kEmpty; t.lkn[i].x = kEmpty; }
-    } else {
-      t.lval[i] = t.lrow[i];                        // self edge: column = the row itself
     }
-    kmin_l = min(kmin_l, key);                      // (kEmpty is the largest value)
-    if (key != kEmpty) kmax_l = max(kmax_l, key);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      if (!ok[e]) continue;
+      const uint32_t i = idx[e];
+      uint32_t k = key[e];
+      if (k & 1u) {
+        const uint32_t cc = c[e];
+        uint32_t lo = 0, hi = n;
+        if (nodes_in_lds) {
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < cc) lo = mid + 1; else hi = mid; }
+        } else {
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g_nodes[mid] < cc) lo = mid + 1; else hi = mid; }
+        }
+        bool keep = lo < n && (nodes_in_lds ? t.nodes[lo] : g_nodes[lo]) == cc;
+        if (keep && !itc && is_root(roots, R, cc)) {
+          // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
+          const uint32_t rr = t.lrow[i];
+          keep = !is_root(roots, R, nodes_in_lds ? t.nodes[rr] : g_nodes[rr]);
+        }
+        if (keep && kFromPos) {
+          // the scan noted (position, row) only: key = 2 * slot + 1, slot = the row's slot prefix + offset in the row
+          k = 2u * (riw[e].z + (pos[e] - riw[e].x)) + 1u;            // RowInfo {e0, deg, rs, v}
+          t.lkn[i].x = k;
+        }
+        if (keep) t.lval[i] = lo;
+        else { k = kEmpty; t.lkn[i].x = kEmpty; }
+      } else {
+        t.lval[i] = t.lrow[i];                        // self edge: column = the row itself
+      }
+      kmin_l = min(kmin_l, k);                        // (kEmpty is the largest value)
+      if (k != kEmpty) { kmax_l = max(kmax_l, k); alive++; }
+    }
   }
   {
     // one LDS atomic per wavefront, not per candidate
@@ -346,53 +367,56 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
       kmin_l = min(kmin_l, (uint32_t)__shfl_xor((int)kmin_l, off, 64));
       kmax_l = max(kmax_l, (uint32_t)__shfl_xor((int)kmax_l, off, 64));
     }
-    if (lane == 0 && kmin_l != kEmpty) { atomicMin(&ctrl[C_CHANGED], kmin_l); atomicMax(&ctrl[C_MFAIL], kmax_l); }
+    alive = wave_reduce_sum(alive);
+    if (lane == 0 && kmin_l != kEmpty) { atomicMin(&ctrl[C_CHANGED], kmin_l); atomicMax(&ctrl[C_MFAIL], kmax_l); atomicAdd(&ctrl[C_MV], alive); }
   }
   __syncthreads();
-  const uint32_t kmin = ctrl[C_CHANGED], kmax = ctrl[C_MFAIL];
+  const uint32_t kmin = ctrl[C_CHANGED], kmax = ctrl[C_MFAIL], mv = ctrl[C_MV];
+  // the survivors' place in the subgraph's edge scratch: ONE global atomic, its round trip hidden behind the sort
+  uint32_t e_base_pending = 0;
+  if (tid == 0) e_base_pending = atomicAdd(&res[R_E], mv);
   uint32_t bshift = 0;
   if (kmin != 0xFFFFFFFFu) { while (((kmax - kmin) >> bshift) >= kSortBuckets) bshift++; }
+  // counting sort, pass 1: bucket sizes; every survivor keeps its ordinal inside its bucket (upper bits of its row word)
   for (uint32_t i = tid; i < m; i += T) {
     const uint32_t key = t.lkn[i].x;
-    if (key != kEmpty) {
-      const uint32_t b = (key - kmin) >> bshift;
-      atomicAdd(&t.bcnt[b], 1u);
-      t.lkn[i].y = atomicExch(&t.bhead[b], i);
-    }
+    if (key != kEmpty) t.lrow[i] |= atomicAdd(&t.bhead[(key - kmin) >> bshift], 1u) << kRankShift;
   }
   __syncthreads();
   SCAN_T(3);
-  // exclusive scan of the bucket counts (kSortBuckets = 256 = 4 per lane of wave 0); the survivors' place in the
-  // subgraph's edge scratch is reserved by ONE global atomic whose round trip overlaps the rank computation
-  uint32_t e_base_pending = 0;
+  // exclusive scan of the bucket sizes (kSortBuckets = 256 = 4 per lane of wave 0): bcnt = first place of the bucket
   if (wave == 0) {
     uint32_t b4[4], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { b4[q] = t.bcnt[lane * 4 + q]; sum += b4[q]; }
+    for (int q = 0; q < 4; q++) { b4[q] = t.bhead[lane * 4 + q]; sum += b4[q]; }
     const uint32_t incl = wave_incl_scan(sum);
     uint32_t run = incl - sum;
 #pragma unroll
     for (int q = 0; q < 4; q++) { t.bcnt[lane * 4 + q] = run; run += b4[q]; }
-    if (lane == 63) {
-      ctrl[C_MV] = run;
-      e_base_pending = atomicAdd(&res[R_E], run);
-    }
+  }
+  __syncthreads();
+  // pass 2: the keys, bucket by bucket, into the second word of the list entries (any order inside a bucket)
+  for (uint32_t i = tid; i < m; i += T) {
+    const uint32_t key = t.lkn[i].x;
+    if (key != kEmpty) t.lkn[t.bcnt[(key - kmin) >> bshift] + (t.lrow[i] >> kRankShift)].y = key;
   }
   __syncthreads();
   SCAN_T(9);
+  // rank = first place of the bucket + smaller keys inside it: consecutive LDS words, no dependent chain
   for (uint32_t i = tid; i < m; i += T) {
     const uint32_t key = t.lkn[i].x;
     if (key == kEmpty) continue;
     const uint32_t b = (key - kmin) >> bshift;
-    uint32_t r = t.bcnt[b];
-    for (uint32_t j = t.bhead[b]; j != kEmpty;) { const uint2 kn = t.lkn[j]; r += (kn.x < key) ? 1u : 0u; j = kn.y; }
-    t.lrow[i] |= r << kRankShift;
+    const uint32_t base = t.bcnt[b], cnt = t.bhead[b];
+    uint32_t r = base;
+    for (uint32_t j = 0; j < cnt; j++) r += (t.lkn[base + j].y < key) ? 1u : 0u;
+    t.lrow[i] = (t.lrow[i] & ((1u << kRankShift) - 1u)) | (r << kRankShift);
   }
   SCAN_T(10);
-  if (wave == 0 && lane == 63) ctrl[C_TICKET] = e_base_pending;
+  if (tid == 0) ctrl[C_TICKET] = e_base_pending;
   __syncthreads();
   SCAN_T(11);
-  const uint32_t mv = ctrl[C_MV], e_base = ctrl[C_TICKET];
+  const uint32_t e_base = ctrl[C_TICKET];
   if (tid == 0) {
     // file the round record
     if (rec_cnt == kRecPerBlock) {
@@ -464,8 +488,10 @@ __global__ void sg_scan_kernel(SampleParams p) {
   while (g < gend) {
     const uint32_t c0 = p.cstart[s], c1 = p.cstart[s + 1];
     if (c1 <= g) { s++; continue; }                       // (subgraphs the selection flagged own no chunk)
-    const uint32_t lc0 = g - c0, lc1 = min(c1, gend) - c0;   // this workgroup's chunks of subgraph s
-    g = c0 + lc1;
+    const uint32_t vc0 = g - c0, vc1 = min(c1, gend) - c0;   // this workgroup's (virtual) chunks of subgraph s
+    g = c0 + vc1;
+    if (vc1 <= p.seg_pad) { s++; continue; }                 // only padding: the next workgroup starts the subgraph
+    const uint32_t lc0 = vc0 > p.seg_pad ? vc0 - p.seg_pad : 0u, lc1 = vc1 - p.seg_pad;
     tacc[5]++;
     uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
     const uint32_t n = res[R_N], Q = res[R_Q];
@@ -725,25 +751,22 @@ __global__ void sg_scan_kernel(SampleParams p) {
 // The plain scan (no self-edge insertion, no compat over-read, single root or include_target_conn): the benchmark's
 // case, built around ONE flat run list per round so that the streaming loop has no row logic in it.
 //
-//   A. one thread per row of the subgraph clips its quads to the round and counts its RUNS (<= 64 quads of one row;
-//      rows with fewer than kLongRow quads in the round are left to C); a block scan places them; every row writes
-//      its 16-byte run records {first id position, row | quads | edge flag, row begin, row end} into the LDS list
-//      (rows with many runs hand them to a whole wavefront).
+//   A. one thread per row of the subgraph clips its quads to the round and counts its RUNS (<= 64 quads of one row); a
+//      block scan places them; every row writes its 16-byte run records {first id position, row | quads | edge flag,
+//      row begin, row end} into the LDS list (rows with many runs hand them to a whole wavefront).
 //   B. wavefront w streams runs w, w + nw, ...: eight 1-KiB loads are always in flight -- the loop is software
 //      pipelined in straight-line code (the load of run j + 8 is issued right after run j was probed; loads are never
-//      predicated or branched around, so the counted `s_waitcnt vmcnt(7)` the compiler derives is exact).  Lanes beyond
-//      a run's length re-read its first quad and are masked.  Found ids -- about one in a hundred -- are filed once
-//      per eight runs: one DPP scan + one LDS atomic per wavefront, entries (position, row).
-//   C. the rows with few quads: windows of 64 rows, their quads packed into shared 64-quad groups (as in the general
-//      kernel).
-//   D. finish_round<true>: ids fetched by position, exact membership, keys derived, bucket sort, write-out.
+//      predicated or branched around, so the counted `s_waitcnt vmcnt(7)` the compiler derives is exact; scheduling
+//      barriers keep the slots in issue order).  Lanes beyond a run's length re-read its last quad and are masked, so a
+//      short row costs one instruction slot but only its own cache lines.  Found ids -- about one in a hundred -- are
+//      filed once per eight runs: one DPP scan + one LDS atomic per wavefront, entries (position, row).
+//   C. finish_round<true>: ids fetched by position, exact membership, keys derived, bucket sort, write-out.
+//
+// Measured against the row-window kernel above on the same box (scripts/ab_scan.sh, products shape): 0.193 vs 0.257 ms
+// at 1 024 roots, 0.995 vs 1.135 ms at 8 192; arxiv shape (rows of ~3 quads) 0.100 vs 0.143 ms at 256 roots.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int C_NRUN = C_NNODES, C_NHUB = C_NF0;
 constexpr uint32_t kHubRuns = 8;             // rows with at least this many runs in the round are expanded by a wavefront
-#ifndef SHADOW_PLAIN_LONGROW
-#define SHADOW_PLAIN_LONGROW 24
-#endif
-constexpr uint32_t kPlainLongRow = SHADOW_PLAIN_LONGROW;   // rows with fewer quads in the round go to the packed pass
 constexpr int kDepth = 8;                    // 1-KiB loads a wavefront keeps in flight
 
 __device__ __forceinline__ uint4 make_run(const RowInfo ri, uint32_t row, uint32_t nq, uint32_t k0, uint32_t len, uint32_t g0) {
@@ -756,7 +779,7 @@ __device__ __forceinline__ uint4 make_run(const RowInfo ri, uint32_t row, uint32
 
 __global__ void sg_scan_plain_kernel(SampleParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const ScanLayout L = scan_layout(p.bit_words, p.capm, p.nodes_lds, blockDim.x >> 6, 64u, p.run_cap);
+  const ScanLayout L = scan_layout(p.bit_words, p.capm, p.nodes_lds, blockDim.x >> 6, 0u, p.run_cap);
   ScanLds t;
   t.bits = (uint32_t *)(smem + L.bits);
   t.lkn = (uint2 *)(smem + L.lkn);
@@ -777,15 +800,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
   const uint32_t capm = p.capm, cape = p.cap_edges_scr, run_cap = p.run_cap;
   const int R = p.R;
   const uint32_t C = p.plan[PL_NCHUNKS], cpw = p.plan[PL_CPW];
-  unsigned char *wflag = t.wtmp + wave * 64u;             // wave-private: 64 start-position flags (all zero between uses)
-  for (uint32_t i = tid; i < (T >> 6) * 16u; i += T) reinterpret_cast<uint32_t *>(t.wtmp)[i] = 0;
 
   uint32_t tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tlast = clock64();
   uint32_t rec_blk = blockIdx.x, rec_cnt = 0;
-  ScanCtx cx;
-  cx.indices = p.indices; cx.nnz = p.nnz; cx.ctrl = ctrl; cx.bw_mask = bw_mask; cx.capm = capm;
-  cx.incl_self = false; cx.compat = false;
 
   uint32_t g = blockIdx.x * cpw;
   const uint32_t gend = min(C, g + cpw);
@@ -793,8 +811,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
   while (g < gend) {
     const uint32_t c0 = p.cstart[s], c1 = p.cstart[s + 1];
     if (c1 <= g) { s++; continue; }
-    const uint32_t lc0 = g - c0, lc1 = min(c1, gend) - c0;
-    g = c0 + lc1;
+    const uint32_t vc0 = g - c0, vc1 = min(c1, gend) - c0;   // this workgroup's (virtual) chunks of subgraph s
+    g = c0 + vc1;
+    if (vc1 <= p.seg_pad) { s++; continue; }                 // only padding: the next workgroup starts the subgraph
+    const uint32_t lc0 = vc0 > p.seg_pad ? vc0 - p.seg_pad : 0u, lc1 = vc1 - p.seg_pad;
     tacc[5]++;
     uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
     const uint32_t n = res[R_N], Q = res[R_Q];
@@ -813,6 +833,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
     __syncthreads();
     for (uint32_t w = tid; w < p.bit_words; w += T) t.bits[w] = 0;
     __syncthreads();
+    // (the row data phase A needs for this thread's first row rides on the same round trip as the node ids)
+    uint32_t pre_qs = 0, pre_qe = 0;
+    uint4 pre_ri = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < n) { pre_qs = g_rowq[tid]; pre_qe = g_rowq[tid + 1]; pre_ri = *reinterpret_cast<const uint4 *>(g_info + tid); }
     for (uint32_t i = tid; i < n; i += T) {
       const uint32_t v = g_nodes[i];
       atomicOr(&t.bits[(v >> 5) & bw_mask], 1u << (v & 31u));
@@ -836,10 +860,12 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
         RowInfo ri;
         ri.e0 = ri.deg = ri.rs = ri.v = 0;
         if (r < n) {
-          const uint32_t qs = g_rowq[r], qe = g_rowq[r + 1];
-          ri = g_info[r];                                   // (with the two loads above: one round trip)
+          uint32_t qs = pre_qs, qe = pre_qe;
+          uint4 riw = pre_ri;
+          if (base != 0) { qs = g_rowq[r]; qe = g_rowq[r + 1]; riw = *reinterpret_cast<const uint4 *>(g_info + r); }
+          ri.e0 = riw.x; ri.deg = riw.y; ri.rs = riw.z; ri.v = riw.w;
           const uint32_t lo = max(qs, rq0), hi = min(qe, rq1);
-          if (hi > lo) { len = hi - lo; k0 = lo - qs; nq = qe - qs; if (len >= kPlainLongRow) nr = (len + 63u) >> 6; }
+          if (hi > lo) { len = hi - lo; k0 = lo - qs; nq = qe - qs; nr = (len + 63u) >> 6; }
         }
         uint32_t tot;
         const uint32_t first = nrun + block_excl_scan(nr, t.bhead, &tot);
@@ -932,63 +958,6 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
         }
       }
       SCAN_T(7);
-      // ---- C. rows with few quads in the round, packed: the rows flag the packed position they start on, the positions
-      //      read the flags back and fill forward (DPP max-scan), lane gathers fetch the row's scalars
-      for (uint32_t wb = wave * 64u; wb < n; wb += nw * 64u) {
-        const uint32_t r = wb + lane;
-        uint32_t w_len = 0, w_k0 = 0;
-        if (r < n) {
-          const uint32_t qs = g_rowq[r], qe = g_rowq[r + 1];
-          const uint32_t lo = max(qs, rq0), hi = min(qe, rq1);
-          if (hi > lo && hi - lo < kPlainLongRow) { w_len = hi - lo; w_k0 = lo - qs; }
-        }
-        if (!__ballot(w_len != 0)) continue;
-        const uint4 wcur = win_fetch(g_info, wb, n);
-        const uint32_t w_e0 = wcur.x, w_deg = wcur.y, w_rs = wcur.z;
-        const bool shortrow = w_len != 0;
-        const uint32_t tincl = wave_incl_scan(w_len);
-        const uint32_t tq = tincl - w_len;
-        const uint32_t ttot = (uint32_t)__builtin_amdgcn_readlane((int)tincl, 63);
-        // groups of 64 packed quads, kPack loads in flight (same straight-line pipelining as B; a lane without a quad
-        // re-reads the window's first quad with degree 0, i.e. fully masked)
-        constexpr int kPack = 4;
-        uint4 q[kPack];
-        uint32_t g_a[kPack], g_e0[kPack], g_deg[kPack], g_rs[kPack], g_rl[kPack];
-        const uint32_t a_dummy = (rl_first(w_e0) >> 2) << 2;
-        auto issue = [&](int u, uint32_t p0) {
-          const uint32_t take = p0 < ttot ? min(64u, ttot - p0) : 0u;
-          const bool starts = shortrow && tq > p0 && tq < p0 + take;
-          if (starts) wflag[tq - p0] = (unsigned char)(lane + 1u);
-          __builtin_amdgcn_wave_barrier();
-          uint32_t rl = wflag[lane];
-          __builtin_amdgcn_wave_barrier();
-          if (starts) wflag[tq - p0] = 0;
-          const uint64_t before = __ballot(shortrow && tq <= p0);
-          const uint32_t f0 = 63u - (uint32_t)__builtin_clzll((unsigned long long)(before | 1ull));   // row that holds p0
-          if (lane == 0) rl = f0 + 1u;
-          rl = wave_incl_max_scan(rl) - 1u;                              // lane of the window that owns my position
-          const uint32_t e0 = lane_get(w_e0, rl), rtq = lane_get(tq, rl), rk0 = lane_get(w_k0, rl);
-          const uint32_t kq = rk0 + (p0 + lane - rtq);                   // quad index inside the row
-          const bool have = lane < take;
-          g_a[u] = have ? ((e0 >> 2) + kq) << 2 : a_dummy;
-          g_e0[u] = e0; g_rl[u] = rl;
-          const uint32_t dg = lane_get(w_deg, rl);                        // (all lanes take part: the owner lane may hold no quad)
-          g_deg[u] = have ? dg : 0u;
-          g_rs[u] = lane_get(w_rs, rl);
-          q[u] = *reinterpret_cast<const uint4 *>(p.indices + g_a[u]);
-          __builtin_amdgcn_sched_barrier(0);
-        };
-#pragma unroll
-        for (int u = 0; u < kPack; u++) issue(u, (uint32_t)u * 64u);
-        for (uint32_t p0 = 0; p0 < ttot; p0 += kPack * 64u) {
-#pragma unroll
-          for (int u = 0; u < kPack; u++) {
-            process_group<true>(cx, t, q[u], g_a[u] - g_e0[u], g_deg[u], g_rs[u], wb + g_rl[u], 0u, g_e0[u], 0u, false, 1u);
-            issue(u, p0 + (uint32_t)(u + kPack) * 64u);
-          }
-        }
-      }
-      SCAN_T(8);
       __syncthreads();
       SCAN_T(2);
       const uint32_t m = ctrl[C_M];
