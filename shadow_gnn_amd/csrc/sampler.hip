@@ -875,9 +875,9 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
         const size_t base = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, 0).total + kHubCap * 32;
         const size_t lim2 = (size_t)(160 * 1024) / 2 - 64;
         const size_t lim = base + 128 * 16 <= lim2 ? lim2 : (size_t)160 * 1024 - 256;
-        if (base + 64 * 16 > lim) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", base);
+        if (base + 128 * 16 > lim) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", base);
         p.run_cap = (uint32_t)std::min<size_t>(1024, (lim - base) / 16) & ~31u;
-        p.run_cap = std::max<uint32_t>(64, std::min<uint32_t>(p.run_cap, env_u32("SHADOW_SG_RUNCAP", 1024)));
+        p.run_cap = std::max<uint32_t>(128, std::min<uint32_t>(p.run_cap, env_u32("SHADOW_SG_RUNCAP", 1024)));   // (>= 128: see the kernel)
       }
       const ScanLayout SL = flat ? scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, p.run_cap)
                                   : scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);

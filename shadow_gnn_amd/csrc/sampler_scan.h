@@ -881,8 +881,9 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
       }
       __syncthreads();
       if (nrun > run_cap) {
-        // (cannot happen for a single chunk: 8 + 512 / kLongRow runs at most)
-        rquads = max((rq1 - rq0) / 2u, kQChunk);
+        // too many rows start in the round: halve it (a run holds at least one quad, so 64 quads always fit: the host
+        // keeps run_cap >= 128)
+        rquads = max((rq1 - rq0) / 2u, 64u);
         __syncthreads();
         continue;
       }

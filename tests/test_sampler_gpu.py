@@ -329,6 +329,36 @@ def test_full_size_shapes_match_oracle(shape, batch, depth, self_e):
         assert np.array_equal(got[f], getattr(ref, f)), (shape, batch, depth, self_e, f)
 
 
+@pytest.mark.parametrize("env", [
+    {"SHADOW_SG_SCAN_IMPL": "flat"}, {"SHADOW_SG_SCAN_IMPL": "window"},
+    {"SHADOW_SG_SCAN_IMPL": "flat", "SHADOW_SG_RUNCAP": "128", "SHADOW_SG_SEG_PAD": "1"},       # many short rounds, no padding
+    {"SHADOW_SG_SCAN_IMPL": "flat", "SHADOW_SG_CAPM": "1024", "SHADOW_SG_SEG_PAD": "200"},     # candidate-list overflow -> halved rounds
+    {"SHADOW_SG_SCAN_IMPL": "flat", "SHADOW_SG_SCAN_THREADS": "256", "SHADOW_SG_BITWORDS": "2048"},
+    {"SHADOW_SG_SCAN_IMPL": "window", "SHADOW_SG_SEG_PAD": "1"},
+])
+def test_plain_scan_kernels_and_geometries_match_oracle(env, monkeypatch):
+    """The two scan kernels a plain call (no self edges, single root) can take -- the flat run list and the row
+    windows -- under several launch geometries (run-list / candidate-list capacities that force extra rounds, span
+    padding on and off, 4-wavefront workgroups with a small filter): hub rows spanning many chunks, rows of one quad,
+    full 2-hop neighbourhoods beyond the LDS node tables.  Every integer field equals the oracle's."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    indptr, indices = make_graph_numpy(30000, 16, seed=12)
+    deg = np.diff(indptr.astype(np.int64))
+    rng = np.random.default_rng(5)
+    roots = np.concatenate([np.argsort(-deg)[:4], np.argsort(deg)[:6], rng.permutation(30000)[:90]]).astype(np.uint32)
+    hs = _make(indptr, indices, seed=11)
+    for depth, budget in ((2, 20), (2, -1), (1, -1)):
+        cfg = SamplerConfig(method="khop", depth=depth, budget=budget, add_self_edge=False, aug=("hops",))
+        b = hs.sample(cfg, roots=roots, serial_base=0)
+        ref = so.sample_batch(indptr, indices, roots, method="khop", depth=depth, budget=budget, add_self_edge=False,
+                              aug=("hops",), seed=11, serial_base=0, num_threads=8)
+        _cmp_batch(ref, b, ("hops",), (env, depth, budget))
+
+
 def test_seeded_fuzz_against_oracle():
     """40 seeded random (graph, sampler config) draws -- directed and undirected graphs, isolated nodes,
     self loops, hubs, 1- and 2-root subgraphs, every flag combination -- HIP vs oracle, every field."""
