@@ -317,6 +317,11 @@ def main():
         sn += sb.num_nodes
     torch.cuda.synchronize(dev)
     sampler_rate = sn / (time.perf_counter() - ts0) * world
+    # ... and the same kernels' HIP-event time with the GPU to themselves (beside the train step the pipeline shares
+    # the chip with the first kernels of the step: both sides' durations then contain each other's work)
+    hs.set_profiling(True)
+    alone_counts = [hs.sample(scfg, B).counts for _ in range(10)]
+    hs.set_profiling(False)
 
     if rank != 0:
         return
@@ -329,6 +334,17 @@ def main():
         for c in pc:
             c["ppr_reads"] = c["n_tot"]
     s_bytes = [sampler_alg_bytes(c, with_hop) for c in pc]
+    sampler_alone = None
+    ac = [c for c in alone_counts if c["sample_kernel_ms"] > 0]
+    if ac:
+        if wl["sampler"]["method"] == "ppr":
+            for c in ac:
+                c["ppr_reads"] = c["n_tot"]
+        a_ms = float(np.mean([c["sample_kernel_ms"] for c in ac]))
+        a_by = float(np.mean([sampler_alg_bytes(c, with_hop) for c in ac]))
+        sampler_alone = dict(kernel="sg_sample_pipeline (select + plan + scan), sampler-only loop", calls=len(ac), avg_ms=round(a_ms, 4),
+                             alg_GBps=round(a_by / 1e9 / (a_ms / 1e3), 1), frac=round(a_by / 1e9 / (a_ms / 1e3) / HBM_PEAK_GBS, 4),
+                             relocate_avg_ms=round(float(np.mean([c["relocate_kernel_ms"] for c in ac])), 4))
     if s_ms:
         kern["sg_sample_pipeline"] = dict(launches=len(s_ms), total_ms=float(sum(s_ms)), avg_ms=float(np.mean(s_ms)),
                                             bytes_per_launch=float(np.mean(s_bytes)),
@@ -435,6 +451,7 @@ def main():
         "target_only_tail": tail_info,
         "cpu_baseline_train_step": cb_step,
         "sampler_only_nodes_per_sec": round(sampler_rate, 1),
+        "sampler_alone": sampler_alone,
         "config": {"workload": f"{args.workload}: {wl['shape']}-shape synthetic CSR (N={N}, nnz={int(indices.numel())}, "
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
                                f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",

@@ -70,7 +70,7 @@ def rw(sub, which=None, of=None):
 
 t = {}
 notes = {}
-sel, plan, scan = rw("sg_select_lds_kernel"), rw("sg_plan_kernel"), rw("sg_scan_kernel<true>")
+sel, plan, scan = rw("sg_select_lds_kernel"), rw("sg_plan_kernel"), rw("sg_scan_plain_kernel")
 t["sg_sample_pipeline"] = sum(sel) + sum(plan) + sum(scan)
 notes["sg_sample_pipeline"] = dict(select=sel, plan=plan, scan=scan)
 t["sg_relocate_kernel"] = sum(rw("sg_relocate_kernel"))
