@@ -268,7 +268,7 @@ def main():
                 prof_counts.append(c)
     torch.cuda.synchronize(dev)
     hs.set_profiling(False)
-    loss = float(ret["loss"])
+    loss = float(ret["loss"].detach())
     nodes = float(sum(c["n_tot"] for c in counts))
     edges = float(sum(c["e_tot"] for c in counts))
     stats = torch.tensor([dt, nodes, edges], dtype=torch.float64, device=dev)

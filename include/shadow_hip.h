@@ -404,6 +404,22 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
                 float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                 float *d_an_partial, float *d_tn_partial, void *d_pack, void *stream);
 
+/* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
+ * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /
+ * norm; the caller provides AX [n, Fin] (ldax), Z, out [n, Fout] and d_pack (sl_gcn_pack_bytes bytes).  backward:
+ * act_norm backward -> dAX = dZ W -> dX = A^T dAX (d_dX NULL: not wanted; lddx its row pitch) -> dW = dZ^T AX; d_buf is
+ * n * (Fout + Fin) floats of scratch, d_an_partial as for sl_act_norm_bwd (nb = 1), d_tn_partial as for sl_gemm_tn_f32.
+ * Fout, Fin % 4 == 0, <= 256.  The same kernels in the same order as the separate entries: identical results.        */
+size_t sl_gcn_pack_bytes(uint32_t Fin, uint32_t Fout);
+int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_W, int64_t ldw,
+               const float *d_b, const float *d_scale, const float *d_offset, int act, float drop_p, uint64_t drop_seed,
+               float *d_AX, int64_t ldax, float *d_Z, float *d_out, float *d_out_dropped, void *d_pack, void *stream);
+int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t ldax, const float *d_Z, uint32_t Fin, uint32_t Fout,
+               const float *d_W, int64_t ldw, const float *d_b, const float *d_scale, const float *d_offset, int act,
+               float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX, int64_t lddx,
+               float *d_dW, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial,
+               float *d_tn_partial, void *d_pack, void *stream);
+
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):
  *   hn = act(z_neigh);  u_s = att[0,h]·act(z_self)_h;  u_n = att[1,h]·hn_h

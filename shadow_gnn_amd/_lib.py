@@ -123,6 +123,11 @@ SIGNATURES = {
     "sl_sage_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),
+    "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
+                              C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "sl_gcn_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int,
+                              C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
@@ -144,7 +149,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 8      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 9      # sg_abi_version() of the library these signatures describe
 
 
 def load():

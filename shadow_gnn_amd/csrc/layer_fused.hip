@@ -1,4 +1,4 @@
-// layer_fused.hip -- one C entry per GraphSAGE layer pass.
+// layer_fused.hip -- one C entry per GraphSAGE / GCN layer pass.
 //
 // The dense part of a GraphSAGE layer (shaDow/layers.py:471-483),
 //     out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn)),
@@ -97,4 +97,67 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
   }
   if ((rc = sl_gemm_tn_f32(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
   return sl_gemm_tn_f32(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GCN (shaDow/layers.py:417-444): out = norm(act((A X) W^T + b)).  Forward: SpMM, weight pack, GEMM, fused bias / act /
+// norm; backward: act_norm backward, dAX = dZ W, dX = A^T dAX, dW = dZ^T (A X).
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t sl_gcn_pack_bytes(uint32_t Fin, uint32_t Fout) {
+  const size_t fwd = sl_gemm_pack_bytes(Fout, Fin), bwd = sl_gemm_pack_bytes(Fin, Fout);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_W,
+                          int64_t ldw, const float *d_b, const float *d_scale, const float *d_offset, int act, float drop_p,
+                          uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Z, float *d_out, float *d_out_dropped,
+                          void *d_pack, void *stream) {
+  if (!adj || !d_X || !d_W || !d_scale || !d_offset || !d_AX || !d_Z || !d_out || !d_pack)
+    return set_error(SG_ERR_INVALID, "sl_gcn_fwd: null argument");
+  if (Fout > 256 || (Fout & 3) || Fin == 0) return set_error(SG_ERR_INVALID, "sl_gcn_fwd: Fout = %u (multiple of 4, at most 256)", Fout);
+  const uint32_t n = adj->n;
+  if (n == 0) return SG_OK;
+  int rc;
+  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_nt_f32(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  const float *Z[1] = {d_Z};
+  const int64_t ldz[1] = {Fout};
+  const float *bias[1] = {d_b};
+  const int acts[1] = {act};
+  return sl_act_norm_fwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
+                         d_out_dropped, Fout, stream);
+}
+
+extern "C" int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t ldax, const float *d_Z, uint32_t Fin, uint32_t Fout,
+                          const float *d_W, int64_t ldw, const float *d_b, const float *d_scale, const float *d_offset, int act,
+                          float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
+                          int64_t lddx, float *d_dW, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
+                          float *d_an_partial, float *d_tn_partial, void *d_pack, void *stream) {
+  if (!adj || !d_AX || !d_Z || !d_W || !d_scale || !d_offset || !d_dW || !d_dscale || !d_doffset || !d_buf || !d_an_partial ||
+      !d_tn_partial || !d_pack || (!d_dout && !d_dout_dropped))
+    return set_error(SG_ERR_INVALID, "sl_gcn_bwd: null argument");
+  if (Fout > 256 || (Fout & 3) || Fin > 256 || (Fin & 3)) return set_error(SG_ERR_INVALID, "sl_gcn_bwd: widths %u -> %u unsupported", Fin, Fout);
+  const uint32_t n = adj->n;
+  if (n == 0) return SG_OK;
+  int rc;
+  // buf = [dZ (n x Fout) | dAX (n x Fin)], both dense
+  float *dZ = d_buf, *dAX = d_buf + (size_t)n * Fout;
+  const float *Z[1] = {d_Z};
+  const int64_t ldz[1] = {Fout};
+  const float *bias[1] = {d_b};
+  const int acts[1] = {act};
+  float *dZs[1] = {dZ};
+  const int64_t lddz[1] = {Fout};
+  if ((rc = sl_act_norm_bwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZs, lddz, d_dscale,
+                            d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
+    return rc;
+  if (d_dX) {
+    if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_gcn_bwd: the input gradient needs the transposed adjacency");
+    // dAX = dZ . W: B image of W^T ([Fin, Fout] read transposed out of W), then dX = A^T dAX
+    if ((rc = sl_gemm_pack_b2(d_W, 1, ldw, Fout, nullptr, 0, 0, Fin, Fout, d_pack, stream)) != SG_OK) return rc;
+    if ((rc = sl_gemm_nt_f32(dZ, Fout, d_pack, dAX, Fin, n, Fin, Fout, stream)) != SG_OK) return rc;
+    if ((rc = spmm_any(adj, true, dAX, Fin, d_dX, lddx, Fin, stream)) != SG_OK) return rc;
+  }
+  return sl_gemm_tn_f32(dZ, Fout, d_AX, ldax, d_dW, n, Fout, Fin, d_tn_partial, stream);
 }

@@ -219,11 +219,15 @@ class GCN(shaDowLayer):
         if isinstance(feat_in, ops.LazyRows) and ops.FUSE_GATHER_INTO_SPMM and ops.can_fuse_gather(adj_norm, feat_in):
             # layer 0 of the fast path: feature gather + input dropout inside the aggregation kernel
             feat_aggr, _x, _seed = ops.spmm_gather(adj_norm, feat_in, drop_p=self._in_p(), want_dense=False)
-        elif isinstance(feat_in, ops.LazyRows):
-            # ... or gather + input dropout in one pass into line-padded rows (the measured faster form)
-            feat_aggr = self.spmm(adj_norm, feat_in.gather_dropped(self._in_p())[0])
         else:
-            feat_aggr = self.spmm(adj_norm, self.in_dropout(feat_in))
+            # gather + input dropout in one pass into line-padded rows (the measured faster form), or the previous layer's output
+            x = feat_in.gather_dropped(self._in_p())[0] if isinstance(feat_in, ops.LazyRows) else self.in_dropout(feat_in)
+            if (self.act is None and self.norm == 'norm_feat' and self.act_name in ops.ACT_CODE
+                    and ops._GcnDense.fusable(x, adj_norm, self.f_lin.weight)):
+                # the whole layer as one autograd node, one C call per direction (small batches are host-bound)
+                feat_out = self._emit(ops.gcn_dense(x, adj_norm, self.f_lin, self.act_name, self.scale, self.offset, **self._drop_kw()))
+                return feat_out, adj_norm, True, 0.
+            feat_aggr = self.spmm(adj_norm, x)
         feat_out = self.f_lin_act_norm([feat_aggr], [self.f_lin], [self.act_name])
         return feat_out, adj_norm, True, 0.
 

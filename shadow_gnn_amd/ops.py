@@ -806,6 +806,90 @@ class _SageDense(torch.autograd.Function):
         return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None
 
 
+class _GcnDense(torch.autograd.Function):
+    """A whole GCN layer (shaDow/layers.py:417-444), out = norm(act((A X) W^T + b)), as ONE autograd node with ONE C call
+    per direction (sl_gcn_fwd / sl_gcn_bwd): at the reference's own batch sizes the separate SpMM and Linear + act + norm
+    nodes cost more host time than GPU time.  Only built when ``fusable`` holds; GCN.forward keeps the two-node path
+    otherwise (same kernels, same order: identical results)."""
+    @staticmethod
+    def fusable(X, adj, W):
+        Fo, Fi = W.shape
+        return (FUSED_LAYER_CALLS and GEMM_SPLIT and KernelTimer.active is None and torch.is_tensor(X) and X.is_cuda and X.shape[0] > 0
+                and X.shape[0] >= GEMM_SPLIT_MIN_ROWS and Fo % 4 == 0 and Fo <= 256 and Fi % 4 == 0 and Fi <= 256
+                and X.dtype == torch.float32 and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+                and W.stride(1) == 1 and W.dtype == torch.float32 and isinstance(adj, NormAdj))
+
+    @staticmethod
+    def forward(ctx, X, adj, W, b, scale, offset, act, drop):
+        lib = _lib.load()
+        n, Fi = X.shape
+        Fo = W.shape[0]
+        dev = X.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        sc = scale.reshape(1, Fo).contiguous().float()
+        of = offset.reshape(1, Fo).contiguous().float()
+        bc = b.detach().contiguous() if b is not None else None
+        pitch = X.stride(0) if (X.stride(0) != Fi and X.stride(0) % 32 == 0) else Fi
+        AX = torch.empty(n, pitch, **f32)[:, :Fi]
+        Z, out = torch.empty(n, Fo, **f32), torch.empty(n, Fo, **f32)
+        out2 = torch.empty(n, Fo, **f32) if _is_dual(drop) else None
+        pack = torch.empty(lib.sl_gcn_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        a = _adj_struct(adj, False)
+        opt = lambda t: t.data_ptr() if t is not None else None
+        check(lib.sl_gcn_fwd(C.byref(a), X.data_ptr(), X.stride(0), Fi, Fo, W.data_ptr(), W.stride(0), opt(bc), sc.data_ptr(),
+                             of.data_ptr(), int(act), float(drop[0]), int(drop[1]), AX.data_ptr(), AX.stride(0), Z.data_ptr(),
+                             out.data_ptr(), opt(out2), pack.data_ptr(), _stream(X)))
+        ctx.save_for_backward(AX, W, Z, sc, of, bc if bc is not None else sc.new_empty(0))
+        ctx.adj = adj
+        ctx.meta = (act, drop, scale.shape, offset.shape, b is not None, Fi)
+        ctx.set_materialize_grads(False)
+        return out if out2 is None else (out, out2)
+
+    @staticmethod
+    def backward(ctx, *dout):
+        lib = _lib.load()
+        AX, W, Z, sc, of, b = ctx.saved_tensors
+        act, drop, sshape, oshape, has_b, Fi = ctx.meta
+        n, Fo = Z.shape
+        dev = Z.device
+        ng = ctx.needs_input_grad
+        d0 = _f32c(dout[0]).contiguous() if dout[0] is not None else None
+        d1 = None
+        if _is_dual(drop):
+            d1 = _f32c(dout[1]).contiguous() if dout[1] is not None else None
+            if d1 is None:
+                drop = (0.0, 0)
+        if d0 is None and d1 is None:
+            d0 = torch.zeros(n, Fo, dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dX = torch.empty(n, Fi, **f32) if ng[0] else None
+        dW = torch.empty(Fo, Fi, **f32)
+        dbi = torch.empty(1, Fo, **f32) if has_b else None
+        dsc, dof = torch.empty(1, Fo, **f32), torch.empty(1, Fo, **f32)
+        buf = torch.empty(n * (Fo + Fi), **f32)
+        an_partial = torch.empty(2048 * 1 * 3 * Fo, **f32)
+        tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)
+        pack = torch.empty(lib.sl_gcn_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        a = _adj_struct(ctx.adj, bool(ng[0]))
+        opt = lambda t: t.data_ptr() if t is not None else None
+        check(lib.sl_gcn_bwd(C.byref(a), AX.data_ptr(), AX.stride(0), Z.data_ptr(), Fi, Fo, W.data_ptr(), W.stride(0),
+                             opt(b if has_b else None), sc.data_ptr(), of.data_ptr(), int(act), float(drop[0]), int(drop[1]), opt(d0),
+                             opt(d1), opt(dX), Fi, dW.data_ptr(), opt(dbi), dsc.data_ptr(), dof.data_ptr(), buf.data_ptr(),
+                             an_partial.data_ptr(), tn_partial.data_ptr(), pack.data_ptr(), _stream(Z)))
+        return (dX, None, dW if ng[2] else None, dbi[0] if (has_b and ng[3]) else None, dsc.reshape(sshape), dof.reshape(oshape),
+                None, None)
+
+
+def gcn_dense(X: torch.Tensor, adj: "NormAdj", lin, act: str, scale: torch.Tensor, offset: torch.Tensor,
+              out_dropout: float = 0.0, dual: bool = False):
+    """norm(act(lin(adj @ X))) -- GCN.forward (shaDow/layers.py:431-435) through the one-call entries.  The caller checks
+    ``_GcnDense.fusable`` first."""
+    if act not in ACT_CODE:
+        raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
+    F = lin.weight.shape[0]
+    return _GcnDense.apply(X, adj, lin.weight, lin.bias, scale, offset, ACT_CODE[act], _drop_arg(out_dropout, F, None, dual))
+
+
 def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
                offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False, in_dropout: float = 0.0):
     """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483).

@@ -939,3 +939,42 @@ def test_one_call_sage_layer_equals_kernel_by_kernel(F_in, F_out, act, p_out, du
     assert torch.equal(dx0, dx1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("F_in,F_out,act,p_out,dual", [(128, 256, "relu", 0.0, False), (256, 256, "elu", 0.4, False),
+                                                        (128, 64, "tanh", 0.3, True), (36, 32, "relu", 0.0, False)])
+def test_one_call_gcn_layer_equals_kernel_by_kernel(F_in, F_out, act, p_out, dual, monkeypatch):
+    """sl_gcn_fwd / sl_gcn_bwd: a whole GCN layer pass per C call (one autograd node) -- the same kernels in the same order
+    as SpMM node + Linear/act/norm node: outputs, input gradient and every parameter gradient are bit-identical (incl. the
+    fused output dropout in single and dual mode)."""
+    from shadow_gnn_amd import layers, ops
+    monkeypatch.setattr(ops, "GEMM_SPLIT_MIN_ROWS", 1)
+    sizes = [40, 1, 200, 17, 333, 5]
+    csr, _A = _blockdiag_batch(sizes, 0.06, seed=F_in + F_out + 1)
+    n = csr.n
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSED_LAYER_CALLS", fused)
+        torch.manual_seed(3)
+        layer = layers.GCN(F_in, F_out, dropout=0.0, act=act, norm="norm_feat").to(DEV)
+        with torch.no_grad():
+            for q in layer.parameters():
+                q.add_(0.1 * torch.randn_like(q))
+        layer.train()
+        layer.out_dropout, layer.out_dual = p_out, dual
+        g = torch.Generator(device=DEV).manual_seed(9)
+        x = torch.randn(n, F_in, device=DEV, generator=g).requires_grad_(True)
+        torch.manual_seed(11)                                   # (dropout seeds come from torch's CPU generator)
+        out, adj_norm, _, _ = layer((x, csr, False, 0.1), None)
+        outs = [out] + ([layer.take_dropped_out()] if dual else [])
+        G = [torch.randn(n, F_out, device=DEV, generator=g) for _ in outs]
+        sum((o * w).sum() for o, w in zip(outs, G)).backward()
+        return [o.detach().clone() for o in outs], x.grad.clone(), {k: q.grad.clone() for k, q in layer.named_parameters()}
+    assert not ops._GcnDense.fusable(torch.empty(0), None, torch.empty(4, 4))
+    o0, dx0, g0 = run(False)
+    o1, dx1, g1 = run(True)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert torch.equal(dx0, dx1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
