@@ -112,4 +112,24 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
   return base + incl - v;
 }
 
+// Two block-wide exclusive scans sharing their barriers.  `wsum`: 2 * (blockDim.x / 64) + 2 words of LDS scratch.
+__device__ __forceinline__ uint32_t block_excl_scan2(uint32_t va, uint32_t vb, uint32_t *wsum, uint32_t *total_a, uint32_t *excl_b,
+                                                     uint32_t *total_b) {
+  const uint32_t lane = lane_id(), wave = wave_id();
+  const uint32_t nw = (blockDim.x + 63) >> 6;
+  const uint32_t ia = wave_incl_scan(va), ib = wave_incl_scan(vb);
+  if (lane == 63) { wsum[wave] = ia; wsum[nw + wave] = ib; }
+  __syncthreads();
+  uint32_t base_a = 0, tot_a = 0, base_b = 0, tot_b = 0;
+  for (uint32_t w = 0; w < nw; w++) {
+    const uint32_t xa = wsum[w], xb = wsum[nw + w];
+    if (w < wave) { base_a += xa; base_b += xb; }
+    tot_a += xa; tot_b += xb;
+  }
+  __syncthreads();
+  *total_a = tot_a; *total_b = tot_b;
+  *excl_b = base_b + ib - vb;
+  return base_a + ia - va;
+}
+
 }  // namespace shadow

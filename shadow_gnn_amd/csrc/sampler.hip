@@ -814,6 +814,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
     auto env_u32 = [](const char *name, uint32_t dflt) { const char *e = getenv(name); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt; };
+    SHD_HIP(hipMemsetAsync(p.plan + 20, 0, 4 * sizeof(uint32_t), stream));
     // ---- 1. selection (one workgroup per subgraph, persistent over a ticket; tables in LDS)
     const uint32_t capn_lds = std::min(capn, kLdsCapNodes);
     const uint32_t capf_lds = std::min(capf, capn_lds);

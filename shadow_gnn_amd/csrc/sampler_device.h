@@ -231,6 +231,57 @@ __device__ __forceinline__ void block_sort_u32(uint32_t *a, uint32_t n) {
   }
 }
 
+// Ascending sort of n DISTINCT ids in LDS by counting: 256 buckets on the offset from the smallest id (sampled node ids
+// spread evenly: ~n / 256 per bucket), keys scattered bucket by bucket into `tmp`, rank = bucket start + smaller keys in
+// the bucket (consecutive LDS words).  Seven barriers where the bitonic network needs log2(n)^2 / 2.  `tmp` holds
+// n + 768 words; ctrl words C_CHANGED / C_MFAIL / C_M are scratch.  Returns false (a left untouched) when the ids
+// cluster so much that a bucket holds more than 64 of them -- the caller then sorts bitonically.
+__device__ __forceinline__ bool block_sort_counting(uint32_t *a, uint32_t n, uint32_t *tmp, uint32_t *ctrl) {
+  const uint32_t tid = threadIdx.x, T = blockDim.x, lane = lane_id();
+  uint32_t *cnt = tmp + n, *start = cnt + 256, *cur = start + 256;
+  if (tid == 0) { ctrl[C_CHANGED] = 0xFFFFFFFFu; ctrl[C_MFAIL] = 0; ctrl[C_M] = 0; }
+  for (uint32_t i = tid; i < 256; i += T) cnt[i] = 0;
+  __syncthreads();
+  uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  for (uint32_t i = tid; i < n; i += T) { const uint32_t v = a[i]; lo = min(lo, v); hi = max(hi, v); }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+  }
+  if (lane == 0) { atomicMin(&ctrl[C_CHANGED], lo); atomicMax(&ctrl[C_MFAIL], hi); }
+  __syncthreads();
+  const uint32_t vmin = ctrl[C_CHANGED], vmax = ctrl[C_MFAIL];
+  uint32_t shift = 0;
+  while (((vmax - vmin) >> shift) >= 256u) shift++;
+  for (uint32_t i = tid; i < n; i += T) atomicAdd(&cnt[(a[i] - vmin) >> shift], 1u);
+  __syncthreads();
+  if (tid < 64) {                                            // exclusive scan of the 256 counts: 4 per lane of wave 0
+    uint32_t c4[4], sum = 0, mx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { c4[q] = cnt[tid * 4 + q]; sum += c4[q]; mx = max(mx, c4[q]); }
+    const uint32_t incl = wave_incl_scan(sum);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { start[tid * 4 + q] = run; cur[tid * 4 + q] = run; run += c4[q]; }
+    mx = wave_reduce_max(mx);
+    if (tid == 0) ctrl[C_M] = mx;
+  }
+  __syncthreads();
+  if (ctrl[C_M] > 64u) return false;
+  for (uint32_t i = tid; i < n; i += T) { const uint32_t v = a[i]; tmp[atomicAdd(&cur[(v - vmin) >> shift], 1u)] = v; }
+  __syncthreads();
+  for (uint32_t j = tid; j < n; j += T) {
+    const uint32_t v = tmp[j], b = (v - vmin) >> shift;
+    const uint32_t s0 = start[b], c = cnt[b];
+    uint32_t r = s0;
+    for (uint32_t k = 0; k < c; k++) r += (tmp[s0 + k] < v) ? 1u : 0u;
+    a[r] = v;
+  }
+  __syncthreads();
+  return true;
+}
+
 __device__ __forceinline__ uint32_t rl_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ __forceinline__ bool is_root(const uint32_t *roots, int R, uint32_t v) {
@@ -255,6 +306,7 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   const uint64_t serial = p.serial_base + s;
   uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
 
+  const uint64_t tsel0 = clock64();
   // ---- phase 0: clear tables
   for (uint32_t i = tid; i < H + kStash; i += T) { t.hkey[i] = kEmpty; t.hval[i] = 0; }
   if (tid < C_WORDS) ctrl[tid] = 0;
@@ -385,18 +437,27 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   const uint32_t nstash = ctrl[C_NSTASH];
 
   // ---- phase 2: sort ids ascending (.cpp:362); the sorted position is the sub id (.cpp:369-372)
-  block_sort_u32(t.nodes, n);
+  const uint64_t tsel1 = clock64();
+  // (hval -- the expansion's level masks -- is free from here on: scratch of the counting sort when it is large enough)
+  if (kGlobalTables || n < 64u || (uint64_t)n + 768u > (uint64_t)H + kStash || !block_sort_counting(t.nodes, n, t.hval, ctrl))
+    block_sort_u32(t.nodes, n);
+  const uint64_t tsel2 = clock64();
   uint32_t *g_nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
   float *g_ppr = p.s_ppr + (size_t)s * p.cap_nodes_scr;
   RowInfo *g_info = p.s_rowinfo + (size_t)s * p.cap_nodes_scr;
   uint32_t *g_rowq = p.s_rowq + (size_t)s * (p.cap_nodes_scr + 1);
-  // ---- phase 3: per-row slot prefix (deg+1), quad prefix, row start -> the subgraph's row records
+  // ---- phase 3: per-row slot prefix (deg+1), quad prefix, row start -> the subgraph's row records.  The indptr pair
+  //      of the NEXT pass of T rows is loaded before this pass's scans (one global round trip per pass is hidden), and
+  //      the two prefixes share their barriers.
   uint32_t carry_s = 0, carry_q = 0;
+  uint32_t nv = 0, ne0 = 0, ne1 = 0;
+  if (tid < n) { nv = t.nodes[tid]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
   for (uint32_t base = 0; base < n; base += T) {
     const uint32_t i = base + tid;
-    uint32_t vs = 0, vq = 0, v = 0, e0 = 0;
+    const uint32_t v = nv, e0 = ne0, e1 = ne1;
+    if (i + T < n) { nv = t.nodes[i + T]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
+    uint32_t vs = 0, vq = 0;
     if (i < n) {
-      v = t.nodes[i];
       g_nodes[i] = v;
       if (p.method == SG_METHOD_PPR) {
         const int32_t slot = tab_find(t.hkey, v, H, hshift, nstash);
@@ -404,14 +465,11 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
       } else {
         g_ppr[i] = -1.0f;                                                // .cpp:545
       }
-      e0 = p.indptr[v];
-      const uint32_t e1 = p.indptr[v + 1];
       vs = e1 - e0 + 1u;
       vq = (e1 > e0) ? (((e1 - 1u) >> 2) - (e0 >> 2) + 1u) : 0u;
     }
-    uint32_t tot_s, tot_q;
-    const uint32_t ex_s = block_excl_scan(vs, wsum, &tot_s);
-    const uint32_t ex_q = block_excl_scan(vq, wsum, &tot_q);
+    uint32_t tot_s, tot_q, ex_q;
+    const uint32_t ex_s = block_excl_scan2(vs, vq, wsum, &tot_s, &ex_q, &tot_q);
     if (i < n) {
       RowInfo ri;
       ri.e0 = e0; ri.deg = vs - 1u; ri.rs = carry_s + ex_s; ri.v = v;
@@ -430,6 +488,11 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   if (tid == 0) {
     res[R_N] = n; res[R_E] = 0; res[R_FLAGS] = 0; res[R_SLOTS] = carry_s; res[R_Q] = carry_q;
     res[R_FNODES] = ctrl[C_FRONT_NODES]; res[R_FREADS] = ctrl[C_FRONT_READS];
+    // phase cycles (units of 16) of the selection, summed over the call's subgraphs (sg_debug_scan_phases words 20..22)
+    const uint64_t tsel3 = clock64();
+    atomicAdd(&p.plan[20], (uint32_t)((tsel1 - tsel0) >> 4));
+    atomicAdd(&p.plan[21], (uint32_t)((tsel2 - tsel1) >> 4));
+    atomicAdd(&p.plan[22], (uint32_t)((tsel3 - tsel2) >> 4));
   }
   __syncthreads();
 }

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(1024) sg_plan_kernel(SampleParams p) {
     p.plan[PL_CPW] = max(1u, (carry + p.scan_grid - 1u) / p.scan_grid);
     p.plan[PL_POOL] = p.scan_grid;                         // blocks [0, scan_grid) belong to the workgroups
     p.plan[PL_FLAGS] = 0;
-    for (int i = PL_T0; i < PL_WORDS; i++) p.plan[i] = 0;
+    for (int i = PL_T0; i < PL_T0 + 12; i++) p.plan[i] = 0;      // (words 20..22: the selection kernel's phase cycles of this call)
   }
 }
 
