@@ -463,6 +463,8 @@ __global__ void sg_scan_kernel(SampleParams p) {
   t.wtmp = smem + L.wtmp;
   uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
 
+  // probe4 forms filter addresses with an OR: the filter must sit on a multiple of its own size in LDS (offset 0 here)
+  if (((uint32_t)(uintptr_t)t.bits) & (p.bit_words * 4u - 1u)) __builtin_trap();
   const uint32_t tid = threadIdx.x, T = blockDim.x;
   const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
   const uint32_t bw_mask = p.bit_words - 1u;
@@ -794,6 +796,8 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
   uint4 *hub = (uint4 *)(smem + L.hub);
   uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
 
+  // probe4 forms filter addresses with an OR: the filter must sit on a multiple of its own size in LDS (offset 0 here)
+  if (((uint32_t)(uintptr_t)t.bits) & (p.bit_words * 4u - 1u)) __builtin_trap();
   const uint32_t tid = threadIdx.x, T = blockDim.x;
   const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
   const uint32_t bw_mask = p.bit_words - 1u, bm4 = bw_mask << 2;
