@@ -19,6 +19,8 @@ shaDow/models.py:166)."""
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -206,6 +208,9 @@ class MinibatchShallowExtractor:
         self.tail_plan_layers = 0
         self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
         self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        # prefetch launched after the consumer's first aggregation (ops.fire_deferred) instead of at once: measured 10.39 ->
+        # 10.25 ms/step on the products benchmark (scripts/ab_defer.sh); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
+        self.defer_prefetch = os.environ.get("SHADOW_DEFER_PREFETCH", "1") != "0"
         self._inflight: Dict[int, Tuple[str, int, int]] = {}   # mode -> (kind, roots in the call, epoch cursor at its start)
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
         self.nocache_modes = set(nocache_modes)
@@ -501,7 +506,15 @@ class MinibatchShallowExtractor:
                             subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
         if not last and self.prefetch:
-            self._launch(mode)        # overlap the next sampler call with this batch's training
+            if self.defer_prefetch:
+                # ... issued once the step's first aggregation is enqueued (ops.fire_deferred), so that it overlaps the
+                # GEMM-bound body of the step instead of its HBM-bound head; if the consumer never aggregates, the next
+                # one_batch launches it itself
+                t1 = t + 1
+                ops.defer((id(self), mode),
+                          lambda: self._launch(mode) if (self._launched[mode] == t1 and self._step[mode] == t1) else None)
+            else:
+                self._launch(mode)        # overlap the next sampler call with this batch's training
         feat = (ops.LazyRows(self.feat_full, subgs.node) if self.lazy_features
                 else ops.gather_rows(self.feat_full, subgs.node))    # minibatch.py:469
         label = self.label_epoch[mode][i0:i0 + batch_size_]

@@ -306,7 +306,9 @@ class _SpMM(torch.autograd.Function):
 
 def spmm(adj: NormAdj, X: torch.Tensor) -> torch.Tensor:
     """adj @ X  (torch.sparse.mm(adj_norm, X), shaDow/layers.py:326-327)."""
-    return _SpMM.apply(X, adj)
+    out = _SpMM.apply(X, adj)
+    fire_deferred()
+    return out
 
 
 def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -708,6 +710,7 @@ class _SageDense(torch.autograd.Function):
         ctx.adj = adj
         ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)])
         ctx.set_materialize_grads(False)
+        fire_deferred()
         return out
 
     @staticmethod
@@ -806,6 +809,23 @@ class _SageDense(torch.autograd.Function):
         return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None
 
 
+# Work the minibatch extractor wants issued right AFTER the first aggregation of a step has been enqueued (the prefetch of
+# the next batch's sampler call: launched at once it shares the chip with the step's HBM-bound head -- feature gather and
+# the layer-0 aggregation -- and all three slow down; launched here it runs beside the matrix-core-bound GEMMs).
+_DEFERRED: dict = {}
+
+
+def defer(key, fn):
+    """One pending callable per ``key`` (a newer one replaces an unfired older one)."""
+    _DEFERRED[key] = fn
+
+
+def fire_deferred():
+    while _DEFERRED:
+        _k, fn = _DEFERRED.popitem()
+        fn()
+
+
 class _GcnDense(torch.autograd.Function):
     """A whole GCN layer (shaDow/layers.py:417-444), out = norm(act((A X) W^T + b)), as ONE autograd node with ONE C call
     per direction (sl_gcn_fwd / sl_gcn_bwd): at the reference's own batch sizes the separate SpMM and Linear + act + norm
@@ -843,6 +863,7 @@ class _GcnDense(torch.autograd.Function):
         ctx.adj = adj
         ctx.meta = (act, drop, scale.shape, offset.shape, b is not None, Fi)
         ctx.set_materialize_grads(False)
+        fire_deferred()
         return out if out2 is None else (out, out2)
 
     @staticmethod

@@ -26,6 +26,7 @@ class _GatAggregate(torch.autograd.Function):
                                      nagg.data_ptr(), ops._stream(z_self)))
         ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape)
+        ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
         return nagg
 
     @staticmethod
