@@ -207,7 +207,10 @@ class MinibatchShallowExtractor:
         # > 0: every batch carries a target-only-tail plan for a model of that many layers (DeepGNN.prune_tail)
         self.tail_plan_layers = 0
         self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
-        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        # (priority -1 = high: when the deferred sampler call meets the GEMMs of the step, its workgroups take the CU slots
+        #  as they free up instead of queueing behind the GEMM's grid; SHADOW_PREFETCH_PRIORITY=0 for a normal stream)
+        prio = int(os.environ.get("SHADOW_PREFETCH_PRIORITY", "-1"))
+        self._side = torch.cuda.Stream(device=self.device, priority=prio) if self.prefetch else None
         # prefetch launched after the consumer's first aggregation (ops.fire_deferred) instead of at once: measured 10.39 ->
         # 10.25 ms/step on the products benchmark (scripts/ab_defer.sh); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
         self.defer_prefetch = os.environ.get("SHADOW_DEFER_PREFETCH", "1") != "0"
