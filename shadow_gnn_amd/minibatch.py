@@ -211,8 +211,9 @@ class MinibatchShallowExtractor:
         #  as they free up instead of queueing behind the GEMM's grid; SHADOW_PREFETCH_PRIORITY=0 for a normal stream)
         prio = int(os.environ.get("SHADOW_PREFETCH_PRIORITY", "-1"))
         self._side = torch.cuda.Stream(device=self.device, priority=prio) if self.prefetch else None
-        # prefetch launched after the consumer's first aggregation (ops.fire_deferred) instead of at once: measured 10.39 ->
-        # 10.25 ms/step on the products benchmark (scripts/ab_defer.sh); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
+        # prefetch launched when the consumer reaches ops.fire_deferred (after its forward pass, see ops.DEFER_POINT) instead of
+        # at once: 10.46 -> 10.38 ms/step on the products benchmark (scripts/ab_defer_point.sh); SHADOW_DEFER_PREFETCH=0
+        # restores the immediate launch
         self.defer_prefetch = os.environ.get("SHADOW_DEFER_PREFETCH", "1") != "0"
         self._inflight: Dict[int, Tuple[str, int, int]] = {}   # mode -> (kind, roots in the call, epoch cursor at its start)
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
@@ -510,9 +511,8 @@ class MinibatchShallowExtractor:
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
         if not last and self.prefetch:
             if self.defer_prefetch:
-                # ... issued once the step's first aggregation is enqueued (ops.fire_deferred), so that it overlaps the
-                # GEMM-bound body of the step instead of its HBM-bound head; if the consumer never aggregates, the next
-                # one_batch launches it itself
+                # ... issued when the consumer reaches ops.fire_deferred, so that it stays off the HBM-bound head of the step
+                # (feature gather, layer-0 aggregation); if the consumer never gets there, the next one_batch launches it
                 t1 = t + 1
                 ops.defer((id(self), mode),
                           lambda: self._launch(mode) if (self._launched[mode] == t1 and self._step[mode] == t1) else None)

@@ -274,6 +274,7 @@ class DeepGNN(nn.Module):
         if training:
             self._begin_update()
             preds, emb_ens = self(mode, dropedge=self.dropedge, **fwd)
+            ops.fire_deferred("fwd")                 # (the extractor's deferred prefetch, if no layer fired it)
             loss = self._loss(preds, labels)
             weight = loss_scale * (getattr(batch_data, "loss_weight", 1.0) if self.grad_sync is not None else 1.0)
             (loss if weight == 1.0 else loss * weight).backward()

@@ -820,7 +820,18 @@ def defer(key, fn):
     _DEFERRED[key] = fn
 
 
-def fire_deferred():
+# "fwd" (default): after the forward pass -- the call then starts in the thin loss kernels and shares the chip with the
+# first backward kernels; "agg": after the step's first aggregation -- beside the forward GEMMs.  Same box, products
+# benchmark (scripts/ab_defer_point.sh): immediate launch 10.46 ms/step, "agg" 10.36, "fwd" 10.38 with the sampler pipeline
+# at 0.32 ms instead of 0.40 (it waits less for CU slots).
+DEFER_POINT = os.environ.get("SHADOW_DEFER_POINT", "fwd")
+
+
+def fire_deferred(point: str = "agg"):
+    """Called by the aggregation nodes ("agg") and by DeepGNN.step after its forward pass ("fwd", which also fires whatever
+    an "agg" point never reached, e.g. an MLP stack)."""
+    if point != DEFER_POINT and point != "fwd":
+        return
     while _DEFERRED:
         _k, fn = _DEFERRED.popitem()
         fn()
