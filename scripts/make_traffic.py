@@ -62,8 +62,11 @@ def rw(sub, which=None, of=None):
             res.append(scale * sum(acc[k]) / len(acc[k]))
         else:
             if len(cl) != of:
-                # small kernels' counters are noisy: merge to the expected count by taking the heaviest clusters
-                cl = sorted(sorted(cl, key=lambda c: -c[1])[:of])
+                # cut at the (of - 1) largest relative jumps of the sorted values instead
+                v = sorted(acc[k])
+                jumps = sorted(range(1, len(v)), key=lambda i: -(v[i] / max(v[i - 1], 1.0)))[:of - 1]
+                cuts = [0] + sorted(jumps) + [len(v)]
+                cl = [(sum(v[a:b]) / (b - a), b - a) for a, b in zip(cuts[:-1], cuts[1:])]
             res.append(scale * cl[which][0])
     return res
 
