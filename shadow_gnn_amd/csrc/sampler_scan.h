@@ -5,25 +5,31 @@
 // row {e0, deg, slot prefix, id} plus the prefix of the rows' aligned 16-byte QUADS in the full graph's indices
 // array.  The concatenated quads of all rows of all subgraphs are the stream this kernel reads exactly once:
 //
-//   sg_plan_kernel   (one workgroup) prefix of the subgraphs' CHUNKS (kQChunk quads = 8 KB of ids); the global chunk
-//                    sequence is cut into equal spans, one per scan workgroup: perfectly balanced in bytes, no
-//                    work queue, and a heavy subgraph simply spreads over several workgroups.
-//   sg_scan_kernel   workgroup w owns chunks [w * cpw, (w + 1) * cpw) -- usually the tail of one subgraph, a few
-//                    whole ones and the head of another.  Per subgraph segment: rebuild that subgraph's membership
-//                    filter in LDS (bit = id mod 2^k; a clear bit is a definite miss), then rounds of <= 64 chunks:
-//                    every WAVEFRONT streams whole chunks with coalesced 16-byte-per-lane loads (64 quads = 1 KiB per
-//                    instruction, a batch of four in flight); the quads of consecutive short rows are packed into the
-//                    same instruction (row WINDOW: 64 rows held one per lane; position -> row by one byte scatter and
-//                    a DPP fill-forward); each id costs one LDS dword probe, and the rare candidates (~1 % of the ids)
-//                    go to an LDS list keyed by 2*slot+kind.  At the end of a round the candidates are resolved exactly
-//                    (binary search in the sorted node list = the sub id), bucket-sorted by key -- which restores the
-//                    reference's edge order -- and appended to the subgraph's edge scratch; a round record remembers
-//                    where.  Key ranges of different rounds / workgroups of a subgraph are disjoint and ordered by quad
-//                    position, so the relocation kernel only concatenates the records in workgroup order.
+//   sg_plan_kernel        (one workgroup) prefix of the subgraphs' CHUNKS (kQChunk quads = 8 KB of ids, plus seg_pad virtual
+//                         chunks per subgraph that stand for its fixed work); the global chunk sequence is cut into equal
+//                         spans, one per scan workgroup: balanced in bytes and in per-subgraph overhead, no work queue,
+//                         and a heavy subgraph simply spreads over several workgroups.
+//   sg_scan_plain_kernel  (plain calls: no self-edge insertion, no compat over-read, single root or include_target_conn)
+//   sg_scan_kernel        (everything else)
+//                         workgroup w owns chunks [w * cpw, (w + 1) * cpw) -- usually the tail of one subgraph, a few
+//                         whole ones and the head of another.  Per subgraph segment: rebuild that subgraph's membership
+//                         filter in LDS (bit = id mod 2^k; a clear bit is a definite miss), then ROUNDS of <= 64 chunks in
+//                         which the wavefronts stream the quads with coalesced 16-byte-per-lane loads (64 quads = 1 KiB
+//                         per instruction, eight in flight), probe every id against the filter (one LDS dword) and note
+//                         the rare candidates (~1 % of the ids) in an LDS list.  The two kernels differ in how a round's
+//                         quads reach the lanes: a flat list of RUNS (<= 64 quads of one row) built per round and a
+//                         software-pipelined loop over it (plain), or row WINDOWS (64 rows held one per lane: long rows as
+//                         runs, the quads of short rows packed into shared instructions; position -> row by one byte
+//                         scatter and a DPP fill-forward).
+//   finish_round          end of a round, shared: candidates resolved exactly (binary search in the sorted node list =
+//                         the sub id), counting-sorted by key 2*slot+kind -- which restores the reference's edge order --
+//                         and appended to the subgraph's edge scratch; a round record remembers where.  Key ranges of
+//                         different rounds / workgroups of a subgraph are disjoint and ordered by quad position, so the
+//                         relocation kernel only concatenates the records in workgroup order.
 //
 // Self-edge insertion (.cpp:386-400), the reference's over-read (compat) and the root<->root exclusion of
-// multi-root subgraphs (.cpp:414-418) ride along: the lane that holds a row's last neighbour decides the trailing
-// self edge, rows without neighbours are handled by the wavefront that finishes the preceding row.
+// multi-root subgraphs (.cpp:414-418) live in sg_scan_kernel: the lane that holds a row's last neighbour decides the
+// trailing self edge, rows without neighbours are handled by the wavefront that finishes the preceding row.
 #pragma once
 #include "sampler_device.h"
 
