@@ -284,6 +284,7 @@ class DeepGNN(nn.Module):
                 self.eval()
             with torch.no_grad():
                 preds, emb_ens = self(mode, dropedge=0., **fwd)
+                ops.fire_deferred("fwd")
                 loss = self._loss(preds, labels)
         assert preds.shape[0] == labels.shape[0]
         return {'batch_size': preds.shape[0], 'loss': loss, 'labels': labels,
