@@ -194,6 +194,7 @@ class DeepGNN(nn.Module):
             emb = self._run_branch(i, feat, adj_i, tgt, size_subg_ens[i], dropedge, levels)
             emb_subg_ens.append(F.normalize(emb, p=2, dim=1))
         pred_subg = self.classifier(self.ensembler(emb_subg_ens))
+        ops.fire_deferred("fwd")                     # (the extractor's deferred prefetch: see ops.defer)
         return pred_subg, emb_subg_ens
 
     def _tail_prunable(self, i):
@@ -274,7 +275,6 @@ class DeepGNN(nn.Module):
         if training:
             self._begin_update()
             preds, emb_ens = self(mode, dropedge=self.dropedge, **fwd)
-            ops.fire_deferred("fwd")                 # (the extractor's deferred prefetch, if no layer fired it)
             loss = self._loss(preds, labels)
             weight = loss_scale * (getattr(batch_data, "loss_weight", 1.0) if self.grad_sync is not None else 1.0)
             (loss if weight == 1.0 else loss * weight).backward()
@@ -284,7 +284,6 @@ class DeepGNN(nn.Module):
                 self.eval()
             with torch.no_grad():
                 preds, emb_ens = self(mode, dropedge=0., **fwd)
-                ops.fire_deferred("fwd")
                 loss = self._loss(preds, labels)
         assert preds.shape[0] == labels.shape[0]
         return {'batch_size': preds.shape[0], 'loss': loss, 'labels': labels,
