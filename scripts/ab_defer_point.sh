@@ -1,4 +1,6 @@
-for rep in 1 2; do for pt in agg fwd none; do
+#!/usr/bin/env bash
+# where the deferred sampler prefetch is launched (ops.DEFER_POINT): products benchmark, same box
+for rep in 1 2; do for pt in body fwd agg none; do
 if [ $pt = none ]; then export SHADOW_DEFER_PREFETCH=0; else export SHADOW_DEFER_PREFETCH=1; fi
 SHADOW_DEFER_POINT=$pt timeout 300 python bench.py --no-cpu-baseline --no-tail 2>/dev/null | python -c "
 import sys,json

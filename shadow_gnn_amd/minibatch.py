@@ -211,9 +211,9 @@ class MinibatchShallowExtractor:
         #  as they free up instead of queueing behind the GEMM's grid; SHADOW_PREFETCH_PRIORITY=0 for a normal stream)
         prio = int(os.environ.get("SHADOW_PREFETCH_PRIORITY", "-1"))
         self._side = torch.cuda.Stream(device=self.device, priority=prio) if self.prefetch else None
-        # prefetch launched when the consumer reaches ops.fire_deferred (after its forward pass, see ops.DEFER_POINT) instead of
-        # at once: 10.46 -> 10.38 ms/step on the products benchmark (scripts/ab_defer_point.sh); SHADOW_DEFER_PREFETCH=0
-        # restores the immediate launch
+        # prefetch launched when the consumer reaches ops.fire_deferred (see ops.DEFER_POINT: once the GNN layers of the forward
+        # pass are enqueued) instead of at once: it then runs in the nearly idle read-out / loss stretch of the step instead of
+        # on its HBM-bound head (scripts/ab_defer_point.sh); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
         self.defer_prefetch = os.environ.get("SHADOW_DEFER_PREFETCH", "1") != "0"
         self._inflight: Dict[int, Tuple[str, int, int]] = {}   # mode -> (kind, roots in the call, epoch cursor at its start)
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)

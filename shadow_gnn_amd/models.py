@@ -192,6 +192,8 @@ class DeepGNN(nn.Module):
                 levels = planned if planned is not None else tail.build_tail_plan(adj_i, tgt, len(self.conv_layers[i]))
                 assert len(levels) <= len(self.conv_layers[i])
             emb = self._run_branch(i, feat, adj_i, tgt, size_subg_ens[i], dropedge, levels)
+            if i + 1 == len(feat_ens):
+                ops.fire_deferred("body")                # (the big kernels of the forward pass are enqueued)
             emb_subg_ens.append(F.normalize(emb, p=2, dim=1))
         pred_subg = self.classifier(self.ensembler(emb_subg_ens))
         ops.fire_deferred("fwd")                     # (the extractor's deferred prefetch: see ops.defer)

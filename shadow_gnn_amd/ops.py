@@ -820,17 +820,19 @@ def defer(key, fn):
     _DEFERRED[key] = fn
 
 
-# "fwd" (default): after the forward pass -- the call then starts in the thin loss kernels and shares the chip with the
-# first backward kernels; "agg": after the step's first aggregation -- beside the forward GEMMs.  Same box, products
-# benchmark (scripts/ab_defer_point.sh): immediate launch 10.46 ms/step, "agg" 10.36, "fwd" 10.38 with the sampler pipeline
-# at 0.32 ms instead of 0.40 (it waits less for CU slots).
-DEFER_POINT = os.environ.get("SHADOW_DEFER_POINT", "fwd")
+# Where the deferred call is issued.  "body" (default): when the last GNN layer of the forward pass is enqueued -- the
+# call then runs beside the read-out / classifier / loss kernels and the first small backward kernels, a stretch of ~15
+# tiny kernels that leaves the chip nearly idle for about as long as the sampler pipeline takes; "fwd": at the end of
+# DeepGNN.forward; "agg": after the step's first aggregation (beside the forward GEMMs).  Same box, products benchmark
+# (scripts/ab_defer_point.sh), step ms / sampler pipeline ms in the step / north-star HBM fraction:
+#   immediate 10.27 / 0.25 / 0.41    agg 10.20 / 0.31-0.40 / 0.40-0.43    fwd 10.21 / 0.28 / 0.44    body 10.21 / 0.21 / 0.46
+DEFER_POINT = os.environ.get("SHADOW_DEFER_POINT", "body")
 
 
 def fire_deferred(point: str = "agg"):
     """Called by the aggregation nodes ("agg") and by DeepGNN.step after its forward pass ("fwd", which also fires whatever
     an "agg" point never reached, e.g. an MLP stack)."""
-    if point != DEFER_POINT and point != "fwd":
+    if point != DEFER_POINT and point != "fwd":         # ("fwd" is the last point of a step: it fires whatever is left)
         return
     while _DEFERRED:
         _k, fn = _DEFERRED.popitem()
