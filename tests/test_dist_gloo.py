@@ -124,3 +124,22 @@ def test_epoch_plan_static_partition_keeps_roots_on_their_rank(E, B, G):
             assert np.array_equal(mine, order[order % G == r])               # epoch order preserved inside the share
             assert local.max() - local.min() <= 1
         assert np.array_equal(sum(p[1] for p in plans), plans[0][2]) and plans[0][2].sum() == E
+
+
+def test_deferred_work_registry():
+    """ops.defer / ops.fire_deferred: one pending callable per key (a newer one replaces an unfired older one), fired
+    at the configured point or, whatever is left, at "fwd"."""
+    from shadow_gnn_amd import ops
+    ops._DEFERRED.clear()
+    fired = []
+    ops.defer(("a", 0), lambda: fired.append("old"))
+    ops.defer(("a", 0), lambda: fired.append("new"))
+    ops.defer(("b", 0), lambda: fired.append("other"))
+    other = "agg" if ops.DEFER_POINT != "agg" else "body"
+    ops.fire_deferred(other)
+    assert fired == []
+    ops.fire_deferred(ops.DEFER_POINT)
+    assert sorted(fired) == ["new", "other"] and not ops._DEFERRED
+    ops.defer(("a", 0), lambda: fired.append("late"))
+    ops.fire_deferred("fwd")
+    assert fired[-1] == "late" and not ops._DEFERRED
