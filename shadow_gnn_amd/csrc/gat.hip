@@ -226,18 +226,33 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
   }
 }
 
-// datt[j] = sum over blocks of datt_part[block][j], fixed order (bit-reproducible; no float atomics)
-__global__ void gat_datt_finish_kernel(const float *__restrict__ part, uint32_t nblocks, uint32_t len, float *__restrict__ datt) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  uint32_t b = 0;
-  for (; b + 4 <= nblocks; b += 4) {
+// datt[j] = sum over blocks of datt_part[block][j] in a fixed order (bit-reproducible; no float atomics).  A workgroup owns
+// 32 outputs; its 32 x 32 threads cut the block range into 32 slices, eight independent running sums per thread (one thread
+// per output walking all ~2 000 partial rows was a 240 us latency chain), the slices are added in slice order through LDS.
+constexpr int kDattCols = 32, kDattSlices = 32;
+__global__ void __launch_bounds__(kDattCols * kDattSlices)
+gat_datt_finish_kernel(const float *__restrict__ part, uint32_t nblocks, uint32_t len, float *__restrict__ datt) {
+  __shared__ float red[kDattSlices][kDattCols];
+  const uint32_t c = threadIdx.x % kDattCols, sl = threadIdx.x / kDattCols;
+  const uint32_t j = blockIdx.x * kDattCols + c;
+  const uint32_t per = (nblocks + kDattSlices - 1) / kDattSlices;
+  const uint32_t b0 = sl * per, b1 = min(nblocks, b0 + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < len) {
+    uint32_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) acc[k] += part[(size_t)(b + k) * len + j];
+      for (int k = 0; k < 8; k++) acc[k] += part[(size_t)(b + k) * len + j];
+    }
+    for (int k = 0; b < b1; b++, k++) acc[k] += part[(size_t)b * len + j];
   }
-  for (int k = 0; b < nblocks; b++, k++) acc[k] += part[(size_t)b * len + j];
-  datt[j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  red[sl][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (sl == 0 && j < len) {
+    float s = 0.f;
+    for (int q = 0; q < kDattSlices; q++) s += red[q][c];
+    datt[j] = s;
+  }
 }
 
 static uint32_t gat_grid(uint32_t n, uint32_t lpr) {
@@ -327,7 +342,8 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   const uint32_t g = gat_grid(n, lpr);
   SHD_GAT_LAUNCH(gat_row_bwd_kernel, lpr, g, st, p);
   SHD_GAT_LAUNCH(gat_col_bwd_kernel, lpr, g, st, p);
-  hipLaunchKernelGGL(gat_datt_finish_kernel, dim3((2 * F + 255) / 256), dim3(256), 0, st, p.datt_part, g, 2 * F, d_datt);
+  hipLaunchKernelGGL(gat_datt_finish_kernel, dim3((2 * F + kDattCols - 1) / kDattCols), dim3(kDattCols * kDattSlices), 0, st,
+                     p.datt_part, g, 2 * F, d_datt);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
