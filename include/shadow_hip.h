@@ -420,6 +420,16 @@ int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t ldax, const fl
                float *d_dW, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial,
                float *d_tn_partial, void *d_pack, void *stream);
 
+/* End of a training step on flat fp32 buffers (shaDow/models.py:225-226: torch.nn.utils.clip_grad_norm_(parameters, 5)
+ * + torch.optim.Adam.step(), default betas / eps, no weight decay): the gradient is scaled IN PLACE by
+ * min(1, max_norm / (||g|| + 1e-6)) (max_norm <= 0: no clipping), the moments and the parameters are updated with
+ * torch's arithmetic (the hyper-parameters are doubles, as in Python: 1 - beta and lr / (1 - beta^t) are formed in double
+ * precision before they are rounded); `step` counts from 1.  Two launches (norm partials, update), deterministic.  d_scratch:
+ * sl_clip_adam_scratch_floats() floats; its last float receives ||g|| before clipping.  Buffers 16-byte aligned.     */
+uint32_t sl_clip_adam_scratch_floats(void);
+int sl_clip_adam(float *d_param, float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, uint64_t n, double lr, double beta1,
+                 double beta2, double eps, uint32_t step, float max_norm, float *d_scratch, void *stream);
+
 /* Fused multi-head GAT attention aggregate (GAT._aggregate_attention for all
  * heads, shaDow/layers.py:560-582,612-619):
  *   hn = act(z_neigh);  u_s = att[0,h]·act(z_self)_h;  u_n = att[1,h]·hn_h

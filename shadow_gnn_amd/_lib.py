@@ -128,6 +128,8 @@ SIGNATURES = {
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "sl_gcn_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int,
                               C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sl_clip_adam_scratch_floats": (C.c_uint32, []),
+    "sl_clip_adam": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_float, _P, _P]),
     "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
@@ -149,7 +151,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 9      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 10      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -245,10 +245,10 @@ class DeepGNN(nn.Module):
         the global batch was empty: the parameters stay identical everywhere."""
         if self.grad_sync is not None:
             self.grad_sync.all_reduce(self.parameters())
-        if hasattr(self.optimizer, "clip_"):             # optim.FlatAdam: clip + Adam on the flat buffers
-            self.optimizer.clip_(GRAD_CLIP_NORM)
-        else:
-            torch.nn.utils.clip_grad_norm_(self.parameters(), GRAD_CLIP_NORM)
+        if hasattr(self.optimizer, "clip_step_"):        # optim.FlatAdam: clip + Adam on the flat buffers, two launches
+            self.optimizer.clip_step_(GRAD_CLIP_NORM)
+            return
+        torch.nn.utils.clip_grad_norm_(self.parameters(), GRAD_CLIP_NORM)
         self.optimizer.step()
 
     def _empty_result(self, batch_data):

@@ -7,6 +7,7 @@ of two foreach passes over ~30 tensors -- what is left of the step's host time a
 sits in exactly those passes.  Arithmetic: torch.optim.Adam's defaults (betas (0.9, 0.999), eps 1e-8, no weight
 decay, no amsgrad), statement for statement, and torch.nn.utils.clip_grad_norm_'s rule."""
 import math
+import os
 from typing import Tuple
 
 import torch
@@ -28,6 +29,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.step_count = 0
+        self._scratch = None
         self.param_groups = [dict(lr=self.lr, betas=self.betas, eps=self.eps, params=list(params))]   # (torch-like, read-only)
 
     # torch.nn.utils.clip_grad_norm_(params, max_norm): no host synchronisation
@@ -49,6 +51,25 @@ class FlatAdam:
         bc2 = 1 - b2 ** self.step_count
         denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(self.eps)
         self.flat_param.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
+
+    @torch.no_grad()
+    def clip_step_(self, max_norm: float) -> torch.Tensor:
+        """clip_(max_norm) + step() in two HIP launches (sl_clip_adam) instead of a dozen element-wise torch kernels; falls
+        back to the torch statements off the GPU.  Returns the gradient norm before clipping (a device scalar)."""
+        g = self.sync.flat
+        if not g.is_cuda or os.environ.get("SHADOW_FUSED_ADAM", "1") == "0":
+            total = self.clip_(max_norm)
+            self.step()
+            return total
+        from . import _lib, ops
+        lib = _lib.load()
+        if self._scratch is None:
+            self._scratch = torch.empty(int(lib.sl_clip_adam_scratch_floats()), dtype=torch.float32, device=g.device)
+        self.step_count += 1
+        _lib.check(lib.sl_clip_adam(self.flat_param.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                    g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, float(max_norm),
+                                    self._scratch.data_ptr(), ops._stream(g)))
+        return self._scratch[-1]
 
     def zero_grad(self, set_to_none: bool = False):
         self.sync.zero()

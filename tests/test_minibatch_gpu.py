@@ -490,3 +490,36 @@ def test_flat_adam_equals_torch_adam():
     np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)
     for k in pa:
         np.testing.assert_allclose(pb[k].numpy(), pa[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("n,scale", [(1003, 0.01), (4096, 3.0), (600001, 0.5), (3, 100.0)])
+def test_fused_clip_adam_equals_the_torch_statements(n, scale, monkeypatch):
+    """sl_clip_adam (norm partials + one update pass) against FlatAdam's torch statements (= clip_grad_norm_ +
+    torch.optim.Adam arithmetic): gradient after clipping, both moments and the parameters over four steps, with the
+    clip active (large gradients) and inactive, lengths that are not a multiple of four."""
+    from shadow_gnn_amd.optim import FlatAdam
+
+    class _Sync:                                       # what FlatAdam needs of dist.GradSync
+        def __init__(self, p):
+            self.params = [p]
+            self.flat = torch.zeros(p.numel(), dtype=torch.float32, device=p.device)
+            p.grad = self.flat.view_as(p)
+
+        def zero(self):
+            self.flat.zero_()
+
+    def run(fused):
+        monkeypatch.setenv("SHADOW_FUSED_ADAM", "1" if fused else "0")
+        g = torch.Generator(device=DEV).manual_seed(n)
+        p = torch.nn.Parameter(torch.randn(n, device=DEV, generator=g))
+        opt = FlatAdam(_Sync(p), lr=3e-3)
+        norms = []
+        for _ in range(4):
+            opt.sync.flat.copy_(torch.randn(n, device=DEV, generator=g) * scale)
+            norms.append(float(opt.clip_step_(5.0)))
+        return norms, opt.sync.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.flat_param.clone()
+    a, b = run(False), run(True)
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+    for x, y, name in zip(a[1:], b[1:], ("clipped grad", "exp_avg", "exp_avg_sq", "param")):
+        # (the clip factor differs in its last bit with the reduction order of the norm; moments cancel towards zero)
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-6, atol=5e-7 * float(x.abs().max()), err_msg=name)
