@@ -908,10 +908,18 @@ __global__ void act_norm_finish_kernel(const float *__restrict__ partial, uint32
   const uint32_t b = blockIdx.y / 3, kind = blockIdx.y % 3;
   float *dst = kind == 0 ? dscale : (kind == 1 ? doffset : dbias);
   if (!dst) return;
-  float acc = 0.f;
-  if (f < F)
-    for (uint32_t k = g; k < nblocks; k += 16) acc += partial[(((size_t)k * nb + b) * 3 + kind) * F + f];
-  red[g][fl] = acc;
+  // four running sums per thread: the partial rows are far apart (L2 round trips), one dependent chain of ~80 loads
+  // per thread made this kernel 20 us long
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (f < F) {
+    uint32_t k = g;
+    for (; k + 48 < nblocks; k += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) a4[u] += partial[(((size_t)(k + 16 * u) * nb + b) * 3 + kind) * F + f];
+    }
+    for (int u = 0; k < nblocks; k += 16, u++) a4[u] += partial[(((size_t)k * nb + b) * 3 + kind) * F + f];
+  }
+  red[g][fl] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   __syncthreads();
   if (g == 0 && f < F) {
     float s = 0.f;
