@@ -228,8 +228,15 @@ __global__ void onehot_linear_finish_kernel(const float *__restrict__ partial, u
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (dim + 1) * F) return;
   const uint32_t c = t / F, f = t % F;
-  float sum = 0.f;
-  for (uint32_t b = 0; b < nblocks; b++) sum += partial[((size_t)b * (dim + 1) + c) * F + f];
+  // (four running sums: the partial rows are L2 round trips apart, one dependent chain made this a 20 us kernel)
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t b = 0;
+  for (; b + 4 <= nblocks; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) a4[u] += partial[((size_t)(b + u) * (dim + 1) + c) * F + f];
+  }
+  for (int u = 0; b < nblocks; b++, u++) a4[u] += partial[((size_t)b * (dim + 1) + c) * F + f];
+  const float sum = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   if (c < dim) dWt[(size_t)c * F + f] = sum;
   else if (db) db[f] = sum;
 }
