@@ -223,22 +223,36 @@ onehot_linear_bwd_kernel(const float *__restrict__ dout, int64_t lddo, const uin
 }
 
 // dWt[c,f] (c < dim) and db[f] (c == dim): ordered sum of the block partials
-__global__ void onehot_linear_finish_kernel(const float *__restrict__ partial, uint32_t nblocks, uint32_t F,
-                                            uint32_t dim, float *__restrict__ dWt, float *__restrict__ db) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (dim + 1) * F) return;
-  const uint32_t c = t / F, f = t % F;
-  // (four running sums: the partial rows are L2 round trips apart, one dependent chain made this a 20 us kernel)
+// dWt / db = sum over the blocks' partial rows, fixed order (deterministic).  A workgroup owns 32 outputs; 32 slices of
+// the block range per output, four running sums per thread, slices combined through LDS in slice order (one thread per
+// output over all blocks was a 50 us chain of L2 round trips).
+constexpr int kOhCols = 32, kOhSlices = 32;
+__global__ void __launch_bounds__(kOhCols * kOhSlices)
+onehot_linear_finish_kernel(const float *__restrict__ partial, uint32_t nblocks, uint32_t F, uint32_t dim,
+                            float *__restrict__ dWt, float *__restrict__ db) {
+  __shared__ float red[kOhSlices][kOhCols];
+  const uint32_t col = threadIdx.x % kOhCols, sl = threadIdx.x / kOhCols;
+  const uint32_t t = blockIdx.x * kOhCols + col, total = (dim + 1) * F;
+  const uint32_t per = (nblocks + kOhSlices - 1) / kOhSlices;
+  const uint32_t b0 = sl * per, b1 = min(nblocks, b0 + per);
   float a4[4] = {0.f, 0.f, 0.f, 0.f};
-  uint32_t b = 0;
-  for (; b + 4 <= nblocks; b += 4) {
+  if (t < total) {
+    uint32_t b = b0;
+    for (; b + 4 <= b1; b += 4) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) a4[u] += partial[((size_t)(b + u) * (dim + 1) + c) * F + f];
+      for (int u = 0; u < 4; u++) a4[u] += partial[(size_t)(b + u) * total + t];
+    }
+    for (int u = 0; b < b1; b++, u++) a4[u] += partial[(size_t)b * total + t];
   }
-  for (int u = 0; b < nblocks; b++, u++) a4[u] += partial[((size_t)b * (dim + 1) + c) * F + f];
-  const float sum = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-  if (c < dim) dWt[(size_t)c * F + f] = sum;
-  else if (db) db[f] = sum;
+  red[sl][col] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  __syncthreads();
+  if (sl == 0 && t < total) {
+    float sum = 0.f;
+    for (int q = 0; q < kOhSlices; q++) sum += red[q][col];
+    const uint32_t c = t / F, f = t % F;
+    if (c < dim) dWt[(size_t)c * F + f] = sum;
+    else if (db) db[f] = sum;
+  }
 }
 
 }  // namespace
@@ -308,8 +322,8 @@ extern "C" int sl_onehot_linear_bwd(const float *d_dout, int64_t lddo, const uin
   hipLaunchKernelGGL(onehot_linear_bwd_kernel, dim3(blocks), dim3(kPB), 0, st, d_dout, lddo, d_codes, n, F, dim,
                      d_partial);
   SHD_HIP(hipGetLastError());
-  hipLaunchKernelGGL(onehot_linear_finish_kernel, dim3(((dim + 1) * F + 255) / 256), dim3(256), 0, st, d_partial,
-                     blocks, F, dim, d_dWt, d_dbias);
+  hipLaunchKernelGGL(onehot_linear_finish_kernel, dim3(((dim + 1) * F + kOhCols - 1) / kOhCols), dim3(kOhCols * kOhSlices), 0, st,
+                     d_partial, blocks, F, dim, d_dWt, d_dbias);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -38,15 +38,20 @@ def init_from_env(backend: Optional[str] = None):
 
 
 class GradSync:
-    """All gradients live in one flat fp32 buffer (``param.grad`` are views of it), so zeroing them is one
-    memset and the data-parallel exchange is a few SUM all-reduces over contiguous slices of it.
+    """All gradients end up in one flat fp32 buffer: the data-parallel exchange is a few SUM all-reduces over contiguous
+    slices of it, clip-by-global-norm and Adam (optim.FlatAdam) run over it in two launches.
 
-    Overlap with backward: the buffer is cut into ``num_buckets`` slices at parameter boundaries, in REVERSE
-    parameter order (the order backward produces gradients in).  A post-accumulate hook per parameter counts a
-    slice down; when it is complete its all-reduce is issued asynchronously (RCCL runs it on its own stream,
-    ordered behind the kernels queued so far) while backward keeps producing the earlier layers' gradients.
-    Slices are always issued in slice order, so every rank issues the same sequence of collectives whatever
-    order its hooks fire in -- including a rank that had nothing to back-propagate this step."""
+    Packing: during backward ``param.grad`` is None, so autograd ASSIGNS each gradient (with ``.grad`` pre-set to a view of
+    the flat buffer it would launch one tiny add kernel per parameter -- 36 per step for SAGE-5); a slice's gradients are
+    copied into the buffer with ONE multi-tensor copy when the slice is complete, and ``param.grad`` becomes the view.
+    Parameters that received no gradient leave zeros (the buffer is cleared at the start of the step).
+
+    Overlap with backward: the buffer is cut into ``num_buckets`` slices at parameter boundaries, in REVERSE parameter
+    order (the order backward produces gradients in).  A post-accumulate hook per parameter counts a slice down; when it
+    is complete it is packed and its all-reduce is issued asynchronously (RCCL runs it on its own stream, ordered behind
+    the kernels queued so far) while backward keeps producing the earlier layers' gradients.  Slices are always issued in
+    slice order, so every rank issues the same sequence of collectives whatever order its hooks fire in -- including a
+    rank that had nothing to back-propagate this step."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], world_size: Optional[int] = None, group=None,
                  num_buckets: int = 2, overlap: bool = True):
@@ -58,9 +63,11 @@ class GradSync:
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self._off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self._views = []
         for i, p in enumerate(self.params):
             assert p.dtype == torch.float32
-            p.grad = self.flat[self._off[i]:self._off[i + 1]].view_as(p)
+            self._views.append(self.flat[self._off[i]:self._off[i + 1]].view_as(p))
+            p.grad = self._views[i]
         # slices (lo_param, hi_param) over the parameter list; slice 0 holds the LAST parameters
         self._slices = []
         nb = max(1, min(int(num_buckets), len(self.params)))
@@ -97,10 +104,28 @@ class GradSync:
             self._issue_ready()
         return hook
 
-    def _issue(self, s):
+    def _pack(self, s):
+        """Gradients of slice s into the flat buffer (one multi-tensor copy); ``.grad`` becomes the buffer's view."""
         lo, hi = self._slices[s]
-        self._works.append(dist.all_reduce(self.flat[self._off[lo]:self._off[hi]], op=dist.ReduceOp.SUM,
-                                           group=self.group, async_op=True))
+        dst, src = [], []
+        for i in range(lo, hi):
+            g = self.params[i].grad
+            if g is None or g is self._views[i]:
+                continue
+            if g.data_ptr() == self._views[i].data_ptr():      # (a foreign view of the same storage: already in place)
+                continue
+            dst.append(self._views[i]); src.append(g.detach().reshape(self._views[i].shape))
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for i in range(lo, hi):
+            self.params[i].grad = self._views[i]
+
+    def _issue(self, s):
+        self._pack(s)
+        if self.world_size > 1:
+            lo, hi = self._slices[s]
+            self._works.append(dist.all_reduce(self.flat[self._off[lo]:self._off[hi]], op=dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True))
 
     def _issue_ready(self):
         while self._next < len(self._slices) and self._left[self._next] <= 0:
@@ -108,26 +133,22 @@ class GradSync:
             self._next += 1
 
     def zero(self):
-        """Start of a step: clear the buffer and arm the hooks."""
+        """Start of a step: clear the buffer, detach the ``.grad`` views (autograd then assigns instead of adding), arm
+        the hooks."""
         self.flat.zero_()
-        # something may have dropped a .grad (zero_grad(set_to_none=True)): re-attach the views.  (A .grad that is set
-        # stays the view: autograd accumulates into it in place.)
-        if any(p.grad is None for p in self.params):
-            for i, p in enumerate(self.params):
-                if p.grad is None:
-                    p.grad = self.flat[self._off[i]:self._off[i + 1]].view_as(p)
+        lazy = os.environ.get("SHADOW_GRAD_PACK", "1") != "0"      # (0: .grad stay views, autograd adds into them)
+        for i, p in enumerate(self.params):
+            p.grad = None if lazy else self._views[i]
         self._left = [hi - lo for lo, hi in self._slices]
         self._next = 0
         self._works = []
         self._armed = self.overlap
 
     def all_reduce(self, _params=None):
-        """End of backward: issue whatever has not gone out yet (parameters without a gradient this step, a
-        rank that skipped backward, overlap off) and wait for the sums.  The result is the global-batch
-        gradient when every rank scaled its loss by its share of the batch."""
+        """End of backward: pack and issue whatever has not gone out yet (parameters without a gradient this step, a
+        rank that skipped backward, overlap off, a single process) and wait for the sums.  The result is the global-batch
+        gradient when every rank scaled its loss by its share of the batch; ``param.grad`` are views of the buffer."""
         self._armed = False
-        if self.world_size <= 1:
-            return
         while self._next < len(self._slices):
             self._issue(self._next)
             self._next += 1
