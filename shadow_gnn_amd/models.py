@@ -272,12 +272,15 @@ class DeepGNN(nn.Module):
         fwd["feat_ens"] = list(fwd["feat_ens"])          # the step consumes the record (features are augmented)
         fwd["tail_ens"] = getattr(batch_data, "tail_ens", None)
         labels = batch_data.label
+        # class indices as they come for the softmax loss (no one-hot -> argmax round trip); the returned record carries
+        # one-hot rows like the reference's label matrix
+        index = labels.to(torch.int64) if (labels.dim() == 1 and not self.sigmoid_loss) else None
         if labels.dim() == 1 and self.num_classes > 1:
             labels = F.one_hot(labels.to(torch.int64), num_classes=self.num_classes)
         if training:
             self._begin_update()
             preds, emb_ens = self(mode, dropedge=self.dropedge, **fwd)
-            loss = self._loss(preds, labels)
+            loss = self._loss(preds, labels if index is None else index)
             weight = loss_scale * (getattr(batch_data, "loss_weight", 1.0) if self.grad_sync is not None else 1.0)
             (loss if weight == 1.0 else loss * weight).backward()
             self._finish_update()
@@ -286,7 +289,7 @@ class DeepGNN(nn.Module):
                 self.eval()
             with torch.no_grad():
                 preds, emb_ens = self(mode, dropedge=0., **fwd)
-                loss = self._loss(preds, labels)
+                loss = self._loss(preds, labels if index is None else index)
         assert preds.shape[0] == labels.shape[0]
         return {'batch_size': preds.shape[0], 'loss': loss, 'labels': labels,
                 'preds': self.predict(preds), 'emb_ens': emb_ens}
