@@ -861,7 +861,6 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       if (capn >= (1u << kRankShift)) return set_error(SG_ERR_INVALID, "sg_sample: subgraphs of %u nodes exceed the scan's row field", capn);
       p.bit_words = env_u32("SHADOW_SG_BITWORDS", big ? kBitWordsBig : kBitWords);
       if (p.bit_words & (p.bit_words - 1)) p.bit_words = big ? kBitWordsBig : kBitWords;
-      p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : 2048)));
       p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
       uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", 512);
       if (T != 256 && T != 512 && T != 1024) T = 512;
@@ -869,6 +868,10 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       // SHADOW_SG_SCAN_IMPL=window: the general (row-window) kernel for plain calls too (A/B measurements, tests)
       const char *impl_env = getenv("SHADOW_SG_SCAN_IMPL");
       const bool flat = plain && !(impl_env && !strcmp(impl_env, "window"));
+      // candidate list: about one id in a hundred of a round.  The flat kernel trades 512 entries for a longer run list --
+      // whole subgraphs then fit one round (scripts/sweep_capm.sh: 23 % fewer rounds, 0.205 -> 0.200 ms at 1 024 roots,
+      // 1.105 -> 1.047 ms at 8 192); a round that overflows the list is redone on half the quads.
+      p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : (flat ? 1536 : 2048))));
       p.run_cap = 0;
       p.seg_pad = std::min<uint32_t>(256, env_u32("SHADOW_SG_SEG_PAD", 25) - 1);   // (env value = pad + 1: 1 means none; default 24, scripts/sweep_seg_pad.sh)
       if (flat) {
