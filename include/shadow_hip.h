@@ -391,7 +391,8 @@ typedef struct {
  * backward: act_norm backward -> A^T dZn -> dX = [dZs | A^T dZn] . [Ws ; Wn] (one K = 2 Fout product; d_dX NULL: not
  * wanted) -> the two weight gradients; d_buf is [n, 3 Fout] scratch, d_an_partial as for sl_act_norm_bwd (nb = 2),
  * d_tn_partial as for sl_gemm_tn_f32; d_dbias [2, Fout] or NULL.  Fout % 4 == 0, <= 256 (input gradient: Fout % 32
- * == 0, Fin <= 256); the same kernels in the same order as the separate entries: identical results.             */
+ * == 0, Fin <= 256).  Forward: when sl_gemm_act_norm_supported(Fout, Fin) the two products and the act / norm run as ONE
+ * kernel (sl_gemm_act_norm_fwd below), otherwise the same kernels in the same order as the separate entries.         */
 size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout);
 int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_Ws,
                 int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
@@ -403,6 +404,63 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
                 float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
                 float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                 float *d_an_partial, float *d_tn_partial, void *d_pack, void *stream);
+
+/* The same products with the activation + feature normalisation in the GEMM's epilogue (csrc/gemm_fused.hip; a
+ * wavefront of the split-bf16 kernel owns 32 whole output rows, the unit `_f_norm_feat` works on -- layers.py:329-338):
+ *   sl_gemm_act_norm_fwd   Z_b = A_b . W_b^T for b < nb <= 2 in ONE launch (d_packed_B: the nb images of
+ *                          sl_gemm_pack_b back to back; all branches share M, N, K), Z_b written (without bias), and
+ *                          out = out_scale * sum_b norm_b(act_b(Z_b + bias_b)) [+ dropout / dual output exactly as
+ *                          sl_act_norm_fwd defines them] written from the accumulators: no second pass over Z.
+ *                          N % 4 == 0, 16 <= N <= 256 (normalisation segment = N); operands 16-byte aligned, ld % 4 == 0.
+ *   sl_gemm_an_bwd         G = A . B^T (A [M, K], d_packed_B its image, G [M, N]) is the gradient of a GraphSAGE layer's
+ *                          output (through that layer's fused output dropout (drop_p, drop_seed) when drop_p > 0); G is
+ *                          not written: the epilogue applies sl_act_norm_bwd (nb = 2, seg = N) to it row by row and
+ *                          writes dZ_b, dscale, doffset and (d_dbias != NULL) dbias.  d_partial:
+ *                          sl_gemm_an_bwd_partial_floats(M, N, nb) floats (one partial row per workgroup, added in a
+ *                          fixed order).
+ * sl_sage_fwd / sl_gcn_fwd use the forward form whenever sl_gemm_act_norm_supported(Fout, Fin) (same arithmetic per
+ * row as sl_act_norm_fwd on 64 lanes; results equal to rounding of the row sums).  sl_set_fused_epilogue(0 | 1) switches
+ * it (returns the previous setting; a negative argument only queries; the environment variable
+ * SHADOW_FUSED_EPILOGUE=0 sets the initial state) -- the A/B handle of the tests and benchmarks.                  */
+int sl_set_fused_epilogue(int on);
+int sl_gemm_act_norm_supported(uint32_t N, uint32_t K);
+int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const void *d_packed_B, uint32_t M, uint32_t N,
+                         uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
+                         const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo, float drop_p,
+                         uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, void *stream);
+size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb);
+int sl_gemm_an_bwd(const float *d_A, int64_t lda, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K, int nb,
+                   const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act, const float *d_scale,
+                   const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                   float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed, void *stream);
+
+/* Backward of a GraphSAGE layer chained with the layer below it (consecutive GraphSAGE layers where nothing but this
+ * layer reads the lower layer's output -- residue 'none' + centre pooling, shaDow/layers.py:159-163): the input gradient
+ * of this layer IS the output gradient of the layer below, so instead of writing it (d_dX) the K = 2 Fout product's
+ * epilogue produces the lower layer's dZs / dZn / dscale / doffset / dbias (sl_gemm_an_bwd) into the buffers `below`
+ * names; the lower layer's own call then passes dz_ready = 1 (its d_buf = below->buf; d_dout*, d_dscale, d_doffset,
+ * d_an_partial and the forward tensors Zs / Zn are not touched) and only runs A^T dZn, its own input-gradient product
+ * and the two weight gradients.  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, stream).                             */
+typedef struct {
+  const float *Zs, *Zn;            /* [n, F] pre-activations of the layer below (dense rows) */
+  const float *bs, *bn;            /* its biases (may be NULL) */
+  const float *scale, *offset;     /* [2, F] */
+  int act;
+  float drop_p;                    /* its fused OUTPUT dropout (= this layer's input dropout), 0: none */
+  uint64_t drop_seed;
+  uint32_t F;                      /* its output width (= this layer's Fin) */
+  float *buf;                      /* [n, 3 F]: receives dZs in columns [0, F) and dZn in [2 F, 3 F) */
+  float *dscale, *doffset, *dbias; /* [2, F] each; dbias may be NULL */
+  float *partial;                  /* sl_sage_chain_partial_floats(n, F) floats */
+} sl_sage_below;
+size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F);
+int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
+                      const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws, const float *d_bs,
+                      const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale, const float *d_offset, int act,
+                      float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
+                      float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
+                      float *d_an_partial, float *d_tn_partial, void *d_pack, int dz_ready, const sl_sage_below *below,
+                      void *stream);
 
 /* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
  * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /

@@ -52,6 +52,15 @@ class SgBatchCounts(C.Structure):
     ]
 
 
+class SlSageBelow(C.Structure):
+    """sl_sage_below: the GraphSAGE layer whose act_norm backward rides in the layer above's input-gradient product."""
+    _fields_ = [
+        ("Zs", C.c_void_p), ("Zn", C.c_void_p), ("bs", C.c_void_p), ("bn", C.c_void_p), ("scale", C.c_void_p),
+        ("offset", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("F", C.c_uint32),
+        ("buf", C.c_void_p), ("dscale", C.c_void_p), ("doffset", C.c_void_p), ("dbias", C.c_void_p), ("partial", C.c_void_p),
+    ]
+
+
 class SlNormAdj(C.Structure):
     _fields_ = [
         ("indptr", C.c_void_p), ("indices", C.c_void_p), ("edge_w", C.c_void_p), ("row_scale", C.c_void_p),
@@ -123,6 +132,19 @@ SIGNATURES = {
     "sl_sage_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),
+    "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
+                                     _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, C.c_int, C.POINTER(SlSageBelow), _P]),
+    "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
+    "sl_gemm_act_norm_supported": (C.c_int, [C.c_uint32, C.c_uint32]),
+    "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), _P, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
+                                        C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P]),
+    "sl_gemm_an_bwd_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
+    "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
+                                  C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
+                                  C.c_float, C.c_uint64, _P]),
     "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
@@ -151,7 +173,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 10      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 11      # sg_abi_version() of the library these signatures describe
 
 
 def load():

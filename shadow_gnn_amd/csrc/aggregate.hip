@@ -18,33 +18,11 @@
 #include <algorithm>
 
 #include "common.h"
+#include "actnorm_common.h"
 
 namespace shadow {
 
 constexpr int kBlock = 256;
-
-__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
-// streaming variants (read once / written once, far larger than the caches): non-temporal hint.  Measured on the products
-// benchmark (same box, A/B of two builds): act_norm forward 0.190 -> 0.187 ms, the rest unchanged; -DSHADOW_NO_NT_STREAM
-// builds the plain accesses.
-typedef float v4f_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld4s(const float *p) {
-#ifndef SHADOW_NO_NT_STREAM
-  const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return ld4(p);
-#endif
-}
-__device__ __forceinline__ void st4s(float *p, float4 v) {
-#ifndef SHADOW_NO_NT_STREAM
-  v4f_nt w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-  __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt *>(p));
-#else
-  st4(p, v);
-#endif
-}
 
 // ---------------------------------------------------------------- gather
 // out[i, :] = table[idx[i], :]; F % 4 == 0, rows 16-B aligned.
@@ -682,27 +660,6 @@ __global__ void spmm_scalar_kernel(const uint32_t *__restrict__ indptr, const ui
 }
 
 // ---------------------------------------------------------------- act + row norm
-// F_ACT of shaDow/layers.py:26-34 (prelu variants carry parameters and stay in torch)
-__device__ __forceinline__ float act_fwd(int act, float x) {
-  switch (act) {
-    case 1: return x > 0.f ? x : 0.f;                       // relu
-    case 2: return x > 0.f ? x : expm1f(x);                 // elu (alpha = 1)
-    case 3: return tanhf(x);                                // tanh
-    case 4: return x > 0.f ? x : 0.2f * x;                  // leakyrelu(0.2)
-    default: return x;                                      // 0: identity ("I")
-  }
-}
-// derivative given the input x and the output h = act(x)
-__device__ __forceinline__ float act_bwd(int act, float x, float h) {
-  switch (act) {
-    case 1: return x > 0.f ? 1.f : 0.f;
-    case 2: return x > 0.f ? 1.f : h + 1.0f;                // d/dx expm1(x) = exp(x) = h + 1
-    case 3: return 1.f - h * h;
-    case 4: return x > 0.f ? 1.f : 0.2f;
-    default: return 1.f;
-  }
-}
-
 struct ActNormParams {
   const float *bias[2];    // optional per-branch bias [F] added to Z before the activation (fused Linear bias)
   float *dbias;            // [nb, F] bias gradients (backward, optional)
@@ -734,11 +691,6 @@ struct ActNormParams {
   float *out2; int64_t ldo2;
   const float *dout2; int64_t lddo2;
 };
-
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return h;
-}
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
 __device__ __forceinline__ uint32_t drop_keep4(const ActNormParams &p, uint64_t r, uint32_t f) {
@@ -1253,6 +1205,18 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
+
+namespace shadow {
+// the second stage of the parameter-gradient reduction for callers outside this file (gemm_fused.hip: the act_norm
+// backward that rides in a GEMM epilogue leaves one partial row per workgroup)
+int act_norm_finish_launch(const float *partial, uint32_t nblocks, int nb, uint32_t F, float *dscale, float *doffset, float *dbias,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(act_norm_finish_kernel, dim3((F + 63) / 64, nb * 3), dim3(1024), 0, st, partial, nblocks, nb, F, dscale, doffset,
+                     dbias);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+}  // namespace shadow
 
 constexpr uint32_t kActNormBwdBlocks = 2048;  // == rows of the partial buffer
 

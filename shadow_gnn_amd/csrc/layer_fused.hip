@@ -25,6 +25,12 @@ int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx,
   return sl_spmm_csr_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, st);
 }
 
+// the GEMM-epilogue forms (gemm_fused.hip) take 16-byte aligned operands with row pitches of whole float4s
+bool fused_epilogue_ok(uint32_t Fout, uint32_t Fin, const float *A0, int64_t lda0, const float *A1, int64_t lda1) {
+  auto ok = [](const float *p, int64_t ld) { return !p || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0); };
+  return sl_gemm_act_norm_supported(Fout, Fin) && ok(A0, lda0) && ok(A1, lda1);
+}
+
 }  // namespace
 
 extern "C" size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout) {
@@ -49,14 +55,86 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
   const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
   if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pb, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_nt_f32(d_X, ldx, pk, d_Zs, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_nt_f32(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
-  const float *Z[2] = {d_Zs, d_Zn};
   const int64_t ldz[2] = {Fout, Fout};
   const float *bias[2] = {d_bs, d_bn};
   const int acts[2] = {act, act};
+  if (fused_epilogue_ok(Fout, Fin, d_X, ldx, d_AX, ldax)) {
+    // both products in one launch, bias / act / norm / branch sum (/ dropout) in its epilogue (gemm_fused.hip)
+    const float *A[2] = {d_X, d_AX};
+    const int64_t lda[2] = {ldx, ldax};
+    float *Zw[2] = {d_Zs, d_Zn};
+    return sl_gemm_act_norm_fwd(2, A, lda, pk, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
+                                drop_seed, d_out_dropped, Fout, stream);
+  }
+  if ((rc = sl_gemm_nt_f32(d_X, ldx, pk, d_Zs, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_nt_f32(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  const float *Z[2] = {d_Zs, d_Zn};
   return sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
                          d_out_dropped, Fout, stream);
+}
+
+extern "C" size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F) { return sl_gemm_an_bwd_partial_floats(n, F, 2); }
+
+// dz_ready: the layer above already left this layer's dZs / dZn in d_buf and its dscale / doffset / dbias (its own call
+// had `below` pointing here); below != NULL: the input gradient is not written -- the epilogue of the K = 2 Fout product
+// turns it into the dZs / dZn of the layer below on the fly (sl_gemm_an_bwd).
+extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax,
+                                 const float *d_Zs, const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws,
+                                 const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
+                                 const float *d_offset, int act, float drop_p, uint64_t drop_seed, const float *d_dout,
+                                 const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
+                                 float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
+                                 void *d_pack, int dz_ready, const sl_sage_below *below, void *stream) {
+  if (!adj || !d_X || !d_AX || !d_Ws || !d_Wn || !d_dWs || !d_dWn || !d_buf || !d_tn_partial || !d_pack)
+    return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
+  if (!dz_ready && (!d_Zs || !d_Zn || !d_scale || !d_offset || !d_dscale || !d_doffset || !d_an_partial || (!d_dout && !d_dout_dropped)))
+    return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
+  if (Fout > 256 || (Fout & 3) || Fin > 256 || (Fin & 3)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: widths %u -> %u unsupported", Fin, Fout);
+  if ((d_dX || below) && ((2 * Fout) % 32 || Fout % 32)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs Fout %% 32 == 0");
+  if (below && (below->F != Fin || !below->Zs || !below->Zn || !below->scale || !below->offset || !below->buf || !below->dscale ||
+                !below->doffset || !below->partial))
+    return set_error(SG_ERR_INVALID, "sl_sage_bwd: incomplete description of the layer below");
+  const uint32_t n = adj->n;
+  if (n == 0) return SG_OK;
+  int rc;
+  // dZs lives in the left third of buf [n, 3 Fout], dZn in the right third (the transposed SpMM reads it and writes
+  // A^T dZn into the middle third): [dZs | A^T dZn | dZn]
+  float *dZs = d_buf, *dZn = d_buf + 2 * (size_t)Fout;
+  const int64_t ld3 = 3 * (int64_t)Fout;
+  if (!dz_ready) {
+    const float *Z[2] = {d_Zs, d_Zn};
+    const int64_t ldz[2] = {Fout, Fout};
+    const float *bias[2] = {d_bs, d_bn};
+    const int acts[2] = {act, act};
+    float *dZ[2] = {dZs, dZn};
+    const int64_t lddz[2] = {ld3, ld3};
+    if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
+                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
+      return rc;
+  }
+  if (d_dX || below) {
+    if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
+    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream)) != SG_OK) return rc;
+    // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
+    if ((rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream)) != SG_OK) return rc;
+    if (below) {
+      const uint32_t Fb = below->F;
+      const float *Zb[2] = {below->Zs, below->Zn};
+      const int64_t ldzb[2] = {Fb, Fb};
+      const float *biasb[2] = {below->bs, below->bn};
+      const int actsb[2] = {below->act, below->act};
+      float *dZb[2] = {below->buf, below->buf + 2 * (size_t)Fb};
+      const int64_t lddzb[2] = {3 * (int64_t)Fb, 3 * (int64_t)Fb};
+      if ((rc = sl_gemm_an_bwd(d_buf, ld3, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
+                               lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
+                               stream)) != SG_OK)
+        return rc;
+    } else if ((rc = sl_gemm_nt_f32(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
+      return rc;
+    }
+  }
+  if ((rc = sl_gemm_tn_f32(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
+  return sl_gemm_tn_f32(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
 }
 
 extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax,
@@ -66,37 +144,9 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                            const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
                            float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
                            void *d_pack, void *stream) {
-  if (!adj || !d_X || !d_AX || !d_Zs || !d_Zn || !d_Ws || !d_Wn || !d_scale || !d_offset || !d_dWs || !d_dWn || !d_dscale ||
-      !d_doffset || !d_buf || !d_an_partial || !d_tn_partial || !d_pack || (!d_dout && !d_dout_dropped))
-    return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
-  if (Fout > 256 || (Fout & 3) || Fin > 256 || (Fin & 3)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: widths %u -> %u unsupported", Fin, Fout);
-  if (d_dX && ((2 * Fout) % 32 || Fout % 32)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs Fout %% 32 == 0");
-  const uint32_t n = adj->n;
-  if (n == 0) return SG_OK;
-  int rc;
-  // act_norm backward: dZs into the left half of buf [n, 2 Fout], dZn into the right half (in place of A^T dZn later)
-  const float *Z[2] = {d_Zs, d_Zn};
-  const int64_t ldz[2] = {Fout, Fout};
-  const float *bias[2] = {d_bs, d_bn};
-  const int acts[2] = {act, act};
-  // dZn needs its own dense [n, Fout] home: the transposed SpMM reads it and writes the right half of buf.  The
-  // caller's buf is [n, 3 Fout]: [dZs | A^T dZn | dZn].
-  float *dZs = d_buf, *dZn = d_buf + 2 * (size_t)Fout;
-  float *dZ[2] = {dZs, dZn};
-  const int64_t ld3 = 3 * (int64_t)Fout;
-  const int64_t lddz[2] = {ld3, ld3};
-  if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
-                            d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
-    return rc;
-  if (d_dX) {
-    if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
-    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream)) != SG_OK) return rc;
-    // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
-    if ((rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream)) != SG_OK) return rc;
-    if ((rc = sl_gemm_nt_f32(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) return rc;
-  }
-  if ((rc = sl_gemm_tn_f32(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
-  return sl_gemm_tn_f32(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+  return sl_sage_bwd_chain(adj, d_X, ldx, d_AX, ldax, d_Zs, d_Zn, Fin, Fout, d_Ws, ldws, d_bs, d_Wn, ldwn, d_bn, d_scale, d_offset, act,
+                           drop_p, drop_seed, d_dout, d_dout_dropped, d_dX, d_dWs, d_dWn, d_dbias, d_dscale, d_doffset, d_buf,
+                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -120,11 +170,18 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
   int rc;
   if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_nt_f32(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
-  const float *Z[1] = {d_Z};
   const int64_t ldz[1] = {Fout};
   const float *bias[1] = {d_b};
   const int acts[1] = {act};
+  if (fused_epilogue_ok(Fout, Fin, d_AX, ldax, nullptr, 0)) {
+    const float *A[1] = {d_AX};
+    const int64_t lda[1] = {ldax};
+    float *Zw[1] = {d_Z};
+    return sl_gemm_act_norm_fwd(1, A, lda, d_pack, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
+                                drop_seed, d_out_dropped, Fout, stream);
+  }
+  if ((rc = sl_gemm_nt_f32(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  const float *Z[1] = {d_Z};
   return sl_act_norm_fwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
                          d_out_dropped, Fout, stream);
 }

@@ -99,6 +99,9 @@ class shaDowLayer(nn.Module):
         self.out_dropout = 0.0
         self.out_dual = False
         self.dropped_out = None
+        # set per step by DeepGNN._plan_dropout_fusion: the next layer is the ONLY reader of this layer's output, so the two
+        # layers' backward passes may be chained (ops.ChainLink; GraphSAGE only)
+        self.chain_next = False
         if norm not in ('norm_feat', 'none'):
             raise NotImplementedError("only norm in {'norm_feat', 'none'} (the reference's pairnorm path is unfinished, layers.py:358)")
         self.norm = norm
@@ -275,13 +278,14 @@ class GraphSAGE(shaDowLayer):
         if fused and isinstance(feat_in, ops.LazyRows):
             # layer 0 of the fast path: gather + input dropout in one pass (or inside the aggregation kernel)
             feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
-                                                 self.scale, self.offset, in_dropout=self._in_p(), **self._drop_kw()))
+                                                 self.scale, self.offset, in_dropout=self._in_p(), chain_next=self.chain_next,
+                                                 **self._drop_kw()))
             return feat_out, adj_norm, True, 0.
         feat_in = self.in_dropout(feat_in)
         if fused:
             # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)
             feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
-                                                 self.scale, self.offset, **self._drop_kw()))
+                                                 self.scale, self.offset, chain_next=self.chain_next, **self._drop_kw()))
         else:
             feat_neigh = self.spmm(adj_norm, feat_in)
             feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],

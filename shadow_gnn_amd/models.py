@@ -223,6 +223,9 @@ class DeepGNN(nn.Module):
                     and md.can_fuse_out_dropout())
             md.out_dropout = nxt.dropout if fuse else 0.0
             md.out_dual = bool(fuse and dual)
+            # nothing but the next layer reads this output (the read-out takes the last layer only): consecutive GraphSAGE
+            # nodes may chain their backward passes (ops.ChainLink)
+            md.chain_next = bool(not dual and isinstance(md, layers.GraphSAGE) and isinstance(nxt, layers.GraphSAGE))
             if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):

@@ -638,6 +638,78 @@ def linear(X, lin: "torch.nn.Linear"):
     return _Linear.apply(X, lin.weight, lin.bias)
 
 
+def gemm_act_norm_usable(Xs, Ws, seg, F) -> bool:
+    """The GEMM-epilogue form of Linear + act + norm (sl_gemm_act_norm_fwd): tall fp32 operands of one shape, the
+    normalisation over the whole row."""
+    X0 = Xs[0]
+    M, K = X0.shape
+    if not (GEMM_SPLIT and X0.is_cuda and M >= GEMM_SPLIT_MIN_ROWS and seg == F and _lib.load().sl_gemm_act_norm_supported(F, K)):
+        return False
+    for x, w in zip(Xs, Ws):
+        if not (x.shape == X0.shape and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0 and tuple(w.shape) == (F, K) and w.dtype == torch.float32):
+            return False
+    return True
+
+
+def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
+    """Z_b = X_b W_b^T (kept for the backward pass) and out = out_scale * sum_b norm_b(act(Z_b + bias_b)) [+ the fused
+    output dropout] from ONE kernel: the activation / normalisation runs in the GEMM's epilogue (csrc/gemm_fused.hip).
+    Returns (Zs, out) or (Zs, (out, out_dropped)) in dual mode."""
+    lib = _lib.load()
+    nb = len(Xs)
+    M, K = Xs[0].shape
+    F = Ws[0].shape[0]
+    dev = Xs[0].device
+    st = _stream(Xs[0])
+    pb = lib.sl_gemm_pack_bytes(F, K)
+    pack = torch.empty(nb * pb, dtype=torch.uint8, device=dev)
+    for b, w in enumerate(Ws):
+        wc = w.detach()
+        if wc.stride(1) != 1:
+            wc = wc.contiguous()
+        check(lib.sl_gemm_pack_b(wc.data_ptr(), wc.stride(0), F, K, pack.data_ptr() + b * pb, st))
+    Zs = [torch.empty(M, F, dtype=torch.float32, device=dev) for _ in range(nb)]
+    out = torch.empty(M, F, dtype=torch.float32, device=dev)
+    out2 = torch.empty_like(out) if _is_dual(drop) else None
+    lda = (C.c_int64 * nb)(*[x.stride(0) for x in Xs])
+    ldz = (C.c_int64 * nb)(*[F] * nb)
+    ac = (C.c_int * nb)(*codes)
+    # algorithmic bytes: read every X_b, write every Z_b and the output(s); flops of the nb products
+    nbytes = 4 * M * (nb * K + nb * F + F * (2 if out2 is not None else 1))
+    with _timed(f"gemm_act_norm_fwd_nb{nb}_N{F}" + ("" if K % 32 == 0 else "_Ktail"), nbytes, dev, flops=2 * nb * M * K * F):
+        check(lib.sl_gemm_act_norm_fwd(nb, _ptr_array(Xs), lda, pack.data_ptr(), M, F, K, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
+                                       sc.data_ptr(), of.data_ptr(), float(out_scale), out.data_ptr(), out.stride(0), float(drop[0]),
+                                       int(drop[1]), out2.data_ptr() if out2 is not None else None,
+                                       out2.stride(0) if out2 is not None else 0, st))
+    return Zs, (out if out2 is None else (out, out2))
+
+
+class ChainLink:
+    """Hand-over between two consecutive GraphSAGE nodes whose only connection is lower.out -> upper.X (residue 'none' +
+    centre pooling: nothing else reads the lower layer's output).  The upper node's input gradient IS the lower node's
+    output gradient, so the upper node's K = 2F input-gradient GEMM runs the lower node's act_norm backward in its
+    epilogue (sl_sage_bwd_chain) and leaves dZs / dZn / dscale / doffset / dbias here; what autograd carries between the
+    two nodes is a storage-less placeholder (`dummy`)."""
+
+    def __init__(self):
+        self.published = False       # forward: the lower node has stored what the upper node's epilogue needs
+        self.filled = False          # backward: the upper node has produced the lower node's dZ
+        self.Zs = self.Zn = self.biases = self.sc = self.of = None
+        self.act = 0
+        self.drop = (0.0, 0)
+        self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = None
+
+    def publish(self, Zs, Zn, biases, sc, of, act, drop):
+        self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
+        self.published = True
+
+    def release(self):
+        self.published = self.filled = False
+        self.Zs = self.Zn = self.biases = self.sc = self.of = None
+        self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = None
+
+
 class _LinearActNorm(torch.autograd.Function):
     """out = out_scale * sum_b norm_b(act_b(X_b W_b^T + bias_b)): the dense tail of a
     GCN / GraphSAGE / MLP layer as ONE autograd node.  GEMMs through mm_nt (split-bf16 MFMA kernel for
@@ -653,9 +725,12 @@ class _LinearActNorm(torch.autograd.Function):
         F = Ws[0].shape[0]
         sc = scale.reshape(nb, F).contiguous().float()
         of = offset.reshape(nb, F).contiguous().float()
-        Zs = [mm_nt(x, w) for x, w in zip(Xs, Ws)]
         bsc = [b.detach().contiguous() if b is not None else None for b in bs]
-        out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale, drop)
+        if gemm_act_norm_usable(Xs, Ws, seg, F):
+            Zs, out = gemm_act_norm_fwd(Xs, Ws, bsc, acts, sc, of, out_scale, drop)
+        else:
+            Zs = [mm_nt(x, w) for x, w in zip(Xs, Ws)]
+            out = _an_fwd(Zs, bsc, acts, sc, of, seg, out_scale, drop)
         ctx.save_for_backward(sc, of, *Xs, *Ws, *Zs, *[b if b is not None else sc.new_empty(0) for b in bsc])
         ctx.meta = (acts, seg, out_scale, nb, scale.shape, offset.shape, [b is not None for b in bs], drop)
         ctx.set_materialize_grads(False)
@@ -680,20 +755,26 @@ class _SageDense(torch.autograd.Function):
     """The whole dense part of a GraphSAGE layer (shaDow/layers.py:471-483) as ONE autograd node:
         out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn))
     so that the backward pass can use  dX = [dZs | A^T dZn] . [Ws ; Wn]  -- one GEMM with K = 2F that writes
-    dX once -- instead of two GEMMs, a transposed SpMM on the product and an add."""
+    dX once -- instead of two GEMMs, a transposed SpMM on the product and an add.  Consecutive nodes can be CHAINED
+    (``link_down`` / ``link_up``, see ChainLink): dX is then never written at all."""
+    fused_calls = 0          # one-call entries taken (tests assert on it: "the path that is timed is the path that is tested")
+    chained_calls = 0        # backward passes that produced the lower layer's dZ in the GEMM epilogue
+
     @staticmethod
-    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop, lazy=None, in_drop=0.0):
+    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop, lazy=None, in_drop=0.0, link_down=None, link_up=None):
         """``lazy`` (a LazyRows; X is then a dummy): layer 0 -- the aggregation kernel gathers the features, applies the
         layer's input dropout ``in_drop`` and leaves the dense copy the self Linear and the weight gradients read."""
         _need_cuda(Ws, Wn, scale, offset)
         c = adj.csr
         F = Ws.shape[0]
+        one_call = False
         if lazy is not None:
             AX, X, _seed = spmm_gather(adj, lazy, drop_p=in_drop, want_dense=True)
         else:
             X = _f32c(X)                   # (may be the [n, F] view of line-padded rows: every consumer takes a row pitch)
             _need_cuda(X)
-            if _SageDense._fusable(X, Ws, Wn):
+            one_call = _SageDense._fusable(X, Ws, Wn)
+            if one_call:
                 AX = None                  # the one-call entry below computes it
             else:
                 AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
@@ -703,12 +784,21 @@ class _SageDense(torch.autograd.Function):
         bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
         if AX is None:
             AX, Zs, Zn, out = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop)
+            _SageDense.fused_calls += 1
+        elif gemm_act_norm_usable([X, AX], [Ws, Wn], F, F):
+            (Zs, Zn), out = gemm_act_norm_fwd([X, AX], [Ws, Wn], bsc, acts, sc, of, 1.0, drop)
         else:
             Zs, Zn = mm_nt(X, Ws), mm_nt(AX, Wn)
             out = _an_fwd([Zs, Zn], bsc, acts, sc, of, F, 1.0, drop)
         ctx.save_for_backward(X, AX, Ws, Wn, Zs, Zn, sc, of, *[b if b is not None else sc.new_empty(0) for b in bsc])
         ctx.adj = adj
-        ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)])
+        ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)], one_call)
+        # chaining (both ends need the one-call entries and a non-dual output)
+        ctx.link_down = link_down if (link_down is not None and link_down.published and one_call and CHAIN_SAGE_BWD) else None
+        ctx.link_up = None
+        if link_up is not None and one_call and CHAIN_SAGE_BWD and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256:
+            link_up.publish(Zs, Zn, bsc, sc, of, acts[0], drop)
+            ctx.link_up = link_up
         ctx.set_materialize_grads(False)
         fire_deferred()
         return out
@@ -716,7 +806,8 @@ class _SageDense(torch.autograd.Function):
     @staticmethod
     def _fusable(X, Ws, Wn):
         Fo, Fi = Ws.shape
-        return (FUSED_LAYER_CALLS and GEMM_SPLIT and KernelTimer.active is None and X.shape[0] > 0 and Fo % 4 == 0 and Fo <= 256
+        return (FUSED_LAYER_CALLS and GEMM_SPLIT and KernelTimer.active is None and X.shape[0] >= max(1, GEMM_SPLIT_MIN_ROWS)
+                and Fo % 4 == 0 and Fo <= 256
                 and Fi % 4 == 0 and X.dtype == torch.float32 and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
                 and Ws.stride(1) == 1 and Wn.stride(1) == 1 and Ws.dtype == torch.float32 and Wn.shape == Ws.shape)
 
@@ -743,53 +834,89 @@ class _SageDense(torch.autograd.Function):
 
     @staticmethod
     def _fused_backward(ctx, dout, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, drop, has_b, want_dx):
+        """One C call for the whole backward pass.  With ``ctx.link_up`` filled the act_norm backward is skipped (the layer
+        above produced dZ); with ``ctx.link_down`` the input gradient is not written: the epilogue of its GEMM produces
+        the dZ of the layer below instead (returns a storage-less placeholder for dX)."""
         lib = _lib.load()
         n, Fo = Zs.shape
         Fi = X.shape[1]
         dev = Zs.device
-        douts = dout if isinstance(dout, (tuple, list)) else (dout,)
-        d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
-        d1 = None
-        if _is_dual(drop):
-            d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
-            if d1 is None:
-                drop = (0.0, 0)
-        if d0 is None and d1 is None:
-            d0 = torch.zeros(n, Fo, dtype=torch.float32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        dX = torch.empty(n, Fi, **f32) if want_dx else None
+        up, down = ctx.link_up, ctx.link_down
+        dz_ready = up is not None and up.filled
+        d0 = d1 = None
+        if dz_ready:
+            g = dout[0] if isinstance(dout, (tuple, list)) else dout
+            if g is None or g.data_ptr() != up.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
+                raise RuntimeError("chained GraphSAGE backward: the lower layer's output has a consumer besides the layer above "
+                                   "(its gradient is not the chain's placeholder); build the model with chaining off")
+            buf, dsc, dof, dbi = up.buf, up.dsc, up.dof, up.dbi
+            an_partial = None
+        else:
+            douts = dout if isinstance(dout, (tuple, list)) else (dout,)
+            d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
+            if _is_dual(drop):
+                d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
+                if d1 is None:
+                    drop = (0.0, 0)
+            if d0 is None and d1 is None:
+                d0 = torch.zeros(n, Fo, **f32)
+            dbi = torch.empty(2, Fo, **f32) if any(has_b) else None
+            dsc, dof = torch.empty(2, Fo, **f32), torch.empty(2, Fo, **f32)
+            buf = torch.empty(n, 3 * Fo, **f32)
+            an_partial = torch.empty(2048 * 2 * 3 * Fo, **f32)
+        chain = down is not None and want_dx and down.Zs.shape == (n, Fi) and Fo % 32 == 0
+        below = None
+        if chain:
+            down.buf = torch.empty(n, 3 * Fi, **f32)
+            down.dsc, down.dof = torch.empty(2, Fi, **f32), torch.empty(2, Fi, **f32)
+            down.dbi = torch.empty(2, Fi, **f32) if any(b is not None for b in down.biases) else None
+            down.partial = torch.empty(lib.sl_sage_chain_partial_floats(n, Fi), **f32)
+            opt = lambda t: t.data_ptr() if t is not None else None
+            below = _lib.SlSageBelow(down.Zs.data_ptr(), down.Zn.data_ptr(), opt(down.biases[0]), opt(down.biases[1]),
+                                     down.sc.data_ptr(), down.of.data_ptr(), down.act, float(down.drop[0]), int(down.drop[1]), Fi,
+                                     down.buf.data_ptr(), down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi),
+                                     down.partial.data_ptr())
+        dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
         dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
-        dbi = torch.empty(2, Fo, **f32) if any(has_b) else None
-        dsc, dof = torch.empty(2, Fo, **f32), torch.empty(2, Fo, **f32)
-        buf = torch.empty(n, 3 * Fo, **f32)
-        an_partial = torch.empty(2048 * 2 * 3 * Fo, **f32)
         tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)
         pack = torch.empty(lib.sl_sage_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, want_dx)
         opt = lambda t: t.data_ptr() if t is not None else None
-        check(lib.sl_sage_bwd(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi, Fo,
-                              Ws.data_ptr(), Ws.stride(0), opt(biases[0]), Wn.data_ptr(), Wn.stride(0), opt(biases[1]), sc.data_ptr(),
-                              of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX), dWs.data_ptr(),
-                              dWn.data_ptr(), opt(dbi), dsc.data_ptr(), dof.data_ptr(), buf.data_ptr(), an_partial.data_ptr(),
-                              tn_partial.data_ptr(), pack.data_ptr(), _stream(Zs)))
+        check(lib.sl_sage_bwd_chain(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi,
+                                    Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]), Wn.data_ptr(), Wn.stride(0), opt(biases[1]),
+                                    sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX),
+                                    dWs.data_ptr(), dWn.data_ptr(), opt(dbi), opt(dsc), opt(dof), buf.data_ptr(), opt(an_partial),
+                                    tn_partial.data_ptr(), pack.data_ptr(), 1 if dz_ready else 0,
+                                    C.byref(below) if below is not None else None, _stream(Zs)))
+        if dz_ready:
+            up.release()
+        if chain:
+            down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)       # what autograd hands to the node below: no storage behind it
+            down.filled = True
+            dX = down.dummy
+            _SageDense.chained_calls += 1
         return dX, dWs, dWn, dbi, dsc, dof
 
     @staticmethod
     def backward(ctx, *dout):
         X, AX, Ws, Wn, Zs, Zn, sc, of, b0, b1 = ctx.saved_tensors
-        acts, drop, sshape, oshape, has_b = ctx.meta
+        acts, drop, sshape, oshape, has_b, one_call = ctx.meta
         adj = ctx.adj
         n, F = Zs.shape
         ng = ctx.needs_input_grad
         biases = [b if hb else None for b, hb in zip((b0, b1), has_b)]
         Fi = X.shape[1]
-        if (_SageDense._fusable(X, Ws, Wn) and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
+        # (the forward's decision, not a re-evaluation: a KernelTimer entered between the passes must not mix the paths)
+        if (one_call and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
                 and (not ng[0] or F % 32 == 0)):
             dX, dWs, dWn, dbi, dsc, dof = _SageDense._fused_backward(ctx, dout, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, drop,
                                                                      has_b, bool(ng[0]))
-            dbs = dbi[0] if (has_b[0] and ng[3]) else None
-            dbn = dbi[1] if (has_b[1] and ng[5]) else None
-            return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None
+            dbs = dbi[0] if (has_b[0] and ng[3] and dbi is not None) else None
+            dbn = dbi[1] if (has_b[1] and ng[5] and dbi is not None) else None
+            return (dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None)
+        if ctx.link_up is not None and ctx.link_up.filled:
+            raise RuntimeError("chained GraphSAGE backward: the layer above filled this layer's dZ but the one-call path is off")
         # dZs lands in the left half of one [n, 2F] buffer; A^T dZn goes into the right half
         buf = torch.empty(n, 2 * F, dtype=torch.float32, device=Zs.device) if ng[0] else None
         dz_out = [buf[:, :F], None] if buf is not None else None
@@ -806,7 +933,11 @@ class _SageDense(torch.autograd.Function):
         dWn = weight_grad(dZn, AX) if ng[4] else None
         dbs = dbi[0] if (has_b[0] and ng[3]) else None
         dbn = dbi[1] if (has_b[1] and ng[5]) else None
-        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None
+        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None
+
+
+# Chained GraphSAGE backward (sl_sage_bwd_chain): on unless SHADOW_CHAIN_SAGE_BWD=0
+CHAIN_SAGE_BWD = os.environ.get("SHADOW_CHAIN_SAGE_BWD", "1") != "0"
 
 
 # Work the minibatch extractor wants issued right AFTER the first aggregation of a step has been enqueued (the prefetch of
@@ -925,10 +1056,12 @@ def gcn_dense(X: torch.Tensor, adj: "NormAdj", lin, act: str, scale: torch.Tenso
 
 
 def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
-               offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False, in_dropout: float = 0.0):
+               offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False, in_dropout: float = 0.0,
+               chain_next: bool = False):
     """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483).
     ``dual`` (with out_dropout > 0): returns (out, dropout(out)) from one kernel pass.  ``X`` may be a LazyRows
-    (layer 0 of the fast path): gather and input dropout ``in_dropout`` then happen inside the aggregation kernel."""
+    (layer 0 of the fast path): gather and input dropout ``in_dropout`` then happen inside the aggregation kernel.
+    ``chain_next``: the caller guarantees that ONLY the next GraphSAGE layer reads the returned tensor (see ChainLink)."""
     if act not in ACT_CODE:
         raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
     F = lin_self.weight.shape[0]
@@ -939,8 +1072,14 @@ def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Te
             lazy, X = X, X.table.new_empty(0)
         else:
             X, _seed = X.gather_dropped(in_dropout)
-    return _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
-                            (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout))
+    # chaining: a producer node left its ChainLink on the tensor it returned; ``chain_next`` asks this node to do the same
+    link_down = getattr(X, "_shadow_chain", None) if torch.is_tensor(X) else None
+    link_up = ChainLink() if (chain_next and not dual and CHAIN_SAGE_BWD) else None
+    res = _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
+                           (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout), link_down, link_up)
+    if link_up is not None and link_up.published and torch.is_tensor(res):
+        res._shadow_chain = link_up
+    return res
 
 
 def _drop_arg(out_dropout: float, F: int, seg: Optional[int] = None, dual: bool = False):

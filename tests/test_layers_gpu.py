@@ -978,3 +978,103 @@ def test_one_call_gcn_layer_equals_kernel_by_kernel(F_in, F_out, act, p_out, dua
     assert torch.equal(dx0, dx1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+# --------------------------------------------------------------------------------------------------------------
+# round 3: activation + normalisation in the GEMM epilogue (csrc/gemm_fused.hip), chained GraphSAGE backward
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,M,K,N,act,p,dual", [(2, 8192, 256, 256, "relu", 0.0, False), (2, 10007, 256, 256, "elu", 0.4, False),
+                                                 (2, 9001, 100, 256, "relu", 0.4, True), (1, 8300, 256, 256, "tanh", 0.0, False),
+                                                 (1, 8192, 128, 64, "leakyrelu", 0.25, False), (2, 8250, 64, 128, "I", 0.0, False),
+                                                 (2, 8197, 256, 200, "relu", 0.3, False), (1, 8200, 36, 32, "relu", 0.0, False),
+                                                 (2, 1100, 512, 256, "elu", 0.0, False)])
+def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act, p, dual):
+    """sl_gemm_act_norm_fwd: the nb <= 2 Linear products of a layer in one launch with bias + act + feature norm + branch
+    sum (+ the fused output dropout, single and dual mode) in the epilogue, against the separate kernels
+    (sl_gemm_nt_f32 per branch, then sl_act_norm_fwd).  The pre-activations come from the same main loop: bit-identical.
+    The normalised output is the same arithmetic on the same 64-lane butterfly sums for 128 < N <= 256; below that the
+    stand-alone kernel packs two or more rows per wavefront (other summation tree): equal to rounding.  Ragged M (not a
+    multiple of the 128-row workgroup / 32-row wavefront tile), K with a zero-padded last unit (100 in a 128-float pitch,
+    36), N below the tile width (200, 64, 32)."""
+    from shadow_gnn_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.sl_gemm_act_norm_supported(N, K)
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    pitch = (K + 31) // 32 * 32
+    Xs = [torch.randn(M, pitch, device=DEV, generator=g)[:, :K] for _ in range(nb)]
+    Ws = [torch.randn(N, K, device=DEV, generator=g) / K ** 0.5 for _ in range(nb)]
+    bs = [torch.randn(N, device=DEV, generator=g) * 0.3 if b == 0 else None for b in range(nb)]
+    sc = (1.0 + 0.2 * torch.randn(nb, N, device=DEV, generator=g)).contiguous()
+    of = (0.2 * torch.randn(nb, N, device=DEV, generator=g)).contiguous()
+    codes = [ops.ACT_CODE[act]] * nb
+    drop = (p, 123456789 + M, True) if dual else ((p, 123456789 + M) if p > 0 else (0.0, 0))
+    assert ops.gemm_act_norm_usable(Xs, Ws, N, N)
+    Zf, outf = ops.gemm_act_norm_fwd(Xs, Ws, bs, codes, sc, of, 0.5 if nb == 1 else 1.0, drop)
+    Zr = [ops.mm_nt(x, w) for x, w in zip(Xs, Ws)]
+    outr = ops._an_fwd(Zr, bs, codes, sc, of, N, 0.5 if nb == 1 else 1.0, drop)
+    for a, b in zip(Zf, Zr):
+        assert torch.equal(a, b)
+    outf = outf if isinstance(outf, tuple) else (outf,)
+    outr = outr if isinstance(outr, tuple) else (outr,)
+    assert len(outf) == len(outr) == (2 if dual else 1)
+    for a, b in zip(outf, outr):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+        if p > 0:                                   # the same hash mask: zeros in the same places
+            assert torch.equal(a == 0, b == 0) or float(((a == 0) != (b == 0)).float().mean()) < 1e-6
+
+
+def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"):
+    """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
+    returns loss, predictions and every parameter gradient."""
+    from shadow_gnn_amd import _lib, ops
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    b, X, labels, F0, C = _bench_scale_batch("sage", B)
+    lib = _lib.load()
+    prev_f = lib.sl_set_fused_epilogue(1 if fused else 0)
+    prev_c = ops.CHAIN_SAGE_BWD
+    ops.CHAIN_SAGE_BWD = chain
+    try:
+        arch = dict(num_layers=n_layers, num_cls_layers=1, heads=1, dim=dim, act=act, layer_norm="norm_feat",
+                    feature_augment_ops="sum", aggr="sage", residue="none", pooling="center", loss="softmax")
+        torch.manual_seed(seed)
+        model = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=p_drop, dropedge=0.0, lr=0.002), "node").to(DEV)
+        with torch.no_grad():
+            for q in model.parameters():
+                q.add_(0.05 * torch.randn_like(q))
+        adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off,
+                            max_subg_nodes=b.counts["max_subg_nodes"])
+        batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
+        model.optimizer = torch.optim.SGD(model.parameters(), lr=0.0)         # keep the (clipped) gradients readable
+        c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls)
+        torch.manual_seed(seed + 1)                                           # dropout seeds come from torch's CPU generator
+        ret = model.step(TRAIN, "running", batch)
+        torch.cuda.synchronize()
+        calls = (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1])
+        grads = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+        return float(ret["loss"]), ret["preds"].detach().clone(), grads, calls
+    finally:
+        lib.sl_set_fused_epilogue(prev_f)
+        ops.CHAIN_SAGE_BWD = prev_c
+
+
+@pytest.mark.parametrize("n_layers,dim,p_drop,act", [(3, 256, 0.4, "relu"), (5, 256, 0.0, "elu"), (3, 128, 0.3, "elu")])
+def test_chained_sage_backward_equals_unchained(n_layers, dim, p_drop, act):
+    """sl_sage_bwd_chain: the input-gradient GEMM of layer l runs layer l-1's act_norm backward in its epilogue (dX is
+    never written) -- loss, predictions and EVERY parameter gradient equal the unchained pass's (same per-row arithmetic;
+    the column sums of dscale / doffset / dbias are added in another fixed order), with the next layer's input dropout
+    fused into the producing layer (mask regenerated in the epilogue) and without.  Also against the fully separate
+    kernels (epilogue fusion off)."""
+    l0, p0, g0, calls0 = _sage_stack_step(n_layers, dim, p_drop, 5, chain=False, fused=False, act=act)
+    l1, p1, g1, calls1 = _sage_stack_step(n_layers, dim, p_drop, 5, chain=True, fused=True, act=act)
+    l2, p2, g2, calls2 = _sage_stack_step(n_layers, dim, p_drop, 5, chain=False, fused=True, act=act)
+    assert calls0 == (n_layers, 0) and calls2 == (n_layers, 0)
+    assert calls1 == (n_layers, n_layers - 1), calls1          # every layer boundary was chained
+    assert abs(l0 - l1) < 1e-5 and abs(l0 - l2) < 1e-5
+    torch.testing.assert_close(p1, p0, rtol=1e-5, atol=1e-6)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        for g in (g1, g2):
+            err = float((g[k] - g0[k]).abs().max())
+            assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
