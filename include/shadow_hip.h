@@ -408,11 +408,11 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
 /* The same products with the activation + feature normalisation in the GEMM's epilogue (csrc/gemm_fused.hip; a
  * wavefront of the split-bf16 kernel owns 32 whole output rows, the unit `_f_norm_feat` works on -- layers.py:329-338):
  *   sl_gemm_act_norm_fwd   Z_b = A_b . W_b^T for b < nb <= 2 in ONE launch (d_packed_B: the nb images of
- *                          sl_gemm_pack_b back to back; all branches share M, N, K), Z_b written (without bias), and
+ *                          sl_gemm_act_norm_pack_b back to back; all branches share M, N, K), Z_b written (without bias), and
  *                          out = out_scale * sum_b norm_b(act_b(Z_b + bias_b)) [+ dropout / dual output exactly as
  *                          sl_act_norm_fwd defines them] written from the accumulators: no second pass over Z.
  *                          N % 4 == 0, 16 <= N <= 256 (normalisation segment = N); operands 16-byte aligned, ld % 4 == 0.
- *   sl_gemm_an_bwd         G = A . B^T (A [M, K], d_packed_B its image, G [M, N]) is the gradient of a GraphSAGE layer's
+ *   sl_gemm_an_bwd         G = A . B^T (A [M, K], d_packed_B its image in sl_gemm_act_norm_tiles(N) tiles, G [M, N]) is the gradient of a GraphSAGE layer's
  *                          output (through that layer's fused output dropout (drop_p, drop_seed) when drop_p > 0); G is
  *                          not written: the epilogue applies sl_act_norm_bwd (nb = 2, seg = N) to it row by row and
  *                          writes dZ_b, dscale, doffset and (d_dbias != NULL) dbias.  d_partial:
@@ -424,6 +424,14 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
  * SHADOW_FUSED_EPILOGUE=0 sets the initial state) -- the A/B handle of the tests and benchmarks.                  */
 int sl_set_fused_epilogue(int on);
 int sl_gemm_act_norm_supported(uint32_t N, uint32_t K);
+/* The epilogue kernels stream B images of sl_gemm_act_norm_tiles(N) = 4 or 8 column tiles (rows >= N are zero):
+ * sl_gemm_act_norm_pack_b writes one (sl_gemm_act_norm_pack_bytes(N, K) bytes); sl_gemm_pack_b2_tiles is the general
+ * form (strided sources as sl_gemm_pack_b2, explicit tile count, 32 tiles >= N).                                  */
+uint32_t sl_gemm_act_norm_tiles(uint32_t N);
+size_t sl_gemm_act_norm_pack_bytes(uint32_t N, uint32_t K);
+int sl_gemm_act_norm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream);
+int sl_gemm_pack_b2_tiles(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k,
+                          uint32_t N, uint32_t K, uint32_t tiles, void *d_packed, void *stream);
 int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const void *d_packed_B, uint32_t M, uint32_t N,
                          uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
                          const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo, float drop_p,

@@ -138,6 +138,11 @@ SIGNATURES = {
                                      _P, C.c_int, C.POINTER(SlSageBelow), _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
     "sl_gemm_act_norm_supported": (C.c_int, [C.c_uint32, C.c_uint32]),
+    "sl_gemm_act_norm_tiles": (C.c_uint32, [C.c_uint32]),
+    "sl_gemm_act_norm_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "sl_gemm_act_norm_pack_b": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_pack_b2_tiles": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         _P, _P]),
     "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
                                         C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P]),

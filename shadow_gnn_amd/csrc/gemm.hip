@@ -272,10 +272,15 @@ extern "C" int sl_gemm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_
 
 extern "C" int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j,
                                int64_t s2k, uint32_t N, uint32_t K, void *d_packed, void *stream) {
+  return sl_gemm_pack_b2_tiles(d_B1, s1j, s1k, K1, d_B2, s2j, s2k, N, K, (N + 31) / 32, d_packed, stream);
+}
+
+extern "C" int sl_gemm_pack_b2_tiles(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j,
+                                     int64_t s2k, uint32_t N, uint32_t K, uint32_t tiles, void *d_packed, void *stream) {
   if (!d_B1 || !d_packed || (K1 < K && !d_B2)) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: null argument");
   if (N == 0 || K == 0) return SG_OK;
-  if (N > 256) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: N = %u (at most 256 output columns)", N);
-  const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
+  if (N > 256 || tiles > 8 || 32 * tiles < N) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: N = %u in %u column tiles", N, tiles);
+  const uint32_t units = (K + 31) / 32;
   const uint32_t total = units * 2 * tiles * 64;
   hipLaunchKernelGGL(gemm_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_B1, s1j, s1k,
                      std::min(K1, K), d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, units, tiles, reinterpret_cast<bf16x8 *>(d_packed));

@@ -15,9 +15,12 @@
 //                       removes one [n, F] write, one [n, F] read and a launch per layer boundary.
 //
 // Epilogue mechanics: after the last k-step the B ring in LDS is dead.  Each wavefront parks its 32 x N accumulator tile
-// there 16 rows at a time (C/D layout -> row-major, conflict-free ds_write_b32) and then walks the rows ONE ROW PER
-// WAVEFRONT with a float4 per lane -- the layout and the arithmetic of act_norm_kernel<64, 64, ...> (aggregate.hip), so
-// every global access of the epilogue is a whole 1-KiB row and the row statistics are plain 64-lane butterfly sums.
+// there 16 rows at a time (C/D layout -> row-major, conflict-free ds_write_b32) and then walks the rows TWO PER PASS, one
+// row on 32 lanes (a lane holds the float4s j, j + 32 of its row): the arithmetic of act_norm_kernel (aggregate.hip)
+// with the row statistics as DPP butterflies + one v_permlane16_swap -- no dependent LDS-crossbar chain, independent
+// float4s per lane -- and every global access of the epilogue a run of 512 contiguous bytes per row.  (First
+// built with a whole wavefront per row and 64-lane shuffle sums: 4-8 dependent 6-step ds_bpermute chains per row made the
+// epilogue longer than the main loop, products step 10.06 -> 11.30 ms.)
 // The other workgroup resident on the CU keeps the matrix cores busy meanwhile (two 4-wave workgroups per CU).
 #include <string.h>
 
@@ -53,81 +56,320 @@ struct FusedDesc {
   const float *Zr[2]; int64_t ldzr[2];
   float *dZ[2];       int64_t lddz[2];
   float *partial;                   // [grid, nb, 3, N]
+  // Start stagger (see gemm_nt_fused_kernel): shader cycles the workgroups of the first dispatch round that sit in an odd
+  // workgroup slot of their CU wait before they start; first_round = workgroups resident at once (2 per CU)
+  uint32_t stagger_cycles, first_round, stagger_mode;
 };
 
-__device__ __forceinline__ float row_sum64(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+// All-reduce over the 16 lanes of a DPP row (quad xor 1, quad xor 2, half-row mirror, row mirror): four dependent VALU
+// adds, no LDS crossbar.  The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass): the row statistics
+// are five VALU operations deep, every lane carries Q independent float4s, and the column accumulators of the backward
+// form (5 Q float4s per lane) stay inside the register budget of two wavefronts per SIMD.
+#define SHD_DPP_F(v, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false))
+__device__ __forceinline__ float sum16(float v) {
+  v += SHD_DPP_F(v, 0xB1);       // quad_perm [1, 0, 3, 2]
+  v += SHD_DPP_F(v, 0x4E);       // quad_perm [2, 3, 0, 1]
+  v += SHD_DPP_F(v, 0x141);      // row_half_mirror
+  v += SHD_DPP_F(v, 0x140);      // row_mirror
   return v;
 }
 
-// out row = out_scale-less sum_b norm_b(act(z_b + bias_b)) for the 4 columns f .. f + 3 of one row (all 64 lanes = one row)
-template <int NBA>
-__device__ __forceinline__ float4 an_row_fwd(const FusedDesc &d, uint32_t f, bool lane_on, const float4 (&zc)[NBA], float inv_seg) {
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int b = 0; b < NBA; b++) {
-    float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
-    if (lane_on) {
-      z = zc[b];
-      if (d.bias[b]) { const float4 bb = ld4(d.bias[b] + f); z.x += bb.x; z.y += bb.y; z.z += bb.z; z.w += bb.w; }
-      h = make_float4(act_fwd(d.act[b], z.x), act_fwd(d.act[b], z.y), act_fwd(d.act[b], z.z), act_fwd(d.act[b], z.w));
-    }
-    // biased mean / variance over the row (layers.py:334-335)
-    const float mean = row_sum64(h.x + h.y + h.z + h.w) * inv_seg;
-    float4 dd = make_float4(h.x - mean, h.y - mean, h.z - mean, h.w - mean);
-    if (!lane_on) dd = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float var = row_sum64(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z + dd.w * dd.w) * inv_seg + d.eps;
-    const float rstd = rsqrtf(var);
-    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), of = sc;
-    if (lane_on) { sc = ld4(d.scale + (size_t)b * d.N + f); of = ld4(d.offset + (size_t)b * d.N + f); }
-    // (x - mean) * scale * rsqrt(var) + offset   (layers.py:336)
-    acc.x += dd.x * sc.x * rstd + of.x; acc.y += dd.y * sc.y * rstd + of.y;
-    acc.z += dd.z * sc.z * rstd + of.z; acc.w += dd.w * sc.w * rstd + of.w;
-  }
-  return acc;
+// ... and over the 32 lanes of a row pair: one v_permlane16_swap (odd rows of one copy <-> even rows of the other) + add
+__device__ __forceinline__ float sum32(float v) {
+  v = sum16(v);
+  const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-// act_norm backward of one row: dy = gradient of the row's (possibly dropped) output; writes dZ_b, accumulates the
-// column sums of dscale (gs), doffset (go) and dbias (gb)
-template <int NBA>
-__device__ __forceinline__ void an_row_bwd(const FusedDesc &d, uint64_t r, uint32_t f, bool lane_on, float4 dy, const float4 (&zc)[NBA],
-                                           float inv_seg, float4 (&gs)[NBA], float4 &go, float4 (&gb)[NBA]) {
-  float4 dm = make_float4(d.out_scale, d.out_scale, d.out_scale, d.out_scale);
-  if (d.drop_thr) {            // gradient of the fused output dropout: same mask, same 1 / (1 - p)
-    const uint32_t keep = drop_keep4_raw(d.seed_lo, d.seed_hi, d.drop_thr, r, f);
-    const float ks = d.out_scale * d.drop_scale;
-    dm = make_float4((keep & 1u) ? ks : 0.f, (keep & 2u) ? ks : 0.f, (keep & 4u) ? ks : 0.f, (keep & 8u) ? ks : 0.f);
-  }
-  dy.x *= dm.x; dy.y *= dm.y; dy.z *= dm.z; dy.w *= dm.w;
+// ... and over the whole wavefront: one v_permlane32_swap more
+__device__ __forceinline__ float sum64(float v) {
+  v = sum32(v);
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+template <int LPR> __device__ __forceinline__ float row_sum(float v) { return LPR == 64 ? sum64(v) : sum32(v); }
+
+__device__ __forceinline__ float hsum4(const float4 &v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4sel(bool c, const float4 &v) { return c ? v : f4zero(); }
+
+// the per-column parameters of one lane (constant over the rows: loaded once per epilogue)
+template <int NBA, int Q>
+struct ColParams {
+  float4 bias[NBA][Q], sc[NBA][Q], of[NBA][Q];
+};
+
+// keep-factors of the fused dropout for the float4 at column c of a row whose hash base is rowh
+__device__ __forceinline__ float4 drop_factors(uint32_t rowh, uint32_t c, uint32_t thr, float keep_value) {
+  const uint32_t base = rowh + c * 0x9E3779B1u;
+  return make_float4(mix32(base) >= thr ? keep_value : 0.f, mix32(base + 0x9E3779B1u) >= thr ? keep_value : 0.f,
+                     mix32(base + 2u * 0x9E3779B1u) >= thr ? keep_value : 0.f, mix32(base + 3u * 0x9E3779B1u) >= thr ? keep_value : 0.f);
+}
+
+// One row on 32 lanes: lane j holds the float4s j, j + 32, ... of the row (columns 4 (j + 32 q) ..).
+// out[q] = sum_b norm_b(act(z_b[q] + bias_b))   (before out_scale); on[q]: the float4 lies inside the row.
+// ACT >= 0: the activation of every branch, known at compile time; ACT < 0: d.act[b] at run time.
+template <int NBA, int Q, int ACT, int LPR>
+__device__ __forceinline__ void an_rows_fwd(const FusedDesc &d, const ColParams<NBA, Q> &cp, const bool (&on)[Q], const float4 (&zc)[NBA][Q],
+                                            float inv_seg, float4 (&out)[Q]) {
+#pragma unroll
+  for (int q = 0; q < Q; q++) out[q] = f4zero();
 #pragma unroll
   for (int b = 0; b < NBA; b++) {
-    float4 z = make_float4(0.f, 0.f, 0.f, 0.f), h = z;
-    if (lane_on) {
-      z = zc[b];
-      if (d.bias[b]) { const float4 bb = ld4(d.bias[b] + f); z.x += bb.x; z.y += bb.y; z.z += bb.z; z.w += bb.w; }
-      h = make_float4(act_fwd(d.act[b], z.x), act_fwd(d.act[b], z.y), act_fwd(d.act[b], z.z), act_fwd(d.act[b], z.w));
+    const int act = ACT >= 0 ? ACT : d.act[b];
+    float4 h[Q];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const float4 z = make_float4(zc[b][q].x + cp.bias[b][q].x, zc[b][q].y + cp.bias[b][q].y, zc[b][q].z + cp.bias[b][q].z,
+                                   zc[b][q].w + cp.bias[b][q].w);
+      h[q] = f4sel(on[q], make_float4(act_fwd(act, z.x), act_fwd(act, z.y), act_fwd(act, z.z), act_fwd(act, z.w)));
+      s += hsum4(h[q]);
     }
-    const float mean = row_sum64(h.x + h.y + h.z + h.w) * inv_seg;
-    float4 dd = make_float4(h.x - mean, h.y - mean, h.z - mean, h.w - mean);
-    if (!lane_on) dd = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float var = row_sum64(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z + dd.w * dd.w) * inv_seg + d.eps;
-    const float rstd = rsqrtf(var);
-    const float4 xh = make_float4(dd.x * rstd, dd.y * rstd, dd.z * rstd, dd.w * rstd);
-    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane_on) sc = ld4(d.scale + (size_t)b * d.N + f);
-    gs[b].x += dy.x * xh.x; gs[b].y += dy.y * xh.y; gs[b].z += dy.z * xh.z; gs[b].w += dy.w * xh.w;
-    if (b == 0) { go.x += dy.x; go.y += dy.y; go.z += dy.z; go.w += dy.w; }
-    const float4 dxh = make_float4(dy.x * sc.x, dy.y * sc.y, dy.z * sc.z, dy.w * sc.w);
-    const float m1 = row_sum64(dxh.x + dxh.y + dxh.z + dxh.w) * inv_seg;
-    const float m2 = row_sum64(dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w) * inv_seg;
-    float4 dh = make_float4(rstd * (dxh.x - m1 - xh.x * m2), rstd * (dxh.y - m1 - xh.y * m2),
-                            rstd * (dxh.z - m1 - xh.z * m2), rstd * (dxh.w - m1 - xh.w * m2));
-    if (lane_on) {
-      dh.x *= act_bwd(d.act[b], z.x, h.x); dh.y *= act_bwd(d.act[b], z.y, h.y);
-      dh.z *= act_bwd(d.act[b], z.z, h.z); dh.w *= act_bwd(d.act[b], z.w, h.w);
-      st4s(d.dZ[b] + (int64_t)r * d.lddz[b] + f, dh);
-      gb[b].x += dh.x; gb[b].y += dh.y; gb[b].z += dh.z; gb[b].w += dh.w;
+    // biased mean / variance over the row (layers.py:334-335)
+    const float mean = row_sum<LPR>(s) * inv_seg;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      h[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
+      v += (h[q].x * h[q].x + h[q].y * h[q].y) + (h[q].z * h[q].z + h[q].w * h[q].w);
+    }
+    const float rstd = rsqrtf(row_sum<LPR>(v) * inv_seg + d.eps);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      // (x - mean) * scale * rsqrt(var) + offset   (layers.py:336)
+      out[q].x += h[q].x * cp.sc[b][q].x * rstd + cp.of[b][q].x; out[q].y += h[q].y * cp.sc[b][q].y * rstd + cp.of[b][q].y;
+      out[q].z += h[q].z * cp.sc[b][q].z * rstd + cp.of[b][q].z; out[q].w += h[q].w * cp.sc[b][q].w * rstd + cp.of[b][q].w;
+    }
+  }
+}
+
+// act_norm backward of one row on 32 lanes: dy[q] = gradient of the row's output, already through the dropout mask and
+// zero outside the row / the matrix; writes dZ_b, accumulates the column sums of dscale (gs), doffset (go) and dbias (gb)
+template <int NBA, int Q, int ACT, int LPR>
+__device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bool row_ok, uint32_t j, const bool (&on)[Q],
+                                            const float4 (&dy)[Q], const float4 (&zc)[NBA][Q], float inv_seg, float4 (&gs)[NBA][Q],
+                                            float4 (&go)[Q], float4 (&gb)[NBA][Q]) {
+#pragma unroll
+  for (int q = 0; q < Q; q++) { go[q].x += dy[q].x; go[q].y += dy[q].y; go[q].z += dy[q].z; go[q].w += dy[q].w; }
+#pragma unroll
+  for (int b = 0; b < NBA; b++) {
+    const int act = ACT >= 0 ? ACT : d.act[b];
+    // (the per-column parameters come from the L1 here: with the 5 Q column accumulators there is no room to keep them)
+    float4 z[Q], h[Q], xh[Q], dxh[Q];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const float4 bb = d.bias[b] ? ld4(d.bias[b] + (on[q] ? 4 * (j + LPR * q) : 0u)) : f4zero();
+      z[q] = make_float4(zc[b][q].x + bb.x, zc[b][q].y + bb.y, zc[b][q].z + bb.z, zc[b][q].w + bb.w);
+      h[q] = f4sel(on[q], make_float4(act_fwd(act, z[q].x), act_fwd(act, z[q].y), act_fwd(act, z[q].z), act_fwd(act, z[q].w)));
+      s += hsum4(h[q]);
+    }
+    const float mean = row_sum<LPR>(s) * inv_seg;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      xh[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
+      v += (xh[q].x * xh[q].x + xh[q].y * xh[q].y) + (xh[q].z * xh[q].z + xh[q].w * xh[q].w);
+    }
+    const float rstd = rsqrtf(row_sum<LPR>(v) * inv_seg + d.eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      xh[q].x *= rstd; xh[q].y *= rstd; xh[q].z *= rstd; xh[q].w *= rstd;
+      gs[b][q].x += dy[q].x * xh[q].x; gs[b][q].y += dy[q].y * xh[q].y; gs[b][q].z += dy[q].z * xh[q].z; gs[b][q].w += dy[q].w * xh[q].w;
+      const float4 sc = ld4(d.scale + (size_t)b * d.N + (on[q] ? 4 * (j + LPR * q) : 0u));
+      dxh[q] = make_float4(dy[q].x * sc.x, dy[q].y * sc.y, dy[q].z * sc.z, dy[q].w * sc.w);
+      s1 += hsum4(dxh[q]);
+      s2 += (dxh[q].x * xh[q].x + dxh[q].y * xh[q].y) + (dxh[q].z * xh[q].z + dxh[q].w * xh[q].w);
+    }
+    const float m1 = row_sum<LPR>(s1) * inv_seg, m2 = row_sum<LPR>(s2) * inv_seg;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      float4 dh = make_float4(rstd * (dxh[q].x - m1 - xh[q].x * m2), rstd * (dxh[q].y - m1 - xh[q].y * m2),
+                              rstd * (dxh[q].z - m1 - xh[q].z * m2), rstd * (dxh[q].w - m1 - xh[q].w * m2));
+      dh.x *= act_bwd(act, z[q].x, h[q].x); dh.y *= act_bwd(act, z[q].y, h[q].y);
+      dh.z *= act_bwd(act, z[q].z, h[q].z); dh.w *= act_bwd(act, z[q].w, h[q].w);
+      if (row_ok && on[q]) st4s(d.dZ[b] + row * d.lddz[b] + 4 * (j + LPR * q), dh);
+      gb[b][q].x += dh.x; gb[b][q].y += dh.y; gb[b][q].z += dh.z; gb[b][q].w += dh.w;
+    }
+  }
+}
+
+// Everything behind the last k-step, for one (activation, full-width) specialisation: the accumulator tile goes through
+// the dead B ring 16 rows at a time and leaves two rows per pass (see the file header).
+template <int TW, int MODE, int NBA, int ACT, bool kFull>
+__device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)[TW], unsigned char *gsm, uint64_t m0) {
+  constexpr int SP = 32 * TW;                               // row pitch of the stash (floats)
+  // forward: a row on 32 lanes (two rows per pass, Q = TW / 4 float4s per lane); backward: one float4 per lane (a 256-wide
+  // row on the whole wavefront) -- its 5 Q column accumulators have to fit beside the waiting half of the tile
+  constexpr int LPR = (MODE == 1 && TW == 8) ? 64 : 32;
+  constexpr int RP = 64 / LPR;                              // rows per pass
+  constexpr int Q = 8 * TW / LPR;                           // float4s per lane
+  constexpr int kThreads = 256;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t r = lane & 31u, g = lane >> 5;             // C/D layout of the accumulators
+  const uint32_t j = lane & (LPR - 1), rs = lane / LPR;     // epilogue layout: lane j of row slot rs
+  const uint32_t M = d.M;
+  float *stash = reinterpret_cast<float *>(gsm) + (size_t)wv * (16 * SP);
+  bool on[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) on[q] = kFull || 4 * (j + LPR * q) < d.N;
+  const float inv_seg = 1.0f / (float)d.N;
+  ColParams<NBA, Q> cp;
+#pragma unroll
+  for (int b = 0; b < (MODE == 0 ? NBA : 0); b++)
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const uint32_t c = on[q] ? 4 * (j + LPR * q) : 0u;     // (lanes outside the row read column 0: harmless, never used)
+      cp.bias[b][q] = d.bias[b] ? ld4(d.bias[b] + c) : f4zero();
+      cp.sc[b][q] = ld4(d.scale + (size_t)b * d.N + c);
+      cp.of[b][q] = ld4(d.offset + (size_t)b * d.N + c);
+    }
+  float4 gs[NBA][Q], go[Q], gb[NBA][Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    go[q] = f4zero();
+#pragma unroll
+    for (int b = 0; b < NBA; b++) gs[b][q] = gb[b][q] = go[q];
+  }
+  if (MODE == 0 && NBA == 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // Z_0 is re-read below by other lanes
+  constexpr int NG = MODE == 0 ? NBA - 1 : NBA;             // operands that come from memory: Z_0 (forward) / both Z of the layer below
+#pragma unroll
+  for (int hf = 0; hf < 2; hf++) {
+    // rows 16 hf .. 16 hf + 15 of the tile: i = 8 hf + ii -> local row (ii & 3) + 8 (ii >> 2) + 4 g
+#pragma unroll
+    for (int t = 0; t < TW; t++)
+#pragma unroll
+      for (int ii = 0; ii < 8; ii++) stash[((ii & 3) + 8 * (ii >> 2) + 4 * g) * SP + 32 * t + r] = acc[t][8 * hf + ii];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t rbase = m0 + 16u * hf + rs;              // this lane's row in pass 0; + RP per pass
+    // The global operands of a pass are loaded D passes ahead (a ring of D register sets, the pass loop unrolled by D):
+    // with two wavefronts per SIMD the epilogue has little else to hide HBM latency behind -- one pass ahead left it
+    // latency-bound (2 KB in flight per wavefront).  Rows past the end re-read the last row (never stored).
+    constexpr int P = 16 / RP;                              // passes per half
+#ifndef SHADOW_EPI_DEPTH_BWD
+#define SHADOW_EPI_DEPTH_BWD 2
+#endif
+#ifndef SHADOW_EPI_DEPTH_FWD
+#define SHADOW_EPI_DEPTH_FWD 1
+#endif
+    constexpr int D = MODE == 1 ? SHADOW_EPI_DEPTH_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH_FWD : 2);
+    static_assert(P % D == 0, "");
+    float4 zpre[D][NG > 0 ? NG : 1][Q];
+    auto load_pass = [&](int slot, uint64_t row) {
+      const uint64_t rr = min(row, (uint64_t)M - 1);
+#pragma unroll
+      for (int b = 0; b < NG; b++)
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          const uint32_t c = on[q] ? 4 * (j + LPR * q) : 0u;
+          if (MODE == 0) zpre[slot][b][q] = ld4(d.Z[0] + rr * d.ldz[0] + c);
+          else zpre[slot][b][q] = ld4s(d.Zr[b] + rr * d.ldzr[b] + c);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < D; k++) load_pass(k, rbase + (uint32_t)(RP * k));
+#pragma unroll 1
+    for (int pg = 0; pg < P / D; pg++) {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const int ps = pg * D + k;
+      const uint64_t row = rbase + (uint32_t)(RP * ps);
+      const bool row_ok = row < M;
+      const float *srow = stash + (RP * ps + rs) * SP;
+      float4 zc[NBA][Q];
+      float4 own[Q];                                        // this GEMM's tile rows: Z_{NBA-1} (forward) / the output gradient (backward)
+#pragma unroll
+      for (int q = 0; q < Q; q++) own[q] = *reinterpret_cast<const float4 *>(srow + (on[q] ? 4 * (j + LPR * q) : 0u));
+#pragma unroll
+      for (int b = 0; b < NG; b++)
+#pragma unroll
+        for (int q = 0; q < Q; q++) zc[b][q] = zpre[k][b][q];
+      if (pg + 1 < P / D) load_pass(k, row + (uint32_t)(RP * D));
+      uint32_t rowh = 0;
+      if (d.drop_thr) rowh = mix32((uint32_t)row ^ d.seed_lo) + (uint32_t)(row >> 32) + d.seed_hi;
+      if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) zc[NBA - 1][q] = own[q];
+        float4 o[Q];
+        an_rows_fwd<NBA, Q, ACT, LPR>(d, cp, on, zc, inv_seg, o);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          if (row_ok && on[q]) {
+            const uint32_t c = 4 * (j + LPR * q);
+            st4s(d.Z[NBA - 1] + row * d.ldz[NBA - 1] + c, own[q]);
+            float4 v = make_float4(o[q].x * d.out_scale, o[q].y * d.out_scale, o[q].z * d.out_scale, o[q].w * d.out_scale);
+            if (d.drop_thr) {
+              const float4 kf = drop_factors(rowh, c, d.drop_thr, d.drop_scale);
+              const float4 dr = make_float4(v.x * kf.x, v.y * kf.y, v.z * kf.z, v.w * kf.w);
+              if (d.out2) st4s(d.out2 + row * d.ldo2 + c, dr);      // dual mode: out stays un-dropped
+              else v = dr;
+            }
+            st4s(d.out + row * d.ldo + c, v);
+          }
+        }
+      } else {
+        float4 dy[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          // gradient of the fused output dropout: same mask, same 1 / (1 - p); nothing outside the matrix
+          float4 dm = make_float4(d.out_scale, d.out_scale, d.out_scale, d.out_scale);
+          if (d.drop_thr) dm = drop_factors(rowh, 4 * (j + LPR * q), d.drop_thr, d.out_scale * d.drop_scale);
+          if (!(row_ok && on[q])) dm = f4zero();
+          dy[q] = make_float4(own[q].x * dm.x, own[q].y * dm.y, own[q].z * dm.z, own[q].w * dm.w);
+        }
+        if (!row_ok) {                                     // (a clamped row's Z must not reach the column sums either)
+#pragma unroll
+          for (int b = 0; b < NBA; b++)
+#pragma unroll
+            for (int q = 0; q < Q; q++) zc[b][q] = f4zero();
+        }
+        an_rows_bwd<NBA, Q, ACT, LPR>(d, row, row_ok, j, on, dy, zc, inv_seg, gs, go, gb);
+      }
+      __builtin_amdgcn_sched_barrier(0);                    // (one pass at a time: interleaved passes multiply the live registers)
+    }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (MODE == 1) {
+    // per-workgroup partial sums of the parameter gradients: RP row slots x 4 wavefronts column-sum rows in LDS, added
+    // in a fixed order and left for act_norm_finish_kernel (deterministic)
+    float *red = reinterpret_cast<float *>(gsm);            // [4 RP][1 + 2 NBA][SP]
+    constexpr int kKinds = 1 + 2 * NBA;
+    static_assert(4 * RP * kKinds * SP * 4 <= 3 * 3 * TW * 64 * 16, "the reduction rows must fit the dead B ring");
+    __syncthreads();                                        // every wavefront is done with its stash
+    float *rw = red + (size_t)(wv * RP + rs) * kKinds * SP;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      if (on[q]) {
+        *reinterpret_cast<float4 *>(rw + 4 * (j + LPR * q)) = go[q];
+#pragma unroll
+        for (int b = 0; b < NBA; b++) {
+          *reinterpret_cast<float4 *>(rw + (1 + 2 * b) * SP + 4 * (j + LPR * q)) = gs[b][q];
+          *reinterpret_cast<float4 *>(rw + (2 + 2 * b) * SP + 4 * (j + LPR * q)) = gb[b][q];
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < d.N; c += kThreads) {
+      float sacc[kKinds];
+#pragma unroll
+      for (int k = 0; k < kKinds; k++) {
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4 * RP; w++) a4[w & 3] += red[((size_t)w * kKinds + k) * SP + c];
+        sacc[k] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      }
+#pragma unroll
+      for (int b = 0; b < NBA; b++) {
+        float *pp = d.partial + (((size_t)blockIdx.x * NBA + b) * 3) * d.N + c;
+        pp[0] = sacc[1 + 2 * b];                            // dscale
+        pp[d.N] = sacc[0];                                  // doffset (the same sum for every branch)
+        pp[2 * (size_t)d.N] = sacc[2 + 2 * b];              // dbias
+      }
     }
   }
 }
@@ -153,6 +395,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   const float *arow0 = d.A[0] + arow_i * d.lda[0] + 16 * g;
   const float *arow1 = NBP == 2 ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
   const uint32_t gunits = NBP * units, steps = 2 * gunits;
+
+  // Every workgroup does the same amount of work, so the two workgroups sharing a CU would run in lock step: both in the
+  // main loop (matrix cores contended), then both in the epilogue (matrix cores idle) -- measured: the epilogue's time
+  // simply added to the GEMM's.  The workgroups of the FIRST dispatch round that landed in an odd workgroup slot of their CU
+  // (HW_ID.TG_ID) start late by about half a workgroup's lifetime; later rounds inherit the offset because a new
+  // workgroup starts when an old one ends.  Purely a scheduling hint: a wrong guess about the slot costs time, not results.
+  if (d.stagger_cycles && blockIdx.x < d.first_round) {
+    const uint32_t tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);      // HW_REG_HW_ID bits [19:16]: TG_ID
+    if (d.stagger_mode == 1 ? blockIdx.x >= d.first_round / 2 : (tg & 1u)) {
+      const uint64_t t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < d.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    }
+  }
 
   f32x16 acc[TW];
 #pragma unroll
@@ -264,103 +519,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     }
   }
 
-  // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier)
-  float *stash = reinterpret_cast<float *>(gsm) + (size_t)wv * (16 * SP);
-  const uint32_t f = 4 * lane;
-  const bool lane_on = f < d.N;
-  const float inv_seg = 1.0f / (float)d.N;
-  float4 gs[NBA], go, gb[NBA];
-  go = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int b = 0; b < NBA; b++) gs[b] = gb[b] = go;
-  if (MODE == 0 && NBA == 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // Z_0 is re-read below by other lanes
-#pragma unroll
-  for (int hf = 0; hf < 2; hf++) {
-    // rows 16 hf .. 16 hf + 15 of the tile: i = 8 hf + ii -> local row (ii & 3) + 8 (ii >> 2) + 4 g
-#pragma unroll
-    for (int t = 0; t < TW; t++)
-#pragma unroll
-      for (int ii = 0; ii < 8; ii++) stash[((ii & 3) + 8 * (ii >> 2) + 4 * g) * SP + 32 * t + r] = acc[t][8 * hf + ii];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t rbase = m0 + 16u * hf;
-    if (MODE == 0) {
-      float4 zpre = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (NBA == 2 && rbase < M && lane_on) zpre = ld4(d.Z[0] + rbase * d.ldz[0] + f);
-      for (int lr = 0; lr < 16; lr++) {
-        const uint64_t row = rbase + lr;
-        if (row >= M) break;                              // wave-uniform
-        float4 zc[NBA];
-        zc[NBA - 1] = lane_on ? *reinterpret_cast<const float4 *>(stash + lr * SP + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (NBA == 2) {
-          zc[0] = zpre;
-          if (lr + 1 < 16 && row + 1 < M && lane_on) zpre = ld4(d.Z[0] + (row + 1) * d.ldz[0] + f);
-        }
-        if (lane_on) st4s(d.Z[NBA - 1] + row * d.ldz[NBA - 1] + f, zc[NBA - 1]);
-        float4 o = an_row_fwd<NBA>(d, f, lane_on, zc, inv_seg);
-        if (lane_on) {
-          o.x *= d.out_scale; o.y *= d.out_scale; o.z *= d.out_scale; o.w *= d.out_scale;
-          if (d.drop_thr) {
-            const uint32_t keep = drop_keep4_raw(d.seed_lo, d.seed_hi, d.drop_thr, row, f);
-            const float4 dr = make_float4((keep & 1u) ? o.x * d.drop_scale : 0.f, (keep & 2u) ? o.y * d.drop_scale : 0.f,
-                                          (keep & 4u) ? o.z * d.drop_scale : 0.f, (keep & 8u) ? o.w * d.drop_scale : 0.f);
-            if (d.out2) st4s(d.out2 + row * d.ldo2 + f, dr);      // dual mode: out stays un-dropped
-            else o = dr;
-          }
-          st4s(d.out + row * d.ldo + f, o);
-        }
-      }
-    } else {
-      float4 zpre[NBA];
-#pragma unroll
-      for (int b = 0; b < NBA; b++)
-        zpre[b] = (rbase < M && lane_on) ? ld4s(d.Zr[b] + rbase * d.ldzr[b] + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int lr = 0; lr < 16; lr++) {
-        const uint64_t row = rbase + lr;
-        if (row >= M) break;
-        float4 zc[NBA];
-#pragma unroll
-        for (int b = 0; b < NBA; b++) {
-          zc[b] = zpre[b];
-          if (lr + 1 < 16 && row + 1 < M && lane_on) zpre[b] = ld4s(d.Zr[b] + (row + 1) * d.ldzr[b] + f);
-        }
-        const float4 dy = lane_on ? *reinterpret_cast<const float4 *>(stash + lr * SP + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        an_row_bwd<NBA>(d, row, f, lane_on, dy, zc, inv_seg, gs, go, gb);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (MODE == 1) {
-    // per-workgroup partial sums of the parameter gradients: the four wavefronts' column sums are added in
-    // wavefront order and left for act_norm_finish_kernel (fixed order: deterministic)
-    float *red = reinterpret_cast<float *>(gsm);            // [4 waves][1 + 2 NBA][SP]
-    constexpr int kKinds = 1 + 2 * NBA;
-    __syncthreads();                                        // every wavefront is done with its stash
-    if (lane_on) {
-      float *rw = red + (size_t)wv * kKinds * SP + f;
-      *reinterpret_cast<float4 *>(rw) = go;
-#pragma unroll
-      for (int b = 0; b < NBA; b++) {
-        *reinterpret_cast<float4 *>(rw + (1 + 2 * b) * SP) = gs[b];
-        *reinterpret_cast<float4 *>(rw + (2 + 2 * b) * SP) = gb[b];
-      }
-    }
-    __syncthreads();
-    for (uint32_t c = tid; c < d.N; c += kThreads) {
-      float s[kKinds];
-#pragma unroll
-      for (int k = 0; k < kKinds; k++)
-        s[k] = (red[(0 * kKinds + k) * SP + c] + red[(1 * kKinds + k) * SP + c]) + (red[(2 * kKinds + k) * SP + c] + red[(3 * kKinds + k) * SP + c]);
-#pragma unroll
-      for (int b = 0; b < NBA; b++) {
-        float *pp = d.partial + (((size_t)blockIdx.x * NBA + b) * 3) * d.N + c;
-        pp[0] = s[1 + 2 * b];                               // dscale
-        pp[d.N] = s[0];                                     // doffset (the same sum for every branch)
-        pp[2 * (size_t)d.N] = s[2 + 2 * b];                 // dbias
-      }
-    }
-  }
+  // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier).  Specialised for the two activations
+  //      the reference's configurations use (config_train: elu, relu) on full-width rows; everything else takes the generic
+  //      copy (activation looked up per element, column predicates)
+  const bool full = d.N == 32 * TW, same = NBA == 1 || d.act[1] == d.act[0];
+  if (full && same && d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true>(d, acc, gsm, m0);
+  else if (full && same && d.act[0] == 2) fused_epilogue<TW, MODE, NBA, 2, true>(d, acc, gsm, m0);
+  else fused_epilogue<TW, MODE, NBA, -1, false>(d, acc, gsm, m0);
 }
 
 int fill_dropout(FusedDesc &p, float drop_p, uint64_t drop_seed, const char *who) {
@@ -375,10 +540,28 @@ int fill_dropout(FusedDesc &p, float drop_p, uint64_t drop_seed, const char *who
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// SHADOW_FUSED_STAGGER=<shader cycles per k-step of one phase> (default 0 = derived below; -1 = off)
+int g_stagger_override = [] {
+  const char *e = getenv("SHADOW_FUSED_STAGGER");
+  return e ? atoi(e) : 0;
+}();
+
 template <int TW, int MODE, int NBP, int NBA>
-int launch_fused(const FusedDesc &d, hipStream_t st) {
+int launch_fused(FusedDesc d, hipStream_t st) {
   const size_t lds = (size_t)3 * 3 * TW * 64 * 16;
   const uint32_t grid = (d.M + 127) / 128;
+  {
+    int ncu = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    d.first_round = 2u * (uint32_t)ncu;
+    static const int mode = [] { const char *e = getenv("SHADOW_FUSED_STAGGER_MODE"); return e ? atoi(e) : 0; }();
+    d.stagger_mode = (uint32_t)mode;
+    // half a workgroup's lifetime: ~5500 shader cycles per k-unit (two k-steps of 48 MFMAs, two wavefronts per SIMD,
+    // measured 110 us per 16-unit workgroup) -- only worth it when there is more than one dispatch round
+    const uint32_t per_unit = g_stagger_override > 0 ? (uint32_t)g_stagger_override : 5500u * TW / 8u;
+    d.stagger_cycles = (g_stagger_override < 0 || grid <= d.first_round) ? 0u : per_unit * (uint32_t)NBP * d.units / 2u;
+  }
   if (d.K % 32 == 0) {
     if (lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>, lds));
     hipLaunchKernelGGL((gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>), dim3(grid), dim3(256), lds, st, d);
@@ -409,6 +592,17 @@ extern "C" int sl_set_fused_epilogue(int on) {
   const int prev = g_fused_epilogue ? 1 : 0;
   if (on >= 0) g_fused_epilogue = on != 0;
   return prev;
+}
+
+// column tiles of the B image the epilogue kernels stream: 4 or 8 (the image is zero-padded above N)
+extern "C" uint32_t sl_gemm_act_norm_tiles(uint32_t N) { return N <= 128 ? 4u : 8u; }
+
+extern "C" size_t sl_gemm_act_norm_pack_bytes(uint32_t N, uint32_t K) {
+  return (size_t)((K + 31) / 32) * 6 * sl_gemm_act_norm_tiles(N) * 64 * 16;
+}
+
+extern "C" int sl_gemm_act_norm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream) {
+  return sl_gemm_pack_b2_tiles(d_B, ldb, 1, K, d_B, ldb, 1, N, K, sl_gemm_act_norm_tiles(N), d_packed, stream);
 }
 
 extern "C" int sl_gemm_act_norm_supported(uint32_t N, uint32_t K) {

@@ -35,7 +35,8 @@ bool fused_epilogue_ok(uint32_t Fout, uint32_t Fin, const float *A0, int64_t lda
 
 extern "C" size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout) {
   // forward: Ws and Wn images ([Fout, Fin] each); backward: the [Fin, 2 Fout] image of [Ws^T | Wn^T]
-  const size_t fwd = 2 * sl_gemm_pack_bytes(Fout, Fin), bwd = sl_gemm_pack_bytes(Fin, 2 * Fout);
+  // (the epilogue kernels stream images of 4 or 8 column tiles: sl_gemm_act_norm_pack_bytes >= sl_gemm_pack_bytes)
+  const size_t fwd = 2 * sl_gemm_act_norm_pack_bytes(Fout, Fin), bwd = sl_gemm_act_norm_pack_bytes(Fin, 2 * Fout);
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -52,20 +53,23 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
   int rc;
   if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
   char *pk = (char *)d_pack;
-  const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
-  if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pb, stream)) != SG_OK) return rc;
   const int64_t ldz[2] = {Fout, Fout};
   const float *bias[2] = {d_bs, d_bn};
   const int acts[2] = {act, act};
   if (fused_epilogue_ok(Fout, Fin, d_X, ldx, d_AX, ldax)) {
     // both products in one launch, bias / act / norm / branch sum (/ dropout) in its epilogue (gemm_fused.hip)
+    const size_t pbf = sl_gemm_act_norm_pack_bytes(Fout, Fin);
+    if ((rc = sl_gemm_act_norm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
+    if ((rc = sl_gemm_act_norm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pbf, stream)) != SG_OK) return rc;
     const float *A[2] = {d_X, d_AX};
     const int64_t lda[2] = {ldx, ldax};
     float *Zw[2] = {d_Zs, d_Zn};
     return sl_gemm_act_norm_fwd(2, A, lda, pk, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
                                 drop_seed, d_out_dropped, Fout, stream);
   }
+  const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
+  if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
+  if ((rc = sl_gemm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pb, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_nt_f32(d_X, ldx, pk, d_Zs, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_nt_f32(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   const float *Z[2] = {d_Zs, d_Zn};
@@ -116,7 +120,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
     if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
     if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream)) != SG_OK) return rc;
     // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
-    if ((rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream)) != SG_OK) return rc;
+    if ((rc = sl_gemm_pack_b2_tiles(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, below ? sl_gemm_act_norm_tiles(Fin) : (Fin + 31) / 32,
+                                    d_pack, stream)) != SG_OK)
+      return rc;
     if (below) {
       const uint32_t Fb = below->F;
       const float *Zb[2] = {below->Zs, below->Zn};
@@ -154,7 +160,7 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
 // norm; backward: act_norm backward, dAX = dZ W, dX = A^T dAX, dW = dZ^T (A X).
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" size_t sl_gcn_pack_bytes(uint32_t Fin, uint32_t Fout) {
-  const size_t fwd = sl_gemm_pack_bytes(Fout, Fin), bwd = sl_gemm_pack_bytes(Fin, Fout);
+  const size_t fwd = sl_gemm_act_norm_pack_bytes(Fout, Fin), bwd = sl_gemm_pack_bytes(Fin, Fout);
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -169,17 +175,18 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
   if (n == 0) return SG_OK;
   int rc;
   if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
   const int64_t ldz[1] = {Fout};
   const float *bias[1] = {d_b};
   const int acts[1] = {act};
   if (fused_epilogue_ok(Fout, Fin, d_AX, ldax, nullptr, 0)) {
+    if ((rc = sl_gemm_act_norm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
     const float *A[1] = {d_AX};
     const int64_t lda[1] = {ldax};
     float *Zw[1] = {d_Z};
     return sl_gemm_act_norm_fwd(1, A, lda, d_pack, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
                                 drop_seed, d_out_dropped, Fout, stream);
   }
+  if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_nt_f32(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   const float *Z[1] = {d_Z};
   return sl_act_norm_fwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,

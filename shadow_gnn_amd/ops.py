@@ -662,13 +662,13 @@ def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
     F = Ws[0].shape[0]
     dev = Xs[0].device
     st = _stream(Xs[0])
-    pb = lib.sl_gemm_pack_bytes(F, K)
+    pb = lib.sl_gemm_act_norm_pack_bytes(F, K)
     pack = torch.empty(nb * pb, dtype=torch.uint8, device=dev)
     for b, w in enumerate(Ws):
         wc = w.detach()
         if wc.stride(1) != 1:
             wc = wc.contiguous()
-        check(lib.sl_gemm_pack_b(wc.data_ptr(), wc.stride(0), F, K, pack.data_ptr() + b * pb, st))
+        check(lib.sl_gemm_act_norm_pack_b(wc.data_ptr(), wc.stride(0), F, K, pack.data_ptr() + b * pb, st))
     Zs = [torch.empty(M, F, dtype=torch.float32, device=dev) for _ in range(nb)]
     out = torch.empty(M, F, dtype=torch.float32, device=dev)
     out2 = torch.empty_like(out) if _is_dual(drop) else None
@@ -683,6 +683,36 @@ def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
                                        int(drop[1]), out2.data_ptr() if out2 is not None else None,
                                        out2.stride(0) if out2 is not None else 0, st))
     return Zs, (out if out2 is None else (out, out2))
+
+
+def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True):
+    """G = A @ W^T is the gradient of out = sum_b norm_b(act(Z_b + bias_b)) (through its fused output dropout when
+    drop[0] > 0); returns (dZs, dscale, doffset, dbias) without ever writing G: the act_norm backward runs in the GEMM's
+    epilogue (sl_gemm_an_bwd; what sl_sage_bwd_chain does between two GraphSAGE layers).  nb = 2 only."""
+    lib = _lib.load()
+    nb = len(Zs)
+    M, K = A.shape
+    N = W.shape[0]
+    dev = A.device
+    st = _stream(A)
+    tiles = lib.sl_gemm_act_norm_tiles(N)
+    pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(N, K), dtype=torch.uint8, device=dev)
+    Wc = W.detach().contiguous()
+    check(lib.sl_gemm_pack_b2_tiles(Wc.data_ptr(), Wc.stride(0), 1, K, Wc.data_ptr(), Wc.stride(0), 1, N, K, tiles, pack.data_ptr(), st))
+    dZs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(nb)]
+    dsc = torch.empty(nb, N, dtype=torch.float32, device=dev)
+    dof = torch.empty(nb, N, dtype=torch.float32, device=dev)
+    dbi = torch.empty(nb, N, dtype=torch.float32, device=dev) if want_dbias else None
+    partial = torch.empty(lib.sl_gemm_an_bwd_partial_floats(M, N, nb), dtype=torch.float32, device=dev)
+    ldz = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
+    lddz = (C.c_int64 * nb)(*[N] * nb)
+    ac = (C.c_int * nb)(*codes)
+    nbytes = 4 * M * (K + 2 * nb * N)           # read A and every Z_b, write every dZ_b
+    with _timed(f"gemm_an_bwd_nb{nb}_N{N}", nbytes, dev, flops=2 * M * K * N):
+        check(lib.sl_gemm_an_bwd(A.data_ptr(), A.stride(0), pack.data_ptr(), M, N, K, nb, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
+                                 sc.data_ptr(), of.data_ptr(), 1.0, _ptr_array(dZs), lddz, dsc.data_ptr(), dof.data_ptr(),
+                                 dbi.data_ptr() if dbi is not None else None, partial.data_ptr(), float(drop[0]), int(drop[1]), st))
+    return dZs, dsc, dof, dbi
 
 
 class ChainLink:
