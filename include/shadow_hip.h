@@ -486,6 +486,16 @@ int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t ldax, const fl
                float *d_dW, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial,
                float *d_tn_partial, void *d_pack, void *stream);
 
+/* Per-kernel timing inside the layer entries above (csrc/prof.hip): while sl_prof_enable(1) is in effect every kernel a
+ * sl_sage_* / sl_gcn_* entry launches is bracketed by a HIP-event pair on its stream, under the kernel class names and
+ * algorithmic byte / flop counts bench.py reports -- the measured call path is the timed call
+ * path.  sl_prof_enable(1) clears earlier records; (0) stops recording; a negative argument only queries; returns the
+ * previous state.  sl_prof_dump waits for the events and writes one line per kernel class,
+ * "name\tlaunches\ttimed launches\ttotal ms\tbytes\tflops\n" (sums over the timed launches), into buf (at most cap
+ * bytes incl. the terminating 0); returns the size the text needs.                                                */
+int sl_prof_enable(int on);
+size_t sl_prof_dump(char *buf, size_t cap);
+
 /* End of a training step on flat fp32 buffers (shaDow/models.py:225-226: torch.nn.utils.clip_grad_norm_(parameters, 5)
  * + torch.optim.Adam.step(), default betas / eps, no weight decay): the gradient is scaled IN PLACE by
  * min(1, max_norm / (||g|| + 1e-6)) (max_norm <= 0: no clipping), the moments and the parameters are updated with

@@ -50,14 +50,36 @@ class EdgeList:
         return torch.zeros(self.n, X.shape[1], dtype=X.dtype).index_add_(0, self.rows, X[self.cols] * self.w[:, None])
 
 
-def gcn_forward(p, X, A, act):
+KINK_BAND = 1e-4       # |pre-activation| below which a relu unit's side may legitimately differ between two precisions
+
+
+def _act(act, p, z, keep, stats):
+    """The layer's activation.  ``keep`` (optional, relu only): the 0/1 pattern z > 0 of ANOTHER evaluation of the same
+    network (the fp32 run under test).  relu has no derivative at 0; among ~10^7 pre-activations of a batch a handful lie
+    within rounding of 0 and two precisions put them on different sides -- each such unit switches one weight row's
+    gradient by that node's whole contribution, in any implementation.  With ``keep`` the oracle takes the other run's
+    side for those units (h = z * keep: the forward value moves by < KINK_BAND) so that both differentiate the SAME
+    piecewise-linear function, and asserts that everywhere outside the band |z| < KINK_BAND the two agree anyway."""
+    if keep is None:
+        return lo.act_fn(act, p)(z)
+    assert act == "relu", act
+    keep = keep.to(torch.bool)
+    differ = (z.detach() > 0) != keep
+    assert not bool((differ & (z.detach().abs() >= KINK_BAND)).any()), "relu sides differ outside the kink band"
+    if stats is not None:
+        stats["kink_units"] = stats.get("kink_units", 0) + int(differ.sum())
+        stats["units"] = stats.get("units", 0) + differ.numel()
+    return z * keep.to(z.dtype)
+
+
+def gcn_forward(p, X, A, act, keep=None, stats=None):
     z = F.linear(A.matmul(X), p["f_lin.weight"], p["f_lin.bias"])                       # layers.py:433-435
-    return lo.f_norm(lo.act_fn(act, p)(z), p["scale"][0], p["offset"][0])
+    return lo.f_norm(_act(act, p, z, keep[0] if keep else None, stats), p["scale"][0], p["offset"][0])
 
 
-def sage_forward(p, X, A, act):
-    hs = lo.act_fn(act, p)(F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"]))   # layers.py:473-483
-    hn = lo.act_fn(act, p)(F.linear(A.matmul(X), p["f_lin_neigh.weight"], p["f_lin_neigh.bias"]))
+def sage_forward(p, X, A, act, keep=None, stats=None):
+    hs = _act(act, p, F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"]), keep[0] if keep else None, stats)   # layers.py:473-483
+    hn = _act(act, p, F.linear(A.matmul(X), p["f_lin_neigh.weight"], p["f_lin_neigh.bias"]), keep[1] if keep else None, stats)
     return lo.f_norm(hs, p["scale"][0], p["offset"][0]) + lo.f_norm(hn, p["scale"][1], p["offset"][1])
 
 
@@ -83,9 +105,10 @@ def gat_forward(p, X, A, act, heads):
     return (torch.cat(outs_s, 1) + torch.cat(outs_n, 1)) / 2                            # :623-625
 
 
-def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtype=torch.float64):
+def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtype=torch.float64, relu_keep=None, stats=None):
     """DeepGNN.forward (models.py:169-204, one branch).  ``p``: state_dict tensors (any float dtype; cast to
-    ``dtype`` here -- pass leaves of that dtype with requires_grad to get gradients)."""
+    ``dtype`` here -- pass leaves of that dtype with requires_grad to get gradients).  ``relu_keep``: per layer, the
+    z > 0 patterns of the run under test (one per Linear branch), see _act; ``stats`` collects the kink-unit count."""
     kind, L, heads, act = arch["aggr"], arch["num_layers"], int(arch.get("heads", 1)), arch["act"]
     p = {k: (v if v.dtype == dtype else v.to(dtype)) for k, v in p.items()}
     x = X.to(dtype)
@@ -96,10 +119,11 @@ def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtyp
     for l in range(L):
         pre = f"conv_layers.0.{l}."
         lp = {k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}
+        keep = relu_keep[l] if relu_keep is not None else None
         if kind == "gcn":
-            x = gcn_forward(lp, x, A, act)
+            x = gcn_forward(lp, x, A, act, keep, stats)
         elif kind == "sage":
-            x = sage_forward(lp, x, A, act)
+            x = sage_forward(lp, x, A, act, keep, stats)
         else:
             x = gat_forward(lp, x, A, act, heads)
         feats.append(x)

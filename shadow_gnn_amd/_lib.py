@@ -137,6 +137,8 @@ SIGNATURES = {
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, C.c_int, C.POINTER(SlSageBelow), _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
+    "sl_prof_enable": (C.c_int, [C.c_int]),
+    "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "sl_gemm_act_norm_supported": (C.c_int, [C.c_uint32, C.c_uint32]),
     "sl_gemm_act_norm_tiles": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_act_norm_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),

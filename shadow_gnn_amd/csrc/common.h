@@ -25,6 +25,23 @@ int set_error(int code, const char *fmt, ...);
 // (kernel, device) and only ask again for more (the hot launches of a training step call it thousands of times otherwise)
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
 
+// Optional per-kernel timing inside the C entries (prof.hip): SHD_PROF(name, algorithmic bytes, flops, stream) at the top of
+// a launch scope records a HIP-event pair around it while sl_prof_enable(1) is in effect; one branch otherwise.
+bool prof_enabled();
+struct ProfScope {
+  int idx;
+  hipStream_t st;
+  ProfScope(const char *name, double bytes, double flops, hipStream_t st);
+  ~ProfScope();
+};
+#define SHD_PROF(NAME, BYTES, FLOPS, ST) shadow::ProfScope prof_scope_((NAME), (double)(BYTES), (double)(FLOPS), (hipStream_t)(ST))
+// (name built only when profiling is on)
+#define SHD_PROF_FMT(BYTES, FLOPS, ST, ...)                                              \
+  char prof_name_[96];                                                                   \
+  prof_name_[0] = 0;                                                                     \
+  if (shadow::prof_enabled()) snprintf(prof_name_, sizeof(prof_name_), __VA_ARGS__);    \
+  SHD_PROF(prof_name_, BYTES, FLOPS, ST)
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

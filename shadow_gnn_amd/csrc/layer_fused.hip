@@ -19,10 +19,23 @@ int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx,
   const uint32_t *perm = (transposed && a->edge_w) ? a->t_perm : nullptr;
   // (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
   const float *rs = transposed ? a->col_scale : a->row_scale, *cs = transposed ? a->row_scale : a->col_scale;
+  // algorithmic bytes: indptr + indices (+ edge values) + read X + write A.X
+  SHD_PROF_FMT(4.0 * (a->n + 1) + 4.0 * a->e + (a->edge_w ? 4.0 * a->e : 0.0) + 8.0 * a->n * F, 0, st, "spmm_F%u", F);
   if (a->subg_node_off && F >= 96)
     return sl_spmm_blockdiag_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
                                  a->num_subg, a->max_subg_nodes, st);
   return sl_spmm_csr_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, st);
+}
+
+// the primitives, each under its profiling scope (names and byte / flop counts as ops.py gives them to KernelTimer)
+int nt_gemm(const float *A, int64_t lda, const void *pk, float *Cm, int64_t ldc, uint32_t M, uint32_t N, uint32_t K, void *st) {
+  SHD_PROF_FMT(4.0 * M * (K + N), 2.0 * M * K * N, st, "gemm_nt_split_N%u%s", N, K % 32 ? "_Ktail" : "");
+  return sl_gemm_nt_f32(A, lda, pk, Cm, ldc, M, N, K, st);
+}
+
+int tn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm, uint32_t M, uint32_t N, uint32_t K, float *partial, void *st) {
+  SHD_PROF_FMT(4.0 * M * (N + K), 2.0 * M * N * K, st, "gemm_tn_split_N%u%s", N, K <= 128 ? "_K128" : "");
+  return sl_gemm_tn_f32(A, lda, B, ldb, Cm, M, N, K, partial, st);
 }
 
 // the GEMM-epilogue forms (gemm_fused.hip) take 16-byte aligned operands with row pitches of whole float4s
@@ -64,15 +77,17 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
     const float *A[2] = {d_X, d_AX};
     const int64_t lda[2] = {ldx, ldax};
     float *Zw[2] = {d_Zs, d_Zn};
+    SHD_PROF_FMT(4.0 * n * (2 * Fin + 2 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 2 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 2, Fout, Fin % 32 ? "_Ktail" : "");
     return sl_gemm_act_norm_fwd(2, A, lda, pk, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
                                 drop_seed, d_out_dropped, Fout, stream);
   }
   const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
   if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pb, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_nt_f32(d_X, ldx, pk, d_Zs, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_nt_f32(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  if ((rc = nt_gemm(d_X, ldx, pk, d_Zs, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  if ((rc = nt_gemm(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   const float *Z[2] = {d_Zs, d_Zn};
+  SHD_PROF_FMT((2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_fwd_nb%d_F%u", 2, Fout);
   return sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
                          d_out_dropped, Fout, stream);
 }
@@ -112,6 +127,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
     const int acts[2] = {act, act};
     float *dZ[2] = {dZs, dZn};
     const int64_t lddz[2] = {ld3, ld3};
+    SHD_PROF_FMT((2 * 2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 2, Fout);
     if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
                               d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
       return rc;
@@ -131,16 +147,18 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       const int actsb[2] = {below->act, below->act};
       float *dZb[2] = {below->buf, below->buf + 2 * (size_t)Fb};
       const int64_t lddzb[2] = {3 * (int64_t)Fb, 3 * (int64_t)Fb};
+      // read [dZs | A^T dZn] and both Z of the layer below, write its two dZ
+      SHD_PROF_FMT(4.0 * n * (2.0 * Fout + 4.0 * Fb), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_an_bwd_nb2_N%u", Fin);
       if ((rc = sl_gemm_an_bwd(d_buf, ld3, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
                                lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
                                stream)) != SG_OK)
         return rc;
-    } else if ((rc = sl_gemm_nt_f32(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
+    } else if ((rc = nt_gemm(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
       return rc;
     }
   }
-  if ((rc = sl_gemm_tn_f32(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
-  return sl_gemm_tn_f32(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+  if ((rc = tn_gemm(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
+  return tn_gemm(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
 }
 
 extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax,
@@ -183,12 +201,14 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
     const float *A[1] = {d_AX};
     const int64_t lda[1] = {ldax};
     float *Zw[1] = {d_Z};
+    SHD_PROF_FMT(4.0 * n * (1 * Fin + 1 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 1 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 1, Fout, Fin % 32 ? "_Ktail" : "");
     return sl_gemm_act_norm_fwd(1, A, lda, d_pack, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
                                 drop_seed, d_out_dropped, Fout, stream);
   }
   if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
-  if ((rc = sl_gemm_nt_f32(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
+  if ((rc = nt_gemm(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   const float *Z[1] = {d_Z};
+  SHD_PROF_FMT((1 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_fwd_nb%d_F%u", 1, Fout);
   return sl_act_norm_fwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
                          d_out_dropped, Fout, stream);
 }
@@ -213,15 +233,18 @@ extern "C" int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t lda
   const int acts[1] = {act};
   float *dZs[1] = {dZ};
   const int64_t lddz[1] = {Fout};
-  if ((rc = sl_act_norm_bwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZs, lddz, d_dscale,
-                            d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
-    return rc;
+  {
+    SHD_PROF_FMT((2 * 1 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 1, Fout);
+    if ((rc = sl_act_norm_bwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZs, lddz, d_dscale,
+                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
+      return rc;
+  }
   if (d_dX) {
     if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_gcn_bwd: the input gradient needs the transposed adjacency");
     // dAX = dZ . W: B image of W^T ([Fin, Fout] read transposed out of W), then dX = A^T dAX
     if ((rc = sl_gemm_pack_b2(d_W, 1, ldw, Fout, nullptr, 0, 0, Fin, Fout, d_pack, stream)) != SG_OK) return rc;
-    if ((rc = sl_gemm_nt_f32(dZ, Fout, d_pack, dAX, Fin, n, Fin, Fout, stream)) != SG_OK) return rc;
+    if ((rc = nt_gemm(dZ, Fout, d_pack, dAX, Fin, n, Fin, Fout, stream)) != SG_OK) return rc;
     if ((rc = spmm_any(adj, true, dAX, Fin, d_dX, lddx, Fin, stream)) != SG_OK) return rc;
   }
-  return sl_gemm_tn_f32(dZ, Fout, d_AX, ldax, d_dW, n, Fout, Fin, d_tn_partial, stream);
+  return tn_gemm(dZ, Fout, d_AX, ldax, d_dW, n, Fout, Fin, d_tn_partial, stream);
 }

@@ -32,8 +32,16 @@ class FlatAdam:
         self._scratch = None
         self.param_groups = [dict(lr=self.lr, betas=self.betas, eps=self.eps, params=list(params))]   # (torch-like, read-only)
 
+    def _gather_grads(self):
+        """The gradients must be IN the flat buffer: GradSync packs them lazily (param.grad is None during backward and
+        the buffer is filled inside GradSync.all_reduce).  DeepGNN._finish_update has normally done that already; a caller
+        that runs backward and then steps this optimiser directly would otherwise update from an all-zero buffer.
+        (Idempotent: a second call finds nothing left to pack or to reduce.)"""
+        self.sync.all_reduce()
+
     # torch.nn.utils.clip_grad_norm_(params, max_norm): no host synchronisation
     def clip_(self, max_norm: float) -> torch.Tensor:
+        self._gather_grads()
         g = self.sync.flat
         total = torch.linalg.vector_norm(g, 2)
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
@@ -42,6 +50,7 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
+        self._gather_grads()
         self.step_count += 1
         b1, b2 = self.betas
         g = self.sync.flat
@@ -56,6 +65,7 @@ class FlatAdam:
     def clip_step_(self, max_norm: float) -> torch.Tensor:
         """clip_(max_norm) + step() in two HIP launches (sl_clip_adam) instead of a dozen element-wise torch kernels; falls
         back to the torch statements off the GPU.  Returns the gradient norm before clipping (a device scalar)."""
+        self._gather_grads()
         g = self.sync.flat
         if not g.is_cuda or os.environ.get("SHADOW_FUSED_ADAM", "1") == "0":
             total = self.clip_(max_norm)
@@ -74,11 +84,45 @@ class FlatAdam:
     def zero_grad(self, set_to_none: bool = False):
         self.sync.zero()
 
+    def _param_slices(self):
+        off = 0
+        for p in self.sync.params:
+            yield off, off + p.numel(), p
+            off += p.numel()
+
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
-                    lr=self.lr, betas=self.betas, eps=self.eps)
+        """torch.optim.Adam's layout -- {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} -- so that
+        the reference's optimizer checkpoints (main.py:130-132, saved_optimizer_*.pkl) and this class's are interchangeable:
+        the flat moment buffers are cut per parameter."""
+        state = {}
+        for i, (lo, hi, p) in enumerate(self._param_slices()):
+            state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[lo:hi].view_as(p).clone(),
+                            exp_avg_sq=self.exp_avg_sq[lo:hi].view_as(p).clone())
+        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None, params=list(range(len(self.sync.params))))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+        if "state" not in sd:                         # the flat layout of round 2
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+            return
+        g = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(g["params"]) != len(self.sync.params):
+            raise ValueError("optimizer state does not match this model's parameter list")
+        if g.get("weight_decay", 0) or g.get("amsgrad", False):
+            raise ValueError("FlatAdam implements Adam without weight decay / amsgrad")
+        self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+        steps = set()
+        with torch.no_grad():
+            for i, (lo, hi, p) in enumerate(self._param_slices()):
+                st = sd["state"].get(g["params"][i], sd["state"].get(i))
+                if st is None:                        # a parameter that never received a gradient has no entry in torch
+                    self.exp_avg[lo:hi].zero_(); self.exp_avg_sq[lo:hi].zero_()
+                    continue
+                self.exp_avg[lo:hi].copy_(st["exp_avg"].reshape(-1)); self.exp_avg_sq[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): FlatAdam keeps one")
+        self.step_count = steps.pop() if steps else 0

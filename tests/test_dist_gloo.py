@@ -143,3 +143,39 @@ def test_deferred_work_registry():
     ops.defer(("a", 0), lambda: fired.append("late"))
     ops.fire_deferred("fwd")
     assert fired[-1] == "late" and not ops._DEFERRED
+
+
+def test_flat_adam_steps_without_an_explicit_all_reduce_and_speaks_torch_adam_state():
+    """ GradSync packs gradients lazily; FlatAdam must gather them itself when nobody called
+    GradSync.all_reduce -- otherwise it silently updates from an all-zero buffer.  Three steps equal torch.optim.Adam's,
+    and the optimizer state round-trips through torch.optim.Adam's state_dict layout in both directions."""
+    import copy
+    from shadow_gnn_amd.dist import GradSync
+    from shadow_gnn_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref = copy.deepcopy(net)
+    x, y = torch.randn(16, 6), torch.randn(16, 3)
+    sync = GradSync(net.parameters(), world_size=1)
+    opt = FlatAdam(sync, lr=0.01)
+    topt = torch.optim.Adam(ref.parameters(), lr=0.01)
+    for _ in range(3):
+        sync.zero()
+        ((net(x) - y) ** 2).mean().backward()
+        opt.step()                                           # no sync.all_reduce() in between
+        topt.zero_grad()
+        ((ref(x) - y) ** 2).mean().backward()
+        topt.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (a - b).abs().max()
+    # FlatAdam -> torch Adam
+    t2 = torch.optim.Adam(ref.parameters(), lr=0.5)
+    t2.load_state_dict(opt.state_dict())
+    assert t2.param_groups[0]["lr"] == 0.01
+    for i, p in enumerate(ref.parameters()):
+        assert torch.allclose(t2.state[p]["exp_avg"], topt.state[p]["exp_avg"], rtol=1e-5, atol=1e-8)
+    # torch Adam -> FlatAdam
+    opt2 = FlatAdam(GradSync(copy.deepcopy(net).parameters(), world_size=1), lr=0.5)
+    opt2.load_state_dict(topt.state_dict())
+    assert opt2.step_count == 3 and opt2.lr == 0.01
+    assert torch.allclose(opt2.exp_avg, opt.exp_avg, rtol=1e-5, atol=1e-8) and torch.allclose(opt2.exp_avg_sq, opt.exp_avg_sq, rtol=1e-5, atol=1e-10)

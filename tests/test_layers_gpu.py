@@ -17,7 +17,7 @@ DEV = "cuda:0"
 def gemm_route(request, monkeypatch):
     """'mfma': every Linear the split-bf16 MFMA kernels can take goes through them (ops.GEMM_SPLIT_MIN_ROWS = 1, the
     SHADOW_GEMM_SPLIT_MIN_ROWS knob), so the reference's small golden fixtures exercise gemm_nt / gemm_tn and the
-    fused GraphSAGE node's K = 2F input gradient; 'default': rocBLAS below 8192 rows."""
+    fused GraphSAGE node's K = 2F input gradient; 'default': rocBLAS below ops.GEMM_SPLIT_MIN_ROWS = 1024 rows."""
     from shadow_gnn_amd import ops
     if request.param == "mfma":
         monkeypatch.setattr(ops, "GEMM_SPLIT_MIN_ROWS", 1)
@@ -708,28 +708,34 @@ def _bench_scale_batch(aggr, B):
     return b, X, labels, F0, C
 
 
+@pytest.mark.parametrize("optimizer", ["adam", "flat"])
 @pytest.mark.parametrize("aggr,layers_,heads,B,act", [("sage", 5, 1, 128, "elu"), ("sage", 5, 1, 128, "relu"), ("gcn", 3, 1, 128, "elu"),
-                                                     ("gat", 5, 4, 96, "elu")])
-def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B, act):
+                                                     ("gcn", 3, 1, 128, "relu"), ("gat", 5, 4, 96, "elu")])
+def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B, act, optimizer):
     """ONE DeepGNN.step at benchmark widths (dim 256, F0 = 100) on a batch large enough (n >= 8192 rows) that every
-    Linear runs on the split-bf16 MFMA kernels (gemm_nt_split / gemm_tn_split) and GraphSAGE goes through the fused
-    _SageDense node (dX = [dZs | A^T dZn] . [Ws ; Wn], K = 2F, column-slice views) -- the path bench.py times --
-    against the fp64 edge-list oracle (oracle/model_oracle_sparse.py, pinned to the reference's golden model steps):
-    predictions, loss, embeddings <= 1e-4; every parameter gradient <= 1e-3 relative (+ 1e-4 of the tensor's
-    scale); clipped-norm Adam update consistent.  dropout = dropedge = 0 (the reference's RNG streams are not
-    reproducible), everything else as in config_train/products/vanilla/sage_5_khop.yml.
+    Linear runs on the split-bf16 MFMA kernels, through EXACTLY the call path bench.py times: the one-call layer
+    entries (sl_sage_fwd: both products + act / norm in one kernel; sl_sage_bwd_chain: the act_norm backward of the layer
+    below in the input-gradient GEMM's epilogue; sl_gcn_fwd / sl_gcn_bwd) -- asserted through the entry counters and the
+    kernel classes the C-side profiler saw (a KernelTimer no longer changes the path) -- and, for optimizer = "flat",
+    dist.GradSync + optim.FlatAdam (sl_clip_adam) as in bench.py.  Checked against the fp64 edge-list oracle
+    (oracle/model_oracle_sparse.py, pinned to the reference's golden model steps): predictions, loss, embeddings <= 1e-4;
+    EVERY entry of every parameter gradient <= 1e-3 relative (+ 1e-4 of the tensor's scale); the clipped-norm Adam update
+    entry by entry.  dropout = dropedge = 0 (the reference's RNG streams are not reproducible), everything else as in
+    config_train/products/vanilla/sage_5_khop.yml.
 
-    Activation: 'elu' (C1-smooth) is held to the element-wise bound on EVERY gradient entry.  'relu' (the products
-    configuration's) has a kink: among the ~10^7 pre-activations of a batch a handful lie within fp32 rounding of 0,
-    fp32 and fp64 put them on different sides, and each such unit switches the gradient of ONE weight row by that
-    node's whole contribution (any fp32 implementation, the reference's included, differs from fp64 this way).  For
-    relu the element-wise bound must therefore hold for all but <= 1 % of a tensor's entries, with the tensor's
-    relative L2 error <= 2e-2; predictions, loss and embeddings are held to 1e-4 as for elu."""
+    relu (the products configuration's activation) has no derivative at 0: among the ~10^7 pre-activations of a batch a
+    handful lie within rounding of 0 and fp32 / fp64 put them on different sides (any fp32 implementation, the
+    reference's included, differs from fp64 this way).  The oracle therefore takes the side the run under test took for
+    units with |z| < 1e-4 (ops.Z_TAP hands over the run's pre-activations; outside that band the sides must agree --
+    asserted) so that both differentiate the same piecewise-linear function, and the relu runs are held to the SAME
+    element-wise bound as the smooth elu runs (round 2 allowed 1 % outliers and 2e-2 in L2 instead)."""
     from oracle import layers_oracle as lo
     from oracle import model_oracle_sparse as mos
+    from shadow_gnn_amd import dist as sdist
     from shadow_gnn_amd import ops
     from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
     from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.optim import FlatAdam
     b, X, labels, F0, C = _bench_scale_batch(aggr, B)
     n = b.num_nodes
     assert n >= ops.GEMM_SPLIT_MIN_ROWS and ops.GEMM_SPLIT, n
@@ -741,7 +747,11 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
     with torch.no_grad():                                # scale / offset / bias away from their initial 1 / 0
         for q in model.parameters():
             q.add_(0.05 * torch.randn_like(q))
-    model.optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+    if optimizer == "flat":                              # bench.py's optimiser path
+        model.grad_sync = sdist.GradSync(model.parameters(), world_size=1)
+        model.optimizer = FlatAdam(model.grad_sync, lr=lr)
+    else:
+        model.optimizer = torch.optim.Adam(model.parameters(), lr=lr)
     p0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     h = b.to_host()
     sizes = np.diff(h["subg_node_off"].astype(np.int64))
@@ -749,14 +759,33 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
     adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off,
                         max_subg_nodes=b.counts["max_subg_nodes"])
     batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
-    with timer:
-        ret = model.step(TRAIN, "running", batch)
-    torch.cuda.synchronize()
+    c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls)
+    ops.Z_TAP = []
+    try:
+        with timer:
+            ret = model.step(TRAIN, "running", batch)
+        torch.cuda.synchronize()
+        tap = ops.Z_TAP
+    finally:
+        ops.Z_TAP = None
     ran = set(timer.summary())
-    assert any(k.startswith("gemm_nt_split") for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
-    # ---- fp64 oracle, same parameters
+    # the call path: one-call entries with the GEMM-epilogue kernels, every layer boundary chained
+    if aggr == "sage":
+        assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (layers_, layers_ - 1)
+        assert any(k.startswith("gemm_act_norm_fwd_nb2") for k in ran) and any(k.startswith("gemm_an_bwd_nb2") for k in ran), ran
+        assert not any(k.startswith("act_norm_fwd") and k.endswith("F256") for k in ran), ran
+    if aggr == "gcn":
+        assert any(k.startswith("gemm_act_norm_fwd_nb1") for k in ran), ran
+    assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
+    # ---- fp64 oracle, same parameters (relu: with the run's own side at the kink, see the docstring)
+    relu_keep, kstats = None, {}
+    if act == "relu" and aggr in ("sage", "gcn"):
+        assert len(tap) >= layers_
+        relu_keep = [[((z + (bb if bb is not None else 0)) > 0).cpu() for z, bb in zip(zs, bs_)] for zs, bs_ in tap[:layers_]]
     p = {k: v.double().requires_grad_(True) for k, v in p0.items()}
-    preds_ref, emb_ref = mos.model_forward(p, arch, X, h["indptr"], h["indices"], sizes, h["target"])
+    preds_ref, emb_ref = mos.model_forward(p, arch, X, h["indptr"], h["indices"], sizes, h["target"], relu_keep=relu_keep, stats=kstats)
+    if relu_keep is not None:
+        assert kstats["kink_units"] <= 1e-5 * kstats["units"], kstats      # a handful among ~10^7
     loss_ref = lo.model_loss(preds_ref, labels.numpy())
     loss_ref.backward()
     assert abs(float(ret["loss"]) - float(loss_ref)) < 1e-4
@@ -772,15 +801,9 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         got = q.grad.cpu().numpy()
         scale = float(np.abs(ref).max())
         bad = np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-4 * scale
-        if act == "relu":
-            worst[k] = float(bad.mean())
-            assert bad.mean() <= 0.01, (k, float(bad.mean()))
-            assert np.linalg.norm(got - ref) <= 2e-2 * np.linalg.norm(ref), (k, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
-        else:
-            worst[k] = float(np.abs(got - ref).max() / max(scale, 1e-30))
-            assert not bad.any(), (k, int(bad.sum()), worst[k])
-    if act != "relu":
-        assert max(worst.values()) < 1e-3, worst
+        worst[k] = float(np.abs(got - ref).max() / max(scale, 1e-30))
+        assert not bad.any(), (k, int(bad.sum()), worst[k])
+    assert max(worst.values()) < 1e-3, worst
     # Adam: entries with a solid gradient moved like the oracle's update, the rest by at most lr
     for k, q in model.named_parameters():
         gref = (grads[k] * coef)
@@ -789,7 +812,7 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         assert float((got - p0[k].double()).abs().max()) <= lr * 1.001 + 1e-7, k
         solid = gref.abs() > 1e-3 * gref.abs().max()
         moved_ok = (got[solid] - want[solid]).abs() <= 1e-4 * want[solid].abs() + 2e-5
-        assert float(moved_ok.double().mean()) >= (0.99 if act == "relu" else 1.0), k
+        assert float(moved_ok.double().mean()) >= 1.0, k
 
 
 # --------------------------------------------------------------------------------------------------------------
