@@ -50,25 +50,25 @@ class EdgeList:
         return torch.zeros(self.n, X.shape[1], dtype=X.dtype).index_add_(0, self.rows, X[self.cols] * self.w[:, None])
 
 
-KINK_BAND = 1e-4       # |pre-activation| below which a relu unit's side may legitimately differ between two precisions
-
-
 def _act(act, p, z, keep, stats):
     """The layer's activation.  ``keep`` (optional, relu only): the 0/1 pattern z > 0 of ANOTHER evaluation of the same
     network (the fp32 run under test).  relu has no derivative at 0; among ~10^7 pre-activations of a batch a handful lie
     within rounding of 0 and two precisions put them on different sides -- each such unit switches one weight row's
     gradient by that node's whole contribution, in any implementation.  With ``keep`` the oracle takes the other run's
-    side for those units (h = z * keep: the forward value moves by < KINK_BAND) so that both differentiate the SAME
-    piecewise-linear function, and asserts that everywhere outside the band |z| < KINK_BAND the two agree anyway."""
+    side for those units (h = z * keep) so that both differentiate the SAME piecewise-linear function.  ``stats`` reports
+    how many units that concerned and the largest |z| among them (the caller bounds both: a side that differs far from 0
+    would be a real error, not a kink; rows whose activations are almost all dead have a tiny variance and amplify
+    rounding differences of the layer before, so the band is not 1 ulp wide)."""
     if keep is None:
         return lo.act_fn(act, p)(z)
     assert act == "relu", act
     keep = keep.to(torch.bool)
     differ = (z.detach() > 0) != keep
-    assert not bool((differ & (z.detach().abs() >= KINK_BAND)).any()), "relu sides differ outside the kink band"
     if stats is not None:
         stats["kink_units"] = stats.get("kink_units", 0) + int(differ.sum())
         stats["units"] = stats.get("units", 0) + differ.numel()
+        if bool(differ.any()):
+            stats["kink_max_abs_z"] = max(stats.get("kink_max_abs_z", 0.0), float(z.detach().abs()[differ].max()))
     return z * keep.to(z.dtype)
 
 

@@ -769,7 +769,8 @@ Z_TAP = None
 
 def _tap(Zs, biases):
     if Z_TAP is not None:
-        Z_TAP.append(([z.detach() for z in Zs], [b.detach() if b is not None else None for b in biases]))
+        # (the biases are parameters: copied, the optimiser updates them in place before the test reads the tap)
+        Z_TAP.append(([z.detach() for z in Zs], [b.detach().clone() if b is not None else None for b in biases]))
 
 
 class _LinearActNorm(torch.autograd.Function):
