@@ -24,6 +24,27 @@ namespace shadow {
 
 constexpr int kBlock = 256;
 
+// Stores of kernels whose output the NEXT kernel reads (the gathered feature rows -> layer-0 aggregation, the aggregate
+// -> the layer's GEMM): plain, so that the lines stay in the L2 / Infinity Cache for the consumer.  Round 2 had made them
+// non-temporal together with the act_norm streams and lost 25 % on the F = 100 aggregation (102 -> 129 us) -- A/B per
+// call site: scripts/ab_nt_stores.sh.  -DSHADOW_NT_GATHER_OUT=1 / -DSHADOW_NT_SPMM_OUT=1 rebuild the non-temporal forms.
+#ifndef SHADOW_NT_GATHER_OUT
+#define SHADOW_NT_GATHER_OUT 0
+#endif
+#ifndef SHADOW_NT_SPMM_OUT
+#define SHADOW_NT_SPMM_OUT 0
+#endif
+#if SHADOW_NT_GATHER_OUT
+#define SHD_ST_GATHER st4s
+#else
+#define SHD_ST_GATHER st4
+#endif
+#if SHADOW_NT_SPMM_OUT
+#define SHD_ST_SPMM st4s
+#else
+#define SHD_ST_SPMM st4
+#endif
+
 // ---------------------------------------------------------------- gather
 // out[i, :] = table[idx[i], :]; F % 4 == 0, rows 16-B aligned.
 template <int LPR>
@@ -474,7 +495,7 @@ __global__ void gather_rows_drop_kernel(const float *__restrict__ table, int64_t
     const float *src = table + (int64_t)idx[r] * ld_table;
     float *dst = out + (int64_t)r * ld_out;
     for (uint32_t c = l * 4; c < Fpad; c += LPR * 4)
-      st4s(dst + c, c < F ? bd_drop4(g, ld4(src + c), r, c) : make_float4(0.f, 0.f, 0.f, 0.f));
+      SHD_ST_GATHER(dst + c, c < F ? bd_drop4(g, ld4(src + c), r, c) : make_float4(0.f, 0.f, 0.f, 0.f));
   }
 }
 
@@ -612,7 +633,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
             acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
           }
           const float rs = rsc[k];
-          if (on) st4s(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
+          if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
         }
       }
     } else if (cur.valid) {
@@ -632,7 +653,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
           }
         }
         const float rs = row_scale ? row_scale[cur.a + i] : 1.0f;
-        if (on) st4s(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
+        if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
       }
     }
     cur = nxt; nxt = nn;

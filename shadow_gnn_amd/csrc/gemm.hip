@@ -86,7 +86,7 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t s1j, int
 template <int RB, int TW, int CS, int WAVES, bool kTail>     // kTail: K % 32 != 0 (the last unit is zero-padded)
 __global__ void __launch_bounds__(WAVES * 64, 2)
 gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__restrict__ Bimg, float *__restrict__ C,
-                     int64_t ldc, uint32_t M, uint32_t N, uint32_t K, uint32_t units) {
+                     int64_t ldc, uint32_t M, uint32_t N, uint32_t K, uint32_t units, uint32_t a_wrap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   constexpr int NT = TW * CS;                            // column tiles of the B image
   constexpr int kGemmThreads = WAVES * 64;
@@ -106,7 +106,8 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
   const float *arow[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; rb++) {
-    const uint64_t row = min(m0 + 32u * rb + r, (uint64_t)M - 1);   // rows past the end repeat the last row (never stored)
+    uint64_t row = min(m0 + 32u * rb + r, (uint64_t)M - 1);   // rows past the end repeat the last row (never stored)
+    if (a_wrap) row %= a_wrap;                                // (probe only, scripts/probe_gemm_alat.py: every workgroup reads the same few rows -- A from the L2)
     arow[rb] = A + row * lda + 16 * g;
   }
 
@@ -182,21 +183,24 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
       //  waits vmcnt(0) for an ordinary load while LDS-DMA copies are in flight)
       __builtin_amdgcn_sched_barrier(0);
       GT_STAMP(1);
-      // B fragments are read one tile ahead of the MFMAs that consume them
+      // B fragments are read one tile ahead of the MFMAs that consume them (by hand, with counted waits: see gemm_common.h)
       bf16x8 fb[2][3];
-#pragma unroll
-      for (int pc = 0; pc < 3; pc++) fb[0][pc] = lb[(pc * NT + wcol * TW) * 64 + lane];
+      const uint32_t la = lds_addr(lb + wcol * TW * 64 + lane);
+      fb[0][0] = lds_read_frag<0>(la); fb[0][1] = lds_read_frag<NT * 1024>(la); fb[0][2] = lds_read_frag<2 * NT * 1024>(la);
 #pragma unroll
       for (int t = 0; t < TW; t++) {
         if (t + 1 < TW) {
-#pragma unroll
-          for (int pc = 0; pc < 3; pc++) fb[(t + 1) & 1][pc] = lb[(pc * NT + wcol * TW + t + 1) * 64 + lane];
+          const uint32_t lt = la + (t + 1) * 1024;          // (one VALU add per tile; the piece offsets are immediates)
+          fb[(t + 1) & 1][0] = lds_read_frag<0>(lt);
+          fb[(t + 1) & 1][1] = lds_read_frag<NT * 1024>(lt);
+          fb[(t + 1) & 1][2] = lds_read_frag<2 * NT * 1024>(lt);
         }
         if (st + 2 < steps) fill_b(st + 2, t);              // two steps ahead: never waited for in this step
         if (u + 1 < units) {
 #pragma unroll
           for (int p = (h * TW + t) * kPPS; p < (h * TW + t + 1) * kPPS && p < kPieces; p++) load_a_piece(u + 1, p);
         }
+        if (t + 1 < TW) lds_wait<3>(); else lds_wait<0>();   // this tile's fragments have landed; the next tile's may still fly
         const bf16x8 bh = fb[t & 1][0], bm = fb[t & 1][1], bl = fb[t & 1][2];
         // small terms first, the dominant product last; row blocks alternate
 #pragma unroll
@@ -300,6 +304,7 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
   hipStream_t st = (hipStream_t)stream;
   const bf16x8 *img = reinterpret_cast<const bf16x8 *>(d_packed_B);
   const size_t lds = (size_t)3 * 3 * tiles * 64 * 16;
+  static const uint32_t a_wrap = [] { const char *e = getenv("SHADOW_GEMM_PROBE_A_WRAP"); return e ? (uint32_t)atoi(e) : 0u; }();
 #define SHD_GEMM(RB, TW, CS, WAVES)                                                                          \
   {                                                                                                          \
     const uint32_t rows_wg = 32u * RB * (WAVES / CS);                                                        \
@@ -310,10 +315,10 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
     }                                                                                                        \
     if (K % 32 == 0)                                                                                         \
       hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,  \
-                         lda, img, d_C, ldc, M, N, K, units);                                                \
+                         lda, img, d_C, ldc, M, N, K, units, a_wrap);                                        \
     else                                                                                                     \
       hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, true>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,   \
-                         lda, img, d_C, ldc, M, N, K, units);                                                \
+                         lda, img, d_C, ldc, M, N, K, units, a_wrap);                                        \
   }
   // (a column-split variant <1, 4, 2, 6> reaches 3 wavefronts per SIMD but measured slower: 0.35 vs 0.29 ms --
   //  A is loaded by both column groups and the vector-memory path is the scarce resource)

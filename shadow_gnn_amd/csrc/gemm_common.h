@@ -36,4 +36,23 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m
   h = H.v; m = Mm.v; l = L.v;
 }
 
+// B-fragment reads of the nt kernels by hand: hipcc waits lgkmcnt(0) before every tile's MFMA group -- i.e. also for the
+// next tile's reads it has just issued (~100 exposed cycles per tile) -- instead of a counted wait.  These reads are
+// invisible to its scoreboard; the kernels wait with lds_wait<N>() (N = reads allowed to stay in flight; LDS returns in
+// order) followed by a sched_barrier so that no MFMA is hoisted above the wait (cdna_hip_programming.md rule 18).
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+template <int kOffset>
+__device__ __forceinline__ bf16x8 lds_read_frag(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(kOffset));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace shadow
