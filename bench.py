@@ -247,11 +247,13 @@ def main():
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, no instrumentation inside
     barrier()
     counts = []
+    wait0 = mb.wait_s
     t0 = time.perf_counter()
     for _ in range(K):
         c, ret = one_step()
         counts.append(c)
     t_host = time.perf_counter() - t0           # host-side enqueue time (diagnostic)
+    t_blocked = mb.wait_s - wait0               # ... of which blocked on the sampler's count read-back (the host is idle there)
     barrier()
     dt = time.perf_counter() - t0
     # ---- the same steps once more with a HIP-event pair around every hand-written kernel (on the stream it is launched
@@ -437,6 +439,7 @@ def main():
             nst, tsec, warm = run(P_run, best_th, 25.0)
             frac = P_run / B
             cb_step = dict(value=round(nst / tsec * frac, 5), unit="train-steps/s", cores=best_th, kind="port",
+                           extrapolated=bool(frac < 1.0), measured_fraction_of_batch=frac,
                            sample=f"oracle/cpu_train_step.py (CPU PyTorch fp32: torch.sparse.mm + nn.Linear + norm, Adam), "
                                   f"{nst} step(s) on the first {P_run} of the {B} subgraphs of one benchmark batch "
                                   f"({int(sizes[:P_run].sum())} nodes), scaled by {frac:g} to whole steps; model only (no sampler); "
@@ -446,6 +449,7 @@ def main():
     line = {
         "metric": "sampled-nodes/sec", "value": round(nodes / dt, 1), "unit": "sampled-nodes/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / K * 1e3, 4),
+        "host_busy_ms_per_step": round((t_host - t_blocked) / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "train_steps_per_sec": round(K / dt, 3),
         "target_only_tail": tail_info,

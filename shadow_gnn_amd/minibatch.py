@@ -229,6 +229,7 @@ class MinibatchShallowExtractor:
         self._local_sizes = {m: np.zeros(0, dtype=np.int64) for m in _MODES}
         self._global_sizes = {m: np.zeros(0, dtype=np.int64) for m in _MODES}
         self._hwm = {m: [1, 1] for m in _MODES}               # largest batch seen (nodes, edges)
+        self.wait_s = 0.0                                      # host seconds blocked on sampler read-backs (see _collect)
 
     @classmethod
     def on_device(cls, adjs, entity_set, sampler_config: Dict[str, Any], aug_feats, feat_full: torch.Tensor,
@@ -458,6 +459,8 @@ class MinibatchShallowExtractor:
                     self._recorded[mode] = np.zeros(self.raw_entity_set[mode].size, dtype=bool)
                 self._recorded[mode][self._mine_pos[mode][c0:c0 + bs]] = True
             return b
+        import time as _time
+        t_wait = _time.perf_counter()
         try:
             if self._side is not None:
                 with torch.cuda.stream(self._side):
@@ -467,6 +470,9 @@ class MinibatchShallowExtractor:
                 b = go()
         finally:
             self._inflight.pop(mode, None)
+            # host time spent here is (almost all) BLOCKED on the sampler's count read-back, not busy: bench.py subtracts
+            # it from the enqueue time of a step to report how much of the step the host is really working
+            self.wait_s += _time.perf_counter() - t_wait
         if discard:
             return None
         self._hwm[mode] = [max(self._hwm[mode][0], b.num_nodes), max(self._hwm[mode][1], b.num_edges)]

@@ -20,10 +20,14 @@ class _GatAggregate(torch.autograd.Function):
         mx = torch.empty(n, heads, device=dev); den = torch.empty(n, heads, device=dev)
         nagg = torch.empty(n, F, device=dev)
         w = adj.edge_w
-        check(_lib.load().sl_gat_fwd(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
-                                     z_self.data_ptr(), z_neigh.data_ptr(), att.data_ptr(), act_code, n, F, heads,
-                                     hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
-                                     nagg.data_ptr(), ops._stream(z_self)))
+        # algorithmic bytes (GAT row): structure + (edge mask) + read z_self, z_neigh, write the aggregate
+        # + the per-node scores / softmax statistics of every head
+        nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 3 * 4 * n * F + 4 * 4 * n * heads
+        with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
+            check(_lib.load().sl_gat_fwd(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
+                                         z_self.data_ptr(), z_neigh.data_ptr(), att.data_ptr(), act_code, n, F, heads,
+                                         hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
+                                         nagg.data_ptr(), ops._stream(z_self)))
         ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape)
         ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
@@ -43,11 +47,14 @@ class _GatAggregate(torch.autograd.Function):
         dzs = torch.empty_like(z_self); dzn = torch.empty_like(z_neigh)
         datt = torch.empty(2, F, device=dev)
         w = adj.edge_w
-        check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
-                                     w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
-                                     att.data_ptr(), act_code, n, c.e, F, heads, hn.data_ptr(), u_s.data_ptr(),
-                                     u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
-                                     work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), ops._stream(dnagg)))
+        # row pass + column pass: both CSR structures, read z_self, z_neigh and the incoming gradient, write dz_self, dz_neigh
+        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + 5 * 4 * n * F + 6 * 4 * n * heads
+        with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
+            check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
+                                         w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
+                                         att.data_ptr(), act_code, n, c.e, F, heads, hn.data_ptr(), u_s.data_ptr(),
+                                         u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
+                                         work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), ops._stream(dnagg)))
         return dzs, dzn, datt.reshape(att_shape), None, None, None
 
 

@@ -523,3 +523,36 @@ def test_fused_clip_adam_equals_the_torch_statements(n, scale, monkeypatch):
     for x, y, name in zip(a[1:], b[1:], ("clipped grad", "exp_avg", "exp_avg_sq", "param")):
         # (the clip factor differs in its last bit with the reduction order of the norm; moments cancel towards zero)
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-6, atol=5e-7 * float(x.abs().max()), err_msg=name)
+
+
+def test_bench_two_ranks_through_torch_distributed_run():
+    """ bench.py exactly as the driver launches it for N > 1 -- `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2` -- on the smallest workload, the two ranks
+    sharing this box's one GPU over gloo (SHADOW_DIST_BACKEND; RCCL refuses two ranks on one device): rank 0 prints ONE
+    JSON line that carries the contract's fields for a 2-rank weak-scaling run, and the whole-job rate is that of two
+    batches per step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SHADOW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "3", "--warmup", "1", "--workload", "arxiv-khop-gcn3", "--no-cpu-baseline", "--no-tail"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]                 # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64
+    assert d["metric"] == "sampled-nodes/sec" and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "roofline" in d and "host_busy_ms_per_step" in d
+    # two batches of 32 roots per step: about twice the nodes of one
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    ratio = d["config"]["nodes_per_step"] / d1["config"]["nodes_per_step"]
+    assert 1.6 < ratio < 2.4, ratio
