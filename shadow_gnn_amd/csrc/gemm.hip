@@ -470,6 +470,135 @@ gemm_tn_split_kernel(const float *__restrict__ A, int64_t lda, const float *__re
   }
 }
 
+// The same product with every operand element split ONCE per workgroup.  In gemm_tn_split_kernel each wavefront splits
+// the fragments it multiplies itself: 2 A tiles + TK B tiles per k-step -- 6 x ~60 VALU operations beside 48 MFMAs, and
+// every A tile is split by two wavefronts, every B tile by four (3 x the necessary work; the kernel is as busy on the
+// VALU as on the matrix cores).  Here wavefront w splits tile w of A and tile w of B of the NEXT k-step (8 LDS reads
+// down a column, split8, three 16-byte LDS writes per fragment) into a double-buffered image of ready bf16 fragments
+// [operand][piece][tile][lane], while everybody multiplies the current step out of the other image with plain
+// ds_read_b128 fragment reads.  One barrier per step as before; LDS = 64 KB fp32 row tiles (two steps) + 96 KB fragment
+// images (two steps) = all 160 KB of the CU (one 8-wave workgroup per CU, as before).  Same arithmetic in the same order:
+// bit-identical products.
+template <int TK>
+__global__ void __launch_bounds__(kTnThreads)
+gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+                    float *__restrict__ partial, uint32_t M, uint32_t N, uint32_t K, uint32_t rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  float *lbuf = reinterpret_cast<float *>(tsm);                                   // [2][kTnStepFloats]: fp32 row tiles
+  bf16x8 *fimg = reinterpret_cast<bf16x8 *>(tsm + (size_t)2 * kTnStepFloats * 4); // [2][2 operands][3 pieces][8 tiles][64 lanes]
+  constexpr int kImgVecs = 2 * 3 * 8 * 64;                                        // bf16x8 vectors of one step's image
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t r = lane & 31u, kg = lane >> 5;
+  const uint32_t wn = wv >> 1, wk = wv & 1u;                  // 4 x 2 wavefront grid
+  const uint64_t m_begin = (uint64_t)blockIdx.x * rows_per_wg;
+  const uint64_t m_end = min((uint64_t)M, m_begin + rows_per_wg);
+  const uint32_t steps = m_end > m_begin ? (uint32_t)((m_end - m_begin + 15) / 16) : 0u;   // (slices past M write zeros)
+
+  // zero both row-tile buffers once: columns >= N / K and rows >= M are never written by the copies
+  for (uint32_t i = tid; i < 2 * kTnStepFloats / 4; i += kTnThreads)
+    reinterpret_cast<float4 *>(lbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  f32x16 acc[2][TK];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int t = 0; t < TK; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[a][t][i] = 0.f;
+
+  // copy `part` (0..3) of k-step s: this wavefront moves rows {2 wv, 2 wv + 1} of the A tile and of the B tile
+  auto fill = [&](uint32_t s, int part) {
+    const uint32_t lr = 2 * wv + (part & 1);                 // row inside the 16-row tile
+    const uint64_t row = m_begin + (uint64_t)s * 16 + lr;
+    const bool isb = part >= 2;
+    float *dst = lbuf + (size_t)(s & 1) * kTnStepFloats + (isb ? 16 * kTnRowFloats : 0) + lr * kTnRowFloats;
+    const uint32_t width = isb ? K : N;
+    if (row < m_end) {
+      const float *src = (isb ? B + row * ldb : A + row * lda);
+      if (lane * 4 < width)     // (width % 4 == 0: whole 16-byte pieces)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane * 4),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    } else if (lane * 4 < width) {
+      *reinterpret_cast<float4 *>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // fragment `lane` of tile `wv` of operand op (0: A, 1: B) of k-step s: row tile -> three bf16 pieces in the image
+  auto split_job = [&](uint32_t s, int op) {
+    const float *tile = lbuf + (size_t)(s & 1) * kTnStepFloats + (op ? 16 * kTnRowFloats : 0);
+    float x[8];
+    lds_frag8(tile, 32 * wv + r, kg, x);
+    bf16x8 h, m, l;
+    split8(x, h, m, l);
+    bf16x8 *dst = fimg + (size_t)(s & 1) * kImgVecs + ((size_t)op * 3 * 8 + wv) * 64 + lane;
+    dst[0] = h; dst[8 * 64] = m; dst[2 * 8 * 64] = l;
+  };
+  if (steps > 0) {
+#pragma unroll
+    for (int part = 0; part < 4; part++) fill(0, part);
+    if (steps > 1) {
+#pragma unroll
+      for (int part = 0; part < 4; part++) fill(1, part);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (steps > 0) { split_job(0, 0); split_job(0, 1); }
+  __syncthreads();
+  for (uint32_t s = 0; s < steps; s++) {
+    const bf16x8 *img = fimg + (size_t)(s & 1) * kImgVecs;
+    // this step's A fragments (tiles 2 wn, 2 wn + 1)
+    bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const bf16x8 *pa = img + (size_t)(2 * wn + a) * 64 + lane;
+      ah[a] = pa[0]; am[a] = pa[8 * 64]; al[a] = pa[2 * 8 * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < TK; t++) {
+      const bf16x8 *pb = img + ((size_t)3 * 8 + TK * wk + t) * 64 + lane;
+      const bf16x8 bh = pb[0], bm = pb[8 * 64], bl = pb[2 * 8 * 64];
+      // the row tiles of step s + 2 trickle in (their buffer was split during the previous step), and this wavefront's two
+      // fragments of step s + 1 are split between the MFMA groups
+      if (s + 2 < steps) {
+        if (TK == 4) fill(s + 2, t);
+        else { fill(s + 2, 2 * t); fill(s + 2, 2 * t + 1); }
+      }
+      if (s + 1 < steps && t == 0) split_job(s + 1, 0);
+      if (s + 1 < steps && t == TK / 2) split_job(s + 1, 1);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // partial[g][n][k]; C/D layout: col (k) = lane & 31, row (n) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  float *out = partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+#pragma unroll
+    for (int t = 0; t < TK; t++) {
+      const uint32_t kc = 32 * (TK * wk + t) + r;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const uint32_t nr = 32 * (2 * wn + a) + (i & 3) + 8 * (i >> 2) + 4 * kg;
+        if (nr < N && kc < K) out[(size_t)nr * K + kc] = acc[a][t][i];
+      }
+    }
+  }
+}
+
 // out[i] = sum_g partial[g][i] in a fixed order: 8 independent running sums per thread (eight loads in
 // flight instead of a dependent chain), 4 row-slice groups per output combined through LDS.
 __global__ void __launch_bounds__(256)
@@ -516,6 +645,28 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
   const uint32_t G = sl_gemm_tn_slices(M);
   uint32_t rows_per_wg = (M + G - 1) / G;
   rows_per_wg = (rows_per_wg + 15u) & ~15u;
+  // (SHADOW_GEMM_TN_COOP=0: the per-wavefront-split kernel; read per call so that a test can compare the two in one process)
+  // Measured (M = 289 k, N = 256, same box, scripts/probe_gemm_tn.py): K = 256: 241 -> 233 us; K = 128: 146 -> 156 us (the
+  // fixed split work of the eight tile slots is not amortised by half the MFMAs) -- so the cooperative form runs for
+  // K > 128 only.  Also measured and dropped: the row-tile copies three steps ahead in a four-buffer ring with counted
+  // waits (235 us: HBM latency is not what holds the step either).
+  const char *coop_env = getenv("SHADOW_GEMM_TN_COOP");
+  const bool coop = coop_env ? coop_env[0] != '0' : K > 128;
+  if (coop) {
+    const size_t ldsc = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * 2 * 3 * 8 * 64 * 16;     // 64 KB row tiles + 96 KB fragment images
+    if (K <= 128) {
+      SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<2>, ldsc));
+      hipLaunchKernelGGL((gemm_tn_coop_kernel<2>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg);
+    } else {
+      SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<4>, ldsc));
+      hipLaunchKernelGGL((gemm_tn_coop_kernel<4>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg);
+    }
+    SHD_HIP(hipGetLastError());
+    const uint32_t NKc = N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NKc + 63) / 64), dim3(256), 0, st, d_partial, G, NKc, d_C);
+    SHD_HIP(hipGetLastError());
+    return SG_OK;
+  }
   const size_t lds = (size_t)2 * kTnStepFloats * 4;
   if (K <= 128) {
     SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_split_kernel<2>, lds));

@@ -442,6 +442,26 @@ def test_split_bf16_weight_gradient_gemm_matches_fp64(M, N, K):
     assert torch.equal(got, ops.weight_grad(dZ, X))
 
 
+@pytest.mark.parametrize("M,N,K,lda", [(8192, 256, 256, 256), (10007, 256, 100, 768), (300000, 256, 256, 768), (8200, 36, 132, 36), (9001, 64, 256, 64)])
+def test_weight_gradient_gemm_cooperative_split_is_bit_identical(M, N, K, lda, monkeypatch):
+    """gemm_tn_coop_kernel splits every operand element once per workgroup (fragment images in LDS) instead of once per
+    consuming wavefront: the same pieces, the same MFMA order, the same row slices -- the product equals
+    gemm_tn_split_kernel's bit for bit (also with a strided dZ operand, the [n, 3F] buffer of the GraphSAGE backward)."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dZ = torch.randn(M, lda, device=DEV, generator=g)[:, :N]
+    pitch = (K + 31) // 32 * 32
+    X = torch.randn(M, pitch, device=DEV, generator=g)[:, :K]
+    monkeypatch.setenv("SHADOW_GEMM_TN_COOP", "0")
+    ref = ops.weight_grad(dZ, X)
+    monkeypatch.setenv("SHADOW_GEMM_TN_COOP", "1")
+    got = ops.weight_grad(dZ, X)
+    assert torch.equal(ref, got)
+    want = (dZ.double().t() @ X.double())
+    bound = (dZ.double().abs().t() @ X.double().abs())
+    assert float(((got.double() - want).abs() / bound.clamp_min(1e-30)).max()) < 2e-6
+
+
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
 def test_act_norm_fused_output_dropout(nb, F, seg):
     """The next layer's input dropout folded into act_norm's output: the kernel's mask equals the documented
