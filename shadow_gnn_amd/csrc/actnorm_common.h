@@ -56,6 +56,28 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
 }
 
 
+// All-reduce sums over aligned groups of LS = 2^k lanes on the DPP network: quad xor 1, quad xor 2, half-row mirror, row
+// mirror (16 lanes), then one v_permlane16_swap (32) and one v_permlane32_swap (64) -- a handful of dependent VALU adds
+// instead of k ds_bpermute round trips through the LDS crossbar (which made every row normalisation a latency chain).
+#define SHD_DPP_ADD(v, CTRL) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false))
+template <int LS>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(LS == 1 || LS == 2 || LS == 4 || LS == 8 || LS == 16 || LS == 32 || LS == 64, "power of two");
+  if (LS >= 2) SHD_DPP_ADD(v, 0xB1);        // quad_perm [1, 0, 3, 2]
+  if (LS >= 4) SHD_DPP_ADD(v, 0x4E);        // quad_perm [2, 3, 0, 1]
+  if (LS >= 8) SHD_DPP_ADD(v, 0x141);       // row_half_mirror
+  if (LS >= 16) SHD_DPP_ADD(v, 0x140);      // row_mirror
+  if (LS >= 32) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  if (LS >= 64) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  return v;
+}
+
 // keep-mask (bit k: component k of the float4 at column f of row r) of the fused dropout: element (r, c) is kept iff
 //   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= thr
 __device__ __forceinline__ uint32_t drop_keep4_raw(uint32_t seed_lo, uint32_t seed_hi, uint32_t thr, uint64_t r, uint32_t f) {

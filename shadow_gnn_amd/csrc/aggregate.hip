@@ -723,9 +723,13 @@ __device__ __forceinline__ uint32_t drop_keep4(const ActNormParams &p, uint64_t 
 // sum over the lanes of one segment group (LS lanes, power of two)
 template <int LS>
 __device__ __forceinline__ float seg_sum(float v) {
+#ifdef SHADOW_SEG_SUM_SHFL
 #pragma unroll
   for (int off = LS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+#else
+  return group_sum<LS>(v);            // DPP butterflies (actnorm_common.h)
+#endif
 }
 
 // One row per LPR lanes, one float4 per lane; LS = lanes per normalisation segment.

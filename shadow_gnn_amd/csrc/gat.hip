@@ -15,6 +15,7 @@
 
 #include <algorithm>
 
+#include "actnorm_common.h"
 #include "common.h"
 
 namespace shadow {
@@ -49,10 +50,17 @@ __device__ __forceinline__ float4 act4(int act, float4 z) {
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// sum over the ls lanes of a head slice (ls power of two, runtime)
+// sum over the ls lanes of a head slice (ls power of two, wave-uniform): DPP butterflies (actnorm_common.h)
 __device__ __forceinline__ float slice_sum(float v, uint32_t ls) {
-  for (uint32_t off = ls >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  switch (ls) {
+    case 1: return v;
+    case 2: return group_sum<2>(v);
+    case 4: return group_sum<4>(v);
+    case 8: return group_sum<8>(v);
+    case 16: return group_sum<16>(v);
+    case 32: return group_sum<32>(v);
+    default: return group_sum<64>(v);
+  }
 }
 
 struct GatParams {

@@ -61,33 +61,11 @@ struct FusedDesc {
   uint32_t stagger_cycles, first_round, stagger_mode;
 };
 
-// All-reduce over the 16 lanes of a DPP row (quad xor 1, quad xor 2, half-row mirror, row mirror): four dependent VALU
-// adds, no LDS crossbar.  The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass): the row statistics
-// are five VALU operations deep, every lane carries Q independent float4s, and the column accumulators of the backward
-// form (5 Q float4s per lane) stay inside the register budget of two wavefronts per SIMD.
-#define SHD_DPP_F(v, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false))
-__device__ __forceinline__ float sum16(float v) {
-  v += SHD_DPP_F(v, 0xB1);       // quad_perm [1, 0, 3, 2]
-  v += SHD_DPP_F(v, 0x4E);       // quad_perm [2, 3, 0, 1]
-  v += SHD_DPP_F(v, 0x141);      // row_half_mirror
-  v += SHD_DPP_F(v, 0x140);      // row_mirror
-  return v;
-}
-
-// ... and over the 32 lanes of a row pair: one v_permlane16_swap (odd rows of one copy <-> even rows of the other) + add
-__device__ __forceinline__ float sum32(float v) {
-  v = sum16(v);
-  const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-}
-
-// ... and over the whole wavefront: one v_permlane32_swap more
-__device__ __forceinline__ float sum64(float v) {
-  v = sum32(v);
-  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-}
-template <int LPR> __device__ __forceinline__ float row_sum(float v) { return LPR == 64 ? sum64(v) : sum32(v); }
+// The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass; 64 lanes in the backward form): the row
+// statistics are group_sum<LPR> (actnorm_common.h: DPP butterflies + permlane swaps, five or six VALU operations deep),
+// every lane carries Q independent float4s, and the column accumulators of the backward form (5 Q float4s per lane) stay
+// inside the register budget of two wavefronts per SIMD.
+template <int LPR> __device__ __forceinline__ float row_sum(float v) { return group_sum<LPR>(v); }
 
 __device__ __forceinline__ float hsum4(const float4 &v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
