@@ -244,8 +244,11 @@ int sg_cache_create(uint32_t num_nodes, int device_id, sg_cache **out);
 void sg_cache_destroy(sg_cache *c);
 int sg_cache_clear(sg_cache *c);
 int sg_cache_stats(const sg_cache *c, uint64_t *num_recorded, uint64_t *nodes, uint64_t *edges);
-/* Append a finished sg_sample batch (num_roots = 1) to the arena; n_tot / e_tot from sg_batch_counts.
- * Asynchronous on `stream` (the batch buffers must stay alive until the stream passes this point). */
+/* Append the subgraphs of a finished sg_sample batch (num_roots = 1) whose root is NOT on file yet to the arena (a root
+ * recorded before keeps its first copy: nothing is appended for it, so recording the same roots again -- the
+ * reference's 'record' mode with percent_per_epoch < 1 revisits most of them epoch after epoch -- does not grow the
+ * arena); n_tot / e_tot from sg_batch_counts size the capacity.  Runs on `stream` and waits for it (the counts of what
+ * was new come back to the host: sg_cache_stats is exact).                                                        */
 int sg_cache_record(sg_cache *c, const sg_batch_out *batch, uint32_t num_subg, uint64_t n_tot, uint64_t e_tot,
                     void *stream);
 /* Rebuild the batch of `d_roots[num_subg]` (device array of root ids) into `out` (same layout and

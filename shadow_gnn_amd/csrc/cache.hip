@@ -2,8 +2,8 @@
 // for deterministic samplers (CachedSubgraph / PoolSubgraph, shaDow/minibatch.py:21-91,
 // par_graph_sample :403-426, collate :42-66 + frontend/graph.py:280-330) kept entirely in HBM.
 //
-//   epoch 1 ("record")  sg_cache_record appends a finished block-diagonal batch to the arena and
-//                       files every subgraph under its root id (id_root = node[target], :411)
+//   epoch 1 ("record")  sg_cache_record appends the subgraphs of a finished block-diagonal batch whose root is not on
+//                       file yet to the arena and files them under their root id (id_root = node[target], :411)
 //   epoch >= 2 ("reuse") sg_cache_collate rebuilds the block-diagonal batch of any list of roots
 //                       from the arena -- no sampling, no full graph needed
 //
@@ -36,6 +36,9 @@ struct sg_cache {
   hipEvent_t ev = nullptr;
   bool pending = false;
   uint32_t pending_P = 0;
+  // record plan: arena offsets of the batch's NEW subgraphs (roots already in the table are skipped)
+  uint64_t *d_plan = nullptr;       // [2 * cap_plan]: node / edge destination per subgraph, ~0 = skip
+  uint32_t cap_plan = 0;
 };
 
 namespace {
@@ -50,32 +53,71 @@ __global__ void cache_init_table_kernel(uint32_t *t_n, uint32_t N) {
 
 // one workgroup per subgraph of the batch being recorded
 __global__ void __launch_bounds__(kCB)
-cache_record_kernel(sg_batch_out b, uint32_t P, uint64_t fill_n, uint64_t fill_e, uint32_t *a_node, uint32_t *a_ptr,
+cache_record_kernel(sg_batch_out b, uint32_t P, const uint64_t *__restrict__ plan, uint32_t *a_node, uint32_t *a_ptr,
                     uint32_t *a_hop, float *a_ppr, uint32_t *a_col, uint32_t *a_eid, uint64_t *t_nstart,
                     uint64_t *t_estart, uint32_t *t_n, uint32_t *t_e, uint32_t *t_tgt, uint32_t N) {
   const uint32_t s = blockIdx.x;
   if (s >= P) return;
+  const uint64_t dn = plan[2 * s], de = plan[2 * s + 1];
+  if (dn == ~0ull) return;                                   // this root is already on file
   const uint32_t a = b.d_subg_nodes[s], ns = b.d_subg_nodes[s + 1] - a;
   const uint32_t e0 = b.d_subg_edges[s], es = b.d_subg_edges[s + 1] - e0;
   for (uint32_t i = threadIdx.x; i < ns; i += kCB) {
-    a_node[fill_n + a + i] = b.d_node[a + i];
-    a_ptr[fill_n + a + i] = b.d_indptr[a + i] - e0;
-    a_hop[fill_n + a + i] = b.d_hop ? b.d_hop[a + i] : 0xFFFFFFFFu;
-    a_ppr[fill_n + a + i] = b.d_ppr ? b.d_ppr[a + i] : -1.0f;
+    a_node[dn + i] = b.d_node[a + i];
+    a_ptr[dn + i] = b.d_indptr[a + i] - e0;
+    a_hop[dn + i] = b.d_hop ? b.d_hop[a + i] : 0xFFFFFFFFu;
+    a_ppr[dn + i] = b.d_ppr ? b.d_ppr[a + i] : -1.0f;
   }
   for (uint32_t p = threadIdx.x; p < es; p += kCB) {
-    a_col[fill_e + e0 + p] = b.d_indices[e0 + p] - a;
-    a_eid[fill_e + e0 + p] = b.d_edge_id[e0 + p];
+    a_col[de + p] = b.d_indices[e0 + p] - a;
+    a_eid[de + p] = b.d_edge_id[e0 + p];
   }
   if (threadIdx.x == 0) {
     const uint32_t tg = b.d_target[s];                       // single-root subgraphs (minibatch.py:410)
     const uint32_t root = b.d_node[tg];
-    if (root < N) {
-      t_nstart[root] = fill_n + a; t_estart[root] = fill_e + e0;
-      t_e[root] = es; t_tgt[root] = tg - a;
-      t_n[root] = ns;
-    }
+    t_nstart[root] = dn; t_estart[root] = de;
+    t_e[root] = es; t_tgt[root] = tg - a;
+    t_n[root] = ns;
   }
+}
+
+// Which subgraphs of the batch are new (their root is not in the table yet -- with percent_per_epoch < 1 most roots of a
+// later "record" epoch already are, and appending them again only grew the arena: ADVICE r2) and where they go: exclusive
+// prefix of the NEW subgraphs' sizes behind the arena's fill marks.  One workgroup; counts[0..2] = new nodes / edges /
+// subgraphs.  (Two subgraphs of one batch with the same new root are both stored; the table keeps the later one.)
+__global__ void __launch_bounds__(1024)
+cache_record_plan_kernel(sg_batch_out b, uint32_t P, const uint32_t *__restrict__ t_n, uint32_t N, uint64_t fill_n, uint64_t fill_e,
+                         uint64_t *__restrict__ plan, uint64_t *__restrict__ counts) {
+  __shared__ uint32_t wsum_n[16], wsum_e[16], wsum_c[16];
+  __shared__ uint64_t carry_n, carry_e;
+  __shared__ uint32_t carry_c;
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  if (tid == 0) { carry_n = 0; carry_e = 0; carry_c = 0; }
+  __syncthreads();
+  for (uint32_t base = 0; base < P; base += 1024) {
+    const uint32_t s = base + tid;
+    uint32_t n = 0, e = 0, isnew = 0;
+    if (s < P) {
+      const uint32_t root = b.d_node[b.d_target[s]];
+      if (root < N && t_n[root] == kAbsent) {
+        isnew = 1; n = b.d_subg_nodes[s + 1] - b.d_subg_nodes[s]; e = b.d_subg_edges[s + 1] - b.d_subg_edges[s];
+      }
+    }
+    const uint32_t in = wave_incl_scan(n), ie = wave_incl_scan(e), ic = wave_incl_scan(isnew);
+    if (lane == 63) { wsum_n[wv] = in; wsum_e[wv] = ie; wsum_c[wv] = ic; }
+    __syncthreads();
+    uint64_t pn = carry_n, pe = carry_e;
+    uint32_t pc = carry_c;
+    for (uint32_t w = 0; w < wv; w++) { pn += wsum_n[w]; pe += wsum_e[w]; pc += wsum_c[w]; }
+    if (s < P) {
+      plan[2 * s] = isnew ? fill_n + pn + in - n : ~0ull;
+      plan[2 * s + 1] = isnew ? fill_e + pe + ie - e : ~0ull;
+    }
+    __syncthreads();
+    if (tid == 1023) { carry_n = pn + in; carry_e = pe + ie; carry_c = pc + ic; }
+    __syncthreads();
+  }
+  if (tid == 0) { counts[0] = carry_n; counts[1] = carry_e; counts[2] = carry_c; }
 }
 
 // sizes of the requested subgraphs + offsets (single workgroup scan) + batch totals
@@ -190,7 +232,7 @@ extern "C" void sg_cache_destroy(sg_cache *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void *ptrs[] = {c->a_node, c->a_ptr, c->a_hop, c->a_col, c->a_eid, c->a_ppr, c->t_nstart, c->t_estart,
-                  c->t_n, c->t_e, c->t_tgt, c->d_counts};
+                  c->t_n, c->t_e, c->t_tgt, c->d_counts, c->d_plan};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev) (void)hipEventDestroy(c->ev);
@@ -242,11 +284,23 @@ extern "C" int sg_cache_record(sg_cache *c, const sg_batch_out *batch, uint32_t 
     if ((rc = grow(&c->a_eid, c->fill_e, want, st)) != SG_OK) return rc;
     c->cap_e = want;
   }
-  hipLaunchKernelGGL(cache_record_kernel, dim3(num_subg), dim3(kCB), 0, st, *batch, num_subg, c->fill_n, c->fill_e,
-                     c->a_node, c->a_ptr, c->a_hop, c->a_ppr, c->a_col, c->a_eid, c->t_nstart, c->t_estart, c->t_n,
-                     c->t_e, c->t_tgt, c->N);
+  if (num_subg > c->cap_plan) {
+    if (c->d_plan) (void)hipFree(c->d_plan);
+    c->d_plan = nullptr; c->cap_plan = 0;
+    const uint32_t want = std::max<uint32_t>(num_subg * 2, 1024);
+    SHD_HIP(hipMalloc((void **)&c->d_plan, (size_t)want * 2 * 8));
+    c->cap_plan = want;
+  }
+  if (c->pending) return set_error(SG_ERR_STATE, "sg_cache_record: a collate is in flight (its counters are in use)");
+  // only the subgraphs whose root is not on file yet are appended (the capacity above covers the whole batch)
+  hipLaunchKernelGGL(cache_record_plan_kernel, dim3(1), dim3(1024), 0, st, *batch, num_subg, c->t_n, c->N, c->fill_n, c->fill_e,
+                     c->d_plan, c->d_counts);
+  hipLaunchKernelGGL(cache_record_kernel, dim3(num_subg), dim3(kCB), 0, st, *batch, num_subg, c->d_plan, c->a_node, c->a_ptr,
+                     c->a_hop, c->a_ppr, c->a_col, c->a_eid, c->t_nstart, c->t_estart, c->t_n, c->t_e, c->t_tgt, c->N);
   SHD_HIP(hipGetLastError());
-  c->fill_n += n_tot; c->fill_e += e_tot; c->num_recorded += num_subg;
+  SHD_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 3 * 8, hipMemcpyDeviceToHost, st));
+  SHD_HIP(hipStreamSynchronize(st));               // (record epochs only; the sampler call before it has synchronised anyway)
+  c->fill_n += c->h_counts[0]; c->fill_e += c->h_counts[1]; c->num_recorded += c->h_counts[2];
   return SG_OK;
 }
 

@@ -284,6 +284,7 @@ struct sg_sampler {
   void *d_big = nullptr;
   size_t big_bytes = 0;
   uint32_t user_cap_nodes = 0, user_cap_edges = 0;
+  uint32_t rec_scale = 1;            // round-record pool multiplier: doubled by sg_sample_finish on overflow flag 16
   uint64_t *d_counts = nullptr;   // [8] + ticket
   uint64_t *h_counts = nullptr;   // pinned
   hipEvent_t ev = nullptr;
@@ -774,7 +775,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
   const size_t o_info = carve(Pz * capn * sizeof(RowInfo)), o_rowq = carve(Pz * ((size_t)capn + 1) * 4);
   const size_t o_lcol = carve((cfg->aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) ? Pz * (size_t)cape * 4 : 16);
   const uint32_t kScanGridMax = 8u * 256u;
-  const uint32_t rec_blocks = 2u * kScanGridMax + (uint32_t)Pz / 4u;
+  const uint32_t rec_blocks = (2u * kScanGridMax + (uint32_t)Pz / 4u) * s->rec_scale;
   const size_t o_cstart = carve((Pz + 1) * 4), o_plan = carve(PL_WORDS * 4);
   const size_t o_recs = carve((size_t)rec_blocks * kRecPerBlock * sizeof(RoundRec)), o_blkinfo = carve((size_t)rec_blocks * sizeof(uint2));
   int rc;
@@ -939,9 +940,13 @@ extern "C" int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts) {
     (void)hipEventElapsedTime(&counts->sample_kernel_ms, s->ev_t[0], s->ev_t[1]);
     (void)hipEventElapsedTime(&counts->relocate_kernel_ms, s->ev_t[1], s->ev_t[2]);
   }
+  // flag 16 (the scan's pool of round records ran out: subgraphs cut into unusually many rounds) is repaired here -- the
+  // next call of this sampler carves a pool twice as large -- so that re-issuing the same call converges
+  if ((counts->overflow & 16u) && s->rec_scale < 64u) s->rec_scale *= 2u;
   if (counts->overflow)
     return set_error(SG_ERR_CAPACITY,
-                     "sg_sample: capacity exceeded (flags=0x%x: 1=subgraph nodes 2=subgraph edges 4=out nodes 8=out edges); "
+                     "sg_sample: capacity exceeded (flags=0x%x: 1=subgraph nodes 2=subgraph edges 4=out nodes 8=out edges "
+                     "16=round records [pool doubled for the next call]); "
                      "largest subgraph %u nodes / %u edges, batch %llu nodes / %llu edges",
                      counts->overflow, counts->max_subg_nodes, counts->max_subg_edges,
                      (unsigned long long)counts->n_tot, (unsigned long long)counts->e_tot);

@@ -349,6 +349,7 @@ class HipSampler:
                 self._pending = None
                 check(rc)
             ov = cnt.overflow
+            # (ov & 16 -- the scan's round-record pool -- is repaired inside the library: the re-run below finds it doubled)
             if ov & 1:
                 self.set_caps(cap_subg_nodes=min(self.num_nodes(), max(2 * cnt.max_subg_nodes, 1024)))
             if ov & 2:

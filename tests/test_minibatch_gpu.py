@@ -216,6 +216,23 @@ def test_subgraph_cache_api_errors_and_growth():
         assert np.array_equal(got[f], ref[f]), f
     with pytest.raises(ShadowHipError):
         cache.collate(np.array([4999], dtype=np.uint32), 64, 64)          # never recorded
+    #  recording roots that are already on file must not grow the arena: a later 'record' epoch of a
+    # percent_per_epoch < 1 run revisits mostly known roots.  A batch of 150 known + 50 new roots appends the 50 only.
+    before = cache.stats()
+    for b in batches:
+        cache.record(b)
+    assert cache.stats() == before
+    mixed_roots = np.concatenate([np.arange(100, 250), np.arange(600, 650)]).astype(np.uint32)
+    mixed = hs.sample(cfg, roots=mixed_roots)
+    new_nodes = int(np.diff(mixed.to_host()["subg_node_off"].astype(np.int64))[150:].sum())
+    cache.record(mixed)
+    st2 = cache.stats()
+    assert st2["num_recorded"] == 650 and st2["nodes"] == before["nodes"] + new_nodes
+    pick2 = np.array([649, 120, 600, 0], dtype=np.uint32)
+    got2 = cache.collate(pick2, 1, 1, want_hop=True).to_host()
+    ref2 = hs.sample(cfg, roots=pick2).to_host()
+    for f in ("node", "indptr", "indices", "edge_id", "target", "hop", "subg_node_off", "subg_edge_off"):
+        assert np.array_equal(got2[f], ref2[f]), f
     cache.clear()
     assert cache.is_empty()
 
