@@ -78,6 +78,17 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// the same butterflies for a maximum over the whole wavefront
+#define SHD_DPP_MAX(v, CTRL) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)))
+__device__ __forceinline__ float wave_max_f(float v) {
+  SHD_DPP_MAX(v, 0xB1); SHD_DPP_MAX(v, 0x4E); SHD_DPP_MAX(v, 0x141); SHD_DPP_MAX(v, 0x140);
+  { const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])); }
+  { const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])); }
+  return v;
+}
+
 // keep-mask (bit k: component k of the float4 at column f of row r) of the fused dropout: element (r, c) is kept iff
 //   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= thr
 __device__ __forceinline__ uint32_t drop_keep4_raw(uint32_t seed_lo, uint32_t seed_hi, uint32_t thr, uint64_t r, uint32_t f) {

@@ -63,6 +63,24 @@ __device__ __forceinline__ float slice_sum(float v, uint32_t ls) {
   }
 }
 
+// Row ranges per XCD: workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; a wrong guess costs
+// speed only).  The eight XCDs get contiguous eighths of the batch's rows and the workgroups of an XCD walk their eighth
+// together, so that the feature rows a row's edges gather (same subgraph = neighbouring row ids, a few MB) are re-read
+// out of that XCD's own 4 MB L2 instead of being spread over all eight.  (Grid-stride over the whole batch before: every
+// XCD touched every subgraph.)  first / last / step for a block that handles `rpb` rows per iteration at offset `sub`.
+struct RowWalk { uint64_t r, end, step; };
+__device__ __forceinline__ RowWalk xcd_row_walk(uint32_t n, uint32_t rpb, uint32_t sub) {
+  RowWalk w;
+  if (gridDim.x % 8u != 0u) { w.r = (uint64_t)blockIdx.x * rpb + sub; w.end = n; w.step = (uint64_t)gridDim.x * rpb; return w; }
+  const uint32_t xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const uint64_t per = (((uint64_t)n + 7) / 8 + rpb - 1) / rpb * rpb;       // rows per XCD, a multiple of rpb
+  const uint64_t lo = (uint64_t)xcd * per;
+  w.end = lo + per < n ? lo + per : n;
+  w.r = lo + (uint64_t)bi * rpb + sub;
+  w.step = (uint64_t)nbx * rpb;
+  return w;
+}
+
 struct GatParams {
   const uint32_t *indptr, *indices;       // CSR of the batch
   const uint32_t *t_indptr, *t_indices, *t_perm;
@@ -92,7 +110,8 @@ __global__ void gat_node_fwd_kernel(GatParams p) {
   const uint32_t h = on ? f / p.D : 0;
   float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
   if (on) { a0 = gld4(p.att + f); a1 = gld4(p.att + p.F + f); }
-  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     float4 hs = make_float4(0, 0, 0, 0), hn = hs;
     if (on) {
       hs = act4(p.act, gld4(p.z_self + r * p.F + f));
@@ -110,7 +129,8 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
   const uint32_t f = l * 4, ls = p.D / 4;
   const bool on = f < p.F;
   const uint32_t h = on ? f / p.D : 0;
-  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
     const float as = lrelu02(p.u_s[r * p.H + h]);
     float mx = -INFINITY;
@@ -146,7 +166,8 @@ __global__ void gat_row_bwd_kernel(GatParams p) {
   const uint32_t h = on ? f / p.D : 0;
   float4 a0 = make_float4(0, 0, 0, 0), g0 = a0;
   if (on) a0 = gld4(p.att + f);
-  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
     float4 dn = make_float4(0, 0, 0, 0), ng = dn;
     if (on) { dn = gld4(p.dnagg + r * p.F + f); ng = gld4(p.nagg + r * p.F + f); }
@@ -199,7 +220,8 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
   const uint32_t h = on ? f / p.D : 0;
   float4 a1 = make_float4(0, 0, 0, 0), g1 = a1;
   if (on) a1 = gld4(p.att + p.F + f);
-  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     const uint32_t a = p.t_indptr[r], b = p.t_indptr[r + 1];
     float4 acc = make_float4(0, 0, 0, 0);
     float dan = 0.f;
@@ -234,6 +256,11 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
   }
 }
 
+// (Round 3, measured and dropped: edge-parallel forms of the three edge kernels -- lane q owns edge q of a 64-edge chunk for
+//  the scores / softmax, the numerators parked in LDS, the feature-row gathers of a chunk issued four at a time.  Slower
+//  than the row-serial kernels above on the depth-3 products batches (forward 0.69 -> 0.72 ms, backward 1.06 -> 1.32 ms):
+//  with e / n = 3.9 these kernels move 2.4 / 4.5 GB per launch counting the gathered rows, i.e. they already run at
+//  3.5 - 4 TB/s of L2 / HBM traffic -- gather-volume-bound, not latency-bound.  What did help: the XCD-contiguous row walk.)
 // datt[j] = sum over blocks of datt_part[block][j] in a fixed order (bit-reproducible; no float atomics).  A workgroup owns
 // 32 outputs; its 32 x 32 threads cut the block range into 32 slices, eight independent running sums per thread (one thread
 // per output walking all ~2 000 partial rows was a 240 us latency chain), the slices are added in slice order through LDS.
@@ -266,7 +293,9 @@ gat_datt_finish_kernel(const float *__restrict__ part, uint32_t nblocks, uint32_
 static uint32_t gat_grid(uint32_t n, uint32_t lpr) {
   const uint32_t rpb = kGatBlock / lpr;
   uint64_t g = ((uint64_t)n + rpb - 1) / rpb;
-  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, 256 * 8));
+  g = std::max<uint64_t>(1, std::min<uint64_t>(g, 256 * 8));
+  if (g >= 8) g = (g + 7) & ~(uint64_t)7;                  // whole workgroups per XCD (xcd_row_walk)
+  return (uint32_t)g;
 }
 
 static int gat_check(uint32_t F, uint32_t H, uint32_t *lpr_out) {
