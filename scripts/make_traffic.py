@@ -73,19 +73,35 @@ def rw(sub, which=None, of=None):
 
 t = {}
 notes = {}
+
+
+def put(label, sub, which=None, of=None):
+    """t[label] = read + write bytes per launch of the kernel whose name contains `sub` (skipped when the run has none)."""
+    if not [k for k in fetch if sub in k]:
+        return
+    t[label] = sum(rw(sub, which, of))
+
+
 sel, plan, scan = rw("sg_select_lds_kernel"), rw("sg_plan_kernel"), rw("sg_scan_plain_kernel")
 t["sg_sample_pipeline"] = sum(sel) + sum(plan) + sum(scan)
 notes["sg_sample_pipeline"] = dict(select=sel, plan=plan, scan=scan)
-t["sg_relocate_kernel"] = sum(rw("sg_relocate_kernel"))
-t["gather_F100"] = sum(rw("gather_rows_drop_kernel"))
-t["spmm_F100"] = sum(rw("spmm_blockdiag_kernel<false>", 0, 2))
-t["spmm_F256"] = sum(rw("spmm_blockdiag_kernel<false>", 1, 2))
-t["act_norm_fwd_nb2_F256"] = sum(rw("act_norm_kernel<64, 64, false, 2>"))
-t["act_norm_bwd_nb2_F256"] = sum(rw("act_norm_kernel<64, 64, true, 2>"))
-t["gemm_nt_split_N256"] = sum(rw("gemm_nt_split_kernel<1, 8, 1, 4, false>"))
-t["gemm_nt_split_N256_Ktail"] = sum(rw("gemm_nt_split_kernel<1, 8, 1, 4, true>"))
-t["gemm_tn_split_N256"] = sum(rw("gemm_tn_split_kernel<4>"))
-t["gemm_tn_split_N256_K128"] = sum(rw("gemm_tn_split_kernel<2>"))
+put("sg_relocate_kernel", "sg_relocate_kernel")
+put("gather_F100", "gather_rows_drop_kernel")
+put("spmm_F100", "spmm_blockdiag_kernel<false>", 0, 2)
+put("spmm_F256", "spmm_blockdiag_kernel<false>", 1, 2)
+put("act_norm_fwd_nb2_F256", "act_norm_kernel<64, 64, false, 2>")
+put("act_norm_bwd_nb2_F256", "act_norm_kernel<64, 64, true, 2>")
+put("gemm_nt_split_N256", "gemm_nt_split_kernel<1, 8, 1, 4, false>")
+put("gemm_nt_split_N256_Ktail", "gemm_nt_split_kernel<1, 8, 1, 4, true>")
+# round 3: the GEMM-epilogue kernels (csrc/gemm_fused.hip) and the cooperative-split weight gradient
+put("gemm_act_norm_fwd_nb2_N256", "gemm_nt_fused_kernel<8, 0, 2, 2, false>")
+put("gemm_act_norm_fwd_nb2_N256_Ktail", "gemm_nt_fused_kernel<8, 0, 2, 2, true>")
+put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>")
+if [k for k in fetch if "gemm_tn_coop_kernel<4>" in k]:
+    put("gemm_tn_split_N256", "gemm_tn_coop_kernel<4>")
+else:
+    put("gemm_tn_split_N256", "gemm_tn_split_kernel<4>")
+put("gemm_tn_split_N256_K128", "gemm_tn_split_kernel<2>")
 t = {k: int(v) for k, v in t.items()}
 
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
@@ -99,7 +115,7 @@ cur[workload] = t
 cur["_source"] = (f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv (separate rocprofv3 --pmc passes of bench.py --steps 10 "
                   "--warmup 3, scripts/collect_profiles.sh); read bytes = 2*FETCH_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md), "
                   "write bytes = WRITE_SIZE*1024; per-launch means by kernel; launches of one kernel that differ in shape (SpMM F = 100 / 256) "
-                  "are separated by counter value (scripts/make_traffic.py); the nt GEMM figure averages its K = 256 and K = 512 launches; "
+                  "are separated by counter value (scripts/make_traffic.py); "
                   "sg_sample_pipeline = select + plan + scan kernels of one call")
 json.dump(cur, open(path, "w"), indent=1)
 print(json.dumps(t, indent=1))

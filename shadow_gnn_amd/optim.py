@@ -37,7 +37,9 @@ class FlatAdam:
         the buffer is filled inside GradSync.all_reduce).  DeepGNN._finish_update has normally done that already; a caller
         that runs backward and then steps this optimiser directly would otherwise update from an all-zero buffer.
         (Idempotent: a second call finds nothing left to pack or to reduce.)"""
-        self.sync.all_reduce()
+        gather = getattr(self.sync, "all_reduce", None)      # (a plain holder of a flat buffer has nothing to gather)
+        if gather is not None:
+            gather()
 
     # torch.nn.utils.clip_grad_norm_(params, max_norm): no host synchronisation
     def clip_(self, max_norm: float) -> torch.Tensor:
