@@ -1,6 +1,8 @@
 """GPU parity tests of the HIP sampler (through the C ABI) against
 (a) the reference's golden vectors and (b) the CPU oracle on seeded inputs.
 Bit-exact on every integer field and on the fp32 ppr scores."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -680,3 +682,29 @@ def test_papers100m_shape_matches_oracle(method):
         assert np.array_equal(got[f], getattr(ref, f)), (method, f)
     eid = got["edge_id"][got["edge_id"] != 0xFFFFFFFF]
     assert eid.size and int(eid.max()) > 2 ** 31                     # ids the int32 view would call negative
+
+
+def test_ppr_push_tables_on_the_products_shape_graph_match_the_oracle():
+    """(the products-shape table check lived in scripts/check_ppr_vs_oracle.py only.)  sg_ppr_push, ordered
+    mode, on the FULL products-shape graph (2.45 M nodes, 123.7 M edges, maximum degree 17 k) for 64 targets, k = 200,
+    alpha = 0.85, eps = 1e-5 -- the table BASELINE.json's configs[2] samples from: lengths, neighbour ids and the fp32
+    score bit patterns are identical to the oracle's (oracle/sampler_oracle.c restates ParallelSampler.cpp:237-344)."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.ppr import ppr_approximate_device
+    from shadow_gnn_amd.sampler import HipSampler
+    from shadow_gnn_amd.synthetic import MAX_DEGREE, SHAPES, make_graph_torch
+    dev = torch.device("cuda:0")
+    N, nnz, _F, _C = SHAPES["products"]
+    indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE["products"])
+    ip, ix = indptr.cpu().numpy().view(np.uint32), indices.cpu().numpy().view(np.uint32)
+    T = 64
+    targets = np.random.default_rng(0).permutation(N)[:T].astype(np.uint32)
+    hs = HipSampler(indptr, indices, device=dev, seed=3)
+    gl, gn, gs = ppr_approximate_device(hs, targets, 200, 0.85, 1e-5)
+    ref = so.ppr_approximate(ip, ix, targets, k=200, alpha=0.85, epsilon=1e-5, num_threads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(gl, ref.len)
+    for i in range(T):
+        L = int(gl[i])
+        assert L > 1
+        assert np.array_equal(gn[i, :L], ref.neigh[i, :L]), i
+        assert np.array_equal(gs[i, :L].view(np.uint32), ref.score[i, :L].view(np.uint32)), i
