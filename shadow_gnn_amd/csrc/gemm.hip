@@ -232,16 +232,48 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
       GT_STAMP(4);
     }
   }
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
+  // Stored straight from that layout the tile leaves as 16 TW dword stores per lane, each covering two 128-byte row
+  // pieces -- measured 17 % of a K = 256 workgroup's lifetime (scripts/probe_gemm_phases.sh), all workgroups at once.
+  // The B ring is dead here: 16 rows of the tile at a time go through it (conflict-free ds_write_b32 in the C/D layout,
+  // ds_read_b128 row-major) and leave as float4s, whole rows per instruction.
+  const bool vec_ok = CS == 1 && (N & 3u) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  if (vec_ok) {
+    constexpr int SP = 32 * TW;                             // stash row pitch (floats)
+    constexpr int F4 = 8 * TW;                              // float4s per row
+    float *stash = reinterpret_cast<float *>(gsm) + (size_t)wv * (16 * SP);
 #pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
+    for (int rb = 0; rb < RB; rb++) {
 #pragma unroll
-    for (int t = 0; t < TW; t++) {
-      const uint32_t col = 32 * (wcol * TW + t) + r;
+      for (int hf = 0; hf < 2; hf++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const uint64_t rr = m0 + 32u * rb + (i & 3) + 8 * (i >> 2) + 4 * g;
-        if (rr < M && col < N) C[rr * ldc + col] = acc[rb][t][i];
+        for (int t = 0; t < TW; t++)
+#pragma unroll
+          for (int ii = 0; ii < 8; ii++) stash[((ii & 3) + 8 * (ii >> 2) + 4 * g) * SP + 32 * t + r] = acc[rb][t][8 * hf + ii];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t rbase = m0 + 32u * rb + 16u * hf;
+#pragma unroll
+        for (int it = 0; it < (16 * F4 + 63) / 64; it++) {
+          const uint32_t idx = it * 64 + lane, lr = idx / F4, c4 = idx % F4;
+          if (idx < 16 * F4 && rbase + lr < M && 4 * c4 < N)
+            *reinterpret_cast<float4 *>(C + (rbase + lr) * ldc + 4 * c4) = *reinterpret_cast<const float4 *>(stash + lr * SP + 4 * c4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++) {
+#pragma unroll
+      for (int t = 0; t < TW; t++) {
+        const uint32_t col = 32 * (wcol * TW + t) + r;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const uint64_t rr = m0 + 32u * rb + (i & 3) + 8 * (i >> 2) + 4 * g;
+          if (rr < M && col < N) C[rr * ldc + col] = acc[rb][t][i];
+        }
       }
     }
   }

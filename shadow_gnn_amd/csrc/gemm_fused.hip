@@ -476,24 +476,49 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     if (NBP == 2 && gu + 1 == units) {
       // end of the first product: Z_0 leaves in the C/D layout (col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5))
       // while the first images of the second product are already on their way; the accumulators start over
-      // (the bounds are made opaque here: as loop invariants the 128 store predicates would be hoisted out of the k-loop
-      //  and live in -- spilled -- scalar registers across it)
+      // The ring slot of the step that has just finished is free (the copies in flight fill the other two): the tile goes
+      // through it 8 rows x half the columns per wavefront at a time and leaves as float4s, 512 contiguous bytes per row and
+      // instruction (straight from the C/D layout it was 16 TW dword stores per lane: 8 % of the workgroup's lifetime).
+      // (the bounds are made opaque: as loop invariants the store predicates would be hoisted out of the k-loop and live
+      //  in -- spilled -- scalar registers across it)
       uint32_t rows_ok = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0))), cols_ok = d.N;
       asm volatile("" : "+s"(rows_ok), "+s"(cols_ok));
-      float *zrow = d.Z[0] + (m0 + 4 * g) * d.ldz[0] + r;
-      const uint32_t rlim = rows_ok > 4 * g ? rows_ok - 4 * g : 0u;       // rows (i & 3) + 8 (i >> 2) below this are stored
+      constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (slot: 3 TW KB)
+      float *zst = reinterpret_cast<float *>(lbuf + (size_t)((2 * gu + 1) % 3u) * kStepVecs) + (size_t)wv * (8 * 32 * CT);
+      const bool zvec = (d.ldz[0] & 3) == 0;
 #pragma unroll
-      for (int t = 0; t < TW; t++) {
-        const bool cok = 32 * t + r < cols_ok;
+      for (int ch = 0; ch < 2; ch++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          if (cok && (uint32_t)((i & 3) + 8 * (i >> 2)) < rlim) zrow[((i & 3) + 8 * (i >> 2)) * d.ldz[0] + 32 * t] = acc[t][i];
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+          for (int t = 0; t < CT; t++)
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) zst[(4 * g + ii) * (32 * CT) + 32 * t + r] = acc[CT * ch + t][4 * q + ii];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int it = 0; it < CT; it++) {
+            const uint32_t idx = it * 64 + lane, lr = idx / (8 * CT), c4 = idx % (8 * CT);
+            const uint32_t rloc = 8 * q + lr, col = 32 * CT * ch + 4 * c4;
+            if (rloc < rows_ok && col < cols_ok) {
+              const float4 v = *reinterpret_cast<const float4 *>(zst + lr * (32 * CT) + 4 * c4);
+              float *dst = d.Z[0] + (m0 + rloc) * d.ldz[0] + col;
+              if (zvec) *reinterpret_cast<float4 *>(dst) = v;
+              else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
       }
 #pragma unroll
       for (int t = 0; t < TW; t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+      // the next step's copies (of step st + 3) go into this very slot: nobody may issue them while a slower wavefront
+      // still reads its part of the stash (bare barrier: the copies in flight are not drained)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   }
 
