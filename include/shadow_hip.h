@@ -207,9 +207,12 @@ int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const uint32_t *d
                        uint32_t F, float *d_out, int64_t ld_out, void *stream);
 /* The same gather with layer 0's input dropout in the same pass (nn.Dropout at layers.py:430,471; the counter-hash
  * mask rule of sl_act_norm_fwd with (drop_p, drop_seed), row = batch row i), written into rows padded with zeros up
- * to F_pad columns (whole 128-byte lines: F = 100 -> F_pad = 128), ld_out >= F_pad.  F % 4 == 0, aligned rows.     */
+ * to F_pad columns (whole 128-byte lines: F = 100 -> F_pad = 128), ld_out >= F_pad.  F % 4 == 0, aligned rows.
+ * d_row_amax (may be NULL): receives max_k |out[i, k]| per row -- the operand scale of the GEMM that reads the rows
+ * next (see sl_row_amax).                                                                                          */
 int sl_gather_rows_drop_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n, uint32_t F,
-                            float drop_p, uint64_t drop_seed, float *d_out, int64_t ld_out, uint32_t F_pad, void *stream);
+                            float drop_p, uint64_t drop_seed, float *d_out, int64_t ld_out, uint32_t F_pad,
+                            float *d_row_amax, void *stream);
 
 /* edge_row[p] = row of edge p (the COO row index adj._indices()[0] of
  * frontend/graph_utils.py:48-56, without the host round trip).               */
@@ -270,12 +273,14 @@ int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const f
  * [edge_off[s], edge_off[s+1]) (sg_batch_out.d_subg_nodes / d_subg_edges; the transpose of such a
  * matrix has the same offsets).  Each subgraph's feature tile is staged in LDS once instead of being
  * gathered per edge; subgraphs beyond the LDS tile (384 rows / 1024 edges) gather from HBM.
- * max_subg_nodes (sg_batch_counts) sizes the tile. */
+ * max_subg_nodes (sg_batch_counts) sizes the tile.
+ * d_row_amax (may be NULL; vector layout only): joined by an atomic maximum with max_k |Y[i, k]| per row (see
+ * sl_row_amax) -- the caller zeroes it, or pre-fills it with the maxima of other columns of the same GEMM operand. */
 int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                           const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                           const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                           const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off,
-                          uint32_t num_subg, uint32_t max_subg_nodes, void *stream);
+                          uint32_t num_subg, uint32_t max_subg_nodes, float *d_row_amax, void *stream);
 /* Layer-0 form of the same product: the input matrix is never materialised by a separate pass -- row i of X is
  * table[ids[i]] (the feature gather feat_full[subgs.node], shaDow/minibatch.py:469), optionally with the layer's
  * input dropout applied (nn.Dropout at layers.py:430,471; the counter-hash mask rule of sl_act_norm_fwd below with
@@ -390,17 +395,22 @@ typedef struct {
  *     out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn))      [+ the next layer's input dropout, as
  *     sl_act_norm_fwd does it; d_out_dropped != NULL: dual mode]
  * forward: SpMM -> weight packs -> two split-bf16 GEMMs -> fused bias / act / norm, enqueued by ONE call; the caller
- * provides AX [n, Fin] (ldax), Zs, Zn, out [n, Fout] and d_pack (sl_sage_pack_bytes(Fin, Fout) bytes).
+ * provides AX [n, Fin] (ldax), Zs, Zn, out [n, Fout] and d_pack (sl_sage_pack_bytes(n, Fin, Fout) bytes).
  * backward: act_norm backward -> A^T dZn -> dX = [dZs | A^T dZn] . [Ws ; Wn] (one K = 2 Fout product; d_dX NULL: not
  * wanted) -> the two weight gradients; d_buf is [n, 3 Fout] scratch, d_an_partial as for sl_act_norm_bwd (nb = 2),
  * d_tn_partial as for sl_gemm_tn_f32; d_dbias [2, Fout] or NULL.  Fout % 4 == 0, <= 256 (input gradient: Fout % 32
  * == 0, Fin <= 256).  Forward: when sl_gemm_act_norm_supported(Fout, Fin) the two products and the act / norm run as ONE
  * kernel (sl_gemm_act_norm_fwd below), otherwise the same kernels in the same order as the separate entries.         */
-size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout);
+/* d_pack: sl_sage_pack_bytes(n, Fin, Fout) bytes of scratch (weight images + the operands' row maxima).
+ * d_x_amax (may be NULL): max_k |X[i, k]| per row (sl_row_amax) when the producer of X already wrote it;
+ * d_out_amax (may be NULL): receives the row maxima of the dropped output (of `out` without dropout) -- the d_x_amax
+ * of the next layer -- from the GEMM epilogue while the rows are in registers.                                     */
+size_t sl_sage_pack_bytes(uint32_t n, uint32_t Fin, uint32_t Fout);
 int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_Ws,
                 int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
                 const float *d_offset, int act, float drop_p, uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs,
-                float *d_Zn, float *d_out, float *d_out_dropped, void *d_pack, void *stream);
+                float *d_Zn, float *d_out, float *d_out_dropped, const float *d_x_amax, float *d_out_amax,
+                void *d_pack, void *stream);
 int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
                 const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws, const float *d_bs,
                 const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale, const float *d_offset, int act,
@@ -408,48 +418,69 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
                 float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                 float *d_an_partial, float *d_tn_partial, void *d_pack, void *stream);
 
-/* The same products with the activation + feature normalisation in the GEMM's epilogue (csrc/gemm_fused.hip; a
- * wavefront of the split-bf16 kernel owns 32 whole output rows, the unit `_f_norm_feat` works on -- layers.py:329-338):
- *   sl_gemm_act_norm_fwd   Z_b = A_b . W_b^T for b < nb <= 2 in ONE launch (d_packed_B: the nb images of
- *                          sl_gemm_act_norm_pack_b back to back; all branches share M, N, K), Z_b written (without bias), and
+/* GEMM-epilogue forms (csrc/gemm_fused.hip): the activation + feature normalisation of a layer (layers.py:329-338)
+ * inside the GEMM that produces (forward) or consumes (backward) its operand -- a wavefront owns 32 whole output rows,
+ * the unit `_f_norm_feat` works on, so there is no separate pass over the [n, F] pre-activations.
+ *
+ * Arithmetic: fp32 operands on the fp16 matrix cores as TWO fp16 pieces per element.  A row of an operand is scaled by a
+ * power of two that puts its largest magnitude into [2^14, 2^15) (exact, taken out of the accumulators again) and every
+ * element is h + m, h = rn16(x), m = rn16(x - h): 23 significand bits for every element within 2^-17 of its row's
+ * maximum, an absolute 2^-39 of that maximum below.  The product keeps hh + hm + mh (the dropped mm <= 2^-22 |ab|,
+ * zero-mean): three v_mfma_f32_32x32x16_f16 per tile and k-step, fp32 accumulation -- the measured error against fp64 is
+ * that of the six-term bf16 form of sl_gemm_nt_f32 and below a plain fp32 GEMM's (tests: test_split_gemm_matches_fp64).
+ * The largest magnitude of every row of A is an input (d_a_amax, [M] floats per operand; the scale follows from it):
+ * sl_row_amax computes it in one pass over A; the kernels that produce an operand write it while the row is in their
+ * registers (d_out_amax here, d_row_amax of sl_spmm_blockdiag_f32 / sl_gather_rows_drop_f32) and the pass disappears.
+ *
+ *   sl_gemm_act_norm_fwd   Z_b = A_b . W_b^T for b < nb <= 2 in ONE launch (d_packed_B: sl_gemm_act_norm_pack of the nb
+ *                          weights; all branches share M, N, K), Z_b written (without bias), and
  *                          out = out_scale * sum_b norm_b(act_b(Z_b + bias_b)) [+ dropout / dual output exactly as
  *                          sl_act_norm_fwd defines them] written from the accumulators: no second pass over Z.
  *                          N % 4 == 0, 16 <= N <= 256 (normalisation segment = N); operands 16-byte aligned, ld % 4 == 0.
- *   sl_gemm_an_bwd         G = A . B^T (A [M, K], d_packed_B its image in sl_gemm_act_norm_tiles(N) tiles, G [M, N]) is the gradient of a GraphSAGE layer's
- *                          output (through that layer's fused output dropout (drop_p, drop_seed) when drop_p > 0); G is
- *                          not written: the epilogue applies sl_act_norm_bwd (nb = 2, seg = N) to it row by row and
- *                          writes dZ_b, dscale, doffset and (d_dbias != NULL) dbias.  d_partial:
+ *                          d_out_amax (may be NULL): receives the row maxima of the dropped output (of out when there
+ *                          is no dropout) for the GEMM that reads it next.
+ *   sl_gemm_an_bwd         G = A . B^T (A [M, K], d_packed_B = sl_gemm_act_norm_pack_b2, G [M, N]) is the gradient of a
+ *                          GraphSAGE layer's output (through that layer's fused output dropout (drop_p, drop_seed) when
+ *                          drop_p > 0); G is not written: the epilogue applies sl_act_norm_bwd (nb = 2, seg = N) to it row
+ *                          by row and writes dZ_b, dscale, doffset and (d_dbias != NULL) dbias.  d_partial:
  *                          sl_gemm_an_bwd_partial_floats(M, N, nb) floats (one partial row per workgroup, added in a
- *                          fixed order).
- * sl_sage_fwd / sl_gcn_fwd use the forward form whenever sl_gemm_act_norm_supported(Fout, Fin) (same arithmetic per
- * row as sl_act_norm_fwd on 64 lanes; results equal to rounding of the row sums).  sl_set_fused_epilogue(0 | 1) switches
- * it (returns the previous setting; a negative argument only queries; the environment variable
- * SHADOW_FUSED_EPILOGUE=0 sets the initial state) -- the A/B handle of the tests and benchmarks.                  */
+ *                          fixed order).  d_dz0_amax (may be NULL): receives the row maxima of dZ_0.
+ * sl_sage_fwd / sl_gcn_fwd use the forward form whenever sl_gemm_act_norm_supported(Fout, Fin).  sl_set_fused_epilogue(0 | 1)
+ * switches it (returns the previous setting; a negative argument only queries; the environment variable
+ * SHADOW_FUSED_EPILOGUE=0 sets the initial state) -- the A/B handle of the tests and benchmarks: the layer entries then
+ * run sl_gemm_nt_f32 + sl_act_norm_* as separate launches.                                                         */
 int sl_set_fused_epilogue(int on);
 int sl_gemm_act_norm_supported(uint32_t N, uint32_t K);
-/* The epilogue kernels stream B images of sl_gemm_act_norm_tiles(N) = 4 or 8 column tiles (rows >= N are zero):
- * sl_gemm_act_norm_pack_b writes one (sl_gemm_act_norm_pack_bytes(N, K) bytes); sl_gemm_pack_b2_tiles is the general
- * form (strided sources as sl_gemm_pack_b2, explicit tile count, 32 tiles >= N).                                  */
+/* d_amax[i] = max_k |A[i, k]| of a row-major fp32 operand A [n, K] (16-byte aligned, lda % 4 == 0).  The kernels scale
+ * row i by the power of two that puts it into [2^14, 2^15) (1 for an all-zero row; exponent clamped to +-62).          */
+int sl_row_amax(const float *d_A, int64_t lda, uint32_t n, uint32_t K, float *d_amax, void *stream);
+/* Weight images of the epilogue kernels: fp16 pieces in sl_gemm_act_norm_tiles(N) (4 or 8) column tiles, zero above N,
+ * followed by a trailer with the power-of-two scale of every weight row and its inverse.  sl_gemm_act_norm_pack writes
+ * the nb images of one forward launch (nb * sl_gemm_act_norm_pack_bytes(N, K) bytes: images back to back, then the
+ * trailers); sl_gemm_act_norm_pack_b2 one image from strided / concatenated sources as sl_gemm_pack_b2.             */
 uint32_t sl_gemm_act_norm_tiles(uint32_t N);
 size_t sl_gemm_act_norm_pack_bytes(uint32_t N, uint32_t K);
-int sl_gemm_act_norm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream);
-int sl_gemm_pack_b2_tiles(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k,
-                          uint32_t N, uint32_t K, uint32_t tiles, void *d_packed, void *stream);
-int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const void *d_packed_B, uint32_t M, uint32_t N,
-                         uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
-                         const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo, float drop_p,
-                         uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, void *stream);
+int sl_gemm_act_norm_pack(int nb, const float *const *d_B, const int64_t *ldb, uint32_t N, uint32_t K, void *d_packed, void *stream);
+int sl_gemm_act_norm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k,
+                             uint32_t N, uint32_t K, void *d_packed, void *stream);
+int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,
+                         uint32_t M, uint32_t N, uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                         const int *act, const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo,
+                         float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax,
+                         void *stream);
 size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb);
-int sl_gemm_an_bwd(const float *d_A, int64_t lda, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K, int nb,
-                   const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act, const float *d_scale,
-                   const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz, float *d_dscale,
-                   float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed, void *stream);
+int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
+                   int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
+                   const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz,
+                   float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                   float *d_dz0_amax, void *stream);
 
 /* Backward of a GraphSAGE layer chained with the layer below it (consecutive GraphSAGE layers where nothing but this
  * layer reads the lower layer's output -- residue 'none' + centre pooling, shaDow/layers.py:159-163): the input gradient
  * of this layer IS the output gradient of the layer below, so instead of writing it (d_dX) the K = 2 Fout product's
  * epilogue produces the lower layer's dZs / dZn / dscale / doffset / dbias (sl_gemm_an_bwd) into the buffers `below`
- * names; the lower layer's own call then passes dz_ready = 1 (its d_buf = below->buf; d_dout*, d_dscale, d_doffset,
+ * names; the lower layer's own call then passes dz_ready = 1 (its d_buf = below->buf, its d_dzs_amax = below->amax;
+ * d_dout*, d_dscale, d_doffset,
  * d_an_partial and the forward tensors Zs / Zn are not touched) and only runs A^T dZn, its own input-gradient product
  * and the two weight gradients.  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, stream).                             */
 typedef struct {
@@ -463,6 +494,7 @@ typedef struct {
   float *buf;                      /* [n, 3 F]: receives dZs in columns [0, F) and dZn in [2 F, 3 F) */
   float *dscale, *doffset, *dbias; /* [2, F] each; dbias may be NULL */
   float *partial;                  /* sl_sage_chain_partial_floats(n, F) floats */
+  float *amax;                     /* [n]: receives max_k |dZs[i, k]| (the lower layer's call passes it as d_dzs_amax) */
 } sl_sage_below;
 size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F);
 int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
@@ -471,7 +503,7 @@ int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, con
                       float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
                       float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                       float *d_an_partial, float *d_tn_partial, void *d_pack, int dz_ready, const sl_sage_below *below,
-                      void *stream);
+                      float *d_dzs_amax, void *stream);
 
 /* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
  * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /
@@ -479,7 +511,7 @@ int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, con
  * act_norm backward -> dAX = dZ W -> dX = A^T dAX (d_dX NULL: not wanted; lddx its row pitch) -> dW = dZ^T AX; d_buf is
  * n * (Fout + Fin) floats of scratch, d_an_partial as for sl_act_norm_bwd (nb = 1), d_tn_partial as for sl_gemm_tn_f32.
  * Fout, Fin % 4 == 0, <= 256.  The same kernels in the same order as the separate entries: identical results.        */
-size_t sl_gcn_pack_bytes(uint32_t Fin, uint32_t Fout);
+size_t sl_gcn_pack_bytes(uint32_t n, uint32_t Fin, uint32_t Fout);
 int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_W, int64_t ldw,
                const float *d_b, const float *d_scale, const float *d_offset, int act, float drop_p, uint64_t drop_seed,
                float *d_AX, int64_t ldax, float *d_Z, float *d_out, float *d_out_dropped, void *d_pack, void *stream);

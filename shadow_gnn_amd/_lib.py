@@ -58,6 +58,7 @@ class SlSageBelow(C.Structure):
         ("Zs", C.c_void_p), ("Zn", C.c_void_p), ("bs", C.c_void_p), ("bn", C.c_void_p), ("scale", C.c_void_p),
         ("offset", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("F", C.c_uint32),
         ("buf", C.c_void_p), ("dscale", C.c_void_p), ("doffset", C.c_void_p), ("dbias", C.c_void_p), ("partial", C.c_void_p),
+        ("amax", C.c_void_p),
     ]
 
 
@@ -105,14 +106,14 @@ SIGNATURES = {
     "sg_debug_stream_rows": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_int, C.c_int, _P]),
     "sl_gather_rows_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_gather_rows_drop_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, _P, C.c_int64,
-                                           C.c_uint32, _P]),
+                                           C.c_uint32, _P, _P]),
     "sl_csr_edge_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_csr_transpose": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P]),
     "sl_degree_scales": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
     "sl_spmm_csr_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                    C.c_uint32, _P]),
     "sl_spmm_blockdiag_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
-                                         C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P]),
+                                         C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_spmm_blockdiag_gather_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_uint64, _P, C.c_int64,
                                                 _P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P]),
     "sg_cache_create": (C.c_int, [C.c_uint32, C.c_int, C.POINTER(_P)]),
@@ -126,33 +127,33 @@ SIGNATURES = {
     "sl_gemm_pack_b": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_gemm_nt_f32": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "sl_gemm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
-    "sl_sage_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "sl_sage_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_sage_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P,
-                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sl_sage_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),
     "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, C.c_int, C.POINTER(SlSageBelow), _P]),
+                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
     "sl_prof_enable": (C.c_int, [C.c_int]),
     "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "sl_gemm_act_norm_supported": (C.c_int, [C.c_uint32, C.c_uint32]),
     "sl_gemm_act_norm_tiles": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_act_norm_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
-    "sl_gemm_act_norm_pack_b": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
-    "sl_gemm_pack_b2_tiles": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
-                                         _P, _P]),
-    "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), _P, C.c_uint32, C.c_uint32, C.c_uint32,
+    "sl_row_amax": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_act_norm_pack": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_act_norm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
-                                        C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P]),
+                                        C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
     "sl_gemm_an_bwd_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
-    "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
+    "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
-                                  C.c_float, C.c_uint64, _P]),
-    "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+                                  C.c_float, C.c_uint64, _P, _P]),
+    "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "sl_gcn_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int,
@@ -180,7 +181,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 11      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 12      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -88,6 +88,25 @@ __device__ __forceinline__ float wave_max_f(float v) {
     v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])); }
   return v;
 }
+// ... and over aligned groups of LS lanes (the row maxima behind the fp16 operand scales, gemm_common.h)
+template <int LS>
+__device__ __forceinline__ float group_max(float v) {
+  static_assert(LS == 1 || LS == 2 || LS == 4 || LS == 8 || LS == 16 || LS == 32 || LS == 64, "power of two");
+  if (LS >= 2) SHD_DPP_MAX(v, 0xB1);
+  if (LS >= 4) SHD_DPP_MAX(v, 0x4E);
+  if (LS >= 8) SHD_DPP_MAX(v, 0x141);
+  if (LS >= 16) SHD_DPP_MAX(v, 0x140);
+  if (LS >= 32) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  if (LS >= 64) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  return v;
+}
+__device__ __forceinline__ float amax4(const float4 &v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // keep-mask (bit k: component k of the float4 at column f of row r) of the fused dropout: element (r, c) is kept iff
 //   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= thr

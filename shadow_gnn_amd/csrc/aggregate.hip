@@ -488,14 +488,27 @@ __device__ __forceinline__ float4 bd_load4(const BdGather &g, const float *__res
 template <int LPR>
 __global__ void gather_rows_drop_kernel(const float *__restrict__ table, int64_t ld_table, const uint32_t *__restrict__ idx,
                                         float *__restrict__ out, int64_t ld_out, uint32_t n, uint32_t F, uint32_t Fpad,
-                                        BdGather g) {
+                                        BdGather g, float *__restrict__ row_amax) {
   const uint32_t rows_per_block = kBlock / LPR;
   const uint32_t sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  for (uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub; r < n; r += (uint64_t)gridDim.x * rows_per_block) {
-    const float *src = table + (int64_t)idx[r] * ld_table;
-    float *dst = out + (int64_t)r * ld_out;
-    for (uint32_t c = l * 4; c < Fpad; c += LPR * 4)
-      SHD_ST_GATHER(dst + c, c < F ? bd_drop4(g, ld4(src + c), r, c) : make_float4(0.f, 0.f, 0.f, 0.f));
+  // (the trip count is rounded up to whole lane groups' worth of rows: the row maximum below is a DPP reduction)
+  const uint64_t stride = (uint64_t)gridDim.x * rows_per_block;
+  for (uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block; r0 < n; r0 += stride) {
+    const uint64_t r = r0 + sub;
+    float mx = 0.f;
+    if (r < n) {
+      const float *src = table + (int64_t)idx[r] * ld_table;
+      float *dst = out + (int64_t)r * ld_out;
+      for (uint32_t c = l * 4; c < Fpad; c += LPR * 4) {
+        const float4 v = c < F ? bd_drop4(g, ld4(src + c), r, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        SHD_ST_GATHER(dst + c, v);
+        mx = fmaxf(mx, amax4(v));
+      }
+    }
+    if (row_amax) {                       // largest magnitude of the row: the fp16 operand scale of the GEMM that reads it
+      mx = group_max<LPR>(mx);
+      if (l == 0 && r < n) row_amax[r] = mx;
+    }
   }
 }
 
@@ -528,6 +541,15 @@ __device__ __forceinline__ BdItem bd_item(uint32_t k, uint32_t tg, uint32_t grou
   return h;
 }
 
+// Largest magnitude of an output row for the fp16 operand scale of the GEMM that reads it (gemm_common.h).  A row's tiles
+// are produced by different work items: every (row, tile) folds its 8 lanes and joins with an atomic maximum on the bit
+// pattern (magnitudes are non-negative floats: integer order = float order; the result does not depend on the order).
+// The caller zeroes the array -- or pre-fills it with the maxima of other columns of the same operand.
+__device__ __forceinline__ void bd_row_amax(uint32_t *dst, float m, uint32_t l8) {
+  m = group_max<8>(m);
+  if (l8 == 0 && m > 0.f) atomicMax(dst, __float_as_uint(m));
+}
+
 // (two 1024-thread workgroups per CU = 8 wavefronts per SIMD: at most 64 VGPRs)
 template <bool kGather>
 __global__ void __launch_bounds__(kBdBlock, 8)
@@ -536,7 +558,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
                       const float *__restrict__ row_scale, const float *__restrict__ col_scale,
                       const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
                       uint32_t F, const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ edge_off,
-                      uint32_t P, uint32_t tiles, uint32_t tg, uint32_t cap_rows, BdGather g) {
+                      uint32_t P, uint32_t tiles, uint32_t tg, uint32_t cap_rows, BdGather g, uint32_t *__restrict__ amax_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem[];
   float *xs = reinterpret_cast<float *>(bd_smem);                        // [cap_rows][kBdRowPad]
   uint32_t *ips = reinterpret_cast<uint32_t *>(xs + (size_t)cap_rows * kBdRowPad);   // [cap_rows + 4]
@@ -633,7 +655,9 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
             acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
           }
           const float rs = rsc[k];
-          if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
+          const float4 y = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
+          if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, y);
+          if (amax_bits) bd_row_amax(amax_bits + cur.a + i, on ? amax4(y) : 0.f, l8);
         }
       }
     } else if (cur.valid) {
@@ -653,7 +677,9 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
           }
         }
         const float rs = row_scale ? row_scale[cur.a + i] : 1.0f;
-        if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs));
+        const float4 y = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
+        if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, y);
+        if (amax_bits) bd_row_amax(amax_bits + cur.a + i, on ? amax4(y) : 0.f, l8);
       }
     }
     cur = nxt; nxt = nn;
@@ -1112,7 +1138,7 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                                  const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                                 uint32_t max_subg_nodes, const BdGather &bg, void *stream_);
+                                 uint32_t max_subg_nodes, const BdGather &bg, float *d_row_amax, void *stream_);
 
 static int make_drop(BdGather *bg, float drop_p, uint64_t drop_seed, const char *who) {
   memset(bg, 0, sizeof(*bg));
@@ -1128,7 +1154,7 @@ static int make_drop(BdGather *bg, float drop_p, uint64_t drop_seed, const char 
 
 extern "C" int sl_gather_rows_drop_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n, uint32_t F,
                                        float drop_p, uint64_t drop_seed, float *d_out, int64_t ld_out, uint32_t F_pad,
-                                       void *stream_) {
+                                       float *d_row_amax, void *stream_) {
   if (n == 0 || F == 0) return SG_OK;
   if (!d_table || !d_idx || !d_out) return set_error(SG_ERR_INVALID, "sl_gather_rows_drop_f32: null argument");
   if ((F % 4) || (F_pad % 4) || F_pad < F || (ld_table % 4) || (ld_out % 4) || ld_out < (int64_t)F_pad || !aligned16(d_table) || !aligned16(d_out))
@@ -1138,11 +1164,11 @@ extern "C" int sl_gather_rows_drop_f32(const float *d_table, int64_t ld_table, c
   if ((rc = make_drop(&bg, drop_p, drop_seed, "sl_gather_rows_drop_f32")) != SG_OK) return rc;
   hipStream_t st = (hipStream_t)stream_;
   if (F_pad <= 64)
-    hipLaunchKernelGGL(gather_rows_drop_kernel<16>, dim3(grid_for(n, kBlock / 16)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg);
+    hipLaunchKernelGGL(gather_rows_drop_kernel<16>, dim3(grid_for(n, kBlock / 16)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg, d_row_amax);
   else if (F_pad <= 128)
-    hipLaunchKernelGGL(gather_rows_drop_kernel<32>, dim3(grid_for(n, kBlock / 32)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg);
+    hipLaunchKernelGGL(gather_rows_drop_kernel<32>, dim3(grid_for(n, kBlock / 32)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg, d_row_amax);
   else
-    hipLaunchKernelGGL(gather_rows_drop_kernel<64>, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg);
+    hipLaunchKernelGGL(gather_rows_drop_kernel<64>, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, st, d_table, ld_table, d_idx, d_out, ld_out, n, F, F_pad, bg, d_row_amax);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -1152,18 +1178,20 @@ extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d
                                      const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
                                      int64_t ldy, uint32_t n, uint32_t F, const uint32_t *d_subg_node_off,
                                      const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                                     uint32_t max_subg_nodes, void *stream_) {
+                                     uint32_t max_subg_nodes, float *d_row_amax, void *stream_) {
   if (!d_indptr || !d_X || !d_Y || !d_subg_node_off || !d_subg_edge_off)
     return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: null argument");
   if (n == 0 || F == 0 || num_subg == 0) return SG_OK;
   const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y);
-  if (!vec)   // unaligned layouts: the general kernel handles them
+  if (!vec) {  // unaligned layouts: the general kernel handles them
+    if (d_row_amax) return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: row maxima need the vector layout (F, ld %% 4 == 0, 16-byte aligned)");
     return sl_spmm_csr_f32(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy,
                            n, F, stream_);
+  }
   BdGather bg;
   memset(&bg, 0, sizeof(bg));
   return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F,
-                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, stream_);
+                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, d_row_amax, stream_);
 }
 
 extern "C" int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
@@ -1183,14 +1211,14 @@ extern "C" int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint
   if ((rc = make_drop(&bg, drop_p, drop_seed, "sl_spmm_blockdiag_gather_f32")) != SG_OK) return rc;
   bg.table = d_table; bg.ldt = ldt; bg.ids = d_ids; bg.xout = d_Xout; bg.ldxo = ldxo;
   return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_table, ldt, d_Y, ldy, n, F,
-                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, stream_);
+                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, nullptr, stream_);
 }
 
 static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                                  const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                                 uint32_t max_subg_nodes, const BdGather &bg, void *stream_) {
+                                 uint32_t max_subg_nodes, const BdGather &bg, float *d_row_amax, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
@@ -1222,11 +1250,11 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   if (bg.table)
     hipLaunchKernelGGL(spmm_blockdiag_kernel<true>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
                        d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
-                       tg, cap_rows, bg);
+                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax));
   else
     hipLaunchKernelGGL(spmm_blockdiag_kernel<false>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
                        d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
-                       tg, cap_rows, bg);
+                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax));
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

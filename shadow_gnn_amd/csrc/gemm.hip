@@ -23,6 +23,7 @@
 //   (2 steps x 3 pieces x N/32 tiles x 1 KiB) at a time.
 #include <algorithm>
 
+#include "actnorm_common.h"
 #include "common.h"
 #include "gemm_common.h"
 
@@ -65,6 +66,78 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t s1j, int
   out[(base + 0 * tiles + t) * 64 + l] = hh;
   out[(base + 1 * tiles + t) * 64 + l] = mm;
   out[(base + 2 * tiles + t) * 64 + l] = ll;
+}
+
+// ---------------------------------------------------------------------------
+// fp16 two-piece images (gemm_common.h): the same fragment order with two pieces per step,
+//   [unit][step][piece h, m][column tile][lane][8 x fp16],
+// followed by a trailer of 2 x 32 tiles floats: the power-of-two scale of every output column's weight row (rows >= N: 1)
+// and its inverse.  gemm_b_scale_kernel (one wavefront per row of B) writes the trailer, the pack kernel reads it.
+__global__ void gemm_b_scale_kernel(const float *__restrict__ B, int64_t s1j, int64_t s1k, uint32_t K1, const float *__restrict__ B2,
+                                    int64_t s2j, int64_t s2k, uint32_t N, uint32_t K, uint32_t tiles, float *__restrict__ trailer) {
+  const uint32_t col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (col >= 32 * tiles) return;
+  float mx = 0.f;
+  if (col < N)
+    for (uint32_t k = lane; k < K; k += 64)
+      mx = fmaxf(mx, fabsf(k < K1 ? B[(int64_t)col * s1j + (int64_t)k * s1k] : B2[(int64_t)col * s2j + (int64_t)(k - K1) * s2k]));
+  mx = wave_max_f(mx);
+  if (lane == 0) {
+    const float sc = row_scale_of(mx);
+    trailer[col] = sc;
+    trailer[32 * tiles + col] = 1.0f / sc;               // (exact: a power of two within 2^+-62)
+  }
+}
+
+__global__ void gemm_pack_b_f16_kernel(const float *__restrict__ B, int64_t s1j, int64_t s1k, uint32_t K1,
+                                       const float *__restrict__ B2, int64_t s2j, int64_t s2k, uint32_t N, uint32_t K,
+                                       uint32_t units, uint32_t tiles, const float *__restrict__ trailer, half8 *__restrict__ out) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = units * 2 * tiles * 64;
+  if (idx >= total) return;
+  const uint32_t l = idx & 63, t = (idx >> 6) % tiles, h = ((idx >> 6) / tiles) & 1, u = (idx >> 6) / tiles / 2;
+  const uint32_t col = 32 * t + (l & 31);
+  const uint32_t k0 = 32 * u + 16 * (l >> 5) + 8 * h;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t k = k0 + j;
+    x[j] = (col < N && k < K) ? (k < K1 ? B[(int64_t)col * s1j + (int64_t)k * s1k] : B2[(int64_t)col * s2j + (int64_t)(k - K1) * s2k]) : 0.f;
+  }
+  half8 hh, mm;
+  split8_f16(x, trailer[col], hh, mm);
+  const size_t base = ((size_t)(u * 2 + h) * 2) * tiles;
+  out[(base + 0 * tiles + t) * 64 + l] = hh;
+  out[(base + 1 * tiles + t) * 64 + l] = mm;
+}
+
+// Largest magnitude of every row of a row-major operand A [n, K] (lda % 4 == 0, 16-byte aligned): LPR lanes per row.
+// The stand-alone form -- an extra pass over A; the kernels that PRODUCE an operand write the maxima while the row is in
+// their registers (aggregate.hip, gemm_fused.hip) and this launch disappears.
+template <int LPR>
+__global__ void row_amax_kernel(const float *__restrict__ A, int64_t lda, uint32_t n, uint32_t K, float *__restrict__ amax) {
+  constexpr int RP = 64 / LPR;
+  const uint32_t lane = threadIdx.x & 63u, j = lane & (LPR - 1), rs = lane / LPR;
+  const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const uint32_t k4 = K / 4;
+  for (uint64_t row0 = wave * (2 * RP); row0 < n; row0 += nwaves * (2 * RP)) {
+    float mx[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint64_t row = row0 + i * RP + rs;
+      if (row < n) {
+        const float *ar = A + row * lda;
+        for (uint32_t c = j; c < k4; c += LPR) mx[i] = fmaxf(mx[i], amax4(ld4(ar + 4 * c)));
+        if (j == 0) for (uint32_t k = 4 * k4; k < K; k++) mx[i] = fmaxf(mx[i], fabsf(ar[k]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float m = group_max<LPR>(mx[i]);
+      const uint64_t row = row0 + i * RP + rs;
+      if (j == 0 && row < n) amax[row] = m;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -308,18 +381,56 @@ extern "C" int sl_gemm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_
 
 extern "C" int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j,
                                int64_t s2k, uint32_t N, uint32_t K, void *d_packed, void *stream) {
-  return sl_gemm_pack_b2_tiles(d_B1, s1j, s1k, K1, d_B2, s2j, s2k, N, K, (N + 31) / 32, d_packed, stream);
-}
-
-extern "C" int sl_gemm_pack_b2_tiles(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j,
-                                     int64_t s2k, uint32_t N, uint32_t K, uint32_t tiles, void *d_packed, void *stream) {
   if (!d_B1 || !d_packed || (K1 < K && !d_B2)) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: null argument");
   if (N == 0 || K == 0) return SG_OK;
-  if (N > 256 || tiles > 8 || 32 * tiles < N) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: N = %u in %u column tiles", N, tiles);
-  const uint32_t units = (K + 31) / 32;
+  if (N > 256) return set_error(SG_ERR_INVALID, "sl_gemm_pack_b2: N = %u (at most 256 output columns)", N);
+  const uint32_t units = (K + 31) / 32, tiles = (N + 31) / 32;
   const uint32_t total = units * 2 * tiles * 64;
   hipLaunchKernelGGL(gemm_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_B1, s1j, s1k,
                      std::min(K1, K), d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, units, tiles, reinterpret_cast<bf16x8 *>(d_packed));
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+// ---- fp16 two-piece operands (the kernels of gemm_fused.hip) ----
+namespace shadow {
+size_t pack_f16_image_bytes(uint32_t K, uint32_t tiles) { return (size_t)((K + 31) / 32) * 4 * tiles * 64 * 16; }
+size_t pack_f16_trailer_bytes(uint32_t tiles) { return (size_t)2 * 32 * tiles * 4; }
+// image of B (strided / concatenated sources as sl_gemm_pack_b2) in `tiles` column tiles at d_img, its trailer at d_trailer
+int pack_f16(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k, uint32_t N,
+             uint32_t K, uint32_t tiles, void *d_img, float *d_trailer, hipStream_t st) {
+  if (!d_B1 || !d_img || !d_trailer || (K1 < K && !d_B2)) return set_error(SG_ERR_INVALID, "fp16 weight pack: null argument");
+  if (N == 0 || K == 0) return SG_OK;
+  if (N > 256 || tiles > 8 || 32 * tiles < N) return set_error(SG_ERR_INVALID, "fp16 weight pack: N = %u in %u column tiles", N, tiles);
+  const uint32_t units = (K + 31) / 32;
+  const uint32_t total = units * 2 * tiles * 64;
+  hipLaunchKernelGGL(gemm_b_scale_kernel, dim3((32 * tiles + 3) / 4), dim3(256), 0, st, d_B1, s1j, s1k, std::min(K1, K),
+                     d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, tiles, d_trailer);
+  hipLaunchKernelGGL(gemm_pack_b_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_B1, s1j, s1k, std::min(K1, K),
+                     d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, units, tiles, d_trailer, reinterpret_cast<half8 *>(d_img));
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+}  // namespace shadow
+
+extern "C" int sl_row_amax(const float *d_A, int64_t lda, uint32_t n, uint32_t K, float *d_amax, void *stream) {
+  if (!d_A || !d_amax) return set_error(SG_ERR_INVALID, "sl_row_amax: null argument");
+  if (n == 0) return SG_OK;
+  if ((lda & 3) || (reinterpret_cast<uintptr_t>(d_A) & 15)) return set_error(SG_ERR_INVALID, "sl_row_amax: A must be 16-byte aligned with lda %% 4 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  SHD_PROF_FMT(4.0 * n * K + 4.0 * n, 0.0, st, "row_amax_K%u", K);
+  const uint32_t k4 = K / 4;
+  // (8 wavefront-rows in flight per wavefront and pass: 2 rows x 64 / LPR row slots)
+  if (k4 > 32) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 7) / 8, 256 * 16);
+    hipLaunchKernelGGL(row_amax_kernel<64>, dim3(blocks), dim3(256), 0, st, d_A, lda, n, K, d_amax);
+  } else if (k4 > 16) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 15) / 16, 256 * 16);
+    hipLaunchKernelGGL(row_amax_kernel<32>, dim3(blocks), dim3(256), 0, st, d_A, lda, n, K, d_amax);
+  } else {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 31) / 32, 256 * 16);
+    hipLaunchKernelGGL(row_amax_kernel<16>, dim3(blocks), dim3(256), 0, st, d_A, lda, n, K, d_amax);
+  }
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -592,12 +703,25 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
       const bf16x8 bh = pb[0], bm = pb[8 * 64], bl = pb[2 * 8 * 64];
       // the row tiles of step s + 2 trickle in (their buffer was split during the previous step), and this wavefront's two
       // fragments of step s + 1 are split between the MFMA groups
+#ifndef TN_KO_FILL
+      // the row tiles of step s + 2: all four copies at the top of the step -- they are waited for at its end, and a copy
+      // issued between the later MFMA groups had less than half a step to arrive (233 -> 225 us at M = 289 k, N = K = 256)
+#ifdef TN_FILL_SPREAD
       if (s + 2 < steps) {
         if (TK == 4) fill(s + 2, t);
         else { fill(s + 2, 2 * t); fill(s + 2, 2 * t + 1); }
       }
+#else
+      if (s + 2 < steps && t == 0) { fill(s + 2, 0); fill(s + 2, 1); fill(s + 2, 2); fill(s + 2, 3); }
+#endif
+#endif
+#ifndef TN_KO_SPLIT
       if (s + 1 < steps && t == 0) split_job(s + 1, 0);
       if (s + 1 < steps && t == TK / 2) split_job(s + 1, 1);
+#endif
+#ifdef TN_KO_MFMA
+      asm volatile("" ::"v"(bh), "v"(bm), "v"(bl), "v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]));
+#else
 #pragma unroll
       for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
 #pragma unroll
@@ -610,10 +734,13 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
       for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef TN_KO_BARRIER
     __syncthreads();
+#endif
   }
   // partial[g][n][k]; C/D layout: col (k) = lane & 31, row (n) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
   float *out = partial + (size_t)blockIdx.x * N * K;

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "actnorm_common.h"
 #include "common.h"
@@ -37,7 +38,9 @@ struct FusedDesc {
   // GEMM: C[M, N] = A_p[M, K] . B_p[N, K]^T for the phases p < NBP; the B images lie back to back
   const float *A[2];
   int64_t lda[2];
-  const bf16x8 *Bimg;
+  const float *aamax[2];            // largest magnitude of every row of A_p, [M]: the power-of-two row scale follows from it (gemm_common.h)
+  const half8 *Bimg;                // the NBP fp16 images back to back ...
+  const float *btrail[2];           // ... and the trailer of each: [32 TW] column scales, [32 TW] inverses
   uint32_t M, N, K, units;          // units = ceil(K / 32) per phase
   // the act + norm the epilogue applies (forward: to this GEMM's own outputs; backward: of the layer below)
   const float *bias[2];
@@ -52,10 +55,12 @@ struct FusedDesc {
   int64_t ldz[2];
   float *out;  int64_t ldo;
   float *out2; int64_t ldo2;        // dual mode: out stays plain, out2 receives the dropped values
+  float *out_amax;                  // optional: row maxima of out2 (or out) for the GEMM that reads it next
   // backward: the layer below
   const float *Zr[2]; int64_t ldzr[2];
   float *dZ[2];       int64_t lddz[2];
   float *partial;                   // [grid, nb, 3, N]
+  float *dz_amax;                   // optional: row maxima of dZ[0] (the left half of the next K = 2F operand)
   // Start stagger (see gemm_nt_fused_kernel): shader cycles the workgroups of the first dispatch round that sit in an odd
   // workgroup slot of their CU wait before they start; first_round = workgroups resident at once (2 per CU)
   uint32_t stagger_cycles, first_round, stagger_mode;
@@ -135,7 +140,7 @@ __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bo
     const int act = ACT >= 0 ? ACT : d.act[b];
     // (the per-column parameters come from the L1 here: with the 5 Q column accumulators there is no room to keep them)
     float4 z[Q], h[Q], xh[Q], dxh[Q];
-    float s = 0.f;
+    float s = 0.f, zmax = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
       const float4 bb = d.bias[b] ? ld4(d.bias[b] + (on[q] ? 4 * (j + LPR * q) : 0u)) : f4zero();
@@ -170,6 +175,11 @@ __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bo
       dh.z *= act_bwd(act, z[q].z, h[q].z); dh.w *= act_bwd(act, z[q].w, h[q].w);
       if (row_ok && on[q]) st4s(d.dZ[b] + row * d.lddz[b] + 4 * (j + LPR * q), dh);
       gb[b][q].x += dh.x; gb[b][q].y += dh.y; gb[b][q].z += dh.z; gb[b][q].w += dh.w;
+      if (b == 0) zmax = fmaxf(zmax, amax4(dh));
+    }
+    if (b == 0 && d.dz_amax) {
+      zmax = group_max<LPR>(zmax);
+      if (j == 0 && row_ok) d.dz_amax[row] = zmax;
     }
   }
 }
@@ -213,8 +223,12 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
   }
   if (MODE == 0 && NBA == 2) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // Z_0 is re-read below by other lanes
   constexpr int NG = MODE == 0 ? NBA - 1 : NBA;             // operands that come from memory: Z_0 (forward) / both Z of the layer below
-#pragma unroll
-  for (int hf = 0; hf < 2; hf++) {
+  // One half (16 rows) of the tile at a time.  While the first half is processed the second half still sits in 8 TW
+  // accumulator registers; during the second half those are free, so its global operands are fetched DEEPER ahead (the
+  // register allocation is the maximum over both halves either way).
+  auto half = [&](auto HFc, auto Dc) {
+    constexpr int hf = decltype(HFc)::value;
+    constexpr int D = decltype(Dc)::value;
     // rows 16 hf .. 16 hf + 15 of the tile: i = 8 hf + ii -> local row (ii & 3) + 8 (ii >> 2) + 4 g
 #pragma unroll
     for (int t = 0; t < TW; t++)
@@ -233,7 +247,6 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
 #ifndef SHADOW_EPI_DEPTH_FWD
 #define SHADOW_EPI_DEPTH_FWD 1
 #endif
-    constexpr int D = MODE == 1 ? SHADOW_EPI_DEPTH_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH_FWD : 2);
     static_assert(P % D == 0, "");
     float4 zpre[D][NG > 0 ? NG : 1][Q];
     auto load_pass = [&](int slot, uint64_t row) {
@@ -272,6 +285,7 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
 #pragma unroll
         for (int q = 0; q < Q; q++) zc[NBA - 1][q] = own[q];
         float4 o[Q];
+        float omax = 0.f;
         an_rows_fwd<NBA, Q, ACT, LPR>(d, cp, on, zc, inv_seg, o);
 #pragma unroll
         for (int q = 0; q < Q; q++) {
@@ -284,9 +298,16 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
               const float4 dr = make_float4(v.x * kf.x, v.y * kf.y, v.z * kf.z, v.w * kf.w);
               if (d.out2) st4s(d.out2 + row * d.ldo2 + c, dr);      // dual mode: out stays un-dropped
               else v = dr;
+              omax = fmaxf(omax, amax4(dr));
+            } else {
+              omax = fmaxf(omax, amax4(v));
             }
             st4s(d.out + row * d.ldo + c, v);
           }
+        }
+        if (d.out_amax) {                                  // the row's largest magnitude for the GEMM that reads it next
+          omax = group_max<LPR>(omax);
+          if (j == 0 && row_ok) d.out_amax[row] = omax;
         }
       } else {
         float4 dy[Q];
@@ -311,13 +332,27 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-  }
+  };
+  // (measured, scripts/ab_fused_depth.sh, M = 289 k: deeper second halves spill -- backward 2/2 538 us, 2/4 587, 2/8 749;
+  //  forward 1/1 420 us, 1/2 435, 1/4 437)
+#ifndef SHADOW_EPI_DEPTH2_BWD
+#define SHADOW_EPI_DEPTH2_BWD 2
+#endif
+#ifndef SHADOW_EPI_DEPTH2_FWD
+#define SHADOW_EPI_DEPTH2_FWD 1
+#endif
+  constexpr int P_ = 16 / RP;
+  constexpr int D0 = MODE == 1 ? SHADOW_EPI_DEPTH_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH_FWD : 2);
+  constexpr int D1w = MODE == 1 ? SHADOW_EPI_DEPTH2_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH2_FWD : 2);
+  constexpr int D1 = D1w > P_ ? P_ : D1w;
+  half(std::integral_constant<int, 0>{}, std::integral_constant<int, D0>{});
+  half(std::integral_constant<int, 1>{}, std::integral_constant<int, D1>{});
   if (MODE == 1) {
     // per-workgroup partial sums of the parameter gradients: RP row slots x 4 wavefronts column-sum rows in LDS, added
     // in a fixed order and left for act_norm_finish_kernel (deterministic)
     float *red = reinterpret_cast<float *>(gsm);            // [4 RP][1 + 2 NBA][SP]
     constexpr int kKinds = 1 + 2 * NBA;
-    static_assert(4 * RP * kKinds * SP * 4 <= 3 * 3 * TW * 64 * 16, "the reduction rows must fit the dead B ring");
+    static_assert(4 * RP * kKinds * SP * 4 <= 4 * 16 * SP * 4, "the reduction rows must fit the stash allocation");
     __syncthreads();                                        // every wavefront is done with its stash
     float *rw = red + (size_t)(wv * RP + rs) * kKinds * SP;
 #pragma unroll
@@ -352,19 +387,34 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
   }
 }
 
+// The accumulators hold (scale_row A) . (scale_col B)^T: take both powers of two out again, in place.  Lane (r, g) of the
+// C/D layout holds column 32 t + r of the rows (i & 3) + 8 (i >> 2) + 4 g; a row's inverse scale lives in lane `row`.
+template <int TW>
+__device__ __forceinline__ void unscale_tile(f32x16 (&acc)[TW], float ainv, const float *__restrict__ binv, uint32_t g, uint32_t r) {
+  float cinv[TW];
+#pragma unroll
+  for (int t = 0; t < TW; t++) cinv[t] = binv[32 * t + r];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const uint32_t row = (i & 3) + 8 * (i >> 2) + 4 * g;
+    const float rinv = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(4 * row), __float_as_int(ainv)));
+#pragma unroll
+    for (int t = 0; t < TW; t++) acc[t][i] *= rinv * cinv[t];
+  }
+}
+
 // TW column tiles (N <= 32 TW); MODE 0 forward / 1 backward; NBP GEMM phases; NBA act_norm branches;
 // kTail: K % 32 != 0 (the last unit of a phase is zero-padded).  Main loop = gemm_nt_split_kernel<1, TW, 1, 4>.
 template <int TW, int MODE, int NBP, int NBA, bool kTail>
 __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   constexpr int kThreads = 256;
-  constexpr int kStepVecs = 3 * TW * 64;                 // bf16x8 vectors of one k-step's B image
+  constexpr int kStepVecs = 2 * TW * 64;                 // half8 vectors of one k-step's B image (pieces h, m)
   constexpr int kFill = (kStepVecs + kThreads - 1) / kThreads;
   constexpr int kFillPerSlot = (kFill + TW - 1) / TW;
   constexpr int SP = 32 * TW;                            // row pitch of the epilogue stash (floats)
   static_assert(TW >= 4, "the four A pieces of a unit are issued in the first four tile slots");
-  static_assert(4 * 16 * SP * 4 <= 3 * kStepVecs * 16, "the stash must fit the dead B ring");
-  bf16x8 *lbuf = reinterpret_cast<bf16x8 *>(gsm);        // [3][kStepVecs]: ring of k-step images
+  half8 *lbuf = reinterpret_cast<half8 *>(gsm);          // [3][kStepVecs]: ring of k-step images (the allocation also covers the epilogue stash)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t r = lane & 31u, g = lane >> 5;
   const uint32_t M = d.M, K = d.K, units = d.units;
@@ -373,6 +423,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   const float *arow0 = d.A[0] + arow_i * d.lda[0] + 16 * g;
   const float *arow1 = NBP == 2 ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
   const uint32_t gunits = NBP * units, steps = 2 * gunits;
+  float asc = row_scale_of(d.aamax[0][arow_i]);           // scale of this lane's row in the current phase
 
   // Every workgroup does the same amount of work, so the two workgroups sharing a CU would run in lock step: both in the
   // main loop (matrix cores contended), then both in the epilogue (matrix cores idle) -- measured: the epilogue's time
@@ -408,8 +459,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     }
   };
   auto fill_b = [&](uint32_t s, int slot) {
-    const bf16x8 *src = d.Bimg + (size_t)s * kStepVecs;
-    bf16x8 *dst = lbuf + (size_t)(s % 3u) * kStepVecs;
+    const half8 *src = d.Bimg + (size_t)s * kStepVecs;
+    half8 *dst = lbuf + (size_t)(s % 3u) * kStepVecs;
 #pragma unroll
     for (int q = slot * kFillPerSlot; q < (slot + 1) * kFillPerSlot && q < kFill; q++) {
       const uint32_t base = q * kThreads + wv * 64u;                     // wave-uniform
@@ -434,34 +485,43 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const uint32_t st = 2 * gu + h;
-      const bf16x8 *lb = lbuf + (size_t)(st % 3u) * kStepVecs;
-      bf16x8 ah, am, al;
+      const half8 *lb = lbuf + (size_t)(st % 3u) * kStepVecs;
+      half8 ah, am;
       {
         const float x[8] = {ac[2 * h].x, ac[2 * h].y, ac[2 * h].z, ac[2 * h].w,
                             ac[2 * h + 1].x, ac[2 * h + 1].y, ac[2 * h + 1].z, ac[2 * h + 1].w};
-        split8(x, ah, am, al);
+#ifdef FUSED_KO_SPLIT
+        { union { float f[4]; half8 v; } u0, u1; for (int j = 0; j < 4; j++) { u0.f[j] = x[j] * asc; u1.f[j] = x[4 + j]; } ah = u0.v; am = u1.v; }
+#else
+        split8_f16(x, asc, ah, am);
+#endif
       }
       // (pin: the A registers are consumed -- and waited for -- BEFORE this step issues new copies)
       __builtin_amdgcn_sched_barrier(0);
-      bf16x8 fb[2][3];
+      half8 fb[2][2];
 #pragma unroll
-      for (int pc = 0; pc < 3; pc++) fb[0][pc] = lb[(pc * TW) * 64 + lane];
+      for (int pc = 0; pc < 2; pc++) fb[0][pc] = lb[(pc * TW) * 64 + lane];
 #pragma unroll
       for (int t = 0; t < TW; t++) {
         if (t + 1 < TW) {
 #pragma unroll
-          for (int pc = 0; pc < 3; pc++) fb[(t + 1) & 1][pc] = lb[(pc * TW + t + 1) * 64 + lane];
+          for (int pc = 0; pc < 2; pc++) fb[(t + 1) & 1][pc] = lb[(pc * TW + t + 1) * 64 + lane];
         }
+#ifndef FUSED_KO_FILL
         if (st + 2 < steps) fill_b(st + 2, t);              // two steps ahead: never waited for in this step
+#endif
+#ifndef FUSED_KO_ALOAD
         if (h == 0 && t < 4 && gu + 1 < gunits) load_a_piece(gu + 1, t);
-        const bf16x8 bh = fb[t & 1][0], bm = fb[t & 1][1], bl = fb[t & 1][2];
-        // small terms first, the dominant product last
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+#endif
+        const half8 bh = fb[t & 1][0], bm = fb[t & 1][1];
+        // the two small terms first, the dominant product last
+#ifdef FUSED_KO_MFMA
+        asm volatile("" ::"v"(bh), "v"(bm), "v"(ah), "v"(am));
+#else
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // wait only for what is OLDER than this step's own copies, then a bare barrier
@@ -471,7 +531,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
+#ifndef FUSED_KO_BARRIER
       __builtin_amdgcn_s_barrier();                      // every wavefront is done with this step's buffer
+#endif
     }
     if (NBP == 2 && gu + 1 == units) {
       // end of the first product: Z_0 leaves in the C/D layout (col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5))
@@ -483,7 +545,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       //  in -- spilled -- scalar registers across it)
       uint32_t rows_ok = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0))), cols_ok = d.N;
       asm volatile("" : "+s"(rows_ok), "+s"(cols_ok));
-      constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (slot: 3 TW KB)
+      unscale_tile<TW>(acc, 1.0f / asc, d.btrail[0] + 32 * TW, g, r);
+      asc = row_scale_of(d.aamax[1][arow_i]);
+      constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (= one ring slot)
       float *zst = reinterpret_cast<float *>(lbuf + (size_t)((2 * gu + 1) % 3u) * kStepVecs) + (size_t)wv * (8 * 32 * CT);
       const bool zvec = (d.ldz[0] & 3) == 0;
 #pragma unroll
@@ -525,6 +589,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier).  Specialised for the two activations
   //      the reference's configurations use (config_train: elu, relu) on full-width rows; everything else takes the generic
   //      copy (activation looked up per element, column predicates)
+#ifdef FUSED_KO_EPI
+  if (d.M != 7) { if (acc[0][0] == 123.456f) d.Z[0][0] = acc[1][1]; return; }
+#endif
+  unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
   const bool full = d.N == 32 * TW, same = NBA == 1 || d.act[1] == d.act[0];
   if (full && same && d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true>(d, acc, gsm, m0);
   else if (full && same && d.act[0] == 2) fused_epilogue<TW, MODE, NBA, 2, true>(d, acc, gsm, m0);
@@ -543,6 +611,15 @@ int fill_dropout(FusedDesc &p, float drop_p, uint64_t drop_seed, const char *who
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// layout of sl_gemm_act_norm_pack: nimg images back to back, then their trailers
+inline void set_images(FusedDesc &p, const void *packed, int nimg, uint32_t N, uint32_t K) {
+  const uint32_t tiles = N <= 128 ? 4u : 8u;
+  const size_t ib = (size_t)((K + 31) / 32) * 4 * tiles * 64 * 16, tb = (size_t)2 * 32 * tiles * 4;
+  const char *base = reinterpret_cast<const char *>(packed);
+  p.Bimg = reinterpret_cast<const half8 *>(base);
+  for (int b = 0; b < nimg; b++) p.btrail[b] = reinterpret_cast<const float *>(base + nimg * ib + b * tb);
+}
+
 // SHADOW_FUSED_STAGGER=<shader cycles per k-step of one phase> (default 0 = derived below; -1 = off)
 int g_stagger_override = [] {
   const char *e = getenv("SHADOW_FUSED_STAGGER");
@@ -551,7 +628,8 @@ int g_stagger_override = [] {
 
 template <int TW, int MODE, int NBP, int NBA>
 int launch_fused(FusedDesc d, hipStream_t st) {
-  const size_t lds = (size_t)3 * 3 * TW * 64 * 16;
+  // ring of three k-step images (3 x 2 TW KB) or the epilogue's stash (4 wavefronts x 16 rows x 32 TW floats), whichever is larger
+  const size_t lds = std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
   const uint32_t grid = (d.M + 127) / 128;
   {
     int ncu = 256, dev = 0;
@@ -583,6 +661,12 @@ bool g_fused_epilogue = [] {
 
 }  // namespace
 
+// fp16 weight images (gemm.hip)
+size_t pack_f16_image_bytes(uint32_t K, uint32_t tiles);
+size_t pack_f16_trailer_bytes(uint32_t tiles);
+int pack_f16(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k, uint32_t N,
+             uint32_t K, uint32_t tiles, void *d_img, float *d_trailer, hipStream_t st);
+
 // the reduction of the per-workgroup partial sums (aggregate.hip)
 int act_norm_finish_launch(const float *partial, uint32_t nblocks, int nb, uint32_t F, float *dscale, float *doffset, float *dbias,
                            hipStream_t st);
@@ -600,25 +684,50 @@ extern "C" int sl_set_fused_epilogue(int on) {
 // column tiles of the B image the epilogue kernels stream: 4 or 8 (the image is zero-padded above N)
 extern "C" uint32_t sl_gemm_act_norm_tiles(uint32_t N) { return N <= 128 ? 4u : 8u; }
 
+// One weight image of the epilogue kernels: fp16 pieces in sl_gemm_act_norm_tiles(N) column tiles + the scale trailer.
 extern "C" size_t sl_gemm_act_norm_pack_bytes(uint32_t N, uint32_t K) {
-  return (size_t)((K + 31) / 32) * 6 * sl_gemm_act_norm_tiles(N) * 64 * 16;
+  const uint32_t tiles = sl_gemm_act_norm_tiles(N);
+  return pack_f16_image_bytes(K, tiles) + pack_f16_trailer_bytes(tiles);
 }
 
-extern "C" int sl_gemm_act_norm_pack_b(const float *d_B, int64_t ldb, uint32_t N, uint32_t K, void *d_packed, void *stream) {
-  return sl_gemm_pack_b2_tiles(d_B, ldb, 1, K, d_B, ldb, 1, N, K, sl_gemm_act_norm_tiles(N), d_packed, stream);
+// The nb <= 2 weights W_b [N, K] of one launch: images back to back, then the trailers (nb x sl_gemm_act_norm_pack_bytes).
+extern "C" int sl_gemm_act_norm_pack(int nb, const float *const *d_B, const int64_t *ldb, uint32_t N, uint32_t K, void *d_packed,
+                                     void *stream) {
+  if (nb < 1 || nb > 2 || !d_B || !ldb || !d_packed) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_pack: bad argument");
+  const uint32_t tiles = sl_gemm_act_norm_tiles(N);
+  const size_t ib = pack_f16_image_bytes(K, tiles), tb = pack_f16_trailer_bytes(tiles);
+  char *base = reinterpret_cast<char *>(d_packed);
+  for (int b = 0; b < nb; b++) {
+    const int rc = pack_f16(d_B[b], ldb[b], 1, K, d_B[b], ldb[b], 1, N, K, tiles, base + b * ib,
+                            reinterpret_cast<float *>(base + nb * ib + b * tb), (hipStream_t)stream);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
+// The general form for one image: B element (j, k) = B1[j s1j + k s1k] for k < K1, B2[j s2j + (k - K1) s2k] behind
+// (a transposed weight, [Ws^T | Wn^T] without materialising the concatenation) -- the operand of sl_gemm_an_bwd.
+extern "C" int sl_gemm_act_norm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j,
+                                        int64_t s2k, uint32_t N, uint32_t K, void *d_packed, void *stream) {
+  if (!d_packed) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_pack_b2: null argument");
+  const uint32_t tiles = sl_gemm_act_norm_tiles(N);
+  char *base = reinterpret_cast<char *>(d_packed);
+  return pack_f16(d_B1, s1j, s1k, K1, d_B2, s2j, s2k, N, K, tiles, base,
+                  reinterpret_cast<float *>(base + pack_f16_image_bytes(K, tiles)), (hipStream_t)stream);
 }
 
 extern "C" int sl_gemm_act_norm_supported(uint32_t N, uint32_t K) {
   return g_fused_epilogue && N >= 16 && N <= 256 && (N & 3) == 0 && K > 0;
 }
 
-extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const void *d_packed_B, uint32_t M,
+extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax,
+                                    const void *d_packed_B, uint32_t M,
                                     uint32_t N, uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                     const int *act, const float *d_scale, const float *d_offset, float out_scale, float *d_out,
                                     int64_t ldo, float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped,
-                                    void *stream) {
+                                    float *d_out_amax, void *stream) {
   if (nb < 1 || nb > 2) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: nb must be 1 or 2");
-  if (!d_A || !lda || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_out)
+  if (!d_A || !lda || !d_a_amax || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_out)
     return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null argument");
   if (M == 0) return SG_OK;
   if (N < 16 || N > 256 || (N & 3) || K == 0)
@@ -626,20 +735,20 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
   FusedDesc p;
   memset(&p, 0, sizeof(p));
   for (int b = 0; b < nb; b++) {
-    if (!d_A[b] || !d_Z[b]) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null operand of branch %d", b);
+    if (!d_A[b] || !d_Z[b] || !d_a_amax[b]) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null operand of branch %d", b);
     if ((lda[b] & 3) || !al16(d_A[b]) || (ldz[b] & 3) || !al16(d_Z[b]))
       return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: operands must be 16-byte aligned with ld %% 4 == 0");
     if (act[b] < 0 || act[b] > 4) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: unknown activation %d", act[b]);
     if (d_bias && d_bias[b] && !al16(d_bias[b])) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: bias must be 16-byte aligned");
-    p.A[b] = d_A[b]; p.lda[b] = lda[b]; p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b];
+    p.A[b] = d_A[b]; p.lda[b] = lda[b]; p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.aamax[b] = d_a_amax[b];
     p.bias[b] = d_bias ? d_bias[b] : nullptr;
   }
+  set_images(p, d_packed_B, nb, N, K);
   if (!al16(d_scale) || !al16(d_offset) || !al16(d_out) || (ldo & 3))
     return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: scale / offset / out must be 16-byte aligned, ldo %% 4 == 0");
-  p.Bimg = reinterpret_cast<const bf16x8 *>(d_packed_B);
   p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
-  p.out = d_out; p.ldo = ldo;
+  p.out = d_out; p.ldo = ldo; p.out_amax = d_out_amax;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_act_norm_fwd")) != SG_OK) return rc;
   if (d_out_dropped) {
@@ -657,13 +766,15 @@ extern "C" size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb) 
   return (size_t)((M + 127) / 128) * (size_t)nb * 3 * N;
 }
 
-extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K, int nb,
+extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N,
+                              uint32_t K, int nb,
                               const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
                               const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ,
                               const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
-                              float drop_p, uint64_t drop_seed, void *stream) {
+                              float drop_p, uint64_t drop_seed, float *d_dz0_amax, void *stream) {
   if (nb != 2) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: nb must be 2 (a GraphSAGE layer below)");
-  if (!d_A || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_dZ || !lddz || !d_dscale || !d_doffset || !d_partial)
+  if (!d_A || !d_a_amax || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_dZ || !lddz || !d_dscale || !d_doffset ||
+      !d_partial)
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
@@ -676,7 +787,8 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const void *d_packe
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: N = %u, K = %u, lda = %lld unsupported", N, K, (long long)lda);
   FusedDesc p;
   memset(&p, 0, sizeof(p));
-  p.A[0] = d_A; p.lda[0] = lda;
+  p.A[0] = d_A; p.lda[0] = lda; p.aamax[0] = d_a_amax;
+  set_images(p, d_packed_B, 1, N, K);
   for (int b = 0; b < nb; b++) {
     if (!d_Z[b] || !d_dZ[b]) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: null operand of branch %d", b);
     if ((ldz[b] & 3) || !al16(d_Z[b]) || (lddz[b] & 3) || !al16(d_dZ[b]))
@@ -687,10 +799,9 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const void *d_packe
     p.bias[b] = d_bias ? d_bias[b] : nullptr;
   }
   if (!al16(d_scale) || !al16(d_offset)) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: scale / offset must be 16-byte aligned");
-  p.Bimg = reinterpret_cast<const bf16x8 *>(d_packed_B);
   p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
-  p.partial = d_partial;
+  p.partial = d_partial; p.dz_amax = d_dz0_amax;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_an_bwd")) != SG_OK) return rc;
   rc = N <= 128 ? launch_fused<4, 1, 1, 2>(p, st) : launch_fused<8, 1, 1, 2>(p, st);

@@ -8,23 +8,42 @@
 // order of the existing ones (the same order ops._SageDense used), so results are identical.
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 using namespace shadow;
 
 namespace {
 
-int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx, float *Y, int64_t ldy, uint32_t F, void *st) {
+// does the SpMM of this shape run on the kernel that can join row maxima atomically?
+bool spmm_joins(const sl_norm_adj *a, uint32_t F, const float *X, int64_t ldx, const float *Y, int64_t ldy) {
+  return a->subg_node_off && F >= 96 && (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && !(reinterpret_cast<uintptr_t>(X) & 15) &&
+         !(reinterpret_cast<uintptr_t>(Y) & 15);
+}
+
+// amax (may be NULL): joined with the row maxima of Y (zeroed here unless `amax_prefilled`); kernels without the atomic
+// form get a separate pass
+int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx, float *Y, int64_t ldy, uint32_t F, void *st,
+             float *amax = nullptr, bool amax_prefilled = false) {
   const uint32_t *ip = transposed ? a->t_indptr : a->indptr, *ix = transposed ? a->t_indices : a->indices;
   const uint32_t *perm = (transposed && a->edge_w) ? a->t_perm : nullptr;
   // (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
   const float *rs = transposed ? a->col_scale : a->row_scale, *cs = transposed ? a->row_scale : a->col_scale;
   // algorithmic bytes: indptr + indices (+ edge values) + read X + write A.X
   SHD_PROF_FMT(4.0 * (a->n + 1) + 4.0 * a->e + (a->edge_w ? 4.0 * a->e : 0.0) + 8.0 * a->n * F, 0, st, "spmm_F%u", F);
-  if (a->subg_node_off && F >= 96)
-    return sl_spmm_blockdiag_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
-                                 a->num_subg, a->max_subg_nodes, st);
-  return sl_spmm_csr_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, st);
+  if (a->subg_node_off && F >= 96) {
+    float *am = spmm_joins(a, F, X, ldx, Y, ldy) ? amax : nullptr;
+    if (am && !amax_prefilled) SHD_HIP(hipMemsetAsync(am, 0, (size_t)a->n * 4, (hipStream_t)st));
+    const int rc = sl_spmm_blockdiag_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
+                                         a->num_subg, a->max_subg_nodes, am, st);
+    if (rc != SG_OK || !amax || am) return rc;
+  } else {
+    const int rc = sl_spmm_csr_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, st);
+    if (rc != SG_OK || !amax) return rc;
+  }
+  if (amax_prefilled) return set_error(SG_ERR_INVALID, "spmm: joined row maxima need the block-diagonal vector kernel");
+  return sl_row_amax(Y, ldy, a->n, F, amax, st);
 }
 
 // the primitives, each under its profiling scope (names and byte / flop counts as ops.py gives them to KernelTimer)
@@ -46,40 +65,52 @@ bool fused_epilogue_ok(uint32_t Fout, uint32_t Fin, const float *A0, int64_t lda
 
 }  // namespace
 
-extern "C" size_t sl_sage_pack_bytes(uint32_t Fin, uint32_t Fout) {
+// scratch of one layer pass: the weight images, then (16-byte aligned) the operands' row scales (2 n floats)
+static size_t images_bytes_sage(uint32_t Fin, uint32_t Fout) {
   // forward: Ws and Wn images ([Fout, Fin] each); backward: the [Fin, 2 Fout] image of [Ws^T | Wn^T]
-  // (the epilogue kernels stream images of 4 or 8 column tiles: sl_gemm_act_norm_pack_bytes >= sl_gemm_pack_bytes)
-  const size_t fwd = 2 * sl_gemm_act_norm_pack_bytes(Fout, Fin), bwd = sl_gemm_act_norm_pack_bytes(Fin, 2 * Fout);
-  return fwd > bwd ? fwd : bwd;
+  // (fp16 epilogue-kernel images or, for widths those do not take, the bf16 images of sl_gemm_nt_f32)
+  const size_t fwd = std::max(2 * sl_gemm_act_norm_pack_bytes(Fout, Fin), 2 * sl_gemm_pack_bytes(Fout, Fin));
+  const size_t bwd = std::max(sl_gemm_act_norm_pack_bytes(Fin, 2 * Fout), sl_gemm_pack_bytes(Fin, 2 * Fout));
+  return (std::max(fwd, bwd) + 15) & ~(size_t)15;
+}
+
+extern "C" size_t sl_sage_pack_bytes(uint32_t n, uint32_t Fin, uint32_t Fout) {
+  return images_bytes_sage(Fin, Fout) + (size_t)2 * n * 4;
 }
 
 extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout,
                            const float *d_Ws, int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn,
                            const float *d_bn, const float *d_scale, const float *d_offset, int act, float drop_p,
                            uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs, float *d_Zn, float *d_out,
-                           float *d_out_dropped, void *d_pack, void *stream) {
+                           float *d_out_dropped, const float *d_x_amax, float *d_out_amax, void *d_pack, void *stream) {
   if (!adj || !d_X || !d_Ws || !d_Wn || !d_scale || !d_offset || !d_AX || !d_Zs || !d_Zn || !d_out || !d_pack)
     return set_error(SG_ERR_INVALID, "sl_sage_fwd: null argument");
   if (Fout > 256 || (Fout & 3) || Fin == 0) return set_error(SG_ERR_INVALID, "sl_sage_fwd: Fout = %u (multiple of 4, at most 256)", Fout);
   const uint32_t n = adj->n;
   if (n == 0) return SG_OK;
   int rc;
-  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
   char *pk = (char *)d_pack;
+  const bool fused = fused_epilogue_ok(Fout, Fin, d_X, ldx, d_AX, ldax);
+  // row maxima of the two A operands (fp16 split, gemm_common.h): the SpMM writes those of A X
+  float *amx = reinterpret_cast<float *>(pk + images_bytes_sage(Fin, Fout));
+  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream, fused ? amx + n : nullptr)) != SG_OK) return rc;
   const int64_t ldz[2] = {Fout, Fout};
   const float *bias[2] = {d_bs, d_bn};
   const int acts[2] = {act, act};
-  if (fused_epilogue_ok(Fout, Fin, d_X, ldx, d_AX, ldax)) {
+  if (fused) {
     // both products in one launch, bias / act / norm / branch sum (/ dropout) in its epilogue (gemm_fused.hip)
-    const size_t pbf = sl_gemm_act_norm_pack_bytes(Fout, Fin);
-    if ((rc = sl_gemm_act_norm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
-    if ((rc = sl_gemm_act_norm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pbf, stream)) != SG_OK) return rc;
+    const float *W[2] = {d_Ws, d_Wn};
+    const int64_t ldw[2] = {ldws, ldwn};
+    if ((rc = sl_gemm_act_norm_pack(2, W, ldw, Fout, Fin, pk, stream)) != SG_OK) return rc;
+    // X's row maxima come with it when its producer wrote them
+    if (!d_x_amax && (rc = sl_row_amax(d_X, ldx, n, Fin, amx, stream)) != SG_OK) return rc;
     const float *A[2] = {d_X, d_AX};
+    const float *asc[2] = {d_x_amax ? d_x_amax : amx, amx + n};
     const int64_t lda[2] = {ldx, ldax};
     float *Zw[2] = {d_Zs, d_Zn};
     SHD_PROF_FMT(4.0 * n * (2 * Fin + 2 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 2 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 2, Fout, Fin % 32 ? "_Ktail" : "");
-    return sl_gemm_act_norm_fwd(2, A, lda, pk, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
-                                drop_seed, d_out_dropped, Fout, stream);
+    return sl_gemm_act_norm_fwd(2, A, lda, asc, pk, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
+                                drop_seed, d_out_dropped, Fout, d_out_amax, stream);
   }
   const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
   if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
@@ -88,8 +119,10 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
   if ((rc = nt_gemm(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   const float *Z[2] = {d_Zs, d_Zn};
   SHD_PROF_FMT((2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_fwd_nb%d_F%u", 2, Fout);
-  return sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
-                         d_out_dropped, Fout, stream);
+  if ((rc = sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
+                            d_out_dropped, Fout, stream)) != SG_OK)
+    return rc;
+  return d_out_amax ? sl_row_amax(d_out_dropped ? d_out_dropped : d_out, Fout, n, Fout, d_out_amax, stream) : SG_OK;
 }
 
 extern "C" size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F) { return sl_gemm_an_bwd_partial_floats(n, F, 2); }
@@ -103,7 +136,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
                                  const float *d_offset, int act, float drop_p, uint64_t drop_seed, const float *d_dout,
                                  const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
                                  float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
-                                 void *d_pack, int dz_ready, const sl_sage_below *below, void *stream) {
+                                 void *d_pack, int dz_ready, const sl_sage_below *below, float *d_dzs_amax, void *stream) {
   if (!adj || !d_X || !d_AX || !d_Ws || !d_Wn || !d_dWs || !d_dWn || !d_buf || !d_tn_partial || !d_pack)
     return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
   if (!dz_ready && (!d_Zs || !d_Zn || !d_scale || !d_offset || !d_dscale || !d_doffset || !d_an_partial || (!d_dout && !d_dout_dropped)))
@@ -111,7 +144,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
   if (Fout > 256 || (Fout & 3) || Fin > 256 || (Fin & 3)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: widths %u -> %u unsupported", Fin, Fout);
   if ((d_dX || below) && ((2 * Fout) % 32 || Fout % 32)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs Fout %% 32 == 0");
   if (below && (below->F != Fin || !below->Zs || !below->Zn || !below->scale || !below->offset || !below->buf || !below->dscale ||
-                !below->doffset || !below->partial))
+                !below->doffset || !below->partial || !below->amax))
     return set_error(SG_ERR_INVALID, "sl_sage_bwd: incomplete description of the layer below");
   const uint32_t n = adj->n;
   if (n == 0) return SG_OK;
@@ -134,11 +167,20 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
   }
   if (d_dX || below) {
     if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
-    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream)) != SG_OK) return rc;
+    // The K = 2 Fout operand [dZs | A^T dZn] of the epilogue form needs its row maxima: those of dZs come from the kernel
+    // that wrote it (the layer above, dz_ready) or from one pass here; the transposed SpMM joins those of its half.
+    float *amx = reinterpret_cast<float *>(reinterpret_cast<char *>(d_pack) + images_bytes_sage(Fin, Fout));
+    const bool join = below && spmm_joins(adj, Fout, dZn, ld3, d_buf + Fout, ld3);
+    if (join) {
+      if (dz_ready && d_dzs_amax) amx = d_dzs_amax;
+      else if ((rc = sl_row_amax(dZs, ld3, n, Fout, amx, stream)) != SG_OK) return rc;
+    }
+    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream, join ? amx : nullptr, true)) != SG_OK) return rc;
+    if (below && !join && (rc = sl_row_amax(d_buf, ld3, n, 2 * Fout, amx, stream)) != SG_OK) return rc;
     // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
-    if ((rc = sl_gemm_pack_b2_tiles(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, below ? sl_gemm_act_norm_tiles(Fin) : (Fin + 31) / 32,
-                                    d_pack, stream)) != SG_OK)
-      return rc;
+    if (below) rc = sl_gemm_act_norm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
+    else rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
+    if (rc != SG_OK) return rc;
     if (below) {
       const uint32_t Fb = below->F;
       const float *Zb[2] = {below->Zs, below->Zn};
@@ -149,9 +191,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       const int64_t lddzb[2] = {3 * (int64_t)Fb, 3 * (int64_t)Fb};
       // read [dZs | A^T dZn] and both Z of the layer below, write its two dZ
       SHD_PROF_FMT(4.0 * n * (2.0 * Fout + 4.0 * Fb), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_an_bwd_nb2_N%u", Fin);
-      if ((rc = sl_gemm_an_bwd(d_buf, ld3, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
+      if ((rc = sl_gemm_an_bwd(d_buf, ld3, amx, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
                                lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
-                               stream)) != SG_OK)
+                               below->amax, stream)) != SG_OK)
         return rc;
     } else if ((rc = nt_gemm(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
       return rc;
@@ -170,17 +212,19 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                            void *d_pack, void *stream) {
   return sl_sage_bwd_chain(adj, d_X, ldx, d_AX, ldax, d_Zs, d_Zn, Fin, Fout, d_Ws, ldws, d_bs, d_Wn, ldwn, d_bn, d_scale, d_offset, act,
                            drop_p, drop_seed, d_dout, d_dout_dropped, d_dX, d_dWs, d_dWn, d_dbias, d_dscale, d_doffset, d_buf,
-                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, stream);
+                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // GCN (shaDow/layers.py:417-444): out = norm(act((A X) W^T + b)).  Forward: SpMM, weight pack, GEMM, fused bias / act /
 // norm; backward: act_norm backward, dAX = dZ W, dX = A^T dAX, dW = dZ^T (A X).
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" size_t sl_gcn_pack_bytes(uint32_t Fin, uint32_t Fout) {
-  const size_t fwd = sl_gemm_act_norm_pack_bytes(Fout, Fin), bwd = sl_gemm_pack_bytes(Fin, Fout);
-  return fwd > bwd ? fwd : bwd;
+static size_t images_bytes_gcn(uint32_t Fin, uint32_t Fout) {
+  const size_t fwd = std::max(sl_gemm_act_norm_pack_bytes(Fout, Fin), sl_gemm_pack_bytes(Fout, Fin)), bwd = sl_gemm_pack_bytes(Fin, Fout);
+  return (std::max(fwd, bwd) + 15) & ~(size_t)15;
 }
+
+extern "C" size_t sl_gcn_pack_bytes(uint32_t n, uint32_t Fin, uint32_t Fout) { return images_bytes_gcn(Fin, Fout) + (size_t)n * 4; }
 
 extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_W,
                           int64_t ldw, const float *d_b, const float *d_scale, const float *d_offset, int act, float drop_p,
@@ -192,18 +236,23 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
   const uint32_t n = adj->n;
   if (n == 0) return SG_OK;
   int rc;
-  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
+  const bool fused = fused_epilogue_ok(Fout, Fin, d_AX, ldax, nullptr, 0);
+  float *amx = reinterpret_cast<float *>(reinterpret_cast<char *>(d_pack) + images_bytes_gcn(Fin, Fout));
+  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream, fused ? amx : nullptr)) != SG_OK) return rc;
   const int64_t ldz[1] = {Fout};
   const float *bias[1] = {d_b};
   const int acts[1] = {act};
-  if (fused_epilogue_ok(Fout, Fin, d_AX, ldax, nullptr, 0)) {
-    if ((rc = sl_gemm_act_norm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
+  if (fused) {
+    const float *W[1] = {d_W};
+    const int64_t ldws[1] = {ldw};
+    if ((rc = sl_gemm_act_norm_pack(1, W, ldws, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
     const float *A[1] = {d_AX};
+    const float *asc[1] = {amx};
     const int64_t lda[1] = {ldax};
     float *Zw[1] = {d_Z};
     SHD_PROF_FMT(4.0 * n * (1 * Fin + 1 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 1 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 1, Fout, Fin % 32 ? "_Ktail" : "");
-    return sl_gemm_act_norm_fwd(1, A, lda, d_pack, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
-                                drop_seed, d_out_dropped, Fout, stream);
+    return sl_gemm_act_norm_fwd(1, A, lda, asc, d_pack, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
+                                drop_seed, d_out_dropped, Fout, nullptr, stream);
   }
   if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
   if ((rc = nt_gemm(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;

@@ -298,7 +298,7 @@ def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, bl
             check(lib.sl_spmm_blockdiag_f32(
                 indptr.data_ptr(), indices.data_ptr(), opt(edge_w), opt(edge_perm), opt(row_scale), opt(col_scale),
                 X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), n, F, off.data_ptr(), eoff.data_ptr(),
-                int(off.numel()) - 1, mn, _stream(X)))
+                int(off.numel()) - 1, mn, None, _stream(X)))
         else:
             check(lib.sl_spmm_csr_f32(
                 indptr.data_ptr(), indices.data_ptr(), opt(edge_w), opt(edge_perm), opt(row_scale), opt(col_scale),
@@ -393,11 +393,12 @@ class LazyRows:
             return (torch.nn.functional.dropout(x, drop_p, True) if drop_p > 0 else x), 0
         Fp = (F + 31) // 32 * 32
         buf = torch.empty(n, Fp, dtype=torch.float32, device=t.device)
+        amax = torch.empty(n, dtype=torch.float32, device=t.device)
         seed = new_dropout_seed() if drop_p > 0 else 0
         with _timed(f"gather_F{F}", 8 * n * F + 4 * n, t.device):
             check(_lib.load().sl_gather_rows_drop_f32(t.data_ptr(), t.stride(0), self.idx.data_ptr(), n, F, float(drop_p), int(seed),
-                                                      buf.data_ptr(), buf.stride(0), Fp, _stream(buf)))
-        return buf[:, :F], seed
+                                                      buf.data_ptr(), buf.stride(0), Fp, amax.data_ptr(), _stream(buf)))
+        return set_row_amax(buf[:, :F], amax), seed
 
 
 def dense_rows(x):
@@ -674,6 +675,29 @@ def gemm_act_norm_usable(Xs, Ws, seg, F) -> bool:
     return True
 
 
+def row_amax(A: torch.Tensor) -> torch.Tensor:
+    """max_k |A[i, k]| per row: what the GEMM-epilogue kernels derive the fp16 operand scales from (sl_row_amax,
+    include/shadow_hip.h).  Kernels that produce an operand leave it on the tensor (``set_row_amax``) instead."""
+    n, K = A.shape
+    am = torch.empty(n, dtype=torch.float32, device=A.device)
+    with _timed(f"row_amax_K{K}", 4 * n * K + 4 * n, A.device):
+        check(_lib.load().sl_row_amax(A.data_ptr(), A.stride(0), n, K, am.data_ptr(), _stream(A)))
+    return am
+
+
+def set_row_amax(t: torch.Tensor, amax: torch.Tensor) -> torch.Tensor:
+    """Attach the row maxima a producer kernel wrote for ``t`` (valid until t is modified in place)."""
+    t._shd_row_amax = (amax, t._version)
+    return t
+
+
+def get_row_amax(t: torch.Tensor) -> Optional[torch.Tensor]:
+    a = getattr(t, "_shd_row_amax", None)
+    if a is None or a[1] != t._version or a[0].shape[0] != t.shape[0] or a[0].device != t.device:
+        return None
+    return a[0]
+
+
 def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
     """Z_b = X_b W_b^T (kept for the backward pass) and out = out_scale * sum_b norm_b(act(Z_b + bias_b)) [+ the fused
     output dropout] from ONE kernel: the activation / normalisation runs in the GEMM's epilogue (csrc/gemm_fused.hip).
@@ -684,13 +708,10 @@ def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
     F = Ws[0].shape[0]
     dev = Xs[0].device
     st = _stream(Xs[0])
-    pb = lib.sl_gemm_act_norm_pack_bytes(F, K)
-    pack = torch.empty(nb * pb, dtype=torch.uint8, device=dev)
-    for b, w in enumerate(Ws):
-        wc = w.detach()
-        if wc.stride(1) != 1:
-            wc = wc.contiguous()
-        check(lib.sl_gemm_act_norm_pack_b(wc.data_ptr(), wc.stride(0), F, K, pack.data_ptr() + b * pb, st))
+    pack = torch.empty(nb * lib.sl_gemm_act_norm_pack_bytes(F, K), dtype=torch.uint8, device=dev)
+    wcs = [w.detach() if w.stride(1) == 1 else w.detach().contiguous() for w in Ws]
+    check(lib.sl_gemm_act_norm_pack(nb, _ptr_array(wcs), (C.c_int64 * nb)(*[w.stride(0) for w in wcs]), F, K, pack.data_ptr(), st))
+    rsc = [get_row_amax(x) if get_row_amax(x) is not None else row_amax(x) for x in Xs]
     Zs = [torch.empty(M, F, dtype=torch.float32, device=dev) for _ in range(nb)]
     out = torch.empty(M, F, dtype=torch.float32, device=dev)
     out2 = torch.empty_like(out) if _is_dual(drop) else None
@@ -700,10 +721,10 @@ def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
     # algorithmic bytes: read every X_b, write every Z_b and the output(s); flops of the nb products
     nbytes = 4 * M * (nb * K + nb * F + F * (2 if out2 is not None else 1))
     with _timed(f"gemm_act_norm_fwd_nb{nb}_N{F}" + ("" if K % 32 == 0 else "_Ktail"), nbytes, dev, flops=2 * nb * M * K * F):
-        check(lib.sl_gemm_act_norm_fwd(nb, _ptr_array(Xs), lda, pack.data_ptr(), M, F, K, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
-                                       sc.data_ptr(), of.data_ptr(), float(out_scale), out.data_ptr(), out.stride(0), float(drop[0]),
-                                       int(drop[1]), out2.data_ptr() if out2 is not None else None,
-                                       out2.stride(0) if out2 is not None else 0, st))
+        check(lib.sl_gemm_act_norm_fwd(nb, _ptr_array(Xs), lda, _ptr_array(rsc), pack.data_ptr(), M, F, K, _ptr_array(Zs), ldz,
+                                       _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(), float(out_scale), out.data_ptr(),
+                                       out.stride(0), float(drop[0]), int(drop[1]), out2.data_ptr() if out2 is not None else None,
+                                       out2.stride(0) if out2 is not None else 0, None, st))
     return Zs, (out if out2 is None else (out, out2))
 
 
@@ -717,10 +738,10 @@ def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True)
     N = W.shape[0]
     dev = A.device
     st = _stream(A)
-    tiles = lib.sl_gemm_act_norm_tiles(N)
     pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(N, K), dtype=torch.uint8, device=dev)
     Wc = W.detach().contiguous()
-    check(lib.sl_gemm_pack_b2_tiles(Wc.data_ptr(), Wc.stride(0), 1, K, Wc.data_ptr(), Wc.stride(0), 1, N, K, tiles, pack.data_ptr(), st))
+    check(lib.sl_gemm_act_norm_pack_b2(Wc.data_ptr(), Wc.stride(0), 1, K, Wc.data_ptr(), Wc.stride(0), 1, N, K, pack.data_ptr(), st))
+    rsc = row_amax(A)
     dZs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(nb)]
     dsc = torch.empty(nb, N, dtype=torch.float32, device=dev)
     dof = torch.empty(nb, N, dtype=torch.float32, device=dev)
@@ -731,9 +752,9 @@ def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True)
     ac = (C.c_int * nb)(*codes)
     nbytes = 4 * M * (K + 2 * nb * N)           # read A and every Z_b, write every dZ_b
     with _timed(f"gemm_an_bwd_nb{nb}_N{N}", nbytes, dev, flops=2 * M * K * N):
-        check(lib.sl_gemm_an_bwd(A.data_ptr(), A.stride(0), pack.data_ptr(), M, N, K, nb, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
+        check(lib.sl_gemm_an_bwd(A.data_ptr(), A.stride(0), rsc.data_ptr(), pack.data_ptr(), M, N, K, nb, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
                                  sc.data_ptr(), of.data_ptr(), 1.0, _ptr_array(dZs), lddz, dsc.data_ptr(), dof.data_ptr(),
-                                 dbi.data_ptr() if dbi is not None else None, partial.data_ptr(), float(drop[0]), int(drop[1]), st))
+                                 dbi.data_ptr() if dbi is not None else None, partial.data_ptr(), float(drop[0]), int(drop[1]), None, st))
     return dZs, dsc, dof, dbi
 
 
@@ -750,7 +771,7 @@ class ChainLink:
         self.Zs = self.Zn = self.biases = self.sc = self.of = None
         self.act = 0
         self.drop = (0.0, 0)
-        self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = None
+        self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
 
     def publish(self, Zs, Zn, biases, sc, of, act, drop):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
@@ -759,7 +780,7 @@ class ChainLink:
     def release(self):
         self.published = self.filled = False
         self.Zs = self.Zn = self.biases = self.sc = self.of = None
-        self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = None
+        self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
 
 
 # Test tap: when a list, every fused Linear + act + norm node appends (pre-activations Z_b, biases) of its forward pass
@@ -888,13 +909,16 @@ class _SageDense(torch.autograd.Function):
         Zn = torch.empty(n, Fo, dtype=torch.float32, device=dev)
         out = torch.empty(n, Fo, dtype=torch.float32, device=dev)
         out2 = torch.empty(n, Fo, dtype=torch.float32, device=dev) if _is_dual(drop) else None
-        pack = torch.empty(lib.sl_sage_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        pack = torch.empty(lib.sl_sage_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
+        x_amax = get_row_amax(X)                                   # left by the kernel that produced X (gather / the layer below)
+        out_amax = torch.empty(n, dtype=torch.float32, device=dev)
         a = _adj_struct(adj, False)
         opt = lambda t: t.data_ptr() if t is not None else None
         check(lib.sl_sage_fwd(C.byref(a), X.data_ptr(), X.stride(0), Fi, Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]),
                               Wn.data_ptr(), Wn.stride(0), opt(biases[1]), sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]),
                               int(drop[1]), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), out.data_ptr(), opt(out2),
-                              pack.data_ptr(), _stream(X)))
+                              opt(x_amax), out_amax.data_ptr(), pack.data_ptr(), _stream(X)))
+        set_row_amax(out if out2 is None else out2, out_amax)      # (of the tensor the next layer's GEMM reads)
         return AX, Zs, Zn, (out if out2 is None else (out, out2))
 
     @staticmethod
@@ -937,15 +961,16 @@ class _SageDense(torch.autograd.Function):
             down.dsc, down.dof = torch.empty(2, Fi, **f32), torch.empty(2, Fi, **f32)
             down.dbi = torch.empty(2, Fi, **f32) if any(b is not None for b in down.biases) else None
             down.partial = torch.empty(lib.sl_sage_chain_partial_floats(n, Fi), **f32)
+            down.amax = torch.empty(n, **f32)
             opt = lambda t: t.data_ptr() if t is not None else None
             below = _lib.SlSageBelow(down.Zs.data_ptr(), down.Zn.data_ptr(), opt(down.biases[0]), opt(down.biases[1]),
                                      down.sc.data_ptr(), down.of.data_ptr(), down.act, float(down.drop[0]), int(down.drop[1]), Fi,
                                      down.buf.data_ptr(), down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi),
-                                     down.partial.data_ptr())
+                                     down.partial.data_ptr(), down.amax.data_ptr())
         dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
         dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
         tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)
-        pack = torch.empty(lib.sl_sage_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        pack = torch.empty(lib.sl_sage_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, want_dx)
         opt = lambda t: t.data_ptr() if t is not None else None
         check(lib.sl_sage_bwd_chain(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi,
@@ -953,7 +978,8 @@ class _SageDense(torch.autograd.Function):
                                     sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX),
                                     dWs.data_ptr(), dWn.data_ptr(), opt(dbi), opt(dsc), opt(dof), buf.data_ptr(), opt(an_partial),
                                     tn_partial.data_ptr(), pack.data_ptr(), 1 if dz_ready else 0,
-                                    C.byref(below) if below is not None else None, _stream(Zs)))
+                                    C.byref(below) if below is not None else None,
+                                    up.amax.data_ptr() if (dz_ready and up.amax is not None) else None, _stream(Zs)))
         if dz_ready:
             up.release()
         if chain:
@@ -1062,7 +1088,7 @@ class _GcnDense(torch.autograd.Function):
         AX = torch.empty(n, pitch, **f32)[:, :Fi]
         Z, out = torch.empty(n, Fo, **f32), torch.empty(n, Fo, **f32)
         out2 = torch.empty(n, Fo, **f32) if _is_dual(drop) else None
-        pack = torch.empty(lib.sl_gcn_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        pack = torch.empty(lib.sl_gcn_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(adj, False)
         opt = lambda t: t.data_ptr() if t is not None else None
         check(lib.sl_gcn_fwd(C.byref(a), X.data_ptr(), X.stride(0), Fi, Fo, W.data_ptr(), W.stride(0), opt(bc), sc.data_ptr(),
@@ -1100,7 +1126,7 @@ class _GcnDense(torch.autograd.Function):
         buf = torch.empty(n * (Fo + Fi), **f32)
         an_partial = torch.empty(2048 * 1 * 3 * Fo, **f32)
         tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)
-        pack = torch.empty(lib.sl_gcn_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        pack = torch.empty(lib.sl_gcn_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, bool(ng[0]))
         opt = lambda t: t.data_ptr() if t is not None else None
         check(lib.sl_gcn_bwd(C.byref(a), AX.data_ptr(), AX.stride(0), Z.data_ptr(), Fi, Fo, W.data_ptr(), W.stride(0),

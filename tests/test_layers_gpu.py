@@ -409,6 +409,46 @@ def test_split_bf16_gemm_matches_fp64(M, K, N):
     np.testing.assert_allclose(got[rows].cpu().numpy(), blas.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(den.max()) ** 0 )
 
 
+@pytest.mark.parametrize("M,K,N", [(8192, 256, 256), (10007, 100, 256), (9001, 512, 128), (8300, 36, 32), (300000, 256, 256)])
+def test_split_gemm_matches_fp64(M, K, N):
+    """The fp16 two-piece split of the GEMM-epilogue kernels (sl_gemm_act_norm_fwd: row-scaled operands, three products per
+    element pair) against fp64, relative to sum |a||b| like the kernel's bound: rows over ~60 binades (the row scales),
+    weights over ~12, dropout zeros, one column 10^4 above the rest (elements far below their row's maximum), K tails,
+    ragged row blocks.  The bound is the six-term bf16 kernel's (test_split_bf16_gemm_matches_fp64); a plain fp32 GEMM
+    (rocBLAS) measured on the same operands must not be better by more than rounding noise."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    pitch = (K + 31) // 32 * 32
+    A = torch.randn(M, pitch, device=DEV, generator=g)[:, :K]
+    A.mul_(torch.exp(torch.randn(M, 1, device=DEV, generator=g) * 6))
+    A[torch.rand(M, K, device=DEV, generator=g) < 0.4] = 0
+    A[: M // 2, K // 3] *= 1e4
+    W = torch.randn(N, K, device=DEV, generator=g) * torch.exp(torch.randn(N, 1, device=DEV, generator=g) * 3)
+    sc, of = torch.ones(1, N, device=DEV), torch.zeros(1, N, device=DEV)
+    (Z,), _ = ops.gemm_act_norm_fwd([A], [W], [None], [0], sc, of, 1.0, (0.0, 0))
+    rows = torch.cat([torch.arange(0, min(M, 3000), device=DEV), torch.arange(max(0, M - 700), M, device=DEV)])
+    ref = A[rows].double() @ W.double().t()
+    den = A[rows].abs().double() @ W.abs().double().t() + 1e-300
+    err = ((Z[rows].double() - ref).abs() / den).max().item()
+    blas = (((A[rows] @ W.t()).double() - ref).abs() / den).max().item()
+    assert err < 1.5e-6 * max(1.0, K / 256) ** 0.5, err          # (fp32 accumulation grows with the length of the sum)
+    assert err < 2 * blas + 2e-7, (err, blas)
+    # a single product per output: the two pieces carry 23 of the 24 significand bits of every element within 2^-17 of its
+    # row's maximum (here: all of the unscaled block), the power-of-two scales are lossless, zero rows stay zero
+    E = torch.zeros(N, K, device=DEV); E[torch.arange(min(N, K)), torch.arange(min(N, K))] = 0.25
+    A2 = torch.randn(M, pitch, device=DEV, generator=g)[:, :K] * torch.exp(torch.randn(M, 1, device=DEV, generator=g) * 6)
+    A2[5] = 0                                   # (row maxima within 2^+-48: the scale exponents are clamped to +-62)
+    (Z2,), _ = ops.gemm_act_norm_fwd([A2], [E], [None], [0], sc, of, 1.0, (0.0, 0))
+    want = A2[:, : min(N, K)] * 0.25
+    rowmax = (A2.abs().amax(dim=1, keepdim=True) * 0.25).clamp_min(1e-30)      # (over ALL K columns: what the scale follows)
+    big = want.abs() >= rowmax * 2.0 ** -16                                    # both pieces normal fp16 numbers
+    err = (Z2[:, : min(N, K)] - want).abs()
+    assert float((err / want.abs().clamp_min(1e-30))[big].max()) <= 2.0 ** -22
+    small = (err / rowmax)[~big]
+    assert small.numel() == 0 or float(small.max()) <= 2.0 ** -37          # ... and an absolute floor below that
+    assert float(Z2[5].abs().max()) == 0 and float(Z2[:, min(N, K):].abs().max() if N > K else 0.0) == 0
+
+
 def test_split_bf16_gemm_exact_cases():
     """Identity weight, powers of two and a single hot column are reproduced exactly (the three bf16
     pieces of every operand add back to the fp32 value bit for bit)."""
@@ -1035,9 +1075,9 @@ def test_one_call_gcn_layer_equals_kernel_by_kernel(F_in, F_out, act, p_out, dua
 def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act, p, dual):
     """sl_gemm_act_norm_fwd: the nb <= 2 Linear products of a layer in one launch with bias + act + feature norm + branch
     sum (+ the fused output dropout, single and dual mode) in the epilogue, against the separate kernels
-    (sl_gemm_nt_f32 per branch, then sl_act_norm_fwd).  The pre-activations come from the same main loop: bit-identical.
-    The normalised output is the same arithmetic on the same 64-lane butterfly sums for 128 < N <= 256; below that the
-    stand-alone kernel packs two or more rows per wavefront (other summation tree): equal to rounding.  Ragged M (not a
+    (sl_gemm_nt_f32 per branch, then sl_act_norm_fwd).  The pre-activations come from different splits (two fp16 pieces,
+    three products, against three bf16 pieces, six products): both within 1e-6 of the fp64 product relative to sum |a||b|.
+    The normalised output is the same arithmetic per row: equal to rounding.  Ragged M (not a
     multiple of the 128-row workgroup / 32-row wavefront tile), K with a zero-padded last unit (100 in a 128-float pitch,
     36), N below the tile width (200, 64, 32)."""
     from shadow_gnn_amd import _lib, ops
@@ -1056,8 +1096,9 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
     Zf, outf = ops.gemm_act_norm_fwd(Xs, Ws, bs, codes, sc, of, 0.5 if nb == 1 else 1.0, drop)
     Zr = [ops.mm_nt(x, w) for x, w in zip(Xs, Ws)]
     outr = ops._an_fwd(Zr, bs, codes, sc, of, N, 0.5 if nb == 1 else 1.0, drop)
-    for a, b in zip(Zf, Zr):
-        assert torch.equal(a, b)
+    for a, b, x, w in zip(Zf, Zr, Xs, Ws):
+        ref, den = x.double() @ w.double().t(), x.abs().double() @ w.abs().double().t()
+        assert float(((a.double() - ref).abs() / den).max()) < 1e-6 and float(((b.double() - ref).abs() / den).max()) < 1.5e-6
     outf = outf if isinstance(outf, tuple) else (outf,)
     outr = outr if isinstance(outr, tuple) else (outr,)
     assert len(outf) == len(outr) == (2 if dual else 1)
