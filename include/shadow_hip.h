@@ -366,7 +366,7 @@ int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p, uint64_t drop_seed,
                     float *d_out_dropped, int64_t ldo_dropped, void *stream);
-/* Backward of the above: dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
+/* Backward of the above (d_dz0_amax, may be NULL: receives max_k |dZ_0[i, k]| per row, see sl_row_amax): dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
  * when d_dbias != NULL, dbias [nb, F] = column sums of dZ_b (all overwritten,
  * reduced over the rows in a fixed order).
  * d_partial: float[2048 * nb * 3 * F] scratch for the two-stage reduction.
@@ -377,7 +377,7 @@ int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
                     const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
                     float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped,
-                    int64_t lddo_dropped, void *stream);
+                    int64_t lddo_dropped, float *d_dz0_amax, void *stream);
 
 /* A normalised batch adjacency  diag(row_scale) (A o edge_w) diag(col_scale)  as the layer entries below take it
  * (what ops.NormAdj holds): any of edge_w / row_scale / col_scale may be NULL (= ones); t_* = the transposed CSR
@@ -428,7 +428,8 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
  * maximum, an absolute 2^-39 of that maximum below.  The product keeps hh + hm + mh (the dropped mm <= 2^-22 |ab|,
  * zero-mean): three v_mfma_f32_32x32x16_f16 per tile and k-step, fp32 accumulation -- the measured error against fp64 is
  * that of the six-term bf16 form of sl_gemm_nt_f32 and below a plain fp32 GEMM's (tests: test_split_gemm_matches_fp64).
- * The largest magnitude of every row of A is an input (d_a_amax, [M] floats per operand; the scale follows from it):
+ * The largest magnitude of every row of A is an input (d_a_amax, [M] floats per operand; the scale follows from it; the
+ * array of arrays or single entries may be NULL: the kernel then reads the rows once more itself -- small batches):
  * sl_row_amax computes it in one pass over A; the kernels that produce an operand write it while the row is in their
  * registers (d_out_amax here, d_row_amax of sl_spmm_blockdiag_f32 / sl_gather_rows_drop_f32) and the pass disappears.
  *
@@ -457,10 +458,12 @@ int sl_row_amax(const float *d_A, int64_t lda, uint32_t n, uint32_t K, float *d_
 /* Weight images of the epilogue kernels: fp16 pieces in sl_gemm_act_norm_tiles(N) (4 or 8) column tiles, zero above N,
  * followed by a trailer with the power-of-two scale of every weight row and its inverse.  sl_gemm_act_norm_pack writes
  * the nb images of one forward launch (nb * sl_gemm_act_norm_pack_bytes(N, K) bytes: images back to back, then the
- * trailers); sl_gemm_act_norm_pack_b2 one image from strided / concatenated sources as sl_gemm_pack_b2.             */
+ * trailers) in ONE kernel launch that also clears n_zero floats at d_zero (may be NULL: the row-maximum array an SpMM of
+ * the same pass joins into); sl_gemm_act_norm_pack_b2 one image from strided / concatenated sources as sl_gemm_pack_b2.             */
 uint32_t sl_gemm_act_norm_tiles(uint32_t N);
 size_t sl_gemm_act_norm_pack_bytes(uint32_t N, uint32_t K);
-int sl_gemm_act_norm_pack(int nb, const float *const *d_B, const int64_t *ldb, uint32_t N, uint32_t K, void *d_packed, void *stream);
+int sl_gemm_act_norm_pack(int nb, const float *const *d_B, const int64_t *ldb, uint32_t N, uint32_t K, void *d_packed,
+                          float *d_zero, uint32_t n_zero, void *stream);
 int sl_gemm_act_norm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k,
                              uint32_t N, uint32_t K, void *d_packed, void *stream);
 int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,

@@ -144,7 +144,7 @@ SIGNATURES = {
     "sl_gemm_act_norm_tiles": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_act_norm_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_row_amax": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
-    "sl_gemm_act_norm_pack": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_act_norm_pack": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P]),
     "sl_gemm_act_norm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
@@ -175,7 +175,7 @@ SIGNATURES = {
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sl_act_norm_bwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
-                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P]),
+                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
 }
 
 _lib = None

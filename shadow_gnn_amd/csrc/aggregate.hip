@@ -737,6 +737,8 @@ struct ActNormParams {
   // dout (may be NULL) for the plain output and dout2 through the dropout mask
   float *out2; int64_t ldo2;
   const float *dout2; int64_t lddo2;
+  // backward, optional: max_k |dZ[0][r, k]| per row (the fp16 operand scale of the GEMM that reads dZ[0] next, sl_row_amax)
+  float *dz0_amax;
 };
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
@@ -847,11 +849,17 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
         const float m2 = seg_sum<LS>(dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w) * inv_seg;
         float4 dh = make_float4(rstd * (dxh.x - m1 - xh.x * m2), rstd * (dxh.y - m1 - xh.y * m2),
                                 rstd * (dxh.z - m1 - xh.z * m2), rstd * (dxh.w - m1 - xh.w * m2));
+        float zmax = 0.f;
         if (lane_on && (p.dZ[b] || p.dbias)) {
           dh.x *= act_bwd(p.act[b], z.x, h.x); dh.y *= act_bwd(p.act[b], z.y, h.y);
           dh.z *= act_bwd(p.act[b], z.z, h.z); dh.w *= act_bwd(p.act[b], z.w, h.w);
           if (p.dZ[b]) st4s(p.dZ[b] + (int64_t)r * p.lddz[b] + f, dh);
           gb[b].x += dh.x; gb[b].y += dh.y; gb[b].z += dh.z; gb[b].w += dh.w;
+          zmax = amax4(dh);
+        }
+        if (b == 0 && p.dz0_amax) {        // (the LPR lanes of a row group share r: the reduction is uniform over the group)
+          zmax = group_max<LPR>(zmax);
+          if (l == 0) p.dz0_amax[r] = zmax;
         }
       }
     }
@@ -1282,7 +1290,7 @@ static uint32_t resident_blocks(const void *kernel) {
   return (uint32_t)per_cu * (uint32_t)ncu;
 }
 
-static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
+static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st, bool *vector_kernel = nullptr) {
   const uint32_t F = p.F, seg = p.seg;
   bool vec = (F % 4 == 0) && (seg % 4 == 0) && F <= 256 && (F % seg == 0);
   // lanes per segment must be a power of two; when seg == F and F/4 is not a
@@ -1336,6 +1344,7 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st) {
   }
 #undef SHD_AN
 #undef SHD_AN_LAUNCH
+  if (vector_kernel) *vector_kernel = done;
   if (!done && p.drop_thr)
     return set_error(SG_ERR_INVALID, "sl_act_norm: fused output dropout needs the vector layout (F %% 4 == 0, F <= 256, "
                                      "16-byte aligned operands); apply dropout separately for this shape");
@@ -1410,7 +1419,7 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                                float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
-                               const float *d_dout_dropped, int64_t lddo_dropped, void *stream_) {
+                               const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
   if (!d_scale || !d_offset || (!d_dout && !d_dout_dropped) || !d_dscale || !d_doffset || !d_dZ)
@@ -1440,5 +1449,10 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
       return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: the dropped-output gradient must be 16-byte aligned, ld %% 4 == 0");
     p.dout2 = d_dout_dropped; p.lddo2 = lddo_dropped;
   }
-  return act_norm_launch(p, true, st);
+  if (d_dz0_amax && !d_dZ[0]) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of a gradient that is not written");
+  p.dz0_amax = d_dz0_amax;
+  bool vec = false;
+  if ((rc = act_norm_launch(p, true, st, &vec)) != SG_OK) return rc;
+  // (the general kernel does not write the row maxima: one more pass)
+  return (d_dz0_amax && !vec) ? sl_row_amax(d_dZ[0], lddz[0], n, F, d_dz0_amax, st) : SG_OK;
 }

@@ -42,6 +42,18 @@ struct ProfScope {
   if (shadow::prof_enabled()) snprintf(prof_name_, sizeof(prof_name_), __VA_ARGS__);    \
   SHD_PROF(prof_name_, BYTES, FLOPS, ST)
 
+// fp16 weight images of the GEMM-epilogue kernels (gemm.hip; used by gemm_fused.hip)
+struct PackF16Src {
+  const float *B1, *B2;          // element (j, k) = B1[j s1j + k s1k] for k < K1, B2[j s2j + (k - K1) s2k] behind
+  int64_t s1j, s1k, s2j, s2k;
+  uint32_t K1;
+  void *img;
+  float *trailer;
+};
+size_t pack_f16_image_bytes(uint32_t K, uint32_t tiles);
+size_t pack_f16_trailer_bytes(uint32_t tiles);
+int pack_f16(int nimg, const PackF16Src *src, uint32_t N, uint32_t K, uint32_t tiles, float *zero, uint32_t n_zero, hipStream_t st);
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

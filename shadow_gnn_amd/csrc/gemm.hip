@@ -21,6 +21,8 @@
 //   B is pre-split and pre-permuted once per call into the exact per-lane fragment image
 //   [unit][step][piece][column tile][lane][8 x bf16] (sl_gemm_pack_b) and streamed through LDS one unit
 //   (2 steps x 3 pieces x N/32 tiles x 1 KiB) at a time.
+#include <string.h>
+
 #include <algorithm>
 
 #include "actnorm_common.h"
@@ -72,43 +74,64 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t s1j, int
 // fp16 two-piece images (gemm_common.h): the same fragment order with two pieces per step,
 //   [unit][step][piece h, m][column tile][lane][8 x fp16],
 // followed by a trailer of 2 x 32 tiles floats: the power-of-two scale of every output column's weight row (rows >= N: 1)
-// and its inverse.  gemm_b_scale_kernel (one wavefront per row of B) writes the trailer, the pack kernel reads it.
-__global__ void gemm_b_scale_kernel(const float *__restrict__ B, int64_t s1j, int64_t s1k, uint32_t K1, const float *__restrict__ B2,
-                                    int64_t s2j, int64_t s2k, uint32_t N, uint32_t K, uint32_t tiles, float *__restrict__ trailer) {
-  const uint32_t col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (col >= 32 * tiles) return;
-  float mx = 0.f;
-  if (col < N)
-    for (uint32_t k = lane; k < K; k += 64)
-      mx = fmaxf(mx, fabsf(k < K1 ? B[(int64_t)col * s1j + (int64_t)k * s1k] : B2[(int64_t)col * s2j + (int64_t)(k - K1) * s2k]));
-  mx = wave_max_f(mx);
-  if (lane == 0) {
-    const float sc = row_scale_of(mx);
-    trailer[col] = sc;
-    trailer[32 * tiles + col] = 1.0f / sc;               // (exact: a power of two within 2^+-62)
-  }
-}
+// and its inverse.  ONE launch packs all images of a layer pass (grid = tiles x images): a workgroup first finds the
+// largest magnitude of its 32 weight rows (8 threads per row), then writes the tile's fragments of every k-step.
+// `zero` (optional): n_zero floats cleared on the way (the row-maximum array the SpMM of the same pass joins into --
+// saves the memset launch that the small batches, bound by the host's launch rate, would pay for).
+struct PackSrc {
+  const float *B1, *B2;          // element (j, k) = B1[j s1j + k s1k] for k < K1, B2[j s2j + (k - K1) s2k] behind
+  int64_t s1j, s1k, s2j, s2k;
+  uint32_t K1;
+  half8 *img;
+  float *trailer;
+};
+struct PackJob {
+  PackSrc src[2];
+  uint32_t N, K, units, tiles;
+  float *zero;
+  uint32_t n_zero;
+};
 
-__global__ void gemm_pack_b_f16_kernel(const float *__restrict__ B, int64_t s1j, int64_t s1k, uint32_t K1,
-                                       const float *__restrict__ B2, int64_t s2j, int64_t s2k, uint32_t N, uint32_t K,
-                                       uint32_t units, uint32_t tiles, const float *__restrict__ trailer, half8 *__restrict__ out) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t total = units * 2 * tiles * 64;
-  if (idx >= total) return;
-  const uint32_t l = idx & 63, t = (idx >> 6) % tiles, h = ((idx >> 6) / tiles) & 1, u = (idx >> 6) / tiles / 2;
-  const uint32_t col = 32 * t + (l & 31);
-  const uint32_t k0 = 32 * u + 16 * (l >> 5) + 8 * h;
-  float x[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const uint32_t k = k0 + j;
-    x[j] = (col < N && k < K) ? (k < K1 ? B[(int64_t)col * s1j + (int64_t)k * s1k] : B2[(int64_t)col * s2j + (int64_t)(k - K1) * s2k]) : 0.f;
+__global__ void __launch_bounds__(256) gemm_pack_f16_kernel(const PackJob job) {
+  __shared__ float smax[8][32];
+  __shared__ float sscale[32];
+  const PackSrc &sr = job.src[blockIdx.y];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x, N = job.N, K = job.K, tiles = job.tiles;
+  if (job.zero)
+    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < job.n_zero; i += gridDim.x * gridDim.y * 256) job.zero[i] = 0.f;
+  auto elem = [&](uint32_t col, uint32_t k) -> float {
+    return k < sr.K1 ? sr.B1[(int64_t)col * sr.s1j + (int64_t)k * sr.s1k] : sr.B2[(int64_t)col * sr.s2j + (int64_t)(k - sr.K1) * sr.s2k];
+  };
+  {
+    const uint32_t c = tid & 31u, kk = tid >> 5, col = 32 * t + c;
+    float mx = 0.f;
+    if (col < N)
+      for (uint32_t k = kk; k < K; k += 8) mx = fmaxf(mx, fabsf(elem(col, k)));
+    smax[kk][c] = mx;
   }
-  half8 hh, mm;
-  split8_f16(x, trailer[col], hh, mm);
-  const size_t base = ((size_t)(u * 2 + h) * 2) * tiles;
-  out[(base + 0 * tiles + t) * 64 + l] = hh;
-  out[(base + 1 * tiles + t) * 64 + l] = mm;
+  __syncthreads();
+  if (tid < 32) {
+    float mx = smax[0][tid];
+#pragma unroll
+    for (int q = 1; q < 8; q++) mx = fmaxf(mx, smax[q][tid]);
+    const float sc = row_scale_of(mx);
+    sscale[tid] = sc;
+    sr.trailer[32 * t + tid] = sc;
+    sr.trailer[32 * tiles + 32 * t + tid] = 1.0f / sc;    // (exact: a power of two within 2^+-62)
+  }
+  __syncthreads();
+  for (uint32_t idx = tid; idx < job.units * 2 * 64; idx += 256) {
+    const uint32_t l = idx & 63u, h = (idx >> 6) & 1u, u = idx >> 7;
+    const uint32_t col = 32 * t + (l & 31u), k0 = 32 * u + 16 * (l >> 5) + 8 * h;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = (col < N && k0 + j < K) ? elem(col, k0 + j) : 0.f;
+    half8 hh, mm;
+    split8_f16(x, sscale[l & 31u], hh, mm);
+    const size_t base = ((size_t)(u * 2 + h) * 2) * tiles;
+    sr.img[(base + 0 * tiles + t) * 64 + l] = hh;
+    sr.img[(base + 1 * tiles + t) * 64 + l] = mm;
+  }
 }
 
 // Largest magnitude of every row of a row-major operand A [n, K] (lda % 4 == 0, 16-byte aligned): LPR lanes per row.
@@ -396,18 +419,23 @@ extern "C" int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint
 namespace shadow {
 size_t pack_f16_image_bytes(uint32_t K, uint32_t tiles) { return (size_t)((K + 31) / 32) * 4 * tiles * 64 * 16; }
 size_t pack_f16_trailer_bytes(uint32_t tiles) { return (size_t)2 * 32 * tiles * 4; }
-// image of B (strided / concatenated sources as sl_gemm_pack_b2) in `tiles` column tiles at d_img, its trailer at d_trailer
-int pack_f16(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k, uint32_t N,
-             uint32_t K, uint32_t tiles, void *d_img, float *d_trailer, hipStream_t st) {
-  if (!d_B1 || !d_img || !d_trailer || (K1 < K && !d_B2)) return set_error(SG_ERR_INVALID, "fp16 weight pack: null argument");
+// nimg <= 2 images of one launch: image b of B_b (strided / concatenated sources as sl_gemm_pack_b2) in `tiles` column tiles at
+// d_img[b], its trailer at d_trailer[b]; zero / n_zero: floats cleared by the same launch (may be NULL)
+int pack_f16(int nimg, const PackF16Src *src, uint32_t N, uint32_t K, uint32_t tiles, float *zero, uint32_t n_zero, hipStream_t st) {
+  if (nimg < 1 || nimg > 2 || !src) return set_error(SG_ERR_INVALID, "fp16 weight pack: bad argument");
   if (N == 0 || K == 0) return SG_OK;
   if (N > 256 || tiles > 8 || 32 * tiles < N) return set_error(SG_ERR_INVALID, "fp16 weight pack: N = %u in %u column tiles", N, tiles);
-  const uint32_t units = (K + 31) / 32;
-  const uint32_t total = units * 2 * tiles * 64;
-  hipLaunchKernelGGL(gemm_b_scale_kernel, dim3((32 * tiles + 3) / 4), dim3(256), 0, st, d_B1, s1j, s1k, std::min(K1, K),
-                     d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, tiles, d_trailer);
-  hipLaunchKernelGGL(gemm_pack_b_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_B1, s1j, s1k, std::min(K1, K),
-                     d_B2 ? d_B2 : d_B1, s2j, s2k, N, K, units, tiles, d_trailer, reinterpret_cast<half8 *>(d_img));
+  PackJob job;
+  memset(&job, 0, sizeof(job));
+  for (int b = 0; b < nimg; b++) {
+    if (!src[b].B1 || !src[b].img || !src[b].trailer || (src[b].K1 < K && !src[b].B2))
+      return set_error(SG_ERR_INVALID, "fp16 weight pack: null argument");
+    PackSrc &d = job.src[b];
+    d.B1 = src[b].B1; d.B2 = src[b].B2 ? src[b].B2 : src[b].B1; d.s1j = src[b].s1j; d.s1k = src[b].s1k; d.s2j = src[b].s2j; d.s2k = src[b].s2k;
+    d.K1 = std::min(src[b].K1, K); d.img = reinterpret_cast<half8 *>(src[b].img); d.trailer = src[b].trailer;
+  }
+  job.N = N; job.K = K; job.units = (K + 31) / 32; job.tiles = tiles; job.zero = zero; job.n_zero = zero ? n_zero : 0;
+  hipLaunchKernelGGL(gemm_pack_f16_kernel, dim3(tiles, nimg), dim3(256), 0, st, job);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -61,9 +61,6 @@ struct FusedDesc {
   float *dZ[2];       int64_t lddz[2];
   float *partial;                   // [grid, nb, 3, N]
   float *dz_amax;                   // optional: row maxima of dZ[0] (the left half of the next K = 2F operand)
-  // Start stagger (see gemm_nt_fused_kernel): shader cycles the workgroups of the first dispatch round that sit in an odd
-  // workgroup slot of their CU wait before they start; first_round = workgroups resident at once (2 per CU)
-  uint32_t stagger_cycles, first_round, stagger_mode;
 };
 
 // The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass; 64 lanes in the backward form): the row
@@ -423,20 +420,28 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   const float *arow0 = d.A[0] + arow_i * d.lda[0] + 16 * g;
   const float *arow1 = NBP == 2 ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
   const uint32_t gunits = NBP * units, steps = 2 * gunits;
-  float asc = row_scale_of(d.aamax[0][arow_i]);           // scale of this lane's row in the current phase
-
-  // Every workgroup does the same amount of work, so the two workgroups sharing a CU would run in lock step: both in the
-  // main loop (matrix cores contended), then both in the epilogue (matrix cores idle) -- measured: the epilogue's time
-  // simply added to the GEMM's.  The workgroups of the FIRST dispatch round that landed in an odd workgroup slot of their CU
-  // (HW_ID.TG_ID) start late by about half a workgroup's lifetime; later rounds inherit the offset because a new
-  // workgroup starts when an old one ends.  Purely a scheduling hint: a wrong guess about the slot costs time, not results.
-  if (d.stagger_cycles && blockIdx.x < d.first_round) {
-    const uint32_t tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);      // HW_REG_HW_ID bits [19:16]: TG_ID
-    if (d.stagger_mode == 1 ? blockIdx.x >= d.first_round / 2 : (tg & 1u)) {
-      const uint64_t t0 = __builtin_amdgcn_s_memtime();
-      while (__builtin_amdgcn_s_memtime() - t0 < d.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+  // Scale of this lane's row in a phase: from the row maxima the operand's producer left behind, or -- no array given: the
+  // small batches, whose operands sit in the L2 and whose steps are bound by the host's launch rate -- from one more read
+  // of the row (the two lanes that share a row hold its two 16-column halves of every unit).
+  auto phase_scale = [&](int ph) -> float {
+    if (d.aamax[ph]) return row_scale_of(d.aamax[ph][arow_i]);
+    const float *base = ph ? arow1 : arow0;
+    float mx = 0.f;
+    for (uint32_t u = 0; u < units; u++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!kTail || 32 * u + 32 <= K) {
+          mx = fmaxf(mx, amax4(*reinterpret_cast<const float4 *>(base + 32 * u + 4 * q)));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; c++) { const uint32_t k = 32 * u + 16 * g + 4 * q + c; if (k < K) mx = fmaxf(mx, fabsf(base[32 * u + 4 * q + c])); }
+        }
+      }
     }
-  }
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    return row_scale_of(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+  };
+  float asc = phase_scale(0);
 
   f32x16 acc[TW];
 #pragma unroll
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       uint32_t rows_ok = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0))), cols_ok = d.N;
       asm volatile("" : "+s"(rows_ok), "+s"(cols_ok));
       unscale_tile<TW>(acc, 1.0f / asc, d.btrail[0] + 32 * TW, g, r);
-      asc = row_scale_of(d.aamax[1][arow_i]);
+      asc = phase_scale(1);
       constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (= one ring slot)
       float *zst = reinterpret_cast<float *>(lbuf + (size_t)((2 * gu + 1) % 3u) * kStepVecs) + (size_t)wv * (8 * 32 * CT);
       const bool zvec = (d.ldz[0] & 3) == 0;
@@ -620,29 +625,11 @@ inline void set_images(FusedDesc &p, const void *packed, int nimg, uint32_t N, u
   for (int b = 0; b < nimg; b++) p.btrail[b] = reinterpret_cast<const float *>(base + nimg * ib + b * tb);
 }
 
-// SHADOW_FUSED_STAGGER=<shader cycles per k-step of one phase> (default 0 = derived below; -1 = off)
-int g_stagger_override = [] {
-  const char *e = getenv("SHADOW_FUSED_STAGGER");
-  return e ? atoi(e) : 0;
-}();
-
 template <int TW, int MODE, int NBP, int NBA>
 int launch_fused(FusedDesc d, hipStream_t st) {
   // ring of three k-step images (3 x 2 TW KB) or the epilogue's stash (4 wavefronts x 16 rows x 32 TW floats), whichever is larger
   const size_t lds = std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
   const uint32_t grid = (d.M + 127) / 128;
-  {
-    int ncu = 256, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    d.first_round = 2u * (uint32_t)ncu;
-    static const int mode = [] { const char *e = getenv("SHADOW_FUSED_STAGGER_MODE"); return e ? atoi(e) : 0; }();
-    d.stagger_mode = (uint32_t)mode;
-    // half a workgroup's lifetime: ~5500 shader cycles per k-unit (two k-steps of 48 MFMAs, two wavefronts per SIMD,
-    // measured 110 us per 16-unit workgroup) -- only worth it when there is more than one dispatch round
-    const uint32_t per_unit = g_stagger_override > 0 ? (uint32_t)g_stagger_override : 5500u * TW / 8u;
-    d.stagger_cycles = (g_stagger_override < 0 || grid <= d.first_round) ? 0u : per_unit * (uint32_t)NBP * d.units / 2u;
-  }
   if (d.K % 32 == 0) {
     if (lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>, lds));
     hipLaunchKernelGGL((gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>), dim3(grid), dim3(256), lds, st, d);
@@ -660,12 +647,6 @@ bool g_fused_epilogue = [] {
 }();
 
 }  // namespace
-
-// fp16 weight images (gemm.hip)
-size_t pack_f16_image_bytes(uint32_t K, uint32_t tiles);
-size_t pack_f16_trailer_bytes(uint32_t tiles);
-int pack_f16(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, const float *d_B2, int64_t s2j, int64_t s2k, uint32_t N,
-             uint32_t K, uint32_t tiles, void *d_img, float *d_trailer, hipStream_t st);
 
 // the reduction of the per-workgroup partial sums (aggregate.hip)
 int act_norm_finish_launch(const float *partial, uint32_t nblocks, int nb, uint32_t F, float *dscale, float *doffset, float *dbias,
@@ -691,18 +672,17 @@ extern "C" size_t sl_gemm_act_norm_pack_bytes(uint32_t N, uint32_t K) {
 }
 
 // The nb <= 2 weights W_b [N, K] of one launch: images back to back, then the trailers (nb x sl_gemm_act_norm_pack_bytes).
+// d_zero / n_zero (may be NULL / 0): floats cleared by the same launch.
 extern "C" int sl_gemm_act_norm_pack(int nb, const float *const *d_B, const int64_t *ldb, uint32_t N, uint32_t K, void *d_packed,
-                                     void *stream) {
+                                     float *d_zero, uint32_t n_zero, void *stream) {
   if (nb < 1 || nb > 2 || !d_B || !ldb || !d_packed) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_pack: bad argument");
   const uint32_t tiles = sl_gemm_act_norm_tiles(N);
   const size_t ib = pack_f16_image_bytes(K, tiles), tb = pack_f16_trailer_bytes(tiles);
   char *base = reinterpret_cast<char *>(d_packed);
-  for (int b = 0; b < nb; b++) {
-    const int rc = pack_f16(d_B[b], ldb[b], 1, K, d_B[b], ldb[b], 1, N, K, tiles, base + b * ib,
-                            reinterpret_cast<float *>(base + nb * ib + b * tb), (hipStream_t)stream);
-    if (rc != SG_OK) return rc;
-  }
-  return SG_OK;
+  PackF16Src src[2];
+  for (int b = 0; b < nb; b++)
+    src[b] = PackF16Src{d_B[b], d_B[b], ldb[b], 1, ldb[b], 1, K, base + b * ib, reinterpret_cast<float *>(base + nb * ib + b * tb)};
+  return pack_f16(nb, src, N, K, tiles, d_zero, n_zero, (hipStream_t)stream);
 }
 
 // The general form for one image: B element (j, k) = B1[j s1j + k s1k] for k < K1, B2[j s2j + (k - K1) s2k] behind
@@ -712,8 +692,8 @@ extern "C" int sl_gemm_act_norm_pack_b2(const float *d_B1, int64_t s1j, int64_t 
   if (!d_packed) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_pack_b2: null argument");
   const uint32_t tiles = sl_gemm_act_norm_tiles(N);
   char *base = reinterpret_cast<char *>(d_packed);
-  return pack_f16(d_B1, s1j, s1k, K1, d_B2, s2j, s2k, N, K, tiles, base,
-                  reinterpret_cast<float *>(base + pack_f16_image_bytes(K, tiles)), (hipStream_t)stream);
+  const PackF16Src src{d_B1, d_B2, s1j, s1k, s2j, s2k, K1, base, reinterpret_cast<float *>(base + pack_f16_image_bytes(K, tiles))};
+  return pack_f16(1, &src, N, K, tiles, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int sl_gemm_act_norm_supported(uint32_t N, uint32_t K) {
@@ -727,7 +707,7 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
                                     int64_t ldo, float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped,
                                     float *d_out_amax, void *stream) {
   if (nb < 1 || nb > 2) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: nb must be 1 or 2");
-  if (!d_A || !lda || !d_a_amax || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_out)
+  if (!d_A || !lda || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_out)
     return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null argument");
   if (M == 0) return SG_OK;
   if (N < 16 || N > 256 || (N & 3) || K == 0)
@@ -735,12 +715,12 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
   FusedDesc p;
   memset(&p, 0, sizeof(p));
   for (int b = 0; b < nb; b++) {
-    if (!d_A[b] || !d_Z[b] || !d_a_amax[b]) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null operand of branch %d", b);
+    if (!d_A[b] || !d_Z[b]) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null operand of branch %d", b);
     if ((lda[b] & 3) || !al16(d_A[b]) || (ldz[b] & 3) || !al16(d_Z[b]))
       return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: operands must be 16-byte aligned with ld %% 4 == 0");
     if (act[b] < 0 || act[b] > 4) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: unknown activation %d", act[b]);
     if (d_bias && d_bias[b] && !al16(d_bias[b])) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: bias must be 16-byte aligned");
-    p.A[b] = d_A[b]; p.lda[b] = lda[b]; p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.aamax[b] = d_a_amax[b];
+    p.A[b] = d_A[b]; p.lda[b] = lda[b]; p.Z[b] = d_Z[b]; p.ldz[b] = ldz[b]; p.act[b] = act[b]; p.aamax[b] = d_a_amax ? d_a_amax[b] : nullptr;
     p.bias[b] = d_bias ? d_bias[b] : nullptr;
   }
   set_images(p, d_packed_B, nb, N, K);
@@ -773,8 +753,7 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_am
                               const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
                               float drop_p, uint64_t drop_seed, float *d_dz0_amax, void *stream) {
   if (nb != 2) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: nb must be 2 (a GraphSAGE layer below)");
-  if (!d_A || !d_a_amax || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_dZ || !lddz || !d_dscale || !d_doffset ||
-      !d_partial)
+  if (!d_A || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_dZ || !lddz || !d_dscale || !d_doffset || !d_partial)
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {

@@ -22,10 +22,15 @@ bool spmm_joins(const sl_norm_adj *a, uint32_t F, const float *X, int64_t ldx, c
          !(reinterpret_cast<uintptr_t>(Y) & 15);
 }
 
-// amax (may be NULL): joined with the row maxima of Y (zeroed here unless `amax_prefilled`); kernels without the atomic
-// form get a separate pass
+// Row maxima of an operand (the fp16 scales of the GEMM-epilogue kernels) are handed from kernel to kernel for batches of
+// at least this many rows; below, the GEMM reads its rows once more itself (they sit in the L2, and the steps of such
+// batches are bound by the host's launch rate: every pass or memset saved counts more than the re-read).
+constexpr uint32_t kAmaxHandoverRows = 32768;
+
+// amax (may be NULL): joined with the row maxima of Y.  amax_state 0: zeroed here first; 1: the caller has zeroed it; 2: it
+// holds the maxima of other columns of the same operand.  Kernels without the atomic form get a separate pass (not for 2).
 int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx, float *Y, int64_t ldy, uint32_t F, void *st,
-             float *amax = nullptr, bool amax_prefilled = false) {
+             float *amax = nullptr, int amax_state = 0) {
   const uint32_t *ip = transposed ? a->t_indptr : a->indptr, *ix = transposed ? a->t_indices : a->indices;
   const uint32_t *perm = (transposed && a->edge_w) ? a->t_perm : nullptr;
   // (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
@@ -34,7 +39,7 @@ int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx,
   SHD_PROF_FMT(4.0 * (a->n + 1) + 4.0 * a->e + (a->edge_w ? 4.0 * a->e : 0.0) + 8.0 * a->n * F, 0, st, "spmm_F%u", F);
   if (a->subg_node_off && F >= 96) {
     float *am = spmm_joins(a, F, X, ldx, Y, ldy) ? amax : nullptr;
-    if (am && !amax_prefilled) SHD_HIP(hipMemsetAsync(am, 0, (size_t)a->n * 4, (hipStream_t)st));
+    if (am && amax_state == 0) SHD_HIP(hipMemsetAsync(am, 0, (size_t)a->n * 4, (hipStream_t)st));
     const int rc = sl_spmm_blockdiag_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
                                          a->num_subg, a->max_subg_nodes, am, st);
     if (rc != SG_OK || !amax || am) return rc;
@@ -42,7 +47,7 @@ int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx,
     const int rc = sl_spmm_csr_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, st);
     if (rc != SG_OK || !amax) return rc;
   }
-  if (amax_prefilled) return set_error(SG_ERR_INVALID, "spmm: joined row maxima need the block-diagonal vector kernel");
+  if (amax_state == 2) return set_error(SG_ERR_INVALID, "spmm: joined row maxima need the block-diagonal vector kernel");
   return sl_row_amax(Y, ldy, a->n, F, amax, st);
 }
 
@@ -91,27 +96,30 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
   int rc;
   char *pk = (char *)d_pack;
   const bool fused = fused_epilogue_ok(Fout, Fin, d_X, ldx, d_AX, ldax);
-  // row maxima of the two A operands (fp16 split, gemm_common.h): the SpMM writes those of A X
-  float *amx = reinterpret_cast<float *>(pk + images_bytes_sage(Fin, Fout));
-  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream, fused ? amx + n : nullptr)) != SG_OK) return rc;
   const int64_t ldz[2] = {Fout, Fout};
   const float *bias[2] = {d_bs, d_bn};
   const int acts[2] = {act, act};
   if (fused) {
-    // both products in one launch, bias / act / norm / branch sum (/ dropout) in its epilogue (gemm_fused.hip)
+    // both products in one launch, bias / act / norm / branch sum (/ dropout) in its epilogue (gemm_fused.hip).
+    // Row maxima of the two A operands (fp16 split, gemm_common.h): X's come with it when its producer wrote them, the SpMM
+    // joins those of A X into an array the weight pack has cleared on its way.
+    float *amx = reinterpret_cast<float *>(pk + images_bytes_sage(Fin, Fout));
+    const bool hand = n >= kAmaxHandoverRows;
+    const bool joins = hand && spmm_joins(adj, Fin, d_X, ldx, d_AX, ldax);
     const float *W[2] = {d_Ws, d_Wn};
     const int64_t ldw[2] = {ldws, ldwn};
-    if ((rc = sl_gemm_act_norm_pack(2, W, ldw, Fout, Fin, pk, stream)) != SG_OK) return rc;
-    // X's row maxima come with it when its producer wrote them
-    if (!d_x_amax && (rc = sl_row_amax(d_X, ldx, n, Fin, amx, stream)) != SG_OK) return rc;
+    if ((rc = sl_gemm_act_norm_pack(2, W, ldw, Fout, Fin, pk, joins ? amx + n : nullptr, joins ? n : 0, stream)) != SG_OK) return rc;
+    if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream, hand ? amx + n : nullptr, joins ? 1 : 0)) != SG_OK) return rc;
+    if (hand && !d_x_amax && (rc = sl_row_amax(d_X, ldx, n, Fin, amx, stream)) != SG_OK) return rc;
     const float *A[2] = {d_X, d_AX};
-    const float *asc[2] = {d_x_amax ? d_x_amax : amx, amx + n};
+    const float *asc[2] = {d_x_amax ? d_x_amax : (hand ? amx : nullptr), hand ? amx + n : nullptr};
     const int64_t lda[2] = {ldx, ldax};
     float *Zw[2] = {d_Zs, d_Zn};
     SHD_PROF_FMT(4.0 * n * (2 * Fin + 2 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 2 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 2, Fout, Fin % 32 ? "_Ktail" : "");
     return sl_gemm_act_norm_fwd(2, A, lda, asc, pk, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
                                 drop_seed, d_out_dropped, Fout, d_out_amax, stream);
   }
+  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
   const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
   if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
   if ((rc = sl_gemm_pack_b(d_Wn, ldwn, Fout, Fin, pk + pb, stream)) != SG_OK) return rc;
@@ -153,6 +161,10 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
   // A^T dZn into the middle third): [dZs | A^T dZn | dZn]
   float *dZs = d_buf, *dZn = d_buf + 2 * (size_t)Fout;
   const int64_t ld3 = 3 * (int64_t)Fout;
+  // (the row maxima of the K = 2 Fout operand of the epilogue form, see below: the act_norm backward writes those of dZs)
+  float *amx = reinterpret_cast<float *>(reinterpret_cast<char *>(d_pack) + images_bytes_sage(Fin, Fout));
+  const bool hand = n >= kAmaxHandoverRows;
+  const bool join = below && hand && adj->t_indptr && spmm_joins(adj, Fout, dZn, ld3, d_buf + Fout, ld3);
   if (!dz_ready) {
     const float *Z[2] = {d_Zs, d_Zn};
     const int64_t ldz[2] = {Fout, Fout};
@@ -162,21 +174,20 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
     const int64_t lddz[2] = {ld3, ld3};
     SHD_PROF_FMT((2 * 2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 2, Fout);
     if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
-                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
+                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, join ? amx : nullptr,
+                              stream)) != SG_OK)
       return rc;
   }
   if (d_dX || below) {
     if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
     // The K = 2 Fout operand [dZs | A^T dZn] of the epilogue form needs its row maxima: those of dZs come from the kernel
-    // that wrote it (the layer above, dz_ready) or from one pass here; the transposed SpMM joins those of its half.
-    float *amx = reinterpret_cast<float *>(reinterpret_cast<char *>(d_pack) + images_bytes_sage(Fin, Fout));
-    const bool join = below && spmm_joins(adj, Fout, dZn, ld3, d_buf + Fout, ld3);
-    if (join) {
-      if (dz_ready && d_dzs_amax) amx = d_dzs_amax;
+    // that wrote it (the layer above when dz_ready, the act_norm backward otherwise); the transposed SpMM joins those of its half.
+    if (join && dz_ready) {
+      if (d_dzs_amax) amx = d_dzs_amax;
       else if ((rc = sl_row_amax(dZs, ld3, n, Fout, amx, stream)) != SG_OK) return rc;
     }
-    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream, join ? amx : nullptr, true)) != SG_OK) return rc;
-    if (below && !join && (rc = sl_row_amax(d_buf, ld3, n, 2 * Fout, amx, stream)) != SG_OK) return rc;
+    if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream, join ? amx : nullptr, 2)) != SG_OK) return rc;
+    if (below && hand && !join && (rc = sl_row_amax(d_buf, ld3, n, 2 * Fout, amx, stream)) != SG_OK) return rc;
     // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
     if (below) rc = sl_gemm_act_norm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
     else rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
@@ -191,9 +202,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       const int64_t lddzb[2] = {3 * (int64_t)Fb, 3 * (int64_t)Fb};
       // read [dZs | A^T dZn] and both Z of the layer below, write its two dZ
       SHD_PROF_FMT(4.0 * n * (2.0 * Fout + 4.0 * Fb), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_an_bwd_nb2_N%u", Fin);
-      if ((rc = sl_gemm_an_bwd(d_buf, ld3, amx, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
+      if ((rc = sl_gemm_an_bwd(d_buf, ld3, hand ? amx : nullptr, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
                                lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
-                               below->amax, stream)) != SG_OK)
+                               hand ? below->amax : nullptr, stream)) != SG_OK)
         return rc;
     } else if ((rc = nt_gemm(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
       return rc;
@@ -238,16 +249,20 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
   int rc;
   const bool fused = fused_epilogue_ok(Fout, Fin, d_AX, ldax, nullptr, 0);
   float *amx = reinterpret_cast<float *>(reinterpret_cast<char *>(d_pack) + images_bytes_gcn(Fin, Fout));
-  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream, fused ? amx : nullptr)) != SG_OK) return rc;
+  const bool hand = fused && n >= kAmaxHandoverRows;
+  const bool joins = hand && spmm_joins(adj, Fin, d_X, ldx, d_AX, ldax);
+  if (fused) {
+    const float *W[1] = {d_W};
+    const int64_t ldws[1] = {ldw};
+    if ((rc = sl_gemm_act_norm_pack(1, W, ldws, Fout, Fin, d_pack, joins ? amx : nullptr, joins ? n : 0, stream)) != SG_OK) return rc;
+  }
+  if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream, hand ? amx : nullptr, joins ? 1 : 0)) != SG_OK) return rc;
   const int64_t ldz[1] = {Fout};
   const float *bias[1] = {d_b};
   const int acts[1] = {act};
   if (fused) {
-    const float *W[1] = {d_W};
-    const int64_t ldws[1] = {ldw};
-    if ((rc = sl_gemm_act_norm_pack(1, W, ldws, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
     const float *A[1] = {d_AX};
-    const float *asc[1] = {amx};
+    const float *asc[1] = {hand ? amx : nullptr};
     const int64_t lda[1] = {ldax};
     float *Zw[1] = {d_Z};
     SHD_PROF_FMT(4.0 * n * (1 * Fin + 1 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 1 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 1, Fout, Fin % 32 ? "_Ktail" : "");
@@ -285,7 +300,7 @@ extern "C" int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t lda
   {
     SHD_PROF_FMT((2 * 1 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 1, Fout);
     if ((rc = sl_act_norm_bwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZs, lddz, d_dscale,
-                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, stream)) != SG_OK)
+                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, nullptr, stream)) != SG_OK)
       return rc;
   }
   if (d_dX) {

@@ -546,7 +546,7 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
                                           dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
                                           partial.data_ptr(), float(drop[0]), int(drop[1]),
                                           dout2.data_ptr() if dout2 is not None else None,
-                                          dout2.stride(0) if dout2 is not None else 0, _stream(Zs[0])))
+                                          dout2.stride(0) if dout2 is not None else 0, None, _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 
@@ -675,6 +675,9 @@ def gemm_act_norm_usable(Xs, Ws, seg, F) -> bool:
     return True
 
 
+AMAX_HANDOVER_ROWS = 32768      # (kAmaxHandoverRows of csrc/layer_fused.hip)
+
+
 def row_amax(A: torch.Tensor) -> torch.Tensor:
     """max_k |A[i, k]| per row: what the GEMM-epilogue kernels derive the fp16 operand scales from (sl_row_amax,
     include/shadow_hip.h).  Kernels that produce an operand leave it on the tensor (``set_row_amax``) instead."""
@@ -710,8 +713,9 @@ def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
     st = _stream(Xs[0])
     pack = torch.empty(nb * lib.sl_gemm_act_norm_pack_bytes(F, K), dtype=torch.uint8, device=dev)
     wcs = [w.detach() if w.stride(1) == 1 else w.detach().contiguous() for w in Ws]
-    check(lib.sl_gemm_act_norm_pack(nb, _ptr_array(wcs), (C.c_int64 * nb)(*[w.stride(0) for w in wcs]), F, K, pack.data_ptr(), st))
-    rsc = [get_row_amax(x) if get_row_amax(x) is not None else row_amax(x) for x in Xs]
+    check(lib.sl_gemm_act_norm_pack(nb, _ptr_array(wcs), (C.c_int64 * nb)(*[w.stride(0) for w in wcs]), F, K, pack.data_ptr(), None, 0, st))
+    # (row maxima: left by the producer, one pass for a tall operand, or none -- the kernel then reads its rows twice)
+    rsc = [get_row_amax(x) if get_row_amax(x) is not None else (row_amax(x) if M >= AMAX_HANDOVER_ROWS else None) for x in Xs]
     Zs = [torch.empty(M, F, dtype=torch.float32, device=dev) for _ in range(nb)]
     out = torch.empty(M, F, dtype=torch.float32, device=dev)
     out2 = torch.empty_like(out) if _is_dual(drop) else None
@@ -741,7 +745,7 @@ def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True)
     pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(N, K), dtype=torch.uint8, device=dev)
     Wc = W.detach().contiguous()
     check(lib.sl_gemm_act_norm_pack_b2(Wc.data_ptr(), Wc.stride(0), 1, K, Wc.data_ptr(), Wc.stride(0), 1, N, K, pack.data_ptr(), st))
-    rsc = row_amax(A)
+    rsc = row_amax(A) if M >= AMAX_HANDOVER_ROWS else None
     dZs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(nb)]
     dsc = torch.empty(nb, N, dtype=torch.float32, device=dev)
     dof = torch.empty(nb, N, dtype=torch.float32, device=dev)
@@ -752,7 +756,7 @@ def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True)
     ac = (C.c_int * nb)(*codes)
     nbytes = 4 * M * (K + 2 * nb * N)           # read A and every Z_b, write every dZ_b
     with _timed(f"gemm_an_bwd_nb{nb}_N{N}", nbytes, dev, flops=2 * M * K * N):
-        check(lib.sl_gemm_an_bwd(A.data_ptr(), A.stride(0), rsc.data_ptr(), pack.data_ptr(), M, N, K, nb, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
+        check(lib.sl_gemm_an_bwd(A.data_ptr(), A.stride(0), rsc.data_ptr() if rsc is not None else None, pack.data_ptr(), M, N, K, nb, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
                                  sc.data_ptr(), of.data_ptr(), 1.0, _ptr_array(dZs), lddz, dsc.data_ptr(), dof.data_ptr(),
                                  dbi.data_ptr() if dbi is not None else None, partial.data_ptr(), float(drop[0]), int(drop[1]), None, st))
     return dZs, dsc, dof, dbi
