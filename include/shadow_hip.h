@@ -471,6 +471,11 @@ int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, co
                          const int *act, const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo,
                          float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax,
                          void *stream);
+/* Plain products on the same kernel (no epilogue arithmetic): C_b = A_b . W_b^T for b < nb <= 2 in ONE launch (images:
+ * sl_gemm_act_norm_pack / _pack_b2; the two products may share A -- GAT's self and neighbour Linear of the same input);
+ * d_a_amax as above.  N % 4 == 0, 16 <= N <= 256; operands 16-byte aligned, ld % 4 == 0.                            */
+int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,
+                    uint32_t M, uint32_t N, uint32_t K, float *const *d_C, const int64_t *ldc, void *stream);
 size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb);
 int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
                    int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,

@@ -149,6 +149,8 @@ SIGNATURES = {
     "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
                                         C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
+    "sl_gemm_nt2_f32": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "sl_gemm_an_bwd_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
     "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,

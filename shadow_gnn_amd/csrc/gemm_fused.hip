@@ -475,6 +475,40 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     }
   };
 
+  // A 32 x 32 TW accumulator tile (C/D layout: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)) to global memory
+  // through one ring slot: 8 rows x half the columns per wavefront at a time, leaving as float4s -- 512 contiguous bytes per
+  // row and instruction (straight from the C/D layout it was 16 TW dword stores per lane: 8 % of the workgroup's lifetime).
+  auto store_tile = [&](float *dst0, int64_t ld, uint32_t slot, uint32_t rows_ok, uint32_t cols_ok) {
+    constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (= one ring slot)
+    float *zst = reinterpret_cast<float *>(lbuf + (size_t)slot * kStepVecs) + (size_t)wv * (8 * 32 * CT);
+    const bool zvec = (ld & 3) == 0;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int t = 0; t < CT; t++)
+#pragma unroll
+          for (int ii = 0; ii < 4; ii++) zst[(4 * g + ii) * (32 * CT) + 32 * t + r] = acc[CT * ch + t][4 * q + ii];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < CT; it++) {
+          const uint32_t idx = it * 64 + lane, lr = idx / (8 * CT), c4 = idx % (8 * CT);
+          const uint32_t rloc = 8 * q + lr, col = 32 * CT * ch + 4 * c4;
+          if (rloc < rows_ok && col < cols_ok) {
+            const float4 v = *reinterpret_cast<const float4 *>(zst + lr * (32 * CT) + 4 * c4);
+            float *dst = dst0 + (m0 + rloc) * ld + col;
+            if (zvec) *reinterpret_cast<float4 *>(dst) = v;
+            else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+
 #pragma unroll
   for (int slot = 0; slot < TW; slot++) fill_b(0, slot);
 #pragma unroll
@@ -541,45 +575,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
 #endif
     }
     if (NBP == 2 && gu + 1 == units) {
-      // end of the first product: Z_0 leaves in the C/D layout (col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5))
-      // while the first images of the second product are already on their way; the accumulators start over
-      // The ring slot of the step that has just finished is free (the copies in flight fill the other two): the tile goes
-      // through it 8 rows x half the columns per wavefront at a time and leaves as float4s, 512 contiguous bytes per row and
-      // instruction (straight from the C/D layout it was 16 TW dword stores per lane: 8 % of the workgroup's lifetime).
+      // end of the first product: Z_0 leaves while the first images of the second product are already on their way; the
+      // accumulators start over.  The ring slot of the step that has just finished is free (the copies in flight fill the
+      // other two).
       // (the bounds are made opaque: as loop invariants the store predicates would be hoisted out of the k-loop and live
       //  in -- spilled -- scalar registers across it)
       uint32_t rows_ok = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0))), cols_ok = d.N;
       asm volatile("" : "+s"(rows_ok), "+s"(cols_ok));
       unscale_tile<TW>(acc, 1.0f / asc, d.btrail[0] + 32 * TW, g, r);
       asc = phase_scale(1);
-      constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (= one ring slot)
-      float *zst = reinterpret_cast<float *>(lbuf + (size_t)((2 * gu + 1) % 3u) * kStepVecs) + (size_t)wv * (8 * 32 * CT);
-      const bool zvec = (d.ldz[0] & 3) == 0;
-#pragma unroll
-      for (int ch = 0; ch < 2; ch++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-#pragma unroll
-          for (int t = 0; t < CT; t++)
-#pragma unroll
-            for (int ii = 0; ii < 4; ii++) zst[(4 * g + ii) * (32 * CT) + 32 * t + r] = acc[CT * ch + t][4 * q + ii];
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int it = 0; it < CT; it++) {
-            const uint32_t idx = it * 64 + lane, lr = idx / (8 * CT), c4 = idx % (8 * CT);
-            const uint32_t rloc = 8 * q + lr, col = 32 * CT * ch + 4 * c4;
-            if (rloc < rows_ok && col < cols_ok) {
-              const float4 v = *reinterpret_cast<const float4 *>(zst + lr * (32 * CT) + 4 * c4);
-              float *dst = d.Z[0] + (m0 + rloc) * d.ldz[0] + col;
-              if (zvec) *reinterpret_cast<float4 *>(dst) = v;
-              else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
+      store_tile(d.Z[0], d.ldz[0], (2 * gu + 1) % 3u, rows_ok, cols_ok);
 #pragma unroll
       for (int t = 0; t < TW; t++)
 #pragma unroll
@@ -591,6 +596,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     }
   }
 
+  if constexpr (MODE == 2) {
+    // plain product(s): the last tile leaves the same way (the ring is dead: every wavefront passed the last step's barrier)
+    unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
+    store_tile(d.Z[NBP - 1], d.ldz[NBP - 1], 0u, (uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0)), d.N);
+  } else {
   // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier).  Specialised for the two activations
   //      the reference's configurations use (config_train: elu, relu) on full-width rows; everything else takes the generic
   //      copy (activation looked up per element, column predicates)
@@ -602,6 +612,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   if (full && same && d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true>(d, acc, gsm, m0);
   else if (full && same && d.act[0] == 2) fused_epilogue<TW, MODE, NBA, 2, true>(d, acc, gsm, m0);
   else fused_epilogue<TW, MODE, NBA, -1, false>(d, acc, gsm, m0);
+  }
 }
 
 int fill_dropout(FusedDesc &p, float drop_p, uint64_t drop_seed, const char *who) {
@@ -628,7 +639,7 @@ inline void set_images(FusedDesc &p, const void *packed, int nimg, uint32_t N, u
 template <int TW, int MODE, int NBP, int NBA>
 int launch_fused(FusedDesc d, hipStream_t st) {
   // ring of three k-step images (3 x 2 TW KB) or the epilogue's stash (4 wavefronts x 16 rows x 32 TW floats), whichever is larger
-  const size_t lds = std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
+  const size_t lds = MODE == 2 ? (size_t)3 * 2 * TW * 64 * 16 : std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
   const uint32_t grid = (d.M + 127) / 128;
   if (d.K % 32 == 0) {
     if (lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>, lds));
@@ -740,6 +751,28 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
   hipStream_t st = (hipStream_t)stream;
   if (N <= 128) return nb == 1 ? launch_fused<4, 0, 1, 1>(p, st) : launch_fused<4, 0, 2, 2>(p, st);
   return nb == 1 ? launch_fused<8, 0, 1, 1>(p, st) : launch_fused<8, 0, 2, 2>(p, st);
+}
+
+// Plain products on the same kernel (no epilogue arithmetic): C_b = A_b . W_b^T for b < nb <= 2 in one launch.
+extern "C" int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,
+                               uint32_t M, uint32_t N, uint32_t K, float *const *d_C, const int64_t *ldc, void *stream) {
+  if (nb < 1 || nb > 2 || !d_A || !lda || !d_packed_B || !d_C || !ldc) return set_error(SG_ERR_INVALID, "sl_gemm_nt2_f32: bad argument");
+  if (M == 0) return SG_OK;
+  if (N < 16 || N > 256 || (N & 3) || K == 0)
+    return set_error(SG_ERR_INVALID, "sl_gemm_nt2_f32: N = %u, K = %u (N a multiple of 4 in [16, 256])", N, K);
+  FusedDesc p;
+  memset(&p, 0, sizeof(p));
+  for (int b = 0; b < nb; b++) {
+    if (!d_A[b] || !d_C[b]) return set_error(SG_ERR_INVALID, "sl_gemm_nt2_f32: null operand of product %d", b);
+    if ((lda[b] & 3) || !al16(d_A[b]) || (ldc[b] & 3) || !al16(d_C[b]))
+      return set_error(SG_ERR_INVALID, "sl_gemm_nt2_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+    p.A[b] = d_A[b]; p.lda[b] = lda[b]; p.Z[b] = d_C[b]; p.ldz[b] = ldc[b]; p.aamax[b] = d_a_amax ? d_a_amax[b] : nullptr;
+  }
+  set_images(p, d_packed_B, nb, N, K);
+  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 128) return nb == 1 ? launch_fused<4, 2, 1, 1>(p, st) : launch_fused<4, 2, 2, 1>(p, st);
+  return nb == 1 ? launch_fused<8, 2, 1, 1>(p, st) : launch_fused<8, 2, 2, 1>(p, st);
 }
 
 extern "C" size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb) {

@@ -164,7 +164,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
   // (the row maxima of the K = 2 Fout operand of the epilogue form, see below: the act_norm backward writes those of dZs)
   float *amx = reinterpret_cast<float *>(reinterpret_cast<char *>(d_pack) + images_bytes_sage(Fin, Fout));
   const bool hand = n >= kAmaxHandoverRows;
-  const bool join = below && hand && adj->t_indptr && spmm_joins(adj, Fout, dZn, ld3, d_buf + Fout, ld3);
+  // the input-gradient product on the fp16 kernels: with the lower layer's act_norm backward in its epilogue (below), or plain
+  const bool f16dx = below || (d_dX && fused_epilogue_ok(Fin, 2 * Fout, d_buf, ld3, nullptr, 0));
+  const bool join = f16dx && hand && adj->t_indptr && spmm_joins(adj, Fout, dZn, ld3, d_buf + Fout, ld3);
   if (!dz_ready) {
     const float *Z[2] = {d_Zs, d_Zn};
     const int64_t ldz[2] = {Fout, Fout};
@@ -187,9 +189,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       else if ((rc = sl_row_amax(dZs, ld3, n, Fout, amx, stream)) != SG_OK) return rc;
     }
     if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream, join ? amx : nullptr, 2)) != SG_OK) return rc;
-    if (below && hand && !join && (rc = sl_row_amax(d_buf, ld3, n, 2 * Fout, amx, stream)) != SG_OK) return rc;
+    if (f16dx && hand && !join && (rc = sl_row_amax(d_buf, ld3, n, 2 * Fout, amx, stream)) != SG_OK) return rc;
     // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
-    if (below) rc = sl_gemm_act_norm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
+    if (f16dx) rc = sl_gemm_act_norm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
     else rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
     if (rc != SG_OK) return rc;
     if (below) {
@@ -206,6 +208,13 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
                                lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
                                hand ? below->amax : nullptr, stream)) != SG_OK)
         return rc;
+    } else if (f16dx) {
+      const float *A1[1] = {d_buf};
+      const int64_t lda1[1] = {ld3}, ldc1[1] = {Fin};
+      const float *am1[1] = {hand ? amx : nullptr};
+      float *C1[1] = {d_dX};
+      SHD_PROF_FMT(4.0 * n * (2.0 * Fout + Fin), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_nt_f16_N%u", Fin);
+      if ((rc = sl_gemm_nt2_f32(1, A1, lda1, am1, d_pack, n, Fin, 2 * Fout, C1, ldc1, stream)) != SG_OK) return rc;
     } else if ((rc = nt_gemm(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
       return rc;
     }
