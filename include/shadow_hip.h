@@ -268,6 +268,13 @@ int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const f
                     const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                     void *stream);
 
+/* Consecutive small subgraphs of a collated batch joined into groups of at most cap_rows rows and cap_edges edges (0: the
+ * LDS tile of sl_spmm_blockdiag_f32, 384 rows / 1024 edges): d_group_*_off receive [num_subg + 1] offsets -- the groups,
+ * then empty groups up to num_subg, so that they can be passed to sl_spmm_blockdiag_f32 in place of the subgraph offsets
+ * (with max_subg_nodes = cap_rows) without reading a count back.  A group is still a diagonal block.  num_subg <= 8191. */
+int sl_merge_subgraphs(const uint32_t *d_node_off, const uint32_t *d_edge_off, uint32_t num_subg, uint32_t cap_rows,
+                       uint32_t cap_edges, uint32_t *d_group_node_off, uint32_t *d_group_edge_off, void *stream);
+
 /* Same product for a BLOCK-DIAGONAL adjacency (a collated minibatch, graph.py:280-330): rows
  * [node_off[s], node_off[s+1]) only reference columns of the same range and own the edges
  * [edge_off[s], edge_off[s+1]) (sg_batch_out.d_subg_nodes / d_subg_edges; the transpose of such a

@@ -112,6 +112,7 @@ SIGNATURES = {
     "sl_degree_scales": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
     "sl_spmm_csr_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                    C.c_uint32, _P]),
+    "sl_merge_subgraphs": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "sl_spmm_blockdiag_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                          C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_spmm_blockdiag_gather_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_uint64, _P, C.c_int64,

@@ -1181,6 +1181,64 @@ extern "C" int sl_gather_rows_drop_f32(const float *d_table, int64_t ld_table, c
   return SG_OK;
 }
 
+// Consecutive small subgraphs joined into groups of at most cap_rows rows and cap_edges edges: the ranges of a group are
+// still a diagonal block (its rows reference its own columns only), so the block-diagonal SpMM can stage a whole group in
+// LDS at once -- PPR subgraphs of ~150 rows fill barely more than one 128-row pass of the kernel each, pairs fill 2.3 of 3.
+// Groups are ALIGNED power-of-two runs of subgraphs: subgraph s belongs to the largest run [s & ~(2^r - 1), + 2^r) that fits
+// the caps (runs nest, so every member of a run finds the same one) -- one thread per subgraph, no serial walk.
+// Output: [P + 1] offsets each (groups first, then empty groups up to P: the launch needs no count from the device).
+__global__ void __launch_bounds__(1024) merge_subgraphs_kernel(const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ edge_off,
+                                                               uint32_t P, uint32_t cap_rows, uint32_t cap_edges,
+                                                               uint32_t *__restrict__ gnode, uint32_t *__restrict__ gedge) {
+  extern __shared__ uint32_t ms[];                       // [2][P + 1] offsets, then [1024] scan cells
+  uint32_t *no = ms, *eo = ms + (P + 1), *cell = eo + (P + 1);
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i <= P; i += 1024) { no[i] = node_off[i]; eo[i] = edge_off[i]; }
+  __syncthreads();
+  // thread t owns the subgraphs [8 t, 8 t + 8): group starts among them, exclusive scan of the counts over the workgroup
+  uint32_t starts = 0, cnt = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 8; q++) {
+    const uint32_t s = 8 * tid + q;
+    if (s < P) {
+      uint32_t r = 0;
+      for (;;) {
+        const uint32_t a = s & ~((2u << r) - 1u), b = a + (2u << r);          // the next larger aligned run
+        if (b > P || no[b] - no[a] > cap_rows || eo[b] - eo[a] > cap_edges) break;
+        r++;
+      }
+      if ((s & ((1u << r) - 1u)) == 0) { starts |= 1u << q; cnt++; }
+    }
+  }
+  cell[tid] = cnt;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = tid >= off ? cell[tid - off] : 0u;
+    __syncthreads();
+    cell[tid] += v;
+    __syncthreads();
+  }
+  uint32_t g = cell[tid] - cnt;
+  const uint32_t ngroups = cell[1023];
+#pragma unroll
+  for (uint32_t q = 0; q < 8; q++)
+    if (starts & (1u << q)) { gnode[g] = no[8 * tid + q]; gedge[g] = eo[8 * tid + q]; g++; }
+  for (uint32_t i = ngroups + tid; i <= P; i += 1024) { gnode[i] = no[P]; gedge[i] = eo[P]; }
+}
+
+extern "C" int sl_merge_subgraphs(const uint32_t *d_node_off, const uint32_t *d_edge_off, uint32_t num_subg, uint32_t cap_rows,
+                                  uint32_t cap_edges, uint32_t *d_group_node_off, uint32_t *d_group_edge_off, void *stream_) {
+  if (!d_node_off || !d_edge_off || !d_group_node_off || !d_group_edge_off) return set_error(SG_ERR_INVALID, "sl_merge_subgraphs: null argument");
+  if (num_subg == 0) return SG_OK;
+  if (num_subg > 8191) return set_error(SG_ERR_INVALID, "sl_merge_subgraphs: at most 8191 subgraphs");
+  if (cap_rows == 0 || cap_rows > (uint32_t)kBdMaxRows) cap_rows = kBdMaxRows;
+  if (cap_edges == 0 || cap_edges > (uint32_t)kBdMaxEdges) cap_edges = kBdMaxEdges;
+  hipLaunchKernelGGL(merge_subgraphs_kernel, dim3(1), dim3(1024), (size_t)2 * (num_subg + 1) * 4 + 1024 * 4, (hipStream_t)stream_, d_node_off,
+                     d_edge_off, num_subg, cap_rows, cap_edges, d_group_node_off, d_group_edge_off);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
 extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                      const uint32_t *d_edge_perm, const float *d_row_scale,
                                      const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,

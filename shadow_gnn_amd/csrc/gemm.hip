@@ -75,7 +75,7 @@ __global__ void gemm_pack_b_kernel(const float *__restrict__ B, int64_t s1j, int
 //   [unit][step][piece h, m][column tile][lane][8 x fp16],
 // followed by a trailer of 2 x 32 tiles floats: the power-of-two scale of every output column's weight row (rows >= N: 1)
 // and its inverse.  ONE launch packs all images of a layer pass (grid = tiles x images): a workgroup first finds the
-// largest magnitude of its 32 weight rows (8 threads per row), then writes the tile's fragments of every k-step.
+// largest magnitude of its 32 weight rows (32 threads per row), then writes the tile's fragments of every k-step.
 // `zero` (optional): n_zero floats cleared on the way (the row-maximum array the SpMM of the same pass joins into --
 // saves the memset launch that the small batches, bound by the host's launch rate, would pay for).
 struct PackSrc {
@@ -92,45 +92,70 @@ struct PackJob {
   uint32_t n_zero;
 };
 
-__global__ void __launch_bounds__(256) gemm_pack_f16_kernel(const PackJob job) {
-  __shared__ float smax[8][32];
+__global__ void __launch_bounds__(1024) gemm_pack_f16_kernel(const PackJob job) {
+  __shared__ float smax[32][32];
   __shared__ float sscale[32];
   const PackSrc &sr = job.src[blockIdx.y];
   const uint32_t t = blockIdx.x, tid = threadIdx.x, N = job.N, K = job.K, tiles = job.tiles;
   if (job.zero)
-    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < job.n_zero; i += gridDim.x * gridDim.y * 256) job.zero[i] = 0.f;
+    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * 1024 + tid; i < job.n_zero; i += gridDim.x * gridDim.y * 1024) job.zero[i] = 0.f;
   auto elem = [&](uint32_t col, uint32_t k) -> float {
     return k < sr.K1 ? sr.B1[(int64_t)col * sr.s1j + (int64_t)k * sr.s1k] : sr.B2[(int64_t)col * sr.s2j + (int64_t)(k - sr.K1) * sr.s2k];
   };
   {
-    const uint32_t c = tid & 31u, kk = tid >> 5, col = 32 * t + c;
+    // 32 threads per weight row; the threads that sit next to each other run along the contiguous direction of the source
+    // (a row-major weight: along k; a transposed one: along the rows)
+    const bool kmajor = sr.s1k == 1;
+    const uint32_t c = kmajor ? tid >> 5 : tid & 31u, kk = kmajor ? tid & 31u : tid >> 5, col = 32 * t + c;
     float mx = 0.f;
-    if (col < N)
-      for (uint32_t k = kk; k < K; k += 8) mx = fmaxf(mx, fabsf(elem(col, k)));
+    if (col < N) {
+      if (kmajor) {
+#pragma unroll 4
+        for (uint32_t k0 = 4 * kk; k0 < K; k0 += 128)
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++) if (k0 + j < K) mx = fmaxf(mx, fabsf(elem(col, k0 + j)));
+      } else {
+#pragma unroll 16
+        for (uint32_t k = kk; k < K; k += 32) mx = fmaxf(mx, fabsf(elem(col, k)));
+      }
+    }
     smax[kk][c] = mx;
   }
   __syncthreads();
   if (tid < 32) {
     float mx = smax[0][tid];
 #pragma unroll
-    for (int q = 1; q < 8; q++) mx = fmaxf(mx, smax[q][tid]);
+    for (int q = 1; q < 32; q++) mx = fmaxf(mx, smax[q][tid]);
     const float sc = row_scale_of(mx);
     sscale[tid] = sc;
     sr.trailer[32 * t + tid] = sc;
     sr.trailer[32 * tiles + 32 * t + tid] = 1.0f / sc;    // (exact: a power of two within 2^+-62)
   }
   __syncthreads();
-  for (uint32_t idx = tid; idx < job.units * 2 * 64; idx += 256) {
-    const uint32_t l = idx & 63u, h = (idx >> 6) & 1u, u = idx >> 7;
-    const uint32_t col = 32 * t + (l & 31u), k0 = 32 * u + 16 * (l >> 5) + 8 * h;
-    float x[8];
+  // (all loads of a thread's fragments in flight before the first is used: the launch is a dependent step of every layer
+  //  pass -- one round trip to the L2 instead of one per fragment)
+  const uint32_t total = job.units * 2 * 64;
+  for (uint32_t base = 0; base < total; base += 2 * 1024) {
+    float x[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = (col < N && k0 + j < K) ? elem(col, k0 + j) : 0.f;
-    half8 hh, mm;
-    split8_f16(x, sscale[l & 31u], hh, mm);
-    const size_t base = ((size_t)(u * 2 + h) * 2) * tiles;
-    sr.img[(base + 0 * tiles + t) * 64 + l] = hh;
-    sr.img[(base + 1 * tiles + t) * 64 + l] = mm;
+    for (int q = 0; q < 2; q++) {
+      const uint32_t idx = base + q * 1024 + tid;
+      const uint32_t l = idx & 63u, h = (idx >> 6) & 1u, u = idx >> 7;
+      const uint32_t col = 32 * t + (l & 31u), k0 = 32 * u + 16 * (l >> 5) + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[q][j] = (idx < total && col < N && k0 + j < K) ? elem(col, k0 + j) : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t idx = base + q * 1024 + tid;
+      if (idx >= total) continue;
+      const uint32_t l = idx & 63u, h = (idx >> 6) & 1u, u = idx >> 7;
+      half8 hh, mm;
+      split8_f16(x[q], sscale[l & 31u], hh, mm);
+      const size_t ob = ((size_t)(u * 2 + h) * 2) * tiles;
+      sr.img[(ob + 0 * tiles + t) * 64 + l] = hh;
+      sr.img[(ob + 1 * tiles + t) * 64 + l] = mm;
+    }
   }
 }
 
@@ -435,7 +460,7 @@ int pack_f16(int nimg, const PackF16Src *src, uint32_t N, uint32_t K, uint32_t t
     d.K1 = std::min(src[b].K1, K); d.img = reinterpret_cast<half8 *>(src[b].img); d.trailer = src[b].trailer;
   }
   job.N = N; job.K = K; job.units = (K + 31) / 32; job.tiles = tiles; job.zero = zero; job.n_zero = zero ? n_zero : 0;
-  hipLaunchKernelGGL(gemm_pack_f16_kernel, dim3(tiles, nimg), dim3(256), 0, st, job);
+  hipLaunchKernelGGL(gemm_pack_f16_kernel, dim3(tiles, nimg), dim3(1024), 0, st, job);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

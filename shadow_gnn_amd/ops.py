@@ -135,6 +135,7 @@ class DeviceCSR:
         self.e = int(indices.numel())
         self._edge_row = None
         self._t = None
+        self._blocks = None
         self.subg_off = subg_off.contiguous() if subg_off is not None else None
         self.subg_edge_off = subg_edge_off.contiguous() if subg_edge_off is not None else None
         self.max_subg_nodes = int(max_subg_nodes)
@@ -142,6 +143,23 @@ class DeviceCSR:
             assert self.subg_edge_off is not None and self.subg_edge_off.numel() == self.subg_off.numel()
             assert self.subg_off.dtype == torch.int32 and self.subg_off.is_cuda
             assert self.subg_edge_off.dtype == torch.int32 and self.subg_edge_off.is_cuda
+
+    @property
+    def spmm_blocks(self):
+        """(node offsets, edge offsets, largest block) the block-diagonal SpMM stages in LDS: the subgraphs themselves, or --
+        small subgraphs (PPR: ~150 rows each, a 128-row kernel pass and a bit) -- consecutive subgraphs joined into groups
+        of up to 384 rows / 1024 edges (sl_merge_subgraphs; computed once per batch, a group is still a diagonal block)."""
+        if self.subg_off is None:
+            return (None, None, 0)
+        if self._blocks is None:
+            P = int(self.subg_off.numel()) - 1
+            self._blocks = (self.subg_off, self.subg_edge_off, self.max_subg_nodes)
+            if MERGE_SMALL_SUBGRAPHS and 2 <= P <= 8191 and self.n < MERGE_BELOW_AVG_ROWS * P:
+                goff, geoff = torch.empty_like(self.subg_off), torch.empty_like(self.subg_edge_off)
+                check(_lib.load().sl_merge_subgraphs(self.subg_off.data_ptr(), self.subg_edge_off.data_ptr(), P, 384, 1024, goff.data_ptr(),
+                                                     geoff.data_ptr(), _stream(self.indptr)))
+                self._blocks = (goff, geoff, max(384, self.max_subg_nodes))
+        return self._blocks
 
     @property
     def shape(self):
@@ -256,6 +274,8 @@ def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
 
 
 BLOCKDIAG_MIN_F = 96      # below this width the per-edge gather kernels are faster (measured)
+MERGE_SMALL_SUBGRAPHS = os.environ.get("SHADOW_MERGE_SUBGRAPHS", "1") != "0"
+MERGE_BELOW_AVG_ROWS = 190   # two average subgraphs must fit the 384-row tile
 
 
 def _adj_struct(adj: "NormAdj", need_transpose: bool):
@@ -265,9 +285,10 @@ def _adj_struct(adj: "NormAdj", need_transpose: bool):
     ti = tx = tp = None
     if need_transpose:
         ti, tx, tp = c.transposed
+    boff, beoff, bmax = c.spmm_blocks
     return _lib.SlNormAdj(c.indptr.data_ptr(), c.indices.data_ptr(), ptr(adj.edge_w), ptr(adj.row_scale), ptr(adj.col_scale),
-                          ptr(ti), ptr(tx), ptr(tp), ptr(c.subg_off), ptr(c.subg_edge_off),
-                          (int(c.subg_off.numel()) - 1) if c.subg_off is not None else 0, c.max_subg_nodes, c.n, c.e)
+                          ptr(ti), ptr(tx), ptr(tp), ptr(boff), ptr(beoff),
+                          (int(boff.numel()) - 1) if boff is not None else 0, bmax, c.n, c.e)
 
 
 # One C call per GraphSAGE layer pass (sl_sage_fwd / sl_sage_bwd_chain) instead of one per kernel.  A KernelTimer does
@@ -313,7 +334,7 @@ class _SpMM(torch.autograd.Function):
         ctx.adj = adj
         c = adj.csr
         return _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
-                         (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
+                         c.spmm_blocks)
 
     @staticmethod
     def backward(ctx, dY):
@@ -322,7 +343,7 @@ class _SpMM(torch.autograd.Function):
         # (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
         c = adj.csr          # the transpose of a block-diagonal matrix has the same blocks
         dX = _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale,
-                       adj.row_scale, dY, c.n, (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
+                       adj.row_scale, dY, c.n, c.spmm_blocks)
         return dX, None
 
 
@@ -867,7 +888,7 @@ class _SageDense(torch.autograd.Function):
                 AX = None                  # the one-call entry below computes it
             else:
                 AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
-                               (c.subg_off, c.subg_edge_off, c.max_subg_nodes))
+                               c.spmm_blocks)
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
         bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
@@ -1022,7 +1043,7 @@ class _SageDense(torch.autograd.Function):
             c = adj.csr
             ti, tx, tp = c.transposed
             _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale, adj.row_scale, dZn,
-                      c.n, (c.subg_off, c.subg_edge_off, c.max_subg_nodes), out=buf[:, F:])
+                      c.n, c.spmm_blocks, out=buf[:, F:])
             dX = mm_nt(buf, torch.cat([Ws.t(), Wn.t()], dim=1))
         dWs = weight_grad(dZs, X) if ng[2] else None
         dWn = weight_grad(dZn, AX) if ng[4] else None

@@ -1195,3 +1195,41 @@ def test_plain_fp16_split_products(nb, M, K, N, shared):
         ref, den = a.double() @ w.double().t(), a.abs().double() @ w.abs().double().t()
         assert float(((c.double() - ref).abs() / den).max()) < 1.5e-6
         assert float(b[:, N:].min()) == 7.0 and float(b[:, N:].max()) == 7.0      # nothing written past the N columns
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [256, 100])
+def test_spmm_over_merged_small_subgraphs_is_bit_identical(F, monkeypatch):
+    """Small subgraphs (PPR-sized: ~150 rows) are joined into groups of up to 384 rows / 1024 edges before the
+    block-diagonal SpMM stages them (sl_merge_subgraphs): the group offsets cover every subgraph once, in order, within
+    the caps (an oversize subgraph stays alone), are padded with empty groups, and the product -- forward and on the
+    transposed adjacency -- is bit-identical to the one over the subgraphs themselves (same rows, same edge order)."""
+    from shadow_gnn_amd import ops
+    rng = np.random.default_rng(F)
+    sizes = [int(x) for x in rng.integers(1, 200, size=60)] + [390, 3, 500, 2, 2, 2, 150, 150, 150]
+    csr, A = _blockdiag_batch(sizes, 0.02, seed=F)
+    n, P = csr.n, len(sizes)
+    monkeypatch.setattr(ops, "MERGE_BELOW_AVG_ROWS", 10 ** 6)
+    goff, geoff, cap = csr.spmm_blocks
+    assert goff.data_ptr() != csr.subg_off.data_ptr() and cap >= 384
+    go, ge = goff.cpu().numpy().astype(np.int64), geoff.cpu().numpy().astype(np.int64)
+    no, eo = csr.subg_off.cpu().numpy().astype(np.int64), csr.subg_edge_off.cpu().numpy().astype(np.int64)
+    assert go[0] == 0 and go[-1] == n and ge[-1] == csr.e and np.all(np.diff(go) >= 0) and np.all(np.diff(ge) >= 0)
+    assert set(go.tolist()) <= set(no.tolist())                       # group boundaries are subgraph boundaries
+    for a, b, ea, eb in zip(go[:-1], go[1:], ge[:-1], ge[1:]):
+        single = (np.searchsorted(no, b) - np.searchsorted(no, a)) <= 1
+        assert single or (b - a <= 384 and eb - ea <= 1024)
+    ngroups = int(np.count_nonzero(np.diff(go)))
+    assert ngroups < P and np.all(go[ngroups:] == n)                 # fewer, fuller blocks; empty groups behind
+    g = torch.Generator(device=DEV).manual_seed(F)
+    X = torch.randn(n, F, device=DEV, generator=g)
+    w = torch.rand(csr.e, device=DEV, generator=g)
+    rs, cs = torch.rand(n, device=DEV, generator=g) + 0.5, torch.rand(n, device=DEV, generator=g) + 0.5
+    merged = ops._spmm_raw(csr.indptr, csr.indices, w, None, rs, cs, X, n, csr.spmm_blocks)
+    plain = ops._spmm_raw(csr.indptr, csr.indices, w, None, rs, cs, X, n, (csr.subg_off, csr.subg_edge_off, csr.max_subg_nodes))
+    assert torch.equal(merged, plain)
+    dense = torch.zeros(n, n, dtype=torch.float64, device=DEV)
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
+    dense[rows, csr.indices.long()] = w.double()
+    want = (rs.double()[:, None] * dense * cs.double()[None, :]) @ X.double()
+    torch.testing.assert_close(merged.double(), want, rtol=1e-5, atol=1e-5)
