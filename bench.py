@@ -373,16 +373,19 @@ def main():
                     avg_ms=round(kern[k]["avg_ms"], 4), bytes_per_launch=int(kern[k]["bytes_per_launch"]))
 
     def mfma_entry(k):
-        # the split-bf16 GEMM: algorithmic flops against the dense bf16 MFMA peak divided by the six bf16 terms the
-        # scheme issues per fp32 product
+        # a split GEMM: algorithmic flops against the dense 16-bit MFMA peak divided by the matrix-core products the scheme
+        # issues per fp32 product -- three for the two-piece fp16 kernels (GEMM-epilogue forms), six for the three-piece
+        # bf16 ones (weight gradients, plain products of odd shapes)
         tf = kern[k]["flops_per_launch"] / (kern[k]["avg_ms"] * 1e-3) / 1e12      # algorithmic 2*M*K*N per launch
-        peak = MFMA_BF16_PEAK_TF / 6.0
+        terms = 3.0 if k.startswith(("gemm_act_norm", "gemm_an_bwd", "gemm_nt_f16")) else 6.0
+        peak = MFMA_BF16_PEAK_TF / terms
         return dict(bound="mfma", kernel=k, achieved=round(tf, 1), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                     traffic=traffic_of(k), traffic_source=tsrc if traffic_of(k) else None, avg_ms=round(kern[k]["avg_ms"], 4),
                     flops_per_launch=int(kern[k]["flops_per_launch"]), bytes_per_launch=int(kern[k]["bytes_per_launch"]),
-                    peak_basis="2500 TFLOP/s dense bf16 MFMA / 6 bf16 terms per fp32 product (exact 3-way split); "
-                               "the fp32-input MFMA peak of gfx950 is 157.3 TFLOP/s",
-                    bf16_tflops_issued=round(6.0 * tf, 1))
+                    peak_basis=f"2500 TFLOP/s dense bf16 / fp16 MFMA / {terms:.0f} matrix-core products per fp32 product "
+                               + ("(two fp16 pieces per row-scaled operand: hh + hm + mh)" if terms == 3.0 else "(exact 3-way bf16 split)")
+                               + "; the fp32-input MFMA peak of gfx950 is 157.3 TFLOP/s",
+                    mfma_tflops_issued=round(terms * tf, 1))
     timed = [k for k in kern if k != "sg_relocate_kernel"]
     hbm_keys = [k for k in timed if not kern[k].get("flops_per_launch")]
     mfma_keys = [k for k in timed if kern[k].get("flops_per_launch")]

@@ -30,7 +30,12 @@ ROC = {
     "spmm_F256": "spmm_blockdiag_kernel<false>",
     "spmm_F100": "spmm_blockdiag_kernel<false>",
 }
-HBM, MFMA6 = 8000.0, 2500.0 / 6.0
+HBM, MFMA6, MFMA3 = 8000.0, 2500.0 / 6.0, 2500.0 / 3.0
+
+
+def mfma_roof(kernel):
+    """fp32-equivalent roof of a GEMM class: six bf16 products per multiply-add (tn, plain nt) or three fp16 ones."""
+    return MFMA3 if kernel.startswith(("gemm_act_norm", "gemm_an_bwd", "gemm_nt_f16")) else MFMA6
 
 
 def main():
@@ -45,7 +50,7 @@ def main():
                f"({d['config']['nodes_per_step']:.0f} nodes, {d['config']['edges_per_step']:.0f} edges per step); host busy "
                f"{d['host_busy_ms_per_step']} ms of it (enqueue {d['host_enqueue_ms_per_step']} ms incl. the blocked count read-back).")
     out.append("")
-    out.append("| kernel class (bench line) | launches / step | avg us, HIP events | avg us, rocprofv3 | algorithmic MB | HBM MB (PMC) | PMC / alg. | alg. GB/s | frac of 8 TB/s | TFLOP/s fp32-equiv. | frac of 2500/6 |")
+    out.append("| kernel class (bench line) | launches / step | avg us, HIP events | avg us, rocprofv3 | algorithmic MB | HBM MB (PMC) | PMC / alg. | alg. GB/s | frac of 8 TB/s | TFLOP/s fp32-equiv. | frac of the split's roof (2500/3 fp16 pieces, 2500/6 bf16) |")
     out.append("|---|---|---|---|---|---|---|---|---|---|---|")
     K = d["kernels"]
     steps_prof = 10
@@ -53,7 +58,7 @@ def main():
         if v["total_ms"] < 0.5 and not k.startswith(("sg_", "gather")):
             continue
         rn = ROC.get(k)
-        rocus = next((f"{t:.1f}" for n, t in roc.items() if rn and rn in n), "—") if k not in ("spmm_F100", "spmm_F256") else ("142.0 (both widths)" if k == "spmm_F256" else "—")
+        rocus = next((f"{t:.1f}" for n, t in roc.items() if rn and rn in n), "—") if k not in ("spmm_F100", "spmm_F256") else (next((f"{t:.1f} (both widths)" for n, t in roc.items() if "spmm_blockdiag_kernel<false>" in n), "—") if k == "spmm_F256" else "—")
         by = None
         for name, e in (("roofline_hbm", d.get("roofline_hbm")), ("roofline_mfma", d.get("roofline_mfma"))):
             if e and e.get("kernel") == k:
@@ -63,7 +68,7 @@ def main():
         tf = v.get("alg_TFLOPs")
         trs = f"{tr / 1e6:.0f} | {tr / 1e6 / alg_mb:.2f}" if (tr and alg_mb > 0) else "— | —"
         out.append(f"| `{k}` | {v['launches'] / steps_prof:.1f} | {v['avg_ms'] * 1e3:.1f} | {rocus} | {alg_mb:.0f} | {trs}"
-                   + f" | {v['alg_GBps']:.0f} | {v['frac']:.3f} | " + (f"{tf:.1f} | {tf / MFMA6:.3f} |" if tf else "— | — |"))
+                   + f" | {v['alg_GBps']:.0f} | {v['frac']:.3f} | " + (f"{tf:.1f} | {tf / mfma_roof(k):.3f} |" if tf else "— | — |"))
     r = d["roofline"]
     out.append("")
     out.append(f"North-star aggregate (k-hop sample + feature gather + SAGE aggregates, `roofline` of the bench line): "
