@@ -304,10 +304,12 @@ int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_ind
 /* Weight gradient of nn.Linear with the same split-bf16 arithmetic:  C[N,K] = A[M,N]^T . B[M,K]
  * (A = dZ, B = the layer input; N, K <= 256 and multiples of 4; operands 16-byte aligned, ld % 4 == 0).
  * The rows are cut into sl_gemm_tn_slices(M) slices, one workgroup each; d_partial holds the per-slice
- * products ([slices, N, K] floats) that a second kernel adds in a fixed order (deterministic). */
+ * products ([slices, N, K] floats) that a second kernel adds in a fixed order (deterministic).
+ * d_a_colsum (may be NULL): receives sum_k A[k, j], j < N -- nn.Linear's bias gradient -- from the same pass (d_partial
+ * then holds slices * (N K + N) floats). */
 uint32_t sl_gemm_tn_slices(uint32_t M);
 int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb, float *d_C, uint32_t M, uint32_t N,
-                   uint32_t K, float *d_partial, void *stream);
+                   uint32_t K, float *d_partial, float *d_a_colsum, void *stream);
 
 /* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
  * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)
@@ -369,10 +371,12 @@ int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, co
  * d_out_dropped != NULL (needs drop_p > 0) is the dual mode for architectures where something besides the next
  * layer reads this output (the residue / ResPool read-outs, shaDow/models.py:176-185): d_out receives the plain
  * value and d_out_dropped the dropped one, from one pass over Z.                                                      */
+/* d_out_amax (may be NULL): receives max_k |row| of the output the next layer reads (the dropped one in dual mode), see
+ * sl_row_amax.                                                                                                     */
 int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p, uint64_t drop_seed,
-                    float *d_out_dropped, int64_t ldo_dropped, void *stream);
+                    float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax, void *stream);
 /* Backward of the above (d_dz0_amax, may be NULL: receives max_k |dZ_0[i, k]| per row, see sl_row_amax): dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
  * when d_dbias != NULL, dbias [nb, F] = column sums of dZ_b (all overwritten,
  * reduced over the rows in a fixed order).
@@ -478,11 +482,18 @@ int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, co
                          const int *act, const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo,
                          float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax,
                          void *stream);
-/* Plain products on the same kernel (no epilogue arithmetic): C_b = A_b . W_b^T for b < nb <= 2 in ONE launch (images:
- * sl_gemm_act_norm_pack / _pack_b2; the two products may share A -- GAT's self and neighbour Linear of the same input);
- * d_a_amax as above.  N % 4 == 0, 16 <= N <= 256; operands 16-byte aligned, ld % 4 == 0.                            */
+/* Plain products on the same kernel: C_b = A_b . W_b^T + bias_b for b < nb <= 2 in ONE launch (images:
+ * sl_gemm_act_norm_pack / _pack_b2; the two products may share A -- GAT's self and neighbour Linear of the same input;
+ * d_bias and its entries may be NULL); d_a_amax as above.  N % 4 == 0, 16 <= N <= 256; operands 16-byte aligned, ld % 4 == 0.
+ * sl_gemm_nt_cat_f32: C = [A0 | A1] . B^T + bias with the K-concatenated operand in two tensors (K0 % 32 == 0 columns from
+ * A0, K - K0 from A1; image: sl_gemm_act_norm_pack_b2 of the matching weight; d_a_amax: the maximum over BOTH parts of a
+ * row, or NULL) -- dX = dZs Ws + dZn Wn of a layer with two Linears on the same input, without the sum pass.           */
 int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,
-                    uint32_t M, uint32_t N, uint32_t K, float *const *d_C, const int64_t *ldc, void *stream);
+                    uint32_t M, uint32_t N, uint32_t K, const float *const *d_bias, float *const *d_C, const int64_t *ldc,
+                    void *stream);
+int sl_gemm_nt_cat_f32(const float *d_A0, int64_t lda0, uint32_t K0, const float *d_A1, int64_t lda1, const float *d_a_amax,
+                       const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K, const float *d_bias, float *d_C, int64_t ldc,
+                       void *stream);
 size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb);
 int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
                    int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,

@@ -151,7 +151,9 @@ SIGNATURES = {
                                         C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
                                         C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
     "sl_gemm_nt2_f32": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
-                                   C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+                                   C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "sl_gemm_nt_cat_f32": (C.c_int, [_P, C.c_int64, C.c_uint32, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P,
+                                      C.c_int64, _P]),
     "sl_gemm_an_bwd_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
     "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
@@ -164,14 +166,14 @@ SIGNATURES = {
     "sl_clip_adam_scratch_floats": (C.c_uint32, []),
     "sl_clip_adam": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_float, _P, _P]),
     "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
-    "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
     "sl_segment_pool_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, _P, C.c_int64, _P]),
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_onehot_linear_fwd": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_onehot_linear_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
     "sl_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
-                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P]),
+                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
     "sl_gat_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                               _P, _P, _P, _P, _P, _P, _P]),
     "sl_gat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -739,6 +739,8 @@ struct ActNormParams {
   const float *dout2; int64_t lddo2;
   // backward, optional: max_k |dZ[0][r, k]| per row (the fp16 operand scale of the GEMM that reads dZ[0] next, sl_row_amax)
   float *dz0_amax;
+  // forward, optional: the same for the output the next layer reads (out2 in dual mode, out otherwise)
+  float *out_amax;
 };
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
@@ -863,16 +865,23 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
         }
       }
     }
+    float omax = 0.f;
     if (!BWD && lane_on) {
       acc.x *= p.out_scale; acc.y *= p.out_scale; acc.z *= p.out_scale; acc.w *= p.out_scale;
+      omax = amax4(acc);
       if (p.drop_thr) {
         const uint32_t keep = drop_keep4(p, r, f);
         const float4 dr = make_float4((keep & 1u) ? acc.x * p.drop_scale : 0.f, (keep & 2u) ? acc.y * p.drop_scale : 0.f,
                                       (keep & 4u) ? acc.z * p.drop_scale : 0.f, (keep & 8u) ? acc.w * p.drop_scale : 0.f);
         if (p.out2) st4s(p.out2 + (int64_t)r * p.ldo2 + f, dr);      // dual mode: out stays un-dropped
         else acc = dr;
+        omax = amax4(dr);
       }
       st4s(p.out + (int64_t)r * p.ldo + f, acc);
+    }
+    if (!BWD && p.out_amax) {             // (the LPR lanes of a row group share r)
+      omax = group_max<LPR>(omax);
+      if (l == 0) p.out_amax[r] = omax;
     }
   }
   if (BWD) {
@@ -1452,7 +1461,7 @@ static int set_dropout(ActNormParams &p, float drop_p, uint64_t drop_seed, const
 extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p,
-                               uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, void *stream_) {
+                               uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax, void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
   if (n == 0) return SG_OK;
@@ -1469,7 +1478,15 @@ extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *l
       return set_error(SG_ERR_INVALID, "sl_act_norm_fwd: the dropped output must be 16-byte aligned, ld %% 4 == 0");
     p.out2 = d_out_dropped; p.ldo2 = ldo_dropped;
   }
-  return act_norm_launch(p, false, (hipStream_t)stream_);
+  p.out_amax = d_out_amax;
+  bool vec = false;
+  if ((rc = act_norm_launch(p, false, (hipStream_t)stream_, &vec)) != SG_OK) return rc;
+  // (the general kernel does not write the row maxima: one more pass, over the tensor the next layer reads)
+  if (d_out_amax && !vec) {
+    const float *o = d_out_dropped ? d_out_dropped : d_out;
+    return sl_row_amax(o, d_out_dropped ? ldo_dropped : ldo, n, F, d_out_amax, stream_);
+  }
+  return SG_OK;
 }
 
 extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,

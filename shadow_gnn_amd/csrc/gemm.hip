@@ -678,7 +678,7 @@ gemm_tn_split_kernel(const float *__restrict__ A, int64_t lda, const float *__re
 template <int TK>
 __global__ void __launch_bounds__(kTnThreads)
 gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
-                    float *__restrict__ partial, uint32_t M, uint32_t N, uint32_t K, uint32_t rows_per_wg) {
+                    float *__restrict__ partial, uint32_t M, uint32_t N, uint32_t K, uint32_t rows_per_wg, uint32_t colsum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
   float *lbuf = reinterpret_cast<float *>(tsm);                                   // [2][kTnStepFloats]: fp32 row tiles
   bf16x8 *fimg = reinterpret_cast<bf16x8 *>(tsm + (size_t)2 * kTnStepFloats * 4); // [2][2 operands][3 pieces][8 tiles][64 lanes]
@@ -703,6 +703,7 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[a][t][i] = 0.f;
 
+  float csum = 0.f;
   // copy `part` (0..3) of k-step s: this wavefront moves rows {2 wv, 2 wv + 1} of the A tile and of the B tile
   auto fill = [&](uint32_t s, int part) {
     const uint32_t lr = 2 * wv + (part & 1);                 // row inside the 16-row tile
@@ -724,6 +725,8 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
     const float *tile = lbuf + (size_t)(s & 1) * kTnStepFloats + (op ? 16 * kTnRowFloats : 0);
     float x[8];
     lds_frag8(tile, 32 * wv + r, kg, x);
+    // (column sums of A -- nn.Linear's bias gradient -- ride along: this wavefront sees every element of its 32 columns once)
+    if (op == 0) csum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     bf16x8 h, m, l;
     split8(x, h, m, l);
     bf16x8 *dst = fimg + (size_t)(s & 1) * kImgVecs + ((size_t)op * 3 * 8 + wv) * 64 + lane;
@@ -795,8 +798,13 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
     __syncthreads();
 #endif
   }
-  // partial[g][n][k]; C/D layout: col (k) = lane & 31, row (n) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
-  float *out = partial + (size_t)blockIdx.x * N * K;
+  // partial[g][n][k] (+ [N] column sums of A behind it when asked for); C/D layout: col (k) = lane & 31,
+  // row (n) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+  float *out = partial + (size_t)blockIdx.x * ((size_t)N * K + (colsum ? N : 0u));
+  if (colsum) {
+    const float both = csum + __shfl_xor(csum, 32, 64);            // the two 8-row halves of every step
+    if (kg == 0 && 32 * wv + r < N) out[(size_t)N * K + 32 * wv + r] = both;
+  }
 #pragma unroll
   for (int a = 0; a < 2; a++) {
 #pragma unroll
@@ -814,7 +822,8 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
 // out[i] = sum_g partial[g][i] in a fixed order: 8 independent running sums per thread (eight loads in
 // flight instead of a dependent chain), 4 row-slice groups per output combined through LDS.
 __global__ void __launch_bounds__(256)
-gemm_tn_reduce_kernel(const float *__restrict__ partial, uint32_t G, uint32_t NK, float *__restrict__ out) {
+gemm_tn_reduce_kernel(const float *__restrict__ partial, uint32_t G, uint32_t NK, float *__restrict__ out, uint32_t NK0,
+                      float *__restrict__ out2) {     // (outputs [NK0, NK) of a slice go to out2: the column sums)
   __shared__ float red[4][64];
   const uint32_t col = threadIdx.x & 63u, grp = threadIdx.x >> 6;       // 64 outputs x 4 slice groups per block
   const uint32_t i = blockIdx.x * 64u + col;
@@ -830,7 +839,11 @@ gemm_tn_reduce_kernel(const float *__restrict__ partial, uint32_t G, uint32_t NK
   }
   red[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (grp == 0 && i < NK) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (grp == 0 && i < NK) {
+    const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (out2 && i >= NK0) out2[i - NK0] = v;
+    else out[i] = v;
+  }
 }
 
 }  // namespace
@@ -846,7 +859,7 @@ extern "C" uint32_t sl_gemm_tn_slices(uint32_t M) {
 }
 
 extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb, float *d_C, uint32_t M,
-                              uint32_t N, uint32_t K, float *d_partial, void *stream) {
+                              uint32_t N, uint32_t K, float *d_partial, float *d_a_colsum, void *stream) {
   if (!d_A || !d_B || !d_C || !d_partial) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f32: null argument");
   if (N == 0 || K == 0) return SG_OK;
   if (N > 256 || K > 256 || (N & 3) || (K & 3))
@@ -863,19 +876,19 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
   // K > 128 only.  Also measured and dropped: the row-tile copies three steps ahead in a four-buffer ring with counted
   // waits (235 us: HBM latency is not what holds the step either).
   const char *coop_env = getenv("SHADOW_GEMM_TN_COOP");
-  const bool coop = coop_env ? coop_env[0] != '0' : K > 128;
+  const bool coop = d_a_colsum || (coop_env ? coop_env[0] != '0' : K > 128);     // (the column sums live in the cooperative kernel)
   if (coop) {
     const size_t ldsc = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * 2 * 3 * 8 * 64 * 16;     // 64 KB row tiles + 96 KB fragment images
     if (K <= 128) {
       SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<2>, ldsc));
-      hipLaunchKernelGGL((gemm_tn_coop_kernel<2>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg);
+      hipLaunchKernelGGL((gemm_tn_coop_kernel<2>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
     } else {
       SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<4>, ldsc));
-      hipLaunchKernelGGL((gemm_tn_coop_kernel<4>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg);
+      hipLaunchKernelGGL((gemm_tn_coop_kernel<4>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
     }
     SHD_HIP(hipGetLastError());
-    const uint32_t NKc = N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NKc + 63) / 64), dim3(256), 0, st, d_partial, G, NKc, d_C);
+    const uint32_t NKc = N * K + (d_a_colsum ? N : 0u);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NKc + 63) / 64), dim3(256), 0, st, d_partial, G, NKc, d_C, N * K, d_a_colsum);
     SHD_HIP(hipGetLastError());
     return SG_OK;
   }
@@ -891,7 +904,7 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
   }
   SHD_HIP(hipGetLastError());
   const uint32_t NK = N * K;
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, 0u, (float *)nullptr);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -38,6 +38,8 @@ struct FusedDesc {
   // GEMM: C[M, N] = A_p[M, K] . B_p[N, K]^T for the phases p < NBP; the B images lie back to back
   const float *A[2];
   int64_t lda[2];
+  uint32_t asplit;                  // plain single product (MODE 2, one phase): units [asplit, units) of A come from A[1] (K-concatenated operand in two tensors); = units otherwise
+  const float *cbias[2];            // MODE 2: per-column bias added to product b when it leaves (may be NULL)
   const float *aamax[2];            // largest magnitude of every row of A_p, [M]: the power-of-two row scale follows from it (gemm_common.h)
   const half8 *Bimg;                // the NBP fp16 images back to back ...
   const float *btrail[2];           // ... and the trailer of each: [32 TW] column scales, [32 TW] inverses
@@ -400,6 +402,17 @@ __device__ __forceinline__ void unscale_tile(f32x16 (&acc)[TW], float ainv, cons
   }
 }
 
+// nn.Linear's bias on a plain product's tile (lane (r, g) holds column 32 t + r of tile t)
+template <int TW>
+__device__ __forceinline__ void add_bias_tile(f32x16 (&acc)[TW], const float *__restrict__ bias, uint32_t N, uint32_t r) {
+#pragma unroll
+  for (int t = 0; t < TW; t++) {
+    const float bv = 32 * t + r < N ? bias[32 * t + r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[t][i] += bv;
+  }
+}
+
 // TW column tiles (N <= 32 TW); MODE 0 forward / 1 backward; NBP GEMM phases; NBA act_norm branches;
 // kTail: K % 32 != 0 (the last unit of a phase is zero-padded).  Main loop = gemm_nt_split_kernel<1, TW, 1, 4>.
 template <int TW, int MODE, int NBP, int NBA, bool kTail>
@@ -418,23 +431,24 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   const uint64_t m0 = (uint64_t)blockIdx.x * 128u + wv * 32u;
   const uint64_t arow_i = min(m0 + r, (uint64_t)M - 1);  // rows past the end repeat the last row (never stored)
   const float *arow0 = d.A[0] + arow_i * d.lda[0] + 16 * g;
-  const float *arow1 = NBP == 2 ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
+  const float *arow1 = (NBP == 2 || (MODE == 2 && d.A[1])) ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
   const uint32_t gunits = NBP * units, steps = 2 * gunits;
   // Scale of this lane's row in a phase: from the row maxima the operand's producer left behind, or -- no array given: the
   // small batches, whose operands sit in the L2 and whose steps are bound by the host's launch rate -- from one more read
   // of the row (the two lanes that share a row hold its two 16-column halves of every unit).
   auto phase_scale = [&](int ph) -> float {
     if (d.aamax[ph]) return row_scale_of(d.aamax[ph][arow_i]);
-    const float *base = ph ? arow1 : arow0;
     float mx = 0.f;
     for (uint32_t u = 0; u < units; u++) {
+      const bool second = MODE == 2 && NBP == 1 && u >= d.asplit;
+      const float *base = (ph || second ? arow1 : arow0) + 32 * (second ? u - d.asplit : u);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if (!kTail || 32 * u + 32 <= K) {
-          mx = fmaxf(mx, amax4(*reinterpret_cast<const float4 *>(base + 32 * u + 4 * q)));
+          mx = fmaxf(mx, amax4(*reinterpret_cast<const float4 *>(base + 4 * q)));
         } else {
 #pragma unroll
-          for (int c = 0; c < 4; c++) { const uint32_t k = 32 * u + 16 * g + 4 * q + c; if (k < K) mx = fmaxf(mx, fabsf(base[32 * u + 4 * q + c])); }
+          for (int c = 0; c < 4; c++) { const uint32_t k = 32 * u + 16 * g + 4 * q + c; if (k < K) mx = fmaxf(mx, fabsf(base[4 * q + c])); }
         }
       }
     }
@@ -453,7 +467,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   auto load_a_piece = [&](uint32_t gu, int q) {
     const bool ph = NBP == 2 && gu >= units;
     const uint32_t u = ph ? gu - units : gu;
-    const float *ptr = (ph ? arow1 : arow0) + 32 * u + 4 * q;
+    const bool second = MODE == 2 && NBP == 1 && u >= d.asplit;      // (the K-concatenated operand's second tensor)
+    const float *ptr = (ph || second ? arow1 : arow0) + 32 * (second ? u - d.asplit : u) + 4 * q;
     if (!kTail || 32 * u + 32 <= K) {
       an[q] = *reinterpret_cast<const float4 *>(ptr);
     } else {
@@ -583,6 +598,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       uint32_t rows_ok = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0))), cols_ok = d.N;
       asm volatile("" : "+s"(rows_ok), "+s"(cols_ok));
       unscale_tile<TW>(acc, 1.0f / asc, d.btrail[0] + 32 * TW, g, r);
+      if (MODE == 2 && d.cbias[0]) add_bias_tile<TW>(acc, d.cbias[0], d.N, r);
       asc = phase_scale(1);
       store_tile(d.Z[0], d.ldz[0], (2 * gu + 1) % 3u, rows_ok, cols_ok);
 #pragma unroll
@@ -599,6 +615,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   if constexpr (MODE == 2) {
     // plain product(s): the last tile leaves the same way (the ring is dead: every wavefront passed the last step's barrier)
     unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
+    if (d.cbias[NBP - 1]) add_bias_tile<TW>(acc, d.cbias[NBP - 1], d.N, r);
     store_tile(d.Z[NBP - 1], d.ldz[NBP - 1], 0u, (uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0)), d.N);
   } else {
   // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier).  Specialised for the two activations
@@ -737,7 +754,7 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
   set_images(p, d_packed_B, nb, N, K);
   if (!al16(d_scale) || !al16(d_offset) || !al16(d_out) || (ldo & 3))
     return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: scale / offset / out must be 16-byte aligned, ldo %% 4 == 0");
-  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32;
+  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
   p.out = d_out; p.ldo = ldo; p.out_amax = d_out_amax;
   int rc;
@@ -753,9 +770,11 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
   return nb == 1 ? launch_fused<8, 0, 1, 1>(p, st) : launch_fused<8, 0, 2, 2>(p, st);
 }
 
-// Plain products on the same kernel (no epilogue arithmetic): C_b = A_b . W_b^T for b < nb <= 2 in one launch.
+// Plain products on the same kernel (no epilogue arithmetic beyond an optional bias): C_b = A_b . W_b^T + bias_b for
+// b < nb <= 2 in one launch.
 extern "C" int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,
-                               uint32_t M, uint32_t N, uint32_t K, float *const *d_C, const int64_t *ldc, void *stream) {
+                               uint32_t M, uint32_t N, uint32_t K, const float *const *d_bias, float *const *d_C, const int64_t *ldc,
+                               void *stream) {
   if (nb < 1 || nb > 2 || !d_A || !lda || !d_packed_B || !d_C || !ldc) return set_error(SG_ERR_INVALID, "sl_gemm_nt2_f32: bad argument");
   if (M == 0) return SG_OK;
   if (N < 16 || N > 256 || (N & 3) || K == 0)
@@ -767,12 +786,33 @@ extern "C" int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *l
     if ((lda[b] & 3) || !al16(d_A[b]) || (ldc[b] & 3) || !al16(d_C[b]))
       return set_error(SG_ERR_INVALID, "sl_gemm_nt2_f32: operands must be 16-byte aligned with ld %% 4 == 0");
     p.A[b] = d_A[b]; p.lda[b] = lda[b]; p.Z[b] = d_C[b]; p.ldz[b] = ldc[b]; p.aamax[b] = d_a_amax ? d_a_amax[b] : nullptr;
+    p.cbias[b] = d_bias ? d_bias[b] : nullptr;
   }
   set_images(p, d_packed_B, nb, N, K);
-  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32;
+  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
   hipStream_t st = (hipStream_t)stream;
   if (N <= 128) return nb == 1 ? launch_fused<4, 2, 1, 1>(p, st) : launch_fused<4, 2, 2, 1>(p, st);
   return nb == 1 ? launch_fused<8, 2, 1, 1>(p, st) : launch_fused<8, 2, 2, 1>(p, st);
+}
+
+// C = [A0 | A1] . B^T with the K-concatenated operand in two tensors (K0 columns from A0, K - K0 from A1; K0 % 32 == 0);
+// d_packed_B = sl_gemm_act_norm_pack_b2 of the matching concatenated weight.  d_a_amax: max over BOTH parts of a row (or NULL).
+extern "C" int sl_gemm_nt_cat_f32(const float *d_A0, int64_t lda0, uint32_t K0, const float *d_A1, int64_t lda1, const float *d_a_amax,
+                                  const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K, const float *d_bias, float *d_C,
+                                  int64_t ldc, void *stream) {
+  if (!d_A0 || !d_A1 || !d_packed_B || !d_C) return set_error(SG_ERR_INVALID, "sl_gemm_nt_cat_f32: null argument");
+  if (M == 0) return SG_OK;
+  if (N < 16 || N > 256 || (N & 3) || K0 == 0 || K0 >= K || (K0 & 31))
+    return set_error(SG_ERR_INVALID, "sl_gemm_nt_cat_f32: N = %u, K0 = %u of K = %u (N %% 4 == 0 in [16, 256], K0 %% 32 == 0)", N, K0, K);
+  if ((lda0 & 3) || !al16(d_A0) || (lda1 & 3) || !al16(d_A1) || (ldc & 3) || !al16(d_C))
+    return set_error(SG_ERR_INVALID, "sl_gemm_nt_cat_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  FusedDesc p;
+  memset(&p, 0, sizeof(p));
+  p.A[0] = d_A0; p.lda[0] = lda0; p.A[1] = d_A1; p.lda[1] = lda1; p.Z[0] = d_C; p.ldz[0] = ldc; p.aamax[0] = d_a_amax; p.cbias[0] = d_bias;
+  set_images(p, d_packed_B, 1, N, K);
+  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = K0 / 32;
+  hipStream_t st = (hipStream_t)stream;
+  return N <= 128 ? launch_fused<4, 2, 1, 1>(p, st) : launch_fused<8, 2, 1, 1>(p, st);
 }
 
 extern "C" size_t sl_gemm_an_bwd_partial_floats(uint32_t M, uint32_t N, int nb) {
@@ -811,7 +851,7 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_am
     p.bias[b] = d_bias ? d_bias[b] : nullptr;
   }
   if (!al16(d_scale) || !al16(d_offset)) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: scale / offset must be 16-byte aligned");
-  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32;
+  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
   p.partial = d_partial; p.dz_amax = d_dz0_amax;
   int rc;

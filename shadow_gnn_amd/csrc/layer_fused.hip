@@ -59,7 +59,7 @@ int nt_gemm(const float *A, int64_t lda, const void *pk, float *Cm, int64_t ldc,
 
 int tn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm, uint32_t M, uint32_t N, uint32_t K, float *partial, void *st) {
   SHD_PROF_FMT(4.0 * M * (N + K), 2.0 * M * N * K, st, "gemm_tn_split_N%u%s", N, K <= 128 ? "_K128" : "");
-  return sl_gemm_tn_f32(A, lda, B, ldb, Cm, M, N, K, partial, st);
+  return sl_gemm_tn_f32(A, lda, B, ldb, Cm, M, N, K, partial, nullptr, st);
 }
 
 // the GEMM-epilogue forms (gemm_fused.hip) take 16-byte aligned operands with row pitches of whole float4s
@@ -127,10 +127,8 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
   if ((rc = nt_gemm(d_AX, ldax, pk + pb, d_Zn, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;
   const float *Z[2] = {d_Zs, d_Zn};
   SHD_PROF_FMT((2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_fwd_nb%d_F%u", 2, Fout);
-  if ((rc = sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
-                            d_out_dropped, Fout, stream)) != SG_OK)
-    return rc;
-  return d_out_amax ? sl_row_amax(d_out_dropped ? d_out_dropped : d_out, Fout, n, Fout, d_out_amax, stream) : SG_OK;
+  return sl_act_norm_fwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed, d_out_dropped,
+                         Fout, d_out_amax, stream);
 }
 
 extern "C" size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F) { return sl_gemm_an_bwd_partial_floats(n, F, 2); }
@@ -214,7 +212,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       const float *am1[1] = {hand ? amx : nullptr};
       float *C1[1] = {d_dX};
       SHD_PROF_FMT(4.0 * n * (2.0 * Fout + Fin), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_nt_f16_N%u", Fin);
-      if ((rc = sl_gemm_nt2_f32(1, A1, lda1, am1, d_pack, n, Fin, 2 * Fout, C1, ldc1, stream)) != SG_OK) return rc;
+      if ((rc = sl_gemm_nt2_f32(1, A1, lda1, am1, d_pack, n, Fin, 2 * Fout, nullptr, C1, ldc1, stream)) != SG_OK) return rc;
     } else if ((rc = nt_gemm(d_buf, ld3, d_pack, d_dX, Fin, n, Fin, 2 * Fout, stream)) != SG_OK) {
       return rc;
     }
@@ -283,7 +281,7 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
   const float *Z[1] = {d_Z};
   SHD_PROF_FMT((1 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_fwd_nb%d_F%u", 1, Fout);
   return sl_act_norm_fwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_out, Fout, drop_p, drop_seed,
-                         d_out_dropped, Fout, stream);
+                         d_out_dropped, Fout, nullptr, stream);
 }
 
 extern "C" int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t ldax, const float *d_Z, uint32_t Fin, uint32_t Fout,

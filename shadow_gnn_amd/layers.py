@@ -430,8 +430,7 @@ class GAT(shaDowLayer):
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self._adj_norm(adj, is_normed, feat_in.device, dropedge=dropedge)
         feat_in = self.in_dropout(feat_in)
-        z_self = ops.linear(feat_in, self.f_lin[0])
-        z_neigh = ops.linear(feat_in, self.f_lin[1])
+        z_self, z_neigh = ops.linear_pair(feat_in, self.f_lin[0], self.f_lin[1])     # (one launch for both transforms)
         if self.act is not None:
             z_self, z_neigh = self.act(z_self), self.act(z_neigh)
         # neigh branch: act -> per-head attention aggregate; both branches normalised per head slice

@@ -520,13 +520,18 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
     n, F = Zs[0].shape
     out = torch.empty(n, F, dtype=torch.float32, device=Zs[0].device)
     out2 = torch.empty_like(out) if _is_dual(drop) else None
+    # (tall outputs: the row maxima for the fp16 products of the layer that reads them, written in the same pass)
+    amax = torch.empty(n, dtype=torch.float32, device=out.device) if (n >= AMAX_HANDOVER_ROWS and out.is_cuda) else None
     ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
     ac = (C.c_int * nb)(*codes)
     with _timed(f"act_norm_fwd_nb{nb}_F{F}", (nb + 1) * 4 * n * F, out.device):
         check(_lib.load().sl_act_norm_fwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
                                           n, F, seg, out_scale, out.data_ptr(), out.stride(0), float(drop[0]),
                                           int(drop[1]), out2.data_ptr() if out2 is not None else None,
-                                          out2.stride(0) if out2 is not None else 0, _stream(out)))
+                                          out2.stride(0) if out2 is not None else 0,
+                                          amax.data_ptr() if amax is not None else None, _stream(out)))
+    if amax is not None:
+        set_row_amax(out2 if out2 is not None else out, amax)
     return out if out2 is None else (out, out2)
 
 
@@ -629,11 +634,13 @@ def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Cm
 
 
-def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
+def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False):
     """dW = dZ^T X for tall inputs (K = number of batch nodes, hundreds of thousands).
     rocBLAS picks a 32-workgroup kernel for a plain 256 x n x 256 product; splitting n
     into a batched GEMM fills the chip (2x faster on MI355X) and the partial sums add
-    in a fixed order."""
+    in a fixed order.  ``want_colsum``: returns (dW, dZ.sum(0)) -- nn.Linear's bias gradient from the same pass over dZ."""
+    if want_colsum:
+        return _weight_grad_colsum(dZ, X)
     n, Fo = dZ.shape
     Fi = X.shape[1]
     if (GEMM_SPLIT and dZ.is_cuda and n >= GEMM_SPLIT_MIN_ROWS and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
@@ -645,7 +652,7 @@ def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
         dW = torch.empty(Fo, Fi, dtype=torch.float32, device=dZ.device)
         with _timed(f"gemm_tn_split_N{Fo}" + ("_K128" if Fi <= 128 else ""), 4 * n * (Fo + Fi), dZ.device, flops=2 * n * Fo * Fi):
             check(lib.sl_gemm_tn_f32(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), n, Fo, Fi,
-                                     partial.data_ptr(), _stream(dZ)))
+                                     partial.data_ptr(), None, _stream(dZ)))
         return dW
     if n < 32768:
         return dZ.t() @ X
@@ -656,6 +663,107 @@ def weight_grad(dZ: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
     if S * c < n:
         dW += dZ[S * c:].t() @ X[S * c:]
     return dW
+
+
+def _tn_usable(dZ, X) -> bool:
+    n, Fo = dZ.shape
+    Fi = X.shape[1]
+    return (GEMM_SPLIT and dZ.is_cuda and n >= GEMM_SPLIT_MIN_ROWS and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
+            and dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.stride(1) == 1 and X.stride(1) == 1
+            and dZ.stride(0) % 4 == 0 and X.stride(0) % 4 == 0 and dZ.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0)
+
+
+def _weight_grad_colsum(dZ, X):
+    if not _tn_usable(dZ, X):
+        return weight_grad(dZ, X), dZ.sum(0)
+    n, Fo = dZ.shape
+    Fi = X.shape[1]
+    lib = _lib.load()
+    G = lib.sl_gemm_tn_slices(n)
+    partial = torch.empty(G * (Fo * Fi + Fo), dtype=torch.float32, device=dZ.device)
+    dW = torch.empty(Fo, Fi, dtype=torch.float32, device=dZ.device)
+    db = torch.empty(Fo, dtype=torch.float32, device=dZ.device)
+    with _timed(f"gemm_tn_split_N{Fo}" + ("_K128" if Fi <= 128 else ""), 4 * n * (Fo + Fi), dZ.device, flops=2 * n * Fo * Fi):
+        check(lib.sl_gemm_tn_f32(dZ.data_ptr(), dZ.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), n, Fo, Fi,
+                                 partial.data_ptr(), db.data_ptr(), _stream(dZ)))
+    return dW, db
+
+
+class _LinearPair(torch.autograd.Function):
+    """Two nn.Linear of the SAME input -- GAT's self / neighbour transforms (shaDow/layers.py:604-611) -- as one autograd
+    node on the fp16 two-piece kernels: forward = ONE two-product launch that reads X once per product and adds the
+    biases as the tiles leave (sl_gemm_nt2_f32); backward: dX = [dZa | dZb] . [Wa ; Wb] as ONE K-concatenated product
+    straight from the two gradient tensors (sl_gemm_nt_cat_f32: no dXa + dXb pass), the bias gradients from the
+    weight-gradient kernel's pass over dZ (column sums of its A tiles)."""
+    @staticmethod
+    def usable(X, Wa, Wb) -> bool:
+        M, K = X.shape
+        N = Wa.shape[0]
+        return (GEMM_SPLIT and X.is_cuda and M >= GEMM_SPLIT_MIN_ROWS and Wa.shape == Wb.shape and X.dtype == torch.float32
+                and Wa.dtype == torch.float32 and N % 32 == 0 and N <= 256 and K % 4 == 0 and 16 <= K <= 256
+                and bool(_lib.load().sl_gemm_act_norm_supported(N, K)))
+
+    @staticmethod
+    def forward(ctx, X, Wa, ba, Wb, bb):
+        X = _f32c(X)
+        if X.stride(0) % 4 or X.data_ptr() % 16:
+            X = X.contiguous()
+        lib = _lib.load()
+        M, K = X.shape
+        N = Wa.shape[0]
+        dev, st = X.device, _stream(X)
+        Ws = [w.detach() if w.stride(1) == 1 else w.detach().contiguous() for w in (Wa, Wb)]
+        pack = torch.empty(2 * lib.sl_gemm_act_norm_pack_bytes(N, K), dtype=torch.uint8, device=dev)
+        check(lib.sl_gemm_act_norm_pack(2, _ptr_array(Ws), (C.c_int64 * 2)(*[w.stride(0) for w in Ws]), N, K, pack.data_ptr(), None, 0, st))
+        am = get_row_amax(X)
+        if am is None and M >= AMAX_HANDOVER_ROWS:
+            am = row_amax(X)
+        Zs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(2)]
+        bs = [b.detach().contiguous() if b is not None else None for b in (ba, bb)]
+        with _timed(f"gemm_nt2_f16_N{N}" + ("" if K % 32 == 0 else "_Ktail"), 4 * M * (K + 2 * N), dev, flops=2 * 2 * M * K * N):
+            check(lib.sl_gemm_nt2_f32(2, _ptr_array([X, X]), (C.c_int64 * 2)(X.stride(0), X.stride(0)), _ptr_array([am, am]), pack.data_ptr(),
+                                      M, N, K, _ptr_array(bs), _ptr_array(Zs), (C.c_int64 * 2)(N, N), st))
+        ctx.save_for_backward(X, Wa, Wb)
+        ctx.has_bias = (ba is not None, bb is not None)
+        ctx.set_materialize_grads(False)
+        return Zs[0], Zs[1]
+
+    @staticmethod
+    def backward(ctx, dZa, dZb):
+        X, Wa, Wb = ctx.saved_tensors
+        lib = _lib.load()
+        M, K = X.shape
+        N = Wa.shape[0]
+        dev, st = X.device, _stream(X)
+        dZs = [(_f32c(d).contiguous() if d is not None else torch.zeros(M, N, dtype=torch.float32, device=dev)) for d in (dZa, dZb)]
+        ng = ctx.needs_input_grad
+        dX = None
+        if ng[0]:
+            # image of [Wa^T | Wb^T]: "row" j = input feature j, K-concatenated over the two branches' outputs
+            pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(K, 2 * N), dtype=torch.uint8, device=dev)
+            wa, wb = Wa.detach(), Wb.detach()
+            check(lib.sl_gemm_act_norm_pack_b2(wa.data_ptr(), wa.stride(1), wa.stride(0), N, wb.data_ptr(), wb.stride(1), wb.stride(0),
+                                               K, 2 * N, pack.data_ptr(), st))
+            dX = torch.empty(M, K, dtype=torch.float32, device=dev)
+            with _timed(f"gemm_nt_f16_N{K}", 4 * M * (2 * N + K), dev, flops=2 * M * 2 * N * K):
+                check(lib.sl_gemm_nt_cat_f32(dZs[0].data_ptr(), dZs[0].stride(0), N, dZs[1].data_ptr(), dZs[1].stride(0), None,
+                                             pack.data_ptr(), M, K, 2 * N, None, dX.data_ptr(), dX.stride(0), st))
+        out = [dX, None, None, None, None]
+        for i, (dz, hb) in enumerate(zip(dZs, ctx.has_bias)):
+            want_w, want_b = ng[1 + 2 * i], hb and ng[2 + 2 * i]
+            if want_b:
+                dW, db = weight_grad(dz, X, want_colsum=True)
+                out[1 + 2 * i], out[2 + 2 * i] = (dW if want_w else None), db
+            elif want_w:
+                out[1 + 2 * i] = weight_grad(dz, X)
+        return tuple(out)
+
+
+def linear_pair(X, lin_a: "torch.nn.Linear", lin_b: "torch.nn.Linear"):
+    """(lin_a(X), lin_b(X)); one fused node when the shapes allow (see _LinearPair), two ``linear`` nodes otherwise."""
+    if isinstance(X, torch.Tensor) and X.dim() == 2 and _LinearPair.usable(X, lin_a.weight, lin_b.weight):
+        return _LinearPair.apply(X, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
+    return linear(X, lin_a), linear(X, lin_b)
 
 
 class _Linear(torch.autograd.Function):

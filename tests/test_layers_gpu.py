@@ -837,7 +837,7 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         assert not any(k.startswith("act_norm_fwd") and k.endswith("F256") for k in ran), ran
     if aggr == "gcn":
         assert any(k.startswith("gemm_act_norm_fwd_nb1") for k in ran), ran
-    assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
+    assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd", "gemm_nt2_f16")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
     # ---- fp64 oracle, same parameters (relu: with the run's own side at the kink, see the docstring)
     relu_keep, kstats = None, {}
     if act == "relu" and aggr in ("sage", "gcn"):
@@ -1189,10 +1189,14 @@ def test_plain_fp16_split_products(nb, M, K, N, shared):
     am = [ops.row_amax(a) if M >= ops.AMAX_HANDOVER_ROWS else None for a in As]
     bases = [torch.full((M, N + 4), 7.0, device=DEV) for _ in range(nb)]
     Cs = [b[:, :N] for b in bases]
+    bias = [torch.randn(N, device=DEV, generator=g) if b == 0 else None for b in range(nb)]      # (product 0 with nn.Linear's bias)
     _lib.check(lib.sl_gemm_nt2_f32(nb, ops._ptr_array(As), (C.c_int64 * nb)(*[a.stride(0) for a in As]), ops._ptr_array(am),
-                                   pack.data_ptr(), M, N, K, ops._ptr_array(Cs), (C.c_int64 * nb)(*[c.stride(0) for c in Cs]), st))
-    for a, w, c, b in zip(As, Ws, Cs, bases):
+                                   pack.data_ptr(), M, N, K, ops._ptr_array(bias), ops._ptr_array(Cs),
+                                   (C.c_int64 * nb)(*[c.stride(0) for c in Cs]), st))
+    for a, w, c, b, bi in zip(As, Ws, Cs, bases, bias):
         ref, den = a.double() @ w.double().t(), a.abs().double() @ w.abs().double().t()
+        if bi is not None:
+            ref, den = ref + bi.double(), den + bi.abs().double()
         assert float(((c.double() - ref).abs() / den).max()) < 1.5e-6
         assert float(b[:, N:].min()) == 7.0 and float(b[:, N:].max()) == 7.0      # nothing written past the N columns
 
@@ -1233,3 +1237,30 @@ def test_spmm_over_merged_small_subgraphs_is_bit_identical(F, monkeypatch):
     dense[rows, csr.indices.long()] = w.double()
     want = (rs.double()[:, None] * dense * cs.double()[None, :]) @ X.double()
     torch.testing.assert_close(merged.double(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(9001, 256, 256), (40000, 100, 256), (8300, 64, 128)])
+def test_linear_pair_matches_fp64_autograd(M, K, N):
+    """ops.linear_pair: the two Linears of one input (GAT's self / neighbour transforms) as one node -- two-product fp16
+    launch with the biases added as the tiles leave, dX from ONE K-concatenated product over the two gradient tensors,
+    bias gradients from the weight-gradient kernel's column sums -- against torch autograd in fp64.  Tall operand with row
+    maxima (40000 rows) and small ones where the kernel finds them itself; K = 100 in a 128-float pitch."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    pitch = (K + 31) // 32 * 32
+    X = (torch.randn(M, pitch, device=DEV, generator=g)[:, :K] * torch.exp(torch.randn(M, 1, device=DEV, generator=g))).requires_grad_(True)
+    la, lb = torch.nn.Linear(K, N).to(DEV), torch.nn.Linear(K, N).to(DEV)
+    assert ops._LinearPair.usable(X, la.weight, lb.weight)
+    Ga, Gb = torch.randn(M, N, device=DEV, generator=g), torch.randn(M, N, device=DEV, generator=g)
+    za, zb = ops.linear_pair(X, la, lb)
+    ((za * Ga).sum() + (zb * Gb).sum()).backward()
+    got = [za.detach(), zb.detach(), X.grad.clone(), la.weight.grad.clone(), la.bias.grad.clone(), lb.weight.grad.clone(), lb.bias.grad.clone()]
+    Xd = X.detach().double().requires_grad_(True)
+    Wa, ba, Wb, bb = [t.detach().double().requires_grad_(True) for t in (la.weight, la.bias, lb.weight, lb.bias)]
+    ra, rb = Xd @ Wa.t() + ba, Xd @ Wb.t() + bb
+    ((ra * Ga.double()).sum() + (rb * Gb.double()).sum()).backward()
+    want = [ra.detach(), rb.detach(), Xd.grad, Wa.grad, ba.grad, Wb.grad, bb.grad]
+    for name, a, b in zip(["za", "zb", "dX", "dWa", "dba", "dWb", "dbb"], got, want):
+        scale = float(b.abs().max())
+        assert float((a.double() - b).abs().max()) <= 2e-5 * scale, name
