@@ -582,13 +582,17 @@ int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float 
 /* Backward: dz_self (attention part only), dz_neigh, datt[2,heads,D].
  * d_work: float[2*e*heads + n*heads + 4096*F] (per-edge alpha / de, du_s, and the per-block partial sums of
  * datt, which are added in block order: no float atomics, bit-reproducible).                */
+/* accumulate_dz_self != 0: d_dz_self already holds the share of z_self's gradient that came through the layer's own
+ * act_norm branch (z_self feeds the attention scores AND the normalised output) -- the kernel adds to it instead of
+ * overwriting; d_row_amax (may be NULL): receives max_k over the final dz_self AND dz_neigh rows (the operand scale of the
+ * K-concatenated input-gradient product, sl_gemm_nt_cat_f32).                                                          */
 int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
                const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
                const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
                uint32_t e, uint32_t F, uint32_t heads, const float *d_hn, const float *d_u_s,
                const float *d_u_n, const float *d_mx, const float *d_den, const float *d_nagg,
                const float *d_dnagg, float *d_work, float *d_dz_self, float *d_dz_neigh, float *d_datt,
-               void *stream);
+               int accumulate_dz_self, float *d_row_amax, void *stream);
 
 /* Development aid: per-subgraph result words of the last sg_sample call,
  * 16 uint32 per subgraph: {nodes, edges, flags, stream slots, frontier nodes,

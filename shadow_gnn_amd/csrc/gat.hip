@@ -98,6 +98,8 @@ struct GatParams {
   float *alpha, *de;                      // [e, H]
   float *du_s;                            // [n, H]
   float *dz_self, *dz_neigh;              // [n, F]
+  int acc_self;                           // dz_self already holds the act_norm branch's share of the gradient: add to it
+  float *row_amax;                        // optional [n]: max |.| over the final dz_self and dz_neigh rows (sl_row_amax)
   float *datt;                            // [2, H, D]
   float *datt_part;                       // [gridDim.x][2][F] per-block sums, reduced in block order (gat_datt_finish_kernel)
 };
@@ -189,14 +191,24 @@ __global__ void gat_row_bwd_kernel(GatParams p) {
       if (on && (l % ls) == 0) { p.alpha[(uint64_t)q * p.H + h] = alpha; p.de[(uint64_t)q * p.H + h] = de; }
     }
     const float dus = das * dlrelu02(usr);
+    float rmax = 0.f;
     if (on) {
       if ((l % ls) == 0) p.du_s[r * p.H + h] = dus;
       const float4 z = gld4(p.z_self + r * p.F + f);
       const float4 hs = act4(p.act, z);
-      gst4(p.dz_self + r * p.F + f,
-           make_float4(dus * a0.x * g_act_bwd(p.act, z.x, hs.x), dus * a0.y * g_act_bwd(p.act, z.y, hs.y),
-                       dus * a0.z * g_act_bwd(p.act, z.z, hs.z), dus * a0.w * g_act_bwd(p.act, z.w, hs.w)));
+      float4 dzv = make_float4(dus * a0.x * g_act_bwd(p.act, z.x, hs.x), dus * a0.y * g_act_bwd(p.act, z.y, hs.y),
+                               dus * a0.z * g_act_bwd(p.act, z.z, hs.z), dus * a0.w * g_act_bwd(p.act, z.w, hs.w));
+      if (p.acc_self) {                  // (z_self also feeds the layer's act_norm: its gradient share is here already)
+        const float4 o = gld4(p.dz_self + r * p.F + f);
+        dzv.x += o.x; dzv.y += o.y; dzv.z += o.z; dzv.w += o.w;
+      }
+      gst4(p.dz_self + r * p.F + f, dzv);
+      rmax = shadow::amax4(dzv);
       g0.x += dus * hs.x; g0.y += dus * hs.y; g0.z += dus * hs.z; g0.w += dus * hs.w;
+    }
+    if (p.row_amax) {                    // (the LPR lanes of a row group share r)
+      rmax = shadow::group_max<LPR>(rmax);
+      if (l == 0) p.row_amax[r] = rmax;
     }
   }
   // datt[0] += sum over this block's rows
@@ -224,7 +236,7 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     const uint32_t a = p.t_indptr[r], b = p.t_indptr[r + 1];
     float4 acc = make_float4(0, 0, 0, 0);
-    float dan = 0.f;
+    float dan = 0.f, rmax = 0.f;
     for (uint32_t q = a; q < b; q++) {
       const uint32_t src = p.t_indices[q], pe = p.t_perm[q];
       const float alpha = p.alpha[(uint64_t)pe * p.H + h];
@@ -239,10 +251,15 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
       const float4 z = gld4(p.z_neigh + r * p.F + f);
       const float4 hn = gld4(p.hn + r * p.F + f);
       acc.x += dun * a1.x; acc.y += dun * a1.y; acc.z += dun * a1.z; acc.w += dun * a1.w;
-      gst4(p.dz_neigh + r * p.F + f,
-           make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
-                       acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w)));
+      const float4 dzv = make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
+                                     acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w));
+      gst4(p.dz_neigh + r * p.F + f, dzv);
+      rmax = shadow::amax4(dzv);
       g1.x += dun * hn.x; g1.y += dun * hn.y; g1.z += dun * hn.z; g1.w += dun * hn.w;
+    }
+    if (p.row_amax) {                    // joined with the maximum the row pass left for dz_self's row
+      rmax = shadow::group_max<LPR>(rmax);
+      if (l == 0) p.row_amax[r] = fmaxf(p.row_amax[r], rmax);
     }
   }
   __shared__ float red[kGatBlock * 4];
@@ -355,7 +372,7 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
                           const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
                           const float *d_nagg, const float *d_dnagg, float *d_work, float *d_dz_self,
-                          float *d_dz_neigh, float *d_datt, void *stream_) {
+                          float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
   if (!d_indptr || !d_t_indptr || !d_z_self || !d_z_neigh || !d_att || !d_hn || !d_u_s || !d_u_n || !d_mx ||
       !d_den || !d_nagg || !d_dnagg || !d_work || !d_dz_self || !d_dz_neigh || !d_datt)
     return set_error(SG_ERR_INVALID, "sl_gat_bwd: null argument");
@@ -375,7 +392,7 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   // work: alpha[e*H], de[e*H], du_s[n*H], datt_part[2048][2][F]
   p.alpha = d_work; p.de = d_work + (size_t)e * heads; p.du_s = p.de + (size_t)e * heads;
   p.datt_part = p.du_s + (size_t)n * heads;
-  p.dz_self = d_dz_self; p.dz_neigh = d_dz_neigh; p.datt = d_datt;
+  p.dz_self = d_dz_self; p.dz_neigh = d_dz_neigh; p.datt = d_datt; p.acc_self = accumulate_dz_self; p.row_amax = d_row_amax;
   const uint32_t g = gat_grid(n, lpr);
   SHD_GAT_LAUNCH(gat_row_bwd_kernel, lpr, g, st, p);
   SHD_GAT_LAUNCH(gat_col_bwd_kernel, lpr, g, st, p);

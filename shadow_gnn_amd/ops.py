@@ -735,6 +735,9 @@ class _LinearPair(torch.autograd.Function):
         M, K = X.shape
         N = Wa.shape[0]
         dev, st = X.device, _stream(X)
+        # (row maxima of the K-concatenated operand: only when the kernel that wrote BOTH gradients left one joint array)
+        ama, amb = (get_row_amax(d) if d is not None else None for d in (dZa, dZb))
+        joint = ama if (ama is not None and amb is not None and ama.data_ptr() == amb.data_ptr()) else None
         dZs = [(_f32c(d).contiguous() if d is not None else torch.zeros(M, N, dtype=torch.float32, device=dev)) for d in (dZa, dZb)]
         ng = ctx.needs_input_grad
         dX = None
@@ -746,7 +749,8 @@ class _LinearPair(torch.autograd.Function):
                                                K, 2 * N, pack.data_ptr(), st))
             dX = torch.empty(M, K, dtype=torch.float32, device=dev)
             with _timed(f"gemm_nt_f16_N{K}", 4 * M * (2 * N + K), dev, flops=2 * M * 2 * N * K):
-                check(lib.sl_gemm_nt_cat_f32(dZs[0].data_ptr(), dZs[0].stride(0), N, dZs[1].data_ptr(), dZs[1].stride(0), None,
+                check(lib.sl_gemm_nt_cat_f32(dZs[0].data_ptr(), dZs[0].stride(0), N, dZs[1].data_ptr(), dZs[1].stride(0),
+                                             joint.data_ptr() if joint is not None else None,
                                              pack.data_ptr(), M, K, 2 * N, None, dX.data_ptr(), dX.stride(0), st))
         out = [dX, None, None, None, None]
         for i, (dz, hb) in enumerate(zip(dZs, ctx.has_bias)):

@@ -54,8 +54,87 @@ class _GatAggregate(torch.autograd.Function):
                                          w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
                                          att.data_ptr(), act_code, n, c.e, F, heads, hn.data_ptr(), u_s.data_ptr(),
                                          u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
-                                         work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), ops._stream(dnagg)))
+                                         work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 0, None,
+                                         ops._stream(dnagg)))
         return dzs, dzn, datt.reshape(att_shape), None, None, None
+
+
+class _GatTail(torch.autograd.Function):
+    """Attention aggregate AND the layer's act + feature normalisation (shaDow/layers.py:612-625) as one autograd node:
+        out = out_scale * (norm_0(N) + norm_1(act(z_self))),   N = the attention aggregate of (z_self, z_neigh).
+    z_self feeds both the attention scores and the normalised output; as two nodes autograd adds its two gradient shares
+    with a separate pass over [n, F].  Here the act_norm backward writes its share into the buffer the attention
+    backward then ADDS to (sl_gat_bwd, accumulate_dz_self), and the two kernels leave the row maxima of the final
+    (dz_self | dz_neigh) behind for the K-concatenated input-gradient product of ops._LinearPair."""
+    @staticmethod
+    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop):
+        z_self, z_neigh = ops._f32c(z_self).contiguous(), ops._f32c(z_neigh).contiguous()
+        att = attention.detach().float().contiguous()
+        ops._need_cuda(z_self, z_neigh, att, scale, offset)
+        n, F = z_self.shape
+        dev = z_self.device
+        c = adj.csr
+        hn = torch.empty(n, F, device=dev)
+        u_s = torch.empty(n, heads, device=dev); u_n = torch.empty(n, heads, device=dev)
+        mx = torch.empty(n, heads, device=dev); den = torch.empty(n, heads, device=dev)
+        nagg = torch.empty(n, F, device=dev)
+        w = adj.edge_w
+        nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 3 * 4 * n * F + 4 * 4 * n * heads
+        with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
+            check(_lib.load().sl_gat_fwd(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
+                                         z_self.data_ptr(), z_neigh.data_ptr(), att.data_ptr(), act_code, n, F, heads,
+                                         hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
+                                         nagg.data_ptr(), ops._stream(z_self)))
+        sc = scale.reshape(2, F).contiguous().float()
+        of = offset.reshape(2, F).contiguous().float()
+        # reference order: f_norm([neigh, self]) -> scale[0] = neigh (identity: the aggregate is activated already), scale[1] = self
+        out = ops._an_fwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, drop)
+        ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of)
+        ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape, seg, out_scale, drop, scale.shape, offset.shape)
+        ctx.set_materialize_grads(False)
+        ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
+        return out
+
+    @staticmethod
+    def backward(ctx, *dout):
+        z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of = ctx.saved_tensors
+        act_code, heads, att_shape, seg, out_scale, drop, sshape, oshape = ctx.meta
+        adj = ctx.adj
+        c = adj.csr
+        n, F = z_self.shape
+        dev = z_self.device
+        # act + norm backward: d aggregate and the normalised branch's share of dz_self
+        (dnagg, dzs), dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, dout, [True, True],
+                                                False, drop)
+        ti, tx, tp = c.transposed
+        work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
+        dzn = torch.empty_like(z_neigh)
+        datt = torch.empty(2, F, device=dev)
+        amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
+        w = adj.edge_w
+        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + 6 * 4 * n * F + 6 * 4 * n * heads
+        with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
+            check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
+                                         w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
+                                         att.data_ptr(), act_code, n, c.e, F, heads, hn.data_ptr(), u_s.data_ptr(),
+                                         u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
+                                         work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 1,
+                                         amax.data_ptr() if amax is not None else None, ops._stream(dnagg)))
+        if amax is not None:              # (ONE array for both gradients: the maximum over the pair of rows)
+            ops.set_row_amax(dzs, amax); ops.set_row_amax(dzn, amax)
+        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None)
+
+
+def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: int, scale, offset, seg: int, out_scale: float,
+             out_dropout: float = 0.0, dual: bool = False):
+    """out_scale * (norm(gat_aggregate(...)) + norm(act(z_self))) as one node (see _GatTail); None when the shape needs the
+    padded multi-launch aggregate (the caller then composes gat_aggregate and ops.act_norm)."""
+    n, F = z_self.shape
+    heads = int(heads)
+    if not (F <= 256 and F % heads == 0 and _fused_slice(F // heads) and z_self.is_cuda):
+        return None
+    drop = ops._drop_arg(out_dropout, F, seg, dual)
+    return _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop)
 
 
 def _fused_slice(D: int) -> bool:
