@@ -726,7 +726,7 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
     float x[8];
     lds_frag8(tile, 32 * wv + r, kg, x);
     // (column sums of A -- nn.Linear's bias gradient -- ride along: this wavefront sees every element of its 32 columns once)
-    if (op == 0) csum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    if (colsum && op == 0) csum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     bf16x8 h, m, l;
     split8(x, h, m, l);
     bf16x8 *dst = fimg + (size_t)(s & 1) * kImgVecs + ((size_t)op * 3 * 8 + wv) * 64 + lane;
