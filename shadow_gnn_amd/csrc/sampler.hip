@@ -911,7 +911,11 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     r.s_eid = p.s_eid; r.s_tgt = p.s_tgt; r.s_cnt = p.s_cnt; r.s_tmp = (uint32_t *)(sc + o_tmp);
     r.cstart = p.cstart; r.recs = p.recs; r.blkinfo = p.blkinfo; r.plan = p.plan; r.s_lcol = (uint32_t *)(sc + o_lcol);
     r.out = *out; r.d_counts = s->d_counts;
-    hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(256), 0, stream, r);
+    // one workgroup per subgraph: subgraphs of thousands of nodes (depth-3 k-hop) get 1024 threads for their edge walk and BFS
+    // (measured, 512 roots of the depth-3 benchmark: 0.27 ms at 256 threads)
+    static const int reloc_env = [] { const char *e = getenv("SHADOW_RELOC_THREADS"); return e ? atoi(e) : 0; }();
+    const uint32_t reloc_threads = reloc_env > 0 ? (uint32_t)reloc_env : (capn >= 2048 ? 1024u : 256u);
+    hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(reloc_threads), 0, stream, r);
     SHD_HIP(hipGetLastError());
     if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[2], stream));
     s->timed = s->profiling;
