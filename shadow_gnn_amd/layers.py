@@ -368,12 +368,23 @@ class ResPool(nn.Module):
         rows = torch.as_tensor(idx_targets, device=feats_in_l[-1].device).long()
         used = feats_in_l if self.type_res != 'none' else feats_in_l[-1:]       # residue 'none' reads the last layer
         merge = self.f_residue if self.type_res != 'none' else (lambda parts: parts[0])
-        at_roots = merge([f[rows] for f in used])
+        pooled = None
+        if self.type_pool in self.POOLED and self.dim_in != 0 and all(f.is_cuda for f in used):
+            # pooled read-out: every layer output is pooled AND read at the roots -- one node per output, one dense gradient
+            sizes = torch.as_tensor(sizes_subg, device=rows.device).reshape(-1)
+            off = torch.zeros(sizes.numel() + 1, dtype=torch.int32, device=rows.device)
+            off[1:] = torch.cumsum(sizes, dim=0)
+            pairs = [ops.pool_and_roots(f, off, rows, self.type_pool) for f in used]
+            at_roots, pooled = merge([p[1] for p in pairs]), merge([p[0] for p in pairs])
+        else:
+            at_roots = merge([f[rows] for f in used])
         if self.dim_in == 0:
             return at_roots                                                    # layers.py:159-163
         feat_in = self.aggr_target_emb(at_roots)
         if self.type_pool in self.POOLED:
-            feat_in = torch.cat([feat_in, merge([self._pool(f, sizes_subg) for f in used])], dim=1)
+            if pooled is None:
+                pooled = merge([self._pool(f, sizes_subg) for f in used])
+            feat_in = torch.cat([feat_in, pooled], dim=1)
         # dropout -> Linear -> act -> norm (layers.py:110,114-118,199)
         drop, lin, act_mod = self.nn[0], self.nn[1], self.nn[2]
         if self.act_name in LEARNED_ACT:

@@ -1385,6 +1385,52 @@ class _SegmentPool(torch.autograd.Function):
         return dX, None, None
 
 
+class _PoolAndRoots(torch.autograd.Function):
+    """(segment_pool(X), X[rows]) as ONE node: a read-out that pools every layer output AND reads its root rows
+    (shaDow/layers.py:154-199 with mean / max / sum pooling) would otherwise hand autograd two dense [n, F] gradients per
+    layer -- a zero-filled index_put and the pooling backward -- plus the pass that adds them.  Here the pooling backward
+    writes the dense gradient once and the few root rows are added in place."""
+    @staticmethod
+    def forward(ctx, X, node_off, rows, mode):
+        X = _f32c(X)
+        _need_cuda(X, node_off, rows)
+        P, F = int(node_off.numel()) - 1, int(X.shape[1])
+        out = torch.empty(P, F, dtype=torch.float32, device=X.device)
+        am = torch.empty(P, F, dtype=torch.int32, device=X.device) if mode == 1 else None
+        with _timed(f"segment_pool_F{F}", 4 * X.shape[0] * F + 4 * P * F, X.device):
+            check(_lib.load().sl_segment_pool_fwd(X.data_ptr(), X.stride(0), node_off.data_ptr(), P, F, mode,
+                                                  out.data_ptr(), out.stride(0),
+                                                  am.data_ptr() if am is not None else None, _stream(X)))
+        ctx.mode, ctx.n = mode, int(X.shape[0])
+        ctx.save_for_backward(node_off, am if am is not None else node_off, rows)
+        ctx.set_materialize_grads(False)
+        return out, X.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, dout, droots):
+        node_off, am, rows = ctx.saved_tensors
+        P = int(node_off.numel()) - 1
+        F = int((dout if dout is not None else droots).shape[1])
+        dev = node_off.device
+        if dout is not None:
+            dout = _f32c(dout)
+            dX = torch.empty(ctx.n, F, dtype=torch.float32, device=dev)
+            check(_lib.load().sl_segment_pool_bwd(dout.data_ptr(), dout.stride(0), node_off.data_ptr(), P, F, ctx.mode,
+                                                  am.data_ptr() if ctx.mode == 1 else None, dX.data_ptr(), dX.stride(0),
+                                                  _stream(dout)))
+        else:
+            dX = torch.zeros(ctx.n, F, dtype=torch.float32, device=dev)
+        if droots is not None:
+            dX.index_add_(0, rows, droots.to(dX.dtype))       # (the roots of a batch are distinct rows: no two adds meet)
+        return dX, None, None, None
+
+
+def pool_and_roots(X: torch.Tensor, node_off: torch.Tensor, rows: torch.Tensor, mode: str):
+    """(segment_pool(X, node_off, mode), X[rows]) with one dense gradient (see _PoolAndRoots)."""
+    assert node_off.dtype == torch.int32 and rows.dtype == torch.int64
+    return _PoolAndRoots.apply(X, node_off, rows, POOL_MODE[mode])
+
+
 def segment_pool(X: torch.Tensor, node_off: torch.Tensor, mode: str) -> torch.Tensor:
     """mean / max / sum of X over the rows of each subgraph; node_off = [P+1] int32 row offsets
     (F.embedding_bag over the subgraph offsets, shaDow/layers.py:166-183).  Rows must tile

@@ -1264,3 +1264,31 @@ def test_linear_pair_matches_fp64_autograd(M, K, N):
     for name, a, b in zip(["za", "zb", "dX", "dWa", "dba", "dWb", "dbb"], got, want):
         scale = float(b.abs().max())
         assert float((a.double() - b).abs().max()) <= 2e-5 * scale, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["mean", "max", "sum"])
+def test_pool_and_roots_equals_separate_ops(mode):
+    """ops.pool_and_roots: segment pooling and the root-row read of one layer output as one node -- values equal to
+    ops.segment_pool / X[rows]; the single dense gradient equals the sum autograd forms from the two separate ops."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(len(mode))
+    sizes = [37, 1, 250, 3, 64, 129, 18]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=DEV)
+    n, F = int(off[-1]), 96
+    rows = (off[:-1].long() + torch.tensor([0, 0, 17, 2, 63, 5, 9], device=DEV)).contiguous()
+    X0 = torch.randn(n, F, device=DEV, generator=g)
+    Gp, Gr = torch.randn(len(sizes), F, device=DEV, generator=g), torch.randn(len(sizes), F, device=DEV, generator=g)
+    Xa = X0.clone().requires_grad_(True)
+    pa, ra = ops.pool_and_roots(Xa, off, rows, mode)
+    ((pa * Gp).sum() + (ra * Gr).sum()).backward()
+    Xb = X0.clone().requires_grad_(True)
+    pb, rb = ops.segment_pool(Xb, off, mode), Xb[rows]
+    ((pb * Gp).sum() + (rb * Gr).sum()).backward()
+    assert torch.equal(pa, pb) and torch.equal(ra, rb)
+    torch.testing.assert_close(Xa.grad, Xb.grad, rtol=1e-6, atol=1e-6)
+    Xc = X0.clone().requires_grad_(True)                      # only the root rows are used downstream
+    _, rc = ops.pool_and_roots(Xc, off, rows, mode)
+    (rc * Gr).sum().backward()
+    want = torch.zeros_like(X0); want[rows] = Gr
+    assert torch.equal(Xc.grad, want)
