@@ -377,7 +377,10 @@ int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p, uint64_t drop_seed,
                     float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax, void *stream);
-/* Backward of the above (d_dz0_amax, may be NULL: receives max_k |dZ_0[i, k]| per row, see sl_row_amax): dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
+/* Backward of the above (d_dz0_amax, may be NULL: receives max_k |dZ_0[i, k]| per row, see sl_row_amax; d_row_idx, may be
+ * NULL: the output gradient is given for n SELECTED rows only -- d_dout / d_dout_dropped are [n, F] compact and row i of them
+ * belongs to row d_row_idx[i] of Z / dZ / the dropout mask: a read-out that takes a few rows of the layer's output; rows of
+ * dZ that are not selected are NOT written): dZ_b (entries may be NULL), dscale / doffset [nb, F] and,
  * when d_dbias != NULL, dbias [nb, F] = column sums of dZ_b (all overwritten,
  * reduced over the rows in a fixed order).
  * d_partial: float[2048 * nb * 3 * F] scratch for the two-stage reduction.
@@ -388,7 +391,8 @@ int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
                     const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
                     float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped,
-                    int64_t lddo_dropped, float *d_dz0_amax, void *stream);
+                    int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                    void *stream);
 
 /* A normalised batch adjacency  diag(row_scale) (A o edge_w) diag(col_scale)  as the layer entries below take it
  * (what ops.NormAdj holds): any of edge_w / row_scale / col_scale may be NULL (= ones); t_* = the transposed CSR
@@ -508,7 +512,9 @@ int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const v
  * names; the lower layer's own call then passes dz_ready = 1 (its d_buf = below->buf, its d_dzs_amax = below->amax;
  * d_dout*, d_dscale, d_doffset,
  * d_an_partial and the forward tensors Zs / Zn are not touched) and only runs A^T dZn, its own input-gradient product
- * and the two weight gradients.  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, stream).                             */
+ * and the two weight gradients.  d_dout_rows (may be NULL; dz_ready = 0 only): the output gradient is given for num_dout_rows
+ * selected rows only (d_dout / d_dout_dropped [num_dout_rows, Fout] compact, see sl_act_norm_bwd) -- the top layer under a
+ * read-out that takes the roots' rows.  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, stream).                             */
 typedef struct {
   const float *Zs, *Zn;            /* [n, F] pre-activations of the layer below (dense rows) */
   const float *bs, *bn;            /* its biases (may be NULL) */
@@ -529,7 +535,7 @@ int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, con
                       float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
                       float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                       float *d_an_partial, float *d_tn_partial, void *d_pack, int dz_ready, const sl_sage_below *below,
-                      float *d_dzs_amax, void *stream);
+                      float *d_dzs_amax, const uint32_t *d_dout_rows, uint32_t num_dout_rows, void *stream);
 
 /* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
  * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /

@@ -137,7 +137,7 @@ SIGNATURES = {
     "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P]),
+                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
     "sl_prof_enable": (C.c_int, [C.c_int]),
     "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -180,7 +180,7 @@ SIGNATURES = {
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_act_norm_bwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
-                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
+                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P]),
 }
 
 _lib = None

@@ -741,6 +741,9 @@ struct ActNormParams {
   float *dz0_amax;
   // forward, optional: the same for the output the next layer reads (out2 in dual mode, out otherwise)
   float *out_amax;
+  // backward, optional: the output gradient is given for `n` SELECTED rows only (dout / dout2 are [n, F] compact, row i of
+  // them belongs to row row_idx[i] of Z / dZ / the dropout mask) -- a read-out that takes a few rows of the layer's output
+  const uint32_t *row_idx;
 };
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
@@ -779,6 +782,8 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
   // reductions of the current one, so two rows per wavefront are in flight
   const uint64_t rstep = (uint64_t)gridDim.x * rows_per_block;
   uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub;
+  // (backward over selected rows: r counts the rows of the compact gradient, RR(r) is the row of Z / dZ / the mask)
+  auto RR = [&](uint64_t i) -> uint64_t { return (BWD && p.row_idx) ? (uint64_t)p.row_idx[i] : i; };
   float4 zn[NB], dyn = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int b = 0; b < NB; b++) zn[b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -787,9 +792,10 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
   if (kPrefetch && r < p.n && lane_on) {
     if (BWD && p.dout) dyn = ld4s(p.dout + (int64_t)r * p.lddo + f);
 #pragma unroll
-    for (int b = 0; b < NB; b++) zn[b] = ld4s(p.Z[b] + (int64_t)r * p.ldz[b] + f);
+    for (int b = 0; b < NB; b++) zn[b] = ld4s(p.Z[b] + (int64_t)RR(r) * p.ldz[b] + f);
   }
   for (; r < p.n; r += rstep) {
+    const uint64_t rr = RR(r);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 dy = dyn;
     float4 zc[NB];
@@ -799,17 +805,17 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
       if (r + rstep < p.n && lane_on) {
         if (BWD && p.dout) dyn = ld4s(p.dout + (int64_t)(r + rstep) * p.lddo + f);
 #pragma unroll
-        for (int b = 0; b < NB; b++) zn[b] = ld4s(p.Z[b] + (int64_t)(r + rstep) * p.ldz[b] + f);
+        for (int b = 0; b < NB; b++) zn[b] = ld4s(p.Z[b] + (int64_t)RR(r + rstep) * p.ldz[b] + f);
       }
     } else {
 #pragma unroll
-      for (int b = 0; b < NB; b++) zc[b] = lane_on ? ld4s(p.Z[b] + (int64_t)r * p.ldz[b] + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int b = 0; b < NB; b++) zc[b] = lane_on ? ld4s(p.Z[b] + (int64_t)rr * p.ldz[b] + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (BWD) {
       float4 ds = make_float4(p.out_scale, p.out_scale, p.out_scale, p.out_scale);
       float4 dm = ds;                      // factors of the gradient that came through the dropout mask
       if (p.drop_thr) {            // gradient of the fused output dropout: same mask, same 1/(1-p)
-        const uint32_t keep = drop_keep4(p, r, f);
+        const uint32_t keep = drop_keep4(p, rr, f);
         const float ks = p.out_scale * p.drop_scale;
         dm = make_float4((keep & 1u) ? ks : 0.f, (keep & 2u) ? ks : 0.f, (keep & 4u) ? ks : 0.f, (keep & 8u) ? ks : 0.f);
       }
@@ -855,13 +861,13 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
         if (lane_on && (p.dZ[b] || p.dbias)) {
           dh.x *= act_bwd(p.act[b], z.x, h.x); dh.y *= act_bwd(p.act[b], z.y, h.y);
           dh.z *= act_bwd(p.act[b], z.z, h.z); dh.w *= act_bwd(p.act[b], z.w, h.w);
-          if (p.dZ[b]) st4s(p.dZ[b] + (int64_t)r * p.lddz[b] + f, dh);
+          if (p.dZ[b]) st4s(p.dZ[b] + (int64_t)rr * p.lddz[b] + f, dh);
           gb[b].x += dh.x; gb[b].y += dh.y; gb[b].z += dh.z; gb[b].w += dh.w;
           zmax = amax4(dh);
         }
         if (b == 0 && p.dz0_amax) {        // (the LPR lanes of a row group share r: the reduction is uniform over the group)
           zmax = group_max<LPR>(zmax);
-          if (l == 0) p.dz0_amax[r] = zmax;
+          if (l == 0) p.dz0_amax[rr] = zmax;
         }
       }
     }
@@ -1357,7 +1363,7 @@ static uint32_t resident_blocks(const void *kernel) {
   return (uint32_t)per_cu * (uint32_t)ncu;
 }
 
-static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st, bool *vector_kernel = nullptr) {
+static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st, bool *vector_kernel = nullptr, bool need_vector = false) {
   const uint32_t F = p.F, seg = p.seg;
   bool vec = (F % 4 == 0) && (seg % 4 == 0) && F <= 256 && (F % seg == 0);
   // lanes per segment must be a power of two; when seg == F and F/4 is not a
@@ -1412,6 +1418,8 @@ static int act_norm_launch(ActNormParams &p, bool bwd, hipStream_t st, bool *vec
 #undef SHD_AN
 #undef SHD_AN_LAUNCH
   if (vector_kernel) *vector_kernel = done;
+  if (!done && need_vector)
+    return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: the selected-rows form needs the vector layout (F %% 4 == 0, F <= 256, aligned operands)");
   if (!done && p.drop_thr)
     return set_error(SG_ERR_INVALID, "sl_act_norm: fused output dropout needs the vector layout (F %% 4 == 0, F <= 256, "
                                      "16-byte aligned operands); apply dropout separately for this shape");
@@ -1494,7 +1502,8 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                                float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                                float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
-                               const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, void *stream_) {
+                               const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                               void *stream_) {
   int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
   if (!d_scale || !d_offset || (!d_dout && !d_dout_dropped) || !d_dscale || !d_doffset || !d_dZ)
@@ -1526,8 +1535,9 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
   }
   if (d_dz0_amax && !d_dZ[0]) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of a gradient that is not written");
   p.dz0_amax = d_dz0_amax;
+  p.row_idx = d_row_idx;
   bool vec = false;
-  if ((rc = act_norm_launch(p, true, st, &vec)) != SG_OK) return rc;
+  if ((rc = act_norm_launch(p, true, st, &vec, d_row_idx != nullptr)) != SG_OK) return rc;
   // (the general kernel does not write the row maxima: one more pass)
   return (d_dz0_amax && !vec) ? sl_row_amax(d_dZ[0], lddz[0], n, F, d_dz0_amax, st) : SG_OK;
 }

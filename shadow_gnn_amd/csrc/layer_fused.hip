@@ -62,6 +62,19 @@ int tn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm,
   return sl_gemm_tn_f32(A, lda, B, ldb, Cm, M, N, K, partial, nullptr, st);
 }
 
+// zeros into the F-wide column slices [b] of a pitched buffer (F % 4 == 0, 16-byte aligned): the rows of dZs / dZn a sparse
+// read-out gradient does not reach (hipMemset2DAsync on a pitched region ran at 0.8 TB/s)
+__global__ void __launch_bounds__(256) zero_slices_kernel(float *a, float *b, int64_t ld, uint32_t n, uint32_t F) {
+  const uint32_t f4 = F / 4;
+  const uint64_t total = (uint64_t)n * f4 * 2;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t half = (uint64_t)n * f4;
+    float *base = i < half ? a : b;
+    const uint64_t j = i < half ? i : i - half;
+    *reinterpret_cast<float4 *>(base + (j / f4) * ld + (j % f4) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // the GEMM-epilogue forms (gemm_fused.hip) take 16-byte aligned operands with row pitches of whole float4s
 bool fused_epilogue_ok(uint32_t Fout, uint32_t Fin, const float *A0, int64_t lda0, const float *A1, int64_t lda1) {
   auto ok = [](const float *p, int64_t ld) { return !p || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0); };
@@ -142,7 +155,8 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
                                  const float *d_offset, int act, float drop_p, uint64_t drop_seed, const float *d_dout,
                                  const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
                                  float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
-                                 void *d_pack, int dz_ready, const sl_sage_below *below, float *d_dzs_amax, void *stream) {
+                                 void *d_pack, int dz_ready, const sl_sage_below *below, float *d_dzs_amax,
+                                 const uint32_t *d_dout_rows, uint32_t num_dout_rows, void *stream) {
   if (!adj || !d_X || !d_AX || !d_Ws || !d_Wn || !d_dWs || !d_dWn || !d_buf || !d_tn_partial || !d_pack)
     return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
   if (!dz_ready && (!d_Zs || !d_Zn || !d_scale || !d_offset || !d_dscale || !d_doffset || !d_an_partial || (!d_dout && !d_dout_dropped)))
@@ -172,11 +186,29 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
     const int acts[2] = {act, act};
     float *dZ[2] = {dZs, dZn};
     const int64_t lddz[2] = {ld3, ld3};
-    SHD_PROF_FMT((2 * 2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 2, Fout);
-    if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
-                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, join ? amx : nullptr,
-                              stream)) != SG_OK)
-      return rc;
+    if (d_dout_rows) {
+      // The output gradient exists for a few rows only (a read-out that takes the roots' rows: the reference's feat[rows]
+      // hands autograd a zero-filled [n, F] tensor).  Every other row of dZs / dZn is zero: cleared here, and the act_norm
+      // backward runs on the selected rows (compact gradient, row indirection).
+      SHD_PROF_FMT(2.0 * 4.0 * n * Fout + 5.0 * 4.0 * num_dout_rows * Fout, 0, stream, "act_norm_bwd_rows_nb%d_F%u", 2, Fout);
+      hipLaunchKernelGGL(zero_slices_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, dZs, dZn, ld3, n, Fout);
+      if (join) SHD_HIP(hipMemsetAsync(amx, 0, (size_t)n * 4, (hipStream_t)stream));
+      if (num_dout_rows == 0) {
+        SHD_HIP(hipMemsetAsync(d_dscale, 0, (size_t)2 * Fout * 4, (hipStream_t)stream));
+        SHD_HIP(hipMemsetAsync(d_doffset, 0, (size_t)2 * Fout * 4, (hipStream_t)stream));
+        if (d_dbias) SHD_HIP(hipMemsetAsync(d_dbias, 0, (size_t)2 * Fout * 4, (hipStream_t)stream));
+      } else if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, num_dout_rows, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz,
+                                       d_dscale, d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout,
+                                       join ? amx : nullptr, d_dout_rows, stream)) != SG_OK) {
+        return rc;
+      }
+    } else {
+      SHD_PROF_FMT((2 * 2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 2, Fout);
+      if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
+                                d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, join ? amx : nullptr,
+                                nullptr, stream)) != SG_OK)
+        return rc;
+    }
   }
   if (d_dX || below) {
     if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
@@ -230,7 +262,7 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                            void *d_pack, void *stream) {
   return sl_sage_bwd_chain(adj, d_X, ldx, d_AX, ldax, d_Zs, d_Zn, Fin, Fout, d_Ws, ldws, d_bs, d_Wn, ldwn, d_bn, d_scale, d_offset, act,
                            drop_p, drop_seed, d_dout, d_dout_dropped, d_dX, d_dWs, d_dWn, d_dbias, d_dscale, d_doffset, d_buf,
-                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, stream);
+                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -307,7 +339,7 @@ extern "C" int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t lda
   {
     SHD_PROF_FMT((2 * 1 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 1, Fout);
     if ((rc = sl_act_norm_bwd(1, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZs, lddz, d_dscale,
-                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, nullptr, stream)) != SG_OK)
+                              d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, nullptr, nullptr, stream)) != SG_OK)
       return rc;
   }
   if (d_dX) {

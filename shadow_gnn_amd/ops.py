@@ -572,7 +572,7 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
                                           dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
                                           partial.data_ptr(), float(drop[0]), int(drop[1]),
                                           dout2.data_ptr() if dout2 is not None else None,
-                                          dout2.stride(0) if dout2 is not None else 0, None, _stream(Zs[0])))
+                                          dout2.stride(0) if dout2 is not None else 0, None, None, _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 
@@ -973,6 +973,58 @@ class _LinearActNorm(torch.autograd.Function):
         return (dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, *dXs, *dWs, *dbs)
 
 
+class RootsLink:
+    """Hand-over between the LAST GraphSAGE node of a stack and a read-out that takes only a few rows of its output
+    (centre pooling, residue 'none': shaDow/layers.py:159-163 reads feat[idx_targets]).  The reference's ``feat[rows]`` hands
+    autograd a zero-filled [n, F] gradient; here ``select_roots`` leaves (rows, their gradient) on the link, autograd carries
+    a storage-less placeholder, and the node's backward runs its act_norm backward on those rows only (every other row of
+    dZ is zero and is cleared, not computed) -- sl_sage_bwd_chain(d_dout_rows)."""
+    def __init__(self):
+        self.published = self.filled = False
+        self.rows32 = self.grad = self.dummy = None
+
+    def release(self):
+        self.filled = False
+        self.rows32 = self.grad = self.dummy = None
+
+
+ROOTS_SPARSE_GRAD = os.environ.get("SHADOW_ROOTS_SPARSE_GRAD", "1") != "0"
+
+
+class _SelectRoots(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, rows, link):
+        ctx.link, ctx.n, ctx.F = link, int(f.shape[0]), int(f.shape[1])
+        ctx.save_for_backward(rows)
+        ctx.set_materialize_grads(False)
+        return f.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, dsel):
+        (rows,) = ctx.saved_tensors
+        link = ctx.link
+        if dsel is None:
+            dsel = torch.zeros(rows.numel(), ctx.F, dtype=torch.float32, device=rows.device)
+        if link is not None and link.published:
+            link.rows32 = rows.to(torch.int32)
+            link.grad = _f32c(dsel).contiguous()
+            link.dummy = torch.empty(1, 1, dtype=torch.float32, device=dsel.device).expand(ctx.n, ctx.F)
+            link.filled = True
+            return link.dummy, None, None
+        dense = torch.zeros(ctx.n, ctx.F, dtype=dsel.dtype, device=dsel.device)
+        dense.index_add_(0, rows, dsel)
+        return dense, None, None
+
+
+def select_roots(f: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """f[rows] (the read-out's row select).  When ``f`` came from a node that published a RootsLink the gradient travels
+    as (rows, values) instead of a zero-filled [n, F] tensor."""
+    link = getattr(f, "_shadow_roots", None)
+    if link is None or not link.published or not ROOTS_SPARSE_GRAD:
+        return f[rows]
+    return _SelectRoots.apply(f, rows, link)
+
+
 class _SageDense(torch.autograd.Function):
     """The whole dense part of a GraphSAGE layer (shaDow/layers.py:471-483) as ONE autograd node:
         out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn))
@@ -983,7 +1035,8 @@ class _SageDense(torch.autograd.Function):
     chained_calls = 0        # backward passes that produced the lower layer's dZ in the GEMM epilogue
 
     @staticmethod
-    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop, lazy=None, in_drop=0.0, link_down=None, link_up=None):
+    def forward(ctx, X, adj, Ws, bs, Wn, bn, scale, offset, acts, drop, lazy=None, in_drop=0.0, link_down=None, link_up=None,
+                link_roots=None):
         """``lazy`` (a LazyRows; X is then a dummy): layer 0 -- the aggregation kernel gathers the features, applies the
         layer's input dropout ``in_drop`` and leaves the dense copy the self Linear and the weight gradients read."""
         _need_cuda(Ws, Wn, scale, offset)
@@ -1018,6 +1071,10 @@ class _SageDense(torch.autograd.Function):
         ctx.meta = (acts, drop, scale.shape, offset.shape, [b is not None for b in (bs, bn)], one_call)
         # chaining (both ends need the one-call entries and a non-dual output)
         ctx.link_down = link_down if (link_down is not None and link_down.published and one_call and CHAIN_SAGE_BWD) else None
+        ctx.link_roots = None
+        if link_roots is not None and one_call and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256:
+            link_roots.published = True
+            ctx.link_roots = link_roots
         ctx.link_up = None
         if link_up is not None and one_call and CHAIN_SAGE_BWD and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256:
             link_up.publish(Zs, Zn, bsc, sc, of, acts[0], drop)
@@ -1070,7 +1127,7 @@ class _SageDense(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         up, down = ctx.link_up, ctx.link_down
         dz_ready = up is not None and up.filled
-        d0 = d1 = None
+        d0 = d1 = dout_rows = None
         if dz_ready:
             g = dout[0] if isinstance(dout, (tuple, list)) else dout
             if g is None or g.data_ptr() != up.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
@@ -1080,13 +1137,21 @@ class _SageDense(torch.autograd.Function):
             an_partial = None
         else:
             douts = dout if isinstance(dout, (tuple, list)) else (dout,)
+            lr = ctx.link_roots
+            if lr is not None and lr.filled:
+                # the read-out handed over (rows, gradient): autograd carried a storage-less placeholder
+                g = douts[0]
+                if g is None or g.data_ptr() != lr.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
+                    raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
+                                       "(its gradient is not the placeholder); set SHADOW_ROOTS_SPARSE_GRAD=0")
+                dout_rows, douts = lr.rows32, (lr.grad,)
             d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
             if _is_dual(drop):
                 d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
                 if d1 is None:
                     drop = (0.0, 0)
             if d0 is None and d1 is None:
-                d0 = torch.zeros(n, Fo, **f32)
+                d0, dout_rows = torch.zeros(n, Fo, **f32), None
             dbi = torch.empty(2, Fo, **f32) if any(has_b) else None
             dsc, dof = torch.empty(2, Fo, **f32), torch.empty(2, Fo, **f32)
             buf = torch.empty(n, 3 * Fo, **f32)
@@ -1116,9 +1181,13 @@ class _SageDense(torch.autograd.Function):
                                     dWs.data_ptr(), dWn.data_ptr(), opt(dbi), opt(dsc), opt(dof), buf.data_ptr(), opt(an_partial),
                                     tn_partial.data_ptr(), pack.data_ptr(), 1 if dz_ready else 0,
                                     C.byref(below) if below is not None else None,
-                                    up.amax.data_ptr() if (dz_ready and up.amax is not None) else None, _stream(Zs)))
+                                    up.amax.data_ptr() if (dz_ready and up.amax is not None) else None,
+                                    dout_rows.data_ptr() if dout_rows is not None else None,
+                                    int(dout_rows.numel()) if dout_rows is not None else 0, _stream(Zs)))
         if dz_ready:
             up.release()
+        if dout_rows is not None:
+            ctx.link_roots.release()
         if chain:
             down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)       # what autograd hands to the node below: no storage behind it
             down.filled = True
@@ -1136,13 +1205,24 @@ class _SageDense(torch.autograd.Function):
         biases = [b if hb else None for b, hb in zip((b0, b1), has_b)]
         Fi = X.shape[1]
         # (the forward's decision, not a re-evaluation: a KernelTimer entered between the passes must not mix the paths)
-        if (one_call and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
-                and (not ng[0] or F % 32 == 0)):
+        fused_bwd = (one_call and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
+                     and (not ng[0] or F % 32 == 0))
+        lr = ctx.link_roots
+        if lr is not None and lr.filled and not fused_bwd:
+            # the read-out left (rows, gradient) on the link but this pass runs kernel by kernel: the dense form after all
+            g = dout[0]
+            if g is None or g.data_ptr() != lr.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
+                raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out")
+            dense = torch.zeros(n, F, dtype=torch.float32, device=Zs.device)
+            dense.index_add_(0, lr.rows32.long(), lr.grad)
+            dout = (dense,) + tuple(dout[1:])
+            lr.release()
+        if fused_bwd:
             dX, dWs, dWn, dbi, dsc, dof = _SageDense._fused_backward(ctx, dout, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, drop,
                                                                      has_b, bool(ng[0]))
             dbs = dbi[0] if (has_b[0] and ng[3] and dbi is not None) else None
             dbn = dbi[1] if (has_b[1] and ng[5] and dbi is not None) else None
-            return (dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None)
+            return (dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None)
         if ctx.link_up is not None and ctx.link_up.filled:
             raise RuntimeError("chained GraphSAGE backward: the layer above filled this layer's dZ but the one-call path is off")
         # dZs lands in the left half of one [n, 2F] buffer; A^T dZn goes into the right half
@@ -1161,7 +1241,7 @@ class _SageDense(torch.autograd.Function):
         dWn = weight_grad(dZn, AX) if ng[4] else None
         dbs = dbi[0] if (has_b[0] and ng[3]) else None
         dbn = dbi[1] if (has_b[1] and ng[5]) else None
-        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None
+        return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None
 
 
 # Chained GraphSAGE backward (sl_sage_bwd_chain): on unless SHADOW_CHAIN_SAGE_BWD=0
@@ -1286,11 +1366,12 @@ def gcn_dense(X: torch.Tensor, adj: "NormAdj", lin, act: str, scale: torch.Tenso
 
 def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
                offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False, in_dropout: float = 0.0,
-               chain_next: bool = False):
+               chain_next: bool = False, roots_only: bool = False):
     """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483).
     ``dual`` (with out_dropout > 0): returns (out, dropout(out)) from one kernel pass.  ``X`` may be a LazyRows
     (layer 0 of the fast path): gather and input dropout ``in_dropout`` then happen inside the aggregation kernel.
-    ``chain_next``: the caller guarantees that ONLY the next GraphSAGE layer reads the returned tensor (see ChainLink)."""
+    ``chain_next``: the caller guarantees that ONLY the next GraphSAGE layer reads the returned tensor (see ChainLink);
+    ``roots_only``: ... that only a row-selecting read-out reads it (ops.select_roots, see RootsLink)."""
     if act not in ACT_CODE:
         raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
     F = lin_self.weight.shape[0]
@@ -1304,10 +1385,13 @@ def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Te
     # chaining: a producer node left its ChainLink on the tensor it returned; ``chain_next`` asks this node to do the same
     link_down = getattr(X, "_shadow_chain", None) if torch.is_tensor(X) else None
     link_up = ChainLink() if (chain_next and not dual and CHAIN_SAGE_BWD) else None
+    link_roots = RootsLink() if (roots_only and not dual and not chain_next and ROOTS_SPARSE_GRAD) else None
     res = _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
-                           (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout), link_down, link_up)
+                           (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout), link_down, link_up, link_roots)
     if link_up is not None and link_up.published and torch.is_tensor(res):
         res._shadow_chain = link_up
+    if link_roots is not None and link_roots.published and torch.is_tensor(res):
+        res._shadow_roots = link_roots
     return res
 
 

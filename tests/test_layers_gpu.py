@@ -1292,3 +1292,32 @@ def test_pool_and_roots_equals_separate_ops(mode):
     (rc * Gr).sum().backward()
     want = torch.zeros_like(X0); want[rows] = Gr
     assert torch.equal(Xc.grad, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,dim,p_drop,act", [(3, 256, 0.4, "relu"), (2, 128, 0.0, "elu")])
+def test_sparse_readout_gradient_equals_dense(n_layers, dim, p_drop, act, monkeypatch):
+    """Centre pooling reads feat[roots] of the last layer: the gradient reaches that layer's node as (rows, values) through
+    ops.RootsLink / select_roots -- the node clears dZ and runs its act_norm backward on the root rows only
+    (sl_sage_bwd_chain, d_dout_rows) -- instead of as the zero-filled [n, F] tensor autograd would build.  Loss, predictions
+    and every parameter gradient equal the dense pass's (the rows without gradient contribute exact zeros there; only the
+    order of the dscale / doffset / dbias column sums differs)."""
+    from shadow_gnn_amd import ops
+    monkeypatch.setattr(ops, "ROOTS_SPARSE_GRAD", False)
+    l0, p0, g0, _ = _sage_stack_step(n_layers, dim, p_drop, 7, chain=True, fused=True, act=act)
+    monkeypatch.setattr(ops, "ROOTS_SPARSE_GRAD", True)
+    seen = []
+    orig = ops._SelectRoots.backward
+
+    def spy(ctx, dsel):
+        out = orig(ctx, dsel)
+        seen.append(tuple(out[0].stride()))
+        return out
+    monkeypatch.setattr(ops._SelectRoots, "backward", staticmethod(spy))
+    l1, p1, g1, _ = _sage_stack_step(n_layers, dim, p_drop, 7, chain=True, fused=True, act=act)
+    assert seen == [(0, 0)]                                   # the placeholder travelled, not a dense tensor
+    assert abs(l0 - l1) < 1e-6
+    torch.testing.assert_close(p1, p0, rtol=1e-6, atol=1e-7)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-6 * scale + 1e-10, k
