@@ -371,6 +371,9 @@ int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, co
  * d_out_dropped != NULL (needs drop_p > 0) is the dual mode for architectures where something besides the next
  * layer reads this output (the residue / ResPool read-outs, shaDow/models.py:176-185): d_out receives the plain
  * value and d_out_dropped the dropped one, from one pass over Z.                                                      */
+/* 1 when sl_act_norm_* run the vector kernel for (F, seg) given aligned operands (fused dropout, row maxima and the
+ * selected-rows backward exist there only).                                                                         */
+int sl_act_norm_vector_layout(uint32_t F, uint32_t seg);
 /* d_out_amax (may be NULL): receives max_k |row| of the output the next layer reads (the dropped one in dual mode), see
  * sl_row_amax.                                                                                                     */
 int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,

@@ -172,6 +172,7 @@ SIGNATURES = {
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_onehot_linear_fwd": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_onehot_linear_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
+    "sl_act_norm_vector_layout": (C.c_int, [C.c_uint32, C.c_uint32]),
     "sl_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
     "sl_gat_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -1466,6 +1466,16 @@ static int set_dropout(ActNormParams &p, float drop_p, uint64_t drop_seed, const
   return SG_OK;
 }
 
+// Does the vector kernel (float4 rows; fused dropout, row maxima, selected-rows backward live there) exist for this shape?
+// (operand alignment is checked per call)
+extern "C" int sl_act_norm_vector_layout(uint32_t F, uint32_t seg) {
+  if (F == 0 || seg == 0 || (F % 4) || (seg % 4) || F > 256 || (F % seg)) return 0;
+  uint32_t lpr = 1; while (lpr * 4 < F) lpr <<= 1;
+  const uint32_t ls = seg == F ? lpr : seg / 4;
+  if (lpr < 4 || (ls & (ls - 1))) return 0;
+  return (lpr == 64 && ls >= 8) || (lpr == 32 && ls >= 8) || (lpr == 16 && ls >= 8) || (lpr == 8 && ls == 8) || (lpr == 4 && ls == 4);
+}
+
 extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, float *d_out, int64_t ldo, float drop_p,

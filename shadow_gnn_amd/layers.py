@@ -450,7 +450,7 @@ class GAT(shaDowLayer):
         if self.norm == 'norm_feat' and self.act is None:
             # (one autograd node for the aggregate and the normalisation when the fused kernels take the shape)
             res = ops_gat.gat_tail(adj_norm, z_self, z_neigh, self.attention, self.kact, self.mulhead, self.scale, self.offset,
-                                   seg=self.dim_slice, out_scale=0.5, **self._drop_kw())
+                                   seg=self.dim_slice, out_scale=0.5, roots_only=self.roots_only, **self._drop_kw())
             if res is not None:
                 return self._emit(res), adj_norm, True, 0.
         feat_neigh = ops_gat.gat_aggregate(adj_norm, z_self, z_neigh, self.attention, self.kact,

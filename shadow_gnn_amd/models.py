@@ -227,7 +227,7 @@ class DeepGNN(nn.Module):
             # nodes may chain their backward passes (ops.ChainLink)
             md.chain_next = bool(not dual and isinstance(md, layers.GraphSAGE) and isinstance(nxt, layers.GraphSAGE))
             # ... and the LAST layer's output only by the read-out's row select: its gradient travels as (rows, values)
-            md.roots_only = bool(not dual and nxt is None and isinstance(md, layers.GraphSAGE))
+            md.roots_only = bool(not dual and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT)))
             if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):

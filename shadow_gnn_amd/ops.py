@@ -535,12 +535,14 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
     return out if out2 is None else (out, out2)
 
 
-def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None):
+def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None, row_idx=None):
     """``douts``: the gradient(s) autograd handed over -- (dout,) or, in dual mode, (dout_plain, dout_dropped) with
     None for an output nothing consumed.  ``dz_out``: optional preallocated dZ destinations (column slices of a
-    wider buffer are fine)."""
+    wider buffer are fine).  ``row_idx`` (int32 [m]): the gradients are compact [m, F] and belong to those rows (a read-out
+    that took a few rows of the output, see RootsLink); the other rows of dZ are zero."""
     nb = len(Zs)
     n, F = Zs[0].shape
+    m = int(row_idx.numel()) if row_idx is not None else n
     dev = sc.device
     if not isinstance(douts, (tuple, list)):
         douts = (douts,)
@@ -553,11 +555,13 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
         elif dout2.stride(1) != 1:
             dout2 = dout2.contiguous()
     if dout is None and dout2 is None:
-        dout = torch.zeros(n, F, dtype=torch.float32, device=dev)
+        dout = torch.zeros(m, F, dtype=torch.float32, device=dev)
     if dout is not None and dout.stride(1) != 1:
         dout = dout.contiguous()
-    dZs = [((dz_out[i] if dz_out is not None and dz_out[i] is not None else torch.empty_like(z)) if nd else None)
+    alloc = torch.zeros_like if row_idx is not None else torch.empty_like
+    dZs = [((dz_out[i] if dz_out is not None and dz_out[i] is not None else alloc(z)) if nd else None)
            for i, (z, nd) in enumerate(zip(Zs, need_dz))]
+    assert row_idx is None or dz_out is None
     dsc = torch.empty(nb, F, dtype=torch.float32, device=dev)
     dof = torch.empty(nb, F, dtype=torch.float32, device=dev)
     dbi = torch.empty(nb, F, dtype=torch.float32, device=dev) if want_dbias else None
@@ -565,14 +569,15 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
     ld = (C.c_int64 * nb)(*[z.stride(0) for z in Zs])
     ldd = (C.c_int64 * nb)(*[(d.stride(0) if d is not None else 0) for d in dZs])
     ac = (C.c_int * nb)(*codes)
-    with _timed(f"act_norm_bwd_nb{nb}_F{F}", (2 * nb + 1) * 4 * n * F, dev):
+    with _timed(f"act_norm_bwd_nb{nb}_F{F}" if row_idx is None else f"act_norm_bwd_rows_nb{nb}_F{F}", (2 * nb + 1) * 4 * m * F, dev):
         check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
-                                          n, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
+                                          m, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
                                           dout.stride(0) if dout is not None else 0, _ptr_array(dZs), ldd,
                                           dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
                                           partial.data_ptr(), float(drop[0]), int(drop[1]),
                                           dout2.data_ptr() if dout2 is not None else None,
-                                          dout2.stride(0) if dout2 is not None else 0, None, None, _stream(Zs[0])))
+                                          dout2.stride(0) if dout2 is not None else 0, None,
+                                          row_idx.data_ptr() if row_idx is not None else None, _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 

@@ -67,7 +67,7 @@ class _GatTail(torch.autograd.Function):
     backward then ADDS to (sl_gat_bwd, accumulate_dz_self), and the two kernels leave the row maxima of the final
     (dz_self | dz_neigh) behind for the K-concatenated input-gradient product of ops._LinearPair."""
     @staticmethod
-    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop):
+    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop, link_roots=None):
         z_self, z_neigh = ops._f32c(z_self).contiguous(), ops._f32c(z_neigh).contiguous()
         att = attention.detach().float().contiguous()
         ops._need_cuda(z_self, z_neigh, att, scale, offset)
@@ -91,6 +91,11 @@ class _GatTail(torch.autograd.Function):
         out = ops._an_fwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, drop)
         ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape, seg, out_scale, drop, scale.shape, offset.shape)
+        ctx.link_roots = None
+        # (the selected-rows act_norm backward lives in the vector kernel: float4 rows, power-of-two head slices)
+        if link_roots is not None and not ops._is_dual(drop) and _lib.load().sl_act_norm_vector_layout(F, int(seg)):
+            link_roots.published = True                       # (only a row-selecting read-out reads `out`, see ops.RootsLink)
+            ctx.link_roots = link_roots
         ctx.set_materialize_grads(False)
         ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
         return out
@@ -103,9 +108,18 @@ class _GatTail(torch.autograd.Function):
         c = adj.csr
         n, F = z_self.shape
         dev = z_self.device
-        # act + norm backward: d aggregate and the normalised branch's share of dz_self
+        # act + norm backward: d aggregate and the normalised branch's share of dz_self (on the read-out's rows only when it
+        # handed over (rows, values): the other rows of both are zero)
+        lr, rows = ctx.link_roots, None
+        if lr is not None and lr.filled:
+            g = dout[0]
+            if g is None or g.data_ptr() != lr.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
+                raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out")
+            rows, dout = lr.rows32, (lr.grad,)
         (dnagg, dzs), dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, dout, [True, True],
-                                                False, drop)
+                                                False, drop, row_idx=rows)
+        if rows is not None:
+            lr.release()
         ti, tx, tp = c.transposed
         work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
         dzn = torch.empty_like(z_neigh)
@@ -122,11 +136,11 @@ class _GatTail(torch.autograd.Function):
                                          amax.data_ptr() if amax is not None else None, ops._stream(dnagg)))
         if amax is not None:              # (ONE array for both gradients: the maximum over the pair of rows)
             ops.set_row_amax(dzs, amax); ops.set_row_amax(dzn, amax)
-        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None)
+        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None)
 
 
 def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: int, scale, offset, seg: int, out_scale: float,
-             out_dropout: float = 0.0, dual: bool = False):
+             out_dropout: float = 0.0, dual: bool = False, roots_only: bool = False):
     """out_scale * (norm(gat_aggregate(...)) + norm(act(z_self))) as one node (see _GatTail); None when the shape needs the
     padded multi-launch aggregate (the caller then composes gat_aggregate and ops.act_norm)."""
     n, F = z_self.shape
@@ -134,7 +148,11 @@ def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: in
     if not (F <= 256 and F % heads == 0 and _fused_slice(F // heads) and z_self.is_cuda):
         return None
     drop = ops._drop_arg(out_dropout, F, seg, dual)
-    return _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop)
+    link = ops.RootsLink() if (roots_only and not dual and ops.ROOTS_SPARSE_GRAD) else None
+    res = _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop, link)
+    if link is not None and link.published and torch.is_tensor(res):
+        res._shadow_roots = link
+    return res
 
 
 def _fused_slice(D: int) -> bool:
