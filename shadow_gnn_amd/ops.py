@@ -280,15 +280,23 @@ MERGE_BELOW_AVG_ROWS = 190   # two average subgraphs must fit the 384-row tile
 
 def _adj_struct(adj: "NormAdj", need_transpose: bool):
     """The ctypes image of a NormAdj for the one-call layer entries (the tensors stay owned by ``adj``)."""
+    # (one image per adjacency and form: a layer stack passes the same NormAdj to ten entries per step)
+    cache = adj.__dict__.setdefault("_struct_cache", {})
+    key = (bool(need_transpose), id(adj.edge_w), id(adj.row_scale), id(adj.col_scale))
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
     c = adj.csr
     ptr = lambda t: t.data_ptr() if t is not None else None
     ti = tx = tp = None
     if need_transpose:
         ti, tx, tp = c.transposed
     boff, beoff, bmax = c.spmm_blocks
-    return _lib.SlNormAdj(c.indptr.data_ptr(), c.indices.data_ptr(), ptr(adj.edge_w), ptr(adj.row_scale), ptr(adj.col_scale),
-                          ptr(ti), ptr(tx), ptr(tp), ptr(boff), ptr(beoff),
-                          (int(boff.numel()) - 1) if boff is not None else 0, bmax, c.n, c.e)
+    st = _lib.SlNormAdj(c.indptr.data_ptr(), c.indices.data_ptr(), ptr(adj.edge_w), ptr(adj.row_scale), ptr(adj.col_scale),
+                        ptr(ti), ptr(tx), ptr(tp), ptr(boff), ptr(beoff),
+                        (int(boff.numel()) - 1) if boff is not None else 0, bmax, c.n, c.e)
+    cache[key] = st
+    return st
 
 
 # One C call per GraphSAGE layer pass (sl_sage_fwd / sl_sage_bwd_chain) instead of one per kernel.  A KernelTimer does
