@@ -6,7 +6,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input:
   sample B subgraphs (HIP sampler) -> gather features (HIP) -> L-layer SAGE forward
-  (HIP SpMM + fused act/norm, split-bf16 MFMA GEMMs) -> CE loss -> backward -> [RCCL gradient
+  (HIP SpMM; fp32 GEMMs on the 16-bit matrix cores as split operands, act / norm in their epilogues) -> CE loss ->
+  backward -> [RCCL gradient
   all-reduce] -> clip -> Adam.
 The full graph CSR, the feature matrix and the root list are resident in HBM
 before the timed region.  Batches are sharded over the ranks (weak scaling: B per
@@ -19,7 +20,8 @@ Rank 0 prints ONE JSON line.  metric/unit follow BASELINE.json:
   roofline            the north-star aggregate: algorithmic bytes of the k-hop sample + feature gather + SAGE
                       aggregation kernels over their summed duration, timed live with HIP events on the streams
                       they are launched on, against the 8 TB/s HBM peak; roofline_hbm: the dominant HBM-bound
-                      kernel; roofline_mfma: the dominant split-bf16 GEMM against the MFMA peak
+                      kernel; roofline_mfma: the dominant split-operand GEMM against the MFMA peak (divided by the
+                      matrix-core products it issues per fp32 product: 3 for two fp16 pieces, 6 for three bf16 pieces)
   cpu_baseline        the reference's own C++/OpenMP sampler (oracle/_ref) timed on this box's host cores on a
                       bounded sample of the same roots: best of a thread sweep {1, 8, 20, 64, all} + the 1-thread rate
   cpu_baseline_train_step  the other half of the reference's CPU path: the training step in CPU
