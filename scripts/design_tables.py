@@ -90,7 +90,9 @@ def main():
     if tl.get("ms_per_step"):
         out.append(f"Opt-in target-only tail (never part of `value`): {tl['ms_per_step']} ms/step.")
     out.append("")
-    out.append("Other BASELINE configurations (`bench.py --workload ...`, `profiles/" + tag + "_bench_<workload>.json`):")
+    out.append("Other BASELINE configurations (`bench.py --workload ...`, `profiles/" + tag + "_bench_<workload>.json`; rocprofv3 kernel "
+               "statistics of the PPR, GAT and arxiv SAGE-5 runs: `profiles/" + tag + "_kernel_stats_<workload>.csv`, "
+               "`scripts/collect_workload_stats.sh`):")
     out.append("")
     out.append("| workload | ms / step | sampled nodes / s | host busy ms | north-star frac | three longest kernel classes (avg us x launches per step, frac) |")
     out.append("|---|---|---|---|---|---|")
