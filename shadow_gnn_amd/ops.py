@@ -1031,7 +1031,8 @@ class _SelectRoots(torch.autograd.Function):
 
 def select_roots(f: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
     """f[rows] (the read-out's row select).  When ``f`` came from a node that published a RootsLink the gradient travels
-    as (rows, values) instead of a zero-filled [n, F] tensor."""
+    as (rows, values) instead of a zero-filled [n, F] tensor.  ``rows`` must be distinct (the roots of a collated batch
+    are: every subgraph owns its rows) -- the sparse backward WRITES the selected rows of dZ, it does not accumulate."""
     link = getattr(f, "_shadow_roots", None)
     if link is None or not link.published or not ROOTS_SPARSE_GRAD:
         return f[rows]
