@@ -233,7 +233,9 @@ class DeepGNN(nn.Module):
             # nodes may chain their backward passes (ops.ChainLink)
             md.chain_next = bool(not dual and isinstance(md, layers.GraphSAGE) and isinstance(nxt, layers.GraphSAGE))
             # ... and the LAST layer's output only by the read-out's row select: its gradient travels as (rows, values)
-            md.roots_only = bool(not dual and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT)))
+            # (node tasks: one root per subgraph, so the selected rows are distinct)
+            md.roots_only = bool(not dual and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT))
+                                 and self.prediction_task == 'node')
             if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):
