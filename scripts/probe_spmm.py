@@ -20,6 +20,8 @@ n, e = b.num_nodes, b.num_edges
 print("n", n, "e", e)
 for F in [int(a) for a in sys.argv[1:]] or [64, 100, 128, 256]:
     X = torch.randn(n, F, device=dev)
+    if os.environ.get("PAD", "0") == "1":          # rows on whole 128-byte lines (what LazyRows.gather_dropped leaves)
+        Xp = torch.zeros(n, (F + 31) // 32 * 32, device=dev); Xp[:, :F] = X; X = Xp[:, :F]
     for _ in range(3):
         Y = ops.spmm(adj, X)
     torch.cuda.synchronize()

@@ -512,10 +512,12 @@ __global__ void gather_rows_drop_kernel(const float *__restrict__ table, int64_t
   }
 }
 
-// float4 column of lane l8 in tile t: the F/4 float4 columns are split evenly over the tiles (F = 100: 7+6+6+6
-// instead of 8+8+8+1), every tile at most 8 wide
-__device__ __forceinline__ uint32_t bd_col4(uint32_t t, uint32_t tiles, uint32_t nf4, uint32_t l8, bool *on) {
-  const uint32_t c0 = t * nf4 / tiles, c1 = (t + 1u) * nf4 / tiles;
+// float4 column of lane l8 in tile t, every tile at most 8 wide.  Rows on a 128-byte pitch (``lines``: the padded rows of
+// LazyRows.gather_dropped and the product that keeps their pitch): tile t is the t-th LINE of the row -- F = 100:
+// 8+8+8+1 -- so that every line is fetched and written by exactly one work item.  Otherwise the F/4 float4 columns are
+// split evenly over the tiles (F = 100: 7+6+6+6).
+__device__ __forceinline__ uint32_t bd_col4(uint32_t t, uint32_t tiles, uint32_t nf4, uint32_t l8, bool *on, uint32_t lines) {
+  const uint32_t c0 = lines ? 8u * t : t * nf4 / tiles, c1 = lines ? min(nf4, 8u * t + 8u) : (t + 1u) * nf4 / tiles;
   *on = c0 + l8 < c1;
   return (c0 + l8) * 4u;
 }
@@ -558,7 +560,8 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
                       const float *__restrict__ row_scale, const float *__restrict__ col_scale,
                       const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
                       uint32_t F, const uint32_t *__restrict__ node_off, const uint32_t *__restrict__ edge_off,
-                      uint32_t P, uint32_t tiles, uint32_t tg, uint32_t cap_rows, BdGather g, uint32_t *__restrict__ amax_bits) {
+                      uint32_t P, uint32_t tiles, uint32_t tg, uint32_t cap_rows, BdGather g, uint32_t *__restrict__ amax_bits,
+                      uint32_t lines) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem[];
   float *xs = reinterpret_cast<float *>(bd_smem);                        // [cap_rows][kBdRowPad]
   uint32_t *ips = reinterpret_cast<uint32_t *>(xs + (size_t)cap_rows * kBdRowPad);   // [cap_rows + 4]
@@ -578,7 +581,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
   auto prefetch = [&](const BdItem &h) {
     if (!h.valid || !fits(h)) return;
     bool pon;
-    const uint32_t f = bd_col4(h.t, tiles, F >> 2, l8, &pon);
+    const uint32_t f = bd_col4(h.t, tiles, F >> 2, l8, &pon, lines);
 #pragma unroll
     for (int k = 0; k < kBdKX; k++) {
       const uint32_t i = rg + k * (kBdBlock / 8);
@@ -615,7 +618,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
   for (;; kq++) {
     if ((uint64_t)blockIdx.x + (uint64_t)(kq / tg) * gridDim.x >= (uint64_t)P * groups) break;   // (wave-uniform)
     bool on;
-    const uint32_t f = bd_col4(cur.t, tiles, F >> 2, l8, &on);
+    const uint32_t f = bd_col4(cur.t, tiles, F >> 2, l8, &on, lines);
     on = on && cur.valid;
     const bool in_lds = cur.valid && fits(cur);
     __syncthreads();                                                     // the previous item's readers are done
@@ -1312,7 +1315,12 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
     SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<false>, lds));
     SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<true>, lds));
   }
-  const uint32_t tiles = (F / 4 + 7) / 8;            // float4 columns split evenly over the tiles, <= 8 per tile
+  const uint32_t tiles = (F / 4 + 7) / 8;            // <= 8 float4 columns per tile (bd_col4)
+  // both operands on whole 128-byte lines per row: tiles = lines (SHADOW_SPMM_LINES=0: the even split)
+  const char *lines_env = getenv("SHADOW_SPMM_LINES");      // (read per call: a test compares the two splits in one process)
+  const bool lines_on = !(lines_env && lines_env[0] == '0');
+  const uint32_t lines = (lines_on && !bg.table && F % 32 != 0 && ldx % 32 == 0 && ldy % 32 == 0 && (reinterpret_cast<uintptr_t>(d_X) & 127) == 0 &&
+                          (reinterpret_cast<uintptr_t>(d_Y) & 127) == 0) ? 1u : 0u;
   // resident workgroups per CU: what LDS allows, at most what 2048 threads allow (a grid beyond the resident set would
   // run as a partial second round of a persistent kernel, which costs a full one)
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / kBdBlock, (size_t)(160 * 1024) / (lds + 256)));
@@ -1331,11 +1339,11 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   if (bg.table)
     hipLaunchKernelGGL(spmm_blockdiag_kernel<true>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
                        d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
-                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax));
+                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax), lines);
   else
     hipLaunchKernelGGL(spmm_blockdiag_kernel<false>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
                        d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
-                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax));
+                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax), lines);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -1240,6 +1240,37 @@ def test_spmm_over_merged_small_subgraphs_is_bit_identical(F, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F", [100, 36, 200, 252])
+def test_spmm_on_line_padded_rows_is_bit_identical(F, monkeypatch):
+    """Rows on a 128-byte pitch (what LazyRows.gather_dropped leaves for layer 0): the block-diagonal SpMM then takes one
+    LINE of a row per tile (F = 100: 8+8+8+1 float4 columns) instead of the even split (7+6+6+6) -- same per-row sums in
+    the same edge order, so the product equals the one over unpadded rows and the one of the even split bit for bit; the
+    product keeps the padded pitch and never touches the pad."""
+    from shadow_gnn_amd import ops
+    sizes = [int(x) for x in np.random.default_rng(F).integers(1, 380, size=40)] + [500, 1, 384]
+    csr, A = _blockdiag_batch(sizes, 0.03, seed=F)
+    n = csr.n
+    g = torch.Generator(device=DEV).manual_seed(F)
+    X = torch.randn(n, F, device=DEV, generator=g)
+    w = torch.rand(csr.e, device=DEV, generator=g)
+    rs = torch.rand(n, device=DEV, generator=g) + 0.5
+    Fp = (F + 31) // 32 * 32
+    Xp = torch.full((n, Fp), float("nan"), device=DEV)
+    Xp[:, :F] = X
+    blocks = (csr.subg_off, csr.subg_edge_off, csr.max_subg_nodes)
+    plain = ops._spmm_raw(csr.indptr, csr.indices, w, None, rs, None, X, n, blocks)
+    lines = ops._spmm_raw(csr.indptr, csr.indices, w, None, rs, None, Xp[:, :F], n, blocks)
+    assert lines.stride(0) == Fp and torch.equal(lines, plain)
+    monkeypatch.setenv("SHADOW_SPMM_LINES", "0")
+    even = ops._spmm_raw(csr.indptr, csr.indices, w, None, rs, None, Xp[:, :F], n, blocks)
+    assert torch.equal(even, plain)
+    out = torch.full((n, Fp), 7.0, device=DEV)
+    monkeypatch.delenv("SHADOW_SPMM_LINES")
+    ops._spmm_raw(csr.indptr, csr.indices, w, None, rs, None, Xp[:, :F], n, blocks, out=out[:, :F])
+    assert torch.equal(out[:, :F], plain) and bool((out[:, F:] == 7.0).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(9001, 256, 256), (40000, 100, 256), (8300, 64, 128)])
 def test_linear_pair_matches_fp64_autograd(M, K, N):
     """ops.linear_pair: the two Linears of one input (GAT's self / neighbour transforms) as one node -- two-product fp16
