@@ -24,6 +24,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #include "actnorm_common.h"
 #include "common.h"
@@ -666,6 +668,12 @@ gemm_tn_split_kernel(const float *__restrict__ A, int64_t lda, const float *__re
   }
 }
 
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // The same product with every operand element split ONCE per workgroup.  In gemm_tn_split_kernel each wavefront splits
 // the fragments it multiplies itself: 2 A tiles + TK B tiles per k-step -- 6 x ~60 VALU operations beside 48 MFMAs, and
 // every A tile is split by two wavefronts, every B tile by four (3 x the necessary work; the kernel is as busy on the
@@ -675,7 +683,13 @@ gemm_tn_split_kernel(const float *__restrict__ A, int64_t lda, const float *__re
 // ds_read_b128 fragment reads.  One barrier per step as before; LDS = 64 KB fp32 row tiles (two steps) + 96 KB fragment
 // images (two steps) = all 160 KB of the CU (one 8-wave workgroup per CU, as before).  Same arithmetic in the same order:
 // bit-identical products.
-template <int TK>
+//
+// kPipe (N = K = 256 only): the steps that have two full steps behind them run as ONE basic block -- no row / width
+// predicates on the copies, no uniform branches -- whose instruction order is given by group barriers: one MFMA, then a few
+// of the split's VALU operations and at most one LDS access, 48 times.  In the plain form the two wavefronts of a SIMD
+// leave the step barrier together, split together (matrix pipe idle) and then multiply together (VALU idle): the parts of
+// a step add up (3b of DESIGN.md).  Interleaved, the split runs in the shadow of the wavefront's own MFMAs.
+template <int TK, bool kPipe>
 __global__ void __launch_bounds__(kTnThreads)
 gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
                     float *__restrict__ partial, uint32_t M, uint32_t N, uint32_t K, uint32_t rows_per_wg, uint32_t colsum) {
@@ -744,7 +758,101 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
   __syncthreads();
   if (steps > 0) { split_job(0, 0); split_job(0, 1); }
   __syncthreads();
-  for (uint32_t s = 0; s < steps; s++) {
+  uint32_t s = 0;
+  if constexpr (kPipe) {
+    // steps s with s + 2 <= steps - 2: the rows of step s + 2 all lie below m_end, step s + 1 exists
+    for (; s + 3 < steps; s++) {
+      const bf16x8 *img = fimg + (size_t)(s & 1) * kImgVecs;
+      {
+        float *tb = lbuf + (size_t)(s & 1) * kTnStepFloats + (size_t)(2 * wv) * kTnRowFloats;
+        const uint64_t row = m_begin + (uint64_t)(s + 2) * 16 + 2 * wv;
+        const float *sa = A + row * lda + lane * 4, *sb = B + row * ldb + lane * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
+                                         (__attribute__((address_space(3))) void *)tb, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sa + lda),
+                                         (__attribute__((address_space(3))) void *)(tb + kTnRowFloats), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sb,
+                                         (__attribute__((address_space(3))) void *)(tb + 16 * kTnRowFloats), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + ldb),
+                                         (__attribute__((address_space(3))) void *)(tb + 17 * kTnRowFloats), 16, 0, 0);
+      }
+      // Every LDS access of this block is issued by hand (invisible to hipcc's scoreboard, which would wait lgkmcnt(0)
+      // before each first use) and waited for with counted waits -- LDS returns in order:
+      //   top      F1 = al0 al1 bh | F2 = ah0 ah1 bl | F3 = am0 am1 bm  (tile 0, in the order the MFMA pairs need them),
+      //            RA = the four raw reads of this wavefront's A column tile of step s + 1
+      //   pair 0   wait F1 (10 younger accesses may stay in flight), pair 1: F2 (7), pair 2: F3 (4), then RA (0)
+      //   pair 6t+3 issues the B fragments of tile t + 1 (waited for at pair 6t+6, nothing younger), pair 8 the raw reads of
+      //   the B column tile; the pieces of the split follow the pairs two slots behind (piece p after pair p + 2).
+      const uint32_t fa = lds_addr(img + (size_t)(2 * wn) * 64 + lane), fb = lds_addr(img + ((size_t)3 * 8 + TK * wk) * 64 + lane);
+      const uint32_t ra = lds_addr(lbuf + (size_t)((s + 1) & 1) * kTnStepFloats + (size_t)(8 * kg) * kTnRowFloats + 32 * wv + r);
+      const uint32_t wa = lds_addr(fimg + (size_t)((s + 1) & 1) * kImgVecs + (size_t)wv * 64 + lane);
+      bf16x8 ah[2], am[2], al[2];
+      bf16x8 bfr[2][3];                                           // B fragments of tile t (t & 1) and of the next one
+      float2v xr[4], xq[4];                                       // raw columns of the A / B tile being split: rows 8 kg .. 8 kg + 7
+      al[0] = lds_read_frag<16384>(fa); al[1] = lds_read_frag<16384 + 1024>(fa); bfr[0][0] = lds_read_frag<0>(fb);
+      ah[0] = lds_read_frag<0>(fa); ah[1] = lds_read_frag<1024>(fa); bfr[0][2] = lds_read_frag<16384>(fb);
+      am[0] = lds_read_frag<8192>(fa); am[1] = lds_read_frag<8192 + 1024>(fa); bfr[0][1] = lds_read_frag<8192>(fb);
+      xr[0] = lds_read2st64<0, 4>(ra); xr[1] = lds_read2st64<8, 12>(ra); xr[2] = lds_read2st64<16, 20>(ra); xr[3] = lds_read2st64<24, 28>(ra);
+      uint32_t hb[2], mb[2], lb[2];
+      union { uint32_t u[4]; bf16x8 v; } H, Mm, L;
+      auto piece = [&](auto pc) {
+        constexpr int p = decltype(pc)::value, job = p / 12, q = p % 12, grp = q / 3, pos = q % 3;
+        if constexpr (p == 0) {          // (column sums of A; unused without colsum)
+          csum += ((xr[0].x + xr[0].y) + (xr[1].x + xr[1].y)) + ((xr[2].x + xr[2].y) + (xr[3].x + xr[3].y));
+        }
+        if constexpr (pos < 2) {
+          const float x = job ? (pos ? xq[grp].y : xq[grp].x) : (pos ? xr[grp].y : xr[grp].x);
+          hb[pos] = __float_as_uint(x) & 0xFFFF0000u;
+          const float r1 = x - __uint_as_float(hb[pos]);
+          mb[pos] = __float_as_uint(r1) & 0xFFFF0000u;
+          lb[pos] = __float_as_uint(r1 - __uint_as_float(mb[pos]));
+        } else {
+          H.u[grp] = pack_hi16(hb[0], hb[1]);
+          Mm.u[grp] = pack_hi16(mb[0], mb[1]);
+          L.u[grp] = pack_hi16(lb[0], lb[1]);
+        }
+        if constexpr (q == 11) {
+          lds_write_frag<job * 24576>(wa, H.v); lds_write_frag<job * 24576 + 8192>(wa, Mm.v); lds_write_frag<job * 24576 + 16384>(wa, L.v);
+        }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<6 * TK>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, t = k / 6, g = k % 6;
+        if constexpr (k == 0) lds_wait<10>();
+        else if constexpr (k == 1) lds_wait<7>();
+        else if constexpr (k == 2) lds_wait<4>();
+        else if constexpr (g == 0) lds_wait<0>();
+        {
+          const bf16x8 &bh = bfr[t & 1][0], &bm = bfr[t & 1][1], &bl = bfr[t & 1][2];
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            if constexpr (g == 0) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
+            else if constexpr (g == 1) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][t], 0, 0, 0);
+            else if constexpr (g == 2) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][t], 0, 0, 0);
+            else if constexpr (g == 3) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][t], 0, 0, 0);
+            else if constexpr (g == 4) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
+            else acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k == 2) lds_wait<0>();                      // the raw A column
+        if constexpr (g == 3 && t + 1 < TK) {
+          constexpr int o = (t + 1) * 1024, nb = (t + 1) & 1;
+          bfr[nb][0] = lds_read_frag<o>(fb); bfr[nb][1] = lds_read_frag<o + 8192>(fb); bfr[nb][2] = lds_read_frag<o + 16384>(fb);
+        }
+        if constexpr (k >= 2 && k < 22) piece(std::integral_constant<int, (k >= 2 && k < 22) ? k - 2 : 0>{});
+        if constexpr (k == 22) { piece(std::integral_constant<int, 20>{}); piece(std::integral_constant<int, 21>{}); }
+        if constexpr (k == 23) { piece(std::integral_constant<int, 22>{}); piece(std::integral_constant<int, 23>{}); }
+        if constexpr (k == 8) {         // the raw B column: first used by piece 12 at pair 14, behind the wait of pair 12
+          xq[0] = lds_read2st64<64, 68>(ra); xq[1] = lds_read2st64<72, 76>(ra); xq[2] = lds_read2st64<80, 84>(ra); xq[3] = lds_read2st64<88, 92>(ra);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  for (; s < steps; s++) {
     const bf16x8 *img = fimg + (size_t)(s & 1) * kImgVecs;
     // this step's A fragments (tiles 2 wn, 2 wn + 1)
     bf16x8 ah[2], am[2], al[2];
@@ -880,11 +988,18 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
   if (coop) {
     const size_t ldsc = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * 2 * 3 * 8 * 64 * 16;     // 64 KB row tiles + 96 KB fragment images
     if (K <= 128) {
-      SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<2>, ldsc));
-      hipLaunchKernelGGL((gemm_tn_coop_kernel<2>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
+      SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<2, false>, ldsc));
+      hipLaunchKernelGGL((gemm_tn_coop_kernel<2, false>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
     } else {
-      SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<4>, ldsc));
-      hipLaunchKernelGGL((gemm_tn_coop_kernel<4>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
+      // (SHADOW_GEMM_TN_PIPE=0: the plain step loop; read per call so that a test can compare the two in one process)
+      const char *pipe_env = getenv("SHADOW_GEMM_TN_PIPE");
+      if (N == 256 && K == 256 && !(pipe_env && pipe_env[0] == '0')) {
+        SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<4, true>, ldsc));
+        hipLaunchKernelGGL((gemm_tn_coop_kernel<4, true>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
+      } else {
+        SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_coop_kernel<4, false>, ldsc));
+        hipLaunchKernelGGL((gemm_tn_coop_kernel<4, false>), dim3(G), dim3(kTnThreads), ldsc, st, d_A, lda, d_B, ldb, d_partial, M, N, K, rows_per_wg, d_a_colsum ? 1u : 0u);
+      }
     }
     SHD_HIP(hipGetLastError());
     const uint32_t NKc = N * K + (d_a_colsum ? N : 0u);

@@ -78,6 +78,18 @@ __device__ __forceinline__ V lds_read_frag(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(kOffset));
   return v;
 }
+template <int kOffset, typename V = bf16x8>
+__device__ __forceinline__ void lds_write_frag(uint32_t addr, const V &v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(kOffset) : "memory");
+}
+// two dwords 256 * k0 and 256 * k1 bytes above addr (a column of a row tile with a 1 KB row pitch: k = 4 * row)
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int k0, int k1>
+__device__ __forceinline__ float2v lds_read2st64(uint32_t addr) {
+  float2v v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(k0), "n"(k1));
+  return v;
+}
 template <int N>
 __device__ __forceinline__ void lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");

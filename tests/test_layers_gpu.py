@@ -502,6 +502,29 @@ def test_weight_gradient_gemm_cooperative_split_is_bit_identical(M, N, K, lda, m
     assert float(((got.double() - want).abs() / bound.clamp_min(1e-30)).max()) < 2e-6
 
 
+@pytest.mark.parametrize("M,lda", [(300000, 768), (289309, 256), (16 * 256 * 4, 256), (16 * 256 * 3 + 5, 768), (40000, 256), (1100, 256)])
+def test_weight_gradient_gemm_interleaved_step_is_bit_identical(M, lda, monkeypatch):
+    """N = K = 256: the steps of gemm_tn_coop_kernel that have two full steps behind them run as one hand-ordered block
+    (one MFMA pair, one piece of the next step's operand split, counted LDS waits; SHADOW_GEMM_TN_PIPE=0: the plain loop).
+    Same pieces, same MFMA order per accumulator, same column-sum order: product and column sums equal the plain loop's bit
+    for bit -- slices of 3 steps and less (no interleaved step at all), ragged last slices, strided dZ."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + lda)
+    dZ = torch.randn(M, lda, device=DEV, generator=g)[:, :256] * (torch.rand(M, 1, device=DEV, generator=g) + 0.01)
+    X = torch.randn(M, 256, device=DEV, generator=g)
+    monkeypatch.setenv("SHADOW_GEMM_TN_COOP", "1")
+    monkeypatch.setenv("SHADOW_GEMM_TN_PIPE", "0")
+    ref, ref_cs = ops.weight_grad(dZ, X, want_colsum=True)
+    monkeypatch.setenv("SHADOW_GEMM_TN_PIPE", "1")
+    got, got_cs = ops.weight_grad(dZ, X, want_colsum=True)
+    assert torch.equal(ref, got) and torch.equal(ref_cs, got_cs)
+    assert torch.equal(got, ops.weight_grad(dZ, X))
+    want = dZ.double().t() @ X.double()
+    bound = dZ.double().abs().t() @ X.double().abs()
+    assert float(((got.double() - want).abs() / bound.clamp_min(1e-30)).max()) < 1.5e-6
+    torch.testing.assert_close(got_cs.double(), dZ.double().sum(0), rtol=1e-5, atol=1e-5 * float(dZ.abs().sum(0).max()))
+
+
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
 def test_act_norm_fused_output_dropout(nb, F, seg):
     """The next layer's input dropout folded into act_norm's output: the kernel's mask equals the documented
