@@ -23,7 +23,7 @@ ROC = {
     "gemm_an_bwd_nb2_N256": "gemm_nt_fused_kernel<8, 1, 1, 2, false>",
     "gemm_act_norm_fwd_nb2_N256": "gemm_nt_fused_kernel<8, 0, 2, 2, false>",
     "gemm_act_norm_fwd_nb2_N256_Ktail": "gemm_nt_fused_kernel<8, 0, 2, 2, true>",
-    "gemm_tn_split_N256": "gemm_tn_coop_kernel<4>",
+    "gemm_tn_split_N256": "gemm_tn_coop_kernel<4, true>",
     "gemm_tn_split_N256_K128": "gemm_tn_split_kernel<2>",
     "act_norm_bwd_nb2_F256": "act_norm_kernel<64, 64, true, 2>",
     "gather_F100": "gather_rows_drop_kernel<32>",
