@@ -962,7 +962,8 @@ extern "C" uint32_t sl_gemm_tn_slices(uint32_t M) {
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const uint32_t min_rows = 256;                                   // at least 16 k-steps per workgroup
+  // at least 8 k-steps per workgroup (SHADOW_GEMM_TN_MIN_ROWS; 256 until round 3: M = 39.5 k, N = K = 256 then ran on 154 CUs)
+  static const uint32_t min_rows = [] { const char *e = getenv("SHADOW_GEMM_TN_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : 128u; }();
   return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ncu, (M + min_rows - 1) / min_rows));
 }
 

@@ -147,6 +147,14 @@ __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bo
       h[q] = f4sel(on[q], make_float4(act_fwd(act, z[q].x), act_fwd(act, z[q].y), act_fwd(act, z[q].z), act_fwd(act, z[q].w)));
       s += hsum4(h[q]);
     }
+#ifdef FUSED_KO_STATS
+    // (knock-out: what the backward epilogue would cost with the row statistics read instead of recomputed -- two floats per
+    //  row and branch stand in for the load)
+    const float mean = d.scale[b] * inv_seg, rstd = d.offset[b] + 1.0f;
+#pragma unroll
+    for (int q = 0; q < Q; q++) xh[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
+    (void)s;
+#else
     const float mean = row_sum<LPR>(s) * inv_seg;
     float v = 0.f;
 #pragma unroll
@@ -155,6 +163,7 @@ __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bo
       v += (xh[q].x * xh[q].x + xh[q].y * xh[q].y) + (xh[q].z * xh[q].z + xh[q].w * xh[q].w);
     }
     const float rstd = rsqrtf(row_sum<LPR>(v) * inv_seg + d.eps);
+#endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
