@@ -826,9 +826,16 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
           const bf16x8 &bh = bfr[t & 1][0], &bm = bfr[t & 1][1], &bl = bfr[t & 1][2];
 #pragma unroll
           for (int a = 0; a < 2; a++) {
+#ifdef TN_KO_HALF
+            // (knock-out: what a two-piece operand split would leave of the step -- three products instead of six)
+            if constexpr (g == 0) asm volatile("" ::"v"(al[a]), "v"(bh));
+            else if constexpr (g == 1) asm volatile("" ::"v"(ah[a]), "v"(bl));
+            else if constexpr (g == 2) asm volatile("" ::"v"(am[a]), "v"(bm));
+#else
             if constexpr (g == 0) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
             else if constexpr (g == 1) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][t], 0, 0, 0);
             else if constexpr (g == 2) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][t], 0, 0, 0);
+#endif
             else if constexpr (g == 3) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][t], 0, 0, 0);
             else if constexpr (g == 4) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
             else acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
