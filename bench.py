@@ -379,7 +379,7 @@ def main():
         # issues per fp32 product -- three for the two-piece fp16 kernels (GEMM-epilogue forms), six for the three-piece
         # bf16 ones (weight gradients, plain products of odd shapes)
         tf = kern[k]["flops_per_launch"] / (kern[k]["avg_ms"] * 1e-3) / 1e12      # algorithmic 2*M*K*N per launch
-        terms = 3.0 if k.startswith(("gemm_act_norm", "gemm_an_bwd", "gemm_nt_f16")) else 6.0
+        terms = 3.0 if k.startswith(("gemm_act_norm", "gemm_an_bwd", "gemm_nt_f16", "gemm_tn_f16")) else 6.0
         peak = MFMA_BF16_PEAK_TF / terms
         return dict(bound="mfma", kernel=k, achieved=round(tf, 1), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                     traffic=traffic_of(k), traffic_source=tsrc if traffic_of(k) else None, avg_ms=round(kern[k]["avg_ms"], 4),

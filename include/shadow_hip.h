@@ -310,6 +310,14 @@ int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_ind
 uint32_t sl_gemm_tn_slices(uint32_t M);
 int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb, float *d_C, uint32_t M, uint32_t N,
                    uint32_t K, float *d_partial, float *d_a_colsum, void *stream);
+/* The same product on two fp16 pieces per element (three matrix-core products per tile instead of six): N = K = 256 only,
+ * at most 3040 rows per slice (M <= 3040 * sl_gemm_tn_slices(M)).  d_a_amax / d_b_amax [M]: max_k |row| of the operands
+ * (upper bounds work too) -- row r of A is scaled by the power of two that puts it at the top of the fp16 range, row r of
+ * B by 2^c over that, c one constant per row slice; rows that are zero in either operand contribute nothing.  Measured
+ * error against fp64: that of the bf16 form.  Same slices, d_partial ([slices, N, K]) and fixed-order reduction.
+ * SG_ERR_INVALID for shapes it does not take (use sl_gemm_tn_f32). */
+int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb, const float *d_b_amax,
+                   float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, void *stream);
 
 /* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
  * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)
@@ -517,7 +525,10 @@ int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const v
  * d_an_partial and the forward tensors Zs / Zn are not touched) and only runs A^T dZn, its own input-gradient product
  * and the two weight gradients.  d_dout_rows (may be NULL; dz_ready = 0 only): the output gradient is given for num_dout_rows
  * selected rows only (d_dout / d_dout_dropped [num_dout_rows, Fout] compact, see sl_act_norm_bwd) -- the top layer under a
- * read-out that takes the roots' rows.  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, stream).                             */
+ * read-out that takes the roots' rows.  d_x_amax (may be NULL): max_k |X[i, k]| per row, as the kernel that produced X left
+ * it -- with it (and n >= 32768, Fin = Fout = 256) the two weight gradients run on two fp16 pieces (sl_gemm_tn_f16), the
+ * neighbour branch as dWn = (A^T dZn)^T X over the transposed aggregate of the input-gradient product (d_AX is then not
+ * read).  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, stream).                                       */
 typedef struct {
   const float *Zs, *Zn;            /* [n, F] pre-activations of the layer below (dense rows) */
   const float *bs, *bn;            /* its biases (may be NULL) */
@@ -538,7 +549,7 @@ int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, con
                       float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
                       float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                       float *d_an_partial, float *d_tn_partial, void *d_pack, int dz_ready, const sl_sage_below *below,
-                      float *d_dzs_amax, const uint32_t *d_dout_rows, uint32_t num_dout_rows, void *stream);
+                      float *d_dzs_amax, const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, void *stream);
 
 /* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
  * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /

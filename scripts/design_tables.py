@@ -24,6 +24,7 @@ ROC = {
     "gemm_act_norm_fwd_nb2_N256": "gemm_nt_fused_kernel<8, 0, 2, 2, false>",
     "gemm_act_norm_fwd_nb2_N256_Ktail": "gemm_nt_fused_kernel<8, 0, 2, 2, true>",
     "gemm_tn_split_N256": "gemm_tn_coop_kernel<4, true>",
+    "gemm_tn_f16_N256": "gemm_tn_f16_kernel",
     "gemm_tn_split_N256_K128": "gemm_tn_split_kernel<2>",
     "act_norm_bwd_nb2_F256": "act_norm_kernel<64, 64, true, 2>",
     "gather_F100": "gather_rows_drop_kernel<32>",
@@ -35,7 +36,7 @@ HBM, MFMA6, MFMA3 = 8000.0, 2500.0 / 6.0, 2500.0 / 3.0
 
 def mfma_roof(kernel):
     """fp32-equivalent roof of a GEMM class: six bf16 products per multiply-add (tn, plain nt) or three fp16 ones."""
-    return MFMA3 if kernel.startswith(("gemm_act_norm", "gemm_an_bwd", "gemm_nt_f16")) else MFMA6
+    return MFMA3 if kernel.startswith(("gemm_act_norm", "gemm_an_bwd", "gemm_nt_f16", "gemm_tn_f16")) else MFMA6
 
 
 def main():

@@ -137,7 +137,7 @@ SIGNATURES = {
     "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P]),
+                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P, _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
     "sl_prof_enable": (C.c_int, [C.c_int]),
     "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -167,6 +167,7 @@ SIGNATURES = {
     "sl_clip_adam": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_float, _P, _P]),
     "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "sl_gemm_tn_f16": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
     "sl_segment_pool_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, _P, C.c_int64, _P]),
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),
@@ -187,7 +188,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 12      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 13      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -961,6 +961,224 @@ gemm_tn_reduce_kernel(const float *__restrict__ partial, uint32_t G, uint32_t NK
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on TWO fp16 pieces per element and three MFMAs per tile (gemm_common.h: h = rn16(x), m = rn16(x - h);
+// terms mh, hm, hh) -- half the matrix-core work the interleaved step above is bound by.  The contraction runs over the
+// ROWS, so a row's scale cannot be taken out of the accumulators afterwards: row r of A is multiplied by s_r (the power of
+// two that puts its largest magnitude into [2^14, 2^15)) and row r of B by t_r = 2^c / s_r, c one constant per row slice --
+// the smallest s_r * (B's own top-of-range scale) over the slice's rows, so that no row of B leaves the fp16 range and the
+// row pair with the largest product sits at the top of it; the partial product leaves the workgroup multiplied by 2^-c
+// (all exact).  Row pairs more than 2^17 below the slice's largest lose low bits of B -- of terms that are below the sum's
+// own fp32 resolution by then.  A row of zeros in either operand gets s_r = t_r = 0 (0 * inf never forms).  The caller
+// supplies max_k |row| of both operands (any upper bound works; the producers' arrays of the nt kernels are used).
+// N = K = 256; same slices, same partial layout and reduction as above; every step runs the hand-ordered block (the last
+// steps with predicated copies): 12 slots of { MFMA pair | piece: two elements of the next step's split }.
+typedef float float4v __attribute__((ext_vector_type(4)));
+constexpr int kTnImg16Vecs = 2 * 2 * 8 * 64;          // half8 vectors of one step's image: [operand][piece][tile][lane]
+constexpr uint32_t kTnF16MaxRows = 3040;              // rows of a slice whose scale pairs fit beside tiles and images
+
+__device__ __forceinline__ int scale_exponent(float amax) {      // row_scale_of(amax) == 2^this (amax > 0)
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu) - 127;
+  return min(max(14 - e, -62), 62);
+}
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }   // -126 <= e <= 127
+
+__global__ void __launch_bounds__(kTnThreads)
+gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ aamax, const float *__restrict__ B, int64_t ldb,
+                   const float *__restrict__ bamax, float *__restrict__ partial, uint32_t M, uint32_t rows_per_wg) {
+  constexpr int TK = 4;
+  constexpr uint32_t N = 256, K = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  float *lbuf = reinterpret_cast<float *>(tsm);                                    // [2][kTnStepFloats]: fp32 row tiles
+  half8 *fimg = reinterpret_cast<half8 *>(tsm + (size_t)2 * kTnStepFloats * 4);    // [2][kTnImg16Vecs]
+  float *S = reinterpret_cast<float *>(tsm + (size_t)2 * kTnStepFloats * 4 + (size_t)2 * kTnImg16Vecs * 16);   // [rows_per_wg + 32]
+  float *T = S + rows_per_wg + 32;
+  __shared__ int red_e[8];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t r = lane & 31u, kg = lane >> 5;
+  const uint32_t wn = wv >> 1, wk = wv & 1u;                  // 4 x 2 wavefront grid
+  const uint64_t m_begin = (uint64_t)blockIdx.x * rows_per_wg;
+  const uint64_t m_end = min((uint64_t)M, m_begin + rows_per_wg);
+  const uint32_t steps = m_end > m_begin ? (uint32_t)((m_end - m_begin + 15) / 16) : 0u;   // (slices past M write zeros)
+
+  for (uint32_t i = tid; i < 2 * kTnStepFloats / 4; i += kTnThreads)
+    reinterpret_cast<float4 *>(lbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- the slice's scale pairs: exponents first (S holds e_A as an int, T the valid flag), then c, then the powers of two
+  const uint32_t padded = (steps + 1) * 16;                   // (one step past the end: the last step splits a step nobody multiplies)
+  int emin = 1 << 20;
+  for (uint32_t i = tid; i < padded; i += kTnThreads) {
+    const uint64_t row = m_begin + i;
+    const float aa = row < m_end ? aamax[row] : 0.f, bb = row < m_end ? bamax[row] : 0.f;
+    const bool valid = aa > 0.f && bb > 0.f;
+    const int ea = valid ? scale_exponent(aa) : 0, eb = valid ? scale_exponent(bb) : 0;
+    if (valid) emin = min(emin, ea + eb);
+    reinterpret_cast<int *>(S)[i] = ea;
+    T[i] = valid ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) emin = min(emin, __shfl_xor(emin, o, 64));
+  if (lane == 0) red_e[wv] = emin;
+  __syncthreads();
+  int c = red_e[0];
+#pragma unroll
+  for (int w = 1; w < 8; w++) c = min(c, red_e[w]);
+  if (c == (1 << 20)) c = 0;                                  // no row pair with a non-zero product
+  for (uint32_t i = tid; i < padded; i += kTnThreads) {
+    const int ea = reinterpret_cast<int *>(S)[i];
+    const bool valid = T[i] != 0.f;
+    const int te = c - ea;                                    // <= the row's own e_B: B stays inside the fp16 range
+    S[i] = valid ? pow2i(ea) : 0.f;
+    T[i] = (valid && te >= -126) ? pow2i(te) : 0.f;           // (below 2^-126: the pair is > 2^120 under the slice's largest)
+  }
+
+  f32x16 acc[2][TK];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int t = 0; t < TK; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[a][t][i] = 0.f;
+
+  // copy `part` (0..3) of k-step s: this wavefront moves rows {2 wv, 2 wv + 1} of the A tile and of the B tile
+  auto fill = [&](uint32_t s, int part) {
+    const uint32_t lr = 2 * wv + (part & 1);
+    const uint64_t row = m_begin + (uint64_t)s * 16 + lr;
+    const bool isb = part >= 2;
+    float *dst = lbuf + (size_t)(s & 1) * kTnStepFloats + (isb ? 16 * kTnRowFloats : 0) + lr * kTnRowFloats;
+    if (row < m_end) {
+      const float *src = (isb ? B + row * ldb : A + row * lda);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane * 4),
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    } else {
+      *reinterpret_cast<float4 *>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // fragment `lane` of tile `wv` of operand op (0: A, 1: B) of k-step s: row tile -> two fp16 pieces in the image
+  auto split_job16 = [&](uint32_t s, int op) {
+    const float *tile = lbuf + (size_t)(s & 1) * kTnStepFloats + (op ? 16 * kTnRowFloats : 0);
+    const float *sc = (op ? T : S) + (size_t)s * 16 + 8 * kg;
+    half8 h, m;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float x = tile[(8 * kg + j) * kTnRowFloats + 32 * wv + r] * sc[j];
+      const _Float16 hj = (_Float16)x;
+      h[j] = hj;
+      m[j] = (_Float16)(x - (float)hj);
+    }
+    half8 *dst = fimg + (size_t)(s & 1) * kTnImg16Vecs + ((size_t)op * 2 * 8 + wv) * 64 + lane;
+    dst[0] = h; dst[8 * 64] = m;
+  };
+  __syncthreads();                                           // the zeroed tiles and the scale pairs are in place
+  if (steps > 0) {
+#pragma unroll
+    for (int part = 0; part < 4; part++) fill(0, part);
+    if (steps > 1) {
+#pragma unroll
+      for (int part = 0; part < 4; part++) fill(1, part);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (steps > 0) { split_job16(0, 0); split_job16(0, 1); }
+  __syncthreads();
+
+  half8 ah[2], am[2];
+  half8 bfr[2][2];                                             // B fragments (h, m) of tile t (t & 1) and of the next one
+  float2v xr[4], xq[4];                                        // raw columns of the A / B tile being split: rows 8 kg .. 8 kg + 7
+  float4v sv[2], tv[2];                                        // their rows' scales
+  auto body = [&](uint32_t s, auto steady_c) {
+    constexpr bool steady = decltype(steady_c)::value;
+    const half8 *img = fimg + (size_t)(s & 1) * kTnImg16Vecs;
+    if constexpr (steady) {
+      float *tb = lbuf + (size_t)(s & 1) * kTnStepFloats + (size_t)(2 * wv) * kTnRowFloats;
+      const uint64_t row = m_begin + (uint64_t)(s + 2) * 16 + 2 * wv;
+      const float *sa = A + row * lda + lane * 4, *sb = B + row * ldb + lane * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
+                                       (__attribute__((address_space(3))) void *)tb, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sa + lda),
+                                       (__attribute__((address_space(3))) void *)(tb + kTnRowFloats), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sb,
+                                       (__attribute__((address_space(3))) void *)(tb + 16 * kTnRowFloats), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + ldb),
+                                       (__attribute__((address_space(3))) void *)(tb + 17 * kTnRowFloats), 16, 0, 0);
+    } else if (s + 2 < steps) {
+      fill(s + 2, 0); fill(s + 2, 1); fill(s + 2, 2); fill(s + 2, 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the zero fill of rows past the end is a plain LDS store)
+    }
+    // LDS accesses by hand, counted waits (see the bf16 kernel above).  Head: F1 = am0 am1 bh | F2 = ah0 ah1 bm (tile 0, in
+    // the order the first two MFMA pairs need them), RA = raw A column of step s + 1, SA = the scales of its eight rows.
+    const uint32_t fa = lds_addr(img + (size_t)(2 * wn) * 64 + lane), fb = lds_addr(img + ((size_t)2 * 8 + TK * wk) * 64 + lane);
+    const uint32_t ra = lds_addr(lbuf + (size_t)((s + 1) & 1) * kTnStepFloats + (size_t)(8 * kg) * kTnRowFloats + 32 * wv + r);
+    const uint32_t sa = lds_addr(S + (size_t)(s + 1) * 16 + 8 * kg), ta = lds_addr(T + (size_t)(s + 1) * 16 + 8 * kg);
+    const uint32_t wa = lds_addr(fimg + (size_t)((s + 1) & 1) * kTnImg16Vecs + (size_t)wv * 64 + lane);
+    am[0] = lds_read_frag<8192, half8>(fa); am[1] = lds_read_frag<8192 + 1024, half8>(fa); bfr[0][0] = lds_read_frag<0, half8>(fb);
+    ah[0] = lds_read_frag<0, half8>(fa); ah[1] = lds_read_frag<1024, half8>(fa); bfr[0][1] = lds_read_frag<8192, half8>(fb);
+    xr[0] = lds_read2st64<0, 4>(ra); xr[1] = lds_read2st64<8, 12>(ra); xr[2] = lds_read2st64<16, 20>(ra); xr[3] = lds_read2st64<24, 28>(ra);
+    sv[0] = lds_read_frag<0, float4v>(sa); sv[1] = lds_read_frag<16, float4v>(sa);
+    half8 H, Mm;
+    auto piece = [&](auto pc) {                               // elements 2 q, 2 q + 1 of job (p / 4)
+      constexpr int p = decltype(pc)::value, job = p / 4, q = p % 4;
+      const float2v xx = job ? xq[q] : xr[q];
+      const float4v ss = job ? tv[q / 2] : sv[q / 2];
+      const float x0 = xx.x * ((q & 1) ? ss.z : ss.x), x1 = xx.y * ((q & 1) ? ss.w : ss.y);
+      const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+      H[2 * q] = h0; H[2 * q + 1] = h1;
+      Mm[2 * q] = (_Float16)(x0 - (float)h0); Mm[2 * q + 1] = (_Float16)(x1 - (float)h1);
+      if constexpr (q == 3) { lds_write_frag<job * 16384>(wa, H); lds_write_frag<job * 16384 + 8192>(wa, Mm); }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<3 * TK>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, t = k / 3, g = k % 3;
+      if constexpr (k == 0) lds_wait<9>();
+      else if constexpr (k == 1) lds_wait<6>();
+      else if constexpr (g == 0) lds_wait<0>();
+      {
+        const half8 &bh = bfr[t & 1][0], &bm = bfr[t & 1][1];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          if constexpr (g == 0) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[a], bh, acc[a][t], 0, 0, 0);
+          else if constexpr (g == 1) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bm, acc[a][t], 0, 0, 0);
+          else acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh, acc[a][t], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k == 1) lds_wait<0>();                      // the raw A column and its scales
+      if constexpr (g == 1 && t + 1 < TK) {
+        constexpr int o = (t + 1) * 1024, nb = (t + 1) & 1;
+        bfr[nb][0] = lds_read_frag<o, half8>(fb); bfr[nb][1] = lds_read_frag<o + 8192, half8>(fb);
+      }
+      if constexpr (k == 2) {           // the raw B column and its scales: first used by piece 4 at pair 5, behind the wait of pair 3
+        xq[0] = lds_read2st64<64, 68>(ra); xq[1] = lds_read2st64<72, 76>(ra); xq[2] = lds_read2st64<80, 84>(ra); xq[3] = lds_read2st64<88, 92>(ra);
+        tv[0] = lds_read_frag<0, float4v>(ta); tv[1] = lds_read_frag<16, float4v>(ta);
+      }
+      if constexpr (k >= 1 && k <= 8) piece(std::integral_constant<int, (k >= 1 && k <= 8) ? k - 1 : 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  uint32_t s = 0;
+  for (; s + 3 < steps; s++) body(s, std::true_type{});
+  for (; s < steps; s++) body(s, std::false_type{});
+
+  // partial[g][n][k] = 2^-c * accumulators
+  const float unscale = pow2i(-c);
+  float *out = partial + (size_t)blockIdx.x * ((size_t)N * K);
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+#pragma unroll
+    for (int t = 0; t < TK; t++) {
+      const uint32_t kc = 32 * (TK * wk + t) + r;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const uint32_t nr = 32 * (2 * wn + a) + (i & 3) + 8 * (i >> 2) + 4 * kg;
+        out[(size_t)nr * K + kc] = acc[a][t][i] * unscale;
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace shadow
 
@@ -972,6 +1190,30 @@ extern "C" uint32_t sl_gemm_tn_slices(uint32_t M) {
   // at least 8 k-steps per workgroup (SHADOW_GEMM_TN_MIN_ROWS; 256 until round 3: M = 39.5 k, N = K = 256 then ran on 154 CUs)
   static const uint32_t min_rows = [] { const char *e = getenv("SHADOW_GEMM_TN_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : 128u; }();
   return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ncu, (M + min_rows - 1) / min_rows));
+}
+
+// dW = A^T B on two fp16 pieces per element (gemm_tn_f16_kernel): N = K = 256, the row maxima of both operands given.
+// Returns SG_ERR_INVALID for shapes the kernel does not take (callers fall back to sl_gemm_tn_f32).
+extern "C" int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb, const float *d_b_amax,
+                              float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, void *stream) {
+  if (!d_A || !d_B || !d_C || !d_partial || !d_a_amax || !d_b_amax) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: null argument");
+  if (N != 256 || K != 256) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: N = %u, K = %u (both 256)", N, K);
+  if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(d_A) & 15) || (reinterpret_cast<uintptr_t>(d_B) & 15))
+    return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (M == 0) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: M = 0");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t G = sl_gemm_tn_slices(M);
+  uint32_t rows_per_wg = (M + G - 1) / G;
+  rows_per_wg = (rows_per_wg + 15u) & ~15u;
+  if (rows_per_wg > kTnF16MaxRows) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: %u rows per slice (at most %u)", rows_per_wg, kTnF16MaxRows);
+  const size_t lds = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * kTnImg16Vecs * 16 + (size_t)2 * (rows_per_wg + 32) * 4;
+  SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_f16_kernel, lds));
+  hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_a_amax, d_B, ldb, d_b_amax, d_partial, M, rows_per_wg);
+  SHD_HIP(hipGetLastError());
+  const uint32_t NK = N * K;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, 0u, (float *)nullptr);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
 }
 
 extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb, float *d_C, uint32_t M,

@@ -156,7 +156,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
                                  const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
                                  float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
                                  void *d_pack, int dz_ready, const sl_sage_below *below, float *d_dzs_amax,
-                                 const uint32_t *d_dout_rows, uint32_t num_dout_rows, void *stream) {
+                                 const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, void *stream) {
   if (!adj || !d_X || !d_AX || !d_Ws || !d_Wn || !d_dWs || !d_dWn || !d_buf || !d_tn_partial || !d_pack)
     return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
   if (!dz_ready && (!d_Zs || !d_Zn || !d_scale || !d_offset || !d_dscale || !d_doffset || !d_an_partial || (!d_dout && !d_dout_dropped)))
@@ -249,6 +249,20 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       return rc;
     }
   }
+  // Weight gradients.  With the row maxima of [dZs | A^T dZn] (amx: the K = 2 Fout operand of the input gradient above) and
+  // of X in hand, both run on two fp16 pieces (sl_gemm_tn_f16) -- the neighbour branch as
+  //     dWn = dZn^T (A X) = (A^T dZn)^T X
+  // over the transposed aggregate that is already there: same operand X, no row maxima of dZn / A X needed.
+  static const bool tn16 = !(getenv("SHADOW_GEMM_TN_F16") && getenv("SHADOW_GEMM_TN_F16")[0] == '0');
+  if (tn16 && d_x_amax && f16dx && hand && Fin == 256 && Fout == 256 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(d_X) & 15) == 0 &&
+      (n + sl_gemm_tn_slices(n) - 1) / sl_gemm_tn_slices(n) <= 3024) {
+    {
+      SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
+      if ((rc = sl_gemm_tn_f16(dZs, ld3, amx, d_X, ldx, d_x_amax, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
+    }
+    SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
+    return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+  }
   if ((rc = tn_gemm(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
   return tn_gemm(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
 }
@@ -262,7 +276,7 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                            void *d_pack, void *stream) {
   return sl_sage_bwd_chain(adj, d_X, ldx, d_AX, ldax, d_Zs, d_Zn, Fin, Fout, d_Ws, ldws, d_bs, d_Wn, ldwn, d_bn, d_scale, d_offset, act,
                            drop_p, drop_seed, d_dout, d_dout_dropped, d_dX, d_dWs, d_dWn, d_dbias, d_dscale, d_doffset, d_buf,
-                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, nullptr, 0, stream);
+                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

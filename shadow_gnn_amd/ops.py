@@ -647,6 +647,21 @@ def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Cm
 
 
+def weight_grad_f16(dZ: torch.Tensor, X: torch.Tensor, dz_amax: Optional[torch.Tensor] = None, x_amax: Optional[torch.Tensor] = None):
+    """dW = dZ^T X (both 256 wide) on two fp16 pieces per element with the joint row scaling of sl_gemm_tn_f16; the row
+    maxima come from the operands' producers (``get_row_amax``) or from one more pass (``row_amax``)."""
+    n = dZ.shape[0]
+    dz_amax = dz_amax if dz_amax is not None else (get_row_amax(dZ) if get_row_amax(dZ) is not None else row_amax(dZ))
+    x_amax = x_amax if x_amax is not None else (get_row_amax(X) if get_row_amax(X) is not None else row_amax(X))
+    lib = _lib.load()
+    partial = torch.empty(lib.sl_gemm_tn_slices(n) * 256 * 256, dtype=torch.float32, device=dZ.device)
+    dW = torch.empty(256, 256, dtype=torch.float32, device=dZ.device)
+    with _timed("gemm_tn_f16_N256", 4 * n * 512, dZ.device, flops=2 * n * 256 * 256):
+        check(lib.sl_gemm_tn_f16(dZ.data_ptr(), dZ.stride(0), dz_amax.data_ptr(), X.data_ptr(), X.stride(0), x_amax.data_ptr(),
+                                 dW.data_ptr(), n, 256, 256, partial.data_ptr(), _stream(dZ)))
+    return dW
+
+
 def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False):
     """dW = dZ^T X for tall inputs (K = number of batch nodes, hundreds of thousands).
     rocBLAS picks a 32-workgroup kernel for a plain 256 x n x 256 product; splitting n
@@ -1071,7 +1086,9 @@ class _SageDense(torch.autograd.Function):
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
         bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
+        ctx.x_amax = None
         if AX is None:
+            ctx.x_amax = get_row_amax(X)        # (the backward's weight gradients scale their fp16 pieces by it, sl_gemm_tn_f16)
             AX, Zs, Zn, out = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop)
             _SageDense.fused_calls += 1
         elif gemm_act_norm_usable([X, AX], [Ws, Wn], F, F):
@@ -1197,7 +1214,7 @@ class _SageDense(torch.autograd.Function):
                                     C.byref(below) if below is not None else None,
                                     up.amax.data_ptr() if (dz_ready and up.amax is not None) else None,
                                     dout_rows.data_ptr() if dout_rows is not None else None,
-                                    int(dout_rows.numel()) if dout_rows is not None else 0, _stream(Zs)))
+                                    int(dout_rows.numel()) if dout_rows is not None else 0, opt(ctx.x_amax), _stream(Zs)))
         if dz_ready:
             up.release()
         if dout_rows is not None:

@@ -525,6 +525,42 @@ def test_weight_gradient_gemm_interleaved_step_is_bit_identical(M, lda, monkeypa
     torch.testing.assert_close(got_cs.double(), dZ.double().sum(0), rtol=1e-5, atol=1e-5 * float(dZ.abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("M,lda", [(300000, 768), (289309, 256), (16 * 256 * 3 + 5, 768), (40000, 256), (1100, 256), (37, 256)])
+@pytest.mark.parametrize("kind", ["normal", "binades", "sparse_rows", "wide_rows"])
+def test_weight_gradient_gemm_on_two_fp16_pieces_matches_fp64(M, lda, kind):
+    """sl_gemm_tn_f16: dW = dZ^T X with every element as two fp16 pieces (three MFMAs per tile), row r of dZ scaled by the
+    power of two that puts it at the top of the fp16 range and row r of X by 2^c over that (c per row slice).  Held to the
+    bf16 x 3 kernel's bound against fp64 relative to sum |a||b| -- unit-normal operands, rows spread over 30 binades
+    (independently in the two operands), a gradient with 0.4 % non-zero rows (the sparse read-out gradient of the top layer:
+    zero rows must not meet an overflowing scale), magnitudes spread inside the rows -- and to twice the bf16 kernel's own
+    error; deterministic; upper bounds instead of the exact row maxima give the same accuracy class."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + lda + len(kind))
+    dZ = torch.randn(M, lda, device=DEV, generator=g)[:, :256]
+    X = torch.randn(M, 256, device=DEV, generator=g)
+    if kind == "binades":
+        dZ = dZ * torch.exp2(torch.randint(-15, 15, (M, 1), device=DEV, generator=g).float())
+        X = X * torch.exp2(torch.randint(-15, 15, (M, 1), device=DEV, generator=g).float())
+    elif kind == "sparse_rows":
+        dZ = dZ * (torch.rand(M, 1, device=DEV, generator=g) < 0.004).float()
+        X = X * 1e3
+    elif kind == "wide_rows":
+        dZ = dZ * torch.exp(2 * torch.randn(M, 256, device=DEV, generator=g))
+        X = X * torch.exp(2 * torch.randn(M, 256, device=DEV, generator=g))
+    dZ = dZ if dZ.stride(1) == 1 else dZ.contiguous()
+    da, xa = ops.row_amax(dZ), ops.row_amax(X)
+    got = ops.weight_grad_f16(dZ, X, da, xa)
+    assert bool(torch.isfinite(got).all())
+    ref = dZ.double().t() @ X.double()
+    den = (dZ.abs().double().t() @ X.abs().double()).clamp_min(1e-300)
+    err = float(((got.double() - ref).abs() / den).max())
+    bf = float(((ops.weight_grad(dZ, X).double() - ref).abs() / den).max()) if M >= 1024 else 1.5e-6
+    assert err < 1.5e-6 and err <= 2 * bf + 1e-9, (err, bf)
+    assert torch.equal(got, ops.weight_grad_f16(dZ, X, da, xa))
+    loose = ops.weight_grad_f16(dZ, X, da * 3.0, xa * 5.0)          # upper bounds of the row maxima
+    assert float(((loose.double() - ref).abs() / den).max()) < 1.5e-6
+
+
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
 def test_act_norm_fused_output_dropout(nb, F, seg):
     """The next layer's input dropout folded into act_norm's output: the kernel's mask equals the documented
