@@ -314,10 +314,10 @@ int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
  * at most 3040 rows per slice (M <= 3040 * sl_gemm_tn_slices(M)).  d_a_amax / d_b_amax [M]: max_k |row| of the operands
  * (upper bounds work too) -- row r of A is scaled by the power of two that puts it at the top of the fp16 range, row r of
  * B by 2^c over that, c one constant per row slice; rows that are zero in either operand contribute nothing.  Measured
- * error against fp64: that of the bf16 form.  Same slices, d_partial ([slices, N, K]) and fixed-order reduction.
- * SG_ERR_INVALID for shapes it does not take (use sl_gemm_tn_f32). */
+ * error against fp64: that of the bf16 form.  Same slices, d_partial ([slices, N, K], + N per slice with d_a_colsum), fixed-order
+ * reduction and d_a_colsum (column sums of the unscaled A) as sl_gemm_tn_f32.  SG_ERR_INVALID for shapes it does not take. */
 int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb, const float *d_b_amax,
-                   float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, void *stream);
+                   float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, float *d_a_colsum, void *stream);
 
 /* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
  * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)

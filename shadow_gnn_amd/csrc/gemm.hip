@@ -986,7 +986,7 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((uint32_t
 
 __global__ void __launch_bounds__(kTnThreads)
 gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ aamax, const float *__restrict__ B, int64_t ldb,
-                   const float *__restrict__ bamax, float *__restrict__ partial, uint32_t M, uint32_t rows_per_wg) {
+                   const float *__restrict__ bamax, float *__restrict__ partial, uint32_t M, uint32_t rows_per_wg, uint32_t colsum) {
   constexpr int TK = 4;
   constexpr uint32_t N = 256, K = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
@@ -1054,14 +1054,19 @@ gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__rest
       *reinterpret_cast<float4 *>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  float csum = 0.f;       // column sums of the RAW A values (nn.Linear's bias gradient): this wavefront sees every element of its 32 columns once
   // fragment `lane` of tile `wv` of operand op (0: A, 1: B) of k-step s: row tile -> two fp16 pieces in the image
   auto split_job16 = [&](uint32_t s, int op) {
     const float *tile = lbuf + (size_t)(s & 1) * kTnStepFloats + (op ? 16 * kTnRowFloats : 0);
     const float *sc = (op ? T : S) + (size_t)s * 16 + 8 * kg;
     half8 h, m;
+    float raw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) raw[j] = tile[(8 * kg + j) * kTnRowFloats + 32 * wv + r];
+    if (op == 0) csum += ((raw[0] + raw[1]) + (raw[2] + raw[3])) + ((raw[4] + raw[5]) + (raw[6] + raw[7]));
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const float x = tile[(8 * kg + j) * kTnRowFloats + 32 * wv + r] * sc[j];
+      const float x = raw[j] * sc[j];
       const _Float16 hj = (_Float16)x;
       h[j] = hj;
       m[j] = (_Float16)(x - (float)hj);
@@ -1119,6 +1124,10 @@ gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__rest
     half8 H, Mm;
     auto piece = [&](auto pc) {                               // elements 2 q, 2 q + 1 of job (p / 4)
       constexpr int p = decltype(pc)::value, job = p / 4, q = p % 4;
+      if constexpr (p == 0) {          // (the same order as split_job16; the step past the end holds stale data: not summed)
+        const float s8 = ((xr[0].x + xr[0].y) + (xr[1].x + xr[1].y)) + ((xr[2].x + xr[2].y) + (xr[3].x + xr[3].y));
+        csum += (s + 1 < steps) ? s8 : 0.f;
+      }
       const float2v xx = job ? xq[q] : xr[q];
       const float4v ss = job ? tv[q / 2] : sv[q / 2];
       const float x0 = xx.x * ((q & 1) ? ss.z : ss.x), x1 = xx.y * ((q & 1) ? ss.w : ss.y);
@@ -1162,9 +1171,13 @@ gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__rest
   for (; s + 3 < steps; s++) body(s, std::true_type{});
   for (; s < steps; s++) body(s, std::false_type{});
 
-  // partial[g][n][k] = 2^-c * accumulators
+  // partial[g][n][k] = 2^-c * accumulators (+ [N] column sums of A behind it when asked for)
   const float unscale = pow2i(-c);
-  float *out = partial + (size_t)blockIdx.x * ((size_t)N * K);
+  float *out = partial + (size_t)blockIdx.x * ((size_t)N * K + (colsum ? N : 0u));
+  if (colsum) {
+    const float both = csum + __shfl_xor(csum, 32, 64);            // the two 8-row halves of every step
+    if (kg == 0) out[(size_t)N * K + 32 * wv + r] = both;
+  }
 #pragma unroll
   for (int a = 0; a < 2; a++) {
 #pragma unroll
@@ -1195,7 +1208,7 @@ extern "C" uint32_t sl_gemm_tn_slices(uint32_t M) {
 // dW = A^T B on two fp16 pieces per element (gemm_tn_f16_kernel): N = K = 256, the row maxima of both operands given.
 // Returns SG_ERR_INVALID for shapes the kernel does not take (callers fall back to sl_gemm_tn_f32).
 extern "C" int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb, const float *d_b_amax,
-                              float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, void *stream) {
+                              float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, float *d_a_colsum, void *stream) {
   if (!d_A || !d_B || !d_C || !d_partial || !d_a_amax || !d_b_amax) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: null argument");
   if (N != 256 || K != 256) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: N = %u, K = %u (both 256)", N, K);
   if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(d_A) & 15) || (reinterpret_cast<uintptr_t>(d_B) & 15))
@@ -1208,10 +1221,11 @@ extern "C" int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_am
   if (rows_per_wg > kTnF16MaxRows) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16: %u rows per slice (at most %u)", rows_per_wg, kTnF16MaxRows);
   const size_t lds = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * kTnImg16Vecs * 16 + (size_t)2 * (rows_per_wg + 32) * 4;
   SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_f16_kernel, lds));
-  hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_a_amax, d_B, ldb, d_b_amax, d_partial, M, rows_per_wg);
+  hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_a_amax, d_B, ldb, d_b_amax, d_partial, M, rows_per_wg,
+                     d_a_colsum ? 1u : 0u);
   SHD_HIP(hipGetLastError());
-  const uint32_t NK = N * K;
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, 0u, (float *)nullptr);
+  const uint32_t NK = N * K + (d_a_colsum ? N : 0u);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, N * K, d_a_colsum);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -258,10 +258,10 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       (n + sl_gemm_tn_slices(n) - 1) / sl_gemm_tn_slices(n) <= 3024) {
     {
       SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
-      if ((rc = sl_gemm_tn_f16(dZs, ld3, amx, d_X, ldx, d_x_amax, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
+      if ((rc = sl_gemm_tn_f16(dZs, ld3, amx, d_X, ldx, d_x_amax, d_dWs, n, Fout, Fin, d_tn_partial, nullptr, stream)) != SG_OK) return rc;
     }
     SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
-    return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+    return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, stream);
   }
   if ((rc = tn_gemm(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
   return tn_gemm(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);

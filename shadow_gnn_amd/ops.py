@@ -647,19 +647,35 @@ def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Cm
 
 
-def weight_grad_f16(dZ: torch.Tensor, X: torch.Tensor, dz_amax: Optional[torch.Tensor] = None, x_amax: Optional[torch.Tensor] = None):
+def weight_grad_f16(dZ: torch.Tensor, X: torch.Tensor, dz_amax: Optional[torch.Tensor] = None, x_amax: Optional[torch.Tensor] = None,
+                    want_colsum: bool = False):
     """dW = dZ^T X (both 256 wide) on two fp16 pieces per element with the joint row scaling of sl_gemm_tn_f16; the row
-    maxima come from the operands' producers (``get_row_amax``) or from one more pass (``row_amax``)."""
+    maxima come from the operands' producers (``get_row_amax``) or from one more pass (``row_amax``).
+    ``want_colsum``: returns (dW, dZ.sum(0)) -- nn.Linear's bias gradient from the same pass over dZ."""
     n = dZ.shape[0]
     dz_amax = dz_amax if dz_amax is not None else (get_row_amax(dZ) if get_row_amax(dZ) is not None else row_amax(dZ))
     x_amax = x_amax if x_amax is not None else (get_row_amax(X) if get_row_amax(X) is not None else row_amax(X))
     lib = _lib.load()
-    partial = torch.empty(lib.sl_gemm_tn_slices(n) * 256 * 256, dtype=torch.float32, device=dZ.device)
+    per = 256 * 256 + (256 if want_colsum else 0)
+    partial = torch.empty(lib.sl_gemm_tn_slices(n) * per, dtype=torch.float32, device=dZ.device)
     dW = torch.empty(256, 256, dtype=torch.float32, device=dZ.device)
+    cs = torch.empty(256, dtype=torch.float32, device=dZ.device) if want_colsum else None
     with _timed("gemm_tn_f16_N256", 4 * n * 512, dZ.device, flops=2 * n * 256 * 256):
         check(lib.sl_gemm_tn_f16(dZ.data_ptr(), dZ.stride(0), dz_amax.data_ptr(), X.data_ptr(), X.stride(0), x_amax.data_ptr(),
-                                 dW.data_ptr(), n, 256, 256, partial.data_ptr(), _stream(dZ)))
-    return dW
+                                 dW.data_ptr(), n, 256, 256, partial.data_ptr(), cs.data_ptr() if cs is not None else None, _stream(dZ)))
+    return (dW, cs) if want_colsum else dW
+
+
+def weight_grad_f16_usable(dZ: torch.Tensor, X: torch.Tensor) -> bool:
+    """Shapes sl_gemm_tn_f16 takes (the callers add: row maxima of both operands in hand)."""
+    n = dZ.shape[0]
+    return (GEMM_SPLIT and TN_F16 and dZ.is_cuda and dZ.shape[1] == 256 and X.shape[1] == 256 and n >= AMAX_HANDOVER_ROWS
+            and dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.stride(1) == 1 and X.stride(1) == 1
+            and dZ.stride(0) % 4 == 0 and X.stride(0) % 4 == 0 and dZ.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
+            and -(-n // _lib.load().sl_gemm_tn_slices(n)) <= 3024)
+
+
+TN_F16 = os.environ.get("SHADOW_GEMM_TN_F16", "1") != "0"
 
 
 def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False):
@@ -753,6 +769,7 @@ class _LinearPair(torch.autograd.Function):
                                       M, N, K, _ptr_array(bs), _ptr_array(Zs), (C.c_int64 * 2)(N, N), st))
         ctx.save_for_backward(X, Wa, Wb)
         ctx.has_bias = (ba is not None, bb is not None)
+        ctx.x_amax = am                  # (the weight gradients scale their fp16 pieces by it, sl_gemm_tn_f16)
         ctx.set_materialize_grads(False)
         return Zs[0], Zs[1]
 
@@ -781,13 +798,15 @@ class _LinearPair(torch.autograd.Function):
                                              joint.data_ptr() if joint is not None else None,
                                              pack.data_ptr(), M, K, 2 * N, None, dX.data_ptr(), dX.stride(0), st))
         out = [dX, None, None, None, None]
+        # two fp16 pieces when the row maxima of both operands are in hand (the joint maxima bound either gradient's rows)
+        f16 = joint is not None and ctx.x_amax is not None and weight_grad_f16_usable(dZs[0], X) and weight_grad_f16_usable(dZs[1], X)
         for i, (dz, hb) in enumerate(zip(dZs, ctx.has_bias)):
             want_w, want_b = ng[1 + 2 * i], hb and ng[2 + 2 * i]
             if want_b:
-                dW, db = weight_grad(dz, X, want_colsum=True)
+                dW, db = weight_grad_f16(dz, X, joint, ctx.x_amax, True) if f16 else weight_grad(dz, X, want_colsum=True)
                 out[1 + 2 * i], out[2 + 2 * i] = (dW if want_w else None), db
             elif want_w:
-                out[1 + 2 * i] = weight_grad(dz, X)
+                out[1 + 2 * i] = weight_grad_f16(dz, X, joint, ctx.x_amax) if f16 else weight_grad(dz, X)
         return tuple(out)
 
 

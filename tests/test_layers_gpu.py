@@ -557,8 +557,10 @@ def test_weight_gradient_gemm_on_two_fp16_pieces_matches_fp64(M, lda, kind):
     bf = float(((ops.weight_grad(dZ, X).double() - ref).abs() / den).max()) if M >= 1024 else 1.5e-6
     assert err < 1.5e-6 and err <= 2 * bf + 1e-9, (err, bf)
     assert torch.equal(got, ops.weight_grad_f16(dZ, X, da, xa))
-    loose = ops.weight_grad_f16(dZ, X, da * 3.0, xa * 5.0)          # upper bounds of the row maxima
+    loose, cs = ops.weight_grad_f16(dZ, X, da * 3.0, xa * 5.0, True)          # upper bounds of the row maxima; column sums of dZ
     assert float(((loose.double() - ref).abs() / den).max()) < 1.5e-6
+    torch.testing.assert_close(cs.double(), dZ.double().sum(0), rtol=1e-5, atol=1e-5 * float(dZ.abs().sum(0).max()) + 1e-30)
+    assert torch.equal(cs, ops.weight_grad_f16(dZ, X, da, xa, True)[1])          # (the sums do not depend on the scales)
 
 
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
