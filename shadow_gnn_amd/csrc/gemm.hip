@@ -1010,7 +1010,7 @@ gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__rest
   for (uint32_t i = tid; i < padded; i += kTnThreads) {
     const uint64_t row = m_begin + i;
     const float aa = row < m_end ? aamax[row] : 0.f, bb = row < m_end ? bamax[row] : 0.f;
-    const bool valid = aa > 0.f && bb > 0.f;
+    const bool valid = !(aa == 0.f) && !(bb == 0.f);          // (a NaN maximum counts: its row must reach the product, not vanish)
     const int ea = valid ? scale_exponent(aa) : 0, eb = valid ? scale_exponent(bb) : 0;
     if (valid) emin = min(emin, ea + eb);
     reinterpret_cast<int *>(S)[i] = ea;

@@ -561,6 +561,12 @@ def test_weight_gradient_gemm_on_two_fp16_pieces_matches_fp64(M, lda, kind):
     assert float(((loose.double() - ref).abs() / den).max()) < 1.5e-6
     torch.testing.assert_close(cs.double(), dZ.double().sum(0), rtol=1e-5, atol=1e-5 * float(dZ.abs().sum(0).max()) + 1e-30)
     assert torch.equal(cs, ops.weight_grad_f16(dZ, X, da, xa, True)[1])          # (the sums do not depend on the scales)
+    if kind == "normal" and M > 1000:
+        # a NaN / Inf in an operand reaches the product (as in any fp32 GEMM) instead of vanishing with its row's scale
+        bad = dZ.clone(); bad[M // 2, 5] = float("nan")
+        assert bool(torch.isnan(ops.weight_grad_f16(bad, X)[5]).all())
+        bad[M // 2, 5] = float("inf")
+        assert not bool(torch.isfinite(ops.weight_grad_f16(bad, X)[5]).any())
 
 
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
