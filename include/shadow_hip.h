@@ -430,13 +430,16 @@ typedef struct {
 /* d_pack: sl_sage_pack_bytes(n, Fin, Fout) bytes of scratch (weight images + the operands' row maxima).
  * d_x_amax (may be NULL): max_k |X[i, k]| per row (sl_row_amax) when the producer of X already wrote it;
  * d_out_amax (may be NULL): receives the row maxima of the dropped output (of `out` without dropout) -- the d_x_amax
- * of the next layer -- from the GEMM epilogue while the rows are in registers.                                     */
+ * of the next layer -- from the GEMM epilogue while the rows are in registers.
+ * x_pad_zero != 0: the caller states that columns [Fin, roundup32(Fin)) of every row of X are zero (ldx reaches that far;
+ * the rows sl_gather_rows_drop_f32 writes are).  With rows of X and A X on whole 128-byte lines the aggregation then
+ * zero-fills the same columns of d_AX and the products read both at the padded width (no K tail).                 */
 size_t sl_sage_pack_bytes(uint32_t n, uint32_t Fin, uint32_t Fout);
 int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t Fin, uint32_t Fout, const float *d_Ws,
                 int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
                 const float *d_offset, int act, float drop_p, uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs,
                 float *d_Zn, float *d_out, float *d_out_dropped, const float *d_x_amax, float *d_out_amax,
-                void *d_pack, void *stream);
+                void *d_pack, int x_pad_zero, void *stream);
 int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
                 const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws, const float *d_bs,
                 const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale, const float *d_offset, int act,

@@ -130,7 +130,7 @@ SIGNATURES = {
     "sl_gemm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_sage_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_sage_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P,
-                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "sl_sage_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),

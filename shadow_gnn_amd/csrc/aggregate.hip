@@ -660,6 +660,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
           const float rs = rsc[k];
           const float4 y = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
           if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, y);
+          else if (lines == 2 && cur.valid) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(0.f, 0.f, 0.f, 0.f));   // the pad of the row's last line
           if (amax_bits) bd_row_amax(amax_bits + cur.a + i, on ? amax4(y) : 0.f, l8);
         }
       }
@@ -682,6 +683,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
         const float rs = row_scale ? row_scale[cur.a + i] : 1.0f;
         const float4 y = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
         if (on) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, y);
+        else if (lines == 2) SHD_ST_SPMM(Y + (int64_t)(cur.a + i) * ldy + f, make_float4(0.f, 0.f, 0.f, 0.f));
         if (amax_bits) bd_row_amax(amax_bits + cur.a + i, on ? amax4(y) : 0.f, l8);
       }
     }
@@ -1164,7 +1166,7 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                                  const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                                 uint32_t max_subg_nodes, const BdGather &bg, float *d_row_amax, void *stream_);
+                                 uint32_t max_subg_nodes, const BdGather &bg, float *d_row_amax, void *stream_, bool zero_pad = false);
 
 static int make_drop(BdGather *bg, float drop_p, uint64_t drop_seed, const char *who) {
   memset(bg, 0, sizeof(*bg));
@@ -1278,6 +1280,27 @@ extern "C" int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d
                                d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, d_row_amax, stream_);
 }
 
+namespace shadow {
+// sl_spmm_blockdiag_f32 on operands whose rows sit on whole 128-byte lines (ld % 32 == 0, 128-byte aligned, F % 32 != 0):
+// additionally writes zeros into the pad of every row's last line, [F, roundup32(F)) -- for callers that own the pad
+// (sl_sage_fwd: the layer's GEMM then reads A X at the padded width, without a K tail).  false: layout not eligible.
+bool spmm_blockdiag_lines_ok(uint32_t F, const float *X, int64_t ldx, const float *Y, int64_t ldy) {
+  const char *e = getenv("SHADOW_SPMM_LINES");
+  return !(e && e[0] == '0') && (F % 4 == 0) && F % 32 != 0 && ldx % 32 == 0 && ldy % 32 == 0 && (reinterpret_cast<uintptr_t>(X) & 127) == 0 &&
+         (reinterpret_cast<uintptr_t>(Y) & 127) == 0;
+}
+int spmm_blockdiag_padded(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const uint32_t *d_edge_perm,
+                          const float *d_row_scale, const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y, int64_t ldy,
+                          uint32_t n, uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                          uint32_t max_subg_nodes, float *d_row_amax, void *stream_) {
+  if (n == 0 || F == 0 || num_subg == 0) return SG_OK;
+  BdGather bg;
+  memset(&bg, 0, sizeof(bg));
+  return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F,
+                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, d_row_amax, stream_, true);
+}
+}  // namespace shadow
+
 extern "C" int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                             const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                             const float *d_table, int64_t ldt, const uint32_t *d_ids, float drop_p,
@@ -1302,7 +1325,7 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                                  const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                                 uint32_t max_subg_nodes, const BdGather &bg, float *d_row_amax, void *stream_) {
+                                 uint32_t max_subg_nodes, const BdGather &bg, float *d_row_amax, void *stream_, bool zero_pad) {
   hipStream_t st = (hipStream_t)stream_;
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
@@ -1319,8 +1342,14 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   // both operands on whole 128-byte lines per row: tiles = lines (SHADOW_SPMM_LINES=0: the even split)
   const char *lines_env = getenv("SHADOW_SPMM_LINES");      // (read per call: a test compares the two splits in one process)
   const bool lines_on = !(lines_env && lines_env[0] == '0');
-  const uint32_t lines = (lines_on && !bg.table && F % 32 != 0 && ldx % 32 == 0 && ldy % 32 == 0 && (reinterpret_cast<uintptr_t>(d_X) & 127) == 0 &&
-                          (reinterpret_cast<uintptr_t>(d_Y) & 127) == 0) ? 1u : 0u;
+  uint32_t lines = (lines_on && !bg.table && F % 32 != 0 && ldx % 32 == 0 && ldy % 32 == 0 && (reinterpret_cast<uintptr_t>(d_X) & 127) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d_Y) & 127) == 0) ? 1u : 0u;
+  // zero_pad (shadow::spmm_blockdiag_padded): the idle lanes of a row's last line write zeros into the pad -- whole-line
+  // writes, and the consumer may read the rows at the padded width (the K-tail-free GEMM of sl_sage_fwd)
+  if (zero_pad) {
+    if (!lines) return set_error(SG_ERR_INVALID, "spmm_blockdiag_padded: the operands are not on whole 128-byte lines per row");
+    lines = 2u;
+  }
   // resident workgroups per CU: what LDS allows, at most what 2048 threads allow (a grid beyond the resident set would
   // run as a partial second round of a persistent kernel, which costs a full one)
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / kBdBlock, (size_t)(160 * 1024) / (lds + 256)));

@@ -53,6 +53,12 @@ struct PackF16Src {
 size_t pack_f16_image_bytes(uint32_t K, uint32_t tiles);
 size_t pack_f16_trailer_bytes(uint32_t tiles);
 int pack_f16(int nimg, const PackF16Src *src, uint32_t N, uint32_t K, uint32_t tiles, float *zero, uint32_t n_zero, hipStream_t st);
+// block-diagonal SpMM on line-pitched rows that also zero-fills the pad of every row's last line (aggregate.hip)
+bool spmm_blockdiag_lines_ok(uint32_t F, const float *X, int64_t ldx, const float *Y, int64_t ldy);
+int spmm_blockdiag_padded(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const uint32_t *d_edge_perm,
+                          const float *d_row_scale, const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y, int64_t ldy,
+                          uint32_t n, uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                          uint32_t max_subg_nodes, float *d_row_amax, void *stream_);
 
 constexpr int kWave = 64;  // CDNA wavefront
 

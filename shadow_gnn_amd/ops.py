@@ -427,7 +427,9 @@ class LazyRows:
         with _timed(f"gather_F{F}", 8 * n * F + 4 * n, t.device):
             check(_lib.load().sl_gather_rows_drop_f32(t.data_ptr(), t.stride(0), self.idx.data_ptr(), n, F, float(drop_p), int(seed),
                                                       buf.data_ptr(), buf.stride(0), Fp, amax.data_ptr(), _stream(buf)))
-        return set_row_amax(buf[:, :F], amax), seed
+        v = set_row_amax(buf[:, :F], amax)
+        v._shd_pad_zero = Fp != F          # (the kernel writes zeros into the pad: the layer's products may read whole lines)
+        return v, seed
 
 
 def dense_rows(x):
@@ -1161,7 +1163,7 @@ class _SageDense(torch.autograd.Function):
         check(lib.sl_sage_fwd(C.byref(a), X.data_ptr(), X.stride(0), Fi, Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]),
                               Wn.data_ptr(), Wn.stride(0), opt(biases[1]), sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]),
                               int(drop[1]), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), out.data_ptr(), opt(out2),
-                              opt(x_amax), out_amax.data_ptr(), pack.data_ptr(), _stream(X)))
+                              opt(x_amax), out_amax.data_ptr(), pack.data_ptr(), 1 if getattr(X, "_shd_pad_zero", False) else 0, _stream(X)))
         set_row_amax(out if out2 is None else out2, out_amax)      # (of the tensor the next layer's GEMM reads)
         return AX, Zs, Zn, (out if out2 is None else (out, out2))
 

@@ -1338,6 +1338,42 @@ def test_spmm_on_line_padded_rows_is_bit_identical(F, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p_in", [0.0, 0.3])
+def test_sage_layer0_on_zero_padded_lines_is_bit_identical(p_in, monkeypatch):
+    """Layer 0 on gathered rows (100 floats in 512-byte lines, pad written as zeros by the gather): the aggregation zero-fills
+    the pad of A X and both products read whole lines -- K = 128 without a tail unit against the same weight images, whose
+    tail columns are zero -- instead of K = 100 with predicated loads.  Output, the saved pre-activations and every gradient
+    equal the K-tail form bit for bit (same pieces, same MFMA order; the extra terms are exact zeros)."""
+    from shadow_gnn_amd import ops
+    sizes = [int(x) for x in np.random.default_rng(5).integers(150, 380, size=140)]
+    csr, A = _blockdiag_batch(sizes, 0.02, seed=5)
+    n = csr.n
+    assert n >= ops.AMAX_HANDOVER_ROWS
+    adj = ops.adj_norm_rw(csr)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    table = torch.randn(n + 7, 100, device=DEV, generator=g)
+    idx = torch.randperm(n + 7, device=DEV, generator=g)[:n].to(torch.int32)
+    lin_s, lin_n = torch.nn.Linear(100, 256).to(DEV), torch.nn.Linear(100, 256).to(DEV)
+    scale, offset = torch.rand(2, 256, device=DEV, generator=g) + 0.5, torch.randn(2, 256, device=DEV, generator=g)
+    w = torch.randn(n, 256, device=DEV, generator=g)
+    outs = []
+    for padded in (True, False):
+        torch.manual_seed(11)                    # (dropout seeds come from torch's CPU generator: the same masks in both runs)
+        X, _ = ops.LazyRows(table, idx).gather_dropped(p_in)
+        assert X.stride(0) == 128 and bool((X.as_strided((n, 128), (128, 1))[:, 100:] == 0).all())
+        if not padded:
+            X._shd_pad_zero = False
+        for l in (lin_s, lin_n):
+            l.zero_grad()
+        out = ops.sage_dense(X, adj, lin_s, lin_n, "relu", scale, offset)
+        (out * w).sum().backward()
+        outs.append((out.detach().clone(), [p.grad.clone() for l in (lin_s, lin_n) for p in l.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(9001, 256, 256), (40000, 100, 256), (8300, 64, 128)])
 def test_linear_pair_matches_fp64_autograd(M, K, N):
     """ops.linear_pair: the two Linears of one input (GAT's self / neighbour transforms) as one node -- two-product fp16
