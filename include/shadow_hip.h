@@ -318,6 +318,12 @@ int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
  * reduction and d_a_colsum (column sums of the unscaled A) as sl_gemm_tn_f32.  SG_ERR_INVALID for shapes it does not take. */
 int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb, const float *d_b_amax,
                    float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, float *d_a_colsum, void *stream);
+/* Two such products against the same B in ONE launch: C1 = A1^T B, C2 = A2^T B (A2 with A1's pitch and row maxima: the two
+ * halves of a K-concatenated operand).  The two workgroups of a row slice are dealt to the same XCD and run in step, so B
+ * is fetched from HBM once.  d_partial: 2 * sl_gemm_tn_slices(M) * N * K floats. */
+int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb,
+                        const float *d_b_amax, float *d_C1, float *d_C2, uint32_t M, uint32_t N, uint32_t K, float *d_partial,
+                        void *stream);
 
 /* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
  * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)
@@ -531,7 +537,8 @@ int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const v
  * read-out that takes the roots' rows.  d_x_amax (may be NULL): max_k |X[i, k]| per row, as the kernel that produced X left
  * it -- with it (and n >= 32768, Fin = Fout = 256) the two weight gradients run on two fp16 pieces (sl_gemm_tn_f16), the
  * neighbour branch as dWn = (A^T dZn)^T X over the transposed aggregate of the input-gradient product (d_AX is then not
- * read).  sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, stream).                                       */
+ * read, and d_tn_partial must hold TWICE the floats of sl_gemm_tn_f32's: sl_gemm_tn_f16_pair).
+ * sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, stream).                                              */
 typedef struct {
   const float *Zs, *Zn;            /* [n, F] pre-activations of the layer below (dense rows) */
   const float *bs, *bn;            /* its biases (may be NULL) */

@@ -25,6 +25,7 @@ ROC = {
     "gemm_act_norm_fwd_nb2_N256_Ktail": "gemm_nt_fused_kernel<8, 0, 2, 2, true>",
     "gemm_tn_split_N256": "gemm_tn_coop_kernel<4, true>",
     "gemm_tn_f16_N256": "gemm_tn_f16_kernel",
+    "gemm_tn_f16_pair_N256": "gemm_tn_f16_kernel",
     "gemm_tn_split_N256_K128": "gemm_tn_split_kernel<2>",
     "act_norm_bwd_nb2_F256": "act_norm_kernel<64, 64, true, 2>",
     "gather_F100": "gather_rows_drop_kernel<32>",

@@ -98,7 +98,7 @@ put("gemm_act_norm_fwd_nb2_N256", "gemm_nt_fused_kernel<8, 0, 2, 2, false>")
 put("gemm_act_norm_fwd_nb2_N256_Ktail", "gemm_nt_fused_kernel<8, 0, 2, 2, true>")
 put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>")
 if [k for k in fetch if "gemm_tn_f16_kernel" in k]:
-    put("gemm_tn_f16_N256", "gemm_tn_f16_kernel")
+    put("gemm_tn_f16_pair_N256", "gemm_tn_f16_kernel")
 if [k for k in fetch if "gemm_tn_coop_kernel<4, true>" in k]:
     put("gemm_tn_split_N256", "gemm_tn_coop_kernel<4, true>")
 else:

@@ -30,9 +30,15 @@ for M in (289309, 40000, 5000):
 M = 289309
 dZ = torch.randn(M, 768, device=dev, generator=g)[:, :256]; X = torch.randn(M, 256, device=dev, generator=g)
 da, xa = ops.row_amax(dZ), ops.row_amax(X)
+buf = torch.randn(M, 768, device=dev, generator=g)
+ja = ops.row_amax(buf[:, :512])
+p1, p2 = ops.weight_grad_f16_pair(buf[:, :256], buf[:, 256:512], X, ja, xa)
+print("pair == two launches:", torch.equal(p1, ops.weight_grad_f16(buf[:, :256], X, ja, xa)), torch.equal(p2, ops.weight_grad_f16(buf[:, 256:512], X, ja, xa)))
 for rnd in range(2):
     out = []
-    for name, fn in (("bf16x3", lambda: ops.weight_grad(dZ, X)), ("fp16x2", lambda: ops.weight_grad_f16(dZ, X, da, xa))):
+    for name, fn in (("bf16x3", lambda: ops.weight_grad(dZ, X)), ("fp16x2", lambda: ops.weight_grad_f16(dZ, X, da, xa)),
+                     ("two fp16x2 launches", lambda: (ops.weight_grad_f16(buf[:, :256], X, ja, xa), ops.weight_grad_f16(buf[:, 256:512], X, ja, xa))),
+                     ("fp16x2 pair", lambda: ops.weight_grad_f16_pair(buf[:, :256], buf[:, 256:512], X, ja, xa))):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -986,7 +986,8 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((uint32_t
 
 __global__ void __launch_bounds__(kTnThreads)
 gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ aamax, const float *__restrict__ B, int64_t ldb,
-                   const float *__restrict__ bamax, float *__restrict__ partial, uint32_t M, uint32_t rows_per_wg, uint32_t colsum) {
+                   const float *__restrict__ bamax, float *__restrict__ partial, uint32_t M, uint32_t rows_per_wg, uint32_t colsum,
+                   const float *__restrict__ A2, uint32_t G) {
   constexpr int TK = 4;
   constexpr uint32_t N = 256, K = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
@@ -998,7 +999,14 @@ gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__rest
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   const uint32_t r = lane & 31u, kg = lane >> 5;
   const uint32_t wn = wv >> 1, wk = wv & 1u;                  // 4 x 2 wavefront grid
-  const uint64_t m_begin = (uint64_t)blockIdx.x * rows_per_wg;
+  // Pair form (A2 != NULL, grid 2 G): TWO products against the same B -- A^T B and A2^T B, A2 with A's pitch and row maxima (the
+  // two halves of the GraphSAGE backward's [dZs | A^T dZn] against X).  Workgroups b and b + 8 take the same row slice, one
+  // product each: the dispatcher deals workgroups round-robin over the 8 XCDs, so the two sit on the same XCD, run in step
+  // (same rows, same work) and the second one's B rows come out of that XCD's L2 instead of HBM.
+  uint32_t slice = blockIdx.x, prod = 0;
+  if (A2) { prod = (blockIdx.x >> 3) & 1u; slice = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u); }
+  if (prod) A = A2;
+  const uint64_t m_begin = (uint64_t)slice * rows_per_wg;
   const uint64_t m_end = min((uint64_t)M, m_begin + rows_per_wg);
   const uint32_t steps = m_end > m_begin ? (uint32_t)((m_end - m_begin + 15) / 16) : 0u;   // (slices past M write zeros)
 
@@ -1173,7 +1181,7 @@ gemm_tn_f16_kernel(const float *__restrict__ A, int64_t lda, const float *__rest
 
   // partial[g][n][k] = 2^-c * accumulators (+ [N] column sums of A behind it when asked for)
   const float unscale = pow2i(-c);
-  float *out = partial + (size_t)blockIdx.x * ((size_t)N * K + (colsum ? N : 0u));
+  float *out = partial + ((size_t)prod * G + slice) * ((size_t)N * K + (colsum ? N : 0u));
   if (colsum) {
     const float both = csum + __shfl_xor(csum, 32, 64);            // the two 8-row halves of every step
     if (kg == 0) out[(size_t)N * K + 32 * wv + r] = both;
@@ -1222,10 +1230,42 @@ extern "C" int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_am
   const size_t lds = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * kTnImg16Vecs * 16 + (size_t)2 * (rows_per_wg + 32) * 4;
   SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_f16_kernel, lds));
   hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(G), dim3(kTnThreads), lds, st, d_A, lda, d_a_amax, d_B, ldb, d_b_amax, d_partial, M, rows_per_wg,
-                     d_a_colsum ? 1u : 0u);
+                     d_a_colsum ? 1u : 0u, (const float *)nullptr, G);
   SHD_HIP(hipGetLastError());
   const uint32_t NK = N * K + (d_a_colsum ? N : 0u);
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, N * K, d_a_colsum);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+// Two products against the same B in one launch: C1 = A1^T B, C2 = A2^T B (A2 with A1's pitch and row maxima); see the kernel.
+// d_partial: 2 * sl_gemm_tn_slices(M) * N * K floats.
+extern "C" int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb,
+                                   const float *d_b_amax, float *d_C1, float *d_C2, uint32_t M, uint32_t N, uint32_t K, float *d_partial,
+                                   void *stream) {
+  if (!d_A1 || !d_A2 || !d_B || !d_C1 || !d_C2 || !d_partial || !d_a_amax || !d_b_amax) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: null argument");
+  if (N != 256 || K != 256) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: N = %u, K = %u (both 256)", N, K);
+  if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(d_A1) & 15) || (reinterpret_cast<uintptr_t>(d_A2) & 15) || (reinterpret_cast<uintptr_t>(d_B) & 15))
+    return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (M == 0) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: M = 0");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t G = sl_gemm_tn_slices(M);
+  uint32_t rows_per_wg = (M + G - 1) / G;
+  rows_per_wg = (rows_per_wg + 15u) & ~15u;
+  if (rows_per_wg > kTnF16MaxRows) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: %u rows per slice (at most %u)", rows_per_wg, kTnF16MaxRows);
+  if (G % 8) {     // (the pairing of workgroups b and b + 8 needs whole groups of eight slices: small M -- two plain launches)
+    int rc = sl_gemm_tn_f16(d_A1, lda, d_a_amax, d_B, ldb, d_b_amax, d_C1, M, N, K, d_partial, nullptr, stream);
+    if (rc != SG_OK) return rc;
+    return sl_gemm_tn_f16(d_A2, lda, d_a_amax, d_B, ldb, d_b_amax, d_C2, M, N, K, d_partial, nullptr, stream);
+  }
+  const size_t lds = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * kTnImg16Vecs * 16 + (size_t)2 * (rows_per_wg + 32) * 4;
+  SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_f16_kernel, lds));
+  hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(2 * G), dim3(kTnThreads), lds, st, d_A1, lda, d_a_amax, d_B, ldb, d_b_amax, d_partial, M, rows_per_wg,
+                     0u, d_A2, G);
+  SHD_HIP(hipGetLastError());
+  const uint32_t NK = N * K;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C1, 0u, (float *)nullptr);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial + (size_t)G * NK, G, NK, d_C2, 0u, (float *)nullptr);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

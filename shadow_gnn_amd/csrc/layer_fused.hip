@@ -264,12 +264,19 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
   static const bool tn16 = !(getenv("SHADOW_GEMM_TN_F16") && getenv("SHADOW_GEMM_TN_F16")[0] == '0');
   if (tn16 && d_x_amax && f16dx && hand && Fin == 256 && Fout == 256 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(d_X) & 15) == 0 &&
       (n + sl_gemm_tn_slices(n) - 1) / sl_gemm_tn_slices(n) <= 3024) {
-    {
+    // (one launch for both: the two workgroups of a row slice share an XCD's L2, X comes from HBM once -- sl_gemm_tn_f16_pair;
+    //  SHADOW_GEMM_TN_PAIR=0: two launches)
+    static const bool pair = !(getenv("SHADOW_GEMM_TN_PAIR") && getenv("SHADOW_GEMM_TN_PAIR")[0] == '0');
+    if (!pair) {
+      {
+        SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
+        if ((rc = sl_gemm_tn_f16(dZs, ld3, amx, d_X, ldx, d_x_amax, d_dWs, n, Fout, Fin, d_tn_partial, nullptr, stream)) != SG_OK) return rc;
+      }
       SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
-      if ((rc = sl_gemm_tn_f16(dZs, ld3, amx, d_X, ldx, d_x_amax, d_dWs, n, Fout, Fin, d_tn_partial, nullptr, stream)) != SG_OK) return rc;
+      return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, stream);
     }
-    SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
-    return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, stream);
+    SHD_PROF_FMT(4.0 * n * (2 * Fout + Fin), 2.0 * 2 * n * Fout * Fin, stream, "gemm_tn_f16_pair_N%u", Fout);
+    return sl_gemm_tn_f16_pair(dZs, d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWs, d_dWn, n, Fout, Fin, d_tn_partial, stream);
   }
   if ((rc = tn_gemm(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
   return tn_gemm(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);

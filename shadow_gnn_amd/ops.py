@@ -668,6 +668,20 @@ def weight_grad_f16(dZ: torch.Tensor, X: torch.Tensor, dz_amax: Optional[torch.T
     return (dW, cs) if want_colsum else dW
 
 
+def weight_grad_f16_pair(dZ1: torch.Tensor, dZ2: torch.Tensor, X: torch.Tensor, dz_amax: torch.Tensor, x_amax: torch.Tensor):
+    """(dZ1^T X, dZ2^T X) from one launch (sl_gemm_tn_f16_pair): dZ1, dZ2 share their pitch and the row maxima ``dz_amax``
+    (two column blocks of one buffer); the two workgroups of a row slice share an XCD's L2, so X leaves HBM once."""
+    n = dZ1.shape[0]
+    assert dZ1.stride(0) == dZ2.stride(0)
+    lib = _lib.load()
+    partial = torch.empty(2 * lib.sl_gemm_tn_slices(n) * 256 * 256, dtype=torch.float32, device=X.device)
+    dW1, dW2 = (torch.empty(256, 256, dtype=torch.float32, device=X.device) for _ in range(2))
+    with _timed("gemm_tn_f16_pair_N256", 4 * n * 768, X.device, flops=2 * 2 * n * 256 * 256):
+        check(lib.sl_gemm_tn_f16_pair(dZ1.data_ptr(), dZ2.data_ptr(), dZ1.stride(0), dz_amax.data_ptr(), X.data_ptr(), X.stride(0),
+                                      x_amax.data_ptr(), dW1.data_ptr(), dW2.data_ptr(), n, 256, 256, partial.data_ptr(), _stream(X)))
+    return dW1, dW2
+
+
 def weight_grad_f16_usable(dZ: torch.Tensor, X: torch.Tensor) -> bool:
     """Shapes sl_gemm_tn_f16 takes (the callers add: row maxima of both operands in hand)."""
     n = dZ.shape[0]
@@ -1223,7 +1237,7 @@ class _SageDense(torch.autograd.Function):
                                      down.partial.data_ptr(), down.amax.data_ptr())
         dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
         dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
-        tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)
+        tn_partial = torch.empty((2 if ctx.x_amax is not None else 1) * lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)   # (both weight gradients in one launch)
         pack = torch.empty(lib.sl_sage_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, want_dx)
         opt = lambda t: t.data_ptr() if t is not None else None

@@ -569,6 +569,25 @@ def test_weight_gradient_gemm_on_two_fp16_pieces_matches_fp64(M, lda, kind):
         assert not bool(torch.isfinite(ops.weight_grad_f16(bad, X)[5]).any())
 
 
+@pytest.mark.parametrize("M", [300000, 289309, 40000, 2049, 700])
+def test_weight_gradient_pair_launch_equals_two_launches(M):
+    """sl_gemm_tn_f16_pair: both halves of a K-concatenated operand against the same X in one launch (the two workgroups of a
+    row slice on one XCD, X fetched from HBM once) -- each product equals its own sl_gemm_tn_f16 launch bit for bit, also when
+    the slice count is not a multiple of eight (two plain launches inside) and for slices of a single step."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M)
+    buf = torch.randn(M, 768, device=DEV, generator=g) * (torch.rand(M, 1, device=DEV, generator=g) + 0.01)
+    buf[:, 256:512] *= 3.0
+    X = torch.randn(M, 256, device=DEV, generator=g)
+    ja, xa = ops.row_amax(buf[:, :512]), ops.row_amax(X)
+    p1, p2 = ops.weight_grad_f16_pair(buf[:, :256], buf[:, 256:512], X, ja, xa)
+    assert torch.equal(p1, ops.weight_grad_f16(buf[:, :256], X, ja, xa))
+    assert torch.equal(p2, ops.weight_grad_f16(buf[:, 256:512], X, ja, xa))
+    ref = buf[:, 256:512].double().t() @ X.double()
+    den = (buf[:, 256:512].abs().double().t() @ X.abs().double()).clamp_min(1e-300)
+    assert float(((p2.double() - ref).abs() / den).max()) < 1.5e-6
+
+
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
 def test_act_norm_fused_output_dropout(nb, F, seg):
     """The next layer's input dropout folded into act_norm's output: the kernel's mask equals the documented
