@@ -320,10 +320,11 @@ int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_amax, const f
                    float *d_C, uint32_t M, uint32_t N, uint32_t K, float *d_partial, float *d_a_colsum, void *stream);
 /* Two such products against the same B in ONE launch: C1 = A1^T B, C2 = A2^T B (A2 with A1's pitch and row maxima: the two
  * halves of a K-concatenated operand).  The two workgroups of a row slice are dealt to the same XCD and run in step, so B
- * is fetched from HBM once.  d_partial: 2 * sl_gemm_tn_slices(M) * N * K floats. */
+ * is fetched from HBM once.  d_a1_colsum / d_a2_colsum (both or neither): the column sums of A1 / A2 as in sl_gemm_tn_f32.
+ * d_partial: 2 * sl_gemm_tn_slices(M) * (N * K [+ N with column sums]) floats. */
 int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb,
                         const float *d_b_amax, float *d_C1, float *d_C2, uint32_t M, uint32_t N, uint32_t K, float *d_partial,
-                        void *stream);
+                        float *d_a1_colsum, float *d_a2_colsum, void *stream);
 
 /* Segment pooling over the rows of each subgraph: out[s,:] = mean | max | sum of X[node_off[s]:node_off[s+1], :]
  * (mode 0 | 1 | 2; an empty subgraph gives zeros).  Replaces F.embedding_bag(arange(n), feat, offsets, mode)

@@ -168,7 +168,7 @@ SIGNATURES = {
     "sl_gemm_tn_slices": (C.c_uint32, [C.c_uint32]),
     "sl_gemm_tn_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "sl_gemm_tn_f16": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
-    "sl_gemm_tn_f16_pair": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_gemm_tn_f16_pair": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
     "sl_segment_pool_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, _P, C.c_int64, _P]),
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),

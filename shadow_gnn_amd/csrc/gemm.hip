@@ -1239,10 +1239,10 @@ extern "C" int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_am
 }
 
 // Two products against the same B in one launch: C1 = A1^T B, C2 = A2^T B (A2 with A1's pitch and row maxima); see the kernel.
-// d_partial: 2 * sl_gemm_tn_slices(M) * N * K floats.
+// d_partial: 2 * sl_gemm_tn_slices(M) * (N * K [+ N with column sums]) floats.
 extern "C" int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t lda, const float *d_a_amax, const float *d_B, int64_t ldb,
                                    const float *d_b_amax, float *d_C1, float *d_C2, uint32_t M, uint32_t N, uint32_t K, float *d_partial,
-                                   void *stream) {
+                                   float *d_a1_colsum, float *d_a2_colsum, void *stream) {
   if (!d_A1 || !d_A2 || !d_B || !d_C1 || !d_C2 || !d_partial || !d_a_amax || !d_b_amax) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: null argument");
   if (N != 256 || K != 256) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: N = %u, K = %u (both 256)", N, K);
   if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(d_A1) & 15) || (reinterpret_cast<uintptr_t>(d_A2) & 15) || (reinterpret_cast<uintptr_t>(d_B) & 15))
@@ -1253,19 +1253,20 @@ extern "C" int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t
   uint32_t rows_per_wg = (M + G - 1) / G;
   rows_per_wg = (rows_per_wg + 15u) & ~15u;
   if (rows_per_wg > kTnF16MaxRows) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: %u rows per slice (at most %u)", rows_per_wg, kTnF16MaxRows);
+  if ((d_a1_colsum == nullptr) != (d_a2_colsum == nullptr)) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: column sums for both products or for none");
   if (G % 8) {     // (the pairing of workgroups b and b + 8 needs whole groups of eight slices: small M -- two plain launches)
-    int rc = sl_gemm_tn_f16(d_A1, lda, d_a_amax, d_B, ldb, d_b_amax, d_C1, M, N, K, d_partial, nullptr, stream);
+    int rc = sl_gemm_tn_f16(d_A1, lda, d_a_amax, d_B, ldb, d_b_amax, d_C1, M, N, K, d_partial, d_a1_colsum, stream);
     if (rc != SG_OK) return rc;
-    return sl_gemm_tn_f16(d_A2, lda, d_a_amax, d_B, ldb, d_b_amax, d_C2, M, N, K, d_partial, nullptr, stream);
+    return sl_gemm_tn_f16(d_A2, lda, d_a_amax, d_B, ldb, d_b_amax, d_C2, M, N, K, d_partial, d_a2_colsum, stream);
   }
   const size_t lds = (size_t)2 * kTnStepFloats * 4 + (size_t)2 * kTnImg16Vecs * 16 + (size_t)2 * (rows_per_wg + 32) * 4;
   SHD_HIP(ensure_dynamic_lds((const void *)gemm_tn_f16_kernel, lds));
   hipLaunchKernelGGL(gemm_tn_f16_kernel, dim3(2 * G), dim3(kTnThreads), lds, st, d_A1, lda, d_a_amax, d_B, ldb, d_b_amax, d_partial, M, rows_per_wg,
-                     0u, d_A2, G);
+                     d_a1_colsum ? 1u : 0u, d_A2, G);
   SHD_HIP(hipGetLastError());
-  const uint32_t NK = N * K;
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C1, 0u, (float *)nullptr);
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial + (size_t)G * NK, G, NK, d_C2, 0u, (float *)nullptr);
+  const uint32_t NK = N * K + (d_a1_colsum ? N : 0u);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C1, N * K, d_a1_colsum);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial + (size_t)G * NK, G, NK, d_C2, N * K, d_a2_colsum);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -276,7 +276,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, stream);
     }
     SHD_PROF_FMT(4.0 * n * (2 * Fout + Fin), 2.0 * 2 * n * Fout * Fin, stream, "gemm_tn_f16_pair_N%u", Fout);
-    return sl_gemm_tn_f16_pair(dZs, d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWs, d_dWn, n, Fout, Fin, d_tn_partial, stream);
+    return sl_gemm_tn_f16_pair(dZs, d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWs, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, nullptr, stream);
   }
   if ((rc = tn_gemm(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
   return tn_gemm(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);

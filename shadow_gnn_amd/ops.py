@@ -668,18 +668,24 @@ def weight_grad_f16(dZ: torch.Tensor, X: torch.Tensor, dz_amax: Optional[torch.T
     return (dW, cs) if want_colsum else dW
 
 
-def weight_grad_f16_pair(dZ1: torch.Tensor, dZ2: torch.Tensor, X: torch.Tensor, dz_amax: torch.Tensor, x_amax: torch.Tensor):
+def weight_grad_f16_pair(dZ1: torch.Tensor, dZ2: torch.Tensor, X: torch.Tensor, dz_amax: torch.Tensor, x_amax: torch.Tensor,
+                         want_colsum: bool = False):
     """(dZ1^T X, dZ2^T X) from one launch (sl_gemm_tn_f16_pair): dZ1, dZ2 share their pitch and the row maxima ``dz_amax``
-    (two column blocks of one buffer); the two workgroups of a row slice share an XCD's L2, so X leaves HBM once."""
+    (two column blocks of one buffer, or two gradients with joint maxima); the two workgroups of a row slice share an XCD's L2,
+    so X leaves HBM once.  ``want_colsum``: (dW1, dW2, dZ1.sum(0), dZ2.sum(0))."""
     n = dZ1.shape[0]
     assert dZ1.stride(0) == dZ2.stride(0)
     lib = _lib.load()
-    partial = torch.empty(2 * lib.sl_gemm_tn_slices(n) * 256 * 256, dtype=torch.float32, device=X.device)
+    per = 256 * 256 + (256 if want_colsum else 0)
+    partial = torch.empty(2 * lib.sl_gemm_tn_slices(n) * per, dtype=torch.float32, device=X.device)
     dW1, dW2 = (torch.empty(256, 256, dtype=torch.float32, device=X.device) for _ in range(2))
+    cs = [torch.empty(256, dtype=torch.float32, device=X.device) for _ in range(2)] if want_colsum else [None, None]
+    opt = lambda t: t.data_ptr() if t is not None else None
     with _timed("gemm_tn_f16_pair_N256", 4 * n * 768, X.device, flops=2 * 2 * n * 256 * 256):
         check(lib.sl_gemm_tn_f16_pair(dZ1.data_ptr(), dZ2.data_ptr(), dZ1.stride(0), dz_amax.data_ptr(), X.data_ptr(), X.stride(0),
-                                      x_amax.data_ptr(), dW1.data_ptr(), dW2.data_ptr(), n, 256, 256, partial.data_ptr(), _stream(X)))
-    return dW1, dW2
+                                      x_amax.data_ptr(), dW1.data_ptr(), dW2.data_ptr(), n, 256, 256, partial.data_ptr(), opt(cs[0]), opt(cs[1]),
+                                      _stream(X)))
+    return (dW1, dW2, cs[0], cs[1]) if want_colsum else (dW1, dW2)
 
 
 def weight_grad_f16_usable(dZ: torch.Tensor, X: torch.Tensor) -> bool:
@@ -816,6 +822,14 @@ class _LinearPair(torch.autograd.Function):
         out = [dX, None, None, None, None]
         # two fp16 pieces when the row maxima of both operands are in hand (the joint maxima bound either gradient's rows)
         f16 = joint is not None and ctx.x_amax is not None and weight_grad_f16_usable(dZs[0], X) and weight_grad_f16_usable(dZs[1], X)
+        if f16 and ng[1] and ng[3] and dZs[0].stride(0) == dZs[1].stride(0):
+            # both weight gradients (and both bias gradients) from one launch: the two products share X (sl_gemm_tn_f16_pair)
+            want_b = [hb and ng[2 + 2 * i] for i, hb in enumerate(ctx.has_bias)]
+            res = weight_grad_f16_pair(dZs[0], dZs[1], X, joint, ctx.x_amax, any(want_b))
+            out[1], out[3] = res[0], res[1]
+            if any(want_b):
+                out[2], out[4] = (res[2] if want_b[0] else None), (res[3] if want_b[1] else None)
+            return tuple(out)
         for i, (dz, hb) in enumerate(zip(dZs, ctx.has_bias)):
             want_w, want_b = ng[1 + 2 * i], hb and ng[2 + 2 * i]
             if want_b:

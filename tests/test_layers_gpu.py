@@ -586,6 +586,9 @@ def test_weight_gradient_pair_launch_equals_two_launches(M):
     ref = buf[:, 256:512].double().t() @ X.double()
     den = (buf[:, 256:512].abs().double().t() @ X.abs().double()).clamp_min(1e-300)
     assert float(((p2.double() - ref).abs() / den).max()) < 1.5e-6
+    q1, q2, c1, c2 = ops.weight_grad_f16_pair(buf[:, :256], buf[:, 256:512], X, ja, xa, True)          # with the column sums
+    assert torch.equal(q1, p1) and torch.equal(q2, p2)
+    assert torch.equal(c1, ops.weight_grad_f16(buf[:, :256], X, ja, xa, True)[1]) and torch.equal(c2, ops.weight_grad_f16(buf[:, 256:512], X, ja, xa, True)[1])
 
 
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
