@@ -2,10 +2,12 @@
 //
 // The dense part of a GraphSAGE layer (shaDow/layers.py:471-483),
 //     out = norm_0(act(X Ws^T + bs)) + norm_1(act((A X) Wn^T + bn)),
-// is six kernels forward (SpMM, two weight packs, two split-bf16 GEMMs, fused bias/act/norm) and about ten backward.
+// was six kernels forward (SpMM, two weight packs, two split-bf16 GEMMs, fused bias/act/norm) and about ten backward.
 // Launched one by one from Python through ctypes they cost more host time than GPU time at the reference's own batch
-// sizes (16-256 roots per step).  These entries enqueue the whole pass with ONE call; they own no kernel, only the
-// order of the existing ones (the same order ops._SageDense used), so results are identical.
+// sizes (16-256 roots per step).  These entries enqueue the whole pass with ONE call; they own no kernel, only the choice and
+// the order of the existing ones.  Round 3: forward = weight pack, SpMM, ONE GEMM-epilogue kernel (gemm_fused.hip); backward =
+// [act_norm backward,] transposed SpMM, the input-gradient GEMM with the act_norm backward of the layer below in its
+// epilogue, ONE launch for both weight gradients (sl_gemm_tn_f16_pair, the neighbour branch as (A^T dZn)^T X).
 #include <string.h>
 
 #include <algorithm>
