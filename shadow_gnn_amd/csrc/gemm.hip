@@ -938,8 +938,10 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
 // flight instead of a dependent chain), 4 row-slice groups per output combined through LDS.
 __global__ void __launch_bounds__(256)
 gemm_tn_reduce_kernel(const float *__restrict__ partial, uint32_t G, uint32_t NK, float *__restrict__ out, uint32_t NK0,
-                      float *__restrict__ out2) {     // (outputs [NK0, NK) of a slice go to out2: the column sums)
+                      float *__restrict__ out2,       // (outputs [NK0, NK) of a slice go to out2: the column sums)
+                      float *__restrict__ outB = nullptr, float *__restrict__ out2B = nullptr) {   // blockIdx.y == 1: the pair launch's second product
   __shared__ float red[4][64];
+  if (blockIdx.y) { partial += (size_t)G * NK; out = outB; out2 = out2B; }
   const uint32_t col = threadIdx.x & 63u, grp = threadIdx.x >> 6;       // 64 outputs x 4 slice groups per block
   const uint32_t i = blockIdx.x * 64u + col;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1233,7 +1235,7 @@ extern "C" int sl_gemm_tn_f16(const float *d_A, int64_t lda, const float *d_a_am
                      d_a_colsum ? 1u : 0u, (const float *)nullptr, G);
   SHD_HIP(hipGetLastError());
   const uint32_t NK = N * K + (d_a_colsum ? N : 0u);
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, N * K, d_a_colsum);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, N * K, d_a_colsum, (float *)nullptr, (float *)nullptr);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -1265,8 +1267,7 @@ extern "C" int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t
                      d_a1_colsum ? 1u : 0u, d_A2, G);
   SHD_HIP(hipGetLastError());
   const uint32_t NK = N * K + (d_a1_colsum ? N : 0u);
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C1, N * K, d_a1_colsum);
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial + (size_t)G * NK, G, NK, d_C2, N * K, d_a2_colsum);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64, 2), dim3(256), 0, st, d_partial, G, NK, d_C1, N * K, d_a1_colsum, d_C2, d_a2_colsum);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -1308,7 +1309,7 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
     }
     SHD_HIP(hipGetLastError());
     const uint32_t NKc = N * K + (d_a_colsum ? N : 0u);
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NKc + 63) / 64), dim3(256), 0, st, d_partial, G, NKc, d_C, N * K, d_a_colsum);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NKc + 63) / 64), dim3(256), 0, st, d_partial, G, NKc, d_C, N * K, d_a_colsum, (float *)nullptr, (float *)nullptr);
     SHD_HIP(hipGetLastError());
     return SG_OK;
   }
@@ -1324,7 +1325,7 @@ extern "C" int sl_gemm_tn_f32(const float *d_A, int64_t lda, const float *d_B, i
   }
   SHD_HIP(hipGetLastError());
   const uint32_t NK = N * K;
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, 0u, (float *)nullptr);
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((NK + 63) / 64), dim3(256), 0, st, d_partial, G, NK, d_C, 0u, (float *)nullptr, (float *)nullptr, (float *)nullptr);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
