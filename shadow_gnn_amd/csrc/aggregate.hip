@@ -1253,7 +1253,9 @@ extern "C" int sl_merge_subgraphs(const uint32_t *d_node_off, const uint32_t *d_
   if (num_subg > 8191) return set_error(SG_ERR_INVALID, "sl_merge_subgraphs: at most 8191 subgraphs");
   if (cap_rows == 0 || cap_rows > (uint32_t)kBdMaxRows) cap_rows = kBdMaxRows;
   if (cap_edges == 0 || cap_edges > (uint32_t)kBdMaxEdges) cap_edges = kBdMaxEdges;
-  hipLaunchKernelGGL(merge_subgraphs_kernel, dim3(1), dim3(1024), (size_t)2 * (num_subg + 1) * 4 + 1024 * 4, (hipStream_t)stream_, d_node_off,
+  const size_t merge_lds = (size_t)2 * (num_subg + 1) * 4 + 1024 * 4;          // (68 KB at the 8191-subgraph limit)
+  if (merge_lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)merge_subgraphs_kernel, merge_lds));
+  hipLaunchKernelGGL(merge_subgraphs_kernel, dim3(1), dim3(1024), merge_lds, (hipStream_t)stream_, d_node_off,
                      d_edge_off, num_subg, cap_rows, cap_edges, d_group_node_off, d_group_edge_off);
   SHD_HIP(hipGetLastError());
   return SG_OK;

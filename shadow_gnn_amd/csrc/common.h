@@ -30,6 +30,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
 bool prof_enabled();
 struct ProfScope {
   int idx;
+  uint32_t gen;          // generation of the record table the scope's slot belongs to (sl_prof_enable(1) starts a new one)
   hipStream_t st;
   ProfScope(const char *name, double bytes, double flops, hipStream_t st);
   ~ProfScope();

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -25,7 +26,8 @@ struct Rec {
 };
 
 std::mutex g_mu;
-bool g_on = false;
+std::atomic<bool> g_on{false};
+uint32_t g_gen = 0;                            // bumped whenever g_recs is cleared: a scope that straddles the clear drops its end event
 std::vector<Rec> g_recs;
 std::map<std::string, uint64_t> g_counts;      // launches per kernel class (all of them; only the first kMaxPerName carry events)
 std::map<std::string, uint32_t> g_timed;
@@ -33,11 +35,12 @@ constexpr uint32_t kMaxPerName = 512;          // keep the number of live HIP ev
 
 }  // namespace
 
-bool prof_enabled() { return g_on; }
+bool prof_enabled() { return g_on.load(std::memory_order_relaxed); }
 
-ProfScope::ProfScope(const char *name, double bytes, double flops, hipStream_t st) : idx(-1), st(st) {
-  if (!g_on) return;
+ProfScope::ProfScope(const char *name, double bytes, double flops, hipStream_t st) : idx(-1), gen(0), st(st) {
+  if (!g_on.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on.load()) return;
   g_counts[name]++;
   if (g_timed[name] >= kMaxPerName) return;
   Rec r;
@@ -48,12 +51,13 @@ ProfScope::ProfScope(const char *name, double bytes, double flops, hipStream_t s
   g_timed[name]++;
   g_recs.push_back(r);
   idx = (int)g_recs.size() - 1;
+  gen = g_gen;
 }
 
 ProfScope::~ProfScope() {
   if (idx < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  if (idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[idx].e1, st);
+  if (gen == g_gen && idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[idx].e1, st);
 }
 
 }  // namespace shadow
@@ -62,12 +66,13 @@ using namespace shadow;
 
 extern "C" int sl_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
-  const int prev = g_on ? 1 : 0;
-  if (on > 0 && !g_on) {
+  const int prev = g_on.load() ? 1 : 0;
+  if (on > 0 && !prev) {
+    g_gen++;
     for (auto &r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_recs.clear(); g_counts.clear(); g_timed.clear();
   }
-  if (on >= 0) g_on = on != 0;
+  if (on >= 0) g_on.store(on != 0);
   return prev;
 }
 

@@ -216,7 +216,8 @@ class DeepGNN(nn.Module):
         fuse_ok = self.training and self.fuse_dropout
         dual = not (rp.type_res == 'none' and rp.type_pool == 'center')
         # (the plan only depends on these: nn.Module attribute writes cost ~2.5 us each, 25 of them per step otherwise)
-        key = (fuse_ok, dual, tuple(float(getattr(md, 'dropout', 0.0)) for md in layers_i))
+        # (layer identities and the task are part of it: a swapped conv layer or a changed read-out re-plans)
+        key = (fuse_ok, dual, self.prediction_task, tuple((id(md), float(getattr(md, 'dropout', 0.0))) for md in layers_i))
         plans = self.__dict__.setdefault('_fusion_plan_keys', {})
         if plans.get(i) == key:
             return
@@ -240,6 +241,14 @@ class DeepGNN(nn.Module):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):
             layers_i[0].input_pre_dropped = False
+
+    def invalidate_fusion_plan(self):
+        """Forget the cached dropout / chaining plan (call after editing planned layer attributes by hand)."""
+        self.__dict__.pop('_fusion_plan_keys', None)
+
+    def train(self, mode: bool = True):
+        self.invalidate_fusion_plan()
+        return super().train(mode)
 
     def predict(self, preds):
         return torch.sigmoid(preds) if self.sigmoid_loss else F.softmax(preds, dim=1)

@@ -893,8 +893,7 @@ def row_amax(A: torch.Tensor) -> torch.Tensor:
     include/shadow_hip.h).  Kernels that produce an operand leave it on the tensor (``set_row_amax``) instead."""
     n, K = A.shape
     am = torch.empty(n, dtype=torch.float32, device=A.device)
-    with _timed(f"row_amax_K{K}", 4 * n * K + 4 * n, A.device):
-        check(_lib.load().sl_row_amax(A.data_ptr(), A.stride(0), n, K, am.data_ptr(), _stream(A)))
+    check(_lib.load().sl_row_amax(A.data_ptr(), A.stride(0), n, K, am.data_ptr(), _stream(A)))    # (timed by the C entry itself)
     return am
 
 
@@ -1156,7 +1155,11 @@ class _SageDense(torch.autograd.Function):
             link_roots.published = True
             ctx.link_roots = link_roots
         ctx.link_up = None
-        if link_up is not None and one_call and CHAIN_SAGE_BWD and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256:
+        # (published only when THIS node's backward will take the one-call entry -- the only consumer of the dZ the layer
+        # above leaves on the link: a layer-0 input wider than 256 (Flickr 500, Yelp 300) or frozen weights run kernel by
+        # kernel, and the layer above must then write a real dX)
+        if (link_up is not None and one_call and CHAIN_SAGE_BWD and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256
+                and _SageDense._bwd_fusable(ctx.needs_input_grad, one_call, X.shape[1], F, AX)):
             link_up.publish(Zs, Zn, bsc, sc, of, acts[0], drop)
             ctx.link_up = link_up
         ctx.set_materialize_grads(False)
@@ -1170,6 +1173,12 @@ class _SageDense(torch.autograd.Function):
                 and Fo % 4 == 0 and Fo <= 256
                 and Fi % 4 == 0 and X.dtype == torch.float32 and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
                 and Ws.stride(1) == 1 and Wn.stride(1) == 1 and Ws.dtype == torch.float32 and Wn.shape == Ws.shape)
+
+    @staticmethod
+    def _bwd_fusable(ng, one_call, Fi, Fo, AX):
+        """Whether the backward pass takes the one-call entry (sl_sage_bwd_chain): decided from what the forward knows."""
+        return bool(one_call and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
+                    and (not ng[0] or Fo % 32 == 0))
 
     @staticmethod
     def _fused_forward(X, adj, Ws, Wn, biases, sc, of, acts, drop):
@@ -1285,8 +1294,7 @@ class _SageDense(torch.autograd.Function):
         biases = [b if hb else None for b, hb in zip((b0, b1), has_b)]
         Fi = X.shape[1]
         # (the forward's decision, not a re-evaluation: a KernelTimer entered between the passes must not mix the paths)
-        fused_bwd = (one_call and ng[2] and ng[4] and Fi <= 256 and AX.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0
-                     and (not ng[0] or F % 32 == 0))
+        fused_bwd = _SageDense._bwd_fusable(ng, one_call, Fi, F, AX)
         lr = ctx.link_roots
         if lr is not None and lr.filled and not fused_bwd:
             # the read-out left (rows, gradient) on the link but this pass runs kernel by kernel: the dense form after all

@@ -840,17 +840,17 @@ def test_model_fuzz_against_oracle():
 # --------------------------------------------------------------------------------------------------------------
 # benchmark-scale parity of the whole train step (round 2; VERDICT r1 "next round" item 1)
 # --------------------------------------------------------------------------------------------------------------
-def _bench_scale_batch(aggr, B):
+def _bench_scale_batch(aggr, B, F0=100, depth=2, N=200_000):
     """A products-like batch (Pareto degrees, mean degree 50, F0 = 100, 47 classes) sampled by the HIP sampler:
     k-hop depth 2 budget 20, B roots -> every activation x weight product has M = n >= 8192 rows."""
     from shadow_gnn_amd import ops
     from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
     from shadow_gnn_amd.synthetic import make_graph_numpy
-    N, F0, C = 200_000, 100, 47
+    C = 47
     indptr, indices = make_graph_numpy(N, 50, seed=21)
     hs = HipSampler(indptr, indices, device=torch.device(DEV), seed=7)
     roots = np.random.default_rng(22).permutation(N)[:B].astype(np.uint32)
-    b = hs.sample(SamplerConfig(method="khop", depth=2, budget=20, add_self_edge=(aggr != "sage")), roots=roots)
+    b = hs.sample(SamplerConfig(method="khop", depth=depth, budget=20, add_self_edge=(aggr != "sage")), roots=roots)
     g = torch.Generator().manual_seed(23)
     X = torch.randn(b.num_nodes, F0, generator=g)
     labels = torch.randint(0, C, (B,), generator=g)
@@ -1199,13 +1199,13 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
             assert torch.equal(a == 0, b == 0) or float(((a == 0) != (b == 0)).float().mean()) < 1e-6
 
 
-def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"):
+def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=()):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
     from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
     from shadow_gnn_amd.models import DeepGNN
-    b, X, labels, F0, C = _bench_scale_batch("sage", B)
+    b, X, labels, F0, C = _bench_scale_batch("sage", B, F0=F0)
     lib = _lib.load()
     prev_f = lib.sl_set_fused_epilogue(1 if fused else 0)
     prev_c = ops.CHAIN_SAGE_BWD
@@ -1218,16 +1218,19 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         with torch.no_grad():
             for q in model.parameters():
                 q.add_(0.05 * torch.randn_like(q))
+        for li in freeze:                                                     # frozen layers (fine-tuning): no weight gradients
+            for q in model.conv_layers[0][li].parameters():
+                q.requires_grad_(False)
         adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off,
                             max_subg_nodes=b.counts["max_subg_nodes"])
         batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
-        model.optimizer = torch.optim.SGD(model.parameters(), lr=0.0)         # keep the (clipped) gradients readable
+        model.optimizer = torch.optim.SGD([q for q in model.parameters() if q.requires_grad], lr=0.0)         # keep the (clipped) gradients readable
         c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls)
         torch.manual_seed(seed + 1)                                           # dropout seeds come from torch's CPU generator
         ret = model.step(TRAIN, "running", batch)
         torch.cuda.synchronize()
         calls = (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1])
-        grads = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+        grads = {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.requires_grad}
         return float(ret["loss"]), ret["preds"].detach().clone(), grads, calls
     finally:
         lib.sl_set_fused_epilogue(prev_f)
@@ -1477,3 +1480,56 @@ def test_sparse_readout_gradient_equals_dense(n_layers, dim, p_drop, act, monkey
     for k in g0:
         scale = float(g0[k].abs().max())
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-6 * scale + 1e-10, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F0,freeze", [(500, ()), (300, ()), (100, (0,)), (100, (1,))])
+def test_chaining_is_only_offered_to_layers_whose_backward_can_take_it(F0, freeze):
+    """a GraphSAGE layer whose backward cannot take the one-call entry -- layer 0 on Flickr's 500 /
+    Yelp's 300 input features (> 256), or a layer with frozen weights -- must not publish a ChainLink: the layer above
+    would leave this layer's dZ on the link and hand autograd a storage-less placeholder that only sl_sage_bwd_chain
+    consumes (round 3 raised 'the layer above filled this layer's dZ but the one-call path is off').  The step trains,
+    chains the other boundaries, and its gradients equal the unchained pass's."""
+    l0, p0, g0, calls0 = _sage_stack_step(3, 256, 0.3, 9, chain=False, fused=True, act="relu", F0=F0, freeze=freeze)
+    l1, p1, g1, calls1 = _sage_stack_step(3, 256, 0.3, 9, chain=True, fused=True, act="relu", F0=F0, freeze=freeze)
+    assert calls0[1] == 0
+    # only a boundary whose BOTH layers run the one-call backward is chained (frozen middle layer: neither of its two)
+    assert calls1[1] == (0 if freeze == (1,) else 1), calls1
+    assert abs(l0 - l1) < 1e-5
+    torch.testing.assert_close(p1, p0, rtol=1e-5, atol=1e-6)
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        err = float((g1[k] - g0[k]).abs().max())
+        assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
+
+
+@pytest.mark.gpu
+def test_merge_of_8000_small_subgraphs_needs_more_than_64k_of_lds():
+    """sl_merge_subgraphs stages 2 (P + 1) offsets + 1024 scan cells in LDS -- above 64 KB from
+    P = 7680 on (a PPR batch of thousands of tiny subgraphs); the launch must raise its dynamic-LDS limit first."""
+    from shadow_gnn_amd import ops
+    P = 8100
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 6, size=P).astype(np.int64)
+    noff = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(noff[-1])
+    # a path inside every subgraph (symmetric): rows reference their own block only
+    rows, cols = [], []
+    for a, b in zip(noff[:-1], noff[1:]):
+        for v in range(a, b - 1):
+            rows += [v, v + 1]; cols += [v + 1, v]
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n, n)); A.sort_indices()
+    csr = ops.DeviceCSR(torch.from_numpy(A.indptr.astype(np.int32)).to(DEV), torch.from_numpy(A.indices.astype(np.int32)).to(DEV),
+                        subg_off=torch.from_numpy(noff.astype(np.int32)).to(DEV),
+                        subg_edge_off=torch.from_numpy(A.indptr[noff].astype(np.int32)).to(DEV), max_subg_nodes=int(sizes.max()))
+    goff, geoff, cap = csr.spmm_blocks
+    torch.cuda.synchronize()
+    go = goff.cpu().numpy().astype(np.int64)
+    assert goff.data_ptr() != csr.subg_off.data_ptr() and go[0] == 0 and go[-1] == n and np.all(np.diff(go) >= 0)
+    assert np.all(np.diff(go) <= 384) and set(go.tolist()) <= set(noff.tolist())
+    X = torch.randn(n, 256, device=DEV)
+    got = ops._spmm_raw(csr.indptr, csr.indices, None, None, None, None, X, n, csr.spmm_blocks)
+    want = torch.from_numpy((A @ X.cpu().numpy().astype(np.float64))).to(DEV)
+    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-5)
