@@ -17,15 +17,20 @@ all-reduce.
 Rank 0 prints ONE JSON line.  metric/unit follow BASELINE.json:
   value               sampled nodes/s through the full train step, summed over ranks
   train_steps_per_sec optimizer steps/s
-  roofline            the north-star aggregate: algorithmic bytes of the k-hop sample + feature gather + SAGE
-                      aggregation kernels over their summed duration, timed live with HIP events on the streams
-                      they are launched on, against the 8 TB/s HBM peak; roofline_hbm: the dominant HBM-bound
-                      kernel; roofline_mfma: the dominant split-operand GEMM against the MFMA peak (divided by the
-                      matrix-core products it issues per fp32 product: 3 for two fp16 pieces, 6 for three bf16 pieces)
+  roofline            THE dominant kernel class of the step (largest total HIP-event time, timed live on its launch
+                      stream): algorithmic bytes / launch duration against the 8 TB/s HBM peak when its arithmetic
+                      intensity is below the ridge of its scheme (the MFMA fraction beside it), against the MFMA
+                      peak otherwise
+  roofline_step       every kernel class's own algorithmic bytes summed, over the TIMED ms_per_step
+  roofline_north_star the north-star aggregate: algorithmic bytes of the k-hop sample + feature gather + SAGE
+                      aggregation kernels over their summed duration
+  roofline_hbm / roofline_mfma   the dominant kernel of each kind (MFMA peak divided by the matrix-core products
+                      a scheme issues per fp32 product: 3 for two fp16 pieces, 6 for three bf16 pieces)
+  dist                (process group initialised) backend, collectives per step, per-rank host-busy / all-reduce wait
   cpu_baseline        the reference's own C++/OpenMP sampler (oracle/_ref) timed on this box's host cores on a
                       bounded sample of the same roots: best of a thread sweep {1, 8, 20, 64, all} + the 1-thread rate
   cpu_baseline_train_step  the other half of the reference's CPU path: the training step in CPU
-                      PyTorch (oracle/cpu_train_step.py) on 1/8 of one benchmark batch, scaled to steps/s
+                      PyTorch (oracle/cpu_train_step.py) on one whole benchmark batch
   target_only_tail    the same step with the opt-in exact dead-row elimination (shadow_gnn_amd/tail.py),
                       10 extra steps after the timed region (single-GPU runs); never part of `value`
 """
@@ -157,6 +162,57 @@ def cpu_baseline(indptr_host, indices_host, roots, scfg, seed, budget_s=24.0):
                     sample=f"oracle/sampler_oracle.c (OpenMP), 1 call x {P} subgraphs per thread count ({type(ex).__name__}: reference build unavailable)")
 
 
+def cpu_baseline_ppr(indptr_host, indices_host, roots, scfg, ppr, seed, budget_s=24.0):
+    """PPR workloads: the reference's own `ppr` sampler (ParallelSampler.cpp:565-595) over a table the reference's own
+    preproc_ppr_approximate (ParallelSampler.cpp:237-344) builds for the sample's roots -- the table build is timed
+    separately (the reference builds it once per run and caches it on disk), the sampler calls are swept over thread
+    counts like the k-hop baseline."""
+    import tempfile
+    cores = os.cpu_count() or 1
+    P = min(500, int(len(roots)))
+    roots = np.ascontiguousarray(roots[:2 * P], dtype=np.uint32)
+    sweep = sorted({t for t in (1, 8, 20, 64) if t <= cores})
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    with _stdout_to_stderr():
+        import ParallelSampler as ref
+        with tempfile.TemporaryDirectory() as td:
+            f_ip, f_ix = os.path.join(td, "indptr.bin"), os.path.join(td, "indices.bin")
+            indptr_host.tofile(f_ip); indices_host.tofile(f_ix)
+            fn, fs = os.path.join(td, "neighs.bin"), os.path.join(td, "scores.bin")
+            cfg = {"method": "ppr", "k": str(scfg["k"]), "threshold": str(scfg.get("threshold", 0.0)), "num_roots": "1",
+                   "add_self_edge": "true" if scfg.get("add_self_edge") else "false", "include_target_conn": "false",
+                   "return_target_only": "false"}
+            uniq = np.unique(roots)
+            rates, t_table, table_threads = {}, None, min(cores, 64)
+            for th in sorted(sweep, key=lambda t: -t):          # the widest run builds the table (and writes the cache files)
+                ps = ref.ParallelSampler([], [], [], P, th if t_table is not None else table_threads, True, True, [], 1, f_ip, f_ix, "", seed)
+                t0 = time.perf_counter()
+                ps.preproc_ppr_approximate(uniq, int(scfg["k"]), float(ppr["alpha"]), float(ppr["epsilon"]), fn, fs)
+                if t_table is None:
+                    t_table = time.perf_counter() - t0           # (later instances load the cache files: not counted)
+                    del ps
+                    ps = ref.ParallelSampler([], [], [], P, th, True, True, [], 1, f_ip, f_ix, "", seed)
+                    ps.preproc_ppr_approximate(uniq, int(scfg["k"]), float(ppr["alpha"]), float(ppr["epsilon"]), fn, fs)
+                ps.shuffle_targets(roots)
+                nodes, t, calls = 0, 0.0, 0
+                while calls < roots.size // P and t < budget_s / len(sweep):
+                    t0 = time.perf_counter()
+                    out = ps.parallel_sampler_ensemble([cfg], [set()])[0]
+                    t += time.perf_counter() - t0
+                    nodes += sum(len(v) for v in out.get_subgraph_node()[:out.get_num_valid_subg()])
+                    calls += 1
+                rates[th] = (nodes / t, calls)
+                del ps
+    best = max(rates, key=lambda k: rates[k][0])
+    return dict(value=round(rates[best][0], 1), unit="sampled-nodes/s", cores=best, kind="reference",
+                one_thread=round(rates[1][0], 1), host_cores=cores, sweep={str(k): round(v[0], 1) for k, v in rates.items()},
+                ppr_table=dict(roots=int(uniq.size), seconds=round(t_table, 3), roots_per_sec=round(uniq.size / t_table, 1),
+                               threads=table_threads, note="reference preproc_ppr_approximate, built once per run; not part of `value`"),
+                sample=f"reference C++/OpenMP ParallelSampler (oracle/_ref), method ppr k={scfg['k']} over the table its own "
+                       f"preproc_ppr_approximate built for {uniq.size} roots (alpha {ppr['alpha']}, epsilon {ppr['epsilon']}), sampler only, "
+                       f"{P} subgraphs per call, up to {roots.size // P} calls per thread count; best of threads {sweep} = {best}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +235,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
+    # one Python process per GPU on a shared host: every rank gets its own slice of the hardware threads
+    pin = sdist.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
 
     from shadow_gnn_amd import ops
     from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
@@ -250,14 +308,19 @@ def main():
     barrier()
     counts = []
     wait0 = mb.wait_s
+    ar_wait0, ar_issued0 = model.grad_sync.wait_s, model.grad_sync.issued
     t0 = time.perf_counter()
     for _ in range(K):
         c, ret = one_step()
         counts.append(c)
     t_host = time.perf_counter() - t0           # host-side enqueue time (diagnostic)
     t_blocked = mb.wait_s - wait0               # ... of which blocked on the sampler's count read-back (the host is idle there)
+    torch.cuda.synchronize(dev)
+    dt_own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the others)
     barrier()
     dt = time.perf_counter() - t0
+    ar_wait = model.grad_sync.wait_s - ar_wait0
+    ar_issued = model.grad_sync.issued - ar_issued0
     # ---- the same steps once more with a HIP-event pair around every hand-written kernel (on the stream it is launched
     #      on) and around the sampler's kernels: the live durations behind `roofline` / `kernels`.  Kept out of the timed
     #      region: ~60 event pairs per step cost host time, and the per-kernel timing needs the kernel-by-kernel call path
@@ -276,10 +339,26 @@ def main():
     nodes = float(sum(c["n_tot"] for c in counts))
     edges = float(sum(c["e_tot"] for c in counts))
     stats = torch.tensor([dt, nodes, edges], dtype=torch.float64, device=dev)
-    if world > 1:
+    dist_info = None
+    if sdist.collectives_on():
         tmax = stats[0:1].clone(); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         tot = stats[1:].clone(); torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
         dt, nodes, edges = float(tmax[0]), float(tot[0]), float(tot[1])
+        # per-rank diagnostics of the timed region (ms per step): where an N-rank run loses time against one rank
+        mine = torch.tensor([(t_host - t_blocked) / K * 1e3, ar_wait / K * 1e3, dt_own / K * 1e3, t_blocked / K * 1e3],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        dist_info = dict(backend=torch.distributed.get_backend(), world=world, collectives_per_step=round(ar_issued / K, 2),
+                         grad_buckets=len(model.grad_sync._slices), grad_bytes=int(model.grad_sync.flat.numel() * 4),
+                         pinning=pin,
+                         per_rank=dict(host_busy_ms_per_step=[round(float(x), 4) for x in allr[:, 0]],
+                                       allreduce_host_wait_ms_per_step=[round(float(x), 4) for x in allr[:, 1]],
+                                       own_ms_per_step=[round(float(x), 4) for x in allr[:, 2]],
+                                       sampler_readback_wait_ms_per_step=[round(float(x), 4) for x in allr[:, 3]]),
+                         note="own_ms_per_step: a rank's K steps up to its own device sync, before the closing barrier; "
+                              "allreduce_host_wait: host time inside Work.wait() (nccl: enqueues a stream wait)")
 
     # ---- the same training step with the exact target-only tail (dead rows of the last layers not computed);
     #      reported separately, never part of `value`
@@ -394,6 +473,32 @@ def main():
     dom_hbm = max(hbm_keys, key=lambda k: kern[k]["total_ms"])
     roofline_hbm = hbm_entry(dom_hbm)                                   # the dominant HBM-bound kernel
     roofline_mfma = mfma_entry(max(mfma_keys, key=lambda k: kern[k]["total_ms"])) if mfma_keys else None
+    # `roofline`: THE dominant kernel of the step by total time, whatever its kind.  A split GEMM is priced against the
+    # roof its arithmetic intensity puts it under (algorithmic flop / algorithmic byte against the ridge of its scheme:
+    # (2500 / products per fp32 product) TFLOP/s over 8 TB/s); the other fraction stands beside it.
+    kernel_ms_total = sum(kern[k]["total_ms"] for k in timed)
+    dom = max(timed, key=lambda k: kern[k]["total_ms"])
+
+    def dominant_entry(k):
+        e = hbm_entry(k)
+        if kern[k].get("flops_per_launch"):
+            m = mfma_entry(k)
+            ai = kern[k]["flops_per_launch"] / max(1.0, kern[k]["bytes_per_launch"])
+            ridge = m["peak"] * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if ai >= ridge:
+                m.update(hbm_frac=e["frac"], hbm_achieved_GBps=e["achieved"])
+                e = m
+            else:
+                e.update(mfma_frac=m["frac"], mfma_achieved_TFLOPs=m["achieved"], mfma_peak_TFLOPs=m["peak"], peak_basis=m["peak_basis"])
+            e.update(arith_intensity_flop_per_byte=round(ai, 1), ridge_flop_per_byte=round(ridge, 1))
+        e.update(launches_per_step=round(kern[k]["launches"] / max(1, K_prof), 2),
+                 share_of_kernel_time=round(kern[k]["total_ms"] / kernel_ms_total, 4),
+                 selected_as="largest total HIP-event time among the step's kernel classes",
+                 measured_over=f"{K_prof} instrumented steps right after the timed region (HIP events per kernel, on its launch stream)")
+        return e
+    roofline_dom = dominant_entry(dom)
+    # the whole step against the roof: every kernel class's own algorithmic bytes over the TIMED step
+    step_bytes = sum(kern[k]["bytes_per_launch"] * kern[k]["launches"] for k in kern) / max(1, K_prof)
     kernels = {k: dict(launches=v["launches"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
                        alg_GBps=round(v["gbps"], 1), frac=round(v["gbps"] / HBM_PEAK_GBS, 4),
                        **({"alg_TFLOPs": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
@@ -409,6 +514,16 @@ def main():
             cb = cpu_baseline(ip, ix, roots_all, wl["sampler"], seed=3)
         except Exception as ex:                          # never lose the main result to a baseline leg
             cb = dict(error=f"{type(ex).__name__}: {ex}"[:300])
+    elif not args.no_cpu_baseline and world == 1 and wl["sampler"]["method"] == "ppr":
+        if int(indices.numel()) > 1_000_000_000:
+            cb = dict(skipped="papers100M shape: the reference loads the CSR from .bin files -- a 13 GB host copy + file write + "
+                              "load per thread count does not fit a bounded baseline leg; see the products-shape PPR line")
+        else:
+            try:
+                ip = indptr.cpu().numpy().view(np.uint32); ix = indices.cpu().numpy().view(np.uint32)
+                cb = cpu_baseline_ppr(ip, ix, roots_all, wl["sampler"], wl["ppr"], seed=3)
+            except Exception as ex:
+                cb = dict(error=f"{type(ex).__name__}: {ex}"[:300])
     cb_step = None
     if (not args.no_cpu_baseline and world == 1 and wl["aggr"] in ("sage", "gcn") and model._tail_prunable(0)
             and set(wl["aug"]) <= {"hops"}):
@@ -435,19 +550,22 @@ def main():
             # torch's CPU kernels do not always get faster with every hardware thread: pick the best of a few counts
             # on a small slice, then time 1/8 of the batch with it and scale to whole steps
             # (batches of a few dozen subgraphs -- the reference's own arxiv configurations -- are timed whole)
-            P_cal, P_run = (max(1, B // 64), max(1, B // 8)) if B >= 256 else (max(1, B // 2), B)
+            # (round 4: the WHOLE batch is timed once -- one untimed-warm-up-free step of ~20 s at the products
+            # shape; round 3 timed 1/8 of it and scaled)
+            P_cal, P_run = (max(1, B // 64), B) if B >= 256 else (max(1, B // 2), B)
             best_t, best_th = None, cores
             for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 32)}, reverse=True):
                 nst, tsec, _w = run(P_cal, th, 3.0)
                 if best_t is None or tsec / nst < best_t:
                     best_t, best_th = tsec / nst, th
-            nst, tsec, warm = run(P_run, best_th, 25.0)
+            nst, tsec, warm = run(P_run, best_th, 30.0)
             frac = P_run / B
             cb_step = dict(value=round(nst / tsec * frac, 5), unit="train-steps/s", cores=best_th, kind="port",
                            extrapolated=bool(frac < 1.0), measured_fraction_of_batch=frac,
                            sample=f"oracle/cpu_train_step.py (CPU PyTorch fp32: torch.sparse.mm + nn.Linear + norm, Adam), "
                                   f"{nst} step(s) on the first {P_run} of the {B} subgraphs of one benchmark batch "
-                                  f"({int(sizes[:P_run].sum())} nodes), scaled by {frac:g} to whole steps; model only (no sampler); "
+                                  f"({int(sizes[:P_run].sum())} nodes)" + (f", scaled by {frac:g} to whole steps" if frac < 1.0 else " = the whole batch")
+                                  + "; model only (no sampler); "
                                   f"{best_th} of {cores} threads (fastest of a 4-way sweep on {P_cal} subgraphs)")
         except Exception as ex:                      # never lose the main result to an extra
             cb_step = dict(error=f"{type(ex).__name__}: {ex}"[:300])
@@ -470,7 +588,14 @@ def main():
         # `roofline` leads with what BASELINE.json's north_star asks for: the HBM fraction of the k-hop-sample + feature
         # gather + SAGE-aggregate kernels together (algorithmic bytes of SURVEY.md 8(d) / their summed live time); the
         # dominant HBM-bound kernel and the dominant MFMA kernel (the split-bf16 GEMM) stand beside it
-        "roofline": {"bound": "hbm", "kernel": "north star: " + " + ".join(ns_keys),
+        "roofline": roofline_dom,
+        "roofline_step": {"bound": "hbm", "kernel": "whole step: sum over every hand-written kernel class of its own algorithmic bytes",
+                          "achieved": round(step_bytes / 1e9 / (dt / K), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(step_bytes / 1e9 / (dt / K) / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),
+                          "ms_per_step": round(dt / K * 1e3, 4), "kernel_ms_per_step": round(kernel_ms_total / max(1, K_prof), 4),
+                          "note": "bytes from the instrumented steps, time = the timed region's ms_per_step (torch's own small kernels, "
+                                  "launch gaps and host stalls count against the fraction)"},
+        "roofline_north_star": {"bound": "hbm", "kernel": "north star: " + " + ".join(ns_keys),
                      "achieved": round(ns_by / 1e9 / (ns_ms / 1e3), 1) if ns_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(ns_by / 1e9 / (ns_ms / 1e3) / HBM_PEAK_GBS, 4) if ns_ms else 0.0,
                      "traffic": (sum(traffic_of(k) * kern[k]["launches"] for k in ns_keys) / max(1, K_prof)
@@ -481,6 +606,7 @@ def main():
         "roofline_hbm": roofline_hbm, "roofline_mfma": roofline_mfma,
         "kernels": kernels,
         "cpu_baseline": cb,
+        "dist": dist_info,
     }
     print(json.dumps(line), flush=True)
 

@@ -105,18 +105,28 @@ def gat_forward(p, X, A, act, heads):
     return (torch.cat(outs_s, 1) + torch.cat(outs_n, 1)) / 2                            # :623-625
 
 
-def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtype=torch.float64, relu_keep=None, stats=None):
+def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtype=torch.float64, relu_keep=None, stats=None,
+                  edge_keep=None, in_drop=None):
     """DeepGNN.forward (models.py:169-204, one branch).  ``p``: state_dict tensors (any float dtype; cast to
     ``dtype`` here -- pass leaves of that dtype with requires_grad to get gradients).  ``relu_keep``: per layer, the
-    z > 0 patterns of the run under test (one per Linear branch), see _act; ``stats`` collects the kink-unit count."""
+    z > 0 patterns of the run under test (one per Linear branch), see _act; ``stats`` collects the kink-unit count.
+    Training-mode randomness is taken from the caller (the reference's torch RNG streams cannot be reproduced, the run
+    under test hands over ITS draws): ``edge_keep`` -- 0/1 per CSR edge, the drop-edge mask applied before the
+    normalisation (graph_utils.py:85-94: dropped positions are zeroed, the degree is the row sum of what is left);
+    ``in_drop`` -- per layer, the multiplier tensor of its input nn.Dropout (keep / (1 - p), layers.py:430,471,601) or None."""
     kind, L, heads, act = arch["aggr"], arch["num_layers"], int(arch.get("heads", 1)), arch["act"]
     p = {k: (v if v.dtype == dtype else v.to(dtype)) for k, v in p.items()}
     x = X.to(dtype)
     if hop1hot is not None:                                                              # models.py:185-189
         x = x + F.linear(hop1hot.to(dtype), p["aug_layers.0.0.weight"], p["aug_layers.0.0.bias"])
-    A = EdgeList(indptr, indices, dtype).normalised(kind)
+    A = EdgeList(indptr, indices, dtype)
+    if edge_keep is not None:
+        A.w = torch.as_tensor(edge_keep).to(dtype)
+    A = A.normalised(kind)
     feats = []
     for l in range(L):
+        if in_drop is not None and in_drop[l] is not None:
+            x = x * in_drop[l].to(dtype)
         pre = f"conv_layers.0.{l}."
         lp = {k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}
         keep = relu_keep[l] if relu_keep is not None else None

@@ -18,23 +18,61 @@ import torch
 import torch.distributed as dist
 
 
+def force_init() -> bool:
+    """SHADOW_DIST_FORCE_INIT=1: build the process group and issue every collective even with ONE rank -- the RCCL path
+    (communicator set-up, GPU-side broadcast, the async bucket all-reduces behind the backward hooks) then runs on a
+    single GPU exactly as it does on eight (tests/test_dist_rccl_gpu.py, `bench.py --gpus 1` under torch.distributed.run)."""
+    return os.environ.get("SHADOW_DIST_FORCE_INIT", "0") == "1"
+
+
+def collectives_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_init())
+
+
 def init_from_env(backend: Optional[str] = None):
     """torchrun-style environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
-    Returns (rank, local_rank, world_size); a no-op for single-process runs."""
+    Returns (rank, local_rank, world_size); a no-op for single-process runs (unless SHADOW_DIST_FORCE_INIT=1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_init()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             # SHADOW_DIST_BACKEND=gloo lets several ranks share one GPU (functional tests only)
             backend = os.environ.get("SHADOW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev            # (eager communicator set-up on this rank's GPU; barrier() needs no device guess)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
+
+
+def pin_host_threads(local_rank: int, local_world: int, threads_per_rank: int = 0) -> dict:
+    """One Python process per GPU on a shared host: give every rank its own contiguous slice of the host's hardware
+    threads (sched_setaffinity) and cap torch's intra-op pool to it.  Without it N ranks each start a pool of ALL cores
+    and their ~2 ms of launch work per step (the autograd walk, ctypes entries) migrate across the sockets and contend --
+    the weak-scaling risk SURVEY 8(e) names.  Single-rank runs are left alone (bench.py's CPU baselines want the cores)."""
+    info = dict(pinned=False)
+    if local_world <= 1:
+        return info
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:                              # (not Linux)
+        return info
+    per = max(1, len(avail) // local_world)
+    mine = avail[local_rank * per:(local_rank + 1) * per] or avail
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return info
+    nthreads = max(1, min(threads_per_rank or 8, len(mine)))
+    torch.set_num_threads(nthreads)
+    info.update(pinned=True, cpus=(mine[0], mine[-1]), n_cpus=len(mine), torch_threads=nthreads)
+    return info
 
 
 class GradSync:
@@ -90,7 +128,11 @@ class GradSync:
         self._left = [0] * len(self._slices)
         self._next = 0
         self._works = []
-        self.overlap = bool(overlap) and self.world_size > 1
+        # (the collectives also run on a single rank under SHADOW_DIST_FORCE_INIT=1: the RCCL smoke path)
+        self.collective = self.world_size > 1 or (force_init() and dist.is_available() and dist.is_initialized())
+        self.overlap = bool(overlap) and self.collective
+        self.wait_s = 0.0                # host time spent in Work.wait() (nccl: the enqueue of a stream wait; gloo: the exchange itself)
+        self.issued = 0                  # collectives issued over the object's lifetime
         if self.overlap:
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -122,10 +164,11 @@ class GradSync:
 
     def _issue(self, s):
         self._pack(s)
-        if self.world_size > 1:
+        if self.collective:
             lo, hi = self._slices[s]
             self._works.append(dist.all_reduce(self.flat[self._off[lo]:self._off[hi]], op=dist.ReduceOp.SUM,
                                                group=self.group, async_op=True))
+            self.issued += 1
 
     def _issue_ready(self):
         while self._next < len(self._slices) and self._left[self._next] <= 0:
@@ -152,13 +195,17 @@ class GradSync:
         while self._next < len(self._slices):
             self._issue(self._next)
             self._next += 1
-        for w in self._works:
-            w.wait()
+        if self._works:
+            import time
+            t0 = time.perf_counter()
+            for w in self._works:
+                w.wait()
+            self.wait_s += time.perf_counter() - t0
         self._works = []
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_on():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
 
@@ -166,7 +213,7 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
 def broadcast_array(arr: np.ndarray, src: int = 0, device=None) -> np.ndarray:
     """The same int64 array on every rank (e.g. the epoch's root permutation: the ranks must cut the SAME
     permutation, which their private numpy generators do not guarantee)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not collectives_on():
         return arr
     on_gpu = dist.get_backend() == "nccl"
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64))

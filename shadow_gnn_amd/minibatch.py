@@ -313,8 +313,8 @@ class MinibatchShallowExtractor:
         raw = self.raw_entity_set[mode]
         if perm is None:
             perm = np.random.permutation(raw.size)
-            if self.world_size > 1:
-                from . import dist as sdist
+            from . import dist as sdist
+            if self.world_size > 1 or sdist.collectives_on():       # (one rank under SHADOW_DIST_FORCE_INIT=1: the RCCL smoke path)
                 perm = sdist.broadcast_array(perm.astype(np.int64), src=0, device=self.device)
         perm = np.asarray(perm).reshape(-1)
         if self.percent_per_epoch[mode] < 1.0:

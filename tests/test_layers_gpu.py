@@ -859,7 +859,7 @@ def _bench_scale_batch(aggr, B, F0=100, depth=2, N=200_000):
 
 @pytest.mark.parametrize("optimizer", ["adam", "flat"])
 @pytest.mark.parametrize("aggr,layers_,heads,B,act", [("sage", 5, 1, 128, "elu"), ("sage", 5, 1, 128, "relu"), ("gcn", 3, 1, 128, "elu"),
-                                                     ("gcn", 3, 1, 128, "relu"), ("gat", 5, 4, 96, "elu")])
+                                                     ("gcn", 3, 1, 128, "relu"), ("gat", 5, 4, 160, "elu")])
 def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B, act, optimizer):
     """ONE DeepGNN.step at benchmark widths (dim 256, F0 = 100) on a batch large enough (n >= 8192 rows) that every
     Linear runs on the split-bf16 MFMA kernels, through EXACTLY the call path bench.py times: the one-call layer
@@ -924,8 +924,17 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (layers_, layers_ - 1)
         assert any(k.startswith("gemm_act_norm_fwd_nb2") for k in ran) and any(k.startswith("gemm_an_bwd_nb2") for k in ran), ran
         assert not any(k.startswith("act_norm_fwd") and k.endswith("F256") for k in ran), ran
+        # ... at a size where the row-maximum hand-over is on: the weight gradients of a layer are ONE two-piece fp16 launch
+        assert n >= ops.AMAX_HANDOVER_ROWS, n
+        assert any(k.startswith("gemm_tn_f16_pair_N256") for k in ran), ran
     if aggr == "gcn":
         assert any(k.startswith("gemm_act_norm_fwd_nb1") for k in ran), ran
+    if aggr == "gat":
+        # the timed GAT configuration's kernels (n >= 40 k rows > AMAX_HANDOVER_ROWS: the paired Linears and their weight
+        # gradients run on two fp16 pieces with the joint row maxima the attention backward leaves)
+        assert n >= 40000 and n >= ops.AMAX_HANDOVER_ROWS, n
+        assert any(k.startswith("gemm_tn_f16") for k in ran) and any(k.startswith("gemm_nt2_f16") for k in ran), ran
+        assert any(k.startswith("gat_fwd") for k in ran) and any(k.startswith("gat_bwd") for k in ran), ran
     assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd", "gemm_nt2_f16")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
     # ---- fp64 oracle, same parameters (relu: with the run's own side at the kink, see the docstring)
     relu_keep, kstats = None, {}
@@ -1533,3 +1542,105 @@ def test_merge_of_8000_small_subgraphs_needs_more_than_64k_of_lds():
     got = ops._spmm_raw(csr.indptr, csr.indices, None, None, None, None, X, n, csr.spmm_blocks)
     want = torch.from_numpy((A @ X.cpu().numpy().astype(np.float64))).to(DEV)
     torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ["relu", "elu"])
+def test_timed_configuration_with_dropout_and_dropedge_matches_fp64_oracle(act, monkeypatch):
+    """parity ON the configuration bench.py times -- GraphSAGE-5, dim 256, dropout 0.4, drop-edge
+    0.05 (config_train/products/vanilla/sage_5_khop.yml), features read lazily by the layer-0 gather, GradSync + FlatAdam.
+    The reference's torch RNG streams cannot be reproduced, but this build's draws can be HANDED to the oracle: every
+    dropout mask is a counter hash of (seed, row, column) (include/shadow_hip.h; restated in ops.dropout_keep_mask) whose
+    seeds are logged here in call order (layer-0 input dropout in the gather, then each layer's fused output dropout =
+    the next layer's input dropout), and the drop-edge mask is captured where it is drawn.  The fp64 edge-list oracle
+    applies exactly those masks (oracle/model_oracle_sparse.py: edge_keep, in_drop) -- loss, predictions, embeddings
+    <= 1e-4, every parameter gradient <= 1e-3 relative + 1e-4 of its scale, as for the dropout-free runs."""
+    from oracle import layers_oracle as lo
+    from oracle import model_oracle_sparse as mos
+    from shadow_gnn_amd import dist as sdist
+    from shadow_gnn_amd import ops
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.optim import FlatAdam
+    P_DROP, P_EDGE, L = 0.4, 0.05, 5
+    b, X, labels, F0, C = _bench_scale_batch("sage", 128)
+    n = b.num_nodes
+    assert n >= ops.AMAX_HANDOVER_ROWS
+    arch = dict(num_layers=L, num_cls_layers=1, heads=1, dim=256, act=act, layer_norm="norm_feat", feature_augment_ops="sum",
+                aggr="sage", residue="none", pooling="center", loss="softmax")
+    torch.manual_seed(41)
+    model = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=P_DROP, dropedge=P_EDGE, lr=0.002), "node").to(DEV)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    model.grad_sync = sdist.GradSync(model.parameters(), world_size=1)
+    model.optimizer = FlatAdam(model.grad_sync, lr=0.002)
+    p0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # the batch as the extractor hands it over with lazy_features on: a table + the batch's node ids
+    table = X.to(DEV)
+    lazy = ops.LazyRows(table, torch.arange(n, device=DEV, dtype=torch.int32))
+    adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off,
+                        max_subg_nodes=b.counts["max_subg_nodes"])
+    batch = OneBatchSubgraph([adj], [lazy], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
+    seeds, edge_masks = [], []
+    real_seed, real_mask = ops.new_dropout_seed, ops.dropedge_mask
+
+    def logged_seed():
+        s_ = real_seed()
+        seeds.append(s_)
+        return s_
+
+    def logged_mask(csr, dropedge, symmetric=False):
+        m = real_mask(csr, dropedge, symmetric)
+        edge_masks.append(m)
+        return m
+    monkeypatch.setattr(ops, "new_dropout_seed", logged_seed)
+    monkeypatch.setattr(ops, "dropedge_mask", logged_mask)
+    c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls)
+    timer = ops.KernelTimer()
+    ops.Z_TAP = []
+    try:
+        with timer:
+            ret = model.step(TRAIN, "running", batch)
+        torch.cuda.synchronize()
+        tap = ops.Z_TAP
+    finally:
+        ops.Z_TAP = None
+    ran = set(timer.summary())
+    # the timed call path: lazy gather with dropout, one-call entries, every boundary chained, fused dropout everywhere
+    assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (L, L - 1)
+    assert any(k.startswith("gather_F") for k in ran) and any(k.startswith("gemm_an_bwd_nb2") for k in ran), ran
+    assert len(seeds) == L and len(edge_masks) == 1 and edge_masks[0] is not None, (len(seeds), len(edge_masks))
+    ek = edge_masks[0].cpu()
+    assert 0.93 < float(ek.mean()) < 0.97                     # ~ e p positions drawn with replacement
+    widths = [F0] + [256] * (L - 1)
+    in_drop = [ops.dropout_keep_mask(n, w, P_DROP, s_, DEV).cpu().double() / (1.0 - P_DROP) for w, s_ in zip(widths, seeds)]
+    for m in in_drop:
+        assert abs(float((m > 0).double().mean()) - (1 - P_DROP)) < 0.01
+    h = b.to_host()
+    sizes = np.diff(h["subg_node_off"].astype(np.int64))
+    relu_keep, kstats = None, {}
+    if act == "relu":
+        relu_keep = [[((z + (bb if bb is not None else 0)) > 0).cpu() for z, bb in zip(zs, bs_)] for zs, bs_ in tap[:L]]
+    p = {k: v.double().requires_grad_(True) for k, v in p0.items()}
+    preds_ref, emb_ref = mos.model_forward(p, arch, X, h["indptr"], h["indices"], sizes, h["target"], relu_keep=relu_keep, stats=kstats,
+                                           edge_keep=ek, in_drop=in_drop)
+    if relu_keep is not None:
+        assert kstats["kink_units"] <= 1e-5 * kstats["units"] and kstats.get("kink_max_abs_z", 0.0) < 5e-3, kstats
+    loss_ref = lo.model_loss(preds_ref, labels.numpy())
+    loss_ref.backward()
+    assert abs(float(ret["loss"]) - float(loss_ref)) < 1e-4
+    np.testing.assert_allclose(ret["preds"].detach().cpu().numpy(), torch.softmax(preds_ref, 1).detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ret["emb_ens"][0].detach().cpu().numpy(), emb_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    grads = {k: v.grad for k, v in p.items() if v.grad is not None}
+    gn = float(torch.sqrt(sum((g_ ** 2).sum() for g_ in grads.values())))
+    coef = min(1.0, 5.0 / (gn + 1e-6))
+    worst = {}
+    for k, q in model.named_parameters():
+        ref = (grads[k] * coef).numpy()
+        got = q.grad.cpu().numpy()
+        scale = float(np.abs(ref).max())
+        bad = np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-4 * scale
+        worst[k] = float(np.abs(got - ref).max() / max(scale, 1e-30))
+        assert not bad.any(), (k, int(bad.sum()), worst[k])
+    assert max(worst.values()) < 1e-3, worst
