@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="roots per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--sampler-steps-per-call", type=int, default=4,
+                    help="steps whose batches ONE sampler call produces (sg_sample_multi; bit-identical batches, the pipeline's "
+                         "four dependent launches paid once per call; 1 = a call per step)")
     ap.add_argument("--no-tail", action="store_true", help="skip the separately reported target-only-tail steps "
                     "(profiling runs: keeps the kernel trace to the timed configuration)")
     ap.add_argument("--prune-tail", action="store_true",
@@ -261,6 +264,8 @@ def main():
                                    label_full, batch_size=B * world, device=dev, seed_cpp=3, rank=rank,
                                    world_size=world, prefetch=not args.no_prefetch)
     mb.lazy_features = True            # layer 0 gathers feat_full[node] inside its aggregation kernel
+    S_call = max(1, min(int(args.sampler_steps_per_call), 16))
+    mb.steps_per_call = S_call
     mb.epoch_start_reset(0, TRAIN)
     mb.shuffle_entity(TRAIN, perm=np.arange(roots_all.size))
     hs = mb.graph_sampler[TRAIN]
@@ -394,16 +399,18 @@ def main():
     if TRAIN in mb._inflight:            # drain the prefetched batch
         mb._collect(TRAIN)
     torch.cuda.synchronize(dev)
+    mb._ready[TRAIN] = []
+    def sampler_call():                  # the call shape of the timed region: S_call batches of B roots per call
+        return hs.sample_multi(scfg, [B] * S_call) if S_call > 1 else [hs.sample(scfg, B)]
     ts0 = time.perf_counter(); sn = 0
-    for _ in range(10):
-        sb = hs.sample(scfg, B)
-        sn += sb.num_nodes
+    for _ in range(max(2, 12 // S_call)):
+        sn += sum(sb.num_nodes for sb in sampler_call())
     torch.cuda.synchronize(dev)
     sampler_rate = sn / (time.perf_counter() - ts0) * world
     # ... and the same kernels' HIP-event time with the GPU to themselves (beside the train step the pipeline shares
     # the chip with the first kernels of the step: both sides' durations then contain each other's work)
     hs.set_profiling(True)
-    alone_counts = [hs.sample(scfg, B).counts for _ in range(10)]
+    alone_counts = [sb.counts for _ in range(max(3, 12 // S_call)) for sb in sampler_call()]
     hs.set_profiling(False)
 
     if rank != 0:
@@ -411,30 +418,40 @@ def main():
     # ---- roofline of the hand-written kernels (live HIP-event timings of the timed region)
     kern = timer.summary()
     with_hop = "hops" in aug
-    pc = [c for c in prof_counts if c["sample_kernel_ms"] > 0]
-    s_ms = [c["sample_kernel_ms"] for c in pc]
-    if wl["sampler"]["method"] == "ppr":       # 8 B (neighbour id + score) per selected table entry
-        for c in pc:
-            c["ppr_reads"] = c["n_tot"]
-    s_bytes = [sampler_alg_bytes(c, with_hop) for c in pc]
-    sampler_alone = None
-    ac = [c for c in alone_counts if c["sample_kernel_ms"] > 0]
-    if ac:
-        if wl["sampler"]["method"] == "ppr":
-            for c in ac:
+    def per_call(count_list):
+        """Sampler CALLS among the batches' counters: a multi-step call's kernel times sit on its first batch
+        (call_index 0), its algorithmic bytes are the sum over its batches; calls seen only in part (the instrumented
+        window opened or closed in the middle of one) are dropped."""
+        calls = {}
+        for i, c in enumerate(count_list):
+            if wl["sampler"]["method"] == "ppr":       # 8 B (neighbour id + score) per selected table entry
                 c["ppr_reads"] = c["n_tot"]
-        a_ms = float(np.mean([c["sample_kernel_ms"] for c in ac]))
-        a_by = float(np.mean([sampler_alg_bytes(c, with_hop) for c in ac]))
+            key = c.get("call_id", ("single", i))
+            e = calls.setdefault(key, dict(ms=0.0, reloc=0.0, by=0.0, reloc_by=0.0, seen=0, want=c.get("call_batches", 1), nodes=0))
+            e["ms"] += c["sample_kernel_ms"]; e["reloc"] += c["relocate_kernel_ms"]
+            e["by"] += sampler_alg_bytes(c, with_hop); e["reloc_by"] += 16 * c["n_tot"] + 16 * c["e_tot"]
+            e["seen"] += 1; e["nodes"] += c["n_tot"]
+        return [e for e in calls.values() if e["seen"] == e["want"] and e["ms"] > 0]
+    pc = per_call(prof_counts)
+    s_ms = [e["ms"] for e in pc]
+    s_bytes = [e["by"] for e in pc]
+    sampler_alone = None
+    ac = per_call(alone_counts)
+    if ac:
+        a_ms = float(np.mean([e["ms"] for e in ac]))
+        a_by = float(np.mean([e["by"] for e in ac]))
         sampler_alone = dict(kernel="sg_sample_pipeline (select + plan + scan), sampler-only loop", calls=len(ac), avg_ms=round(a_ms, 4),
+                             batches_per_call=S_call, roots_per_call=B * S_call,
+                             us_per_subgraph=round(a_ms * 1e3 / (B * S_call), 4),
                              alg_GBps=round(a_by / 1e9 / (a_ms / 1e3), 1), frac=round(a_by / 1e9 / (a_ms / 1e3) / HBM_PEAK_GBS, 4),
-                             relocate_avg_ms=round(float(np.mean([c["relocate_kernel_ms"] for c in ac])), 4))
+                             relocate_avg_ms=round(float(np.mean([e["reloc"] for e in ac])), 4))
     if s_ms:
         kern["sg_sample_pipeline"] = dict(launches=len(s_ms), total_ms=float(sum(s_ms)), avg_ms=float(np.mean(s_ms)),
                                             bytes_per_launch=float(np.mean(s_bytes)),
                                             gbps=float(np.mean(s_bytes)) / 1e9 / (float(np.mean(s_ms)) / 1e3))
-        r_ms = [c["relocate_kernel_ms"] for c in pc]
+        r_ms = [e["reloc"] for e in pc]
         kern["sg_relocate_kernel"] = dict(launches=len(r_ms), total_ms=float(sum(r_ms)), avg_ms=float(np.mean(r_ms)),
-                                          bytes_per_launch=float(np.mean([16 * c["n_tot"] + 16 * c["e_tot"] for c in pc])),
+                                          bytes_per_launch=float(np.mean([e["reloc_by"] for e in pc])),
                                           gbps=0.0)
     # PMC-derived HBM bytes per launch (separate FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles.sh over this
     # same command), kept as a static file: bench.py cannot run the profiler around itself
@@ -583,6 +600,7 @@ def main():
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
                                f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",
                    "global_batch": B * world, "parallelism": f"dp{world}", "prune_tail": bool(args.prune_tail),
+                   "sampler_steps_per_call": S_call,
                    "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4),
                    "ppr_preproc": ppr_info},
         # `roofline` leads with what BASELINE.json's north_star asks for: the HBM fraction of the k-hop-sample + feature

@@ -191,6 +191,21 @@ int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t
               uint64_t serial_base, const uint32_t *d_roots_override, const sg_batch_out *out,
               void *stream);
 int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts);
+/* Several consecutive batches from ONE call: the subgraphs of batch b are the next batch_subgraphs[b] root groups behind
+ * those of batch b - 1 (roots targets[root_start ...) or the override list, RNG serials serial_base ...), written
+ * block-diagonally into outs[b] with offsets relative to that batch -- exactly what num_batches consecutive sg_sample
+ * calls write (the draws are keyed on the subgraph's serial number, not on the call), but the four dependent kernels of
+ * the pipeline are launched once: at the benchmark's 1 024 roots per step their fixed latency is a third of a call
+ * (DESIGN section 3).  The reference has no counterpart: its trainer asks for one batch at a time
+ * (ParallelSampler::parallel_sampler_ensemble, .cpp:662-704); a prefetching caller asks for the next few steps' batches.
+ * 1 <= num_batches <= SG_MAX_BATCHES_PER_CALL, every batch non-empty.  sg_sample_finish_multi fills counts[num_batches];
+ * the kernel durations of the call (profiling on) are reported on counts[0].  A capacity overflow of any batch fails the
+ * whole call (SG_ERR_CAPACITY, flags OR-ed): grow and call again. */
+#define SG_MAX_BATCHES_PER_CALL 16
+int sg_sample_multi(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t num_batches,
+                    const uint32_t *batch_subgraphs, uint64_t serial_base, const uint32_t *d_roots_override,
+                    const sg_batch_out *outs, void *stream);
+int sg_sample_finish_multi(sg_sampler *s, uint32_t num_batches, sg_batch_counts *counts);
 /* Bracket the kernels of every sg_sample call with timing events (bench.py's
  * live roofline measurement).                                                 */
 int sg_set_profiling(sg_sampler *s, int enable);

@@ -100,6 +100,9 @@ SIGNATURES = {
     "sg_sample": (C.c_int, [_P, C.POINTER(SgConfig), C.c_uint64, C.c_uint32, C.c_uint64, _P,
                              C.POINTER(SgBatchOut), _P]),
     "sg_sample_finish": (C.c_int, [_P, C.POINTER(SgBatchCounts)]),
+    "sg_sample_multi": (C.c_int, [_P, C.POINTER(SgConfig), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64, _P,
+                                  C.POINTER(SgBatchOut), _P]),
+    "sg_sample_finish_multi": (C.c_int, [_P, C.c_uint32, C.POINTER(SgBatchCounts)]),
     "sg_set_profiling": (C.c_int, [_P, C.c_int]),
     "sg_debug_subgraph_stats": (C.c_int, [_P, _P, C.c_uint32]),
     "sg_debug_scan_phases": (C.c_int, [_P, _P]),
@@ -189,7 +192,8 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 13      # sg_abi_version() of the library these signatures describe
+MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
+ABI_VERSION = 14      # sg_abi_version() of the library these signatures describe
 
 
 def load():

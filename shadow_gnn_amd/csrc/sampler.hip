@@ -79,6 +79,8 @@ namespace shadow {
 // Relocation into the block-diagonal batch (frontend/graph.py:280-320), hop
 // BFS (Graph.cpp:32-64) and DRNL (Graph.cpp:66-73, .cpp:438-451).
 // ---------------------------------------------------------------------------
+constexpr uint32_t kMaxBatches = SG_MAX_BATCHES_PER_CALL;
+
 struct RelocParams {
   uint32_t P;
   int R;
@@ -98,8 +100,12 @@ struct RelocParams {
   const uint32_t *plan;
   uint32_t *s_tmp;       // [P*cap_nodes_scr] BFS scratch (drnl)
   uint32_t *s_lcol;      // [P*cap_edges_scr] local column ids in final order (hop / drnl BFS)
-  sg_batch_out out;
-  uint64_t *d_counts;    // [8] n_tot, e_tot, max_n, max_e, overflow, slots, fnodes, freads
+  // One call may fill SEVERAL batches (sg_sample_multi): the subgraphs [bstart[b], bstart[b+1]) of the call form batch b,
+  // written block-diagonally into outs[b] with offsets relative to that batch, counted in d_counts[8 b ...].
+  uint32_t nbatch;
+  uint32_t bstart[kMaxBatches + 1];
+  sg_batch_out outs[kMaxBatches];
+  uint64_t *d_counts;    // [nbatch][8] n_tot, e_tot, max_n, max_e, overflow, slots, fnodes, freads
 };
 
 __device__ __forceinline__ void bfs_local(const uint32_t *rowptr, const uint32_t *col, uint32_t n,
@@ -132,12 +138,17 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   __shared__ uint32_t changed;
   const uint32_t s = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
-  // exclusive prefix of (nodes, edges) over the preceding subgraphs; the LAST workgroup also folds
-  // the batch statistics of every subgraph (same pass, no contended global atomics)
-  const bool last = (s + 1 == p.P);
+  // the batch this subgraph belongs to (uniform; a handful of batches per call)
+  uint32_t bi = 0;
+  while (bi + 1 < p.nbatch && s >= p.bstart[bi + 1]) bi++;
+  const uint32_t s0 = p.bstart[bi], s1 = p.bstart[bi + 1], sb = s - s0, Pb = s1 - s0;
+  uint64_t *const counts = p.d_counts + 8 * bi;
+  // exclusive prefix of (nodes, edges) over the preceding subgraphs OF THE BATCH; the batch's LAST workgroup also
+  // folds the batch statistics of every subgraph (same pass, no contended global atomics)
+  const bool last = (s + 1 == s1);
   uint64_t pn = 0, pe = 0, sl = 0, fn = 0, fr = 0;
   uint32_t mxn = 0, mxe = 0;
-  for (uint32_t q = tid; q < s + (last ? 1u : 0u); q += T) {
+  for (uint32_t q = s0 + tid; q < s + (last ? 1u : 0u); q += T) {
     const uint32_t *c = p.s_cnt + (size_t)q * R_WORDS;
     if (q < s) { pn += c[R_N]; pe += c[R_E]; }
     if (last) { sl += c[R_SLOTS]; fn += c[R_FNODES]; fr += c[R_FREADS]; mxn = max(mxn, c[R_N]); mxe = max(mxe, c[R_E]); }
@@ -161,18 +172,18 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   const uint64_t noff = offs[0], eoff = offs[1];
   const uint32_t *c = p.s_cnt + (size_t)s * R_WORDS;
   const uint32_t n = c[R_N], e = c[R_E], flags = c[R_FLAGS];
-  const sg_batch_out &o = p.out;
+  const sg_batch_out &o = p.outs[bi];
   if (tid == 0) {
-    o.d_subg_nodes[s] = (uint32_t)noff;
-    o.d_subg_edges[s] = (uint32_t)eoff;
+    o.d_subg_nodes[sb] = (uint32_t)noff;
+    o.d_subg_edges[sb] = (uint32_t)eoff;
     if (last) {
-      o.d_subg_nodes[p.P] = (uint32_t)(noff + n); o.d_subg_edges[p.P] = (uint32_t)(eoff + e);
+      o.d_subg_nodes[Pb] = (uint32_t)(noff + n); o.d_subg_edges[Pb] = (uint32_t)(eoff + e);
       uint64_t t0 = 0, t1 = 0, t2 = 0, m0 = 0, m1 = 0;
       for (uint32_t w = 0; w < nw; w++) {
         t0 += stat[w][0]; t1 += stat[w][1]; t2 += stat[w][2]; m0 = max(m0, stat[w][3]); m1 = max(m1, stat[w][4]);
       }
-      p.d_counts[0] = noff + n; p.d_counts[1] = eoff + e;
-      p.d_counts[2] = m0; p.d_counts[3] = m1; p.d_counts[5] = t0; p.d_counts[6] = t1; p.d_counts[7] = t2;
+      counts[0] = noff + n; counts[1] = eoff + e;
+      counts[2] = m0; counts[3] = m1; counts[5] = t0; counts[6] = t1; counts[7] = t2;
     }
   }
   uint32_t ovf = flags & 3u;
@@ -181,7 +192,7 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   if (noff + n > o.cap_nodes) ovf |= 4u;
   if (eoff + e > o.cap_edges) ovf |= 8u;
   if (ovf) {
-    if (tid == 0) atomicOr((unsigned long long *)&p.d_counts[4], (unsigned long long)ovf);
+    if (tid == 0) atomicOr((unsigned long long *)&counts[4], (unsigned long long)ovf);
     return;
   }
   const uint32_t *nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
@@ -231,9 +242,9 @@ __global__ void sg_relocate_kernel(RelocParams p) {
   for (uint32_t i = (e > 0 ? prev_row + 1u : 0u) + tid; i <= n; i += T) rowptr[i] = e;   // rows behind the last edge
   __syncthreads();
   for (uint32_t i = tid; i < n; i += T) o.d_indptr[noff + i] = (uint32_t)(eoff + rowptr[i]);
-  if (s + 1 == p.P && tid == 0) o.d_indptr[noff + n] = (uint32_t)(eoff + e);
+  if (last && tid == 0) o.d_indptr[noff + n] = (uint32_t)(eoff + e);
   const uint32_t *tgt = p.s_tgt + (size_t)s * kMaxRoots;
-  if (tid < (uint32_t)p.R) o.d_target[(size_t)s * p.R + tid] = (uint32_t)(noff + tgt[tid]);
+  if (tid < (uint32_t)p.R) o.d_target[(size_t)sb * p.R + tid] = (uint32_t)(noff + tgt[tid]);
   if ((p.aug_flags & SG_AUG_HOPS) && o.d_hop) {
     bfs_local(rowptr, lcol, n, tgt[0], o.d_hop + noff, &changed);           // .cpp:433-436
   }
@@ -285,11 +296,13 @@ struct sg_sampler {
   size_t big_bytes = 0;
   uint32_t user_cap_nodes = 0, user_cap_edges = 0;
   uint32_t rec_scale = 1;            // round-record pool multiplier: doubled by sg_sample_finish on overflow flag 16
-  uint64_t *d_counts = nullptr;   // [8] + ticket
+  uint64_t *d_counts = nullptr;   // [kMaxBatches][8] + tickets
   uint64_t *h_counts = nullptr;   // pinned
   hipEvent_t ev = nullptr;
   bool pending = false;
   uint32_t pending_P = 0;
+  uint32_t pending_nbatch = 0;
+  uint32_t pending_bsize[kMaxBatches] = {0};
   const uint32_t *last_cnt = nullptr;   // per-subgraph result words of the last call
   const uint32_t *last_plan = nullptr;  // plan words of the last call (item count, phase cycles of the scan)
   bool profiling = false;
@@ -345,13 +358,13 @@ extern "C" const char *sg_last_error(void) { return last_error().c_str(); }
 // 2: sl_act_norm_* carry (drop_p, drop_seed); gemm / cache / pooling entries.  3: sl_act_norm_* dual (plain + dropped) output
 // 4: sg_ppr_push(mode).  5: sl_gat_bwd work buffer holds the datt partial sums.  6: sg_create_from_bin_ex
 // 7: sl_spmm_blockdiag_gather_f32, sampler debug entries.  8: sl_sage_fwd / sl_sage_bwd, sl_gemm_pack_b2, sl_gather_rows_drop_f32
-extern "C" int sg_abi_version(void) { return 13; }
+extern "C" int sg_abi_version(void) { return 14; }
 
 static int create_common(sg_sampler *s, int device_id, int64_t seed) {
   s->device = device_id;
   s->seed = seed < 0 ? (uint64_t)time(nullptr) : (uint64_t)seed;
-  SHD_HIP(hipMalloc((void **)&s->d_counts, 16 * sizeof(uint64_t)));
-  SHD_HIP(hipHostMalloc((void **)&s->h_counts, 16 * sizeof(uint64_t), hipHostMallocDefault));
+  SHD_HIP(hipMalloc((void **)&s->d_counts, (8 * kMaxBatches + 8) * sizeof(uint64_t)));
+  SHD_HIP(hipHostMalloc((void **)&s->h_counts, (8 * kMaxBatches + 8) * sizeof(uint64_t), hipHostMallocDefault));
   SHD_HIP(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
   return SG_OK;
 }
@@ -735,12 +748,18 @@ extern "C" int sg_drop_full_graph_info(sg_sampler *s) {
   return SG_OK;
 }
 
-extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
-                         uint32_t num_subgraphs, uint64_t serial_base,
-                         const uint32_t *d_roots_override, const sg_batch_out *out, void *stream_) {
-  if (!s || !cfg || !out) return set_error(SG_ERR_INVALID, "sg_sample: null argument");
+static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t nbatch, const uint32_t *bsize,
+                       uint64_t serial_base, const uint32_t *d_roots_override, const sg_batch_out *outs, void *stream_) {
+  if (!s || !cfg || !outs || !bsize) return set_error(SG_ERR_INVALID, "sg_sample: null argument");
+  if (nbatch < 1 || nbatch > kMaxBatches) return set_error(SG_ERR_INVALID, "sg_sample_multi: %u batches per call (1..%u)", nbatch, kMaxBatches);
   hipStream_t stream = (hipStream_t)stream_;
-  const uint32_t P = num_subgraphs;
+  uint64_t Psum = 0;
+  for (uint32_t b = 0; b < nbatch; b++) {
+    if (nbatch > 1 && bsize[b] == 0) return set_error(SG_ERR_INVALID, "sg_sample_multi: batch %u is empty", b);
+    Psum += bsize[b];
+  }
+  if (Psum >= ((uint64_t)1 << 31)) return set_error(SG_ERR_INVALID, "sg_sample: too many subgraphs in one call");
+  const uint32_t P = (uint32_t)Psum;
   const int R = cfg->num_roots;
   if (s->graph_dropped) return set_error(SG_ERR_STATE, "sg_sample: full graph was dropped");
   if (R < 1 || R > (int)kMaxRoots) return set_error(SG_ERR_INVALID, "sg_sample: num_roots=%d unsupported (1..%u)", R, kMaxRoots);
@@ -755,9 +774,13 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       return set_error(SG_ERR_INVALID, "sg_sample: roots [%llu, +%u*%d) outside the %llu targets",
                        (unsigned long long)root_start, P, R, (unsigned long long)s->num_targets);
   }
-  if (!out->d_node || !out->d_indptr || !out->d_indices || !out->d_edge_id || !out->d_target ||
-      !out->d_subg_nodes || !out->d_subg_edges)
-    return set_error(SG_ERR_INVALID, "sg_sample: missing output buffer");
+  for (uint32_t b = 0; b < nbatch; b++) {
+    const sg_batch_out *out = outs + b;
+    if (!out->d_node || !out->d_indptr || !out->d_indices || !out->d_edge_id || !out->d_target ||
+        !out->d_subg_nodes || !out->d_subg_edges)
+      return set_error(SG_ERR_INVALID, "sg_sample: missing output buffer (batch %u)", b);
+  }
+  const sg_batch_out *out = outs;
   SHD_HIP(hipSetDevice(s->device));
   if (s->pending) { SHD_HIP(hipEventSynchronize(s->ev)); s->pending = false; }
 
@@ -783,7 +806,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
   char *sc = (char *)s->d_scratch;
 
   s->timed = false;
-  SHD_HIP(hipMemsetAsync(s->d_counts, 0, 16 * sizeof(uint64_t), stream));
+  SHD_HIP(hipMemsetAsync(s->d_counts, 0, (8 * kMaxBatches + 8) * sizeof(uint64_t), stream));
   if (P == 0) {
     SHD_HIP(hipMemsetAsync(out->d_indptr, 0, 4, stream));
     SHD_HIP(hipMemsetAsync(out->d_subg_nodes, 0, 4, stream));
@@ -827,7 +850,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       while ((size_t)H * 8 > 16 * 1024 && (H >> 1) >= capn_lds * 2) H >>= 1;
       p.capn = capn_lds; p.capf = capf_lds; p.H = H;
       p.hshift = 32; for (uint32_t h = H / 4; h > 1; h >>= 1) p.hshift--;
-      p.g_ticket = (uint32_t *)(s->d_counts + 8);
+      p.g_ticket = (uint32_t *)(s->d_counts + 8 * kMaxBatches);
       const LdsLayout L = lds_layout(H, capn_lds, capf_lds, cfg->method == SG_METHOD_PPR);
       if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));
@@ -852,7 +875,7 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
       while (nslots > 1 && (uint64_t)nslots * stride * 4 > ((uint64_t)4 << 30)) nslots >>= 1;
       if ((rc = ensure(&s->d_big, &s->big_bytes, (size_t)nslots * stride * 4)) != SG_OK) return rc;
       q.g_tables = (uint32_t *)s->d_big; q.g_stride = stride;
-      q.g_ticket = (uint32_t *)(s->d_counts + 8) + 1;
+      q.g_ticket = (uint32_t *)(s->d_counts + 8 * kMaxBatches) + 1;
       hipLaunchKernelGGL(sg_select_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
       SHD_HIP(hipGetLastError());
     }
@@ -910,7 +933,9 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     r.s_row = p.s_row; r.s_col = p.s_col;
     r.s_eid = p.s_eid; r.s_tgt = p.s_tgt; r.s_cnt = p.s_cnt; r.s_tmp = (uint32_t *)(sc + o_tmp);
     r.cstart = p.cstart; r.recs = p.recs; r.blkinfo = p.blkinfo; r.plan = p.plan; r.s_lcol = (uint32_t *)(sc + o_lcol);
-    r.out = *out; r.d_counts = s->d_counts;
+    r.nbatch = nbatch; r.bstart[0] = 0;
+    for (uint32_t b = 0; b < nbatch; b++) { r.bstart[b + 1] = r.bstart[b] + bsize[b]; r.outs[b] = outs[b]; }
+    r.d_counts = s->d_counts;
     // one workgroup per subgraph: subgraphs of thousands of nodes (depth-3 k-hop) get 1024 threads for their edge walk and BFS
     // (measured, 512 roots of the depth-3 benchmark: 0.27 ms at 256 threads)
     static const int reloc_env = [] { const char *e = getenv("SHADOW_RELOC_THREADS"); return e ? atoi(e) : 0; }();
@@ -920,41 +945,70 @@ extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_star
     if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[2], stream));
     s->timed = s->profiling;
   }
-  SHD_HIP(hipMemcpyAsync(s->h_counts, s->d_counts, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  SHD_HIP(hipMemcpyAsync(s->h_counts, s->d_counts, 8 * nbatch * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   SHD_HIP(hipEventRecord(s->ev, stream));
   s->pending = true;
   s->pending_P = P;
+  s->pending_nbatch = nbatch;
+  for (uint32_t b = 0; b < nbatch; b++) s->pending_bsize[b] = bsize[b];
+  return SG_OK;
+}
+
+extern "C" int sg_sample(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
+                         uint32_t num_subgraphs, uint64_t serial_base,
+                         const uint32_t *d_roots_override, const sg_batch_out *out, void *stream_) {
+  return sample_impl(s, cfg, root_start, 1, &num_subgraphs, serial_base, d_roots_override, out, stream_);
+}
+
+extern "C" int sg_sample_multi(sg_sampler *s, const sg_config *cfg, uint64_t root_start, uint32_t num_batches,
+                               const uint32_t *batch_subgraphs, uint64_t serial_base, const uint32_t *d_roots_override,
+                               const sg_batch_out *outs, void *stream_) {
+  return sample_impl(s, cfg, root_start, num_batches, batch_subgraphs, serial_base, d_roots_override, outs, stream_);
+}
+
+extern "C" int sg_sample_finish_multi(sg_sampler *s, uint32_t num_batches, sg_batch_counts *counts) {
+  if (!s || !counts) return set_error(SG_ERR_INVALID, "sg_sample_finish: null argument");
+  if (!s->pending) return set_error(SG_ERR_STATE, "sg_sample_finish: no sample in flight");
+  if (num_batches != s->pending_nbatch)
+    return set_error(SG_ERR_INVALID, "sg_sample_finish: the call in flight has %u batches, not %u", s->pending_nbatch, num_batches);
+  SHD_HIP(hipSetDevice(s->device));
+  SHD_HIP(hipEventSynchronize(s->ev));
+  s->pending = false;
+  uint32_t overflow = 0, worst = 0;
+  for (uint32_t b = 0; b < num_batches; b++) {
+    const uint64_t *h = s->h_counts + 8 * b;
+    sg_batch_counts *c = counts + b;
+    c->n_tot = h[0]; c->e_tot = h[1];
+    c->num_subgraphs = s->pending_bsize[b];
+    c->max_subg_nodes = (uint32_t)h[2]; c->max_subg_edges = (uint32_t)h[3];
+    c->overflow = (uint32_t)h[4];
+    c->slots_scanned = h[5]; c->frontier_reads = h[7]; c->frontier_nodes = h[6];
+    c->sample_kernel_ms = 0.f; c->relocate_kernel_ms = 0.f;
+    if (c->overflow && !overflow) worst = b;
+    overflow |= c->overflow;
+  }
+  // (the kernels of a call serve all of its batches: their durations are reported on the FIRST batch's counts)
+  if (s->timed) {
+    (void)hipEventElapsedTime(&counts[0].sample_kernel_ms, s->ev_t[0], s->ev_t[1]);
+    (void)hipEventElapsedTime(&counts[0].relocate_kernel_ms, s->ev_t[1], s->ev_t[2]);
+  }
+  // flag 16 (the scan's pool of round records ran out: subgraphs cut into unusually many rounds) is repaired here -- the
+  // next call of this sampler carves a pool twice as large -- so that re-issuing the same call converges
+  if ((overflow & 16u) && s->rec_scale < 64u) s->rec_scale *= 2u;
+  if (overflow)
+    return set_error(SG_ERR_CAPACITY,
+                     "sg_sample: capacity exceeded (flags=0x%x: 1=subgraph nodes 2=subgraph edges 4=out nodes 8=out edges "
+                     "16=round records [pool doubled for the next call]); "
+                     "batch %u: largest subgraph %u nodes / %u edges, batch %llu nodes / %llu edges",
+                     overflow, worst, counts[worst].max_subg_nodes, counts[worst].max_subg_edges,
+                     (unsigned long long)counts[worst].n_tot, (unsigned long long)counts[worst].e_tot);
   return SG_OK;
 }
 
 extern "C" int sg_sample_finish(sg_sampler *s, sg_batch_counts *counts) {
-  if (!s || !counts) return set_error(SG_ERR_INVALID, "sg_sample_finish: null argument");
-  if (!s->pending) return set_error(SG_ERR_STATE, "sg_sample_finish: no sample in flight");
-  SHD_HIP(hipSetDevice(s->device));
-  SHD_HIP(hipEventSynchronize(s->ev));
-  s->pending = false;
-  const uint64_t *h = s->h_counts;
-  counts->n_tot = h[0]; counts->e_tot = h[1];
-  counts->num_subgraphs = s->pending_P;
-  counts->max_subg_nodes = (uint32_t)h[2]; counts->max_subg_edges = (uint32_t)h[3];
-  counts->overflow = (uint32_t)h[4];
-  counts->slots_scanned = h[5]; counts->frontier_reads = h[7]; counts->frontier_nodes = h[6];
-  counts->sample_kernel_ms = 0.f; counts->relocate_kernel_ms = 0.f;
-  if (s->timed) {
-    (void)hipEventElapsedTime(&counts->sample_kernel_ms, s->ev_t[0], s->ev_t[1]);
-    (void)hipEventElapsedTime(&counts->relocate_kernel_ms, s->ev_t[1], s->ev_t[2]);
-  }
-  // flag 16 (the scan's pool of round records ran out: subgraphs cut into unusually many rounds) is repaired here -- the
-  // next call of this sampler carves a pool twice as large -- so that re-issuing the same call converges
-  if ((counts->overflow & 16u) && s->rec_scale < 64u) s->rec_scale *= 2u;
-  if (counts->overflow)
-    return set_error(SG_ERR_CAPACITY,
-                     "sg_sample: capacity exceeded (flags=0x%x: 1=subgraph nodes 2=subgraph edges 4=out nodes 8=out edges "
-                     "16=round records [pool doubled for the next call]); "
-                     "largest subgraph %u nodes / %u edges, batch %llu nodes / %llu edges",
-                     counts->overflow, counts->max_subg_nodes, counts->max_subg_edges,
-                     (unsigned long long)counts->n_tot, (unsigned long long)counts->e_tot);
-  return SG_OK;
+  if (s && s->pending && s->pending_nbatch != 1)
+    return set_error(SG_ERR_STATE, "sg_sample_finish: a %u-batch call is in flight (sg_sample_finish_multi)", s->pending_nbatch);
+  return sg_sample_finish_multi(s, 1, counts);
 }
 
 extern "C" int sg_set_profiling(sg_sampler *s, int enable) {

@@ -216,6 +216,12 @@ class MinibatchShallowExtractor:
         # on its HBM-bound head (scripts/ab_defer_point.sh); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
         self.defer_prefetch = os.environ.get("SHADOW_DEFER_PREFETCH", "1") != "0"
         self._inflight: Dict[int, Tuple[str, int, int]] = {}   # mode -> (kind, roots in the call, epoch cursor at its start)
+        # Sampler calls that cover several steps (HipSampler.sample_multi_async -> sg_sample_multi): the pipeline's four
+        # dependent kernel launches cost ~0.08 ms whatever the call's size -- a third of a 1 024-root call -- and the draws are
+        # keyed on the subgraph's serial number, so S steps' batches from one call are bit-identical to S calls.  The batches
+        # of a call wait in ``_ready`` until their step comes.  1 = one call per step (the reference's rhythm).
+        self.steps_per_call = max(1, min(int(os.environ.get("SHADOW_SAMPLER_STEPS_PER_CALL", "1")), 16))
+        self._ready: Dict[int, list] = {m: [] for m in _MODES}  # collected batches of later steps, in step order
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
         self.nocache_modes = set(nocache_modes)
         self.record_subgraphs: Dict[int, str] = {}
@@ -299,9 +305,12 @@ class MinibatchShallowExtractor:
 
     def _drain(self, mode):
         """Finish and discard a prefetched sampler call (its outputs are dropped); returns its root count."""
+        bs = sum(b.num_subgraphs for b in self._ready[mode])           # batches of a multi-step call not consumed yet
+        self._ready[mode] = []
         if mode not in self._inflight:
-            return 0
-        bs = self._inflight[mode][1]
+            return bs
+        n = self._inflight[mode][1]
+        bs += sum(n) if isinstance(n, (list, tuple)) else n
         self._collect(mode, discard=True)
         return bs
 
@@ -415,18 +424,30 @@ class MinibatchShallowExtractor:
         """Issue the sampler call of the next un-launched step (nothing to issue for an empty share)."""
         t = self._launched[mode]
         bs = int(self._local_sizes[mode][t])
-        self._launched[mode] = t + 1
         if bs == 0:
+            self._launched[mode] = t + 1
             return
         hs = self.graph_sampler[mode]
         reuse = self.record_subgraphs.get(mode) == "reuse"
         c0 = self._cursor[mode]
+        # several steps from one call: the following steps' shares, up to the first empty one (ragged epoch tails)
+        sizes = [bs]
+        if not reuse and self.steps_per_call > 1:
+            for x in self._local_sizes[mode][t + 1:t + self.steps_per_call]:
+                if int(x) == 0:
+                    break
+                sizes.append(int(x))
+        multi = len(sizes) > 1
+        self._launched[mode] = t + len(sizes)
+        bs = sum(sizes)
 
         def go():
             if reuse:
                 hn, he = self._hwm[mode]
                 self.cache_subg[mode].collate_async(self._roots_dev[mode][c0:c0 + bs], hn + hn // 8 + 64, he + he // 8 + 64,
                                                     want_hop="hops" in self.aug_feats)
+            elif multi:
+                hs.sample_multi_async(self.sampler_cfg, sizes)
             else:
                 hs.sample_async(self.sampler_cfg, bs)
         if self._side is not None:
@@ -436,7 +457,7 @@ class MinibatchShallowExtractor:
         else:
             go()
         self._cursor[mode] = c0 + bs
-        self._inflight[mode] = ("reuse" if reuse else "sample", bs, c0)
+        self._inflight[mode] = ("reuse" if reuse else ("multi" if multi else "sample"), sizes if multi else bs, c0)
 
     def _collect(self, mode, discard: bool = False) -> Optional[DeviceBatch]:
         hs = self.graph_sampler[mode]
@@ -449,15 +470,25 @@ class MinibatchShallowExtractor:
             if self._side is not None:
                 self._side.wait_stream(main)
 
-        def go():
-            if kind == "reuse":
-                return self.cache_subg[mode].finish(on_retry=before_rerun)
-            b = hs.finish(on_retry=before_rerun)
+        def record(b, lo, hi):
             if not discard and self.record_subgraphs.get(mode) == "record":
                 self.cache_subg[mode].record(b)                      # minibatch.py:407-412
                 if mode not in self._recorded:
                     self._recorded[mode] = np.zeros(self.raw_entity_set[mode].size, dtype=bool)
-                self._recorded[mode][self._mine_pos[mode][c0:c0 + bs]] = True
+                self._recorded[mode][self._mine_pos[mode][lo:hi]] = True
+
+        def go():
+            if kind == "reuse":
+                return self.cache_subg[mode].finish(on_retry=before_rerun)
+            if kind == "multi":          # the batches of several steps: the first one is returned, the others wait their turn
+                bl = hs.finish_multi(on_retry=before_rerun)
+                lo = c0
+                for b_, n_ in zip(bl, bs):
+                    record(b_, lo, lo + n_)
+                    lo += n_
+                return bl
+            b = hs.finish(on_retry=before_rerun)
+            record(b, c0, c0 + bs)
             return b
         import time as _time
         t_wait = _time.perf_counter()
@@ -475,6 +506,11 @@ class MinibatchShallowExtractor:
             self.wait_s += _time.perf_counter() - t_wait
         if discard:
             return None
+        if kind == "multi":
+            for b_ in b:
+                self._hwm[mode] = [max(self._hwm[mode][0], b_.num_nodes), max(self._hwm[mode][1], b_.num_edges)]
+            self._ready[mode] = list(b[1:])
+            return b[0]
         self._hwm[mode] = [max(self._hwm[mode][0], b.num_nodes), max(self._hwm[mode][1], b.num_edges)]
         return b
 
@@ -492,9 +528,12 @@ class MinibatchShallowExtractor:
         t = self._step[mode]
         assert t < self._local_sizes[mode].size, "epoch exhausted: call shuffle_entity before the next epoch"
         batch_size_ = int(self._local_sizes[mode][t])
-        if self._launched[mode] <= t:
-            self._launch(mode)
-        subgs = self._collect(mode) if batch_size_ > 0 else None
+        if batch_size_ > 0 and self._ready[mode]:
+            subgs = self._ready[mode].pop(0)               # sampled by an earlier step's multi-step call
+        else:
+            if self._launched[mode] <= t:
+                self._launch(mode)
+            subgs = self._collect(mode) if batch_size_ > 0 else None
         assert subgs is None or subgs.num_subgraphs == batch_size_, (subgs.num_subgraphs, batch_size_)
         i0 = self.idx_entity_evaluated[mode]
         self.idx_entity_evaluated[mode] += batch_size_
@@ -509,7 +548,7 @@ class MinibatchShallowExtractor:
                 assert self.graph_sampler[mode].get_idx_root() == 0      # samplers_ensemble.py:298-301
         weight = batch_size_ / float(self._global_sizes[mode][t])
         if subgs is None:
-            if not last and self.prefetch:
+            if not last and self.prefetch and self._launched[mode] == t + 1:
                 self._launch(mode)
             return self._empty_batch(mode)
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
@@ -522,7 +561,7 @@ class MinibatchShallowExtractor:
                 t1 = t + 1
                 ops.defer((id(self), mode),
                           lambda: self._launch(mode) if (self._launched[mode] == t1 and self._step[mode] == t1) else None)
-            else:
+            elif self._launched[mode] == t + 1:
                 self._launch(mode)        # overlap the next sampler call with this batch's training
         feat = (ops.LazyRows(self.feat_full, subgs.node) if self.lazy_features
                 else ops.gather_rows(self.feat_full, subgs.node))    # minibatch.py:469

@@ -148,7 +148,7 @@ class DeviceBatch:
 
 
 class _Pending:
-    __slots__ = ("cfg", "P", "root_start", "serial", "bufs", "out", "roots_dev")
+    __slots__ = ("cfg", "P", "root_start", "serial", "bufs", "out", "roots_dev", "sizes")
 
 
 class HipSampler:
@@ -284,8 +284,7 @@ class HipSampler:
     def _cfg_key(cfg: SamplerConfig):
         return (cfg.method, cfg.num_roots, cfg.depth, cfg.budget, cfg.k, cfg.add_self_edge)
 
-    def _launch(self, pend: _Pending, cap_edges_out: Optional[int] = None, cap_nodes_out: Optional[int] = None):
-        cfg, P = pend.cfg, pend.P
+    def _out_caps(self, cfg, P, cap_edges_out, cap_nodes_out):
         capn, cape = self.get_caps(cfg)
         if cap_nodes_out is None:
             # worst case P * capn when that is small; otherwise (hub-heavy graphs, grown caps) the running
@@ -298,12 +297,33 @@ class HipSampler:
             per = max(self._hwm.get(self._cfg_key(cfg), (0, 0))[0] * 3 // 2, min(cape, 8 * capn), 64)
             cap_edges_out = max(1, P * per)
         cap_edges_out = min(cap_edges_out, max(1, P * cape))
-        pend.bufs, pend.out = self._alloc(cfg, P, cap_nodes_out, cap_edges_out)
+        return cap_nodes_out, cap_edges_out
+
+    def _launch(self, pend: _Pending, cap_edges_out=None, cap_nodes_out=None):
+        """Allocate the outputs and enqueue the call.  ``pend.sizes`` (optional): the call fills SEVERAL consecutive
+        batches (sg_sample_multi); the caps are then lists (or None) with one entry per batch."""
+        cfg, P = pend.cfg, pend.P
+        sizes = getattr(pend, "sizes", None)
         c = cfg.to_c()
         stream = torch._C._cuda_getCurrentRawStream(self.device.index)
         roots_ptr = pend.roots_dev.data_ptr() if pend.roots_dev is not None else None
-        check(self._lib.sg_sample(self._h, C.byref(c), pend.root_start, P, pend.serial, roots_ptr,
-                                  C.byref(pend.out), stream))
+        if not sizes:
+            cn, ce = self._out_caps(cfg, P, cap_edges_out, cap_nodes_out)
+            pend.bufs, pend.out = self._alloc(cfg, P, cn, ce)
+            check(self._lib.sg_sample(self._h, C.byref(c), pend.root_start, P, pend.serial, roots_ptr,
+                                      C.byref(pend.out), stream))
+            return
+        S = len(sizes)
+        outs = (SgBatchOut * S)()
+        pend.bufs = []
+        for i, Pi in enumerate(sizes):
+            cn, ce = self._out_caps(cfg, Pi, cap_edges_out[i] if cap_edges_out else None, cap_nodes_out[i] if cap_nodes_out else None)
+            b, o = self._alloc(cfg, Pi, cn, ce)
+            pend.bufs.append(b)
+            outs[i] = o
+        pend.out = outs
+        check(self._lib.sg_sample_multi(self._h, C.byref(c), pend.root_start, S, (C.c_uint32 * S)(*sizes), pend.serial, roots_ptr,
+                                        outs, stream))
 
     def sample_async(self, cfg: SamplerConfig, max_subgraphs: int = 0, *, roots=None,
                      serial_base: Optional[int] = None):
@@ -315,6 +335,7 @@ class HipSampler:
         pend = _Pending()
         pend.cfg = cfg
         pend.roots_dev = None
+        pend.sizes = None
         if roots is not None:
             r = torch.as_tensor(np.ascontiguousarray(np.asarray(roots).reshape(-1), dtype=np.uint32).view(np.int32))
             assert r.numel() % cfg.num_roots == 0
@@ -331,6 +352,105 @@ class HipSampler:
         self._pending = pend
         return pend
 
+    def sample_multi_async(self, cfg: SamplerConfig, sizes, *, roots=None, serial_base: Optional[int] = None):
+        """ONE sampler call for several consecutive batches (sg_sample_multi): batch i takes the next ``sizes[i]`` root
+        groups of the shuffled target list behind batch i - 1 (or of ``roots``).  Subgraph for subgraph the result equals
+        ``len(sizes)`` separate ``sample_async`` calls -- the draws are keyed on the subgraph's serial number -- but the
+        pipeline's four dependent launches are paid once.  The root cursor must not wrap inside the call: the sizes
+        have to fit what is left of the target list (a trainer's epoch plan guarantees that)."""
+        if self._pending is not None:
+            raise RuntimeError("a sample is already in flight; call finish() first")
+        sizes = [int(x) for x in sizes]
+        if not (1 <= len(sizes) <= _lib.MAX_BATCHES_PER_CALL) or min(sizes) < 1:
+            raise ValueError(f"1..{_lib.MAX_BATCHES_PER_CALL} non-empty batches per call, got {sizes}")
+        pend = _Pending()
+        pend.cfg, pend.roots_dev, pend.sizes, pend.P = cfg, None, sizes, sum(sizes)
+        if roots is not None:
+            r = torch.as_tensor(np.ascontiguousarray(np.asarray(roots).reshape(-1), dtype=np.uint32).view(np.int32))
+            if r.numel() != pend.P * cfg.num_roots:
+                raise ValueError(f"{r.numel()} roots for batches of {sizes} x {cfg.num_roots}")
+            pend.roots_dev = r.to(self.device)
+            pend.root_start = 0
+            pend.serial = 0 if serial_base is None else serial_base
+        else:
+            left = (self.num_nodes_target() - self.get_idx_root()) // cfg.num_roots
+            if pend.P > left:
+                raise ValueError(f"batches of {sizes} subgraphs do not fit the {left} root groups left before the cursor wraps")
+            pend.root_start, got, pend.serial = self.next_roots(cfg.num_roots, pend.P)
+            assert got == pend.P
+            if serial_base is not None:
+                pend.serial = serial_base
+        with torch.cuda.device(self.device):
+            self._launch(pend)
+        self._pending = pend
+        return pend
+
+    def _wrap(self, cfg, b, cnt, P, call=None) -> DeviceBatch:
+        n, e = int(cnt.n_tot), int(cnt.e_tot)
+        counts = dict(n_tot=n, e_tot=e, max_subg_nodes=cnt.max_subg_nodes,
+                      max_subg_edges=cnt.max_subg_edges, slots_scanned=int(cnt.slots_scanned),
+                      frontier_reads=int(cnt.frontier_reads), frontier_nodes=int(cnt.frontier_nodes),
+                      sample_kernel_ms=float(cnt.sample_kernel_ms),
+                      relocate_kernel_ms=float(cnt.relocate_kernel_ms))
+        if call is not None:           # (batch `index` of a `batches`-batch call: the call's kernel times sit on index 0)
+            counts.update(call_id=call[0], call_index=call[1], call_batches=call[2])
+        return DeviceBatch(
+            node=b["node"][:n], indptr=b["indptr"][:n + 1], indices=b["indices"][:e],
+            edge_id=b["edge_id"][:e], target=b["target"][:P * cfg.num_roots],
+            subg_node_off=b["subg_node_off"], subg_edge_off=b["subg_edge_off"], ppr=b["ppr"][:n],
+            hop=b["hop"][:n] if b["hop"] is not None else None,
+            drnl=b["drnl"][:n] if b["drnl"] is not None else None,
+            num_subgraphs=P, num_roots=cfg.num_roots, counts=counts)
+
+    def finish_multi(self, on_retry=None) -> List[DeviceBatch]:
+        """Wait for the in-flight multi-batch call; returns its batches in order.  A capacity overflow of any batch grows
+        the caps and re-runs the WHOLE call with the same roots / serials."""
+        pend = self._pending
+        if pend is None or not getattr(pend, "sizes", None):
+            raise RuntimeError("no multi-batch sample in flight")
+        S = len(pend.sizes)
+        cnts = (SgBatchCounts * S)()
+        for _ in range(12):
+            rc = self._lib.sg_sample_finish_multi(self._h, S, cnts)
+            if rc == _lib.SG_OK:
+                break
+            if rc != _lib.SG_ERR_CAPACITY:
+                self._pending = None
+                check(rc)
+            ov = 0
+            for c_ in cnts:
+                ov |= c_.overflow
+            if ov & 1:
+                self.set_caps(cap_subg_nodes=min(self.num_nodes(), max(2 * max(c_.max_subg_nodes for c_ in cnts), 1024)))
+            if ov & 2:
+                m = max(c_.max_subg_edges for c_ in cnts)
+                self.set_caps(cap_subg_edges=m + m // 4 + 64)
+            cap_e = cap_n = None
+            if (ov & 8) and not (ov & 3):
+                cap_e = [int(c_.e_tot) + int(c_.e_tot) // 8 + 64 if (c_.overflow & 8) else None for c_ in cnts]
+            if (ov & 4) and not (ov & 3):
+                cap_n = [int(c_.n_tot) + int(c_.n_tot) // 8 + 64 if (c_.overflow & 4) else None for c_ in cnts]
+            if on_retry is not None:
+                on_retry()
+            with torch.cuda.device(self.device):
+                self._launch(pend, cap_e, cap_n)
+        else:
+            self._pending = None
+            raise CapacityError(_lib.SG_ERR_CAPACITY, "sampler capacity did not converge")
+        self._pending = None
+        k = self._cfg_key(pend.cfg)
+        self._call_serial = getattr(self, "_call_serial", 0) + 1
+        out = []
+        for i, (Pi, b, cnt) in enumerate(zip(pend.sizes, pend.bufs, cnts)):
+            he, hn = self._hwm.get(k, (0, 0))
+            self._hwm[k] = (max(he, -(-int(cnt.e_tot) // Pi)), max(hn, -(-int(cnt.n_tot) // Pi)))
+            out.append(self._wrap(pend.cfg, b, cnt, Pi, call=(self._call_serial, i, S)))
+        return out
+
+    def sample_multi(self, cfg: SamplerConfig, sizes, *, roots=None, serial_base: Optional[int] = None) -> List[DeviceBatch]:
+        self.sample_multi_async(cfg, sizes, roots=roots, serial_base=serial_base)
+        return self.finish_multi()
+
     def finish(self, on_retry=None) -> DeviceBatch:
         """Wait for the in-flight call and wrap the outputs.  Capacity overflows
         are handled here by growing and re-running the same roots / serials;
@@ -340,6 +460,8 @@ class HipSampler:
         pend = self._pending
         if pend is None:
             raise RuntimeError("no sample in flight")
+        if getattr(pend, "sizes", None):
+            raise RuntimeError("a multi-batch call is in flight: finish_multi()")
         cnt = SgBatchCounts()
         for _ in range(12):
             rc = self._lib.sg_sample_finish(self._h, C.byref(cnt))
@@ -372,19 +494,7 @@ class HipSampler:
             k = self._cfg_key(pend.cfg)
             he, hn = self._hwm.get(k, (0, 0))
             self._hwm[k] = (max(he, -(-e // P)), max(hn, -(-n // P)))
-        b = pend.bufs
-        return DeviceBatch(
-            node=b["node"][:n], indptr=b["indptr"][:n + 1], indices=b["indices"][:e],
-            edge_id=b["edge_id"][:e], target=b["target"][:P * pend.cfg.num_roots],
-            subg_node_off=b["subg_node_off"], subg_edge_off=b["subg_edge_off"], ppr=b["ppr"][:n],
-            hop=b["hop"][:n] if b["hop"] is not None else None,
-            drnl=b["drnl"][:n] if b["drnl"] is not None else None,
-            num_subgraphs=P, num_roots=pend.cfg.num_roots,
-            counts=dict(n_tot=n, e_tot=e, max_subg_nodes=cnt.max_subg_nodes,
-                        max_subg_edges=cnt.max_subg_edges, slots_scanned=int(cnt.slots_scanned),
-                        frontier_reads=int(cnt.frontier_reads), frontier_nodes=int(cnt.frontier_nodes),
-                        sample_kernel_ms=float(cnt.sample_kernel_ms),
-                        relocate_kernel_ms=float(cnt.relocate_kernel_ms)))
+        return self._wrap(pend.cfg, pend.bufs, cnt, P)
 
     def sample(self, cfg: SamplerConfig, max_subgraphs: int = 0, *, roots=None,
                serial_base: Optional[int] = None) -> DeviceBatch:
@@ -666,7 +776,7 @@ class ParallelSampler:
                 vec._fill_targets_only(self._targets[start:start + P * num_roots], num_roots)
             else:
                 pend = _Pending()
-                pend.cfg, pend.P, pend.root_start, pend.roots_dev = cfg, P, start, None
+                pend.cfg, pend.P, pend.root_start, pend.roots_dev, pend.sizes = cfg, P, start, None, None
                 # every branch draws from its own serial range
                 pend.serial = serial + i * (1 << 40)
                 with torch.cuda.device(self._hip.device):

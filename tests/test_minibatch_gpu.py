@@ -72,6 +72,37 @@ def test_prefetch_does_not_change_batches():
         assert torch.equal(x.adj_ens[0].indices, y.adj_ens[0].indices) and torch.equal(x.feat_ens[0], y.feat_ens[0])
 
 
+@pytest.mark.parametrize("prefetch", [True, False])
+@pytest.mark.parametrize("S", [3, 4, 16])
+def test_multi_step_sampler_calls_do_not_change_batches(S, prefetch):
+    """``steps_per_call`` > 1: one sg_sample_multi call covers the next S steps (7 steps = calls of 3 + 3 + 1, 4 + 3,
+    or one of 7) -- every step gets exactly the batch it gets with one call per step, over two epochs, and a model
+    trained on them takes the same steps."""
+    a = _setup(prefetch=prefetch)[0]
+    b = _setup(prefetch=prefetch)[0]
+    b.steps_per_call = S
+    for epoch in range(2):
+        if epoch:
+            a.shuffle_entity(0, perm=np.arange(103)[::-1].copy()); b.shuffle_entity(0, perm=np.arange(103)[::-1].copy())
+        xa, xb = _epoch(a), _epoch(b)
+        assert [x.batch_size for x in xb] == [16] * 6 + [7]
+        for x, y in zip(xa, xb):
+            assert torch.equal(x.adj_ens[0].indptr, y.adj_ens[0].indptr) and torch.equal(x.adj_ens[0].indices, y.adj_ens[0].indices)
+            assert torch.equal(x.idx_raw[0], y.idx_raw[0]) and torch.equal(x.target_ens[0], y.target_ens[0])
+            assert torch.equal(x.feat_ens[0], y.feat_ens[0]) and torch.equal(x.label, y.label)
+            assert torch.equal(x.size_subg_ens[0], y.size_subg_ens[0])
+            assert x.adj_ens[0].max_subg_nodes == y.adj_ens[0].max_subg_nodes
+    # an epoch abandoned in the middle of a call: the unconsumed batches are dropped and the cursor is put back
+    b.shuffle_entity(0, perm=np.arange(103))
+    first = b.one_batch(0, ret_raw_idx=True)
+    b.shuffle_entity(0, perm=np.arange(103))
+    again = _epoch(b)
+    assert [x.batch_size for x in again] == [16] * 6 + [7]
+    roots_of = lambda x: x.idx_raw[0][x.target_ens[0].long()]
+    assert torch.equal(roots_of(again[0]), roots_of(first))            # (new draws -- later serials -- around the same roots)
+    assert b.graph_sampler[0].get_idx_root() == 0
+
+
 def test_rank_sharding_covers_the_global_batches():
     full = _epoch(_setup(prefetch=False, batch=16)[0])
     r0 = _epoch(_setup(prefetch=False, rank=0, world=2, batch=16)[0])

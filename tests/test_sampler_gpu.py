@@ -114,6 +114,52 @@ def test_khop_matches_oracle(depth, budget, self_e, aug):
     assert hs.get_idx_root() == 0          # cursor wrapped (ParallelSampler.cpp:462)
 
 
+@pytest.mark.parametrize("depth,budget,self_e,aug,method", [(2, 20, False, (), "khop"), (2, 5, True, ("hops",), "khop"),
+                                                             (3, 4, True, ("hops",), "khop"), (0, 0, False, ("hops", "pprs"), "ppr")])
+def test_multi_step_call_equals_separate_calls_and_the_oracle(depth, budget, self_e, aug, method):
+    """sg_sample_multi: ONE call for the batches of several steps -- 300 + 200 + 1 + 199 roots through
+    the sequential cursor -- writes, batch for batch, exactly what four sg_sample calls write (the Philox draws are keyed
+    on the subgraph's serial number, not on the call), and every batch equals the oracle's with the matching serial
+    base.  The cursor then wraps like the reference's (ParallelSampler.cpp:462)."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    indptr, indices = make_graph_numpy(20000, 14, seed=5)
+    roots = np.random.default_rng(9).permutation(20000)[:700].astype(np.uint32)
+    sizes = (300, 200, 1, 199)
+    okw = dict(method=method, add_self_edge=self_e, aug=aug, seed=1234, num_threads=8)
+    if method == "khop":
+        cfg = SamplerConfig(method="khop", depth=depth, budget=budget, add_self_edge=self_e, aug=aug)
+        okw.update(depth=depth, budget=budget)
+    else:
+        cfg = SamplerConfig(method="ppr", k=12, threshold=0.0, add_self_edge=self_e, aug=aug)
+        tab = so.ppr_approximate(indptr, indices, roots, k=12, alpha=0.85, epsilon=1e-4, num_threads=8)
+        okw.update(k=12, threshold=0.0, ppr=tab)
+    multi, single = _make(indptr, indices, seed=1234), _make(indptr, indices, seed=1234)
+    for hs in (multi, single):
+        hs.shuffle_targets(roots)
+        if method == "ppr":
+            hs.set_ppr(roots, tab.len, tab.neigh, tab.score)
+    got = multi.sample_multi(cfg, sizes)
+    assert [b.num_subgraphs for b in got] == list(sizes) and multi.get_idx_root() == 0
+    assert [b.counts["call_index"] for b in got] == [0, 1, 2, 3] and len({b.counts["call_id"] for b in got}) == 1
+    lo = 0
+    for i, P in enumerate(sizes):
+        one = single.sample(cfg, P)
+        a, c = got[i].to_host(), one.to_host()
+        for k in a:
+            assert np.array_equal(a[k], c[k]), (i, k)
+        assert got[i].counts["n_tot"] == one.counts["n_tot"] and got[i].counts["max_subg_nodes"] == one.counts["max_subg_nodes"]
+        ref = so.sample_batch(indptr, indices, roots[lo:lo + P], serial_base=lo, **okw)
+        _cmp_batch(ref, got[i], aug, ("multi", method, i))
+        lo += P
+    # too much for what is left of the root list: refused before anything is reserved
+    multi.next_roots(1, 650)
+    with pytest.raises(ValueError):
+        multi.sample_multi(cfg, (40, 40))
+    assert multi.get_idx_root() == 650
+
+
 def test_link_task_two_roots_drnl():
     from oracle import sampler_oracle as so
     from shadow_gnn_amd.sampler import SamplerConfig
