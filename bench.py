@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--sampler-steps-per-call", type=int, default=4,
                     help="steps whose batches ONE sampler call produces (sg_sample_multi; bit-identical batches, the pipeline's "
                          "four dependent launches paid once per call; 1 = a call per step)")
+    ap.add_argument("--dense-top-backward", action="store_true",
+                    help="run the top layer's backward pass on every row (streams the zero rows of the read-out gradient) instead "
+                         "of the exact row-sparse form")
     ap.add_argument("--no-tail", action="store_true", help="skip the separately reported target-only-tail steps "
                     "(profiling runs: keeps the kernel trace to the timed configuration)")
     ap.add_argument("--prune-tail", action="store_true",
@@ -256,7 +259,7 @@ def main():
     feat_full = torch.randn(N, F0, generator=g, device=dev)
     label_full = torch.randint(0, C, (N,), generator=g, device=dev)
     TAIL_STEPS, TAIL_WARMUP = 10, 3      # extra steps for the separately reported target-only-tail variant
-    need = B * world * (K + W + 2 + TAIL_STEPS + TAIL_WARMUP + 12)
+    need = B * world * (K + W + 2 + TAIL_STEPS + TAIL_WARMUP + 12 + 48 + 16 * 16)     # (+ instrumented steps, + a prefetched multi-step call, + the sampler-only loops)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy()
     roots_all = np.resize(perm, need).astype(np.int64)
     aug = tuple(wl["aug"])
@@ -289,6 +292,11 @@ def main():
     model.grad_sync = sdist.GradSync(model.parameters(), world_size=world)
     from shadow_gnn_amd.optim import FlatAdam
     model.optimizer = FlatAdam(model.grad_sync, lr=wl["lr"])      # clip + Adam on the flat gradient / parameter buffers
+    # node task, residue none + centre pooling, GraphSAGE: the read-out gradient lives on the roots' rows -- the top layer's
+    # backward pass runs on the rows it is non-zero on (exact; tail.TopBackwardPlan, --dense-top-backward switches it off)
+    if args.dense_top_backward:
+        ops.SPARSE_TOP_BWD = False
+    mb.top_backward_plan = bool(ops.SPARSE_TOP_BWD and wl["aggr"] == "sage" and model._tail_prunable(0) and not args.prune_tail)
     model.prune_tail = bool(args.prune_tail)
     if args.prune_tail and model._tail_prunable(0):
         mb.tail_plan_layers = wl["layers"]
@@ -330,6 +338,8 @@ def main():
     #      on) and around the sampler's kernels: the live durations behind `roofline` / `kernels`.  Kept out of the timed
     #      region: ~60 event pairs per step cost host time, and the per-kernel timing needs the kernel-by-kernel call path
     K_prof = min(K, 10)              # (every rank takes them: the steps carry the gradient all-reduce)
+    if S_call > 1 and K >= 10:       # ... enough of them to see whole multi-step sampler calls (their kernel times sit on the call)
+        K_prof = max(K_prof, 3 * S_call)
     hs.set_profiling(True)
     timer = ops.KernelTimer()
     prof_counts = []
@@ -393,6 +403,30 @@ def main():
         finally:
             model.prune_tail = False
             mb.tail_plan_layers = 0
+
+    # ---- the same step with the top layer's backward pass on every row (the dense kernels stream the read-out gradient's
+    #      zero rows): what `value` would be without the exact row-sparse form -- reported, never part of `value`
+    dense_top_info = None
+    if world == 1 and mb.top_backward_plan and not args.no_tail:
+        try:
+            ops.SPARSE_TOP_BWD, mb.top_backward_plan = False, False
+            for _ in range(TAIL_WARMUP):
+                one_step()
+            barrier()
+            tt0 = time.perf_counter()
+            tn = 0.0
+            for _ in range(TAIL_STEPS):
+                c, _r = one_step()
+                tn += c["n_tot"]
+            barrier()
+            tdt = time.perf_counter() - tt0
+            dense_top_info = dict(steps=TAIL_STEPS, ms_per_step=round(tdt / TAIL_STEPS * 1e3, 4), sampled_nodes_per_sec=round(tn / tdt, 1),
+                                  note="top layer's backward on every row (SHADOW_SPARSE_TOP_BWD=0 / --dense-top-backward): identical "
+                                       "gradients, the transposed SpMM + K = 2F GEMM + weight-gradient kernels stream 99.6 % zero rows")
+        except Exception as ex:
+            dense_top_info = dict(error=f"{type(ex).__name__}: {ex}"[:300])
+        finally:
+            ops.SPARSE_TOP_BWD, mb.top_backward_plan = True, True
 
     # ---- sampler-only rate (same kernels, no model), a few calls
     scfg = mb.sampler_cfg
@@ -593,6 +627,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "train_steps_per_sec": round(K / dt, 3),
         "target_only_tail": tail_info,
+        "dense_top_backward": dense_top_info,
         "cpu_baseline_train_step": cb_step,
         "sampler_only_nodes_per_sec": round(sampler_rate, 1),
         "sampler_alone": sampler_alone,
@@ -600,7 +635,7 @@ def main():
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
                                f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",
                    "global_batch": B * world, "parallelism": f"dp{world}", "prune_tail": bool(args.prune_tail),
-                   "sampler_steps_per_call": S_call,
+                   "sampler_steps_per_call": S_call, "sparse_top_backward": bool(mb.top_backward_plan),
                    "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4),
                    "ppr_preproc": ppr_info},
         # `roofline` leads with what BASELINE.json's north_star asks for: the HBM fraction of the k-hop-sample + feature

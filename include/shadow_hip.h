@@ -610,6 +610,10 @@ size_t sl_prof_dump(char *buf, size_t cap);
  * precision before they are rounded); `step` counts from 1.  Two launches (norm partials, update), deterministic.  d_scratch:
  * sl_clip_adam_scratch_floats() floats; its last float receives ||g|| before clipping.  Buffers 16-byte aligned.     */
 uint32_t sl_clip_adam_scratch_floats(void);
+/* Zeros into the F-wide column slices d_a and d_b (either may be NULL) of a buffer with row pitch ld: the rows around the
+ * few a row-sparse backward pass fills itself (F % 4 == 0, ld % 4 == 0, 16-byte aligned slices). */
+int sl_zero_slices(float *d_a, float *d_b, int64_t ld, uint32_t n, uint32_t F, void *stream);
+
 int sl_clip_adam(float *d_param, float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, uint64_t n, double lr, double beta1,
                  double beta2, double eps, uint32_t step, float max_norm, float *d_scratch, void *stream);
 

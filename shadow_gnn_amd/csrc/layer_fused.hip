@@ -79,6 +79,23 @@ __global__ void __launch_bounds__(256) zero_slices_kernel(float *a, float *b, in
   }
 }
 
+}  // namespace
+
+// Zeros into the F-wide column slices a and b (may be NULL) of a pitched buffer: what a caller that fills a few rows of a
+// [dZs | . | dZn] buffer itself (the row-sparse top-layer backward of ops._SageDense) clears around them.
+extern "C" int sl_zero_slices(float *d_a, float *d_b, int64_t ld, uint32_t n, uint32_t F, void *stream) {
+  if (n == 0 || F == 0 || (!d_a && !d_b)) return SG_OK;
+  if ((F & 3) || (ld & 3) || (reinterpret_cast<uintptr_t>(d_a) & 15) || (reinterpret_cast<uintptr_t>(d_b) & 15))
+    return set_error(SG_ERR_INVALID, "sl_zero_slices: needs F %% 4 == 0, ld %% 4 == 0 and 16-byte aligned slices");
+  float *a = d_a ? d_a : d_b, *b = d_b ? d_b : d_a;          // (one slice: cleared twice -- idempotent)
+  SHD_PROF_FMT(2.0 * 4.0 * n * F, 0, stream, "zero_slices_F%u", F);
+  hipLaunchKernelGGL(zero_slices_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, a, b, ld, n, F);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+namespace {
+
 // the GEMM-epilogue forms (gemm_fused.hip) take 16-byte aligned operands with row pitches of whole float4s
 bool fused_epilogue_ok(uint32_t Fout, uint32_t Fin, const float *A0, int64_t lda0, const float *A1, int64_t lda1) {
   auto ok = [](const float *p, int64_t ld) { return !p || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0); };

@@ -207,6 +207,9 @@ class MinibatchShallowExtractor:
         # > 0: every batch carries a target-only-tail plan for a model of that many layers (DeepGNN.prune_tail)
         self.tail_plan_layers = 0
         self.tail_plan_square = False      # True for GAT stacks: prepare the square form of every level instead
+        # True: every batch carries the row sets of the row-sparse top-layer backward (tail.TopBackwardPlan; node tasks whose
+        # read-out takes the roots' rows of the last GraphSAGE layer), built on the prefetch stream like the tail plan
+        self.top_backward_plan = False
         # (priority -1 = high: when the deferred sampler call meets the GEMMs of the step, its workgroups take the CU slots
         #  as they free up instead of queueing behind the GEMM's grid; SHADOW_PREFETCH_PRIORITY=0 for a normal stream)
         prio = int(os.environ.get("SHADOW_PREFETCH_PRIORITY", "-1"))
@@ -420,6 +423,22 @@ class MinibatchShallowExtractor:
                 t.record_stream(main)
         return levels
 
+    def _top_plan(self, subgs, adj):
+        """tail.TopBackwardPlan of this batch, on the prefetch stream (its two host syncs wait for the side stream only);
+        stream bookkeeping as in _tail_plan."""
+        from . import tail
+        if self._side is None:
+            return tail.TopBackwardPlan(adj, subgs.target)
+        main = torch.cuda.current_stream(self.device)
+        for t in (subgs.indptr, subgs.indices, subgs.target):
+            t.record_stream(main)
+        with torch.cuda.stream(self._side):
+            plan = tail.TopBackwardPlan(adj, subgs.target)
+        main.wait_stream(self._side)
+        for t in plan.tensors():
+            t.record_stream(main)
+        return plan
+
     def _launch(self, mode):
         """Issue the sampler call of the next un-launched step (nothing to issue for an empty share)."""
         t = self._launched[mode]
@@ -554,6 +573,8 @@ class MinibatchShallowExtractor:
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
                             subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
+        if self.top_backward_plan and self.tail_plan_layers == 0 and adj.n >= ops.SPARSE_TOP_BWD_MIN_ROWS and ops.SPARSE_TOP_BWD:
+            subgs.target._shd_top_plan = self._top_plan(subgs, adj)
         if not last and self.prefetch:
             if self.defer_prefetch:
                 # ... issued when the consumer reaches ops.fire_deferred, so that it stays off the HBM-bound head of the step

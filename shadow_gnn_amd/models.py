@@ -180,6 +180,8 @@ class DeepGNN(nn.Module):
         emb_subg_ens = []
         for i, feat in enumerate(feat_ens):
             tgt = torch.as_tensor(target_ens[i], device=feat.device).long()
+            if getattr(target_ens[i], "_shd_top_plan", None) is not None:      # (minibatch: row sets of the row-sparse top-layer backward)
+                tgt._shd_top_plan = target_ens[i]._shd_top_plan
             if self.dim_label_in > 0 and mode == TRAIN:
                 feat = ops.dense_rows(feat)
                 feat[tgt, -self.dim_label_in:] = 0            # a root never sees its own label (models.py:181-182)

@@ -545,7 +545,8 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
     return out if out2 is None else (out, out2)
 
 
-def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None, row_idx=None):
+def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None, row_idx=None,
+            dz0_amax=None):
     """``douts``: the gradient(s) autograd handed over -- (dout,) or, in dual mode, (dout_plain, dout_dropped) with
     None for an output nothing consumed.  ``dz_out``: optional preallocated dZ destinations (column slices of a
     wider buffer are fine).  ``row_idx`` (int32 [m]): the gradients are compact [m, F] and belong to those rows (a read-out
@@ -571,7 +572,8 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
     alloc = torch.zeros_like if row_idx is not None else torch.empty_like
     dZs = [((dz_out[i] if dz_out is not None and dz_out[i] is not None else alloc(z)) if nd else None)
            for i, (z, nd) in enumerate(zip(Zs, need_dz))]
-    assert row_idx is None or dz_out is None
+    # (row_idx together with dz_out: the caller has cleared the rows outside row_idx itself, see sl_zero_slices;
+    #  dz0_amax [n]: receives max |dZ_0[row]| of the rows written -- the caller clears it first when row_idx is given)
     dsc = torch.empty(nb, F, dtype=torch.float32, device=dev)
     dof = torch.empty(nb, F, dtype=torch.float32, device=dev)
     dbi = torch.empty(nb, F, dtype=torch.float32, device=dev) if want_dbias else None
@@ -586,7 +588,8 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
                                           dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
                                           partial.data_ptr(), float(drop[0]), int(drop[1]),
                                           dout2.data_ptr() if dout2 is not None else None,
-                                          dout2.stride(0) if dout2 is not None else 0, None,
+                                          dout2.stride(0) if dout2 is not None else 0,
+                                          dz0_amax.data_ptr() if dz0_amax is not None else None,
                                           row_idx.data_ptr() if row_idx is not None else None, _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
@@ -1058,13 +1061,19 @@ class RootsLink:
     def __init__(self):
         self.published = self.filled = False
         self.rows32 = self.grad = self.dummy = None
+        self.csr = None              # the batch CSR of the publishing node (a TopBackwardPlan is built from it when none came along)
+        self.plan = None             # tail.TopBackwardPlan of the selected rows: the node's backward may then run row-sparse
 
     def release(self):
         self.filled = False
-        self.rows32 = self.grad = self.dummy = None
+        self.rows32 = self.grad = self.dummy = self.plan = None
 
 
 ROOTS_SPARSE_GRAD = os.environ.get("SHADOW_ROOTS_SPARSE_GRAD", "1") != "0"
+# The top GraphSAGE layer's backward pass on the rows its gradient is non-zero on (tail.TopBackwardPlan): exact, see there.
+# Off: the dense kernels stream the 99.6 %-zero gradient (SHADOW_SPARSE_TOP_BWD=0; bench.py reports that step time beside `value`).
+SPARSE_TOP_BWD = os.environ.get("SHADOW_SPARSE_TOP_BWD", "1") != "0"
+SPARSE_TOP_BWD_MIN_ROWS = 32768      # below: a dozen small launches cost more host time than the three dense kernels cost GPU time
 
 
 class _SelectRoots(torch.autograd.Function):
@@ -1073,6 +1082,15 @@ class _SelectRoots(torch.autograd.Function):
         ctx.link, ctx.n, ctx.F = link, int(f.shape[0]), int(f.shape[1])
         ctx.save_for_backward(rows)
         ctx.set_materialize_grads(False)
+        # the row sets of the row-sparse top-layer backward: handed over with the rows (built by the minibatch extractor on its
+        # prefetch stream) or, for hand-made batches, built here (two host syncs)
+        ctx.plan = None
+        if SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None:
+            plan = getattr(rows, "_shd_top_plan", None)
+            if plan is None or not plan.matches(link.csr, int(rows.numel())):
+                from . import tail
+                plan = tail.TopBackwardPlan(link.csr, rows)
+            ctx.plan = plan
         return f.index_select(0, rows)
 
     @staticmethod
@@ -1084,6 +1102,7 @@ class _SelectRoots(torch.autograd.Function):
         if link is not None and link.published:
             link.rows32 = rows.to(torch.int32)
             link.grad = _f32c(dsel).contiguous()
+            link.plan = ctx.plan
             link.dummy = torch.empty(1, 1, dtype=torch.float32, device=dsel.device).expand(ctx.n, ctx.F)
             link.filled = True
             return link.dummy, None, None
@@ -1153,6 +1172,7 @@ class _SageDense(torch.autograd.Function):
         ctx.link_roots = None
         if link_roots is not None and one_call and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256:
             link_roots.published = True
+            link_roots.csr = c
             ctx.link_roots = link_roots
         ctx.link_up = None
         # (published only when THIS node's backward will take the one-call entry -- the only consumer of the dZ the layer
@@ -1216,6 +1236,15 @@ class _SageDense(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         up, down = ctx.link_up, ctx.link_down
         dz_ready = up is not None and up.filled
+        lr0 = ctx.link_roots
+        if (SPARSE_TOP_BWD and not dz_ready and lr0 is not None and lr0.filled and lr0.plan is not None and down is not None and want_dx
+                and down.Zs.shape == (n, Fi) and Fo % 32 == 0 and Fi % 4 == 0 and float(drop[0]) == 0.0 and n >= SPARSE_TOP_BWD_MIN_ROWS
+                and lr0.plan.matches(ctx.adj.csr, int(lr0.rows32.numel()))):
+            g = dout[0] if isinstance(dout, (tuple, list)) else dout
+            if g is None or g.data_ptr() != lr0.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
+                raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
+                                   "(its gradient is not the placeholder); set SHADOW_ROOTS_SPARSE_GRAD=0")
+            return _SageDense._sparse_top_backward(ctx, lr0, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b)
         d0 = d1 = dout_rows = None
         if dz_ready:
             g = dout[0] if isinstance(dout, (tuple, list)) else dout
@@ -1283,6 +1312,50 @@ class _SageDense(torch.autograd.Function):
             dX = down.dummy
             _SageDense.chained_calls += 1
         return dX, dWs, dWn, dbi, dsc, dof
+
+    sparse_top_calls = 0     # backward passes of a top layer that ran on the rows R u N(R) only
+
+    @staticmethod
+    def _sparse_top_backward(ctx, lr, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b):
+        """The top layer of a GraphSAGE stack under a row-selecting read-out: its output gradient lives on the roots R
+        (``lr.grad`` [P, Fo]), so dZs / dZn are zero outside R, dWs = dZs[R]^T X[R], dWn = dZn[R]^T (A X)[R], and the input
+        gradient dX = dZs Ws + A^T (dZn Wn) is zero outside T = R u N(R) (tail.TopBackwardPlan).  The layer BELOW is chained
+        (ChainLink): its act_norm backward runs on the rows T of dX -- through its fused output dropout mask -- and leaves
+        dZs / dZn (zero elsewhere), the parameter gradients and the row maxima where sl_sage_bwd_chain's epilogue would.
+        Replaces, on ~7 % of the rows, the transposed SpMM + K = 2F GEMM-epilogue + weight-gradient kernels that otherwise
+        stream the zeros (0.99 ms of the 7.4 ms products step); same gradients (tests/test_layers_gpu.py::
+        test_sparse_top_layer_backward_equals_dense)."""
+        lib = _lib.load()
+        n, Fo = Zs.shape
+        Fi = X.shape[1]
+        dev = Zs.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        plan = lr.plan
+        lv = plan.level
+        R = lv.rows_full
+        (dZsR, dZnR), dsc, dof, dbi = _an_bwd([Zs.index_select(0, R), Zn.index_select(0, R)], biases, acts, sc, of, Fo, 1.0, (lr.grad,),
+                                              [True, True], any(has_b), (0.0, 0))
+        dWs = dZsR.t() @ X.index_select(0, R)
+        dWn = dZnR.t() @ AX.index_select(0, R)
+        # dX on the rows T: the self term lands on the roots, the neighbour term is the rectangular transposed aggregate
+        ew, rs, cs = lv.norm(ctx.adj)
+        ti, tx, tp = lv.transposed
+        dXT = _spmm_raw(ti, tx, ew, tp if ew is not None else None, cs, rs, (dZnR @ Wn).contiguous(), lv.m_in)
+        dXT.index_add_(0, lv.self_idx, dZsR @ Ws)            # (the roots are distinct rows: one add per target)
+        # the layer below: act_norm backward on the rows T of its output gradient, everything else of [dZs | . | dZn] cleared
+        down.buf = torch.empty(n, 3 * Fi, **f32)
+        check(lib.sl_zero_slices(down.buf.data_ptr(), down.buf.data_ptr() + 8 * Fi, 3 * Fi, n, Fi, _stream(Zs)))
+        down.amax = torch.zeros(n, **f32)
+        _dz, down.dsc, down.dof, down.dbi = _an_bwd([down.Zs, down.Zn], down.biases, (down.act, down.act), down.sc, down.of, Fi, 1.0,
+                                                   (dXT,), [True, True], any(b is not None for b in down.biases), down.drop,
+                                                   dz_out=[down.buf[:, :Fi], down.buf[:, 2 * Fi:]], row_idx=plan.T32, dz0_amax=down.amax)
+        down.partial = None
+        lr.release()
+        down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)
+        down.filled = True
+        _SageDense.chained_calls += 1
+        _SageDense.sparse_top_calls += 1
+        return down.dummy, dWs, dWn, dbi, dsc, dof
 
     @staticmethod
     def backward(ctx, *dout):

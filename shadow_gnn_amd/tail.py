@@ -194,3 +194,39 @@ def rect_gather_spmm(X: torch.Tensor, level: RectLevel, full_adj: "ops.NormAdj")
     """Returns (X[level.self_idx], A[level rows, :] @ X) under the normalisation of ``full_adj``."""
     ew, rs, cs = level.norm(full_adj)
     return _RectGatherSpMM.apply(X, level, ew, rs, cs)
+
+
+class TopBackwardPlan:
+    """Row sets of the EXACT row-sparse backward pass of the top GraphSAGE layer (ops._SageDense._sparse_top_backward).
+
+    Residue 'none' + centre pooling on a node task reads one row per subgraph of the last layer's output
+    (shaDow/layers.py:159-163), so the gradient of that output is zero outside the roots R, the top layer's dZs / dZn are
+    zero outside R, and its input gradient  dX = dZs Ws + A^T (dZn Wn)  is zero outside  T = R u N(R)  (the roots and their
+    in-subgraph neighbours: ~7 % of a depth-2 k-hop batch).  The forward pass is untouched -- every row of every layer is
+    computed, as in the reference; the backward pass multiplies by the zeros the reference's autograd multiplies by, or skips
+    them: the same gradients.  ``level``: the rows R of the batch adjacency with columns renumbered into T (transposed
+    form ready); ``T32``: T as sorted int32 batch-level row ids.  Two host syncs (array sizes): the minibatch extractor builds the
+    plan on its prefetch stream."""
+
+    def __init__(self, csr: "ops.DeviceCSR", targets: torch.Tensor):
+        n, dev = csr.n, csr.device
+        rows = torch.as_tensor(targets, device=dev).long().reshape(-1)
+        ip, er, pos = _select_rows(csr.indptr, rows)
+        cols = csr.indices[pos].long()
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        mask[rows] = True
+        mask[cols] = True
+        in_ids = mask.nonzero().reshape(-1)              # (host sync) ascending
+        newid = torch.cumsum(mask, 0) - 1
+        self.level = RectLevel(ip.to(torch.int32), newid[cols].to(torch.int32), er, pos, rows, in_ids, newid[rows], in_ids.numel())
+        self.level.transposed                              # (built here: the backward pass must not sort)
+        self.T32 = in_ids.to(torch.int32)
+        self.n = n
+        self.num_roots = int(rows.numel())
+        self._indptr_ptr = csr.indptr.data_ptr()
+
+    def matches(self, csr: "ops.DeviceCSR", num_roots: int) -> bool:
+        return csr.n == self.n and csr.indptr.data_ptr() == self._indptr_ptr and num_roots == self.num_roots
+
+    def tensors(self):
+        return self.level.tensors() + [self.T32]
