@@ -461,7 +461,7 @@ int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, uint32_t 
                 int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale,
                 const float *d_offset, int act, float drop_p, uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs,
                 float *d_Zn, float *d_out, float *d_out_dropped, const float *d_x_amax, float *d_out_amax,
-                void *d_pack, int x_pad_zero, void *stream);
+                void *d_pack, int x_pad_zero, float *d_row_stats, void *stream);
 int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
                 const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws, const float *d_bs,
                 const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale, const float *d_offset, int act,
@@ -521,7 +521,10 @@ int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, co
                          uint32_t M, uint32_t N, uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                          const int *act, const float *d_scale, const float *d_offset, float out_scale, float *d_out, int64_t ldo,
                          float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped, float *d_out_amax,
-                         void *stream);
+                         float *d_row_stats, void *stream);
+/* d_row_stats (may be NULL; sl_gemm_act_norm_fwd writes, sl_gemm_an_bwd / sl_sage_below.stats read): [M, 2 nb] floats, per row and
+ * branch b the pair (mean, 1 / sqrt(var + eps)) of act(Z_b + bias_b) that `_f_norm_feat` (layers.py:334-336) normalises with -- 16
+ * bytes per row that spare the backward epilogue two of its four row reductions per branch.                                   */
 /* Plain products on the same kernel: C_b = A_b . W_b^T + bias_b for b < nb <= 2 in ONE launch (images:
  * sl_gemm_act_norm_pack / _pack_b2; the two products may share A -- GAT's self and neighbour Linear of the same input;
  * d_bias and its entries may be NULL); d_a_amax as above.  N % 4 == 0, 16 <= N <= 256; operands 16-byte aligned, ld % 4 == 0.
@@ -539,7 +542,7 @@ int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const v
                    int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
                    const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz,
                    float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
-                   float *d_dz0_amax, void *stream);
+                   float *d_dz0_amax, const float *d_row_stats, void *stream);
 
 /* Backward of a GraphSAGE layer chained with the layer below it (consecutive GraphSAGE layers where nothing but this
  * layer reads the lower layer's output -- residue 'none' + centre pooling, shaDow/layers.py:159-163): the input gradient
@@ -567,6 +570,7 @@ typedef struct {
   float *dscale, *doffset, *dbias; /* [2, F] each; dbias may be NULL */
   float *partial;                  /* sl_sage_chain_partial_floats(n, F) floats */
   float *amax;                     /* [n]: receives max_k |dZs[i, k]| (the lower layer's call passes it as d_dzs_amax) */
+  const float *stats;              /* [n, 4] row statistics its forward pass left (sl_sage_fwd d_row_stats), or NULL */
 } sl_sage_below;
 size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F);
 int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,

@@ -78,8 +78,12 @@ def gcn_forward(p, X, A, act, keep=None, stats=None):
 
 
 def sage_forward(p, X, A, act, keep=None, stats=None):
-    hs = _act(act, p, F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"]), keep[0] if keep else None, stats)   # layers.py:473-483
-    hn = _act(act, p, F.linear(A.matmul(X), p["f_lin_neigh.weight"], p["f_lin_neigh.bias"]), keep[1] if keep else None, stats)
+    zs = F.linear(X, p["f_lin_self.weight"], p["f_lin_self.bias"])
+    zn = F.linear(A.matmul(X), p["f_lin_neigh.weight"], p["f_lin_neigh.bias"])
+    if stats is not None and "z_taps" in stats:           # (diagnostics: the pre-activations incl. bias, per layer)
+        stats["z_taps"].append((zs.detach(), zn.detach()))
+    hs = _act(act, p, zs, keep[0] if keep else None, stats)   # layers.py:473-483
+    hn = _act(act, p, zn, keep[1] if keep else None, stats)
     return lo.f_norm(hs, p["scale"][0], p["offset"][0]) + lo.f_norm(hn, p["scale"][1], p["offset"][1])
 
 

@@ -58,7 +58,7 @@ class SlSageBelow(C.Structure):
         ("Zs", C.c_void_p), ("Zn", C.c_void_p), ("bs", C.c_void_p), ("bn", C.c_void_p), ("scale", C.c_void_p),
         ("offset", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("F", C.c_uint32),
         ("buf", C.c_void_p), ("dscale", C.c_void_p), ("doffset", C.c_void_p), ("dbias", C.c_void_p), ("partial", C.c_void_p),
-        ("amax", C.c_void_p),
+        ("amax", C.c_void_p), ("stats", C.c_void_p),
     ]
 
 
@@ -133,7 +133,7 @@ SIGNATURES = {
     "sl_gemm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_sage_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_sage_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P,
-                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+                               C.c_int, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_sage_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),
@@ -152,7 +152,7 @@ SIGNATURES = {
     "sl_gemm_act_norm_pack_b2": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, _P, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_gemm_act_norm_fwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, _P,
-                                        C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
+                                        C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P]),
     "sl_gemm_nt2_f32": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), _P]),
     "sl_gemm_nt_cat_f32": (C.c_int, [_P, C.c_int64, C.c_uint32, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P,
@@ -160,7 +160,7 @@ SIGNATURES = {
     "sl_gemm_an_bwd_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
     "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
-                                  C.c_float, C.c_uint64, _P, _P]),
+                                  C.c_float, C.c_uint64, _P, _P, _P]),
     "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
@@ -194,7 +194,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 14      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 15      # sg_abi_version() of the library these signatures describe
 
 
 def load():

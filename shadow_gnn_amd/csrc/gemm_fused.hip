@@ -58,11 +58,13 @@ struct FusedDesc {
   float *out;  int64_t ldo;
   float *out2; int64_t ldo2;        // dual mode: out stays plain, out2 receives the dropped values
   float *out_amax;                  // optional: row maxima of out2 (or out) for the GEMM that reads it next
+  float *stats_w;                   // optional [M, 2 NBA]: (mean, 1 / std) of act(Z_b + bias_b) per row and branch, for the backward epilogue
   // backward: the layer below
   const float *Zr[2]; int64_t ldzr[2];
   float *dZ[2];       int64_t lddz[2];
   float *partial;                   // [grid, nb, 3, N]
   float *dz_amax;                   // optional: row maxima of dZ[0] (the left half of the next K = 2F operand)
+  const float *stats_r;             // optional [M, 2 NBA]: the row statistics the forward epilogue left (stats_w); NULL: recomputed
 };
 
 // The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass; 64 lanes in the backward form): the row
@@ -93,7 +95,7 @@ __device__ __forceinline__ float4 drop_factors(uint32_t rowh, uint32_t c, uint32
 // ACT >= 0: the activation of every branch, known at compile time; ACT < 0: d.act[b] at run time.
 template <int NBA, int Q, int ACT, int LPR>
 __device__ __forceinline__ void an_rows_fwd(const FusedDesc &d, const ColParams<NBA, Q> &cp, const bool (&on)[Q], const float4 (&zc)[NBA][Q],
-                                            float inv_seg, float4 (&out)[Q]) {
+                                            float inv_seg, float4 (&out)[Q], float *stat_row) {
 #pragma unroll
   for (int q = 0; q < Q; q++) out[q] = f4zero();
 #pragma unroll
@@ -117,6 +119,7 @@ __device__ __forceinline__ void an_rows_fwd(const FusedDesc &d, const ColParams<
       v += (h[q].x * h[q].x + h[q].y * h[q].y) + (h[q].z * h[q].z + h[q].w * h[q].w);
     }
     const float rstd = rsqrtf(row_sum<LPR>(v) * inv_seg + d.eps);
+    if (stat_row) { stat_row[2 * b] = mean; stat_row[2 * b + 1] = rstd; }     // (one lane of the row; nullptr elsewhere)
 #pragma unroll
     for (int q = 0; q < Q; q++) {
       // (x - mean) * scale * rsqrt(var) + offset   (layers.py:336)
@@ -128,10 +131,11 @@ __device__ __forceinline__ void an_rows_fwd(const FusedDesc &d, const ColParams<
 
 // act_norm backward of one row on 32 lanes: dy[q] = gradient of the row's output, already through the dropout mask and
 // zero outside the row / the matrix; writes dZ_b, accumulates the column sums of dscale (gs), doffset (go) and dbias (gb)
-template <int NBA, int Q, int ACT, int LPR>
+// kStats: (mean, 1 / std) of every branch come in `st` (what the forward epilogue stored) instead of two row reductions each
+template <int NBA, int Q, int ACT, int LPR, bool kStats>
 __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bool row_ok, uint32_t j, const bool (&on)[Q],
                                             const float4 (&dy)[Q], const float4 (&zc)[NBA][Q], float inv_seg, float4 (&gs)[NBA][Q],
-                                            float4 (&go)[Q], float4 (&gb)[NBA][Q]) {
+                                            float4 (&go)[Q], float4 (&gb)[NBA][Q], const float (&st)[2 * NBA]) {
 #pragma unroll
   for (int q = 0; q < Q; q++) { go[q].x += dy[q].x; go[q].y += dy[q].y; go[q].z += dy[q].z; go[q].w += dy[q].w; }
 #pragma unroll
@@ -147,23 +151,22 @@ __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bo
       h[q] = f4sel(on[q], make_float4(act_fwd(act, z[q].x), act_fwd(act, z[q].y), act_fwd(act, z[q].z), act_fwd(act, z[q].w)));
       s += hsum4(h[q]);
     }
-#ifdef FUSED_KO_STATS
-    // (knock-out: what the backward epilogue would cost with the row statistics read instead of recomputed -- two floats per
-    //  row and branch stand in for the load)
-    const float mean = d.scale[b] * inv_seg, rstd = d.offset[b] + 1.0f;
+    float mean, rstd;
+    if (kStats) {
+      mean = st[2 * b]; rstd = st[2 * b + 1];
 #pragma unroll
-    for (int q = 0; q < Q; q++) xh[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
-    (void)s;
-#else
-    const float mean = row_sum<LPR>(s) * inv_seg;
-    float v = 0.f;
+      for (int q = 0; q < Q; q++) xh[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
+      (void)s;
+    } else {
+      mean = row_sum<LPR>(s) * inv_seg;
+      float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-      xh[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
-      v += (xh[q].x * xh[q].x + xh[q].y * xh[q].y) + (xh[q].z * xh[q].z + xh[q].w * xh[q].w);
+      for (int q = 0; q < Q; q++) {
+        xh[q] = f4sel(on[q], make_float4(h[q].x - mean, h[q].y - mean, h[q].z - mean, h[q].w - mean));
+        v += (xh[q].x * xh[q].x + xh[q].y * xh[q].y) + (xh[q].z * xh[q].z + xh[q].w * xh[q].w);
+      }
+      rstd = rsqrtf(row_sum<LPR>(v) * inv_seg + d.eps);
     }
-    const float rstd = rsqrtf(row_sum<LPR>(v) * inv_seg + d.eps);
-#endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -194,7 +197,7 @@ __device__ __forceinline__ void an_rows_bwd(const FusedDesc &d, uint64_t row, bo
 
 // Everything behind the last k-step, for one (activation, full-width) specialisation: the accumulator tile goes through
 // the dead B ring 16 rows at a time and leaves two rows per pass (see the file header).
-template <int TW, int MODE, int NBA, int ACT, bool kFull>
+template <int TW, int MODE, int NBA, int ACT, bool kFull, bool kStats = false>
 __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)[TW], unsigned char *gsm, uint64_t m0) {
   constexpr int SP = 32 * TW;                               // row pitch of the stash (floats)
   // forward: a row on 32 lanes (two rows per pass, Q = TW / 4 float4s per lane); backward: one float4 per lane (a 256-wide
@@ -257,8 +260,18 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
 #endif
     static_assert(P % D == 0, "");
     float4 zpre[D][NG > 0 ? NG : 1][Q];
+    float spre[D][2 * NBA];                                 // (backward with kStats: the row's saved statistics, same look-ahead)
     auto load_pass = [&](int slot, uint64_t row) {
       const uint64_t rr = min(row, (uint64_t)M - 1);
+      if (MODE == 1 && kStats) {
+        if (NBA == 2) {                                   // (one 16-byte load, the same address in every lane of the row)
+          const float4 sv = ld4(d.stats_r + rr * 4);
+          spre[slot][0] = sv.x; spre[slot][1] = sv.y; spre[slot][2 * NBA - 2] = sv.z; spre[slot][2 * NBA - 1] = sv.w;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2 * NBA; k++) spre[slot][k] = d.stats_r[rr * (2 * NBA) + k];
+        }
+      }
 #pragma unroll
       for (int b = 0; b < NG; b++)
 #pragma unroll
@@ -286,6 +299,9 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
       for (int b = 0; b < NG; b++)
 #pragma unroll
         for (int q = 0; q < Q; q++) zc[b][q] = zpre[k][b][q];
+      float stc[2 * NBA];
+#pragma unroll
+      for (int kk = 0; kk < 2 * NBA; kk++) stc[kk] = (MODE == 1 && kStats) ? spre[k][kk] : 0.f;
       if (pg + 1 < P / D) load_pass(k, row + (uint32_t)(RP * D));
       uint32_t rowh = 0;
       if (d.drop_thr) rowh = mix32((uint32_t)row ^ d.seed_lo) + (uint32_t)(row >> 32) + d.seed_hi;
@@ -294,7 +310,7 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
         for (int q = 0; q < Q; q++) zc[NBA - 1][q] = own[q];
         float4 o[Q];
         float omax = 0.f;
-        an_rows_fwd<NBA, Q, ACT, LPR>(d, cp, on, zc, inv_seg, o);
+        an_rows_fwd<NBA, Q, ACT, LPR>(d, cp, on, zc, inv_seg, o, (d.stats_w && j == 0 && row_ok) ? d.stats_w + row * (2 * NBA) : nullptr);
 #pragma unroll
         for (int q = 0; q < Q; q++) {
           if (row_ok && on[q]) {
@@ -333,7 +349,7 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
 #pragma unroll
             for (int q = 0; q < Q; q++) zc[b][q] = f4zero();
         }
-        an_rows_bwd<NBA, Q, ACT, LPR>(d, row, row_ok, j, on, dy, zc, inv_seg, gs, go, gb);
+        an_rows_bwd<NBA, Q, ACT, LPR, kStats>(d, row, row_ok, j, on, dy, zc, inv_seg, gs, go, gb, stc);
       }
       __builtin_amdgcn_sched_barrier(0);                    // (one pass at a time: interleaved passes multiply the live registers)
     }
@@ -635,7 +651,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
 #endif
   unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
   const bool full = d.N == 32 * TW, same = NBA == 1 || d.act[1] == d.act[0];
-  if (full && same && d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true>(d, acc, gsm, m0);
+  if (MODE == 1 && d.stats_r && full && same && (d.act[0] == 1 || d.act[0] == 2)) {
+    // (the row statistics saved by the forward epilogue: the specialised copies only -- what the benchmark's layers run)
+    if (d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true, MODE == 1>(d, acc, gsm, m0);
+    else fused_epilogue<TW, MODE, NBA, 2, true, MODE == 1>(d, acc, gsm, m0);
+  }
+  else if (full && same && d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true>(d, acc, gsm, m0);
   else if (full && same && d.act[0] == 2) fused_epilogue<TW, MODE, NBA, 2, true>(d, acc, gsm, m0);
   else fused_epilogue<TW, MODE, NBA, -1, false>(d, acc, gsm, m0);
   }
@@ -742,7 +763,7 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
                                     uint32_t N, uint32_t K, float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                     const int *act, const float *d_scale, const float *d_offset, float out_scale, float *d_out,
                                     int64_t ldo, float drop_p, uint64_t drop_seed, float *d_out_dropped, int64_t ldo_dropped,
-                                    float *d_out_amax, void *stream) {
+                                    float *d_out_amax, float *d_row_stats, void *stream) {
   if (nb < 1 || nb > 2) return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: nb must be 1 or 2");
   if (!d_A || !lda || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_out)
     return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: null argument");
@@ -765,7 +786,7 @@ extern "C" int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64
     return set_error(SG_ERR_INVALID, "sl_gemm_act_norm_fwd: scale / offset / out must be 16-byte aligned, ldo %% 4 == 0");
   p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
-  p.out = d_out; p.ldo = ldo; p.out_amax = d_out_amax;
+  p.out = d_out; p.ldo = ldo; p.out_amax = d_out_amax; p.stats_w = d_row_stats;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_act_norm_fwd")) != SG_OK) return rc;
   if (d_out_dropped) {
@@ -833,7 +854,7 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_am
                               const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
                               const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ,
                               const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
-                              float drop_p, uint64_t drop_seed, float *d_dz0_amax, void *stream) {
+                              float drop_p, uint64_t drop_seed, float *d_dz0_amax, const float *d_row_stats, void *stream) {
   if (nb != 2) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: nb must be 2 (a GraphSAGE layer below)");
   if (!d_A || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_dZ || !lddz || !d_dscale || !d_doffset || !d_partial)
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: null argument");
@@ -863,6 +884,8 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_am
   p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
   p.partial = d_partial; p.dz_amax = d_dz0_amax;
+  static const bool use_stats = !(getenv("SHADOW_FUSED_ROW_STATS") && getenv("SHADOW_FUSED_ROW_STATS")[0] == '0');
+  p.stats_r = use_stats ? d_row_stats : nullptr;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_an_bwd")) != SG_OK) return rc;
   rc = N <= 128 ? launch_fused<4, 1, 1, 2>(p, st) : launch_fused<8, 1, 1, 2>(p, st);

@@ -121,7 +121,8 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                            const float *d_Ws, int64_t ldws, const float *d_bs, const float *d_Wn, int64_t ldwn,
                            const float *d_bn, const float *d_scale, const float *d_offset, int act, float drop_p,
                            uint64_t drop_seed, float *d_AX, int64_t ldax, float *d_Zs, float *d_Zn, float *d_out,
-                           float *d_out_dropped, const float *d_x_amax, float *d_out_amax, void *d_pack, int x_pad_zero, void *stream) {
+                           float *d_out_dropped, const float *d_x_amax, float *d_out_amax, void *d_pack, int x_pad_zero,
+                           float *d_row_stats, void *stream) {
   if (!adj || !d_X || !d_Ws || !d_Wn || !d_scale || !d_offset || !d_AX || !d_Zs || !d_Zn || !d_out || !d_pack)
     return set_error(SG_ERR_INVALID, "sl_sage_fwd: null argument");
   if (Fout > 256 || (Fout & 3) || Fin == 0) return set_error(SG_ERR_INVALID, "sl_sage_fwd: Fout = %u (multiple of 4, at most 256)", Fout);
@@ -157,8 +158,10 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
     float *Zw[2] = {d_Zs, d_Zn};
     SHD_PROF_FMT(4.0 * n * (2 * Fin + 2 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 2 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 2, Fout, Fin % 32 ? "_Ktail" : "");
     return sl_gemm_act_norm_fwd(2, A, lda, asc, pk, n, Fout, kpad ? Fp : Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
-                                drop_seed, d_out_dropped, Fout, d_out_amax, stream);
+                                drop_seed, d_out_dropped, Fout, d_out_amax, d_row_stats, stream);
   }
+  if (d_row_stats) return set_error(SG_ERR_INVALID, "sl_sage_fwd: row statistics come from the GEMM-epilogue kernel only (sl_gemm_act_norm_supported, "
+                                     "16-byte aligned operands): pass d_row_stats = NULL for this shape");
   if ((rc = spmm_any(adj, false, d_X, ldx, d_AX, ldax, Fin, stream)) != SG_OK) return rc;
   const size_t pb = sl_gemm_pack_bytes(Fout, Fin);
   if ((rc = sl_gemm_pack_b(d_Ws, ldws, Fout, Fin, pk, stream)) != SG_OK) return rc;
@@ -263,7 +266,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       SHD_PROF_FMT(4.0 * n * (2.0 * Fout + 4.0 * Fb), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_an_bwd_nb2_N%u", Fin);
       if ((rc = sl_gemm_an_bwd(d_buf, ld3, hand ? amx : nullptr, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f, dZb,
                                lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
-                               hand ? below->amax : nullptr, stream)) != SG_OK)
+                               hand ? below->amax : nullptr, below->stats, stream)) != SG_OK)
         return rc;
     } else if (f16dx) {
       const float *A1[1] = {d_buf};
@@ -354,7 +357,7 @@ extern "C" int sl_gcn_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx,
     float *Zw[1] = {d_Z};
     SHD_PROF_FMT(4.0 * n * (1 * Fin + 1 * Fout + Fout * (d_out_dropped ? 2 : 1)), 2.0 * 1 * n * Fin * Fout, stream, "gemm_act_norm_fwd_nb%d_N%u%s", 1, Fout, Fin % 32 ? "_Ktail" : "");
     return sl_gemm_act_norm_fwd(1, A, lda, asc, d_pack, n, Fout, Fin, Zw, ldz, bias, acts, d_scale, d_offset, 1.0f, d_out, Fout, drop_p,
-                                drop_seed, d_out_dropped, Fout, nullptr, stream);
+                                drop_seed, d_out_dropped, Fout, nullptr, nullptr, stream);
   }
   if ((rc = sl_gemm_pack_b(d_W, ldw, Fout, Fin, d_pack, stream)) != SG_OK) return rc;
   if ((rc = nt_gemm(d_AX, ldax, d_pack, d_Z, Fout, n, Fout, Fin, stream)) != SG_OK) return rc;

@@ -10,6 +10,7 @@ torch stream.  No CPU / torch fallback: tensors must live on a ROCm device.
 """
 import ctypes as C
 import os
+import sys
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -940,11 +941,11 @@ def gemm_act_norm_fwd(Xs, Ws, biases, codes, sc, of, out_scale, drop):
         check(lib.sl_gemm_act_norm_fwd(nb, _ptr_array(Xs), lda, _ptr_array(rsc), pack.data_ptr(), M, F, K, _ptr_array(Zs), ldz,
                                        _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(), float(out_scale), out.data_ptr(),
                                        out.stride(0), float(drop[0]), int(drop[1]), out2.data_ptr() if out2 is not None else None,
-                                       out2.stride(0) if out2 is not None else 0, None, st))
+                                       out2.stride(0) if out2 is not None else 0, None, None, st))
     return Zs, (out if out2 is None else (out, out2))
 
 
-def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True):
+def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True, row_stats=None):
     """G = A @ W^T is the gradient of out = sum_b norm_b(act(Z_b + bias_b)) (through its fused output dropout when
     drop[0] > 0); returns (dZs, dscale, doffset, dbias) without ever writing G: the act_norm backward runs in the GEMM's
     epilogue (sl_gemm_an_bwd; what sl_sage_bwd_chain does between two GraphSAGE layers).  nb = 2 only."""
@@ -970,7 +971,8 @@ def gemm_an_bwd(A, W, Zs, biases, codes, sc, of, drop=(0.0, 0), want_dbias=True)
     with _timed(f"gemm_an_bwd_nb{nb}_N{N}", nbytes, dev, flops=2 * M * K * N):
         check(lib.sl_gemm_an_bwd(A.data_ptr(), A.stride(0), rsc.data_ptr() if rsc is not None else None, pack.data_ptr(), M, N, K, nb, _ptr_array(Zs), ldz, _ptr_array(biases), ac,
                                  sc.data_ptr(), of.data_ptr(), 1.0, _ptr_array(dZs), lddz, dsc.data_ptr(), dof.data_ptr(),
-                                 dbi.data_ptr() if dbi is not None else None, partial.data_ptr(), float(drop[0]), int(drop[1]), None, st))
+                                 dbi.data_ptr() if dbi is not None else None, partial.data_ptr(), float(drop[0]), int(drop[1]), None,
+                                 row_stats.data_ptr() if row_stats is not None else None, st))
     return dZs, dsc, dof, dbi
 
 
@@ -988,14 +990,16 @@ class ChainLink:
         self.act = 0
         self.drop = (0.0, 0)
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
+        self.stats = None            # [n, 4] (mean, 1 / std) per row and branch, left by the forward GEMM epilogue (or None)
 
-    def publish(self, Zs, Zn, biases, sc, of, act, drop):
+    def publish(self, Zs, Zn, biases, sc, of, act, drop, stats=None):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
+        self.stats = stats
         self.published = True
 
     def release(self):
         self.published = self.filled = False
-        self.Zs = self.Zn = self.biases = self.sc = self.of = None
+        self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = None
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
 
 
@@ -1154,9 +1158,13 @@ class _SageDense(torch.autograd.Function):
         of = offset.reshape(2, F).contiguous().float()
         bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
         ctx.x_amax = None
+        ctx_stats = None
         if AX is None:
             ctx.x_amax = get_row_amax(X)        # (the backward's weight gradients scale their fp16 pieces by it, sl_gemm_tn_f16)
-            AX, Zs, Zn, out = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop)
+            # (row statistics for the chained backward of this layer: only when a layer above will chain into it)
+            want_stats = (link_up is not None and CHAIN_SAGE_BWD and not _is_dual(drop) and ROW_STATS_HANDOVER
+                          and _lib.load().sl_gemm_act_norm_supported(F, X.shape[1]) and F % 32 == 0)
+            AX, Zs, Zn, out, ctx_stats = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop, want_stats)
             _SageDense.fused_calls += 1
         elif gemm_act_norm_usable([X, AX], [Ws, Wn], F, F):
             (Zs, Zn), out = gemm_act_norm_fwd([X, AX], [Ws, Wn], bsc, acts, sc, of, 1.0, drop)
@@ -1180,7 +1188,7 @@ class _SageDense(torch.autograd.Function):
         # kernel, and the layer above must then write a real dX)
         if (link_up is not None and one_call and CHAIN_SAGE_BWD and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256
                 and _SageDense._bwd_fusable(ctx.needs_input_grad, one_call, X.shape[1], F, AX)):
-            link_up.publish(Zs, Zn, bsc, sc, of, acts[0], drop)
+            link_up.publish(Zs, Zn, bsc, sc, of, acts[0], drop, ctx_stats)
             ctx.link_up = link_up
         ctx.set_materialize_grads(False)
         fire_deferred()
@@ -1201,7 +1209,7 @@ class _SageDense(torch.autograd.Function):
                     and (not ng[0] or Fo % 32 == 0))
 
     @staticmethod
-    def _fused_forward(X, adj, Ws, Wn, biases, sc, of, acts, drop):
+    def _fused_forward(X, adj, Ws, Wn, biases, sc, of, acts, drop, want_stats=False):
         lib = _lib.load()
         n, Fi = X.shape
         Fo = Ws.shape[0]
@@ -1217,12 +1225,16 @@ class _SageDense(torch.autograd.Function):
         out_amax = torch.empty(n, dtype=torch.float32, device=dev)
         a = _adj_struct(adj, False)
         opt = lambda t: t.data_ptr() if t is not None else None
+        # (the GEMM-epilogue kernel writes them: same eligibility as inside sl_sage_fwd)
+        stats = (torch.empty(n, 4, dtype=torch.float32, device=dev)
+                 if (want_stats and X.data_ptr() % 16 == 0 and X.stride(0) % 4 == 0 and AX.data_ptr() % 16 == 0 and AX.stride(0) % 4 == 0) else None)
         check(lib.sl_sage_fwd(C.byref(a), X.data_ptr(), X.stride(0), Fi, Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]),
                               Wn.data_ptr(), Wn.stride(0), opt(biases[1]), sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]),
                               int(drop[1]), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), out.data_ptr(), opt(out2),
-                              opt(x_amax), out_amax.data_ptr(), pack.data_ptr(), 1 if getattr(X, "_shd_pad_zero", False) else 0, _stream(X)))
+                              opt(x_amax), out_amax.data_ptr(), pack.data_ptr(), 1 if getattr(X, "_shd_pad_zero", False) else 0,
+                              opt(stats), _stream(X)))
         set_row_amax(out if out2 is None else out2, out_amax)      # (of the tensor the next layer's GEMM reads)
-        return AX, Zs, Zn, (out if out2 is None else (out, out2))
+        return AX, Zs, Zn, (out if out2 is None else (out, out2)), stats
 
     @staticmethod
     def _fused_backward(ctx, dout, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, drop, has_b, want_dx):
@@ -1286,7 +1298,7 @@ class _SageDense(torch.autograd.Function):
             below = _lib.SlSageBelow(down.Zs.data_ptr(), down.Zn.data_ptr(), opt(down.biases[0]), opt(down.biases[1]),
                                      down.sc.data_ptr(), down.of.data_ptr(), down.act, float(down.drop[0]), int(down.drop[1]), Fi,
                                      down.buf.data_ptr(), down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi),
-                                     down.partial.data_ptr(), down.amax.data_ptr())
+                                     down.partial.data_ptr(), down.amax.data_ptr(), opt(down.stats))
         dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
         dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
         tn_partial = torch.empty((2 if ctx.x_amax is not None else 1) * lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)   # (both weight gradients in one launch)
@@ -1316,6 +1328,12 @@ class _SageDense(torch.autograd.Function):
     sparse_top_calls = 0     # backward passes of a top layer that ran on the rows R u N(R) only
 
     @staticmethod
+    def _dbg(msg):
+        if os.environ.get("SHADOW_DEBUG_TRACE"):
+            torch.cuda.synchronize()
+            print("[trace]", msg, file=sys.stderr, flush=True)
+
+    @staticmethod
     def _sparse_top_backward(ctx, lr, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b):
         """The top layer of a GraphSAGE stack under a row-selecting read-out: its output gradient lives on the roots R
         (``lr.grad`` [P, Fo]), so dZs / dZn are zero outside R, dWs = dZs[R]^T X[R], dWn = dZn[R]^T (A X)[R], and the input
@@ -1333,22 +1351,29 @@ class _SageDense(torch.autograd.Function):
         plan = lr.plan
         lv = plan.level
         R = lv.rows_full
+        _SageDense._dbg(f"sparse top: n={n} P={R.numel()} t={lv.m_in} E={lv.indices.numel()}")
         (dZsR, dZnR), dsc, dof, dbi = _an_bwd([Zs.index_select(0, R), Zn.index_select(0, R)], biases, acts, sc, of, Fo, 1.0, (lr.grad,),
                                               [True, True], any(has_b), (0.0, 0))
+        _SageDense._dbg("an_bwd roots ok")
         dWs = dZsR.t() @ X.index_select(0, R)
         dWn = dZnR.t() @ AX.index_select(0, R)
+        _SageDense._dbg("weight grads ok")
         # dX on the rows T: the self term lands on the roots, the neighbour term is the rectangular transposed aggregate
         ew, rs, cs = lv.norm(ctx.adj)
         ti, tx, tp = lv.transposed
         dXT = _spmm_raw(ti, tx, ew, tp if ew is not None else None, cs, rs, (dZnR @ Wn).contiguous(), lv.m_in)
+        _SageDense._dbg("rect spmm ok")
         dXT.index_add_(0, lv.self_idx, dZsR @ Ws)            # (the roots are distinct rows: one add per target)
+        _SageDense._dbg("dXT ok")
         # the layer below: act_norm backward on the rows T of its output gradient, everything else of [dZs | . | dZn] cleared
         down.buf = torch.empty(n, 3 * Fi, **f32)
         check(lib.sl_zero_slices(down.buf.data_ptr(), down.buf.data_ptr() + 8 * Fi, 3 * Fi, n, Fi, _stream(Zs)))
         down.amax = torch.zeros(n, **f32)
+        _SageDense._dbg("zero slices ok")
         _dz, down.dsc, down.dof, down.dbi = _an_bwd([down.Zs, down.Zn], down.biases, (down.act, down.act), down.sc, down.of, Fi, 1.0,
                                                    (dXT,), [True, True], any(b is not None for b in down.biases), down.drop,
                                                    dz_out=[down.buf[:, :Fi], down.buf[:, 2 * Fi:]], row_idx=plan.T32, dz0_amax=down.amax)
+        _SageDense._dbg("an_bwd below ok")
         down.partial = None
         lr.release()
         down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)
@@ -1405,6 +1430,8 @@ class _SageDense(torch.autograd.Function):
         return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None
 
 
+# (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (SHADOW_ROW_STATS=0: recomputed)
+ROW_STATS_HANDOVER = os.environ.get("SHADOW_ROW_STATS", "1") != "0"
 # Chained GraphSAGE backward (sl_sage_bwd_chain): on unless SHADOW_CHAIN_SAGE_BWD=0
 CHAIN_SAGE_BWD = os.environ.get("SHADOW_CHAIN_SAGE_BWD", "1") != "0"
 
