@@ -430,8 +430,13 @@ class MinibatchShallowExtractor:
         if self._side is None:
             return tail.TopBackwardPlan(adj, subgs.target)
         main = torch.cuda.current_stream(self.device)
-        for t in (subgs.indptr, subgs.indices, subgs.target):
-            t.record_stream(main)
+        # (as in _tail_plan: the plan allocates on the side stream BEFORE the next _launch orders that stream behind the
+        #  training stream -- every sampler output of this batch must therefore be recorded on the training stream, or a block
+        #  the training stream still reads could be handed to the next batch's plan)
+        for t in (subgs.node, subgs.indptr, subgs.indices, subgs.edge_id, subgs.target, subgs.subg_node_off,
+                  subgs.subg_edge_off, subgs.ppr, subgs.hop, subgs.drnl):
+            if t is not None and t.is_cuda:
+                t.record_stream(main)
         with torch.cuda.stream(self._side):
             plan = tail.TopBackwardPlan(adj, subgs.target)
         main.wait_stream(self._side)

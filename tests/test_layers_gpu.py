@@ -1632,28 +1632,12 @@ def test_timed_configuration_with_dropout_and_dropedge_matches_fp64_oracle(act, 
     preds_ref, emb_ref = mos.model_forward(p, arch, X, h["indptr"], h["indices"], sizes, h["target"], relu_keep=relu_keep, stats=kstats,
                                            edge_keep=ek, in_drop=in_drop)
     if relu_keep is not None:
-        # With 40 % of every input row zeroed, relu leaves some rows (almost) entirely dead; their normalised output
-        # divides by a standard deviation of a few ulps, so the NEXT layer's pre-activations of that node and its
-        # neighbours differ between fp32 and fp64 by far more than rounding (measured: 35 of 9.1e7 units, |z| up to 0.09;
-        # the dropout-free runs above stay below 5e-3).  The count stays a handful per ten million; a wrong mask would flip
-        # units by the million and fail the end-to-end bounds below, which are the same as for the dropout-free runs.
-        assert kstats["kink_units"] <= 1e-5 * kstats["units"] and kstats.get("kink_max_abs_z", 0.0) < 0.25, kstats
+        assert kstats["kink_units"] <= 1e-5 * kstats["units"] and kstats.get("kink_max_abs_z", 0.0) < 5e-3, kstats
     loss_ref = lo.model_loss(preds_ref, labels.numpy())
     loss_ref.backward()
     assert abs(float(ret["loss"]) - float(loss_ref)) < 1e-4
     np.testing.assert_allclose(ret["preds"].detach().cpu().numpy(), torch.softmax(preds_ref, 1).detach().numpy(), rtol=1e-4, atol=1e-4)
-    # Embeddings: <= 1e-4 against fp64 -- except on the few root rows where fp32 ITSELF is not that close to fp64: the same
-    # oracle evaluated in fp32 (the precision the reference runs in), same masks and relu sides, gives the distance plain
-    # fp32 arithmetic has from fp64 on every row (the dead-row amplification above: measured 2e-4 on 28 of 32 768 entries);
-    # a row may differ from fp64 by 1e-4 plus three times that.
-    with torch.no_grad():
-        _p32, emb32 = mos.model_forward({k: v.detach() for k, v in p.items()}, arch, X, h["indptr"], h["indices"], sizes, h["target"],
-                                        dtype=torch.float32, relu_keep=relu_keep, edge_keep=ek, in_drop=in_drop)
-    e64 = emb_ref.detach().numpy()
-    fp32_dist = np.abs(emb32.double().numpy() - e64).max(axis=1, keepdims=True)
-    got_emb = ret["emb_ens"][0].detach().cpu().numpy()
-    assert np.all(np.abs(got_emb - e64) <= 1e-4 + 1e-4 * np.abs(e64) + 3.0 * fp32_dist), float(np.abs(got_emb - e64).max())
-    assert float(np.mean(np.abs(got_emb - e64) <= 1e-4 + 1e-4 * np.abs(e64))) >= 0.995          # ... and almost all of them plainly
+    np.testing.assert_allclose(ret["emb_ens"][0].detach().cpu().numpy(), emb_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
     grads = {k: v.grad for k, v in p.items() if v.grad is not None}
     gn = float(torch.sqrt(sum((g_ ** 2).sum() for g_ in grads.values())))
     coef = min(1.0, 5.0 / (gn + 1e-6))
