@@ -618,6 +618,22 @@ uint32_t sl_clip_adam_scratch_floats(void);
  * few a row-sparse backward pass fills itself (F % 4 == 0, ld % 4 == 0, 16-byte aligned slices). */
 int sl_zero_slices(float *d_a, float *d_b, int64_t ld, uint32_t n, uint32_t F, void *stream);
 
+/* Row sets and input gradient of the exact row-sparse backward pass of a stack's top layer under a read-out that takes ONE
+ * row per subgraph (the roots, shaDow/layers.py:159-163): the layer's dZ is zero outside the roots R and its input gradient
+ * zero outside T = R u N(R), where a row j gets at most one neighbour term -- from its own subgraph's root through the
+ * edge (root, j).  sl_top_plan: d_targets [P] = the root row of every subgraph (num_roots = 1, ascending); writes
+ * d_off [P + 2] (exclusive offsets of the subgraphs' shares of T, d_off[P] = |T|, d_off[P + 1] != 0: a root's neighbour list
+ * is not strictly ascending -- repeated edges -- and the plan must not be used), and, when |T| <= cap, d_T / d_slot / d_epos
+ * [|T|] (row id, subgraph, position of the edge (root, row) in the batch CSR or -1 for a root without self edge) and
+ * d_self_idx [P] (position of every root in T).  sl_top_dx: d_out[j, :] = A[root, T[j]] G[slot[j], :] + [T[j] is the root]
+ * S[slot[j], :] with A = diag(row_scale) (A o edge_w) diag(col_scale) (any of the three may be NULL), G = dZn[R] Wn,
+ * S = dZs[R] Ws ([P, F] each, pitch ldg); F % 4 == 0, 16-byte aligned rows.                                            */
+int sl_top_plan(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_targets, uint32_t num_subg, uint32_t cap,
+                uint32_t *d_off, uint32_t *d_T, uint32_t *d_slot, int32_t *d_epos, uint32_t *d_self_idx, void *stream);
+int sl_top_dx(const float *d_G, const float *d_S, int64_t ldg, const uint32_t *d_T, const uint32_t *d_slot, const int32_t *d_epos,
+              const uint32_t *d_self_idx, const uint32_t *d_targets, const float *d_edge_w, const float *d_row_scale,
+              const float *d_col_scale, uint32_t t, uint32_t F, float *d_out, int64_t ldo, void *stream);
+
 int sl_clip_adam(float *d_param, float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, uint64_t n, double lr, double beta1,
                  double beta2, double eps, uint32_t step, float max_norm, float *d_scratch, void *stream);
 

@@ -1097,7 +1097,7 @@ class _SelectRoots(torch.autograd.Function):
             if plan is None or not plan.matches(link.csr, int(rows.numel())):
                 from . import tail
                 plan = tail.TopBackwardPlan(link.csr, rows)
-            ctx.plan = plan
+            ctx.plan = plan if plan.matches(link.csr, int(rows.numel())) else None       # (not ok: a multigraph root row -- dense pass)
         return f.index_select(0, rows)
 
     @staticmethod
@@ -1352,21 +1352,22 @@ class _SageDense(torch.autograd.Function):
         dev = Zs.device
         f32 = dict(dtype=torch.float32, device=dev)
         plan = lr.plan
-        lv = plan.level
-        R = lv.rows_full
-        _SageDense._dbg(f"sparse top: n={n} P={R.numel()} t={lv.m_in} E={lv.indices.numel()}")
+        R = plan.rows64
+        _SageDense._dbg(f"sparse top: n={n} P={R.numel()} t={plan.t}")
         (dZsR, dZnR), dsc, dof, dbi = _an_bwd([Zs.index_select(0, R), Zn.index_select(0, R)], biases, acts, sc, of, Fo, 1.0, (lr.grad,),
                                               [True, True], any(has_b), (0.0, 0))
-        _SageDense._dbg("an_bwd roots ok")
         dWs = dZsR.t() @ X.index_select(0, R)
         dWn = dZnR.t() @ AX.index_select(0, R)
-        _SageDense._dbg("weight grads ok")
-        # dX on the rows T: the self term lands on the roots, the neighbour term is the rectangular transposed aggregate
-        ew, rs, cs = lv.norm(ctx.adj)
-        ti, tx, tp = lv.transposed
-        dXT = _spmm_raw(ti, tx, ew, tp if ew is not None else None, cs, rs, (dZnR @ Wn).contiguous(), lv.m_in)
-        _SageDense._dbg("rect spmm ok")
-        dXT.index_add_(0, lv.self_idx, dZsR @ Ws)            # (the roots are distinct rows: one add per target)
+        # dX on the rows T: a row gets its root's neighbour term through the edge (root, row), the root itself the self term
+        GS = torch.empty(2, int(R.numel()), Fi, **f32)
+        torch.mm(dZnR, Wn, out=GS[0])
+        torch.mm(dZsR, Ws, out=GS[1])
+        adj = ctx.adj
+        opt = lambda t_: t_.data_ptr() if t_ is not None else None
+        dXT = torch.empty(plan.t, Fi, **f32)
+        check(lib.sl_top_dx(GS[0].data_ptr(), GS[1].data_ptr(), Fi, plan.T32.data_ptr(), plan.slot.data_ptr(), plan.epos.data_ptr(),
+                            plan.self_idx.data_ptr(), plan.targets32.data_ptr(), opt(adj.edge_w), opt(adj.row_scale), opt(adj.col_scale),
+                            plan.t, Fi, dXT.data_ptr(), Fi, _stream(Zs)))
         _SageDense._dbg("dXT ok")
         # the layer below: act_norm backward on the rows T of its output gradient, everything else of [dZs | . | dZn] cleared
         down.buf = torch.empty(n, 3 * Fi, **f32)

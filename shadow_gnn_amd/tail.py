@@ -204,29 +204,35 @@ class TopBackwardPlan:
     zero outside R, and its input gradient  dX = dZs Ws + A^T (dZn Wn)  is zero outside  T = R u N(R)  (the roots and their
     in-subgraph neighbours: ~7 % of a depth-2 k-hop batch).  The forward pass is untouched -- every row of every layer is
     computed, as in the reference; the backward pass multiplies by the zeros the reference's autograd multiplies by, or skips
-    them: the same gradients.  ``level``: the rows R of the batch adjacency with columns renumbered into T (transposed
-    form ready); ``T32``: T as sorted int32 batch-level row ids.  Two host syncs (array sizes): the minibatch extractor builds the
-    plan on its prefetch stream."""
+    them: the same gradients.  Built by two small kernels (sl_top_plan) and ONE host sync (the size of T): the minibatch
+    extractor builds it on its prefetch stream.  ``ok`` False: a root row lists a neighbour twice (a multigraph) -- the
+    dense pass is taken."""
 
     def __init__(self, csr: "ops.DeviceCSR", targets: torch.Tensor):
+        import ctypes as C
+
+        from . import _lib
         n, dev = csr.n, csr.device
-        rows = torch.as_tensor(targets, device=dev).long().reshape(-1)
-        ip, er, pos = _select_rows(csr.indptr, rows)
-        cols = csr.indices[pos].long()
-        mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        mask[rows] = True
-        mask[cols] = True
-        in_ids = mask.nonzero().reshape(-1)              # (host sync) ascending
-        newid = torch.cumsum(mask, 0) - 1
-        self.level = RectLevel(ip.to(torch.int32), newid[cols].to(torch.int32), er, pos, rows, in_ids, newid[rows], in_ids.numel())
-        self.level.transposed                              # (built here: the backward pass must not sort)
-        self.T32 = in_ids.to(torch.int32)
+        tg = torch.as_tensor(targets, device=dev).reshape(-1)
+        self.targets32 = (tg if tg.dtype == torch.int32 else tg.to(torch.int32)).contiguous()
+        self.rows64 = self.targets32.long()
+        P = int(self.targets32.numel())
+        cap = n + P
+        i32 = dict(dtype=torch.int32, device=dev)
+        off = torch.empty(P + 2, **i32)
+        T, slot, epos, self_idx = torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(max(P, 1), **i32)
+        _lib.check(_lib.load().sl_top_plan(csr.indptr.data_ptr(), csr.indices.data_ptr(), self.targets32.data_ptr(), P, cap, off.data_ptr(),
+                                           T.data_ptr(), slot.data_ptr(), epos.data_ptr(), self_idx.data_ptr(), ops._stream(csr.indptr)))
+        t, bad = (int(x) for x in off[P:P + 2].tolist()) if P else (0, 0)          # (the one host sync)
+        self.ok = bool(P > 0 and bad == 0 and t <= cap)
+        self.t = t if self.ok else 0
+        self.T32, self.slot, self.epos, self.self_idx = T[:self.t], slot[:self.t], epos[:self.t], self_idx[:P]
         self.n = n
-        self.num_roots = int(rows.numel())
+        self.num_roots = P
         self._indptr_ptr = csr.indptr.data_ptr()
 
     def matches(self, csr: "ops.DeviceCSR", num_roots: int) -> bool:
-        return csr.n == self.n and csr.indptr.data_ptr() == self._indptr_ptr and num_roots == self.num_roots
+        return self.ok and csr.n == self.n and csr.indptr.data_ptr() == self._indptr_ptr and num_roots == self.num_roots
 
     def tensors(self):
-        return self.level.tensors() + [self.T32]
+        return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx]

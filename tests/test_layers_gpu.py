@@ -1674,3 +1674,54 @@ def test_sparse_top_layer_backward_equals_dense(n_layers, p_drop, dropedge, act,
         scale = float(g0[k].abs().max())
         err = float((g1[k] - g0[k]).abs().max())
         assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
+
+
+@pytest.mark.gpu
+def test_top_backward_plan_lists_roots_and_their_neighbours():
+    """sl_top_plan against numpy: T = the roots and their in-subgraph neighbours (ascending, each row once), per row its
+    subgraph, the position of the edge (root, row) in the batch CSR (-1: the root without a self edge) and every root's
+    position in T; sl_top_dx = the rows T of  A^T (G scattered to the roots) + S scattered to the roots.  A root row that
+    lists a neighbour twice (multigraph) makes the plan unusable (the dense pass is taken)."""
+    from shadow_gnn_amd import _lib, ops, tail
+    b, X, labels, F0, C = _bench_scale_batch("gcn", 64)             # (add_self_edge: some roots carry a self edge ...)
+    b2, _x, _l, _f, _c = _bench_scale_batch("sage", 64)             # (... and here none does)
+    for bb in (b, b2):
+        adj = ops.DeviceCSR(bb.indptr, bb.indices, subg_off=bb.subg_node_off, subg_edge_off=bb.subg_edge_off, max_subg_nodes=bb.counts["max_subg_nodes"])
+        plan = tail.TopBackwardPlan(adj, bb.target)
+        assert plan.ok
+        h = bb.to_host()
+        ip, ix, tg = h["indptr"].astype(np.int64), h["indices"].astype(np.int64), h["target"].astype(np.int64)
+        want_T, want_slot, want_epos, want_self = [], [], [], []
+        for s_, r in enumerate(tg):
+            nb = ix[ip[r]:ip[r + 1]]
+            rows = np.union1d(nb, [r])
+            want_self.append(len(want_T) + int(np.searchsorted(rows, r)))
+            for j in rows:
+                pos = np.nonzero(nb == j)[0]
+                want_T.append(j); want_slot.append(s_); want_epos.append(ip[r] + pos[0] if pos.size else -1)
+        assert plan.t == len(want_T)
+        assert np.array_equal(plan.T32.cpu().numpy().astype(np.int64), want_T) and np.array_equal(plan.slot.cpu().numpy(), want_slot)
+        assert np.array_equal(plan.epos.cpu().numpy(), want_epos) and np.array_equal(plan.self_idx.cpu().numpy(), want_self)
+        # dX on T against the dense formula, with random edge weights and both scale vectors
+        n, P, F = adj.n, len(tg), 64
+        g = torch.Generator(device=DEV).manual_seed(3)
+        ew = torch.rand(adj.e, device=DEV, generator=g); rs = torch.rand(n, device=DEV, generator=g) + 0.5; cs = torch.rand(n, device=DEV, generator=g) + 0.5
+        G = torch.randn(P, F, device=DEV, generator=g); S = torch.randn(P, F, device=DEV, generator=g)
+        out = torch.empty(plan.t, F, device=DEV)
+        _lib.check(_lib.load().sl_top_dx(G.data_ptr(), S.data_ptr(), F, plan.T32.data_ptr(), plan.slot.data_ptr(), plan.epos.data_ptr(),
+                                         plan.self_idx.data_ptr(), plan.targets32.data_ptr(), ew.data_ptr(), rs.data_ptr(), cs.data_ptr(), plan.t, F,
+                                         out.data_ptr(), F, ops._stream(out)))
+        dense = torch.zeros(n, F, dtype=torch.float64, device=DEV)
+        tgd = torch.from_numpy(tg).to(DEV)
+        dense[tgd] += S.double()
+        for s_, r in enumerate(tg):
+            for e in range(ip[r], ip[r + 1]):
+                dense[ix[e]] += (rs[r] * ew[e] * cs[ix[e]]).double() * G[s_].double()
+        torch.testing.assert_close(out.double(), dense[plan.T32.long()], rtol=1e-6, atol=1e-6)
+        mask = torch.ones(n, dtype=torch.bool, device=DEV); mask[plan.T32.long()] = False
+        assert float(dense[mask].abs().max()) == 0.0                      # nothing outside T
+    # a repeated neighbour in a root's row: not usable
+    ip = torch.tensor([0, 3, 4, 5], dtype=torch.int32, device=DEV)
+    ix = torch.tensor([1, 1, 2, 0, 0], dtype=torch.int32, device=DEV)
+    bad = tail.TopBackwardPlan(ops.DeviceCSR(ip, ix), torch.tensor([0], dtype=torch.int32, device=DEV))
+    assert not bad.ok and not bad.matches(ops.DeviceCSR(ip, ix), 1)
