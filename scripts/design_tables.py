@@ -71,15 +71,24 @@ def main():
         trs = f"{tr / 1e6:.0f} | {tr / 1e6 / alg_mb:.2f}" if (tr and alg_mb > 0) else "— | —"
         out.append(f"| `{k}` | {v['launches'] / steps_prof:.1f} | {v['avg_ms'] * 1e3:.1f} | {rocus} | {alg_mb:.0f} | {trs}"
                    + f" | {v['alg_GBps']:.0f} | {v['frac']:.3f} | " + (f"{tf:.1f} | {tf / mfma_roof(k):.3f} |" if tf else "— | — |"))
-    r = d["roofline"]
+    r = d.get("roofline_north_star") or d["roofline"]
+    dom, rs = d["roofline"], d.get("roofline_step")
     out.append("")
-    out.append(f"North-star aggregate (k-hop sample + feature gather + SAGE aggregates, `roofline` of the bench line): "
+    if d.get("roofline_north_star"):
+        out.append(f"`roofline` of the line = the dominant kernel class by total time: `{dom['kernel']}`, {dom.get('launches_per_step')} launches per step x "
+                   f"{dom['avg_ms'] * 1e3:.1f} us = {dom.get('share_of_kernel_time', 0) * 100:.0f} % of the kernel time; {dom['achieved']:.0f} GB/s algorithmic = "
+                   f"**{dom['frac']:.3f} of 8 TB/s** (arithmetic intensity {dom.get('arith_intensity_flop_per_byte')} flop/B against a ridge of "
+                   f"{dom.get('ridge_flop_per_byte')}: HBM is its roof; {dom.get('mfma_frac')} of the fp16 split's matrix-core roof beside it).")
+        if rs:
+            out.append(f"`roofline_step`: every kernel class's own algorithmic bytes, {rs['bytes_per_step'] / 1e9:.2f} GB per step, over the timed "
+                       f"{rs['ms_per_step']} ms = {rs['achieved']:.0f} GB/s = **{rs['frac']:.3f} of 8 TB/s** ({rs['kernel_ms_per_step']} ms of it inside the hand-written kernels).")
+    out.append(f"North-star aggregate (k-hop sample + feature gather + SAGE aggregates, `roofline_north_star` of the bench line): "
                f"{r['bytes_per_step'] / 1e6:.0f} MB / {r['ms_per_step']} ms = {r['achieved']:.0f} GB/s = **{r['frac']:.3f} of 8 TB/s**; "
                f"PMC traffic of those kernels {r['traffic'] / 1e6:.0f} MB per step." if r.get("traffic") else "")
     sa = d.get("sampler_alone")
     if sa:
-        out.append(f"Sampler kernels with the GPU to themselves: {sa['avg_ms']} ms per 1 024-root call = {sa['alg_GBps']:.0f} GB/s = {sa['frac']} "
-                   f"of peak (+ relocation {sa['relocate_avg_ms']} ms).")
+        out.append(f"Sampler kernels with the GPU to themselves: {sa['avg_ms']} ms per call of {sa.get('batches_per_call', 1)} x 1 024 roots "
+                   f"({sa.get('us_per_subgraph')} us per subgraph) = {sa['alg_GBps']:.0f} GB/s = {sa['frac']} of peak (+ relocation {sa['relocate_avg_ms']} ms).")
     cb = d.get("cpu_baseline") or {}
     if cb.get("value"):
         out.append(f"CPU baseline (the reference's own C++/OpenMP sampler, `oracle/_ref`, best of a thread sweep): {cb['value'] / 1e6:.2f} M sampled "
@@ -88,6 +97,9 @@ def main():
     if cs.get("value"):
         out.append(f"CPU train step (`oracle/cpu_train_step.py`, kind port, {'extrapolated from ' + str(cs.get('measured_fraction_of_batch')) + ' of a batch' if cs.get('extrapolated') else 'whole batch'}): "
                    f"{cs['value']} steps/s on {cs.get('cores')} threads.")
+    dt = d.get("dense_top_backward") or {}
+    if dt.get("ms_per_step"):
+        out.append(f"The same step with the top layer's backward pass on every row (`--dense-top-backward`, 10 steps after the timed region): {dt['ms_per_step']} ms/step.")
     tl = d.get("target_only_tail") or {}
     if tl.get("ms_per_step"):
         out.append(f"Opt-in target-only tail (never part of `value`): {tl['ms_per_step']} ms/step.")
@@ -106,7 +118,7 @@ def main():
         top = sorted(w["kernels"].items(), key=lambda kv: -kv[1]["total_ms"])[:3]
         sp = 10 if w["steps"] >= 10 else w["steps"]
         tops = "; ".join(f"`{k}` {v['avg_ms'] * 1e3:.0f} x {v['launches'] / sp:.0f} ({v['frac']:.2f})" for k, v in top)
-        out.append(f"| {m.group(1)} | {w['ms_per_step']} | {w['value'] / 1e6:.2f} M | {w.get('host_busy_ms_per_step')} | {w['roofline']['frac']} | {tops} |")
+        out.append(f"| {m.group(1)} | {w['ms_per_step']} | {w['value'] / 1e6:.2f} M | {w.get('host_busy_ms_per_step')} | {(w.get('roofline_north_star') or w['roofline'])['frac']} | {tops} |")
     text = "\n".join(out)
     if "--write" in sys.argv:
         path = os.path.join(ROOT, "DESIGN.md")

@@ -1080,7 +1080,9 @@ ROOTS_SPARSE_GRAD = os.environ.get("SHADOW_ROOTS_SPARSE_GRAD", "1") != "0"
 # The top GraphSAGE layer's backward pass on the rows its gradient is non-zero on (tail.TopBackwardPlan): exact, see there.
 # Off: the dense kernels stream the 99.6 %-zero gradient (SHADOW_SPARSE_TOP_BWD=0; bench.py reports that step time beside `value`).
 SPARSE_TOP_BWD = os.environ.get("SHADOW_SPARSE_TOP_BWD", "1") != "0"
-SPARSE_TOP_BWD_MIN_ROWS = 32768      # below: a dozen small launches cost more host time than the three dense kernels cost GPU time
+# below: ~20 small launches cost more host time than the three dense kernels cost GPU time (products shape, 128 roots = 36 k rows:
+# 2.14 ms / step dense, 2.87 with the row-sparse pass; 1 024 roots = 289 k rows: 7.28 -> 6.59)
+SPARSE_TOP_BWD_MIN_ROWS = int(os.environ.get("SHADOW_SPARSE_TOP_BWD_MIN_ROWS", "131072"))
 
 
 class _SelectRoots(torch.autograd.Function):

@@ -1220,8 +1220,10 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
     prev_f = lib.sl_set_fused_epilogue(1 if fused else 0)
     prev_c, prev_s = ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD
     ops.CHAIN_SAGE_BWD = chain
+    prev_m = ops.SPARSE_TOP_BWD_MIN_ROWS
     if sparse_top is not None:
         ops.SPARSE_TOP_BWD = sparse_top
+        ops.SPARSE_TOP_BWD_MIN_ROWS = 1024          # (the production threshold is a host-time trade-off, not a correctness bound)
     try:
         arch = dict(num_layers=n_layers, num_cls_layers=1, heads=1, dim=dim, act=act, layer_norm="norm_feat",
                     feature_augment_ops="sum", aggr="sage", residue="none", pooling="center", loss="softmax")
@@ -1249,7 +1251,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         return float(ret["loss"]), ret["preds"].detach().clone(), grads, calls
     finally:
         lib.sl_set_fused_epilogue(prev_f)
-        ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD = prev_c, prev_s
+        ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS = prev_c, prev_s, prev_m
 
 
 @pytest.mark.parametrize("n_layers,dim,p_drop,act", [(3, 256, 0.4, "relu"), (5, 256, 0.0, "elu"), (3, 128, 0.3, "elu")])
@@ -1602,6 +1604,11 @@ def test_timed_configuration_with_dropout_and_dropedge_matches_fp64_oracle(act, 
         return m
     monkeypatch.setattr(ops, "new_dropout_seed", logged_seed)
     monkeypatch.setattr(ops, "dropedge_mask", logged_mask)
+    # ... and the top layer's backward pass in its row-sparse form, as at the benchmark's 289 k rows (the production
+    # threshold keeps batches of this size on the dense kernels for host-time reasons)
+    monkeypatch.setattr(ops, "SPARSE_TOP_BWD", True)
+    monkeypatch.setattr(ops, "SPARSE_TOP_BWD_MIN_ROWS", 1024)
+    s0 = ops._SageDense.sparse_top_calls
     c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls)
     timer = ops.KernelTimer()
     ops.Z_TAP = []
@@ -1616,6 +1623,7 @@ def test_timed_configuration_with_dropout_and_dropedge_matches_fp64_oracle(act, 
     # the timed call path: lazy gather with dropout, one-call entries, every boundary chained, fused dropout everywhere
     assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (L, L - 1)
     assert any(k.startswith("gather_F") for k in ran) and any(k.startswith("gemm_an_bwd_nb2") for k in ran), ran
+    assert ops._SageDense.sparse_top_calls == s0 + 1 and any(k.startswith("top_dx_F") for k in ran), ran
     assert len(seeds) == L and len(edge_masks) == 1 and edge_masks[0] is not None, (len(seeds), len(edge_masks))
     ek = edge_masks[0].cpu()
     assert 0.93 < float(ek.mean()) < 0.97                     # ~ e p positions drawn with replacement
