@@ -625,7 +625,7 @@ def main():
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / K * 1e3, 4),
         "host_busy_ms_per_step": round((t_host - t_blocked) / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "train_steps_per_sec": round(K / dt, 3),
+        "train_steps_per_sec": round(K / dt, 3), "instrumented_steps": K_prof,
         "target_only_tail": tail_info,
         "dense_top_backward": dense_top_info,
         "cpu_baseline_train_step": cb_step,

@@ -55,7 +55,13 @@ def main():
     out.append("| kernel class (bench line) | launches / step | avg us, HIP events | avg us, rocprofv3 | algorithmic MB | HBM MB (PMC) | PMC / alg. | alg. GB/s | frac of 8 TB/s | TFLOP/s fp32-equiv. | frac of the split's roof (2500/3 fp16 pieces, 2500/6 bf16) |")
     out.append("|---|---|---|---|---|---|---|---|---|---|---|")
     K = d["kernels"]
-    steps_prof = 10
+    def prof_steps(line):
+        """instrumented steps behind the line's kernel statistics"""
+        if line.get("instrumented_steps"):
+            return int(line["instrumented_steps"])
+        mo = re.match(r"(\d+) instrumented", (line.get("roofline_north_star") or line.get("roofline") or {}).get("measured_over", ""))
+        return int(mo.group(1)) if mo else (10 if line["steps"] >= 10 else line["steps"])
+    steps_prof = prof_steps(d)
     for k, v in sorted(K.items(), key=lambda kv: -kv[1]["total_ms"]):
         if v["total_ms"] < 0.5 and not k.startswith(("sg_", "gather")):
             continue
@@ -116,7 +122,7 @@ def main():
             continue
         w = json.load(open(os.path.join(P, f)))
         top = sorted(w["kernels"].items(), key=lambda kv: -kv[1]["total_ms"])[:3]
-        sp = 10 if w["steps"] >= 10 else w["steps"]
+        sp = prof_steps(w)
         tops = "; ".join(f"`{k}` {v['avg_ms'] * 1e3:.0f} x {v['launches'] / sp:.0f} ({v['frac']:.2f})" for k, v in top)
         out.append(f"| {m.group(1)} | {w['ms_per_step']} | {w['value'] / 1e6:.2f} M | {w.get('host_busy_ms_per_step')} | {(w.get('roofline_north_star') or w['roofline'])['frac']} | {tops} |")
     text = "\n".join(out)

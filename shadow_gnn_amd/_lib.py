@@ -138,6 +138,7 @@ SIGNATURES = {
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),
     "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "sl_set_aux_stream": (C.c_int, [_P]),
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P, _P]),

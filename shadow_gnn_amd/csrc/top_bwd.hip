@@ -17,9 +17,29 @@
 namespace shadow {
 namespace {
 
-// One workgroup: t_s = deg(r_s) + [r_s not among its own neighbours] per subgraph, exclusive scan -> off[P + 1]
-__global__ void __launch_bounds__(1024) top_count_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                         const uint32_t *__restrict__ targets, uint32_t P, uint32_t *__restrict__ off) {
+// One wavefront per subgraph: t_s = deg(r_s) + [r_s not among its own neighbours] -> off[s] (scanned below); a neighbour list
+// that is not strictly ascending (repeated edges) raises off[P + 1]
+__global__ void __launch_bounds__(256) top_count_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                        const uint32_t *__restrict__ targets, uint32_t P, uint32_t *__restrict__ off) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= P) return;
+  const uint32_t r = targets[s], e0 = indptr[r], e1 = indptr[r + 1];
+  uint32_t self = 0, bad = 0;
+  for (uint32_t e = e0 + lane; e < e1; e += 64) {
+    const uint32_t c = indices[e];
+    self |= c == r ? 1u : 0u;
+    bad |= (e > e0 && c <= indices[e - 1]) ? 1u : 0u;
+  }
+  for (int d = 32; d >= 1; d >>= 1) { self |= __shfl_xor(self, d, 64); bad |= __shfl_xor(bad, d, 64); }
+  if (lane == 0) {
+    off[s] = (e1 - e0) + (self ? 0u : 1u);
+    if (bad) off[P + 1] = 1u;                               // (cleared by the host entry; the caller falls back to the dense pass)
+  }
+}
+
+// One workgroup: exclusive scan of off[0 .. P) in place, off[P] = total
+__global__ void __launch_bounds__(1024) top_scan_kernel(uint32_t P, uint32_t *__restrict__ off) {
   __shared__ uint32_t cell[1024];
   __shared__ uint32_t carry;
   const uint32_t tid = threadIdx.x;
@@ -27,17 +47,7 @@ __global__ void __launch_bounds__(1024) top_count_kernel(const uint32_t *__restr
   __syncthreads();
   for (uint32_t base = 0; base < P; base += 1024) {
     const uint32_t s = base + tid;
-    uint32_t cnt = 0;
-    if (s < P) {
-      const uint32_t r = targets[s], e0 = indptr[r], e1 = indptr[r + 1];
-      bool self = false, bad = false;
-      for (uint32_t e = e0; e < e1; e++) {
-        self |= indices[e] == r;
-        bad |= e > e0 && indices[e] <= indices[e - 1];       // repeated or unordered neighbours: T would list a row twice
-      }
-      cnt = (e1 - e0) + (self ? 0u : 1u);
-      if (bad) off[P + 1] = 1u;                               // (cleared by the host entry; the caller falls back to the dense pass)
-    }
+    const uint32_t cnt = s < P ? off[s] : 0u;
     cell[tid] = cnt;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -119,7 +129,8 @@ extern "C" int sl_top_plan(const uint32_t *d_indptr, const uint32_t *d_indices, 
     return set_error(SG_ERR_INVALID, "sl_top_plan: null argument");
   hipStream_t st = (hipStream_t)stream;
   SHD_HIP(hipMemsetAsync(d_off + num_subg + 1, 0, 4, st));
-  hipLaunchKernelGGL(top_count_kernel, dim3(1), dim3(1024), 0, st, d_indptr, d_indices, d_targets, num_subg, d_off);
+  hipLaunchKernelGGL(top_count_kernel, dim3((num_subg + 3) / 4), dim3(256), 0, st, d_indptr, d_indices, d_targets, num_subg, d_off);
+  hipLaunchKernelGGL(top_scan_kernel, dim3(1), dim3(1024), 0, st, num_subg, d_off);
   hipLaunchKernelGGL(top_fill_kernel, dim3((num_subg + 3) / 4), dim3(256), 0, st, d_indptr, d_indices, d_targets, num_subg, d_off, cap, d_T, d_slot,
                      d_epos, d_self_idx);
   SHD_HIP(hipGetLastError());

@@ -149,6 +149,8 @@ class GradSync:
     def _pack(self, s):
         """Gradients of slice s into the flat buffer (one multi-tensor copy); ``.grad`` becomes the buffer's view."""
         lo, hi = self._slices[s]
+        from . import ops
+        ops.join_aux()               # (weight gradients computed on the auxiliary stream of the chained backward)
         dst, src = [], []
         for i in range(lo, hi):
             g = self.params[i].grad

@@ -1310,6 +1310,8 @@ class _SageDense(torch.autograd.Function):
         pack = torch.empty(lib.sl_sage_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, want_dx)
         opt = lambda t: t.data_ptr() if t is not None else None
+        aux = _aux_stream(dev) if (_AUX["armed"] and ctx.x_amax is not None and n >= AMAX_HANDOVER_ROWS and Fi == 256 and Fo == 256) else None
+        lib.sl_set_aux_stream(aux.cuda_stream if aux is not None else None)
         check(lib.sl_sage_bwd_chain(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi,
                                     Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]), Wn.data_ptr(), Wn.stride(0), opt(biases[1]),
                                     sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX),
@@ -1319,6 +1321,14 @@ class _SageDense(torch.autograd.Function):
                                     up.amax.data_ptr() if (dz_ready and up.amax is not None) else None,
                                     dout_rows.data_ptr() if dout_rows is not None else None,
                                     int(dout_rows.numel()) if dout_rows is not None else 0, opt(ctx.x_amax), _stream(Zs)))
+        if aux is not None:
+            # the weight-gradient kernels may still run when these tensors are dropped: their blocks must not be handed out
+            # again before the auxiliary stream is done with them
+            lib.sl_set_aux_stream(None)
+            for t_ in (X, buf, pack, tn_partial, dWs, dWn, ctx.x_amax, up.amax if (dz_ready and up.amax is not None) else None):
+                if t_ is not None:
+                    t_.record_stream(aux)
+            _AUX["dirty"] = aux
         if dz_ready:
             up.release()
         if dout_rows is not None:
@@ -1438,6 +1448,33 @@ class _SageDense(torch.autograd.Function):
 
 # (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (SHADOW_ROW_STATS=0: recomputed)
 ROW_STATS_HANDOVER = os.environ.get("SHADOW_ROW_STATS", "1") != "0"
+# Weight-gradient kernels of the chained backward on a second stream, beside the input-gradient kernel of the same layer
+# (sl_set_aux_stream).  Armed by DeepGNN.step around its backward pass (it joins the stream before the gradients are read);
+# SHADOW_BWD_AUX_STREAM=0 switches it off.
+BWD_AUX_STREAM = os.environ.get("SHADOW_BWD_AUX_STREAM", "1") != "0"
+_AUX = {"streams": {}, "armed": False, "dirty": None}
+
+
+def arm_aux_stream(on: bool):
+    """DeepGNN.step: True before loss.backward(), False (after join_aux) behind it."""
+    _AUX["armed"] = bool(on) and BWD_AUX_STREAM
+
+
+def _aux_stream(dev):
+    st = _AUX["streams"].get(dev)
+    if st is None:
+        st = _AUX["streams"][dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def join_aux():
+    """The current stream waits for the auxiliary stream's weight-gradient kernels (no-op when none were launched)."""
+    st = _AUX["dirty"]
+    if st is not None:
+        torch.cuda.current_stream(st.device).wait_stream(st)
+        _AUX["dirty"] = None
+
+
 # Chained GraphSAGE backward (sl_sage_bwd_chain): on unless SHADOW_CHAIN_SAGE_BWD=0
 CHAIN_SAGE_BWD = os.environ.get("SHADOW_CHAIN_SAGE_BWD", "1") != "0"
 
