@@ -1,6 +1,8 @@
 """cProfile of the host side of the train step at a small batch (arxiv shape, SAGE-5, 256 roots; or gcn3 / 32 roots):
 which Python frames the host-bound configurations spend their time in (development aid)."""
-import cProfile, pstats, sys, numpy as np, torch
+import cProfile, os, pstats, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
 from shadow_gnn_amd import dist as sdist
 from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
 from shadow_gnn_amd.models import DeepGNN

@@ -1449,9 +1449,12 @@ class _SageDense(torch.autograd.Function):
 # (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (SHADOW_ROW_STATS=0: recomputed)
 ROW_STATS_HANDOVER = os.environ.get("SHADOW_ROW_STATS", "1") != "0"
 # Weight-gradient kernels of the chained backward on a second stream, beside the input-gradient kernel of the same layer
-# (sl_set_aux_stream).  Armed by DeepGNN.step around its backward pass (it joins the stream before the gradients are read);
-# SHADOW_BWD_AUX_STREAM=0 switches it off.
-BWD_AUX_STREAM = os.environ.get("SHADOW_BWD_AUX_STREAM", "1") != "0"
+# (sl_set_aux_stream).  Armed by DeepGNN.step around its backward pass (it joins the stream before the gradients are read).
+# OFF by default -- measured slower (two A/B pairs on one box, products benchmark: 6.72 / 6.71 ms per step without, 6.84 / 6.79
+# with): the two kernels cannot share a CU (137 KB + 2 x 64 KB of LDS), so they time-slice the chip and contend for HBM --
+# overlapped they take 0.74 + 0.83 ms of event time per layer against 0.53 + 0.27 one after the other -- and what the tails
+# gain is less than that costs.  SHADOW_BWD_AUX_STREAM=1 switches it on.
+BWD_AUX_STREAM = os.environ.get("SHADOW_BWD_AUX_STREAM", "0") == "1"
 _AUX = {"streams": {}, "armed": False, "dirty": None}
 
 
