@@ -557,7 +557,9 @@ int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const v
  * it -- with it (and n >= 32768, Fin = Fout = 256) the two weight gradients run on two fp16 pieces (sl_gemm_tn_f16), the
  * neighbour branch as dWn = (A^T dZn)^T X over the transposed aggregate of the input-gradient product (d_AX is then not
  * read, and d_tn_partial must hold TWICE the floats of sl_gemm_tn_f32's: sl_gemm_tn_f16_pair).
- * sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, stream).                                              */
+ * sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, stream).
+ * d_dWs == d_dWn == NULL (round 4): the weight gradients are not computed (a caller that knows dZ to be non-zero on a few rows
+ * only forms them on those rows itself); d_tn_partial may then be NULL too.                                                  */
 typedef struct {
   const float *Zs, *Zn;            /* [n, F] pre-activations of the layer below (dense rows) */
   const float *bs, *bn;            /* its biases (may be NULL) */

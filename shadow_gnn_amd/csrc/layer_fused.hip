@@ -210,7 +210,10 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
                                  float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
                                  void *d_pack, int dz_ready, const sl_sage_below *below, float *d_dzs_amax,
                                  const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, void *stream) {
-  if (!adj || !d_X || !d_AX || !d_Ws || !d_Wn || !d_dWs || !d_dWn || !d_buf || !d_tn_partial || !d_pack)
+  // (d_dWs == d_dWn == NULL: the caller computes the weight gradients itself -- on the few rows dZ is non-zero on, see
+  //  ops._SageDense: the layer below a row-sparse top pass)
+  const bool want_dw = d_dWs || d_dWn;
+  if (!adj || !d_X || !d_AX || !d_Ws || !d_Wn || (want_dw && (!d_dWs || !d_dWn || !d_tn_partial)) || !d_buf || !d_pack)
     return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
   if (!dz_ready && (!d_Zs || !d_Zn || !d_scale || !d_offset || !d_dscale || !d_doffset || !d_an_partial || (!d_dout && !d_dout_dropped)))
     return set_error(SG_ERR_INVALID, "sl_sage_bwd: null argument");
@@ -304,6 +307,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       return rc;
     }
   }
+  if (!want_dw) return SG_OK;
   // Weight gradients.  With the row maxima of [dZs | A^T dZn] (amx: the K = 2 Fout operand of the input gradient above) and
   // of X in hand, both run on two fp16 pieces (sl_gemm_tn_f16) -- the neighbour branch as
   //     dWn = dZn^T (A X) = (A^T dZn)^T X

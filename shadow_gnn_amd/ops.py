@@ -994,6 +994,7 @@ class ChainLink:
         self.drop = (0.0, 0)
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
         self.stats = None            # [n, 4] (mean, 1 / std) per row and branch, left by the forward GEMM epilogue (or None)
+        self.rows = None             # int32 row ids outside which the dZ in ``buf`` is zero (left by a row-sparse top pass), or None
 
     def publish(self, Zs, Zn, biases, sc, of, act, drop, stats=None):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
@@ -1002,7 +1003,7 @@ class ChainLink:
 
     def release(self):
         self.published = self.filled = False
-        self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = None
+        self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = self.rows = None
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
 
 
@@ -1305,8 +1306,17 @@ class _SageDense(torch.autograd.Function):
                                      down.buf.data_ptr(), down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi),
                                      down.partial.data_ptr(), down.amax.data_ptr(), opt(down.stats))
         dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
-        dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
-        tn_partial = torch.empty((2 if ctx.x_amax is not None else 1) * lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)   # (both weight gradients in one launch)
+        # dZ non-zero on a few rows only (the layer above ran its row-sparse pass): dWs = dZs[T]^T X[T], dWn = dZn[T]^T (A X)[T] on
+        # those rows (21 k of 289 k) instead of the paired kernel over all of them
+        sparse_rows = up.rows if (dz_ready and up.rows is not None and SPARSE_TOP_BWD) else None
+        if sparse_rows is not None:
+            Tl = sparse_rows.long()
+            dWs = weight_grad(buf[:, :Fo].index_select(0, Tl), X.index_select(0, Tl))
+            dWn = weight_grad(buf[:, 2 * Fo:].index_select(0, Tl), AX.index_select(0, Tl))
+            tn_partial = None
+        else:
+            dWs, dWn = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32)
+            tn_partial = torch.empty((2 if ctx.x_amax is not None else 1) * lib.sl_gemm_tn_slices(n) * Fo * Fi, **f32)   # (both weight gradients in one launch)
         pack = torch.empty(lib.sl_sage_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, want_dx)
         opt = lambda t: t.data_ptr() if t is not None else None
@@ -1315,8 +1325,9 @@ class _SageDense(torch.autograd.Function):
         check(lib.sl_sage_bwd_chain(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi,
                                     Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]), Wn.data_ptr(), Wn.stride(0), opt(biases[1]),
                                     sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX),
-                                    dWs.data_ptr(), dWn.data_ptr(), opt(dbi), opt(dsc), opt(dof), buf.data_ptr(), opt(an_partial),
-                                    tn_partial.data_ptr(), pack.data_ptr(), 1 if dz_ready else 0,
+                                    dWs.data_ptr() if sparse_rows is None else None, dWn.data_ptr() if sparse_rows is None else None,
+                                    opt(dbi), opt(dsc), opt(dof), buf.data_ptr(), opt(an_partial),
+                                    opt(tn_partial), pack.data_ptr(), 1 if dz_ready else 0,
                                     C.byref(below) if below is not None else None,
                                     up.amax.data_ptr() if (dz_ready and up.amax is not None) else None,
                                     dout_rows.data_ptr() if dout_rows is not None else None,
@@ -1391,6 +1402,7 @@ class _SageDense(torch.autograd.Function):
                                                    dz_out=[down.buf[:, :Fi], down.buf[:, 2 * Fi:]], row_idx=plan.T32, dz0_amax=down.amax)
         _SageDense._dbg("an_bwd below ok")
         down.partial = None
+        down.rows = plan.T32           # (dZs / dZn of the layer below are zero outside T: its weight gradients need those rows only)
         lr.release()
         down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)
         down.filled = True
