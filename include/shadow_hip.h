@@ -309,6 +309,14 @@ int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, c
  * (drop_p, drop_seed), row = batch row i) -- read ONCE while the subgraph tile is staged in LDS.  d_Xout (optional,
  * [n, F]) receives the gathered (+ dropped) rows for the layer's other consumers (the self Linear of GraphSAGE, the
  * weight gradients).  Y = diag(row_scale) (A o w) diag(col_scale) X as above.  F % 4 == 0, 16-byte aligned rows.   */
+/* Y = A . table[ids] on a block-diagonal batch adjacency: the input rows come through a row map (ids[r] = the row of `table` that
+ * stands for batch row r; many rows may share one -- a zero row for the rows a row-sparse gradient does not reach); d_row_amax
+ * (may be NULL) joins the row maxima of Y as sl_spmm_blockdiag_f32 does.  F % 4 == 0, 16-byte aligned rows.               */
+int sl_spmm_blockdiag_rows_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                               const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                               const float *d_table, int64_t ldt, const uint32_t *d_ids, float *d_Y, int64_t ldy, uint32_t n,
+                               uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                               uint32_t max_subg_nodes, float *d_row_amax, void *stream);
 int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_table, int64_t ldt, const uint32_t *d_ids, float drop_p,
@@ -419,6 +427,15 @@ int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *ldz, const f
  * d_partial: float[2048 * nb * 3 * F] scratch for the two-stage reduction.
  * Dual mode: d_dout_dropped != NULL is the gradient of d_out_dropped (goes through the mask), d_dout the gradient
  * of the plain output and may then be NULL (= zero).                            */
+/* sl_act_norm_bwd with d_row_idx and dz_compact != 0: d_dZ[b] / d_dz0_amax are compact too ([n, F] / [n] in the order of
+ * d_row_idx) instead of scattered into full-height buffers -- only Z and the dropout mask are addressed through the row ids. */
+int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                         const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                         uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
+                         const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
+                         float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped,
+                         int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx, int dz_compact,
+                         void *stream);
 int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
@@ -543,6 +560,16 @@ int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_amax, const v
                    const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz,
                    float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                    float *d_dz0_amax, const float *d_row_stats, void *stream);
+/* The same with a ROW-SPARSE ADDEND of the product: G = A . B^T + scatter(corr), row i of G gets d_corr[d_corr_row[i], :]
+ * ([corr_rows, N], pitch ldcorr) when d_corr_row[i] < corr_rows.  What it is for: [dZs | A^T dZn] . [Ws ; Wn] with dZs non-zero on
+ * a few rows only (the layer below a row-sparse top pass) = (A^T dZn) . Wn-part as a K = Fout product + (dZs[T] . Ws-part) on those
+ * rows, added before the act + norm backward of the epilogue uses G.  d_corr NULL: sl_gemm_an_bwd.                              */
+int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
+                        int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
+                        const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz,
+                        float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                        float *d_dz0_amax, const float *d_row_stats, const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row,
+                        uint32_t corr_rows, void *stream);
 
 /* Backward of a GraphSAGE layer chained with the layer below it (consecutive GraphSAGE layers where nothing but this
  * layer reads the lower layer's output -- residue 'none' + centre pooling, shaDow/layers.py:159-163): the input gradient

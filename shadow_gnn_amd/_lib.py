@@ -162,6 +162,9 @@ SIGNATURES = {
     "sl_gemm_an_bwd": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
                                   C.c_float, C.c_uint64, _P, _P, _P]),
+    "sl_gemm_an_bwd_corr": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
+                                  C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
+                                  C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, C.c_uint32, _P]),
     "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
@@ -187,17 +190,22 @@ SIGNATURES = {
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_top_plan": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_dx": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
+    "sl_spmm_blockdiag_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P,
+                                              C.c_uint32, C.c_uint32, _P, _P]),
     "sl_zero_slices": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, C.c_uint32, _P]),
     "sl_act_norm_bwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
                                    C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P]),
+    "sl_act_norm_bwd_rows": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
+                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
+                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, C.c_int, _P]),
 }
 
 _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 15      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 16      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -749,6 +749,8 @@ struct ActNormParams {
   // backward, optional: the output gradient is given for `n` SELECTED rows only (dout / dout2 are [n, F] compact, row i of
   // them belongs to row row_idx[i] of Z / dZ / the dropout mask) -- a read-out that takes a few rows of the layer's output
   const uint32_t *row_idx;
+  // ... and dZ / dz0_amax are compact as well ([n, F] in the order of row_idx) instead of scattered into full-height buffers
+  int dz_compact;
 };
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
@@ -866,13 +868,13 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
         if (lane_on && (p.dZ[b] || p.dbias)) {
           dh.x *= act_bwd(p.act[b], z.x, h.x); dh.y *= act_bwd(p.act[b], z.y, h.y);
           dh.z *= act_bwd(p.act[b], z.z, h.z); dh.w *= act_bwd(p.act[b], z.w, h.w);
-          if (p.dZ[b]) st4s(p.dZ[b] + (int64_t)rr * p.lddz[b] + f, dh);
+          if (p.dZ[b]) st4s(p.dZ[b] + (int64_t)(p.dz_compact ? r : rr) * p.lddz[b] + f, dh);
           gb[b].x += dh.x; gb[b].y += dh.y; gb[b].z += dh.z; gb[b].w += dh.w;
           zmax = amax4(dh);
         }
         if (b == 0 && p.dz0_amax) {        // (the LPR lanes of a row group share r: the reduction is uniform over the group)
           zmax = group_max<LPR>(zmax);
-          if (l == 0) p.dz0_amax[rr] = zmax;
+          if (l == 0) p.dz0_amax[p.dz_compact ? r : rr] = zmax;
         }
       }
     }
@@ -1323,6 +1325,27 @@ extern "C" int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint
                                d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, nullptr, stream_);
 }
 
+// Y = A . table[ids] on a block-diagonal A: the input rows are taken through a row map (ids[r] = row of `table` that stands for
+// batch row r; many rows may share one -- e.g. a zero row for the rows a row-sparse gradient does not reach), joined row maxima
+// of Y as in sl_spmm_blockdiag_f32.
+extern "C" int sl_spmm_blockdiag_rows_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                          const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                                          const float *d_table, int64_t ldt, const uint32_t *d_ids, float *d_Y, int64_t ldy, uint32_t n,
+                                          uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
+                                          uint32_t max_subg_nodes, float *d_row_amax, void *stream_) {
+  if (!d_indptr || !d_table || !d_ids || !d_Y || !d_subg_node_off || !d_subg_edge_off)
+    return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_rows_f32: null argument");
+  if (n == 0 || F == 0 || num_subg == 0) return SG_OK;
+  if ((F % 4) || (ldt % 4) || (ldy % 4) || !aligned16(d_table) || !aligned16(d_Y))
+    return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_rows_f32: needs F %% 4 == 0 and 16-byte aligned rows");
+  BdGather bg;
+  int rc;
+  if ((rc = make_drop(&bg, 0.f, 0, "sl_spmm_blockdiag_rows_f32")) != SG_OK) return rc;
+  bg.table = d_table; bg.ldt = ldt; bg.ids = d_ids; bg.xout = nullptr; bg.ldxo = 0;
+  return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_table, ldt, d_Y, ldy, n, F,
+                               d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, d_row_amax, stream_);
+}
+
 static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
@@ -1546,6 +1569,14 @@ extern "C" int sl_act_norm_fwd(int nb, const float *const *d_Z, const int64_t *l
   return SG_OK;
 }
 
+extern "C" int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                                    const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                                    uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                                    float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                                    float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                                    const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                                    int dz_compact, void *stream_);
+
 extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                                const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                                uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
@@ -1553,6 +1584,18 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
                                float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                                const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
                                void *stream_) {
+  return sl_act_norm_bwd_rows(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale, d_doffset,
+                              d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, d_row_idx, 0, stream_);
+}
+
+extern "C" int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                                    const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                                    uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                                    float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                                    float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                                    const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                                    int dz_compact, void *stream_) {
+  if (dz_compact && !d_row_idx) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_rows: compact dZ without row indices");
   int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
   if (!d_scale || !d_offset || (!d_dout && !d_dout_dropped) || !d_dscale || !d_doffset || !d_dZ)
@@ -1585,6 +1628,7 @@ extern "C" int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *l
   if (d_dz0_amax && !d_dZ[0]) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of a gradient that is not written");
   p.dz0_amax = d_dz0_amax;
   p.row_idx = d_row_idx;
+  p.dz_compact = dz_compact ? 1 : 0;
   bool vec = false;
   if ((rc = act_norm_launch(p, true, st, &vec, d_row_idx != nullptr)) != SG_OK) return rc;
   // (the general kernel does not write the row maxima: one more pass)

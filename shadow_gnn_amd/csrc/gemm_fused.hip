@@ -65,6 +65,11 @@ struct FusedDesc {
   float *partial;                   // [grid, nb, 3, N]
   float *dz_amax;                   // optional: row maxima of dZ[0] (the left half of the next K = 2F operand)
   const float *stats_r;             // optional [M, 2 NBA]: the row statistics the forward epilogue left (stats_w); NULL: recomputed
+  // backward, optional: a row-sparse ADDEND of the product -- row i of G gets corr[corr_row[i], :] added before the epilogue
+  // uses it when corr_row[i] < corr_rows (G = A B^T + scatter(corr): the part of a K-concatenated product whose operand rows
+  // are non-zero on a few rows only, computed on those rows by the caller)
+  const float *corr; int64_t ldcorr;
+  const uint32_t *corr_row; uint32_t corr_rows;
 };
 
 // The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass; 64 lanes in the backward form): the row
@@ -261,8 +266,10 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
     static_assert(P % D == 0, "");
     float4 zpre[D][NG > 0 ? NG : 1][Q];
     float spre[D][2 * NBA];                                 // (backward with kStats: the row's saved statistics, same look-ahead)
+    uint32_t cpre[D];                                       // (backward with a sparse addend: its row of corr, or >= corr_rows)
     auto load_pass = [&](int slot, uint64_t row) {
       const uint64_t rr = min(row, (uint64_t)M - 1);
+      if (MODE == 1) cpre[slot] = d.corr ? d.corr_row[rr] : 0xFFFFFFFFu;
       if (MODE == 1 && kStats) {
         if (NBA == 2) {                                   // (one 16-byte load, the same address in every lane of the row)
           const float4 sv = ld4(d.stats_r + rr * 4);
@@ -302,6 +309,18 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
       float stc[2 * NBA];
 #pragma unroll
       for (int kk = 0; kk < 2 * NBA; kk++) stc[kk] = (MODE == 1 && kStats) ? spre[k][kk] : 0.f;
+      if (MODE == 1) {
+        const uint32_t ci = cpre[k];
+        if (ci < d.corr_rows) {                             // (one row in fourteen: the rows the sparse addend reaches)
+#pragma unroll
+          for (int q = 0; q < Q; q++) {
+            if (on[q]) {
+              const float4 cv = ld4(d.corr + (int64_t)ci * d.ldcorr + 4 * (j + LPR * q));
+              own[q].x += cv.x; own[q].y += cv.y; own[q].z += cv.z; own[q].w += cv.w;
+            }
+          }
+        }
+      }
       if (pg + 1 < P / D) load_pass(k, row + (uint32_t)(RP * D));
       uint32_t rowh = 0;
       if (d.drop_thr) rowh = mix32((uint32_t)row ^ d.seed_lo) + (uint32_t)(row >> 32) + d.seed_hi;
@@ -855,6 +874,19 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_am
                               const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ,
                               const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
                               float drop_p, uint64_t drop_seed, float *d_dz0_amax, const float *d_row_stats, void *stream) {
+  return sl_gemm_an_bwd_corr(d_A, lda, d_a_amax, d_packed_B, M, N, K, nb, d_Z, ldz, d_bias, act, d_scale, d_offset, out_scale, d_dZ, lddz,
+                             d_dscale, d_doffset, d_dbias, d_partial, drop_p, drop_seed, d_dz0_amax, d_row_stats, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N,
+                                   uint32_t K, int nb,
+                                   const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
+                                   const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ,
+                                   const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
+                                   float drop_p, uint64_t drop_seed, float *d_dz0_amax, const float *d_row_stats,
+                                   const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row, uint32_t corr_rows, void *stream) {
+  if (d_corr && (!d_corr_row || (ldcorr & 3) || !al16(d_corr) || ldcorr < (int64_t)N))
+    return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd_corr: the sparse addend needs its row map, ld %% 4 == 0 >= N and 16-byte alignment");
   if (nb != 2) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: nb must be 2 (a GraphSAGE layer below)");
   if (!d_A || !d_packed_B || !d_Z || !ldz || !act || !d_scale || !d_offset || !d_dZ || !lddz || !d_dscale || !d_doffset || !d_partial)
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: null argument");
@@ -886,6 +918,7 @@ extern "C" int sl_gemm_an_bwd(const float *d_A, int64_t lda, const float *d_a_am
   p.partial = d_partial; p.dz_amax = d_dz0_amax;
   static const bool use_stats = !(getenv("SHADOW_FUSED_ROW_STATS") && getenv("SHADOW_FUSED_ROW_STATS")[0] == '0');
   p.stats_r = use_stats ? d_row_stats : nullptr;
+  p.corr = d_corr; p.ldcorr = ldcorr; p.corr_row = d_corr_row; p.corr_rows = d_corr ? corr_rows : 0;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_an_bwd")) != SG_OK) return rc;
   rc = N <= 128 ? launch_fused<4, 1, 1, 2>(p, st) : launch_fused<8, 1, 1, 2>(p, st);

@@ -550,7 +550,7 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
 
 
 def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None, row_idx=None,
-            dz0_amax=None):
+            dz0_amax=None, dz_compact=False):
     """``douts``: the gradient(s) autograd handed over -- (dout,) or, in dual mode, (dout_plain, dout_dropped) with
     None for an output nothing consumed.  ``dz_out``: optional preallocated dZ destinations (column slices of a
     wider buffer are fine).  ``row_idx`` (int32 [m]): the gradients are compact [m, F] and belong to those rows (a read-out
@@ -586,15 +586,16 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
     ldd = (C.c_int64 * nb)(*[(d.stride(0) if d is not None else 0) for d in dZs])
     ac = (C.c_int * nb)(*codes)
     with _timed(f"act_norm_bwd_nb{nb}_F{F}" if row_idx is None else f"act_norm_bwd_rows_nb{nb}_F{F}", (2 * nb + 1) * 4 * m * F, dev):
-        check(_lib.load().sl_act_norm_bwd(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
-                                          m, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
-                                          dout.stride(0) if dout is not None else 0, _ptr_array(dZs), ldd,
-                                          dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
-                                          partial.data_ptr(), float(drop[0]), int(drop[1]),
-                                          dout2.data_ptr() if dout2 is not None else None,
-                                          dout2.stride(0) if dout2 is not None else 0,
-                                          dz0_amax.data_ptr() if dz0_amax is not None else None,
-                                          row_idx.data_ptr() if row_idx is not None else None, _stream(Zs[0])))
+        # (dz_compact: with row_idx, dZ / dz0_amax are [m, F] / [m] in the order of row_idx -- the caller's dz_out)
+        check(_lib.load().sl_act_norm_bwd_rows(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
+                                               m, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
+                                               dout.stride(0) if dout is not None else 0, _ptr_array(dZs), ldd,
+                                               dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
+                                               partial.data_ptr(), float(drop[0]), int(drop[1]),
+                                               dout2.data_ptr() if dout2 is not None else None,
+                                               dout2.stride(0) if dout2 is not None else 0,
+                                               dz0_amax.data_ptr() if dz0_amax is not None else None,
+                                               row_idx.data_ptr() if row_idx is not None else None, 1 if dz_compact else 0, _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 
@@ -995,6 +996,7 @@ class ChainLink:
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
         self.stats = None            # [n, 4] (mean, 1 / std) per row and branch, left by the forward GEMM epilogue (or None)
         self.rows = None             # int32 row ids outside which the dZ in ``buf`` is zero (left by a row-sparse top pass), or None
+        self.compact = None          # (dZs[T] [t, F], dZn[T] with a zero row behind [t + 1, F], plan): dZ on the rows T only, no ``buf``
 
     def publish(self, Zs, Zn, biases, sc, of, act, drop, stats=None):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
@@ -1003,7 +1005,7 @@ class ChainLink:
 
     def release(self):
         self.published = self.filled = False
-        self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = self.rows = None
+        self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = self.rows = self.compact = None
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
 
 
@@ -1269,6 +1271,12 @@ class _SageDense(torch.autograd.Function):
             if g is None or g.data_ptr() != up.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("chained GraphSAGE backward: the lower layer's output has a consumer besides the layer above "
                                    "(its gradient is not the chain's placeholder); build the model with chaining off")
+            if up.compact is not None:
+                # the layer above ran its row-sparse pass: this layer's dZs / dZn exist on the rows T only
+                res = _SageDense._compact_dz_backward(ctx, up, down, X, AX, Ws, Wn, want_dx)
+                if res is not None:
+                    return res
+                _SageDense._densify(up, n, Fo)                 # (no chained layer below / shapes the row-mapped kernels do not take)
             buf, dsc, dof, dbi = up.buf, up.dsc, up.dof, up.dbi
             an_partial = None
         else:
@@ -1352,6 +1360,87 @@ class _SageDense(torch.autograd.Function):
         return dX, dWs, dWn, dbi, dsc, dof
 
     sparse_top_calls = 0     # backward passes of a top layer that ran on the rows R u N(R) only
+    compact_dz_calls = 0     # backward passes of the layer below such a pass that took dZ on the rows T only
+
+    @staticmethod
+    def _densify(up, n, F):
+        """Full-height [dZs | . | dZn] from the compact rows a row-sparse top pass left (the general fallback)."""
+        dZsT, dZnT, plan = up.compact
+        f32 = dict(dtype=torch.float32, device=dZsT.device)
+        up.buf = torch.empty(n, 3 * F, **f32)
+        check(_lib.load().sl_zero_slices(up.buf.data_ptr(), up.buf.data_ptr() + 8 * F, 3 * F, n, F, _stream(dZsT)))
+        Tl = plan.T32.long()
+        up.buf[:, :F].index_copy_(0, Tl, dZsT)
+        up.buf[:, 2 * F:].index_copy_(0, Tl, dZnT[:plan.t])
+        up.amax = None                  # (the C entry takes one more pass over dZs for its row maxima)
+        up.rows, up.compact = plan.T32, None
+
+    @staticmethod
+    def _compact_dz_backward(ctx, up, down, X, AX, Ws, Wn, want_dx):
+        """Backward pass of the layer BELOW a row-sparse top pass: dZs / dZn are given on the rows T (``up.compact``), zero elsewhere.
+            dWs = dZs[T]^T X[T],  dWn = dZn[T]^T (A X)[T]                                   (21 k of 289 k rows)
+            dX  = [dZs | A^T dZn] . [Ws ; Wn] = (A^T dZn) Wn  +  scatter_T(dZs[T] Ws)
+        -- the dense half as a K = F product over A^T dZn (transposed block-diagonal SpMM whose staging reads dZn through a row
+        map: the rows outside T share one zero row), the other half on the rows T, added in the GEMM's epilogue before it runs
+        the act + norm backward of the layer below (sl_gemm_an_bwd_corr).  No [n, F] tensor of zeros is written or read.
+        None: not applicable (the caller densifies)."""
+        lib = _lib.load()
+        dZsT, dZnT, plan = up.compact
+        n, Fo = ctx.saved_tensors[4].shape
+        Fi = X.shape[1]
+        c = ctx.adj.csr
+        off, eoff, mn = c.spmm_blocks
+        chain = down is not None and want_dx and down.Zs.shape == (n, Fi) and Fo % 32 == 0
+        if not (chain and off is not None and Fo >= BLOCKDIAG_MIN_F and Fo % 4 == 0 and lib.sl_gemm_act_norm_supported(Fi, Fo)
+                and plan.rowmap.numel() == n):
+            return None
+        dev = X.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _stream(X)
+        opt = lambda t_: t_.data_ptr() if t_ is not None else None
+        adj = ctx.adj
+        t = plan.t
+        Tl = plan.T32.long()
+        dWs = weight_grad(dZsT, X.index_select(0, Tl))
+        dWn = weight_grad(dZnT[:t], AX.index_select(0, Tl))
+        # A^T dZn over the row map (transposed structure: row scale <- the adjacency's column scale and vice versa)
+        ti, tx, tp = c.transposed
+        AtdZn = torch.empty(n, Fo, **f32)
+        amx = torch.zeros(n, **f32)
+        ew = adj.edge_w
+        nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
+        with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
+            check(lib.sl_spmm_blockdiag_rows_f32(ti.data_ptr(), tx.data_ptr(), opt(ew), tp.data_ptr() if ew is not None else None,
+                                                 opt(adj.col_scale), opt(adj.row_scale), dZnT.data_ptr(), dZnT.stride(0), plan.rowmap.data_ptr(),
+                                                 AtdZn.data_ptr(), Fo, n, Fo, off.data_ptr(), eoff.data_ptr(), int(off.numel()) - 1, mn,
+                                                 amx.data_ptr(), st))
+        corr = mm_nt(dZsT, Ws.t())                                  # dZs[T] Ws  [t, Fi]
+        pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        check(lib.sl_gemm_act_norm_pack_b2(Wn.data_ptr(), 1, Wn.stride(0), Fo, Wn.data_ptr(), 1, Wn.stride(0), Fi, Fo, pack.data_ptr(), st))
+        down.buf = torch.empty(n, 3 * Fi, **f32)
+        down.dsc, down.dof = torch.empty(2, Fi, **f32), torch.empty(2, Fi, **f32)
+        down.dbi = torch.empty(2, Fi, **f32) if any(b is not None for b in down.biases) else None
+        partial = torch.empty(lib.sl_gemm_an_bwd_partial_floats(n, Fi, 2), **f32)
+        down.amax = torch.empty(n, **f32)
+        ld2 = (C.c_int64 * 2)(Fi, Fi)
+        ld3 = (C.c_int64 * 2)(3 * Fi, 3 * Fi)
+        ac = (C.c_int * 2)(down.act, down.act)
+        dZb = (C.c_void_p * 2)(down.buf.data_ptr(), down.buf.data_ptr() + 8 * Fi)
+        nbytes = 4 * n * (Fo + 4 * Fi) + 4 * t * Fi                 # read A^T dZn and both Z of the layer below, write its two dZ (+ the addend)
+        with _timed(f"gemm_an_bwd_corr_nb2_N{Fi}", nbytes, dev, flops=2 * n * Fo * Fi):
+            check(lib.sl_gemm_an_bwd_corr(AtdZn.data_ptr(), Fo, amx.data_ptr(), pack.data_ptr(), n, Fi, Fo, 2, _ptr_array([down.Zs, down.Zn]), ld2,
+                                          _ptr_array(down.biases), ac, down.sc.data_ptr(), down.of.data_ptr(), 1.0, dZb, ld3,
+                                          down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi), partial.data_ptr(), float(down.drop[0]),
+                                          int(down.drop[1]), down.amax.data_ptr(), opt(down.stats), corr.data_ptr(), corr.stride(0),
+                                          plan.rowmap.data_ptr(), t, st))
+        down.partial = partial
+        down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)
+        down.filled = True
+        dsc, dof, dbi = up.dsc, up.dof, up.dbi
+        up.release()
+        _SageDense.chained_calls += 1
+        _SageDense.compact_dz_calls += 1
+        return down.dummy, dWs, dWn, dbi, dsc, dof
 
     @staticmethod
     def _dbg(msg):
@@ -1392,14 +1481,16 @@ class _SageDense(torch.autograd.Function):
                             plan.self_idx.data_ptr(), plan.targets32.data_ptr(), opt(adj.edge_w), opt(adj.row_scale), opt(adj.col_scale),
                             plan.t, Fi, dXT.data_ptr(), Fi, _stream(Zs)))
         _SageDense._dbg("dXT ok")
-        # the layer below: act_norm backward on the rows T of its output gradient, everything else of [dZs | . | dZn] cleared
-        down.buf = torch.empty(n, 3 * Fi, **f32)
-        check(lib.sl_zero_slices(down.buf.data_ptr(), down.buf.data_ptr() + 8 * Fi, 3 * Fi, n, Fi, _stream(Zs)))
-        down.amax = torch.zeros(n, **f32)
-        _SageDense._dbg("zero slices ok")
+        # the layer below: act_norm backward on the rows T of its output gradient; its dZs / dZn stay COMPACT ([t, F], a zero
+        # row behind dZn for the row-mapped transposed SpMM): nothing of height n is cleared or written here
+        dZsT = torch.empty(plan.t, Fi, **f32)
+        dZnT = torch.empty(plan.t + 1, Fi, **f32)
+        dZnT[plan.t].zero_()
         _dz, down.dsc, down.dof, down.dbi = _an_bwd([down.Zs, down.Zn], down.biases, (down.act, down.act), down.sc, down.of, Fi, 1.0,
                                                    (dXT,), [True, True], any(b is not None for b in down.biases), down.drop,
-                                                   dz_out=[down.buf[:, :Fi], down.buf[:, 2 * Fi:]], row_idx=plan.T32, dz0_amax=down.amax)
+                                                   dz_out=[dZsT, dZnT[:plan.t]], row_idx=plan.T32, dz_compact=True)
+        down.compact = (dZsT, dZnT, plan)
+        down.buf = down.amax = None
         _SageDense._dbg("an_bwd below ok")
         down.partial = None
         down.rows = plan.T32           # (dZs / dZn of the layer below are zero outside T: its weight gradients need those rows only)

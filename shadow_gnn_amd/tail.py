@@ -227,6 +227,11 @@ class TopBackwardPlan:
         self.ok = bool(P > 0 and bad == 0 and t <= cap)
         self.t = t if self.ok else 0
         self.T32, self.slot, self.epos, self.self_idx = T[:self.t], slot[:self.t], epos[:self.t], self_idx[:P]
+        # batch row -> its position in T, or t (= "the zero row behind a [t, F] compact tensor"): the row map of
+        # sl_spmm_blockdiag_rows_f32 / sl_gemm_an_bwd_corr
+        self.rowmap = torch.full((n,), self.t, **i32)
+        if self.ok:
+            self.rowmap[self.T32.long()] = torch.arange(self.t, **i32)
         self.n = n
         self.num_roots = P
         self._indptr_ptr = csr.indptr.data_ptr()
@@ -235,4 +240,4 @@ class TopBackwardPlan:
         return self.ok and csr.n == self.n and csr.indptr.data_ptr() == self._indptr_ptr and num_roots == self.num_roots
 
     def tensors(self):
-        return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx]
+        return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx, self.rowmap]
