@@ -310,13 +310,14 @@ int sl_spmm_blockdiag_f32(const uint32_t *d_indptr, const uint32_t *d_indices, c
  * [n, F]) receives the gathered (+ dropped) rows for the layer's other consumers (the self Linear of GraphSAGE, the
  * weight gradients).  Y = diag(row_scale) (A o w) diag(col_scale) X as above.  F % 4 == 0, 16-byte aligned rows.   */
 /* Y = A . table[ids] on a block-diagonal batch adjacency: the input rows come through a row map (ids[r] = the row of `table` that
- * stands for batch row r; many rows may share one -- a zero row for the rows a row-sparse gradient does not reach); d_row_amax
- * (may be NULL) joins the row maxima of Y as sl_spmm_blockdiag_f32 does.  F % 4 == 0, 16-byte aligned rows.               */
+ * stands for batch row r; ids[r] == zero_id: row r is all zeros and is not fetched -- the rows a row-sparse gradient does not
+ * reach; 0xFFFFFFFF: no such id); d_row_amax (may be NULL) joins the row maxima of Y as sl_spmm_blockdiag_f32 does.
+ * F % 4 == 0, 16-byte aligned rows.                                                                                          */
 int sl_spmm_blockdiag_rows_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                const float *d_table, int64_t ldt, const uint32_t *d_ids, float *d_Y, int64_t ldy, uint32_t n,
                                uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                               uint32_t max_subg_nodes, float *d_row_amax, void *stream);
+                               uint32_t max_subg_nodes, float *d_row_amax, uint32_t zero_id, void *stream);
 int sl_spmm_blockdiag_gather_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                                  const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                  const float *d_table, int64_t ldt, const uint32_t *d_ids, float drop_p,

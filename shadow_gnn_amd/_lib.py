@@ -191,7 +191,7 @@ SIGNATURES = {
     "sl_top_plan": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_dx": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_spmm_blockdiag_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P,
-                                              C.c_uint32, C.c_uint32, _P, _P]),
+                                              C.c_uint32, C.c_uint32, _P, C.c_uint32, _P]),
     "sl_zero_slices": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, C.c_uint32, _P]),
     "sl_act_norm_bwd": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,

@@ -457,6 +457,7 @@ struct BdGather {
   uint32_t drop_thr;        // 0: no dropout
   float drop_scale;
   uint32_t seed_lo, seed_hi;
+  uint32_t zero_id;         // ids[r] == zero_id: the row is all zeros and is not fetched (row-mapped inputs); 0xFFFFFFFF: none
 };
 
 __device__ __forceinline__ uint32_t bd_mix32(uint32_t h) {
@@ -479,7 +480,9 @@ __device__ __forceinline__ float4 bd_drop4(const BdGather &g, float4 v, uint64_t
 template <bool kGather>
 __device__ __forceinline__ float4 bd_load4(const BdGather &g, const float *__restrict__ X, int64_t ldx, uint64_t r, uint32_t f) {
   if (!kGather) return ld4(X + (int64_t)r * ldx + f);
-  return bd_drop4(g, ld4(g.table + (int64_t)g.ids[r] * g.ldt + f), r, f);
+  const uint32_t id = g.ids[r];
+  if (id == g.zero_id) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return bd_drop4(g, ld4(g.table + (int64_t)id * g.ldt + f), r, f);
 }
 
 // out[i, 0:F] = dropout(table[idx[i], :]), out[i, F:Fpad] = 0: the feature gather of a batch (shaDow/minibatch.py:469)
@@ -1172,6 +1175,7 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
 
 static int make_drop(BdGather *bg, float drop_p, uint64_t drop_seed, const char *who) {
   memset(bg, 0, sizeof(*bg));
+  bg->zero_id = 0xFFFFFFFFu;
   if (!(drop_p >= 0.f && drop_p < 1.f)) return set_error(SG_ERR_INVALID, "%s: drop_p = %g", who, drop_p);
   bg->drop_scale = 1.0f; bg->seed_lo = (uint32_t)drop_seed; bg->seed_hi = (uint32_t)(drop_seed >> 32);
   if (drop_p > 0.f) {
@@ -1332,7 +1336,7 @@ extern "C" int sl_spmm_blockdiag_rows_f32(const uint32_t *d_indptr, const uint32
                                           const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                                           const float *d_table, int64_t ldt, const uint32_t *d_ids, float *d_Y, int64_t ldy, uint32_t n,
                                           uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
-                                          uint32_t max_subg_nodes, float *d_row_amax, void *stream_) {
+                                          uint32_t max_subg_nodes, float *d_row_amax, uint32_t zero_id, void *stream_) {
   if (!d_indptr || !d_table || !d_ids || !d_Y || !d_subg_node_off || !d_subg_edge_off)
     return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_rows_f32: null argument");
   if (n == 0 || F == 0 || num_subg == 0) return SG_OK;
@@ -1341,7 +1345,7 @@ extern "C" int sl_spmm_blockdiag_rows_f32(const uint32_t *d_indptr, const uint32
   BdGather bg;
   int rc;
   if ((rc = make_drop(&bg, 0.f, 0, "sl_spmm_blockdiag_rows_f32")) != SG_OK) return rc;
-  bg.table = d_table; bg.ldt = ldt; bg.ids = d_ids; bg.xout = nullptr; bg.ldxo = 0;
+  bg.table = d_table; bg.ldt = ldt; bg.ids = d_ids; bg.xout = nullptr; bg.ldxo = 0; bg.zero_id = zero_id;
   return spmm_blockdiag_launch(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_table, ldt, d_Y, ldy, n, F,
                                d_subg_node_off, d_subg_edge_off, num_subg, max_subg_nodes, bg, d_row_amax, stream_);
 }

@@ -1413,7 +1413,7 @@ class _SageDense(torch.autograd.Function):
             check(lib.sl_spmm_blockdiag_rows_f32(ti.data_ptr(), tx.data_ptr(), opt(ew), tp.data_ptr() if ew is not None else None,
                                                  opt(adj.col_scale), opt(adj.row_scale), dZnT.data_ptr(), dZnT.stride(0), plan.rowmap.data_ptr(),
                                                  AtdZn.data_ptr(), Fo, n, Fo, off.data_ptr(), eoff.data_ptr(), int(off.numel()) - 1, mn,
-                                                 amx.data_ptr(), st))
+                                                 amx.data_ptr(), t, st))
         corr = mm_nt(dZsT, Ws.t())                                  # dZs[T] Ws  [t, Fi]
         pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
         check(lib.sl_gemm_act_norm_pack_b2(Wn.data_ptr(), 1, Wn.stride(0), Fo, Wn.data_ptr(), 1, Wn.stride(0), Fi, Fo, pack.data_ptr(), st))
