@@ -96,7 +96,13 @@ put("gemm_nt_split_N256_Ktail", "gemm_nt_split_kernel<1, 8, 1, 4, true>")
 # round 3: the GEMM-epilogue kernels (csrc/gemm_fused.hip) and the cooperative-split weight gradient
 put("gemm_act_norm_fwd_nb2_N256", "gemm_nt_fused_kernel<8, 0, 2, 2, false>")
 put("gemm_act_norm_fwd_nb2_N256_Ktail", "gemm_nt_fused_kernel<8, 0, 2, 2, true>")
-put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>")
+# round 4: the same kernel runs the K = 2F product (two launches per step) and the K = F product with the sparse addend (one)
+if [k for k in fetch if "gemm_nt_fused_kernel<8, 1, 1, 2, false>" in k] and len(clusters(fetch[find("gemm_nt_fused_kernel<8, 1, 1, 2, false>")])) >= 2:
+    put("gemm_an_bwd_corr_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>", 0, 2)
+    put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>", 1, 2)
+else:
+    put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>")
+put("spmm_rows_F256", "spmm_blockdiag_kernel<true>")
 if [k for k in fetch if "gemm_tn_f16_kernel" in k]:
     put("gemm_tn_f16_pair_N256", "gemm_tn_f16_kernel")
 if [k for k in fetch if "gemm_tn_coop_kernel<4, true>" in k]:
