@@ -66,7 +66,7 @@ def main():
         if v["total_ms"] < 0.5 and not k.startswith(("sg_", "gather")):
             continue
         rn = ROC.get(k)
-        rocus = next((f"{t:.1f}" for n, t in roc.items() if rn and rn in n), "—") if k not in ("spmm_F100", "spmm_F256") else (next((f"{t:.1f} (both widths)" for n, t in roc.items() if "spmm_blockdiag_kernel<false>" in n), "—") if k == "spmm_F256" else "—")
+        rocus = next((f"{t:.1f}" for n, t in roc.items() if rn and rn in n), "—") if k not in ("spmm_F100", "spmm_F256") else (next((f"{t:.1f} (both widths)" for n, t in roc.items() if ("spmm_blockdiag_kernel<false>" in n or "spmm_blockdiag_kernel<0>" in n)), "—") if k == "spmm_F256" else "—")
         by = None
         for name, e in (("roofline_hbm", d.get("roofline_hbm")), ("roofline_mfma", d.get("roofline_mfma"))):
             if e and e.get("kernel") == k:
@@ -90,7 +90,7 @@ def main():
                        f"{rs['ms_per_step']} ms = {rs['achieved']:.0f} GB/s = **{rs['frac']:.3f} of 8 TB/s** ({rs['kernel_ms_per_step']} ms of it inside the hand-written kernels).")
     out.append(f"North-star aggregate (k-hop sample + feature gather + SAGE aggregates, `roofline_north_star` of the bench line): "
                f"{r['bytes_per_step'] / 1e6:.0f} MB / {r['ms_per_step']} ms = {r['achieved']:.0f} GB/s = **{r['frac']:.3f} of 8 TB/s**; "
-               f"PMC traffic of those kernels {r['traffic'] / 1e6:.0f} MB per step." if r.get("traffic") else "")
+               + (f"PMC traffic of those kernels {r['traffic'] / 1e6:.0f} MB per step." if r.get("traffic") else ""))
     sa = d.get("sampler_alone")
     if sa:
         out.append(f"Sampler kernels with the GPU to themselves: {sa['avg_ms']} ms per call of {sa.get('batches_per_call', 1)} x 1 024 roots "

@@ -76,10 +76,12 @@ notes = {}
 
 
 def put(label, sub, which=None, of=None):
-    """t[label] = read + write bytes per launch of the kernel whose name contains `sub` (skipped when the run has none)."""
-    if not [k for k in fetch if sub in k]:
-        return
-    t[label] = sum(rw(sub, which, of))
+    """t[label] = read + write bytes per launch of the kernel whose name contains `sub` (a tuple: the first alternative the
+    run has -- kernel names change with their template arguments); skipped when the run has none."""
+    for one in ((sub,) if isinstance(sub, str) else sub):
+        if [k for k in fetch if one in k]:
+            t[label] = sum(rw(one, which, of))
+            return
 
 
 sel, plan, scan = rw("sg_select_lds_kernel"), rw("sg_plan_kernel"), rw("sg_scan_plain_kernel")
@@ -87,8 +89,8 @@ t["sg_sample_pipeline"] = sum(sel) + sum(plan) + sum(scan)
 notes["sg_sample_pipeline"] = dict(select=sel, plan=plan, scan=scan)
 put("sg_relocate_kernel", "sg_relocate_kernel")
 put("gather_F100", "gather_rows_drop_kernel")
-put("spmm_F100", "spmm_blockdiag_kernel<false>", 0, 2)
-put("spmm_F256", "spmm_blockdiag_kernel<false>", 1, 2)
+put("spmm_F100", ("spmm_blockdiag_kernel<0>", "spmm_blockdiag_kernel<false>"), 0, 2)
+put("spmm_F256", ("spmm_blockdiag_kernel<0>", "spmm_blockdiag_kernel<false>"), 1, 2)
 put("act_norm_fwd_nb2_F256", "act_norm_kernel<64, 64, false, 2>")
 put("act_norm_bwd_nb2_F256", "act_norm_kernel<64, 64, true, 2>")
 put("gemm_nt_split_N256", "gemm_nt_split_kernel<1, 8, 1, 4, false>")
@@ -102,7 +104,7 @@ if [k for k in fetch if "gemm_nt_fused_kernel<8, 1, 1, 2, false>" in k] and len(
     put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>", 1, 2)
 else:
     put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>")
-put("spmm_rows_F256", "spmm_blockdiag_kernel<true>")
+put("spmm_rows_F256", ("spmm_blockdiag_kernel<2>", "spmm_blockdiag_kernel<true>"))
 if [k for k in fetch if "gemm_tn_f16_kernel" in k]:
     put("gemm_tn_f16_pair_N256", "gemm_tn_f16_kernel")
 if [k for k in fetch if "gemm_tn_coop_kernel<4, true>" in k]:

@@ -477,11 +477,14 @@ __device__ __forceinline__ float4 bd_drop4(const BdGather &g, float4 v, uint64_t
 }
 
 // row r of the (virtual) input matrix: dense X or the gathered, dropped table row
-template <bool kGather>
+// kGather: 0 dense X; 1 table[ids[r]] with the dropout hash (+ the dense copy xout); 2 table[ids[r]] through a plain row map
+// (rows mapped to zero_id are zeros and not fetched; no hash, no copy: the lean instantiation of sl_spmm_blockdiag_rows_f32 --
+// the full one spills 34 VGPRs at the kernel's 64-register cap)
+template <int kGather>
 __device__ __forceinline__ float4 bd_load4(const BdGather &g, const float *__restrict__ X, int64_t ldx, uint64_t r, uint32_t f) {
-  if (!kGather) return ld4(X + (int64_t)r * ldx + f);
+  if (kGather == 0) return ld4(X + (int64_t)r * ldx + f);
   const uint32_t id = g.ids[r];
-  if (id == g.zero_id) return make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kGather == 2) return id == g.zero_id ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(g.table + (int64_t)id * g.ldt + f);
   return bd_drop4(g, ld4(g.table + (int64_t)id * g.ldt + f), r, f);
 }
 
@@ -556,7 +559,7 @@ __device__ __forceinline__ void bd_row_amax(uint32_t *dst, float m, uint32_t l8)
 }
 
 // (two 1024-thread workgroups per CU = 8 wavefronts per SIMD: at most 64 VGPRs)
-template <bool kGather>
+template <int kGather>
 __global__ void __launch_bounds__(kBdBlock, 8)
 spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                       const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
@@ -592,7 +595,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
       rsv[k] = 1.0f;
       if (i < h.ns && pon) {
         xv[k] = bd_load4<kGather>(g, X, ldx, (uint64_t)h.a + i, f);
-        if (kGather && g.xout) st4(g.xout + (int64_t)(h.a + i) * g.ldxo + f, xv[k]);       // the dense copy of the staged rows
+        if (kGather == 1 && g.xout) st4(g.xout + (int64_t)(h.a + i) * g.ldxo + f, xv[k]);       // the dense copy of the staged rows
       }
       if (i < h.ns && row_scale) rsv[k] = row_scale[h.a + i];
     }
@@ -670,7 +673,7 @@ spmm_blockdiag_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__res
     } else if (cur.valid) {
       // oversize subgraph: gather the feature rows from global memory
       for (uint32_t i = rg; i < cur.ns; i += kBdBlock / 8) {
-        if (kGather && g.xout && on) st4(g.xout + (int64_t)(cur.a + i) * g.ldxo + f, bd_load4<kGather>(g, X, ldx, (uint64_t)cur.a + i, f));
+        if (kGather == 1 && g.xout && on) st4(g.xout + (int64_t)(cur.a + i) * g.ldxo + f, bd_load4<kGather>(g, X, ldx, (uint64_t)cur.a + i, f));
         const uint32_t p0 = indptr[cur.a + i], p1 = indptr[cur.a + i + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t p = p0; p < p1; p++) {
@@ -1364,8 +1367,8 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   cap_rows = (cap_rows + 31u) & ~31u;
   const size_t lds = (size_t)cap_rows * kBdRowPad * 4 + ((size_t)cap_rows + 4) * 4 + (size_t)kBdMaxEdges * 8;
   if (lds > 64 * 1024) {
-    SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<false>, lds));
-    SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<true>, lds));
+    SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<0>, lds));
+    SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<1>, lds));
   }
   const uint32_t tiles = (F / 4 + 7) / 8;            // <= 8 float4 columns per tile (bd_col4)
   // both operands on whole 128-byte lines per row: tiles = lines (SHADOW_SPMM_LINES=0: the even split)
@@ -1394,12 +1397,17 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   if (total + 2 * (uint64_t)ncu * per_cu >= ((uint64_t)1 << 32))
     return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: too many (subgraph, tile) items");
   const uint32_t grid = (uint32_t)std::min<uint64_t>(total, (uint64_t)ncu * per_cu);
-  if (bg.table)
-    hipLaunchKernelGGL(spmm_blockdiag_kernel<true>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
+  if (bg.table && bg.zero_id != 0xFFFFFFFFu && !bg.drop_thr && !bg.xout) {
+    if (lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)spmm_blockdiag_kernel<2>, lds));
+    hipLaunchKernelGGL(spmm_blockdiag_kernel<2>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
+                       d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
+                       tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax), lines);
+  } else if (bg.table)
+    hipLaunchKernelGGL(spmm_blockdiag_kernel<1>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
                        d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
                        tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax), lines);
   else
-    hipLaunchKernelGGL(spmm_blockdiag_kernel<false>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
+    hipLaunchKernelGGL(spmm_blockdiag_kernel<0>, dim3(grid), dim3(kBdBlock), lds, st, d_indptr, d_indices, d_edge_w, d_edge_perm,
                        d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, F, d_subg_node_off, d_subg_edge_off, num_subg, tiles,
                        tg, cap_rows, bg, reinterpret_cast<uint32_t *>(d_row_amax), lines);
   SHD_HIP(hipGetLastError());
