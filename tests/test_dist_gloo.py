@@ -179,3 +179,41 @@ def test_flat_adam_steps_without_an_explicit_all_reduce_and_speaks_torch_adam_st
     opt2.load_state_dict(topt.state_dict())
     assert opt2.step_count == 3 and opt2.lr == 0.01
     assert torch.allclose(opt2.exp_avg, opt.exp_avg, rtol=1e-5, atol=1e-8) and torch.allclose(opt2.exp_avg_sq, opt.exp_avg_sq, rtol=1e-5, atol=1e-10)
+
+
+def _pin_worker(local_rank, local_world, q):
+    import os
+    from shadow_gnn_amd import dist as sdist
+    before = sorted(os.sched_getaffinity(0))
+    info = sdist.pin_host_threads(local_rank, local_world)
+    q.put((local_rank, before, sorted(os.sched_getaffinity(0)), info, torch.get_num_threads()))
+
+
+def test_pin_host_threads_gives_every_rank_its_own_cpu_slice():
+    """dist.pin_host_threads: N ranks on one host get disjoint, contiguous slices of the allowed hardware threads that
+    together cover them (up to the remainder), torch's intra-op pool is capped to the slice, and a single-rank run is left
+    alone (bench.py's CPU baselines want every core)."""
+    import os
+    import torch.multiprocessing as mp
+    from shadow_gnn_amd import dist as sdist
+    avail = sorted(os.sched_getaffinity(0))
+    assert sdist.pin_host_threads(0, 1) == dict(pinned=False) and sorted(os.sched_getaffinity(0)) == avail
+    if len(avail) < 2:
+        pytest.skip("one hardware thread: nothing to slice")
+    world = 2 if len(avail) < 8 else 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pin_worker, args=(r, world, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per = len(avail) // world
+    seen = []
+    for r, before, after, info, nthreads in res:
+        assert before == avail and info["pinned"] and after == avail[r * per:(r + 1) * per]
+        assert info["n_cpus"] == per and nthreads == min(8, per) == info["torch_threads"]
+        seen += after
+    assert len(seen) == len(set(seen)) == per * world
