@@ -296,7 +296,8 @@ def main():
     # backward pass runs on the rows it is non-zero on (exact; tail.TopBackwardPlan, --dense-top-backward switches it off)
     if args.dense_top_backward:
         ops.SPARSE_TOP_BWD = False
-    mb.top_backward_plan = bool(ops.SPARSE_TOP_BWD and wl["aggr"] == "sage" and model._tail_prunable(0) and not args.prune_tail)
+    mb.top_backward_plan = bool(ops.SPARSE_TOP_BWD and wl["aggr"] in ("sage", "gat") and model._tail_prunable(0) and not args.prune_tail)
+    mb.top_backward_compact = wl["aggr"] == "gat"        # (GAT's attention backward runs on the roots' rows as a t x t CSR)
     model.prune_tail = bool(args.prune_tail)
     if args.prune_tail and model._tail_prunable(0):
         mb.tail_plan_layers = wl["layers"]

@@ -104,6 +104,8 @@ class shaDowLayer(nn.Module):
         self.chain_next = False
         # True (set per step by DeepGNN._plan_dropout_fusion): only a row-selecting read-out reads this layer's output
         self.roots_only = False
+        # True (set per step by DeepGNN._plan_dropout_fusion): only the next GAT layer's paired Linear reads this output
+        self.rows_next = False
         if norm not in ('norm_feat', 'none'):
             raise NotImplementedError("only norm in {'norm_feat', 'none'} (the reference's pairnorm path is unfinished, layers.py:358)")
         self.norm = norm
@@ -450,7 +452,7 @@ class GAT(shaDowLayer):
         if self.norm == 'norm_feat' and self.act is None:
             # (one autograd node for the aggregate and the normalisation when the fused kernels take the shape)
             res = ops_gat.gat_tail(adj_norm, z_self, z_neigh, self.attention, self.kact, self.mulhead, self.scale, self.offset,
-                                   seg=self.dim_slice, out_scale=0.5, roots_only=self.roots_only, **self._drop_kw())
+                                   seg=self.dim_slice, out_scale=0.5, roots_only=self.roots_only or self.rows_next, **self._drop_kw())
             if res is not None:
                 return self._emit(res), adj_norm, True, 0.
         feat_neigh = ops_gat.gat_aggregate(adj_norm, z_self, z_neigh, self.attention, self.kact,

@@ -210,6 +210,7 @@ class MinibatchShallowExtractor:
         # True: every batch carries the row sets of the row-sparse top-layer backward (tail.TopBackwardPlan; node tasks whose
         # read-out takes the roots' rows of the last GraphSAGE layer), built on the prefetch stream like the tail plan
         self.top_backward_plan = False
+        self.top_backward_compact = False  # ... with the roots' rows as a square CSR over T (GAT stacks: tail.TopBackwardPlan.compact_csr)
         # (priority -1 = high: when the deferred sampler call meets the GEMMs of the step, its workgroups take the CU slots
         #  as they free up instead of queueing behind the GEMM's grid; SHADOW_PREFETCH_PRIORITY=0 for a normal stream)
         prio = int(os.environ.get("SHADOW_PREFETCH_PRIORITY", "-1"))
@@ -428,7 +429,7 @@ class MinibatchShallowExtractor:
         stream bookkeeping as in _tail_plan."""
         from . import tail
         if self._side is None:
-            return tail.TopBackwardPlan(adj, subgs.target)
+            return tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact)
         main = torch.cuda.current_stream(self.device)
         # (as in _tail_plan: the plan allocates on the side stream BEFORE the next _launch orders that stream behind the
         #  training stream -- every sampler output of this batch must therefore be recorded on the training stream, or a block
@@ -438,7 +439,7 @@ class MinibatchShallowExtractor:
             if t is not None and t.is_cuda:
                 t.record_stream(main)
         with torch.cuda.stream(self._side):
-            plan = tail.TopBackwardPlan(adj, subgs.target)
+            plan = tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact)
         main.wait_stream(self._side)
         for t in plan.tensors():
             t.record_stream(main)

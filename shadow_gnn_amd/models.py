@@ -239,6 +239,10 @@ class DeepGNN(nn.Module):
             # (node tasks: one root per subgraph, so the selected rows are distinct)
             md.roots_only = bool(not dual and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT))
                                  and self.prediction_task == 'node')
+            # GAT below GAT, nothing else reads this output and the next layer's input dropout is fused into it (or absent): the
+            # next layer may hand its input gradient down as (rows, values) -- the row-sparse top pass of ops_gat._GatTail
+            md.rows_next = bool(not dual and isinstance(md, layers.GAT) and isinstance(nxt, layers.GAT)
+                                and (fuse or float(getattr(nxt, 'dropout', 0.0)) == 0.0 or not self.training))
             if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):

@@ -763,6 +763,19 @@ def _weight_grad_colsum(dZ, X):
     return dW, db
 
 
+class PairLink:
+    """Hand-over between a _LinearPair node (GAT's self / neighbour Linears of one input) and the node that consumes BOTH of
+    its outputs and nothing else does (ops_gat._GatTail): when that node's backward ran row-sparse it leaves the two output
+    gradients on the rows T here -- (rows32 [t], dza [t, N], dzb [t, N]) -- and hands autograd storage-less placeholders."""
+    def __init__(self):
+        self.filled = False
+        self.rows32 = self.dza = self.dzb = self.dummy = None
+
+    def release(self):
+        self.filled = False
+        self.rows32 = self.dza = self.dzb = self.dummy = None
+
+
 class _LinearPair(torch.autograd.Function):
     """Two nn.Linear of the SAME input -- GAT's self / neighbour transforms (shaDow/layers.py:604-611) -- as one autograd
     node on the fp16 two-piece kernels: forward = ONE two-product launch that reads X once per product and adds the
@@ -778,10 +791,13 @@ class _LinearPair(torch.autograd.Function):
                 and bool(_lib.load().sl_gemm_act_norm_supported(N, K)))
 
     @staticmethod
-    def forward(ctx, X, Wa, ba, Wb, bb):
+    def forward(ctx, X, Wa, ba, Wb, bb, pair=None, in_link=None):
+        """``pair`` (PairLink): the consumer of both outputs may leave their gradients on a few rows; ``in_link`` (RootsLink
+        the producer of X published): the input gradient may then go down as (rows, values) too."""
         X = _f32c(X)
         if X.stride(0) % 4 or X.data_ptr() % 16:
             X = X.contiguous()
+        ctx.pair, ctx.in_link = pair, (in_link if (in_link is not None and in_link.published) else None)
         lib = _lib.load()
         M, K = X.shape
         N = Wa.shape[0]
@@ -804,7 +820,46 @@ class _LinearPair(torch.autograd.Function):
         return Zs[0], Zs[1]
 
     @staticmethod
+    def _rows_backward(ctx, dZa, dZb):
+        """Both output gradients are non-zero on the rows ``pair.rows32`` only (compact in ``pair.dza`` / ``pair.dzb``): weight and
+        bias gradients from those rows, the input gradient on those rows -- handed down as (rows, values) when the producer of X
+        published a RootsLink, scattered into a zero tensor otherwise."""
+        X, Wa, Wb = ctx.saved_tensors
+        pair = ctx.pair
+        for g in (dZa, dZb):
+            if g is None or g.data_ptr() != pair.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
+                raise RuntimeError("row-sparse GAT backward: an output of the paired Linear has a consumer besides the attention node")
+        M, K = X.shape
+        rows32, dza, dzb = pair.rows32, pair.dza, pair.dzb
+        pair.release()
+        Tl = rows32.long()
+        XT = X.index_select(0, Tl)
+        ng = ctx.needs_input_grad
+        out = [None] * 7
+        if ng[1]:
+            out[1] = dza.t() @ XT
+        if ng[3]:
+            out[3] = dzb.t() @ XT
+        if ctx.has_bias[0] and ng[2]:
+            out[2] = dza.sum(0)
+        if ctx.has_bias[1] and ng[4]:
+            out[4] = dzb.sum(0)
+        if ng[0]:
+            dXT = torch.addmm(dza @ Wa, dzb, Wb)               # [t, K]
+            link = ctx.in_link
+            if link is not None:
+                link.rows32, link.grad, link.plan = rows32, dXT, None
+                link.dummy = torch.empty(1, 1, dtype=torch.float32, device=X.device).expand(M, K)
+                link.filled = True
+                out[0] = link.dummy
+            else:
+                out[0] = torch.zeros(M, K, dtype=torch.float32, device=X.device).index_copy_(0, Tl, dXT)
+        return tuple(out)
+
+    @staticmethod
     def backward(ctx, dZa, dZb):
+        if ctx.pair is not None and ctx.pair.filled:
+            return _LinearPair._rows_backward(ctx, dZa, dZb)
         X, Wa, Wb = ctx.saved_tensors
         lib = _lib.load()
         M, K = X.shape
@@ -827,7 +882,7 @@ class _LinearPair(torch.autograd.Function):
                 check(lib.sl_gemm_nt_cat_f32(dZs[0].data_ptr(), dZs[0].stride(0), N, dZs[1].data_ptr(), dZs[1].stride(0),
                                              joint.data_ptr() if joint is not None else None,
                                              pack.data_ptr(), M, K, 2 * N, None, dX.data_ptr(), dX.stride(0), st))
-        out = [dX, None, None, None, None]
+        out = [dX, None, None, None, None, None, None]
         # two fp16 pieces when the row maxima of both operands are in hand (the joint maxima bound either gradient's rows)
         f16 = joint is not None and ctx.x_amax is not None and weight_grad_f16_usable(dZs[0], X) and weight_grad_f16_usable(dZs[1], X)
         if f16 and ng[1] and ng[3] and dZs[0].stride(0) == dZs[1].stride(0):
@@ -851,7 +906,12 @@ class _LinearPair(torch.autograd.Function):
 def linear_pair(X, lin_a: "torch.nn.Linear", lin_b: "torch.nn.Linear"):
     """(lin_a(X), lin_b(X)); one fused node when the shapes allow (see _LinearPair), two ``linear`` nodes otherwise."""
     if isinstance(X, torch.Tensor) and X.dim() == 2 and _LinearPair.usable(X, lin_a.weight, lin_b.weight):
-        return _LinearPair.apply(X, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
+        # (row-sparse GAT backward: a PairLink travels with the two outputs, the producer's RootsLink with the input)
+        pair = PairLink() if (SPARSE_TOP_BWD and ROOTS_SPARSE_GRAD) else None
+        za, zb = _LinearPair.apply(X, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias, pair, getattr(X, "_shadow_roots", None))
+        if pair is not None:
+            za._shd_pair = zb._shd_pair = pair
+        return za, zb
     return linear(X, lin_a), linear(X, lin_b)
 
 

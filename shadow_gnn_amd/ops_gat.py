@@ -67,7 +67,7 @@ class _GatTail(torch.autograd.Function):
     backward then ADDS to (sl_gat_bwd, accumulate_dz_self), and the two kernels leave the row maxima of the final
     (dz_self | dz_neigh) behind for the K-concatenated input-gradient product of ops._LinearPair."""
     @staticmethod
-    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop, link_roots=None):
+    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop, link_roots=None, pair=None):
         z_self, z_neigh = ops._f32c(z_self).contiguous(), ops._f32c(z_neigh).contiguous()
         att = attention.detach().float().contiguous()
         ops._need_cuda(z_self, z_neigh, att, scale, offset)
@@ -92,13 +92,61 @@ class _GatTail(torch.autograd.Function):
         ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape, seg, out_scale, drop, scale.shape, offset.shape)
         ctx.link_roots = None
+        ctx.pair = pair                                       # (ops.PairLink of the node that produced z_self and z_neigh, or None)
         # (the selected-rows act_norm backward lives in the vector kernel: float4 rows, power-of-two head slices)
         if link_roots is not None and not ops._is_dual(drop) and _lib.load().sl_act_norm_vector_layout(F, int(seg)):
             link_roots.published = True                       # (only a row-selecting read-out reads `out`, see ops.RootsLink)
+            link_roots.csr = c                                # (ops.select_roots may build the row sets of the row-sparse pass from it)
             ctx.link_roots = link_roots
         ctx.set_materialize_grads(False)
         ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
         return out
+
+    sparse_top_calls = 0
+
+    @staticmethod
+    def _rows_backward(ctx, lr, plan):
+        """The TOP layer under a read-out that takes the roots' rows: the output gradient lives on the roots R, so the gradient of
+        the aggregate and the normalised branch's share of dz_self live on R, the attention backward touches the edges of the
+        roots' rows only, and dz_self / dz_neigh are non-zero on R / on T = R u N(R) (tail.TopBackwardPlan).  The ordinary kernels
+        run on the COMPACT problem -- the saved tensors gathered on T, the roots' rows as a t x t CSR (plan.compact_csr) -- and the
+        two gradients go to the paired Linear's node on the rows T (ops.PairLink); the forward pass is untouched."""
+        z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of = ctx.saved_tensors
+        act_code, heads, att_shape, seg, out_scale, drop, sshape, oshape = ctx.meta
+        adj = ctx.adj
+        n, F = z_self.shape
+        dev = z_self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        R, Tl, sidx, t = plan.rows64, plan.T32.long(), plan.self_idx.long(), plan.t
+        # act + norm backward on the roots (compact): d aggregate and the normalised branch's share of dz_self
+        (dn_R, dzs_R), dsc, dof, _ = ops._an_bwd([nagg.index_select(0, R), z_self.index_select(0, R)], [None, None], (0, act_code), sc, of,
+                                                 seg, out_scale, (lr.grad,), [True, True], False, (0.0, 0))
+        lr.release()
+        csr_c, eid = plan.compact_csr()
+        E = csr_c.e
+        ti, tx, tp = csr_c.transposed
+        w = adj.edge_w.index_select(0, eid) if adj.edge_w is not None else None
+        g = lambda x: x.index_select(0, Tl)
+        zs_c, zn_c, hn_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(z_neigh), g(hn), g(u_s), g(u_n), g(mx), g(den), g(nagg)
+        dn_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dn_R)
+        dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_R)
+        dzn_c = torch.empty(t, F, **f32)
+        datt = torch.empty(2, F, **f32)
+        work = torch.empty(2 * E * heads + t * heads + 4096 * F + 4, **f32)
+        nbytes = 2 * (4 * (t + 1) + 4 * E) + (4 * E if w is not None else 0) + 6 * 4 * t * F + 6 * 4 * t * heads
+        with ops._timed(f"gat_bwd_rows_F{F}_H{heads}", nbytes, dev):
+            check(_lib.load().sl_gat_bwd(csr_c.indptr.data_ptr(), csr_c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
+                                         w.data_ptr() if w is not None else None, zs_c.data_ptr(), zn_c.data_ptr(),
+                                         att.data_ptr(), act_code, t, E, F, heads, hn_c.data_ptr(), us_c.data_ptr(),
+                                         un_c.data_ptr(), mx_c.data_ptr(), den_c.data_ptr(), na_c.data_ptr(), dn_c.data_ptr(),
+                                         work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
+        pair = ctx.pair
+        pair.rows32, pair.dza, pair.dzb = plan.T32, dzs_c, dzn_c
+        pair.dummy = torch.empty(1, 1, **f32).expand(n, F)
+        pair.filled = True
+        _GatTail.sparse_top_calls += 1
+        return (pair.dummy, pair.dummy, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None,
+                None, None)
 
     @staticmethod
     def backward(ctx, *dout):
@@ -115,6 +163,10 @@ class _GatTail(torch.autograd.Function):
             g = dout[0]
             if g is None or g.data_ptr() != lr.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out")
+            plan = lr.plan
+            if (ops.SPARSE_TOP_BWD and plan is not None and ctx.pair is not None and n >= ops.SPARSE_TOP_BWD_MIN_ROWS and float(drop[0]) == 0.0
+                    and plan.matches(c, int(lr.rows32.numel()))):
+                return _GatTail._rows_backward(ctx, lr, plan)
             rows, dout = lr.rows32, (lr.grad,)
         (dnagg, dzs), dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, dout, [True, True],
                                                 False, drop, row_idx=rows)
@@ -136,7 +188,7 @@ class _GatTail(torch.autograd.Function):
                                          amax.data_ptr() if amax is not None else None, ops._stream(dnagg)))
         if amax is not None:              # (ONE array for both gradients: the maximum over the pair of rows)
             ops.set_row_amax(dzs, amax); ops.set_row_amax(dzn, amax)
-        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None)
+        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None, None)
 
 
 def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: int, scale, offset, seg: int, out_scale: float,
@@ -149,7 +201,10 @@ def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: in
         return None
     drop = ops._drop_arg(out_dropout, F, seg, dual)
     link = ops.RootsLink() if (roots_only and not dual and ops.ROOTS_SPARSE_GRAD) else None
-    res = _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop, link)
+    pair = getattr(z_self, "_shd_pair", None)
+    if pair is None or getattr(z_neigh, "_shd_pair", None) is not pair:
+        pair = None                     # (the two inputs are not the two outputs of ONE paired Linear)
+    res = _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop, link, pair)
     if link is not None and link.published and torch.is_tensor(res):
         res._shadow_roots = link
     return res

@@ -1736,3 +1736,54 @@ def test_top_backward_plan_lists_roots_and_their_neighbours():
     ix = torch.tensor([1, 1, 2, 0, 0], dtype=torch.int32, device=DEV)
     bad = tail.TopBackwardPlan(ops.DeviceCSR(ip, ix), torch.tensor([0], dtype=torch.int32, device=DEV))
     assert not bad.ok and not bad.matches(ops.DeviceCSR(ip, ix), 1)
+
+
+def _gat_stack_step(n_layers, p_drop, dropedge, seed, sparse_top, B=96, given_plan=False):
+    """One DeepGNN.step of a GAT stack (dim 256, 4 heads, residue none, centre pooling) on a sampled batch; loss, predictions,
+    every parameter gradient, and how often the row-sparse top pass ran."""
+    from shadow_gnn_amd import ops, ops_gat, tail
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    b, X, labels, F0, C = _bench_scale_batch("gat", B)
+    prev = (ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS)
+    ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS = sparse_top, 1024
+    try:
+        arch = dict(num_layers=n_layers, num_cls_layers=1, heads=4, dim=256, act="elu", layer_norm="norm_feat", feature_augment_ops="sum",
+                    aggr="gat", residue="none", pooling="center", loss="softmax")
+        torch.manual_seed(seed)
+        model = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
+        with torch.no_grad():
+            for q in model.parameters():
+                q.add_(0.05 * torch.randn_like(q))
+        adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off, max_subg_nodes=b.counts["max_subg_nodes"])
+        if given_plan:
+            b.target._shd_top_plan = tail.TopBackwardPlan(adj, b.target, compact=True)
+        batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
+        model.optimizer = torch.optim.SGD(model.parameters(), lr=0.0)
+        c0 = ops_gat._GatTail.sparse_top_calls
+        torch.manual_seed(seed + 1)
+        ret = model.step(TRAIN, "running", batch)
+        torch.cuda.synchronize()
+        grads = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+        return float(ret["loss"]), ret["preds"].detach().clone(), grads, ops_gat._GatTail.sparse_top_calls - c0
+    finally:
+        ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS = prev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,p_drop,dropedge,given", [(3, 0.35, 0.1, True), (2, 0.0, 0.0, False), (1, 0.2, 0.0, False)])
+def test_sparse_top_gat_backward_equals_dense(n_layers, p_drop, dropedge, given):
+    """The top GAT layer's backward on the rows its gradient lives on: act + norm backward on the roots, the attention backward
+    (ordinary kernels) on the roots' rows as a t x t CSR over T = R u N(R) with the saved tensors gathered on T, the paired
+    Linear's weight / bias / input gradients from the rows T (ops.PairLink), and the layer below taking its output gradient as
+    (rows, values) -- against the dense pass: same loss, predictions and every parameter gradient, with dropout and drop-edge
+    on, 1-3 layers (a single layer: the input gradient is not needed at all)."""
+    l0, p0, g0, n0 = _gat_stack_step(n_layers, p_drop, dropedge, 17, sparse_top=False)
+    l1, p1, g1, n1 = _gat_stack_step(n_layers, p_drop, dropedge, 17, sparse_top=True, given_plan=given)
+    assert n0 == 0 and n1 == 1
+    assert abs(l0 - l1) < 1e-6
+    torch.testing.assert_close(p1, p0, rtol=0, atol=0)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        err = float((g1[k] - g0[k]).abs().max())
+        assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
