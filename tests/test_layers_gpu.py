@@ -860,7 +860,7 @@ def _bench_scale_batch(aggr, B, F0=100, depth=2, N=200_000):
 @pytest.mark.parametrize("optimizer", ["adam", "flat"])
 @pytest.mark.parametrize("aggr,layers_,heads,B,act", [("sage", 5, 1, 128, "elu"), ("sage", 5, 1, 128, "relu"), ("gcn", 3, 1, 128, "elu"),
                                                      ("gcn", 3, 1, 128, "relu"), ("gat", 5, 4, 160, "elu")])
-def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B, act, optimizer):
+def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B, act, optimizer, monkeypatch):
     """ONE DeepGNN.step at benchmark widths (dim 256, F0 = 100) on a batch large enough (n >= 8192 rows) that every
     Linear runs on the split-bf16 MFMA kernels, through EXACTLY the call path bench.py times: the one-call layer
     entries (sl_sage_fwd: both products + act / norm in one kernel; sl_sage_bwd_chain: the act_norm backward of the layer
@@ -889,6 +889,12 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
     b, X, labels, F0, C = _bench_scale_batch(aggr, B)
     n = b.num_nodes
     assert n >= ops.GEMM_SPLIT_MIN_ROWS and ops.GEMM_SPLIT, n
+    # the top layer's backward pass in its row-sparse form, as at the benchmark's 289 k rows (round 4; the production threshold
+    # keeps batches of this size on the dense kernels for host-time reasons only)
+    from shadow_gnn_amd import ops_gat
+    monkeypatch.setattr(ops, "SPARSE_TOP_BWD", True)
+    monkeypatch.setattr(ops, "SPARSE_TOP_BWD_MIN_ROWS", 1024)
+    sparse0 = (ops._SageDense.sparse_top_calls, ops._SageDense.compact_dz_calls, ops_gat._GatTail.sparse_top_calls)
     arch = dict(num_layers=layers_, num_cls_layers=1, heads=heads, dim=256, act=act,
                 layer_norm="norm_feat", feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
     torch.manual_seed(31)
@@ -920,6 +926,11 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         ops.Z_TAP = None
     ran = set(timer.summary())
     # the call path: one-call entries with the GEMM-epilogue kernels, every layer boundary chained
+    sparse1 = (ops._SageDense.sparse_top_calls, ops._SageDense.compact_dz_calls, ops_gat._GatTail.sparse_top_calls)
+    if aggr == "sage":
+        assert (sparse1[0] - sparse0[0], sparse1[1] - sparse0[1]) == (1, 1) and any(k.startswith("gemm_an_bwd_corr_nb2") for k in ran), ran
+    if aggr == "gat":
+        assert sparse1[2] - sparse0[2] == 1 and any(k.startswith("gat_bwd_rows") for k in ran), ran
     if aggr == "sage":
         assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (layers_, layers_ - 1)
         assert any(k.startswith("gemm_act_norm_fwd_nb2") for k in ran) and any(k.startswith("gemm_an_bwd_nb2") for k in ran), ran
