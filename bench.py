@@ -297,7 +297,7 @@ def main():
     if args.dense_top_backward:
         ops.SPARSE_TOP_BWD = False
     mb.top_backward_plan = bool(ops.SPARSE_TOP_BWD and wl["aggr"] in ("sage", "gat") and model._tail_prunable(0) and not args.prune_tail)
-    mb.top_backward_compact = wl["aggr"] == "gat"        # (GAT's attention backward runs on the roots' rows as a t x t CSR)
+    mb.backward_levels = 2 if wl["aggr"] == "gat" else 0   # (GAT: nested levels -- roots, their neighbours -- for the top layers' backward)
     model.prune_tail = bool(args.prune_tail)
     if args.prune_tail and model._tail_prunable(0):
         mb.tail_plan_layers = wl["layers"]

@@ -210,7 +210,10 @@ class MinibatchShallowExtractor:
         # True: every batch carries the row sets of the row-sparse top-layer backward (tail.TopBackwardPlan; node tasks whose
         # read-out takes the roots' rows of the last GraphSAGE layer), built on the prefetch stream like the tail plan
         self.top_backward_plan = False
-        self.top_backward_compact = False  # ... with the roots' rows as a square CSR over T (GAT stacks: tail.TopBackwardPlan.compact_csr)
+        self.top_backward_compact = False  # ... with the roots' rows as a square CSR over T (tail.TopBackwardPlan.compact_csr)
+        # > 0: every batch carries up to that many nested levels of a row-sparse backward pass instead (GAT stacks on deep
+        # subgraphs: tail.build_backward_levels)
+        self.backward_levels = 0
         # (priority -1 = high: when the deferred sampler call meets the GEMMs of the step, its workgroups take the CU slots
         #  as they free up instead of queueing behind the GEMM's grid; SHADOW_PREFETCH_PRIORITY=0 for a normal stream)
         prio = int(os.environ.get("SHADOW_PREFETCH_PRIORITY", "-1"))
@@ -429,7 +432,8 @@ class MinibatchShallowExtractor:
         stream bookkeeping as in _tail_plan."""
         from . import tail
         if self._side is None:
-            return tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact)
+            return (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
+                    else tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact))
         main = torch.cuda.current_stream(self.device)
         # (as in _tail_plan: the plan allocates on the side stream BEFORE the next _launch orders that stream behind the
         #  training stream -- every sampler output of this batch must therefore be recorded on the training stream, or a block
@@ -439,9 +443,10 @@ class MinibatchShallowExtractor:
             if t is not None and t.is_cuda:
                 t.record_stream(main)
         with torch.cuda.stream(self._side):
-            plan = tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact)
+            plan = (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
+                    else tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact))
         main.wait_stream(self._side)
-        for t in plan.tensors():
+        for t in ([x for lv in plan for x in lv.tensors()] if isinstance(plan, list) else plan.tensors()):
             t.record_stream(main)
         return plan
 
@@ -580,7 +585,11 @@ class MinibatchShallowExtractor:
                             subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
         if self.top_backward_plan and self.tail_plan_layers == 0 and adj.n >= ops.SPARSE_TOP_BWD_MIN_ROWS and ops.SPARSE_TOP_BWD:
-            subgs.target._shd_top_plan = self._top_plan(subgs, adj)
+            plan = self._top_plan(subgs, adj)
+            if isinstance(plan, list):
+                subgs.target._shd_bwd_levels = plan
+            else:
+                subgs.target._shd_top_plan = plan
         if not last and self.prefetch:
             if self.defer_prefetch:
                 # ... issued when the consumer reaches ops.fire_deferred, so that it stays off the HBM-bound head of the step

@@ -182,6 +182,8 @@ class DeepGNN(nn.Module):
             tgt = torch.as_tensor(target_ens[i], device=feat.device).long()
             if getattr(target_ens[i], "_shd_top_plan", None) is not None:      # (minibatch: row sets of the row-sparse top-layer backward)
                 tgt._shd_top_plan = target_ens[i]._shd_top_plan
+            if getattr(target_ens[i], "_shd_bwd_levels", None) is not None:    # (... of a GAT stack's row-sparse backward, tail.build_backward_levels)
+                tgt._shd_bwd_levels = target_ens[i]._shd_bwd_levels
             if self.dim_label_in > 0 and mode == TRAIN:
                 feat = ops.dense_rows(feat)
                 feat[tgt, -self.dim_label_in:] = 0            # a root never sees its own label (models.py:181-182)

@@ -769,11 +769,11 @@ class PairLink:
     gradients on the rows T here -- (rows32 [t], dza [t, N], dzb [t, N]) -- and hands autograd storage-less placeholders."""
     def __init__(self):
         self.filled = False
-        self.rows32 = self.dza = self.dzb = self.dummy = None
+        self.rows32 = self.dza = self.dzb = self.dummy = self.levels = None
 
     def release(self):
         self.filled = False
-        self.rows32 = self.dza = self.dzb = self.dummy = None
+        self.rows32 = self.dza = self.dzb = self.dummy = self.levels = None
 
 
 class _LinearPair(torch.autograd.Function):
@@ -830,7 +830,7 @@ class _LinearPair(torch.autograd.Function):
             if g is None or g.data_ptr() != pair.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("row-sparse GAT backward: an output of the paired Linear has a consumer besides the attention node")
         M, K = X.shape
-        rows32, dza, dzb = pair.rows32, pair.dza, pair.dzb
+        rows32, dza, dzb, levels = pair.rows32, pair.dza, pair.dzb, pair.levels
         pair.release()
         Tl = rows32.long()
         XT = X.index_select(0, Tl)
@@ -848,7 +848,7 @@ class _LinearPair(torch.autograd.Function):
             dXT = torch.addmm(dza @ Wa, dzb, Wb)               # [t, K]
             link = ctx.in_link
             if link is not None:
-                link.rows32, link.grad, link.plan = rows32, dXT, None
+                link.rows32, link.grad, link.plan, link.levels = rows32, dXT, None, (levels or None)
                 link.dummy = torch.empty(1, 1, dtype=torch.float32, device=X.device).expand(M, K)
                 link.filled = True
                 out[0] = link.dummy
@@ -1133,10 +1133,12 @@ class RootsLink:
         self.rows32 = self.grad = self.dummy = None
         self.csr = None              # the batch CSR of the publishing node (a TopBackwardPlan is built from it when none came along)
         self.plan = None             # tail.TopBackwardPlan of the selected rows: the node's backward may then run row-sparse
+        self.want_levels = False     # the publishing node works from tail.build_backward_levels instead (GAT)
+        self.levels = None           # remaining levels of a row-sparse backward pass, the one for THIS node's rows first
 
     def release(self):
         self.filled = False
-        self.rows32 = self.grad = self.dummy = self.plan = None
+        self.rows32 = self.grad = self.dummy = self.plan = self.levels = None
 
 
 ROOTS_SPARSE_GRAD = os.environ.get("SHADOW_ROOTS_SPARSE_GRAD", "1") != "0"
@@ -1156,8 +1158,14 @@ class _SelectRoots(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # the row sets of the row-sparse top-layer backward: handed over with the rows (built by the minibatch extractor on its
         # prefetch stream) or, for hand-made batches, built here (two host syncs)
-        ctx.plan = None
-        if SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None:
+        ctx.plan = ctx.levels = None
+        if SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None and link.want_levels:
+            lv = getattr(rows, "_shd_bwd_levels", None)
+            if lv is None:
+                from . import tail
+                lv = tail.build_backward_levels(link.csr, rows)
+            ctx.levels = lv if (lv and lv[0].r == int(rows.numel())) else None
+        elif SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None:
             plan = getattr(rows, "_shd_top_plan", None)
             if plan is None or not plan.matches(link.csr, int(rows.numel())):
                 from . import tail
@@ -1175,6 +1183,7 @@ class _SelectRoots(torch.autograd.Function):
             link.rows32 = rows.to(torch.int32)
             link.grad = _f32c(dsel).contiguous()
             link.plan = ctx.plan
+            link.levels = list(ctx.levels) if ctx.levels else None
             link.dummy = torch.empty(1, 1, dtype=torch.float32, device=dsel.device).expand(ctx.n, ctx.F)
             link.filled = True
             return link.dummy, None, None

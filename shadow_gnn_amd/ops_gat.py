@@ -97,6 +97,7 @@ class _GatTail(torch.autograd.Function):
         if link_roots is not None and not ops._is_dual(drop) and _lib.load().sl_act_norm_vector_layout(F, int(seg)):
             link_roots.published = True                       # (only a row-selecting read-out reads `out`, see ops.RootsLink)
             link_roots.csr = c                                # (ops.select_roots may build the row sets of the row-sparse pass from it)
+            link_roots.want_levels = True
             ctx.link_roots = link_roots
         ctx.set_materialize_grads(False)
         ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
@@ -105,31 +106,35 @@ class _GatTail(torch.autograd.Function):
     sparse_top_calls = 0
 
     @staticmethod
-    def _rows_backward(ctx, lr, plan):
-        """The TOP layer under a read-out that takes the roots' rows: the output gradient lives on the roots R, so the gradient of
-        the aggregate and the normalised branch's share of dz_self live on R, the attention backward touches the edges of the
-        roots' rows only, and dz_self / dz_neigh are non-zero on R / on T = R u N(R) (tail.TopBackwardPlan).  The ordinary kernels
-        run on the COMPACT problem -- the saved tensors gathered on T, the roots' rows as a t x t CSR (plan.compact_csr) -- and the
-        two gradients go to the paired Linear's node on the rows T (ops.PairLink); the forward pass is untouched."""
+    def _rows_backward(ctx, lr, level, rest):
+        """A layer whose output gradient lives on a few rows (``lr.rows32`` / ``lr.grad`` -- the roots under a row-selecting
+        read-out for the top layer, the rows T the layer above handed down for the one below): the gradient of the aggregate and
+        the normalised branch's share of dz_self live on those rows, the attention backward touches THEIR edges only, and
+        dz_self / dz_neigh are non-zero on those rows / on their inputs ``level.in_ids_full`` (tail.build_backward_levels).  The
+        ordinary kernels run on the COMPACT problem -- the saved tensors gathered on the input set, the rows as a square CSR over
+        it (RectLevel.square) -- and the two gradients go to the paired Linear's node on that set (ops.PairLink) together with the
+        levels that are left; the forward pass is untouched."""
         z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of = ctx.saved_tensors
         act_code, heads, att_shape, seg, out_scale, drop, sshape, oshape = ctx.meta
         adj = ctx.adj
         n, F = z_self.shape
         dev = z_self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        R, Tl, sidx, t = plan.rows64, plan.T32.long(), plan.self_idx.long(), plan.t
-        # act + norm backward on the roots (compact): d aggregate and the normalised branch's share of dz_self
-        (dn_R, dzs_R), dsc, dof, _ = ops._an_bwd([nagg.index_select(0, R), z_self.index_select(0, R)], [None, None], (0, act_code), sc, of,
-                                                 seg, out_scale, (lr.grad,), [True, True], False, (0.0, 0))
+        Tl, sidx, t, r = level.in_ids_full, level.self_idx, level.m_in, level.r
+        # act + norm backward on the given rows: Z and this layer's output-dropout mask are addressed through the row ids, the
+        # two gradients stay compact ([r, F])
+        dn_r, dzs_r = torch.empty(r, F, **f32), torch.empty(r, F, **f32)
+        _dz, dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, (lr.grad,), [True, True], False, drop,
+                                       dz_out=[dn_r, dzs_r], row_idx=lr.rows32, dz_compact=True)
         lr.release()
-        csr_c, eid = plan.compact_csr()
+        csr_c, order = level.square
         E = csr_c.e
         ti, tx, tp = csr_c.transposed
-        w = adj.edge_w.index_select(0, eid) if adj.edge_w is not None else None
+        w = adj.edge_w.index_select(0, level.edge_pos.index_select(0, order)) if adj.edge_w is not None else None
         g = lambda x: x.index_select(0, Tl)
         zs_c, zn_c, hn_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(z_neigh), g(hn), g(u_s), g(u_n), g(mx), g(den), g(nagg)
-        dn_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dn_R)
-        dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_R)
+        dn_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dn_r)
+        dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_r)
         dzn_c = torch.empty(t, F, **f32)
         datt = torch.empty(2, F, **f32)
         work = torch.empty(2 * E * heads + t * heads + 4096 * F + 4, **f32)
@@ -141,7 +146,7 @@ class _GatTail(torch.autograd.Function):
                                          un_c.data_ptr(), mx_c.data_ptr(), den_c.data_ptr(), na_c.data_ptr(), dn_c.data_ptr(),
                                          work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
         pair = ctx.pair
-        pair.rows32, pair.dza, pair.dzb = plan.T32, dzs_c, dzn_c
+        pair.rows32, pair.dza, pair.dzb, pair.levels = level.in32, dzs_c, dzn_c, list(rest)
         pair.dummy = torch.empty(1, 1, **f32).expand(n, F)
         pair.filled = True
         _GatTail.sparse_top_calls += 1
@@ -163,10 +168,10 @@ class _GatTail(torch.autograd.Function):
             g = dout[0]
             if g is None or g.data_ptr() != lr.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out")
-            plan = lr.plan
-            if (ops.SPARSE_TOP_BWD and plan is not None and ctx.pair is not None and n >= ops.SPARSE_TOP_BWD_MIN_ROWS and float(drop[0]) == 0.0
-                    and plan.matches(c, int(lr.rows32.numel()))):
-                return _GatTail._rows_backward(ctx, lr, plan)
+            lv = lr.levels[0] if lr.levels else None
+            if (ops.SPARSE_TOP_BWD and lv is not None and ctx.pair is not None and n >= ops.SPARSE_TOP_BWD_MIN_ROWS and not ops._is_dual(drop)
+                    and lv.r == int(lr.rows32.numel()) and lv.in_ids_full is not None):
+                return _GatTail._rows_backward(ctx, lr, lv, lr.levels[1:])
             rows, dout = lr.rows32, (lr.grad,)
         (dnagg, dzs), dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, dout, [True, True],
                                                 False, drop, row_idx=rows)

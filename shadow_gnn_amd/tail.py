@@ -44,6 +44,7 @@ class RectLevel:
         self.r = int(rows_full.numel())
         self._t = None
         self._sq = None
+        self.rows32 = self.in32 = None  # int32 copies of rows_full / in_ids_full (build_backward_levels)
 
     @property
     def transposed(self):
@@ -62,6 +63,7 @@ class RectLevel:
         ts = [self.indptr, self.indices, self.edge_row, self.edge_pos, self.rows_full, self.self_idx]
         if self.in_ids_full is not None:
             ts.append(self.in_ids_full)
+        ts.extend(x for x in (self.rows32, self.in32) if x is not None)
         if self._t is not None:
             ts.extend(self._t)
         if self._sq is not None:
@@ -268,3 +270,32 @@ class TopBackwardPlan:
             c, eid = self._compact
             ts += [c.indptr, c.indices, eid] + [x for x in (c._t or ()) if x is not None] + ([c._edge_row] if c._edge_row is not None else [])
         return ts
+
+
+def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_levels: int = 2, frac: float = 0.25) -> List[RectLevel]:
+    """Nested row sets of a row-sparse BACKWARD pass, top layer first: level 0 = the roots' rows with their inputs T = R u N(R),
+    level 1 = the rows T with inputs T2 = T u N(T), ... -- every level compact (column ids renumbered into its input set), kept
+    while that input set is at most ``frac`` of the batch.  Depth-2 k-hop batches stop after one level (T2 is the whole
+    subgraph), depth-3 batches after two (T: 0.5 %, T2: 10 % of the rows).  The square form and its transpose are built here
+    (GAT's attention backward runs its ordinary kernels on them, ops_gat._GatTail).  Two host syncs per level: the extractor
+    calls this on its prefetch stream."""
+    n, dev = csr.n, csr.device
+    rows = torch.as_tensor(targets, device=dev).long().reshape(-1)
+    levels: List[RectLevel] = []
+    for _ in range(max_levels):
+        ip, er, pos = _select_rows(csr.indptr, rows)
+        cols = csr.indices[pos].long()
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        mask[rows] = True
+        mask[cols] = True
+        in_ids = mask.nonzero().reshape(-1)                 # (host sync) ascending
+        if in_ids.numel() > frac * n:
+            break
+        newid = torch.cumsum(mask, 0) - 1
+        lv = RectLevel(ip.to(torch.int32), newid[cols].to(torch.int32), er, pos, rows, in_ids, newid[rows], in_ids.numel())
+        lv.square[0].transposed
+        lv.rows32 = rows.to(torch.int32)
+        lv.in32 = in_ids.to(torch.int32)
+        levels.append(lv)
+        rows = in_ids
+    return levels
