@@ -210,7 +210,6 @@ class MinibatchShallowExtractor:
         # True: every batch carries the row sets of the row-sparse top-layer backward (tail.TopBackwardPlan; node tasks whose
         # read-out takes the roots' rows of the last GraphSAGE layer), built on the prefetch stream like the tail plan
         self.top_backward_plan = False
-        self.top_backward_compact = False  # ... with the roots' rows as a square CSR over T (tail.TopBackwardPlan.compact_csr)
         # > 0: every batch carries up to that many nested levels of a row-sparse backward pass instead (GAT stacks on deep
         # subgraphs: tail.build_backward_levels)
         self.backward_levels = 0
@@ -433,7 +432,7 @@ class MinibatchShallowExtractor:
         from . import tail
         if self._side is None:
             return (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
-                    else tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact))
+                    else tail.TopBackwardPlan(adj, subgs.target))
         main = torch.cuda.current_stream(self.device)
         # (as in _tail_plan: the plan allocates on the side stream BEFORE the next _launch orders that stream behind the
         #  training stream -- every sampler output of this batch must therefore be recorded on the training stream, or a block
@@ -444,7 +443,7 @@ class MinibatchShallowExtractor:
                 t.record_stream(main)
         with torch.cuda.stream(self._side):
             plan = (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
-                    else tail.TopBackwardPlan(adj, subgs.target, compact=self.top_backward_compact))
+                    else tail.TopBackwardPlan(adj, subgs.target))
         main.wait_stream(self._side)
         for t in ([x for lv in plan for x in lv.tensors()] if isinstance(plan, list) else plan.tensors()):
             t.record_stream(main)

@@ -210,7 +210,7 @@ class TopBackwardPlan:
     extractor builds it on its prefetch stream.  ``ok`` False: a root row lists a neighbour twice (a multigraph) -- the
     dense pass is taken."""
 
-    def __init__(self, csr: "ops.DeviceCSR", targets: torch.Tensor, compact: bool = False):
+    def __init__(self, csr: "ops.DeviceCSR", targets: torch.Tensor):
         import ctypes as C
 
         from . import _lib
@@ -225,9 +225,7 @@ class TopBackwardPlan:
         T, slot, epos, self_idx = torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(max(P, 1), **i32)
         _lib.check(_lib.load().sl_top_plan(csr.indptr.data_ptr(), csr.indices.data_ptr(), self.targets32.data_ptr(), P, cap, off.data_ptr(),
                                            T.data_ptr(), slot.data_ptr(), epos.data_ptr(), self_idx.data_ptr(), ops._stream(csr.indptr)))
-        # (edges of the roots' rows: with the size of T in ONE transfer -- the one host sync)
-        deg_sum = (csr.indptr[self.rows64 + 1] - csr.indptr[self.rows64]).sum().to(torch.int32).reshape(1) if P else off[:1]
-        t, bad, num_edges = (int(x) for x in torch.cat([off[P:P + 2], deg_sum]).tolist()) if P else (0, 0, 0)
+        t, bad = (int(x) for x in off[P:P + 2].tolist()) if P else (0, 0)          # (the one host sync)
         self.ok = bool(P > 0 and bad == 0 and t <= cap)
         self.t = t if self.ok else 0
         self.T32, self.slot, self.epos, self.self_idx = T[:self.t], slot[:self.t], epos[:self.t], self_idx[:P]
@@ -238,38 +236,13 @@ class TopBackwardPlan:
             self.rowmap[self.T32.long()] = torch.arange(self.t, **i32)
         self.n = n
         self.num_roots = P
-        self.num_edges = num_edges if self.ok else 0            # edges of the roots' rows (T holds one more entry per root without self edge)
         self._indptr_ptr = csr.indptr.data_ptr()
-        self._compact = None
-        if compact and self.ok:
-            self.compact_csr()
-
-    def compact_csr(self):
-        """The roots' rows as a square CSR over T (t x t, every other row empty; columns = positions in T) with the position of
-        every edge in the batch CSR: what a layer whose backward works on T x T -- GAT's attention -- runs its ordinary kernels
-        on (ops_gat._GatTail).  Built without a host sync (the edge count came with the size of T)."""
-        if self._compact is None:
-            dev = self.T32.device
-            t, E = self.t, self.num_edges
-            valid = self.epos >= 0                                   # entries of T that are neighbours (all but roots without self edge)
-            k = torch.argsort(~valid, stable=True)[:E]               # their positions, ascending
-            row = self.self_idx.long()[self.slot.long()[k]]          # the root's position in T
-            ip = torch.zeros(t + 1, dtype=torch.int64, device=dev)
-            ip.index_add_(0, row + 1, torch.ones_like(row))
-            ip = torch.cumsum(ip, 0).to(torch.int32)
-            self._compact = (ops.DeviceCSR(ip, k.to(torch.int32)), self.epos.long()[k])
-            self._compact[0].transposed                              # (built here, on the stream the plan is built on)
-        return self._compact
 
     def matches(self, csr: "ops.DeviceCSR", num_roots: int) -> bool:
         return self.ok and csr.n == self.n and csr.indptr.data_ptr() == self._indptr_ptr and num_roots == self.num_roots
 
     def tensors(self):
-        ts = [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx, self.rowmap]
-        if self._compact is not None:
-            c, eid = self._compact
-            ts += [c.indptr, c.indices, eid] + [x for x in (c._t or ()) if x is not None] + ([c._edge_row] if c._edge_row is not None else [])
-        return ts
+        return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx, self.rowmap]
 
 
 def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_levels: int = 2, frac: float = 0.25) -> List[RectLevel]:
