@@ -1800,3 +1800,16 @@ def test_sparse_top_gat_backward_equals_dense(n_layers, p_drop, dropedge, given)
         scale = float(g0[k].abs().max())
         err = float((g1[k] - g0[k]).abs().max())
         assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
+
+
+@pytest.mark.gpu
+def test_sparse_top_backward_fuzz():
+    """40 seeded random ragged batches (subgraphs of 1 .. 60 nodes, roots with / without self edges or neighbours) x random
+    GraphSAGE / GAT stacks: the row-sparse top-layer backward passes against the dense ones (scripts/fuzz_sparse_top.py)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_sparse_top", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz_sparse_top.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    failures, used = mod.run(3, 40, verbose=False)
+    assert not failures, failures[:3]
+    assert used >= 20, used                                  # (most trials must actually take a row-sparse pass)
