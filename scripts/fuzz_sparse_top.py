@@ -28,7 +28,7 @@ def run(seed: int, trials: int, verbose: bool = True):
         for trial in range(trials):
             aggr = str(rng.choice(["sage", "gat"]))
             heads = int(rng.choice([1, 2, 4])) if aggr == "gat" else 1
-            dim = int(rng.choice([32, 64, 96])) if aggr == "sage" else heads * int(rng.choice([8, 16]))
+            dim = int(rng.choice([32, 64, 96])) if aggr == "sage" else int(rng.choice([32, 64]))      # (GAT: head slices of 8 .. 64 floats)
             L = int(rng.integers(2, 5)) if aggr == "sage" else int(rng.integers(1, 4))
             p_drop, p_edge = float(rng.choice([0.0, 0.3])), float(rng.choice([0.0, 0.2]))
             B = int(rng.choice([1, 4, 17])); F0 = int(rng.choice([8, 20, 32])); C = int(rng.choice([2, 5]))
