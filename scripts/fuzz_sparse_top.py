@@ -20,8 +20,9 @@ def run(seed: int, trials: int, verbose: bool = True):
     from shadow_gnn_amd.models import DeepGNN
     rng = np.random.default_rng(seed)
     failures = []
-    saved = (ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS, ops.GEMM_SPLIT_MIN_ROWS, ops.AMAX_HANDOVER_ROWS)
+    saved = (ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS, ops.GEMM_SPLIT_MIN_ROWS, ops.AMAX_HANDOVER_ROWS, ops.BACKWARD_LEVELS_FRAC)
     ops.SPARSE_TOP_BWD_MIN_ROWS = 1
+    ops.BACKWARD_LEVELS_FRAC = 2.0                   # (GAT: keep both levels whatever share of these tiny batches they cover)
     ops.GEMM_SPLIT_MIN_ROWS = 1                      # (tiny batches through the one-call entries, as the golden tests do)
     used = 0
     try:
@@ -83,7 +84,7 @@ def run(seed: int, trials: int, verbose: bool = True):
                 if verbose:
                     print("FAIL", ctx, failures[-1][1])
     finally:
-        ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS, ops.GEMM_SPLIT_MIN_ROWS, ops.AMAX_HANDOVER_ROWS = saved
+        ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS, ops.GEMM_SPLIT_MIN_ROWS, ops.AMAX_HANDOVER_ROWS, ops.BACKWARD_LEVELS_FRAC = saved
     if verbose:
         print(f"{trials} trials, {used} took a row-sparse pass, {len(failures)} failures")
     return failures, used

@@ -125,7 +125,8 @@ using namespace shadow;
 extern "C" int sl_top_plan(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_targets, uint32_t num_subg, uint32_t cap,
                            uint32_t *d_off, uint32_t *d_T, uint32_t *d_slot, int32_t *d_epos, uint32_t *d_self_idx, void *stream) {
   if (num_subg == 0) return SG_OK;
-  if (!d_indptr || !d_indices || !d_targets || !d_off || !d_T || !d_slot || !d_epos || !d_self_idx)
+  // (d_indices may be NULL: a batch without a single edge -- every root row is empty and nothing is read through it)
+  if (!d_indptr || !d_targets || !d_off || !d_T || !d_slot || !d_epos || !d_self_idx)
     return set_error(SG_ERR_INVALID, "sl_top_plan: null argument");
   hipStream_t st = (hipStream_t)stream;
   SHD_HIP(hipMemsetAsync(d_off + num_subg + 1, 0, 4, st));

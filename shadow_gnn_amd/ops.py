@@ -1148,6 +1148,9 @@ SPARSE_TOP_BWD = os.environ.get("SHADOW_SPARSE_TOP_BWD", "1") != "0"
 # below: ~20 small launches cost more host time than the three dense kernels cost GPU time (products shape, 128 roots = 36 k rows:
 # 2.14 ms / step dense, 2.87 with the row-sparse pass; 1 024 roots = 289 k rows: 7.28 -> 6.59)
 SPARSE_TOP_BWD_MIN_ROWS = int(os.environ.get("SHADOW_SPARSE_TOP_BWD_MIN_ROWS", "131072"))
+# a level of tail.build_backward_levels is kept while its input set is at most this share of the batch (built on the spot by
+# select_roots when the batch brings none)
+BACKWARD_LEVELS_FRAC = 0.25
 
 
 class _SelectRoots(torch.autograd.Function):
@@ -1163,7 +1166,7 @@ class _SelectRoots(torch.autograd.Function):
             lv = getattr(rows, "_shd_bwd_levels", None)
             if lv is None:
                 from . import tail
-                lv = tail.build_backward_levels(link.csr, rows)
+                lv = tail.build_backward_levels(link.csr, rows, frac=BACKWARD_LEVELS_FRAC)
             ctx.levels = lv if (lv and lv[0].r == int(rows.numel())) else None
         elif SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None:
             plan = getattr(rows, "_shd_top_plan", None)
