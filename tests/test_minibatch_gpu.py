@@ -172,8 +172,9 @@ def test_two_rank_data_parallel_step_equals_single_process():
         np.testing.assert_allclose(res[0][k], v.cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=k)
 
 
+@pytest.mark.parametrize("S", [1, 3])
 @pytest.mark.parametrize("prefetch", [False, True])
-def test_subgraph_cache_record_then_reuse(prefetch):
+def test_subgraph_cache_record_then_reuse(prefetch, S):
     """Deterministic (PPR) sampler: epoch 1 records every subgraph on the device, later epochs are
     rebuilt from the cache for a DIFFERENT root order and equal a fresh sample of the same roots
     (CachedSubgraph / PoolSubgraph.collate, shaDow/minibatch.py:21-91, :403-426); the full graph can be
@@ -191,6 +192,7 @@ def test_subgraph_cache_record_then_reuse(prefetch):
     mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
                                    dict(method="ppr", k=12, threshold=0.0, add_self_edge=True), ("hops",), feat, label,
                                    batch_size=16, device=DEV, seed_cpp=2, prefetch=prefetch)
+    mb.steps_per_call = S                # (S = 3: the recording epoch samples three steps per call, sg_sample_multi)
     mb.epoch_start_reset(0, TRAIN)
     hs = mb.graph_sampler[TRAIN]
     hs.set_ppr(roots, table.len, table.neigh, table.score)
@@ -473,8 +475,9 @@ def test_reference_constructor_signature_and_bin_files(tmp_path):
                                   feat, label, 12, True, 4, device=DEV)
 
 
+@pytest.mark.parametrize("S", [1, 3])
 @pytest.mark.parametrize("prefetch", [False, True])
-def test_mid_epoch_reshuffle_and_disable_cache(prefetch):
+def test_mid_epoch_reshuffle_and_disable_cache(prefetch, S):
     """shuffle_entity / disable_cache with a prefetched call in flight finish and drop it instead of leaving
     the sampler 'already in flight'; after disable_cache the epoch continues from where it stood, sampling again."""
     from oracle import sampler_oracle as so
@@ -489,6 +492,7 @@ def test_mid_epoch_reshuffle_and_disable_cache(prefetch):
     mb = MinibatchShallowExtractor.on_device({TRAIN: (indptr, indices)}, {TRAIN: roots},
                                              dict(method="ppr", k=12, threshold=0.0, add_self_edge=True), (), feat, label,
                                              batch_size=16, device=DEV, seed_cpp=2, prefetch=prefetch)
+    mb.steps_per_call = S                # (S = 3: calls cover three steps; dropped calls carry unconsumed batches too)
     mb.epoch_start_reset(0, TRAIN)
     mb.graph_sampler[TRAIN].set_ppr(roots, table.len, table.neigh, table.score)
     mb.shuffle_entity(TRAIN, perm=np.arange(70))
