@@ -616,6 +616,46 @@ int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, con
                       float *d_an_partial, float *d_tn_partial, void *d_pack, int dz_ready, const sl_sage_below *below,
                       float *d_dzs_amax, const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, void *stream);
 
+/* A whole stack of chained GraphSAGE layers per call -- the conv loop of DeepGNN.forward (shaDow/models.py:193-197) over
+ * GraphSAGE layers (layers.py:471-483) under residue 'none' + centre pooling (layers.py:159-163), forward and backward.  The
+ * entries run sl_sage_fwd / sl_sage_bwd_chain layer by layer with exactly the arguments a caller of those would pass (layer l
+ * reads layer l - 1's `out` / `out_amax`; backward top-down, each call's `below` = the next lower layer, its d_buf / d_dzs_amax
+ * the halves of d_buf / d_amax in turn): the same kernels in the same order, identical results -- what they remove is the host
+ * work between the layers, which bounds a step at the reference's own batch sizes (16-256 roots).
+ * One descriptor per layer; the caller owns every buffer:
+ *   parameters        Ws, Wn [Fout, Fin] (row pitch ldws / ldwn), bs, bn [Fout] (may be NULL), scale, offset [2, Fout]
+ *   drop_p, drop_seed the layer's fused OUTPUT dropout (= the next layer's input dropout); 0 for the top layer
+ *   forward products  AX [n, Fin] (pitch ldax), Zs, Zn, out [n, Fout] dense, out_amax [n], row_stats [n, 4] or NULL
+ *                     (written by sl_sage_stack_fwd, read by sl_sage_stack_bwd)
+ *   gradients         dWs, dWn [Fout, Fin], dbias [2, Fout] (NULL: no bias), dscale, doffset [2, Fout]
+ * Fin of layer l = Fout of layer l - 1; every chained layer needs Fout % 32 == 0 (see sl_sage_bwd_chain).
+ * sl_sage_stack_fwd: d_X0 [n, Fin_0] (pitch ldx0), d_x0_amax / x0_pad_zero as sl_sage_fwd's d_x_amax / x_pad_zero for layer 0;
+ * d_pack: sl_sage_stack_pack_bytes(n, L, layers) bytes (shared by the layers: stream order).
+ * sl_sage_stack_bwd: d_dout = the gradient of the top layer's `out`, [n, Fout] or -- d_dout_rows != NULL -- compact
+ * [num_dout_rows, Fout] for the selected rows only (the read-out's feat[roots]); d_dX0 [n, Fin_0] dense or NULL (input gradient
+ * not wanted); scratch: d_buf 2 * n * 3 * max Fout floats, d_amax 2 n floats, d_an_partial as for sl_act_norm_bwd (nb = 2),
+ * d_chain_partial max_l sl_sage_chain_partial_floats(n, Fout_l) floats (L > 1), d_tn_partial the largest any layer's
+ * sl_sage_bwd_chain needs, d_pack as above.  adj must carry the transposed adjacency when L > 1 or d_dX0 != NULL.          */
+typedef struct {
+  const float *Ws, *bs, *Wn, *bn, *scale, *offset;
+  int64_t ldws, ldwn;
+  uint32_t Fin, Fout;
+  int act;
+  float drop_p;
+  uint64_t drop_seed;
+  float *AX;
+  int64_t ldax;
+  float *Zs, *Zn, *out, *out_amax, *row_stats;
+  float *dWs, *dWn, *dbias, *dscale, *doffset;
+} sl_sage_stack_layer;
+size_t sl_sage_stack_pack_bytes(uint32_t n, uint32_t L, const sl_sage_stack_layer *layers);
+int sl_sage_stack_fwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, const float *d_x0_amax, int x0_pad_zero, uint32_t L,
+                      const sl_sage_stack_layer *layers, void *d_pack, void *stream);
+int sl_sage_stack_bwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, const float *d_x0_amax, uint32_t L,
+                      const sl_sage_stack_layer *layers, const float *d_dout, const uint32_t *d_dout_rows, uint32_t num_dout_rows,
+                      float *d_dX0, float *d_buf, float *d_amax, float *d_an_partial, float *d_chain_partial, float *d_tn_partial,
+                      void *d_pack, void *stream);
+
 /* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
  * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /
  * norm; the caller provides AX [n, Fin] (ldax), Z, out [n, Fout] and d_pack (sl_gcn_pack_bytes bytes).  backward:

@@ -62,6 +62,17 @@ class SlSageBelow(C.Structure):
     ]
 
 
+class SlSageStackLayer(C.Structure):
+    """sl_sage_stack_layer: one GraphSAGE layer of a stack run by sl_sage_stack_fwd / sl_sage_stack_bwd."""
+    _fields_ = [
+        ("Ws", C.c_void_p), ("bs", C.c_void_p), ("Wn", C.c_void_p), ("bn", C.c_void_p), ("scale", C.c_void_p), ("offset", C.c_void_p),
+        ("ldws", C.c_int64), ("ldwn", C.c_int64), ("Fin", C.c_uint32), ("Fout", C.c_uint32), ("act", C.c_int), ("drop_p", C.c_float),
+        ("drop_seed", C.c_uint64), ("AX", C.c_void_p), ("ldax", C.c_int64), ("Zs", C.c_void_p), ("Zn", C.c_void_p), ("out", C.c_void_p),
+        ("out_amax", C.c_void_p), ("row_stats", C.c_void_p), ("dWs", C.c_void_p), ("dWn", C.c_void_p), ("dbias", C.c_void_p),
+        ("dscale", C.c_void_p), ("doffset", C.c_void_p),
+    ]
+
+
 class SlNormAdj(C.Structure):
     _fields_ = [
         ("indptr", C.c_void_p), ("indices", C.c_void_p), ("edge_w", C.c_void_p), ("row_scale", C.c_void_p),
@@ -142,6 +153,10 @@ SIGNATURES = {
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P, _P]),
+    "sl_sage_stack_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.POINTER(SlSageStackLayer)]),
+    "sl_sage_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P]),
+    "sl_sage_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P, C.c_uint32,
+                                     _P, _P, _P, _P, _P, _P, _P, _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
     "sl_prof_enable": (C.c_int, [C.c_int]),
     "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -205,7 +220,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 16      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 17      # sg_abi_version() of the library these signatures describe
 
 
 def load():

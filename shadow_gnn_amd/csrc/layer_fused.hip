@@ -347,6 +347,80 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A whole stack of GraphSAGE layers per call (the conv loop of shaDow/models.py:193-197 over layers.py:471-483 layers whose only
+// connection is out_l -> X_{l+1}: residue 'none' + centre pooling).  The same per-layer entries in the same order with the same
+// arguments the host would pass one by one (identical results); what goes away is the host work between them -- at the
+// reference's own batch sizes (16-256 roots) a step is bound by it.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t sl_sage_stack_pack_bytes(uint32_t n, uint32_t L, const sl_sage_stack_layer *ly) {
+  size_t b = 0;
+  for (uint32_t l = 0; ly && l < L; ++l) b = std::max(b, sl_sage_pack_bytes(n, ly[l].Fin, ly[l].Fout));
+  return b;
+}
+
+static int stack_check(const sl_norm_adj *adj, const float *d_X0, uint32_t L, const sl_sage_stack_layer *ly, const char *who) {
+  if (!adj || !d_X0 || !ly || L == 0) return set_error(SG_ERR_INVALID, "%s: null argument", who);
+  for (uint32_t l = 1; l < L; ++l)
+    if (ly[l].Fin != ly[l - 1].Fout) return set_error(SG_ERR_INVALID, "%s: layer %u reads %u columns, layer %u writes %u", who, l, ly[l].Fin, l - 1, ly[l - 1].Fout);
+  return SG_OK;
+}
+
+extern "C" int sl_sage_stack_fwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, const float *d_x0_amax, int x0_pad_zero,
+                                 uint32_t L, const sl_sage_stack_layer *ly, void *d_pack, void *stream) {
+  int rc;
+  if ((rc = stack_check(adj, d_X0, L, ly, "sl_sage_stack_fwd")) != SG_OK) return rc;
+  const float *X = d_X0, *xam = d_x0_amax;
+  int64_t ldx = ldx0;
+  for (uint32_t l = 0; l < L; ++l) {
+    const sl_sage_stack_layer &y = ly[l];
+    if ((rc = sl_sage_fwd(adj, X, ldx, y.Fin, y.Fout, y.Ws, y.ldws, y.bs, y.Wn, y.ldwn, y.bn, y.scale, y.offset, y.act, y.drop_p, y.drop_seed,
+                          y.AX, y.ldax, y.Zs, y.Zn, y.out, nullptr, xam, y.out_amax, d_pack, l == 0 ? x0_pad_zero : 0, y.row_stats,
+                          stream)) != SG_OK)
+      return rc;
+    X = y.out, ldx = y.Fout, xam = y.out_amax;
+  }
+  return SG_OK;
+}
+
+extern "C" int sl_sage_stack_bwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, const float *d_x0_amax, uint32_t L,
+                                 const sl_sage_stack_layer *ly, const float *d_dout, const uint32_t *d_dout_rows, uint32_t num_dout_rows,
+                                 float *d_dX0, float *d_buf, float *d_amax, float *d_an_partial, float *d_chain_partial,
+                                 float *d_tn_partial, void *d_pack, void *stream) {
+  int rc;
+  if ((rc = stack_check(adj, d_X0, L, ly, "sl_sage_stack_bwd")) != SG_OK) return rc;
+  if (!d_dout || !d_buf || !d_amax || !d_an_partial || !d_tn_partial || !d_pack || (L > 1 && !d_chain_partial))
+    return set_error(SG_ERR_INVALID, "sl_sage_stack_bwd: null argument");
+  const uint32_t n = adj->n;
+  uint32_t Fmax = 0;
+  for (uint32_t l = 0; l < L; ++l) Fmax = std::max(Fmax, ly[l].Fout);
+  // [dZs | A^T dZn | dZn] of layer l lives in half (l & 1) of d_buf: written by layer l + 1's call (or layer l's own act_norm
+  // backward at the top), read by layer l's -- two halves in turn do for the whole stack
+  const size_t half = (size_t)n * 3 * Fmax;
+  for (uint32_t l = L; l-- > 0;) {
+    const sl_sage_stack_layer &y = ly[l];
+    const bool top = l + 1 == L;
+    float *buf = d_buf + (l & 1u) * half, *am = d_amax + (l & 1u) * (size_t)n;
+    sl_sage_below below;
+    if (l > 0) {
+      const sl_sage_stack_layer &b = ly[l - 1];
+      if (y.Fout % 32) return set_error(SG_ERR_INVALID, "sl_sage_stack_bwd: chained layers need Fout %% 32 == 0 (layer %u: %u)", l, y.Fout);
+      below.Zs = b.Zs, below.Zn = b.Zn, below.bs = b.bs, below.bn = b.bn, below.scale = b.scale, below.offset = b.offset;
+      below.act = b.act, below.drop_p = b.drop_p, below.drop_seed = b.drop_seed, below.F = b.Fout;
+      below.buf = d_buf + ((l - 1) & 1u) * half, below.dscale = b.dscale, below.doffset = b.doffset, below.dbias = b.dbias;
+      below.partial = d_chain_partial, below.amax = d_amax + ((l - 1) & 1u) * (size_t)n, below.stats = b.row_stats;
+    }
+    const float *X = l ? ly[l - 1].out : d_X0;
+    if ((rc = sl_sage_bwd_chain(adj, X, l ? (int64_t)ly[l - 1].Fout : ldx0, y.AX, y.ldax, y.Zs, y.Zn, y.Fin, y.Fout, y.Ws, y.ldws, y.bs, y.Wn,
+                                y.ldwn, y.bn, y.scale, y.offset, y.act, y.drop_p, y.drop_seed, top ? d_dout : nullptr, nullptr,
+                                l == 0 ? d_dX0 : nullptr, y.dWs, y.dWn, y.dbias, y.dscale, y.doffset, buf, d_an_partial, d_tn_partial, d_pack,
+                                top ? 0 : 1, l > 0 ? &below : nullptr, top ? nullptr : am, top ? d_dout_rows : nullptr,
+                                top ? num_dout_rows : 0, l ? ly[l - 1].out_amax : d_x0_amax, stream)) != SG_OK)
+      return rc;
+  }
+  return SG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // GCN (shaDow/layers.py:417-444): out = norm(act((A X) W^T + b)).  Forward: SpMM, weight pack, GEMM, fused bias / act /
 // norm; backward: act_norm backward, dAX = dZ W, dX = A^T dAX, dW = dZ^T (A X).
 // ---------------------------------------------------------------------------------------------------------------

@@ -157,6 +157,10 @@ class DeepGNN(nn.Module):
         state = (feat, adj, False, dropedge)
         outs = []
         self._plan_dropout_fusion(i)
+        if not levels and ops.SAGE_STACK and self._stack_plan.get(i):
+            emb = self._run_stack(convs, feat, adj, tgt, dropedge)
+            if emb is not None:
+                return emb
         for md in convs[:num_full]:
             state = md(state, sizes_subg=sizes)
             outs.append(state[0])
@@ -175,6 +179,31 @@ class DeepGNN(nn.Module):
         for md, level in zip(convs[num_full:], levels):
             x = md.forward_rows(x, adj_norm, level)
         return x
+
+    def _run_stack(self, convs, feat, adj, tgt, dropedge):
+        """The whole GraphSAGE stack + the read-out's row select as one node (ops._SageStack: one C call per direction), or None
+        when this batch goes layer by layer: training batches large enough for the row-sparse top-layer backward (ops.SPARSE_TOP_BWD,
+        a different set of kernels), a layer 0 that gathers inside its aggregation kernel."""
+        first = convs[0]
+        n = int(feat.shape[0])
+        if self.training and torch.is_grad_enabled() and ops.SPARSE_TOP_BWD and n >= ops.SPARSE_TOP_BWD_MIN_ROWS:
+            return None
+        if n < max(1, ops.GEMM_SPLIT_MIN_ROWS) or not feat.is_cuda:
+            return None
+        lazy = isinstance(feat, ops.LazyRows)
+        if lazy and ops.FUSE_GATHER_INTO_SPMM:
+            return None
+        if torch.is_grad_enabled() and not all(p.requires_grad for md in convs for p in md.parameters()):
+            return None
+        # (from here on the step's random draws are taken in the layer-by-layer order: drop-edge, input dropout, output dropouts)
+        adj_norm = first.norm_adj(adj, False, dropedge, feat.device)
+        if lazy:
+            x0, _seed = feat.gather_dropped(first._in_p())
+        else:
+            x0 = first.in_dropout(feat)
+        emb = ops.sage_stack(x0, adj_norm, convs, tgt)
+        assert emb is not None
+        return emb
 
     def forward(self, mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge, tail_ens=None):
         emb_subg_ens = []
@@ -249,10 +278,21 @@ class DeepGNN(nn.Module):
                 nxt.input_pre_dropped = bool(fuse)
         if layers_i and hasattr(layers_i[0], 'input_pre_dropped'):
             layers_i[0].input_pre_dropped = False
+        # the whole stack as one autograd node (ops._SageStack): GraphSAGE layers only, nothing but the next layer / the row select
+        # reads a layer's output, and every inner input dropout is applied by the producing layer's kernel (or is the identity)
+        self._stack_plan[i] = bool(not dual and self.prediction_task == 'node' and rp.dim_in == 0
+                                   and all(type(md) is layers.GraphSAGE for md in layers_i)
+                                   and all((not self.training) or md.dropout <= 0 or md.input_pre_dropped for md in layers_i[1:])
+                                   and ops.sage_stack_usable(layers_i))
+
+    @property
+    def _stack_plan(self):
+        return self.__dict__.setdefault('_stack_plan_d', {})
 
     def invalidate_fusion_plan(self):
         """Forget the cached dropout / chaining plan (call after editing planned layer attributes by hand)."""
         self.__dict__.pop('_fusion_plan_keys', None)
+        self.__dict__.pop('_stack_plan_d', None)
 
     def train(self, mode: bool = True):
         self.invalidate_fusion_plan()

@@ -1621,6 +1621,175 @@ class _SageDense(torch.autograd.Function):
         return dX, None, dWs, dbs, dWn, dbn, dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None
 
 
+# One C call per direction for a whole stack of chained GraphSAGE layers (sl_sage_stack_fwd / sl_sage_stack_bwd) instead of one
+# per layer: the same per-layer entries in the same order (bit-identical), minus ~100 us of Python, ctypes and autograd work per
+# layer and direction -- which is what bounds a step at the reference's own batch sizes.  SHADOW_SAGE_STACK=0: layer by layer.
+SAGE_STACK = os.environ.get("SHADOW_SAGE_STACK", "1") != "0"
+
+
+class _SageStack(torch.autograd.Function):
+    """The conv loop of DeepGNN.forward (shaDow/models.py:193-197) over L GraphSAGE layers (layers.py:471-483) plus the
+    read-out's row select (layers.py:159-163) as ONE autograd node: forward = sl_sage_stack_fwd, backward = sl_sage_stack_bwd,
+    i.e. the chained one-call layer passes of _SageDense issued from C.  Preconditions (``stack_usable``): residue 'none' +
+    centre pooling on a node task (nothing but layer l + 1 reads layer l's output, nothing but the row select reads the last
+    one), one hidden width F with F % 32 == 0 <= 256, no dual output."""
+    calls = 0
+
+    @staticmethod
+    def forward(ctx, X0, adj, rows, meta, *params):
+        lib = _lib.load()
+        L = len(meta)
+        n, F0 = X0.shape
+        F = params[0].shape[0]
+        dev = X0.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
+        AX0 = torch.empty(n, pitch0, **f32)
+        big = torch.empty(4 * L - 1, n, F, **f32)            # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
+        amax = torch.empty(L, n, **f32)
+        # (row statistics for the chained backward: the layers another layer chains into, as _SageDense.forward decides)
+        stats_ok = CHAIN_SAGE_BWD and ROW_STATS_HANDOVER and bool(lib.sl_gemm_act_norm_supported(F, F))
+        stats0_ok = CHAIN_SAGE_BWD and ROW_STATS_HANDOVER and bool(lib.sl_gemm_act_norm_supported(F, F0)) and AX0.stride(0) % 4 == 0
+        stats = torch.empty(max(1, L - 1), n, 4, **f32) if (L > 1 and (stats_ok or stats0_ok)) else None
+        arr = (_lib.SlSageStackLayer * L)()
+        base, step = big.data_ptr(), n * F * 4
+        for l in range(L):
+            Ws, bs, Wn, bn, sc, of = params[6 * l:6 * l + 6]
+            y = arr[l]
+            y.Ws, y.Wn, y.scale, y.offset = Ws.data_ptr(), Wn.data_ptr(), sc.data_ptr(), of.data_ptr()
+            y.bs = bs.data_ptr() if bs is not None else None
+            y.bn = bn.data_ptr() if bn is not None else None
+            y.ldws, y.ldwn = Ws.stride(0), Wn.stride(0)
+            y.Fin, y.Fout = (F0 if l == 0 else F), F
+            y.act, y.drop_p, y.drop_seed = meta[l]
+            if l == 0:
+                y.AX, y.ldax = AX0.data_ptr(), AX0.stride(0)
+            else:
+                y.AX, y.ldax = base + (3 * L + l - 1) * step, F
+            y.Zs, y.Zn, y.out = base + 3 * l * step, base + (3 * l + 1) * step, base + (3 * l + 2) * step
+            y.out_amax = amax.data_ptr() + l * n * 4
+            if stats is not None and l < L - 1 and (stats_ok if l else stats0_ok):
+                y.row_stats = stats.data_ptr() + l * n * 16
+        x0_amax = get_row_amax(X0)
+        pack = torch.empty(lib.sl_sage_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
+        a = _adj_struct(adj, False)
+        check(lib.sl_sage_stack_fwd(C.byref(a), X0.data_ptr(), X0.stride(0), x0_amax.data_ptr() if x0_amax is not None else None,
+                                    1 if getattr(X0, "_shd_pad_zero", False) else 0, L, arr, pack.data_ptr(), _stream(X0)))
+        if Z_TAP is not None:
+            for l in range(L):
+                _tap([big[3 * l], big[3 * l + 1]], [params[6 * l + 1], params[6 * l + 3]])
+        ctx.save_for_backward(X0, *[p for p in params if p is not None])
+        ctx.has = [p is not None for p in params]
+        ctx.rows = rows
+        ctx.adj, ctx.arr, ctx.L, ctx.x0_amax = adj, arr, L, x0_amax
+        ctx.keep = (AX0, big, amax, stats)                   # (the forward products the descriptors point into)
+        ctx.set_materialize_grads(False)
+        _SageStack.calls += 1
+        _SageDense.fused_calls += L                          # (the one-call layer entries ran L times, from C)
+        fire_deferred()
+        out = big[3 * (L - 1) + 2]
+        return out.index_select(0, rows) if rows is not None else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        X0 = saved[0]
+        it = iter(saved[1:])
+        params = [next(it) if h else None for h in ctx.has]
+        L, arr, adj, rows = ctx.L, ctx.arr, ctx.adj, ctx.rows
+        n, F0 = X0.shape
+        F = params[0].shape[0]
+        dev = X0.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        r = int(rows.numel()) if rows is not None else n
+        d = _f32c(dout).contiguous() if dout is not None else torch.zeros(r, F, **f32)
+        want_dx0 = bool(ctx.needs_input_grad[0])
+        dX0 = torch.empty(n, F0, **f32) if want_dx0 else None
+        dW = torch.empty(max(1, L - 1), 2, F, F, **f32)
+        dW0 = torch.empty(2, F, F0, **f32)
+        ds = torch.empty(L, 3, 2, F, **f32)                  # per layer dscale, doffset, dbias
+        buf = torch.empty(2, n, 3 * F, **f32)
+        am = torch.empty(2, n, **f32)
+        an_partial = torch.empty(2048 * 2 * 3 * F, **f32)
+        chain_partial = torch.empty(max(lib.sl_sage_chain_partial_floats(n, F), 1), **f32) if L > 1 else None
+        sl = lib.sl_gemm_tn_slices(n)
+        tn_partial = torch.empty(max((2 if ctx.x0_amax is not None else 1) * sl * F * F0, 2 * sl * F * F if L > 1 else 0), **f32)
+        pack = torch.empty(lib.sl_sage_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
+        wbase, wstep = dW.data_ptr(), F * F * 4
+        sbase, sstep = ds.data_ptr(), 2 * F * 4
+        for l in range(L):
+            y = arr[l]
+            if l == 0:
+                y.dWs, y.dWn = dW0.data_ptr(), dW0.data_ptr() + F * F0 * 4
+            else:
+                y.dWs, y.dWn = wbase + 2 * (l - 1) * wstep, wbase + (2 * (l - 1) + 1) * wstep
+            y.dscale, y.doffset = sbase + 3 * l * sstep, sbase + (3 * l + 1) * sstep
+            y.dbias = (sbase + (3 * l + 2) * sstep) if (ctx.has[6 * l + 1] or ctx.has[6 * l + 3]) else None
+        a = _adj_struct(adj, want_dx0 or L > 1)
+        rows32 = rows.to(torch.int32) if rows is not None else None
+        check(lib.sl_sage_stack_bwd(C.byref(a), X0.data_ptr(), X0.stride(0), ctx.x0_amax.data_ptr() if ctx.x0_amax is not None else None, L,
+                                    arr, d.data_ptr(), rows32.data_ptr() if rows32 is not None else None, r if rows32 is not None else 0,
+                                    dX0.data_ptr() if dX0 is not None else None, buf.data_ptr(), am.data_ptr(), an_partial.data_ptr(),
+                                    chain_partial.data_ptr() if chain_partial is not None else None, tn_partial.data_ptr(),
+                                    pack.data_ptr(), _stream(X0)))
+        _SageDense.chained_calls += L - 1
+        ctx.keep = ctx.arr = None
+        grads = []
+        ng = ctx.needs_input_grad
+        for l in range(L):
+            Wg = dW0 if l == 0 else dW[l - 1]
+            g = ds[l]
+            hb_s, hb_n = ctx.has[6 * l + 1], ctx.has[6 * l + 3]
+            k = 4 + 6 * l
+            grads += [Wg[0] if ng[k] else None, g[2, 0] if (hb_s and ng[k + 1]) else None, Wg[1] if ng[k + 2] else None,
+                      g[2, 1] if (hb_n and ng[k + 3]) else None, g[0].view(params[6 * l + 4].shape) if ng[k + 4] else None,
+                      g[1].view(params[6 * l + 5].shape) if ng[k + 5] else None]
+        return (dX0, None, None, None, *grads)
+
+
+def sage_stack_usable(mods) -> bool:
+    """The static part of _SageStack's preconditions for a list of layers.GraphSAGE modules (everything that does not change
+    from step to step; DeepGNN caches it)."""
+    if not (SAGE_STACK and FUSED_LAYER_CALLS and GEMM_SPLIT and CHAIN_SAGE_BWD and ROOTS_SPARSE_GRAD and mods):
+        return False
+    F = mods[0].f_lin_self.weight.shape[0]
+    if not (F % 32 == 0 and 32 <= F <= 256):
+        return False
+    for l, md in enumerate(mods):
+        ws, wn = md.f_lin_self.weight, md.f_lin_neigh.weight
+        Fi = ws.shape[1]
+        if not (getattr(md, "norm", None) == "norm_feat" and md.act is None and md.act_name in ACT_CODE and tuple(ws.shape) == tuple(wn.shape)
+                and ws.shape[0] == F and (Fi == F if l else (Fi % 4 == 0 and Fi <= 256)) and ws.is_cuda and ws.dtype == torch.float32
+                and ws.stride(1) == 1 and wn.stride(1) == 1 and tuple(md.scale.shape) == (2, F) and md.scale.is_contiguous()
+                and md.offset.is_contiguous() and md.scale.dtype == torch.float32):
+            return False
+    return True
+
+
+def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tensor]):
+    """out_L[rows] of the GraphSAGE modules ``mods`` applied in turn to X0 (already through layer 0's input dropout) -- see
+    _SageStack; every layer's fused output dropout is ``mods[l]._out_p()`` (drawn here, in layer order).  Returns None when the
+    stack form does not apply to this call (the caller then runs the layers one by one)."""
+    n = X0.shape[0]
+    if n < max(1, GEMM_SPLIT_MIN_ROWS) or not X0.is_cuda:
+        return None
+    params = []
+    for md in mods:
+        params += [md.f_lin_self.weight, md.f_lin_self.bias, md.f_lin_neigh.weight, md.f_lin_neigh.bias, md.scale, md.offset]
+    if torch.is_grad_enabled() and not all(p is None or p.requires_grad for p in params):
+        return None                                          # (frozen parameters: the layer-by-layer nodes handle them)
+    X0 = _f32c(X0)
+    if not (X0.stride(1) == 1 and X0.stride(0) % 4 == 0 and X0.data_ptr() % 16 == 0):
+        X0 = X0.contiguous()
+    F = mods[0].f_lin_self.weight.shape[0]
+    meta = []
+    for md in mods:
+        drop = _drop_arg(md._out_p(), F)
+        meta.append((ACT_CODE[md.act_name], float(drop[0]), int(drop[1])))
+    return _SageStack.apply(X0, adj, rows, tuple(meta), *params)
+
+
 # (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (SHADOW_ROW_STATS=0: recomputed)
 ROW_STATS_HANDOVER = os.environ.get("SHADOW_ROW_STATS", "1") != "0"
 # Weight-gradient kernels of the chained backward on a second stream, beside the input-gradient kernel of the same layer

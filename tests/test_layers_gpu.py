@@ -1220,7 +1220,7 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
-                     dropedge=0.0):
+                     dropedge=0.0, stack=None, aug=False, train=True):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
@@ -1232,6 +1232,9 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
     prev_c, prev_s = ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD
     ops.CHAIN_SAGE_BWD = chain
     prev_m = ops.SPARSE_TOP_BWD_MIN_ROWS
+    prev_k = ops.SAGE_STACK
+    if stack is not None:
+        ops.SAGE_STACK = stack                     # (the whole stack as one autograd node / layer by layer)
     if sparse_top is not None:
         ops.SPARSE_TOP_BWD = sparse_top
         ops.SPARSE_TOP_BWD_MIN_ROWS = 1024          # (the production threshold is a host-time trade-off, not a correctness bound)
@@ -1239,7 +1242,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         arch = dict(num_layers=n_layers, num_cls_layers=1, heads=1, dim=dim, act=act, layer_norm="norm_feat",
                     feature_augment_ops="sum", aggr="sage", residue="none", pooling="center", loss="softmax")
         torch.manual_seed(seed)
-        model = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
+        model = DeepGNN(F0, F0, C, 0, arch, [("hops", 7)] if aug else [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
         with torch.no_grad():
             for q in model.parameters():
                 q.add_(0.05 * torch.randn_like(q))
@@ -1251,10 +1254,20 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         if given_plan:                       # the row sets of the row-sparse top-layer backward come with the batch (as from the extractor)
             from shadow_gnn_amd import tail
             b.target._shd_top_plan = tail.TopBackwardPlan(adj, b.target)
-        batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
+        feat_aug = {}
+        if aug:                              # hop codes of the encoding the augmentation Linear reads (any values in range do here)
+            hop = torch.randint(-1, 5, (b.num_nodes,), generator=torch.Generator().manual_seed(seed + 3)).to(torch.int32).to(DEV)
+            feat_aug = {"hops": ops.OneHotCodes(ops.encode_codes("hops", hop, 7), 7)}
+        batch = OneBatchSubgraph([adj], [X.to(DEV)], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [feat_aug])
         model.optimizer = torch.optim.SGD([q for q in model.parameters() if q.requires_grad], lr=0.0)         # keep the (clipped) gradients readable
         c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls)
         torch.manual_seed(seed + 1)                                           # dropout seeds come from torch's CPU generator
+        torch.cuda.manual_seed(seed + 2)                                      # (drop-edge positions, nn.Dropout on an augmented layer-0 input)
+        if not train:
+            from shadow_gnn_amd.minibatch import VALID
+            ret = model.step(VALID, "running", batch)
+            torch.cuda.synchronize()
+            return float(ret["loss"]), ret["preds"].detach().clone(), {}, (ops._SageDense.fused_calls - c0[0], 0)
         ret = model.step(TRAIN, "running", batch)
         torch.cuda.synchronize()
         calls = (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1])
@@ -1263,6 +1276,36 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
     finally:
         lib.sl_set_fused_epilogue(prev_f)
         ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS = prev_c, prev_s, prev_m
+        ops.SAGE_STACK = prev_k
+
+
+@pytest.mark.parametrize("n_layers,dim,p_drop,dropedge,act,aug,F0", [(5, 256, 0.4, 0.05, "relu", False, 100), (3, 128, 0.3, 0.0, "elu", True, 100),
+                                                                     (2, 64, 0.0, 0.1, "elu", False, 128), (1, 256, 0.2, 0.0, "relu", True, 100),
+                                                                     (4, 32, 0.25, 0.15, "tanh", False, 36)])
+def test_sage_stack_call_equals_layer_by_layer(n_layers, dim, p_drop, dropedge, act, aug, F0):
+    """ops._SageStack (sl_sage_stack_fwd / sl_sage_stack_bwd: the whole GraphSAGE stack + the read-out's row select as ONE
+    autograd node, one C call per direction) against the layer-by-layer nodes: the C entries run the same per-layer entries with
+    the same arguments in the same order, so loss, predictions and EVERY parameter gradient are bit-identical -- with fused
+    dropout masks, drop-edge, an augmented (gradient-carrying) layer-0 input, widths with and without a K tail; also in
+    evaluation mode."""
+    from shadow_gnn_amd import ops
+    k0 = ops._SageStack.calls
+    l0, p0, g0, calls0 = _sage_stack_step(n_layers, dim, p_drop, 31, chain=True, fused=True, B=128, act=act, F0=F0, sparse_top=False,
+                                          dropedge=dropedge, stack=False, aug=aug)
+    assert ops._SageStack.calls == k0
+    l1, p1, g1, calls1 = _sage_stack_step(n_layers, dim, p_drop, 31, chain=True, fused=True, B=128, act=act, F0=F0, sparse_top=False,
+                                          dropedge=dropedge, stack=True, aug=aug)
+    assert ops._SageStack.calls == k0 + 1, "the stack entry was not taken"
+    assert calls0 == calls1 == (n_layers, n_layers - 1)
+    assert l0 == l1
+    torch.testing.assert_close(p1, p0, rtol=0, atol=0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+    e0 = _sage_stack_step(n_layers, dim, p_drop, 31, chain=True, fused=True, B=128, act=act, F0=F0, stack=False, aug=aug, train=False)
+    e1 = _sage_stack_step(n_layers, dim, p_drop, 31, chain=True, fused=True, B=128, act=act, F0=F0, stack=True, aug=aug, train=False)
+    assert ops._SageStack.calls == k0 + 2 and e0[0] == e1[0]
+    torch.testing.assert_close(e1[1], e0[1], rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("n_layers,dim,p_drop,act", [(3, 256, 0.4, "relu"), (5, 256, 0.0, "elu"), (3, 128, 0.3, "elu")])
