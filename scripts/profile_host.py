@@ -42,3 +42,5 @@ torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step under the profiler")
 st = pstats.Stats(pr); st.sort_stats("tottime")
 st.print_stats(45)
+st.sort_stats("cumulative")
+st.print_stats(70)

@@ -152,17 +152,18 @@ class GradSync:
         from . import ops
         ops.join_aux()               # (weight gradients computed on the auxiliary stream of the chained backward)
         dst, src = [], []
+        views, params = self._views, self.params
         for i in range(lo, hi):
-            g = self.params[i].grad
-            if g is None or g is self._views[i]:
+            g = params[i].grad
+            v = views[i]
+            if g is v:
                 continue
-            if g.data_ptr() == self._views[i].data_ptr():      # (a foreign view of the same storage: already in place)
+            params[i].grad = v                                 # (also for a parameter without a gradient this step: zeros)
+            if g is None or g.data_ptr() == v.data_ptr():      # (a foreign view of the same storage: already in place)
                 continue
-            dst.append(self._views[i]); src.append(g.detach().reshape(self._views[i].shape))
+            dst.append(v); src.append(g if g.shape == v.shape else g.reshape(v.shape))
         if dst:
             torch._foreach_copy_(dst, src)
-        for i in range(lo, hi):
-            self.params[i].grad = self._views[i]
 
     def _issue(self, s):
         self._pack(s)

@@ -193,7 +193,10 @@ class DeepGNN(nn.Module):
         lazy = isinstance(feat, ops.LazyRows)
         if lazy and ops.FUSE_GATHER_INTO_SPMM:
             return None
-        if torch.is_grad_enabled() and not all(p.requires_grad for md in convs for p in md.parameters()):
+        plist = self.__dict__.get('_stack_params')
+        if plist is None or plist[0] is not convs[0]:
+            plist = self.__dict__['_stack_params'] = (convs[0], [p for md in convs for p in md.parameters()])
+        if torch.is_grad_enabled() and not all(p.requires_grad for p in plist[1]):
             return None
         # (from here on the step's random draws are taken in the layer-by-layer order: drop-edge, input dropout, output dropouts)
         adj_norm = first.norm_adj(adj, False, dropedge, feat.device)
@@ -206,7 +209,17 @@ class DeepGNN(nn.Module):
         return emb
 
     def forward(self, mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge, tail_ens=None):
-        emb_subg_ens = []
+        return self._head(self._embed(mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge, tail_ens))
+
+    def _head(self, embs):
+        emb_subg_ens = [F.normalize(emb, p=2, dim=1) for emb in embs]          # shaDow/models.py:200
+        pred_subg = self.classifier(self.ensembler(emb_subg_ens))
+        ops.fire_deferred("fwd")                     # (the extractor's deferred prefetch: see ops.defer)
+        return pred_subg, emb_subg_ens
+
+    def _embed(self, mode, feat_ens, adj_ens, target_ens, size_subg_ens, feat_aug_ens, dropedge, tail_ens=None):
+        """The branches' read-out rows (before the L2 normalisation): augmentation, conv stack, ResPool per branch."""
+        embs = []
         for i, feat in enumerate(feat_ens):
             tgt = torch.as_tensor(target_ens[i], device=feat.device).long()
             if getattr(target_ens[i], "_shd_top_plan", None) is not None:      # (minibatch: row sets of the row-sparse top-layer backward)
@@ -227,10 +240,23 @@ class DeepGNN(nn.Module):
             emb = self._run_branch(i, feat, adj_i, tgt, size_subg_ens[i], dropedge, levels)
             if i + 1 == len(feat_ens):
                 ops.fire_deferred("body")                # (the big kernels of the forward pass are enqueued)
-            emb_subg_ens.append(F.normalize(emb, p=2, dim=1))
-        pred_subg = self.classifier(self.ensembler(emb_subg_ens))
-        ops.fire_deferred("fwd")                     # (the extractor's deferred prefetch: see ops.defer)
-        return pred_subg, emb_subg_ens
+            embs.append(emb)
+        return embs
+
+    def _fused_head(self, embs, index):
+        """(loss, softmax(preds), [normalised embeddings]) from ops.node_head (csrc/head.hip: one kernel forward, two backward) when
+        the head is the default one -- a single branch, the one-layer classifier with feature normalisation, softmax loss on class
+        indices -- else None."""
+        if not ops.FUSED_HEAD or self.sigmoid_loss or len(embs) != 1 or len(self.classifier) != 1 or index is None:
+            return None
+        cls = self.classifier[0]
+        if not (type(cls) is layers.MLP and isinstance(self.ensembler, layers.EnsembleDummy) and cls.norm == 'norm_feat' and cls.act is None
+                and cls.act_name == 'I' and (cls.dropout <= 0 or not self.training)
+                and ops.node_head_usable(embs[0], cls.f_lin, cls.scale, cls.offset, index)):
+            return None
+        loss, _preds, prob, xn = ops.node_head(embs[0], cls.f_lin, cls.scale, cls.offset, index)
+        ops.fire_deferred("fwd")
+        return loss, prob, [xn]
 
     def _tail_prunable(self, i):
         rp = self.res_pool_layers[i]
@@ -293,6 +319,7 @@ class DeepGNN(nn.Module):
         """Forget the cached dropout / chaining plan (call after editing planned layer attributes by hand)."""
         self.__dict__.pop('_fusion_plan_keys', None)
         self.__dict__.pop('_stack_plan_d', None)
+        self.__dict__.pop('_stack_params', None)
 
     def train(self, mode: bool = True):
         self.invalidate_fusion_plan()
@@ -347,10 +374,16 @@ class DeepGNN(nn.Module):
         index = labels.to(torch.int64) if (labels.dim() == 1 and not self.sigmoid_loss) else None
         if labels.dim() == 1 and self.num_classes > 1:
             labels = F.one_hot(labels.to(torch.int64), num_classes=self.num_classes)
+        probs = None
         if training:
             self._begin_update()
-            preds, emb_ens = self(mode, dropedge=self.dropedge, **fwd)
-            loss = self._loss(preds, labels if index is None else index)
+            embs = self._embed(mode, dropedge=self.dropedge, **fwd)
+            head = self._fused_head(embs, index)
+            if head is not None:
+                loss, probs, emb_ens = head
+            else:
+                preds, emb_ens = self._head(embs)
+                loss = self._loss(preds, labels if index is None else index)
             weight = loss_scale * (getattr(batch_data, "loss_weight", 1.0) if self.grad_sync is not None else 1.0)
             ops.arm_aux_stream(True)         # (weight-gradient kernels beside the input-gradient kernels, joined right below)
             try:
@@ -363,11 +396,17 @@ class DeepGNN(nn.Module):
             if self.training:
                 self.eval()
             with torch.no_grad():
-                preds, emb_ens = self(mode, dropedge=0., **fwd)
-                loss = self._loss(preds, labels if index is None else index)
-        assert preds.shape[0] == labels.shape[0]
-        return {'batch_size': preds.shape[0], 'loss': loss, 'labels': labels,
-                'preds': self.predict(preds), 'emb_ens': emb_ens}
+                embs = self._embed(mode, dropedge=0., **fwd)
+                head = self._fused_head(embs, index)
+                if head is not None:
+                    loss, probs, emb_ens = head
+                else:
+                    preds, emb_ens = self._head(embs)
+                    loss = self._loss(preds, labels if index is None else index)
+        if probs is None:
+            probs = self.predict(preds)
+        assert probs.shape[0] == labels.shape[0]
+        return {'batch_size': probs.shape[0], 'loss': loss, 'labels': labels, 'preds': probs, 'emb_ens': emb_ens}
 
     def __str__(self):
         return f"model name: {type(self).__name__}"

@@ -1706,9 +1706,10 @@ class _SageStack(torch.autograd.Function):
         d = _f32c(dout).contiguous() if dout is not None else torch.zeros(r, F, **f32)
         want_dx0 = bool(ctx.needs_input_grad[0])
         dX0 = torch.empty(n, F0, **f32) if want_dx0 else None
-        dW = torch.empty(max(1, L - 1), 2, F, F, **f32)
+        dW = torch.empty(2 * max(1, L - 1), F, F, **f32)     # dWs, dWn of the layers 1 .. L - 1
         dW0 = torch.empty(2, F, F0, **f32)
-        ds = torch.empty(L, 3, 2, F, **f32)                  # per layer dscale, doffset, dbias
+        ds = torch.empty(2 * L, 2, F, **f32)                 # per layer dscale, doffset [2, F]
+        db = torch.empty(2 * L, F, **f32)                    # per layer dbias of the self / neighbour Linear
         buf = torch.empty(2, n, 3 * F, **f32)
         am = torch.empty(2, n, **f32)
         an_partial = torch.empty(2048 * 2 * 3 * F, **f32)
@@ -1717,15 +1718,15 @@ class _SageStack(torch.autograd.Function):
         tn_partial = torch.empty(max((2 if ctx.x0_amax is not None else 1) * sl * F * F0, 2 * sl * F * F if L > 1 else 0), **f32)
         pack = torch.empty(lib.sl_sage_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
         wbase, wstep = dW.data_ptr(), F * F * 4
-        sbase, sstep = ds.data_ptr(), 2 * F * 4
+        sbase, sstep, bbase = ds.data_ptr(), 2 * F * 4, db.data_ptr()
         for l in range(L):
             y = arr[l]
             if l == 0:
                 y.dWs, y.dWn = dW0.data_ptr(), dW0.data_ptr() + F * F0 * 4
             else:
                 y.dWs, y.dWn = wbase + 2 * (l - 1) * wstep, wbase + (2 * (l - 1) + 1) * wstep
-            y.dscale, y.doffset = sbase + 3 * l * sstep, sbase + (3 * l + 1) * sstep
-            y.dbias = (sbase + (3 * l + 2) * sstep) if (ctx.has[6 * l + 1] or ctx.has[6 * l + 3]) else None
+            y.dscale, y.doffset = sbase + 2 * l * sstep, sbase + (2 * l + 1) * sstep
+            y.dbias = (bbase + l * sstep) if (ctx.has[6 * l + 1] or ctx.has[6 * l + 3]) else None
         a = _adj_struct(adj, want_dx0 or L > 1)
         rows32 = rows.to(torch.int32) if rows is not None else None
         check(lib.sl_sage_stack_bwd(C.byref(a), X0.data_ptr(), X0.stride(0), ctx.x0_amax.data_ptr() if ctx.x0_amax is not None else None, L,
@@ -1735,16 +1736,16 @@ class _SageStack(torch.autograd.Function):
                                     pack.data_ptr(), _stream(X0)))
         _SageDense.chained_calls += L - 1
         ctx.keep = ctx.arr = None
+        # (one unbind per buffer instead of an index op per gradient: ~40 views per step)
+        Wg = dW0.unbind(0) + (dW.unbind(0) if L > 1 else ())
+        sg, bg = ds.unbind(0), db.unbind(0)
         grads = []
         ng = ctx.needs_input_grad
         for l in range(L):
-            Wg = dW0 if l == 0 else dW[l - 1]
-            g = ds[l]
             hb_s, hb_n = ctx.has[6 * l + 1], ctx.has[6 * l + 3]
             k = 4 + 6 * l
-            grads += [Wg[0] if ng[k] else None, g[2, 0] if (hb_s and ng[k + 1]) else None, Wg[1] if ng[k + 2] else None,
-                      g[2, 1] if (hb_n and ng[k + 3]) else None, g[0].view(params[6 * l + 4].shape) if ng[k + 4] else None,
-                      g[1].view(params[6 * l + 5].shape) if ng[k + 5] else None]
+            grads += [Wg[2 * l] if ng[k] else None, bg[2 * l] if (hb_s and ng[k + 1]) else None, Wg[2 * l + 1] if ng[k + 2] else None,
+                      bg[2 * l + 1] if (hb_n and ng[k + 3]) else None, sg[2 * l] if ng[k + 4] else None, sg[2 * l + 1] if ng[k + 5] else None]
         return (dX0, None, None, None, *grads)
 
 
@@ -1788,6 +1789,99 @@ def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tens
         drop = _drop_arg(md._out_p(), F)
         meta.append((ACT_CODE[md.act_name], float(drop[0]), int(drop[1])))
     return _SageStack.apply(X0, adj, rows, tuple(meta), *params)
+
+
+# The head of a node-classification step (L2 normalisation of the root embeddings, the one-layer classifier, softmax cross
+# entropy) as one kernel forward and two backward (csrc/head.hip) instead of ~35 small torch / HIP kernels and their launches.
+# SHADOW_FUSED_HEAD=0: the separate nodes.
+FUSED_HEAD = os.environ.get("SHADOW_FUSED_HEAD", "1") != "0"
+_HEAD_COUNTERS = {}
+
+
+def _head_counter(dev):
+    c = _HEAD_COUNTERS.get(dev)
+    if c is None:
+        c = _HEAD_COUNTERS[dev] = torch.zeros(int(_lib.load().sl_head_counter_words()), dtype=torch.int32, device=dev)
+    return c
+
+
+class _NodeHead(torch.autograd.Function):
+    """(loss, preds, softmax(preds), normalised embeddings) of shaDow/models.py:200-203 + :163-166 for a one-layer classifier
+    with feature normalisation: sl_head_fwd / sl_head_bwd.  Only ``loss`` carries a gradient."""
+    calls = 0
+
+    @staticmethod
+    def forward(ctx, emb, W, b, scale, offset, label):
+        lib = _lib.load()
+        r, F = emb.shape
+        Cn = W.shape[0]
+        dev = emb.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        xn = torch.empty(r, F, **f32)
+        zpp = torch.empty(3, r, Cn, **f32)                   # z, preds, softmax(preds)
+        small = torch.empty(2 * r + 1, **f32)                # |emb_i|, the roots' losses, the mean loss
+        cnt = _head_counter(dev)
+        step = r * Cn * 4
+        check(lib.sl_head_fwd(emb.data_ptr(), emb.stride(0), W.data_ptr(), W.stride(0), b.data_ptr() if b is not None else None,
+                              scale.data_ptr(), offset.data_ptr(), label.data_ptr(), r, F, Cn, xn.data_ptr(), zpp.data_ptr(),
+                              zpp.data_ptr() + step, zpp.data_ptr() + 2 * step, small.data_ptr(), small.data_ptr() + 4 * r,
+                              small.data_ptr() + 8 * r, cnt.data_ptr(), _stream(emb)))
+        ctx.save_for_backward(W, scale, label)
+        ctx.keep = (xn, zpp, small)
+        ctx.shapes = (tuple(scale.shape), tuple(offset.shape), b is not None)
+        ctx.set_materialize_grads(False)
+        _NodeHead.calls += 1
+        _z, preds, prob = zpp.unbind(0)
+        loss = small[2 * r:].view(())
+        ctx.mark_non_differentiable(preds, prob, xn)
+        return loss, preds, prob, xn
+
+    @staticmethod
+    def backward(ctx, dloss, *_unused):
+        lib = _lib.load()
+        W, scale, label = ctx.saved_tensors
+        xn, zpp, small = ctx.keep
+        r, F = xn.shape
+        Cn = W.shape[0]
+        dev = xn.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if dloss is None:
+            dloss = torch.zeros((), **f32)
+        g = dloss.to(torch.float32).contiguous()
+        demb = torch.empty(r, F, **f32)
+        dW = torch.empty(Cn, F, **f32)
+        dsm = torch.empty(3, Cn, **f32)                      # dbias, dscale, doffset
+        work = torch.empty(3 * r * Cn, **f32)
+        partial = torch.empty(max(1, int(lib.sl_head_partial_floats(r, F, Cn))), **f32)
+        step = r * Cn * 4
+        check(lib.sl_head_bwd(g.data_ptr(), xn.data_ptr(), zpp.data_ptr(), zpp.data_ptr() + 2 * step, small.data_ptr(), label.data_ptr(),
+                              W.data_ptr(), W.stride(0), scale.data_ptr(), r, F, Cn, demb.data_ptr(), dW.data_ptr(), dsm.data_ptr(),
+                              dsm.data_ptr() + 4 * Cn, dsm.data_ptr() + 8 * Cn, work.data_ptr(), partial.data_ptr(),
+                              _head_counter(dev).data_ptr(), _stream(xn)))
+        ctx.keep = None
+        sshape, oshape, has_b = ctx.shapes
+        db, dsc, dof = dsm.unbind(0)
+        ng = ctx.needs_input_grad
+        return (demb if ng[0] else None, dW if ng[1] else None, db if (has_b and ng[2]) else None,
+                dsc.view(sshape) if ng[3] else None, dof.view(oshape) if ng[4] else None, None)
+
+
+def node_head_usable(emb, lin, scale, offset, label) -> bool:
+    W = lin.weight
+    return bool(FUSED_HEAD and torch.is_tensor(emb) and emb.is_cuda and emb.dim() == 2 and emb.dtype == torch.float32
+                and emb.shape[0] > 0 and emb.shape[1] % 4 == 0 and emb.shape[1] <= 256 and W.shape[0] <= 256 and W.shape[1] == emb.shape[1]
+                and W.dtype == torch.float32 and W.stride(1) == 1 and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0
+                and scale.numel() == W.shape[0] and scale.is_contiguous() and offset.is_contiguous() and scale.dtype == torch.float32
+                and label is not None and label.dim() == 1 and label.dtype == torch.int64 and label.shape[0] == emb.shape[0]
+                and label.is_cuda)
+
+
+def node_head(emb, lin, scale, offset, label):
+    """(mean CE loss, preds, softmax(preds), F.normalize(emb)) -- see _NodeHead."""
+    emb = _f32c(emb)
+    if not (emb.stride(1) == 1 and emb.stride(0) % 4 == 0 and emb.data_ptr() % 16 == 0):
+        emb = emb.contiguous()
+    return _NodeHead.apply(emb, lin.weight, lin.bias, scale, offset, label.contiguous())
 
 
 # (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (SHADOW_ROW_STATS=0: recomputed)

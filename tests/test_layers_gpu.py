@@ -1534,7 +1534,8 @@ def test_sparse_readout_gradient_equals_dense(n_layers, dim, p_drop, act, monkey
     order of the dscale / doffset / dbias column sums differs)."""
     from shadow_gnn_amd import ops
     monkeypatch.setattr(ops, "ROOTS_SPARSE_GRAD", False)
-    l0, p0, g0, _ = _sage_stack_step(n_layers, dim, p_drop, 7, chain=True, fused=True, act=act)
+    # (layer by layer: the whole-stack node of ops._SageStack takes the roots' gradient directly, test_sage_stack_call_equals_layer_by_layer)
+    l0, p0, g0, _ = _sage_stack_step(n_layers, dim, p_drop, 7, chain=True, fused=True, act=act, stack=False)
     monkeypatch.setattr(ops, "ROOTS_SPARSE_GRAD", True)
     seen = []
     orig = ops._SelectRoots.backward
@@ -1544,7 +1545,7 @@ def test_sparse_readout_gradient_equals_dense(n_layers, dim, p_drop, act, monkey
         seen.append(tuple(out[0].stride()))
         return out
     monkeypatch.setattr(ops._SelectRoots, "backward", staticmethod(spy))
-    l1, p1, g1, _ = _sage_stack_step(n_layers, dim, p_drop, 7, chain=True, fused=True, act=act)
+    l1, p1, g1, _ = _sage_stack_step(n_layers, dim, p_drop, 7, chain=True, fused=True, act=act, stack=False)
     assert seen == [(0, 0)]                                   # the placeholder travelled, not a dense tensor
     assert abs(l0 - l1) < 1e-6
     torch.testing.assert_close(p1, p0, rtol=1e-6, atol=1e-7)
@@ -1856,3 +1857,64 @@ def test_sparse_top_backward_fuzz():
     failures, used = mod.run(3, 40, verbose=False)
     assert not failures, failures[:3]
     assert used >= 24, used                                  # (most trials must actually take a row-sparse pass)
+
+
+@pytest.mark.parametrize("r,F,C", [(1, 256, 47), (37, 64, 7), (128, 256, 47), (1024, 256, 47), (2500, 100, 172), (300, 256, 256), (513, 32, 3)])
+def test_fused_node_head_matches_fp64_reference(r, F, C):
+    """ops.node_head (csrc/head.hip: F.normalize -> the classifier's Linear -> _f_norm_feat over the classes -> softmax cross
+    entropy, shaDow/models.py:200-203, 163-166, layers.py:329-338) against the same chain in fp64 torch: loss, predictions,
+    probabilities, normalised embeddings <= 1e-5; the gradients of the embeddings and of every classifier parameter <= 1e-5 of
+    their scale, with an upstream factor on the loss; one all-zero embedding row (the normalisation's clamp); run-to-run
+    bit-identical (the sums over the roots run in a fixed order)."""
+    from shadow_gnn_amd import ops
+    g = torch.Generator().manual_seed(100 + r + F + C)
+    emb = torch.randn(r, F, generator=g)
+    if r > 2:
+        emb[2] = 0.0
+    lin = torch.nn.Linear(F, C)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(C, F, generator=g) * 0.5)
+        lin.bias.copy_(torch.randn(C, generator=g) * 0.1)
+    scale = (1.0 + 0.2 * torch.randn(1, C, generator=g))
+    offset = 0.1 * torch.randn(1, C, generator=g)
+    label = torch.randint(0, C, (r,), generator=g)
+    # fp64 reference
+    e64 = emb.double().requires_grad_(True)
+    p64 = [t.detach().double().requires_grad_(True) for t in (lin.weight, lin.bias, scale, offset)]
+    xn64 = torch.nn.functional.normalize(e64, p=2, dim=1)
+    z = xn64 @ p64[0].t() + p64[1]
+    mean = z.mean(dim=1, keepdim=True)
+    var = z.var(dim=1, unbiased=False).view(-1, 1) + 1e-9
+    preds64 = (z - mean) * p64[2] * torch.rsqrt(var) + p64[3]
+    loss64 = torch.nn.functional.cross_entropy(preds64, label)
+    (loss64 * 0.37).backward()
+    # the kernels
+    lin_d = torch.nn.Linear(F, C).to(DEV)
+    with torch.no_grad():
+        lin_d.weight.copy_(lin.weight); lin_d.bias.copy_(lin.bias)
+    sc_d, of_d = scale.to(DEV).requires_grad_(True), offset.to(DEV).requires_grad_(True)
+    lab_d = label.to(DEV)
+
+    def run():
+        e = emb.to(DEV).requires_grad_(True)
+        for t in (lin_d.weight, lin_d.bias, sc_d, of_d):
+            t.grad = None
+        assert ops.node_head_usable(e, lin_d, sc_d, of_d, lab_d)
+        loss, preds, prob, xn = ops.node_head(e, lin_d, sc_d, of_d, lab_d)
+        (loss * 0.37).backward()
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in (loss, preds, prob, xn, e.grad, lin_d.weight.grad, lin_d.bias.grad, sc_d.grad, of_d.grad)]
+
+    k0 = ops._NodeHead.calls
+    a = run()
+    b = run()
+    assert ops._NodeHead.calls == k0 + 2
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x, y, rtol=0, atol=0)
+    refs = [loss64, preds64, torch.softmax(preds64, 1), xn64, e64.grad, p64[0].grad, p64[1].grad, p64[2].grad, p64[3].grad]
+    names = ["loss", "preds", "prob", "xn", "demb", "dW", "db", "dscale", "doffset"]
+    for nm, got, ref in zip(names, a, refs):
+        ref = ref.detach()
+        s = max(float(ref.abs().max()), 1e-30)
+        err = float((got.cpu().double().reshape(ref.shape) - ref).abs().max())
+        assert err <= (1e-5 * s if nm not in ("preds", "loss") else 2e-5 * max(s, 1.0)), (nm, err, s)
