@@ -1,5 +1,5 @@
-"""Regenerates tests/golden/ref_config_archs.json: the `architecture` section and the dropout / dropedge / lr values
-of every training configuration the reference ships (config_train/<dataset>/<family>/<name>.yml) as plain DATA -- the
+"""Regenerates tests/golden/ref_config_archs.json: the `architecture` and `sampler` sections and the dropout / dropedge / lr /
+batch-size values of every training configuration the reference ships (config_train/<dataset>/<family>/<name>.yml) as plain DATA -- the
 list the `-m gpu` test test_ref_configs_gpu.py builds and trains one model per entry from.  Reads /root/reference (not
 present on the GPU box: only the JSON travels).
 
@@ -34,8 +34,11 @@ def collect():
             arch = arch[0]
         if isinstance(hp, list):
             hp = hp[0]
+        # the `sampler` section as it stands in the file (a list of {method, phase, per-ensemble parameter lists}) and the
+        # batch size it is cut into: the sampler parameters test_ref_configs_gpu.py checks against the oracle
         out.append(dict(name=os.path.relpath(path, base), architecture=dict(arch), dropout=_scalar(hp["dropout"]),
-                        dropedge=_scalar(hp["dropedge"]), lr=_scalar(hp["lr"])))
+                        dropedge=_scalar(hp["dropedge"]), lr=_scalar(hp["lr"]), batch_size=hp.get("batch_size"),
+                        sampler=[dict(s) for s in cfg.get("sampler", [])]))
     return out
 
 
