@@ -75,6 +75,9 @@ def pin_host_threads(local_rank: int, local_world: int, threads_per_rank: int = 
     return info
 
 
+FLAT_ALIGN = 32          # floats: tensors of the flat gradient / parameter buffers start on 128-byte lines
+
+
 class GradSync:
     """All gradients end up in one flat fp32 buffer: the data-parallel exchange is a few SUM all-reduces over contiguous
     slices of it, clip-by-global-norm and Adam (optim.FlatAdam) run over it in two launches.
@@ -97,14 +100,20 @@ class GradSync:
         self.world_size = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.group = group
         sizes = [p.numel() for p in self.params]
-        n = sum(sizes)
         dev = self.params[0].device
+        # every tensor starts on a 128-byte line of the flat buffer (the kernels take 16-byte aligned rows: a 47-class
+        # classifier's offset / scale vectors would leave the weight matrix behind them on an 8-byte boundary); the pad is zero
+        # and stays zero (zero gradient, zero moments)
+        self._off = np.zeros(len(sizes) + 1, dtype=np.int64)
+        for i, sz in enumerate(sizes):
+            self._off[i + 1] = (self._off[i] + sz + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+        self._sizes = sizes
+        n = int(self._off[-1])
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         self._views = []
         for i, p in enumerate(self.params):
             assert p.dtype == torch.float32
-            self._views.append(self.flat[self._off[i]:self._off[i + 1]].view_as(p))
+            self._views.append(self.flat[self._off[i]:self._off[i] + sizes[i]].view_as(p))
             p.grad = self._views[i]
         # slices (lo_param, hi_param) over the parameter list; slice 0 holds the LAST parameters
         self._slices = []

@@ -18,19 +18,24 @@ class FlatAdam:
         self.sync = grad_sync
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         params = grad_sync.params
-        self.flat_param = torch.empty_like(grad_sync.flat)
-        off = 0
+        self.flat_param = torch.zeros_like(grad_sync.flat)
         with torch.no_grad():
-            for p in params:
-                n = p.numel()
+            for i, p in enumerate(params):
+                n, off = p.numel(), self._offset(i)                       # (the gradient buffer's layout: line-aligned tensors, zero pads)
                 self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[off:off + n].view_as(p)          # the module's parameters ARE the flat buffer
-                off += n
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.step_count = 0
         self._scratch = None
         self.param_groups = [dict(lr=self.lr, betas=self.betas, eps=self.eps, params=list(params))]   # (torch-like, read-only)
+
+    def _offset(self, i: int) -> int:
+        """Start of parameter i in the flat buffers: dist.GradSync's table, or back to back for a plain holder of a flat buffer."""
+        off = getattr(self.sync, "_off", None)
+        if off is not None:
+            return int(off[i])
+        return sum(p.numel() for p in self.sync.params[:i])
 
     def _gather_grads(self):
         """The gradients must be IN the flat buffer: GradSync packs them lazily (param.grad is None during backward and
@@ -87,10 +92,9 @@ class FlatAdam:
         self.sync.zero()
 
     def _param_slices(self):
-        off = 0
-        for p in self.sync.params:
+        for i, p in enumerate(self.sync.params):
+            off = self._offset(i)
             yield off, off + p.numel(), p
-            off += p.numel()
 
     def state_dict(self):
         """torch.optim.Adam's layout -- {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} -- so that

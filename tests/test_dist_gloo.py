@@ -48,7 +48,7 @@ def _worker(rank, world, port, q, shares, num_buckets):
             (torch.nn.functional.cross_entropy(model(xs), ys) * (shares[rank] / total)).backward()
             assert sync._next == len(sync._slices)     # the hooks issued every slice during backward (overlap)
         sync.all_reduce()                          # ... but still enters every collective
-        flat = sync.flat.clone()
+        flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])      # (views of sync.flat, every tensor on its own 128-byte line)
         # single-process reference on the whole batch
         ref = _toy_model()
         ref.load_state_dict(model.state_dict())

@@ -947,6 +947,11 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         assert any(k.startswith("gemm_tn_f16") for k in ran) and any(k.startswith("gemm_nt2_f16") for k in ran), ran
         assert any(k.startswith("gat_fwd") for k in ran) and any(k.startswith("gat_bwd") for k in ran), ran
     assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd", "gemm_nt2_f16")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
+    # the head (normalisation + 47-class classifier + loss) ran as the fused kernels -- also with the parameters living in
+    # FlatAdam's flat buffer (optimizer "flat": every tensor on its own 128-byte line, or the classifier's weight would sit on an
+    # 8-byte boundary behind its 47-float offset / scale vectors and fall back to the separate nodes)
+    assert any(k.startswith("head_fwd_F256_C47") for k in ran) and any(k.startswith("head_bwd_rows") for k in ran), ran
+    assert not any(k.startswith("act_norm_fwd_nb1_F47") for k in ran), ran
     # ---- fp64 oracle, same parameters (relu: with the run's own side at the kink, see the docstring)
     relu_keep, kstats = None, {}
     if act == "relu" and aggr in ("sage", "gcn"):
