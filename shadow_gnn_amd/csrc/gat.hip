@@ -125,6 +125,106 @@ __global__ void gat_node_fwd_kernel(GatParams p) {
   }
 }
 
+
+// Edge loops run in GROUPS: the G column ids, then the G scores, then the G feature rows of a group are loaded together, so a
+// group costs one dependent round trip per stage instead of one per edge (sums keep the edge order: same bits as one by one).
+template <int G>
+__device__ __forceinline__ void gat_max_group(const GatParams &p, uint32_t q, uint32_t h, float as, float &mx) {
+  uint32_t c[G];
+  float u[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) c[j] = p.indices[q + j];
+#pragma unroll
+  for (int j = 0; j < G; j++) u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
+#pragma unroll
+  for (int j = 0; j < G; j++) mx = fmaxf(mx, as + lrelu02(u[j]));
+}
+template <int G>
+__device__ __forceinline__ void gat_fwd_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, float as, float mx,
+                                              float &den, float4 &acc) {
+  uint32_t c[G];
+  float u[G], w[G];
+  float4 v[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = p.edge_w ? p.edge_w[q + j] : 1.0f; }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
+    v[j] = on ? gld4(p.hn + (uint64_t)c[j] * p.F + f) : make_float4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    float pe = expf(as + lrelu02(u[j]) - mx);
+    if (p.edge_w) pe *= w[j];
+    den += pe;
+    acc.x += pe * v[j].x; acc.y += pe * v[j].y; acc.z += pe * v[j].z; acc.w += pe * v[j].w;
+  }
+}
+template <int G>
+__device__ __forceinline__ void gat_bwd_row_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, bool lead, uint32_t ls,
+                                                  float as, float mx, float inv, float t, const float4 &dn, float &das) {
+  uint32_t c[G];
+  float u[G], w[G];
+  float4 v[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = p.edge_w ? p.edge_w[q + j] : 1.0f; }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
+    v[j] = on ? gld4(p.hn + (uint64_t)c[j] * p.F + f) : make_float4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    float pe = expf(as + lrelu02(u[j]) - mx);
+    if (p.edge_w) pe *= w[j];
+    const float alpha = pe * inv;
+    const float dal = slice_sum(dot4(dn, v[j]), ls);
+    const float de = alpha * (dal - t);
+    das += de;
+    if (lead) { p.alpha[(uint64_t)(q + j) * p.H + h] = alpha; p.de[(uint64_t)(q + j) * p.H + h] = de; }
+  }
+}
+template <int G>
+__device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, float &dan, float4 &acc) {
+  uint32_t s_[G], e_[G];
+  float al[G], de[G];
+  float4 v[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) { s_[j] = p.t_indices[q + j]; e_[j] = p.t_perm[q + j]; }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    al[j] = p.alpha[(uint64_t)e_[j] * p.H + h];
+    de[j] = p.de[(uint64_t)e_[j] * p.H + h];
+    v[j] = on ? gld4(p.dnagg + (uint64_t)s_[j] * p.F + f) : make_float4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    dan += de[j];
+    acc.x += al[j] * v[j].x; acc.y += al[j] * v[j].y; acc.z += al[j] * v[j].z; acc.w += al[j] * v[j].w;
+  }
+}
+// group sizes tried before the single-edge tail: bit masks of {8, 4, 2} per kernel (scripts/ab_gat_group.sh; same box, products
+// depth-3 GAT batches, gat_fwd / gat_bwd per launch and the step: one by one 641 / 1279 us, 13.73 ms; one mask for all three
+// kernels {4} 505 / 1222, {4, 2} 481 / 1164, {2} 549 / 1101, {8, 4} 614 / 1241; forward {4, 2} with backward row / column
+// {2} / {2} 1128 us, 12.52 ms; {4} / {2} 1106, 12.43; {2} / {4, 2} 1237; one by one / {2} 1233 -- the forward kernel takes the
+// deeper groups, the backward kernels lose their occupancy to them)
+#ifndef SHADOW_GAT_GROUPS_FWD
+#define SHADOW_GAT_GROUPS_FWD 6
+#endif
+#ifndef SHADOW_GAT_GROUPS_ROW
+#define SHADOW_GAT_GROUPS_ROW 4
+#endif
+#ifndef SHADOW_GAT_GROUPS_COL
+#define SHADOW_GAT_GROUPS_COL 2
+#endif
+#define SHD_GAT_EDGES(MASK, q, b, CALL)                          \
+  do {                                                           \
+    if ((MASK) & 8) for (; q + 8 <= b; q += 8) { CALL(8); }      \
+    if ((MASK) & 4) for (; q + 4 <= b; q += 4) { CALL(4); }      \
+    if ((MASK) & 2) for (; q + 2 <= b; q += 2) { CALL(2); }      \
+    for (; q < b; q++) { CALL(1); }                              \
+  } while (0)
+
 template <int LPR>
 __global__ void gat_row_fwd_kernel(GatParams p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
@@ -136,20 +236,17 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
     const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
     const float as = lrelu02(p.u_s[r * p.H + h]);
     float mx = -INFINITY;
-    for (uint32_t q = a; q < b; q++) mx = fmaxf(mx, as + lrelu02(p.u_n[(uint64_t)p.indices[q] * p.H + h]));
+    uint32_t q = a;
+#define SHD_CALL(G) gat_max_group<G>(p, q, h, as, mx)
+    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
+#undef SHD_CALL
     if (a == b) mx = 0.f;
     float den = 0.f;
     float4 acc = make_float4(0, 0, 0, 0);
-    for (uint32_t q = a; q < b; q++) {
-      const uint32_t c = p.indices[q];
-      float pe = expf(as + lrelu02(p.u_n[(uint64_t)c * p.H + h]) - mx);
-      if (p.edge_w) pe *= p.edge_w[q];
-      den += pe;
-      if (on) {
-        const float4 v = gld4(p.hn + (uint64_t)c * p.F + f);
-        acc.x += pe * v.x; acc.y += pe * v.y; acc.z += pe * v.z; acc.w += pe * v.w;
-      }
-    }
+    q = a;
+#define SHD_CALL(G) gat_fwd_group<G>(p, q, h, f, on, as, mx, den, acc)
+    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
+#undef SHD_CALL
     den = fmaxf(den, 1e-10f);
     const float inv = 1.0f / den;
     if (on) {
@@ -178,18 +275,11 @@ __global__ void gat_row_bwd_kernel(GatParams p) {
     const float as = lrelu02(usr);
     const float mx = p.mx[r * p.H + h], inv = 1.0f / p.den[r * p.H + h];
     float das = 0.f;
-    for (uint32_t q = a; q < b; q++) {
-      const uint32_t c = p.indices[q];
-      float pe = expf(as + lrelu02(p.u_n[(uint64_t)c * p.H + h]) - mx);
-      if (p.edge_w) pe *= p.edge_w[q];
-      const float alpha = pe * inv;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (on) v = gld4(p.hn + (uint64_t)c * p.F + f);
-      const float dal = slice_sum(dot4(dn, v), ls);
-      const float de = alpha * (dal - t);
-      das += de;
-      if (on && (l % ls) == 0) { p.alpha[(uint64_t)q * p.H + h] = alpha; p.de[(uint64_t)q * p.H + h] = de; }
-    }
+    uint32_t q = a;
+    const bool lead = on && (l % ls) == 0;
+#define SHD_CALL(G) gat_bwd_row_group<G>(p, q, h, f, on, lead, ls, as, mx, inv, t, dn, das)
+    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_ROW, q, b, SHD_CALL);
+#undef SHD_CALL
     const float dus = das * dlrelu02(usr);
     float rmax = 0.f;
     if (on) {
@@ -237,15 +327,10 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
     const uint32_t a = p.t_indptr[r], b = p.t_indptr[r + 1];
     float4 acc = make_float4(0, 0, 0, 0);
     float dan = 0.f, rmax = 0.f;
-    for (uint32_t q = a; q < b; q++) {
-      const uint32_t src = p.t_indices[q], pe = p.t_perm[q];
-      const float alpha = p.alpha[(uint64_t)pe * p.H + h];
-      dan += p.de[(uint64_t)pe * p.H + h];
-      if (on) {
-        const float4 v = gld4(p.dnagg + (uint64_t)src * p.F + f);
-        acc.x += alpha * v.x; acc.y += alpha * v.y; acc.z += alpha * v.z; acc.w += alpha * v.w;
-      }
-    }
+    uint32_t q = a;
+#define SHD_CALL(G) gat_bwd_col_group<G>(p, q, h, f, on, dan, acc)
+    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_COL, q, b, SHD_CALL);
+#undef SHD_CALL
     if (on) {
       const float dun = dan * dlrelu02(p.u_n[r * p.H + h]);
       const float4 z = gld4(p.z_neigh + r * p.F + f);
