@@ -672,6 +672,32 @@ int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t ldax, const fl
                float *d_dW, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial,
                float *d_tn_partial, void *d_pack, void *stream);
 
+/* A whole stack of GCN layers per call (as sl_sage_stack_* for GraphSAGE): sl_gcn_fwd / sl_gcn_bwd layer by layer with the arguments a
+ * per-layer caller passes -- identical results.  Per layer: W [Fout, Fin] (pitch ldw), b [Fout] or NULL, scale, offset [Fout], the
+ * fused output dropout (drop_p, drop_seed), the forward products AX [n, Fin] (pitch ldax), Z, out [n, Fout] dense, and the gradients dW
+ * [Fout, Fin], dbias (NULL: no bias), dscale, doffset [Fout].  sl_gcn_stack_bwd: d_dout = the gradient of the top layer's `out`, dense
+ * [n, Fout] or -- d_dout_rows != NULL -- [num_dout_rows, Fout] for the selected (distinct) rows, scattered into a cleared buffer;
+ * d_dX0 [n, Fin_0] or NULL; scratch: d_grad 2 n max(F) floats (the layers' output gradients in turn), d_buf n * max(Fout + Fin)
+ * floats, d_an_partial / d_tn_partial / d_pack as for sl_gcn_bwd (the largest any layer needs; sl_gcn_stack_pack_bytes).          */
+typedef struct {
+  const float *W, *b, *scale, *offset;
+  int64_t ldw;
+  uint32_t Fin, Fout;
+  int act;
+  float drop_p;
+  uint64_t drop_seed;
+  float *AX;
+  int64_t ldax;
+  float *Z, *out;
+  float *dW, *dbias, *dscale, *doffset;
+} sl_gcn_stack_layer;
+size_t sl_gcn_stack_pack_bytes(uint32_t n, uint32_t L, const sl_gcn_stack_layer *layers);
+int sl_gcn_stack_fwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, uint32_t L, const sl_gcn_stack_layer *layers, void *d_pack,
+                     void *stream);
+int sl_gcn_stack_bwd(const sl_norm_adj *adj, uint32_t L, const sl_gcn_stack_layer *layers, const float *d_dout,
+                     const uint32_t *d_dout_rows, uint32_t num_dout_rows, float *d_dX0, float *d_grad, float *d_buf, float *d_an_partial,
+                     float *d_tn_partial, void *d_pack, void *stream);
+
 /* Head of a node-classification step (csrc/head.hip): emb [r, F] = the roots' rows of the last layer (layers.py:159-163) ->
  * xn = emb / max(|emb|_2, 1e-12) (models.py:200, F.normalize) -> z = xn W^T + b, preds = _f_norm_feat(z) over the C classes
  * (the one-layer classifier MLP(dim_hid -> num_classes, act 'I'), models.py:139-146, layers.py:329-338, 376-400) -> prob =

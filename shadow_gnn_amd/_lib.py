@@ -73,6 +73,15 @@ class SlSageStackLayer(C.Structure):
     ]
 
 
+class SlGcnStackLayer(C.Structure):
+    """sl_gcn_stack_layer: one GCN layer of a stack run by sl_gcn_stack_fwd / sl_gcn_stack_bwd."""
+    _fields_ = [
+        ("W", C.c_void_p), ("b", C.c_void_p), ("scale", C.c_void_p), ("offset", C.c_void_p), ("ldw", C.c_int64), ("Fin", C.c_uint32),
+        ("Fout", C.c_uint32), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("AX", C.c_void_p), ("ldax", C.c_int64),
+        ("Z", C.c_void_p), ("out", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("dscale", C.c_void_p), ("doffset", C.c_void_p),
+    ]
+
+
 class SlNormAdj(C.Structure):
     _fields_ = [
         ("indptr", C.c_void_p), ("indices", C.c_void_p), ("edge_w", C.c_void_p), ("row_scale", C.c_void_p),
@@ -157,6 +166,10 @@ SIGNATURES = {
     "sl_sage_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P]),
     "sl_sage_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P, C.c_uint32,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sl_gcn_stack_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.POINTER(SlGcnStackLayer)]),
+    "sl_gcn_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.POINTER(SlGcnStackLayer), _P, _P]),
+    "sl_gcn_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), C.c_uint32, C.POINTER(SlGcnStackLayer), _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
+                                    _P]),
     "sl_head_counter_words": (C.c_size_t, []),
     "sl_head_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_head_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
@@ -226,7 +239,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 17      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 18      # sg_abi_version() of the library these signatures describe
 
 
 def load():

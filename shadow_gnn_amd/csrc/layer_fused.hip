@@ -506,3 +506,84 @@ extern "C" int sl_gcn_bwd(const sl_norm_adj *adj, const float *d_AX, int64_t lda
   }
   return tn_gemm(dZ, Fout, d_AX, ldax, d_dW, n, Fout, Fin, d_tn_partial, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A whole stack of GCN layers per call (the conv loop of shaDow/models.py:193-197 over layers.py:417-444 layers, residue 'none' +
+// centre pooling): sl_gcn_fwd / sl_gcn_bwd layer by layer with the arguments the per-layer nodes pass; the input gradient of layer
+// l is the output gradient of layer l - 1 (two buffers in turn).  The top layer's output gradient may come as (rows, values) of
+// the read-out's row select: it is scattered into a cleared [n, Fout] buffer -- what autograd's zero-filled index_add builds.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void scatter_rows_kernel(float *__restrict__ dst, int64_t ld, const uint32_t *__restrict__ rows, const float *__restrict__ src,
+                                    uint32_t r, uint32_t F4) {
+  const uint64_t total = (uint64_t)r * F4;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t i = (uint32_t)(t / F4), c = (uint32_t)(t % F4) * 4u;
+    *reinterpret_cast<float4 *>(dst + (int64_t)rows[i] * ld + c) = *reinterpret_cast<const float4 *>(src + (size_t)i * F4 * 4 + c);
+  }
+}
+}  // namespace
+
+extern "C" size_t sl_gcn_stack_pack_bytes(uint32_t n, uint32_t L, const sl_gcn_stack_layer *ly) {
+  size_t b = 0;
+  for (uint32_t l = 0; ly && l < L; ++l) b = std::max(b, sl_gcn_pack_bytes(n, ly[l].Fin, ly[l].Fout));
+  return b;
+}
+
+static int gcn_stack_check(const sl_norm_adj *adj, uint32_t L, const sl_gcn_stack_layer *ly, const char *who) {
+  if (!adj || !ly || L == 0) return set_error(SG_ERR_INVALID, "%s: null argument", who);
+  for (uint32_t l = 1; l < L; ++l)
+    if (ly[l].Fin != ly[l - 1].Fout) return set_error(SG_ERR_INVALID, "%s: layer %u reads %u columns, layer %u writes %u", who, l, ly[l].Fin, l - 1, ly[l - 1].Fout);
+  return SG_OK;
+}
+
+extern "C" int sl_gcn_stack_fwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, uint32_t L, const sl_gcn_stack_layer *ly,
+                                void *d_pack, void *stream) {
+  int rc;
+  if ((rc = gcn_stack_check(adj, L, ly, "sl_gcn_stack_fwd")) != SG_OK) return rc;
+  if (!d_X0 || !d_pack) return set_error(SG_ERR_INVALID, "sl_gcn_stack_fwd: null argument");
+  const float *X = d_X0;
+  int64_t ldx = ldx0;
+  for (uint32_t l = 0; l < L; ++l) {
+    const sl_gcn_stack_layer &y = ly[l];
+    if ((rc = sl_gcn_fwd(adj, X, ldx, y.Fin, y.Fout, y.W, y.ldw, y.b, y.scale, y.offset, y.act, y.drop_p, y.drop_seed, y.AX, y.ldax, y.Z,
+                         y.out, nullptr, d_pack, stream)) != SG_OK)
+      return rc;
+    X = y.out, ldx = y.Fout;
+  }
+  return SG_OK;
+}
+
+extern "C" int sl_gcn_stack_bwd(const sl_norm_adj *adj, uint32_t L, const sl_gcn_stack_layer *ly, const float *d_dout,
+                                const uint32_t *d_dout_rows, uint32_t num_dout_rows, float *d_dX0, float *d_grad, float *d_buf,
+                                float *d_an_partial, float *d_tn_partial, void *d_pack, void *stream) {
+  int rc;
+  if ((rc = gcn_stack_check(adj, L, ly, "sl_gcn_stack_bwd")) != SG_OK) return rc;
+  if (!d_dout || !d_grad || !d_buf || !d_an_partial || !d_tn_partial || !d_pack) return set_error(SG_ERR_INVALID, "sl_gcn_stack_bwd: null argument");
+  const uint32_t n = adj->n;
+  if (n == 0) return SG_OK;
+  uint32_t Fmax = 0;
+  for (uint32_t l = 0; l < L; ++l) Fmax = std::max(Fmax, std::max(ly[l].Fout, ly[l].Fin));
+  const size_t half = (size_t)n * Fmax;
+  // the gradient of layer l's output lives in half (l & 1) of d_grad: written by layer l + 1's call as its input gradient
+  const float *dout = d_dout;
+  if (d_dout_rows) {
+    const uint32_t F = ly[L - 1].Fout;
+    if (F & 3) return set_error(SG_ERR_INVALID, "sl_gcn_stack_bwd: the scattered output gradient needs Fout %% 4 == 0");
+    float *dense = d_grad + ((L - 1) & 1u) * half;
+    SHD_HIP(hipMemsetAsync(dense, 0, (size_t)n * F * 4, (hipStream_t)stream));
+    if (num_dout_rows)
+      hipLaunchKernelGGL(scatter_rows_kernel, dim3(std::min<uint32_t>((num_dout_rows * (F / 4) + 255) / 256, 2048)), dim3(256), 0,
+                         (hipStream_t)stream, dense, (int64_t)F, d_dout_rows, d_dout, num_dout_rows, F / 4);
+    dout = dense;
+  }
+  for (uint32_t l = L; l-- > 0;) {
+    const sl_gcn_stack_layer &y = ly[l];
+    float *dX = l ? d_grad + ((l - 1) & 1u) * half : d_dX0;
+    if ((rc = sl_gcn_bwd(adj, y.AX, y.ldax, y.Z, y.Fin, y.Fout, y.W, y.ldw, y.b, y.scale, y.offset, y.act, y.drop_p, y.drop_seed, dout, nullptr,
+                         dX, y.Fin, y.dW, y.dbias, y.dscale, y.doffset, d_buf, d_an_partial, d_tn_partial, d_pack, stream)) != SG_OK)
+      return rc;
+    dout = dX;
+  }
+  return SG_OK;
+}

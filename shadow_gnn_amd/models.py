@@ -158,7 +158,7 @@ class DeepGNN(nn.Module):
         outs = []
         self._plan_dropout_fusion(i)
         if not levels and ops.SAGE_STACK and self._stack_plan.get(i):
-            emb = self._run_stack(convs, feat, adj, tgt, dropedge)
+            emb = self._run_stack(self._stack_plan[i], convs, feat, adj, tgt, dropedge)
             if emb is not None:
                 return emb
         for md in convs[:num_full]:
@@ -180,13 +180,13 @@ class DeepGNN(nn.Module):
             x = md.forward_rows(x, adj_norm, level)
         return x
 
-    def _run_stack(self, convs, feat, adj, tgt, dropedge):
-        """The whole GraphSAGE stack + the read-out's row select as one node (ops._SageStack: one C call per direction), or None
-        when this batch goes layer by layer: training batches large enough for the row-sparse top-layer backward (ops.SPARSE_TOP_BWD,
-        a different set of kernels), a layer 0 that gathers inside its aggregation kernel."""
+    def _run_stack(self, kind, convs, feat, adj, tgt, dropedge):
+        """The whole GraphSAGE / GCN stack + the read-out's row select as one node (ops._SageStack / ops._GcnStack: one C call per
+        direction), or None when this batch goes layer by layer: GraphSAGE training batches large enough for the row-sparse
+        top-layer backward (ops.SPARSE_TOP_BWD, a different set of kernels), a layer 0 that gathers inside its aggregation kernel."""
         first = convs[0]
         n = int(feat.shape[0])
-        if self.training and torch.is_grad_enabled() and ops.SPARSE_TOP_BWD and n >= ops.SPARSE_TOP_BWD_MIN_ROWS:
+        if kind == 'sage' and self.training and torch.is_grad_enabled() and ops.SPARSE_TOP_BWD and n >= ops.SPARSE_TOP_BWD_MIN_ROWS:
             return None
         if n < max(1, ops.GEMM_SPLIT_MIN_ROWS) or not feat.is_cuda:
             return None
@@ -204,7 +204,7 @@ class DeepGNN(nn.Module):
             x0, _seed = feat.gather_dropped(first._in_p())
         else:
             x0 = first.in_dropout(feat)
-        emb = ops.sage_stack(x0, adj_norm, convs, tgt)
+        emb = (ops.sage_stack if kind == 'sage' else ops.gcn_stack)(x0, adj_norm, convs, tgt)
         assert emb is not None
         return emb
 
@@ -306,10 +306,14 @@ class DeepGNN(nn.Module):
             layers_i[0].input_pre_dropped = False
         # the whole stack as one autograd node (ops._SageStack): GraphSAGE layers only, nothing but the next layer / the row select
         # reads a layer's output, and every inner input dropout is applied by the producing layer's kernel (or is the identity)
-        self._stack_plan[i] = bool(not dual and self.prediction_task == 'node' and rp.dim_in == 0
-                                   and all(type(md) is layers.GraphSAGE for md in layers_i)
-                                   and all((not self.training) or md.dropout <= 0 or md.input_pre_dropped for md in layers_i[1:])
-                                   and ops.sage_stack_usable(layers_i))
+        kind = ''
+        if (not dual and self.prediction_task == 'node' and rp.dim_in == 0 and layers_i
+                and all((not self.training) or md.dropout <= 0 or md.input_pre_dropped for md in layers_i[1:])):
+            if all(type(md) is layers.GraphSAGE for md in layers_i) and ops.sage_stack_usable(layers_i):
+                kind = 'sage'
+            elif all(type(md) is layers.GCN for md in layers_i) and ops.gcn_stack_usable(layers_i):
+                kind = 'gcn'
+        self._stack_plan[i] = kind
 
     @property
     def _stack_plan(self):

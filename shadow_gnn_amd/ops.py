@@ -1791,6 +1791,142 @@ def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tens
     return _SageStack.apply(X0, adj, rows, tuple(meta), *params)
 
 
+class _GcnStack(torch.autograd.Function):
+    """The conv loop of DeepGNN.forward over L GCN layers (shaDow/layers.py:417-444) plus the read-out's row select as ONE
+    autograd node (sl_gcn_stack_fwd / sl_gcn_stack_bwd: the one-call layer passes of _GcnDense issued from C, identical
+    results).  Same preconditions as _SageStack: nothing but layer l + 1 reads layer l's output, nothing but the row select
+    the last one; one hidden width."""
+    calls = 0
+
+    @staticmethod
+    def forward(ctx, X0, adj, rows, meta, *params):
+        lib = _lib.load()
+        L = len(meta)
+        n, F0 = X0.shape
+        F = params[0].shape[0]
+        dev = X0.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
+        AX0 = torch.empty(n, pitch0, **f32)
+        big = torch.empty(3 * L - 1, n, F, **f32)            # per layer Z, out; then A X of the layers 1 .. L - 1
+        arr = (_lib.SlGcnStackLayer * L)()
+        base, step = big.data_ptr(), n * F * 4
+        for l in range(L):
+            W, b, sc, of = params[4 * l:4 * l + 4]
+            y = arr[l]
+            y.W, y.scale, y.offset, y.ldw = W.data_ptr(), sc.data_ptr(), of.data_ptr(), W.stride(0)
+            y.b = b.data_ptr() if b is not None else None
+            y.Fin, y.Fout = (F0 if l == 0 else F), F
+            y.act, y.drop_p, y.drop_seed = meta[l]
+            if l == 0:
+                y.AX, y.ldax = AX0.data_ptr(), AX0.stride(0)
+            else:
+                y.AX, y.ldax = base + (2 * L + l - 1) * step, F
+            y.Z, y.out = base + 2 * l * step, base + (2 * l + 1) * step
+        pack = torch.empty(lib.sl_gcn_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
+        a = _adj_struct(adj, False)
+        check(lib.sl_gcn_stack_fwd(C.byref(a), X0.data_ptr(), X0.stride(0), L, arr, pack.data_ptr(), _stream(X0)))
+        if Z_TAP is not None:
+            for l in range(L):
+                _tap([big[2 * l]], [params[4 * l + 1]])
+        ctx.save_for_backward(X0, *[p for p in params if p is not None])
+        ctx.has = [p is not None for p in params]
+        ctx.rows, ctx.adj, ctx.arr, ctx.L = rows, adj, arr, L
+        ctx.keep = (AX0, big)
+        ctx.set_materialize_grads(False)
+        _GcnStack.calls += 1
+        fire_deferred()
+        out = big[2 * (L - 1) + 1]
+        return out.index_select(0, rows) if rows is not None else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        X0 = saved[0]
+        it = iter(saved[1:])
+        params = [next(it) if h else None for h in ctx.has]
+        L, arr, adj, rows = ctx.L, ctx.arr, ctx.adj, ctx.rows
+        n, F0 = X0.shape
+        F = params[0].shape[0]
+        dev = X0.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        r = int(rows.numel()) if rows is not None else n
+        d = _f32c(dout).contiguous() if dout is not None else torch.zeros(r, F, **f32)
+        want_dx0 = bool(ctx.needs_input_grad[0])
+        Fm = max(F, F0)
+        dX0 = torch.empty(n, F0, **f32) if want_dx0 else None
+        dW = torch.empty(max(1, L - 1), F, F, **f32)
+        dW0 = torch.empty(F, F0, **f32)
+        ds = torch.empty(3 * L, F, **f32)                    # per layer dscale, doffset, dbias
+        grad = torch.empty(2, n, Fm, **f32)
+        buf = torch.empty(n * (F + Fm), **f32)
+        an_partial = torch.empty(2048 * 3 * F, **f32)
+        tn_partial = torch.empty(lib.sl_gemm_tn_slices(n) * F * Fm, **f32)
+        pack = torch.empty(lib.sl_gcn_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
+        sbase, sstep = ds.data_ptr(), F * 4
+        for l in range(L):
+            y = arr[l]
+            y.dW = dW0.data_ptr() if l == 0 else dW.data_ptr() + (l - 1) * F * F * 4
+            y.dscale, y.doffset = sbase + 3 * l * sstep, sbase + (3 * l + 1) * sstep
+            y.dbias = (sbase + (3 * l + 2) * sstep) if ctx.has[4 * l + 1] else None
+        a = _adj_struct(adj, want_dx0 or L > 1)
+        rows32 = rows.to(torch.int32) if rows is not None else None
+        check(lib.sl_gcn_stack_bwd(C.byref(a), L, arr, d.data_ptr(), rows32.data_ptr() if rows32 is not None else None,
+                                   r if rows32 is not None else 0, dX0.data_ptr() if dX0 is not None else None, grad.data_ptr(),
+                                   buf.data_ptr(), an_partial.data_ptr(), tn_partial.data_ptr(), pack.data_ptr(), _stream(X0)))
+        ctx.keep = ctx.arr = None
+        Wg = (dW0,) + (dW.unbind(0) if L > 1 else ())
+        sg = ds.unbind(0)
+        ng = ctx.needs_input_grad
+        grads = []
+        for l in range(L):
+            k = 4 + 4 * l
+            grads += [Wg[l] if ng[k] else None, sg[3 * l + 2] if (ctx.has[4 * l + 1] and ng[k + 1]) else None,
+                      sg[3 * l].view(params[4 * l + 2].shape) if ng[k + 2] else None,
+                      sg[3 * l + 1].view(params[4 * l + 3].shape) if ng[k + 3] else None]
+        return (dX0, None, None, None, *grads)
+
+
+def gcn_stack_usable(mods) -> bool:
+    """The static part of _GcnStack's preconditions for a list of layers.GCN modules."""
+    if not (SAGE_STACK and FUSED_LAYER_CALLS and GEMM_SPLIT and mods):
+        return False
+    F = mods[0].f_lin.weight.shape[0]
+    if not (F % 4 == 0 and 16 <= F <= 256):
+        return False
+    for l, md in enumerate(mods):
+        w = md.f_lin.weight
+        Fi = w.shape[1]
+        if not (getattr(md, "norm", None) == "norm_feat" and md.act is None and md.act_name in ACT_CODE and w.shape[0] == F
+                and (Fi == F if l else (Fi % 4 == 0 and Fi <= 256)) and w.is_cuda and w.dtype == torch.float32 and w.stride(1) == 1
+                and md.scale.numel() == F and md.scale.is_contiguous() and md.offset.is_contiguous() and md.scale.dtype == torch.float32):
+            return False
+    return True
+
+
+def gcn_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tensor]):
+    """out_L[rows] of the GCN modules ``mods`` applied in turn to X0 (already through layer 0's input dropout) -- see _GcnStack;
+    None when the stack form does not apply to this call."""
+    n = X0.shape[0]
+    if n < max(1, GEMM_SPLIT_MIN_ROWS) or not X0.is_cuda or not isinstance(adj, NormAdj):
+        return None
+    params = []
+    for md in mods:
+        params += [md.f_lin.weight, md.f_lin.bias, md.scale, md.offset]
+    if torch.is_grad_enabled() and not all(p is None or p.requires_grad for p in params):
+        return None
+    X0 = _f32c(X0)
+    if not (X0.stride(1) == 1 and X0.stride(0) % 4 == 0 and X0.data_ptr() % 16 == 0):
+        X0 = X0.contiguous()
+    F = mods[0].f_lin.weight.shape[0]
+    meta = []
+    for md in mods:
+        drop = _drop_arg(md._out_p(), F)
+        meta.append((ACT_CODE[md.act_name], float(drop[0]), int(drop[1])))
+    return _GcnStack.apply(X0, adj, rows, tuple(meta), *params)
+
+
 # The head of a node-classification step (L2 normalisation of the root embeddings, the one-layer classifier, softmax cross
 # entropy) as one kernel forward and two backward (csrc/head.hip) instead of ~35 small torch / HIP kernels and their launches.
 # SHADOW_FUSED_HEAD=0: the separate nodes.

@@ -1225,13 +1225,13 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
-                     dropedge=0.0, stack=None, aug=False, train=True):
+                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage"):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
     from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
     from shadow_gnn_amd.models import DeepGNN
-    b, X, labels, F0, C = _bench_scale_batch("sage", B, F0=F0)
+    b, X, labels, F0, C = _bench_scale_batch(aggr, B, F0=F0)
     lib = _lib.load()
     prev_f = lib.sl_set_fused_epilogue(1 if fused else 0)
     prev_c, prev_s = ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD
@@ -1245,7 +1245,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         ops.SPARSE_TOP_BWD_MIN_ROWS = 1024          # (the production threshold is a host-time trade-off, not a correctness bound)
     try:
         arch = dict(num_layers=n_layers, num_cls_layers=1, heads=1, dim=dim, act=act, layer_norm="norm_feat",
-                    feature_augment_ops="sum", aggr="sage", residue="none", pooling="center", loss="softmax")
+                    feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
         torch.manual_seed(seed)
         model = DeepGNN(F0, F0, C, 0, arch, [("hops", 7)] if aug else [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
         with torch.no_grad():
@@ -1862,6 +1862,30 @@ def test_sparse_top_backward_fuzz():
     failures, used = mod.run(3, 40, verbose=False)
     assert not failures, failures[:3]
     assert used >= 24, used                                  # (most trials must actually take a row-sparse pass)
+
+
+@pytest.mark.parametrize("n_layers,dim,p_drop,dropedge,act,aug,F0", [(3, 256, 0.25, 0.15, "elu", True, 128), (2, 64, 0.3, 0.0, "relu", False, 100),
+                                                                     (1, 128, 0.0, 0.1, "tanh", False, 36), (4, 32, 0.5, 0.05, "elu", True, 100)])
+def test_gcn_stack_call_equals_layer_by_layer(n_layers, dim, p_drop, dropedge, act, aug, F0):
+    """ops._GcnStack (sl_gcn_stack_fwd / sl_gcn_stack_bwd: the whole GCN stack + the read-out's row select as ONE autograd node)
+    against the layer-by-layer _GcnDense nodes: bit-identical loss, predictions and parameter gradients (the C entries run the
+    per-layer entries with the same arguments; the roots' gradient is scattered into a cleared buffer exactly as autograd's
+    zero-filled index_add builds it), with fused dropout, symmetric drop-edge, an augmented layer-0 input; also in evaluation."""
+    from shadow_gnn_amd import ops
+    k0 = ops._GcnStack.calls
+    a = _sage_stack_step(n_layers, dim, p_drop, 41, chain=True, fused=True, B=96, act=act, F0=F0, dropedge=dropedge, stack=False, aug=aug, aggr="gcn")
+    assert ops._GcnStack.calls == k0
+    b = _sage_stack_step(n_layers, dim, p_drop, 41, chain=True, fused=True, B=96, act=act, F0=F0, dropedge=dropedge, stack=True, aug=aug, aggr="gcn")
+    assert ops._GcnStack.calls == k0 + 1, "the stack entry was not taken"
+    assert a[0] == b[0]
+    torch.testing.assert_close(b[1], a[1], rtol=0, atol=0)
+    assert set(a[2]) == set(b[2])
+    for k in a[2]:
+        torch.testing.assert_close(b[2][k], a[2][k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+    e0 = _sage_stack_step(n_layers, dim, p_drop, 41, chain=True, fused=True, B=96, act=act, F0=F0, stack=False, aug=aug, train=False, aggr="gcn")
+    e1 = _sage_stack_step(n_layers, dim, p_drop, 41, chain=True, fused=True, B=96, act=act, F0=F0, stack=True, aug=aug, train=False, aggr="gcn")
+    assert ops._GcnStack.calls == k0 + 2 and e0[0] == e1[0]
+    torch.testing.assert_close(e1[1], e0[1], rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("r,F,C", [(1, 256, 47), (37, 64, 7), (128, 256, 47), (1024, 256, 47), (2500, 100, 172), (300, 256, 256), (513, 32, 3)])
