@@ -111,6 +111,13 @@ def _need_cuda(*ts):
             raise RuntimeError("shadow_gnn_amd ops need tensors on a ROCm device (no CPU fallback)")
 
 
+def placeholder(n: int, F: int, device) -> torch.Tensor:
+    """An [n, F] fp32 tensor with ONE float of storage behind it (strides (0, 0) -- also for n == 1 or F == 1, where expand() would
+    keep a unit stride): what autograd carries between two nodes whose real hand-over travels on a link object.  The consumer
+    recognises it by its data pointer and strides."""
+    return torch.empty(1, dtype=torch.float32, device=device).as_strided((int(n), int(F)), (0, 0))
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
@@ -849,7 +856,7 @@ class _LinearPair(torch.autograd.Function):
             link = ctx.in_link
             if link is not None:
                 link.rows32, link.grad, link.plan, link.levels = rows32, dXT, None, (levels or None)
-                link.dummy = torch.empty(1, 1, dtype=torch.float32, device=X.device).expand(M, K)
+                link.dummy = placeholder(M, K, X.device)
                 link.filled = True
                 out[0] = link.dummy
             else:
@@ -1187,7 +1194,7 @@ class _SelectRoots(torch.autograd.Function):
             link.grad = _f32c(dsel).contiguous()
             link.plan = ctx.plan
             link.levels = list(ctx.levels) if ctx.levels else None
-            link.dummy = torch.empty(1, 1, dtype=torch.float32, device=dsel.device).expand(ctx.n, ctx.F)
+            link.dummy = placeholder(ctx.n, ctx.F, dsel.device)
             link.filled = True
             return link.dummy, None, None
         dense = torch.zeros(ctx.n, ctx.F, dtype=dsel.dtype, device=dsel.device)
@@ -1425,7 +1432,7 @@ class _SageDense(torch.autograd.Function):
         if dout_rows is not None:
             ctx.link_roots.release()
         if chain:
-            down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)       # what autograd hands to the node below: no storage behind it
+            down.dummy = placeholder(n, Fi, dev)       # what autograd hands to the node below: no storage behind it
             down.filled = True
             dX = down.dummy
             _SageDense.chained_calls += 1
@@ -1506,7 +1513,7 @@ class _SageDense(torch.autograd.Function):
                                           int(down.drop[1]), down.amax.data_ptr(), opt(down.stats), corr.data_ptr(), corr.stride(0),
                                           plan.rowmap.data_ptr(), t, st))
         down.partial = partial
-        down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)
+        down.dummy = placeholder(n, Fi, dev)
         down.filled = True
         dsc, dof, dbi = up.dsc, up.dof, up.dbi
         up.release()
@@ -1567,7 +1574,7 @@ class _SageDense(torch.autograd.Function):
         down.partial = None
         down.rows = plan.T32           # (dZs / dZn of the layer below are zero outside T: its weight gradients need those rows only)
         lr.release()
-        down.dummy = torch.empty(1, 1, **f32).expand(n, Fi)
+        down.dummy = placeholder(n, Fi, dev)
         down.filled = True
         _SageDense.chained_calls += 1
         _SageDense.sparse_top_calls += 1

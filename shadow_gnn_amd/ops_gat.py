@@ -147,7 +147,7 @@ class _GatTail(torch.autograd.Function):
                                          work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
         pair = ctx.pair
         pair.rows32, pair.dza, pair.dzb, pair.levels = level.in32, dzs_c, dzn_c, list(rest)
-        pair.dummy = torch.empty(1, 1, **f32).expand(n, F)
+        pair.dummy = ops.placeholder(n, F, dev)
         pair.filled = True
         _GatTail.sparse_top_calls += 1
         return (pair.dummy, pair.dummy, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None,

@@ -1947,3 +1947,40 @@ def test_fused_node_head_matches_fp64_reference(r, F, C):
         s = max(float(ref.abs().max()), 1e-30)
         err = float((got.cpu().double().reshape(ref.shape) - ref).abs().max())
         assert err <= (1e-5 * s if nm not in ("preds", "loss") else 2e-5 * max(s, 1.0)), (nm, err, s)
+
+
+@pytest.mark.parametrize("aggr,layers_", [("sage", 3), ("gat", 2)])
+def test_single_node_batch_through_the_placeholder_links(aggr, layers_, monkeypatch):
+    """A batch of ONE subgraph of ONE node (an isolated root): every hand-over that autograd carries as a storage-less
+    placeholder ([n, F] with strides (0, 0) -- `expand` of a [1, 1] tensor keeps a unit stride when n == 1 and the consumer took
+    the placeholder for a foreign gradient: found by scripts/fuzz_sparse_top.py) works, row-sparse and dense passes agree."""
+    from shadow_gnn_amd import ops
+    from shadow_gnn_amd.minibatch import TRAIN, OneBatchSubgraph
+    from shadow_gnn_amd.models import DeepGNN
+    monkeypatch.setattr(ops, "SPARSE_TOP_BWD_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "GEMM_SPLIT_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "BACKWARD_LEVELS_FRAC", 2.0)
+    F0, C, dim = 20, 5, 32 if aggr == "gat" else 96
+    arch = dict(num_layers=layers_, num_cls_layers=1, heads=2 if aggr == "gat" else 1, dim=dim, act="elu", layer_norm="norm_feat",
+                feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
+    self_loop = aggr == "gat"
+    ip = torch.tensor([0, 1 if self_loop else 0], dtype=torch.int32, device=DEV)
+    ix = torch.zeros(1 if self_loop else 0, dtype=torch.int32, device=DEV)
+    X = torch.randn(1, F0, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = []
+    for sparse in (False, True):
+        monkeypatch.setattr(ops, "SPARSE_TOP_BWD", sparse)
+        torch.manual_seed(5)
+        m = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(lr=0.01, dropout=0.0, dropedge=0.0), "node").to(DEV)
+        m.optimizer = torch.optim.SGD(m.parameters(), lr=0.0)
+        csr = ops.DeviceCSR(ip, ix, subg_off=torch.tensor([0, 1], dtype=torch.int32, device=DEV),
+                            subg_edge_off=torch.tensor([0, int(ix.numel())], dtype=torch.int32, device=DEV), max_subg_nodes=1)
+        bt = OneBatchSubgraph([csr], [X], torch.tensor([2], device=DEV), torch.ones(1, 1, dtype=torch.int64, device=DEV),
+                              [torch.zeros(1, dtype=torch.int64, device=DEV)], [{}])
+        ret = m.step(TRAIN, "running", bt)
+        torch.cuda.synchronize()
+        res.append((float(ret["loss"]), {k: q.grad.detach().clone() for k, q in m.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) < 1e-6
+    for k in res[0][1]:
+        s = float(res[0][1][k].abs().max())
+        assert float((res[0][1][k] - res[1][1][k]).abs().max()) <= 5e-5 * s + 1e-8, k
