@@ -217,6 +217,9 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
 #ifndef SHADOW_GAT_GROUPS_COL
 #define SHADOW_GAT_GROUPS_COL 2
 #endif
+#ifndef SHADOW_GAT_ROW_PREFETCH
+#define SHADOW_GAT_ROW_PREFETCH 1      // the next row's pointers / score / gradient rows are loaded while this row's edges are walked
+#endif
 #define SHD_GAT_EDGES(MASK, q, b, CALL)                          \
   do {                                                           \
     if ((MASK) & 8) for (; q + 8 <= b; q += 8) { CALL(8); }      \
@@ -232,9 +235,17 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
   const bool on = f < p.F;
   const uint32_t h = on ? f / p.D : 0;
   const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  // (the next row's pointers and score are loaded while this row's edges are walked: one dependent stage less per row)
+  uint32_t na = 0, nb = 0;
+  float nus = 0.f;
+  if (rw_.r < rw_.end) { na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1]; nus = p.u_s[rw_.r * p.H + h]; }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
-    const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
-    const float as = lrelu02(p.u_s[r * p.H + h]);
+#if !SHADOW_GAT_ROW_PREFETCH
+    na = p.indptr[r]; nb = p.indptr[r + 1]; nus = p.u_s[r * p.H + h];
+#endif
+    const uint32_t a = na, b = nb;
+    const float as = lrelu02(nus);
+    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * p.H + h]; }
     float mx = -INFINITY;
     uint32_t q = a;
 #define SHD_CALL(G) gat_max_group<G>(p, q, h, as, mx)
@@ -266,10 +277,24 @@ __global__ void gat_row_bwd_kernel(GatParams p) {
   float4 a0 = make_float4(0, 0, 0, 0), g0 = a0;
   if (on) a0 = gld4(p.att + f);
   const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  uint32_t na = 0, nb = 0;                              // (next row's pointers ahead: see gat_row_fwd_kernel)
+  float4 ndn = make_float4(0, 0, 0, 0), nng = ndn;
+  if (rw_.r < rw_.end) {
+    na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1];
+    if (on) { ndn = gld4(p.dnagg + rw_.r * p.F + f); nng = gld4(p.nagg + rw_.r * p.F + f); }
+  }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
-    const uint32_t a = p.indptr[r], b = p.indptr[r + 1];
-    float4 dn = make_float4(0, 0, 0, 0), ng = dn;
-    if (on) { dn = gld4(p.dnagg + r * p.F + f); ng = gld4(p.nagg + r * p.F + f); }
+#if !SHADOW_GAT_ROW_PREFETCH
+    na = p.indptr[r]; nb = p.indptr[r + 1];
+    if (on) { ndn = gld4(p.dnagg + r * p.F + f); nng = gld4(p.nagg + r * p.F + f); }
+#endif
+    const uint32_t a = na, b = nb;
+    const float4 dn = ndn, ng = nng;
+    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) {
+      const uint64_t r2 = r + rw_.step;
+      na = p.indptr[r2]; nb = p.indptr[r2 + 1];
+      if (on) { ndn = gld4(p.dnagg + r2 * p.F + f); nng = gld4(p.nagg + r2 * p.F + f); }
+    }
     const float t = slice_sum(dot4(dn, ng), ls);          // dN_i . N_i per head
     const float usr = p.u_s[r * p.H + h];
     const float as = lrelu02(usr);
@@ -323,8 +348,14 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
   float4 a1 = make_float4(0, 0, 0, 0), g1 = a1;
   if (on) a1 = gld4(p.att + p.F + f);
   const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  uint32_t na = 0, nb = 0;                              // (next row's pointers ahead: see gat_row_fwd_kernel)
+  if (rw_.r < rw_.end) { na = p.t_indptr[rw_.r]; nb = p.t_indptr[rw_.r + 1]; }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
-    const uint32_t a = p.t_indptr[r], b = p.t_indptr[r + 1];
+#if !SHADOW_GAT_ROW_PREFETCH
+    na = p.t_indptr[r]; nb = p.t_indptr[r + 1];
+#endif
+    const uint32_t a = na, b = nb;
+    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.t_indptr[r + rw_.step]; nb = p.t_indptr[r + rw_.step + 1]; }
     float4 acc = make_float4(0, 0, 0, 0);
     float dan = 0.f, rmax = 0.f;
     uint32_t q = a;
