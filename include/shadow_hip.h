@@ -701,21 +701,19 @@ int sl_gcn_stack_bwd(const sl_norm_adj *adj, uint32_t L, const sl_gcn_stack_laye
 /* Head of a node-classification step (csrc/head.hip): emb [r, F] = the roots' rows of the last layer (layers.py:159-163) ->
  * xn = emb / max(|emb|_2, 1e-12) (models.py:200, F.normalize) -> z = xn W^T + b, preds = _f_norm_feat(z) over the C classes
  * (the one-layer classifier MLP(dim_hid -> num_classes, act 'I'), models.py:139-146, layers.py:329-338, 376-400) -> prob =
- * softmax(preds), loss = mean_i CE(preds_i, label_i) (models.py:163-166) -- ONE kernel; backward (sl_head_bwd) two kernels:
- * d_gloss [1] (device) = d L / d loss, outputs d_demb [r, F], d_dW [C, F] dense, d_db, d_dscale, d_doffset [C].
- * F % 4 == 0 <= 256, C <= 256, 16-byte aligned rows; d_label int64 class indices; d_xn [r, F], d_z / d_preds / d_prob [r, C] dense,
- * d_nrm, d_rowloss [r], d_loss [1]; d_counter: sl_head_counter_words() uint32 that are ZERO on entry (the kernels leave them zero);
- * d_work 3 r C floats, d_partial sl_head_partial_floats(r, F, C) floats.  The sums over the roots run in a fixed order
- * (run-to-run identical results).                                                                                            */
-size_t sl_head_counter_words(void);
+ * softmax(preds), loss = mean_i CE(preds_i, label_i) (models.py:163-166) -- one kernel + a one-workgroup mean; backward
+ * (sl_head_bwd) two kernels + a slice reduction: d_gloss [1] (device) = d L / d loss, outputs d_demb [r, F], d_dW [C, F] dense,
+ * d_db, d_dscale, d_doffset [C].  F % 4 == 0 <= 256, C <= 256, 16-byte aligned rows; d_label int64 class indices; d_xn [r, F],
+ * d_z / d_preds / d_prob [r, C] dense, d_nrm, d_rowloss [r], d_loss [1]; d_work 3 r C floats, d_partial
+ * sl_head_partial_floats(r, F, C) floats.  The sums over the roots run in a fixed order (run-to-run identical results).       */
 size_t sl_head_partial_floats(uint32_t r, uint32_t F, uint32_t C);
 int sl_head_fwd(const float *d_emb, int64_t lde, const float *d_W, int64_t ldw, const float *d_b, const float *d_scale,
                 const float *d_offset, const int64_t *d_label, uint32_t r, uint32_t F, uint32_t C, float *d_xn, float *d_z,
-                float *d_preds, float *d_prob, float *d_nrm, float *d_rowloss, float *d_loss, uint32_t *d_counter, void *stream);
+                float *d_preds, float *d_prob, float *d_nrm, float *d_rowloss, float *d_loss, void *stream);
 int sl_head_bwd(const float *d_gloss, const float *d_xn, const float *d_z, const float *d_prob, const float *d_nrm,
                 const int64_t *d_label, const float *d_W, int64_t ldw, const float *d_scale, uint32_t r, uint32_t F, uint32_t C,
                 float *d_demb, float *d_dW, float *d_db, float *d_dscale, float *d_doffset, float *d_work, float *d_partial,
-                uint32_t *d_counter, void *stream);
+                void *stream);
 
 /* Per-kernel timing inside the layer entries above (csrc/prof.hip): while sl_prof_enable(1) is in effect every kernel a
  * sl_sage_* / sl_gcn_* entry launches is bracketed by a HIP-event pair on its stream, under the kernel class names and

@@ -170,12 +170,11 @@ SIGNATURES = {
     "sl_gcn_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.POINTER(SlGcnStackLayer), _P, _P]),
     "sl_gcn_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), C.c_uint32, C.POINTER(SlGcnStackLayer), _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
                                     _P]),
-    "sl_head_counter_words": (C.c_size_t, []),
     "sl_head_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_head_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
-                               _P, _P]),
+                               _P]),
     "sl_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
-                               _P, _P]),
+                               _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
     "sl_prof_enable": (C.c_int, [C.c_int]),
     "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),

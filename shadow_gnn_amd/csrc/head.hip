@@ -6,10 +6,10 @@
 // the roots (models.py:163-166).  On r = 16 .. 1024 rows that is a chain of ~15 forward and ~20 backward kernels of 3-10 us each
 // on an idle chip, and as many host launches -- a tenth of a small-batch step.  Here:
 //   head_fwd_kernel      one wavefront per root: L2 normalisation, the [C, F] product (W from LDS), norm over the classes,
-//                        softmax, the root's loss; the last workgroup adds the losses in a fixed order (deterministic mean)
+//                        softmax, the root's loss (+ head_loss_kernel: their mean, added in a fixed order)
 //   head_bwd_rows_kernel one wavefront per root: d preds -> norm backward -> dz, d emb (through the Linear and the normalisation)
-//   head_bwd_cols_kernel dW = dz^T xn, dbias, dscale, doffset: a workgroup per (class, 256-row slice), the slices added in a
-//                        fixed order by the last workgroup of a class
+//   head_bwd_cols_kernel dW = dz^T xn, dbias, dscale, doffset: a workgroup per (class, 256-row slice), the slices added in
+//                        slice order by head_cols_finish_kernel
 // Plain fp32 FMA arithmetic (2 r C F flop is nothing); lane layouts: FEATURE lanes hold the float4 at column 4 j of a row
 // (F <= 256), CLASS lanes hold classes j, j + 64, j + 128, j + 192 (C <= 256).
 #include "actnorm_common.h"
@@ -29,7 +29,6 @@ struct HeadParams {
   const int64_t *label;
   uint32_t r, F, C;
   float *xn, *z, *preds, *prob, *nrm, *rowloss, *loss;
-  uint32_t *counter;
   // backward
   const float *gloss;
   float *demb, *dz, *dp, *dph;
@@ -67,8 +66,6 @@ __device__ __forceinline__ void class_stats(const float (&zq)[4], uint32_t lane,
 template <bool kLds>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
   extern __shared__ float lds[];
-  __shared__ float red[256];
-  __shared__ uint32_t last;
   if (kLds) stage_w(p, lds);
   const float *Wp = kLds ? lds : p.W;
   const int64_t ldw = kLds ? (int64_t)p.F : p.ldw;
@@ -128,25 +125,22 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadParams p) {
       p.rowloss[i] = mx + logf(se) - py;
     }
   }
-  // the mean over the roots: the workgroup that finishes last adds the r losses in a fixed order
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(p.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
+}
+
+// loss = mean of the r per-root losses, added in a fixed order by one workgroup.  (A separate launch on purpose: the single-kernel
+// form -- the last workgroup to finish adds them, behind a device-scope fence per workgroup -- cost 41 us instead of 12 + 3 at
+// 1 024 roots: on this chip such a fence writes the workgroup's whole L2 slice back, once per workgroup.)
+__global__ __launch_bounds__(256) void head_loss_kernel(const float *__restrict__ rowloss, uint32_t r, float *__restrict__ loss) {
+  __shared__ float red[256];
   float s = 0.f;
-  for (uint32_t i = threadIdx.x; i < p.r; i += 256) s += __builtin_nontemporal_load(p.rowloss + i);
+  for (uint32_t i = threadIdx.x; i < r; i += 256) s += rowloss[i];
   red[threadIdx.x] = s;
   __syncthreads();
   for (uint32_t w = 128; w > 0; w >>= 1) {
     if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    p.loss[0] = red[0] / (float)p.r;
-    *p.counter = 0u;                         // (ready for the next call on this stream)
-  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)r;
 }
 
 template <bool kLds>
@@ -223,7 +217,6 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(HeadParams p) {
 __global__ __launch_bounds__(256) void head_bwd_cols_kernel(HeadParams p) {
   __shared__ float col[256];
   __shared__ float red[3][256];
-  __shared__ uint32_t last;
   const uint32_t c = blockIdx.x, sl = blockIdx.y, t = threadIdx.x;
   const uint32_t i0 = sl * 256u, rows = min(256u, p.r - i0);
   float a = 0.f, b = 0.f, d = 0.f;
@@ -248,31 +241,38 @@ __global__ __launch_bounds__(256) void head_bwd_cols_kernel(HeadParams p) {
     if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
     __syncthreads();
   }
-  // partial [slices][C][F + 4]
+  // partial [slices][C][F + 4]; head_cols_finish_kernel adds the slices in slice order
   const uint32_t pw = p.F + 4;
-  float *mine = p.partial + ((size_t)sl * p.C + c) * pw;
   if (p.slices == 1) {
     if (t < p.F) p.dW[(size_t)c * p.F + t] = acc;
     if (t == 0) { p.db[c] = red[0][0]; p.dscale[c] = red[1][0]; p.doffset[c] = red[2][0]; }
     return;
   }
+  float *mine = p.partial + ((size_t)sl * p.C + c) * pw;
   if (t < p.F) mine[t] = acc;
   if (t < 3) mine[p.F + t] = red[t][0];
-  __threadfence();
-  __syncthreads();
-  if (t == 0) last = atomicAdd(p.counter + 1 + c, 1u) == p.slices - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  for (uint32_t k = t; k < pw - 1; k += 256) {
+}
+
+__global__ __launch_bounds__(256) void head_cols_finish_kernel(HeadParams p) {
+  const uint32_t c = blockIdx.x, pw = p.F + 4;
+  const size_t qs = (size_t)p.C * pw;
+  for (uint32_t k = threadIdx.x; k < pw - 1; k += 256) {
+    const float *src = p.partial + (size_t)c * pw + k;
     float s = 0.f;
-    for (uint32_t q = 0; q < p.slices; ++q) s += __builtin_nontemporal_load(p.partial + ((size_t)q * p.C + c) * pw + k);
+    uint32_t q = 0;
+    for (; q + 8 <= p.slices; q += 8) {                     // (eight loads in flight, added in slice order)
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(q + j) * qs];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; q < p.slices; ++q) s += src[q * qs];
     if (k < p.F) p.dW[(size_t)c * p.F + k] = s;
     else if (k == p.F) p.db[c] = s;
     else if (k == p.F + 1) p.dscale[c] = s;
     else p.doffset[c] = s;
   }
-  if (t == 0) p.counter[1 + c] = 0u;
 }
 
 int head_check(const char *who, uint32_t r, uint32_t F, uint32_t C, const void *emb, int64_t lde, const void *W, int64_t ldw) {
@@ -286,8 +286,6 @@ constexpr size_t kHeadLdsMax = 128 * 1024;
 
 }  // namespace
 
-extern "C" size_t sl_head_counter_words(void) { return 1 + 256; }
-
 extern "C" size_t sl_head_partial_floats(uint32_t r, uint32_t F, uint32_t C) {
   const size_t slices = (r + 255u) / 256u;
   return slices > 1 ? slices * C * (size_t)(F + 4) : 1;
@@ -295,16 +293,15 @@ extern "C" size_t sl_head_partial_floats(uint32_t r, uint32_t F, uint32_t C) {
 
 extern "C" int sl_head_fwd(const float *d_emb, int64_t lde, const float *d_W, int64_t ldw, const float *d_b, const float *d_scale,
                            const float *d_offset, const int64_t *d_label, uint32_t r, uint32_t F, uint32_t C, float *d_xn, float *d_z,
-                           float *d_preds, float *d_prob, float *d_nrm, float *d_rowloss, float *d_loss, uint32_t *d_counter,
-                           void *stream) {
-  if (!d_emb || !d_W || !d_scale || !d_offset || !d_label || !d_xn || !d_z || !d_preds || !d_prob || !d_nrm || !d_rowloss || !d_loss || !d_counter)
+                           float *d_preds, float *d_prob, float *d_nrm, float *d_rowloss, float *d_loss, void *stream) {
+  if (!d_emb || !d_W || !d_scale || !d_offset || !d_label || !d_xn || !d_z || !d_preds || !d_prob || !d_nrm || !d_rowloss || !d_loss)
     return set_error(SG_ERR_INVALID, "sl_head_fwd: null argument");
   int rc;
   if ((rc = head_check("sl_head_fwd", r, F, C, d_emb, lde, d_W, ldw)) != SG_OK) return rc;
   HeadParams p{};
   p.emb = d_emb; p.lde = lde; p.W = d_W; p.ldw = ldw; p.b = d_b; p.scale = d_scale; p.offset = d_offset; p.label = d_label;
   p.r = r; p.F = F; p.C = C; p.xn = d_xn; p.z = d_z; p.preds = d_preds; p.prob = d_prob; p.nrm = d_nrm; p.rowloss = d_rowloss;
-  p.loss = d_loss; p.counter = d_counter;
+  p.loss = d_loss;
   const size_t lds = (size_t)C * F * 4;
   const uint32_t grid = std::min<uint32_t>((r + 3) / 4, 512);
   SHD_PROF_FMT(4.0 * r * (2.0 * F + 3.0 * C) + 4.0 * C * F, 2.0 * r * C * F, stream, "head_fwd_F%u_C%u", F, C);
@@ -314,6 +311,7 @@ extern "C" int sl_head_fwd(const float *d_emb, int64_t lde, const float *d_W, in
   } else {
     hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   }
+  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_rowloss, r, d_loss);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -321,16 +319,16 @@ extern "C" int sl_head_fwd(const float *d_emb, int64_t lde, const float *d_W, in
 extern "C" int sl_head_bwd(const float *d_gloss, const float *d_xn, const float *d_z, const float *d_prob, const float *d_nrm,
                            const int64_t *d_label, const float *d_W, int64_t ldw, const float *d_scale, uint32_t r, uint32_t F,
                            uint32_t C, float *d_demb, float *d_dW, float *d_db, float *d_dscale, float *d_doffset, float *d_work,
-                           float *d_partial, uint32_t *d_counter, void *stream) {
+                           float *d_partial, void *stream) {
   if (!d_gloss || !d_xn || !d_z || !d_prob || !d_nrm || !d_label || !d_W || !d_scale || !d_demb || !d_dW || !d_db || !d_dscale || !d_doffset ||
-      !d_work || !d_partial || !d_counter)
+      !d_work || !d_partial)
     return set_error(SG_ERR_INVALID, "sl_head_bwd: null argument");
   int rc;
   if ((rc = head_check("sl_head_bwd", r, F, C, d_xn, F, d_W, ldw)) != SG_OK) return rc;
   HeadParams p{};
   p.W = d_W; p.ldw = ldw; p.scale = d_scale; p.label = d_label; p.r = r; p.F = F; p.C = C;
   p.xn = const_cast<float *>(d_xn); p.z = const_cast<float *>(d_z); p.prob = const_cast<float *>(d_prob); p.nrm = const_cast<float *>(d_nrm);
-  p.counter = d_counter; p.gloss = d_gloss; p.demb = d_demb;
+  p.gloss = d_gloss; p.demb = d_demb;
   p.dz = d_work; p.dp = d_work + (size_t)r * C; p.dph = d_work + 2 * (size_t)r * C;
   p.dW = d_dW; p.db = d_db; p.dscale = d_dscale; p.doffset = d_doffset; p.partial = d_partial;
   p.slices = (r + 255u) / 256u;
@@ -347,6 +345,7 @@ extern "C" int sl_head_bwd(const float *d_gloss, const float *d_xn, const float 
   }
   SHD_PROF_FMT(4.0 * r * (F + 3.0 * C) + 4.0 * C * F, 2.0 * r * C * F, stream, "head_bwd_cols_F%u_C%u", F, C);
   hipLaunchKernelGGL(head_bwd_cols_kernel, dim3(C, p.slices), dim3(256), 0, (hipStream_t)stream, p);
+  if (p.slices > 1) hipLaunchKernelGGL(head_cols_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, p);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -420,10 +420,6 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   // below read it with plain loads -> drop this CU's possibly stale L1 lines.
   if (kGlobalTables) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
 
-  // Global-memory tables: the hash set was built with L2 atomics, the phases
-  // below read it with plain loads -> drop this CU's possibly stale L1 lines.
-  if (kGlobalTables) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __syncthreads(); }
-
   const uint32_t n_all = ctrl[C_NNODES];
   if (overflowed(ctrl) || n_all > capn || n_all > p.cap_nodes_scr) {
     if (tid == 0) {

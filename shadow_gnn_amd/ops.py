@@ -1938,15 +1938,6 @@ def gcn_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tenso
 # entropy) as one kernel forward and two backward (csrc/head.hip) instead of ~35 small torch / HIP kernels and their launches.
 # SHADOW_FUSED_HEAD=0: the separate nodes.
 FUSED_HEAD = os.environ.get("SHADOW_FUSED_HEAD", "1") != "0"
-_HEAD_COUNTERS = {}
-
-
-def _head_counter(dev):
-    c = _HEAD_COUNTERS.get(dev)
-    if c is None:
-        c = _HEAD_COUNTERS[dev] = torch.zeros(int(_lib.load().sl_head_counter_words()), dtype=torch.int32, device=dev)
-    return c
-
 
 class _NodeHead(torch.autograd.Function):
     """(loss, preds, softmax(preds), normalised embeddings) of shaDow/models.py:200-203 + :163-166 for a one-layer classifier
@@ -1963,12 +1954,11 @@ class _NodeHead(torch.autograd.Function):
         xn = torch.empty(r, F, **f32)
         zpp = torch.empty(3, r, Cn, **f32)                   # z, preds, softmax(preds)
         small = torch.empty(2 * r + 1, **f32)                # |emb_i|, the roots' losses, the mean loss
-        cnt = _head_counter(dev)
         step = r * Cn * 4
         check(lib.sl_head_fwd(emb.data_ptr(), emb.stride(0), W.data_ptr(), W.stride(0), b.data_ptr() if b is not None else None,
                               scale.data_ptr(), offset.data_ptr(), label.data_ptr(), r, F, Cn, xn.data_ptr(), zpp.data_ptr(),
                               zpp.data_ptr() + step, zpp.data_ptr() + 2 * step, small.data_ptr(), small.data_ptr() + 4 * r,
-                              small.data_ptr() + 8 * r, cnt.data_ptr(), _stream(emb)))
+                              small.data_ptr() + 8 * r, _stream(emb)))
         ctx.save_for_backward(W, scale, label)
         ctx.keep = (xn, zpp, small)
         ctx.shapes = (tuple(scale.shape), tuple(offset.shape), b is not None)
@@ -1999,8 +1989,7 @@ class _NodeHead(torch.autograd.Function):
         step = r * Cn * 4
         check(lib.sl_head_bwd(g.data_ptr(), xn.data_ptr(), zpp.data_ptr(), zpp.data_ptr() + 2 * step, small.data_ptr(), label.data_ptr(),
                               W.data_ptr(), W.stride(0), scale.data_ptr(), r, F, Cn, demb.data_ptr(), dW.data_ptr(), dsm.data_ptr(),
-                              dsm.data_ptr() + 4 * Cn, dsm.data_ptr() + 8 * Cn, work.data_ptr(), partial.data_ptr(),
-                              _head_counter(dev).data_ptr(), _stream(xn)))
+                              dsm.data_ptr() + 4 * Cn, dsm.data_ptr() + 8 * Cn, work.data_ptr(), partial.data_ptr(), _stream(xn)))
         ctx.keep = None
         sshape, oshape, has_b = ctx.shapes
         db, dsc, dof = dsm.unbind(0)
