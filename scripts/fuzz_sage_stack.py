@@ -1,4 +1,4 @@
-"""Fuzz of the whole-stack GraphSAGE node (ops._SageStack, sl_sage_stack_fwd / sl_sage_stack_bwd) against the layer-by-layer nodes:
+"""Fuzz of the whole-stack nodes (GraphSAGE: ops._SageStack, sl_sage_stack_fwd / sl_sage_stack_bwd; GCN: ops._GcnStack, sl_gcn_stack_*) against the layer-by-layer nodes:
 random depth, width, input width, activation, dropout, drop-edge, augmentation, batch size -- loss, predictions and every
 parameter gradient must be bit-identical (the C entries run the same per-layer entries in the same order), in training and in
 evaluation mode.  python scripts/fuzz_sage_stack.py [seed] [trials]"""
@@ -22,14 +22,15 @@ def main(seed, trials):
         kw = dict(n_layers=int(rng.integers(1, 6)), dim=int(rng.choice([32, 64, 128, 256])), p_drop=float(rng.choice([0.0, 0.2, 0.5])),
                   seed=int(rng.integers(1, 1000)), chain=True, fused=True, B=int(rng.choice([16, 64, 128, 300])),
                   act=str(rng.choice(["relu", "elu", "tanh", "leakyrelu"])), F0=int(rng.choice([36, 100, 128, 256])), sparse_top=False,
-                  dropedge=float(rng.choice([0.0, 0.1])), aug=bool(rng.random() < 0.4))
+                  dropedge=float(rng.choice([0.0, 0.1])), aug=bool(rng.random() < 0.4), aggr=str(rng.choice(["sage", "sage", "gcn"])))
         ok = True
+        calls = lambda: ops._SageStack.calls + ops._GcnStack.calls
         for train in (True, False):
-            k0 = ops._SageStack.calls
+            k0 = calls()
             a = T._sage_stack_step(stack=False, train=train, **kw)
-            k1 = ops._SageStack.calls
+            k1 = calls()
             b = T._sage_stack_step(stack=True, train=train, **kw)
-            took = ops._SageStack.calls - k1
+            took = calls() - k1
             same = a[0] == b[0] and torch.equal(a[1], b[1]) and set(a[2]) == set(b[2]) and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
             ok = ok and same and k1 == k0
             if not same or k1 != k0:
