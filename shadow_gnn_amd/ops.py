@@ -1705,6 +1705,9 @@ class _SageStack(torch.autograd.Function):
         it = iter(saved[1:])
         params = [next(it) if h else None for h in ctx.has]
         L, arr, adj, rows = ctx.L, ctx.arr, ctx.adj, ctx.rows
+        if arr is None:
+            raise RuntimeError("the layer-stack node was already back-propagated through (its forward products are released after the "
+                               "first backward pass; retain_graph is not supported on this path: set SHADOW_SAGE_STACK=0)")
         n, F0 = X0.shape
         F = params[0].shape[0]
         dev = X0.device
@@ -1854,6 +1857,9 @@ class _GcnStack(torch.autograd.Function):
         it = iter(saved[1:])
         params = [next(it) if h else None for h in ctx.has]
         L, arr, adj, rows = ctx.L, ctx.arr, ctx.adj, ctx.rows
+        if arr is None:
+            raise RuntimeError("the layer-stack node was already back-propagated through (its forward products are released after the "
+                               "first backward pass; retain_graph is not supported on this path: set SHADOW_SAGE_STACK=0)")
         n, F0 = X0.shape
         F = params[0].shape[0]
         dev = X0.device
@@ -1973,6 +1979,9 @@ class _NodeHead(torch.autograd.Function):
     def backward(ctx, dloss, *_unused):
         lib = _lib.load()
         W, scale, label = ctx.saved_tensors
+        if ctx.keep is None:
+            raise RuntimeError("the fused head was already back-propagated through (retain_graph is not supported on this path: set "
+                               "SHADOW_FUSED_HEAD=0)")
         xn, zpp, small = ctx.keep
         r, F = xn.shape
         Cn = W.shape[0]
