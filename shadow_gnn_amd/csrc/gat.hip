@@ -160,6 +160,38 @@ __device__ __forceinline__ void gat_fwd_group(const GatParams &p, uint32_t q, ui
     acc.x += pe * v[j].x; acc.y += pe * v[j].y; acc.z += pe * v[j].z; acc.w += pe * v[j].w;
   }
 }
+// One pass instead of two (SHADOW_GAT_ONLINE_SOFTMAX): the running maximum m is raised group by group and the sums so far are
+// rescaled by exp(m_old - m_new) -- the pass that only looked for the maximum (column ids -> scores: two dependent stages per
+// group) goes away.  mx / den come out as max_j e_j and sum_j exp(e_j - mx) w_j like before, to rounding.
+template <int G>
+__device__ __forceinline__ void gat_fwd_group_online(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, float as, float &m,
+                                                     float &den, float4 &acc) {
+  uint32_t c[G];
+  float u[G], w[G];
+  float4 v[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = p.edge_w ? p.edge_w[q + j] : 1.0f; }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
+    v[j] = on ? gld4(p.hn + (uint64_t)c[j] * p.F + f) : make_float4(0, 0, 0, 0);
+  }
+  float gm = m;
+#pragma unroll
+  for (int j = 0; j < G; j++) { u[j] = as + lrelu02(u[j]); gm = fmaxf(gm, u[j]); }
+  if (gm > m) {
+    const float sc = expf(m - gm);            // (m = -inf at the first group: exp(-inf) = 0, the sums are still zero)
+    den *= sc; acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+    m = gm;
+  }
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    float pe = expf(u[j] - m);
+    if (p.edge_w) pe *= w[j];
+    den += pe;
+    acc.x += pe * v[j].x; acc.y += pe * v[j].y; acc.z += pe * v[j].z; acc.w += pe * v[j].w;
+  }
+}
 template <int G>
 __device__ __forceinline__ void gat_bwd_row_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, bool lead, uint32_t ls,
                                                   float as, float mx, float inv, float t, const float4 &dn, float &das) {
@@ -217,6 +249,9 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
 #ifndef SHADOW_GAT_GROUPS_COL
 #define SHADOW_GAT_GROUPS_COL 2
 #endif
+#ifndef SHADOW_GAT_ONLINE_SOFTMAX
+#define SHADOW_GAT_ONLINE_SOFTMAX 1
+#endif
 #ifndef SHADOW_GAT_ROW_PREFETCH
 #define SHADOW_GAT_ROW_PREFETCH 1      // the next row's pointers / score / gradient rows are loaded while this row's edges are walked
 #endif
@@ -248,16 +283,23 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
     if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * p.H + h]; }
     float mx = -INFINITY;
     uint32_t q = a;
+    float den = 0.f;
+    float4 acc = make_float4(0, 0, 0, 0);
+#if SHADOW_GAT_ONLINE_SOFTMAX
+#define SHD_CALL(G) gat_fwd_group_online<G>(p, q, h, f, on, as, mx, den, acc)
+    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
+#undef SHD_CALL
+    if (a == b) mx = 0.f;
+#else
 #define SHD_CALL(G) gat_max_group<G>(p, q, h, as, mx)
     SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
 #undef SHD_CALL
     if (a == b) mx = 0.f;
-    float den = 0.f;
-    float4 acc = make_float4(0, 0, 0, 0);
     q = a;
 #define SHD_CALL(G) gat_fwd_group<G>(p, q, h, f, on, as, mx, den, acc)
     SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
 #undef SHD_CALL
+#endif
     den = fmaxf(den, 1e-10f);
     const float inv = 1.0f / den;
     if (on) {
