@@ -1652,12 +1652,17 @@ class _SageStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
-        big = torch.empty(4 * L - 1, n, F, **f32)            # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
+        keep_all = any(ctx.needs_input_grad)                 # (no backward pass will come: nothing is kept -- one Zs / Zn / A X slot, two `out` slots in turn)
+        # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
+        big = torch.empty(4 * L - 1, n, F, **f32) if keep_all else torch.empty(5 if L > 1 else 3, n, F, **f32)
+        slot_z = (lambda l: 3 * l) if keep_all else (lambda l: 0)
+        slot_out = (lambda l: 3 * l + 2) if keep_all else (lambda l: 2 + (l & 1) if L > 1 else 2)
+        slot_ax = (lambda l: 3 * L + l - 1) if keep_all else (lambda l: 4)
         amax = torch.empty(L, n, **f32)
         # (row statistics for the chained backward: the layers another layer chains into, as _SageDense.forward decides)
         stats_ok = CHAIN_SAGE_BWD and ROW_STATS_HANDOVER and bool(lib.sl_gemm_act_norm_supported(F, F))
         stats0_ok = CHAIN_SAGE_BWD and ROW_STATS_HANDOVER and bool(lib.sl_gemm_act_norm_supported(F, F0)) and AX0.stride(0) % 4 == 0
-        stats = torch.empty(max(1, L - 1), n, 4, **f32) if (L > 1 and (stats_ok or stats0_ok)) else None
+        stats = torch.empty(max(1, L - 1), n, 4, **f32) if (keep_all and L > 1 and (stats_ok or stats0_ok)) else None
         arr = (_lib.SlSageStackLayer * L)()
         base, step = big.data_ptr(), n * F * 4
         for l in range(L):
@@ -1672,8 +1677,8 @@ class _SageStack(torch.autograd.Function):
             if l == 0:
                 y.AX, y.ldax = AX0.data_ptr(), AX0.stride(0)
             else:
-                y.AX, y.ldax = base + (3 * L + l - 1) * step, F
-            y.Zs, y.Zn, y.out = base + 3 * l * step, base + (3 * l + 1) * step, base + (3 * l + 2) * step
+                y.AX, y.ldax = base + slot_ax(l) * step, F
+            y.Zs, y.Zn, y.out = base + slot_z(l) * step, base + (slot_z(l) + 1) * step, base + slot_out(l) * step
             y.out_amax = amax.data_ptr() + l * n * 4
             if stats is not None and l < L - 1 and (stats_ok if l else stats0_ok):
                 y.row_stats = stats.data_ptr() + l * n * 16
@@ -1682,7 +1687,7 @@ class _SageStack(torch.autograd.Function):
         a = _adj_struct(adj, False)
         check(lib.sl_sage_stack_fwd(C.byref(a), X0.data_ptr(), X0.stride(0), x0_amax.data_ptr() if x0_amax is not None else None,
                                     1 if getattr(X0, "_shd_pad_zero", False) else 0, L, arr, pack.data_ptr(), _stream(X0)))
-        if Z_TAP is not None:
+        if Z_TAP is not None and keep_all:
             for l in range(L):
                 _tap([big[3 * l], big[3 * l + 1]], [params[6 * l + 1], params[6 * l + 3]])
         ctx.save_for_backward(X0, *[p for p in params if p is not None])
@@ -1694,7 +1699,7 @@ class _SageStack(torch.autograd.Function):
         _SageStack.calls += 1
         _SageDense.fused_calls += L                          # (the one-call layer entries ran L times, from C)
         fire_deferred()
-        out = big[3 * (L - 1) + 2]
+        out = big[slot_out(L - 1)]
         return out.index_select(0, rows) if rows is not None else out
 
     @staticmethod
@@ -1818,7 +1823,11 @@ class _GcnStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
-        big = torch.empty(3 * L - 1, n, F, **f32)            # per layer Z, out; then A X of the layers 1 .. L - 1
+        keep_all = any(ctx.needs_input_grad)                 # (no backward pass will come: one Z / A X slot, two `out` slots in turn)
+        big = torch.empty(3 * L - 1, n, F, **f32) if keep_all else torch.empty(4 if L > 1 else 2, n, F, **f32)   # per layer Z, out; then A X of the layers 1 .. L - 1
+        slot_z = (lambda l: 2 * l) if keep_all else (lambda l: 0)
+        slot_out = (lambda l: 2 * l + 1) if keep_all else (lambda l: 1 + (l & 1) if L > 1 else 1)
+        slot_ax = (lambda l: 2 * L + l - 1) if keep_all else (lambda l: 3)
         arr = (_lib.SlGcnStackLayer * L)()
         base, step = big.data_ptr(), n * F * 4
         for l in range(L):
@@ -1831,12 +1840,12 @@ class _GcnStack(torch.autograd.Function):
             if l == 0:
                 y.AX, y.ldax = AX0.data_ptr(), AX0.stride(0)
             else:
-                y.AX, y.ldax = base + (2 * L + l - 1) * step, F
-            y.Z, y.out = base + 2 * l * step, base + (2 * l + 1) * step
+                y.AX, y.ldax = base + slot_ax(l) * step, F
+            y.Z, y.out = base + slot_z(l) * step, base + slot_out(l) * step
         pack = torch.empty(lib.sl_gcn_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
         a = _adj_struct(adj, False)
         check(lib.sl_gcn_stack_fwd(C.byref(a), X0.data_ptr(), X0.stride(0), L, arr, pack.data_ptr(), _stream(X0)))
-        if Z_TAP is not None:
+        if Z_TAP is not None and keep_all:
             for l in range(L):
                 _tap([big[2 * l]], [params[4 * l + 1]])
         ctx.save_for_backward(X0, *[p for p in params if p is not None])
@@ -1846,7 +1855,7 @@ class _GcnStack(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         _GcnStack.calls += 1
         fire_deferred()
-        out = big[2 * (L - 1) + 1]
+        out = big[slot_out(L - 1)]
         return out.index_select(0, rows) if rows is not None else out
 
     @staticmethod
