@@ -296,9 +296,8 @@ def main():
     # backward pass runs on the rows it is non-zero on (exact; tail.TopBackwardPlan, --dense-top-backward switches it off)
     if args.dense_top_backward:
         ops.SPARSE_TOP_BWD = False
-    mb.top_backward_plan = bool(ops.SPARSE_TOP_BWD and wl["aggr"] in ("sage", "gat") and model._tail_prunable(0) and not args.prune_tail)
-    mb.backward_levels = 2 if wl["aggr"] == "gat" else 0   # (GAT: nested levels -- roots, their neighbours -- for the top layers' backward)
     model.prune_tail = bool(args.prune_tail)
+    mb.attach_model(model)                 # (row sets of the row-sparse top-layer backward built on the prefetch stream)
     if args.prune_tail and model._tail_prunable(0):
         mb.tail_plan_layers = wl["layers"]
         mb.tail_plan_square = wl["aggr"] == "gat"

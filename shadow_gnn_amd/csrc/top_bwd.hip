@@ -18,7 +18,7 @@ namespace shadow {
 namespace {
 
 // One wavefront per subgraph: t_s = deg(r_s) + [r_s not among its own neighbours] -> off[s] (scanned below); a neighbour list
-// that is not strictly ascending (repeated edges) raises off[P + 1]
+// that is not strictly ascending (repeated edges), or row sets of consecutive subgraphs that interleave, raise off[P + 1]
 __global__ void __launch_bounds__(256) top_count_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ targets, uint32_t P, uint32_t *__restrict__ off) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -33,6 +33,16 @@ __global__ void __launch_bounds__(256) top_count_kernel(const uint32_t *__restri
   }
   for (int d = 32; d >= 1; d >>= 1) { self |= __shfl_xor(self, d, 64); bad |= __shfl_xor(bad, d, 64); }
   if (lane == 0) {
+    // T must come out strictly ascending over the whole batch (every row of T then receives exactly one neighbour term and
+    // rowmap[T] = arange has no collisions): this subgraph's smallest row lies above the previous subgraph's largest.  True for
+    // any collated batch (block-diagonal CSR, one root per block); a hand-made batch whose targets share a neighbour, or whose
+    // target sits outside its own block, raises the flag instead of producing overwritten terms
+    if (s > 0) {
+      const uint32_t rp = targets[s - 1], p0 = indptr[rp], p1 = indptr[rp + 1];
+      const uint32_t pmax = p1 > p0 ? max(rp, indices[p1 - 1]) : rp;
+      const uint32_t mymin = e1 > e0 ? min(r, indices[e0]) : r;
+      if (mymin <= pmax) bad = 1u;
+    }
     off[s] = (e1 - e0) + (self ? 0u : 1u);
     if (bad) off[P + 1] = 1u;                               // (cleared by the host entry; the caller falls back to the dense pass)
   }

@@ -226,7 +226,8 @@ class MinibatchShallowExtractor:
         # dependent kernel launches cost ~0.08 ms whatever the call's size -- a third of a 1 024-root call -- and the draws are
         # keyed on the subgraph's serial number, so S steps' batches from one call are bit-identical to S calls.  The batches
         # of a call wait in ``_ready`` until their step comes.  1 = one call per step (the reference's rhythm).
-        self.steps_per_call = max(1, min(int(os.environ.get("SHADOW_SAMPLER_STEPS_PER_CALL", "1")), 16))
+        # Default 4 = what bench.py times (the published configuration is the library's default).
+        self.steps_per_call = max(1, min(int(os.environ.get("SHADOW_SAMPLER_STEPS_PER_CALL", "4")), 16))
         self._ready: Dict[int, list] = {m: [] for m in _MODES}  # collected batches of later steps, in step order
         # record -> reuse of sampled subgraphs for deterministic samplers (minibatch.py:306-339, :403-426)
         self.nocache_modes = set(nocache_modes)
@@ -255,6 +256,21 @@ class MinibatchShallowExtractor:
                    rank=rank, world_size=world_size, prefetch=prefetch)
 
     # ------------------------------------------------------------------ API
+    def attach_model(self, model):
+        """Let the extractor prepare what ``model``'s training step will ask of every TRAIN batch: the row sets of the row-sparse
+        top-layer backward pass (node task, residue none + centre pooling: GraphSAGE stacks take a tail.TopBackwardPlan, GAT
+        stacks two nested levels), built on the prefetch stream.  Without it the model builds them inside its forward pass
+        (two host syncs on the training stream per step).  Returns self."""
+        from . import layers as _layers
+        ok = bool(ops.SPARSE_TOP_BWD and getattr(model, "prediction_task", None) == "node" and len(model.conv_layers) == 1
+                  and model._tail_prunable(0) and not getattr(model, "prune_tail", False))
+        convs = list(model.conv_layers[0]) if ok else []
+        sage = ok and all(isinstance(md, _layers.GraphSAGE) for md in convs)
+        gat = ok and all(isinstance(md, _layers.GAT) for md in convs)
+        self.top_backward_plan = bool(sage or gat)
+        self.backward_levels = 2 if gat else 0
+        return self
+
     def get_aug_dim(self, aug_type):
         return getattr(self, f'dim_1hot_{aug_type[:-1]}')
 
@@ -583,7 +599,8 @@ class MinibatchShallowExtractor:
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
                             subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
-        if self.top_backward_plan and self.tail_plan_layers == 0 and adj.n >= ops.SPARSE_TOP_BWD_MIN_ROWS and ops.SPARSE_TOP_BWD:
+        if (self.top_backward_plan and mode == TRAIN and self.tail_plan_layers == 0 and adj.n >= ops.SPARSE_TOP_BWD_MIN_ROWS
+                and ops.SPARSE_TOP_BWD):                  # (evaluation batches: no backward pass will ask for the row sets)
             plan = self._top_plan(subgs, adj)
             if isinstance(plan, list):
                 subgs.target._shd_bwd_levels = plan

@@ -1169,13 +1169,14 @@ class _SelectRoots(torch.autograd.Function):
         # the row sets of the row-sparse top-layer backward: handed over with the rows (built by the minibatch extractor on its
         # prefetch stream) or, for hand-made batches, built here (two host syncs)
         ctx.plan = ctx.levels = None
-        if SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None and link.want_levels:
+        want = SPARSE_TOP_BWD and torch.is_grad_enabled() and f.requires_grad     # (evaluation: no backward pass will ask for the row sets)
+        if want and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None and link.want_levels:
             lv = getattr(rows, "_shd_bwd_levels", None)
             if lv is None:
                 from . import tail
                 lv = tail.build_backward_levels(link.csr, rows, frac=BACKWARD_LEVELS_FRAC)
             ctx.levels = lv if (lv and lv[0].r == int(rows.numel())) else None
-        elif SPARSE_TOP_BWD and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None:
+        elif want and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None:
             plan = getattr(rows, "_shd_top_plan", None)
             if plan is None or not plan.matches(link.csr, int(rows.numel())):
                 from . import tail
@@ -1652,7 +1653,7 @@ class _SageStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
-        keep_all = any(ctx.needs_input_grad)                 # (no backward pass will come: nothing is kept -- one Zs / Zn / A X slot, two `out` slots in turn)
+        keep_all = torch.is_grad_enabled() and any(ctx.needs_input_grad)   # (no backward pass will come -- no_grad keeps needs_input_grad True for live parameters --: nothing is kept: one Zs / Zn / A X slot, two `out` slots in turn)
         # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
         big = torch.empty(4 * L - 1, n, F, **f32) if keep_all else torch.empty(5 if L > 1 else 3, n, F, **f32)
         slot_z = (lambda l: 3 * l) if keep_all else (lambda l: 0)
@@ -1697,6 +1698,7 @@ class _SageStack(torch.autograd.Function):
         ctx.keep = (AX0, big, amax, stats)                   # (the forward products the descriptors point into)
         ctx.set_materialize_grads(False)
         _SageStack.calls += 1
+        _SageStack.last_slots = int(big.shape[0])             # ([n, F] slots this call allocated: tests hold the evaluation footprint)
         _SageDense.fused_calls += L                          # (the one-call layer entries ran L times, from C)
         fire_deferred()
         out = big[slot_out(L - 1)]
@@ -1823,7 +1825,7 @@ class _GcnStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
-        keep_all = any(ctx.needs_input_grad)                 # (no backward pass will come: one Z / A X slot, two `out` slots in turn)
+        keep_all = torch.is_grad_enabled() and any(ctx.needs_input_grad)   # (no backward pass will come: one Z / A X slot, two `out` slots in turn)
         big = torch.empty(3 * L - 1, n, F, **f32) if keep_all else torch.empty(4 if L > 1 else 2, n, F, **f32)   # per layer Z, out; then A X of the layers 1 .. L - 1
         slot_z = (lambda l: 2 * l) if keep_all else (lambda l: 0)
         slot_out = (lambda l: 2 * l + 1) if keep_all else (lambda l: 1 + (l & 1) if L > 1 else 1)
@@ -1854,6 +1856,7 @@ class _GcnStack(torch.autograd.Function):
         ctx.keep = (AX0, big)
         ctx.set_materialize_grads(False)
         _GcnStack.calls += 1
+        _GcnStack.last_slots = int(big.shape[0])
         fire_deferred()
         out = big[slot_out(L - 1)]
         return out.index_select(0, rows) if rows is not None else out

@@ -110,8 +110,19 @@ class FlatAdam:
 
     def load_state_dict(self, sd):
         if "state" not in sd:                         # the flat layout of round 2
+            # (that layout packed the parameters back to back; the buffers now start every tensor on a dist.FLAT_ALIGN line:
+            #  each parameter's slice is copied to its own offset -- ADVICE r4)
+            total = sum(p.numel() for p in self.sync.params)
+            ea, es = sd["exp_avg"].reshape(-1), sd["exp_avg_sq"].reshape(-1)
+            if ea.numel() != total or es.numel() != total:
+                raise ValueError(f"flat optimizer state holds {ea.numel()} / {es.numel()} moments, this model has {total} parameters")
             self.step_count = int(sd["step"])
-            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            with torch.no_grad():
+                self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+                src = 0
+                for lo, hi, p in self._param_slices():
+                    self.exp_avg[lo:hi].copy_(ea[src:src + p.numel()]); self.exp_avg_sq[lo:hi].copy_(es[src:src + p.numel()])
+                    src += p.numel()
             self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
             return
         g = sd["param_groups"][0]

@@ -179,6 +179,17 @@ def test_flat_adam_steps_without_an_explicit_all_reduce_and_speaks_torch_adam_st
     opt2.load_state_dict(topt.state_dict())
     assert opt2.step_count == 3 and opt2.lr == 0.01
     assert torch.allclose(opt2.exp_avg, opt.exp_avg, rtol=1e-5, atol=1e-8) and torch.allclose(opt2.exp_avg_sq, opt.exp_avg_sq, rtol=1e-5, atol=1e-10)
+    # round 2's flat layout (moments packed back to back, no line padding) lands at the padded offsets
+    packed = dict(step=3, lr=0.01, betas=(0.9, 0.999), eps=1e-8,
+                  exp_avg=torch.cat([topt.state[p]["exp_avg"].reshape(-1) for p in ref.parameters()]),
+                  exp_avg_sq=torch.cat([topt.state[p]["exp_avg_sq"].reshape(-1) for p in ref.parameters()]))
+    opt3 = FlatAdam(GradSync(copy.deepcopy(net).parameters(), world_size=1), lr=0.5)
+    assert opt3.exp_avg.numel() > packed["exp_avg"].numel()          # (the padded buffers are longer: a plain copy_ would raise)
+    opt3.load_state_dict(packed)
+    assert opt3.step_count == 3 and torch.allclose(opt3.exp_avg, opt.exp_avg, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(opt3.exp_avg_sq, opt.exp_avg_sq, rtol=1e-5, atol=1e-10)
+    with pytest.raises(ValueError):
+        opt3.load_state_dict(dict(packed, exp_avg=packed["exp_avg"][:-1]))
 
 
 def _pin_worker(local_rank, local_world, q):

@@ -1311,6 +1311,9 @@ def test_sage_stack_call_equals_layer_by_layer(n_layers, dim, p_drop, dropedge, 
     e1 = _sage_stack_step(n_layers, dim, p_drop, 31, chain=True, fused=True, B=128, act=act, F0=F0, stack=True, aug=aug, train=False)
     assert ops._SageStack.calls == k0 + 2 and e0[0] == e1[0]
     torch.testing.assert_close(e1[1], e0[1], rtol=0, atol=0)
+    #  the evaluation step runs under no_grad with LIVE parameters: nothing is kept for a backward pass that will not
+    # come -- 5 (3 for one layer) [n, F] slots instead of 4 L - 1
+    assert ops._SageStack.last_slots == (5 if n_layers > 1 else 3), ops._SageStack.last_slots
 
 
 @pytest.mark.parametrize("n_layers,dim,p_drop,act", [(3, 256, 0.4, "relu"), (5, 256, 0.0, "elu"), (3, 128, 0.3, "elu")])
@@ -1796,6 +1799,16 @@ def test_top_backward_plan_lists_roots_and_their_neighbours():
     ix = torch.tensor([1, 1, 2, 0, 0], dtype=torch.int32, device=DEV)
     bad = tail.TopBackwardPlan(ops.DeviceCSR(ip, ix), torch.tensor([0], dtype=torch.int32, device=DEV))
     assert not bad.ok and not bad.matches(ops.DeviceCSR(ip, ix), 1)
+    #  hand-made batches that break "one root per diagonal block": two targets sharing a neighbour (rows 0 and 2 both
+    # list row 1), and a target whose row set lies below the previous one's -- rowmap[T] = arange would collide: not usable
+    ip = torch.tensor([0, 1, 1, 2, 2], dtype=torch.int32, device=DEV)
+    ix = torch.tensor([1, 1], dtype=torch.int32, device=DEV)
+    shared = tail.TopBackwardPlan(ops.DeviceCSR(ip, ix), torch.tensor([0, 2], dtype=torch.int32, device=DEV))
+    assert not shared.ok
+    swapped = tail.TopBackwardPlan(ops.DeviceCSR(ip, ix), torch.tensor([3, 0], dtype=torch.int32, device=DEV))
+    assert not swapped.ok
+    fine = tail.TopBackwardPlan(ops.DeviceCSR(ip, ix), torch.tensor([0, 3], dtype=torch.int32, device=DEV))
+    assert fine.ok and fine.T32.tolist() == [0, 1, 3]
 
 
 def _gat_stack_step(n_layers, p_drop, dropedge, seed, sparse_top, B=96, given_plan=False, levels=2):
@@ -1885,6 +1898,7 @@ def test_gcn_stack_call_equals_layer_by_layer(n_layers, dim, p_drop, dropedge, a
     e0 = _sage_stack_step(n_layers, dim, p_drop, 41, chain=True, fused=True, B=96, act=act, F0=F0, stack=False, aug=aug, train=False, aggr="gcn")
     e1 = _sage_stack_step(n_layers, dim, p_drop, 41, chain=True, fused=True, B=96, act=act, F0=F0, stack=True, aug=aug, train=False, aggr="gcn")
     assert ops._GcnStack.calls == k0 + 2 and e0[0] == e1[0]
+    assert ops._GcnStack.last_slots == (4 if n_layers > 1 else 2), ops._GcnStack.last_slots    # (evaluation: no saved per-layer tensors)
     torch.testing.assert_close(e1[1], e0[1], rtol=0, atol=0)
 
 
