@@ -220,6 +220,45 @@ def gen_budget_stats():
     print(f"wrote {path}")
 
 
+def hub_graph_and_roots():
+    """The graph and roots of the budget-20 statistics fixture: 5 000 nodes, heavy tail (maximum degree 580 >> budget 20);
+    64 roots = the 24 largest hubs (degree 100 .. 580), 24 nodes of degree 21 .. 60 (budget binds, few repeats possible) and
+    16 of degree <= 20 (all neighbours taken)."""
+    indptr, indices = make_graph(5000, 16, seed=21)
+    deg = np.diff(indptr.astype(np.int64))
+    rng = np.random.default_rng(23)
+    hubs = np.argsort(-deg, kind="stable")[:24]
+    mid = rng.choice(np.nonzero((deg > 20) & (deg <= 60))[0], size=24, replace=False)
+    low = rng.choice(np.nonzero((deg >= 3) & (deg <= 20))[0], size=16, replace=False)
+    roots = np.concatenate([hubs, mid, low]).astype(np.uint32)
+    return indptr, indices, roots
+
+
+def gen_budget_hub_stats(reps=256):
+    """(round 5) The draw statistics of the reference's budgeted k-hop where the budget BINDS hard --
+    budget 20 on roots of degree up to 580, as in every k-hop BASELINE config (products: mean degree 50) -- over `reps`
+    one-thread runs with seeds 0 .. reps-1: per (root, node) how many runs' subgraphs contain the node, and every run's
+    subgraph sizes, at depth 1 (exact theory available: 20 uniform draws WITH replacement from the root's row,
+    ParallelSampler.cpp:528-540) and depth 2.  Data only."""
+    indptr, indices, roots = hub_graph_and_roots()
+    N = indptr.size - 1
+    store = dict(indptr=indptr, indices=indices, roots=roots, budget=20, reps=reps)
+    for depth in (1, 2):
+        cfg = dict(method="khop", num_roots=1, depth=depth, budget=20, add_self_edge=False, include_target_conn=False)
+        counts = np.zeros((roots.size, N), dtype=np.uint16)
+        sizes = np.zeros((reps, roots.size), dtype=np.uint16)
+        for rep in range(reps):
+            res, _ = run_reference(indptr, indices, roots, cfg, [], threads=1, seed=rep)
+            for r, nodes in enumerate(res["node"]):
+                counts[r, nodes] += 1
+                sizes[rep, r] = nodes.size
+        store[f"d{depth}_counts"] = counts
+        store[f"d{depth}_sizes"] = sizes
+    path = os.path.join(ROOT, "tests", "golden", "sampler_budget_hub_stats.npz")
+    np.savez_compressed(path, **store)
+    print(f"wrote {path}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
 def gen_ppr_cache_files():
     """The reference's two PPR cache files as RAW BYTES (ParallelSampler.cpp:94-137, written by
     preproc_ppr_approximate :344) for a small graph: the byte-compatibility fixture of sg_load_ppr_bin /
@@ -267,6 +306,7 @@ def main():
     ip, ix = make_graph(400, 6, seed=9, directed=True)
     gen_graph_fixture("directed400", ip, ix, seed=6, link=False)
     gen_budget_stats()
+    gen_budget_hub_stats()
     gen_ppr_cache_files()
 
 

@@ -114,6 +114,32 @@ def test_khop_matches_oracle(depth, budget, self_e, aug):
     assert hs.get_idx_root() == 0          # cursor wrapped (ParallelSampler.cpp:462)
 
 
+def test_budget_20_draw_law_on_hub_rows_matches_the_reference():
+    """ The HIP sampler's budgeted draws on rows of degree >> budget (budget 20, degrees up to 580)
+    against the reference's draw law: exact occupancy theory at depth 1, the reference's own 256-run tables at depth 1
+    and 2 (tests/_budget_stats.py; fixture tests/golden/sampler_budget_hub_stats.npz from oracle/_ref).  256 calls of one
+    sampler: the serial numbers advance, every call draws afresh."""
+    from shadow_gnn_amd.sampler import SamplerConfig
+    from tests import _budget_stats as bs
+    fx = bs.load()
+    roots = fx["roots"].astype(np.uint32)
+    reports = {}
+    for depth in (1, 2):
+        hs = _make(fx["indptr"], fx["indices"], seed=77 + depth)
+        hs.shuffle_targets(roots)
+        cfg = SamplerConfig(method="khop", depth=depth, budget=int(fx["budget"]), add_self_edge=False)
+
+        def call(rep, depth_):
+            b = hs.sample(cfg, roots.size)
+            h = b.to_host()
+            off = h["subg_node_off"].astype(np.int64)
+            return [h["node"][off[i]:off[i + 1]] for i in range(roots.size)]
+        reports[depth] = bs.tables(call, fx, depth)
+    c1, s1 = reports[1]
+    c2, s2 = reports[2]
+    bs.check(bs.depth1_theory(c1, s1, fx), bs.against_reference(c1, s1, fx, 1), bs.against_reference(c2, s2, fx, 2))
+
+
 @pytest.mark.parametrize("depth,budget,self_e,aug,method", [(2, 20, False, (), "khop"), (2, 5, True, ("hops",), "khop"),
                                                              (3, 4, True, ("hops",), "khop"), (0, 0, False, ("hops", "pprs"), "ppr")])
 def test_multi_step_call_equals_separate_calls_and_the_oracle(depth, budget, self_e, aug, method):
