@@ -2299,6 +2299,8 @@ class _PoolAndRoots(torch.autograd.Function):
     (shaDow/layers.py:154-199 with mean / max / sum pooling) would otherwise hand autograd two dense [n, F] gradients per
     layer -- a zero-filled index_put and the pooling backward -- plus the pass that adds them.  Here the pooling backward
     writes the dense gradient once and the few root rows are added in place."""
+    calls = 0
+
     @staticmethod
     def forward(ctx, X, node_off, rows, mode):
         X = _f32c(X)
@@ -2313,6 +2315,7 @@ class _PoolAndRoots(torch.autograd.Function):
         ctx.mode, ctx.n = mode, int(X.shape[0])
         ctx.save_for_backward(node_off, am if am is not None else node_off, rows)
         ctx.set_materialize_grads(False)
+        _PoolAndRoots.calls += 1
         return out, X.index_select(0, rows)
 
     @staticmethod

@@ -1724,6 +1724,127 @@ def test_timed_configuration_with_dropout_and_dropedge_matches_fp64_oracle(act, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("act,p_drop,p_edge", [("relu", 0.0, 0.0), ("elu", 0.0, 0.0), ("relu", 0.4, 0.05), ("elu", 0.4, 0.05)])
+def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act, p_drop, p_edge, monkeypatch):
+    """ BASELINE configs[2] -- PPR sampler, GraphSAGE-5 dim 256, residue max + mean pooling
+    (config_train/products/vanilla/sage_5_ppr.yml per SURVEY 8(d)) -- at benchmark WIDTH through the timed call path and
+    against the fp64 edge-list oracle: the batch is drawn by the HIP `ppr` method (k = 200) from a table the HIP push kernel
+    built (sg_ppr_push), ~200-row subgraphs, n >= 40 k rows.  Every layer output is read by the read-out, so the layers
+    are NOT chained: the kernel classes of that path -- the un-chained input-gradient product `gemm_nt_f16_N256`, the
+    stand-alone `act_norm_bwd_nb2_F256`, the block-diagonal SpMM over MERGED small subgraphs, `ops.pool_and_roots` -- are
+    asserted to have run; with dropout 0.4 / drop-edge 0.05 ON the forward epilogue writes the plain AND the dropped output
+    (dual mode) and the oracle applies the run's own masks (as in test_timed_configuration_...).  Bounds as for the other
+    benchmark-scale runs: loss / predictions / embeddings 1e-4, every parameter gradient entry 1e-3 relative + 1e-4 of its scale."""
+    from oracle import layers_oracle as lo
+    from oracle import model_oracle_sparse as mos
+    from shadow_gnn_amd import dist as sdist
+    from shadow_gnn_amd import ops
+    from shadow_gnn_amd.minibatch import OneBatchSubgraph, TRAIN
+    from shadow_gnn_amd.models import DeepGNN
+    from shadow_gnn_amd.optim import FlatAdam
+    from shadow_gnn_amd.ppr import ppr_approximate_device
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+    from shadow_gnn_amd.synthetic import make_graph_numpy
+    L, B, F0, C, N = 5, 256, 100, 47, 200_000
+    indptr, indices = make_graph_numpy(N, 50, seed=21)
+    hs = HipSampler(indptr, indices, device=torch.device(DEV), seed=7)
+    roots = np.sort(np.random.default_rng(24).permutation(N)[:B]).astype(np.uint32)
+    ln, nb, sc = ppr_approximate_device(hs, roots, 200, 0.85, 1e-5)
+    hs.set_ppr(roots, ln, nb, sc)
+    b = hs.sample(SamplerConfig(method="ppr", k=200, threshold=0.0, add_self_edge=False), roots=roots)
+    n = b.num_nodes
+    assert n >= ops.AMAX_HANDOVER_ROWS and b.counts["max_subg_nodes"] <= 201, (n, b.counts)
+    g = torch.Generator().manual_seed(25)
+    X = torch.randn(n, F0, generator=g)
+    labels = torch.randint(0, C, (B,), generator=g)
+    arch = dict(num_layers=L, num_cls_layers=1, heads=1, dim=256, act=act, layer_norm="norm_feat", feature_augment_ops="sum",
+                aggr="sage", residue="max", pooling="mean", loss="softmax")
+    torch.manual_seed(43)
+    model = DeepGNN(F0, F0, C, 0, arch, [], 1, dict(dropout=p_drop, dropedge=p_edge, lr=0.002), "node").to(DEV)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    model.grad_sync = sdist.GradSync(model.parameters(), world_size=1)
+    model.optimizer = FlatAdam(model.grad_sync, lr=0.002)
+    p0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    lazy = ops.LazyRows(X.to(DEV), torch.arange(n, device=DEV, dtype=torch.int32))       # (the extractor's lazy_features form)
+    adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off,
+                        max_subg_nodes=b.counts["max_subg_nodes"])
+    batch = OneBatchSubgraph([adj], [lazy], labels.to(DEV), b.size_subg.unsqueeze(0), [b.target], [{}])
+    seeds, edge_masks = [], []
+    real_seed, real_mask = ops.new_dropout_seed, ops.dropedge_mask
+
+    def logged_seed():
+        s_ = real_seed()
+        seeds.append(s_)
+        return s_
+
+    def logged_mask(csr, dropedge, symmetric=False):
+        m = real_mask(csr, dropedge, symmetric)
+        edge_masks.append(m)
+        return m
+    monkeypatch.setattr(ops, "new_dropout_seed", logged_seed)
+    monkeypatch.setattr(ops, "dropedge_mask", logged_mask)
+    c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls, ops._PoolAndRoots.calls)
+    timer = ops.KernelTimer()
+    ops.Z_TAP = []
+    try:
+        with timer:
+            ret = model.step(TRAIN, "running", batch)
+        torch.cuda.synchronize()
+        tap = ops.Z_TAP
+    finally:
+        ops.Z_TAP = None
+    ran = set(timer.summary())
+    # ---- the call path of the timed configs[2] line
+    assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (L, 0), "one-call entries, nothing chained"
+    assert ops._PoolAndRoots.calls - c0[2] == L, "every layer output goes through ops.pool_and_roots"
+    for cls in ("gemm_act_norm_fwd_nb2_N256", "gemm_nt_f16_N256", "act_norm_bwd_nb2_F256", "spmm_F256", "segment_pool_F256", "gemm_tn_f16_pair_N256"):
+        assert any(k.startswith(cls) for k in ran), (cls, sorted(ran))
+    assert not any(k.startswith("gemm_an_bwd") for k in ran), sorted(ran)
+    blocks = adj.spmm_blocks
+    assert blocks[0] is not adj.subg_off and int(blocks[0][1:].ne(blocks[0][:-1]).sum()) < B, "the SpMM staged merged groups of subgraphs"
+    convs = list(model.conv_layers[0])
+    if p_drop > 0:
+        assert all(md.out_dual and md.out_dropout == p_drop for md in convs[:-1]) and not convs[-1].out_dual     # dual-output epilogues
+        assert len(seeds) == L and len(edge_masks) == 1 and edge_masks[0] is not None, (len(seeds), len(edge_masks))
+        ek = edge_masks[0].cpu()
+        widths = [F0] + [256] * (L - 1)
+        in_drop = [ops.dropout_keep_mask(n, w, p_drop, s_, DEV).cpu().double() / (1.0 - p_drop) for w, s_ in zip(widths, seeds)]
+    else:
+        ek, in_drop = None, None
+    # ---- fp64 oracle with the same parameters (relu: the run's own side at the kink) and the run's own masks
+    h = b.to_host()
+    sizes = np.diff(h["subg_node_off"].astype(np.int64))
+    relu_keep, kstats = None, {}
+    if act == "relu":
+        assert len(tap) >= L
+        relu_keep = [[((z + (bb if bb is not None else 0)) > 0).cpu() for z, bb in zip(zs, bs_)] for zs, bs_ in tap[:L]]
+    p = {k: v.double().requires_grad_(True) for k, v in p0.items()}
+    preds_ref, emb_ref = mos.model_forward(p, arch, X, h["indptr"], h["indices"], sizes, h["target"], relu_keep=relu_keep, stats=kstats,
+                                           edge_keep=ek, in_drop=in_drop)
+    if relu_keep is not None:
+        assert kstats["kink_units"] <= 1e-5 * kstats["units"] and kstats.get("kink_max_abs_z", 0.0) < 5e-3, kstats
+    loss_ref = lo.model_loss(preds_ref, labels.numpy())
+    loss_ref.backward()
+    assert abs(float(ret["loss"]) - float(loss_ref)) < 1e-4
+    np.testing.assert_allclose(ret["preds"].detach().cpu().numpy(), torch.softmax(preds_ref, 1).detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ret["emb_ens"][0].detach().cpu().numpy(), emb_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    grads = {k: v.grad for k, v in p.items() if v.grad is not None}
+    gn = float(torch.sqrt(sum((g_ ** 2).sum() for g_ in grads.values())))
+    coef = min(1.0, 5.0 / (gn + 1e-6))
+    worst = {}
+    for k, q in model.named_parameters():
+        ref = (grads[k] * coef).numpy()
+        got = q.grad.cpu().numpy()
+        scale = float(np.abs(ref).max())
+        bad = np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-4 * scale
+        worst[k] = float(np.abs(got - ref).max() / max(scale, 1e-30))
+        assert not bad.any(), (k, int(bad.sum()), worst[k])
+    assert max(worst.values()) < 1e-3, worst
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_layers,p_drop,dropedge,act,given", [(5, 0.4, 0.05, "relu", True), (3, 0.0, 0.0, "elu", False), (2, 0.3, 0.1, "relu", True)])
 def test_sparse_top_layer_backward_equals_dense(n_layers, p_drop, dropedge, act, given):
     """The top GraphSAGE layer's backward on the rows its gradient is non-zero on (tail.TopBackwardPlan: the roots R for
