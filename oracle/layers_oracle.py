@@ -136,9 +136,11 @@ def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None):
     return readout_and_classify(p, arch, feats, sizes, target)
 
 
-def readout_and_classify(p, arch, feats, sizes, target):
+def readout_and_classify(p, arch, feats, sizes, target, readout_drop=None):
     """ResPool + L2 normalisation + classifier on the per-layer outputs ``feats`` (layers.py:154-199,
-    models.py:198-204); shared by the dense model above and oracle/model_oracle_sparse.py."""
+    models.py:198-204); shared by the dense model above and oracle/model_oracle_sparse.py.  ``readout_drop``: the
+    multiplier tensor (keep / (1 - p)) of the read-out's own nn.Dropout in training mode (layers.py:110), taken from the
+    run under test -- the reference's torch RNG stream cannot be reproduced."""
     act = arch["act"]
     tgt = torch.as_tensor(np.asarray(target, dtype=np.int64))
     type_res, type_pool = arch["residue"], arch["pooling"]
@@ -167,6 +169,8 @@ def readout_and_classify(p, arch, feats, sizes, target):
             feat_in = torch.cat([feats[-1][tgt], pool(feats[-1])], 1)
         else:
             feat_in = torch.cat([residue([f[tgt] for f in feats]), residue([pool(f) for f in feats])], 1)
+        if readout_drop is not None:
+            feat_in = feat_in * readout_drop.to(feat_in.dtype)
         z = act_fn(act, p, "res_pool_layers.0.nn.2.weight")(
             F.linear(feat_in, p["res_pool_layers.0.nn.1.weight"], p["res_pool_layers.0.nn.1.bias"]))
         emb = f_norm(z, p["res_pool_layers.0.scale"], p["res_pool_layers.0.offset"])    # layers.py:114-118,199

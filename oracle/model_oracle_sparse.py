@@ -110,14 +110,15 @@ def gat_forward(p, X, A, act, heads):
 
 
 def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtype=torch.float64, relu_keep=None, stats=None,
-                  edge_keep=None, in_drop=None):
+                  edge_keep=None, in_drop=None, readout_drop=None):
     """DeepGNN.forward (models.py:169-204, one branch).  ``p``: state_dict tensors (any float dtype; cast to
     ``dtype`` here -- pass leaves of that dtype with requires_grad to get gradients).  ``relu_keep``: per layer, the
     z > 0 patterns of the run under test (one per Linear branch), see _act; ``stats`` collects the kink-unit count.
     Training-mode randomness is taken from the caller (the reference's torch RNG streams cannot be reproduced, the run
     under test hands over ITS draws): ``edge_keep`` -- 0/1 per CSR edge, the drop-edge mask applied before the
     normalisation (graph_utils.py:85-94: dropped positions are zeroed, the degree is the row sum of what is left);
-    ``in_drop`` -- per layer, the multiplier tensor of its input nn.Dropout (keep / (1 - p), layers.py:430,471,601) or None."""
+    ``in_drop`` -- per layer, the multiplier tensor of its input nn.Dropout (keep / (1 - p), layers.py:430,471,601) or None;
+    ``readout_drop`` -- the same for the read-out MLP's input dropout (layers.py:110; residue / pooling read-outs only)."""
     kind, L, heads, act = arch["aggr"], arch["num_layers"], int(arch.get("heads", 1)), arch["act"]
     p = {k: (v if v.dtype == dtype else v.to(dtype)) for k, v in p.items()}
     x = X.to(dtype)
@@ -141,4 +142,4 @@ def model_forward(p, arch, X, indptr, indices, sizes, target, hop1hot=None, dtyp
         else:
             x = gat_forward(lp, x, A, act, heads)
         feats.append(x)
-    return lo.readout_and_classify(p, arch, feats, sizes, target)
+    return lo.readout_and_classify(p, arch, feats, sizes, target, readout_drop=readout_drop)

@@ -13,7 +13,8 @@ hs = HipSampler(indptr, indices, device=dev, seed=3)
 roots = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy().astype(np.uint32)
 hs.shuffle_targets(roots)
 hs.set_profiling(True)
-cfg = SamplerConfig(method="khop", depth=2, budget=20)
+cfg = SamplerConfig(method="khop", depth=int(os.environ.get("DEPTH", "2")), budget=int(os.environ.get("BUDGET", "20")),
+                    add_self_edge=os.environ.get("SELF", "0") == "1")
 Bs = [int(a) for a in sys.argv[1:]] or [256, 512, 768, 1024, 1536, 2048, 4096, 8192]
 for B in Bs:
     ms, nn, slots = [], 0, 0

@@ -1162,14 +1162,16 @@ BACKWARD_LEVELS_FRAC = 0.25
 
 class _SelectRoots(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f, rows, link):
+    def forward(ctx, f, rows, link, grad_on=True):
         ctx.link, ctx.n, ctx.F = link, int(f.shape[0]), int(f.shape[1])
         ctx.save_for_backward(rows)
         ctx.set_materialize_grads(False)
         # the row sets of the row-sparse top-layer backward: handed over with the rows (built by the minibatch extractor on its
         # prefetch stream) or, for hand-made batches, built here (two host syncs)
         ctx.plan = ctx.levels = None
-        want = SPARSE_TOP_BWD and torch.is_grad_enabled() and f.requires_grad     # (evaluation: no backward pass will ask for the row sets)
+        # (autograd is switched off INSIDE a Function's forward: the caller's grad mode comes in as an argument.  Evaluation /
+        #  a frozen producer: no backward pass will ask for the row sets -- no plan, no host syncs)
+        want = bool(SPARSE_TOP_BWD and grad_on and ctx.needs_input_grad[0])
         if want and link is not None and link.published and ctx.n >= SPARSE_TOP_BWD_MIN_ROWS and link.csr is not None and link.want_levels:
             lv = getattr(rows, "_shd_bwd_levels", None)
             if lv is None:
@@ -1197,10 +1199,10 @@ class _SelectRoots(torch.autograd.Function):
             link.levels = list(ctx.levels) if ctx.levels else None
             link.dummy = placeholder(ctx.n, ctx.F, dsel.device)
             link.filled = True
-            return link.dummy, None, None
+            return link.dummy, None, None, None
         dense = torch.zeros(ctx.n, ctx.F, dtype=dsel.dtype, device=dsel.device)
         dense.index_add_(0, rows, dsel)
-        return dense, None, None
+        return dense, None, None, None
 
 
 def select_roots(f: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
@@ -1210,7 +1212,7 @@ def select_roots(f: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
     link = getattr(f, "_shadow_roots", None)
     if link is None or not link.published or not ROOTS_SPARSE_GRAD:
         return f[rows]
-    return _SelectRoots.apply(f, rows, link)
+    return _SelectRoots.apply(f, rows, link, torch.is_grad_enabled())
 
 
 class _SageDense(torch.autograd.Function):
@@ -1644,7 +1646,7 @@ class _SageStack(torch.autograd.Function):
     calls = 0
 
     @staticmethod
-    def forward(ctx, X0, adj, rows, meta, *params):
+    def forward(ctx, X0, adj, rows, meta, grad_on, *params):
         lib = _lib.load()
         L = len(meta)
         n, F0 = X0.shape
@@ -1653,7 +1655,7 @@ class _SageStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
-        keep_all = torch.is_grad_enabled() and any(ctx.needs_input_grad)   # (no backward pass will come -- no_grad keeps needs_input_grad True for live parameters --: nothing is kept: one Zs / Zn / A X slot, two `out` slots in turn)
+        keep_all = bool(grad_on) and any(ctx.needs_input_grad)   # (no backward pass will come -- no_grad keeps needs_input_grad True for live parameters --: nothing is kept: one Zs / Zn / A X slot, two `out` slots in turn)
         # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
         big = torch.empty(4 * L - 1, n, F, **f32) if keep_all else torch.empty(5 if L > 1 else 3, n, F, **f32)
         slot_z = (lambda l: 3 * l) if keep_all else (lambda l: 0)
@@ -1760,10 +1762,10 @@ class _SageStack(torch.autograd.Function):
         ng = ctx.needs_input_grad
         for l in range(L):
             hb_s, hb_n = ctx.has[6 * l + 1], ctx.has[6 * l + 3]
-            k = 4 + 6 * l
+            k = 5 + 6 * l
             grads += [Wg[2 * l] if ng[k] else None, bg[2 * l] if (hb_s and ng[k + 1]) else None, Wg[2 * l + 1] if ng[k + 2] else None,
                       bg[2 * l + 1] if (hb_n and ng[k + 3]) else None, sg[2 * l] if ng[k + 4] else None, sg[2 * l + 1] if ng[k + 5] else None]
-        return (dX0, None, None, None, *grads)
+        return (dX0, None, None, None, None, *grads)
 
 
 def sage_stack_usable(mods) -> bool:
@@ -1805,7 +1807,7 @@ def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tens
     for md in mods:
         drop = _drop_arg(md._out_p(), F)
         meta.append((ACT_CODE[md.act_name], float(drop[0]), int(drop[1])))
-    return _SageStack.apply(X0, adj, rows, tuple(meta), *params)
+    return _SageStack.apply(X0, adj, rows, tuple(meta), torch.is_grad_enabled(), *params)
 
 
 class _GcnStack(torch.autograd.Function):
@@ -1816,7 +1818,7 @@ class _GcnStack(torch.autograd.Function):
     calls = 0
 
     @staticmethod
-    def forward(ctx, X0, adj, rows, meta, *params):
+    def forward(ctx, X0, adj, rows, meta, grad_on, *params):
         lib = _lib.load()
         L = len(meta)
         n, F0 = X0.shape
@@ -1825,7 +1827,7 @@ class _GcnStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
-        keep_all = torch.is_grad_enabled() and any(ctx.needs_input_grad)   # (no backward pass will come: one Z / A X slot, two `out` slots in turn)
+        keep_all = bool(grad_on) and any(ctx.needs_input_grad)   # (no backward pass will come: one Z / A X slot, two `out` slots in turn)
         big = torch.empty(3 * L - 1, n, F, **f32) if keep_all else torch.empty(4 if L > 1 else 2, n, F, **f32)   # per layer Z, out; then A X of the layers 1 .. L - 1
         slot_z = (lambda l: 2 * l) if keep_all else (lambda l: 0)
         slot_out = (lambda l: 2 * l + 1) if keep_all else (lambda l: 1 + (l & 1) if L > 1 else 1)
@@ -1906,11 +1908,11 @@ class _GcnStack(torch.autograd.Function):
         ng = ctx.needs_input_grad
         grads = []
         for l in range(L):
-            k = 4 + 4 * l
+            k = 5 + 4 * l
             grads += [Wg[l] if ng[k] else None, sg[3 * l + 2] if (ctx.has[4 * l + 1] and ng[k + 1]) else None,
                       sg[3 * l].view(params[4 * l + 2].shape) if ng[k + 2] else None,
                       sg[3 * l + 1].view(params[4 * l + 3].shape) if ng[k + 3] else None]
-        return (dX0, None, None, None, *grads)
+        return (dX0, None, None, None, None, *grads)
 
 
 def gcn_stack_usable(mods) -> bool:
@@ -1949,7 +1951,7 @@ def gcn_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tenso
     for md in mods:
         drop = _drop_arg(md._out_p(), F)
         meta.append((ACT_CODE[md.act_name], float(drop[0]), int(drop[1])))
-    return _GcnStack.apply(X0, adj, rows, tuple(meta), *params)
+    return _GcnStack.apply(X0, adj, rows, tuple(meta), torch.is_grad_enabled(), *params)
 
 
 # The head of a node-classification step (L2 normalisation of the root embeddings, the one-layer classifier, softmax cross

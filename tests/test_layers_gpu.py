@@ -1785,6 +1785,11 @@ def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act,
         return m
     monkeypatch.setattr(ops, "new_dropout_seed", logged_seed)
     monkeypatch.setattr(ops, "dropedge_mask", logged_mask)
+    # (the read-out MLP's own nn.Dropout on the [B, 2 F] pooled features draws from torch's generator: captured as a multiplier)
+    ro_drop = []
+    hook = model.res_pool_layers[0].nn[0].register_forward_hook(
+        lambda _m, inp, out: ro_drop.append(torch.where(out != 0, torch.full_like(out, 1.0 / (1.0 - p_drop)), torch.zeros_like(out)).cpu().double()
+                                            if p_drop > 0 else None))
     c0 = (ops._SageDense.fused_calls, ops._SageDense.chained_calls, ops._PoolAndRoots.calls)
     timer = ops.KernelTimer()
     ops.Z_TAP = []
@@ -1795,7 +1800,9 @@ def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act,
         tap = ops.Z_TAP
     finally:
         ops.Z_TAP = None
+        hook.remove()
     ran = set(timer.summary())
+    assert len(ro_drop) == 1
     # ---- the call path of the timed configs[2] line
     assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (L, 0), "one-call entries, nothing chained"
     assert ops._PoolAndRoots.calls - c0[2] == L, "every layer output goes through ops.pool_and_roots"
@@ -1822,7 +1829,7 @@ def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act,
         relu_keep = [[((z + (bb if bb is not None else 0)) > 0).cpu() for z, bb in zip(zs, bs_)] for zs, bs_ in tap[:L]]
     p = {k: v.double().requires_grad_(True) for k, v in p0.items()}
     preds_ref, emb_ref = mos.model_forward(p, arch, X, h["indptr"], h["indices"], sizes, h["target"], relu_keep=relu_keep, stats=kstats,
-                                           edge_keep=ek, in_drop=in_drop)
+                                           edge_keep=ek, in_drop=in_drop, readout_drop=ro_drop[0])
     if relu_keep is not None:
         assert kstats["kink_units"] <= 1e-5 * kstats["units"] and kstats.get("kink_max_abs_z", 0.0) < 5e-3, kstats
     loss_ref = lo.model_loss(preds_ref, labels.numpy())
