@@ -796,6 +796,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
   const size_t o_col = carve(Pz * (size_t)cape * 4), o_eid = carve(Pz * (size_t)cape * 4);
   const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
   const size_t o_info = carve(Pz * capn * sizeof(RowInfo)), o_rowq = carve(Pz * ((size_t)capn + 1) * 4);
+  const size_t o_selfpos = carve(cfg->add_self_edge ? Pz * capn * 4 : 16);
   const size_t o_lcol = carve((cfg->aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) ? Pz * (size_t)cape * 4 : 16);
   const uint32_t kScanGridMax = 8u * 256u;
   const uint32_t rec_blocks = (2u * kScanGridMax + (uint32_t)Pz / 4u) * s->rec_scale;
@@ -831,7 +832,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
     p.s_row = (uint32_t *)(sc + o_row); p.s_col = (uint32_t *)(sc + o_col);
     p.s_eid = (uint32_t *)(sc + o_eid); p.s_tgt = (uint32_t *)(sc + o_tgt);
     p.s_cnt = (uint32_t *)(sc + o_cnt);
-    p.s_rowinfo = (RowInfo *)(sc + o_info); p.s_rowq = (uint32_t *)(sc + o_rowq);
+    p.s_rowinfo = (RowInfo *)(sc + o_info); p.s_rowq = (uint32_t *)(sc + o_rowq); p.s_selfpos = (uint32_t *)(sc + o_selfpos);
     p.cstart = (uint32_t *)(sc + o_cstart); p.plan = (uint32_t *)(sc + o_plan);
     p.recs = (RoundRec *)(sc + o_recs); p.blkinfo = (uint2 *)(sc + o_blkinfo); p.rec_blocks = rec_blocks;
     s->last_cnt = p.s_cnt; s->last_plan = p.plan;
@@ -890,8 +891,10 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       if (T != 256 && T != 512 && T != 1024) T = 512;
       const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
       // SHADOW_SG_SCAN_IMPL=window: the general (row-window) kernel for plain calls too (A/B measurements, tests)
+      // (round 5: the flat kernel also takes calls WITH self-edge insertion -- the rows' insertion slots come from the
+      //  selection kernel; compat over-read and the root<->root exclusion stay with the row-window kernel)
       const char *impl_env = getenv("SHADOW_SG_SCAN_IMPL");
-      const bool flat = plain && !(impl_env && !strcmp(impl_env, "window"));
+      const bool flat = !p.compat && (p.include_target_conn || R == 1) && !(impl_env && !strcmp(impl_env, "window"));
       // candidate list: about one id in a hundred of a round.  The flat kernel trades 512 entries for a longer run list --
       // whole subgraphs then fit one round (scripts/sweep_capm.sh: 23 % fewer rounds, 0.205 -> 0.200 ms at 1 024 roots,
       // 1.105 -> 1.047 ms at 8 192); a round that overflows the list is redone on half the quads.

@@ -96,6 +96,7 @@ struct SampleParams {
   float *s_ppr;        // [P*cap_nodes_scr]
   RowInfo *s_rowinfo;  // [P*cap_nodes_scr]
   uint32_t *s_rowq;    // [P*(cap_nodes_scr+1)] quad prefix
+  uint32_t *s_selfpos; // [P*cap_nodes_scr] include_self: neighbours of the row below its own id = the slot the self edge is inserted at (.cpp:386-400); kEmpty: the row lists itself
   uint32_t *s_row;     // [P*cap_edges_scr] local row of each emitted edge
   uint32_t *s_col;     // [P*cap_edges_scr]
   uint32_t *s_eid;     // [P*cap_edges_scr]
@@ -453,6 +454,14 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
     const uint32_t v = nv, e0 = ne0, e1 = ne1;
     if (i + T < n) { nv = t.nodes[i + T]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
     uint32_t vs = 0, vq = 0;
+    if (i < n && p.include_self) {
+      // where the reference inserts the row's self edge (.cpp:386-400: lower_bound of the row's own id among its
+      // neighbours; nothing is inserted when the row already lists itself): the plain scan kernel files the edge from here
+      uint32_t lo = 0, hi = e1 - e0;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p.indices[e0 + mid] < v) lo = mid + 1; else hi = mid; }
+      const bool has = lo < e1 - e0 && p.indices[e0 + lo] == v;
+      p.s_selfpos[(size_t)s * p.cap_nodes_scr + i] = has ? kEmpty : lo;
+    }
     if (i < n) {
       g_nodes[i] = v;
       if (p.method == SG_METHOD_PPR) {

@@ -298,9 +298,40 @@ __device__ __forceinline__ void process_group(const ScanCtx &x, const ScanLds &t
 // only and the key is derived here.
 // ---------------------------------------------------------------------------------------------------------------
 #define SCAN_T(k) do { if (threadIdx.x == 0) { const uint64_t now_ = clock64(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+// Exact membership of id `cc` in the subgraph's sorted node list: its sub id, or n when absent.  stride == 1: the whole list
+// sits in LDS.  stride > 1 (node sets beyond the LDS copy: depth-3 k-hop): LDS holds every stride-th id -- the search runs
+// there and ends with ONE global round trip over the <= stride ids of the block it lands in (all loads issued together)
+// instead of log2(n) dependent ones.
+__device__ __forceinline__ uint32_t node_lookup(const uint32_t *lds_nodes, const uint32_t *g_nodes, uint32_t n, uint32_t stride, uint32_t cc) {
+  if (stride == 1u) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lds_nodes[mid] < cc) lo = mid + 1; else hi = mid; }
+    return (lo < n && lds_nodes[lo] == cc) ? lo : n;
+  }
+  const uint32_t ms = (n + stride - 1u) / stride;
+  uint32_t lo = 0, hi = ms;                                // number of samples <= cc
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lds_nodes[mid] <= cc) lo = mid + 1; else hi = mid; }
+  if (lo == 0) return n;
+  const uint32_t j0 = (lo - 1u) * stride, j1 = min(n, j0 + stride);
+  if (stride <= 16u) {
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = (j0 + (uint32_t)k < j1) ? g_nodes[j0 + k] : kEmpty;
+    uint32_t below = 0, hit = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { below += v[k] < cc ? 1u : 0u; hit |= v[k] == cc ? 1u : 0u; }
+    return hit ? j0 + below : n;
+  }
+  uint32_t a = j0, b = j1;
+  while (a < b) { const uint32_t mid = (a + b) >> 1; if (g_nodes[mid] < cc) a = mid + 1; else b = mid; }
+  return (a < j1 && g_nodes[a] == cc) ? a : n;
+}
+
+constexpr uint32_t kSelfEntry = 0x80000000u;     // plain scan: list entry = inserted self edge (row word), lval = position of its slot
+
 template <bool kFromPos>
 __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLds &t, uint32_t *ctrl, uint32_t m, uint32_t n,
-                                             bool nodes_in_lds, const uint32_t *g_nodes, const RowInfo *g_info,
+                                             uint32_t nstride, const uint32_t *g_nodes, const RowInfo *g_info,
                                              const uint32_t *roots, bool itc, uint32_t *res, uint32_t *g_row, uint32_t *g_col,
                                              uint32_t *g_eid, uint32_t s, uint32_t &rec_blk, uint32_t &rec_cnt, uint32_t *tacc,
                                              uint64_t &tlast) {
@@ -326,10 +357,16 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
       key[e] = 0; riw[e] = make_uint4(0u, 0u, 0u, 0u);
       if (ok[e]) {
         key[e] = kFromPos ? 1u : t.lkn[idx[e]].x;
-        if (key[e] & 1u) {
+        if (kFromPos) {
+          // (position, row) entries: neighbours, or -- kSelfEntry in the row word -- the slot of an inserted self edge
+          const uint32_t rwf = t.lrow[idx[e]];
+          pos[e] = t.lval[idx[e]];
+          if (rwf & kSelfEntry) { key[e] = 0u; t.lrow[idx[e]] = rwf & ~kSelfEntry; }
+          else c[e] = p.indices[pos[e]];
+          riw[e] = *reinterpret_cast<const uint4 *>(g_info + (rwf & ~kSelfEntry));
+        } else if (key[e] & 1u) {
           pos[e] = t.lval[idx[e]];
           c[e] = p.indices[pos[e]];
-          if (kFromPos) riw[e] = *reinterpret_cast<const uint4 *>(g_info + t.lrow[idx[e]]);
         }
       }
     }
@@ -340,17 +377,12 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
       uint32_t k = key[e];
       if (k & 1u) {
         const uint32_t cc = c[e];
-        uint32_t lo = 0, hi = n;
-        if (nodes_in_lds) {
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < cc) lo = mid + 1; else hi = mid; }
-        } else {
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g_nodes[mid] < cc) lo = mid + 1; else hi = mid; }
-        }
-        bool keep = lo < n && (nodes_in_lds ? t.nodes[lo] : g_nodes[lo]) == cc;
+        const uint32_t lo = node_lookup(t.nodes, g_nodes, n, nstride, cc);
+        bool keep = lo < n;
         if (keep && !itc && is_root(roots, R, cc)) {
           // multi-root subgraph without include_target_conn: drop root<->root edges (.cpp:414-418)
           const uint32_t rr = t.lrow[i];
-          keep = !is_root(roots, R, nodes_in_lds ? t.nodes[rr] : g_nodes[rr]);
+          keep = !is_root(roots, R, g_nodes[rr]);
         }
         if (keep && kFromPos) {
           // the scan noted (position, row) only: key = 2 * slot + 1, slot = the row's slot prefix + offset in the row
@@ -360,6 +392,10 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
         if (keep) t.lval[i] = lo;
         else { k = kEmpty; t.lkn[i].x = kEmpty; }
       } else {
+        if (kFromPos) {                               // (plain scan: the self edge's key from the position of its slot)
+          k = 2u * (riw[e].z + (pos[e] - riw[e].x));
+          t.lkn[i].x = k;
+        }
         t.lval[i] = t.lrow[i];                        // self edge: column = the row itself
       }
       kmin_l = min(kmin_l, k);                        // (kEmpty is the largest value)
@@ -510,18 +546,20 @@ __global__ void sg_scan_kernel(SampleParams p) {
     uint32_t *g_row = p.s_row + (size_t)s * cape;
     uint32_t *g_col = p.s_col + (size_t)s * cape;
     uint32_t *g_eid = p.s_eid + (size_t)s * cape;
-    const bool nodes_in_lds = n <= p.nodes_lds;
+    // (node sets beyond the LDS copy: every nstride-th id is kept -- node_lookup)
+    const uint32_t nstride = n <= p.nodes_lds ? 1u : (n + p.nodes_lds - 1u) / p.nodes_lds;
     const uint32_t iq0 = min(Q, lc0 * kQChunk);
     const uint32_t iq1 = min(Q, lc1 * kQChunk);
 
-    // ---- per segment: the subgraph's membership filter (+ its sorted node list when it fits)
+    // ---- per segment: the subgraph's membership filter (+ its sorted node list, or a sample of it)
     __syncthreads();                                       // (the previous segment's last readers are done)
     for (uint32_t w = tid; w < p.bit_words; w += T) t.bits[w] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
       const uint32_t v = g_nodes[i];
       atomicOr(&t.bits[(v >> 5) & bw_mask], 1u << (v & 31u));
-      if (nodes_in_lds) t.nodes[i] = v;
+      if (nstride == 1u) t.nodes[i] = v;
+      else if (i % nstride == 0u) t.nodes[i / nstride] = v;
     }
     // (the first barrier of the round loop orders these writes before the scan)
 
@@ -740,7 +778,7 @@ __global__ void sg_scan_kernel(SampleParams p) {
         __syncthreads();
         continue;
       }
-      finish_round<false>(p, t, ctrl, m, n, nodes_in_lds, g_nodes, g_info, roots, itc, res, g_row, g_col, g_eid, s, rec_blk, rec_cnt,
+      finish_round<false>(p, t, ctrl, m, n, nstride, g_nodes, g_info, roots, itc, res, g_row, g_col, g_eid, s, rec_blk, rec_cnt,
                           tacc, tlast);
       rq0 = rq1;
       __syncthreads();
@@ -773,7 +811,7 @@ __global__ void sg_scan_kernel(SampleParams p) {
 // Measured against the row-window kernel above on the same box (scripts/ab_scan.sh, products shape): 0.193 vs 0.257 ms
 // at 1 024 roots, 0.995 vs 1.135 ms at 8 192; arxiv shape (rows of ~3 quads) 0.100 vs 0.143 ms at 256 roots.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int C_NRUN = C_NNODES, C_NHUB = C_NF0;
+constexpr int C_NRUN = C_NNODES, C_NHUB = C_NF0, C_ROWSTOP = 12 /* and 13: one word per pass parity */, C_ROWNEXT = 14;
 constexpr uint32_t kHubRuns = 8;             // rows with at least this many runs in the round are expanded by a wavefront
 constexpr int kDepth = 8;                    // 1-KiB loads a wavefront keeps in flight
 
@@ -809,6 +847,7 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
   const uint32_t bw_mask = p.bit_words - 1u, bm4 = bw_mask << 2;
   const uint32_t capm = p.capm, cape = p.cap_edges_scr, run_cap = p.run_cap;
   const int R = p.R;
+  const bool incl_self = p.include_self != 0;              // (the rows' insertion slots come from the selection kernel: s_selfpos)
   const uint32_t C = p.plan[PL_NCHUNKS], cpw = p.plan[PL_CPW];
 
   uint32_t tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -835,23 +874,26 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
     uint32_t *g_row = p.s_row + (size_t)s * cape;
     uint32_t *g_col = p.s_col + (size_t)s * cape;
     uint32_t *g_eid = p.s_eid + (size_t)s * cape;
-    const bool nodes_in_lds = n <= p.nodes_lds;
+    const uint32_t nstride = n <= p.nodes_lds ? 1u : (n + p.nodes_lds - 1u) / p.nodes_lds;
     const uint32_t iq0 = min(Q, lc0 * kQChunk);
     const uint32_t iq1 = min(Q, lc1 * kQChunk);
+    const uint32_t *g_selfpos = p.s_selfpos + (size_t)s * p.cap_nodes_scr;
 
-    // ---- per segment: the subgraph's membership filter (+ its sorted node list when it fits)
+    // ---- per segment: the subgraph's membership filter (+ its sorted node list, or a sample of it)
     __syncthreads();
     for (uint32_t w = tid; w < p.bit_words; w += T) t.bits[w] = 0;
     __syncthreads();
-    // (the row data phase A needs for this thread's first row rides on the same round trip as the node ids)
-    uint32_t pre_qs = 0, pre_qe = 0;
-    uint4 pre_ri = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < n) { pre_qs = g_rowq[tid]; pre_qe = g_rowq[tid + 1]; pre_ri = *reinterpret_cast<const uint4 *>(g_info + tid); }
     for (uint32_t i = tid; i < n; i += T) {
       const uint32_t v = g_nodes[i];
       atomicOr(&t.bits[(v >> 5) & bw_mask], 1u << (v & 31u));
-      if (nodes_in_lds) t.nodes[i] = v;
+      if (nstride == 1u) t.nodes[i] = v;
+      else if (i % nstride == 0u) t.nodes[i / nstride] = v;
     }
+    // The rows are ordered by quad position: a round only looks at the rows from the one that holds its first quad on, in
+    // passes of T rows, until a row starts behind its end (a depth-3 subgraph has 4 600 rows and ~20 rounds per segment:
+    // walking all rows every round was half the kernel's time).  row_lo: found by search once per segment, then carried
+    // from round to round.
+    uint32_t row_lo = (iq0 == 0u || iq0 >= Q) ? (iq0 == 0u ? 0u : n) : find_span(g_rowq, n, iq0);
 
     // runs of a round <= quads / 64 + rows with >= kLongRow quads: start with a round that fits for sure
     uint32_t rq0 = iq0;
@@ -860,22 +902,48 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
       const uint32_t rq1 = min(iq1, rq0 + rquads);
       tacc[6]++;
       SCAN_T(0);
-      if (tid == 0) { ctrl[C_M] = 0; ctrl[C_NHUB] = 0; }
+      if (tid == 0) { ctrl[C_M] = 0; ctrl[C_NHUB] = 0; ctrl[C_ROWSTOP] = 0; ctrl[C_ROWSTOP + 1] = 0; ctrl[C_ROWNEXT] = row_lo; }
       __syncthreads();
-      // ---- A. the round's run list
+      // ---- A. the round's run list (+ the inserted self edges whose slot lies in the round, ParallelSampler.cpp:386-400)
       uint32_t nrun = 0;
-      for (uint32_t base = 0; base < n; base += T) {
+      uint32_t pass = 0;
+      for (uint32_t base = row_lo; base < n; base += T, pass ^= 1u) {
         const uint32_t r = base + tid;
-        uint32_t nr = 0, len = 0, k0 = 0, nq = 0;
+        uint32_t nr = 0, len = 0, k0 = 0, nq = 0, qs = 0xFFFFFFFFu;
         RowInfo ri;
         ri.e0 = ri.deg = ri.rs = ri.v = 0;
         if (r < n) {
-          uint32_t qs = pre_qs, qe = pre_qe;
-          uint4 riw = pre_ri;
-          if (base != 0) { qs = g_rowq[r]; qe = g_rowq[r + 1]; riw = *reinterpret_cast<const uint4 *>(g_info + r); }
+          qs = g_rowq[r];
+          const uint32_t qe = g_rowq[r + 1];
+          const uint4 riw = *reinterpret_cast<const uint4 *>(g_info + r);
+          const uint32_t sp = incl_self ? g_selfpos[r] : kEmpty;
           ri.e0 = riw.x; ri.deg = riw.y; ri.rs = riw.z; ri.v = riw.w;
           const uint32_t lo = max(qs, rq0), hi = min(qe, rq1);
-          if (hi > lo) { len = hi - lo; k0 = lo - qs; nq = qe - qs; nr = (len + 63u) >> 6; }
+          nq = qe - qs;
+          if (hi > lo) { len = hi - lo; k0 = lo - qs; nr = (len + 63u) >> 6; }
+          if (sp != kEmpty) {
+            // the self edge sits in front of neighbour `sp` (behind the last one: sp == deg) and belongs to the round that
+            // streams that neighbour's quad; a row without neighbours hands it to the round whose range ends at or behind
+            // its (empty) position -- the very first round of the subgraph for position 0 (as sg_scan_kernel files them)
+            bool mine;
+            if (nq == 0u) mine = (qs > rq0 && qs <= rq1) || (qs == 0u && rq0 == 0u && lc0 == 0u);
+            else {
+              const uint32_t aq = qs + (sp < ri.deg ? ((ri.e0 + sp) >> 2) - (ri.e0 >> 2) : nq - 1u);
+              mine = aq >= rq0 && aq < rq1;
+            }
+            if (mine) {
+              const uint32_t idx = atomicAdd(&ctrl[C_M], 1u);
+              if (idx < capm) { t.lval[idx] = ri.e0 + sp; t.lrow[idx] = r | kSelfEntry; }
+            }
+          }
+        }
+        // (rows ascend: the last lane of a wavefront whose row starts in front of the round's end is the wavefront's largest)
+        {
+          const uint64_t before = __ballot(r < n && qs < rq1);
+          if (before && lane == 63u - (uint32_t)__builtin_clzll((unsigned long long)before)) atomicMax(&ctrl[C_ROWNEXT], r);
+          // (one stop word per pass parity: a wavefront that is already in the next pass must not change what a slower one
+          //  still has to read -- the scan's barriers keep everybody within one pass of each other)
+          if (__ballot(r >= n || qs > rq1) && lane == 0) ctrl[C_ROWSTOP + pass] = 1u;
         }
         uint32_t tot;
         const uint32_t first = nrun + block_excl_scan(nr, t.bhead, &tot);
@@ -888,8 +956,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
             for (uint32_t g0 = 0, i = first; g0 < len; g0 += 64u, i++) runs[i] = make_run(ri, r, nq, k0, len, g0);
           }
         }
+        if (ctrl[C_ROWSTOP + pass]) break;                // (written before the scan's barriers, uniform behind them)
       }
       __syncthreads();
+      const uint32_t row_next = ctrl[C_ROWNEXT];
       if (nrun > run_cap) {
         // too many rows start in the round: halve it (a run holds at least one quad, so 64 quads always fit: the host
         // keeps run_cap >= 128)
@@ -982,9 +1052,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
         __syncthreads();
         continue;
       }
-      finish_round<true>(p, t, ctrl, m, n, nodes_in_lds, g_nodes, g_info, roots, true, res, g_row, g_col, g_eid, s, rec_blk, rec_cnt,
+      finish_round<true>(p, t, ctrl, m, n, nstride, g_nodes, g_info, roots, true, res, g_row, g_col, g_eid, s, rec_blk, rec_cnt,
                          tacc, tlast);
       rq0 = rq1;
+      row_lo = row_next;                                // (the last row that starts in front of the round's end may reach into the next)
       __syncthreads();
       SCAN_T(4);
       if (rq0 >= iq1) break;

@@ -411,8 +411,8 @@ def test_full_size_shapes_match_oracle(shape, batch, depth, self_e):
     {"SHADOW_SG_SCAN_IMPL": "window", "SHADOW_SG_SEG_PAD": "1"},
 ])
 def test_plain_scan_kernels_and_geometries_match_oracle(env, monkeypatch):
-    """The two scan kernels a plain call (no self edges, single root) can take -- the flat run list and the row
-    windows -- under several launch geometries (run-list / candidate-list capacities that force extra rounds, span
+    """The two scan kernels a single-root call without the compat over-read can take -- the flat run list and the row
+    windows -- with and without self-edge insertion, under several launch geometries (run-list / candidate-list capacities that force extra rounds, span
     padding on and off, 4-wavefront workgroups with a small filter): hub rows spanning many chunks, rows of one quad,
     full 2-hop neighbourhoods beyond the LDS node tables.  Every integer field equals the oracle's."""
     from oracle import sampler_oracle as so
@@ -425,12 +425,14 @@ def test_plain_scan_kernels_and_geometries_match_oracle(env, monkeypatch):
     rng = np.random.default_rng(5)
     roots = np.concatenate([np.argsort(-deg)[:4], np.argsort(deg)[:6], rng.permutation(30000)[:90]]).astype(np.uint32)
     hs = _make(indptr, indices, seed=11)
-    for depth, budget in ((2, 20), (2, -1), (1, -1)):
-        cfg = SamplerConfig(method="khop", depth=depth, budget=budget, add_self_edge=False, aug=("hops",))
+    # (round 5: the flat kernel also files the reference's inserted self edges -- slots found by the selection kernel; under
+    #  "window" the same calls run on the row-window kernel)
+    for depth, budget, self_e in ((2, 20, False), (2, -1, False), (1, -1, False), (2, 20, True), (2, -1, True), (3, 6, True)):
+        cfg = SamplerConfig(method="khop", depth=depth, budget=budget, add_self_edge=self_e, aug=("hops",))
         b = hs.sample(cfg, roots=roots, serial_base=0)
-        ref = so.sample_batch(indptr, indices, roots, method="khop", depth=depth, budget=budget, add_self_edge=False,
+        ref = so.sample_batch(indptr, indices, roots, method="khop", depth=depth, budget=budget, add_self_edge=self_e,
                               aug=("hops",), seed=11, serial_base=0, num_threads=8)
-        _cmp_batch(ref, b, ("hops",), (env, depth, budget))
+        _cmp_batch(ref, b, ("hops",), (env, depth, budget, self_e))
 
 
 def test_seeded_fuzz_against_oracle():
