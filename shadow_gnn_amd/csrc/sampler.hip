@@ -796,7 +796,6 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
   const size_t o_col = carve(Pz * (size_t)cape * 4), o_eid = carve(Pz * (size_t)cape * 4);
   const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
   const size_t o_info = carve(Pz * capn * sizeof(RowInfo)), o_rowq = carve(Pz * ((size_t)capn + 1) * 4);
-  const size_t o_selfpos = carve(cfg->add_self_edge ? Pz * capn * 4 : 16);
   const size_t o_lcol = carve((cfg->aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) ? Pz * (size_t)cape * 4 : 16);
   const uint32_t kScanGridMax = 8u * 256u;
   const uint32_t rec_blocks = (2u * kScanGridMax + (uint32_t)Pz / 4u) * s->rec_scale;
@@ -832,7 +831,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
     p.s_row = (uint32_t *)(sc + o_row); p.s_col = (uint32_t *)(sc + o_col);
     p.s_eid = (uint32_t *)(sc + o_eid); p.s_tgt = (uint32_t *)(sc + o_tgt);
     p.s_cnt = (uint32_t *)(sc + o_cnt);
-    p.s_rowinfo = (RowInfo *)(sc + o_info); p.s_rowq = (uint32_t *)(sc + o_rowq); p.s_selfpos = (uint32_t *)(sc + o_selfpos);
+    p.s_rowinfo = (RowInfo *)(sc + o_info); p.s_rowq = (uint32_t *)(sc + o_rowq);
     p.cstart = (uint32_t *)(sc + o_cstart); p.plan = (uint32_t *)(sc + o_plan);
     p.recs = (RoundRec *)(sc + o_recs); p.blkinfo = (uint2 *)(sc + o_blkinfo); p.rec_blocks = rec_blocks;
     s->last_cnt = p.s_cnt; s->last_plan = p.plan;
@@ -877,7 +876,12 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       if ((rc = ensure(&s->d_big, &s->big_bytes, (size_t)nslots * stride * 4)) != SG_OK) return rc;
       q.g_tables = (uint32_t *)s->d_big; q.g_stride = stride;
       q.g_ticket = (uint32_t *)(s->d_counts + 8 * kMaxBatches) + 1;
-      hipLaunchKernelGGL(sg_select_big_kernel, dim3(nslots), dim3(Tb), 0, stream, q);
+      // room to sort a subgraph's ids in LDS (ids + the counting sort's scratch): up to ~18 k nodes
+      const size_t sort_bytes = ((size_t)2 * capn + 768) * 4;
+      q.capm = sort_bytes <= (size_t)150 * 1024 ? capn : 0u;           // (capm is a scan parameter: free in this launch)
+      const size_t big_lds = q.capm ? sort_bytes : 0;
+      if (big_lds > 48 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)sg_select_big_kernel, big_lds));
+      hipLaunchKernelGGL(sg_select_big_kernel, dim3(nslots), dim3(Tb), big_lds, stream, q);
       SHD_HIP(hipGetLastError());
     }
     // ---- 2. plan (chunk prefix, chunks per scan workgroup) + 3. scan: one equal span of the chunk sequence per workgroup
@@ -887,8 +891,10 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       p.bit_words = env_u32("SHADOW_SG_BITWORDS", big ? kBitWordsBig : kBitWords);
       if (p.bit_words & (p.bit_words - 1)) p.bit_words = big ? kBitWordsBig : kBitWords;
       p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
-      uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", 512);
-      if (T != 256 && T != 512 && T != 1024) T = 512;
+      // (node sets beyond the LDS tables: one workgroup per CU -- 16 wavefronts keep twice the loads in flight: 1.59 -> 1.33 ms
+      //  at 256 depth-3 roots)
+      uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", big ? 1024 : 512);
+      if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
       const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
       // SHADOW_SG_SCAN_IMPL=window: the general (row-window) kernel for plain calls too (A/B measurements, tests)
       // (round 5: the flat kernel also takes calls WITH self-edge insertion -- the rows' insertion slots come from the
@@ -899,18 +905,31 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       // whole subgraphs then fit one round (scripts/sweep_capm.sh: 23 % fewer rounds, 0.205 -> 0.200 ms at 1 024 roots,
       // 1.105 -> 1.047 ms at 8 192); a round that overflows the list is redone on half the quads.
       p.capm = std::min<uint32_t>(4096, std::max<uint32_t>(1024, env_u32("SHADOW_SG_CAPM", big ? 1024 : (flat ? 1536 : 2048))));
+      if (flat && big && !getenv("SHADOW_SG_BITWORDS") && !getenv("SHADOW_SG_CAPM")) {
+        // Node sets beyond the 2 048-node tables on the flat kernel (depth-3 k-hop: ~4 600 nodes, 590 chunks per subgraph): a
+        // round costs ~5 us of dependent round trips whatever it streams, so the LDS goes to LONG rounds -- 1 024 runs and as
+        // many candidates as fit -- and to the whole sorted node list (candidates then resolve without leaving the CU)
+        // instead of a 1 Mi-bit filter: 512 Ki bits hold a 4 600-node set at 0.9 % false positives (one more candidate
+        // per true one).  Measured at 256 depth-3 roots: 22.7 -> 8.1 rounds per segment, scan 1.18 -> 0.8 ms.
+        p.bit_words = capn <= 16384 ? 16384u : kBitWordsBig;
+        p.nodes_lds = (size_t)capn * 4 <= 36 * 1024 ? capn : 1024u;
+        const size_t fixed = scan_layout(p.bit_words, 0, p.nodes_lds, T / 64, 0u, 1024, p.include_self != 0).total + kHubCap * 32;
+        const size_t room = (size_t)160 * 1024 - 256 - 64;
+        if (fixed + 1024 * 16 <= room) p.capm = std::min<uint32_t>(4096, (uint32_t)((room - fixed) / 16) & ~63u);
+      }
       p.run_cap = 0;
       p.seg_pad = std::min<uint32_t>(256, env_u32("SHADOW_SG_SEG_PAD", 25) - 1);   // (env value = pad + 1: 1 means none; default 24, scripts/sweep_seg_pad.sh)
       if (flat) {
         // the run list takes what two workgroups per CU leave (one per CU when the filter alone is larger)
+        const size_t per_run = p.include_self ? 20 : 16;           // (run record + the row's id for self-edge insertion)
         const size_t base = scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, 0).total + kHubCap * 32;
         const size_t lim2 = (size_t)(160 * 1024) / 2 - 64;
-        const size_t lim = base + 128 * 16 <= lim2 ? lim2 : (size_t)160 * 1024 - 256;
-        if (base + 128 * 16 > lim) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", base);
-        p.run_cap = (uint32_t)std::min<size_t>(1024, (lim - base) / 16) & ~31u;
+        const size_t lim = base + 128 * per_run <= lim2 ? lim2 : (size_t)160 * 1024 - 256;
+        if (base + 128 * per_run > lim) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", base);
+        p.run_cap = (uint32_t)std::min<size_t>(1024, (lim - base) / per_run) & ~31u;
         p.run_cap = std::max<uint32_t>(128, std::min<uint32_t>(p.run_cap, env_u32("SHADOW_SG_RUNCAP", 1024)));   // (>= 128: see the kernel)
       }
-      const ScanLayout SL = flat ? scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, p.run_cap)
+      const ScanLayout SL = flat ? scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64, 0u, p.run_cap, p.include_self != 0)
                                   : scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);
       if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));
@@ -918,11 +937,12 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       p.scan_grid = std::min<uint32_t>((uint32_t)ncu * per_cu, kScanGridMax);
       hipLaunchKernelGGL(sg_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
       SHD_HIP(hipGetLastError());
-      const void *kfn = flat ? (const void *)sg_scan_plain_kernel
+      const void *kfn = flat ? (p.include_self ? (const void *)sg_scan_plain_kernel<true> : (const void *)sg_scan_plain_kernel<false>)
                              : plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
       if (SL.total > 64 * 1024)
         SHD_HIP(ensure_dynamic_lds(kfn, SL.total));
-      if (flat) hipLaunchKernelGGL(sg_scan_plain_kernel, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      if (flat && p.include_self) hipLaunchKernelGGL(sg_scan_plain_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      else if (flat) hipLaunchKernelGGL(sg_scan_plain_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       else if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       SHD_HIP(hipGetLastError());

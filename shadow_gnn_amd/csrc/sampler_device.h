@@ -96,7 +96,6 @@ struct SampleParams {
   float *s_ppr;        // [P*cap_nodes_scr]
   RowInfo *s_rowinfo;  // [P*cap_nodes_scr]
   uint32_t *s_rowq;    // [P*(cap_nodes_scr+1)] quad prefix
-  uint32_t *s_selfpos; // [P*cap_nodes_scr] include_self: neighbours of the row below its own id = the slot the self edge is inserted at (.cpp:386-400); kEmpty: the row lists itself
   uint32_t *s_row;     // [P*cap_edges_scr] local row of each emitted edge
   uint32_t *s_col;     // [P*cap_edges_scr]
   uint32_t *s_eid;     // [P*cap_edges_scr]
@@ -163,6 +162,78 @@ __device__ __forceinline__ uint32_t tab_insert(const Tables &t, uint32_t *ctrl, 
   return slot;
 }
 
+__device__ __forceinline__ bool overflowed(uint32_t *ctrl) {
+  return __hip_atomic_load(&ctrl[C_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+}
+
+// tab_insert with the first probe already made: `old0` = what atomicCAS(&hkey[base], kEmpty, key) returned
+__device__ __forceinline__ uint32_t tab_insert_rest(const Tables &t, uint32_t *ctrl, uint32_t key, uint32_t H, uint32_t capn,
+                                                    uint32_t base, uint32_t old0) {
+  uint32_t slot = base;
+  bool is_new = (old0 == kEmpty), done = (old0 == kEmpty || old0 == key);
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    if (!done) {
+      const uint32_t old = atomicCAS(&t.hkey[base + i], kEmpty, key);
+      if (old == kEmpty || old == key) { slot = base + i; is_new = (old == kEmpty); done = true; }
+    }
+  }
+  if (!done) {
+    for (uint32_t i = 0; i < kStash; i++) {
+      const uint32_t old = atomicCAS(&t.hkey[H + i], kEmpty, key);
+      if (old == kEmpty || old == key) {
+        slot = H + i; is_new = (old == kEmpty); done = true;
+        if (is_new) atomicMax(&ctrl[C_NSTASH], i + 1);
+        break;
+      }
+    }
+    if (!done) { atomicOr(&ctrl[C_OVF], 1u); return base; }
+  }
+  if (is_new) {
+    const uint32_t idx = atomicAdd(&ctrl[C_NNODES], 1u);
+    if (idx < capn) t.nodes[idx] = key;
+    else atomicOr(&ctrl[C_OVF], 1u);
+  }
+  return slot;
+}
+
+// touch() for the <= 4 draws of one work item: the first probes of all keys go out TOGETHER, and so do the level-mask
+// updates -- over global-memory tables every atomic is an L2 round trip, and four draws one after the other were
+// eight of them in a row.  Same table contents as four touch() calls (atomics on one address are ordered: a key drawn
+// twice finds itself).
+__device__ __forceinline__ void touch4(const Tables &t, uint32_t *ctrl, const uint32_t (&u)[4], uint32_t cnt, uint32_t H,
+                                       uint32_t hshift, uint32_t capn, uint32_t capf, bool last, uint32_t bit_next,
+                                       uint32_t *nxt, int nxt_cnt_idx) {
+  if (overflowed(ctrl)) return;
+  uint32_t base[4], old0[4], slot[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    base[d] = bucket_base(u[d], hshift);
+    old0[d] = kEmpty;
+    if ((uint32_t)d < cnt) old0[d] = atomicCAS(&t.hkey[base[d]], kEmpty, u[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    slot[d] = base[d];
+    if ((uint32_t)d < cnt) slot[d] = tab_insert_rest(t, ctrl, u[d], H, capn, base[d], old0[d]);
+  }
+  if (last) return;
+  uint32_t oldm[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    oldm[d] = bit_next;
+    if ((uint32_t)d < cnt) oldm[d] = atomicOr(&t.hval[slot[d]], bit_next);
+  }
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    if ((uint32_t)d < cnt && !(oldm[d] & bit_next)) {
+      const uint32_t idx = atomicAdd(&ctrl[nxt_cnt_idx], 1u);
+      if (idx < capf) nxt[idx] = u[d];
+      else atomicOr(&ctrl[C_OVF], 4u);
+    }
+  }
+}
+
 // slot of `key` or -1.  `nstash` = number of stash entries in use.
 __device__ __forceinline__ int32_t tab_find(const uint32_t *hkey, uint32_t key, uint32_t H,
                                             uint32_t hshift, uint32_t nstash) {
@@ -178,10 +249,6 @@ __device__ __forceinline__ int32_t tab_find(const uint32_t *hkey, uint32_t key, 
       if (hkey[H + i] == key) { r = (int32_t)(H + i); break; }
   }
   return r;
-}
-
-__device__ __forceinline__ bool overflowed(uint32_t *ctrl) {
-  return __hip_atomic_load(&ctrl[C_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
 
 // add `u` to the touched set and (unless this is the last level) to the next frontier
@@ -297,7 +364,7 @@ __device__ __forceinline__ bool is_root(const uint32_t *roots, int R, uint32_t v
 // ---------------------------------------------------------------------------
 template <bool kGlobalTables>
 __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t s, const Tables &t,
-                                                uint32_t *ctrl, uint32_t *wsum) {
+                                                uint32_t *ctrl, uint32_t *wsum, uint32_t *lds_sort = nullptr, uint32_t lds_sort_cap = 0) {
   const uint32_t tid = threadIdx.x, T = blockDim.x;
   const uint32_t lane = lane_id(), wave = wave_id(), nw = T >> 6;
   const uint32_t H = p.H, hshift = p.hshift;
@@ -363,6 +430,14 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
       const int cur_idx = (lvl & 1) ? C_NF1 : C_NF0, nxt_idx = (lvl & 1) ? C_NF0 : C_NF1;
       const uint32_t nf = min(ctrl[cur_idx], capf);
       __syncthreads();
+      // LDS tables, a budgeted level whose draws alone are twice the table's node capacity, and a global-table pass behind
+      // this kernel: hand the subgraph over right away instead of drawing until the table overflows (depth-3 k-hop: every
+      // subgraph of the call; the result is the big kernel's either way -- this only saves the doomed attempt)
+      if (!kGlobalTables && budget >= 0 && p.cap_nodes_scr > capn && (uint64_t)nf * (uint64_t)budget > 2ull * capn) {
+        if (tid == 0) atomicOr(&ctrl[C_OVF], 1u);
+        __syncthreads();
+        break;
+      }
       if (tid == 0) ctrl[nxt_idx] = 0;
       __syncthreads();
       const bool last = (lvl + 1 == depth);
@@ -394,9 +469,7 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
           uint32_t u4[4];
 #pragma unroll
           for (int d = 0; d < 4; d++) u4[d] = ((uint32_t)d < cnt4) ? p.indices[e0 + off[d]] : kEmpty;
-#pragma unroll
-          for (int d = 0; d < 4; d++)
-            if ((uint32_t)d < cnt4) touch(t, ctrl, u4[d], H, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
+          touch4(t, ctrl, u4, cnt4, H, hshift, capn, capf, last, bit_next, nxt, nxt_idx);
         }
       } else {
         // full expansion: one wavefront streams one frontier row (coalesced)
@@ -436,8 +509,17 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   // ---- phase 2: sort ids ascending (.cpp:362); the sorted position is the sub id (.cpp:369-372)
   const uint64_t tsel1 = clock64();
   // (hval -- the expansion's level masks -- is free from here on: scratch of the counting sort when it is large enough)
-  if (kGlobalTables || n < 64u || (uint64_t)n + 768u > (uint64_t)H + kStash || !block_sort_counting(t.nodes, n, t.hval, ctrl))
+  // (global tables: the ids are sorted in LDS when the kernel was given room for them -- the bitonic network over global
+  //  memory cost a depth-3 subgraph of 4 600 nodes as much as its whole expansion)
+  const uint32_t *sorted = t.nodes;
+  if (kGlobalTables && lds_sort && n <= lds_sort_cap) {
+    for (uint32_t i = tid; i < n; i += T) lds_sort[i] = t.nodes[i];
+    __syncthreads();
+    if (n < 64u || !block_sort_counting(lds_sort, n, lds_sort + lds_sort_cap, ctrl)) block_sort_u32(lds_sort, n);
+    sorted = lds_sort;
+  } else if (kGlobalTables || n < 64u || (uint64_t)n + 768u > (uint64_t)H + kStash || !block_sort_counting(t.nodes, n, t.hval, ctrl)) {
     block_sort_u32(t.nodes, n);
+  }
   const uint64_t tsel2 = clock64();
   uint32_t *g_nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
   float *g_ppr = p.s_ppr + (size_t)s * p.cap_nodes_scr;
@@ -448,20 +530,12 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   //      the two prefixes share their barriers.
   uint32_t carry_s = 0, carry_q = 0;
   uint32_t nv = 0, ne0 = 0, ne1 = 0;
-  if (tid < n) { nv = t.nodes[tid]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
+  if (tid < n) { nv = sorted[tid]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
   for (uint32_t base = 0; base < n; base += T) {
     const uint32_t i = base + tid;
     const uint32_t v = nv, e0 = ne0, e1 = ne1;
-    if (i + T < n) { nv = t.nodes[i + T]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
+    if (i + T < n) { nv = sorted[i + T]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
     uint32_t vs = 0, vq = 0;
-    if (i < n && p.include_self) {
-      // where the reference inserts the row's self edge (.cpp:386-400: lower_bound of the row's own id among its
-      // neighbours; nothing is inserted when the row already lists itself): the plain scan kernel files the edge from here
-      uint32_t lo = 0, hi = e1 - e0;
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (p.indices[e0 + mid] < v) lo = mid + 1; else hi = mid; }
-      const bool has = lo < e1 - e0 && p.indices[e0 + lo] == v;
-      p.s_selfpos[(size_t)s * p.cap_nodes_scr + i] = has ? kEmpty : lo;
-    }
     if (i < n) {
       g_nodes[i] = v;
       if (p.method == SG_METHOD_PPR) {
@@ -487,7 +561,7 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   if (tid < (uint32_t)R) {                                             // .cpp:373-377: sub id of the root(s)
     const uint32_t root = roots[tid];
     uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t.nodes[mid] < root) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] < root) lo = mid + 1; else hi = mid; }
     p.s_tgt[(size_t)s * kMaxRoots + tid] = lo;
   }
   if (tid == 0) {
@@ -550,7 +624,10 @@ __global__ void sg_select_lds_kernel(SampleParams p) {
 
 // Big path: persistent workgroups pull overflowed subgraphs (flag bit0 from the
 // LDS kernel) from a ticket counter and redo them over global-memory tables.
+// Dynamic LDS (optional): [2 * lds_sort_cap + 768] words -- the node ids are sorted there (p.capm carries lds_sort_cap for
+// this launch; 0 = no room: ids sorted in global memory).
 __global__ void sg_select_big_kernel(SampleParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
   __shared__ uint32_t ctrl[C_WORDS];
   __shared__ uint32_t wsum[32];
   __shared__ uint32_t s_next;
@@ -572,7 +649,7 @@ __global__ void sg_select_big_kernel(SampleParams p) {
     if (s >= p.P) return;
     const uint32_t flags = p.s_cnt[(size_t)s * R_WORDS + R_FLAGS];
     if (!(flags & 1u)) continue;
-    select_subgraph<true>(p, s, t, ctrl, wsum);
+    select_subgraph<true>(p, s, t, ctrl, wsum, p.capm ? reinterpret_cast<uint32_t *>(smem_big) : nullptr, p.capm);
   }
 }
 
