@@ -603,11 +603,6 @@ typedef struct {
   const float *stats;              /* [n, 4] row statistics its forward pass left (sl_sage_fwd d_row_stats), or NULL */
 } sl_sage_below;
 size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F);
-/* Auxiliary stream (of the calling thread; NULL = none, the default) on which sl_sage_bwd_chain launches its paired
- * weight-gradient kernel: dWs / dWn depend on [dZs | A^T dZn] and X only, so they may run beside the input-gradient product of
- * the same call.  The caller keeps d_X, d_buf, d_pack, d_tn_partial, d_x_amax, d_dWs, d_dWn alive for that stream and joins it
- * before reading the gradients.                                                                                          */
-int sl_set_aux_stream(void *stream);
 int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,
                       const float *d_Zn, uint32_t Fin, uint32_t Fout, const float *d_Ws, int64_t ldws, const float *d_bs,
                       const float *d_Wn, int64_t ldwn, const float *d_bn, const float *d_scale, const float *d_offset, int act,

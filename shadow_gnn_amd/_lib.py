@@ -158,7 +158,6 @@ SIGNATURES = {
                                _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P, _P]),
     "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
-    "sl_set_aux_stream": (C.c_int, [_P]),
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P, _P]),
@@ -238,7 +237,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 18      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 19      # sg_abi_version() of the library these signatures describe
 
 
 def load():

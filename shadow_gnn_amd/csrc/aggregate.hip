@@ -1387,12 +1387,11 @@ static int spmm_blockdiag_launch(const uint32_t *d_indptr, const uint32_t *d_ind
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / kBdBlock, (size_t)(160 * 1024) / (lds + 256)));
   // tiles a workgroup takes back to back (the structure is staged once per group): as many as keep enough groups per
   // resident workgroup for the ragged subgraph sizes to even out -- 4 for the k-hop batches (~280 rows per subgraph),
-  // 12 for small subgraphs such as PPR's (~150 rows, sizes 1 .. k) (scripts/sweep_spmm_tg.sh: products PPR batch
+  // 12 for small subgraphs such as PPR's (~150 rows, sizes 1 .. k) (round-2 sweep: products PPR batch
   // 0.175 ms at groups of 4, 0.153 at single tiles; k-hop batch 0.147 vs 0.180)
   uint32_t tg = tiles;
   const uint64_t want = ((uint64_t)n >= (uint64_t)224 * num_subg) ? 4 : 12;
-  if (const char *e = getenv("SHADOW_SPMM_TG")) { const int v = atoi(e); if (v >= 1) tg = std::min<uint32_t>(tiles, (uint32_t)v); }
-  else while (tg > 1 && (uint64_t)num_subg * ((tiles + tg - 1) / tg) < want * ncu * per_cu) tg = (tg + 1) / 2;
+  while (tg > 1 && (uint64_t)num_subg * ((tiles + tg - 1) / tg) < want * ncu * per_cu) tg = (tg + 1) / 2;
   const uint64_t total = (uint64_t)num_subg * ((tiles + tg - 1) / tg);
   if (total + 2 * (uint64_t)ncu * per_cu >= ((uint64_t)1 << 32))
     return set_error(SG_ERR_INVALID, "sl_spmm_blockdiag_f32: too many (subgraph, tile) items");

@@ -209,7 +209,7 @@ __global__ void row_amax_kernel(const float *__restrict__ A, int64_t lda, uint32
 template <int RB, int TW, int CS, int WAVES, bool kTail>     // kTail: K % 32 != 0 (the last unit is zero-padded)
 __global__ void __launch_bounds__(WAVES * 64, 2)
 gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__restrict__ Bimg, float *__restrict__ C,
-                     int64_t ldc, uint32_t M, uint32_t N, uint32_t K, uint32_t units, uint32_t a_wrap) {
+                     int64_t ldc, uint32_t M, uint32_t N, uint32_t K, uint32_t units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   constexpr int NT = TW * CS;                            // column tiles of the B image
   constexpr int kGemmThreads = WAVES * 64;
@@ -230,7 +230,6 @@ gemm_nt_split_kernel(const float *__restrict__ A, int64_t lda, const bf16x8 *__r
 #pragma unroll
   for (int rb = 0; rb < RB; rb++) {
     uint64_t row = min(m0 + 32u * rb + r, (uint64_t)M - 1);   // rows past the end repeat the last row (never stored)
-    if (a_wrap) row %= a_wrap;                                // (probe only, scripts/probe_gemm_alat.py: every workgroup reads the same few rows -- A from the L2)
     arow[rb] = A + row * lda + 16 * g;
   }
 
@@ -502,7 +501,6 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
   hipStream_t st = (hipStream_t)stream;
   const bf16x8 *img = reinterpret_cast<const bf16x8 *>(d_packed_B);
   const size_t lds = (size_t)3 * 3 * tiles * 64 * 16;
-  static const uint32_t a_wrap = [] { const char *e = getenv("SHADOW_GEMM_PROBE_A_WRAP"); return e ? (uint32_t)atoi(e) : 0u; }();
 #define SHD_GEMM(RB, TW, CS, WAVES)                                                                          \
   {                                                                                                          \
     const uint32_t rows_wg = 32u * RB * (WAVES / CS);                                                        \
@@ -513,10 +511,10 @@ extern "C" int sl_gemm_nt_f32(const float *d_A, int64_t lda, const void *d_packe
     }                                                                                                        \
     if (K % 32 == 0)                                                                                         \
       hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,  \
-                         lda, img, d_C, ldc, M, N, K, units, a_wrap);                                        \
+                         lda, img, d_C, ldc, M, N, K, units);                                        \
     else                                                                                                     \
       hipLaunchKernelGGL((gemm_nt_split_kernel<RB, TW, CS, WAVES, true>), dim3(grid), dim3(WAVES * 64), lds, st, d_A,   \
-                         lda, img, d_C, ldc, M, N, K, units, a_wrap);                                        \
+                         lda, img, d_C, ldc, M, N, K, units);                                        \
   }
   // (a column-split variant <1, 4, 2, 6> reaches 3 wavefronts per SIMD but measured slower: 0.35 vs 0.29 ms --
   //  A is loaded by both column groups and the vector-memory path is the scarce resource)
@@ -1210,8 +1208,9 @@ extern "C" uint32_t sl_gemm_tn_slices(uint32_t M) {
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  // at least 8 k-steps per workgroup (SHADOW_GEMM_TN_MIN_ROWS; 256 until round 3: M = 39.5 k, N = K = 256 then ran on 154 CUs)
-  static const uint32_t min_rows = [] { const char *e = getenv("SHADOW_GEMM_TN_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : 128u; }();
+  // at least 8 k-steps per workgroup (256 until round 3: M = 39.5 k, N = K = 256 then ran on 154 CUs; 128 / 256 / 512 measured 76 / 80 /
+  // 96 us per launch at 36 k rows)
+  const uint32_t min_rows = 128u;
   return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ncu, (M + min_rows - 1) / min_rows));
 }
 

@@ -718,10 +718,7 @@ int launch_fused(FusedDesc d, hipStream_t st) {
   return SG_OK;
 }
 
-bool g_fused_epilogue = [] {
-  const char *e = getenv("SHADOW_FUSED_EPILOGUE");
-  return !(e && e[0] == '0');
-}();
+bool g_fused_epilogue = true;      // (sl_set_fused_epilogue: the separate act + norm kernels instead, A/B and tests)
 
 }  // namespace
 
@@ -916,8 +913,7 @@ extern "C" int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d
   p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
   p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f;
   p.partial = d_partial; p.dz_amax = d_dz0_amax;
-  static const bool use_stats = !(getenv("SHADOW_FUSED_ROW_STATS") && getenv("SHADOW_FUSED_ROW_STATS")[0] == '0');
-  p.stats_r = use_stats ? d_row_stats : nullptr;
+  p.stats_r = d_row_stats;
   p.corr = d_corr; p.ldcorr = ldcorr; p.corr_row = d_corr_row; p.corr_rows = d_corr ? corr_rows : 0;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_an_bwd")) != SG_OK) return rc;

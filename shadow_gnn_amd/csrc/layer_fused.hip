@@ -174,29 +174,6 @@ extern "C" int sl_sage_fwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                          Fout, d_out_amax, stream);
 }
 
-// Auxiliary stream for the weight-gradient kernels of the chained backward (sl_set_aux_stream; NULL = off): dWs / dWn read
-// [dZs | A^T dZn] and X only, nothing downstream of the input-gradient product -- on a second stream they run BESIDE that
-// product's kernel instead of behind it, so that each fills the CUs the other's last round of workgroups leaves idle (2 260
-// GEMM workgroups on 512 slots = 4.4 rounds).  The caller owns the stream, keeps the operands alive for it (record_stream) and
-// joins it before it reads the gradients.
-static thread_local hipStream_t g_aux_stream = nullptr;
-static thread_local hipEvent_t g_aux_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-static thread_local unsigned g_aux_ev_next = 0;
-
-extern "C" int sl_set_aux_stream(void *stream) {
-  g_aux_stream = (hipStream_t)stream;
-  return SG_OK;
-}
-
-// the auxiliary stream waits for everything enqueued on `main` so far; returns it (or `main` itself when there is none)
-static hipStream_t aux_after(hipStream_t main) {
-  if (!g_aux_stream || g_aux_stream == main) return main;
-  hipEvent_t &ev = g_aux_ev[g_aux_ev_next++ & 7u];
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; return main; }
-  if (hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(g_aux_stream, ev, 0) != hipSuccess) return main;
-  return g_aux_stream;
-}
-
 extern "C" size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F) { return sl_gemm_an_bwd_partial_floats(n, F, 2); }
 
 // dz_ready: the layer above already left this layer's dZs / dZn in d_buf and its dscale / doffset / dbias (its own call
@@ -266,7 +243,6 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
         return rc;
     }
   }
-  void *wstream = nullptr;                                // stream of the weight-gradient kernels (the auxiliary one when set)
   if (d_dX || below) {
     if (!adj->t_indptr) return set_error(SG_ERR_INVALID, "sl_sage_bwd: the input gradient needs the transposed adjacency");
     // The K = 2 Fout operand [dZs | A^T dZn] of the epilogue form needs its row maxima: those of dZs come from the kernel
@@ -277,7 +253,6 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
     }
     if ((rc = spmm_any(adj, true, dZn, ld3, d_buf + Fout, ld3, Fout, stream, join ? amx : nullptr, 2)) != SG_OK) return rc;
     if (f16dx && hand && !join && (rc = sl_row_amax(d_buf, ld3, n, 2 * Fout, amx, stream)) != SG_OK) return rc;
-    wstream = aux_after((hipStream_t)stream);          // ([dZs | A^T dZn] and its row maxima are complete: the weight gradients may start)
     // dX = [dZs | A^T dZn] . [Ws ; Wn]   (K = 2 Fout)
     if (f16dx) rc = sl_gemm_act_norm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
     else rc = sl_gemm_pack_b2(d_Ws, 1, ldws, Fout, d_Wn, 1, ldwn, Fin, 2 * Fout, d_pack, stream);
@@ -312,23 +287,11 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
   // of X in hand, both run on two fp16 pieces (sl_gemm_tn_f16) -- the neighbour branch as
   //     dWn = dZn^T (A X) = (A^T dZn)^T X
   // over the transposed aggregate that is already there: same operand X, no row maxima of dZn / A X needed.
-  static const bool tn16 = !(getenv("SHADOW_GEMM_TN_F16") && getenv("SHADOW_GEMM_TN_F16")[0] == '0');
-  if (tn16 && d_x_amax && f16dx && hand && Fin == 256 && Fout == 256 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(d_X) & 15) == 0 &&
+  if (d_x_amax && f16dx && hand && Fin == 256 && Fout == 256 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(d_X) & 15) == 0 &&
       (n + sl_gemm_tn_slices(n) - 1) / sl_gemm_tn_slices(n) <= 3024) {
-    // (one launch for both: the two workgroups of a row slice share an XCD's L2, X comes from HBM once -- sl_gemm_tn_f16_pair;
-    //  SHADOW_GEMM_TN_PAIR=0: two launches)
-    static const bool pair = !(getenv("SHADOW_GEMM_TN_PAIR") && getenv("SHADOW_GEMM_TN_PAIR")[0] == '0');
-    if (!pair) {
-      {
-        SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
-        if ((rc = sl_gemm_tn_f16(dZs, ld3, amx, d_X, ldx, d_x_amax, d_dWs, n, Fout, Fin, d_tn_partial, nullptr, stream)) != SG_OK) return rc;
-      }
-      SHD_PROF_FMT(4.0 * n * (Fout + Fin), 2.0 * n * Fout * Fin, stream, "gemm_tn_f16_N%u", Fout);
-      return sl_gemm_tn_f16(d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, stream);
-    }
-    if (!wstream) wstream = stream;
-    SHD_PROF_FMT(4.0 * n * (2 * Fout + Fin), 2.0 * 2 * n * Fout * Fin, wstream, "gemm_tn_f16_pair_N%u", Fout);
-    return sl_gemm_tn_f16_pair(dZs, d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWs, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, nullptr, wstream);
+    // (one launch for both: the two workgroups of a row slice share an XCD's L2, X comes from HBM once -- sl_gemm_tn_f16_pair)
+    SHD_PROF_FMT(4.0 * n * (2 * Fout + Fin), 2.0 * 2 * n * Fout * Fin, stream, "gemm_tn_f16_pair_N%u", Fout);
+    return sl_gemm_tn_f16_pair(dZs, d_buf + Fout, ld3, amx, d_X, ldx, d_x_amax, d_dWs, d_dWn, n, Fout, Fin, d_tn_partial, nullptr, nullptr, stream);
   }
   if ((rc = tn_gemm(dZs, ld3, d_X, ldx, d_dWs, n, Fout, Fin, d_tn_partial, stream)) != SG_OK) return rc;
   return tn_gemm(dZn, ld3, d_AX, ldax, d_dWn, n, Fout, Fin, d_tn_partial, stream);

@@ -358,7 +358,7 @@ extern "C" const char *sg_last_error(void) { return last_error().c_str(); }
 // 2: sl_act_norm_* carry (drop_p, drop_seed); gemm / cache / pooling entries.  3: sl_act_norm_* dual (plain + dropped) output
 // 4: sg_ppr_push(mode).  5: sl_gat_bwd work buffer holds the datt partial sums.  6: sg_create_from_bin_ex
 // 7: sl_spmm_blockdiag_gather_f32, sampler debug entries.  8: sl_sage_fwd / sl_sage_bwd, sl_gemm_pack_b2, sl_gather_rows_drop_f32
-extern "C" int sg_abi_version(void) { return 18; }
+extern "C" int sg_abi_version(void) { return 19; }
 
 static int create_common(sg_sampler *s, int device_id, int64_t seed) {
   s->device = device_id;
@@ -843,8 +843,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
     const uint32_t capn_lds = std::min(capn, kLdsCapNodes);
     const uint32_t capf_lds = std::min(capf, capn_lds);
     {
-      uint32_t T = env_u32("SHADOW_SG_THREADS", 256);
-      if (T != 256 && T != 512 && T != 1024) T = 256;
+      const uint32_t T = 256;
       // bucketised table: ~4 key slots per possible node (power-of-two bucket count)
       uint32_t H = std::max<uint32_t>(64, next_pow2((uint64_t)capn_lds * 4));
       while ((size_t)H * 8 > 16 * 1024 && (H >> 1) >= capn_lds * 2) H >>= 1;
@@ -854,7 +853,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       const LdsLayout L = lds_layout(H, capn_lds, capf_lds, cfg->method == SG_METHOD_PPR);
       if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));
-      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_PER_CU", 8)));
+      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 8));
       const uint32_t grid = std::min<uint32_t>(P, (uint32_t)ncu * per_cu);
       if (L.total > 64 * 1024)
         SHD_HIP(ensure_dynamic_lds((const void *)sg_select_lds_kernel, L.total));
@@ -933,7 +932,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
                                   : scan_layout(p.bit_words, p.capm, p.nodes_lds, T / 64);
       if (SL.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: scan LDS layout %zu B too large", SL.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (SL.total + 64), 32 / (T / 64));
-      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, env_u32("SHADOW_SG_SCAN_PER_CU", 8)));
+      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 8));
       p.scan_grid = std::min<uint32_t>((uint32_t)ncu * per_cu, kScanGridMax);
       hipLaunchKernelGGL(sg_plan_kernel, dim3(1), dim3(1024), 0, stream, p);
       SHD_HIP(hipGetLastError());
@@ -961,8 +960,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
     r.d_counts = s->d_counts;
     // one workgroup per subgraph: subgraphs of thousands of nodes (depth-3 k-hop) get 1024 threads for their edge walk and BFS
     // (measured, 512 roots of the depth-3 benchmark: 0.27 ms at 256 threads)
-    static const int reloc_env = [] { const char *e = getenv("SHADOW_RELOC_THREADS"); return e ? atoi(e) : 0; }();
-    const uint32_t reloc_threads = reloc_env > 0 ? (uint32_t)reloc_env : (capn >= 2048 ? 1024u : 256u);
+    const uint32_t reloc_threads = capn >= 2048 ? 1024u : 256u;
     hipLaunchKernelGGL(sg_relocate_kernel, dim3(P), dim3(reloc_threads), 0, stream, r);
     SHD_HIP(hipGetLastError());
     if (s->profiling) SHD_HIP(hipEventRecord(s->ev_t[2], stream));

@@ -78,6 +78,9 @@ def pin_host_threads(local_rank: int, local_world: int, threads_per_rank: int = 
 FLAT_ALIGN = 32          # floats: tensors of the flat gradient / parameter buffers start on 128-byte lines
 
 
+LAZY_GRAD_PACK = True      # gradients packed into the flat buffer when a slice is complete (GradSync)
+
+
 class GradSync:
     """All gradients end up in one flat fp32 buffer: the data-parallel exchange is a few SUM all-reduces over contiguous
     slices of it, clip-by-global-norm and Adam (optim.FlatAdam) run over it in two launches.
@@ -159,7 +162,6 @@ class GradSync:
         """Gradients of slice s into the flat buffer (one multi-tensor copy); ``.grad`` becomes the buffer's view."""
         lo, hi = self._slices[s]
         from . import ops
-        ops.join_aux()               # (weight gradients computed on the auxiliary stream of the chained backward)
         dst, src = [], []
         views, params = self._views, self.params
         for i in range(lo, hi):
@@ -191,7 +193,7 @@ class GradSync:
         """Start of a step: clear the buffer, detach the ``.grad`` views (autograd then assigns instead of adding), arm
         the hooks."""
         self.flat.zero_()
-        lazy = os.environ.get("SHADOW_GRAD_PACK", "1") != "0"      # (0: .grad stay views, autograd adds into them)
+        lazy = LAZY_GRAD_PACK      # (False: .grad stay views, autograd adds into them)
         for i, p in enumerate(self.params):
             p.grad = None if lazy else self._views[i]
         self._left = [hi - lo for lo, hi in self._slices]

@@ -219,7 +219,7 @@ class MinibatchShallowExtractor:
         self._side = torch.cuda.Stream(device=self.device, priority=prio) if self.prefetch else None
         # prefetch launched when the consumer reaches ops.fire_deferred (see ops.DEFER_POINT: once the GNN layers of the forward
         # pass are enqueued) instead of at once: it then runs in the nearly idle read-out / loss stretch of the step instead of
-        # on its HBM-bound head (scripts/ab_defer_point.sh); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
+        # on its HBM-bound head (round-3 A/B); SHADOW_DEFER_PREFETCH=0 restores the immediate launch
         self.defer_prefetch = os.environ.get("SHADOW_DEFER_PREFETCH", "1") != "0"
         self._inflight: Dict[int, Tuple[str, int, int]] = {}   # mode -> (kind, roots in the call, epoch cursor at its start)
         # Sampler calls that cover several steps (HipSampler.sample_multi_async -> sg_sample_multi): the pipeline's four

@@ -389,12 +389,7 @@ class DeepGNN(nn.Module):
                 preds, emb_ens = self._head(embs)
                 loss = self._loss(preds, labels if index is None else index)
             weight = loss_scale * (getattr(batch_data, "loss_weight", 1.0) if self.grad_sync is not None else 1.0)
-            ops.arm_aux_stream(True)         # (weight-gradient kernels beside the input-gradient kernels, joined right below)
-            try:
-                (loss if weight == 1.0 else loss * weight).backward()
-            finally:
-                ops.arm_aux_stream(False)
-                ops.join_aux()
+            (loss if weight == 1.0 else loss * weight).backward()
             self._finish_update()
         else:
             if self.training:

@@ -282,7 +282,7 @@ def adj_norm_sym(csr: DeviceCSR, dropedge: float = 0.0) -> NormAdj:
 
 
 BLOCKDIAG_MIN_F = 96      # below this width the per-edge gather kernels are faster (measured)
-MERGE_SMALL_SUBGRAPHS = os.environ.get("SHADOW_MERGE_SUBGRAPHS", "1") != "0"
+MERGE_SMALL_SUBGRAPHS = True
 MERGE_BELOW_AVG_ROWS = 190   # two average subgraphs must fit the 384-row tile
 
 
@@ -309,7 +309,7 @@ def _adj_struct(adj: "NormAdj", need_transpose: bool):
 
 # One C call per GraphSAGE layer pass (sl_sage_fwd / sl_sage_bwd_chain) instead of one per kernel.  A KernelTimer does
 # not change the path: the C entries time their own kernels (csrc/prof.hip).
-FUSED_LAYER_CALLS = os.environ.get("SHADOW_FUSED_LAYER_CALLS", "1") != "0"
+FUSED_LAYER_CALLS = True
 
 
 def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None, out=None):
@@ -387,7 +387,7 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # SpMM (sl_spmm_blockdiag_gather_f32: 152 us incl. the dense copy the self Linear needs) and ONE gather + dropout pass
 # into 128-byte-padded rows followed by the dense SpMM (43 + 81 us).  The dependent id -> row loads inside the SpMM's
 # software pipeline cost more than the extra pass saves, so the second is the default.
-FUSE_GATHER_INTO_SPMM = os.environ.get("SHADOW_FUSE_GATHER_SPMM", "0") == "1"
+FUSE_GATHER_INTO_SPMM = False
 
 
 class LazyRows:
@@ -638,7 +638,7 @@ class _ActNorm(torch.autograd.Function):
 #  launch -- ~65 us of heuristics per call against ~10 us for the two ctypes calls -- that decides, measured on the
 #  arxiv-shape GCN-3 / 32-root configuration: 2.42 -> 1.95 ms per step)
 GEMM_SPLIT_MIN_ROWS = int(os.environ.get("SHADOW_GEMM_SPLIT_MIN_ROWS", "1024"))
-GEMM_SPLIT = os.environ.get("SHADOW_GEMM_SPLIT", "1") != "0"
+GEMM_SPLIT = True
 
 
 def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
@@ -712,7 +712,7 @@ def weight_grad_f16_usable(dZ: torch.Tensor, X: torch.Tensor) -> bool:
             and -(-n // _lib.load().sl_gemm_tn_slices(n)) <= 3024)
 
 
-TN_F16 = os.environ.get("SHADOW_GEMM_TN_F16", "1") != "0"
+TN_F16 = True
 
 
 def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False):
@@ -1148,7 +1148,7 @@ class RootsLink:
         self.rows32 = self.grad = self.dummy = self.plan = self.levels = None
 
 
-ROOTS_SPARSE_GRAD = os.environ.get("SHADOW_ROOTS_SPARSE_GRAD", "1") != "0"
+ROOTS_SPARSE_GRAD = True
 # The top GraphSAGE layer's backward pass on the rows its gradient is non-zero on (tail.TopBackwardPlan): exact, see there.
 # Off: the dense kernels stream the 99.6 %-zero gradient (SHADOW_SPARSE_TOP_BWD=0; bench.py reports that step time beside `value`).
 SPARSE_TOP_BWD = os.environ.get("SHADOW_SPARSE_TOP_BWD", "1") != "0"
@@ -1345,7 +1345,7 @@ class _SageDense(torch.autograd.Function):
             g = dout[0] if isinstance(dout, (tuple, list)) else dout
             if g is None or g.data_ptr() != lr0.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
-                                   "(its gradient is not the placeholder); set SHADOW_ROOTS_SPARSE_GRAD=0")
+                                   "(its gradient is not the placeholder); set ops.ROOTS_SPARSE_GRAD = False")
             return _SageDense._sparse_top_backward(ctx, lr0, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b)
         d0 = d1 = dout_rows = None
         if dz_ready:
@@ -1369,7 +1369,7 @@ class _SageDense(torch.autograd.Function):
                 g = douts[0]
                 if g is None or g.data_ptr() != lr.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                     raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
-                                       "(its gradient is not the placeholder); set SHADOW_ROOTS_SPARSE_GRAD=0")
+                                       "(its gradient is not the placeholder); set ops.ROOTS_SPARSE_GRAD = False")
                 dout_rows, douts = lr.rows32, (lr.grad,)
             d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
             if _is_dual(drop):
@@ -1410,8 +1410,6 @@ class _SageDense(torch.autograd.Function):
         pack = torch.empty(lib.sl_sage_pack_bytes(n, Fi, Fo), dtype=torch.uint8, device=dev)
         a = _adj_struct(ctx.adj, want_dx)
         opt = lambda t: t.data_ptr() if t is not None else None
-        aux = _aux_stream(dev) if (_AUX["armed"] and ctx.x_amax is not None and n >= AMAX_HANDOVER_ROWS and Fi == 256 and Fo == 256) else None
-        lib.sl_set_aux_stream(aux.cuda_stream if aux is not None else None)
         check(lib.sl_sage_bwd_chain(C.byref(a), X.data_ptr(), X.stride(0), AX.data_ptr(), AX.stride(0), Zs.data_ptr(), Zn.data_ptr(), Fi,
                                     Fo, Ws.data_ptr(), Ws.stride(0), opt(biases[0]), Wn.data_ptr(), Wn.stride(0), opt(biases[1]),
                                     sc.data_ptr(), of.data_ptr(), int(acts[0]), float(drop[0]), int(drop[1]), opt(d0), opt(d1), opt(dX),
@@ -1422,14 +1420,6 @@ class _SageDense(torch.autograd.Function):
                                     up.amax.data_ptr() if (dz_ready and up.amax is not None) else None,
                                     dout_rows.data_ptr() if dout_rows is not None else None,
                                     int(dout_rows.numel()) if dout_rows is not None else 0, opt(ctx.x_amax), _stream(Zs)))
-        if aux is not None:
-            # the weight-gradient kernels may still run when these tensors are dropped: their blocks must not be handed out
-            # again before the auxiliary stream is done with them
-            lib.sl_set_aux_stream(None)
-            for t_ in (X, buf, pack, tn_partial, dWs, dWn, ctx.x_amax, up.amax if (dz_ready and up.amax is not None) else None):
-                if t_ is not None:
-                    t_.record_stream(aux)
-            _AUX["dirty"] = aux
         if dz_ready:
             up.release()
         if dout_rows is not None:
@@ -1525,12 +1515,6 @@ class _SageDense(torch.autograd.Function):
         return down.dummy, dWs, dWn, dbi, dsc, dof
 
     @staticmethod
-    def _dbg(msg):
-        if os.environ.get("SHADOW_DEBUG_TRACE"):
-            torch.cuda.synchronize()
-            print("[trace]", msg, file=sys.stderr, flush=True)
-
-    @staticmethod
     def _sparse_top_backward(ctx, lr, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b):
         """The top layer of a GraphSAGE stack under a row-selecting read-out: its output gradient lives on the roots R
         (``lr.grad`` [P, Fo]), so dZs / dZn are zero outside R, dWs = dZs[R]^T X[R], dWn = dZn[R]^T (A X)[R], and the input
@@ -1547,7 +1531,6 @@ class _SageDense(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         plan = lr.plan
         R = plan.rows64
-        _SageDense._dbg(f"sparse top: n={n} P={R.numel()} t={plan.t}")
         (dZsR, dZnR), dsc, dof, dbi = _an_bwd([Zs.index_select(0, R), Zn.index_select(0, R)], biases, acts, sc, of, Fo, 1.0, (lr.grad,),
                                               [True, True], any(has_b), (0.0, 0))
         dWs = dZsR.t() @ X.index_select(0, R)
@@ -1562,7 +1545,6 @@ class _SageDense(torch.autograd.Function):
         check(lib.sl_top_dx(GS[0].data_ptr(), GS[1].data_ptr(), Fi, plan.T32.data_ptr(), plan.slot.data_ptr(), plan.epos.data_ptr(),
                             plan.self_idx.data_ptr(), plan.targets32.data_ptr(), opt(adj.edge_w), opt(adj.row_scale), opt(adj.col_scale),
                             plan.t, Fi, dXT.data_ptr(), Fi, _stream(Zs)))
-        _SageDense._dbg("dXT ok")
         # the layer below: act_norm backward on the rows T of its output gradient; its dZs / dZn stay COMPACT ([t, F], a zero
         # row behind dZn for the row-mapped transposed SpMM): nothing of height n is cleared or written here
         dZsT = torch.empty(plan.t, Fi, **f32)
@@ -1573,7 +1555,6 @@ class _SageDense(torch.autograd.Function):
                                                    dz_out=[dZsT, dZnT[:plan.t]], row_idx=plan.T32, dz_compact=True)
         down.compact = (dZsT, dZnT, plan)
         down.buf = down.amax = None
-        _SageDense._dbg("an_bwd below ok")
         down.partial = None
         down.rows = plan.T32           # (dZs / dZn of the layer below are zero outside T: its weight gradients need those rows only)
         lr.release()
@@ -2039,40 +2020,11 @@ def node_head(emb, lin, scale, offset, label):
     return _NodeHead.apply(emb, lin.weight, lin.bias, scale, offset, label.contiguous())
 
 
-# (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (SHADOW_ROW_STATS=0: recomputed)
-ROW_STATS_HANDOVER = os.environ.get("SHADOW_ROW_STATS", "1") != "0"
-# Weight-gradient kernels of the chained backward on a second stream, beside the input-gradient kernel of the same layer
-# (sl_set_aux_stream).  Armed by DeepGNN.step around its backward pass (it joins the stream before the gradients are read).
-# OFF by default -- measured slower (two A/B pairs on one box, products benchmark: 6.72 / 6.71 ms per step without, 6.84 / 6.79
-# with): the two kernels cannot share a CU (137 KB + 2 x 64 KB of LDS), so they time-slice the chip and contend for HBM --
-# overlapped they take 0.74 + 0.83 ms of event time per layer against 0.53 + 0.27 one after the other -- and what the tails
-# gain is less than that costs.  SHADOW_BWD_AUX_STREAM=1 switches it on.
-BWD_AUX_STREAM = os.environ.get("SHADOW_BWD_AUX_STREAM", "0") == "1"
-_AUX = {"streams": {}, "armed": False, "dirty": None}
-
-
-def arm_aux_stream(on: bool):
-    """DeepGNN.step: True before loss.backward(), False (after join_aux) behind it."""
-    _AUX["armed"] = bool(on) and BWD_AUX_STREAM
-
-
-def _aux_stream(dev):
-    st = _AUX["streams"].get(dev)
-    if st is None:
-        st = _AUX["streams"][dev] = torch.cuda.Stream(device=dev)
-    return st
-
-
-def join_aux():
-    """The current stream waits for the auxiliary stream's weight-gradient kernels (no-op when none were launched)."""
-    st = _AUX["dirty"]
-    if st is not None:
-        torch.cuda.current_stream(st.device).wait_stream(st)
-        _AUX["dirty"] = None
-
-
-# Chained GraphSAGE backward (sl_sage_bwd_chain): on unless SHADOW_CHAIN_SAGE_BWD=0
-CHAIN_SAGE_BWD = os.environ.get("SHADOW_CHAIN_SAGE_BWD", "1") != "0"
+# (mean, 1 / std) per row and branch handed from the forward GEMM epilogue to the chained backward epilogue (False: recomputed)
+ROW_STATS_HANDOVER = True
+# Chained GraphSAGE backward (sl_sage_bwd_chain).  (A module attribute, like the path switches below without an environment
+# variable: tests and A/B scripts set them in the process -- round 5 cut the environment switchboard to the ones a user needs.)
+CHAIN_SAGE_BWD = True
 
 
 # Work the minibatch extractor wants issued right AFTER the first aggregation of a step has been enqueued (the prefetch of
@@ -2090,9 +2042,9 @@ def defer(key, fn):
 # call then runs beside the read-out / classifier / loss kernels and the first small backward kernels, a stretch of ~15
 # tiny kernels that leaves the chip nearly idle for about as long as the sampler pipeline takes; "fwd": at the end of
 # DeepGNN.forward; "agg": after the step's first aggregation (beside the forward GEMMs).  Same box, products benchmark
-# (scripts/ab_defer_point.sh), step ms / sampler pipeline ms in the step / north-star HBM fraction:
+# (round-3 A/B), step ms / sampler pipeline ms in the step / north-star HBM fraction:
 #   immediate 10.27 / 0.25 / 0.41    agg 10.20 / 0.31-0.40 / 0.40-0.43    fwd 10.21 / 0.28 / 0.44    body 10.21 / 0.21 / 0.46
-DEFER_POINT = os.environ.get("SHADOW_DEFER_POINT", "body")
+DEFER_POINT = "body"
 
 
 def fire_deferred(point: str = "agg"):
