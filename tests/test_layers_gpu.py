@@ -1745,7 +1745,7 @@ def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act,
     from shadow_gnn_amd.ppr import ppr_approximate_device
     from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
     from shadow_gnn_amd.synthetic import make_graph_numpy
-    L, B, F0, C, N = 5, 176, 100, 47, 200_000          # (176 roots x ~200 rows: above the 32 768-row hand-over of the timed path)
+    L, B, F0, C, N = 5, 224, 100, 47, 200_000          # (224 roots x ~160 rows: above the 32 768-row hand-over of the timed path)
     indptr, indices = make_graph_numpy(N, 50, seed=21)
     hs = HipSampler(indptr, indices, device=torch.device(DEV), seed=7)
     roots = np.sort(np.random.default_rng(24).permutation(N)[:B]).astype(np.uint32)
