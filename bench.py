@@ -162,16 +162,16 @@ def cpu_baseline(indptr_host, indices_host, roots, scfg, seed, budget_s=24.0):
                     sample=f"oracle/sampler_oracle.c (OpenMP), 1 call x {P} subgraphs per thread count ({type(ex).__name__}: reference build unavailable)")
 
 
-def cpu_baseline_ppr(indptr_host, indices_host, roots, scfg, ppr, seed, budget_s=24.0):
+def cpu_baseline_ppr(indptr_host, indices_host, roots, scfg, ppr, seed, budget_s=24.0, sweep=(1, 8, 20, 64), P_max=500):
     """PPR workloads: the reference's own `ppr` sampler (ParallelSampler.cpp:565-595) over a table the reference's own
     preproc_ppr_approximate (ParallelSampler.cpp:237-344) builds for the sample's roots -- the table build is timed
     separately (the reference builds it once per run and caches it on disk), the sampler calls are swept over thread
     counts like the k-hop baseline."""
     import tempfile
     cores = os.cpu_count() or 1
-    P = min(500, int(len(roots)))
+    P = min(P_max, int(len(roots)))
     roots = np.ascontiguousarray(roots[:2 * P], dtype=np.uint32)
-    sweep = sorted({t for t in (1, 8, 20, 64) if t <= cores})
+    sweep = sorted({t for t in sweep if t <= cores})
     sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
     with _stdout_to_stderr():
         import ParallelSampler as ref
@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--workload", default="products-khop-sage5", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="roots per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-large", action="store_true",
+                    help="papers100M shape: also time the reference's sampler there (writes the 13 GB CSR to .bin files and loads it "
+                         "once per thread count: minutes; skipped by default)")
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--sampler-steps-per-call", type=int, default=4,
                     help="steps whose batches ONE sampler call produces (sg_sample_multi; bit-identical batches, the pipeline's "
@@ -566,9 +569,15 @@ def main():
         except Exception as ex:                          # never lose the main result to a baseline leg
             cb = dict(error=f"{type(ex).__name__}: {ex}"[:300])
     elif not args.no_cpu_baseline and world == 1 and wl["sampler"]["method"] == "ppr":
-        if int(indices.numel()) > 1_000_000_000:
+        if int(indices.numel()) > 1_000_000_000 and not args.cpu_baseline_large:
             cb = dict(skipped="papers100M shape: the reference loads the CSR from .bin files -- a 13 GB host copy + file write + "
-                              "load per thread count does not fit a bounded baseline leg; see the products-shape PPR line")
+                              "load per thread count; run with --cpu-baseline-large for the bounded form (64 roots per call, threads 1 and 8)")
+        elif int(indices.numel()) > 1_000_000_000:
+            try:                                        # (one 13 GB file, two loads: minutes, opt-in)
+                ip = indptr.cpu().numpy().view(np.uint32); ix = indices.cpu().numpy().view(np.uint32)
+                cb = cpu_baseline_ppr(ip, ix, roots_all, wl["sampler"], wl["ppr"], seed=3, budget_s=60.0, sweep=(1, 8), P_max=64)
+            except Exception as ex:
+                cb = dict(error=f"{type(ex).__name__}: {ex}"[:300])
         else:
             try:
                 ip = indptr.cpu().numpy().view(np.uint32); ix = indices.cpu().numpy().view(np.uint32)

@@ -768,7 +768,10 @@ int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float 
 /* accumulate_dz_self != 0: d_dz_self already holds the share of z_self's gradient that came through the layer's own
  * act_norm branch (z_self feeds the attention scores AND the normalised output) -- the kernel adds to it instead of
  * overwriting; d_row_amax (may be NULL): receives max_k over the final dz_self AND dz_neigh rows (the operand scale of the
- * K-concatenated input-gradient product, sl_gemm_nt_cat_f32).                                                          */
+ * K-concatenated input-gradient product, sl_gemm_nt_cat_f32).  Round 5: the attention's share of dz_self is exactly zero on
+ * every row whose softmax denominator is not on its 1e-10 clamp (the row softmax does not depend on u_s[i]) -- those rows of
+ * d_dz_self are not read or written in accumulate mode (zeros are written otherwise), and with accumulate_dz_self != 0
+ * d_row_amax must come in HOLDING max_k |dz_self[i, k]| of the incoming rows (an upper bound will do).                     */
 int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
                const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
                const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,

@@ -340,32 +340,48 @@ __global__ void gat_row_bwd_kernel(GatParams p) {
     const float t = slice_sum(dot4(dn, ng), ls);          // dN_i . N_i per head
     const float usr = p.u_s[r * p.H + h];
     const float as = lrelu02(usr);
-    const float mx = p.mx[r * p.H + h], inv = 1.0f / p.den[r * p.H + h];
+    const float mx = p.mx[r * p.H + h], den_r = p.den[r * p.H + h], inv = 1.0f / den_r;
     float das = 0.f;
     uint32_t q = a;
     const bool lead = on && (l % ls) == 0;
 #define SHD_CALL(G) gat_bwd_row_group<G>(p, q, h, f, on, lead, ls, as, mx, inv, t, dn, das)
     SHD_GAT_EDGES(SHADOW_GAT_GROUPS_ROW, q, b, SHD_CALL);
 #undef SHD_CALL
-    const float dus = das * dlrelu02(usr);
+    // The score of edge (i, j) is lrelu(u_s[i]) + lrelu(u_n[j]): the row's softmax does not change when u_s[i] moves, so the
+    // aggregate's gradient with respect to u_s[i] is EXACTLY zero (sum_j de_ij = t - t sum_j alpha_ij, sum_j alpha_ij = 1) --
+    // the reference's autograd produces rounding noise around 0 there (layers.py:568-581).  The one exception is a row whose
+    // denominator sits on its 1e-10 clamp (every kept edge more than e^-23 below the dropped maximum): there alpha does not
+    // sum to one and the sum is kept.  Everywhere else the attention's share of dz_self and of datt[0] is zero: the lanes of an
+    // unclamped head neither read z_self nor touch dz_self (0.9 GB less per launch at 294 k rows).
+    const bool clamped = !(den_r > 1e-10f);          // (the forward pass stored max(sum, 1e-10))
+    const float dus = clamped ? das * dlrelu02(usr) : 0.f;
     float rmax = 0.f;
     if (on) {
       if ((l % ls) == 0) p.du_s[r * p.H + h] = dus;
-      const float4 z = gld4(p.z_self + r * p.F + f);
-      const float4 hs = act4(p.act, z);
-      float4 dzv = make_float4(dus * a0.x * g_act_bwd(p.act, z.x, hs.x), dus * a0.y * g_act_bwd(p.act, z.y, hs.y),
-                               dus * a0.z * g_act_bwd(p.act, z.z, hs.z), dus * a0.w * g_act_bwd(p.act, z.w, hs.w));
-      if (p.acc_self) {                  // (z_self also feeds the layer's act_norm: its gradient share is here already)
-        const float4 o = gld4(p.dz_self + r * p.F + f);
-        dzv.x += o.x; dzv.y += o.y; dzv.z += o.z; dzv.w += o.w;
+      if (clamped) {
+        const float4 z = gld4(p.z_self + r * p.F + f);
+        const float4 hs = act4(p.act, z);
+        float4 dzv = make_float4(dus * a0.x * g_act_bwd(p.act, z.x, hs.x), dus * a0.y * g_act_bwd(p.act, z.y, hs.y),
+                                 dus * a0.z * g_act_bwd(p.act, z.z, hs.z), dus * a0.w * g_act_bwd(p.act, z.w, hs.w));
+        if (p.acc_self) {                  // (z_self also feeds the layer's act_norm: its gradient share is here already)
+          const float4 o = gld4(p.dz_self + r * p.F + f);
+          dzv.x += o.x; dzv.y += o.y; dzv.z += o.z; dzv.w += o.w;
+        }
+        gst4(p.dz_self + r * p.F + f, dzv);
+        rmax = shadow::amax4(dzv);
+        g0.x += dus * hs.x; g0.y += dus * hs.y; g0.z += dus * hs.z; g0.w += dus * hs.w;
+      } else if (!p.acc_self) {
+        gst4(p.dz_self + r * p.F + f, make_float4(0.f, 0.f, 0.f, 0.f));
       }
-      gst4(p.dz_self + r * p.F + f, dzv);
-      rmax = shadow::amax4(dzv);
-      g0.x += dus * hs.x; g0.y += dus * hs.y; g0.z += dus * hs.z; g0.w += dus * hs.w;
     }
     if (p.row_amax) {                    // (the LPR lanes of a row group share r)
+      // accumulate mode: the array holds max |dz_self| of the incoming rows (the caller's contract); what this pass changed
+      // is joined in.  Otherwise this pass wrote the whole row.
       rmax = shadow::group_max<LPR>(rmax);
-      if (l == 0) p.row_amax[r] = rmax;
+      if (l == 0) {
+        if (!p.acc_self) p.row_amax[r] = rmax;
+        else if (rmax > 0.f) p.row_amax[r] = fmaxf(p.row_amax[r], rmax);
+      }
     }
   }
   // datt[0] += sum over this block's rows

@@ -892,14 +892,15 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       p.nodes_lds = std::min(capn, big ? 1024u : kLdsCapNodes);
       // (node sets beyond the LDS tables: one workgroup per CU -- 16 wavefronts keep twice the loads in flight: 1.59 -> 1.33 ms
       //  at 256 depth-3 roots)
-      uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", big ? 1024 : 512);
-      if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
       const bool plain = !p.include_self && !p.compat && (p.include_target_conn || R == 1);
       // SHADOW_SG_SCAN_IMPL=window: the general (row-window) kernel for plain calls too (A/B measurements, tests)
-      // (round 5: the flat kernel also takes calls WITH self-edge insertion -- the rows' insertion slots come from the
-      //  selection kernel; compat over-read and the root<->root exclusion stay with the row-window kernel)
+      // (round 5: the flat kernel also takes calls WITH self-edge insertion -- the streaming loop finds the slot where the ids
+      //  pass by; compat over-read and the root<->root exclusion stay with the row-window kernel)
       const char *impl_env = getenv("SHADOW_SG_SCAN_IMPL");
       const bool flat = !p.compat && (p.include_target_conn || R == 1) && !(impl_env && !strcmp(impl_env, "window"));
+      const uint32_t Tdef = (big && flat) ? 1024u : 512u;
+      uint32_t T = env_u32("SHADOW_SG_SCAN_THREADS", Tdef);
+      if (T != 256 && T != 512 && T != 1024) T = Tdef;
       // candidate list: about one id in a hundred of a round.  The flat kernel trades 512 entries for a longer run list --
       // whole subgraphs then fit one round (scripts/sweep_capm.sh: 23 % fewer rounds, 0.205 -> 0.200 ms at 1 024 roots,
       // 1.105 -> 1.047 ms at 8 192); a round that overflows the list is redone on half the quads.

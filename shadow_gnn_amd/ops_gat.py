@@ -173,17 +173,24 @@ class _GatTail(torch.autograd.Function):
                     and lv.r == int(lr.rows32.numel()) and lv.in_ids_full is not None):
                 return _GatTail._rows_backward(ctx, lr, lv, lr.levels[1:])
             rows, dout = lr.rows32, (lr.grad,)
-        (dnagg, dzs), dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, dout, [True, True],
-                                                False, drop, row_idx=rows)
+        # (branches passed self-first: the kernel's row maxima are those of its first gradient -- dz_self's, which the attention
+        #  backward below no longer reads on the rows it leaves alone; per-branch arithmetic does not depend on the order)
+        amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
+        if amax is not None and rows is not None:
+            amax.zero_()                 # (rows the read-out gradient does not reach: dz_self = 0)
+        (dzs, dnagg), dsc, dof, _ = ops._an_bwd([z_self, nagg], [None, None], (act_code, 0), sc.flip(0).contiguous(), of.flip(0).contiguous(), seg,
+                                                out_scale, dout, [True, True], False, drop, row_idx=rows, dz0_amax=amax)
+        dsc, dof = dsc.flip(0), dof.flip(0)
         if rows is not None:
             lr.release()
         ti, tx, tp = c.transposed
         work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
         dzn = torch.empty_like(z_neigh)
         datt = torch.empty(2, F, device=dev)
-        amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
         w = adj.edge_w
-        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + 6 * 4 * n * F + 6 * 4 * n * heads
+        # (round 5: both CSR structures; the incoming gradient, the aggregate, z_neigh and hn in, dz_neigh out -- dz_self / z_self are
+        #  no longer touched: the attention's share of dz_self is exactly zero, see gat_row_bwd_kernel)
+        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + 5 * 4 * n * F + 6 * 4 * n * heads
         with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
