@@ -282,6 +282,13 @@ int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const f
                     const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
                     const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
                     void *stream);
+/* The same with d_row_amax [n] (may be NULL) = max_k |Y[i, k]| per row (the operand scale of the fp16 GEMM that reads Y,
+ * see sl_row_amax) -- from the same pass for 128 < F <= 256, one more pass over Y otherwise.  Round 5: the transposed
+ * aggregate of a gradient that lives on a few rows runs here over a FILTERED transposed CSR (tail.TopBackwardPlan).     */
+int sl_spmm_csr_amax_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                         const uint32_t *d_edge_perm, const float *d_row_scale, const float *d_col_scale,
+                         const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n, uint32_t F,
+                         float *d_row_amax, void *stream);
 
 /* Consecutive small subgraphs of a collated batch joined into groups of at most cap_rows rows and cap_edges edges (0: the
  * LDS tile of sl_spmm_blockdiag_f32, 384 rows / 1024 edges): d_group_*_off receive [num_subg + 1] offsets -- the groups,
@@ -743,6 +750,15 @@ int sl_zero_slices(float *d_a, float *d_b, int64_t ld, uint32_t n, uint32_t F, v
  * S = dZs[R] Ws ([P, F] each, pitch ldg); F % 4 == 0, 16-byte aligned rows.                                            */
 int sl_top_plan(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_targets, uint32_t num_subg, uint32_t cap,
                 uint32_t *d_off, uint32_t *d_T, uint32_t *d_slot, int32_t *d_epos, uint32_t *d_self_idx, void *stream);
+/* The row map of T and the batch's TRANSPOSED adjacency restricted to the columns T, behind sl_top_plan on the same stream (no
+ * host round trip in between): d_rowmap[i] = position of row i in T, 0xFFFFFFFF outside; (d_f_indptr [n + 1], d_f_indices,
+ * d_f_perm [e]) = per row of A^T the entries whose source row lies in T, in their original order, column ids = positions in T,
+ * d_f_perm = the edge's place in the batch CSR.  d_work: n / 1024 + 4 words.  The number of kept entries lands in
+ * d_off[num_subg + 2] (d_off: the plan's [num_subg + 3] counter array).  The aggregation A^T dZ of a gradient that lives on T
+ * runs over this structure (sl_spmm_csr_amax_f32 on the compact [t, F] rows).                                           */
+int sl_top_plan_filter(const uint32_t *d_T, uint32_t *d_off, uint32_t num_subg, uint32_t cap, const uint32_t *d_t_indptr,
+                       const uint32_t *d_t_indices, const uint32_t *d_t_perm, uint32_t n, uint32_t *d_rowmap, uint32_t *d_f_indptr,
+                       uint32_t *d_f_indices, uint32_t *d_f_perm, uint32_t *d_work, void *stream);
 int sl_top_dx(const float *d_G, const float *d_S, int64_t ldg, const uint32_t *d_T, const uint32_t *d_slot, const int32_t *d_epos,
               const uint32_t *d_self_idx, const uint32_t *d_targets, const float *d_edge_w, const float *d_row_scale,
               const float *d_col_scale, uint32_t t, uint32_t F, float *d_out, int64_t ldo, void *stream);

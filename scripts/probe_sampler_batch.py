@@ -32,6 +32,7 @@ for B in Bs:
           + f"\n         wave 0 (cycles per segment): run streaming {16 * ph[15] / max(1, ph[13]):.0f}, short rows {16 * ph[16] / max(1, ph[13]):.0f}, "
           f"barrier wait {16 * ph[10] / max(1, ph[13]):.0f}; bucket scan {16 * ph[17] / max(1, ph[13]):.0f}, rank {16 * ph[18] / max(1, ph[13]):.0f}, "
           f"ticket wait {16 * ph[19] / max(1, ph[13]):.0f}, write-out {16 * ph[12] / max(1, ph[13]):.0f}")
+    print(f"   scan workgroups: longest {16 * ph[16]:.0f} cycles, mean {16 * tot / 256:.0f} (256 workgroups assumed: one per CU for node sets beyond the LDS tables)")
     print(f"   select (cycles per subgraph): expansion {16 * ph[20] / B:.0f}, sort {16 * ph[21] / B:.0f}, row records {16 * ph[22] / B:.0f}")
     print(f"B={B:5d}: sample kernel {m:.3f} ms  {nn / 4 / m / 1e3:.0f} M nodes/s  neighbour ids scanned {slots / 4 * 4 / m / 1e6:.0f} GB/s  "
           f"({m / B * 1e3:.3f} us per subgraph)")

@@ -135,6 +135,8 @@ SIGNATURES = {
     "sl_degree_scales": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
     "sl_spmm_csr_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                    C.c_uint32, _P]),
+    "sl_spmm_csr_amax_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
+                                        C.c_uint32, _P, _P]),
     "sl_merge_subgraphs": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "sl_spmm_blockdiag_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_uint32,
                                          C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
@@ -221,6 +223,7 @@ SIGNATURES = {
     "sl_gat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_top_plan": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "sl_top_plan_filter": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_dx": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_spmm_blockdiag_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_uint32, C.c_uint32, _P, _P,
                                               C.c_uint32, C.c_uint32, _P, C.c_uint32, _P]),

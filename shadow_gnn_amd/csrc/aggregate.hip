@@ -303,7 +303,7 @@ spmm_pipe_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict
                  const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
                  const float *__restrict__ row_scale, const float *__restrict__ col_scale,
                  const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
-                 uint32_t n, uint32_t F, uint32_t chunk) {
+                 uint32_t n, uint32_t F, uint32_t chunk, float *__restrict__ row_amax) {
   static_assert(KMAX <= LPG && R + 1 <= LPG, "edge ids / row pointers live one per lane");
   const uint32_t lane = lane_id();
   const uint32_t sl = lane & (LPG - 1);              // lane inside the unit
@@ -417,8 +417,12 @@ spmm_pipe_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict
 #pragma unroll
       for (int q = 0; q < R; q++) {
         const float rs = grp_f32<LPG>(rsl, q, gb);
-        if (r0 + q < n && on)
-          st4(Y + (int64_t)(r0 + q) * ldy + f, make_float4(acc[q].x * rs, acc[q].y * rs, acc[q].z * rs, acc[q].w * rs));
+        const float4 y = make_float4(acc[q].x * rs, acc[q].y * rs, acc[q].z * rs, acc[q].w * rs);
+        if (r0 + q < n && on) st4(Y + (int64_t)(r0 + q) * ldy + f, y);
+        if (row_amax) {                   // (largest magnitude of the row: the fp16 operand scale of the GEMM that reads Y)
+          const float m = group_max<LPG>(on ? amax4(y) : 0.f);
+          if (sl == 0 && r0 + q < n) row_amax[r0 + q] = m;
+        }
       }
     }
     ipl_d = ipl_c; ipl_c = ipl_b; ipl_b = ipl_a;
@@ -457,7 +461,7 @@ struct BdGather {
   uint32_t drop_thr;        // 0: no dropout
   float drop_scale;
   uint32_t seed_lo, seed_hi;
-  uint32_t zero_id;         // ids[r] == zero_id: the row is all zeros and is not fetched (row-mapped inputs); 0xFFFFFFFF: none
+  uint32_t zero_id;         // ids[r] >= zero_id: the row is all zeros and is not fetched (row-mapped inputs); 0xFFFFFFFF: none
 };
 
 __device__ __forceinline__ uint32_t bd_mix32(uint32_t h) {
@@ -484,7 +488,7 @@ template <int kGather>
 __device__ __forceinline__ float4 bd_load4(const BdGather &g, const float *__restrict__ X, int64_t ldx, uint64_t r, uint32_t f) {
   if (kGather == 0) return ld4(X + (int64_t)r * ldx + f);
   const uint32_t id = g.ids[r];
-  if (kGather == 2) return id == g.zero_id ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(g.table + (int64_t)id * g.ldt + f);
+  if (kGather == 2) return id >= g.zero_id ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(g.table + (int64_t)id * g.ldt + f);
   return bd_drop4(g, ld4(g.table + (int64_t)id * g.ldt + f), r, f);
 }
 
@@ -1135,9 +1139,19 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
                                const uint32_t *d_edge_perm, const float *d_row_scale,
                                const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
                                int64_t ldy, uint32_t n, uint32_t F, void *stream_) {
+  return sl_spmm_csr_amax_f32(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, nullptr, stream_);
+}
+
+// ... with the row maxima of Y (d_row_amax [n], may be NULL) written by the same pass where the kernel holds whole rows
+// (128 < F <= 256: a row per wavefront), by one more pass over Y otherwise.
+extern "C" int sl_spmm_csr_amax_f32(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
+                                    const uint32_t *d_edge_perm, const float *d_row_scale,
+                                    const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
+                                    int64_t ldy, uint32_t n, uint32_t F, float *d_row_amax, void *stream_) {
   if (n == 0 || F == 0) return SG_OK;
   if (!d_indptr || !d_X || !d_Y) return set_error(SG_ERR_INVALID, "sl_spmm_csr_f32: null argument");
   hipStream_t st = (hipStream_t)stream_;
+  bool amax_done = false;
   const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y) && F <= 1024;
 #define SHD_SPMM(LPR, CH)                                                                          \
   hipLaunchKernelGGL((spmm_kernel<LPR, CH>), dim3((((n + (kBlock / LPR) - 1) / (kBlock / LPR)) + 7u) & ~7u), dim3(kBlock), 0, st, \
@@ -1161,12 +1175,14 @@ extern "C" int sl_spmm_csr_f32(const uint32_t *d_indptr, const uint32_t *d_indic
     const uint64_t units = (G + chunk - 1) / chunk;
     const uint32_t blocks = (uint32_t)((((units + upb - 1) / upb) + 7u) & ~(uint64_t)7u);
     hipLaunchKernelGGL((spmm_pipe_kernel<R, KMAX, 64>), dim3(blocks), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_w,
-                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, chunk);
+                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, chunk, d_row_amax);
+    amax_done = true;
   }
   else if (F <= 512) { SHD_SPMM(64, 2); }
   else { SHD_SPMM(64, 4); }
 #undef SHD_SPMM
   SHD_HIP(hipGetLastError());
+  if (d_row_amax && !amax_done) return sl_row_amax(d_Y, ldy, n, F, d_row_amax, stream_);
   return SG_OK;
 }
 

@@ -791,7 +791,11 @@ __global__ void sg_scan_kernel(SampleParams p) {
   }
   if (tid == 0) {
     p.blkinfo[rec_blk] = make_uint2(rec_cnt, 0xFFFFFFFFu);
-    for (int i = 0; i < 12; i++) atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
+    tacc[8] = tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];          // (word 8: the LONGEST workgroup's phase cycles -- balance of the span partition)
+    for (int i = 0; i < 12; i++) {
+      if (i == 8) atomicMax(&p.plan[PL_T0 + i], tacc[i] >> 4);
+      else atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
+    }
   }
 }
 
@@ -1104,7 +1108,11 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
   }
   if (tid == 0) {
     p.blkinfo[rec_blk] = make_uint2(rec_cnt, 0xFFFFFFFFu);
-    for (int i = 0; i < 12; i++) atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
+    tacc[8] = tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];          // (word 8: the LONGEST workgroup's phase cycles -- balance of the span partition)
+    for (int i = 0; i < 12; i++) {
+      if (i == 8) atomicMax(&p.plan[PL_T0 + i], tacc[i] >> 4);
+      else atomicAdd(&p.plan[PL_T0 + i], (i < 5 || i > 6) ? tacc[i] >> 4 : tacc[i]);   // cycles in units of 16
+    }
   }
 }
 

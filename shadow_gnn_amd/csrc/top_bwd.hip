@@ -100,6 +100,58 @@ __global__ void __launch_bounds__(256) top_fill_kernel(const uint32_t *__restric
   }
 }
 
+// ---- the batch's transposed adjacency restricted to the columns T (round 5) -----------------------------------------------
+// A^T dZn of the layer below the row-sparse pass has terms from the rows T only: its aggregation then walks ~300 of a
+// subgraph's ~2 000 transposed edges.  rowmap[i] = position of row i in T (all ones: not in T); per row of A^T the kept
+// entries in their original order -- the same sums, bit for bit, as the walk over zero rows -- as a CSR whose column ids are
+// positions in the compact [t, F] gradient, f_perm = the edge's place in the batch CSR (its drop-edge weight).
+__global__ void __launch_bounds__(256) top_rowmap_kernel(const uint32_t *__restrict__ T, const uint32_t *__restrict__ off, uint32_t P, uint32_t cap,
+                                                         uint32_t n, uint32_t *__restrict__ rowmap) {
+  const uint32_t t = min(off[P], cap);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < t; i += gridDim.x * 256) { const uint32_t r = T[i]; if (r < n) rowmap[r] = i; }
+}
+
+// thread per row j of A^T: entries whose source row lies in T
+__global__ void __launch_bounds__(256) top_filt_count_kernel(const uint32_t *__restrict__ t_indptr, const uint32_t *__restrict__ t_indices,
+                                                             const uint32_t *__restrict__ rowmap, uint32_t n, uint32_t *__restrict__ cnt) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t c = 0;
+  for (uint32_t p = t_indptr[j]; p < t_indptr[j + 1]; p++) c += rowmap[t_indices[p]] != 0xFFFFFFFFu ? 1u : 0u;
+  cnt[j] = c;
+}
+
+// exclusive scan of cnt[0 .. n) in three steps: 1 024-element blocks (local prefix in place, block total to bsum), the block totals
+// by top_scan_kernel, then the block's offset added; f_indptr[n] = total
+__global__ void __launch_bounds__(1024) top_scan_local_kernel(uint32_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ bsum) {
+  __shared__ uint32_t wsum[32];
+  const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t x = i < n ? v[i] : 0u;
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan(x, wsum, &tot);
+  if (i < n) v[i] = ex;
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) top_scan_add_kernel(uint32_t *__restrict__ v, uint32_t n, const uint32_t *__restrict__ bsum, uint32_t nblocks,
+                                                            uint32_t *__restrict__ total_out) {
+  const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+  if (i < n) v[i] += bsum[blockIdx.x];
+  if (i == 0) { v[n] = bsum[nblocks]; *total_out = bsum[nblocks]; }
+}
+
+__global__ void __launch_bounds__(256) top_filt_fill_kernel(const uint32_t *__restrict__ t_indptr, const uint32_t *__restrict__ t_indices,
+                                                            const uint32_t *__restrict__ t_perm, const uint32_t *__restrict__ rowmap, uint32_t n,
+                                                            const uint32_t *__restrict__ f_indptr, uint32_t *__restrict__ f_indices,
+                                                            uint32_t *__restrict__ f_perm) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t o = f_indptr[j];
+  for (uint32_t p = t_indptr[j]; p < t_indptr[j + 1]; p++) {
+    const uint32_t m = rowmap[t_indices[p]];
+    if (m != 0xFFFFFFFFu) { f_indices[o] = m; f_perm[o] = t_perm[p]; o++; }
+  }
+}
+
 // dX[j, :] = w(j) G[slot(j), :] + [j is its subgraph's root] S[slot(j), :];  F % 4 == 0, a row on F / 4 lanes
 __global__ void __launch_bounds__(256) top_dx_kernel(const float *__restrict__ G, const float *__restrict__ S, int64_t ldg, const uint32_t *__restrict__ T,
                                                      const uint32_t *__restrict__ slot, const int32_t *__restrict__ epos,
@@ -144,6 +196,30 @@ extern "C" int sl_top_plan(const uint32_t *d_indptr, const uint32_t *d_indices, 
   hipLaunchKernelGGL(top_scan_kernel, dim3(1), dim3(1024), 0, st, num_subg, d_off);
   hipLaunchKernelGGL(top_fill_kernel, dim3((num_subg + 3) / 4), dim3(256), 0, st, d_indptr, d_indices, d_targets, num_subg, d_off, cap, d_T, d_slot,
                      d_epos, d_self_idx);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+// Row map + filtered transposed structure behind sl_top_plan (same stream, no host round trip in between): d_rowmap [n],
+// d_f_indptr [n + 1], d_f_indices / d_f_perm [e] (capacity: every edge), d_work [n / 1024 + 4] words; the number of kept
+// entries lands in d_off[num_subg + 2] beside the plan's own counters.  Nothing is written when the plan overflowed `cap`
+// or raised its flag (the caller reads both with the same copy and drops the plan).
+extern "C" int sl_top_plan_filter(const uint32_t *d_T, uint32_t *d_off, uint32_t num_subg, uint32_t cap, const uint32_t *d_t_indptr,
+                                  const uint32_t *d_t_indices, const uint32_t *d_t_perm, uint32_t n, uint32_t *d_rowmap,
+                                  uint32_t *d_f_indptr, uint32_t *d_f_indices, uint32_t *d_f_perm, uint32_t *d_work, void *stream) {
+  if (n == 0 || num_subg == 0) return SG_OK;
+  if (!d_T || !d_off || !d_t_indptr || !d_rowmap || !d_f_indptr || !d_f_indices || !d_f_perm || !d_work)
+    return set_error(SG_ERR_INVALID, "sl_top_plan_filter: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  SHD_HIP(hipMemsetAsync(d_rowmap, 0xFF, (size_t)n * 4, st));
+  hipLaunchKernelGGL(top_rowmap_kernel, dim3(std::min<uint32_t>((cap + 255) / 256, 2048)), dim3(256), 0, st, d_T, d_off, num_subg, cap, n, d_rowmap);
+  hipLaunchKernelGGL(top_filt_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_t_indptr, d_t_indices, d_rowmap, n, d_f_indptr);
+  const uint32_t nblocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(top_scan_local_kernel, dim3(nblocks), dim3(1024), 0, st, d_f_indptr, n, d_work);
+  hipLaunchKernelGGL(top_scan_kernel, dim3(1), dim3(1024), 0, st, nblocks, d_work);
+  hipLaunchKernelGGL(top_scan_add_kernel, dim3(nblocks), dim3(1024), 0, st, d_f_indptr, n, d_work, nblocks, d_off + num_subg + 2);
+  hipLaunchKernelGGL(top_filt_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_t_indptr, d_t_indices, d_t_perm, d_rowmap, n, d_f_indptr,
+                     d_f_indices, d_f_perm);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -1431,6 +1431,7 @@ class _SageDense(torch.autograd.Function):
             _SageDense.chained_calls += 1
         return dX, dWs, dWn, dbi, dsc, dof
 
+    filtered_spmm_calls = 0  # ... whose transposed aggregate ran over the structure filtered to T
     sparse_top_calls = 0     # backward passes of a top layer that ran on the rows R u N(R) only
     compact_dz_calls = 0     # backward passes of the layer below such a pass that took dZ on the rows T only
 
@@ -1480,8 +1481,21 @@ class _SageDense(torch.autograd.Function):
         AtdZn = torch.empty(n, Fo, **f32)
         amx = torch.zeros(n, **f32)
         ew = adj.edge_w
-        nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
-        with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
+        if plan.f_indptr is not None and 128 < Fo <= 256:
+            # the transposed structure filtered to the columns T (tail.TopBackwardPlan): the rows' kept entries in their
+            # original order -- the sums of the row-mapped walk below without its zero terms -- gathered from the compact
+            # gradient (22 MB: L2 / Infinity Cache), row maxima from the same pass
+            ef = plan.f_nnz
+            rsT = adj.row_scale.index_select(0, Tl) if adj.row_scale is not None else None
+            nbytes = 4 * (n + 1) + 4 * ef + (8 * ef if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
+            with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
+                check(lib.sl_spmm_csr_amax_f32(plan.f_indptr.data_ptr(), plan.f_indices.data_ptr(), opt(ew),
+                                               plan.f_perm.data_ptr() if ew is not None else None, opt(adj.col_scale), opt(rsT),
+                                               dZnT.data_ptr(), dZnT.stride(0), AtdZn.data_ptr(), Fo, n, Fo, amx.data_ptr(), st))
+            _SageDense.filtered_spmm_calls += 1
+        else:
+          nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
+          with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
             check(lib.sl_spmm_blockdiag_rows_f32(ti.data_ptr(), tx.data_ptr(), opt(ew), tp.data_ptr() if ew is not None else None,
                                                  opt(adj.col_scale), opt(adj.row_scale), dZnT.data_ptr(), dZnT.stride(0), plan.rowmap.data_ptr(),
                                                  AtdZn.data_ptr(), Fo, n, Fo, off.data_ptr(), eoff.data_ptr(), int(off.numel()) - 1, mn,

@@ -221,19 +221,38 @@ class TopBackwardPlan:
         P = int(self.targets32.numel())
         cap = n + P
         i32 = dict(dtype=torch.int32, device=dev)
-        off = torch.empty(P + 2, **i32)
+        off = torch.zeros(P + 3, **i32)
         T, slot, epos, self_idx = torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(max(P, 1), **i32)
-        _lib.check(_lib.load().sl_top_plan(csr.indptr.data_ptr(), csr.indices.data_ptr(), self.targets32.data_ptr(), P, cap, off.data_ptr(),
-                                           T.data_ptr(), slot.data_ptr(), epos.data_ptr(), self_idx.data_ptr(), ops._stream(csr.indptr)))
-        t, bad = (int(x) for x in off[P:P + 2].tolist()) if P else (0, 0)          # (the one host sync)
+        lib = _lib.load()
+        st = ops._stream(csr.indptr)
+        _lib.check(lib.sl_top_plan(csr.indptr.data_ptr(), csr.indices.data_ptr(), self.targets32.data_ptr(), P, cap, off.data_ptr(),
+                                   T.data_ptr(), slot.data_ptr(), epos.data_ptr(), self_idx.data_ptr(), st))
+        # batch row -> its position in T, or all ones (any value >= t stands for "the zero row behind a [t, F] compact tensor":
+        # the row map of sl_spmm_blockdiag_rows_f32 / sl_gemm_an_bwd_corr), and -- round 5 -- the transposed adjacency restricted
+        # to the columns T: A^T dZn of the layer below the row-sparse pass has terms from the rows T only, its aggregation walks
+        # ~300 of a subgraph's ~2 000 transposed edges (ops._SageDense._compact_dz_backward).  Built by the same C call chain
+        # on this stream: still ONE host sync per plan.
+        self.rowmap = torch.empty(n, **i32)
+        self.f_indptr = self.f_indices = self.f_perm = None
+        self._t_keep = ()
+        if P and csr.e > 0:
+            ti, tx, tp = csr.transposed
+            self.f_indptr = torch.empty(n + 1, **i32)
+            self.f_indices, self.f_perm = torch.empty(csr.e, **i32), torch.empty(csr.e, **i32)
+            work = torch.empty(n // 1024 + 8, **i32)
+            _lib.check(lib.sl_top_plan_filter(T.data_ptr(), off.data_ptr(), P, cap, ti.data_ptr(), tx.data_ptr(), tp.data_ptr(), n,
+                                              self.rowmap.data_ptr(), self.f_indptr.data_ptr(), self.f_indices.data_ptr(),
+                                              self.f_perm.data_ptr(), work.data_ptr(), st))
+            self._t_keep = (ti, tx, tp, work)                     # (built on this stream: handed to the consumer's stream with the plan)
+        else:
+            self.rowmap.fill_(-1)
+        t, bad, ef = (int(x) for x in off[P:P + 3].tolist()) if P else (0, 0, 0)          # (the one host sync)
         self.ok = bool(P > 0 and bad == 0 and t <= cap)
         self.t = t if self.ok else 0
+        self.f_nnz = ef if self.ok else 0
+        if not self.ok:
+            self.f_indptr = self.f_indices = self.f_perm = None
         self.T32, self.slot, self.epos, self.self_idx = T[:self.t], slot[:self.t], epos[:self.t], self_idx[:P]
-        # batch row -> its position in T, or t (= "the zero row behind a [t, F] compact tensor"): the row map of
-        # sl_spmm_blockdiag_rows_f32 / sl_gemm_an_bwd_corr
-        self.rowmap = torch.full((n,), self.t, **i32)
-        if self.ok:
-            self.rowmap[self.T32.long()] = torch.arange(self.t, **i32)
         self.n = n
         self.num_roots = P
         self._indptr_ptr = csr.indptr.data_ptr()
@@ -242,7 +261,8 @@ class TopBackwardPlan:
         return self.ok and csr.n == self.n and csr.indptr.data_ptr() == self._indptr_ptr and num_roots == self.num_roots
 
     def tensors(self):
-        return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx, self.rowmap]
+        extra = [x for x in (self.f_indptr, self.f_indices, self.f_perm, *self._t_keep) if x is not None]
+        return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx, self.rowmap, *extra]
 
 
 def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_levels: int = 2, frac: float = 0.25) -> List[RectLevel]:

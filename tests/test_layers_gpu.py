@@ -1861,7 +1861,7 @@ def test_sparse_top_layer_backward_equals_dense(n_layers, p_drop, dropedge, act,
     (The dense pass computes the top layer's weight gradients and input gradient on two fp16 pieces, the sparse one in
     plain fp32: equal to the products' rounding.)"""
     from shadow_gnn_amd import ops
-    c0, d0 = ops._SageDense.sparse_top_calls, ops._SageDense.compact_dz_calls
+    c0, d0, f0 = ops._SageDense.sparse_top_calls, ops._SageDense.compact_dz_calls, ops._SageDense.filtered_spmm_calls
     l0, p0, g0, calls0 = _sage_stack_step(n_layers, 256, p_drop, 13, chain=True, fused=True, B=128, act=act, sparse_top=False, dropedge=dropedge)
     assert ops._SageDense.sparse_top_calls == c0
     l1, p1, g1, calls1 = _sage_stack_step(n_layers, 256, p_drop, 13, chain=True, fused=True, B=128, act=act, sparse_top=True, given_plan=given,
@@ -1870,6 +1870,8 @@ def test_sparse_top_layer_backward_equals_dense(n_layers, p_drop, dropedge, act,
     # the layer below takes dZ on the rows T only (K = F product + sparse addend) when a third layer is chained below it; in a
     # two-layer stack it is layer 0 and rebuilds the full-height dZ (the fallback)
     assert ops._SageDense.compact_dz_calls == d0 + (1 if n_layers >= 3 else 0)
+    # (round 5: ... and its transposed aggregate walked the structure filtered to the rows T -- dim 256, a plan that carries it)
+    assert ops._SageDense.filtered_spmm_calls == f0 + (1 if n_layers >= 3 else 0)
     assert abs(l0 - l1) < 1e-6
     torch.testing.assert_close(p1, p0, rtol=0, atol=0)                 # (the forward pass is the same pass)
     for k in g0:
