@@ -773,7 +773,8 @@ int sl_clip_adam(float *d_param, float *d_grad, float *d_exp_avg, float *d_exp_a
  *   subtraction, numerator * edge_w (drop-edge mask), denominator >= 1e-10
  *   nagg_i = sum_j p_ij hn_j / den_i
  * F = heads*D <= 256, D = 4*2^k.  Outputs hn[n,F], u_s/u_n/mx/den[n,heads]
- * are kept for the backward pass.                                             */
+ * are kept for the backward pass.  d_hn may be NULL (forward and backward alike): hn is then not materialised, the
+ * kernels apply the activation to the z_neigh rows they gather.                                                  */
 int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w,
                const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
                uint32_t F, uint32_t heads, float *d_hn, float *d_u_s, float *d_u_n, float *d_mx,

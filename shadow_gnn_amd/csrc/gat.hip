@@ -81,6 +81,9 @@ __device__ __forceinline__ RowWalk xcd_row_walk(uint32_t n, uint32_t rpb, uint32
   return w;
 }
 
+struct GatParams;
+__device__ __forceinline__ float4 gat_hn_row(const GatParams &p, uint64_t row, uint32_t f);
+
 struct GatParams {
   const uint32_t *indptr, *indices;       // CSR of the batch
   const uint32_t *t_indptr, *t_indices, *t_perm;
@@ -89,7 +92,7 @@ struct GatParams {
   const float *att;                       // [2, H, D]
   int act;
   uint32_t n, F, H, D;
-  float *hn;                              // [n, F]  act(z_neigh)
+  float *hn;                              // [n, F]  act(z_neigh), or NULL: recomputed from z_neigh wherever it is read (round 5)
   float *u_s, *u_n;                       // [n, H]  pre-leakyrelu scores
   float *mx, *den;                        // [n, H]
   float *nagg;                            // [n, F]  output
@@ -103,6 +106,13 @@ struct GatParams {
   float *datt;                            // [2, H, D]
   float *datt_part;                       // [gridDim.x][2][F] per-block sums, reduced in block order (gat_datt_finish_kernel)
 };
+
+// hn = act(z_neigh) of one row slice: the materialised copy, or -- hn not kept -- the activation applied where the row is
+// gathered (one [n, F] write per forward pass and one read per backward pass less; the edge kernels wait for their gathers,
+// the few extra VALU operations per gathered float4 ride in that shadow)
+__device__ __forceinline__ float4 gat_hn_row(const GatParams &p, uint64_t row, uint32_t f) {
+  return p.hn ? gld4(p.hn + row * p.F + f) : act4(p.act, gld4(p.z_neigh + row * p.F + f));
+}
 
 template <int LPR>
 __global__ void gat_node_fwd_kernel(GatParams p) {
@@ -118,7 +128,7 @@ __global__ void gat_node_fwd_kernel(GatParams p) {
     if (on) {
       hs = act4(p.act, gld4(p.z_self + r * p.F + f));
       hn = act4(p.act, gld4(p.z_neigh + r * p.F + f));
-      gst4(p.hn + r * p.F + f, hn);
+      if (p.hn) gst4(p.hn + r * p.F + f, hn);
     }
     const float us = slice_sum(dot4(a0, hs), ls), un = slice_sum(dot4(a1, hn), ls);
     if (on && (l % ls) == 0) { p.u_s[r * p.H + h] = us; p.u_n[r * p.H + h] = un; }
@@ -150,7 +160,7 @@ __device__ __forceinline__ void gat_fwd_group(const GatParams &p, uint32_t q, ui
 #pragma unroll
   for (int j = 0; j < G; j++) {
     u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-    v[j] = on ? gld4(p.hn + (uint64_t)c[j] * p.F + f) : make_float4(0, 0, 0, 0);
+    v[j] = on ? gat_hn_row(p, c[j], f) : make_float4(0, 0, 0, 0);
   }
 #pragma unroll
   for (int j = 0; j < G; j++) {
@@ -174,7 +184,7 @@ __device__ __forceinline__ void gat_fwd_group_online(const GatParams &p, uint32_
 #pragma unroll
   for (int j = 0; j < G; j++) {
     u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-    v[j] = on ? gld4(p.hn + (uint64_t)c[j] * p.F + f) : make_float4(0, 0, 0, 0);
+    v[j] = on ? gat_hn_row(p, c[j], f) : make_float4(0, 0, 0, 0);
   }
   float gm = m;
 #pragma unroll
@@ -203,7 +213,7 @@ __device__ __forceinline__ void gat_bwd_row_group(const GatParams &p, uint32_t q
 #pragma unroll
   for (int j = 0; j < G; j++) {
     u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-    v[j] = on ? gld4(p.hn + (uint64_t)c[j] * p.F + f) : make_float4(0, 0, 0, 0);
+    v[j] = on ? gat_hn_row(p, c[j], f) : make_float4(0, 0, 0, 0);
   }
 #pragma unroll
   for (int j = 0; j < G; j++) {
@@ -423,7 +433,7 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
     if (on) {
       const float dun = dan * dlrelu02(p.u_n[r * p.H + h]);
       const float4 z = gld4(p.z_neigh + r * p.F + f);
-      const float4 hn = gld4(p.hn + r * p.F + f);
+      const float4 hn = p.hn ? gld4(p.hn + r * p.F + f) : act4(p.act, z);
       acc.x += dun * a1.x; acc.y += dun * a1.y; acc.z += dun * a1.z; acc.w += dun * a1.w;
       const float4 dzv = make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
                                      acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w));
@@ -520,7 +530,7 @@ extern "C" int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
                           uint32_t n, uint32_t F, uint32_t heads, float *d_hn, float *d_u_s,
                           float *d_u_n, float *d_mx, float *d_den, float *d_nagg, void *stream_) {
-  if (!d_indptr || !d_z_self || !d_z_neigh || !d_att || !d_hn || !d_u_s || !d_u_n || !d_mx || !d_den || !d_nagg)
+  if (!d_indptr || !d_z_self || !d_z_neigh || !d_att || !d_u_s || !d_u_n || !d_mx || !d_den || !d_nagg)
     return set_error(SG_ERR_INVALID, "sl_gat_fwd: null argument");
   if (act < 0 || act > 4) return set_error(SG_ERR_INVALID, "sl_gat_fwd: unknown activation %d", act);
   uint32_t lpr;
@@ -547,7 +557,7 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
                           const float *d_nagg, const float *d_dnagg, float *d_work, float *d_dz_self,
                           float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
-  if (!d_indptr || !d_t_indptr || !d_z_self || !d_z_neigh || !d_att || !d_hn || !d_u_s || !d_u_n || !d_mx ||
+  if (!d_indptr || !d_t_indptr || !d_z_self || !d_z_neigh || !d_att || !d_u_s || !d_u_n || !d_mx ||
       !d_den || !d_nagg || !d_dnagg || !d_work || !d_dz_self || !d_dz_neigh || !d_datt)
     return set_error(SG_ERR_INVALID, "sl_gat_bwd: null argument");
   uint32_t lpr;

@@ -6,6 +6,21 @@ from . import _lib, ops
 from ._lib import check
 
 
+# True: hn = act(z_neigh) is not materialised -- the edge kernels apply the activation to the z_neigh rows they gather (one [n, F]
+# tensor less kept per layer, one write per forward and one read per backward pass less).  Measured on the depth-3 products
+# batches with elu (round 5, same box): gat_fwd 0.463 -> 0.592 ms, gat_bwd 0.948 -> 1.213 ms, step 11.59 -> 12.94 ms -- the gathers
+# are issue-bound, four expm1f per gathered float4 cost more than the [n, F] stream they save.  Off; kept as the memory option.
+RECOMPUTE_HN = False
+
+
+def _hn_buffer(n, F, dev):
+    return None if RECOMPUTE_HN else torch.empty(n, F, device=dev)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None and t.numel() else None
+
+
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z_self, z_neigh, attention, adj, act_code, heads):
@@ -15,7 +30,7 @@ class _GatAggregate(torch.autograd.Function):
         n, F = z_self.shape
         dev = z_self.device
         c = adj.csr
-        hn = torch.empty(n, F, device=dev)
+        hn = _hn_buffer(n, F, dev)
         u_s = torch.empty(n, heads, device=dev); u_n = torch.empty(n, heads, device=dev)
         mx = torch.empty(n, heads, device=dev); den = torch.empty(n, heads, device=dev)
         nagg = torch.empty(n, F, device=dev)
@@ -26,9 +41,9 @@ class _GatAggregate(torch.autograd.Function):
         with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_fwd(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
                                          z_self.data_ptr(), z_neigh.data_ptr(), att.data_ptr(), act_code, n, F, heads,
-                                         hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
+                                         _p(hn), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
                                          nagg.data_ptr(), ops._stream(z_self)))
-        ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg)
+        ctx.save_for_backward(z_self, z_neigh, att, hn if hn is not None else att.new_empty(0), u_s, u_n, mx, den, nagg)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape)
         ops.fire_deferred()               # (the step's first aggregation is enqueued: see ops.defer)
         return nagg
@@ -52,7 +67,7 @@ class _GatAggregate(torch.autograd.Function):
         with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
-                                         att.data_ptr(), act_code, n, c.e, F, heads, hn.data_ptr(), u_s.data_ptr(),
+                                         att.data_ptr(), act_code, n, c.e, F, heads, _p(hn), u_s.data_ptr(),
                                          u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
                                          work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 0, None,
                                          ops._stream(dnagg)))
@@ -74,7 +89,7 @@ class _GatTail(torch.autograd.Function):
         n, F = z_self.shape
         dev = z_self.device
         c = adj.csr
-        hn = torch.empty(n, F, device=dev)
+        hn = _hn_buffer(n, F, dev)
         u_s = torch.empty(n, heads, device=dev); u_n = torch.empty(n, heads, device=dev)
         mx = torch.empty(n, heads, device=dev); den = torch.empty(n, heads, device=dev)
         nagg = torch.empty(n, F, device=dev)
@@ -83,13 +98,13 @@ class _GatTail(torch.autograd.Function):
         with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_fwd(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
                                          z_self.data_ptr(), z_neigh.data_ptr(), att.data_ptr(), act_code, n, F, heads,
-                                         hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
+                                         _p(hn), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
                                          nagg.data_ptr(), ops._stream(z_self)))
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
         # reference order: f_norm([neigh, self]) -> scale[0] = neigh (identity: the aggregate is activated already), scale[1] = self
         out = ops._an_fwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, drop)
-        ctx.save_for_backward(z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of)
+        ctx.save_for_backward(z_self, z_neigh, att, hn if hn is not None else att.new_empty(0), u_s, u_n, mx, den, nagg, sc, of)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape, seg, out_scale, drop, scale.shape, offset.shape)
         ctx.link_roots = None
         ctx.pair = pair                                       # (ops.PairLink of the node that produced z_self and z_neigh, or None)
@@ -132,7 +147,8 @@ class _GatTail(torch.autograd.Function):
         ti, tx, tp = csr_c.transposed
         w = adj.edge_w.index_select(0, level.edge_pos.index_select(0, order)) if adj.edge_w is not None else None
         g = lambda x: x.index_select(0, Tl)
-        zs_c, zn_c, hn_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(z_neigh), g(hn), g(u_s), g(u_n), g(mx), g(den), g(nagg)
+        zs_c, zn_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(z_neigh), g(u_s), g(u_n), g(mx), g(den), g(nagg)
+        hn_c = g(hn) if hn.numel() else None
         dn_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dn_r)
         dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_r)
         dzn_c = torch.empty(t, F, **f32)
@@ -142,7 +158,7 @@ class _GatTail(torch.autograd.Function):
         with ops._timed(f"gat_bwd_rows_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(csr_c.indptr.data_ptr(), csr_c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, zs_c.data_ptr(), zn_c.data_ptr(),
-                                         att.data_ptr(), act_code, t, E, F, heads, hn_c.data_ptr(), us_c.data_ptr(),
+                                         att.data_ptr(), act_code, t, E, F, heads, _p(hn_c), us_c.data_ptr(),
                                          un_c.data_ptr(), mx_c.data_ptr(), den_c.data_ptr(), na_c.data_ptr(), dn_c.data_ptr(),
                                          work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
         pair = ctx.pair
@@ -190,11 +206,11 @@ class _GatTail(torch.autograd.Function):
         w = adj.edge_w
         # (round 5: both CSR structures; the incoming gradient, the aggregate, z_neigh and hn in, dz_neigh out -- dz_self / z_self are
         #  no longer touched: the attention's share of dz_self is exactly zero, see gat_row_bwd_kernel)
-        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + 5 * 4 * n * F + 6 * 4 * n * heads
+        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + (4 if RECOMPUTE_HN else 5) * 4 * n * F + 6 * 4 * n * heads
         with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
-                                         att.data_ptr(), act_code, n, c.e, F, heads, hn.data_ptr(), u_s.data_ptr(),
+                                         att.data_ptr(), act_code, n, c.e, F, heads, _p(hn), u_s.data_ptr(),
                                          u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
                                          work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 1,
                                          amax.data_ptr() if amax is not None else None, ops._stream(dnagg)))
