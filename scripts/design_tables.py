@@ -31,6 +31,7 @@ ROC = {
     "gather_F100": "gather_rows_drop_kernel<32>",
     "spmm_F256": "spmm_blockdiag_kernel<false>",
     "spmm_F100": "spmm_blockdiag_kernel<false>",
+    "spmm_rows_F256": "spmm_pipe_kernel",
 }
 HBM, MFMA6, MFMA3 = 8000.0, 2500.0 / 6.0, 2500.0 / 3.0
 

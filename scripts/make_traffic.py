@@ -104,7 +104,7 @@ if [k for k in fetch if "gemm_nt_fused_kernel<8, 1, 1, 2, false>" in k] and len(
     put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>", 1, 2)
 else:
     put("gemm_an_bwd_nb2_N256", "gemm_nt_fused_kernel<8, 1, 1, 2, false>")
-put("spmm_rows_F256", ("spmm_blockdiag_kernel<2>", "spmm_blockdiag_kernel<true>"))
+put("spmm_rows_F256", ("spmm_pipe_kernel", "spmm_blockdiag_kernel<2>", "spmm_blockdiag_kernel<true>"))   # (round 5: the filtered transposed structure on the pipelined kernel)
 if [k for k in fetch if "gemm_tn_f16_kernel" in k]:
     put("gemm_tn_f16_pair_N256", "gemm_tn_f16_kernel")
 if [k for k in fetch if "gemm_tn_coop_kernel<4, true>" in k]:
@@ -123,7 +123,7 @@ if os.path.exists(path):
         cur = {}
 cur[workload] = t
 cur["_source"] = (f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv (separate rocprofv3 --pmc passes of bench.py --steps 10 "
-                  "--warmup 3, scripts/collect_profiles.sh); read bytes = 2*FETCH_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md), "
+                  "--warmup 3, scripts/collect_profiles.sh); read bytes = 2*FETCH_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md; calibrated on known-byte kernels in every access shape of this repository, profiles/r05_pmc_calibration.md: 2*FETCH_SIZE*1024 = bytes of the 128-B lines touched, WRITE_SIZE*1024 = bytes written at 32-B granularity), "
                   "write bytes = WRITE_SIZE*1024; per-launch means by kernel; launches of one kernel that differ in shape (SpMM F = 100 / 256) "
                   "are separated by counter value (scripts/make_traffic.py); "
                   "sg_sample_pipeline = select + plan + scan kernels of one call")
