@@ -253,6 +253,8 @@ class TopBackwardPlan:
         if not self.ok:
             self.f_indptr = self.f_indices = self.f_perm = None
         self.T32, self.slot, self.epos, self.self_idx = T[:self.t], slot[:self.t], epos[:self.t], self_idx[:P]
+        if not (P and csr.e > 0) and self.ok:                      # (a batch without a single edge: no transposed structure to filter)
+            self.rowmap[self.T32.long()] = torch.arange(self.t, **i32)
         self.n = n
         self.num_roots = P
         self._indptr_ptr = csr.indptr.data_ptr()
