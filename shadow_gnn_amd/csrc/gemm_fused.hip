@@ -705,7 +705,12 @@ inline void set_images(FusedDesc &p, const void *packed, int nimg, uint32_t N, u
 template <int TW, int MODE, int NBP, int NBA>
 int launch_fused(FusedDesc d, hipStream_t st) {
   // ring of three k-step images (3 x 2 TW KB) or the epilogue's stash (4 wavefronts x 16 rows x 32 TW floats), whichever is larger
-  const size_t lds = MODE == 2 ? (size_t)3 * 2 * TW * 64 * 16 : std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
+  const size_t lds_ = MODE == 2 ? (size_t)3 * 2 * TW * 64 * 16 : std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
+#ifdef FUSED_ONE_WG          // (experiment, scripts/micro/ko_one_wg.sh: one workgroup per CU -- a single wavefront per SIMD)
+  const size_t lds = std::max<size_t>(lds_, (size_t)84 * 1024);
+#else
+  const size_t lds = lds_;
+#endif
   const uint32_t grid = (d.M + 127) / 128;
   if (d.K % 32 == 0) {
     if (lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>, lds));
