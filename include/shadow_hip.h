@@ -657,6 +657,12 @@ int sl_sage_stack_bwd(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, c
                       const sl_sage_stack_layer *layers, const float *d_dout, const uint32_t *d_dout_rows, uint32_t num_dout_rows,
                       float *d_dX0, float *d_buf, float *d_amax, float *d_an_partial, float *d_chain_partial, float *d_tn_partial,
                       void *d_pack, void *stream);
+/* The lower part of a stack whose top layers ran row-sparse (round 5): the chained dense passes of sl_sage_stack_bwd over the
+ * layers 0 .. L - 1 of `layers`, where layer L - 1's [dZs | . | dZn] (d_top_buf, [n, 3 Fout]), its row maxima (d_top_amax) and its
+ * dscale / doffset / dbias were already produced by the caller (sl_gemm_an_bwd_corr of the layer above).                      */
+int sl_sage_stack_bwd_ready(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, const float *d_x0_amax, uint32_t L,
+                            const sl_sage_stack_layer *layers, float *d_top_buf, const float *d_top_amax, float *d_dX0, float *d_buf,
+                            float *d_amax, float *d_chain_partial, float *d_tn_partial, void *d_pack, void *stream);
 
 /* One GCN layer pass per call (shaDow/layers.py:417-444 and its autograd):  out = norm(act((A X) W^T + b))  [+ the next
  * layer's input dropout / dual output as above].  forward: SpMM -> weight pack -> split-bf16 GEMM -> fused bias / act /

@@ -167,6 +167,8 @@ SIGNATURES = {
     "sl_sage_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P]),
     "sl_sage_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P, C.c_uint32,
                                      _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sl_sage_stack_bwd_ready": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P,
+                                           _P, _P, _P, _P, _P, _P, _P]),
     "sl_gcn_stack_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.POINTER(SlGcnStackLayer)]),
     "sl_gcn_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.POINTER(SlGcnStackLayer), _P, _P]),
     "sl_gcn_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), C.c_uint32, C.POINTER(SlGcnStackLayer), _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
@@ -240,7 +242,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 19      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 20      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -383,6 +383,45 @@ extern "C" int sl_sage_stack_bwd(const sl_norm_adj *adj, const float *d_X0, int6
   return SG_OK;
 }
 
+// The lower part of a stack whose top layers ran row-sparse (round 5): layers 0 .. L - 1 of `ly`, layer L - 1's
+// [dZs | . | dZn], its row maxima and its dscale / doffset / dbias already produced by the caller (the K = F product with the
+// sparse addend of the layer above, sl_gemm_an_bwd_corr) in d_top_buf / d_top_amax; from there down the chained dense passes
+// of sl_sage_stack_bwd.
+extern "C" int sl_sage_stack_bwd_ready(const sl_norm_adj *adj, const float *d_X0, int64_t ldx0, const float *d_x0_amax, uint32_t L,
+                                       const sl_sage_stack_layer *ly, float *d_top_buf, const float *d_top_amax, float *d_dX0, float *d_buf,
+                                       float *d_amax, float *d_chain_partial, float *d_tn_partial, void *d_pack, void *stream) {
+  int rc;
+  if ((rc = stack_check(adj, d_X0, L, ly, "sl_sage_stack_bwd_ready")) != SG_OK) return rc;
+  if (!d_top_buf || !d_buf || !d_amax || !d_tn_partial || !d_pack || (L > 1 && !d_chain_partial))
+    return set_error(SG_ERR_INVALID, "sl_sage_stack_bwd_ready: null argument");
+  const uint32_t n = adj->n;
+  uint32_t Fmax = 0;
+  for (uint32_t l = 0; l < L; ++l) Fmax = std::max(Fmax, ly[l].Fout);
+  const size_t half = (size_t)n * 3 * Fmax;
+  for (uint32_t l = L; l-- > 0;) {
+    const sl_sage_stack_layer &y = ly[l];
+    const bool top = l + 1 == L;
+    float *buf = top ? d_top_buf : d_buf + (l & 1u) * half;
+    float *am = top ? const_cast<float *>(d_top_amax) : d_amax + (l & 1u) * (size_t)n;
+    sl_sage_below below;
+    if (l > 0) {
+      const sl_sage_stack_layer &b = ly[l - 1];
+      if (y.Fout % 32) return set_error(SG_ERR_INVALID, "sl_sage_stack_bwd_ready: chained layers need Fout %% 32 == 0 (layer %u: %u)", l, y.Fout);
+      below.Zs = b.Zs, below.Zn = b.Zn, below.bs = b.bs, below.bn = b.bn, below.scale = b.scale, below.offset = b.offset;
+      below.act = b.act, below.drop_p = b.drop_p, below.drop_seed = b.drop_seed, below.F = b.Fout;
+      below.buf = d_buf + ((l - 1) & 1u) * half, below.dscale = b.dscale, below.doffset = b.doffset, below.dbias = b.dbias;
+      below.partial = d_chain_partial, below.amax = d_amax + ((l - 1) & 1u) * (size_t)n, below.stats = b.row_stats;
+    }
+    const float *X = l ? ly[l - 1].out : d_X0;
+    if ((rc = sl_sage_bwd_chain(adj, X, l ? (int64_t)ly[l - 1].Fout : ldx0, y.AX, y.ldax, y.Zs, y.Zn, y.Fin, y.Fout, y.Ws, y.ldws, y.bs, y.Wn,
+                                y.ldwn, y.bn, y.scale, y.offset, y.act, y.drop_p, y.drop_seed, nullptr, nullptr,
+                                l == 0 ? d_dX0 : nullptr, y.dWs, y.dWn, y.dbias, y.dscale, y.doffset, buf, nullptr, d_tn_partial, d_pack,
+                                1, l > 0 ? &below : nullptr, am, nullptr, 0, l ? ly[l - 1].out_amax : d_x0_amax, stream)) != SG_OK)
+      return rc;
+  }
+  return SG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // GCN (shaDow/layers.py:417-444): out = norm(act((A X) W^T + b)).  Forward: SpMM, weight pack, GEMM, fused bias / act /
 // norm; backward: act_norm backward, dAX = dZ W, dX = A^T dAX, dW = dZ^T (A X).

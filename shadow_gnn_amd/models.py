@@ -182,12 +182,13 @@ class DeepGNN(nn.Module):
 
     def _run_stack(self, kind, convs, feat, adj, tgt, dropedge):
         """The whole GraphSAGE / GCN stack + the read-out's row select as one node (ops._SageStack / ops._GcnStack: one C call per
-        direction), or None when this batch goes layer by layer: GraphSAGE training batches large enough for the row-sparse
-        top-layer backward (ops.SPARSE_TOP_BWD, a different set of kernels), a layer 0 that gathers inside its aggregation kernel."""
+        direction; large GraphSAGE training batches: the two top layers' backward row-sparse from the node, the rest one C call),
+        or None when this batch goes layer by layer (a layer 0 that gathers inside its aggregation kernel, frozen parameters)."""
         first = convs[0]
         n = int(feat.shape[0])
-        if kind == 'sage' and self.training and torch.is_grad_enabled() and ops.SPARSE_TOP_BWD and n >= ops.SPARSE_TOP_BWD_MIN_ROWS:
-            return None
+        sparse_top = kind == 'sage' and self.training and torch.is_grad_enabled() and ops.SPARSE_TOP_BWD and n >= ops.SPARSE_TOP_BWD_MIN_ROWS
+        if sparse_top and not ops.sparse_top_stack_usable(adj, convs):
+            return None                                      # (the row-sparse top pass of the layer-by-layer nodes)
         if n < max(1, ops.GEMM_SPLIT_MIN_ROWS) or not feat.is_cuda:
             return None
         lazy = isinstance(feat, ops.LazyRows)
@@ -204,7 +205,20 @@ class DeepGNN(nn.Module):
             x0, _seed = feat.gather_dropped(first._in_p())
         else:
             x0 = first.in_dropout(feat)
-        emb = (ops.sage_stack if kind == 'sage' else ops.gcn_stack)(x0, adj_norm, convs, tgt)
+        if kind == 'sage':
+            plan = None
+            if sparse_top:
+                # (training batches large enough for the row-sparse backward of the two top layers: the row sets the minibatch
+                #  extractor built on its prefetch stream, or -- hand-made batches -- built here with two host syncs)
+                plan = getattr(tgt, "_shd_top_plan", None)
+                if plan is None or not plan.matches(adj_norm.csr, int(tgt.numel())):
+                    from . import tail
+                    plan = tail.TopBackwardPlan(adj_norm.csr, tgt)
+                if not plan.matches(adj_norm.csr, int(tgt.numel())):
+                    plan = None                              # (a multigraph root row: the dense pass)
+            emb = ops.sage_stack(x0, adj_norm, convs, tgt, plan)
+        else:
+            emb = ops.gcn_stack(x0, adj_norm, convs, tgt)
         assert emb is not None
         return emb
 

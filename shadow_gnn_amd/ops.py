@@ -641,13 +641,14 @@ GEMM_SPLIT_MIN_ROWS = int(os.environ.get("SHADOW_GEMM_SPLIT_MIN_ROWS", "1024"))
 GEMM_SPLIT = True
 
 
-def mm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+def mm_nt(A: torch.Tensor, B: torch.Tensor, min_rows: Optional[int] = None) -> torch.Tensor:
     """A[M,K] @ B[N,K]^T in fp32.  Tall products (M >= GEMM_SPLIT_MIN_ROWS, N <= 256) run on the bf16 matrix cores
     with the exact three-way operand split (fp32-level accuracy, see csrc/gemm.hip); the rest goes to
-    rocBLAS."""
+    rocBLAS.  ``min_rows``: the caller's own threshold (the row-sparse backward's products over the roots: a rocBLAS call
+    with a transposed operand costs 0.2 - 0.8 ms of HOST time on MI355X, scripts/host_breakdown.py)."""
     M, K = A.shape
     N = B.shape[0]
-    if not (GEMM_SPLIT and A.is_cuda and M >= GEMM_SPLIT_MIN_ROWS and N <= 256 and A.dtype == torch.float32
+    if not (GEMM_SPLIT and A.is_cuda and M >= (GEMM_SPLIT_MIN_ROWS if min_rows is None else min_rows) and N <= 256 and A.dtype == torch.float32
             and A.stride(1) == 1 and A.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0):
         return A @ B.t()
     lib = _lib.load()
@@ -715,16 +716,16 @@ def weight_grad_f16_usable(dZ: torch.Tensor, X: torch.Tensor) -> bool:
 TN_F16 = True
 
 
-def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False):
+def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False, min_rows: Optional[int] = None):
     """dW = dZ^T X for tall inputs (K = number of batch nodes, hundreds of thousands).
     rocBLAS picks a 32-workgroup kernel for a plain 256 x n x 256 product; splitting n
     into a batched GEMM fills the chip (2x faster on MI355X) and the partial sums add
     in a fixed order.  ``want_colsum``: returns (dW, dZ.sum(0)) -- nn.Linear's bias gradient from the same pass over dZ."""
     if want_colsum:
-        return _weight_grad_colsum(dZ, X)
+        return _weight_grad_colsum(dZ, X, min_rows)
     n, Fo = dZ.shape
     Fi = X.shape[1]
-    if (GEMM_SPLIT and dZ.is_cuda and n >= GEMM_SPLIT_MIN_ROWS and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
+    if (GEMM_SPLIT and dZ.is_cuda and n >= (GEMM_SPLIT_MIN_ROWS if min_rows is None else min_rows) and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
             and dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.stride(1) == 1 and X.stride(1) == 1
             and dZ.stride(0) % 4 == 0 and X.stride(0) % 4 == 0 and dZ.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0):
         lib = _lib.load()
@@ -746,17 +747,17 @@ def weight_grad(dZ: torch.Tensor, X: torch.Tensor, want_colsum: bool = False):
     return dW
 
 
-def _tn_usable(dZ, X) -> bool:
+def _tn_usable(dZ, X, min_rows=None) -> bool:
     n, Fo = dZ.shape
     Fi = X.shape[1]
-    return (GEMM_SPLIT and dZ.is_cuda and n >= GEMM_SPLIT_MIN_ROWS and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
+    return (GEMM_SPLIT and dZ.is_cuda and n >= (GEMM_SPLIT_MIN_ROWS if min_rows is None else min_rows) and Fo <= 256 and Fi <= 256 and Fo % 4 == 0 and Fi % 4 == 0
             and dZ.dtype == torch.float32 and X.dtype == torch.float32 and dZ.stride(1) == 1 and X.stride(1) == 1
             and dZ.stride(0) % 4 == 0 and X.stride(0) % 4 == 0 and dZ.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0)
 
 
-def _weight_grad_colsum(dZ, X):
-    if not _tn_usable(dZ, X):
-        return weight_grad(dZ, X), dZ.sum(0)
+def _weight_grad_colsum(dZ, X, min_rows=None):
+    if not _tn_usable(dZ, X, min_rows):
+        return weight_grad(dZ, X, min_rows=min_rows), dZ.sum(0)
     n, Fo = dZ.shape
     Fi = X.shape[1]
     lib = _lib.load()
@@ -843,16 +844,31 @@ class _LinearPair(torch.autograd.Function):
         XT = X.index_select(0, Tl)
         ng = ctx.needs_input_grad
         out = [None] * 7
-        if ng[1]:
-            out[1] = dza.t() @ XT
-        if ng[3]:
-            out[3] = dzb.t() @ XT
-        if ctx.has_bias[0] and ng[2]:
-            out[2] = dza.sum(0)
-        if ctx.has_bias[1] and ng[4]:
-            out[4] = dzb.sum(0)
+        # (the library's own kernels from ROOT_GEMM_MIN_ROWS rows on: a rocBLAS call with a transposed operand costs 0.2 - 0.8 ms of
+        #  host time here, and the bias gradient comes out of the weight gradient's pass over dZ)
+        for i, dz in ((0, dza), (1, dzb)):
+            want_w, want_b = ng[1 + 2 * i], ctx.has_bias[i] and ng[2 + 2 * i]
+            if want_b:
+                dW, db = weight_grad(dz, XT, want_colsum=True, min_rows=ROOT_GEMM_MIN_ROWS)
+                out[1 + 2 * i], out[2 + 2 * i] = (dW if want_w else None), db
+            elif want_w:
+                out[1 + 2 * i] = weight_grad(dz, XT, min_rows=ROOT_GEMM_MIN_ROWS)
         if ng[0]:
-            dXT = torch.addmm(dza @ Wa, dzb, Wb)               # [t, K]
+            t, N = dza.shape
+            lib = _lib.load()
+            if (GEMM_SPLIT and t >= ROOT_GEMM_MIN_ROWS and K <= 256 and dza.stride(1) == 1 and dzb.stride(1) == 1 and dza.stride(0) % 4 == 0
+                    and dzb.stride(0) % 4 == 0 and dza.data_ptr() % 16 == 0 and dzb.data_ptr() % 16 == 0 and lib.sl_gemm_act_norm_supported(K, 2 * N)):
+                # [dZa | dZb] . [Wa ; Wb] on the rows T: the K-concatenated product of the dense pass (sl_gemm_nt_cat_f32)
+                st = _stream(X)
+                pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(K, 2 * N), dtype=torch.uint8, device=X.device)
+                wa, wb = Wa.detach(), Wb.detach()
+                check(lib.sl_gemm_act_norm_pack_b2(wa.data_ptr(), wa.stride(1), wa.stride(0), N, wb.data_ptr(), wb.stride(1), wb.stride(0),
+                                                   K, 2 * N, pack.data_ptr(), st))
+                dXT = torch.empty(t, K, dtype=torch.float32, device=X.device)
+                check(lib.sl_gemm_nt_cat_f32(dza.data_ptr(), dza.stride(0), N, dzb.data_ptr(), dzb.stride(0), None, pack.data_ptr(), t, K, 2 * N,
+                                             None, dXT.data_ptr(), dXT.stride(0), st))
+            else:
+                dXT = torch.addmm(dza @ Wa, dzb, Wb)           # [t, K]
             link = ctx.in_link
             if link is not None:
                 link.rows32, link.grad, link.plan, link.levels = rows32, dXT, None, (levels or None)
@@ -1155,6 +1171,15 @@ SPARSE_TOP_BWD = os.environ.get("SHADOW_SPARSE_TOP_BWD", "1") != "0"
 # below: ~20 small launches cost more host time than the three dense kernels cost GPU time (products shape, 128 roots = 36 k rows:
 # 2.14 ms / step dense, 2.87 with the row-sparse pass; 1 024 roots = 289 k rows: 7.28 -> 6.59)
 SPARSE_TOP_BWD_MIN_ROWS = int(os.environ.get("SHADOW_SPARSE_TOP_BWD_MIN_ROWS", "131072"))
+# the row-sparse pass from the whole-stack node (_SageStack._sparse_top: the layers below it in ONE C call) instead of the
+# layer-by-layer nodes (False: tests compare the two)
+SPARSE_TOP_STACK = True
+# the row-sparse passes' small products on the library's own kernels from this many rows on, torch.mm / rocBLAS below.  Same-box
+# A/B (scripts/ab_root_gemm.sh, scripts/ab_top_stack.sh): the GAT stack's products over the rows T (~20 k rows) 11.63 -> 11.45 ms
+# per step on the own kernels; the GraphSAGE top layer's four products over the 1 024 roots 6.37 -> 6.46 (a workgroup covers 128
+# rows: 8 workgroups) -- although rocBLAS holds the HOST for 0.2 - 0.8 ms per call with a transposed operand there
+# (scripts/host_breakdown.py), which the GPU-bound step hides.
+ROOT_GEMM_MIN_ROWS = 2048
 # a level of tail.build_backward_levels is kept while its input set is at most this share of the batch (built on the spot by
 # select_roots when the batch brings none)
 BACKWARD_LEVELS_FRAC = 0.25
@@ -1213,6 +1238,41 @@ def select_roots(f: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
     if link is None or not link.published or not ROOTS_SPARSE_GRAD:
         return f[rows]
     return _SelectRoots.apply(f, rows, link, torch.is_grad_enabled())
+
+
+def _at_dzn_on_rows(adj: "NormAdj", plan, dZnT: torch.Tensor, n: int, Fo: int):
+    """(A^T dZn [n, Fo], its row maxima [n]) for a gradient dZn that lives on the rows T of ``plan`` (``dZnT`` [t + 1, Fo]: the
+    compact rows and a zero row behind them).  Transposed structure: row scale <- the adjacency's column scale and vice versa."""
+    lib = _lib.load()
+    c = adj.csr
+    dev = dZnT.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    st = _stream(dZnT)
+    opt = lambda t_: t_.data_ptr() if t_ is not None else None
+    t = plan.t
+    AtdZn = torch.empty(n, Fo, **f32)
+    amx = torch.zeros(n, **f32)
+    ew = adj.edge_w
+    if plan.f_indptr is not None and 128 < Fo <= 256:
+        # the transposed structure filtered to the columns T (tail.TopBackwardPlan): the rows' kept entries in their
+        # original order -- the sums of the row-mapped walk below without its zero terms -- gathered from the compact
+        # gradient (22 MB: L2 / Infinity Cache), row maxima from the same pass
+        ef = plan.f_nnz
+        rsT = adj.row_scale.index_select(0, plan.T32.long()) if adj.row_scale is not None else None
+        nbytes = 4 * (n + 1) + 4 * ef + (8 * ef if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
+        with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
+            check(lib.sl_spmm_csr_amax_f32(plan.f_indptr.data_ptr(), plan.f_indices.data_ptr(), opt(ew),
+                                           plan.f_perm.data_ptr() if ew is not None else None, opt(adj.col_scale), opt(rsT),
+                                           dZnT.data_ptr(), dZnT.stride(0), AtdZn.data_ptr(), Fo, n, Fo, amx.data_ptr(), st))
+        _SageDense.filtered_spmm_calls += 1
+    else:
+      nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
+      with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
+        check(lib.sl_spmm_blockdiag_rows_f32(c.transposed[0].data_ptr(), c.transposed[1].data_ptr(), opt(ew), c.transposed[2].data_ptr() if ew is not None else None,
+                                             opt(adj.col_scale), opt(adj.row_scale), dZnT.data_ptr(), dZnT.stride(0), plan.rowmap.data_ptr(),
+                                             AtdZn.data_ptr(), Fo, n, Fo, c.spmm_blocks[0].data_ptr(), c.spmm_blocks[1].data_ptr(), int(c.spmm_blocks[0].numel()) - 1, c.spmm_blocks[2],
+                                             amx.data_ptr(), t, st))
+    return AtdZn, amx
 
 
 class _SageDense(torch.autograd.Function):
@@ -1476,30 +1536,7 @@ class _SageDense(torch.autograd.Function):
         Tl = plan.T32.long()
         dWs = weight_grad(dZsT, X.index_select(0, Tl))
         dWn = weight_grad(dZnT[:t], AX.index_select(0, Tl))
-        # A^T dZn over the row map (transposed structure: row scale <- the adjacency's column scale and vice versa)
-        ti, tx, tp = c.transposed
-        AtdZn = torch.empty(n, Fo, **f32)
-        amx = torch.zeros(n, **f32)
-        ew = adj.edge_w
-        if plan.f_indptr is not None and 128 < Fo <= 256:
-            # the transposed structure filtered to the columns T (tail.TopBackwardPlan): the rows' kept entries in their
-            # original order -- the sums of the row-mapped walk below without its zero terms -- gathered from the compact
-            # gradient (22 MB: L2 / Infinity Cache), row maxima from the same pass
-            ef = plan.f_nnz
-            rsT = adj.row_scale.index_select(0, Tl) if adj.row_scale is not None else None
-            nbytes = 4 * (n + 1) + 4 * ef + (8 * ef if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
-            with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
-                check(lib.sl_spmm_csr_amax_f32(plan.f_indptr.data_ptr(), plan.f_indices.data_ptr(), opt(ew),
-                                               plan.f_perm.data_ptr() if ew is not None else None, opt(adj.col_scale), opt(rsT),
-                                               dZnT.data_ptr(), dZnT.stride(0), AtdZn.data_ptr(), Fo, n, Fo, amx.data_ptr(), st))
-            _SageDense.filtered_spmm_calls += 1
-        else:
-          nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if ew is not None else 0) + 4 * n * Fo + 4 * t * Fo
-          with _timed(f"spmm_rows_F{Fo}", nbytes, dev):
-            check(lib.sl_spmm_blockdiag_rows_f32(ti.data_ptr(), tx.data_ptr(), opt(ew), tp.data_ptr() if ew is not None else None,
-                                                 opt(adj.col_scale), opt(adj.row_scale), dZnT.data_ptr(), dZnT.stride(0), plan.rowmap.data_ptr(),
-                                                 AtdZn.data_ptr(), Fo, n, Fo, off.data_ptr(), eoff.data_ptr(), int(off.numel()) - 1, mn,
-                                                 amx.data_ptr(), t, st))
+        AtdZn, amx = _at_dzn_on_rows(adj, plan, dZnT, n, Fo)
         corr = mm_nt(dZsT, Ws.t())                                  # dZs[T] Ws  [t, Fi]
         pack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
         check(lib.sl_gemm_act_norm_pack_b2(Wn.data_ptr(), 1, Wn.stride(0), Fo, Wn.data_ptr(), 1, Wn.stride(0), Fi, Fo, pack.data_ptr(), st))
@@ -1547,12 +1584,10 @@ class _SageDense(torch.autograd.Function):
         R = plan.rows64
         (dZsR, dZnR), dsc, dof, dbi = _an_bwd([Zs.index_select(0, R), Zn.index_select(0, R)], biases, acts, sc, of, Fo, 1.0, (lr.grad,),
                                               [True, True], any(has_b), (0.0, 0))
-        dWs = dZsR.t() @ X.index_select(0, R)
-        dWn = dZnR.t() @ AX.index_select(0, R)
+        dWs = weight_grad(dZsR, X.index_select(0, R), min_rows=ROOT_GEMM_MIN_ROWS)
+        dWn = weight_grad(dZnR, AX.index_select(0, R), min_rows=ROOT_GEMM_MIN_ROWS)
         # dX on the rows T: a row gets its root's neighbour term through the edge (root, row), the root itself the self term
-        GS = torch.empty(2, int(R.numel()), Fi, **f32)
-        torch.mm(dZnR, Wn, out=GS[0])
-        torch.mm(dZsR, Ws, out=GS[1])
+        GS = (mm_nt(dZnR, Wn.t(), min_rows=ROOT_GEMM_MIN_ROWS), mm_nt(dZsR, Ws.t(), min_rows=ROOT_GEMM_MIN_ROWS))
         adj = ctx.adj
         opt = lambda t_: t_.data_ptr() if t_ is not None else None
         dXT = torch.empty(plan.t, Fi, **f32)
@@ -1639,9 +1674,10 @@ class _SageStack(torch.autograd.Function):
     centre pooling on a node task (nothing but layer l + 1 reads layer l's output, nothing but the row select reads the last
     one), one hidden width F with F % 32 == 0 <= 256, no dual output."""
     calls = 0
+    sparse_top_calls = 0     # backward passes whose two top layers ran row-sparse from here (round 5)
 
     @staticmethod
-    def forward(ctx, X0, adj, rows, meta, grad_on, *params):
+    def forward(ctx, X0, adj, rows, meta, grad_on, plan, *params):
         lib = _lib.load()
         L = len(meta)
         n, F0 = X0.shape
@@ -1650,6 +1686,7 @@ class _SageStack(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
+        ctx.plan, ctx.meta_l = plan, meta
         keep_all = bool(grad_on) and any(ctx.needs_input_grad)   # (no backward pass will come -- no_grad keeps needs_input_grad True for live parameters --: nothing is kept: one Zs / Zn / A X slot, two `out` slots in turn)
         # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
         big = torch.empty(4 * L - 1, n, F, **f32) if keep_all else torch.empty(5 if L > 1 else 3, n, F, **f32)
@@ -1743,11 +1780,21 @@ class _SageStack(torch.autograd.Function):
             y.dbias = (bbase + l * sstep) if (ctx.has[6 * l + 1] or ctx.has[6 * l + 3]) else None
         a = _adj_struct(adj, want_dx0 or L > 1)
         rows32 = rows.to(torch.int32) if rows is not None else None
-        check(lib.sl_sage_stack_bwd(C.byref(a), X0.data_ptr(), X0.stride(0), ctx.x0_amax.data_ptr() if ctx.x0_amax is not None else None, L,
-                                    arr, d.data_ptr(), rows32.data_ptr() if rows32 is not None else None, r if rows32 is not None else 0,
-                                    dX0.data_ptr() if dX0 is not None else None, buf.data_ptr(), am.data_ptr(), an_partial.data_ptr(),
-                                    chain_partial.data_ptr() if chain_partial is not None else None, tn_partial.data_ptr(),
-                                    pack.data_ptr(), _stream(X0)))
+        plan = ctx.plan
+        top_g = None
+        if (plan is not None and SPARSE_TOP_BWD and L >= 3 and rows is not None and F % 32 == 0 and float(ctx.meta_l[L - 1][1]) == 0.0
+                and plan.matches(adj.csr, r) and plan.rowmap.numel() == n and lib.sl_gemm_act_norm_supported(F, F)
+                and adj.csr.spmm_blocks[0] is not None and F >= BLOCKDIAG_MIN_F):
+            # The read-out gradient lives on the roots: the top layer's backward pass on the rows R, the layer below it from the
+            # compact rows T = R u N(R) (the passes of _SageDense._sparse_top_backward / _compact_dz_backward on this node's
+            # buffers), then ONE C call for the dense chained passes of the layers below (sl_sage_stack_bwd_ready).
+            top_g = _SageStack._sparse_top(ctx, lib, a, d, plan, params, X0, arr, ds, db, buf, am, chain_partial, tn_partial, pack, dX0)
+        if top_g is None:
+            check(lib.sl_sage_stack_bwd(C.byref(a), X0.data_ptr(), X0.stride(0), ctx.x0_amax.data_ptr() if ctx.x0_amax is not None else None, L,
+                                        arr, d.data_ptr(), rows32.data_ptr() if rows32 is not None else None, r if rows32 is not None else 0,
+                                        dX0.data_ptr() if dX0 is not None else None, buf.data_ptr(), am.data_ptr(), an_partial.data_ptr(),
+                                        chain_partial.data_ptr() if chain_partial is not None else None, tn_partial.data_ptr(),
+                                        pack.data_ptr(), _stream(X0)))
         _SageDense.chained_calls += L - 1
         ctx.keep = ctx.arr = None
         # (one unbind per buffer instead of an index op per gradient: ~40 views per step)
@@ -1757,10 +1804,90 @@ class _SageStack(torch.autograd.Function):
         ng = ctx.needs_input_grad
         for l in range(L):
             hb_s, hb_n = ctx.has[6 * l + 1], ctx.has[6 * l + 3]
-            k = 5 + 6 * l
+            k = 6 + 6 * l
+            if top_g is not None and l in top_g:           # (the two row-sparse layers: their gradients are separate tensors)
+                tWs, tWn, tbi, tsc, tof = top_g[l]
+                grads += [tWs if ng[k] else None, tbi[0] if (hb_s and ng[k + 1] and tbi is not None) else None, tWn if ng[k + 2] else None,
+                          tbi[1] if (hb_n and ng[k + 3] and tbi is not None) else None, tsc if ng[k + 4] else None, tof if ng[k + 5] else None]
+                continue
             grads += [Wg[2 * l] if ng[k] else None, bg[2 * l] if (hb_s and ng[k + 1]) else None, Wg[2 * l + 1] if ng[k + 2] else None,
                       bg[2 * l + 1] if (hb_n and ng[k + 3]) else None, sg[2 * l] if ng[k + 4] else None, sg[2 * l + 1] if ng[k + 5] else None]
-        return (dX0, None, None, None, None, *grads)
+        return (dX0, None, None, None, None, None, *grads)
+
+    @staticmethod
+    def _sparse_top(ctx, lib, a, d, plan, params, X0, arr, ds, db, buf, am, chain_partial, tn_partial, pack, dX0):
+        """Layers L - 1 (on the roots R) and L - 2 (from the compact rows T) of the stack, then sl_sage_stack_bwd_ready for the
+        layers 0 .. L - 3.  Returns {layer: (dWs, dWn, dbias [2, F] or None, dscale [2, F], doffset [2, F])} for the two
+        row-sparse layers; the others' gradients land in the node's flat buffers as in the dense pass."""
+        L, adj = ctx.L, ctx.adj
+        AX0, big, amax, stats = ctx.keep
+        n, F = big.shape[1], big.shape[2]
+        dev = big.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _stream(big)
+        opt = lambda t_: t_.data_ptr() if t_ is not None else None
+        top, mid, low = L - 1, L - 2, L - 3
+        Zs = lambda l: big[3 * l]
+        Zn = lambda l: big[3 * l + 1]
+        out = lambda l: big[3 * l + 2]
+        AX = lambda l: big[3 * L + l - 1]                    # (l >= 1)
+        prm = lambda l: params[6 * l:6 * l + 6]              # Ws, bs, Wn, bn, scale, offset
+        meta = ctx.meta_l
+        # ---- top layer on the roots (ops._SageDense._sparse_top_backward)
+        Ws, bs, Wn, bn, sc, of = prm(top)
+        R = plan.rows64
+        (dZsR, dZnR), tsc, tof, tbi = _an_bwd([Zs(top).index_select(0, R), Zn(top).index_select(0, R)], [bs, bn], (meta[top][0],) * 2, sc, of, F, 1.0,
+                                              (d,), [True, True], bs is not None or bn is not None, (0.0, 0))
+        g_top = (weight_grad(dZsR, out(mid).index_select(0, R), min_rows=ROOT_GEMM_MIN_ROWS),
+                 weight_grad(dZnR, AX(top).index_select(0, R), min_rows=ROOT_GEMM_MIN_ROWS), tbi, tsc, tof)
+        GS = (mm_nt(dZnR, Wn.t(), min_rows=ROOT_GEMM_MIN_ROWS), mm_nt(dZsR, Ws.t(), min_rows=ROOT_GEMM_MIN_ROWS))
+        dXT = torch.empty(plan.t, F, **f32)
+        check(lib.sl_top_dx(GS[0].data_ptr(), GS[1].data_ptr(), F, plan.T32.data_ptr(), plan.slot.data_ptr(), plan.epos.data_ptr(),
+                            plan.self_idx.data_ptr(), plan.targets32.data_ptr(), opt(adj.edge_w), opt(adj.row_scale), opt(adj.col_scale),
+                            plan.t, F, dXT.data_ptr(), F, st))
+        # ---- the layer below: act + norm backward on the rows T (through its output dropout mask), dZ compact
+        Wsm, bsm, Wnm, bnm, scm, ofm = prm(mid)
+        t = plan.t
+        dZsT = torch.empty(t, F, **f32)
+        dZnT = torch.empty(t + 1, F, **f32)
+        dZnT[t].zero_()
+        _dz, msc, mof, mbi = _an_bwd([Zs(mid), Zn(mid)], [bsm, bnm], (meta[mid][0],) * 2, scm, ofm, F, 1.0, (dXT,), [True, True],
+                                     bsm is not None or bnm is not None, (float(meta[mid][1]), int(meta[mid][2])),
+                                     dz_out=[dZsT, dZnT[:t]], row_idx=plan.T32, dz_compact=True)
+        Tl = plan.T32.long()
+        Xm = out(low) if mid >= 1 else X0
+        g_mid = (weight_grad(dZsT, Xm.index_select(0, Tl)), weight_grad(dZnT[:t], AX(mid).index_select(0, Tl)), mbi, msc, mof)
+        # ---- its input gradient = the output gradient of layer L - 3: (A^T dZn) Wn + scatter_T(dZs[T] Ws), with that layer's act +
+        #      norm backward in the product's epilogue (ops._SageDense._compact_dz_backward)
+        AtdZn, amx = _at_dzn_on_rows(adj, plan, dZnT, n, F)
+        corr = mm_nt(dZsT, Wsm.t())
+        wpack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(F, F), dtype=torch.uint8, device=dev)
+        check(lib.sl_gemm_act_norm_pack_b2(Wnm.data_ptr(), 1, Wnm.stride(0), F, Wnm.data_ptr(), 1, Wnm.stride(0), F, F, wpack.data_ptr(), st))
+        _Wl, bsl, _Wnl, bnl, scl, ofl = prm(low)
+        low_buf = torch.empty(n, 3 * F, **f32)
+        low_amax = torch.empty(n, **f32)
+        partial = torch.empty(lib.sl_gemm_an_bwd_partial_floats(n, F, 2), **f32)
+        ld2 = (C.c_int64 * 2)(F, F)
+        ld3 = (C.c_int64 * 2)(3 * F, 3 * F)
+        ac = (C.c_int * 2)(meta[low][0], meta[low][0])
+        dZb = (C.c_void_p * 2)(low_buf.data_ptr(), low_buf.data_ptr() + 8 * F)
+        y = arr[low]
+        nbytes = 4 * n * (F + 4 * F) + 4 * t * F
+        with _timed(f"gemm_an_bwd_corr_nb2_N{F}", nbytes, dev, flops=2 * n * F * F):
+            check(lib.sl_gemm_an_bwd_corr(AtdZn.data_ptr(), F, amx.data_ptr(), wpack.data_ptr(), n, F, F, 2, _ptr_array([Zs(low), Zn(low)]), ld2,
+                                          _ptr_array([bsl, bnl]), ac, scl.data_ptr(), ofl.data_ptr(), 1.0, dZb, ld3,
+                                          y.dscale, y.doffset, y.dbias, partial.data_ptr(), float(meta[low][1]), int(meta[low][2]),
+                                          low_amax.data_ptr(), stats[low].data_ptr() if (stats is not None and y.row_stats) else None,
+                                          corr.data_ptr(), corr.stride(0), plan.rowmap.data_ptr(), t, st))
+        # ---- the layers 0 .. L - 3: dense chained passes, one C call
+        check(lib.sl_sage_stack_bwd_ready(C.byref(a), X0.data_ptr(), X0.stride(0), ctx.x0_amax.data_ptr() if ctx.x0_amax is not None else None,
+                                          low + 1, arr, low_buf.data_ptr(), low_amax.data_ptr(), dX0.data_ptr() if dX0 is not None else None,
+                                          buf.data_ptr(), am.data_ptr(), opt(chain_partial), tn_partial.data_ptr(), pack.data_ptr(), st))
+        _SageDense.sparse_top_calls += 1
+        _SageDense.compact_dz_calls += 1
+        _SageStack.sparse_top_calls += 1
+        return {top: g_top, mid: g_mid}
+
 
 
 def sage_stack_usable(mods) -> bool:
@@ -1782,7 +1909,17 @@ def sage_stack_usable(mods) -> bool:
     return True
 
 
-def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tensor]):
+def sparse_top_stack_usable(csr, mods) -> bool:
+    """Can _SageStack run the row-sparse backward of its two top layers on this batch?  (Three layers or more of one width F with
+    F % 32 == 0 and the block-diagonal aggregate: what the compact-dZ pass of the layer below the top needs.  Otherwise the
+    layer-by-layer nodes take the row-sparse pass, with their dense fall-back for that layer.)"""
+    F = mods[0].f_lin_self.weight.shape[0]
+    blocks = getattr(csr, "spmm_blocks", None)
+    return bool(SPARSE_TOP_STACK and len(mods) >= 3 and F % 32 == 0 and F >= BLOCKDIAG_MIN_F and blocks is not None and blocks[0] is not None
+                and _lib.load().sl_gemm_act_norm_supported(F, F))
+
+
+def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tensor], plan=None):
     """out_L[rows] of the GraphSAGE modules ``mods`` applied in turn to X0 (already through layer 0's input dropout) -- see
     _SageStack; every layer's fused output dropout is ``mods[l]._out_p()`` (drawn here, in layer order).  Returns None when the
     stack form does not apply to this call (the caller then runs the layers one by one)."""
@@ -1802,7 +1939,7 @@ def sage_stack(X0: torch.Tensor, adj: "NormAdj", mods, rows: Optional[torch.Tens
     for md in mods:
         drop = _drop_arg(md._out_p(), F)
         meta.append((ACT_CODE[md.act_name], float(drop[0]), int(drop[1])))
-    return _SageStack.apply(X0, adj, rows, tuple(meta), torch.is_grad_enabled(), *params)
+    return _SageStack.apply(X0, adj, rows, tuple(meta), torch.is_grad_enabled(), plan, *params)
 
 
 class _GcnStack(torch.autograd.Function):

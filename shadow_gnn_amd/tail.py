@@ -246,7 +246,10 @@ class TopBackwardPlan:
             self._t_keep = (ti, tx, tp, work)                     # (built on this stream: handed to the consumer's stream with the plan)
         else:
             self.rowmap.fill_(-1)
+        import time as _time
+        t0 = _time.perf_counter()
         t, bad, ef = (int(x) for x in off[P:P + 3].tolist()) if P else (0, 0, 0)          # (the one host sync)
+        self.sync_wait_s = _time.perf_counter() - t0                # (host time BLOCKED on this stream, not busy: minibatch.wait_s)
         self.ok = bool(P > 0 and bad == 0 and t <= cap)
         self.t = t if self.ok else 0
         self.f_nnz = ef if self.ok else 0

@@ -894,6 +894,8 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
     from shadow_gnn_amd import ops_gat
     monkeypatch.setattr(ops, "SPARSE_TOP_BWD", True)
     monkeypatch.setattr(ops, "SPARSE_TOP_BWD_MIN_ROWS", 1024)
+    # (... and its small products over the rows T on the library's own kernels, as at the benchmark's ~20 k rows)
+    monkeypatch.setattr(ops, "ROOT_GEMM_MIN_ROWS", 64)
     sparse0 = (ops._SageDense.sparse_top_calls, ops._SageDense.compact_dz_calls, ops_gat._GatTail.sparse_top_calls)
     arch = dict(num_layers=layers_, num_cls_layers=1, heads=heads, dim=256, act=act,
                 layer_norm="norm_feat", feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
@@ -1225,7 +1227,7 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
-                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage"):
+                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
@@ -1237,7 +1239,9 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
     prev_c, prev_s = ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD
     ops.CHAIN_SAGE_BWD = chain
     prev_m = ops.SPARSE_TOP_BWD_MIN_ROWS
-    prev_k = ops.SAGE_STACK
+    prev_k, prev_t = ops.SAGE_STACK, ops.SPARSE_TOP_STACK
+    if top_stack is not None:
+        ops.SPARSE_TOP_STACK = top_stack           # (row-sparse top pass from the whole-stack node / from the layer-by-layer nodes)
     if stack is not None:
         ops.SAGE_STACK = stack                     # (the whole stack as one autograd node / layer by layer)
     if sparse_top is not None:
@@ -1281,7 +1285,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
     finally:
         lib.sl_set_fused_epilogue(prev_f)
         ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS = prev_c, prev_s, prev_m
-        ops.SAGE_STACK = prev_k
+        ops.SAGE_STACK, ops.SPARSE_TOP_STACK = prev_k, prev_t
 
 
 @pytest.mark.parametrize("n_layers,dim,p_drop,dropedge,act,aug,F0", [(5, 256, 0.4, 0.05, "relu", False, 100), (3, 128, 0.3, 0.0, "elu", True, 100),
@@ -1878,6 +1882,32 @@ def test_sparse_top_layer_backward_equals_dense(n_layers, p_drop, dropedge, act,
         scale = float(g0[k].abs().max())
         err = float((g1[k] - g0[k]).abs().max())
         assert err <= 2e-5 * scale + 1e-9, (k, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,p_drop,dropedge,act,given,F0", [(5, 0.4, 0.05, "relu", True, 100), (3, 0.3, 0.0, "elu", False, 100),
+                                                                  (4, 0.0, 0.1, "relu", True, 128)])
+def test_sparse_top_pass_from_the_stack_node_equals_the_layer_nodes(n_layers, p_drop, dropedge, act, given, F0):
+    """Round 5: the headline step's backward = the row-sparse passes of the two top layers issued from ops._SageStack + ONE C call
+    (sl_sage_stack_bwd_ready) for the layers below, instead of one autograd node per layer.  Same kernels, same arguments, same
+    order as the layer-by-layer nodes' row-sparse pass: loss, predictions and EVERY parameter gradient bit-identical (3 layers:
+    the C call covers layer 0 alone, whose input is the feature matrix)."""
+    from shadow_gnn_amd import ops
+    k0, s0 = ops._SageStack.calls, ops._SageStack.sparse_top_calls
+    l0, p0, g0, calls0 = _sage_stack_step(n_layers, 256, p_drop, 17, chain=True, fused=True, B=128, act=act, F0=F0, sparse_top=True, given_plan=given,
+                                          dropedge=dropedge, top_stack=False)
+    assert ops._SageStack.calls == k0 and ops._SageStack.sparse_top_calls == s0
+    c0, d0 = ops._SageDense.sparse_top_calls, ops._SageDense.compact_dz_calls
+    l1, p1, g1, calls1 = _sage_stack_step(n_layers, 256, p_drop, 17, chain=True, fused=True, B=128, act=act, F0=F0, sparse_top=True, given_plan=given,
+                                          dropedge=dropedge, top_stack=True)
+    assert ops._SageStack.calls == k0 + 1 and ops._SageStack.sparse_top_calls == s0 + 1, "the stack node's row-sparse pass was not taken"
+    assert ops._SageDense.sparse_top_calls == c0 + 1 and ops._SageDense.compact_dz_calls == d0 + 1
+    assert calls0 == calls1 == (n_layers, n_layers - 1)
+    assert l0 == l1
+    torch.testing.assert_close(p1, p0, rtol=0, atol=0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
 
 
 @pytest.mark.gpu
