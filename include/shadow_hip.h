@@ -559,6 +559,15 @@ int sl_gemm_act_norm_fwd(int nb, const float *const *d_A, const int64_t *lda, co
 int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *lda, const float *const *d_a_amax, const void *d_packed_B,
                     uint32_t M, uint32_t N, uint32_t K, const float *const *d_bias, float *const *d_C, const int64_t *ldc,
                     void *stream);
+/* GAT's two Linears of one input (shaDow/layers.py:604-611) WITH the attention's per-node terms (layers.py:566-569) where the
+ * tiles leave the kernel: d_z_self = A W0^T + b0, d_u_s[row, h] = att[0, h] . act(z_self[row, head h]); d_hn = act(A W1^T + b1)
+ * (z_neigh itself is not written), d_u_n[row, h] = att[1, h] . hn[row, head h].  d_packed_B: sl_gemm_act_norm_pack of (W0, W1);
+ * d_att [2, heads, N / heads]; act as sl_gat_fwd.  Replaces sl_gemm_nt2_f32 + the per-node pass of sl_gat_fwd (then
+ * sl_gat_fwd_rows); bit-identical hn / u_s / u_n.  sl_gemm_nt2_gat_supported(N, heads): N == 256, head width 4 * 2^k <= 128. */
+int sl_gemm_nt2_gat_supported(uint32_t N, uint32_t heads);
+int sl_gemm_nt2_gat_f32(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
+                        const float *const *d_bias, float *d_z_self, int64_t ldzs, float *d_hn, int64_t ldhn, const float *d_att, int act,
+                        uint32_t heads, float *d_u_s, float *d_u_n, void *stream);
 int sl_gemm_nt_cat_f32(const float *d_A0, int64_t lda0, uint32_t K0, const float *d_A1, int64_t lda1, const float *d_a_amax,
                        const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K, const float *d_bias, float *d_C, int64_t ldc,
                        void *stream);
@@ -785,6 +794,10 @@ int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float 
                const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
                uint32_t F, uint32_t heads, float *d_hn, float *d_u_s, float *d_u_n, float *d_mx,
                float *d_den, float *d_nagg, void *stream);
+/* The row pass of sl_gat_fwd alone: d_hn, d_u_s, d_u_n are given (sl_gemm_nt2_gat_f32 left them).  sl_gat_bwd then takes
+ * d_z_neigh = NULL: the activation's derivative follows from hn (relu / elu / leaky relu: z > 0 <=> hn > 0; tanh: 1 - hn^2). */
+int sl_gat_fwd_rows(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const float *d_hn, const float *d_u_s,
+                    const float *d_u_n, uint32_t n, uint32_t F, uint32_t heads, float *d_mx, float *d_den, float *d_nagg, void *stream);
 /* Backward: dz_self (attention part only), dz_neigh, datt[2,heads,D].
  * d_work: float[2*e*heads + n*heads + 4096*F] (per-edge alpha / de, du_s, and the per-block partial sums of
  * datt, which are added in block order: no float atomics, bit-reproducible).                */

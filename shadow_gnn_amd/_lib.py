@@ -192,6 +192,9 @@ SIGNATURES = {
                                         C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, _P]),
     "sl_gemm_nt2_f32": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), _P, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), _P]),
+    "sl_gemm_nt2_gat_supported": (C.c_int, [C.c_uint32, C.c_uint32]),
+    "sl_gemm_nt2_gat_f32": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P), _P, C.c_int64, _P, C.c_int64,
+                                       _P, C.c_int, C.c_uint32, _P, _P, _P]),
     "sl_gemm_nt_cat_f32": (C.c_int, [_P, C.c_int64, C.c_uint32, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P,
                                       C.c_int64, _P]),
     "sl_gemm_an_bwd_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
@@ -222,6 +225,7 @@ SIGNATURES = {
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
     "sl_gat_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                               _P, _P, _P, _P, _P, _P, _P]),
+    "sl_gat_fwd_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "sl_gat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_top_plan": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
@@ -242,7 +246,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 20      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 21      # sg_abi_version() of the library these signatures describe
 
 
 def load():

@@ -17,6 +17,7 @@
 
 #include "actnorm_common.h"
 #include "common.h"
+#include "gat_act.h"
 
 namespace shadow {
 
@@ -27,41 +28,7 @@ __device__ __forceinline__ void gst4(float *p, float4 v) { *reinterpret_cast<flo
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
 __device__ __forceinline__ float dlrelu02(float x) { return x > 0.f ? 1.f : 0.2f; }
 
-__device__ __forceinline__ float g_act_fwd(int act, float x) {
-  switch (act) {
-    case 1: return x > 0.f ? x : 0.f;
-    case 2: return x > 0.f ? x : expm1f(x);
-    case 3: return tanhf(x);
-    case 4: return x > 0.f ? x : 0.2f * x;
-    default: return x;
-  }
-}
-__device__ __forceinline__ float g_act_bwd(int act, float x, float h) {
-  switch (act) {
-    case 1: return x > 0.f ? 1.f : 0.f;
-    case 2: return x > 0.f ? 1.f : h + 1.0f;
-    case 3: return 1.f - h * h;
-    case 4: return x > 0.f ? 1.f : 0.2f;
-    default: return 1.f;
-  }
-}
-__device__ __forceinline__ float4 act4(int act, float4 z) {
-  return make_float4(g_act_fwd(act, z.x), g_act_fwd(act, z.y), g_act_fwd(act, z.z), g_act_fwd(act, z.w));
-}
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-// sum over the ls lanes of a head slice (ls power of two, wave-uniform): DPP butterflies (actnorm_common.h)
-__device__ __forceinline__ float slice_sum(float v, uint32_t ls) {
-  switch (ls) {
-    case 1: return v;
-    case 2: return group_sum<2>(v);
-    case 4: return group_sum<4>(v);
-    case 8: return group_sum<8>(v);
-    case 16: return group_sum<16>(v);
-    case 32: return group_sum<32>(v);
-    default: return group_sum<64>(v);
-  }
-}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return gat_dot4(a, b); }
 
 // Row ranges per XCD: workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; a wrong guess costs
 // speed only).  The eight XCDs get contiguous eighths of the batch's rows and the workgroups of an XCD walk their eighth
@@ -432,11 +399,18 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
 #undef SHD_CALL
     if (on) {
       const float dun = dan * dlrelu02(p.u_n[r * p.H + h]);
-      const float4 z = gld4(p.z_neigh + r * p.F + f);
-      const float4 hn = p.hn ? gld4(p.hn + r * p.F + f) : act4(p.act, z);
+      float4 hn, dzv;
       acc.x += dun * a1.x; acc.y += dun * a1.y; acc.z += dun * a1.z; acc.w += dun * a1.w;
-      const float4 dzv = make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
-                                     acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w));
+      if (p.z_neigh) {
+        const float4 z = gld4(p.z_neigh + r * p.F + f);
+        hn = p.hn ? gld4(p.hn + r * p.F + f) : act4(p.act, z);
+        dzv = make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
+                          acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w));
+      } else {                           // (the paired Linear wrote hn = act(z_neigh) straight away: the derivative from hn, gat_act.h)
+        hn = gld4(p.hn + r * p.F + f);
+        dzv = make_float4(acc.x * g_act_bwd_h(p.act, hn.x), acc.y * g_act_bwd_h(p.act, hn.y),
+                          acc.z * g_act_bwd_h(p.act, hn.z), acc.w * g_act_bwd_h(p.act, hn.w));
+      }
       gst4(p.dz_neigh + r * p.F + f, dzv);
       rmax = shadow::amax4(dzv);
       g1.x += dun * hn.x; g1.y += dun * hn.y; g1.z += dun * hn.z; g1.w += dun * hn.w;
@@ -462,6 +436,12 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
 //  than the row-serial kernels above on the depth-3 products batches (forward 0.69 -> 0.72 ms, backward 1.06 -> 1.32 ms):
 //  with e / n = 3.9 these kernels move 2.4 / 4.5 GB per launch counting the gathered rows, i.e. they already run at
 //  3.5 - 4 TB/s of L2 / HBM traffic -- gather-volume-bound, not latency-bound.  What did help: the XCD-contiguous row walk.)
+// (Round 5, measured and dropped: a head-split walk -- items (row, head) of D / 4 lanes in the order XCD range -> chunk of
+//  4 096 rows -> head -> row, so that the slice re-touched between a row's first and last gather is 1 MB instead of the
+//  subgraph's 4.6 MB of hn against a 4 MB L2.  Forward 0.47 -> 0.88 ms per launch at chunk heights 2 048 / 4 096 / 8 192
+//  (scripts/ab_gat_head_chunk.sh, git show 80bf3cc..: four times the wave iterations of a quarter of the work each, four
+//  diverging items per wavefront): the row walk is bound by its dependent loads and per-edge arithmetic, not by where the
+//  gathered rows come from -- recomputing elu where a row is gathered costs the same kernels 28 % (RECOMPUTE_HN).)
 // datt[j] = sum over blocks of datt_part[block][j] in a fixed order (bit-reproducible; no float atomics).  A workgroup owns
 // 32 outputs; its 32 x 32 threads cut the block range into 32 slices, eight independent running sums per thread (one thread
 // per output walking all ~2 000 partial rows was a 240 us latency chain), the slices are added in slice order through LDS.
@@ -550,6 +530,28 @@ extern "C" int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   return SG_OK;
 }
 
+// The row pass alone: hn = act(z_neigh) and the per-node terms u_s / u_n are given (the paired Linear's GAT tail,
+// sl_gemm_nt2_gat_f32, left them: gat_node_fwd_kernel's pass over z_self / z_neigh is not run).
+extern "C" int sl_gat_fwd_rows(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const float *d_hn,
+                               const float *d_u_s, const float *d_u_n, uint32_t n, uint32_t F, uint32_t heads, float *d_mx,
+                               float *d_den, float *d_nagg, void *stream_) {
+  if (!d_indptr || !d_hn || !d_u_s || !d_u_n || !d_mx || !d_den || !d_nagg) return set_error(SG_ERR_INVALID, "sl_gat_fwd_rows: null argument");
+  uint32_t lpr;
+  int rc = gat_check(F, heads, &lpr);
+  if (rc) return rc;
+  if (n == 0) return SG_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  GatParams p;
+  memset(&p, 0, sizeof(p));
+  p.indptr = d_indptr; p.indices = d_indices; p.edge_w = d_edge_w; p.n = n; p.F = F; p.H = heads; p.D = F / heads;
+  p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
+  p.mx = d_mx; p.den = d_den; p.nagg = d_nagg;
+  const uint32_t g = gat_grid(n, lpr);
+  SHD_GAT_LAUNCH(gat_row_fwd_kernel, lpr, g, st, p);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
 extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
                           const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
                           const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
@@ -557,9 +559,9 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
                           const float *d_nagg, const float *d_dnagg, float *d_work, float *d_dz_self,
                           float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
-  if (!d_indptr || !d_t_indptr || !d_z_self || !d_z_neigh || !d_att || !d_u_s || !d_u_n || !d_mx ||
+  if (!d_indptr || !d_t_indptr || !d_z_self || !(d_z_neigh || d_hn) || !d_att || !d_u_s || !d_u_n || !d_mx ||
       !d_den || !d_nagg || !d_dnagg || !d_work || !d_dz_self || !d_dz_neigh || !d_datt)
-    return set_error(SG_ERR_INVALID, "sl_gat_bwd: null argument");
+    return set_error(SG_ERR_INVALID, "sl_gat_bwd: null argument");      // (d_z_neigh may be NULL when d_hn is given)
   uint32_t lpr;
   int rc = gat_check(F, heads, &lpr);
   if (rc) return rc;

@@ -29,6 +29,7 @@
 
 #include "actnorm_common.h"
 #include "common.h"
+#include "gat_act.h"
 #include "gemm_common.h"
 
 namespace shadow {
@@ -70,6 +71,14 @@ struct FusedDesc {
   // are non-zero on a few rows only, computed on those rows by the caller)
   const float *corr; int64_t ldcorr;
   const uint32_t *corr_row; uint32_t corr_rows;
+  // MODE 2, optional: the GAT layer's per-node terms from the paired Linear's own tiles (sl_gemm_nt2_gat_f32).  For product b with
+  // gat_u[b] set: u[row, h] = sum over head h's D columns of gat_att[b][col] * act(C[row, col]) -- shaDow/layers.py:566-569 -- and,
+  // with gat_store_act[b], the tile leaves as act(C) (hn = act(z_neigh): the pre-activation is never written).  N == 32 TW == H D.
+  const float *gat_att[2];
+  float *gat_u[2];
+  int gat_store_act[2];
+  int gat_act;
+  uint32_t gat_ls, gat_H;           // lanes per head slice (D / 4: a power of two <= 32), heads
 };
 
 // The epilogue puts ONE FEATURE ROW ON 32 LANES (2 rows per wavefront pass; 64 lanes in the backward form): the row
@@ -475,7 +484,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   const uint64_t m0 = (uint64_t)blockIdx.x * 128u + wv * 32u;
   const uint64_t arow_i = min(m0 + r, (uint64_t)M - 1);  // rows past the end repeat the last row (never stored)
   const float *arow0 = d.A[0] + arow_i * d.lda[0] + 16 * g;
-  const float *arow1 = (NBP == 2 || (MODE == 2 && d.A[1])) ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
+  const float *arow1 = (NBP == 2 || (MODE >= 2 && d.A[1])) ? d.A[1] + arow_i * d.lda[1] + 16 * g : arow0;
   const uint32_t gunits = NBP * units, steps = 2 * gunits;
   // Scale of this lane's row in a phase: from the row maxima the operand's producer left behind, or -- no array given: the
   // small batches, whose operands sit in the L2 and whose steps are bound by the host's launch rate -- from one more read
@@ -484,7 +493,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     if (d.aamax[ph]) return row_scale_of(d.aamax[ph][arow_i]);
     float mx = 0.f;
     for (uint32_t u = 0; u < units; u++) {
-      const bool second = MODE == 2 && NBP == 1 && u >= d.asplit;
+      const bool second = MODE >= 2 && NBP == 1 && u >= d.asplit;
       const float *base = (ph || second ? arow1 : arow0) + 32 * (second ? u - d.asplit : u);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -511,7 +520,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   auto load_a_piece = [&](uint32_t gu, int q) {
     const bool ph = NBP == 2 && gu >= units;
     const uint32_t u = ph ? gu - units : gu;
-    const bool second = MODE == 2 && NBP == 1 && u >= d.asplit;      // (the K-concatenated operand's second tensor)
+    const bool second = MODE >= 2 && NBP == 1 && u >= d.asplit;      // (the K-concatenated operand's second tensor)
     const float *ptr = (ph || second ? arow1 : arow0) + 32 * (second ? u - d.asplit : u) + 4 * q;
     if (!kTail || 32 * u + 32 <= K) {
       an[q] = *reinterpret_cast<const float4 *>(ptr);
@@ -537,10 +546,21 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   // A 32 x 32 TW accumulator tile (C/D layout: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)) to global memory
   // through one ring slot: 8 rows x half the columns per wavefront at a time, leaving as float4s -- 512 contiguous bytes per
   // row and instruction (straight from the C/D layout it was 16 TW dword stores per lane: 8 % of the workgroup's lifetime).
-  auto store_tile = [&](float *dst0, int64_t ld, uint32_t slot, uint32_t rows_ok, uint32_t cols_ok) {
+  auto store_tile = [&](float *dst0, int64_t ld, uint32_t slot, uint32_t rows_ok, uint32_t cols_ok, int prod) {
+    constexpr int GACT = MODE == 4 ? 1 : MODE == 5 ? 2 : -1;   // (GAT tail, MODE 3 / 4 / 5: the activation looked up / relu / elu)
     constexpr int CT = TW / 2;                            // column tiles per chunk: 8 rows x 32 CT floats per wavefront = 2 TW KB per workgroup (= one ring slot)
     float *zst = reinterpret_cast<float *>(lbuf + (size_t)slot * kStepVecs) + (size_t)wv * (8 * 32 * CT);
     const bool zvec = (ld & 3) == 0;
+    // (GAT tail: a lane's column within a chunk is fixed -- 4 (lane % (8 CT)) -- so its four attention weights are too)
+    // (GAT tail: a lane's column within a chunk is fixed -- 32 CT ch + 4 (lane % (8 CT)) -- so its four attention weights are
+    //  too: loaded once, BEFORE the stores -- a load between them would wait for every store issued so far, vmcnt is shared)
+    float *gat_u = MODE >= 3 ? d.gat_u[prod] : nullptr;
+    float4 gat_a[2] = {f4zero(), f4zero()};
+    const uint32_t gat_lmask = MODE >= 3 ? d.gat_ls - 1u : 0u, gat_hshift = MODE >= 3 ? (uint32_t)__builtin_ctz(d.gat_ls) + 2u : 0u;
+    if constexpr (MODE >= 3) {
+#pragma unroll
+      for (int ch = 0; ch < 2; ch++) gat_a[ch] = ld4(d.gat_att[prod] + 32 * CT * ch + 4 * (lane % (8 * CT)));
+    }
 #pragma unroll
     for (int ch = 0; ch < 2; ch++) {
 #pragma unroll
@@ -551,11 +571,21 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
           for (int ii = 0; ii < 4; ii++) zst[(4 * g + ii) * (32 * CT) + 32 * t + r] = acc[CT * ch + t][4 * q + ii];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll(MODE >= 3 ? 1 : CT)
         for (int it = 0; it < CT; it++) {
           const uint32_t idx = it * 64 + lane, lr = idx / (8 * CT), c4 = idx % (8 * CT);
           const uint32_t rloc = 8 * q + lr, col = 32 * CT * ch + 4 * c4;
-          if (rloc < rows_ok && col < cols_ok) {
+          if constexpr (MODE >= 3) {
+            // (whole wavefront: the head-slice sums are DPP butterflies; N == 32 TW here, every column is inside)
+            float4 v = *reinterpret_cast<const float4 *>(zst + lr * (32 * CT) + 4 * c4);
+            const float4 hv = act4(GACT >= 0 ? GACT : d.gat_act, v);
+            const float u = slice_sum(gat_dot4(gat_a[ch], hv), d.gat_ls);
+            if (rloc < rows_ok) {
+              if ((lane & gat_lmask) == 0) gat_u[(m0 + rloc) * d.gat_H + (col >> gat_hshift)] = u;
+              if (d.gat_store_act[prod]) v = hv;
+              *reinterpret_cast<float4 *>(dst0 + (m0 + rloc) * ld + col) = v;
+            }
+          } else if (rloc < rows_ok && col < cols_ok) {
             const float4 v = *reinterpret_cast<const float4 *>(zst + lr * (32 * CT) + 4 * c4);
             float *dst = dst0 + (m0 + rloc) * ld + col;
             if (zvec) *reinterpret_cast<float4 *>(dst) = v;
@@ -642,9 +672,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       uint32_t rows_ok = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0))), cols_ok = d.N;
       asm volatile("" : "+s"(rows_ok), "+s"(cols_ok));
       unscale_tile<TW>(acc, 1.0f / asc, d.btrail[0] + 32 * TW, g, r);
-      if (MODE == 2 && d.cbias[0]) add_bias_tile<TW>(acc, d.cbias[0], d.N, r);
+      if (MODE >= 2 && d.cbias[0]) add_bias_tile<TW>(acc, d.cbias[0], d.N, r);
       asc = phase_scale(1);
-      store_tile(d.Z[0], d.ldz[0], (2 * gu + 1) % 3u, rows_ok, cols_ok);
+      store_tile(d.Z[0], d.ldz[0], (2 * gu + 1) % 3u, rows_ok, cols_ok, 0);
 #pragma unroll
       for (int t = 0; t < TW; t++)
 #pragma unroll
@@ -656,11 +686,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     }
   }
 
-  if constexpr (MODE == 2) {
+  if constexpr (MODE >= 2) {
     // plain product(s): the last tile leaves the same way (the ring is dead: every wavefront passed the last step's barrier)
     unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
     if (d.cbias[NBP - 1]) add_bias_tile<TW>(acc, d.cbias[NBP - 1], d.N, r);
-    store_tile(d.Z[NBP - 1], d.ldz[NBP - 1], 0u, (uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0)), d.N);
+    store_tile(d.Z[NBP - 1], d.ldz[NBP - 1], 0u, (uint32_t)min((uint64_t)32, (uint64_t)M - min((uint64_t)M, m0)), d.N, NBP - 1);
   } else {
   // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier).  Specialised for the two activations
   //      the reference's configurations use (config_train: elu, relu) on full-width rows; everything else takes the generic
@@ -705,7 +735,7 @@ inline void set_images(FusedDesc &p, const void *packed, int nimg, uint32_t N, u
 template <int TW, int MODE, int NBP, int NBA>
 int launch_fused(FusedDesc d, hipStream_t st) {
   // ring of three k-step images (3 x 2 TW KB) or the epilogue's stash (4 wavefronts x 16 rows x 32 TW floats), whichever is larger
-  const size_t lds_ = MODE == 2 ? (size_t)3 * 2 * TW * 64 * 16 : std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
+  const size_t lds_ = MODE >= 2 ? (size_t)3 * 2 * TW * 64 * 16 : std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
 #ifdef FUSED_ONE_WG          // (experiment, scripts/micro/ko_one_wg.sh: one workgroup per CU -- a single wavefront per SIMD)
   const size_t lds = std::max<size_t>(lds_, (size_t)84 * 1024);
 #else
@@ -844,6 +874,43 @@ extern "C" int sl_gemm_nt2_f32(int nb, const float *const *d_A, const int64_t *l
   hipStream_t st = (hipStream_t)stream;
   if (N <= 128) return nb == 1 ? launch_fused<4, 2, 1, 1>(p, st) : launch_fused<4, 2, 2, 1>(p, st);
   return nb == 1 ? launch_fused<8, 2, 1, 1>(p, st) : launch_fused<8, 2, 2, 1>(p, st);
+}
+
+// The GAT layer's two Linears of one input (shaDow/layers.py:604-611) WITH the per-node attention terms of layers.py:566-569:
+//   C0 = A W0^T + b0 = z_self,  u_s[row, h] = att[0, h, :] . act(z_self[row, head h]);
+//   C1 = act(A W1^T + b1) = hn (z_neigh itself is not written: every later use needs act(z_neigh) or, in the backward pass, a
+//   derivative that follows from it -- gat_act.h),  u_n[row, h] = att[1, h, :] . hn[row, head h]
+// computed where the tiles leave the kernel: gat_node_fwd_kernel's pass over z_self / z_neigh (0.18 ms per layer at 294 k rows)
+// is not run, bit-identical u_s / u_n / hn (same activation, same dot4 + butterfly per head slice).
+// N = heads * D == 256 with D / 4 a power of two <= 32; otherwise SG_ERR_INVALID (callers keep sl_gemm_nt2_f32 + sl_gat_fwd).
+extern "C" int sl_gemm_nt2_gat_supported(uint32_t N, uint32_t heads) {
+  if (N != 256 || heads == 0 || N % heads) return 0;
+  const uint32_t ls = N / heads / 4;
+  return (N / heads) % 4 == 0 && ls >= 1 && ls <= 32 && (ls & (ls - 1)) == 0;
+}
+
+extern "C" int sl_gemm_nt2_gat_f32(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N,
+                                   uint32_t K, const float *const *d_bias, float *d_z_self, int64_t ldzs, float *d_hn, int64_t ldhn,
+                                   const float *d_att, int act, uint32_t heads, float *d_u_s, float *d_u_n, void *stream) {
+  if (!d_A || !d_packed_B || !d_z_self || !d_hn || !d_att || !d_u_s || !d_u_n) return set_error(SG_ERR_INVALID, "sl_gemm_nt2_gat_f32: null argument");
+  if (M == 0) return SG_OK;
+  if (!sl_gemm_nt2_gat_supported(N, heads) || K == 0 || act < 0 || act > 4)
+    return set_error(SG_ERR_INVALID, "sl_gemm_nt2_gat_f32: N = %u, heads = %u, act = %d (N == 256, head width 4 * 2^k <= 128)", N, heads, act);
+  if ((lda & 3) || !al16(d_A) || (ldzs & 3) || !al16(d_z_self) || (ldhn & 3) || !al16(d_hn) || !al16(d_att))
+    return set_error(SG_ERR_INVALID, "sl_gemm_nt2_gat_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  FusedDesc p;
+  memset(&p, 0, sizeof(p));
+  for (int b = 0; b < 2; b++) {
+    p.A[b] = d_A; p.lda[b] = lda; p.aamax[b] = d_a_amax; p.cbias[b] = d_bias ? d_bias[b] : nullptr;
+    p.gat_att[b] = d_att + (size_t)b * N;
+  }
+  p.Z[0] = d_z_self; p.ldz[0] = ldzs; p.Z[1] = d_hn; p.ldz[1] = ldhn;
+  p.gat_u[0] = d_u_s; p.gat_u[1] = d_u_n; p.gat_store_act[0] = 0; p.gat_store_act[1] = 1;
+  p.gat_act = act; p.gat_ls = N / heads / 4; p.gat_H = heads;
+  set_images(p, d_packed_B, 2, N, K);
+  p.M = M; p.N = N; p.K = K; p.units = (K + 31) / 32; p.asplit = p.units;
+  hipStream_t st = (hipStream_t)stream;
+  return act == 2 ? launch_fused<8, 5, 2, 1>(p, st) : act == 1 ? launch_fused<8, 4, 2, 1>(p, st) : launch_fused<8, 3, 2, 1>(p, st);
 }
 
 // C = [A0 | A1] . B^T with the K-concatenated operand in two tensors (K0 columns from A0, K - K0 from A1; K0 % 32 == 0);

@@ -445,7 +445,11 @@ class GAT(shaDowLayer):
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self._adj_norm(adj, is_normed, feat_in.device, dropedge=dropedge)
         feat_in = self.in_dropout(feat_in)
-        z_self, z_neigh = ops.linear_pair(feat_in, self.f_lin[0], self.f_lin[1])     # (one launch for both transforms)
+        # (one launch for both transforms; when the fused tail below is their only consumer the same launch also leaves
+        #  hn = act(z_neigh) -- in z_neigh's place -- and the attention's per-node terms, ops.GatPre)
+        tail_only = self.norm == 'norm_feat' and self.act is None and ops_gat.gat_tail_usable(feat_in, self.f_lin[0].weight.shape[0], self.mulhead)
+        pre = ops.GatPre(self.attention, ops.ACT_CODE[self.kact], self.mulhead) if tail_only else None
+        z_self, z_neigh = ops.linear_pair(feat_in, self.f_lin[0], self.f_lin[1], gat=pre)
         if self.act is not None:
             z_self, z_neigh = self.act(z_self), self.act(z_neigh)
         # neigh branch: act -> per-head attention aggregate; both branches normalised per head slice

@@ -784,12 +784,28 @@ class PairLink:
         self.rows32 = self.dza = self.dzb = self.dummy = self.levels = None
 
 
+class GatPre:
+    """The GAT layer's attention terms that the paired Linear's kernel leaves with its outputs (sl_gemm_nt2_gat_f32): the
+    node's SECOND output is then hn = act(z_neigh) instead of z_neigh, and u_s / u_n [n, heads] are here for ops_gat._GatTail --
+    the only consumer such a pair may have (layers.GAT.forward asks for it only then)."""
+    def __init__(self, attention, act_code: int, heads: int):
+        self.attention, self.act_code, self.heads = attention, int(act_code), int(heads)
+        self.u_s = self.u_n = None
+        self.filled = False
+
+
+# the GAT layer's per-node attention terms from the paired Linear's kernel (False: gat_node_fwd_kernel's pass; tests compare the two)
+GAT_PAIR_TAIL = True
+
+
 class _LinearPair(torch.autograd.Function):
     """Two nn.Linear of the SAME input -- GAT's self / neighbour transforms (shaDow/layers.py:604-611) -- as one autograd
     node on the fp16 two-piece kernels: forward = ONE two-product launch that reads X once per product and adds the
     biases as the tiles leave (sl_gemm_nt2_f32); backward: dX = [dZa | dZb] . [Wa ; Wb] as ONE K-concatenated product
     straight from the two gradient tensors (sl_gemm_nt_cat_f32: no dXa + dXb pass), the bias gradients from the
     weight-gradient kernel's pass over dZ (column sums of its A tiles)."""
+    gat_tail_calls = 0          # forward passes that also left hn / u_s / u_n (tests assert on it)
+
     @staticmethod
     def usable(X, Wa, Wb) -> bool:
         M, K = X.shape
@@ -799,7 +815,7 @@ class _LinearPair(torch.autograd.Function):
                 and bool(_lib.load().sl_gemm_act_norm_supported(N, K)))
 
     @staticmethod
-    def forward(ctx, X, Wa, ba, Wb, bb, pair=None, in_link=None):
+    def forward(ctx, X, Wa, ba, Wb, bb, pair=None, in_link=None, gat=None):
         """``pair`` (PairLink): the consumer of both outputs may leave their gradients on a few rows; ``in_link`` (RootsLink
         the producer of X published): the input gradient may then go down as (rows, values) too."""
         X = _f32c(X)
@@ -818,7 +834,18 @@ class _LinearPair(torch.autograd.Function):
             am = row_amax(X)
         Zs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(2)]
         bs = [b.detach().contiguous() if b is not None else None for b in (ba, bb)]
-        with _timed(f"gemm_nt2_f16_N{N}" + ("" if K % 32 == 0 else "_Ktail"), 4 * M * (K + 2 * N), dev, flops=2 * 2 * M * K * N):
+        if gat is not None:
+            # (z_self, hn = act(z_neigh)) and the attention's per-node terms from the same launch (GatPre)
+            att = gat.attention.detach().float().contiguous()
+            gat.u_s, gat.u_n = torch.empty(M, gat.heads, dtype=torch.float32, device=dev), torch.empty(M, gat.heads, dtype=torch.float32, device=dev)
+            with _timed(f"gemm_nt2_gat_f16_N{N}" + ("" if K % 32 == 0 else "_Ktail"), 4 * M * (K + 2 * N + 2 * gat.heads), dev, flops=2 * 2 * M * K * N):
+                check(lib.sl_gemm_nt2_gat_f32(X.data_ptr(), X.stride(0), am.data_ptr() if am is not None else None, pack.data_ptr(), M, N, K,
+                                              _ptr_array(bs), Zs[0].data_ptr(), N, Zs[1].data_ptr(), N, att.data_ptr(), gat.act_code, gat.heads,
+                                              gat.u_s.data_ptr(), gat.u_n.data_ptr(), st))
+            gat.filled = True
+            _LinearPair.gat_tail_calls += 1
+        else:
+          with _timed(f"gemm_nt2_f16_N{N}" + ("" if K % 32 == 0 else "_Ktail"), 4 * M * (K + 2 * N), dev, flops=2 * 2 * M * K * N):
             check(lib.sl_gemm_nt2_f32(2, _ptr_array([X, X]), (C.c_int64 * 2)(X.stride(0), X.stride(0)), _ptr_array([am, am]), pack.data_ptr(),
                                       M, N, K, _ptr_array(bs), _ptr_array(Zs), (C.c_int64 * 2)(N, N), st))
         ctx.save_for_backward(X, Wa, Wb)
@@ -843,7 +870,7 @@ class _LinearPair(torch.autograd.Function):
         Tl = rows32.long()
         XT = X.index_select(0, Tl)
         ng = ctx.needs_input_grad
-        out = [None] * 7
+        out = [None] * 8
         # (the library's own kernels from ROOT_GEMM_MIN_ROWS rows on: a rocBLAS call with a transposed operand costs 0.2 - 0.8 ms of
         #  host time here, and the bias gradient comes out of the weight gradient's pass over dZ)
         for i, dz in ((0, dza), (1, dzb)):
@@ -905,7 +932,7 @@ class _LinearPair(torch.autograd.Function):
                 check(lib.sl_gemm_nt_cat_f32(dZs[0].data_ptr(), dZs[0].stride(0), N, dZs[1].data_ptr(), dZs[1].stride(0),
                                              joint.data_ptr() if joint is not None else None,
                                              pack.data_ptr(), M, K, 2 * N, None, dX.data_ptr(), dX.stride(0), st))
-        out = [dX, None, None, None, None, None, None]
+        out = [dX, None, None, None, None, None, None, None]
         # two fp16 pieces when the row maxima of both operands are in hand (the joint maxima bound either gradient's rows)
         f16 = joint is not None and ctx.x_amax is not None and weight_grad_f16_usable(dZs[0], X) and weight_grad_f16_usable(dZs[1], X)
         if f16 and ng[1] and ng[3] and dZs[0].stride(0) == dZs[1].stride(0):
@@ -926,14 +953,20 @@ class _LinearPair(torch.autograd.Function):
         return tuple(out)
 
 
-def linear_pair(X, lin_a: "torch.nn.Linear", lin_b: "torch.nn.Linear"):
-    """(lin_a(X), lin_b(X)); one fused node when the shapes allow (see _LinearPair), two ``linear`` nodes otherwise."""
+def linear_pair(X, lin_a: "torch.nn.Linear", lin_b: "torch.nn.Linear", gat: Optional[GatPre] = None):
+    """(lin_a(X), lin_b(X)); one fused node when the shapes allow (see _LinearPair), two ``linear`` nodes otherwise.
+    ``gat``: the caller is a GAT layer whose fused tail (ops_gat.gat_tail) is the ONLY consumer of the two outputs -- where the
+    kernel takes the shape the second output is then act(lin_b(X)) and ``gat`` carries u_s / u_n (``gat.filled``)."""
     if isinstance(X, torch.Tensor) and X.dim() == 2 and _LinearPair.usable(X, lin_a.weight, lin_b.weight):
         # (row-sparse GAT backward: a PairLink travels with the two outputs, the producer's RootsLink with the input)
         pair = PairLink() if (SPARSE_TOP_BWD and ROOTS_SPARSE_GRAD) else None
-        za, zb = _LinearPair.apply(X, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias, pair, getattr(X, "_shadow_roots", None))
+        if gat is not None and not (GAT_PAIR_TAIL and _lib.load().sl_gemm_nt2_gat_supported(lin_a.weight.shape[0], gat.heads)):
+            gat = None
+        za, zb = _LinearPair.apply(X, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias, pair, getattr(X, "_shadow_roots", None), gat)
         if pair is not None:
             za._shd_pair = zb._shd_pair = pair
+        if gat is not None:
+            zb._shd_gat_pre = gat
         return za, zb
     return linear(X, lin_a), linear(X, lin_b)
 

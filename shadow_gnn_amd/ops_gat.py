@@ -82,20 +82,32 @@ class _GatTail(torch.autograd.Function):
     backward then ADDS to (sl_gat_bwd, accumulate_dz_self), and the two kernels leave the row maxima of the final
     (dz_self | dz_neigh) behind for the K-concatenated input-gradient product of ops._LinearPair."""
     @staticmethod
-    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop, link_roots=None, pair=None):
+    def forward(ctx, z_self, z_neigh, attention, scale, offset, adj, act_code, heads, seg, out_scale, drop, link_roots=None, pair=None, pre=None):
         z_self, z_neigh = ops._f32c(z_self).contiguous(), ops._f32c(z_neigh).contiguous()
         att = attention.detach().float().contiguous()
         ops._need_cuda(z_self, z_neigh, att, scale, offset)
         n, F = z_self.shape
         dev = z_self.device
         c = adj.csr
-        hn = _hn_buffer(n, F, dev)
-        u_s = torch.empty(n, heads, device=dev); u_n = torch.empty(n, heads, device=dev)
         mx = torch.empty(n, heads, device=dev); den = torch.empty(n, heads, device=dev)
         nagg = torch.empty(n, F, device=dev)
         w = adj.edge_w
-        nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 3 * 4 * n * F + 4 * 4 * n * heads
-        with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
+        if pre is not None:
+            # ``z_neigh`` IS hn = act(z_neigh) and the per-node terms are in hand (the paired Linear's kernel left them, ops.GatPre):
+            # the row pass alone; the pre-activation does not exist -- the backward kernels take its derivative from hn
+            hn, u_s, u_n = z_neigh, pre.u_s, pre.u_n
+            z_neigh = att.new_empty(0)
+            nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 2 * 4 * n * F + 4 * 4 * n * heads
+            with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
+                check(_lib.load().sl_gat_fwd_rows(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
+                                                  hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), n, F, heads, mx.data_ptr(), den.data_ptr(),
+                                                  nagg.data_ptr(), ops._stream(z_self)))
+            _GatTail.pre_calls += 1
+        else:
+          hn = _hn_buffer(n, F, dev)
+          u_s = torch.empty(n, heads, device=dev); u_n = torch.empty(n, heads, device=dev)
+          nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 3 * 4 * n * F + 4 * 4 * n * heads
+          with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_fwd(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
                                          z_self.data_ptr(), z_neigh.data_ptr(), att.data_ptr(), act_code, n, F, heads,
                                          _p(hn), u_s.data_ptr(), u_n.data_ptr(), mx.data_ptr(), den.data_ptr(),
@@ -119,6 +131,7 @@ class _GatTail(torch.autograd.Function):
         return out
 
     sparse_top_calls = 0
+    pre_calls = 0            # forward passes that took hn / u_s / u_n from the paired Linear's kernel (tests assert on it)
 
     @staticmethod
     def _rows_backward(ctx, lr, level, rest):
@@ -147,7 +160,8 @@ class _GatTail(torch.autograd.Function):
         ti, tx, tp = csr_c.transposed
         w = adj.edge_w.index_select(0, level.edge_pos.index_select(0, order)) if adj.edge_w is not None else None
         g = lambda x: x.index_select(0, Tl)
-        zs_c, zn_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(z_neigh), g(u_s), g(u_n), g(mx), g(den), g(nagg)
+        zs_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(u_s), g(u_n), g(mx), g(den), g(nagg)
+        zn_c = g(z_neigh) if z_neigh.numel() else None          # (no pre-activation kept: hn carries the derivative, ops.GatPre)
         hn_c = g(hn) if hn.numel() else None
         dn_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dn_r)
         dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_r)
@@ -157,7 +171,7 @@ class _GatTail(torch.autograd.Function):
         nbytes = 2 * (4 * (t + 1) + 4 * E) + (4 * E if w is not None else 0) + 6 * 4 * t * F + 6 * 4 * t * heads
         with ops._timed(f"gat_bwd_rows_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(csr_c.indptr.data_ptr(), csr_c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
-                                         w.data_ptr() if w is not None else None, zs_c.data_ptr(), zn_c.data_ptr(),
+                                         w.data_ptr() if w is not None else None, zs_c.data_ptr(), _p(zn_c),
                                          att.data_ptr(), act_code, t, E, F, heads, _p(hn_c), us_c.data_ptr(),
                                          un_c.data_ptr(), mx_c.data_ptr(), den_c.data_ptr(), na_c.data_ptr(), dn_c.data_ptr(),
                                          work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
@@ -167,7 +181,7 @@ class _GatTail(torch.autograd.Function):
         pair.filled = True
         _GatTail.sparse_top_calls += 1
         return (pair.dummy, pair.dummy, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
     @staticmethod
     def backward(ctx, *dout):
@@ -201,22 +215,28 @@ class _GatTail(torch.autograd.Function):
             lr.release()
         ti, tx, tp = c.transposed
         work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
-        dzn = torch.empty_like(z_neigh)
+        dzn = torch.empty_like(z_self)
         datt = torch.empty(2, F, device=dev)
         w = adj.edge_w
         # (round 5: both CSR structures; the incoming gradient, the aggregate, z_neigh and hn in, dz_neigh out -- dz_self / z_self are
         #  no longer touched: the attention's share of dz_self is exactly zero, see gat_row_bwd_kernel)
-        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + (4 if RECOMPUTE_HN else 5) * 4 * n * F + 6 * 4 * n * heads
+        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + (4 if (RECOMPUTE_HN or not z_neigh.numel()) else 5) * 4 * n * F + 6 * 4 * n * heads
         with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
-                                         w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
+                                         w.data_ptr() if w is not None else None, z_self.data_ptr(), _p(z_neigh),
                                          att.data_ptr(), act_code, n, c.e, F, heads, _p(hn), u_s.data_ptr(),
                                          u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
                                          work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 1,
                                          amax.data_ptr() if amax is not None else None, ops._stream(dnagg)))
         if amax is not None:              # (ONE array for both gradients: the maximum over the pair of rows)
             ops.set_row_amax(dzs, amax); ops.set_row_amax(dzn, amax)
-        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None, None)
+        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None, None, None)
+
+
+def gat_tail_usable(x, F: int, heads: int) -> bool:
+    """Shapes gat_tail takes (the caller may then ask the paired Linear for hn / u_s / u_n: ops.GatPre)."""
+    heads = int(heads)
+    return bool(torch.is_tensor(x) and x.is_cuda and F <= 256 and F % heads == 0 and _fused_slice(F // heads))
 
 
 def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: int, scale, offset, seg: int, out_scale: float,
@@ -225,14 +245,18 @@ def gat_tail(adj: "ops.NormAdj", z_self, z_neigh, attention, act: str, heads: in
     padded multi-launch aggregate (the caller then composes gat_aggregate and ops.act_norm)."""
     n, F = z_self.shape
     heads = int(heads)
-    if not (F <= 256 and F % heads == 0 and _fused_slice(F // heads) and z_self.is_cuda):
+    pre = getattr(z_neigh, "_shd_gat_pre", None)
+    pre = pre if (pre is not None and pre.filled) else None
+    if not gat_tail_usable(z_self, F, heads):
+        if pre is not None:
+            raise RuntimeError("gat_tail: the paired Linear already left hn in z_neigh's place but the fused tail does not take this shape")
         return None
     drop = ops._drop_arg(out_dropout, F, seg, dual)
     link = ops.RootsLink() if (roots_only and not dual and ops.ROOTS_SPARSE_GRAD) else None
     pair = getattr(z_self, "_shd_pair", None)
     if pair is None or getattr(z_neigh, "_shd_pair", None) is not pair:
         pair = None                     # (the two inputs are not the two outputs of ONE paired Linear)
-    res = _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop, link, pair)
+    res = _GatTail.apply(z_self, z_neigh, attention, scale, offset, adj, ops.ACT_CODE[act], heads, int(seg), float(out_scale), drop, link, pair, pre)
     if link is not None and link.published and torch.is_tensor(res):
         res._shadow_roots = link
     return res

@@ -946,9 +946,9 @@ def test_benchmark_scale_train_step_matches_fp64_oracle(aggr, layers_, heads, B,
         # the timed GAT configuration's kernels (n >= 40 k rows > AMAX_HANDOVER_ROWS: the paired Linears and their weight
         # gradients run on two fp16 pieces with the joint row maxima the attention backward leaves)
         assert n >= 40000 and n >= ops.AMAX_HANDOVER_ROWS, n
-        assert any(k.startswith("gemm_tn_f16") for k in ran) and any(k.startswith("gemm_nt2_f16") for k in ran), ran
+        assert any(k.startswith("gemm_tn_f16") for k in ran) and any(k.startswith("gemm_nt2_gat_f16") for k in ran), ran
         assert any(k.startswith("gat_fwd") for k in ran) and any(k.startswith("gat_bwd") for k in ran), ran
-    assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd", "gemm_nt2_f16")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
+    assert any(k.startswith(("gemm_nt_split", "gemm_act_norm_fwd", "gemm_nt2_f16", "gemm_nt2_gat_f16")) for k in ran) and any(k.startswith("gemm_tn_split") for k in ran), ran
     # the head (normalisation + 47-class classifier + loss) ran as the fused kernels -- also with the parameters living in
     # FlatAdam's flat buffer (optimizer "flat": every tensor on its own 128-byte line, or the classifier's weight would sit on an
     # 8-byte boundary behind its 47-float offset / scale vectors and fall back to the separate nodes)
@@ -1227,7 +1227,7 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
-                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None):
+                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None, heads=1):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
@@ -1248,7 +1248,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         ops.SPARSE_TOP_BWD = sparse_top
         ops.SPARSE_TOP_BWD_MIN_ROWS = 1024          # (the production threshold is a host-time trade-off, not a correctness bound)
     try:
-        arch = dict(num_layers=n_layers, num_cls_layers=1, heads=1, dim=dim, act=act, layer_norm="norm_feat",
+        arch = dict(num_layers=n_layers, num_cls_layers=1, heads=heads, dim=dim, act=act, layer_norm="norm_feat",
                     feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
         torch.manual_seed(seed)
         model = DeepGNN(F0, F0, C, 0, arch, [("hops", 7)] if aug else [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
@@ -1903,6 +1903,37 @@ def test_sparse_top_pass_from_the_stack_node_equals_the_layer_nodes(n_layers, p_
     assert ops._SageStack.calls == k0 + 1 and ops._SageStack.sparse_top_calls == s0 + 1, "the stack node's row-sparse pass was not taken"
     assert ops._SageDense.sparse_top_calls == c0 + 1 and ops._SageDense.compact_dz_calls == d0 + 1
     assert calls0 == calls1 == (n_layers, n_layers - 1)
+    assert l0 == l1
+    torch.testing.assert_close(p1, p0, rtol=0, atol=0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,heads,p_drop,dropedge,act,sparse_top", [(3, 4, 0.3, 0.1, "elu", True), (2, 8, 0.0, 0.0, "relu", False),
+                                                                           (3, 2, 0.2, 0.0, "tanh", False), (2, 4, 0.0, 0.05, "elu", False)])
+def test_gat_attention_terms_from_the_paired_linear_equal_the_node_pass(n_layers, heads, p_drop, dropedge, act, sparse_top):
+    """Round 5: at the benchmark width the GAT layer's paired Linear launch (sl_gemm_nt2_gat_f32) also leaves hn = act(z_neigh) -- in
+    z_neigh's place, the pre-activation is never written -- and the attention's per-node terms u_s / u_n, the row pass runs alone
+    (sl_gat_fwd_rows) and the backward kernels take the activation's derivative from hn.  Against the separate per-node pass
+    (ops.GAT_PAIR_TAIL = False: sl_gemm_nt2_f32 + sl_gat_fwd): same activation, same dot4 + butterfly per head slice, same
+    derivative values -- loss, predictions and EVERY parameter gradient bit-identical, with dropout masks, drop-edge and the
+    row-sparse top pass."""
+    from shadow_gnn_amd import ops, ops_gat
+    res = []
+    for on in (False, True):
+        prev = ops.GAT_PAIR_TAIL
+        ops.GAT_PAIR_TAIL = on
+        c0 = (ops._LinearPair.gat_tail_calls, ops_gat._GatTail.pre_calls)
+        try:
+            res.append(_sage_stack_step(n_layers, 256, p_drop, 23, chain=True, fused=True, B=96, act=act, sparse_top=sparse_top, dropedge=dropedge,
+                                        aggr="gat", heads=heads))
+        finally:
+            ops.GAT_PAIR_TAIL = prev
+        took = (ops._LinearPair.gat_tail_calls - c0[0], ops_gat._GatTail.pre_calls - c0[1])
+        assert took == ((n_layers, n_layers) if on else (0, 0)), took
+    (l0, p0, g0, _c0), (l1, p1, g1, _c1) = res
     assert l0 == l1
     torch.testing.assert_close(p1, p0, rtol=0, atol=0)
     assert set(g0) == set(g1)
