@@ -523,7 +523,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     const bool second = MODE >= 2 && NBP == 1 && u >= d.asplit;      // (the K-concatenated operand's second tensor)
     const float *ptr = (ph || second ? arow1 : arow0) + 32 * (second ? u - d.asplit : u) + 4 * q;
     if (!kTail || 32 * u + 32 <= K) {
+#ifdef FUSED_A_NT       // (experiment, scripts/micro/ab_fused_a_nt.sh: non-temporal A loads -- forward launch 0.416 -> 0.49 ms: the four 16-byte pieces a lane takes from a 128-byte line then fetch it again)
+      an[q] = ld4s(ptr);
+#else
       an[q] = *reinterpret_cast<const float4 *>(ptr);
+#endif
     } else {
       float v[4];
 #pragma unroll

@@ -186,11 +186,16 @@ class DeepGNN(nn.Module):
         or None when this batch goes layer by layer (a layer 0 that gathers inside its aggregation kernel, frozen parameters)."""
         first = convs[0]
         n = int(feat.shape[0])
-        sparse_top = kind == 'sage' and self.training and torch.is_grad_enabled() and ops.SPARSE_TOP_BWD and n >= ops.SPARSE_TOP_BWD_MIN_ROWS
-        if sparse_top and not ops.sparse_top_stack_usable(adj, convs):
-            return None                                      # (the row-sparse top pass of the layer-by-layer nodes)
-        if n < max(1, ops.GEMM_SPLIT_MIN_ROWS) or not feat.is_cuda:
+        if not feat.is_cuda:
             return None
+        # the table of ops.step_path decides (this branch's stack passed the static preconditions: `kind` is set)
+        F = first.f_lin_self.weight.shape[0] if kind == 'sage' else first.f_lin.weight.shape[0]
+        blocks = getattr(adj, "spmm_blocks", None)
+        path = ops.step_path(kind, n, F, len(convs), bool(self.training and torch.is_grad_enabled()), "center", stackable=True,
+                             blockdiag=blocks is not None and blocks[0] is not None)
+        if path.forward != "stack":
+            return None                                      # (kernel by kernel, or the layer-by-layer nodes' row-sparse top pass)
+        sparse_top = path.backward == "stack+sparse-top" and ops.sparse_top_stack_usable(adj, convs)
         lazy = isinstance(feat, ops.LazyRows)
         if lazy and ops.FUSE_GATHER_INTO_SPMM:
             return None

@@ -11,7 +11,7 @@ torch stream.  No CPU / torch fallback: tensors must live on a ROCm device.
 import ctypes as C
 import os
 import sys
-from typing import List, Optional, Sequence
+from typing import NamedTuple, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -804,7 +804,8 @@ class _LinearPair(torch.autograd.Function):
     biases as the tiles leave (sl_gemm_nt2_f32); backward: dX = [dZa | dZb] . [Wa ; Wb] as ONE K-concatenated product
     straight from the two gradient tensors (sl_gemm_nt_cat_f32: no dXa + dXb pass), the bias gradients from the
     weight-gradient kernel's pass over dZ (column sums of its A tiles)."""
-    gat_tail_calls = 0          # forward passes that also left hn / u_s / u_n (tests assert on it)
+    calls = 0                   # forward passes of the paired node (tests assert on it)
+    gat_tail_calls = 0          # ... that also left hn / u_s / u_n
 
     @staticmethod
     def usable(X, Wa, Wb) -> bool:
@@ -848,6 +849,7 @@ class _LinearPair(torch.autograd.Function):
           with _timed(f"gemm_nt2_f16_N{N}" + ("" if K % 32 == 0 else "_Ktail"), 4 * M * (K + 2 * N), dev, flops=2 * 2 * M * K * N):
             check(lib.sl_gemm_nt2_f32(2, _ptr_array([X, X]), (C.c_int64 * 2)(X.stride(0), X.stride(0)), _ptr_array([am, am]), pack.data_ptr(),
                                       M, N, K, _ptr_array(bs), _ptr_array(Zs), (C.c_int64 * 2)(N, N), st))
+        _LinearPair.calls += 1
         ctx.save_for_backward(X, Wa, Wb)
         ctx.has_bias = (ba is not None, bb is not None)
         ctx.x_amax = am                  # (the weight gradients scale their fp16 pieces by it, sl_gemm_tn_f16)
@@ -1942,6 +1944,65 @@ def sage_stack_usable(mods) -> bool:
     return True
 
 
+class StepPath(NamedTuple):
+    """How one conv stack of a step runs (step_path): ``forward`` / ``backward`` name a row of the table below."""
+    forward: str
+    backward: str
+
+
+def step_path(kind: str, n: int, F: int, layers: int, training: bool, readout: str, stackable: bool = True, blockdiag: bool = True,
+              heads: int = 1) -> StepPath:
+    """THE table of the ways through a conv stack: (layer kind, batch rows n, hidden width F, layer count, training, read-out) -> path.
+    models.DeepGNN._run_stack dispatches on it; tests/test_layers_gpu.py::test_step_path_table walks its cells (the entry counters
+    must show the path the table names, the results must equal the kernel-by-kernel path's).
+
+    ``stackable``: the stack's static preconditions hold (sage_stack_usable / gcn_stack_usable, residue 'none', node task, inner
+    input dropouts fused into the producing layer); ``readout``: 'center' = the read-out selects one row per subgraph, anything
+    else reads every row; ``blockdiag``: the batch carries its subgraph offsets (the block-diagonal aggregate).
+
+      kind  rows n                       forward            backward (training)
+      ----  ---------------------------  -----------------  ---------------------------------------------------------------
+      any   n < GEMM_SPLIT_MIN_ROWS      kernels            kernels              torch.mm / SpMM / act_norm kernel by kernel
+      sage  >= 1 024, stackable, center  stack              stack                sl_sage_stack_fwd / sl_sage_stack_bwd: one C call each
+      sage  ... n >= SPARSE_TOP_BWD_MIN  stack              stack+sparse-top     two top layers on R / T = R u N(R), the rest
+            _ROWS, >= 3 layers, F >= 96                                          sl_sage_stack_bwd_ready (the headline step)
+      sage  ... fewer layers / F < 96    layer-calls        chained+sparse-top   _SageDense nodes: sl_sage_fwd per layer, ChainLink
+      sage  >= 1 024, not stackable,     layer-calls        chained              sl_sage_fwd / sl_sage_bwd_chain per layer
+            center
+      sage  >= 1 024, other read-outs    layer-calls        layer-calls          dual-output layers: sl_sage_fwd / sl_sage_bwd_chain
+                                                                                 without a link between the layers
+      gcn   >= 1 024, stackable, center  stack              stack                sl_gcn_stack_fwd / sl_gcn_stack_bwd
+      gcn   >= 1 024, not stackable      layer-calls        layer-calls          sl_gcn_fwd / sl_gcn_bwd per layer
+      gat   >= 1 024, F == 256,          pair-tail          dense | rows         sl_gemm_nt2_gat_f32 + sl_gat_fwd_rows; backward
+            head width 4 * 2^k <= 128                                            row-sparse ('rows') from SPARSE_TOP_BWD_MIN_ROWS, center
+      gat   >= 1 024, other widths       node-pass          dense | rows         sl_gemm_nt2_f32 + sl_gat_fwd (per-node pass)
+    Evaluation (``training`` False): the forward column, backward 'none'."""
+    tall = bool(GEMM_SPLIT and FUSED_LAYER_CALLS and n >= max(1, GEMM_SPLIT_MIN_ROWS))
+    none = "none"
+    if not tall:
+        return StepPath("kernels", "kernels" if training else none)
+    center = readout == "center"
+    big = bool(training and SPARSE_TOP_BWD and center and n >= SPARSE_TOP_BWD_MIN_ROWS)
+    if kind == "sage":
+        if stackable and center and SAGE_STACK:
+            if big and not (SPARSE_TOP_STACK and layers >= 3 and F % 32 == 0 and F >= BLOCKDIAG_MIN_F and blockdiag):
+                return StepPath("layer-calls", "chained+sparse-top")
+            return StepPath("stack", ("stack+sparse-top" if big else "stack") if training else none)
+        # (a read-out that reads every row of every layer -- mean / max / sort pooling, residue concat / max -- puts the layers in
+        #  dual-output mode: no ChainLink between them, every layer's own one-call backward)
+        chained = "chained" if (CHAIN_SAGE_BWD and F % 32 == 0 and center) else "layer-calls"
+        return StepPath("layer-calls", ((chained + "+sparse-top") if (big and chained == "chained") else chained) if training else none)
+    if kind == "gcn":
+        if stackable and center and SAGE_STACK:
+            return StepPath("stack", "stack" if training else none)
+        return StepPath("layer-calls", "layer-calls" if training else none)
+    if kind == "gat":
+        D = F // max(1, heads)
+        fwd = "pair-tail" if (GAT_PAIR_TAIL and F == 256 and D * heads == F and D % 4 == 0 and D <= 128 and (D // 4) & (D // 4 - 1) == 0) else "node-pass"
+        return StepPath(fwd, ("rows" if big else "dense") if training else none)
+    raise ValueError(f"step_path: unknown layer kind {kind!r}")
+
+
 def sparse_top_stack_usable(csr, mods) -> bool:
     """Can _SageStack run the row-sparse backward of its two top layers on this batch?  (Three layers or more of one width F with
     F % 32 == 0 and the block-diagonal aggregate: what the compact-dZ pass of the layer below the top needs.  Otherwise the
@@ -2246,6 +2307,8 @@ class _GcnDense(torch.autograd.Function):
     per direction (sl_gcn_fwd / sl_gcn_bwd): at the reference's own batch sizes the separate SpMM and Linear + act + norm
     nodes cost more host time than GPU time.  Only built when ``fusable`` holds; GCN.forward keeps the two-node path
     otherwise (same kernels, same order: identical results)."""
+    calls = 0                # forward passes through the one-call entry (tests assert on it)
+
     @staticmethod
     def fusable(X, adj, W):
         Fo, Fi = W.shape
@@ -2275,6 +2338,7 @@ class _GcnDense(torch.autograd.Function):
                              of.data_ptr(), int(act), float(drop[0]), int(drop[1]), AX.data_ptr(), AX.stride(0), Z.data_ptr(),
                              out.data_ptr(), opt(out2), pack.data_ptr(), _stream(X)))
         _tap([Z], [bc])
+        _GcnDense.calls += 1
         ctx.save_for_backward(AX, W, Z, sc, of, bc if bc is not None else sc.new_empty(0))
         ctx.adj = adj
         ctx.meta = (act, drop, scale.shape, offset.shape, b is not None, Fi)

@@ -1227,7 +1227,8 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
-                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None, heads=1):
+                     dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None, heads=1, pooling="center",
+                     split_min_rows=None):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
@@ -1240,6 +1241,9 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
     ops.CHAIN_SAGE_BWD = chain
     prev_m = ops.SPARSE_TOP_BWD_MIN_ROWS
     prev_k, prev_t = ops.SAGE_STACK, ops.SPARSE_TOP_STACK
+    prev_g = ops.GEMM_SPLIT_MIN_ROWS
+    if split_min_rows is not None:
+        ops.GEMM_SPLIT_MIN_ROWS = split_min_rows   # (1 << 30: every product and aggregate kernel by kernel)
     if top_stack is not None:
         ops.SPARSE_TOP_STACK = top_stack           # (row-sparse top pass from the whole-stack node / from the layer-by-layer nodes)
     if stack is not None:
@@ -1249,7 +1253,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         ops.SPARSE_TOP_BWD_MIN_ROWS = 1024          # (the production threshold is a host-time trade-off, not a correctness bound)
     try:
         arch = dict(num_layers=n_layers, num_cls_layers=1, heads=heads, dim=dim, act=act, layer_norm="norm_feat",
-                    feature_augment_ops="sum", aggr=aggr, residue="none", pooling="center", loss="softmax")
+                    feature_augment_ops="sum", aggr=aggr, residue="none", pooling=pooling, loss="softmax")
         torch.manual_seed(seed)
         model = DeepGNN(F0, F0, C, 0, arch, [("hops", 7)] if aug else [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
         with torch.no_grad():
@@ -1286,6 +1290,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         lib.sl_set_fused_epilogue(prev_f)
         ops.CHAIN_SAGE_BWD, ops.SPARSE_TOP_BWD, ops.SPARSE_TOP_BWD_MIN_ROWS = prev_c, prev_s, prev_m
         ops.SAGE_STACK, ops.SPARSE_TOP_STACK = prev_k, prev_t
+        ops.GEMM_SPLIT_MIN_ROWS = prev_g
 
 
 @pytest.mark.parametrize("n_layers,dim,p_drop,dropedge,act,aug,F0", [(5, 256, 0.4, 0.05, "relu", False, 100), (3, 128, 0.3, 0.0, "elu", True, 100),
@@ -1939,6 +1944,65 @@ def test_gat_attention_terms_from_the_paired_linear_equal_the_node_pass(n_layers
     assert set(g0) == set(g1)
     for k in g0:
         torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+
+
+_PATH_CELLS = [  # kind, roots B (rows n), F, layers, heads, training, read-out, SPARSE_TOP_BWD_MIN_ROWS
+    ("sage", 2, 256, 3, 1, True, "center", None), ("sage", 24, 256, 3, 1, True, "center", None), ("sage", 24, 256, 3, 1, True, "center", 1024),
+    ("sage", 24, 256, 2, 1, True, "center", 1024), ("sage", 24, 64, 3, 1, True, "center", 1024), ("sage", 24, 64, 3, 1, True, "center", None),
+    ("sage", 24, 256, 3, 1, True, "mean", 1024), ("sage", 24, 256, 3, 1, False, "center", None), ("sage", 24, 256, 3, 1, False, "mean", None),
+    ("gcn", 2, 256, 2, 1, True, "center", None), ("gcn", 24, 256, 3, 1, True, "center", 1024), ("gcn", 24, 64, 2, 1, True, "mean", None),
+    ("gcn", 24, 256, 2, 1, False, "center", None),
+    ("gat", 2, 256, 2, 4, True, "center", None), ("gat", 24, 256, 2, 4, True, "center", None), ("gat", 24, 256, 3, 4, True, "center", 1024),
+    ("gat", 24, 64, 2, 2, True, "center", 1024), ("gat", 24, 256, 2, 4, False, "center", None), ("gat", 24, 256, 2, 8, True, "mean", 1024),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,B,F,layers_,heads,training,readout,sparse_min", _PATH_CELLS)
+def test_step_path_table(kind, B, F, layers_, heads, training, readout, sparse_min, monkeypatch):
+    """ops.step_path -- THE table (layer kind, rows n, width F, layers, training, read-out) -> path that DeepGNN dispatches on -- cell by
+    cell: the entry counters show the path the table names, and loss / predictions / every parameter gradient equal the
+    kernel-by-kernel path's (GEMM_SPLIT_MIN_ROWS above the batch: torch.mm, the plain SpMM and the act_norm kernels, which the
+    golden layer tests hold against the fp64 layer oracle).  B = 2 roots: ~560 rows, under the 1 024-row threshold; B = 24: ~6.7 k
+    rows, "large" with the row-sparse threshold lowered to 1 024 (the table reads the thresholds it is asked about)."""
+    from shadow_gnn_amd import ops, ops_gat
+    if sparse_min is not None:
+        monkeypatch.setattr(ops, "SPARSE_TOP_BWD_MIN_ROWS", sparse_min)
+    b, _X, _l, _F0, _C = _bench_scale_batch(kind, B)
+    n = b.num_nodes
+    want = ops.step_path(kind, n, F, layers_, training, readout, stackable=True, blockdiag=True, heads=heads)
+    cnt = lambda: dict(stack=ops._SageStack.calls, stack_sp=ops._SageStack.sparse_top_calls, fused=ops._SageDense.fused_calls,
+                       chained=ops._SageDense.chained_calls, sparse=ops._SageDense.sparse_top_calls, gstack=ops._GcnStack.calls,
+                       gdense=ops._GcnDense.calls, pair=ops._LinearPair.calls, pre=ops._LinearPair.gat_tail_calls,
+                       grows=ops_gat._GatTail.sparse_top_calls)
+    c0 = cnt()
+    kw = dict(chain=True, fused=True, B=B, act="elu", dropedge=0.05, aggr=kind, heads=heads, pooling=readout, train=training)
+    got = _sage_stack_step(layers_, F, 0.2, 29, **kw)
+    d = {k: v - c0[k] for k, v in cnt().items()}
+    L = layers_
+    if kind == "sage":
+        fwd = "stack" if d["stack"] else ("layer-calls" if d["fused"] == L else "kernels")
+        if d["stack"]:
+            bwd = "stack+sparse-top" if d["stack_sp"] else "stack"
+        elif d["fused"] == L:
+            bwd = ("chained" if d["chained"] == L - 1 else "layer-calls") + ("+sparse-top" if d["sparse"] else "")
+        else:
+            bwd = "kernels"
+    elif kind == "gcn":
+        fwd = bwd = "stack" if d["gstack"] else ("layer-calls" if d["gdense"] == L else "kernels")
+    else:
+        fwd = "pair-tail" if d["pre"] == L else ("node-pass" if d["pair"] == L else "kernels")
+        bwd = "kernels" if fwd == "kernels" else ("rows" if d["grows"] else "dense")
+    if not training:
+        bwd = "none"
+    assert ops.StepPath(fwd, bwd) == want, (n, d)
+    ref = _sage_stack_step(layers_, F, 0.2, 29, split_min_rows=1 << 30, **kw)
+    assert abs(got[0] - ref[0]) < 2e-5 * max(1.0, abs(ref[0]))
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-5)
+    for k in ref[2]:
+        scale = float(ref[2][k].abs().max())
+        err = float((got[2][k] - ref[2][k]).abs().max())
+        assert err <= 2e-4 * scale + 1e-8, (k, err, scale)
 
 
 @pytest.mark.gpu
