@@ -6,7 +6,19 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from shadow_gnn_amd import ops, models, minibatch, tail, optim, dist   # noqa: F401
 
+if os.environ.get("HB_ROOT_GEMM"):            # (A/B: the row-sparse pass's small products on the library's kernels from this many rows on)
+    ops.ROOT_GEMM_MIN_ROWS = int(os.environ["HB_ROOT_GEMM"])
 acc = collections.defaultdict(lambda: [0, 0.0])
+# only the TIMED region counts (bench.py's warm-up steps come before it, its instrumented steps -- a HIP-event pair and a
+# synchronisation around every kernel -- after it): the window is [warmup, warmup + steps) in calls of DeepGNN.step
+_argv = sys.argv[1:]
+_opt = lambda name, dflt: int(_argv[_argv.index(name) + 1]) if name in _argv else dflt
+WARM, STEPS = _opt("--warmup", 5), _opt("--steps", 30)
+state = {"step": 0}
+
+
+def live():
+    return WARM <= state["step"] < WARM + STEPS
 
 
 def wrap(owner, name, label=None, static=False):
@@ -14,11 +26,15 @@ def wrap(owner, name, label=None, static=False):
     label = label or f"{getattr(owner, '__name__', owner)}.{name}"
 
     def inner(*a, **k):
+        on = live()
         t0 = time.perf_counter()
         try:
             return fn(*a, **k)
         finally:
-            e = acc[label]; e[0] += 1; e[1] += time.perf_counter() - t0
+            if on:
+                e = acc[label]; e[0] += 1; e[1] += time.perf_counter() - t0
+            if label == "DeepGNN.step":
+                state["step"] += 1
     setattr(owner, name, staticmethod(inner) if static else inner)
 
 
@@ -37,6 +53,8 @@ def _line_tracer(frame, event, arg):
     nm = _codes.get(frame.f_code)
     if nm is None:
         return None
+    if not live():
+        return _line_tracer
     now = time.perf_counter()
     key = id(frame)
     prev = _last.get(key)

@@ -287,8 +287,13 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
 }
 
 // backward, row side: alpha / de per edge, du_s, attention part of dz_self, datt[0]
+#ifndef SHADOW_GAT_ROW_BWD_WAVES     // (scripts/micro/ab_gat_row_waves.sh: a register cap for more resident wavefronts)
+#define SHADOW_GAT_ROW_BWD_ATTR
+#else
+#define SHADOW_GAT_ROW_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SHADOW_GAT_ROW_BWD_WAVES, 8)))
+#endif
 template <int LPR>
-__global__ void gat_row_bwd_kernel(GatParams p) {
+__global__ void SHADOW_GAT_ROW_BWD_ATTR gat_row_bwd_kernel(GatParams p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const uint32_t f = l * 4, ls = p.D / 4;
   const bool on = f < p.F;

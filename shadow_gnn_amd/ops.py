@@ -644,8 +644,7 @@ GEMM_SPLIT = True
 def mm_nt(A: torch.Tensor, B: torch.Tensor, min_rows: Optional[int] = None) -> torch.Tensor:
     """A[M,K] @ B[N,K]^T in fp32.  Tall products (M >= GEMM_SPLIT_MIN_ROWS, N <= 256) run on the bf16 matrix cores
     with the exact three-way operand split (fp32-level accuracy, see csrc/gemm.hip); the rest goes to
-    rocBLAS.  ``min_rows``: the caller's own threshold (the row-sparse backward's products over the roots: a rocBLAS call
-    with a transposed operand costs 0.2 - 0.8 ms of HOST time on MI355X, scripts/host_breakdown.py)."""
+    rocBLAS.  ``min_rows``: the caller's own threshold (the row-sparse backward's small products: ROOT_GEMM_MIN_ROWS)."""
     M, K = A.shape
     N = B.shape[0]
     if not (GEMM_SPLIT and A.is_cuda and M >= (GEMM_SPLIT_MIN_ROWS if min_rows is None else min_rows) and N <= 256 and A.dtype == torch.float32
@@ -873,8 +872,7 @@ class _LinearPair(torch.autograd.Function):
         XT = X.index_select(0, Tl)
         ng = ctx.needs_input_grad
         out = [None] * 8
-        # (the library's own kernels from ROOT_GEMM_MIN_ROWS rows on: a rocBLAS call with a transposed operand costs 0.2 - 0.8 ms of
-        #  host time here, and the bias gradient comes out of the weight gradient's pass over dZ)
+        # (the library's own kernels from ROOT_GEMM_MIN_ROWS rows on; the bias gradient comes out of the weight gradient's pass over dZ)
         for i, dz in ((0, dza), (1, dzb)):
             want_w, want_b = ng[1 + 2 * i], ctx.has_bias[i] and ng[2 + 2 * i]
             if want_b:
@@ -1211,9 +1209,9 @@ SPARSE_TOP_BWD_MIN_ROWS = int(os.environ.get("SHADOW_SPARSE_TOP_BWD_MIN_ROWS", "
 SPARSE_TOP_STACK = True
 # the row-sparse passes' small products on the library's own kernels from this many rows on, torch.mm / rocBLAS below.  Same-box
 # A/B (scripts/ab_root_gemm.sh, scripts/ab_top_stack.sh): the GAT stack's products over the rows T (~20 k rows) 11.63 -> 11.45 ms
-# per step on the own kernels; the GraphSAGE top layer's four products over the 1 024 roots 6.37 -> 6.46 (a workgroup covers 128
-# rows: 8 workgroups) -- although rocBLAS holds the HOST for 0.2 - 0.8 ms per call with a transposed operand there
-# (scripts/host_breakdown.py), which the GPU-bound step hides.
+# per step on the own kernels (and the bias gradient comes out of the weight gradient's pass); the GraphSAGE top layer's four
+# products over the 1 024 roots 6.37 -> 6.46 (a workgroup covers 128 rows: 8 workgroups); host time equal either way
+# (scripts/host_breakdown.py with HB_ROOT_GEMM).
 ROOT_GEMM_MIN_ROWS = 2048
 # a level of tail.build_backward_levels is kept while its input set is at most this share of the batch (built on the spot by
 # select_roots when the batch brings none)
