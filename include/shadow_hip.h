@@ -462,6 +462,9 @@ typedef struct {
   const uint32_t *t_indptr, *t_indices, *t_perm;
   const uint32_t *subg_node_off, *subg_edge_off;
   uint32_t num_subg, max_subg_nodes, n, e;
+  uint32_t row_entries_bound;   /* an upper bound of a row's entries when the caller knows one (the k of a top-k PPR batch), 0: unknown.
+                                 * More than 64 in a batch of at least 98 304 rows: the aggregations of 256-float rows run on the
+                                 * pipelined CSR kernel (sl_set_spmm_wide_pipe)                                                     */
 } sl_norm_adj;
 
 /* One GraphSAGE layer pass per call (shaDow/layers.py:471-483 and its autograd):
@@ -527,6 +530,13 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
  * SHADOW_FUSED_EPILOGUE=0 sets the initial state) -- the A/B handle of the tests and benchmarks: the layer entries then
  * run sl_gemm_nt_f32 + sl_act_norm_* as separate launches.                                                         */
 int sl_set_fused_epilogue(int on);
+/* Aggregations of rows wider than 128 floats inside the sl_sage_* / sl_gcn_* entries: the pipelined CSR kernel (a row per
+ * wavefront, sl_spmm_csr_amax_f32: its long-row loop keeps six gathers in flight) or the block-diagonal LDS kernel (every edge
+ * an LDS read, but a row's entries are walked by ONE thread per float4 column).  1 (default): the CSR kernel for batches whose
+ * rows may be long (sl_norm_adj.row_entries_bound > 64 and n >= 98 304: top-k PPR subgraphs, whose root rows list up to k - 1 neighbours), the
+ * LDS kernel otherwise; 0: always the LDS kernel; 2: always the CSR kernel; < 0: query.  Returns the previous setting.  Identical
+ * sums (both keep the edge order).                                                                                                */
+int sl_set_spmm_wide_pipe(int on);
 int sl_gemm_act_norm_supported(uint32_t N, uint32_t K);
 /* d_amax[i] = max_k |A[i, k]| of a row-major fp32 operand A [n, K] (16-byte aligned, lda % 4 == 0).  The kernels scale
  * row i by the power of two that puts it into [2^14, 2^15) (1 for an all-zero row; exponent clamped to +-62).          */

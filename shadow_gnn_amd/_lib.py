@@ -87,7 +87,7 @@ class SlNormAdj(C.Structure):
         ("indptr", C.c_void_p), ("indices", C.c_void_p), ("edge_w", C.c_void_p), ("row_scale", C.c_void_p),
         ("col_scale", C.c_void_p), ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("t_perm", C.c_void_p),
         ("subg_node_off", C.c_void_p), ("subg_edge_off", C.c_void_p), ("num_subg", C.c_uint32),
-        ("max_subg_nodes", C.c_uint32), ("n", C.c_uint32), ("e", C.c_uint32),
+        ("max_subg_nodes", C.c_uint32), ("n", C.c_uint32), ("e", C.c_uint32), ("row_entries_bound", C.c_uint32),
     ]
 
 
@@ -179,6 +179,7 @@ SIGNATURES = {
     "sl_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
                                _P]),
     "sl_set_fused_epilogue": (C.c_int, [C.c_int]),
+    "sl_set_spmm_wide_pipe": (C.c_int, [C.c_int]),
     "sl_prof_enable": (C.c_int, [C.c_int]),
     "sl_prof_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "sl_gemm_act_norm_supported": (C.c_int, [C.c_uint32, C.c_uint32]),
@@ -246,7 +247,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 21      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 22      # sg_abi_version() of the library these signatures describe
 
 
 def load():

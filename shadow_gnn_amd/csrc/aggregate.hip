@@ -303,7 +303,7 @@ spmm_pipe_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict
                  const float *__restrict__ edge_w, const uint32_t *__restrict__ edge_perm,
                  const float *__restrict__ row_scale, const float *__restrict__ col_scale,
                  const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy,
-                 uint32_t n, uint32_t F, uint32_t chunk, float *__restrict__ row_amax) {
+                 uint32_t n, uint32_t F, uint32_t chunk, float *__restrict__ row_amax, uint32_t amax_join) {
   static_assert(KMAX <= LPG && R + 1 <= LPG, "edge ids / row pointers live one per lane");
   const uint32_t lane = lane_id();
   const uint32_t sl = lane & (LPG - 1);              // lane inside the unit
@@ -391,6 +391,30 @@ spmm_pipe_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict
         for (int q = 0; q < R; q++) {
           uint32_t p = ip[q];
           const uint32_t b = ip[q + 1];
+#ifndef SHADOW_SPMM_LONG
+#define SHADOW_SPMM_LONG 6      // gathers in flight on the long rows before the pairs (scripts/micro/ab_spmm_long.sh)
+#endif
+#if SHADOW_SPMM_LONG > 2
+          for (; p + (SHADOW_SPMM_LONG - 1) < b; p += SHADOW_SPMM_LONG) {
+            uint32_t c[SHADOW_SPMM_LONG];
+            float w[SHADOW_SPMM_LONG];
+#pragma unroll
+            for (int k = 0; k < SHADOW_SPMM_LONG; k++) c[k] = indices[p + k];
+#pragma unroll
+            for (int k = 0; k < SHADOW_SPMM_LONG; k++) {
+              w[k] = 1.f;
+              if (edge_w) w[k] = edge_w[edge_perm ? edge_perm[p + k] : p + k];
+              if (col_scale) w[k] *= col_scale[c[k]];
+            }
+            if (on) {
+              float4 v[SHADOW_SPMM_LONG];
+#pragma unroll
+              for (int k = 0; k < SHADOW_SPMM_LONG; k++) v[k] = ld4(X + (int64_t)c[k] * ldx + f);
+#pragma unroll
+              for (int k = 0; k < SHADOW_SPMM_LONG; k++) { acc[q].x += w[k] * v[k].x; acc[q].y += w[k] * v[k].y; acc[q].z += w[k] * v[k].z; acc[q].w += w[k] * v[k].w; }
+            }
+          }
+#endif
           for (; p + 1 < b; p += 2) {
             const uint32_t c0 = indices[p], c1 = indices[p + 1];
             float w0 = 1.f, w1 = 1.f;
@@ -421,7 +445,8 @@ spmm_pipe_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict
         if (r0 + q < n && on) st4(Y + (int64_t)(r0 + q) * ldy + f, y);
         if (row_amax) {                   // (largest magnitude of the row: the fp16 operand scale of the GEMM that reads Y)
           const float m = group_max<LPG>(on ? amax4(y) : 0.f);
-          if (sl == 0 && r0 + q < n) row_amax[r0 + q] = m;
+          // (amax_join: the array holds the maxima of other columns of the same operand -- one wavefront owns the row)
+          if (sl == 0 && r0 + q < n) row_amax[r0 + q] = amax_join ? fmaxf(row_amax[r0 + q], m) : m;
         }
       }
     }
@@ -1148,6 +1173,19 @@ extern "C" int sl_spmm_csr_amax_f32(const uint32_t *d_indptr, const uint32_t *d_
                                     const uint32_t *d_edge_perm, const float *d_row_scale,
                                     const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y,
                                     int64_t ldy, uint32_t n, uint32_t F, float *d_row_amax, void *stream_) {
+  return shadow::spmm_csr_amax(d_indptr, d_indices, d_edge_w, d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, d_row_amax, 0,
+                               stream_);
+}
+
+// (library-internal: amax_join = 1 joins the row maxima with what d_row_amax holds -- the second half of a K-concatenated operand;
+//  only where the kernel holds whole rows, spmm_csr_whole_rows)
+bool shadow::spmm_csr_whole_rows(uint32_t F, const float *X, int64_t ldx, const float *Y, int64_t ldy) {
+  return F > 128 && F <= 256 && (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(X) && aligned16(Y);
+}
+
+int shadow::spmm_csr_amax(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const uint32_t *d_edge_perm,
+                          const float *d_row_scale, const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y, int64_t ldy,
+                          uint32_t n, uint32_t F, float *d_row_amax, int amax_join, void *stream_) {
   if (n == 0 || F == 0) return SG_OK;
   if (!d_indptr || !d_X || !d_Y) return set_error(SG_ERR_INVALID, "sl_spmm_csr_f32: null argument");
   hipStream_t st = (hipStream_t)stream_;
@@ -1175,14 +1213,17 @@ extern "C" int sl_spmm_csr_amax_f32(const uint32_t *d_indptr, const uint32_t *d_
     const uint64_t units = (G + chunk - 1) / chunk;
     const uint32_t blocks = (uint32_t)((((units + upb - 1) / upb) + 7u) & ~(uint64_t)7u);
     hipLaunchKernelGGL((spmm_pipe_kernel<R, KMAX, 64>), dim3(blocks), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_w,
-                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, chunk, d_row_amax);
+                       d_edge_perm, d_row_scale, d_col_scale, d_X, ldx, d_Y, ldy, n, F, chunk, d_row_amax, amax_join ? 1u : 0u);
     amax_done = true;
   }
   else if (F <= 512) { SHD_SPMM(64, 2); }
   else { SHD_SPMM(64, 4); }
 #undef SHD_SPMM
   SHD_HIP(hipGetLastError());
-  if (d_row_amax && !amax_done) return sl_row_amax(d_Y, ldy, n, F, d_row_amax, stream_);
+  if (d_row_amax && !amax_done) {
+    if (amax_join) return set_error(SG_ERR_INVALID, "spmm_csr_amax: joined row maxima need 128 < F <= 256 (F = %u)", F);
+    return sl_row_amax(d_Y, ldy, n, F, d_row_amax, stream_);
+  }
   return SG_OK;
 }
 

@@ -60,6 +60,12 @@ int spmm_blockdiag_padded(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const float *d_row_scale, const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y, int64_t ldy,
                           uint32_t n, uint32_t F, const uint32_t *d_subg_node_off, const uint32_t *d_subg_edge_off, uint32_t num_subg,
                           uint32_t max_subg_nodes, float *d_row_amax, void *stream_);
+// pipelined CSR SpMM with the output's row maxima from the same pass (aggregate.hip): whole rows per wavefront for 128 < F <= 256;
+// amax_join: d_row_amax holds the maxima of other columns of the same operand
+bool spmm_csr_whole_rows(uint32_t F, const float *X, int64_t ldx, const float *Y, int64_t ldy);
+int spmm_csr_amax(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const uint32_t *d_edge_perm,
+                  const float *d_row_scale, const float *d_col_scale, const float *d_X, int64_t ldx, float *d_Y, int64_t ldy, uint32_t n,
+                  uint32_t F, float *d_row_amax, int amax_join, void *stream_);
 
 constexpr int kWave = 64;  // CDNA wavefront
 

@@ -18,8 +18,23 @@ using namespace shadow;
 
 namespace {
 
-// does the SpMM of this shape run on the kernel that can join row maxima atomically?
+// Rows wider than 128 floats on the pipelined CSR kernel (a row per wavefront, the gathers out of the L2) instead of the
+// block-diagonal LDS kernel, for batches whose rows may be long (round 5, after the CSR kernel's long-row loop took 6 gathers in
+// flight).  One launch at 256 floats, plain row-normalised adjacency (scripts/micro/ab_spmm_long.sh): PPR batch (153 k rows, root
+// rows of up to 199 entries: the LDS kernel walks them with one thread per float4 column) 122 -> 94 us, k-hop batch (290 k rows)
+// 155 -> 141; inside the training step, with the drop-edge mask and the transposed passes' permutation (scripts/ab_spmm_wide.sh):
+// PPR 139 -> 112 us (step 5.98 -> 5.76 ms), but k-hop 151 -> 163 (6.11 -> 6.18) and arxiv 41 -> 52 (2.26 -> 2.41): by the bound.
+static int g_spmm_wide_pipe = 1;                     // 0: never, 1: batches with long rows, 2: always
+// (... and enough rows to fill the persistent kernel's 4 096 wavefronts with chunks of six 4-row groups: the papers100M PPR batches,
+//  ~40 k rows, run 0.051 ms on the LDS kernel and 0.072 on the pipelined one)
+constexpr uint32_t kWidePipeRowEntries = 64, kWidePipeMinRows = 98304;
+static bool spmm_wide_pipe(const sl_norm_adj *a) {
+  return g_spmm_wide_pipe == 2 || (g_spmm_wide_pipe == 1 && a->row_entries_bound > kWidePipeRowEntries && a->n >= kWidePipeMinRows);
+}
+
+// does the SpMM of this shape run on a kernel that can join row maxima with what the array holds?
 bool spmm_joins(const sl_norm_adj *a, uint32_t F, const float *X, int64_t ldx, const float *Y, int64_t ldy) {
+  if (spmm_wide_pipe(a) && spmm_csr_whole_rows(F, X, ldx, Y, ldy)) return true;     // (a row per wavefront: plain read-modify-write)
   return a->subg_node_off && F >= 96 && (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && !(reinterpret_cast<uintptr_t>(X) & 15) &&
          !(reinterpret_cast<uintptr_t>(Y) & 15);
 }
@@ -39,6 +54,10 @@ int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx,
   const float *rs = transposed ? a->col_scale : a->row_scale, *cs = transposed ? a->row_scale : a->col_scale;
   // algorithmic bytes: indptr + indices (+ edge values) + read X + write A.X
   SHD_PROF_FMT(4.0 * (a->n + 1) + 4.0 * a->e + (a->edge_w ? 4.0 * a->e : 0.0) + 8.0 * a->n * F, 0, st, "spmm_F%u", F);
+  if (!zero_pad && spmm_wide_pipe(a) && spmm_csr_whole_rows(F, X, ldx, Y, ldy)) {
+    // (the kernel writes every row's maximum: nothing to clear; amax_state 2: joined with what the array holds)
+    return spmm_csr_amax(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, amax, amax_state == 2 ? 1 : 0, st);
+  }
   if (a->subg_node_off && F >= 96) {
     float *am = spmm_joins(a, F, X, ldx, Y, ldy) ? amax : nullptr;
     if (am && amax_state == 0) SHD_HIP(hipMemsetAsync(am, 0, (size_t)a->n * 4, (hipStream_t)st));
@@ -111,6 +130,12 @@ static size_t images_bytes_sage(uint32_t Fin, uint32_t Fout) {
   const size_t fwd = std::max(2 * sl_gemm_act_norm_pack_bytes(Fout, Fin), 2 * sl_gemm_pack_bytes(Fout, Fin));
   const size_t bwd = std::max(sl_gemm_act_norm_pack_bytes(Fin, 2 * Fout), sl_gemm_pack_bytes(Fin, 2 * Fout));
   return (std::max(fwd, bwd) + 15) & ~(size_t)15;
+}
+
+extern "C" int sl_set_spmm_wide_pipe(int on) {
+  const int prev = g_spmm_wide_pipe;
+  if (on >= 0) g_spmm_wide_pipe = on > 2 ? 2 : on;
+  return prev;
 }
 
 extern "C" size_t sl_sage_pack_bytes(uint32_t n, uint32_t Fin, uint32_t Fout) {

@@ -597,8 +597,12 @@ class MinibatchShallowExtractor:
             if not last and self.prefetch and self._launched[mode] == t + 1:
                 self._launch(mode)
             return self._empty_batch(mode)
+        # (a top-k PPR subgraph holds k nodes, its root's row up to k - 1 of them: the bound that sends the 256-float aggregations
+        #  of such batches to the pipelined CSR kernel, ops.DeviceCSR; the rows of a node-induced k-hop subgraph have no such bound)
+        cfg = self.sampler_cfg
+        bound = int(cfg.k) if (cfg.method == "ppr" and int(cfg.num_roots) == 1) else 0
         adj = ops.DeviceCSR(subgs.indptr, subgs.indices, subg_off=subgs.subg_node_off,
-                            subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"])
+                            subg_edge_off=subgs.subg_edge_off, max_subg_nodes=subgs.counts["max_subg_nodes"], row_entries_bound=bound)
         tail_plan = self._tail_plan(subgs, adj, subgs.target) if self.tail_plan_layers > 0 else None
         if (self.top_backward_plan and mode == TRAIN and self.tail_plan_layers == 0 and adj.n >= ops.SPARSE_TOP_BWD_MIN_ROWS
                 and ops.SPARSE_TOP_BWD):                  # (evaluation batches: no backward pass will ask for the row sets)

@@ -131,10 +131,12 @@ class DeviceCSR:
     uint32 values, all-ones data (the sampler emits data = 1., .cpp:411,423)."""
 
     def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, subg_off: Optional[torch.Tensor] = None,
-                 subg_edge_off: Optional[torch.Tensor] = None, max_subg_nodes: int = 0):
+                 subg_edge_off: Optional[torch.Tensor] = None, max_subg_nodes: int = 0, row_entries_bound: int = 0):
         """``subg_off`` / ``subg_edge_off`` ([P+1] int32 node / edge offsets of the diagonal blocks, as
         the sampler returns them) let SpMM stage each subgraph's features in LDS
-        (sl_spmm_blockdiag_f32)."""
+        (sl_spmm_blockdiag_f32).  ``row_entries_bound``: an upper bound of a row's entries when the caller knows one (the k of a
+        top-k PPR batch, budget + 1 of a budgeted k-hop batch; 0: unknown) -- batches with long rows aggregate their 256-float
+        rows on the pipelined CSR kernel (sl_set_spmm_wide_pipe)."""
         _need_cuda(indptr, indices)
         assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
         self.indptr = indptr.contiguous()
@@ -147,6 +149,7 @@ class DeviceCSR:
         self.subg_off = subg_off.contiguous() if subg_off is not None else None
         self.subg_edge_off = subg_edge_off.contiguous() if subg_edge_off is not None else None
         self.max_subg_nodes = int(max_subg_nodes)
+        self.row_entries_bound = int(row_entries_bound)
         if self.subg_off is not None:
             assert self.subg_edge_off is not None and self.subg_edge_off.numel() == self.subg_off.numel()
             assert self.subg_off.dtype == torch.int32 and self.subg_off.is_cuda
@@ -302,7 +305,7 @@ def _adj_struct(adj: "NormAdj", need_transpose: bool):
     boff, beoff, bmax = c.spmm_blocks
     st = _lib.SlNormAdj(c.indptr.data_ptr(), c.indices.data_ptr(), ptr(adj.edge_w), ptr(adj.row_scale), ptr(adj.col_scale),
                         ptr(ti), ptr(tx), ptr(tp), ptr(boff), ptr(beoff),
-                        (int(boff.numel()) - 1) if boff is not None else 0, bmax, c.n, c.e)
+                        (int(boff.numel()) - 1) if boff is not None else 0, bmax, c.n, c.e, int(getattr(c, "row_entries_bound", 0)))
     cache[key] = st
     return st
 
@@ -312,9 +315,9 @@ def _adj_struct(adj: "NormAdj", need_transpose: bool):
 FUSED_LAYER_CALLS = True
 
 
-def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None, out=None):
+def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, blocks=None, out=None, row_entries_bound=0):
     """``blocks`` = (subg_off, subg_edge_off, max_subg_nodes) of a block-diagonal adjacency.
-    ``out``: optional [n, F] destination (may be a column slice of a wider buffer)."""
+    ``out``: optional [n, F] destination (may be a column slice of a wider buffer).  ``row_entries_bound``: DeviceCSR's."""
     X = _f32c(X)
     F = X.shape[1]
     if out is not None:
@@ -330,7 +333,12 @@ def _spmm_raw(indptr, indices, edge_w, edge_perm, row_scale, col_scale, X, n, bl
     lib = _lib.load()
     opt = lambda t: t.data_ptr() if t is not None else None
     with _timed(f"spmm_F{F}", nbytes, X.device):
-        if blocks is not None and blocks[0] is not None and F >= BLOCKDIAG_MIN_F:
+        # (rows wider than 128 floats: the pipelined CSR kernel -- a row per wavefront, gathers out of the L2 -- as inside the
+        #  sl_sage_* / sl_gcn_* entries, sl_set_spmm_wide_pipe; the block-diagonal LDS kernel for 96 .. 128 floats)
+        mode = lib.sl_set_spmm_wide_pipe(-1)
+        wide = (128 < F <= 256 and F % 4 == 0 and X.stride(0) % 4 == 0 and Y.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+                and Y.data_ptr() % 16 == 0 and (mode == 2 or (mode == 1 and row_entries_bound > 64 and n >= 98304)))   # (layer_fused.hip: spmm_wide_pipe)
+        if blocks is not None and blocks[0] is not None and F >= BLOCKDIAG_MIN_F and not wide:
             off, eoff, mn = blocks
             check(lib.sl_spmm_blockdiag_f32(
                 indptr.data_ptr(), indices.data_ptr(), opt(edge_w), opt(edge_perm), opt(row_scale), opt(col_scale),
@@ -350,7 +358,7 @@ class _SpMM(torch.autograd.Function):
         ctx.adj = adj
         c = adj.csr
         return _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
-                         c.spmm_blocks)
+                         c.spmm_blocks, row_entries_bound=c.row_entries_bound)
 
     @staticmethod
     def backward(ctx, dY):
@@ -359,7 +367,7 @@ class _SpMM(torch.autograd.Function):
         # (diag(rs) W diag(cs))^T = diag(cs) W^T diag(rs)
         c = adj.csr          # the transpose of a block-diagonal matrix has the same blocks
         dX = _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale,
-                       adj.row_scale, dY, c.n, c.spmm_blocks)
+                       adj.row_scale, dY, c.n, c.spmm_blocks, row_entries_bound=c.row_entries_bound)
         return dX, None
 
 
@@ -1336,7 +1344,7 @@ class _SageDense(torch.autograd.Function):
                 AX = None                  # the one-call entry below computes it
             else:
                 AX = _spmm_raw(c.indptr, c.indices, adj.edge_w, None, adj.row_scale, adj.col_scale, X, c.n,
-                               c.spmm_blocks)
+                               c.spmm_blocks, row_entries_bound=c.row_entries_bound)
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
         bsc = [b.detach().contiguous() if b is not None else None for b in (bs, bn)]
@@ -1685,7 +1693,7 @@ class _SageDense(torch.autograd.Function):
             c = adj.csr
             ti, tx, tp = c.transposed
             _spmm_raw(ti, tx, adj.edge_w, tp if adj.edge_w is not None else None, adj.col_scale, adj.row_scale, dZn,
-                      c.n, c.spmm_blocks, out=buf[:, F:])
+                      c.n, c.spmm_blocks, out=buf[:, F:], row_entries_bound=c.row_entries_bound)
             dX = mm_nt(buf, torch.cat([Ws.t(), Wn.t()], dim=1))
         dWs = weight_grad(dZs, X) if ng[2] else None
         dWn = weight_grad(dZn, AX) if ng[4] else None

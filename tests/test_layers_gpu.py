@@ -1228,7 +1228,7 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
                      dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None, heads=1, pooling="center",
-                     split_min_rows=None):
+                     split_min_rows=None, row_bound=0):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
@@ -1263,7 +1263,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
             for q in model.conv_layers[0][li].parameters():
                 q.requires_grad_(False)
         adj = ops.DeviceCSR(b.indptr, b.indices, subg_off=b.subg_node_off, subg_edge_off=b.subg_edge_off,
-                            max_subg_nodes=b.counts["max_subg_nodes"])
+                            max_subg_nodes=b.counts["max_subg_nodes"], row_entries_bound=row_bound)
         if given_plan:                       # the row sets of the row-sparse top-layer backward come with the batch (as from the extractor)
             from shadow_gnn_amd import tail
             b.target._shd_top_plan = tail.TopBackwardPlan(adj, b.target)
@@ -1944,6 +1944,42 @@ def test_gat_attention_terms_from_the_paired_linear_equal_the_node_pass(n_layers
     assert set(g0) == set(g1)
     for k in g0:
         torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggr,n_layers,pooling,sparse_top", [("sage", 3, "center", True), ("sage", 3, "mean", False), ("gcn", 2, "center", False)])
+def test_long_row_batches_aggregate_on_the_pipelined_kernel(aggr, n_layers, pooling, sparse_top):
+    """Round 5: a batch whose rows may be long (DeviceCSR.row_entries_bound > 64: the root rows of top-k PPR subgraphs) aggregates its
+    256-float rows on the pipelined CSR kernel -- a row per wavefront, six gathers in flight on long rows, the row maxima written
+    (or, for the second half of a K-concatenated operand, joined) in the same pass -- instead of the block-diagonal LDS kernel, inside
+    the one-call entries and outside them.  Both kernels add a row's terms in edge order: the step's loss, predictions and every
+    parameter gradient agree to rounding (1e-6 of the scale) with the bound given (mode 1), always (2) and never (0)."""
+    from shadow_gnn_amd import _lib
+    lib = _lib.load()
+    assert lib.sl_set_spmm_wide_pipe(-1) == 1
+    res = {}
+    # (B = 384 roots: ~108 k rows, above the 98 304 rows from which the bound selects the pipelined kernel)
+    for mode, bound in ((0, 200), (1, 200), (2, 0), (1, 0)):
+        prev = lib.sl_set_spmm_wide_pipe(mode)
+        try:
+            res[(mode, bound)] = _sage_stack_step(n_layers, 256, 0.2, 37, chain=True, fused=True, B=384, act="relu", dropedge=0.1, aggr=aggr,
+                                                  pooling=pooling, sparse_top=sparse_top, row_bound=bound)
+        finally:
+            lib.sl_set_spmm_wide_pipe(prev)
+    ref = res[(0, 200)]
+    # (without a bound the default mode stays on the LDS kernel: bit-identical to "never")
+    assert res[(1, 0)][0] == ref[0]
+    torch.testing.assert_close(res[(1, 0)][1], ref[1], rtol=0, atol=0)
+    for key in ((1, 200), (2, 0)):
+        got = res[key]
+        assert abs(got[0] - ref[0]) <= 1e-6 * max(1.0, abs(ref[0])), key
+        torch.testing.assert_close(got[1], ref[1], rtol=1e-5, atol=1e-6)
+        for k in ref[2]:
+            scale = float(ref[2][k].abs().max())
+            err = float((got[2][k] - ref[2][k]).abs().max())
+            assert err <= 2e-6 * scale + 1e-9, (key, k, err, scale)
+    # the two runs on the pipelined kernel are the same run
+    assert res[(1, 200)][0] == res[(2, 0)][0]
 
 
 _PATH_CELLS = [  # kind, roots B (rows n), F, layers, heads, training, read-out, SPARSE_TOP_BWD_MIN_ROWS
