@@ -1292,9 +1292,10 @@ def _at_dzn_on_rows(adj: "NormAdj", plan, dZnT: torch.Tensor, n: int, Fo: int):
     opt = lambda t_: t_.data_ptr() if t_ is not None else None
     t = plan.t
     AtdZn = torch.empty(n, Fo, **f32)
-    amx = torch.zeros(n, **f32)
     ew = adj.edge_w
-    if plan.f_indptr is not None and 128 < Fo <= 256:
+    filtered = plan.f_indptr is not None and 128 < Fo <= 256
+    amx = torch.empty(n, **f32) if filtered else torch.zeros(n, **f32)      # (the filtered pass writes every row's maximum)
+    if filtered:
         # the transposed structure filtered to the columns T (tail.TopBackwardPlan): the rows' kept entries in their
         # original order -- the sums of the row-mapped walk below without its zero terms -- gathered from the compact
         # gradient (22 MB: L2 / Infinity Cache), row maxima from the same pass
