@@ -99,8 +99,18 @@ __global__ void __launch_bounds__(1024) gemm_pack_f16_kernel(const PackJob job) 
   __shared__ float sscale[32];
   const PackSrc &sr = job.src[blockIdx.y];
   const uint32_t t = blockIdx.x, tid = threadIdx.x, N = job.N, K = job.K, tiles = job.tiles;
-  if (job.zero)
-    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * 1024 + tid; i < job.n_zero; i += gridDim.x * gridDim.y * 1024) job.zero[i] = 0.f;
+  if (job.zero) {
+    // (16 workgroups clear ~1.2 MB -- the aggregation's row-maximum array -- on a launch every layer pass waits for: 16-byte stores)
+    const uint32_t nthr = gridDim.x * gridDim.y * 1024, me = (blockIdx.y * gridDim.x + blockIdx.x) * 1024 + tid;
+    if ((reinterpret_cast<uintptr_t>(job.zero) & 15) == 0) {
+      const uint32_t n4 = job.n_zero >> 2;
+      float4 *z4 = reinterpret_cast<float4 *>(job.zero);
+      for (uint32_t i = me; i < n4; i += nthr) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t i = 4 * n4 + me; i < job.n_zero; i += nthr) job.zero[i] = 0.f;
+    } else {
+      for (uint32_t i = me; i < job.n_zero; i += nthr) job.zero[i] = 0.f;
+    }
+  }
   auto elem = [&](uint32_t col, uint32_t k) -> float {
     return k < sr.K1 ? sr.B1[(int64_t)col * sr.s1j + (int64_t)k * sr.s1k] : sr.B2[(int64_t)col * sr.s2j + (int64_t)(k - sr.K1) * sr.s2k];
   };
