@@ -444,8 +444,8 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
 // (Round 5, measured and dropped: a head-split walk -- items (row, head) of D / 4 lanes in the order XCD range -> chunk of
 //  4 096 rows -> head -> row, so that the slice re-touched between a row's first and last gather is 1 MB instead of the
 //  subgraph's 4.6 MB of hn against a 4 MB L2.  Forward 0.47 -> 0.88 ms per launch at chunk heights 2 048 / 4 096 / 8 192
-//  (scripts/ab_gat_head_chunk.sh, git show 80bf3cc..: four times the wave iterations of a quarter of the work each, four
-//  diverging items per wavefront): the row walk is bound by its dependent loads and per-edge arithmetic, not by where the
+//  (same box, the products depth-3 GAT bench; the kernel was not kept: four times the wave iterations of a quarter of the work
+//  each, four diverging items per wavefront): the row walk is bound by its dependent loads and per-edge arithmetic, not by where the
 //  gathered rows come from -- recomputing elu where a row is gathered costs the same kernels 28 % (RECOMPUTE_HN).)
 // datt[j] = sum over blocks of datt_part[block][j] in a fixed order (bit-reproducible; no float atomics).  A workgroup owns
 // 32 outputs; its 32 x 32 threads cut the block range into 32 slices, eight independent running sums per thread (one thread
