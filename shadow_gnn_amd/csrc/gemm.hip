@@ -1260,7 +1260,13 @@ extern "C" int sl_gemm_tn_f16_pair(const float *d_A1, const float *d_A2, int64_t
     return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: operands must be 16-byte aligned with ld %% 4 == 0");
   if (M == 0) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: M = 0");
   hipStream_t st = (hipStream_t)stream;
-  const uint32_t G = sl_gemm_tn_slices(M);
+  uint32_t G = sl_gemm_tn_slices(M);
+  // The pair runs 2 G workgroups of ~137 KB LDS each -- one per CU: with G = #CUs that is two rounds, and every slice leaves a 256 KB
+  // partial product per weight for the reduction to read back (2 x 64 MB written + read at 289 k rows).  Half the slices: one round of
+  // twice the rows, half the partial traffic (SHADOW_GEMM_TN_PAIR_HALF=0: the full count; same sums per slice, the slices added in
+  // slice order as before -- a different split of the rows, i.e. different rounding than G slices, deterministic either way).
+  static const bool half_slices = [] { const char *e = getenv("SHADOW_GEMM_TN_PAIR_HALF"); return !(e && e[0] == '0'); }();
+  if (half_slices && G >= 32 && (G / 2) % 8 == 0 && ((M + G / 2 - 1) / (G / 2) + 15u) / 16u * 16u <= kTnF16MaxRows) G /= 2;
   uint32_t rows_per_wg = (M + G - 1) / G;
   rows_per_wg = (rows_per_wg + 15u) & ~15u;
   if (rows_per_wg > kTnF16MaxRows) return set_error(SG_ERR_INVALID, "sl_gemm_tn_f16_pair: %u rows per slice (at most %u)", rows_per_wg, kTnF16MaxRows);

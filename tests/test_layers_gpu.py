@@ -572,8 +572,11 @@ def test_weight_gradient_gemm_on_two_fp16_pieces_matches_fp64(M, lda, kind):
 @pytest.mark.parametrize("M", [300000, 289309, 40000, 2049, 700])
 def test_weight_gradient_pair_launch_equals_two_launches(M):
     """sl_gemm_tn_f16_pair: both halves of a K-concatenated operand against the same X in one launch (the two workgroups of a
-    row slice on one XCD, X fetched from HBM once) -- each product equals its own sl_gemm_tn_f16 launch bit for bit, also when
-    the slice count is not a multiple of eight (two plain launches inside) and for slices of a single step."""
+    row slice on one XCD, X fetched from HBM once).  Small M (fewer than 32 slices, or a slice count that is not a multiple of
+    eight: two plain launches inside; slices of a single step): each product equals its own sl_gemm_tn_f16 launch bit for bit.
+    From 32 slices on (round 5) the pair runs on HALF the slices -- one round of workgroups, half the partial products -- so the
+    rows are cut differently than by the single launch: both are held to the same bound against the fp64 product (1.5e-6 of the
+    sum of magnitudes), agree with each other to that bound, and the pair is run-to-run bit-identical."""
     from shadow_gnn_amd import ops
     g = torch.Generator(device=DEV).manual_seed(M)
     buf = torch.randn(M, 768, device=DEV, generator=g) * (torch.rand(M, 1, device=DEV, generator=g) + 0.01)
@@ -581,14 +584,24 @@ def test_weight_gradient_pair_launch_equals_two_launches(M):
     X = torch.randn(M, 256, device=DEV, generator=g)
     ja, xa = ops.row_amax(buf[:, :512]), ops.row_amax(X)
     p1, p2 = ops.weight_grad_f16_pair(buf[:, :256], buf[:, 256:512], X, ja, xa)
-    assert torch.equal(p1, ops.weight_grad_f16(buf[:, :256], X, ja, xa))
-    assert torch.equal(p2, ops.weight_grad_f16(buf[:, 256:512], X, ja, xa))
-    ref = buf[:, 256:512].double().t() @ X.double()
-    den = (buf[:, 256:512].abs().double().t() @ X.abs().double()).clamp_min(1e-300)
-    assert float(((p2.double() - ref).abs() / den).max()) < 1.5e-6
+    s1, s2 = ops.weight_grad_f16(buf[:, :256], X, ja, xa), ops.weight_grad_f16(buf[:, 256:512], X, ja, xa)
+    same_split = M < 32 * 128
+    for p_, s_, A in ((p1, s1, buf[:, :256]), (p2, s2, buf[:, 256:512])):
+        ref = A.double().t() @ X.double()
+        den = (A.abs().double().t() @ X.abs().double()).clamp_min(1e-300)
+        assert float(((p_.double() - ref).abs() / den).max()) < 1.5e-6
+        assert float(((s_.double() - ref).abs() / den).max()) < 1.5e-6
+        if same_split:
+            assert torch.equal(p_, s_)
     q1, q2, c1, c2 = ops.weight_grad_f16_pair(buf[:, :256], buf[:, 256:512], X, ja, xa, True)          # with the column sums
-    assert torch.equal(q1, p1) and torch.equal(q2, p2)
-    assert torch.equal(c1, ops.weight_grad_f16(buf[:, :256], X, ja, xa, True)[1]) and torch.equal(c2, ops.weight_grad_f16(buf[:, 256:512], X, ja, xa, True)[1])
+    assert torch.equal(q1, p1) and torch.equal(q2, p2)                     # (run to run, with and without the column sums)
+    t1, t2 = ops.weight_grad_f16(buf[:, :256], X, ja, xa, True)[1], ops.weight_grad_f16(buf[:, 256:512], X, ja, xa, True)[1]
+    if same_split:
+        assert torch.equal(c1, t1) and torch.equal(c2, t2)
+    else:
+        for c_, A in ((c1, buf[:, :256]), (c2, buf[:, 256:512])):
+            ref = A.double().sum(0)
+            assert float(((c_.double() - ref).abs() / A.abs().double().sum(0).clamp_min(1e-300)).max()) < 1e-6
 
 
 @pytest.mark.parametrize("nb,F,seg", [(2, 256, 256), (1, 256, 256), (2, 256, 64), (2, 100, 100), (1, 48, 48)])
