@@ -325,11 +325,15 @@ def main():
     counts = []
     wait0 = mb.wait_s
     ar_wait0, ar_issued0 = model.grad_sync.wait_s, model.grad_sync.issued
+    ms0 = torch.cuda.memory_stats(dev)          # (diagnostic: hipMalloc / hipFree calls of the caching allocator inside the timed region)
     t0 = time.perf_counter()
     for _ in range(K):
         c, ret = one_step()
         counts.append(c)
     t_host = time.perf_counter() - t0           # host-side enqueue time (diagnostic)
+    ms1 = torch.cuda.memory_stats(dev)
+    alloc_diag = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc_diag["reserved_GB"] = round(ms1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)
     t_blocked = mb.wait_s - wait0               # ... of which blocked on the sampler's count read-back (the host is idle there)
     torch.cuda.synchronize(dev)
     dt_own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the others)
@@ -632,7 +636,7 @@ def main():
     line = {
         "metric": "sampled-nodes/sec", "value": round(nodes / dt, 1), "unit": "sampled-nodes/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / K * 1e3, 4),
-        "host_busy_ms_per_step": round((t_host - t_blocked) / K * 1e3, 4),
+        "host_busy_ms_per_step": round((t_host - t_blocked) / K * 1e3, 4), "allocator_in_timed_region": alloc_diag,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "train_steps_per_sec": round(K / dt, 3), "instrumented_steps": K_prof,
         "target_only_tail": tail_info,
