@@ -1291,7 +1291,7 @@ def _at_dzn_on_rows(adj: "NormAdj", plan, dZnT: torch.Tensor, n: int, Fo: int):
     st = _stream(dZnT)
     opt = lambda t_: t_.data_ptr() if t_ is not None else None
     t = plan.t
-    AtdZn = torch.empty(n, Fo, **f32)
+    AtdZn = rows_empty(0, n, Fo, dev)
     ew = adj.edge_w
     filtered = plan.f_indptr is not None and 128 < Fo <= 256
     amx = torch.empty(n, **f32) if filtered else torch.zeros(n, **f32)      # (the filtered pass writes every row's maximum)
@@ -1709,6 +1709,40 @@ class _SageDense(torch.autograd.Function):
 SAGE_STACK = os.environ.get("SHADOW_SAGE_STACK", "1") != "0"
 
 
+class _SlotList:
+    """[n, F] tensors addressed like the rows of a [k, n, F] tensor (shape / device / indexing): the whole-stack node's saved
+    forward products as separate allocations (STACK_SEPARATE_SLOTS)."""
+    def __init__(self, ts):
+        self.ts = ts
+        self.shape = (len(ts),) + tuple(ts[0].shape)
+        self.device = ts[0].device
+
+    def __getitem__(self, k):
+        return self.ts[k]
+
+
+# The whole-stack node's saved forward products as one allocation per tensor (True) or as the slots of ONE [4 L - 1, n, F] tensor.
+# One tensor is 5.6 GB at 289 k rows, and the batches' row counts differ by a few per cent: whenever a batch exceeded every batch
+# before it the caching allocator had to hipMalloc a new multi-GB block -- on some boxes that cost the HOST 2 - 3 ms per step
+# averaged over a 60-step run (same box, scripts/ab_stack_slots.sh: 9.03 / 8.38 ms per step against 6.34 / 6.33 with separate
+# 296 MB allocations and 6.35 / 6.31 for the layer-by-layer nodes; on other boxes 6.18 / 6.21 against 6.14 / 6.17).
+STACK_SEPARATE_SLOTS = os.environ.get("SHADOW_STACK_SEPARATE_SLOTS", "1") != "0"
+ROW_QUANTUM = 16384
+
+
+def rows_empty(lead: int, n: int, width: int, device) -> torch.Tensor:
+    """A float32 tensor [lead, n, width] (lead = 0: [n, width]) carved from the front of an allocation sized for n rounded up to
+    ROW_QUANTUM rows: consecutive batches (whose n differ by a few per cent) request the SAME number of bytes, so the caching
+    allocator hands the same block back instead of growing by a new multi-hundred-MB block at every new maximum."""
+    k = max(1, lead)
+    cap = -(-max(n, 1) // ROW_QUANTUM) * ROW_QUANTUM
+    flat = torch.empty(k * cap * width, dtype=torch.float32, device=device)
+    t = flat[:k * n * width]
+    return t.view(k, n, width) if lead else t.view(n, width)
+
+
+
+
 class _SageStack(torch.autograd.Function):
     """The conv loop of DeepGNN.forward (shaDow/models.py:193-197) over L GraphSAGE layers (layers.py:471-483) plus the
     read-out's row select (layers.py:159-163) as ONE autograd node: forward = sl_sage_stack_fwd, backward = sl_sage_stack_bwd,
@@ -1731,7 +1765,10 @@ class _SageStack(torch.autograd.Function):
         ctx.plan, ctx.meta_l = plan, meta
         keep_all = bool(grad_on) and any(ctx.needs_input_grad)   # (no backward pass will come -- no_grad keeps needs_input_grad True for live parameters --: nothing is kept: one Zs / Zn / A X slot, two `out` slots in turn)
         # per layer Zs, Zn, out; then A X of the layers 1 .. L - 1
-        big = torch.empty(4 * L - 1, n, F, **f32) if keep_all else torch.empty(5 if L > 1 else 3, n, F, **f32)
+        if keep_all and STACK_SEPARATE_SLOTS:
+            big = _SlotList([rows_empty(0, n, F, dev) for _ in range(4 * L - 1)])        # (one allocation per saved tensor, as the layer-by-layer nodes make them)
+        else:
+            big = torch.empty(4 * L - 1, n, F, **f32) if keep_all else torch.empty(5 if L > 1 else 3, n, F, **f32)
         slot_z = (lambda l: 3 * l) if keep_all else (lambda l: 0)
         slot_out = (lambda l: 3 * l + 2) if keep_all else (lambda l: 2 + (l & 1) if L > 1 else 2)
         slot_ax = (lambda l: 3 * L + l - 1) if keep_all else (lambda l: 4)
@@ -1741,7 +1778,7 @@ class _SageStack(torch.autograd.Function):
         stats0_ok = CHAIN_SAGE_BWD and ROW_STATS_HANDOVER and bool(lib.sl_gemm_act_norm_supported(F, F0)) and AX0.stride(0) % 4 == 0
         stats = torch.empty(max(1, L - 1), n, 4, **f32) if (keep_all and L > 1 and (stats_ok or stats0_ok)) else None
         arr = (_lib.SlSageStackLayer * L)()
-        base, step = big.data_ptr(), n * F * 4
+        sp = (lambda k: big[k].data_ptr()) if isinstance(big, _SlotList) else (lambda k, base=big.data_ptr(), step=n * F * 4: base + k * step)
         for l in range(L):
             Ws, bs, Wn, bn, sc, of = params[6 * l:6 * l + 6]
             y = arr[l]
@@ -1754,8 +1791,8 @@ class _SageStack(torch.autograd.Function):
             if l == 0:
                 y.AX, y.ldax = AX0.data_ptr(), AX0.stride(0)
             else:
-                y.AX, y.ldax = base + slot_ax(l) * step, F
-            y.Zs, y.Zn, y.out = base + slot_z(l) * step, base + (slot_z(l) + 1) * step, base + slot_out(l) * step
+                y.AX, y.ldax = sp(slot_ax(l)), F
+            y.Zs, y.Zn, y.out = sp(slot_z(l)), sp(slot_z(l) + 1), sp(slot_out(l))
             y.out_amax = amax.data_ptr() + l * n * 4
             if stats is not None and l < L - 1 and (stats_ok if l else stats0_ok):
                 y.row_stats = stats.data_ptr() + l * n * 16
@@ -1803,7 +1840,7 @@ class _SageStack(torch.autograd.Function):
         dW0 = torch.empty(2, F, F0, **f32)
         ds = torch.empty(2 * L, 2, F, **f32)                 # per layer dscale, doffset [2, F]
         db = torch.empty(2 * L, F, **f32)                    # per layer dbias of the self / neighbour Linear
-        buf = torch.empty(2, n, 3 * F, **f32)
+        buf = rows_empty(2, n, 3 * F, dev)
         am = torch.empty(2, n, **f32)
         an_partial = torch.empty(2048 * 2 * 3 * F, **f32)
         chain_partial = torch.empty(max(lib.sl_sage_chain_partial_floats(n, F), 1), **f32) if L > 1 else None
@@ -1866,7 +1903,7 @@ class _SageStack(torch.autograd.Function):
         n, F = big.shape[1], big.shape[2]
         dev = big.device
         f32 = dict(dtype=torch.float32, device=dev)
-        st = _stream(big)
+        st = _stream(big[0])
         opt = lambda t_: t_.data_ptr() if t_ is not None else None
         top, mid, low = L - 1, L - 2, L - 3
         Zs = lambda l: big[3 * l]
@@ -1906,7 +1943,7 @@ class _SageStack(torch.autograd.Function):
         wpack = torch.empty(lib.sl_gemm_act_norm_pack_bytes(F, F), dtype=torch.uint8, device=dev)
         check(lib.sl_gemm_act_norm_pack_b2(Wnm.data_ptr(), 1, Wnm.stride(0), F, Wnm.data_ptr(), 1, Wnm.stride(0), F, F, wpack.data_ptr(), st))
         _Wl, bsl, _Wnl, bnl, scl, ofl = prm(low)
-        low_buf = torch.empty(n, 3 * F, **f32)
+        low_buf = rows_empty(0, n, 3 * F, dev)
         low_amax = torch.empty(n, **f32)
         partial = torch.empty(lib.sl_gemm_an_bwd_partial_floats(n, F, 2), **f32)
         ld2 = (C.c_int64 * 2)(F, F)
