@@ -42,7 +42,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m
 // m = rn16(x - h): 11 + 1 (sign of m) + 11 bits, i.e. |x - (h + m)| <= 2^-23 |x| for every element within 2^-17 of the
 // row's maximum (both pieces normal), and <= 2^-39 of the row's maximum below that.  The product needs the three terms
 // hh, hm, mh (mm <= 2^-22 |ab|, zero-mean under round-to-nearest): half the matrix-core work of the six-term bf16 form at
-// the same measured error against fp64 (tests/test_layers_gpu.py::test_split_gemm_matches_fp64; scripts/split_error_model.py).
+// the same measured error against fp64 (tests/test_layers_gpu.py::test_split_gemm_matches_fp64; scripts/probe_f16_split.py).
 // The scale of a row is exact (power of two) and is taken out again when the accumulators leave the registers.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
