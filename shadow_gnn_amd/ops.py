@@ -2098,12 +2098,16 @@ class _GcnStack(torch.autograd.Function):
         pitch0 = X0.stride(0) if (X0.stride(0) != F0 and X0.stride(0) % 32 == 0) else F0
         AX0 = torch.empty(n, pitch0, **f32)
         keep_all = bool(grad_on) and any(ctx.needs_input_grad)   # (no backward pass will come: one Z / A X slot, two `out` slots in turn)
-        big = torch.empty(3 * L - 1, n, F, **f32) if keep_all else torch.empty(4 if L > 1 else 2, n, F, **f32)   # per layer Z, out; then A X of the layers 1 .. L - 1
+        # per layer Z, out; then A X of the layers 1 .. L - 1 (training: one allocation per saved tensor, see STACK_SEPARATE_SLOTS)
+        if keep_all and STACK_SEPARATE_SLOTS:
+            big = _SlotList([rows_empty(0, n, F, dev) for _ in range(3 * L - 1)])
+        else:
+            big = torch.empty(3 * L - 1, n, F, **f32) if keep_all else torch.empty(4 if L > 1 else 2, n, F, **f32)
         slot_z = (lambda l: 2 * l) if keep_all else (lambda l: 0)
         slot_out = (lambda l: 2 * l + 1) if keep_all else (lambda l: 1 + (l & 1) if L > 1 else 1)
         slot_ax = (lambda l: 2 * L + l - 1) if keep_all else (lambda l: 3)
         arr = (_lib.SlGcnStackLayer * L)()
-        base, step = big.data_ptr(), n * F * 4
+        sp = (lambda k: big[k].data_ptr()) if isinstance(big, _SlotList) else (lambda k, base=big.data_ptr(), step=n * F * 4: base + k * step)
         for l in range(L):
             W, b, sc, of = params[4 * l:4 * l + 4]
             y = arr[l]
@@ -2114,8 +2118,8 @@ class _GcnStack(torch.autograd.Function):
             if l == 0:
                 y.AX, y.ldax = AX0.data_ptr(), AX0.stride(0)
             else:
-                y.AX, y.ldax = base + slot_ax(l) * step, F
-            y.Z, y.out = base + slot_z(l) * step, base + slot_out(l) * step
+                y.AX, y.ldax = sp(slot_ax(l)), F
+            y.Z, y.out = sp(slot_z(l)), sp(slot_out(l))
         pack = torch.empty(lib.sl_gcn_stack_pack_bytes(n, L, arr), dtype=torch.uint8, device=dev)
         a = _adj_struct(adj, False)
         check(lib.sl_gcn_stack_fwd(C.byref(a), X0.data_ptr(), X0.stride(0), L, arr, pack.data_ptr(), _stream(X0)))
