@@ -457,9 +457,11 @@ class MinibatchShallowExtractor:
                   subgs.subg_edge_off, subgs.ppr, subgs.hop, subgs.drnl):
             if t is not None and t.is_cuda:
                 t.record_stream(main)
+        w0 = tail._SYNC_WAIT[0]
         with torch.cuda.stream(self._side):
             plan = (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
                     else tail.TopBackwardPlan(adj, subgs.target))
+        self.wait_s += tail._SYNC_WAIT[0] - w0                      # (the levels' size read-backs: blocked on the prefetch stream, as _collect)
         main.wait_stream(self._side)
         for t in ([x for lv in plan for x in lv.tensors()] if isinstance(plan, list) else plan.tensors()):
             t.record_stream(main)

@@ -111,6 +111,11 @@ class RectLevel:
         return ew, rs, cs
 
 
+# host seconds spent BLOCKED in the size read-backs of the row-set builders below (the stream they run on -- the extractor's
+# prefetch stream -- also carries the sampler's kernels): MinibatchShallowExtractor adds the difference to its wait_s
+_SYNC_WAIT = [0.0]
+
+
 def _select_rows(indptr: torch.Tensor, rows: torch.Tensor):
     """CSR row selection: local indptr (int64), local row of every edge, position of every edge in the source."""
     dev = indptr.device
@@ -118,7 +123,10 @@ def _select_rows(indptr: torch.Tensor, rows: torch.Tensor):
     lens = indptr[rows + 1].long() - start
     ip = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lens, 0, out=ip[1:])
+    import time as _time
+    t0 = _time.perf_counter()
     E = int(ip[-1])                                    # (host sync: the edge count sizes the arrays below)
+    _SYNC_WAIT[0] += _time.perf_counter() - t0
     er = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), lens, output_size=E)
     pos = start[er] + (torch.arange(E, device=dev) - ip[er])
     return ip, er, pos
@@ -286,7 +294,10 @@ def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_level
         mask = torch.zeros(n, dtype=torch.bool, device=dev)
         mask[rows] = True
         mask[cols] = True
+        import time as _time
+        t0 = _time.perf_counter()
         in_ids = mask.nonzero().reshape(-1)                 # (host sync) ascending
+        _SYNC_WAIT[0] += _time.perf_counter() - t0
         if in_ids.numel() > frac * n:
             break
         newid = torch.cumsum(mask, 0) - 1
