@@ -459,8 +459,9 @@ class MinibatchShallowExtractor:
                 t.record_stream(main)
         w0 = tail._SYNC_WAIT[0]
         with torch.cuda.stream(self._side):
-            plan = (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
-                    else tail.TopBackwardPlan(adj, subgs.target))
+            # (a collated batch's roots ascend: one per subgraph, the subgraphs in order)
+            plan = (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels, targets_ascending=int(self.sampler_cfg.num_roots) == 1)
+                    if self.backward_levels > 0 else tail.TopBackwardPlan(adj, subgs.target))
         self.wait_s += tail._SYNC_WAIT[0] - w0                      # (the levels' size read-backs: blocked on the prefetch stream, as _collect)
         main.wait_stream(self._side)
         for t in ([x for lv in plan for x in lv.tensors()] if isinstance(plan, list) else plan.tensors()):

@@ -45,6 +45,7 @@ class RectLevel:
         self._t = None
         self._sq = None
         self.rows32 = self.in32 = None  # int32 copies of rows_full / in_ids_full (build_backward_levels)
+        self.rows_ascending = False     # rows_full ascending: the edges are already in the square form's order (no sort, no bincount)
 
     @property
     def transposed(self):
@@ -82,6 +83,18 @@ class RectLevel:
         the input rows anyway) run their ordinary kernels on it; rows outside the level produce values nobody
         reads."""
         if self._sq is None:
+            if self.rows_ascending:
+                # the selected rows ascend, so do their positions in the input numbering: the edges (grouped by selected row, in
+                # row order) ARE the square form's edges in order -- row lengths scattered to those positions, no sort, no
+                # bincount (a device-wide maximum read back by the host)
+                dev = self.indptr.device
+                lens = (self.indptr[1:] - self.indptr[:-1]).to(torch.int64)
+                cnt = torch.zeros(self.m_in + 1, dtype=torch.int64, device=dev)
+                cnt.index_copy_(0, self.self_idx + 1, lens)
+                ip = torch.cumsum(cnt, 0)
+                order = torch.arange(self.indices.numel(), device=dev)
+                self._sq = (ops.DeviceCSR(ip.to(torch.int32), self.indices.contiguous()), order)
+                return self._sq
             srow = self.self_idx[self.edge_row]                 # row of every edge in the input numbering
             order = torch.argsort(srow, stable=True)
             ip = torch.zeros(self.m_in + 1, dtype=torch.int64, device=srow.device)
@@ -149,8 +162,8 @@ def build_tail_plan(csr: "ops.DeviceCSR", targets: torch.Tensor, num_layers: int
         ip, er, pos = _select_rows(csr.indptr, rows)
         cols = csr.indices[pos].long()
         mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        mask[rows] = True
-        mask[cols] = True
+        mask.index_fill_(0, rows, True)
+        mask.index_fill_(0, cols, True)
         cnt = int(mask.sum())                          # (host sync)
         if layer == 0 or cnt > frac * n:               # input = the whole batch, batch numbering
             levels.append(RectLevel(ip.to(torch.int32), cols.to(torch.int32), er, pos, rows, None, rows, n))
@@ -278,22 +291,26 @@ class TopBackwardPlan:
         return [self.targets32, self.rows64, self.T32, self.slot, self.epos, self.self_idx, self.rowmap, *extra]
 
 
-def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_levels: int = 2, frac: float = 0.25) -> List[RectLevel]:
+def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_levels: int = 2, frac: float = 0.25,
+                          targets_ascending: bool = False) -> List[RectLevel]:
     """Nested row sets of a row-sparse BACKWARD pass, top layer first: level 0 = the roots' rows with their inputs T = R u N(R),
     level 1 = the rows T with inputs T2 = T u N(T), ... -- every level compact (column ids renumbered into its input set), kept
     while that input set is at most ``frac`` of the batch.  Depth-2 k-hop batches stop after one level (T2 is the whole
     subgraph), depth-3 batches after two (T: 0.5 %, T2: 10 % of the rows).  The square form and its transpose are built here
     (GAT's attention backward runs its ordinary kernels on them, ops_gat._GatTail).  Two host syncs per level: the extractor
-    calls this on its prefetch stream."""
+    calls this on its prefetch stream.  ``targets_ascending``: the caller's word that ``targets`` ascend (a collated batch's roots
+    do: one per subgraph, subgraphs in order) -- the levels' square forms then need no sort (the lower levels' rows ascend by
+    construction)."""
     n, dev = csr.n, csr.device
     rows = torch.as_tensor(targets, device=dev).long().reshape(-1)
     levels: List[RectLevel] = []
+    ascending = bool(targets_ascending)
     for _ in range(max_levels):
         ip, er, pos = _select_rows(csr.indptr, rows)
         cols = csr.indices[pos].long()
         mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        mask[rows] = True
-        mask[cols] = True
+        mask.index_fill_(0, rows, True)                     # (`mask[rows] = True` stages its scalar through a blocking H2D copy)
+        mask.index_fill_(0, cols, True)
         import time as _time
         t0 = _time.perf_counter()
         in_ids = mask.nonzero().reshape(-1)                 # (host sync) ascending
@@ -302,6 +319,8 @@ def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_level
             break
         newid = torch.cumsum(mask, 0) - 1
         lv = RectLevel(ip.to(torch.int32), newid[cols].to(torch.int32), er, pos, rows, in_ids, newid[rows], in_ids.numel())
+        lv.rows_ascending = ascending
+        ascending = True                                    # (in_ids come out of nonzero(): ascending)
         lv.square[0].transposed
         lv.rows32 = rows.to(torch.int32)
         lv.in32 = in_ids.to(torch.int32)

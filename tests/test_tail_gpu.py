@@ -168,3 +168,24 @@ def test_minibatch_builds_the_plan_on_its_prefetch_stream(prefetch):
         pruned = m.step(VALID, "running", clone())["preds"]
         np.testing.assert_allclose(pruned.cpu().numpy(), full.cpu().numpy(), rtol=1e-5, atol=1e-6)
         m.step(TRAIN, "running", clone())          # a training step through the pruned path
+
+
+@pytest.mark.gpu
+def test_backward_levels_square_form_without_the_sort_equals_the_sorted_one():
+    """tail.build_backward_levels with ``targets_ascending`` (a collated batch's roots: one per subgraph, in order): the levels'
+    square forms are built from the row lengths -- no argsort, no bincount (a host read-back) -- and equal the sorted
+    construction entry by entry: row pointers, column ids, edge order, and the transposed form the attention backward walks."""
+    from shadow_gnn_amd import tail
+    _make, _A, n = _batch(24, 700, 16, 5, seed=11, deg=2)
+    csr = _make().adj_ens[0]
+    tgt = (torch.arange(24) * 700).to(DEV)
+    a = tail.build_backward_levels(csr, tgt, max_levels=2, frac=0.6, targets_ascending=False)
+    b = tail.build_backward_levels(csr, tgt, max_levels=2, frac=0.6, targets_ascending=True)
+    assert len(a) == len(b) == 2
+    assert [lv.rows_ascending for lv in a] == [False, True] and [lv.rows_ascending for lv in b] == [True, True]
+    for la, lb in zip(a, b):
+        (ca, oa), (cb, ob) = la.square, lb.square
+        assert torch.equal(ca.indptr, cb.indptr) and torch.equal(ca.indices, cb.indices) and torch.equal(oa, ob)
+        for x, y in zip(ca.transposed, cb.transposed):
+            assert torch.equal(x, y)
+        assert torch.equal(la.in_ids_full, lb.in_ids_full) and torch.equal(la.self_idx, lb.self_idx)
