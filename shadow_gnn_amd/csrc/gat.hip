@@ -221,7 +221,7 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
 #define SHADOW_GAT_GROUPS_FWD 6
 #endif
 #ifndef SHADOW_GAT_GROUPS_ROW
-#define SHADOW_GAT_GROUPS_ROW 4
+#define SHADOW_GAT_GROUPS_ROW 2      // (round 5, after the row pass stopped reading z_self: groups of two -- 92 VGPRs instead of 106 -- 0.87 -> 0.82 ms per gat_bwd launch, step 10.42 -> 10.24 ms, same box twice: scripts/micro/ab_gat_row_waves.sh; {4} was round 3's choice)
 #endif
 #ifndef SHADOW_GAT_GROUPS_COL
 #define SHADOW_GAT_GROUPS_COL 2
