@@ -237,7 +237,17 @@ def main():
                     help="run the WHOLE benchmark with the exact target-only tail (shadow_gnn_amd/tail.py); without the "
                          "flag the timed region computes every row of every layer like the reference, and the pruned "
                          "variant is timed separately afterwards and reported as 'target_only_tail'")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short runs of the other BASELINE configurations (`other_workloads`, default workload on one GPU only)")
+    ap.add_argument("--other-workloads-budget", type=float, default=420.0,
+                    help="wall-clock seconds the `other_workloads` sub-runs may take together")
+    ap.add_argument("--hang-dump-after", type=float, default=0.0,
+                    help="diagnostic: dump every thread's Python stack to stderr after that many seconds (and every that many again)")
+    ap.add_argument("--no-pin", action="store_true", help="multi-rank runs: leave the ranks' host threads unpinned (A/B of dist.pin_host_threads)")
     args = ap.parse_args()
+    if args.hang_dump_after > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.hang_dump_after, repeat=True, file=sys.stderr)
 
     from shadow_gnn_amd import dist as sdist
     rank, local_rank, world = sdist.init_from_env()
@@ -245,7 +255,8 @@ def main():
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     # one Python process per GPU on a shared host: every rank gets its own slice of the hardware threads
-    pin = sdist.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    pin = (dict(pinned=False, disabled="--no-pin") if args.no_pin
+           else sdist.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
 
     from shadow_gnn_amd import ops
     from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
@@ -674,7 +685,53 @@ def main():
         "cpu_baseline": cb,
         "dist": dist_info,
     }
+    # ---- the other BASELINE configurations, timed by whoever runs this command: short sub-runs of this
+    #      same script AFTER the main line is assembled, each in its own process under a wall-clock budget; a failure or a
+    #      time-out is recorded in its entry and never touches the main line
+    if (world == 1 and args.workload == "products-khop-sage5" and not args.batch and not args.no_other_workloads
+            and not args.no_tail and not args.prune_tail):
+        line["other_workloads"] = other_workloads(args.other_workloads_budget)
     print(json.dumps(line), flush=True)
+
+
+OTHER_WORKLOADS = ("arxiv-khop-sage5", "products-ppr-sage5", "products-khop3-gat5")     # BASELINE.json configs[1], [2], [3] (per-GPU share)
+
+
+def other_workloads(budget_s, steps=10, warmup=3):
+    """`python bench.py --workload W --steps 10 --warmup 3` for the BASELINE configurations the main line is not quoted on,
+    one sub-process each (fresh allocator / sampler state; the parent's graph stays resident -- 1.5 GB of 288), summarised to
+    {ms_per_step, value, roofline_step.frac, dominant kernel + frac, host_busy}.  Sub-lines go to stderr as they finish."""
+    import subprocess
+    out, t_start = {}, time.perf_counter()
+    for w in OTHER_WORKLOADS:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 45.0:
+            out[w] = dict(skipped=f"wall-clock budget of {budget_s:.0f} s spent")
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", w, "--steps", str(steps),
+                                "--warmup", str(warmup), "--no-cpu-baseline", "--no-tail"], cwd=ROOT, capture_output=True, text=True,
+                               timeout=min(left, 240.0), env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not js:
+                out[w] = dict(error=f"rc {r.returncode}: " + r.stderr.strip()[-300:])
+            else:
+                d = json.loads(js[-1])
+                rf = d["roofline"]
+                out[w] = dict(ms_per_step=d["ms_per_step"], value=d["value"], unit=d["unit"], steps=d["steps"], warmup=d["warmup"],
+                              train_steps_per_sec=d["train_steps_per_sec"], nodes_per_step=d["config"]["nodes_per_step"],
+                              roofline_step_frac=d["roofline_step"]["frac"], kernel_ms_per_step=d["roofline_step"]["kernel_ms_per_step"],
+                              dominant_kernel=rf["kernel"], dominant_frac=rf["frac"], dominant_bound=rf["bound"],
+                              dominant_avg_ms=rf["avg_ms"], host_busy_ms_per_step=d["host_busy_ms_per_step"],
+                              sampler_alone_frac=(d.get("sampler_alone") or {}).get("frac"), workload=d["config"]["workload"])
+        except subprocess.TimeoutExpired:
+            out[w] = dict(error="timed out")
+        except Exception as ex:                       # noqa: BLE001  (never lose the main line to an extra)
+            out[w] = dict(error=f"{type(ex).__name__}: {ex}"[:300])
+        out[w]["wall_s"] = round(time.perf_counter() - t0, 1)
+        print(f"[bench] other_workloads {w}: {json.dumps(out[w])}", file=sys.stderr, flush=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ export PYTHONPATH="$R"
 cd /tmp && export TMPDIR=/tmp
 for C in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
   tag=$(echo $C | tr ' ' '_' | cut -c1-60)
-  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/$tag" -- python "$R/scripts/ko_fused.py" > "$OUT/$tag.log" 2>&1
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/$tag" -- python "$R/scripts/probe_fused_pair.py" > "$OUT/$tag.log" 2>&1
   find "$OUT/$tag" -name "*kernel_trace.csv" -delete
 done
 python - "$OUT" <<'PY'

@@ -1,4 +1,4 @@
-"""Kernel times of the two GEMM-epilogue launches at the benchmark's shape (knock-out experiments, scripts/ko_fused.sh)."""
+"""Kernel times of the two GEMM-epilogue launches at the benchmark's shape (the workload of scripts/pmc_fused.sh / ab_fused_depth.sh)."""
 import torch
 from shadow_gnn_amd import ops
 DEV = "cuda"

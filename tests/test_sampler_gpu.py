@@ -380,6 +380,7 @@ def test_ppr_push_kernel_matches_reference_tables_and_oracle():
     ("products", 1024, 2, False),      # BASELINE configs[1]-style k-hop batch at the full products shape
     ("products", 512, 2, True),
     ("products", 128, 3, False),       # depth 3: node sets beyond the LDS tables (global-table path)
+    ("products", 256, 3, True),        # configs[3]'s timed sampler: depth 3 WITH the inserted self edges (sg_scan_plain_kernel<true>)
     ("arxiv", 2048, 2, True),
 ])
 def test_full_size_shapes_match_oracle(shape, batch, depth, self_e):
@@ -401,6 +402,31 @@ def test_full_size_shapes_match_oracle(shape, batch, depth, self_e):
                           aug=("hops",), seed=3, serial_base=0, num_threads=16)
     for f in INT_FIELDS + ["hop"]:
         assert np.array_equal(got[f], getattr(ref, f)), (shape, batch, depth, self_e, f)
+
+
+def test_configs3_call_shape_multi_step_depth3_self_edges_at_products_shape():
+    """The sampler call bench.py times for configs[3] (products k-hop depth 3 budget 20, self edges, 4 batches x 64 roots in
+    ONE sg_sample_multi call): every batch equals the oracle's with the matching serial base, every integer field + hop
+    (ParallelSampler.cpp:386-400,510-556; GAT always samples with self edges, shaDow/utils.py:126-131)."""
+    from oracle import sampler_oracle as so
+    from shadow_gnn_amd.sampler import HipSampler, SamplerConfig
+    from shadow_gnn_amd.synthetic import MAX_DEGREE, SHAPES, make_graph_torch
+    dev = torch.device("cuda:0")
+    N, nnz, _, _ = SHAPES["products"]
+    indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE["products"])
+    ip, ix = indptr.cpu().numpy(), indices.cpu().numpy()
+    sizes = (64, 64, 64, 64)
+    roots = torch.randperm(N, generator=torch.Generator().manual_seed(2))[:sum(sizes)].numpy().astype(np.uint32)
+    hs = HipSampler(indptr, indices, device=dev, seed=3)
+    hs.shuffle_targets(roots)
+    cfg = SamplerConfig(method="khop", depth=3, budget=20, add_self_edge=True, aug=("hops",))
+    got = hs.sample_multi(cfg, sizes)
+    lo = 0
+    for i, P in enumerate(sizes):
+        ref = so.sample_batch(ip, ix, roots[lo:lo + P], method="khop", depth=3, budget=20, add_self_edge=True,
+                              aug=("hops",), seed=3, serial_base=lo, num_threads=16)
+        _cmp_batch(ref, got[i], ("hops",), ("configs3-multi", i))
+        lo += P
 
 
 @pytest.mark.parametrize("env", [
