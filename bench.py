@@ -33,6 +33,10 @@ Rank 0 prints ONE JSON line.  metric/unit follow BASELINE.json:
                       PyTorch (oracle/cpu_train_step.py) on one whole benchmark batch
   target_only_tail    the same step with the opt-in exact dead-row elimination (shadow_gnn_amd/tail.py),
                       10 extra steps after the timed region (single-GPU runs); never part of `value`
+  other_workloads     (default workload, one GPU) the other BASELINE configurations -- arxiv-khop-sage5 (configs[1]),
+                      products-ppr-sage5 (configs[2]), products-khop3-gat5 (configs[3], one GPU's share) -- timed by the same
+                      command: 10 + 3 steps each in a sub-process after the main line is assembled; {ms_per_step, value,
+                      roofline_step_frac, dominant kernel + frac, host_busy}; sub-lines on stderr; never part of `value`
 """
 import argparse
 import json
@@ -241,6 +245,9 @@ def main():
                     help="skip the short runs of the other BASELINE configurations (`other_workloads`, default workload on one GPU only)")
     ap.add_argument("--other-workloads-budget", type=float, default=420.0,
                     help="wall-clock seconds the `other_workloads` sub-runs may take together")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
+                    help="A/B handle: set a module attribute of the package before the run, e.g. --set ops_gat.FUSED_FWD_TAIL=False "
+                         "(recorded in config.overrides)")
     ap.add_argument("--hang-dump-after", type=float, default=0.0,
                     help="diagnostic: dump every thread's Python stack to stderr after that many seconds (and every that many again)")
     ap.add_argument("--no-pin", action="store_true", help="multi-rank runs: leave the ranks' host threads unpinned (A/B of dist.pin_host_threads)")
@@ -259,6 +266,15 @@ def main():
            else sdist.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
 
     from shadow_gnn_amd import ops
+    import ast
+    import importlib
+    for item in args.set:
+        target, _, val = item.partition("=")
+        modname, _, attr = target.rpartition(".")
+        mod_ = importlib.import_module("shadow_gnn_amd." + modname)
+        if not hasattr(mod_, attr):
+            raise SystemExit(f"--set {item}: shadow_gnn_amd.{modname} has no attribute {attr}")
+        setattr(mod_, attr, ast.literal_eval(val))
     from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
     from shadow_gnn_amd.models import DeepGNN
     from shadow_gnn_amd.synthetic import MAX_DEGREE, SHAPES, make_graph_torch
@@ -268,10 +284,20 @@ def main():
     B = args.batch or wl["batch"]
     K, W = args.steps, args.warmup
     # ---- synthetic inputs, resident in HBM before the timed region (seeds: SURVEY.md 8(d))
-    indptr, indices = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE[wl["shape"]])
-    g = torch.Generator(device=dev); g.manual_seed(1)
-    feat_full = torch.randn(N, F0, generator=g, device=dev)
-    label_full = torch.randint(0, C, (N,), generator=g, device=dev)
+    def make_inputs():
+        ip_, ix_ = make_graph_torch(N, nnz, seed=0, device=dev, max_degree=MAX_DEGREE[wl["shape"]])
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        return ip_, ix_, torch.randn(N, F0, generator=g, device=dev), torch.randint(0, C, (N,), generator=g, device=dev)
+    if world > 1 and torch.cuda.device_count() < world:
+        # several ranks on ONE GPU (SHADOW_DIST_BACKEND=gloo functional runs): the generator's device-wide sorts of 124 M keys from
+        # eight processes at once time-slice the GPU to a crawl (8 ranks: > 15 minutes, 4 ranks: seconds) -- one rank at a time
+        for r_ in range(world):
+            if r_ == rank:
+                indptr, indices, feat_full, label_full = make_inputs()
+                torch.cuda.synchronize(dev)
+            torch.distributed.barrier()
+    else:
+        indptr, indices, feat_full, label_full = make_inputs()
     TAIL_STEPS, TAIL_WARMUP = 10, 3      # extra steps for the separately reported target-only-tail variant
     need = B * world * (K + W + 2 + TAIL_STEPS + TAIL_WARMUP + 12 + 48 + 16 * 16)     # (+ instrumented steps, + a prefetched multi-step call, + the sampler-only loops)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).numpy()
@@ -658,7 +684,7 @@ def main():
         "config": {"workload": f"{args.workload}: {wl['shape']}-shape synthetic CSR (N={N}, nnz={int(indices.numel())}, "
                                f"F0={F0}, {C} classes), sampler {wl['sampler']}, {wl['layers']}-layer {wl['aggr']} dim {wl['dim']}, "
                                f"batch {B} roots/GPU, dropout {wl['dropout']} dropedge {wl['dropedge']}",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "prune_tail": bool(args.prune_tail),
+                   "global_batch": B * world, "parallelism": f"dp{world}", "prune_tail": bool(args.prune_tail), "overrides": list(args.set),
                    "sampler_steps_per_call": S_call, "sparse_top_backward": bool(mb.top_backward_plan),
                    "nodes_per_step": round(nodes / K, 1), "edges_per_step": round(edges / K, 1), "final_loss": round(loss, 4),
                    "ppr_preproc": ppr_info},

@@ -444,6 +444,18 @@ int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64_t *ldz, co
                          float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped,
                          int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx, int dz_compact,
                          void *stream);
+/* sl_act_norm_bwd_rows that also leaves d_t_out[row, F / seg] = sum over each normalisation segment of dZ[t_branch] * Z[t_branch]
+ * for an IDENTITY branch without a bias (vector layout only: sl_act_norm_vector_layout) -- for the GAT layer, whose aggregate N is
+ * such a branch, the attention backward's t_i = dN_i . N_i per head (sl_gat_bwd's d_t).  The normalisation is invariant under
+ * scaling of its input row, so this dot is S eps rstd^2 m2 (m2 = the segment mean of dy scale xhat the backward pass forms
+ * anyway): written from that closed form, no extra reduction.  d_t_out NULL: as without.                                    */
+int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                           const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                           uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                           float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                           float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                           const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                           int dz_compact, int t_branch, float *d_t_out, void *stream);
 int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
@@ -526,9 +538,9 @@ int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const flo
  *                          sl_gemm_an_bwd_partial_floats(M, N, nb) floats (one partial row per workgroup, added in a
  *                          fixed order).  d_dz0_amax (may be NULL): receives the row maxima of dZ_0.
  * sl_sage_fwd / sl_gcn_fwd use the forward form whenever sl_gemm_act_norm_supported(Fout, Fin).  sl_set_fused_epilogue(0 | 1)
- * switches it (returns the previous setting; a negative argument only queries; the environment variable
- * SHADOW_FUSED_EPILOGUE=0 sets the initial state) -- the A/B handle of the tests and benchmarks: the layer entries then
- * run sl_gemm_nt_f32 + sl_act_norm_* as separate launches.                                                         */
+ * switches it (returns the previous setting; a negative argument only queries; the initial state is ON -- the former
+ * environment variable SHADOW_FUSED_EPILOGUE is no longer read) -- the A/B handle of the tests and benchmarks: the layer
+ * entries then run sl_gemm_nt_f32 + sl_act_norm_* as separate launches.                                                         */
 int sl_set_fused_epilogue(int on);
 /* Aggregations of rows wider than 128 floats inside the sl_sage_* / sl_gcn_* entries: the pipelined CSR kernel (a row per
  * wavefront, sl_spmm_csr_amax_f32: its long-row loop keeps six gathers in flight) or the block-diagonal LDS kernel (every edge
@@ -808,22 +820,38 @@ int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, const float 
  * d_z_neigh = NULL: the activation's derivative follows from hn (relu / elu / leaky relu: z > 0 <=> hn > 0; tanh: 1 - hn^2). */
 int sl_gat_fwd_rows(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const float *d_hn, const float *d_u_s,
                     const float *d_u_n, uint32_t n, uint32_t F, uint32_t heads, float *d_mx, float *d_den, float *d_nagg, void *stream);
+/* sl_gat_fwd_rows and the layer's activation + per-head feature normalisation + branch average + output dropout in the same
+ * pass (shaDow/layers.py:612-625, 329-338): the aggregate of a row leaves the kernel normalised,
+ *   d_out = out_scale * (norm_0(N) + norm_1(act(z_self)))   per head slice (d_scale / d_offset [2, F]: row 0 the aggregate's)
+ * followed by the fused output dropout (drop_p, drop_seed: the mask rule of sl_act_norm_fwd) and, optionally, the row maxima
+ * d_out_amax [n] -- what sl_act_norm_fwd(nb = 2, seg = F / heads) makes of (N, z_self), to rounding (the compiler fuses
+ * multiply-add pairs differently in the two kernels: 1 - 2 ulp per stage; same dropout mask).  d_nagg (may be NULL when
+ * no backward pass follows) still receives N.                                                                               */
+int sl_gat_fwd_tail(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const float *d_hn,
+                    const float *d_u_s, const float *d_u_n, const float *d_z_self, int act, const float *d_scale,
+                    const float *d_offset, uint32_t n, uint32_t F, uint32_t heads, float out_scale, float drop_p,
+                    uint64_t drop_seed, float *d_mx, float *d_den, float *d_nagg, float *d_out, float *d_out_amax, void *stream);
 /* Backward: dz_self (attention part only), dz_neigh, datt[2,heads,D].
- * d_work: float[2*e*heads + n*heads + 4096*F] (per-edge alpha / de, du_s, and the per-block partial sums of
- * datt, which are added in block order: no float atomics, bit-reproducible).                */
-/* accumulate_dz_self != 0: d_dz_self already holds the share of z_self's gradient that came through the layer's own
- * act_norm branch (z_self feeds the attention scores AND the normalised output) -- the kernel adds to it instead of
- * overwriting; d_row_amax (may be NULL): receives max_k over the final dz_self AND dz_neigh rows (the operand scale of the
- * K-concatenated input-gradient product, sl_gemm_nt_cat_f32).  Round 5: the attention's share of dz_self is exactly zero on
- * every row whose softmax denominator is not on its 1e-10 clamp (the row softmax does not depend on u_s[i]) -- those rows of
- * d_dz_self are not read or written in accumulate mode (zeros are written otherwise), and with accumulate_dz_self != 0
- * d_row_amax must come in HOLDING max_k |dz_self[i, k]| of the incoming rows (an upper bound will do).                     */
+ * Round 6: ONE edge walk.  The column walk (transposed CSR) gathers dN_i for every edge (i -> j) anyway and holds hn_j in
+ * registers: it forms alpha_ij again from row i's (u_s, max, denominator) -- the forward pass's expression -- and
+ * de_ij = alpha_ij (dN_i . hn_j - t_i) itself; the row walk that gathered hn_j per edge to leave alpha / de [e, heads] behind is
+ * gone.  d_t [n, heads]: t_i = dN_i . N_i per head, left by the act + norm backward that produced d_dnagg
+ * (sl_act_norm_bwd_rows_t); NULL: computed here into d_work.
+ * d_work: float[n*heads + 4096*F] (t when not given, and the per-block partial sums of datt, which are added in block order:
+ * no float atomics, bit-reproducible).                */
+/* The attention's share of dz_self and datt[0] are EXACTLY zero: a row's weights exp(e_ij - max_j e_ij) / max(sum, 1e-10) do not
+ * change when u_s[i] moves every e_ij of the row together (on a row whose sum sits on the clamp the reference's autograd gets
+ * there through the arg-max of torch_scatter's max; the column walk hands -t_i to that edge).  d_z_self is not read (may be NULL).
+ * accumulate_dz_self != 0: d_dz_self already holds the share of z_self's gradient that came through the layer's own act_norm
+ * branch and is left alone; 0: it is cleared.  d_row_amax (may be NULL): receives max_k over the final dz_self AND dz_neigh rows
+ * (the operand scale of the K-concatenated input-gradient product, sl_gemm_nt_cat_f32); with accumulate_dz_self != 0 it must
+ * come in HOLDING max_k |dz_self[i, k]| of the incoming rows (an upper bound will do).                     */
 int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
                const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
                const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
                uint32_t e, uint32_t F, uint32_t heads, const float *d_hn, const float *d_u_s,
                const float *d_u_n, const float *d_mx, const float *d_den, const float *d_nagg,
-               const float *d_dnagg, float *d_work, float *d_dz_self, float *d_dz_neigh, float *d_datt,
+               const float *d_dnagg, const float *d_t, float *d_work, float *d_dz_self, float *d_dz_neigh, float *d_datt,
                int accumulate_dz_self, float *d_row_amax, void *stream);
 
 /* Development aid: per-subgraph result words of the last sg_sample call,

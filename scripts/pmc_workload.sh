@@ -29,7 +29,7 @@ for f in sorted(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True)
         kn = r["Kernel_Name"]
         if filt not in kn:
             continue
-        kn = re.sub(r"\(.*", "", kn[kn.index(filt):])[:70]
+        kn = re.sub(r"\(.*", "", kn[kn.index(filt):])[:70].replace(", ", " ").replace(",", " ")
         k = (kn, r["Counter_Name"])
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 kern = sorted({k for k, _ in acc})

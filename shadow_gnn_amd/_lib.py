@@ -227,8 +227,10 @@ SIGNATURES = {
     "sl_gat_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                               _P, _P, _P, _P, _P, _P, _P]),
     "sl_gat_fwd_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
+    "sl_gat_fwd_tail": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                                   C.c_uint64, _P, _P, _P, _P, _P, _P]),
     "sl_gat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
-                              C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+                              C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_top_plan": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_plan_filter": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_dx": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
@@ -241,13 +243,17 @@ SIGNATURES = {
     "sl_act_norm_bwd_rows": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
                                    C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, C.c_int, _P]),
+    "sl_act_norm_bwd_rows_t": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
+                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
+                                   C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, C.c_int,
+                                   C.c_int, _P, _P]),
 }
 
 _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 22      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 23      # sg_abi_version() of the library these signatures describe
 
 
 def load():

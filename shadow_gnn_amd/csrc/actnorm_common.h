@@ -29,11 +29,26 @@ __device__ __forceinline__ void st4s(float *p, float4 v) {
 #endif
 }
 
+// e^x - 1 for the negative side of elu (round 6).  libm's expm1f is ~25 VALU instructions per element and elu sits in the
+// epilogues / edge walks of kernels bound by VALU issue (the paired Linear's GAT tail: 512 of them per row); here the hardware
+// exp2 where the result is not small (x <= -1/16: one ulp of e^x is below 1e-6 of e^x - 1) and four series terms near zero
+// (next term x^5 / 120: 1.3e-7 relative at -1/16) -- about nine instructions, every kernel the same function (the bit-for-bit
+// comparisons between alternative paths hold; against libm the difference is <= 1e-6 relative).  -DSHADOW_LIBM_ELU: expm1f.
+__device__ __forceinline__ float elu_neg(float x) {
+#ifdef SHADOW_LIBM_ELU
+  return expm1f(x);
+#else
+  const float e = __builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f;
+  const float s = x * (1.0f + x * (0.5f + x * (0.16666667f + x * 0.041666668f)));
+  return x > -0.0625f ? s : e;
+#endif
+}
+
 // F_ACT of shaDow/layers.py:26-34 (prelu variants carry parameters and stay in torch)
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case 1: return x > 0.f ? x : 0.f;                       // relu
-    case 2: return x > 0.f ? x : expm1f(x);                 // elu (alpha = 1)
+    case 2: return x > 0.f ? x : elu_neg(x);                // elu (alpha = 1)
     case 3: return tanhf(x);                                // tanh
     case 4: return x > 0.f ? x : 0.2f * x;                  // leakyrelu(0.2)
     default: return x;                                      // 0: identity ("I")

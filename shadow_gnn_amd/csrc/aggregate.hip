@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "actnorm_common.h"
+#include "gat_act.h"
 
 namespace shadow {
 
@@ -786,6 +787,9 @@ struct ActNormParams {
   const uint32_t *row_idx;
   // ... and dZ / dz0_amax are compact as well ([n, F] in the order of row_idx) instead of scattered into full-height buffers
   int dz_compact;
+  // backward, optional (vector kernel): t_out[row, F / seg] = sum over each segment of dZ[t_branch] * Z[t_branch] -- the GAT
+  // attention backward's t_i = dN_i . N_i per head (gat.hip) while both rows are in registers; t_branch < 0: none
+  float *t_out; int t_branch;
 };
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
@@ -906,6 +910,14 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
           if (p.dZ[b]) st4s(p.dZ[b] + (int64_t)(p.dz_compact ? r : rr) * p.lddz[b] + f, dh);
           gb[b].x += dh.x; gb[b].y += dh.y; gb[b].z += dh.z; gb[b].w += dh.w;
           zmax = amax4(dh);
+        }
+        if (p.t_out && b == p.t_branch) {
+          // t = sum over the segment of dZ_b * Z_b for an IDENTITY branch (the GAT aggregate): the normalisation does not change
+          // when its input row is scaled, so its gradient is orthogonal to the row up to eps --
+          //   sum_k dh_k z_k = m2 (S - sum_k xh_k^2) = S eps rstd^2 m2          (sum_k dh_k = 0, sum_k xh_k = 0, var rstd^2 = 1 - eps rstd^2)
+          // -- the closed form instead of a fifth butterfly (summed directly in fp32 the same quantity is this plus rounding noise
+          // of 1e-7 |dh| |z|; the plain backward kernel sits exactly on its register cap, the direct sum spilled nine dwords: + 28 %)
+          if (lane_on && (l % LS) == 0) p.t_out[(p.dz_compact ? r : rr) * (p.F / p.seg) + f / p.seg] = (float)p.seg * p.eps * rstd * rstd * m2;
         }
         if (b == 0 && p.dz0_amax) {        // (the LPR lanes of a row group share r: the reduction is uniform over the group)
           zmax = group_max<LPR>(zmax);
@@ -1663,6 +1675,20 @@ extern "C" int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64
                                     float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                                     const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
                                     int dz_compact, void *stream_) {
+  return sl_act_norm_bwd_rows_t(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale,
+                                d_doffset, d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, d_row_idx,
+                                dz_compact, -1, nullptr, stream_);
+}
+
+extern "C" int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                                      const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                                      uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                                      float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                                      float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                                      const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                                      int dz_compact, int t_branch, float *d_t_out, void *stream_) {
+  if (d_t_out && (t_branch < 0 || t_branch >= nb || act[t_branch] != 0 || (d_bias && d_bias[t_branch])))
+    return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_rows_t: the segment dots are provided for an identity branch without a bias");
   if (dz_compact && !d_row_idx) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_rows: compact dZ without row indices");
   int rc = act_norm_check(nb, F, seg, d_Z, act, n);
   if (rc) return rc;
@@ -1697,8 +1723,9 @@ extern "C" int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64
   p.dz0_amax = d_dz0_amax;
   p.row_idx = d_row_idx;
   p.dz_compact = dz_compact ? 1 : 0;
+  p.t_out = d_t_out; p.t_branch = d_t_out ? t_branch : -1;
   bool vec = false;
-  if ((rc = act_norm_launch(p, true, st, &vec, d_row_idx != nullptr)) != SG_OK) return rc;
+  if ((rc = act_norm_launch(p, true, st, &vec, d_row_idx != nullptr || d_t_out != nullptr)) != SG_OK) return rc;
   // (the general kernel does not write the row maxima: one more pass)
   return (d_dz0_amax && !vec) ? sl_row_amax(d_dZ[0], lddz[0], n, F, d_dz0_amax, st) : SG_OK;
 }

@@ -8,8 +8,12 @@
 //                      softmax over the row with max subtraction,    layers.py:572-578
 //                      numerator * drop-edge mask, denominator clamp 1e-10
 //                      N_i = sum_j p_ij hn_j / den_i                 layers.py:580-581
-// backward (per row)   t = dN_i·N_i ; d e_ij = alpha_ij (dN_i·hn_j - t) ; du_s ; dz_self (attention part)
-//          (per col)   d hn_j = sum_i alpha_ij dN_i + du_n att[1] ; dz_neigh ; datt
+// backward (per row)   t = dN_i·N_i per head (written by the act + norm backward that produces dN, or gat_t_kernel)
+//          (per col)   alpha_ij recomputed from the row's (u_s, max, denominator); d e_ij = alpha_ij (dN_i·hn_j - t_i);
+//                      d hn_j = sum_i alpha_ij dN_i + du_n att[1] ; dz_neigh ; datt[1]
+//          du_s, the attention's share of dz_self and datt[0] are exactly zero (a row's weights do not change with u_s[i])
+// (round 6: ONE edge walk instead of two -- the row walk that gathered hn_j per edge to leave alpha / de per edge behind
+//  is gone: the column walk gathers dN_i anyway and holds hn_j in registers, so it forms dN_i·hn_j itself)
 // The reference runs ~10 torch/scatter kernels per head per layer for this.
 #include <string.h>
 
@@ -29,6 +33,16 @@ __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * 
 __device__ __forceinline__ float dlrelu02(float x) { return x > 0.f ? 1.f : 0.2f; }
 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return gat_dot4(a, b); }
+// e^x of the edge softmax: the hardware exp2 on x log2(e) -- two instructions per edge and lane where libm's expf spends about ten
+// on range handling these kernels do not need (arguments <= 0 up to rounding; a weight below 2^-126 is zero either way); relative
+// error <= |x| 1e-7, forward and backward passes use the same function.  -DSHADOW_LIBM_EXP: expf.
+__device__ __forceinline__ float gat_exp(float x) {
+#ifdef SHADOW_LIBM_EXP
+  return expf(x);
+#else
+  return __builtin_amdgcn_exp2f(x * 1.44269504f);
+#endif
+}
 
 // Row ranges per XCD: workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; a wrong guess costs
 // speed only).  The eight XCDs get contiguous eighths of the batch's rows and the workgroups of an XCD walk their eighth
@@ -65,13 +79,18 @@ struct GatParams {
   float *nagg;                            // [n, F]  output
   // backward
   const float *dnagg;                     // [n, F]
-  float *alpha, *de;                      // [e, H]
-  float *du_s;                            // [n, H]
+  const float *tdot;                      // [n, H]  t_i = dN_i . N_i per head
   float *dz_self, *dz_neigh;              // [n, F]
   int acc_self;                           // dz_self already holds the act_norm branch's share of the gradient: add to it
   float *row_amax;                        // optional [n]: max |.| over the final dz_self and dz_neigh rows (sl_row_amax)
   float *datt;                            // [2, H, D]
   float *datt_part;                       // [gridDim.x][2][F] per-block sums, reduced in block order (gat_datt_finish_kernel)
+  // forward tail (sl_gat_fwd_tail): out = out_scale * (norm_0(N) + norm_1(act(z_self))) per head slice, fused output dropout,
+  // row maxima -- what sl_act_norm_fwd (nb = 2, seg = D) makes of (N, z_self), from the registers that hold N
+  const float *scale, *offset;            // [2, F]: row 0 the aggregate's, row 1 the self branch's (shaDow/layers.py:620-622)
+  float out_scale, eps, drop_scale;
+  uint32_t drop_thr, seed_lo, seed_hi;
+  float *out, *out_amax;                  // [n, F], optional [n]
 };
 
 // hn = act(z_neigh) of one row slice: the materialised copy, or -- hn not kept -- the activation applied where the row is
@@ -79,6 +98,27 @@ struct GatParams {
 // the few extra VALU operations per gathered float4 ride in that shadow)
 __device__ __forceinline__ float4 gat_hn_row(const GatParams &p, uint64_t row, uint32_t f) {
   return p.hn ? gld4(p.hn + row * p.F + f) : act4(p.act, gld4(p.z_neigh + row * p.F + f));
+}
+
+// Compile-time shape of a launch (round 6).  The edge walks are bound by instruction ISSUE (rocprofv3 SQ counters of the round-5
+// kernels, profiles/r06_pmc_products-khop3-gat5_before.csv: the SIMDs issue 60 - 70 % of the kernel's cycles while every wavefront
+// waits 80 - 90 % of its own), and with everything decided at run time the forward kernel's group-of-four loop body was 808 VALU
+// instructions around 179 scalar branches (is there an edge mask?  is hn materialised?  which butterfly for this head width?).
+// The configuration every GAT of config_train runs at the benchmark width -- 256 columns, 4 heads of 64, hn materialised -- is
+// instantiated with those answers built in (edge mask: both ways); everything else takes the run-time form.
+//   LS  lanes per head slice (0: p.D / 4 at run time)      W   1 / 0: edge mask present / absent, -1: look at p.edge_w
+//   HN  1: hn is materialised, -1: look at p.hn             FIX 1: F == 256, H == 4 (D == 64): strides are shifts
+template <int LS_, int W_, int HN_, int FIX_>
+struct GatCfg { static constexpr int LS = LS_, W = W_, HN = HN_, FIX = FIX_; };
+using GatDyn = GatCfg<0, -1, -1, 0>;
+
+template <class C> __device__ __forceinline__ bool cfg_w(const GatParams &p) { if constexpr (C::W >= 0) return C::W != 0; else return p.edge_w != nullptr; }
+template <class C> __device__ __forceinline__ uint32_t cfg_F(const GatParams &p) { if constexpr (C::FIX) return 256u; else return p.F; }
+template <class C> __device__ __forceinline__ uint32_t cfg_H(const GatParams &p) { if constexpr (C::FIX) return 4u; else return p.H; }
+template <class C> __device__ __forceinline__ float cfg_sum(float v, uint32_t ls) { if constexpr (C::LS > 0) return group_sum<C::LS>(v); else return slice_sum(v, ls); }
+template <class C> __device__ __forceinline__ float4 cfg_hn_row(const GatParams &p, uint64_t row, uint32_t f) {
+  if constexpr (C::HN == 1) return gld4(p.hn + row * cfg_F<C>(p) + f);
+  else return gat_hn_row(p, row, f);
 }
 
 template <int LPR>
@@ -105,111 +145,70 @@ __global__ void gat_node_fwd_kernel(GatParams p) {
 
 // Edge loops run in GROUPS: the G column ids, then the G scores, then the G feature rows of a group are loaded together, so a
 // group costs one dependent round trip per stage instead of one per edge (sums keep the edge order: same bits as one by one).
-template <int G>
-__device__ __forceinline__ void gat_max_group(const GatParams &p, uint32_t q, uint32_t h, float as, float &mx) {
-  uint32_t c[G];
-  float u[G];
-#pragma unroll
-  for (int j = 0; j < G; j++) c[j] = p.indices[q + j];
-#pragma unroll
-  for (int j = 0; j < G; j++) u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-#pragma unroll
-  for (int j = 0; j < G; j++) mx = fmaxf(mx, as + lrelu02(u[j]));
-}
-template <int G>
-__device__ __forceinline__ void gat_fwd_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, float as, float mx,
-                                              float &den, float4 &acc) {
-  uint32_t c[G];
-  float u[G], w[G];
-  float4 v[G];
-#pragma unroll
-  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = p.edge_w ? p.edge_w[q + j] : 1.0f; }
-#pragma unroll
-  for (int j = 0; j < G; j++) {
-    u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-    v[j] = on ? gat_hn_row(p, c[j], f) : make_float4(0, 0, 0, 0);
-  }
-#pragma unroll
-  for (int j = 0; j < G; j++) {
-    float pe = expf(as + lrelu02(u[j]) - mx);
-    if (p.edge_w) pe *= w[j];
-    den += pe;
-    acc.x += pe * v[j].x; acc.y += pe * v[j].y; acc.z += pe * v[j].z; acc.w += pe * v[j].w;
-  }
-}
-// One pass instead of two (SHADOW_GAT_ONLINE_SOFTMAX): the running maximum m is raised group by group and the sums so far are
-// rescaled by exp(m_old - m_new) -- the pass that only looked for the maximum (column ids -> scores: two dependent stages per
-// group) goes away.  mx / den come out as max_j e_j and sum_j exp(e_j - mx) w_j like before, to rounding.
-template <int G>
+// Online softmax (one pass instead of a maximum pass and a sum pass): the running maximum m is raised group by group and the sums
+// so far are rescaled by exp(m_old - m_new).  mx / den come out as max_j e_j and sum_j exp(e_j - mx) w_j, to rounding.
+template <int G, class C>
 __device__ __forceinline__ void gat_fwd_group_online(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, float as, float &m,
                                                      float &den, float4 &acc) {
   uint32_t c[G];
   float u[G], w[G];
   float4 v[G];
+  const bool hw = cfg_w<C>(p);
 #pragma unroll
-  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = p.edge_w ? p.edge_w[q + j] : 1.0f; }
+  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = hw ? p.edge_w[q + j] : 1.0f; }
 #pragma unroll
   for (int j = 0; j < G; j++) {
-    u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-    v[j] = on ? gat_hn_row(p, c[j], f) : make_float4(0, 0, 0, 0);
+    u[j] = p.u_n[(uint64_t)c[j] * cfg_H<C>(p) + h];
+    v[j] = on ? cfg_hn_row<C>(p, c[j], f) : make_float4(0, 0, 0, 0);
   }
   float gm = m;
 #pragma unroll
   for (int j = 0; j < G; j++) { u[j] = as + lrelu02(u[j]); gm = fmaxf(gm, u[j]); }
   if (gm > m) {
-    const float sc = expf(m - gm);            // (m = -inf at the first group: exp(-inf) = 0, the sums are still zero)
+    const float sc = gat_exp(m - gm);            // (m = -inf at the first group: exp(-inf) = 0, the sums are still zero)
     den *= sc; acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
     m = gm;
   }
 #pragma unroll
   for (int j = 0; j < G; j++) {
-    float pe = expf(u[j] - m);
-    if (p.edge_w) pe *= w[j];
+    float pe = gat_exp(u[j] - m);
+    if (hw) pe *= w[j];
     den += pe;
     acc.x += pe * v[j].x; acc.y += pe * v[j].y; acc.z += pe * v[j].z; acc.w += pe * v[j].w;
   }
 }
-template <int G>
-__device__ __forceinline__ void gat_bwd_row_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, bool lead, uint32_t ls,
-                                                  float as, float mx, float inv, float t, const float4 &dn, float &das) {
-  uint32_t c[G];
-  float u[G], w[G];
+// Column walk (transposed CSR): the edges (i -> j) into column j.  alpha_ij = exp(lrelu(u_s[i]) + lrelu(u_n[j]) - mx_i) w_ij / den_i
+// is formed again from row i's three scalars -- the expression of the forward pass, same bits -- and de_ij = alpha_ij (dN_i.hn_j - t_i)
+// with the gathered dN_i against the column's own hn_j (in registers).
+template <int G, class C>
+__device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, uint32_t ls, float lun,
+                                                  const float4 &hn, float &dan, float4 &acc) {
+  uint32_t s_[G];
+  float us[G], mx[G], dn[G], t[G], w[G];
   float4 v[G];
+  const bool hw = cfg_w<C>(p);
 #pragma unroll
-  for (int j = 0; j < G; j++) { c[j] = p.indices[q + j]; w[j] = p.edge_w ? p.edge_w[q + j] : 1.0f; }
+  for (int j = 0; j < G; j++) { s_[j] = p.t_indices[q + j]; w[j] = hw ? p.edge_w[p.t_perm[q + j]] : 1.0f; }
 #pragma unroll
   for (int j = 0; j < G; j++) {
-    u[j] = p.u_n[(uint64_t)c[j] * p.H + h];
-    v[j] = on ? gat_hn_row(p, c[j], f) : make_float4(0, 0, 0, 0);
+    const uint64_t o = (uint64_t)s_[j] * cfg_H<C>(p) + h;
+    us[j] = p.u_s[o]; mx[j] = p.mx[o]; dn[j] = p.den[o]; t[j] = p.tdot[o];
+    v[j] = on ? gld4(p.dnagg + (uint64_t)s_[j] * cfg_F<C>(p) + f) : make_float4(0, 0, 0, 0);
   }
 #pragma unroll
   for (int j = 0; j < G; j++) {
-    float pe = expf(as + lrelu02(u[j]) - mx);
-    if (p.edge_w) pe *= w[j];
-    const float alpha = pe * inv;
-    const float dal = slice_sum(dot4(dn, v[j]), ls);
-    const float de = alpha * (dal - t);
-    das += de;
-    if (lead) { p.alpha[(uint64_t)(q + j) * p.H + h] = alpha; p.de[(uint64_t)(q + j) * p.H + h] = de; }
-  }
-}
-template <int G>
-__device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, float &dan, float4 &acc) {
-  uint32_t s_[G], e_[G];
-  float al[G], de[G];
-  float4 v[G];
-#pragma unroll
-  for (int j = 0; j < G; j++) { s_[j] = p.t_indices[q + j]; e_[j] = p.t_perm[q + j]; }
-#pragma unroll
-  for (int j = 0; j < G; j++) {
-    al[j] = p.alpha[(uint64_t)e_[j] * p.H + h];
-    de[j] = p.de[(uint64_t)e_[j] * p.H + h];
-    v[j] = on ? gld4(p.dnagg + (uint64_t)s_[j] * p.F + f) : make_float4(0, 0, 0, 0);
-  }
-#pragma unroll
-  for (int j = 0; j < G; j++) {
-    dan += de[j];
-    acc.x += al[j] * v[j].x; acc.y += al[j] * v[j].y; acc.z += al[j] * v[j].z; acc.w += al[j] * v[j].w;
+    const float ev = lrelu02(us[j]) + lun;        // e_ij, the forward pass's expression: == mx_i exactly on row i's maximum edge
+    float pe = gat_exp(ev - mx[j]);
+    if (hw) pe *= w[j];
+    const float alpha = pe * (1.0f / dn[j]);
+    const float dal = cfg_sum<C>(dot4(v[j], hn), ls);
+    // d e_ij.  Ordinary row: alpha_ij (dN_i . hn_j - t_i) -- the softmax's denominator moves with e_ij, the subtracted maximum
+    // cancels.  A row whose denominator sits on its 1e-10 clamp: the denominator is a constant there, so the direct term is
+    // alpha_ij dN_i . hn_j alone, and the subtracted row maximum no longer cancels: -t_i reaches the maximum edge (kept or dropped
+    // by the edge mask) the way torch_scatter's max hands its gradient to the arg-max (shaDow/layers.py:572-578)
+    const float tt = (dn[j] > 1e-10f) ? alpha * t[j] : (ev == mx[j] ? t[j] : 0.f);
+    dan += alpha * dal - tt;
+    acc.x += alpha * v[j].x; acc.y += alpha * v[j].y; acc.z += alpha * v[j].z; acc.w += alpha * v[j].w;
   }
 }
 // group sizes tried before the single-edge tail: bit masks of {8, 4, 2} per kernel (scripts/ab_gat_group.sh; same box, products
@@ -220,14 +219,11 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
 #ifndef SHADOW_GAT_GROUPS_FWD
 #define SHADOW_GAT_GROUPS_FWD 6
 #endif
-#ifndef SHADOW_GAT_GROUPS_ROW
-#define SHADOW_GAT_GROUPS_ROW 2      // (round 5, after the row pass stopped reading z_self: groups of two -- 92 VGPRs instead of 106 -- 0.87 -> 0.82 ms per gat_bwd launch, step 10.42 -> 10.24 ms, same box twice: scripts/micro/ab_gat_row_waves.sh; {4} was round 3's choice)
-#endif
 #ifndef SHADOW_GAT_GROUPS_COL
 #define SHADOW_GAT_GROUPS_COL 2
 #endif
-#ifndef SHADOW_GAT_ONLINE_SOFTMAX
-#define SHADOW_GAT_ONLINE_SOFTMAX 1
+#ifndef SHADOW_GAT_TAIL_ZS_EARLY
+#define SHADOW_GAT_TAIL_ZS_EARLY 0
 #endif
 #ifndef SHADOW_GAT_ROW_PREFETCH
 #define SHADOW_GAT_ROW_PREFETCH 1      // the next row's pointers / score / gradient rows are loaded while this row's edges are walked
@@ -240,153 +236,127 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
     for (; q < b; q++) { CALL(1); }                              \
   } while (0)
 
-template <int LPR>
+template <int LPR, bool TAIL, class C>
 __global__ void gat_row_fwd_kernel(GatParams p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  const uint32_t f = l * 4, ls = p.D / 4;
-  const bool on = f < p.F;
-  const uint32_t h = on ? f / p.D : 0;
+  const uint32_t f = l * 4, ls = C::LS > 0 ? (uint32_t)C::LS : p.D / 4;
+  const uint32_t F = cfg_F<C>(p), H = cfg_H<C>(p);
+  const bool on = f < F;
+  const uint32_t h = on ? f / (C::FIX ? 64u : p.D) : 0;
   const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
   // (the next row's pointers and score are loaded while this row's edges are walked: one dependent stage less per row)
   uint32_t na = 0, nb = 0;
   float nus = 0.f;
-  if (rw_.r < rw_.end) { na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1]; nus = p.u_s[rw_.r * p.H + h]; }
+  if (rw_.r < rw_.end) { na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1]; nus = p.u_s[rw_.r * H + h]; }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
 #if !SHADOW_GAT_ROW_PREFETCH
-    na = p.indptr[r]; nb = p.indptr[r + 1]; nus = p.u_s[r * p.H + h];
+    na = p.indptr[r]; nb = p.indptr[r + 1]; nus = p.u_s[r * H + h];
 #endif
     const uint32_t a = na, b = nb;
     const float as = lrelu02(nus);
-    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * p.H + h]; }
+    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * H + h]; }
+    // (tail: the row's own z_self slice.  Asked for before the edge walk it is four more registers live through it -- 75 VGPRs,
+    //  six wavefronts per SIMD; asked for after it 71 / seven, the latency covered by the other wavefronts)
+    float4 zs = make_float4(0, 0, 0, 0);
+    if (SHADOW_GAT_TAIL_ZS_EARLY && TAIL && on) zs = ld4s(p.z_self + r * F + f);
     float mx = -INFINITY;
     uint32_t q = a;
     float den = 0.f;
     float4 acc = make_float4(0, 0, 0, 0);
-#if SHADOW_GAT_ONLINE_SOFTMAX
-#define SHD_CALL(G) gat_fwd_group_online<G>(p, q, h, f, on, as, mx, den, acc)
+#define SHD_CALL(G) gat_fwd_group_online<G, C>(p, q, h, f, on, as, mx, den, acc)
     SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
 #undef SHD_CALL
     if (a == b) mx = 0.f;
-#else
-#define SHD_CALL(G) gat_max_group<G>(p, q, h, as, mx)
-    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
-#undef SHD_CALL
-    if (a == b) mx = 0.f;
-    q = a;
-#define SHD_CALL(G) gat_fwd_group<G>(p, q, h, f, on, as, mx, den, acc)
-    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_FWD, q, b, SHD_CALL);
-#undef SHD_CALL
-#endif
     den = fmaxf(den, 1e-10f);
     const float inv = 1.0f / den;
+    const float4 nv = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     if (on) {
-      gst4(p.nagg + r * p.F + f, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
-      if ((l % ls) == 0) { p.mx[r * p.H + h] = mx; p.den[r * p.H + h] = den; }
+      if (!TAIL || p.nagg) gst4(p.nagg + r * F + f, nv);
+      if ((l % ls) == 0) { p.mx[r * H + h] = mx; p.den[r * H + h] = den; }
     }
-  }
-}
-
-// backward, row side: alpha / de per edge, du_s, attention part of dz_self, datt[0]
-#ifndef SHADOW_GAT_ROW_BWD_WAVES     // (scripts/micro/ab_gat_row_waves.sh: a register cap for more resident wavefronts)
-#define SHADOW_GAT_ROW_BWD_ATTR
-#else
-#define SHADOW_GAT_ROW_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SHADOW_GAT_ROW_BWD_WAVES, 8)))
-#endif
-template <int LPR>
-__global__ void SHADOW_GAT_ROW_BWD_ATTR gat_row_bwd_kernel(GatParams p) {
-  const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  const uint32_t f = l * 4, ls = p.D / 4;
-  const bool on = f < p.F;
-  const uint32_t h = on ? f / p.D : 0;
-  float4 a0 = make_float4(0, 0, 0, 0), g0 = a0;
-  if (on) a0 = gld4(p.att + f);
-  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
-  uint32_t na = 0, nb = 0;                              // (next row's pointers ahead: see gat_row_fwd_kernel)
-  float4 ndn = make_float4(0, 0, 0, 0), nng = ndn;
-  if (rw_.r < rw_.end) {
-    na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1];
-    if (on) { ndn = gld4(p.dnagg + rw_.r * p.F + f); nng = gld4(p.nagg + rw_.r * p.F + f); }
-  }
-  for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
-#if !SHADOW_GAT_ROW_PREFETCH
-    na = p.indptr[r]; nb = p.indptr[r + 1];
-    if (on) { ndn = gld4(p.dnagg + r * p.F + f); nng = gld4(p.nagg + r * p.F + f); }
-#endif
-    const uint32_t a = na, b = nb;
-    const float4 dn = ndn, ng = nng;
-    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) {
-      const uint64_t r2 = r + rw_.step;
-      na = p.indptr[r2]; nb = p.indptr[r2 + 1];
-      if (on) { ndn = gld4(p.dnagg + r2 * p.F + f); nng = gld4(p.nagg + r2 * p.F + f); }
-    }
-    const float t = slice_sum(dot4(dn, ng), ls);          // dN_i . N_i per head
-    const float usr = p.u_s[r * p.H + h];
-    const float as = lrelu02(usr);
-    const float mx = p.mx[r * p.H + h], den_r = p.den[r * p.H + h], inv = 1.0f / den_r;
-    float das = 0.f;
-    uint32_t q = a;
-    const bool lead = on && (l % ls) == 0;
-#define SHD_CALL(G) gat_bwd_row_group<G>(p, q, h, f, on, lead, ls, as, mx, inv, t, dn, das)
-    SHD_GAT_EDGES(SHADOW_GAT_GROUPS_ROW, q, b, SHD_CALL);
-#undef SHD_CALL
-    // The score of edge (i, j) is lrelu(u_s[i]) + lrelu(u_n[j]): the row's softmax does not change when u_s[i] moves, so the
-    // aggregate's gradient with respect to u_s[i] is EXACTLY zero (sum_j de_ij = t - t sum_j alpha_ij, sum_j alpha_ij = 1) --
-    // the reference's autograd produces rounding noise around 0 there (layers.py:568-581).  The one exception is a row whose
-    // denominator sits on its 1e-10 clamp (every kept edge more than e^-23 below the dropped maximum): there alpha does not
-    // sum to one and the sum is kept.  Everywhere else the attention's share of dz_self and of datt[0] is zero: the lanes of an
-    // unclamped head neither read z_self nor touch dz_self (0.9 GB less per launch at 294 k rows).
-    const bool clamped = !(den_r > 1e-10f);          // (the forward pass stored max(sum, 1e-10))
-    const float dus = clamped ? das * dlrelu02(usr) : 0.f;
-    float rmax = 0.f;
-    if (on) {
-      if ((l % ls) == 0) p.du_s[r * p.H + h] = dus;
-      if (clamped) {
-        const float4 z = gld4(p.z_self + r * p.F + f);
-        const float4 hs = act4(p.act, z);
-        float4 dzv = make_float4(dus * a0.x * g_act_bwd(p.act, z.x, hs.x), dus * a0.y * g_act_bwd(p.act, z.y, hs.y),
-                                 dus * a0.z * g_act_bwd(p.act, z.z, hs.z), dus * a0.w * g_act_bwd(p.act, z.w, hs.w));
-        if (p.acc_self) {                  // (z_self also feeds the layer's act_norm: its gradient share is here already)
-          const float4 o = gld4(p.dz_self + r * p.F + f);
-          dzv.x += o.x; dzv.y += o.y; dzv.z += o.z; dzv.w += o.w;
+    if (TAIL) {
+      if (!SHADOW_GAT_TAIL_ZS_EARLY && on) zs = ld4s(p.z_self + r * F + f);
+      // out = out_scale * (norm_0(N) + norm_1(act(z_self))), each over the head slice (shaDow/layers.py:329-338,620-625): the
+      // arithmetic of act_norm_kernel<.., false, 2> (aggregate.hip), statement for statement.  NOT bit for bit the separate pass:
+      // hipcc contracts multiply-add pairs differently from one instantiation to the next (this kernel's edge walk uses packed
+      // fmas where the plain row pass uses scalar ones, act_norm_kernel squares with v_pk_mul and adds unfused) -- the two forms
+      // agree to 1 - 2 units in the last place per stage (tests: <= 2e-6 of the tensor's scale); each is reproducible run to run
+      const float inv_seg = C::FIX ? 1.0f / 64.0f : 1.0f / (float)p.D;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t fo = f;
+      asm volatile("" : "+v"(fo));       // (keeps the four loop-invariant scale / offset loads below from being hoisted over the edge walk: 16 VGPRs)
+#pragma unroll
+      for (int br = 0; br < 2; br++) {
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) hv = br == 0 ? nv : act4(p.act, zs);
+        const float mean = cfg_sum<C>(hv.x + hv.y + hv.z + hv.w, ls) * inv_seg;
+        float4 d = make_float4(hv.x - mean, hv.y - mean, hv.z - mean, hv.w - mean);
+        if (!on) d = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float var = cfg_sum<C>(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w, ls) * inv_seg + p.eps;
+        const float rstd = rsqrtf(var);
+        float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), of = sc;
+        if (on) { sc = gld4(p.scale + (size_t)br * F + fo); of = gld4(p.offset + (size_t)br * F + fo); }
+        o.x += d.x * sc.x * rstd + of.x; o.y += d.y * sc.y * rstd + of.y;
+        o.z += d.z * sc.z * rstd + of.z; o.w += d.w * sc.w * rstd + of.w;
+      }
+      float omax = 0.f;
+      if (on) {
+        o.x *= p.out_scale; o.y *= p.out_scale; o.z *= p.out_scale; o.w *= p.out_scale;
+        omax = amax4(o);
+        if (p.drop_thr) {
+          const uint32_t keep = drop_keep4_raw(p.seed_lo, p.seed_hi, p.drop_thr, r, f);
+          o = make_float4((keep & 1u) ? o.x * p.drop_scale : 0.f, (keep & 2u) ? o.y * p.drop_scale : 0.f,
+                          (keep & 4u) ? o.z * p.drop_scale : 0.f, (keep & 8u) ? o.w * p.drop_scale : 0.f);
+          omax = amax4(o);
         }
-        gst4(p.dz_self + r * p.F + f, dzv);
-        rmax = shadow::amax4(dzv);
-        g0.x += dus * hs.x; g0.y += dus * hs.y; g0.z += dus * hs.z; g0.w += dus * hs.w;
-      } else if (!p.acc_self) {
-        gst4(p.dz_self + r * p.F + f, make_float4(0.f, 0.f, 0.f, 0.f));
+        st4s(p.out + r * F + f, o);
+      }
+      if (p.out_amax) {                   // (the LPR lanes of a row group share r)
+        omax = group_max<LPR>(omax);
+        if (l == 0) p.out_amax[r] = omax;
       }
     }
-    if (p.row_amax) {                    // (the LPR lanes of a row group share r)
-      // accumulate mode: the array holds max |dz_self| of the incoming rows (the caller's contract); what this pass changed
-      // is joined in.  Otherwise this pass wrote the whole row.
-      rmax = shadow::group_max<LPR>(rmax);
-      if (l == 0) {
-        if (!p.acc_self) p.row_amax[r] = rmax;
-        else if (rmax > 0.f) p.row_amax[r] = fmaxf(p.row_amax[r], rmax);
-      }
-    }
-  }
-  // datt[0] += sum over this block's rows
-  __shared__ float red[kGatBlock * 4];
-  red[threadIdx.x * 4 + 0] = g0.x; red[threadIdx.x * 4 + 1] = g0.y; red[threadIdx.x * 4 + 2] = g0.z; red[threadIdx.x * 4 + 3] = g0.w;
-  __syncthreads();
-  if (sub == 0 && on) {
-    float s4[4] = {0, 0, 0, 0};
-    for (uint32_t q = 0; q < rpb; q++)
-      for (int k = 0; k < 4; k++) s4[k] += red[(q * LPR + l) * 4 + k];
-    for (int k = 0; k < 4; k++) p.datt_part[((size_t)blockIdx.x * 2 + 0) * p.F + f + k] = s4[k];
   }
 }
 
-// backward, column side (transposed CSR): d hn, du_n, dz_neigh, datt[1]
+// t_i = dN_i . N_i per head, for callers whose act + norm backward did not leave it (sl_gat_bwd with d_t == NULL)
 template <int LPR>
-__global__ void gat_col_bwd_kernel(GatParams p) {
+__global__ void gat_t_kernel(GatParams p) {
+  float *__restrict__ t_out = const_cast<float *>(p.tdot);
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const uint32_t f = l * 4, ls = p.D / 4;
   const bool on = f < p.F;
   const uint32_t h = on ? f / p.D : 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * rpb + sub; r < p.n; r += (uint64_t)gridDim.x * rpb) {
+    float4 dn = make_float4(0, 0, 0, 0), ng = dn;
+    if (on) { dn = ld4s(p.dnagg + r * p.F + f); ng = ld4s(p.nagg + r * p.F + f); }
+    const float t = slice_sum(dot4(dn, ng), ls);
+    if (on && (l % ls) == 0) t_out[r * p.H + h] = t;
+  }
+}
+
+// backward, row side: there is none.  The score of edge (i, j) is lrelu(u_s[i]) + lrelu(u_n[j]) and the row's weights are
+// exp(e_ij - max_j e_ij) over their (clamped) sum: adding a constant to every e_ij of a row -- which is all that moving u_s[i] does
+// -- changes neither the numerators nor the sum, clamp or no clamp.  The aggregate's gradient with respect to u_s[i] is EXACTLY
+// zero on every row; the reference's autograd arrives at rounding noise around zero (layers.py:568-581: sum_j de_ij = t_i - t_i
+// for an ordinary row; sum_j alpha_ij dN_i.hn_j - t_i = 0 through the arg-max of torch_scatter's max for a row on the 1e-10 clamp).
+// So the attention's share of dz_self and datt[0] are zero and z_self is not read at all by the backward pass (rounds 5 / 6 walked
+// the clamped rows' edges row-wise and kept a sum there that the reference's graph does not have).
+// backward, column side (transposed CSR): alpha, de, d hn, du_n, dz_neigh, datt[1]
+#ifndef SHADOW_GAT_COL_BWD_WAVES     // (a register cap for more resident wavefronts, scripts/micro)
+#define SHADOW_GAT_COL_BWD_ATTR
+#else
+#define SHADOW_GAT_COL_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SHADOW_GAT_COL_BWD_WAVES, 8)))
+#endif
+template <int LPR, class C>
+__global__ void SHADOW_GAT_COL_BWD_ATTR gat_col_bwd_kernel(GatParams p) {
+  const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t f = l * 4, ls = C::LS > 0 ? (uint32_t)C::LS : p.D / 4;
+  const uint32_t F = cfg_F<C>(p), H = cfg_H<C>(p);
+  const bool on = f < F;
+  const uint32_t h = on ? f / (C::FIX ? 64u : p.D) : 0;
   float4 a1 = make_float4(0, 0, 0, 0), g1 = a1;
-  if (on) a1 = gld4(p.att + p.F + f);
+  if (on) a1 = gld4(p.att + F + f);
   const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
   uint32_t na = 0, nb = 0;                              // (next row's pointers ahead: see gat_row_fwd_kernel)
   if (rw_.r < rw_.end) { na = p.t_indptr[rw_.r]; nb = p.t_indptr[rw_.r + 1]; }
@@ -396,33 +366,38 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
 #endif
     const uint32_t a = na, b = nb;
     if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.t_indptr[r + rw_.step]; nb = p.t_indptr[r + rw_.step + 1]; }
+    // the column's own hn_j and score (every edge's dN_i . hn_j and alpha_ij need them)
+    float4 z = make_float4(0, 0, 0, 0), hn = z;
+    if (on) {
+      if (p.z_neigh) { z = gld4(p.z_neigh + r * F + f); hn = (C::HN == 1 || p.hn) ? gld4(p.hn + r * F + f) : act4(p.act, z); }
+      else hn = gld4(p.hn + r * F + f);   // (the paired Linear wrote hn = act(z_neigh) straight away)
+    }
+    const float unr = p.u_n[r * H + h];
+    const float lun = lrelu02(unr);
     float4 acc = make_float4(0, 0, 0, 0);
     float dan = 0.f, rmax = 0.f;
     uint32_t q = a;
-#define SHD_CALL(G) gat_bwd_col_group<G>(p, q, h, f, on, dan, acc)
+#define SHD_CALL(G) gat_bwd_col_group<G, C>(p, q, h, f, on, ls, lun, hn, dan, acc)
     SHD_GAT_EDGES(SHADOW_GAT_GROUPS_COL, q, b, SHD_CALL);
 #undef SHD_CALL
     if (on) {
-      const float dun = dan * dlrelu02(p.u_n[r * p.H + h]);
-      float4 hn, dzv;
+      const float dun = dan * dlrelu02(unr);
+      float4 dzv;
       acc.x += dun * a1.x; acc.y += dun * a1.y; acc.z += dun * a1.z; acc.w += dun * a1.w;
       if (p.z_neigh) {
-        const float4 z = gld4(p.z_neigh + r * p.F + f);
-        hn = p.hn ? gld4(p.hn + r * p.F + f) : act4(p.act, z);
         dzv = make_float4(acc.x * g_act_bwd(p.act, z.x, hn.x), acc.y * g_act_bwd(p.act, z.y, hn.y),
                           acc.z * g_act_bwd(p.act, z.z, hn.z), acc.w * g_act_bwd(p.act, z.w, hn.w));
-      } else {                           // (the paired Linear wrote hn = act(z_neigh) straight away: the derivative from hn, gat_act.h)
-        hn = gld4(p.hn + r * p.F + f);
+      } else {                           // (the derivative from hn, gat_act.h)
         dzv = make_float4(acc.x * g_act_bwd_h(p.act, hn.x), acc.y * g_act_bwd_h(p.act, hn.y),
                           acc.z * g_act_bwd_h(p.act, hn.z), acc.w * g_act_bwd_h(p.act, hn.w));
       }
-      gst4(p.dz_neigh + r * p.F + f, dzv);
+      gst4(p.dz_neigh + r * F + f, dzv);
       rmax = shadow::amax4(dzv);
       g1.x += dun * hn.x; g1.y += dun * hn.y; g1.z += dun * hn.z; g1.w += dun * hn.w;
     }
-    if (p.row_amax) {                    // joined with the maximum the row pass left for dz_self's row
+    if (p.row_amax) {                    // joined with the maximum of dz_self's row (accumulate mode: the caller's; otherwise zero rows)
       rmax = shadow::group_max<LPR>(rmax);
-      if (l == 0) p.row_amax[r] = fmaxf(p.row_amax[r], rmax);
+      if (l == 0) p.row_amax[r] = p.acc_self ? fmaxf(p.row_amax[r], rmax) : rmax;
     }
   }
   __shared__ float red[kGatBlock * 4];
@@ -432,7 +407,10 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
     float s4[4] = {0, 0, 0, 0};
     for (uint32_t q = 0; q < rpb; q++)
       for (int k = 0; k < 4; k++) s4[k] += red[(q * LPR + l) * 4 + k];
-    for (int k = 0; k < 4; k++) p.datt_part[((size_t)blockIdx.x * 2 + 1) * p.F + f + k] = s4[k];
+    for (int k = 0; k < 4; k++) {
+      p.datt_part[((size_t)blockIdx.x * 2 + 1) * F + f + k] = s4[k];
+      p.datt_part[((size_t)blockIdx.x * 2 + 0) * F + f + k] = 0.f;       // (datt[0]: no gradient through u_s, see above)
+    }
   }
 }
 
@@ -507,6 +485,23 @@ static int gat_check(uint32_t F, uint32_t H, uint32_t *lpr_out) {
     }                                                                                     \
   } while (0)
 
+// the run-time form for every width, or -- 256 columns, 4 heads, hn materialised -- the built-in one (edge mask: both ways)
+#define SHD_GAT_LAUNCH_CFG(KERN, lpr, grid, st, p, ...)                                                                   \
+  do {                                                                                                                   \
+    if ((p).F == 256 && (p).H == 4 && (p).hn) {                                                                          \
+      if ((p).edge_w) hipLaunchKernelGGL((KERN<64, ##__VA_ARGS__, GatCfg<16, 1, 1, 1>>), dim3(grid), dim3(kGatBlock), 0, st, p); \
+      else hipLaunchKernelGGL((KERN<64, ##__VA_ARGS__, GatCfg<16, 0, 1, 1>>), dim3(grid), dim3(kGatBlock), 0, st, p);     \
+    } else {                                                                                                             \
+      switch (lpr) {                                                                                                     \
+        case 4: hipLaunchKernelGGL((KERN<4, ##__VA_ARGS__, GatDyn>), dim3(grid), dim3(kGatBlock), 0, st, p); break;       \
+        case 8: hipLaunchKernelGGL((KERN<8, ##__VA_ARGS__, GatDyn>), dim3(grid), dim3(kGatBlock), 0, st, p); break;       \
+        case 16: hipLaunchKernelGGL((KERN<16, ##__VA_ARGS__, GatDyn>), dim3(grid), dim3(kGatBlock), 0, st, p); break;     \
+        case 32: hipLaunchKernelGGL((KERN<32, ##__VA_ARGS__, GatDyn>), dim3(grid), dim3(kGatBlock), 0, st, p); break;     \
+        default: hipLaunchKernelGGL((KERN<64, ##__VA_ARGS__, GatDyn>), dim3(grid), dim3(kGatBlock), 0, st, p); break;     \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  } while (0)
+
 }  // namespace shadow
 
 using namespace shadow;
@@ -530,7 +525,7 @@ extern "C" int sl_gat_fwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   p.hn = d_hn; p.u_s = d_u_s; p.u_n = d_u_n; p.mx = d_mx; p.den = d_den; p.nagg = d_nagg;
   const uint32_t g = gat_grid(n, lpr);
   SHD_GAT_LAUNCH(gat_node_fwd_kernel, lpr, g, st, p);
-  SHD_GAT_LAUNCH(gat_row_fwd_kernel, lpr, g, st, p);
+  SHD_GAT_LAUNCH_CFG(gat_row_fwd_kernel, lpr, g, st, p, false);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -552,7 +547,45 @@ extern "C" int sl_gat_fwd_rows(const uint32_t *d_indptr, const uint32_t *d_indic
   p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
   p.mx = d_mx; p.den = d_den; p.nagg = d_nagg;
   const uint32_t g = gat_grid(n, lpr);
-  SHD_GAT_LAUNCH(gat_row_fwd_kernel, lpr, g, st, p);
+  SHD_GAT_LAUNCH_CFG(gat_row_fwd_kernel, lpr, g, st, p, false);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+// sl_gat_fwd_rows AND the layer's act + feature normalisation + branch average + output dropout in the same pass
+// (shaDow/layers.py:612-625): the aggregate N of a row leaves the kernel normalised,
+//   out = out_scale * (norm_0(N) + norm_1(act(z_self)))  per head slice, then the fused output dropout and the row maxima,
+// what sl_act_norm_fwd (nb = 2, seg = F / heads, acts (identity, act)) makes of (N, z_self) -- same statements, equal to
+// rounding -- without N going to memory and back in between.  d_nagg (optional) still receives N for the backward pass.
+extern "C" int sl_gat_fwd_tail(const uint32_t *d_indptr, const uint32_t *d_indices, const float *d_edge_w, const float *d_hn,
+                               const float *d_u_s, const float *d_u_n, const float *d_z_self, int act, const float *d_scale,
+                               const float *d_offset, uint32_t n, uint32_t F, uint32_t heads, float out_scale, float drop_p,
+                               uint64_t drop_seed, float *d_mx, float *d_den, float *d_nagg, float *d_out, float *d_out_amax,
+                               void *stream_) {
+  if (!d_indptr || !d_hn || !d_u_s || !d_u_n || !d_z_self || !d_scale || !d_offset || !d_mx || !d_den || !d_out)
+    return set_error(SG_ERR_INVALID, "sl_gat_fwd_tail: null argument");
+  if (act < 0 || act > 4) return set_error(SG_ERR_INVALID, "sl_gat_fwd_tail: unknown activation %d", act);
+  uint32_t lpr;
+  int rc = gat_check(F, heads, &lpr);
+  if (rc) return rc;
+  if (n == 0) return SG_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  GatParams p;
+  memset(&p, 0, sizeof(p));
+  p.indptr = d_indptr; p.indices = d_indices; p.edge_w = d_edge_w; p.n = n; p.F = F; p.H = heads; p.D = F / heads;
+  p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
+  p.z_self = d_z_self; p.act = act;
+  p.mx = d_mx; p.den = d_den; p.nagg = d_nagg;
+  p.scale = d_scale; p.offset = d_offset; p.out_scale = out_scale; p.eps = 1e-9f; p.out = d_out; p.out_amax = d_out_amax;
+  p.drop_thr = 0; p.drop_scale = 1.0f; p.seed_lo = (uint32_t)drop_seed; p.seed_hi = (uint32_t)(drop_seed >> 32);
+  if (drop_p > 0.f) {                    // (the threshold rule of sl_act_norm_fwd, aggregate.hip set_dropout)
+    if (!(drop_p < 1.f)) return set_error(SG_ERR_INVALID, "sl_gat_fwd_tail: dropout probability %g", drop_p);
+    const double t = (double)drop_p * 4294967296.0;
+    p.drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+    p.drop_scale = 1.0f / (1.0f - drop_p);
+  }
+  const uint32_t g = gat_grid(n, lpr);
+  SHD_GAT_LAUNCH_CFG(gat_row_fwd_kernel, lpr, g, st, p, true);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }
@@ -562,9 +595,10 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
                           const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
                           uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
                           const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
-                          const float *d_nagg, const float *d_dnagg, float *d_work, float *d_dz_self,
+                          const float *d_nagg, const float *d_dnagg, const float *d_t, float *d_work, float *d_dz_self,
                           float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
-  if (!d_indptr || !d_t_indptr || !d_z_self || !(d_z_neigh || d_hn) || !d_att || !d_u_s || !d_u_n || !d_mx ||
+  (void)e;
+  if (!d_indptr || !d_t_indptr || !(d_z_neigh || d_hn) || !d_att || !d_u_s || !d_u_n || !d_mx ||
       !d_den || !d_nagg || !d_dnagg || !d_work || !d_dz_self || !d_dz_neigh || !d_datt)
     return set_error(SG_ERR_INVALID, "sl_gat_bwd: null argument");      // (d_z_neigh may be NULL when d_hn is given)
   uint32_t lpr;
@@ -580,13 +614,17 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
   p.mx = const_cast<float *>(d_mx); p.den = const_cast<float *>(d_den); p.nagg = const_cast<float *>(d_nagg);
   p.dnagg = d_dnagg;
-  // work: alpha[e*H], de[e*H], du_s[n*H], datt_part[2048][2][F]
-  p.alpha = d_work; p.de = d_work + (size_t)e * heads; p.du_s = p.de + (size_t)e * heads;
-  p.datt_part = p.du_s + (size_t)n * heads;
+  // work: t[n*H] (when not given), datt_part[2048][2][F]
+  p.datt_part = d_work + (size_t)n * heads;
   p.dz_self = d_dz_self; p.dz_neigh = d_dz_neigh; p.datt = d_datt; p.acc_self = accumulate_dz_self; p.row_amax = d_row_amax;
   const uint32_t g = gat_grid(n, lpr);
-  SHD_GAT_LAUNCH(gat_row_bwd_kernel, lpr, g, st, p);
-  SHD_GAT_LAUNCH(gat_col_bwd_kernel, lpr, g, st, p);
+  if (d_t) p.tdot = d_t;
+  else {
+    p.tdot = d_work;
+    SHD_GAT_LAUNCH(gat_t_kernel, lpr, g, st, p);
+  }
+  if (!accumulate_dz_self) SHD_HIP(hipMemsetAsync(d_dz_self, 0, (size_t)n * F * 4, st));     // (the attention's share of dz_self: zero)
+  SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p);
   hipLaunchKernelGGL(gat_datt_finish_kernel, dim3((2 * F + kDattCols - 1) / kDattCols), dim3(kDattCols * kDattSlices), 0, st,
                      p.datt_part, g, 2 * F, d_datt);
   SHD_HIP(hipGetLastError());

@@ -9,7 +9,7 @@ namespace shadow {
 __device__ __forceinline__ float g_act_fwd(int act, float x) {
   switch (act) {
     case 1: return x > 0.f ? x : 0.f;
-    case 2: return x > 0.f ? x : expm1f(x);
+    case 2: return x > 0.f ? x : elu_neg(x);
     case 3: return tanhf(x);
     case 4: return x > 0.f ? x : 0.2f * x;
     default: return x;

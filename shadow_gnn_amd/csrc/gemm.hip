@@ -834,16 +834,9 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
           const bf16x8 &bh = bfr[t & 1][0], &bm = bfr[t & 1][1], &bl = bfr[t & 1][2];
 #pragma unroll
           for (int a = 0; a < 2; a++) {
-#ifdef TN_KO_HALF
-            // (knock-out: what a two-piece operand split would leave of the step -- three products instead of six)
-            if constexpr (g == 0) asm volatile("" ::"v"(al[a]), "v"(bh));
-            else if constexpr (g == 1) asm volatile("" ::"v"(ah[a]), "v"(bl));
-            else if constexpr (g == 2) asm volatile("" ::"v"(am[a]), "v"(bm));
-#else
             if constexpr (g == 0) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
             else if constexpr (g == 1) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][t], 0, 0, 0);
             else if constexpr (g == 2) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm, acc[a][t], 0, 0, 0);
-#endif
             else if constexpr (g == 3) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh, acc[a][t], 0, 0, 0);
             else if constexpr (g == 4) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
             else acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
@@ -882,25 +875,11 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
       const bf16x8 bh = pb[0], bm = pb[8 * 64], bl = pb[2 * 8 * 64];
       // the row tiles of step s + 2 trickle in (their buffer was split during the previous step), and this wavefront's two
       // fragments of step s + 1 are split between the MFMA groups
-#ifndef TN_KO_FILL
       // the row tiles of step s + 2: all four copies at the top of the step -- they are waited for at its end, and a copy
       // issued between the later MFMA groups had less than half a step to arrive (233 -> 225 us at M = 289 k, N = K = 256)
-#ifdef TN_FILL_SPREAD
-      if (s + 2 < steps) {
-        if (TK == 4) fill(s + 2, t);
-        else { fill(s + 2, 2 * t); fill(s + 2, 2 * t + 1); }
-      }
-#else
       if (s + 2 < steps && t == 0) { fill(s + 2, 0); fill(s + 2, 1); fill(s + 2, 2); fill(s + 2, 3); }
-#endif
-#endif
-#ifndef TN_KO_SPLIT
       if (s + 1 < steps && t == 0) split_job(s + 1, 0);
       if (s + 1 < steps && t == TK / 2) split_job(s + 1, 1);
-#endif
-#ifdef TN_KO_MFMA
-      asm volatile("" ::"v"(bh), "v"(bm), "v"(bl), "v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]));
-#else
 #pragma unroll
       for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][t], 0, 0, 0);
 #pragma unroll
@@ -913,13 +892,10 @@ gemm_tn_coop_kernel(const float *__restrict__ A, int64_t lda, const float *__res
       for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm, acc[a][t], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < 2; a++) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][t], 0, 0, 0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef TN_KO_BARRIER
     __syncthreads();
-#endif
   }
   // partial[g][n][k] (+ [N] column sums of A behind it when asked for); C/D layout: col (k) = lane & 31,
   // row (n) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)

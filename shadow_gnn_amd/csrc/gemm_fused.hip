@@ -523,11 +523,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
     const bool second = MODE >= 2 && NBP == 1 && u >= d.asplit;      // (the K-concatenated operand's second tensor)
     const float *ptr = (ph || second ? arow1 : arow0) + 32 * (second ? u - d.asplit : u) + 4 * q;
     if (!kTail || 32 * u + 32 <= K) {
-#ifdef FUSED_A_NT       // (experiment, scripts/micro/ab_fused_a_nt.sh: non-temporal A loads -- forward launch 0.416 -> 0.49 ms: the four 16-byte pieces a lane takes from a 128-byte line then fetch it again)
-      an[q] = ld4s(ptr);
-#else
       an[q] = *reinterpret_cast<const float4 *>(ptr);
-#endif
     } else {
       float v[4];
 #pragma unroll
@@ -622,11 +618,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       {
         const float x[8] = {ac[2 * h].x, ac[2 * h].y, ac[2 * h].z, ac[2 * h].w,
                             ac[2 * h + 1].x, ac[2 * h + 1].y, ac[2 * h + 1].z, ac[2 * h + 1].w};
-#ifdef FUSED_KO_SPLIT
-        { union { float f[4]; half8 v; } u0, u1; for (int j = 0; j < 4; j++) { u0.f[j] = x[j] * asc; u1.f[j] = x[4 + j]; } ah = u0.v; am = u1.v; }
-#else
         split8_f16(x, asc, ah, am);
-#endif
       }
       // (pin: the A registers are consumed -- and waited for -- BEFORE this step issues new copies)
       __builtin_amdgcn_sched_barrier(0);
@@ -639,21 +631,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
 #pragma unroll
           for (int pc = 0; pc < 2; pc++) fb[(t + 1) & 1][pc] = lb[(pc * TW + t + 1) * 64 + lane];
         }
-#ifndef FUSED_KO_FILL
         if (st + 2 < steps) fill_b(st + 2, t);              // two steps ahead: never waited for in this step
-#endif
-#ifndef FUSED_KO_ALOAD
         if (h == 0 && t < 4 && gu + 1 < gunits) load_a_piece(gu + 1, t);
-#endif
         const half8 bh = fb[t & 1][0], bm = fb[t & 1][1];
         // the two small terms first, the dominant product last
-#ifdef FUSED_KO_MFMA
-        asm volatile("" ::"v"(bh), "v"(bm), "v"(ah), "v"(am));
-#else
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // wait only for what is OLDER than this step's own copies, then a bare barrier
@@ -663,9 +647,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
-#ifndef FUSED_KO_BARRIER
       __builtin_amdgcn_s_barrier();                      // every wavefront is done with this step's buffer
-#endif
     }
     if (NBP == 2 && gu + 1 == units) {
       // end of the first product: Z_0 leaves while the first images of the second product are already on their way; the
@@ -699,9 +681,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   // ---- epilogue: the ring is dead (every wavefront passed the last step's barrier).  Specialised for the two activations
   //      the reference's configurations use (config_train: elu, relu) on full-width rows; everything else takes the generic
   //      copy (activation looked up per element, column predicates)
-#ifdef FUSED_KO_EPI
-  if (d.M != 7) { if (acc[0][0] == 123.456f) d.Z[0][0] = acc[1][1]; return; }
-#endif
   unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
   const bool full = d.N == 32 * TW, same = NBA == 1 || d.act[1] == d.act[0];
   if (MODE == 1 && d.stats_r && full && same && (d.act[0] == 1 || d.act[0] == 2)) {
@@ -740,11 +719,7 @@ template <int TW, int MODE, int NBP, int NBA>
 int launch_fused(FusedDesc d, hipStream_t st) {
   // ring of three k-step images (3 x 2 TW KB) or the epilogue's stash (4 wavefronts x 16 rows x 32 TW floats), whichever is larger
   const size_t lds_ = MODE >= 2 ? (size_t)3 * 2 * TW * 64 * 16 : std::max<size_t>((size_t)3 * 2 * TW * 64 * 16, (size_t)4 * 16 * 32 * TW * 4);
-#ifdef FUSED_ONE_WG          // (experiment, scripts/micro/ko_one_wg.sh: one workgroup per CU -- a single wavefront per SIMD)
-  const size_t lds = std::max<size_t>(lds_, (size_t)84 * 1024);
-#else
   const size_t lds = lds_;
-#endif
   const uint32_t grid = (d.M + 127) / 128;
   if (d.K % 32 == 0) {
     if (lds > 64 * 1024) SHD_HIP(ensure_dynamic_lds((const void *)gemm_nt_fused_kernel<TW, MODE, NBP, NBA, false>, lds));

@@ -202,8 +202,9 @@ extern "C" int sl_top_plan(const uint32_t *d_indptr, const uint32_t *d_indices, 
 
 // Row map + filtered transposed structure behind sl_top_plan (same stream, no host round trip in between): d_rowmap [n],
 // d_f_indptr [n + 1], d_f_indices / d_f_perm [e] (capacity: every edge), d_work [n / 1024 + 4] words; the number of kept
-// entries lands in d_off[num_subg + 2] beside the plan's own counters.  Nothing is written when the plan overflowed `cap`
-// or raised its flag (the caller reads both with the same copy and drops the plan).
+// entries lands in d_off[num_subg + 2] beside the plan's own counters.  The kernels run whatever the plan's outcome -- on
+// min(d_off[num_subg], cap) entries of T: a plan that overflowed `cap` or raised its flag leaves unusable structures behind, and
+// the caller, who reads both counters with the same copy, drops them with the plan.
 extern "C" int sl_top_plan_filter(const uint32_t *d_T, uint32_t *d_off, uint32_t num_subg, uint32_t cap, const uint32_t *d_t_indptr,
                                   const uint32_t *d_t_indices, const uint32_t *d_t_perm, uint32_t n, uint32_t *d_rowmap,
                                   uint32_t *d_f_indptr, uint32_t *d_f_indices, uint32_t *d_f_perm, uint32_t *d_work, void *stream) {

@@ -20,6 +20,7 @@ from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -210,6 +211,7 @@ class MinibatchShallowExtractor:
         # True: every batch carries the row sets of the row-sparse top-layer backward (tail.TopBackwardPlan; node tasks whose
         # read-out takes the roots' rows of the last GraphSAGE layer), built on the prefetch stream like the tail plan
         self.top_backward_plan = False
+        self.top_plan_filter = True        # (the plan's filtered transposed structure is wanted: attach_model narrows it to its one reader)
         # > 0: every batch carries up to that many nested levels of a row-sparse backward pass instead (GAT stacks on deep
         # subgraphs: tail.build_backward_levels)
         self.backward_levels = 0
@@ -262,6 +264,7 @@ class MinibatchShallowExtractor:
         stacks two nested levels), built on the prefetch stream.  Without it the model builds them inside its forward pass
         (two host syncs on the training stream per step).  Returns self."""
         from . import layers as _layers
+        self._attached_model = weakref.ref(model)
         ok = bool(ops.SPARSE_TOP_BWD and getattr(model, "prediction_task", None) == "node" and len(model.conv_layers) == 1
                   and model._tail_prunable(0) and not getattr(model, "prune_tail", False))
         convs = list(model.conv_layers[0]) if ok else []
@@ -269,6 +272,9 @@ class MinibatchShallowExtractor:
         gat = ok and all(isinstance(md, _layers.GAT) for md in convs)
         self.top_backward_plan = bool(sage or gat)
         self.backward_levels = 2 if gat else 0
+        # the plan's filtered transposed structure has one reader: the A^T dZn of the layer below the row-sparse pass at
+        # hidden widths in (128, 256] (ops._at_dzn_on_rows)
+        self.top_plan_filter = bool(sage and any(128 < int(md.dim_out) <= 256 for md in convs))
         return self
 
     def get_aug_dim(self, aug_type):
@@ -448,7 +454,7 @@ class MinibatchShallowExtractor:
         from . import tail
         if self._side is None:
             return (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels) if self.backward_levels > 0
-                    else tail.TopBackwardPlan(adj, subgs.target))
+                    else tail.TopBackwardPlan(adj, subgs.target, want_filter=self.top_plan_filter))
         main = torch.cuda.current_stream(self.device)
         # (as in _tail_plan: the plan allocates on the side stream BEFORE the next _launch orders that stream behind the
         #  training stream -- every sampler output of this batch must therefore be recorded on the training stream, or a block
@@ -461,7 +467,7 @@ class MinibatchShallowExtractor:
         with torch.cuda.stream(self._side):
             # (a collated batch's roots ascend: one per subgraph, the subgraphs in order)
             plan = (tail.build_backward_levels(adj, subgs.target, max_levels=self.backward_levels, targets_ascending=int(self.sampler_cfg.num_roots) == 1)
-                    if self.backward_levels > 0 else tail.TopBackwardPlan(adj, subgs.target))
+                    if self.backward_levels > 0 else tail.TopBackwardPlan(adj, subgs.target, want_filter=self.top_plan_filter))
         self.wait_s += tail._SYNC_WAIT[0] - w0                      # (the levels' size read-backs: blocked on the prefetch stream, as _collect)
         main.wait_stream(self._side)
         for t in ([x for lv in plan for x in lv.tensors()] if isinstance(plan, list) else plan.tensors()):
@@ -638,6 +644,7 @@ class MinibatchShallowExtractor:
         if tail_plan is not None:
             ret.tail_ens = [tail_plan]
         ret.device_batch = subgs
+        ret.extractor = weakref.ref(self)       # (DeepGNN.step attaches itself on its first training batch: attach_model)
         if ret_raw_idx:
             ret.idx_raw = [subgs.node]
         return ret

@@ -383,6 +383,15 @@ class DeepGNN(nn.Module):
         if status not in ('running', 'final'):
             raise ValueError(f"status {status!r}")
         training = mode == TRAIN and status == 'running'
+        if training:
+            # a batch of MinibatchShallowExtractor knows where it came from: from the next batch on the extractor prepares what this
+            # model's step asks of every TRAIN batch on its prefetch stream (the benchmarked path is the library default)
+            ex = getattr(batch_data, "extractor", None)
+            ex = ex() if ex is not None else None
+            if ex is not None:
+                at = getattr(ex, "_attached_model", None)
+                if at is None or at() is not self:
+                    ex.attach_model(self)
         if batch_data.batch_size == 0:          # a rank without roots in this global batch (minibatch.plan_epoch)
             if training:
                 self._begin_update()

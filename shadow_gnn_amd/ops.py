@@ -565,11 +565,12 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
 
 
 def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None, row_idx=None,
-            dz0_amax=None, dz_compact=False):
+            dz0_amax=None, dz_compact=False, t_out=None):
     """``douts``: the gradient(s) autograd handed over -- (dout,) or, in dual mode, (dout_plain, dout_dropped) with
     None for an output nothing consumed.  ``dz_out``: optional preallocated dZ destinations (column slices of a
     wider buffer are fine).  ``row_idx`` (int32 [m]): the gradients are compact [m, F] and belong to those rows (a read-out
-    that took a few rows of the output, see RootsLink); the other rows of dZ are zero."""
+    that took a few rows of the output, see RootsLink); the other rows of dZ are zero.  ``t_out`` = (branch, tensor [rows, F / seg]):
+    also leave the per-segment dots dZ[branch] . Z[branch] there (sl_act_norm_bwd_rows_t: the GAT attention backward's t)."""
     nb = len(Zs)
     n, F = Zs[0].shape
     m = int(row_idx.numel()) if row_idx is not None else n
@@ -602,15 +603,17 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
     ac = (C.c_int * nb)(*codes)
     with _timed(f"act_norm_bwd_nb{nb}_F{F}" if row_idx is None else f"act_norm_bwd_rows_nb{nb}_F{F}", (2 * nb + 1) * 4 * m * F, dev):
         # (dz_compact: with row_idx, dZ / dz0_amax are [m, F] / [m] in the order of row_idx -- the caller's dz_out)
-        check(_lib.load().sl_act_norm_bwd_rows(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
-                                               m, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
-                                               dout.stride(0) if dout is not None else 0, _ptr_array(dZs), ldd,
-                                               dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
-                                               partial.data_ptr(), float(drop[0]), int(drop[1]),
-                                               dout2.data_ptr() if dout2 is not None else None,
-                                               dout2.stride(0) if dout2 is not None else 0,
-                                               dz0_amax.data_ptr() if dz0_amax is not None else None,
-                                               row_idx.data_ptr() if row_idx is not None else None, 1 if dz_compact else 0, _stream(Zs[0])))
+        check(_lib.load().sl_act_norm_bwd_rows_t(nb, _ptr_array(Zs), ld, _ptr_array(biases), ac, sc.data_ptr(), of.data_ptr(),
+                                                 m, F, seg, out_scale, dout.data_ptr() if dout is not None else None,
+                                                 dout.stride(0) if dout is not None else 0, _ptr_array(dZs), ldd,
+                                                 dsc.data_ptr(), dof.data_ptr(), dbi.data_ptr() if dbi is not None else None,
+                                                 partial.data_ptr(), float(drop[0]), int(drop[1]),
+                                                 dout2.data_ptr() if dout2 is not None else None,
+                                                 dout2.stride(0) if dout2 is not None else 0,
+                                                 dz0_amax.data_ptr() if dz0_amax is not None else None,
+                                                 row_idx.data_ptr() if row_idx is not None else None, 1 if dz_compact else 0,
+                                                 t_out[0] if t_out is not None else -1, t_out[1].data_ptr() if t_out is not None else None,
+                                                 _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 
@@ -1735,7 +1738,10 @@ def rows_empty(lead: int, n: int, width: int, device) -> torch.Tensor:
     ROW_QUANTUM rows: consecutive batches (whose n differ by a few per cent) request the SAME number of bytes, so the caching
     allocator hands the same block back instead of growing by a new multi-hundred-MB block at every new maximum."""
     k = max(1, lead)
-    cap = -(-max(n, 1) // ROW_QUANTUM) * ROW_QUANTUM
+    # (the quantum follows the batch: 1/16 of the next power of two up to ROW_QUANTUM -- a 1 100-row batch rounds up to 1 152
+    #  rows, not to 16 384)
+    q = min(ROW_QUANTUM, max(64, (1 << max(n - 1, 1).bit_length()) // 16))
+    cap = -(-max(n, 1) // q) * q
     flat = torch.empty(k * cap * width, dtype=torch.float32, device=device)
     t = flat[:k * n * width]
     return t.view(k, n, width) if lead else t.view(n, width)

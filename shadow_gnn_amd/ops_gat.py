@@ -13,6 +13,12 @@ from ._lib import check
 RECOMPUTE_HN = False
 
 
+# The row pass of the forward also applies the layer's act + per-head normalisation + branch average + output dropout to the
+# aggregate it holds in registers (sl_gat_fwd_tail, round 6; equal to sl_gat_fwd_rows + sl_act_norm_fwd to rounding -- the compiler
+# fuses multiply-add pairs differently in the two kernels).  False: the two separate launches (tests compare the two).
+FUSED_FWD_TAIL = True
+
+
 def _hn_buffer(n, F, dev):
     return None if RECOMPUTE_HN else torch.empty(n, F, device=dev)
 
@@ -58,17 +64,18 @@ class _GatAggregate(torch.autograd.Function):
         dev = z_self.device
         dnagg = ops._f32c(dnagg).contiguous()
         ti, tx, tp = c.transposed
-        work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
+        work = torch.empty(n * heads + 4096 * F + 4, device=dev)
         dzs = torch.empty_like(z_self); dzn = torch.empty_like(z_neigh)
         datt = torch.empty(2, F, device=dev)
         w = adj.edge_w
-        # row pass + column pass: both CSR structures, read z_self, z_neigh and the incoming gradient, write dz_self, dz_neigh
-        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + 5 * 4 * n * F + 6 * 4 * n * heads
+        # t pass + column pass: the transposed CSR structure; the incoming gradient (twice) and the aggregate, z_neigh and hn in, dz_self
+        # (zeros) and dz_neigh out
+        nbytes = 4 * (n + 1) + 8 * c.e + (4 * c.e if w is not None else 0) + 7 * 4 * n * F + 7 * 4 * n * heads
         with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, z_self.data_ptr(), z_neigh.data_ptr(),
                                          att.data_ptr(), act_code, n, c.e, F, heads, _p(hn), u_s.data_ptr(),
-                                         u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
+                                         u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(), None,
                                          work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 0, None,
                                          ops._stream(dnagg)))
         return dzs, dzn, datt.reshape(att_shape), None, None, None
@@ -92,13 +99,33 @@ class _GatTail(torch.autograd.Function):
         mx = torch.empty(n, heads, device=dev); den = torch.empty(n, heads, device=dev)
         nagg = torch.empty(n, F, device=dev)
         w = adj.edge_w
+        out = None
         if pre is not None:
             # ``z_neigh`` IS hn = act(z_neigh) and the per-node terms are in hand (the paired Linear's kernel left them, ops.GatPre):
             # the row pass alone; the pre-activation does not exist -- the backward kernels take its derivative from hn
             hn, u_s, u_n = z_neigh, pre.u_s, pre.u_n
             z_neigh = att.new_empty(0)
-            nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 2 * 4 * n * F + 4 * 4 * n * heads
-            with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
+            if FUSED_FWD_TAIL and not ops._is_dual(drop) and int(seg) * heads == F:
+                # ... and the act + norm + average + dropout of the layer in the same pass: the aggregate goes to memory once (for the
+                # backward pass) instead of out and back in
+                out = torch.empty(n, F, device=dev)
+                amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
+                sc = scale.reshape(2, F).contiguous().float()
+                of = offset.reshape(2, F).contiguous().float()
+                # structure (+ mask); hn and z_self in, the aggregate and the layer output out; per-node scores / softmax statistics
+                nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 4 * 4 * n * F + 4 * 4 * n * heads
+                with ops._timed(f"gat_fwd_tail_F{F}_H{heads}", nbytes, dev):
+                    check(_lib.load().sl_gat_fwd_tail(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
+                                                      hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), z_self.data_ptr(), act_code,
+                                                      sc.data_ptr(), of.data_ptr(), n, F, heads, float(out_scale), float(drop[0]), int(drop[1]),
+                                                      mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), out.data_ptr(),
+                                                      amax.data_ptr() if amax is not None else None, ops._stream(z_self)))
+                if amax is not None:
+                    ops.set_row_amax(out, amax)
+                _GatTail.fused_tail_calls += 1
+            else:
+              nbytes = 4 * (n + 1) + 4 * c.e + (4 * c.e if w is not None else 0) + 2 * 4 * n * F + 4 * 4 * n * heads
+              with ops._timed(f"gat_fwd_F{F}_H{heads}", nbytes, dev):
                 check(_lib.load().sl_gat_fwd_rows(c.indptr.data_ptr(), c.indices.data_ptr(), w.data_ptr() if w is not None else None,
                                                   hn.data_ptr(), u_s.data_ptr(), u_n.data_ptr(), n, F, heads, mx.data_ptr(), den.data_ptr(),
                                                   nagg.data_ptr(), ops._stream(z_self)))
@@ -115,7 +142,8 @@ class _GatTail(torch.autograd.Function):
         sc = scale.reshape(2, F).contiguous().float()
         of = offset.reshape(2, F).contiguous().float()
         # reference order: f_norm([neigh, self]) -> scale[0] = neigh (identity: the aggregate is activated already), scale[1] = self
-        out = ops._an_fwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, drop)
+        if out is None:
+            out = ops._an_fwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, drop)
         ctx.save_for_backward(z_self, z_neigh, att, hn if hn is not None else att.new_empty(0), u_s, u_n, mx, den, nagg, sc, of)
         ctx.adj, ctx.meta = adj, (act_code, heads, attention.shape, seg, out_scale, drop, scale.shape, offset.shape)
         ctx.link_roots = None
@@ -131,6 +159,7 @@ class _GatTail(torch.autograd.Function):
         return out
 
     sparse_top_calls = 0
+    fused_tail_calls = 0     # forward passes whose row pass carried the act + norm tail (sl_gat_fwd_tail)
     pre_calls = 0            # forward passes that took hn / u_s / u_n from the paired Linear's kernel (tests assert on it)
 
     @staticmethod
@@ -167,13 +196,13 @@ class _GatTail(torch.autograd.Function):
         dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_r)
         dzn_c = torch.empty(t, F, **f32)
         datt = torch.empty(2, F, **f32)
-        work = torch.empty(2 * E * heads + t * heads + 4096 * F + 4, **f32)
-        nbytes = 2 * (4 * (t + 1) + 4 * E) + (4 * E if w is not None else 0) + 6 * 4 * t * F + 6 * 4 * t * heads
+        work = torch.empty(t * heads + 4096 * F + 4, **f32)
+        nbytes = 4 * (t + 1) + 8 * E + (4 * E if w is not None else 0) + 6 * 4 * t * F + 7 * 4 * t * heads
         with ops._timed(f"gat_bwd_rows_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(csr_c.indptr.data_ptr(), csr_c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, zs_c.data_ptr(), _p(zn_c),
                                          att.data_ptr(), act_code, t, E, F, heads, _p(hn_c), us_c.data_ptr(),
-                                         un_c.data_ptr(), mx_c.data_ptr(), den_c.data_ptr(), na_c.data_ptr(), dn_c.data_ptr(),
+                                         un_c.data_ptr(), mx_c.data_ptr(), den_c.data_ptr(), na_c.data_ptr(), dn_c.data_ptr(), None,
                                          work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
         pair = ctx.pair
         pair.rows32, pair.dza, pair.dzb, pair.levels = level.in32, dzs_c, dzn_c, list(rest)
@@ -208,24 +237,33 @@ class _GatTail(torch.autograd.Function):
         amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
         if amax is not None and rows is not None:
             amax.zero_()                 # (rows the read-out gradient does not reach: dz_self = 0)
+        # (... and t_i = dN_i . N_i per head for the attention backward, while both rows are in registers; with the read-out's row
+        #  list the other rows' dN is zero: t cleared first)
+        #  (the act + norm vector kernel only: other head widths leave t to sl_gat_bwd's own row-wise pre-pass)
+        tdot = None
+        if _lib.load().sl_act_norm_vector_layout(F, int(seg)) and int(seg) * heads == F:
+            tdot = (torch.zeros if rows is not None else torch.empty)(n, heads, device=dev)
         (dzs, dnagg), dsc, dof, _ = ops._an_bwd([z_self, nagg], [None, None], (act_code, 0), sc.flip(0).contiguous(), of.flip(0).contiguous(), seg,
-                                                out_scale, dout, [True, True], False, drop, row_idx=rows, dz0_amax=amax)
+                                                out_scale, dout, [True, True], False, drop, row_idx=rows, dz0_amax=amax,
+                                                t_out=(1, tdot) if tdot is not None else None)
         dsc, dof = dsc.flip(0), dof.flip(0)
         if rows is not None:
             lr.release()
         ti, tx, tp = c.transposed
-        work = torch.empty(2 * c.e * heads + n * heads + 4096 * F + 4, device=dev)
+        work = torch.empty(4096 * F + n * heads + 4, device=dev)
         dzn = torch.empty_like(z_self)
         datt = torch.empty(2, F, device=dev)
         w = adj.edge_w
         # (round 5: both CSR structures; the incoming gradient, the aggregate, z_neigh and hn in, dz_neigh out -- dz_self / z_self are
         #  no longer touched: the attention's share of dz_self is exactly zero, see gat_row_bwd_kernel)
-        nbytes = 2 * (4 * (n + 1) + 4 * c.e) + (4 * c.e if w is not None else 0) + (4 if (RECOMPUTE_HN or not z_neigh.numel()) else 5) * 4 * n * F + 6 * 4 * n * heads
+        # (round 6: one edge walk -- the transposed structure (+ the mask through its permutation); the incoming gradient and hn in,
+        #  dz_neigh out; the [n, heads] scores / statistics / t)
+        nbytes = 4 * (n + 1) + 8 * c.e + (4 * c.e if w is not None else 0) + (3 if (RECOMPUTE_HN or not z_neigh.numel()) else 4) * 4 * n * F + 7 * 4 * n * heads
         with ops._timed(f"gat_bwd_F{F}_H{heads}", nbytes, dev):
             check(_lib.load().sl_gat_bwd(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
                                          w.data_ptr() if w is not None else None, z_self.data_ptr(), _p(z_neigh),
                                          att.data_ptr(), act_code, n, c.e, F, heads, _p(hn), u_s.data_ptr(),
-                                         u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(),
+                                         u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dnagg.data_ptr(), tdot.data_ptr() if tdot is not None else None,
                                          work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 1,
                                          amax.data_ptr() if amax is not None else None, ops._stream(dnagg)))
         if amax is not None:              # (ONE array for both gradients: the maximum over the pair of rows)

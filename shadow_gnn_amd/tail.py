@@ -231,7 +231,7 @@ class TopBackwardPlan:
     extractor builds it on its prefetch stream.  ``ok`` False: a root row lists a neighbour twice (a multigraph) -- the
     dense pass is taken."""
 
-    def __init__(self, csr: "ops.DeviceCSR", targets: torch.Tensor):
+    def __init__(self, csr: "ops.DeviceCSR", targets: torch.Tensor, want_filter: bool = True):
         import ctypes as C
 
         from . import _lib
@@ -256,7 +256,10 @@ class TopBackwardPlan:
         self.rowmap = torch.empty(n, **i32)
         self.f_indptr = self.f_indices = self.f_perm = None
         self._t_keep = ()
-        if P and csr.e > 0:
+        # (``want_filter`` False: nobody reads the filtered structure -- ops._at_dzn_on_rows takes it for 128 < F <= 256 only,
+        #  MinibatchShallowExtractor.attach_model knows the model's widths -- and the six kernels + three [e] tensors are not spent)
+        filt = bool(want_filter and P and csr.e > 0)
+        if filt:
             ti, tx, tp = csr.transposed
             self.f_indptr = torch.empty(n + 1, **i32)
             self.f_indices, self.f_perm = torch.empty(csr.e, **i32), torch.empty(csr.e, **i32)
@@ -277,7 +280,7 @@ class TopBackwardPlan:
         if not self.ok:
             self.f_indptr = self.f_indices = self.f_perm = None
         self.T32, self.slot, self.epos, self.self_idx = T[:self.t], slot[:self.t], epos[:self.t], self_idx[:P]
-        if not (P and csr.e > 0) and self.ok:                      # (a batch without a single edge: no transposed structure to filter)
+        if not filt and self.ok:                      # (no filter pass -- not wanted, or a batch without a single edge: the row map alone)
             self.rowmap[self.T32.long()] = torch.arange(self.t, **i32)
         self.n = n
         self.num_roots = P
@@ -305,12 +308,17 @@ def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_level
     rows = torch.as_tensor(targets, device=dev).long().reshape(-1)
     levels: List[RectLevel] = []
     ascending = bool(targets_ascending)
-    for _ in range(max_levels):
+    for li in range(max_levels):
         ip, er, pos = _select_rows(csr.indptr, rows)
         cols = csr.indices[pos].long()
         mask = torch.zeros(n, dtype=torch.bool, device=dev)
         mask.index_fill_(0, rows, True)                     # (`mask[rows] = True` stages its scalar through a blocking H2D copy)
         mask.index_fill_(0, cols, True)
+        if li == 0 and ascending and rows.numel() > 1:
+            # the caller's word is checked on the device and rides on the read-back below: targets that do not strictly ascend
+            # (a collate / cache path that reorders or repeats roots) fill the mask -- the input set is then the whole batch, no
+            # level is kept and the dense backward pass runs (RectLevel.square's sort-free form would be wrong for them)
+            mask.logical_or_((rows[1:] <= rows[:-1]).any())
         import time as _time
         t0 = _time.perf_counter()
         in_ids = mask.nonzero().reshape(-1)                 # (host sync) ascending

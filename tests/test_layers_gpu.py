@@ -1941,14 +1941,15 @@ def test_gat_attention_terms_from_the_paired_linear_equal_the_node_pass(n_layers
     from shadow_gnn_amd import ops, ops_gat
     res = []
     for on in (False, True):
-        prev = ops.GAT_PAIR_TAIL
+        prev, prev_t = ops.GAT_PAIR_TAIL, ops_gat.FUSED_FWD_TAIL
         ops.GAT_PAIR_TAIL = on
+        ops_gat.FUSED_FWD_TAIL = False      # (round 6: the row pass that also normalises is a different kernel -- equal to rounding, its own test below)
         c0 = (ops._LinearPair.gat_tail_calls, ops_gat._GatTail.pre_calls)
         try:
             res.append(_sage_stack_step(n_layers, 256, p_drop, 23, chain=True, fused=True, B=96, act=act, sparse_top=sparse_top, dropedge=dropedge,
                                         aggr="gat", heads=heads))
         finally:
-            ops.GAT_PAIR_TAIL = prev
+            ops.GAT_PAIR_TAIL, ops_gat.FUSED_FWD_TAIL = prev, prev_t
         took = (ops._LinearPair.gat_tail_calls - c0[0], ops_gat._GatTail.pre_calls - c0[1])
         assert took == ((n_layers, n_layers) if on else (0, 0)), took
     (l0, p0, g0, _c0), (l1, p1, g1, _c1) = res
@@ -1957,6 +1958,112 @@ def test_gat_attention_terms_from_the_paired_linear_equal_the_node_pass(n_layers
     assert set(g0) == set(g1)
     for k in g0:
         torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,heads,p_drop,dropedge,act,sparse_top", [(3, 4, 0.3, 0.1, "elu", True), (2, 8, 0.0, 0.0, "relu", False),
+                                                                           (3, 2, 0.25, 0.05, "tanh", False)])
+def test_gat_row_pass_with_the_act_norm_tail_equals_the_two_launches(n_layers, heads, p_drop, dropedge, act, sparse_top):
+    """Round 6: the forward row pass also applies the layer's act + per-head feature normalisation + (self + neigh) / 2 + output
+    dropout to the aggregate it holds in registers (sl_gat_fwd_tail) -- shaDow/layers.py:612-625.  Against the two launches
+    (sl_gat_fwd_rows + sl_act_norm_fwd, ops_gat.FUSED_FWD_TAIL = False): the same statements on the same values with the same
+    dropout masks; hipcc fuses multiply-add pairs differently in the two kernels, so the results agree to rounding, not bit for
+    bit -- loss, predictions and every parameter gradient within 2e-6 of their scale (the parity bar is 1e-4), with drop-edge
+    and the row-sparse top pass."""
+    from shadow_gnn_amd import ops_gat
+    res = []
+    for on in (False, True):
+        prev = ops_gat.FUSED_FWD_TAIL
+        ops_gat.FUSED_FWD_TAIL = on
+        c0 = ops_gat._GatTail.fused_tail_calls
+        try:
+            res.append(_sage_stack_step(n_layers, 256, p_drop, 29, chain=True, fused=True, B=96, act=act, sparse_top=sparse_top, dropedge=dropedge,
+                                        aggr="gat", heads=heads))
+        finally:
+            ops_gat.FUSED_FWD_TAIL = prev
+        assert ops_gat._GatTail.fused_tail_calls - c0 == (n_layers if on else 0)
+    (l0, p0, g0, _c0), (l1, p1, g1, _c1) = res
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0))
+    assert float((p1 - p0).abs().max()) <= 2e-6 * float(p0.abs().max()) + 1e-7
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 5e-6 * scale + 1e-9, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,heads,act", [(256, 4, "elu"), (64, 2, "relu"), (32, 8, "relu")])
+def test_gat_aggregate_one_edge_walk_backward_matches_fp64_autograd_also_on_clamped_rows(F, heads, act):
+    """Round 6: the attention backward is ONE edge walk (the column walk re-forms alpha_ij from the row's score, maximum and
+    denominator and takes dN_i . hn_j against the column's own hn_j; t_i = dN_i . N_i comes from a row-wise pre-pass).  Rows whose
+    softmax denominator sits on its 1e-10 clamp -- the maximum edge dropped by the edge mask and every kept edge more than e^23
+    below it, or every edge dropped -- differentiate differently: the clamp is a constant there and the subtracted row maximum hands
+    -t_i to its arg-max edge (a dropped one included), as the reference's autograd does through torch_scatter's max.
+    The aggregate and all three gradients against an fp64 torch-autograd restatement of shaDow/layers.py:560-582 (maximum,
+    clamp and all)."""
+    from shadow_gnn_amd import ops, ops_gat
+    rng = np.random.default_rng(F + heads)
+    n, D = 700, F // heads
+    deg = rng.integers(0, 9, n); deg[:5] = 0                                # (some rows without edges)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n, d, replace=False)) for d in deg] + [np.zeros(0, np.int64)]).astype(np.int64)
+    E = int(indptr[-1])
+    hub = 3                                                               # a column whose neighbour score towers over the others
+    rows_with_hub = [r for r in range(n) if hub in indices[indptr[r]:indptr[r + 1]]]
+    for r in range(10, 60):                                                # make sure enough rows see it
+        if deg[r] > 0 and r not in rows_with_hub:
+            indices[indptr[r]] = hub if hub not in indices[indptr[r]:indptr[r + 1]] else indices[indptr[r]]
+            indices[indptr[r]:indptr[r + 1]] = np.sort(indices[indptr[r]:indptr[r + 1]])
+    w = (rng.random(E) > 0.15).astype(np.float32)
+    w[indices == hub] = 0.0                                                # the towering edge is always dropped
+    for r in range(60, 70):                                                # ... and rows with every edge dropped
+        w[indptr[r]:indptr[r + 1]] = 0.0
+    torch.manual_seed(F)
+    zs, zn = torch.randn(n, F), torch.randn(n, F)
+    att = 0.3 * torch.randn(2, heads, D)
+    att[1, :, 0] = att[1, :, 0].abs() + 0.1                                # (every head has a positive neighbour weight)
+    # the hub's neighbour score is ~32 in every head: e^-30 = 1e-13 for the edges next to it -- below the 1e-10 clamp, far above fp32 underflow
+    pos = att[1].clamp(min=0.0)
+    zn[hub] = ((32.0 / pos.sum(dim=1, keepdim=True)) * (att[1] > 0)).reshape(-1) - 0.5 * (att[1] <= 0).reshape(-1).float()
+    G = torch.randn(n, F)
+    csr = _csr(indptr, indices)
+    adj = ops.NormAdj(csr, edge_w=torch.tensor(w).to(DEV))
+    a_, b_, c_ = zs.to(DEV).requires_grad_(True), zn.to(DEV).requires_grad_(True), att.to(DEV).requires_grad_(True)
+    out = ops_gat.gat_aggregate(adj, a_, b_, c_, act, heads)
+    (out * G.to(DEV)).sum().backward()
+    # fp64 restatement
+    actf = {"elu": torch.nn.functional.elu, "relu": torch.relu}[act]
+    zs64, zn64, at64 = (t.double().requires_grad_(True) for t in (zs, zn, att))
+    hs, hn = actf(zs64).view(n, heads, D), actf(zn64).view(n, heads, D)
+    us, un = (hs * at64[0]).sum(-1), (hn * at64[1]).sum(-1)
+    row = torch.repeat_interleave(torch.arange(n), torch.tensor(deg)); col = torch.tensor(indices)
+    lre = torch.nn.functional.leaky_relu
+    e = lre(us, 0.2)[row] + lre(un, 0.2)[col]
+    # (the row maximum is NOT detached: on a clamped row its gradient -- torch_scatter's max hands it to the arg-max edge -- no longer cancels)
+    mx = torch.full((n, heads), -float("inf"), dtype=torch.float64).scatter_reduce(0, row[:, None].expand(-1, heads), e, "amax", include_self=True)
+    mx = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
+    pe = torch.exp(e - mx[row]) * torch.tensor(w).double()[:, None]
+    den = torch.zeros(n, heads, dtype=torch.float64).index_add(0, row, pe).clamp(min=1e-10)
+    ref = torch.zeros(n, heads, D, dtype=torch.float64).index_add(0, row, pe[:, :, None] * hn[col]) / den[:, :, None]
+    ref = ref.reshape(n, F)
+    (ref * G.double()).sum().backward()
+    clamped = (den.detach() <= 1e-10).any(dim=1)
+    assert int(clamped.sum()) >= 20 and int((~clamped).sum()) >= 400            # both kinds of rows are there
+    # no gradient through u_s on ANY row (the row's weights do not change when all its scores move together): the kernels write
+    # exact zeros where autograd leaves rounding noise
+    assert float(zs64.grad.abs().max()) < 1e-12 * float(zn64.grad.abs().max()) and float(a_.grad.abs().max()) == 0.0
+    assert float(at64.grad[0].abs().max()) < 1e-12 * float(at64.grad[1].abs().max()) and float(c_.grad[0].abs().max()) == 0.0
+    # ... while the clamped rows' -t reaches the hub's neighbour score through the arg-max: a large part of its gradient
+    assert float(zn64.grad[hub].abs().max()) > 0
+
+    def close(got, want, name):
+        want = want.float()
+        scale = float(want.abs().max()) + 1e-30
+        err = float((got.cpu() - want).abs().max())
+        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)
+    close(out.detach(), ref.detach(), "aggregate")
+    close(b_.grad, zn64.grad, "dz_neigh"); close(c_.grad[1], at64.grad[1], "dattention[1]")
+    close(b_.grad[hub], zn64.grad[hub], "dz_neigh[hub]")
 
 
 @pytest.mark.gpu
