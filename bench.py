@@ -540,7 +540,7 @@ def main():
             tfile = json.load(open(tpath))
         except Exception:
             tfile = {}
-    tsrc = tfile.get("_source") if isinstance(tfile.get("_source"), str) else None
+    tsrc = (tfile.get("_sources") or {}).get(args.workload) or (tfile.get("_source") if isinstance(tfile.get("_source"), str) else None)
     traffic_of = lambda k: tfile.get(args.workload, {}).get(k)
 
     def hbm_entry(k):

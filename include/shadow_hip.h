@@ -409,8 +409,10 @@ int sl_gemm_pack_b2(const float *d_B1, int64_t s1j, int64_t s1k, uint32_t K1, co
  * d_Z / ldz / d_bias / act are HOST arrays of nb entries (d_bias or its entries
  * may be NULL); scale / offset are [nb, F].
  * drop_p > 0 fuses the dropout the NEXT layer applies to its input (nn.Dropout at layers.py:430,471,601)
- * into this output: element (row r, column c) is kept iff
- *   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= drop_p * 2^32      (32-bit wrap-around),
+ * into this output: element (row r, column c) is kept iff the 16-bit field (c odd: the high half, c even: the low half) of
+ *   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + (c >> 1) * 0x9E3779B1)                (32-bit wrap-around)
+ * is >= clamp(floor(drop_p * 65536), 1, 65535)   (ABI 23; before: one hash per element against drop_p * 2^32 -- the hash's
+ * quarter-rate multiplies were 7 % of the forward GEMM-epilogue launch);
  * mix32 = the murmur3 finaliser (h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16);
  * kept values are scaled by 1 / (1 - drop_p); the backward entry regenerates the same mask from
  * (drop_p, drop_seed), no mask tensor exists.  Vector layout only (F % 4 == 0, F <= 256, 16-byte aligned operands).

@@ -123,12 +123,29 @@ __device__ __forceinline__ float group_max(float v) {
 }
 __device__ __forceinline__ float amax4(const float4 &v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
-// keep-mask (bit k: component k of the float4 at column f of row r) of the fused dropout: element (r, c) is kept iff
-//   mix32(mix32(r_lo ^ seed_lo) + r_hi + seed_hi + c * 0x9E3779B1) >= thr
-__device__ __forceinline__ uint32_t drop_keep4_raw(uint32_t seed_lo, uint32_t seed_hi, uint32_t thr, uint64_t r, uint32_t f) {
-  const uint32_t base = mix32((uint32_t)r ^ seed_lo) + (uint32_t)(r >> 32) + seed_hi + f * 0x9E3779B1u;
-  return (mix32(base) >= thr ? 1u : 0u) | (mix32(base + 0x9E3779B1u) >= thr ? 2u : 0u) |
-         (mix32(base + 2u * 0x9E3779B1u) >= thr ? 4u : 0u) | (mix32(base + 3u * 0x9E3779B1u) >= thr ? 8u : 0u);
+// The fused dropout's mask rule (round 6: one murmur finaliser per TWO elements -- its two 32-bit multiplies run at quarter rate
+// and the epilogues that carry the mask are bound by instruction issue; rounds 1 - 5 spent one finaliser per element).  Element
+// (r, c) is kept iff the 16-bit field (c odd: high, c even: low) of
+//   mix32(rowhash(r) + (c >> 1) * 0x9E3779B1),   rowhash(r) = mix32(r_lo ^ seed_lo) + r_hi + seed_hi          (32-bit wrap-around)
+// is >= thr16 = clamp(floor(p * 65536), 1, 65535); kept values are scaled by 1 / (1 - p).  (The keep probability is
+// 1 - thr16 / 65536: within 1.6e-5 of 1 - p.)  Restated in torch by ops.dropout_keep_mask.
+__device__ __forceinline__ uint32_t drop_row_hash(uint32_t seed_lo, uint32_t seed_hi, uint64_t r) {
+  return mix32((uint32_t)r ^ seed_lo) + (uint32_t)(r >> 32) + seed_hi;
+}
+// keep-mask (bit k: component k) of the float4 at column f (f % 4 == 0) of a row with hash `rowh`
+__device__ __forceinline__ uint32_t drop_keep4_h(uint32_t rowh, uint32_t thr16, uint32_t f) {
+  const uint32_t base = rowh + (f >> 1) * 0x9E3779B1u;
+  const uint32_t h0 = mix32(base), h1 = mix32(base + 0x9E3779B1u);
+  return ((h0 & 0xFFFFu) >= thr16 ? 1u : 0u) | ((h0 >> 16) >= thr16 ? 2u : 0u) | ((h1 & 0xFFFFu) >= thr16 ? 4u : 0u) |
+         ((h1 >> 16) >= thr16 ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t drop_keep4_raw(uint32_t seed_lo, uint32_t seed_hi, uint32_t thr16, uint64_t r, uint32_t f) {
+  return drop_keep4_h(drop_row_hash(seed_lo, seed_hi, r), thr16, f);
+}
+// host side: the threshold of a dropout probability 0 < p < 1
+inline uint32_t drop_threshold16(float drop_p) {
+  const double t = (double)drop_p * 65536.0;
+  return (uint32_t)(t < 1.0 ? 1.0 : (t > 65535.0 ? 65535.0 : t));
 }
 
 }  // namespace shadow

@@ -490,19 +490,14 @@ struct BdGather {
   uint32_t zero_id;         // ids[r] >= zero_id: the row is all zeros and is not fetched (row-mapped inputs); 0xFFFFFFFF: none
 };
 
-__device__ __forceinline__ uint32_t bd_mix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return h;
-}
-
-// the four features f..f+3 of batch row r after the input dropout
+// the four features f..f+3 of batch row r after the input dropout (mask rule: actnorm_common.h)
 __device__ __forceinline__ float4 bd_drop4(const BdGather &g, float4 v, uint64_t r, uint32_t f) {
   if (!g.drop_thr) return v;
-  const uint32_t base = bd_mix32((uint32_t)r ^ g.seed_lo) + (uint32_t)(r >> 32) + g.seed_hi + f * 0x9E3779B1u;
-  v.x = bd_mix32(base) >= g.drop_thr ? v.x * g.drop_scale : 0.f;
-  v.y = bd_mix32(base + 0x9E3779B1u) >= g.drop_thr ? v.y * g.drop_scale : 0.f;
-  v.z = bd_mix32(base + 2u * 0x9E3779B1u) >= g.drop_thr ? v.z * g.drop_scale : 0.f;
-  v.w = bd_mix32(base + 3u * 0x9E3779B1u) >= g.drop_thr ? v.w * g.drop_scale : 0.f;
+  const uint32_t keep = drop_keep4_raw(g.seed_lo, g.seed_hi, g.drop_thr, r, f);
+  v.x = (keep & 1u) ? v.x * g.drop_scale : 0.f;
+  v.y = (keep & 2u) ? v.y * g.drop_scale : 0.f;
+  v.z = (keep & 4u) ? v.z * g.drop_scale : 0.f;
+  v.w = (keep & 8u) ? v.w * g.drop_scale : 0.f;
   return v;
 }
 
@@ -794,9 +789,7 @@ struct ActNormParams {
 
 // keep-mask (bit k: component k of the float4 at column f) of the fused output dropout
 __device__ __forceinline__ uint32_t drop_keep4(const ActNormParams &p, uint64_t r, uint32_t f) {
-  const uint32_t base = mix32((uint32_t)r ^ p.seed_lo) + (uint32_t)(r >> 32) + p.seed_hi + f * 0x9E3779B1u;
-  return (mix32(base) >= p.drop_thr ? 1u : 0u) | (mix32(base + 0x9E3779B1u) >= p.drop_thr ? 2u : 0u) |
-         (mix32(base + 2u * 0x9E3779B1u) >= p.drop_thr ? 4u : 0u) | (mix32(base + 3u * 0x9E3779B1u) >= p.drop_thr ? 8u : 0u);
+  return drop_keep4_raw(p.seed_lo, p.seed_hi, p.drop_thr, r, f);
 }
 
 // sum over the lanes of one segment group (LS lanes, power of two)
@@ -1251,8 +1244,7 @@ static int make_drop(BdGather *bg, float drop_p, uint64_t drop_seed, const char 
   if (!(drop_p >= 0.f && drop_p < 1.f)) return set_error(SG_ERR_INVALID, "%s: drop_p = %g", who, drop_p);
   bg->drop_scale = 1.0f; bg->seed_lo = (uint32_t)drop_seed; bg->seed_hi = (uint32_t)(drop_seed >> 32);
   if (drop_p > 0.f) {
-    const double t = (double)drop_p * 4294967296.0;
-    bg->drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+    bg->drop_thr = drop_threshold16(drop_p);
     bg->drop_scale = 1.0f / (1.0f - drop_p);
   }
   return SG_OK;
@@ -1602,8 +1594,7 @@ static int set_dropout(ActNormParams &p, float drop_p, uint64_t drop_seed, const
   p.drop_thr = 0; p.drop_scale = 1.0f; p.seed_lo = (uint32_t)drop_seed; p.seed_hi = (uint32_t)(drop_seed >> 32);
   if (drop_p <= 0.f) return SG_OK;
   if (!(drop_p < 1.f)) return set_error(SG_ERR_INVALID, "%s: dropout probability %g", who, drop_p);
-  const double t = (double)drop_p * 4294967296.0;
-  p.drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+  p.drop_thr = drop_threshold16(drop_p);
   p.drop_scale = 1.0f / (1.0f - drop_p);
   return SG_OK;
 }

@@ -580,8 +580,7 @@ extern "C" int sl_gat_fwd_tail(const uint32_t *d_indptr, const uint32_t *d_indic
   p.drop_thr = 0; p.drop_scale = 1.0f; p.seed_lo = (uint32_t)drop_seed; p.seed_hi = (uint32_t)(drop_seed >> 32);
   if (drop_p > 0.f) {                    // (the threshold rule of sl_act_norm_fwd, aggregate.hip set_dropout)
     if (!(drop_p < 1.f)) return set_error(SG_ERR_INVALID, "sl_gat_fwd_tail: dropout probability %g", drop_p);
-    const double t = (double)drop_p * 4294967296.0;
-    p.drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+    p.drop_thr = drop_threshold16(drop_p);
     p.drop_scale = 1.0f / (1.0f - drop_p);
   }
   const uint32_t g = gat_grid(n, lpr);

@@ -97,11 +97,10 @@ struct ColParams {
   float4 bias[NBA][Q], sc[NBA][Q], of[NBA][Q];
 };
 
-// keep-factors of the fused dropout for the float4 at column c of a row whose hash base is rowh
+// keep-factors of the fused dropout for the float4 at column c of a row whose hash base is rowh (mask rule: actnorm_common.h)
 __device__ __forceinline__ float4 drop_factors(uint32_t rowh, uint32_t c, uint32_t thr, float keep_value) {
-  const uint32_t base = rowh + c * 0x9E3779B1u;
-  return make_float4(mix32(base) >= thr ? keep_value : 0.f, mix32(base + 0x9E3779B1u) >= thr ? keep_value : 0.f,
-                     mix32(base + 2u * 0x9E3779B1u) >= thr ? keep_value : 0.f, mix32(base + 3u * 0x9E3779B1u) >= thr ? keep_value : 0.f);
+  const uint32_t keep = drop_keep4_h(rowh, thr, c);
+  return make_float4((keep & 1u) ? keep_value : 0.f, (keep & 2u) ? keep_value : 0.f, (keep & 4u) ? keep_value : 0.f, (keep & 8u) ? keep_value : 0.f);
 }
 
 // One row on 32 lanes: lane j holds the float4s j, j + 32, ... of the row (columns 4 (j + 32 q) ..).
@@ -332,7 +331,7 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
       }
       if (pg + 1 < P / D) load_pass(k, row + (uint32_t)(RP * D));
       uint32_t rowh = 0;
-      if (d.drop_thr) rowh = mix32((uint32_t)row ^ d.seed_lo) + (uint32_t)(row >> 32) + d.seed_hi;
+      if (d.drop_thr) rowh = drop_row_hash(d.seed_lo, d.seed_hi, row);
       if (MODE == 0) {
 #pragma unroll
         for (int q = 0; q < Q; q++) zc[NBA - 1][q] = own[q];
@@ -698,8 +697,7 @@ int fill_dropout(FusedDesc &p, float drop_p, uint64_t drop_seed, const char *who
   p.drop_thr = 0; p.drop_scale = 1.0f; p.seed_lo = (uint32_t)drop_seed; p.seed_hi = (uint32_t)(drop_seed >> 32);
   if (drop_p <= 0.f) return SG_OK;
   if (!(drop_p < 1.f)) return set_error(SG_ERR_INVALID, "%s: dropout probability %g", who, drop_p);
-  const double t = (double)drop_p * 4294967296.0;
-  p.drop_thr = (uint32_t)std::min<double>(std::max<double>(t, 1.0), 4294967295.0);
+  p.drop_thr = drop_threshold16(drop_p);
   p.drop_scale = 1.0f / (1.0f - drop_p);
   return SG_OK;
 }

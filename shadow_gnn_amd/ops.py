@@ -525,18 +525,18 @@ def _mul32(b: torch.Tensor, a: int) -> torch.Tensor:
 
 
 def dropout_keep_mask(n: int, F: int, p: float, seed: int, device) -> torch.Tensor:
-    """The keep mask the kernels generate for (p, seed) -- the rule documented in include/shadow_hip.h,
-    restated in torch for the tests."""
+    """The keep mask the kernels generate for (p, seed) -- the rule documented in include/shadow_hip.h (csrc/actnorm_common.h),
+    restated in torch for the tests: one murmur finaliser per PAIR of columns, a 16-bit field per element."""
     M32 = 0xFFFFFFFF
     r = torch.arange(n, device=device, dtype=torch.int64).unsqueeze(1)
     c = torch.arange(F, device=device, dtype=torch.int64).unsqueeze(0)
     row = (_mix32((r & M32) ^ (seed & M32)) + (r >> 32) + ((seed >> 32) & M32)) & M32
-    h = _mix32((row + _mul32(c, 0x9E3779B1)) & M32)
-    # (the kernels take p as a C float: the threshold is that of the ROUNDED probability -- 0.4f = 0.4000000059604645 moves it by 26,
-    #  one element in 1.6e8; found by the dropout-on parity test through exactly one such element)
+    h = _mix32((row + _mul32(c >> 1, 0x9E3779B1)) & M32)
+    field = torch.where((c & 1) == 1, h >> 16, h & 0xFFFF)
+    # (the kernels take p as a C float: the threshold is that of the ROUNDED probability)
     import numpy as _np
-    thr = int(min(max(float(_np.float32(p)) * 4294967296.0, 1.0), 4294967295.0))
-    return h >= thr
+    thr = int(min(max(float(_np.float32(p)) * 65536.0, 1.0), 65535.0))
+    return field >= thr
 
 
 def _is_dual(drop) -> bool:
