@@ -611,6 +611,16 @@ int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d_a_amax, co
                         float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                         float *d_dz0_amax, const float *d_row_stats, const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row,
                         uint32_t corr_rows, void *stream);
+/* ... and with a DENSE addend d_dout_plain [M, N] (pitch lddp; may be NULL: sl_gemm_an_bwd_corr) that does NOT pass the dropout mask:
+ * the layer below is in dual-output mode (its plain output feeds a read-out -- residue / pooling, shaDow/models.py:176-185 -- its
+ * dropped output this layer), the epilogue forms  dy = G * mask / (1 - p) + d_dout_plain * out_scale  before its act + norm backward:
+ * sl_act_norm_bwd's (d_dout, d_dout_dropped) sum.  128 < N <= 256.                                                                 */
+int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
+                         int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
+                         const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz,
+                         float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                         float *d_dz0_amax, const float *d_row_stats, const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row,
+                         uint32_t corr_rows, const float *d_dout_plain, int64_t lddp, void *stream);
 
 /* Backward of a GraphSAGE layer chained with the layer below it (consecutive GraphSAGE layers where nothing but this
  * layer reads the lower layer's output -- residue 'none' + centre pooling, shaDow/layers.py:159-163): the input gradient
@@ -641,6 +651,8 @@ typedef struct {
   float *partial;                  /* sl_sage_chain_partial_floats(n, F) floats */
   float *amax;                     /* [n]: receives max_k |dZs[i, k]| (the lower layer's call passes it as d_dzs_amax) */
   const float *stats;              /* [n, 4] row statistics its forward pass left (sl_sage_fwd d_row_stats), or NULL */
+  const float *dout_plain;         /* (ABI 23) dual-output layer below: the gradient of its PLAIN output, [n, F] dense, added unmasked
+                                      before its act + norm backward (sl_gemm_an_bwd_plain); NULL: a single-output layer */
 } sl_sage_below;
 size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F);
 int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,

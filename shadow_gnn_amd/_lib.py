@@ -58,7 +58,7 @@ class SlSageBelow(C.Structure):
         ("Zs", C.c_void_p), ("Zn", C.c_void_p), ("bs", C.c_void_p), ("bn", C.c_void_p), ("scale", C.c_void_p),
         ("offset", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("F", C.c_uint32),
         ("buf", C.c_void_p), ("dscale", C.c_void_p), ("doffset", C.c_void_p), ("dbias", C.c_void_p), ("partial", C.c_void_p),
-        ("amax", C.c_void_p), ("stats", C.c_void_p),
+        ("amax", C.c_void_p), ("stats", C.c_void_p), ("dout_plain", C.c_void_p),
     ]
 
 
@@ -205,6 +205,9 @@ SIGNATURES = {
     "sl_gemm_an_bwd_corr": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
                                   C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, C.c_uint32, _P]),
+    "sl_gemm_an_bwd_plain": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
+                                  C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
+                                  C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, C.c_uint32, _P, C.c_int64, _P]),
     "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),

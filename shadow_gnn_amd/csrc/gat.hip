@@ -211,23 +211,13 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
     acc.x += alpha * v[j].x; acc.y += alpha * v[j].y; acc.z += alpha * v[j].z; acc.w += alpha * v[j].w;
   }
 }
-// group sizes tried before the single-edge tail: bit masks of {8, 4, 2} per kernel (scripts/ab_gat_group.sh; same box, products
+// group sizes tried before the single-edge tail: bit masks of {8, 4, 2} per kernel (round 3, on the round-3 kernels; same box, products
 // depth-3 GAT batches, gat_fwd / gat_bwd per launch and the step: one by one 641 / 1279 us, 13.73 ms; one mask for all three
 // kernels {4} 505 / 1222, {4, 2} 481 / 1164, {2} 549 / 1101, {8, 4} 614 / 1241; forward {4, 2} with backward row / column
 // {2} / {2} 1128 us, 12.52 ms; {4} / {2} 1106, 12.43; {2} / {4, 2} 1237; one by one / {2} 1233 -- the forward kernel takes the
 // deeper groups, the backward kernels lose their occupancy to them)
-#ifndef SHADOW_GAT_GROUPS_FWD
-#define SHADOW_GAT_GROUPS_FWD 6
-#endif
-#ifndef SHADOW_GAT_GROUPS_COL
-#define SHADOW_GAT_GROUPS_COL 2
-#endif
-#ifndef SHADOW_GAT_TAIL_ZS_EARLY
-#define SHADOW_GAT_TAIL_ZS_EARLY 0
-#endif
-#ifndef SHADOW_GAT_ROW_PREFETCH
-#define SHADOW_GAT_ROW_PREFETCH 1      // the next row's pointers / score / gradient rows are loaded while this row's edges are walked
-#endif
+#define SHADOW_GAT_GROUPS_FWD 6      // groups of 4, then 2, then single edges
+#define SHADOW_GAT_GROUPS_COL 2      // groups of 2, then single edges
 #define SHD_GAT_EDGES(MASK, q, b, CALL)                          \
   do {                                                           \
     if ((MASK) & 8) for (; q + 8 <= b; q += 8) { CALL(8); }      \
@@ -249,16 +239,12 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
   float nus = 0.f;
   if (rw_.r < rw_.end) { na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1]; nus = p.u_s[rw_.r * H + h]; }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
-#if !SHADOW_GAT_ROW_PREFETCH
-    na = p.indptr[r]; nb = p.indptr[r + 1]; nus = p.u_s[r * H + h];
-#endif
     const uint32_t a = na, b = nb;
     const float as = lrelu02(nus);
-    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * H + h]; }
-    // (tail: the row's own z_self slice.  Asked for before the edge walk it is four more registers live through it -- 75 VGPRs,
-    //  six wavefronts per SIMD; asked for after it 71 / seven, the latency covered by the other wavefronts)
+    if (r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * H + h]; }
+    // (tail: the row's own z_self slice is asked for AFTER the edge walk: before it, it is four more registers live through the walk --
+    //  75 VGPRs, six wavefronts per SIMD, 437 us per launch against 360 with 71 / seven; docs/measurements/r06.md)
     float4 zs = make_float4(0, 0, 0, 0);
-    if (SHADOW_GAT_TAIL_ZS_EARLY && TAIL && on) zs = ld4s(p.z_self + r * F + f);
     float mx = -INFINITY;
     uint32_t q = a;
     float den = 0.f;
@@ -275,7 +261,7 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
       if ((l % ls) == 0) { p.mx[r * H + h] = mx; p.den[r * H + h] = den; }
     }
     if (TAIL) {
-      if (!SHADOW_GAT_TAIL_ZS_EARLY && on) zs = ld4s(p.z_self + r * F + f);
+      if (on) zs = ld4s(p.z_self + r * F + f);
       // out = out_scale * (norm_0(N) + norm_1(act(z_self))), each over the head slice (shaDow/layers.py:329-338,620-625): the
       // arithmetic of act_norm_kernel<.., false, 2> (aggregate.hip), statement for statement.  NOT bit for bit the separate pass:
       // hipcc contracts multiply-add pairs differently from one instantiation to the next (this kernel's edge walk uses packed
@@ -343,13 +329,9 @@ __global__ void gat_t_kernel(GatParams p) {
 // So the attention's share of dz_self and datt[0] are zero and z_self is not read at all by the backward pass (rounds 5 / 6 walked
 // the clamped rows' edges row-wise and kept a sum there that the reference's graph does not have).
 // backward, column side (transposed CSR): alpha, de, d hn, du_n, dz_neigh, datt[1]
-#ifndef SHADOW_GAT_COL_BWD_WAVES     // (a register cap for more resident wavefronts, scripts/micro)
-#define SHADOW_GAT_COL_BWD_ATTR
-#else
-#define SHADOW_GAT_COL_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SHADOW_GAT_COL_BWD_WAVES, 8)))
-#endif
+// (register caps -- amdgpu_waves_per_eu(6 / 7) -- measured and dropped: 578 us against 503 at the 87 VGPRs / 5 wavefronts hipcc picks)
 template <int LPR, class C>
-__global__ void SHADOW_GAT_COL_BWD_ATTR gat_col_bwd_kernel(GatParams p) {
+__global__ void gat_col_bwd_kernel(GatParams p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const uint32_t f = l * 4, ls = C::LS > 0 ? (uint32_t)C::LS : p.D / 4;
   const uint32_t F = cfg_F<C>(p), H = cfg_H<C>(p);
@@ -361,11 +343,8 @@ __global__ void SHADOW_GAT_COL_BWD_ATTR gat_col_bwd_kernel(GatParams p) {
   uint32_t na = 0, nb = 0;                              // (next row's pointers ahead: see gat_row_fwd_kernel)
   if (rw_.r < rw_.end) { na = p.t_indptr[rw_.r]; nb = p.t_indptr[rw_.r + 1]; }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
-#if !SHADOW_GAT_ROW_PREFETCH
-    na = p.t_indptr[r]; nb = p.t_indptr[r + 1];
-#endif
     const uint32_t a = na, b = nb;
-    if (SHADOW_GAT_ROW_PREFETCH && r + rw_.step < rw_.end) { na = p.t_indptr[r + rw_.step]; nb = p.t_indptr[r + rw_.step + 1]; }
+    if (r + rw_.step < rw_.end) { na = p.t_indptr[r + rw_.step]; nb = p.t_indptr[r + rw_.step + 1]; }
     // the column's own hn_j and score (every edge's dN_i . hn_j and alpha_ij need them)
     float4 z = make_float4(0, 0, 0, 0), hn = z;
     if (on) {

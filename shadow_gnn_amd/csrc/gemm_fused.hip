@@ -71,6 +71,11 @@ struct FusedDesc {
   // are non-zero on a few rows only, computed on those rows by the caller)
   const float *corr; int64_t ldcorr;
   const uint32_t *corr_row; uint32_t corr_rows;
+  // backward, MODE -1: a DENSE addend of the lower layer's output gradient that does NOT pass the dropout mask -- the layer
+  // below is in dual-output mode (its plain output feeds a read-out, its dropped output the layer above): the epilogue forms
+  //   dy = G * mask / (1 - p)  +  dplain * out_scale        (G: this product = the gradient of the dropped output)
+  // before the act + norm backward; what sl_act_norm_bwd does with (d_dout, d_dout_dropped)
+  const float *dplain; int64_t lddplain;
   // MODE 2, optional: the GAT layer's per-node terms from the paired Linear's own tiles (sl_gemm_nt2_gat_f32).  For product b with
   // gat_u[b] set: u[row, h] = sum over head h's D columns of gat_att[b][col] * act(C[row, col]) -- shaDow/layers.py:566-569 -- and,
   // with gat_store_act[b], the tile leaves as act(C) (hn = act(z_neigh): the pre-activation is never written).  N == 32 TW == H D.
@@ -215,7 +220,8 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
   constexpr int SP = 32 * TW;                               // row pitch of the stash (floats)
   // forward: a row on 32 lanes (two rows per pass, Q = TW / 4 float4s per lane); backward: one float4 per lane (a 256-wide
   // row on the whole wavefront) -- its 5 Q column accumulators have to fit beside the waiting half of the tile
-  constexpr int LPR = (MODE == 1 && TW == 8) ? 64 : 32;
+  constexpr bool kBwd = MODE == 1 || MODE == -1, kPlain = MODE == -1;
+  constexpr int LPR = (kBwd && TW == 8) ? 64 : 32;
   constexpr int RP = 64 / LPR;                              // rows per pass
   constexpr int Q = 8 * TW / LPR;                           // float4s per lane
   constexpr int kThreads = 256;
@@ -275,10 +281,15 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
     float4 zpre[D][NG > 0 ? NG : 1][Q];
     float spre[D][2 * NBA];                                 // (backward with kStats: the row's saved statistics, same look-ahead)
     uint32_t cpre[D];                                       // (backward with a sparse addend: its row of corr, or >= corr_rows)
+    float4 ppre[D][kPlain ? Q : 1];                         // (backward with a dense plain addend: its row, same look-ahead)
     auto load_pass = [&](int slot, uint64_t row) {
       const uint64_t rr = min(row, (uint64_t)M - 1);
-      if (MODE == 1) cpre[slot] = d.corr ? d.corr_row[rr] : 0xFFFFFFFFu;
-      if (MODE == 1 && kStats) {
+      if (kBwd) cpre[slot] = d.corr ? d.corr_row[rr] : 0xFFFFFFFFu;
+      if (kPlain) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) ppre[slot][q] = ld4s(d.dplain + rr * d.lddplain + (on[q] ? 4 * (j + LPR * q) : 0u));
+      }
+      if (kBwd && kStats) {
         if (NBA == 2) {                                   // (one 16-byte load, the same address in every lane of the row)
           const float4 sv = ld4(d.stats_r + rr * 4);
           spre[slot][0] = sv.x; spre[slot][1] = sv.y; spre[slot][2 * NBA - 2] = sv.z; spre[slot][2 * NBA - 1] = sv.w;
@@ -316,8 +327,13 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
         for (int q = 0; q < Q; q++) zc[b][q] = zpre[k][b][q];
       float stc[2 * NBA];
 #pragma unroll
-      for (int kk = 0; kk < 2 * NBA; kk++) stc[kk] = (MODE == 1 && kStats) ? spre[k][kk] : 0.f;
-      if (MODE == 1) {
+      for (int kk = 0; kk < 2 * NBA; kk++) stc[kk] = (kBwd && kStats) ? spre[k][kk] : 0.f;
+      float4 pl[kPlain ? Q : 1];
+      if (kPlain) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) pl[q] = ppre[k][q];
+      }
+      if (kBwd) {
         const uint32_t ci = cpre[k];
         if (ci < d.corr_rows) {                             // (one row in fourteen: the rows the sparse addend reaches)
 #pragma unroll
@@ -369,6 +385,9 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
           if (d.drop_thr) dm = drop_factors(rowh, 4 * (j + LPR * q), d.drop_thr, d.out_scale * d.drop_scale);
           if (!(row_ok && on[q])) dm = f4zero();
           dy[q] = make_float4(own[q].x * dm.x, own[q].y * dm.y, own[q].z * dm.z, own[q].w * dm.w);
+          if (kPlain && row_ok && on[q]) {          // (the plain output's gradient: no mask, sl_act_norm_bwd's dual-mode sum)
+            dy[q].x += pl[q].x * d.out_scale; dy[q].y += pl[q].y * d.out_scale; dy[q].z += pl[q].z * d.out_scale; dy[q].w += pl[q].w * d.out_scale;
+          }
         }
         if (!row_ok) {                                     // (a clamped row's Z must not reach the column sums either)
 #pragma unroll
@@ -393,12 +412,12 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
 #define SHADOW_EPI_DEPTH2_FWD 1
 #endif
   constexpr int P_ = 16 / RP;
-  constexpr int D0 = MODE == 1 ? SHADOW_EPI_DEPTH_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH_FWD : 2);
-  constexpr int D1w = MODE == 1 ? SHADOW_EPI_DEPTH2_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH2_FWD : 2);
+  constexpr int D0 = kBwd ? SHADOW_EPI_DEPTH_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH_FWD : 2);
+  constexpr int D1w = kBwd ? SHADOW_EPI_DEPTH2_BWD : ((NBA == 2 && TW == 8) ? SHADOW_EPI_DEPTH2_FWD : 2);
   constexpr int D1 = D1w > P_ ? P_ : D1w;
   half(std::integral_constant<int, 0>{}, std::integral_constant<int, D0>{});
   half(std::integral_constant<int, 1>{}, std::integral_constant<int, D1>{});
-  if (MODE == 1) {
+  if (kBwd) {
     // per-workgroup partial sums of the parameter gradients: RP row slots x 4 wavefronts column-sum rows in LDS, added
     // in a fixed order and left for act_norm_finish_kernel (deterministic)
     float *red = reinterpret_cast<float *>(gsm);            // [4 RP][1 + 2 NBA][SP]
@@ -682,10 +701,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_fused_kernel(const FusedDesc d
   //      copy (activation looked up per element, column predicates)
   unscale_tile<TW>(acc, 1.0f / asc, d.btrail[NBP - 1] + 32 * TW, g, r);
   const bool full = d.N == 32 * TW, same = NBA == 1 || d.act[1] == d.act[0];
-  if (MODE == 1 && d.stats_r && full && same && (d.act[0] == 1 || d.act[0] == 2)) {
+  if ((MODE == 1 || MODE == -1) && d.stats_r && full && same && (d.act[0] == 1 || d.act[0] == 2)) {
     // (the row statistics saved by the forward epilogue: the specialised copies only -- what the benchmark's layers run)
-    if (d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true, MODE == 1>(d, acc, gsm, m0);
-    else fused_epilogue<TW, MODE, NBA, 2, true, MODE == 1>(d, acc, gsm, m0);
+    if (d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true, MODE == 1 || MODE == -1>(d, acc, gsm, m0);
+    else fused_epilogue<TW, MODE, NBA, 2, true, MODE == 1 || MODE == -1>(d, acc, gsm, m0);
   }
   else if (full && same && d.act[0] == 1) fused_epilogue<TW, MODE, NBA, 1, true>(d, acc, gsm, m0);
   else if (full && same && d.act[0] == 2) fused_epilogue<TW, MODE, NBA, 2, true>(d, acc, gsm, m0);
@@ -931,6 +950,23 @@ extern "C" int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d
                                    const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
                                    float drop_p, uint64_t drop_seed, float *d_dz0_amax, const float *d_row_stats,
                                    const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row, uint32_t corr_rows, void *stream) {
+  return sl_gemm_an_bwd_plain(d_A, lda, d_a_amax, d_packed_B, M, N, K, nb, d_Z, ldz, d_bias, act, d_scale, d_offset, out_scale, d_dZ, lddz,
+                              d_dscale, d_doffset, d_dbias, d_partial, drop_p, drop_seed, d_dz0_amax, d_row_stats, d_corr, ldcorr, d_corr_row,
+                              corr_rows, nullptr, 0, stream);
+}
+
+// ... and with a DENSE addend d_dout_plain [M, N] (pitch lddp) that does not pass the dropout mask: the layer below is in
+// dual-output mode (FusedDesc::dplain).  N == 256 only (the benchmark width's instantiation).
+extern "C" int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N,
+                                    uint32_t K, int nb,
+                                    const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
+                                    const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ,
+                                    const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
+                                    float drop_p, uint64_t drop_seed, float *d_dz0_amax, const float *d_row_stats,
+                                    const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row, uint32_t corr_rows,
+                                    const float *d_dout_plain, int64_t lddp, void *stream) {
+  if (d_dout_plain && (N <= 128 || (lddp & 3) || !al16(d_dout_plain) || lddp < (int64_t)N))
+    return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd_plain: the dense addend needs 128 < N <= 256, ld %% 4 == 0 >= N and 16-byte alignment");
   if (d_corr && (!d_corr_row || (ldcorr & 3) || !al16(d_corr) || ldcorr < (int64_t)N))
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd_corr: the sparse addend needs its row map, ld %% 4 == 0 >= N and 16-byte alignment");
   if (nb != 2) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd: nb must be 2 (a GraphSAGE layer below)");
@@ -964,9 +1000,10 @@ extern "C" int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d
   p.partial = d_partial; p.dz_amax = d_dz0_amax;
   p.stats_r = d_row_stats;
   p.corr = d_corr; p.ldcorr = ldcorr; p.corr_row = d_corr_row; p.corr_rows = d_corr ? corr_rows : 0;
+  p.dplain = d_dout_plain; p.lddplain = lddp;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_an_bwd")) != SG_OK) return rc;
-  rc = N <= 128 ? launch_fused<4, 1, 1, 2>(p, st) : launch_fused<8, 1, 1, 2>(p, st);
+  rc = d_dout_plain ? launch_fused<8, -1, 1, 2>(p, st) : (N <= 128 ? launch_fused<4, 1, 1, 2>(p, st) : launch_fused<8, 1, 1, 2>(p, st));
   if (rc != SG_OK) return rc;
   return act_norm_finish_launch(d_partial, (M + 127) / 128, nb, N, d_dscale, d_doffset, d_dbias, st);
 }

@@ -292,10 +292,15 @@ class DeepGNN(nn.Module):
         layers_i = list(self.conv_layers[i])
         rp = self.res_pool_layers[i]
         fuse_ok = self.training and self.fuse_dropout
-        dual = not (rp.type_res == 'none' and rp.type_pool == 'center')
+        # the read-out takes the roots' rows of the LAST layer only (row-sparse gradient hand-overs apply) ...
+        center_only = rp.type_res == 'none' and rp.type_pool == 'center'
+        # ... or also reads the plain output of every lower layer (residue concat / max / ...): those layers then have two readers.
+        # (Residue 'none' with a pooled read-out reads every row of the last layer but nothing of the layers below: they stay
+        #  single-output and chain like under centre pooling -- round 6; rounds 1 - 5 ran them dual with an unread plain copy.)
+        dual = rp.type_res != 'none'
         # (the plan only depends on these: nn.Module attribute writes cost ~2.5 us each, 25 of them per step otherwise)
         # (layer identities and the task are part of it: a swapped conv layer or a changed read-out re-plans)
-        key = (fuse_ok, dual, self.prediction_task, tuple((id(md), float(getattr(md, 'dropout', 0.0))) for md in layers_i))
+        key = (fuse_ok, dual, center_only, ops.CHAIN_DUAL, self.prediction_task, tuple((id(md), float(getattr(md, 'dropout', 0.0))) for md in layers_i))
         plans = self.__dict__.setdefault('_fusion_plan_keys', {})
         if plans.get(i) == key:
             return
@@ -310,14 +315,16 @@ class DeepGNN(nn.Module):
             md.out_dual = bool(fuse and dual)
             # nothing but the next layer reads this output (the read-out takes the last layer only): consecutive GraphSAGE
             # nodes may chain their backward passes (ops.ChainLink)
-            md.chain_next = bool(not dual and isinstance(md, layers.GraphSAGE) and isinstance(nxt, layers.GraphSAGE))
+            # (dual-output layers chain too -- ops.CHAIN_DUAL -- when the read-out's pooling node hands the plain gradient over)
+            md.chain_next = bool((not dual or (ops.CHAIN_DUAL and fuse and rp.type_pool in rp.POOLED)) and isinstance(md, layers.GraphSAGE)
+                                 and isinstance(nxt, layers.GraphSAGE))
             # ... and the LAST layer's output only by the read-out's row select: its gradient travels as (rows, values)
             # (node tasks: one root per subgraph, so the selected rows are distinct)
-            md.roots_only = bool(not dual and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT))
+            md.roots_only = bool(center_only and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT))
                                  and self.prediction_task == 'node')
             # GAT below GAT, nothing else reads this output and the next layer's input dropout is fused into it (or absent): the
             # next layer may hand its input gradient down as (rows, values) -- the row-sparse top pass of ops_gat._GatTail
-            md.rows_next = bool(not dual and isinstance(md, layers.GAT) and isinstance(nxt, layers.GAT)
+            md.rows_next = bool(center_only and isinstance(md, layers.GAT) and isinstance(nxt, layers.GAT)
                                 and (fuse or float(getattr(nxt, 'dropout', 0.0)) == 0.0 or not self.training))
             if nxt is not None and hasattr(nxt, 'input_pre_dropped'):
                 nxt.input_pre_dropped = bool(fuse)
@@ -326,7 +333,7 @@ class DeepGNN(nn.Module):
         # the whole stack as one autograd node (ops._SageStack): GraphSAGE layers only, nothing but the next layer / the row select
         # reads a layer's output, and every inner input dropout is applied by the producing layer's kernel (or is the identity)
         kind = ''
-        if (not dual and self.prediction_task == 'node' and rp.dim_in == 0 and layers_i
+        if (center_only and self.prediction_task == 'node' and rp.dim_in == 0 and layers_i
                 and all((not self.training) or md.dropout <= 0 or md.input_pre_dropped for md in layers_i[1:])):
             if all(type(md) is layers.GraphSAGE for md in layers_i) and ops.sage_stack_usable(layers_i):
                 kind = 'sage'

@@ -1124,6 +1124,10 @@ class ChainLink:
         self.stats = None            # [n, 4] (mean, 1 / std) per row and branch, left by the forward GEMM epilogue (or None)
         self.rows = None             # int32 row ids outside which the dZ in ``buf`` is zero (left by a row-sparse top pass), or None
         self.compact = None          # (dZs[T] [t, F], dZn[T] with a zero row behind [t + 1, F], plan): dZ on the rows T only, no ``buf``
+        # dual-output lower layer (round 6): its PLAIN output feeds a read-out (ops.pool_and_roots), whose backward leaves the dense
+        # gradient here -- autograd carries ``plain_dummy`` -- for the layer above's epilogue to add unmasked (sl_gemm_an_bwd_plain)
+        self.dual = False
+        self.plain_grad = self.plain_dummy = None
 
     def publish(self, Zs, Zn, biases, sc, of, act, drop, stats=None):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
@@ -1134,6 +1138,14 @@ class ChainLink:
         self.published = self.filled = False
         self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = self.rows = self.compact = None
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
+        self.plain_grad = self.plain_dummy = None
+
+
+# Dual-output GraphSAGE layers (a read-out that reads every layer: residue max / concat, mean / max pooling) chain their backward
+# passes too: the lower layer's act + norm backward rides in the upper layer's input-gradient product, the plain output's gradient
+# -- handed over by the read-out's pooling node -- added in the epilogue (round 6; False: every dual layer runs its own
+# stand-alone act + norm backward, the round-5 path; tests compare the two)
+CHAIN_DUAL = True
 
 
 # Test tap: when a list, every fused Linear + act + norm node appends (pre-activations Z_b, biases) of its forward pass
@@ -1357,7 +1369,7 @@ class _SageDense(torch.autograd.Function):
         if AX is None:
             ctx.x_amax = get_row_amax(X)        # (the backward's weight gradients scale their fp16 pieces by it, sl_gemm_tn_f16)
             # (row statistics for the chained backward of this layer: only when a layer above will chain into it)
-            want_stats = (link_up is not None and CHAIN_SAGE_BWD and not _is_dual(drop) and ROW_STATS_HANDOVER
+            want_stats = (link_up is not None and CHAIN_SAGE_BWD and (not _is_dual(drop) or (CHAIN_DUAL and F > 128)) and ROW_STATS_HANDOVER
                           and _lib.load().sl_gemm_act_norm_supported(F, X.shape[1]) and F % 32 == 0)
             AX, Zs, Zn, out, ctx_stats = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop, want_stats)
             _SageDense.fused_calls += 1
@@ -1381,9 +1393,13 @@ class _SageDense(torch.autograd.Function):
         # (published only when THIS node's backward will take the one-call entry -- the only consumer of the dZ the layer
         # above leaves on the link: a layer-0 input wider than 256 (Flickr 500, Yelp 300) or frozen weights run kernel by
         # kernel, and the layer above must then write a real dX)
-        if (link_up is not None and one_call and CHAIN_SAGE_BWD and not _is_dual(drop) and F % 4 == 0 and 16 <= F <= 256
+        # (a dual-output layer publishes too -- CHAIN_DUAL, the 256-wide epilogue instantiation: the read-out's pooling node will
+        #  leave the plain output's gradient on the link)
+        if (link_up is not None and one_call and CHAIN_SAGE_BWD and (not _is_dual(drop) or (CHAIN_DUAL and 128 < F <= 256 and F % 32 == 0))
+                and F % 4 == 0 and 16 <= F <= 256
                 and _SageDense._bwd_fusable(ctx.needs_input_grad, one_call, X.shape[1], F, AX)):
             link_up.publish(Zs, Zn, bsc, sc, of, acts[0], drop, ctx_stats)
+            link_up.dual = _is_dual(drop)
             ctx.link_up = link_up
         ctx.set_materialize_grads(False)
         fire_deferred()
@@ -1454,7 +1470,15 @@ class _SageDense(torch.autograd.Function):
             return _SageDense._sparse_top_backward(ctx, lr0, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b)
         d0 = d1 = dout_rows = None
         if dz_ready:
-            g = dout[0] if isinstance(dout, (tuple, list)) else dout
+            if up.dual:
+                # (dual-output layer: the dropped output's gradient must be the chain's placeholder, the plain output's the one
+                #  the read-out's pooling node left -- both already inside the dZ the layer above produced)
+                gp, g = dout[0], dout[1]
+                if gp is not None and (up.plain_dummy is None or gp.data_ptr() != up.plain_dummy.data_ptr() or tuple(gp.stride()) != (0, 0)):
+                    raise RuntimeError("chained GraphSAGE backward: the lower layer's plain output has a consumer that did not hand its "
+                                       "gradient to the chain; set ops.CHAIN_DUAL = False")
+            else:
+                g = dout[0] if isinstance(dout, (tuple, list)) else dout
             if g is None or g.data_ptr() != up.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("chained GraphSAGE backward: the lower layer's output has a consumer besides the layer above "
                                    "(its gradient is not the chain's placeholder); build the model with chaining off")
@@ -1476,6 +1500,10 @@ class _SageDense(torch.autograd.Function):
                     raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
                                        "(its gradient is not the placeholder); set ops.ROOTS_SPARSE_GRAD = False")
                 dout_rows, douts = lr.rows32, (lr.grad,)
+            if (up is not None and up.dual and up.plain_grad is not None and douts[0] is not None and up.plain_dummy is not None
+                    and douts[0].data_ptr() == up.plain_dummy.data_ptr()):
+                # the pooling node left the plain gradient on the link but the layer above did not chain: it is consumed here
+                douts = (up.plain_grad,) + tuple(douts[1:])
             d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
             if _is_dual(drop):
                 d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
@@ -1488,6 +1516,11 @@ class _SageDense(torch.autograd.Function):
             buf = torch.empty(n, 3 * Fo, **f32)
             an_partial = torch.empty(2048 * 2 * 3 * Fo, **f32)
         chain = down is not None and want_dx and down.Zs.shape == (n, Fi) and Fo % 32 == 0
+        if chain and down.dual:
+            # (the plain output's gradient must be on the link by now -- the read-out's nodes run before any conv layer's -- and dense)
+            pg = down.plain_grad
+            chain = bool(CHAIN_DUAL and pg is not None and pg.shape == (n, Fi) and pg.stride(1) == 1 and pg.stride(0) == Fi
+                         and pg.data_ptr() % 16 == 0 and 128 < Fi <= 256)
         below = None
         if chain:
             down.buf = torch.empty(n, 3 * Fi, **f32)
@@ -1499,7 +1532,8 @@ class _SageDense(torch.autograd.Function):
             below = _lib.SlSageBelow(down.Zs.data_ptr(), down.Zn.data_ptr(), opt(down.biases[0]), opt(down.biases[1]),
                                      down.sc.data_ptr(), down.of.data_ptr(), down.act, float(down.drop[0]), int(down.drop[1]), Fi,
                                      down.buf.data_ptr(), down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi),
-                                     down.partial.data_ptr(), down.amax.data_ptr(), opt(down.stats))
+                                     down.partial.data_ptr(), down.amax.data_ptr(), opt(down.stats),
+                                     down.plain_grad.data_ptr() if down.dual else None)
         dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
         # dZ non-zero on a few rows only (the layer above ran its row-sparse pass): dWs = dZs[T]^T X[T], dWn = dZn[T]^T (A X)[T] on
         # those rows (21 k of 289 k) instead of the paired kernel over all of them
@@ -2001,14 +2035,16 @@ class StepPath(NamedTuple):
 
 
 def step_path(kind: str, n: int, F: int, layers: int, training: bool, readout: str, stackable: bool = True, blockdiag: bool = True,
-              heads: int = 1) -> StepPath:
+              heads: int = 1, residue: str = "none") -> StepPath:
     """THE table of the ways through a conv stack: (layer kind, batch rows n, hidden width F, layer count, training, read-out) -> path.
     models.DeepGNN._run_stack dispatches on it; tests/test_layers_gpu.py::test_step_path_table walks its cells (the entry counters
     must show the path the table names, the results must equal the kernel-by-kernel path's).
 
     ``stackable``: the stack's static preconditions hold (sage_stack_usable / gcn_stack_usable, residue 'none', node task, inner
-    input dropouts fused into the producing layer); ``readout``: 'center' = the read-out selects one row per subgraph, anything
-    else reads every row; ``blockdiag``: the batch carries its subgraph offsets (the block-diagonal aggregate).
+    input dropouts fused into the producing layer); ``readout``: the pooling -- 'center' = one row per subgraph, 'mean' / 'max' / 'sum'
+    = every row; ``residue``: 'none' = the read-out reads the LAST layer only, anything else = every layer's plain output (the lower
+    layers are then dual-output: one tensor for the read-out, the dropped one for the next layer); ``blockdiag``: the batch carries
+    its subgraph offsets (the block-diagonal aggregate).
 
       kind  rows n                       forward            backward (training)
       ----  ---------------------------  -----------------  ---------------------------------------------------------------
@@ -2019,8 +2055,12 @@ def step_path(kind: str, n: int, F: int, layers: int, training: bool, readout: s
       sage  ... fewer layers / F < 96    layer-calls        chained+sparse-top   _SageDense nodes: sl_sage_fwd per layer, ChainLink
       sage  >= 1 024, not stackable,     layer-calls        chained              sl_sage_fwd / sl_sage_bwd_chain per layer
             center
-      sage  >= 1 024, other read-outs    layer-calls        layer-calls          dual-output layers: sl_sage_fwd / sl_sage_bwd_chain
-                                                                                 without a link between the layers
+      sage  >= 1 024, residue none,      layer-calls        chained              the lower layers have ONE reader (the next layer): chained as
+            pooled read-out                                                      under centre pooling, dense gradient into the top layer
+      sage  >= 1 024, residue != none,   layer-calls        chained              dual-output layers (round 6): the plain output's gradient from
+            pooled, 128 < F <= 256                                               the pooling node is added in the chained epilogue
+      sage  >= 1 024, residue != none,   layer-calls        layer-calls          dual-output layers: sl_sage_fwd / sl_sage_bwd_chain
+            centre pooling / other F                                             without a link between the layers
       gcn   >= 1 024, stackable, center  stack              stack                sl_gcn_stack_fwd / sl_gcn_stack_bwd
       gcn   >= 1 024, not stackable      layer-calls        layer-calls          sl_gcn_fwd / sl_gcn_bwd per layer
       gat   >= 1 024, F == 256,          pair-tail          dense | rows         sl_gemm_nt2_gat_f32 + sl_gat_fwd_rows; backward
@@ -2031,7 +2071,7 @@ def step_path(kind: str, n: int, F: int, layers: int, training: bool, readout: s
     none = "none"
     if not tall:
         return StepPath("kernels", "kernels" if training else none)
-    center = readout == "center"
+    center = readout == "center" and residue == "none"
     big = bool(training and SPARSE_TOP_BWD and center and n >= SPARSE_TOP_BWD_MIN_ROWS)
     if kind == "sage":
         if stackable and center and SAGE_STACK:
@@ -2040,7 +2080,13 @@ def step_path(kind: str, n: int, F: int, layers: int, training: bool, readout: s
             return StepPath("stack", ("stack+sparse-top" if big else "stack") if training else none)
         # (a read-out that reads every row of every layer -- mean / max / sort pooling, residue concat / max -- puts the layers in
         #  dual-output mode: no ChainLink between them, every layer's own one-call backward)
-        chained = "chained" if (CHAIN_SAGE_BWD and F % 32 == 0 and center) else "layer-calls"
+        # (round 6: a lower layer is dual-output only when the read-out reads it -- residue != 'none' -- and such layers chain too
+        #  under a pooled read-out at widths in (128, 256]: CHAIN_DUAL, the plain output's gradient added in the epilogue above)
+        if residue == "none":
+            can_chain = True
+        else:
+            can_chain = bool(CHAIN_DUAL and 128 < F <= 256 and readout in ("mean", "max", "sum"))
+        chained = "chained" if (CHAIN_SAGE_BWD and F % 32 == 0 and can_chain) else "layer-calls"
         return StepPath("layer-calls", ((chained + "+sparse-top") if (big and chained == "chained") else chained) if training else none)
     if kind == "gcn":
         if stackable and center and SAGE_STACK:
@@ -2465,12 +2511,17 @@ def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Te
             X, _seed = X.gather_dropped(in_dropout)
     # chaining: a producer node left its ChainLink on the tensor it returned; ``chain_next`` asks this node to do the same
     link_down = getattr(X, "_shadow_chain", None) if torch.is_tensor(X) else None
-    link_up = ChainLink() if (chain_next and not dual and CHAIN_SAGE_BWD) else None
+    link_up = ChainLink() if (chain_next and (not dual or CHAIN_DUAL) and CHAIN_SAGE_BWD) else None
     link_roots = RootsLink() if (roots_only and not dual and not chain_next and ROOTS_SPARSE_GRAD) else None
     res = _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
                            (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout), link_down, link_up, link_roots)
     if link_up is not None and link_up.published and torch.is_tensor(res):
         res._shadow_chain = link_up
+    elif link_up is not None and link_up.published and isinstance(res, tuple):
+        # dual mode: the dropped output goes to the layer above (which finds the link on it), the plain one to the read-out
+        # (ops.pool_and_roots leaves its gradient on the link)
+        res[1]._shadow_chain = link_up
+        res[0]._shadow_plain = link_up
     if link_roots is not None and link_roots.published and torch.is_tensor(res):
         res._shadow_roots = link_roots
     return res
@@ -2558,9 +2609,10 @@ class _PoolAndRoots(torch.autograd.Function):
     calls = 0
 
     @staticmethod
-    def forward(ctx, X, node_off, rows, mode):
+    def forward(ctx, X, node_off, rows, mode, link=None):
         X = _f32c(X)
         _need_cuda(X, node_off, rows)
+        ctx.link = link
         P, F = int(node_off.numel()) - 1, int(X.shape[1])
         out = torch.empty(P, F, dtype=torch.float32, device=X.device)
         am = torch.empty(P, F, dtype=torch.int32, device=X.device) if mode == 1 else None
@@ -2590,13 +2642,20 @@ class _PoolAndRoots(torch.autograd.Function):
             dX = torch.zeros(ctx.n, F, dtype=torch.float32, device=dev)
         if droots is not None:
             dX.index_add_(0, rows, droots.to(dX.dtype))       # (the roots of a batch are distinct rows: no two adds meet)
-        return dX, None, None, None
+        link = ctx.link
+        if link is not None and link.published and link.dual and CHAIN_DUAL and link.plain_grad is None:
+            # X is the plain output of a dual-output GraphSAGE layer that chains its backward pass: the gradient stays on the link
+            # (the layer above adds it in its epilogue, or the layer itself picks it up), autograd carries a storage-less placeholder
+            link.plain_grad = dX
+            link.plain_dummy = placeholder(ctx.n, F, dev)
+            return link.plain_dummy, None, None, None, None
+        return dX, None, None, None, None
 
 
 def pool_and_roots(X: torch.Tensor, node_off: torch.Tensor, rows: torch.Tensor, mode: str):
     """(segment_pool(X, node_off, mode), X[rows]) with one dense gradient (see _PoolAndRoots)."""
     assert node_off.dtype == torch.int32 and rows.dtype == torch.int64
-    return _PoolAndRoots.apply(X, node_off, rows, POOL_MODE[mode])
+    return _PoolAndRoots.apply(X, node_off, rows, POOL_MODE[mode], getattr(X, "_shadow_plain", None))
 
 
 def segment_pool(X: torch.Tensor, node_off: torch.Tensor, mode: str) -> torch.Tensor:

@@ -707,7 +707,8 @@ def test_model_dropout_fusion_plan_and_training_step():
         losses = [float(m2.step(TRAIN, "running", batch())["loss"]) for _ in range(2)]
         assert all(np.isfinite(losses))
         L2 = list(m2.conv_layers[0])
-        assert [l.out_dropout for l in L2] == [0.3, 0.3, 0.0] and [l.out_dual for l in L2] == [True, True, False]
+        # (dual-output only where the read-out reads the layer: residue 'none' reads the last layer alone -- round 6)
+        assert [l.out_dropout for l in L2] == [0.3, 0.3, 0.0] and [l.out_dual for l in L2] == ([True, True, False] if residue != "none" else [False] * 3)
         assert [l.input_pre_dropped for l in L2] == [False, True, True] and all(l.dropped_out is None for l in L2)
         assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m2.parameters())
     # plumbing: with residue none + centre pooling the read-out ignores the plain copies, so forcing the dual
@@ -1241,7 +1242,7 @@ def test_gemm_epilogue_act_norm_forward_equals_separate_kernels(nb, M, K, N, act
 
 def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu", F0=100, freeze=(), sparse_top=None, given_plan=False,
                      dropedge=0.0, stack=None, aug=False, train=True, aggr="sage", top_stack=None, heads=1, pooling="center",
-                     split_min_rows=None, row_bound=0):
+                     split_min_rows=None, row_bound=0, residue="none"):
     """One DeepGNN.step of a GraphSAGE stack on a sampled batch (n >= 1024 rows) through the one-call layer entries;
     returns loss, predictions and every parameter gradient."""
     from shadow_gnn_amd import _lib, ops
@@ -1266,7 +1267,7 @@ def _sage_stack_step(n_layers, dim, p_drop, seed, chain, fused, B=96, act="relu"
         ops.SPARSE_TOP_BWD_MIN_ROWS = 1024          # (the production threshold is a host-time trade-off, not a correctness bound)
     try:
         arch = dict(num_layers=n_layers, num_cls_layers=1, heads=heads, dim=dim, act=act, layer_norm="norm_feat",
-                    feature_augment_ops="sum", aggr=aggr, residue="none", pooling=pooling, loss="softmax")
+                    feature_augment_ops="sum", aggr=aggr, residue=residue, pooling=pooling, loss="softmax")
         torch.manual_seed(seed)
         model = DeepGNN(F0, F0, C, 0, arch, [("hops", 7)] if aug else [], 1, dict(dropout=p_drop, dropedge=dropedge, lr=0.002), "node").to(DEV)
         with torch.no_grad():
@@ -1751,11 +1752,13 @@ def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act,
     """ BASELINE configs[2] -- PPR sampler, GraphSAGE-5 dim 256, residue max + mean pooling
     (config_train/products/vanilla/sage_5_ppr.yml per SURVEY 8(d)) -- at benchmark WIDTH through the timed call path and
     against the fp64 edge-list oracle: the batch is drawn by the HIP `ppr` method (k = 200) from a table the HIP push kernel
-    built (sg_ppr_push), ~200-row subgraphs, n >= 40 k rows.  Every layer output is read by the read-out, so the layers
-    are NOT chained: the kernel classes of that path -- the un-chained input-gradient product `gemm_nt_f16_N256`, the
-    stand-alone `act_norm_bwd_nb2_F256`, the block-diagonal SpMM over MERGED small subgraphs, `ops.pool_and_roots` -- are
-    asserted to have run; with dropout 0.4 / drop-edge 0.05 ON the forward epilogue writes the plain AND the dropped output
-    (dual mode) and the oracle applies the run's own masks (as in test_timed_configuration_...).  Bounds as for the other
+    built (sg_ppr_push), ~200-row subgraphs, n >= 40 k rows.  Every layer output is read by the read-out: without dropout nothing
+    chains (the un-chained input-gradient product `gemm_nt_f16_N256`, a stand-alone `act_norm_bwd_nb2_F256` per layer); with
+    dropout 0.4 / drop-edge 0.05 ON the forward epilogue writes the plain AND the dropped output (dual mode) and -- round 6 -- the
+    dual-output layers CHAIN: `ops.pool_and_roots` hands the plain output's gradient to the chain, the layer above adds it unmasked
+    in its epilogue (`gemm_an_bwd_nb2_N256`, sl_gemm_an_bwd_plain), one stand-alone act + norm backward is left (the top layer's).
+    The block-diagonal SpMM over MERGED small subgraphs and `ops.pool_and_roots` are asserted either way; the oracle applies the
+    run's own masks (as in test_timed_configuration_...).  Bounds as for the other
     benchmark-scale runs: loss / predictions / embeddings 1e-4, every parameter gradient entry 1e-3 relative + 1e-4 of its scale."""
     from oracle import layers_oracle as lo
     from oracle import model_oracle_sparse as mos
@@ -1826,11 +1829,19 @@ def test_ppr_mean_pool_configuration_at_benchmark_width_matches_fp64_oracle(act,
     ran = set(timer.summary())
     assert len(ro_drop) == 1
     # ---- the call path of the timed configs[2] line
-    assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (L, 0), "one-call entries, nothing chained"
+    # (round 6: with the fused dropout on, the layers are dual-output AND chained -- the pooling node of every layer hands the plain
+    #  output's gradient to the chain, the layer above adds it in its epilogue: no un-chained input-gradient product, ONE stand-alone
+    #  act_norm backward (the top layer's); without dropout a layer's single output has two consumers and nothing chains)
+    chained_want = L - 1 if p_drop > 0 else 0
+    assert (ops._SageDense.fused_calls - c0[0], ops._SageDense.chained_calls - c0[1]) == (L, chained_want), "one-call entries, dual-output layers chained"
     assert ops._PoolAndRoots.calls - c0[2] == L, "every layer output goes through ops.pool_and_roots"
-    for cls in ("gemm_act_norm_fwd_nb2_N256", "gemm_nt_f16_N256", "act_norm_bwd_nb2_F256", "spmm_F256", "segment_pool_F256", "gemm_tn_f16_pair_N256"):
+    classes = ["gemm_act_norm_fwd_nb2_N256", "act_norm_bwd_nb2_F256", "spmm_F256", "segment_pool_F256", "gemm_tn_f16_pair_N256"]
+    classes.append("gemm_an_bwd_nb2_N256" if p_drop > 0 else "gemm_nt_f16_N256")
+    for cls in classes:
         assert any(k.startswith(cls) for k in ran), (cls, sorted(ran))
-    assert not any(k.startswith("gemm_an_bwd") for k in ran), sorted(ran)
+    assert not any(k.startswith("gemm_nt_f16_N256" if p_drop > 0 else "gemm_an_bwd") for k in ran), sorted(ran)
+    if p_drop > 0:
+        assert timer.summary()["act_norm_bwd_nb2_F256"]["launches"] == 1, "only the top layer runs a stand-alone act + norm backward"
     blocks = adj.spmm_blocks
     assert blocks[0] is not adj.subg_off and int(blocks[0][1:].ne(blocks[0][:-1]).sum()) < B, "the SpMM staged merged groups of subgraphs"
     convs = list(model.conv_layers[0])
@@ -2064,6 +2075,39 @@ def test_gat_aggregate_one_edge_walk_backward_matches_fp64_autograd_also_on_clam
     close(out.detach(), ref.detach(), "aggregate")
     close(b_.grad, zn64.grad, "dz_neigh"); close(c_.grad[1], at64.grad[1], "dattention[1]")
     close(b_.grad[hub], zn64.grad[hub], "dz_neigh[hub]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,act,residue,pooling,p_drop,dropedge", [(4, "relu", "max", "mean", 0.4, 0.05), (3, "elu", "concat", "max", 0.25, 0.0),
+                                                                           (3, "relu", "none", "mean", 0.3, 0.1)])
+def test_dual_output_layers_chain_their_backward_passes(n_layers, act, residue, pooling, p_drop, dropedge):
+    """Round 6 (configs[2]): GraphSAGE layers whose plain output feeds the read-out (residue max / concat, mean / max pooling) and whose
+    dropped output feeds the next layer chain their backward passes like single-output layers do: ops.pool_and_roots leaves the plain
+    output's gradient on the chain's link, the layer above adds it -- unmasked -- in the epilogue of its input-gradient product
+    (sl_gemm_an_bwd_plain: dy = G mask / (1 - p) + dplain) and runs the lower layer's act + norm backward there.  Against the round-5
+    path (ops.CHAIN_DUAL = False: un-chained product + stand-alone sl_act_norm_bwd with (d_dout, d_dout_dropped)): the same sums in a
+    different kernel -- loss and predictions identical (the forward pass is the same), every parameter gradient within 5e-6 of its
+    scale.  Residue 'none' reads the last layer only: the lower layers have ONE reader, are not dual-output at all and chain either
+    way (round 6; rounds 1 - 5 wrote an unread plain copy for them)."""
+    from shadow_gnn_amd import ops
+    res = []
+    for on in (False, True):
+        prev = ops.CHAIN_DUAL
+        ops.CHAIN_DUAL = on
+        try:
+            res.append(_sage_stack_step(n_layers, 256, p_drop, 41, chain=True, fused=True, B=96, act=act, dropedge=dropedge, pooling=pooling,
+                                        residue=residue))
+        finally:
+            ops.CHAIN_DUAL = prev
+    (l0, p0, g0, c0), (l1, p1, g1, c1) = res
+    assert c0 == (n_layers, (n_layers - 1) if residue == "none" else 0), c0
+    assert c1 == (n_layers, n_layers - 1), c1
+    assert l0 == l1
+    torch.testing.assert_close(p1, p0, rtol=0, atol=0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 5e-6 * scale + 1e-9, k
 
 
 @pytest.mark.gpu

@@ -19,7 +19,14 @@ def test_graphsage_rows(monkeypatch):
     assert ops.step_path("sage", big, 256, 2, True, "center") == ops.StepPath("layer-calls", "chained+sparse-top")  # too few layers for the node's pass
     assert ops.step_path("sage", big, 64, 5, True, "center") == ops.StepPath("layer-calls", "chained+sparse-top")   # under the block-diagonal width
     assert ops.step_path("sage", big, 256, 5, True, "center", blockdiag=False) == ops.StepPath("layer-calls", "chained+sparse-top")
-    assert ops.step_path("sage", big, 256, 5, True, "mean") == ops.StepPath("layer-calls", "layer-calls")           # dual-output layers
+    assert ops.step_path("sage", big, 256, 5, True, "mean") == ops.StepPath("layer-calls", "chained")               # residue none: single-output lower layers
+    assert ops.step_path("sage", big, 64, 5, True, "mean") == ops.StepPath("layer-calls", "chained")
+    assert ops.step_path("sage", big, 256, 5, True, "mean", residue="max") == ops.StepPath("layer-calls", "chained")  # dual-output layers chain (round 6)
+    assert ops.step_path("sage", big, 64, 5, True, "mean", residue="max") == ops.StepPath("layer-calls", "layer-calls")   # ... at widths in (128, 256] only
+    assert ops.step_path("sage", big, 256, 5, True, "center", residue="concat") == ops.StepPath("layer-calls", "layer-calls")
+    monkeypatch.setattr(ops, "CHAIN_DUAL", False)
+    assert ops.step_path("sage", big, 256, 5, True, "mean", residue="max") == ops.StepPath("layer-calls", "layer-calls")
+    monkeypatch.setattr(ops, "CHAIN_DUAL", True)
     assert ops.step_path("sage", big, 256, 5, True, "center", stackable=False) == ops.StepPath("layer-calls", "chained+sparse-top")
     assert ops.step_path("sage", big, 256, 5, False, "center") == ops.StepPath("stack", "none")
     monkeypatch.setattr(ops, "SPARSE_TOP_BWD", False)
