@@ -444,7 +444,12 @@ class GAT(shaDowLayer):
         from . import ops_gat
         feat_in, adj, is_normed, dropedge = inputs
         adj_norm = self._adj_norm(adj, is_normed, feat_in.device, dropedge=dropedge)
-        feat_in = self.in_dropout(feat_in)
+        if isinstance(feat_in, ops.LazyRows):
+            # layer 0 of the fast path: feat_full[node] and the layer's input dropout in ONE pass (line-padded rows, row maxima for the
+            # paired Linear's operand scales) instead of gather + nn.Dropout + a row-maximum pass -- as GraphSAGE's layer 0 does
+            feat_in, _seed = feat_in.gather_dropped(self._in_p())
+        else:
+            feat_in = self.in_dropout(feat_in)
         # (one launch for both transforms; when the fused tail below is their only consumer the same launch also leaves
         #  hn = act(z_neigh) -- in z_neigh's place -- and the attention's per-node terms, ops.GatPre)
         tail_only = self.norm == 'norm_feat' and self.act is None and ops_gat.gat_tail_usable(feat_in, self.f_lin[0].weight.shape[0], self.mulhead)
