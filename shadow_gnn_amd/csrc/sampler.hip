@@ -276,6 +276,7 @@ struct sg_sampler {
   uint64_t nnz = 0;
   uint32_t *d_indptr = nullptr;
   uint32_t *d_indices = nullptr;
+  uint32_t *d_self_slot = nullptr;   // [N] where the reference inserts node v's self edge (first add_self_edge call on the flat scan builds it)
   bool owns_graph = false;
   bool graph_dropped = false;
   uint32_t *d_targets = nullptr;
@@ -535,6 +536,7 @@ extern "C" void sg_destroy(sg_sampler *s) {
   if (s->pending && s->ev) (void)hipEventSynchronize(s->ev);
   if (s->owns_graph) { if (s->d_indptr) (void)hipFree(s->d_indptr); if (s->d_indices) (void)hipFree(s->d_indices); }
   if (s->d_targets) (void)hipFree(s->d_targets);
+  if (s->d_self_slot) (void)hipFree(s->d_self_slot);
   free_ppr(s);
   if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->d_big) (void)hipFree(s->d_big);
@@ -941,7 +943,17 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
                              : plain ? (const void *)sg_scan_kernel<true> : (const void *)sg_scan_kernel<false>;
       if (SL.total > 64 * 1024)
         SHD_HIP(ensure_dynamic_lds(kfn, SL.total));
-      if (flat && p.include_self) hipLaunchKernelGGL(sg_scan_plain_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      if (flat && p.include_self) {
+        if (!s->d_self_slot) {
+          // once per handle: lower_bound == upper_bound of every node in its own row (ParallelSampler.cpp:386-400), 4 N bytes
+          hipError_t e = hipMalloc((void **)&s->d_self_slot, (size_t)s->N * 4);
+          if (e != hipSuccess) { s->d_self_slot = nullptr; return set_error(SG_ERR_HIP, "sg_sample: hipMalloc of %zu bytes for the self-edge slots failed", (size_t)s->N * 4); }
+          hipLaunchKernelGGL(sg_self_slot_kernel, dim3((s->N + 255) / 256), dim3(256), 0, stream, s->d_indptr, s->d_indices, s->N, s->d_self_slot);
+          SHD_HIP(hipGetLastError());
+        }
+        p.self_slot = s->d_self_slot;
+        hipLaunchKernelGGL(sg_scan_plain_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
+      }
       else if (flat) hipLaunchKernelGGL(sg_scan_plain_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       else if (plain) hipLaunchKernelGGL(sg_scan_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       else hipLaunchKernelGGL(sg_scan_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);

@@ -112,6 +112,10 @@ struct SampleParams {
   uint32_t *g_tables;        // [n_slots * g_stride]
   uint64_t g_stride;         // words per slot
   uint32_t *g_ticket;        // work queue head (subgraph ids)
+  // add_self_edge on the flat scan: per NODE of the full graph, the position in `indices` where the reference inserts its self
+  // edge (ParallelSampler.cpp:386-400: lower_bound == upper_bound of v in its own row), kEmpty for a node that lists itself.
+  // A property of the full graph alone: built once per sampler handle (sg_self_slot_kernel), read once per subgraph row.
+  const uint32_t *self_slot;
 };
 
 struct Tables {

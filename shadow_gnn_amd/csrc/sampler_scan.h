@@ -829,6 +829,22 @@ __device__ __forceinline__ uint4 make_run(const RowInfo ri, uint32_t row, uint32
   return make_uint4(((ri.e0 >> 2) + kq) << 2, row | ((take - 1u) << 20) | (edge << 26), ri.e0, ri.e0 + ri.deg);
 }
 
+// slot[v] = the position in `indices` where the reference inserts v's self edge: in front of the first neighbour above v, behind the
+// last one when all lie below (== e1), kEmpty when the row lists v itself (lower_bound != upper_bound, ParallelSampler.cpp:386-400)
+__global__ void sg_self_slot_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, uint32_t N,
+                                    uint32_t *__restrict__ slot) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= N) return;
+  uint32_t lo = indptr[v];
+  const uint32_t e1 = indptr[v + 1];
+  uint32_t hi = e1;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (indices[mid] < v) lo = mid + 1u; else hi = mid;
+  }
+  slot[v] = (lo < e1 && indices[lo] == v) ? kEmpty : lo;
+}
+
 template <bool kSelf>
 __global__ void sg_scan_plain_kernel(SampleParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -844,7 +860,6 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
   t.crow = (uint32_t *)(smem + L.crow);
   t.wtmp = smem + L.wtmp;
   uint4 *runs = (uint4 *)(smem + L.runs);
-  uint32_t *runv = (uint32_t *)(smem + L.runv);            // (kSelf: the id of every run's row)
   uint4 *hub = (uint4 *)(smem + L.hub);
   uint32_t *ctrl = (uint32_t *)(smem + L.ctrl);
 
@@ -926,13 +941,28 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
           const uint32_t lo = max(qs, rq0), hi = min(qe, rq1);
           nq = qe - qs;
           if (hi > lo) { len = hi - lo; k0 = lo - qs; nr = (len + 63u) >> 6; }
-          if (kSelf && nq == 0u) {
-            // a row WITHOUT neighbours: its self edge (.cpp:387-400 with an empty row) goes to the round whose range ends at or
-            // behind its (empty) position -- the very first round of the subgraph for position 0, as sg_scan_kernel files
-            // them.  (Rows with neighbours: the streaming loop decides, where the ids pass by.)
-            if ((qs > rq0 && qs <= rq1) || (qs == 0u && rq0 == 0u && lc0 == 0u)) {
-              const uint32_t idx = atomicAdd(&ctrl[C_M], 1u);
-              if (idx < capm) { t.lval[idx] = ri.e0; t.lrow[idx] = r | kSelfEntry; }
+          if (kSelf) {
+            // The inserted self edge (.cpp:386-400) sits in front of the first neighbour above the row's own id v -- behind the last
+            // one when all lie below -- and a row that lists itself gets none: a property of the FULL graph's row, looked up in the
+            // per-node table the handle built once (SampleParams::self_slot; rounds 5 found the place where the ids stream by:
+            // ~200 scalar instructions per run, a third of the depth-3 scan).  The entry is filed by the round that scans the quad
+            // its position lies in (the last quad for a slot behind the row), so that it is ranked with that quad's survivors.
+            const uint32_t sp = p.self_slot[ri.v];
+            if (sp != kEmpty) {
+              bool mine;
+              if (nq == 0u) {
+                // a row WITHOUT neighbours: the round whose range ends at or behind its (empty) position -- the very first round
+                // of the subgraph for position 0, as sg_scan_kernel files them
+                mine = (qs > rq0 && qs <= rq1) || (qs == 0u && rq0 == 0u && lc0 == 0u);
+              } else {
+                const uint32_t pos = sp >= ri.e0 + ri.deg ? ri.e0 + ri.deg - 1u : sp;
+                const uint32_t qi = qs + ((pos >> 2) - (ri.e0 >> 2));
+                mine = qi >= rq0 && qi < rq1;
+              }
+              if (mine) {
+                const uint32_t idx = atomicAdd(&ctrl[C_M], 1u);
+                if (idx < capm) { t.lval[idx] = sp; t.lrow[idx] = r | kSelfEntry; }
+              }
             }
           }
         }
@@ -952,7 +982,7 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
           if (nr >= kHubRuns) h = atomicAdd(&ctrl[C_NHUB], 1u);
           if (h < kHubCap) { hub[2 * h] = make_uint4(r, first, k0, len); hub[2 * h + 1] = make_uint4(ri.e0, ri.deg, nq, ri.v); }
           else {
-            for (uint32_t g0 = 0, i = first; g0 < len; g0 += 64u, i++) { runs[i] = make_run(ri, r, nq, k0, len, g0); if (kSelf) runv[i] = ri.v; }
+            for (uint32_t g0 = 0, i = first; g0 < len; g0 += 64u, i++) runs[i] = make_run(ri, r, nq, k0, len, g0);
           }
         }
         if (ctrl[C_ROWSTOP + pass]) break;                // (written before the scan's barriers, uniform behind them)
@@ -973,7 +1003,7 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
           RowInfo ri;
           ri.e0 = hr.x; ri.deg = hr.y; ri.rs = 0; ri.v = 0;
           const uint32_t nq = hr.z;
-          for (uint32_t j = lane; j * 64u < hb.w; j += 64u) { runs[hb.y + j] = make_run(ri, hb.x, nq, hb.z, hb.w, j * 64u); if (kSelf) runv[hb.y + j] = hr.w; }
+          for (uint32_t j = lane; j * 64u < hb.w; j += 64u) runs[hb.y + j] = make_run(ri, hb.x, nq, hb.z, hb.w, j * 64u);
         }
       }
       __syncthreads();
@@ -984,14 +1014,6 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
         const uint32_t J = (nrun - wave + nw - 1u) / nw;
         uint4 q[kDepth];
         uint32_t r_meta[kDepth], r_e0[kDepth], r_e1[kDepth], r_a0[kDepth];
-        // kSelf: the row's own id and the id in front of the run's first position (one more load per run, one address for
-        // the whole wavefront)
-        uint32_t r_v[kSelf ? kDepth : 1], pvv[kSelf ? kDepth : 1];
-        // (that load must be a VECTOR load although its address is uniform: as a scalar load it would sit behind the
-        //  `s_waitcnt lgkmcnt(0)` of every filter probe -- each run then waited for the load issued eight runs ahead of it:
-        //  measured 2.3 x on the whole kernel.  A zero the compiler cannot see through keeps the address in a VGPR.)
-        uint32_t vzero = 0;
-        asm volatile("" : "+v"(vzero));
 #pragma unroll
         for (int u = 0; u < kDepth; u++) {
           const uint32_t i = wave + (uint32_t)u * nw;
@@ -1000,12 +1022,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
           r_meta[u] = rl_first(i < nrun ? rc.y : 0xFFFFFFFFu);                        // (all ones: no such run)
           const uint32_t tk = r_meta[u] == 0xFFFFFFFFu ? 0u : (r_meta[u] >> 20) & 63u;
           q[u] = *reinterpret_cast<const uint4 *>(p.indices + r_a0[u] + 4u * min(lane, tk));
-          if (kSelf) { r_v[u] = rl_first(runv[min(i, nrun - 1u)]); pvv[u] = p.indices[max(r_a0[u], 1u) - 1u + vzero]; }
           __builtin_amdgcn_sched_barrier(0);                  // (keep the slots in issue order: the counted waits below rely on it)
         }
         for (uint32_t j0 = 0; j0 < J; j0 += kDepth) {
           uint32_t hm = 0;
-          uint32_t myspos = kEmpty;                           // kSelf: lane u carries the self-edge slot found in run j0 + u
 #pragma unroll
           for (int u = 0; u < kDepth; u++) {
             // consume run j0 + u ...
@@ -1022,36 +1042,6 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
               h &= vm;
             }
             hm |= h << (4 * u);
-            if (kSelf && meta != 0xFFFFFFFFu) {
-              // The inserted self edge (.cpp:387-400) sits in front of the first neighbour above the row's own id v whose left
-              // neighbour lies below v (or is the row's first), or behind the last neighbour when that lies below v; a row that
-              // lists itself gets none.  The ids ascend, so ONE quad of the run can hold that place: the first whose last id
-              // exceeds v (one compare per lane + a ballot) -- or the run's last quad.  Its four ids come over by v_readlane
-              // and the rest is scalar arithmetic: per-lane tests of every component tripled the streaming loop's VALU work.
-              const uint32_t v = r_v[u], e0 = r_e0[u], e1 = r_e1[u], a0 = r_a0[u];
-              const uint32_t nfull = (a0 + 4u * (tk + 1u) > e1) ? tk : tk + 1u;        // quads whose last id belongs to the row
-              uint64_t m = __ballot(q[u].w > v);
-              m &= nfull >= 64u ? ~0ull : ((1ull << nfull) - 1ull);
-              const uint32_t F = rl_first(m ? (uint32_t)__builtin_ctzll(m) : tk);
-              const uint32_t c4[4] = {(uint32_t)__builtin_amdgcn_readlane((int)q[u].x, F), (uint32_t)__builtin_amdgcn_readlane((int)q[u].y, F),
-                                      (uint32_t)__builtin_amdgcn_readlane((int)q[u].z, F), (uint32_t)__builtin_amdgcn_readlane((int)q[u].w, F)};
-              const uint32_t pv = F ? (uint32_t)__builtin_amdgcn_readlane((int)q[u].w, F - 1u) : rl_first(pvv[u]);
-              const uint32_t i0F = a0 + 4u * F;
-              // (branch-free scalar arithmetic on four-bit masks: written with tests and early exits the compiler made this
-              //  ~100 SALU instructions with eight branches per run -- 300 cycles, three times the run's own streaming work)
-              const uint32_t lo = max(e0, i0F) - i0F, hi = min(e1, i0F + 4u) - i0F;   // components [lo, hi) belong to the row
-              const uint32_t vmask = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-              const uint32_t ltv = ((uint32_t)(c4[0] < v) | ((uint32_t)(c4[1] < v) << 1) | ((uint32_t)(c4[2] < v) << 2) | ((uint32_t)(c4[3] < v) << 3)) & vmask;
-              const uint32_t gtv = ((uint32_t)(c4[0] > v) | ((uint32_t)(c4[1] > v) << 1) | ((uint32_t)(c4[2] > v) << 2) | ((uint32_t)(c4[3] > v) << 3)) & vmask;
-              const uint32_t fg = (uint32_t)__builtin_ctz(gtv | 16u);                // first component above v (4: none)
-              const uint32_t below = vmask & ((1u << fg) - 1u);                       // the row's components in front of it
-              const uint32_t noeq = (uint32_t)((below & ~ltv) == 0u);                 // ... all lie below v (none equals it)
-              const uint32_t startok = (uint32_t)(fg != lo) | (uint32_t)(i0F + lo == e0) | (uint32_t)(pv < v);
-              const uint32_t ins = (uint32_t)(fg < 4u) & noeq & startok;
-              const uint32_t trail = (uint32_t)(gtv == 0u) & (uint32_t)(i0F + hi == e1) & (uint32_t)(hi > lo) & ((ltv >> ((hi - 1u) & 3u)) & 1u);
-              const uint32_t spos = ins ? i0F + fg : (trail ? e1 : kEmpty);
-              if (lane == (uint32_t)u) myspos = spos;
-            }
             // ... and put run j0 + u + kDepth in its place
             const uint32_t i2 = wave + (j0 + (uint32_t)u + kDepth) * nw;
             const uint4 rc = runs[min(i2, nrun - 1u)];
@@ -1059,10 +1049,9 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
             r_meta[u] = rl_first(i2 < nrun ? rc.y : 0xFFFFFFFFu);
             const uint32_t tk2 = r_meta[u] == 0xFFFFFFFFu ? 0u : (r_meta[u] >> 20) & 63u;
             q[u] = *reinterpret_cast<const uint4 *>(p.indices + r_a0[u] + 4u * min(lane, tk2));
-            if (kSelf) { r_v[u] = rl_first(runv[min(i2, nrun - 1u)]); pvv[u] = p.indices[max(r_a0[u], 1u) - 1u + vzero]; }
             __builtin_amdgcn_sched_barrier(0);
           }
-          const uint32_t cnt = (uint32_t)__popc(hm) + ((kSelf && myspos != kEmpty) ? 1u : 0u);
+          const uint32_t cnt = (uint32_t)__popc(hm);
           if (__ballot(cnt != 0)) {
             const uint32_t incl = wave_incl_scan(cnt);
             uint32_t basev = 0;
@@ -1074,10 +1063,6 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
               const uint4 d = runs[wave + (j0 + (b >> 2)) * nw];
               if (r < capm) { t.lval[r] = d.x + 4u * lane + (b & 3u); t.lrow[r] = d.y & ((1u << kRankShift) - 1u); }   // .cpp:420-422
               r++;
-            }
-            if (kSelf && myspos != kEmpty) {                  // (lanes 0 .. kDepth - 1: the slot found in "their" run)
-              const uint4 d = runs[wave + (j0 + lane) * nw];
-              if (r < capm) { t.lval[r] = myspos; t.lrow[r] = (d.y & ((1u << kRankShift) - 1u)) | kSelfEntry; }
             }
           }
         }
