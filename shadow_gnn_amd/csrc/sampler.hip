@@ -852,6 +852,13 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       p.capn = capn_lds; p.capf = capf_lds; p.H = H;
       p.hshift = 32; for (uint32_t h = H / 4; h > 1; h >>= 1) p.hshift--;
       p.g_ticket = (uint32_t *)(s->d_counts + 8 * kMaxBatches);
+      p.lds_skip = 0;
+      if (cfg->method == SG_METHOD_KHOP && cfg->budget > 1 && cfg->depth >= 1 && capn > capn_lds) {
+        // level sizes of a budgeted expansion: 1 + b + b^2 + ... (an ordinary subgraph reaches about half of it)
+        uint64_t est = 1, lvl = 1;
+        for (int l = 0; l < cfg->depth && est < ((uint64_t)1 << 40); l++) { lvl *= (uint64_t)cfg->budget; est += lvl; }
+        p.lds_skip = est >= (uint64_t)4 * capn_lds ? 1u : 0u;
+      }
       const LdsLayout L = lds_layout(H, capn_lds, capf_lds, cfg->method == SG_METHOD_PPR);
       if (L.total > 160 * 1024 - 256) return set_error(SG_ERR_INVALID, "sg_sample: LDS layout %zu B too large", L.total);
       uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)(160 * 1024) / (L.total + 64), 32 / (T / 64));

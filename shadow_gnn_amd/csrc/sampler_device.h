@@ -116,6 +116,10 @@ struct SampleParams {
   // edge (ParallelSampler.cpp:386-400: lower_bound == upper_bound of v in its own row), kEmpty for a node that lists itself.
   // A property of the full graph alone: built once per sampler handle (sg_self_slot_kernel), read once per subgraph row.
   const uint32_t *self_slot;
+  // budgeted k-hop whose level sizes alone put every ordinary subgraph far beyond the LDS tables (depth 3, budget 20: ~4 600 nodes
+  // against 2 048): the LDS attempt is not made, every subgraph goes to the global-table kernel straight away (0.07 ms per
+  // 256-root call of attempts that were abandoned anyway).  A subgraph that would have fitted is merely selected over global tables.
+  uint32_t lds_skip;
 };
 
 struct Tables {
@@ -622,6 +626,13 @@ __global__ void sg_select_lds_kernel(SampleParams p) {
     const uint32_t s = s_next;
     __syncthreads();
     if (s >= p.P) return;
+    if (p.lds_skip) {
+      if (threadIdx.x == 0) {
+        uint32_t *res = p.s_cnt + (size_t)s * R_WORDS;
+        res[R_N] = 0; res[R_E] = 0; res[R_FLAGS] = 1u; res[R_SLOTS] = 0; res[R_Q] = 0; res[R_FNODES] = 0; res[R_FREADS] = 0;
+      }
+      continue;
+    }
     select_subgraph<false>(p, s, t, ctrl, wsum);
   }
 }

@@ -348,14 +348,18 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
   if (tid == 0) { ctrl[C_MV] = 0; ctrl[C_CHANGED] = 0xFFFFFFFFu; ctrl[C_MFAIL] = 0; }
   __syncthreads();
   uint32_t kmin_l = kEmpty, kmax_l = 0, alive = 0;
-  for (uint32_t i0 = tid; i0 < m; i0 += 2u * T) {
-    // two entries per pass: their global loads (the id at its position, the row record) share one round trip
-    const uint32_t idx[2] = {i0, i0 + T};
-    const bool ok[2] = {true, i0 + T < m};
-    uint32_t key[2], pos[2] = {0, 0}, c[2] = {0, 0};
-    uint4 riw[2];
+  constexpr int kPer = kFromPos ? 4 : 2;
+  for (uint32_t i0 = tid; i0 < m; i0 += (uint32_t)kPer * T) {
+    // kPer entries per pass: their global loads (the id at its position, the row record) share one round trip (round 6: four for
+    // the flat scan -- a 1 024-thread workgroup then resolves a full 4 096-entry list in ONE pass instead of two)
+    uint32_t idx[kPer];
+    bool ok[kPer];
+    uint32_t key[kPer], pos[kPer], c[kPer];
+    uint4 riw[kPer];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
+    for (int e = 0; e < kPer; e++) { idx[e] = i0 + (uint32_t)e * T; ok[e] = idx[e] < m; pos[e] = 0; c[e] = 0; }
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
       key[e] = 0; riw[e] = make_uint4(0u, 0u, 0u, 0u);
       if (ok[e]) {
         key[e] = kFromPos ? 1u : t.lkn[idx[e]].x;
@@ -373,7 +377,7 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
       }
     }
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
+    for (int e = 0; e < kPer; e++) {
       if (!ok[e]) continue;
       const uint32_t i = idx[e];
       uint32_t k = key[e];
@@ -934,6 +938,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
         RowInfo ri;
         ri.e0 = ri.deg = ri.rs = ri.v = 0;
         if (r < n) {
+          // (kSelf: the row's self-edge slot is asked for through the node list in LDS -- not through the row record's id, a
+          //  second dependent global round trip per pass)
+          uint32_t sp = kEmpty;
+          if (kSelf) sp = p.self_slot[nstride == 1u ? t.nodes[r] : g_nodes[r]];
           qs = g_rowq[r];
           const uint32_t qe = g_rowq[r + 1];
           const uint4 riw = *reinterpret_cast<const uint4 *>(g_info + r);
@@ -947,7 +955,6 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
             // per-node table the handle built once (SampleParams::self_slot; rounds 5 found the place where the ids stream by:
             // ~200 scalar instructions per run, a third of the depth-3 scan).  The entry is filed by the round that scans the quad
             // its position lies in (the last quad for a slot behind the row), so that it is ranked with that quad's survivors.
-            const uint32_t sp = p.self_slot[ri.v];
             if (sp != kEmpty) {
               bool mine;
               if (nq == 0u) {
