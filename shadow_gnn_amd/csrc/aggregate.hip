@@ -1135,7 +1135,7 @@ extern "C" int sl_csr_transpose(const uint32_t *d_indptr, const uint32_t *d_indi
   // work: [0] flag, [4 .. 4+n+1) cursors, then 2*e sort scratch
   uint32_t *flag = d_work, *cursor = d_work + 4, *tmp_idx = cursor + (size_t)n + 4, *tmp_perm = tmp_idx + e;
   SHD_HIP(hipMemsetAsync(flag, 0, 16, st));
-  if (e) SHD_HIP(hipMemsetAsync(d_t_perm, 0xFF, (size_t)e * 4, st));
+  if (e) { const int frc = fill_words(d_t_perm, 0xFFFFFFFFu, (size_t)e, st); if (frc != SG_OK) return frc; }
   const uint32_t ge = grid_for(std::max<uint64_t>(e, (uint64_t)n + 1), kBlock);
   hipLaunchKernelGGL(tr_sym_kernel, dim3(ge), dim3(kBlock), 0, st, d_indptr, d_indices, d_edge_row, n, e,
                      d_t_indptr, d_t_indices, d_t_perm, flag);

@@ -25,6 +25,11 @@ int set_error(int code, const char *fmt, ...);
 // (kernel, device) and only ask again for more (the hot launches of a training step call it thousands of times otherwise)
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
 
+// 32-bit fill of a device buffer on a stream (prof.hip).  hipMemsetAsync's blit kernel takes 16 us for the 1.2 MB row-maximum /
+// row-map arrays of a 289 k-row batch (rocprofv3: __amd_rocclr_fillBufferAligned, seven per headline step): a plain grid-stride
+// store kernel fills them at HBM speed.  `value`: the word written (0xFFFFFFFF for the index arrays cleared to "none").
+int fill_words(void *dst, uint32_t value, size_t nwords, hipStream_t st);
+
 // Optional per-kernel timing inside the C entries (prof.hip): SHD_PROF(name, algorithmic bytes, flops, stream) at the top of
 // a launch scope records a HIP-event pair around it while sl_prof_enable(1) is in effect; one branch otherwise.
 bool prof_enabled();

@@ -60,7 +60,7 @@ int spmm_any(const sl_norm_adj *a, bool transposed, const float *X, int64_t ldx,
   }
   if (a->subg_node_off && F >= 96) {
     float *am = spmm_joins(a, F, X, ldx, Y, ldy) ? amax : nullptr;
-    if (am && amax_state == 0) SHD_HIP(hipMemsetAsync(am, 0, (size_t)a->n * 4, (hipStream_t)st));
+    if (am && amax_state == 0) { const int frc = fill_words(am, 0u, (size_t)a->n, (hipStream_t)st); if (frc != SG_OK) return frc; }
     const int rc = zero_pad ? spmm_blockdiag_padded(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
                                                     a->num_subg, a->max_subg_nodes, am, st)
                             : sl_spmm_blockdiag_f32(ip, ix, a->edge_w, perm, rs, cs, X, ldx, Y, ldy, a->n, F, a->subg_node_off, a->subg_edge_off,
@@ -250,7 +250,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       // backward runs on the selected rows (compact gradient, row indirection).
       SHD_PROF_FMT(2.0 * 4.0 * n * Fout + 5.0 * 4.0 * num_dout_rows * Fout, 0, stream, "act_norm_bwd_rows_nb%d_F%u", 2, Fout);
       hipLaunchKernelGGL(zero_slices_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, dZs, dZn, ld3, n, Fout);
-      if (join) SHD_HIP(hipMemsetAsync(amx, 0, (size_t)n * 4, (hipStream_t)stream));
+      if (join && (rc = fill_words(amx, 0u, (size_t)n, (hipStream_t)stream)) != SG_OK) return rc;
       if (num_dout_rows == 0) {
         SHD_HIP(hipMemsetAsync(d_dscale, 0, (size_t)2 * Fout * 4, (hipStream_t)stream));
         SHD_HIP(hipMemsetAsync(d_doffset, 0, (size_t)2 * Fout * 4, (hipStream_t)stream));

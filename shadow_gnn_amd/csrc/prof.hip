@@ -60,6 +60,29 @@ ProfScope::~ProfScope() {
   if (gen == g_gen && idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[idx].e1, st);
 }
 
+
+// ---- fill_words (common.h): 16 bytes per lane and iteration, one workgroup per CU-slot at most
+__global__ void __launch_bounds__(256) fill_words_kernel(uint32_t *__restrict__ dst, uint32_t value, size_t nwords) {
+  const size_t nvec = nwords / 4;
+  uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+  const uint4 v4 = make_uint4(value, value, value, value);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) d4[i] = v4;
+  for (size_t i = nvec * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+int fill_words(void *dst, uint32_t value, size_t nwords, hipStream_t st) {
+  if (nwords == 0) return SG_OK;
+  if (((uintptr_t)dst & 15u) != 0) {           // (not 16-byte aligned: the runtime's own fill)
+    SHD_HIP(hipMemsetD32Async((hipDeviceptr_t)dst, (int)value, nwords, st));
+    return SG_OK;
+  }
+  const size_t blocks = (nwords / 4 + 255) / 256;
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(blocks, 1), 2048)), dim3(256), 0, st,
+                     reinterpret_cast<uint32_t *>(dst), value, nwords);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
 }  // namespace shadow
 
 using namespace shadow;

@@ -212,7 +212,7 @@ extern "C" int sl_top_plan_filter(const uint32_t *d_T, uint32_t *d_off, uint32_t
   if (!d_T || !d_off || !d_t_indptr || !d_rowmap || !d_f_indptr || !d_f_indices || !d_f_perm || !d_work)
     return set_error(SG_ERR_INVALID, "sl_top_plan_filter: null argument");
   hipStream_t st = (hipStream_t)stream;
-  SHD_HIP(hipMemsetAsync(d_rowmap, 0xFF, (size_t)n * 4, st));
+  { const int frc = fill_words(d_rowmap, 0xFFFFFFFFu, (size_t)n, st); if (frc != SG_OK) return frc; }
   hipLaunchKernelGGL(top_rowmap_kernel, dim3(std::min<uint32_t>((cap + 255) / 256, 2048)), dim3(256), 0, st, d_T, d_off, num_subg, cap, n, d_rowmap);
   hipLaunchKernelGGL(top_filt_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_t_indptr, d_t_indices, d_rowmap, n, d_f_indptr);
   const uint32_t nblocks = (n + 1023) / 1024;
