@@ -53,6 +53,16 @@ pair = collections.defaultdict(lambda: [0, 0])
 for g, a, b in gaps:
     pk, pq = end_at.get(a, ("?", "?")); nk, nq = start_at.get(b, ("?", "?"))
     pair[(short(pk), pq, short(nk), nq)][0] += g; pair[(short(pk), pq, short(nk), nq)][1] += 1
+own = collections.defaultdict(lambda: [0, 0])
+is_lib = lambda k: any(x in k for x in ("at::native", "at::cuda", "rocprim", "rocclr", "Cijk_"))
+for e in win:
+    key = (("torch/rocclr/rocprim " if is_lib(e[2]) else "") + short(e[2]), e[3])
+    own[key][0] += e[1] - e[0]; own[key][1] += 1
+lib = sum(v[0] for k, v in own.items() if k[0].startswith("torch/"))
+print(f"library (torch / rocclr / rocprim) kernels: {lib / nsteps / 1e3:.1f} us per step in {sum(v[1] for k, v in own.items() if k[0].startswith('torch/')) / nsteps:.1f} launches per step")
+print("kernels in the window by time (us per step, launches per step, queue):")
+for (k, q), (t, c) in sorted(own.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"  {t / nsteps / 1e3:8.1f} us  {c / nsteps:5.1f}/step  [{q}] {k}")
 print("largest idle gaps by (kernel that ended [queue] -> kernel that started [queue]):")
 for (pk, pq, nk, nq), (g, c) in sorted(pair.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"  {g / nsteps / 1e3:8.1f} us  {c / nsteps:5.1f}/step  {pk} [{pq}] -> {nk} [{nq}]")
