@@ -365,6 +365,17 @@ int sl_segment_pool_fwd(const float *d_X, int64_t ldx, const uint32_t *d_node_of
                         int mode, float *d_out, int64_t ldo, uint32_t *d_argmax, void *stream);
 int sl_segment_pool_bwd(const float *d_dout, int64_t lddo, const uint32_t *d_node_off, uint32_t num_subg,
                         uint32_t F, int mode, const uint32_t *d_argmax, float *d_dX, int64_t lddx, void *stream);
+/* (ABI 24) The gradient of (mean | sum pooling of X, X[rows]) -- the read-out of shaDow/layers.py:154-199 -- as a TABLE instead of its
+ * [n, F] expansion: sl_pool_grad_rows fills d_index [n] (row i of the batch -> its table row: its subgraph s < num_subg, or
+ * num_subg + k for the row of root k), sl_pool_grad_table fills d_table [num_subg + num_roots, F]: row s = dout[s] (/ n_s for the
+ * mean: mode 0; 2 = sum), row num_subg + k = that of root k's subgraph + droots[k] (+ every other root entry on the same row).
+ * table[index[i]] equals sl_segment_pool_bwd's dX[i] followed by index_add_(rows, droots), bit for bit; d_dout / d_droots may be
+ * NULL (no gradient from that side).  Consumer: sl_gemm_an_bwd_plain / sl_sage_below.plain_row. */
+int sl_pool_grad_rows(const uint32_t *d_node_off, uint32_t num_subg, const int64_t *d_rows, uint32_t num_roots, uint32_t n,
+                      uint32_t *d_index, void *stream);
+int sl_pool_grad_table(const float *d_dout, int64_t lddo, const float *d_droots, int64_t lddr, const uint32_t *d_node_off,
+                       uint32_t num_subg, const int64_t *d_rows, uint32_t num_roots, uint32_t n, uint32_t F, int mode,
+                       float *d_table, int64_t ldt, void *stream);
 
 /* Entity encodings as bit masks of the active one-hot columns (frontend/graph.py:134-172):
  * kind 0 hops (uint32, 0xFFFFFFFF unreachable -> column 0, hop h <= dim-2 -> column h+1, h >= 255 -> column 0),
@@ -614,13 +625,14 @@ int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d_a_amax, co
 /* ... and with a DENSE addend d_dout_plain [M, N] (pitch lddp; may be NULL: sl_gemm_an_bwd_corr) that does NOT pass the dropout mask:
  * the layer below is in dual-output mode (its plain output feeds a read-out -- residue / pooling, shaDow/models.py:176-185 -- its
  * dropped output this layer), the epilogue forms  dy = G * mask / (1 - p) + d_dout_plain * out_scale  before its act + norm backward:
- * sl_act_norm_bwd's (d_dout, d_dout_dropped) sum.  128 < N <= 256.                                                                 */
+ * sl_act_norm_bwd's (d_dout, d_dout_dropped) sum.  128 < N <= 256.  d_plain_row (may be NULL): row i's addend is row d_plain_row[i] of
+ * d_dout_plain (ABI 24: the gradient table of a mean / sum pooling read-out, sl_pool_grad_table).                                   */
 int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N, uint32_t K,
                          int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
                          const float *d_scale, const float *d_offset, float out_scale, float *const *d_dZ, const int64_t *lddz,
                          float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                          float *d_dz0_amax, const float *d_row_stats, const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row,
-                         uint32_t corr_rows, const float *d_dout_plain, int64_t lddp, void *stream);
+                         uint32_t corr_rows, const float *d_dout_plain, int64_t lddp, const uint32_t *d_plain_row, void *stream);
 
 /* Backward of a GraphSAGE layer chained with the layer below it (consecutive GraphSAGE layers where nothing but this
  * layer reads the lower layer's output -- residue 'none' + centre pooling, shaDow/layers.py:159-163): the input gradient
@@ -653,6 +665,9 @@ typedef struct {
   const float *stats;              /* [n, 4] row statistics its forward pass left (sl_sage_fwd d_row_stats), or NULL */
   const float *dout_plain;         /* (ABI 23) dual-output layer below: the gradient of its PLAIN output, [n, F] dense, added unmasked
                                       before its act + norm backward (sl_gemm_an_bwd_plain); NULL: a single-output layer */
+  const uint32_t *plain_row;       /* (ABI 24) NULL, or [n]: row i's plain gradient is row plain_row[i] of dout_plain -- the table of a
+                                      pooled read-out's gradient (sl_pool_grad_table) instead of its [n, F] expansion */
+  int64_t plain_ld;                /* pitch of dout_plain in floats (0: F) */
 } sl_sage_below;
 size_t sl_sage_chain_partial_floats(uint32_t n, uint32_t F);
 int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, const float *d_AX, int64_t ldax, const float *d_Zs,

@@ -58,7 +58,7 @@ class SlSageBelow(C.Structure):
         ("Zs", C.c_void_p), ("Zn", C.c_void_p), ("bs", C.c_void_p), ("bn", C.c_void_p), ("scale", C.c_void_p),
         ("offset", C.c_void_p), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("F", C.c_uint32),
         ("buf", C.c_void_p), ("dscale", C.c_void_p), ("doffset", C.c_void_p), ("dbias", C.c_void_p), ("partial", C.c_void_p),
-        ("amax", C.c_void_p), ("stats", C.c_void_p), ("dout_plain", C.c_void_p),
+        ("amax", C.c_void_p), ("stats", C.c_void_p), ("dout_plain", C.c_void_p), ("plain_row", C.c_void_p), ("plain_ld", C.c_int64),
     ]
 
 
@@ -207,7 +207,7 @@ SIGNATURES = {
                                   C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, C.c_uint32, _P]),
     "sl_gemm_an_bwd_plain": (C.c_int, [_P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64),
                                   C.POINTER(_P), C.POINTER(C.c_int), _P, _P, C.c_float, C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P,
-                                  C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, C.c_uint32, _P, C.c_int64, _P]),
+                                  C.c_float, C.c_uint64, _P, _P, _P, C.c_int64, _P, C.c_uint32, _P, C.c_int64, _P, _P]),
     "sl_gcn_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "sl_gcn_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float,
                               C.c_uint64, _P, C.c_int64, _P, _P, _P, _P, _P]),
@@ -221,6 +221,9 @@ SIGNATURES = {
     "sl_gemm_tn_f16_pair": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "sl_segment_pool_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_int64, _P, _P]),
     "sl_segment_pool_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_int, _P, _P, C.c_int64, _P]),
+    "sl_pool_grad_rows": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    "sl_pool_grad_table": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P,
+                                     C.c_int64, _P]),
     "sl_encode_codes": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "sl_onehot_linear_fwd": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
     "sl_onehot_linear_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P]),
@@ -256,7 +259,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 23      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 24      # sg_abi_version() of the library these signatures describe
 
 
 def load():

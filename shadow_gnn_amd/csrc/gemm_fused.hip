@@ -76,6 +76,9 @@ struct FusedDesc {
   //   dy = G * mask / (1 - p)  +  dplain * out_scale        (G: this product = the gradient of the dropped output)
   // before the act + norm backward; what sl_act_norm_bwd does with (d_dout, d_dout_dropped)
   const float *dplain; int64_t lddplain;
+  // ... or, with plain_row set, row i's addend is dplain[plain_row[i], :]: the gradient of a mean / sum pooling read-out is one row
+  // per subgraph (+ one per root), kept as that small table instead of its [M, N] expansion (sl_pool_grad_table)
+  const uint32_t *plain_row;
   // MODE 2, optional: the GAT layer's per-node terms from the paired Linear's own tiles (sl_gemm_nt2_gat_f32).  For product b with
   // gat_u[b] set: u[row, h] = sum over head h's D columns of gat_att[b][col] * act(C[row, col]) -- shaDow/layers.py:566-569 -- and,
   // with gat_store_act[b], the tile leaves as act(C) (hn = act(z_neigh): the pre-activation is never written).  N == 32 TW == H D.
@@ -282,12 +285,24 @@ __device__ __forceinline__ void fused_epilogue(const FusedDesc &d, f32x16 (&acc)
     float spre[D][2 * NBA];                                 // (backward with kStats: the row's saved statistics, same look-ahead)
     uint32_t cpre[D];                                       // (backward with a sparse addend: its row of corr, or >= corr_rows)
     float4 ppre[D][kPlain ? Q : 1];                         // (backward with a dense plain addend: its row, same look-ahead)
+    uint32_t pnext = (kPlain && d.plain_row) ? d.plain_row[min((uint64_t)rbase, (uint64_t)M - 1)] : 0u;
+    uint32_t pnext2 = (kPlain && d.plain_row) ? d.plain_row[min((uint64_t)rbase + RP, (uint64_t)M - 1)] : 0u;
     auto load_pass = [&](int slot, uint64_t row) {
       const uint64_t rr = min(row, (uint64_t)M - 1);
       if (kBwd) cpre[slot] = d.corr ? d.corr_row[rr] : 0xFFFFFFFFu;
       if (kPlain) {
+        if (d.plain_row) {                                  // (a few thousand distinct rows: cached loads)
+          // (the map entries are asked for two passes earlier -- passes are loaded in row order, RP rows apart -- so that the table
+          //  row's address is not a second round trip in front of this pass's loads)
+          const float *pr = d.dplain + (uint64_t)pnext * d.lddplain;
+          pnext = pnext2;
+          pnext2 = d.plain_row[min(row + (uint64_t)(2 * RP), (uint64_t)M - 1)];
 #pragma unroll
-        for (int q = 0; q < Q; q++) ppre[slot][q] = ld4s(d.dplain + rr * d.lddplain + (on[q] ? 4 * (j + LPR * q) : 0u));
+          for (int q = 0; q < Q; q++) ppre[slot][q] = ld4(pr + (on[q] ? 4 * (j + LPR * q) : 0u));
+        } else {
+#pragma unroll
+          for (int q = 0; q < Q; q++) ppre[slot][q] = ld4s(d.dplain + rr * d.lddplain + (on[q] ? 4 * (j + LPR * q) : 0u));
+        }
       }
       if (kBwd && kStats) {
         if (NBA == 2) {                                   // (one 16-byte load, the same address in every lane of the row)
@@ -952,11 +967,12 @@ extern "C" int sl_gemm_an_bwd_corr(const float *d_A, int64_t lda, const float *d
                                    const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row, uint32_t corr_rows, void *stream) {
   return sl_gemm_an_bwd_plain(d_A, lda, d_a_amax, d_packed_B, M, N, K, nb, d_Z, ldz, d_bias, act, d_scale, d_offset, out_scale, d_dZ, lddz,
                               d_dscale, d_doffset, d_dbias, d_partial, drop_p, drop_seed, d_dz0_amax, d_row_stats, d_corr, ldcorr, d_corr_row,
-                              corr_rows, nullptr, 0, stream);
+                              corr_rows, nullptr, 0, nullptr, stream);
 }
 
 // ... and with a DENSE addend d_dout_plain [M, N] (pitch lddp) that does not pass the dropout mask: the layer below is in
-// dual-output mode (FusedDesc::dplain).  N == 256 only (the benchmark width's instantiation).
+// dual-output mode (FusedDesc::dplain).  N == 256 only (the benchmark width's instantiation).  d_plain_row: the addend of row i is
+// row d_plain_row[i] of d_dout_plain (a pooled read-out's gradient table, sl_pool_grad_table).
 extern "C" int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *d_a_amax, const void *d_packed_B, uint32_t M, uint32_t N,
                                     uint32_t K, int nb,
                                     const float *const *d_Z, const int64_t *ldz, const float *const *d_bias, const int *act,
@@ -964,7 +980,8 @@ extern "C" int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *
                                     const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias, float *d_partial,
                                     float drop_p, uint64_t drop_seed, float *d_dz0_amax, const float *d_row_stats,
                                     const float *d_corr, int64_t ldcorr, const uint32_t *d_corr_row, uint32_t corr_rows,
-                                    const float *d_dout_plain, int64_t lddp, void *stream) {
+                                    const float *d_dout_plain, int64_t lddp, const uint32_t *d_plain_row, void *stream) {
+  if (d_plain_row && !d_dout_plain) return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd_plain: a row map without the addend's table");
   if (d_dout_plain && (N <= 128 || (lddp & 3) || !al16(d_dout_plain) || lddp < (int64_t)N))
     return set_error(SG_ERR_INVALID, "sl_gemm_an_bwd_plain: the dense addend needs 128 < N <= 256, ld %% 4 == 0 >= N and 16-byte alignment");
   if (d_corr && (!d_corr_row || (ldcorr & 3) || !al16(d_corr) || ldcorr < (int64_t)N))
@@ -1000,7 +1017,7 @@ extern "C" int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *
   p.partial = d_partial; p.dz_amax = d_dz0_amax;
   p.stats_r = d_row_stats;
   p.corr = d_corr; p.ldcorr = ldcorr; p.corr_row = d_corr_row; p.corr_rows = d_corr ? corr_rows : 0;
-  p.dplain = d_dout_plain; p.lddplain = lddp;
+  p.dplain = d_dout_plain; p.lddplain = lddp; p.plain_row = d_plain_row;
   int rc;
   if ((rc = fill_dropout(p, drop_p, drop_seed, "sl_gemm_an_bwd")) != SG_OK) return rc;
   rc = d_dout_plain ? launch_fused<8, -1, 1, 2>(p, st) : (N <= 128 ? launch_fused<4, 1, 1, 2>(p, st) : launch_fused<8, 1, 1, 2>(p, st));

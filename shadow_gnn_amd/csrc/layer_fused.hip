@@ -294,7 +294,7 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       SHD_PROF_FMT(4.0 * n * (2.0 * Fout + 4.0 * Fb), 2.0 * n * (2.0 * Fout) * Fin, stream, "gemm_an_bwd_nb2_N%u", Fin);
       if ((rc = sl_gemm_an_bwd_plain(d_buf, ld3, hand ? amx : nullptr, d_pack, n, Fin, 2 * Fout, 2, Zb, ldzb, biasb, actsb, below->scale, below->offset, 1.0f,
                                      dZb, lddzb, below->dscale, below->doffset, below->dbias, below->partial, below->drop_p, below->drop_seed,
-                                     hand ? below->amax : nullptr, below->stats, nullptr, 0, nullptr, 0, below->dout_plain, Fb, stream)) != SG_OK)
+                                     hand ? below->amax : nullptr, below->stats, nullptr, 0, nullptr, 0, below->dout_plain, below->plain_ld ? below->plain_ld : (int64_t)Fb, below->plain_row, stream)) != SG_OK)
         return rc;
     } else if (f16dx) {
       const float *A1[1] = {d_buf};
@@ -395,7 +395,7 @@ extern "C" int sl_sage_stack_bwd(const sl_norm_adj *adj, const float *d_X0, int6
       below.Zs = b.Zs, below.Zn = b.Zn, below.bs = b.bs, below.bn = b.bn, below.scale = b.scale, below.offset = b.offset;
       below.act = b.act, below.drop_p = b.drop_p, below.drop_seed = b.drop_seed, below.F = b.Fout;
       below.buf = d_buf + ((l - 1) & 1u) * half, below.dscale = b.dscale, below.doffset = b.doffset, below.dbias = b.dbias;
-      below.partial = d_chain_partial, below.amax = d_amax + ((l - 1) & 1u) * (size_t)n, below.stats = b.row_stats; below.dout_plain = nullptr;
+      below.partial = d_chain_partial, below.amax = d_amax + ((l - 1) & 1u) * (size_t)n, below.stats = b.row_stats; below.dout_plain = nullptr; below.plain_row = nullptr; below.plain_ld = 0;
     }
     const float *X = l ? ly[l - 1].out : d_X0;
     if ((rc = sl_sage_bwd_chain(adj, X, l ? (int64_t)ly[l - 1].Fout : ldx0, y.AX, y.ldax, y.Zs, y.Zn, y.Fin, y.Fout, y.Ws, y.ldws, y.bs, y.Wn,
@@ -435,7 +435,7 @@ extern "C" int sl_sage_stack_bwd_ready(const sl_norm_adj *adj, const float *d_X0
       below.Zs = b.Zs, below.Zn = b.Zn, below.bs = b.bs, below.bn = b.bn, below.scale = b.scale, below.offset = b.offset;
       below.act = b.act, below.drop_p = b.drop_p, below.drop_seed = b.drop_seed, below.F = b.Fout;
       below.buf = d_buf + ((l - 1) & 1u) * half, below.dscale = b.dscale, below.doffset = b.doffset, below.dbias = b.dbias;
-      below.partial = d_chain_partial, below.amax = d_amax + ((l - 1) & 1u) * (size_t)n, below.stats = b.row_stats; below.dout_plain = nullptr;
+      below.partial = d_chain_partial, below.amax = d_amax + ((l - 1) & 1u) * (size_t)n, below.stats = b.row_stats; below.dout_plain = nullptr; below.plain_row = nullptr; below.plain_ld = 0;
     }
     const float *X = l ? ly[l - 1].out : d_X0;
     if ((rc = sl_sage_bwd_chain(adj, X, l ? (int64_t)ly[l - 1].Fout : ldx0, y.AX, y.ldax, y.Zs, y.Zn, y.Fin, y.Fout, y.Ws, y.ldws, y.bs, y.Wn,

@@ -126,6 +126,58 @@ segment_pool_bwd_kernel(const float *__restrict__ dout, int64_t lddo, const uint
   }
 }
 
+// The same gradient as a TABLE: row s < P = dout[s, :] (/ n_s for the mean) -- what every non-root row of subgraph s receives --
+// and row P + k = that of root k's subgraph + droots[k, :] (+ the droots of every other root on the same row, in index order:
+// index_add_'s sum), with idx[i] = the table row of batch row i.  A consumer that adds the gradient inside its own pass
+// (sl_gemm_an_bwd_plain) reads the 2 MB table instead of an [n, F] expansion somebody had to write first.
+__device__ __forceinline__ uint32_t seg_of_row(const uint32_t *__restrict__ node_off, uint32_t P, uint32_t r) {
+  uint32_t lo = 0, hi = P;                      // largest s with node_off[s] <= r (empty subgraphs share an offset: the last wins)
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (node_off[mid] <= r) lo = mid; else hi = mid; }
+  return lo;
+}
+
+__global__ void pool_row_index_kernel(const uint32_t *__restrict__ node_off, uint32_t P, uint32_t n, uint32_t *__restrict__ idx) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) idx[r] = seg_of_row(node_off, P, r);
+}
+
+__global__ void pool_root_index_kernel(const int64_t *__restrict__ rows, uint32_t K, uint32_t P, uint32_t n, uint32_t *__restrict__ idx) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K && (uint64_t)rows[k] < (uint64_t)n) atomicMax(&idx[rows[k]], P + k);        // (a row listed twice: its last entry's table row)
+}
+
+__global__ void __launch_bounds__(64)
+pool_grad_table_kernel(const float *__restrict__ dout, int64_t lddo, const float *__restrict__ droots, int64_t lddr,
+                       const uint32_t *__restrict__ node_off, uint32_t P, const int64_t *__restrict__ rows, uint32_t K, uint32_t n,
+                       uint32_t F, int mode, float *__restrict__ table, int64_t ldt) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  uint32_t s = b;
+  int64_t r = -1;
+  if (b >= P) {
+    r = rows[b - P];
+    if ((uint64_t)r >= (uint64_t)n) return;
+    s = seg_of_row(node_off, P, (uint32_t)r);
+  }
+  const uint32_t ns = node_off[s + 1] - node_off[s];
+  const float inv = (mode == 0 && ns) ? 1.0f / (float)ns : 1.0f;
+  for (uint32_t f = lane; f < F; f += 64) {
+    float g = dout ? dout[(int64_t)s * lddo + f] : 0.f;
+    if (mode == 0) g *= inv;
+    table[(int64_t)b * ldt + f] = g;
+  }
+  if (b < P || !droots) return;
+  // the roots on row r, in index order (the wavefront looks at 64 entries at a time)
+  for (uint32_t k0 = 0; k0 < K; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    unsigned long long m = __ballot(k < K && rows[k] == r);
+    while (m) {
+      const uint32_t kk = k0 + (uint32_t)__builtin_ctzll(m);
+      m &= m - 1;
+      for (uint32_t f = lane; f < F; f += 64) table[(int64_t)b * ldt + f] += droots[(int64_t)kk * lddr + f];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- encodings
 // kind 0: hops (uint32; 0xFFFFFFFF = unreachable)   graph.py:134-147
 //      1: pprs (float)                              graph.py:149-159 (bins can overlap at their edges)
@@ -281,6 +333,33 @@ extern "C" int sl_segment_pool_bwd(const float *d_dout, int64_t lddo, const uint
   if (num_subg == 0 || F == 0) return SG_OK;
   hipLaunchKernelGGL(segment_pool_bwd_kernel, dim3(num_subg, (F + 255) / 256), dim3(kPB), 0, (hipStream_t)stream,
                      d_dout, lddo, d_node_off, F, mode, d_argmax, d_dX, lddx);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
+extern "C" int sl_pool_grad_rows(const uint32_t *d_node_off, uint32_t num_subg, const int64_t *d_rows, uint32_t num_roots, uint32_t n,
+                                 uint32_t *d_index, void *stream) {
+  if (!d_node_off || !d_index || (num_roots && !d_rows)) return set_error(SG_ERR_INVALID, "sl_pool_grad_rows: null argument");
+  if (num_subg == 0) return set_error(SG_ERR_INVALID, "sl_pool_grad_rows: no subgraph");
+  if (n == 0) return SG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pool_row_index_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_node_off, num_subg, n, d_index);
+  SHD_HIP(hipGetLastError());
+  if (num_roots) {
+    hipLaunchKernelGGL(pool_root_index_kernel, dim3((num_roots + 255) / 256), dim3(256), 0, st, d_rows, num_roots, num_subg, n, d_index);
+    SHD_HIP(hipGetLastError());
+  }
+  return SG_OK;
+}
+
+extern "C" int sl_pool_grad_table(const float *d_dout, int64_t lddo, const float *d_droots, int64_t lddr, const uint32_t *d_node_off,
+                                  uint32_t num_subg, const int64_t *d_rows, uint32_t num_roots, uint32_t n, uint32_t F, int mode,
+                                  float *d_table, int64_t ldt, void *stream) {
+  if (!d_node_off || !d_table || (num_roots && !d_rows)) return set_error(SG_ERR_INVALID, "sl_pool_grad_table: null argument");
+  if (mode != 0 && mode != 2) return set_error(SG_ERR_INVALID, "sl_pool_grad_table: mode %d (mean 0 / sum 2: the max's gradient is not one row per subgraph)", mode);
+  if (num_subg == 0 || F == 0) return SG_OK;
+  hipLaunchKernelGGL(pool_grad_table_kernel, dim3(num_subg + num_roots), dim3(64), 0, (hipStream_t)stream, d_dout, lddo, d_droots, lddr,
+                     d_node_off, num_subg, d_rows, num_roots, n, F, mode, d_table, ldt);
   SHD_HIP(hipGetLastError());
   return SG_OK;
 }

@@ -1125,9 +1125,11 @@ class ChainLink:
         self.rows = None             # int32 row ids outside which the dZ in ``buf`` is zero (left by a row-sparse top pass), or None
         self.compact = None          # (dZs[T] [t, F], dZn[T] with a zero row behind [t + 1, F], plan): dZ on the rows T only, no ``buf``
         # dual-output lower layer (round 6): its PLAIN output feeds a read-out (ops.pool_and_roots), whose backward leaves the dense
-        # gradient here -- autograd carries ``plain_dummy`` -- for the layer above's epilogue to add unmasked (sl_gemm_an_bwd_plain)
+        # gradient here -- autograd carries ``plain_dummy`` -- for the layer above's epilogue to add unmasked (sl_gemm_an_bwd_plain).
+        # ``plain_index`` set: ``plain_grad`` is the [P + K, F] TABLE of a mean / sum pooling read-out's gradient and row i's gradient
+        # is plain_grad[plain_index[i]] (POOL_GRAD_TABLE: the [n, F] expansion is never written)
         self.dual = False
-        self.plain_grad = self.plain_dummy = None
+        self.plain_grad = self.plain_dummy = self.plain_index = None
 
     def publish(self, Zs, Zn, biases, sc, of, act, drop, stats=None):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
@@ -1138,8 +1140,19 @@ class ChainLink:
         self.published = self.filled = False
         self.Zs = self.Zn = self.biases = self.sc = self.of = self.stats = self.rows = self.compact = None
         self.buf = self.dsc = self.dof = self.dbi = self.partial = self.dummy = self.amax = None
-        self.plain_grad = self.plain_dummy = None
+        self.plain_grad = self.plain_dummy = self.plain_index = None
 
+    def plain_dense(self):
+        """The plain output's gradient as an [n, F] tensor (a consumer that does not take the table form)."""
+        if self.plain_index is None:
+            return self.plain_grad
+        return self.plain_grad.index_select(0, self.plain_index.long())
+
+
+# The pooled read-out's gradient reaches a chained dual-output layer as a table [subgraphs + roots, F] and a row map (mean / sum
+# pooling: every non-root row of a subgraph receives the same gradient row), not as the [n, F] tensor segment_pool_bwd writes:
+# products-ppr-sage5 spends 59 us per layer writing that tensor and ~35 us reading it back.  False: the dense form.
+POOL_GRAD_TABLE = True
 
 # Dual-output GraphSAGE layers (a read-out that reads every layer: residue max / concat, mean / max pooling) chain their backward
 # passes too: the lower layer's act + norm backward rides in the upper layer's input-gradient product, the plain output's gradient
@@ -1503,7 +1516,7 @@ class _SageDense(torch.autograd.Function):
             if (up is not None and up.dual and up.plain_grad is not None and douts[0] is not None and up.plain_dummy is not None
                     and douts[0].data_ptr() == up.plain_dummy.data_ptr()):
                 # the pooling node left the plain gradient on the link but the layer above did not chain: it is consumed here
-                douts = (up.plain_grad,) + tuple(douts[1:])
+                douts = (up.plain_dense(),) + tuple(douts[1:])
             d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
             if _is_dual(drop):
                 d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
@@ -1518,9 +1531,10 @@ class _SageDense(torch.autograd.Function):
         chain = down is not None and want_dx and down.Zs.shape == (n, Fi) and Fo % 32 == 0
         if chain and down.dual:
             # (the plain output's gradient must be on the link by now -- the read-out's nodes run before any conv layer's -- and dense)
-            pg = down.plain_grad
-            chain = bool(CHAIN_DUAL and pg is not None and pg.shape == (n, Fi) and pg.stride(1) == 1 and pg.stride(0) == Fi
-                         and pg.data_ptr() % 16 == 0 and 128 < Fi <= 256)
+            pg, pi = down.plain_grad, down.plain_index
+            chain = bool(CHAIN_DUAL and pg is not None and pg.dim() == 2 and pg.shape[1] == Fi and pg.stride(1) == 1 and pg.stride(0) == Fi
+                         and pg.data_ptr() % 16 == 0 and 128 < Fi <= 256
+                         and (pg.shape[0] == n if pi is None else (pi.numel() == n and pi.dtype == torch.int32 and pi.is_contiguous())))
         below = None
         if chain:
             down.buf = torch.empty(n, 3 * Fi, **f32)
@@ -1533,7 +1547,8 @@ class _SageDense(torch.autograd.Function):
                                      down.sc.data_ptr(), down.of.data_ptr(), down.act, float(down.drop[0]), int(down.drop[1]), Fi,
                                      down.buf.data_ptr(), down.dsc.data_ptr(), down.dof.data_ptr(), opt(down.dbi),
                                      down.partial.data_ptr(), down.amax.data_ptr(), opt(down.stats),
-                                     down.plain_grad.data_ptr() if down.dual else None)
+                                     down.plain_grad.data_ptr() if down.dual else None,
+                                     down.plain_index.data_ptr() if (down.dual and down.plain_index is not None) else None, Fi)
         dX = torch.empty(n, Fi, **f32) if (want_dx and not chain) else None
         # dZ non-zero on a few rows only (the layer above ran its row-sparse pass): dWs = dZs[T]^T X[T], dWn = dZn[T]^T (A X)[T] on
         # those rows (21 k of 289 k) instead of the paired kernel over all of them
@@ -2607,6 +2622,7 @@ class _PoolAndRoots(torch.autograd.Function):
     layer -- a zero-filled index_put and the pooling backward -- plus the pass that adds them.  Here the pooling backward
     writes the dense gradient once and the few root rows are added in place."""
     calls = 0
+    table_calls = 0          # backward passes that handed a gradient TABLE to the chain (POOL_GRAD_TABLE)
 
     @staticmethod
     def forward(ctx, X, node_off, rows, mode, link=None):
@@ -2623,6 +2639,14 @@ class _PoolAndRoots(torch.autograd.Function):
         ctx.mode, ctx.n = mode, int(X.shape[0])
         ctx.save_for_backward(node_off, am if am is not None else node_off, rows)
         ctx.set_materialize_grads(False)
+        # (what the nodes of one read-out share in their backward passes: the row -> table-row map of POOL_GRAD_TABLE, built once)
+        ctx.shared = getattr(node_off, "_shd_pool_shared", None)
+        if ctx.shared is None:
+            ctx.shared = {}
+            try:
+                node_off._shd_pool_shared = ctx.shared
+            except Exception:
+                pass
         _PoolAndRoots.calls += 1
         return out, X.index_select(0, rows)
 
@@ -2632,6 +2656,29 @@ class _PoolAndRoots(torch.autograd.Function):
         P = int(node_off.numel()) - 1
         F = int((dout if dout is not None else droots).shape[1])
         dev = node_off.device
+        link = ctx.link
+        hand_over = link is not None and link.published and link.dual and CHAIN_DUAL and link.plain_grad is None
+        if hand_over and POOL_GRAD_TABLE and ctx.mode != 1 and P > 0 and 128 < F <= 256 and F % 4 == 0:
+            # mean / sum pooling: one gradient row per subgraph (+ one per root) -- the chained layer above reads the table through a
+            # row map instead of an [n, F] tensor this node would write and it would read (sl_pool_grad_table)
+            lib = _lib.load()
+            K = int(rows.numel())
+            key = ("index", rows.data_ptr(), K, ctx.n)
+            index = ctx.shared.get(key)
+            if index is None:
+                index = torch.empty(max(ctx.n, 1), dtype=torch.int32, device=dev)[:ctx.n]
+                check(lib.sl_pool_grad_rows(node_off.data_ptr(), P, rows.data_ptr(), K, ctx.n, index.data_ptr(), _stream(node_off)))
+                ctx.shared[key] = index
+            d_o = _f32c(dout).contiguous() if dout is not None else None
+            d_r = _f32c(droots).contiguous() if droots is not None else None
+            table = torch.empty(P + K, F, dtype=torch.float32, device=dev)
+            check(lib.sl_pool_grad_table(d_o.data_ptr() if d_o is not None else None, F, d_r.data_ptr() if d_r is not None else None, F,
+                                         node_off.data_ptr(), P, rows.data_ptr(), K, ctx.n, F, ctx.mode, table.data_ptr(), F,
+                                         _stream(node_off)))
+            link.plain_grad, link.plain_index = table, index
+            link.plain_dummy = placeholder(ctx.n, F, dev)
+            _PoolAndRoots.table_calls += 1
+            return link.plain_dummy, None, None, None, None
         if dout is not None:
             dout = _f32c(dout)
             dX = torch.empty(ctx.n, F, dtype=torch.float32, device=dev)
@@ -2642,8 +2689,7 @@ class _PoolAndRoots(torch.autograd.Function):
             dX = torch.zeros(ctx.n, F, dtype=torch.float32, device=dev)
         if droots is not None:
             dX.index_add_(0, rows, droots.to(dX.dtype))       # (the roots of a batch are distinct rows: no two adds meet)
-        link = ctx.link
-        if link is not None and link.published and link.dual and CHAIN_DUAL and link.plain_grad is None:
+        if hand_over:
             # X is the plain output of a dual-output GraphSAGE layer that chains its backward pass: the gradient stays on the link
             # (the layer above adds it in its epilogue, or the layer itself picks it up), autograd carries a storage-less placeholder
             link.plain_grad = dX

@@ -2111,6 +2111,84 @@ def test_dual_output_layers_chain_their_backward_passes(n_layers, act, residue, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,F,with_dout,with_droots", [("mean", 256, True, True), ("sum", 192, True, True), ("mean", 256, False, True),
+                                                          ("mean", 132, True, False)])
+def test_pool_gradient_table_is_the_dense_pooling_backward_row_for_row(mode, F, with_dout, with_droots):
+    """Round 6: the gradient of (mean | sum pooling of X, X[rows]) -- shaDow/layers.py:154-199 -- as a table [subgraphs + roots, F] and
+    a row map (sl_pool_grad_table / sl_pool_grad_rows).  table[index[i]] is BIT FOR BIT row i of what the dense path builds
+    (sl_segment_pool_bwd, then index_add_ of the roots' gradient): empty subgraphs, a one-row subgraph, a root listed twice (a link
+    whose end points coincide: both gradients land on the row, in index order) and a root that is its subgraph's last row included."""
+    from shadow_gnn_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    sizes = torch.tensor([7, 0, 1, 150, 0, 33, 64, 2, 0], dtype=torch.int32)
+    off = torch.zeros(sizes.numel() + 1, dtype=torch.int32); off[1:] = torch.cumsum(sizes, 0)
+    P, n = int(sizes.numel()), int(off[-1])
+    rows = torch.tensor([0, 7, 8, 8, 157, 190, 255, 256, 256], dtype=torch.int64)      # (row 8 twice, row 256 twice; 157 = last row of subgraph 3)
+    K = int(rows.numel())
+    dout = torch.randn(P, F, generator=g).to(dev) if with_dout else None
+    droots = torch.randn(K, F, generator=g).to(dev) if with_droots else None
+    off_d, rows_d = off.to(dev), rows.to(dev)
+    m = ops.POOL_MODE[mode]
+    # dense reference: the kernel the table replaces, then the roots' rows one after the other (index order)
+    if dout is not None:
+        dX = torch.empty(n, F, device=dev)
+        _lib.check(lib.sl_segment_pool_bwd(dout.data_ptr(), F, off_d.data_ptr(), P, F, m, None, dX.data_ptr(), F, None))
+    else:
+        dX = torch.zeros(n, F, device=dev)
+    if droots is not None:
+        for k in range(K):
+            dX[rows[k]] += droots[k]
+    index = torch.empty(n, dtype=torch.int32, device=dev)
+    table = torch.full((P + K, F), float("nan"), device=dev)
+    _lib.check(lib.sl_pool_grad_rows(off_d.data_ptr(), P, rows_d.data_ptr(), K, n, index.data_ptr(), None))
+    _lib.check(lib.sl_pool_grad_table(dout.data_ptr() if dout is not None else None, F, droots.data_ptr() if droots is not None else None, F,
+                                      off_d.data_ptr(), P, rows_d.data_ptr(), K, n, F, m, table.data_ptr(), F, None))
+    torch.cuda.synchronize()
+    idx = index.long().cpu()
+    seg = torch.repeat_interleave(torch.arange(P), sizes.long())
+    last = {int(r): k for k, r in enumerate(rows.tolist())}
+    want = torch.tensor([P + last[i] if i in last else int(seg[i]) for i in range(n)])
+    assert torch.equal(idx, want)
+    got = table.index_select(0, index.long())
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, dX)
+    # max pooling has no such table
+    assert lib.sl_pool_grad_table(None, F, None, F, off_d.data_ptr(), P, rows_d.data_ptr(), K, n, F, 1, table.data_ptr(), F, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,act,residue,pooling,p_drop,dropedge", [(4, "relu", "max", "mean", 0.4, 0.05), (3, "elu", "concat", "sum", 0.25, 0.0),
+                                                                           (5, "relu", "concat", "mean", 0.2, 0.1)])
+def test_pooled_read_out_gradient_reaches_the_chain_as_a_table(n_layers, act, residue, pooling, p_drop, dropedge):
+    """Round 6: with mean / sum pooling the plain outputs' gradients are handed to the chained layers as a table + row map
+    (ops.POOL_GRAD_TABLE; sl_gemm_an_bwd_plain's d_plain_row) instead of dense [n, F] tensors: the epilogue adds the same fp32 value to
+    the same product, so the step is BIT-IDENTICAL to the dense hand-over -- loss, predictions and every parameter gradient -- and
+    every pooling node below the top layer's takes the table path (the top layer's own node too: its layer expands the table itself)."""
+    from shadow_gnn_amd import ops
+    res, calls = [], []
+    for on in (False, True):
+        prev = ops.POOL_GRAD_TABLE
+        ops.POOL_GRAD_TABLE = on
+        c0 = ops._PoolAndRoots.table_calls
+        try:
+            res.append(_sage_stack_step(n_layers, 256, p_drop, 43, chain=True, fused=True, B=96, act=act, dropedge=dropedge, pooling=pooling,
+                                        residue=residue))
+        finally:
+            ops.POOL_GRAD_TABLE = prev
+        calls.append(ops._PoolAndRoots.table_calls - c0)
+    (l0, p0, g0, c0), (l1, p1, g1, c1) = res
+    assert calls[0] == 0 and calls[1] >= n_layers - 1, calls
+    assert c0 == c1 == (n_layers, n_layers - 1)
+    assert l0 == l1
+    assert torch.equal(p0, p1)
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("aggr,n_layers,pooling,sparse_top", [("sage", 3, "center", True), ("sage", 3, "mean", False), ("gcn", 2, "center", False)])
 def test_long_row_batches_aggregate_on_the_pipelined_kernel(aggr, n_layers, pooling, sparse_top):
     """Round 5: a batch whose rows may be long (DeviceCSR.row_entries_bound > 64: the root rows of top-k PPR subgraphs) aggregates its
