@@ -469,6 +469,16 @@ int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, 
                            float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                            const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
                            int dz_compact, int t_branch, float *d_t_out, void *stream);
+/* (ABI 24) sl_act_norm_bwd with the output gradient given as a TABLE: row i's gradient is d_dout[d_dout_map[i], :] -- the gradient of
+ * a mean / sum pooling read-out (shaDow/layers.py:166-183) has one row per subgraph (+ one per root), sl_pool_grad_table builds that
+ * table and the map; the [n, F] expansion is never written.  Same arithmetic on the same values: bit-identical to sl_act_norm_bwd
+ * on the expanded tensor.  d_dout_dropped (dual mode) stays a dense [n, F] tensor.                                                */
+int sl_act_norm_bwd_map(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                        const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                        uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, const uint32_t *d_dout_map,
+                        float *const *d_dZ, const int64_t *lddz, float *d_dscale, float *d_doffset, float *d_dbias,
+                        float *d_partial, float drop_p, uint64_t drop_seed, const float *d_dout_dropped, int64_t lddo_dropped,
+                        float *d_dz0_amax, void *stream);
 int sl_act_norm_bwd(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                     const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                     uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, float *const *d_dZ,
@@ -647,7 +657,9 @@ int sl_gemm_an_bwd_plain(const float *d_A, int64_t lda, const float *d_a_amax, c
  * it -- with it (and n >= 32768, Fin = Fout = 256) the two weight gradients run on two fp16 pieces (sl_gemm_tn_f16), the
  * neighbour branch as dWn = (A^T dZn)^T X over the transposed aggregate of the input-gradient product (d_AX is then not
  * read, and d_tn_partial must hold TWICE the floats of sl_gemm_tn_f32's: sl_gemm_tn_f16_pair).
- * sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, stream).
+ * d_dout_map (ABI 24; may be NULL; dz_ready = 0, no d_dout_rows): row i's d_dout is row d_dout_map[i] of the table d_dout points to
+ * (sl_pool_grad_table: a pooled read-out's gradient), sl_act_norm_bwd_map.
+ * sl_sage_bwd == sl_sage_bwd_chain(..., 0, NULL, NULL, NULL, 0, NULL, NULL, stream).
  * d_dWs == d_dWn == NULL (round 4): the weight gradients are not computed (a caller that knows dZ to be non-zero on a few rows
  * only forms them on those rows itself); d_tn_partial may then be NULL too.                                                  */
 typedef struct {
@@ -676,7 +688,8 @@ int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64_t ldx, con
                       float drop_p, uint64_t drop_seed, const float *d_dout, const float *d_dout_dropped, float *d_dX,
                       float *d_dWs, float *d_dWn, float *d_dbias, float *d_dscale, float *d_doffset, float *d_buf,
                       float *d_an_partial, float *d_tn_partial, void *d_pack, int dz_ready, const sl_sage_below *below,
-                      float *d_dzs_amax, const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, void *stream);
+                      float *d_dzs_amax, const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax,
+                      const uint32_t *d_dout_map, void *stream);
 
 /* A whole stack of chained GraphSAGE layers per call -- the conv loop of DeepGNN.forward (shaDow/models.py:193-197) over
  * GraphSAGE layers (layers.py:471-483) under residue 'none' + centre pooling (layers.py:159-163), forward and backward.  The

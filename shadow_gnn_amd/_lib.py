@@ -162,7 +162,7 @@ SIGNATURES = {
     "sl_sage_chain_partial_floats": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sl_sage_bwd_chain": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P,
                                      _P, C.c_int64, _P, _P, _P, C.c_int, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P, _P]),
+                                     _P, C.c_int, C.POINTER(SlSageBelow), _P, _P, C.c_uint32, _P, _P, _P]),
     "sl_sage_stack_pack_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.POINTER(SlSageStackLayer)]),
     "sl_sage_stack_fwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_int, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P]),
     "sl_sage_stack_bwd": (C.c_int, [C.POINTER(SlNormAdj), _P, C.c_int64, _P, C.c_uint32, C.POINTER(SlSageStackLayer), _P, _P, C.c_uint32,
@@ -253,6 +253,9 @@ SIGNATURES = {
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
                                    C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, C.c_int,
                                    C.c_int, _P, _P]),
+    "sl_act_norm_bwd_map": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, _P,
+                                      C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),
 }
 
 _lib = None

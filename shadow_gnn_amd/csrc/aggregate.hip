@@ -780,6 +780,7 @@ struct ActNormParams {
   // backward, optional: the output gradient is given for `n` SELECTED rows only (dout / dout2 are [n, F] compact, row i of
   // them belongs to row row_idx[i] of Z / dZ / the dropout mask) -- a read-out that takes a few rows of the layer's output
   const uint32_t *row_idx;
+  const uint32_t *dout_map;      // backward, optional [n]: row i's output gradient is dout[dout_map[i], :] (a pooled read-out's gradient table)
   // ... and dZ / dz0_amax are compact as well ([n, F] in the order of row_idx) instead of scattered into full-height buffers
   int dz_compact;
   // backward, optional (vector kernel): t_out[row, F / seg] = sum over each segment of dZ[t_branch] * Z[t_branch] -- the GAT
@@ -823,13 +824,16 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
   uint64_t r = (uint64_t)blockIdx.x * rows_per_block + sub;
   // (backward over selected rows: r counts the rows of the compact gradient, RR(r) is the row of Z / dZ / the mask)
   auto RR = [&](uint64_t i) -> uint64_t { return (BWD && p.row_idx) ? (uint64_t)p.row_idx[i] : i; };
+  auto DR = [&](uint64_t i) -> uint64_t { return (BWD && p.dout_map) ? (uint64_t)p.dout_map[i] : i; };
   float4 zn[NB], dyn = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int b = 0; b < NB; b++) zn[b] = make_float4(0.f, 0.f, 0.f, 0.f);
   // (backward only: the forward kernel runs at full occupancy and measured slower with it)
   constexpr bool kPrefetch = BWD;
+  // (a gradient table's row map is read one row further ahead than the rows themselves: no second round trip in front of dyn)
+  uint32_t mnext = (BWD && p.dout_map && r + rstep < p.n) ? p.dout_map[r + rstep] : 0u;
   if (kPrefetch && r < p.n && lane_on) {
-    if (BWD && p.dout) dyn = ld4s(p.dout + (int64_t)r * p.lddo + f);
+    if (BWD && p.dout) dyn = ld4s(p.dout + (int64_t)DR(r) * p.lddo + f);
 #pragma unroll
     for (int b = 0; b < NB; b++) zn[b] = ld4s(p.Z[b] + (int64_t)RR(r) * p.ldz[b] + f);
   }
@@ -842,10 +846,11 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
 #pragma unroll
       for (int b = 0; b < NB; b++) zc[b] = zn[b];
       if (r + rstep < p.n && lane_on) {
-        if (BWD && p.dout) dyn = ld4s(p.dout + (int64_t)(r + rstep) * p.lddo + f);
+        if (BWD && p.dout) dyn = ld4s(p.dout + (int64_t)(p.dout_map ? (uint64_t)mnext : r + rstep) * p.lddo + f);
 #pragma unroll
         for (int b = 0; b < NB; b++) zn[b] = ld4s(p.Z[b] + (int64_t)RR(r + rstep) * p.ldz[b] + f);
       }
+      if (BWD && p.dout_map && r + 2 * rstep < p.n) mnext = p.dout_map[r + 2 * rstep];
     } else {
 #pragma unroll
       for (int b = 0; b < NB; b++) zc[b] = lane_on ? ld4s(p.Z[b] + (int64_t)rr * p.ldz[b] + f) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1038,7 +1043,7 @@ __global__ void act_norm_generic_kernel(ActNormParams p) {
             o[k] = (b == 0) ? y : o[k] + y;
           }
         } else {
-          const float *dy = p.dout + (int64_t)r * p.lddo + s0;
+          const float *dy = p.dout + (int64_t)(p.dout_map ? p.dout_map[r] : (uint32_t)r) * p.lddo + s0;
           float a1 = 0.f, a2 = 0.f;
           for (uint32_t k = lane; k < p.seg; k += 64) {
             const float xh = (act_fwd(p.act[b], SHD_ZB(k)) - mean) * rstd;
@@ -1671,13 +1676,14 @@ extern "C" int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64
                                 dz_compact, -1, nullptr, stream_);
 }
 
-extern "C" int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
-                                      const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
-                                      uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
-                                      float *const *d_dZ, const int64_t *lddz, float *d_dscale,
-                                      float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
-                                      const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
-                                      int dz_compact, int t_branch, float *d_t_out, void *stream_) {
+static int act_norm_bwd_impl(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                             const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                             uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                             float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                             float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                             const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                             int dz_compact, int t_branch, float *d_t_out, const uint32_t *d_dout_map, void *stream_) {
+  if (d_dout_map && (!d_dout || d_row_idx)) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_map: a gradient table needs d_dout and no row selection");
   if (d_t_out && (t_branch < 0 || t_branch >= nb || act[t_branch] != 0 || (d_bias && d_bias[t_branch])))
     return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_rows_t: the segment dots are provided for an identity branch without a bias");
   if (dz_compact && !d_row_idx) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_rows: compact dZ without row indices");
@@ -1713,10 +1719,35 @@ extern "C" int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int
   if (d_dz0_amax && !d_dZ[0]) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of a gradient that is not written");
   p.dz0_amax = d_dz0_amax;
   p.row_idx = d_row_idx;
+  p.dout_map = d_dout_map;
   p.dz_compact = dz_compact ? 1 : 0;
   p.t_out = d_t_out; p.t_branch = d_t_out ? t_branch : -1;
   bool vec = false;
   if ((rc = act_norm_launch(p, true, st, &vec, d_row_idx != nullptr || d_t_out != nullptr)) != SG_OK) return rc;
   // (the general kernel does not write the row maxima: one more pass)
   return (d_dz0_amax && !vec) ? sl_row_amax(d_dZ[0], lddz[0], n, F, d_dz0_amax, st) : SG_OK;
+}
+
+extern "C" int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                                      const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                                      uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
+                                      float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                                      float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                                      const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
+                                      int dz_compact, int t_branch, float *d_t_out, void *stream_) {
+  return act_norm_bwd_impl(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale, d_doffset,
+                           d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, d_row_idx, dz_compact, t_branch,
+                           d_t_out, nullptr, stream_);
+}
+
+// ... with the output gradient given as a table: row i's gradient is d_dout[d_dout_map[i], :] (sl_pool_grad_table)
+extern "C" int sl_act_norm_bwd_map(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
+                                   const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
+                                   uint32_t seg, float out_scale, const float *d_dout, int64_t lddo, const uint32_t *d_dout_map,
+                                   float *const *d_dZ, const int64_t *lddz, float *d_dscale,
+                                   float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
+                                   const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, void *stream_) {
+  return act_norm_bwd_impl(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale, d_doffset,
+                           d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, nullptr, 0, -1, nullptr,
+                           d_dout_map, stream_);
 }

@@ -211,7 +211,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
                                  const float *d_dout_dropped, float *d_dX, float *d_dWs, float *d_dWn, float *d_dbias,
                                  float *d_dscale, float *d_doffset, float *d_buf, float *d_an_partial, float *d_tn_partial,
                                  void *d_pack, int dz_ready, const sl_sage_below *below, float *d_dzs_amax,
-                                 const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, void *stream) {
+                                 const uint32_t *d_dout_rows, uint32_t num_dout_rows, const float *d_x_amax, const uint32_t *d_dout_map,
+                                 void *stream) {
+  if (d_dout_map && (d_dout_rows || dz_ready || !d_dout)) return set_error(SG_ERR_INVALID, "sl_sage_bwd: a gradient table comes with d_dout alone");
   // (d_dWs == d_dWn == NULL: the caller computes the weight gradients itself -- on the few rows dZ is non-zero on, see
   //  ops._SageDense: the layer below a row-sparse top pass)
   const bool want_dw = d_dWs || d_dWn;
@@ -262,9 +264,9 @@ extern "C" int sl_sage_bwd_chain(const sl_norm_adj *adj, const float *d_X, int64
       }
     } else {
       SHD_PROF_FMT((2 * 2 + 1) * 4.0 * n * Fout, 0, stream, "act_norm_bwd_nb%d_F%u", 2, Fout);
-      if ((rc = sl_act_norm_bwd(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, dZ, lddz, d_dscale,
-                                d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, join ? amx : nullptr,
-                                nullptr, stream)) != SG_OK)
+      if ((rc = sl_act_norm_bwd_map(2, Z, ldz, bias, acts, d_scale, d_offset, n, Fout, Fout, 1.0f, d_dout, Fout, d_dout_map, dZ, lddz, d_dscale,
+                                    d_doffset, d_dbias, d_an_partial, drop_p, drop_seed, d_dout_dropped, Fout, join ? amx : nullptr,
+                                    stream)) != SG_OK)
         return rc;
     }
   }
@@ -331,7 +333,7 @@ extern "C" int sl_sage_bwd(const sl_norm_adj *adj, const float *d_X, int64_t ldx
                            void *d_pack, void *stream) {
   return sl_sage_bwd_chain(adj, d_X, ldx, d_AX, ldax, d_Zs, d_Zn, Fin, Fout, d_Ws, ldws, d_bs, d_Wn, ldwn, d_bn, d_scale, d_offset, act,
                            drop_p, drop_seed, d_dout, d_dout_dropped, d_dX, d_dWs, d_dWn, d_dbias, d_dscale, d_doffset, d_buf,
-                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, nullptr, 0, nullptr, stream);
+                           d_an_partial, d_tn_partial, d_pack, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -402,7 +404,7 @@ extern "C" int sl_sage_stack_bwd(const sl_norm_adj *adj, const float *d_X0, int6
                                 y.ldwn, y.bn, y.scale, y.offset, y.act, y.drop_p, y.drop_seed, top ? d_dout : nullptr, nullptr,
                                 l == 0 ? d_dX0 : nullptr, y.dWs, y.dWn, y.dbias, y.dscale, y.doffset, buf, d_an_partial, d_tn_partial, d_pack,
                                 top ? 0 : 1, l > 0 ? &below : nullptr, top ? nullptr : am, top ? d_dout_rows : nullptr,
-                                top ? num_dout_rows : 0, l ? ly[l - 1].out_amax : d_x0_amax, stream)) != SG_OK)
+                                top ? num_dout_rows : 0, l ? ly[l - 1].out_amax : d_x0_amax, nullptr, stream)) != SG_OK)
       return rc;
   }
   return SG_OK;
@@ -441,7 +443,7 @@ extern "C" int sl_sage_stack_bwd_ready(const sl_norm_adj *adj, const float *d_X0
     if ((rc = sl_sage_bwd_chain(adj, X, l ? (int64_t)ly[l - 1].Fout : ldx0, y.AX, y.ldax, y.Zs, y.Zn, y.Fin, y.Fout, y.Ws, y.ldws, y.bs, y.Wn,
                                 y.ldwn, y.bn, y.scale, y.offset, y.act, y.drop_p, y.drop_seed, nullptr, nullptr,
                                 l == 0 ? d_dX0 : nullptr, y.dWs, y.dWn, y.dbias, y.dscale, y.doffset, buf, nullptr, d_tn_partial, d_pack,
-                                1, l > 0 ? &below : nullptr, am, nullptr, 0, l ? ly[l - 1].out_amax : d_x0_amax, stream)) != SG_OK)
+                                1, l > 0 ? &below : nullptr, am, nullptr, 0, l ? ly[l - 1].out_amax : d_x0_amax, nullptr, stream)) != SG_OK)
       return rc;
   }
   return SG_OK;

@@ -102,6 +102,7 @@ class shaDowLayer(nn.Module):
         # set per step by DeepGNN._plan_dropout_fusion: the next layer is the ONLY reader of this layer's output, so the two
         # layers' backward passes may be chained (ops.ChainLink; GraphSAGE only)
         self.chain_next = False
+        self.pool_only = False
         # True (set per step by DeepGNN._plan_dropout_fusion): only a row-selecting read-out reads this layer's output
         self.roots_only = False
         # True (set per step by DeepGNN._plan_dropout_fusion): only the next GAT layer's paired Linear reads this output
@@ -282,14 +283,14 @@ class GraphSAGE(shaDowLayer):
         if fused and isinstance(feat_in, ops.LazyRows):
             # layer 0 of the fast path: gather + input dropout in one pass (or inside the aggregation kernel)
             feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
-                                                 self.scale, self.offset, in_dropout=self._in_p(), chain_next=self.chain_next, roots_only=self.roots_only,
+                                                 self.scale, self.offset, in_dropout=self._in_p(), chain_next=self.chain_next, roots_only=self.roots_only, pool_only=self.pool_only,
                                                  **self._drop_kw()))
             return feat_out, adj_norm, True, 0.
         feat_in = self.in_dropout(feat_in)
         if fused:
             # aggregate + both Linears + act/norm/add as one autograd node (single K = 2F input-gradient GEMM)
             feat_out = self._emit(ops.sage_dense(feat_in, adj_norm, self.f_lin_self, self.f_lin_neigh, self.act_name,
-                                                 self.scale, self.offset, chain_next=self.chain_next, roots_only=self.roots_only, **self._drop_kw()))
+                                                 self.scale, self.offset, chain_next=self.chain_next, roots_only=self.roots_only, pool_only=self.pool_only, **self._drop_kw()))
         else:
             feat_neigh = self.spmm(adj_norm, feat_in)
             feat_out = self.f_lin_act_norm([feat_in, feat_neigh], [self.f_lin_self, self.f_lin_neigh],

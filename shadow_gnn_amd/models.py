@@ -300,7 +300,7 @@ class DeepGNN(nn.Module):
         dual = rp.type_res != 'none'
         # (the plan only depends on these: nn.Module attribute writes cost ~2.5 us each, 25 of them per step otherwise)
         # (layer identities and the task are part of it: a swapped conv layer or a changed read-out re-plans)
-        key = (fuse_ok, dual, center_only, ops.CHAIN_DUAL, self.prediction_task, tuple((id(md), float(getattr(md, 'dropout', 0.0))) for md in layers_i))
+        key = (fuse_ok, dual, center_only, ops.CHAIN_DUAL, rp.type_pool, self.prediction_task, tuple((id(md), float(getattr(md, 'dropout', 0.0))) for md in layers_i))
         plans = self.__dict__.setdefault('_fusion_plan_keys', {})
         if plans.get(i) == key:
             return
@@ -320,6 +320,9 @@ class DeepGNN(nn.Module):
                                  and isinstance(nxt, layers.GraphSAGE))
             # ... and the LAST layer's output only by the read-out's row select: its gradient travels as (rows, values)
             # (node tasks: one root per subgraph, so the selected rows are distinct)
+            # ... or only by a pooled read-out (ops.pool_and_roots: pooled rows + root rows from one node): its gradient may arrive as a
+            # table of one row per subgraph and root (ops.POOL_GRAD_TABLE)
+            md.pool_only = bool(nxt is None and rp.type_pool in rp.POOLED and getattr(rp, 'dim_in', 1) != 0 and isinstance(md, layers.GraphSAGE))
             md.roots_only = bool(center_only and nxt is None and isinstance(md, (layers.GraphSAGE, layers.GAT))
                                  and self.prediction_task == 'node')
             # GAT below GAT, nothing else reads this output and the next layer's input dropout is fused into it (or absent): the

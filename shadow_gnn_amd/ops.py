@@ -1130,6 +1130,9 @@ class ChainLink:
         # is plain_grad[plain_index[i]] (POOL_GRAD_TABLE: the [n, F] expansion is never written)
         self.dual = False
         self.plain_grad = self.plain_dummy = self.plain_index = None
+        # the LAST layer of a stack under a pooled read-out: no layer above, the link only carries the read-out's gradient table to
+        # the layer's own act + norm backward (sl_act_norm_bwd_map)
+        self.plain_only = False
 
     def publish(self, Zs, Zn, biases, sc, of, act, drop, stats=None):
         self.Zs, self.Zn, self.biases, self.sc, self.of, self.act, self.drop = Zs, Zn, biases, sc, of, int(act), drop
@@ -1382,7 +1385,7 @@ class _SageDense(torch.autograd.Function):
         if AX is None:
             ctx.x_amax = get_row_amax(X)        # (the backward's weight gradients scale their fp16 pieces by it, sl_gemm_tn_f16)
             # (row statistics for the chained backward of this layer: only when a layer above will chain into it)
-            want_stats = (link_up is not None and CHAIN_SAGE_BWD and (not _is_dual(drop) or (CHAIN_DUAL and F > 128)) and ROW_STATS_HANDOVER
+            want_stats = (link_up is not None and not link_up.plain_only and CHAIN_SAGE_BWD and (not _is_dual(drop) or (CHAIN_DUAL and F > 128)) and ROW_STATS_HANDOVER
                           and _lib.load().sl_gemm_act_norm_supported(F, X.shape[1]) and F % 32 == 0)
             AX, Zs, Zn, out, ctx_stats = _SageDense._fused_forward(X, adj, Ws, Wn, bsc, sc, of, acts, drop, want_stats)
             _SageDense.fused_calls += 1
@@ -1481,7 +1484,7 @@ class _SageDense(torch.autograd.Function):
                 raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
                                    "(its gradient is not the placeholder); set ops.ROOTS_SPARSE_GRAD = False")
             return _SageDense._sparse_top_backward(ctx, lr0, down, X, AX, Ws, Wn, Zs, Zn, sc, of, biases, acts, has_b)
-        d0 = d1 = dout_rows = None
+        d0 = d1 = dout_rows = dout_map = None
         if dz_ready:
             if up.dual:
                 # (dual-output layer: the dropped output's gradient must be the chain's placeholder, the plain output's the one
@@ -1513,10 +1516,16 @@ class _SageDense(torch.autograd.Function):
                     raise RuntimeError("sparse read-out gradient: the layer's output has a consumer besides the read-out "
                                        "(its gradient is not the placeholder); set ops.ROOTS_SPARSE_GRAD = False")
                 dout_rows, douts = lr.rows32, (lr.grad,)
-            if (up is not None and up.dual and up.plain_grad is not None and douts[0] is not None and up.plain_dummy is not None
+            if (up is not None and (up.dual or up.plain_only) and up.plain_grad is not None and douts[0] is not None and up.plain_dummy is not None
                     and douts[0].data_ptr() == up.plain_dummy.data_ptr()):
                 # the pooling node left the plain gradient on the link but the layer above did not chain: it is consumed here
-                douts = (up.plain_dense(),) + tuple(douts[1:])
+                # (a gradient TABLE stays one when this layer's own act + norm backward can read through the row map)
+                if (up.plain_index is not None and dout_rows is None and lib.sl_act_norm_vector_layout(Fo, Fo)
+                        and up.plain_grad.stride(0) == Fo and up.plain_grad.data_ptr() % 16 == 0):
+                    dout_map = up.plain_index
+                    douts = (up.plain_grad,) + tuple(douts[1:])
+                else:
+                    douts = (up.plain_dense(),) + tuple(douts[1:])
             d0 = _f32c(douts[0]).contiguous() if douts[0] is not None else None
             if _is_dual(drop):
                 d1 = _f32c(douts[1]).contiguous() if douts[1] is not None else None
@@ -1573,7 +1582,7 @@ class _SageDense(torch.autograd.Function):
                                     C.byref(below) if below is not None else None,
                                     up.amax.data_ptr() if (dz_ready and up.amax is not None) else None,
                                     dout_rows.data_ptr() if dout_rows is not None else None,
-                                    int(dout_rows.numel()) if dout_rows is not None else 0, opt(ctx.x_amax), _stream(Zs)))
+                                    int(dout_rows.numel()) if dout_rows is not None else 0, opt(ctx.x_amax), opt(dout_map), _stream(Zs)))
         if dz_ready:
             up.release()
         if dout_rows is not None:
@@ -2508,12 +2517,13 @@ def gcn_dense(X: torch.Tensor, adj: "NormAdj", lin, act: str, scale: torch.Tenso
 
 def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Tensor,
                offset: torch.Tensor, out_dropout: float = 0.0, dual: bool = False, in_dropout: float = 0.0,
-               chain_next: bool = False, roots_only: bool = False):
+               chain_next: bool = False, roots_only: bool = False, pool_only: bool = False):
     """norm(act(lin_self(X))) + norm(act(lin_neigh(adj @ X))) -- GraphSAGE.forward (shaDow/layers.py:471-483).
     ``dual`` (with out_dropout > 0): returns (out, dropout(out)) from one kernel pass.  ``X`` may be a LazyRows
     (layer 0 of the fast path): gather and input dropout ``in_dropout`` then happen inside the aggregation kernel.
     ``chain_next``: the caller guarantees that ONLY the next GraphSAGE layer reads the returned tensor (see ChainLink);
-    ``roots_only``: ... that only a row-selecting read-out reads it (ops.select_roots, see RootsLink)."""
+    ``roots_only``: ... that only a row-selecting read-out reads it (ops.select_roots, see RootsLink); ``pool_only``: ... that only a
+    pooled read-out does (ops.pool_and_roots: its gradient may then arrive as a table, POOL_GRAD_TABLE)."""
     if act not in ACT_CODE:
         raise NotImplementedError(f"activation {act!r} is not available in the fused HIP kernel")
     F = lin_self.weight.shape[0]
@@ -2527,10 +2537,15 @@ def sage_dense(X, adj: "NormAdj", lin_self, lin_neigh, act: str, scale: torch.Te
     # chaining: a producer node left its ChainLink on the tensor it returned; ``chain_next`` asks this node to do the same
     link_down = getattr(X, "_shadow_chain", None) if torch.is_tensor(X) else None
     link_up = ChainLink() if (chain_next and (not dual or CHAIN_DUAL) and CHAIN_SAGE_BWD) else None
+    if link_up is None and pool_only and not dual and not chain_next and POOL_GRAD_TABLE and CHAIN_DUAL and CHAIN_SAGE_BWD and 128 < F <= 256:
+        link_up = ChainLink()
+        link_up.plain_only = True
     link_roots = RootsLink() if (roots_only and not dual and not chain_next and ROOTS_SPARSE_GRAD) else None
     res = _SageDense.apply(X, adj, lin_self.weight, lin_self.bias, lin_neigh.weight, lin_neigh.bias, scale, offset,
                            (code, code), _drop_arg(out_dropout, F, None, dual), lazy, float(in_dropout), link_down, link_up, link_roots)
-    if link_up is not None and link_up.published and torch.is_tensor(res):
+    if link_up is not None and link_up.published and link_up.plain_only and torch.is_tensor(res):
+        res._shadow_plain = link_up
+    elif link_up is not None and link_up.published and torch.is_tensor(res):
         res._shadow_chain = link_up
     elif link_up is not None and link_up.published and isinstance(res, tuple):
         # dual mode: the dropped output goes to the layer above (which finds the link on it), the plain one to the read-out
@@ -2658,6 +2673,11 @@ class _PoolAndRoots(torch.autograd.Function):
         dev = node_off.device
         link = ctx.link
         hand_over = link is not None and link.published and link.dual and CHAIN_DUAL and link.plain_grad is None
+        if (link is not None and link.published and link.plain_only and link.plain_grad is None
+                and not (POOL_GRAD_TABLE and CHAIN_DUAL and ctx.mode != 1 and P > 0 and 128 < F <= 256 and F % 4 == 0)):
+            link = None                              # (the last layer's link only ever carries a table)
+        elif link is not None and link.plain_only:
+            hand_over = link.published and link.plain_grad is None
         if hand_over and POOL_GRAD_TABLE and ctx.mode != 1 and P > 0 and 128 < F <= 256 and F % 4 == 0:
             # mean / sum pooling: one gradient row per subgraph (+ one per root) -- the chained layer above reads the table through a
             # row map instead of an [n, F] tensor this node would write and it would read (sl_pool_grad_table)
