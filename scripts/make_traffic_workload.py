@@ -28,7 +28,7 @@ LABELS = {
     },
     "products-ppr-sage5": {
         "gemm_act_norm_fwd_nb2_N256": "gemm_nt_fused_kernel<8 0 2 2 false>", "act_norm_bwd_nb2_F256": "act_norm_kernel<64 64 true 2>",
-        "spmm_F256": "spmm_pipe_kernel<4 16 64>", "gemm_nt_f16_N256": "gemm_nt_fused_kernel<8 2 1 1 false>",
+        "spmm_F256": "spmm_pipe_kernel<4 16 64>", "gemm_an_bwd_nb2_N256": "gemm_nt_fused_kernel<8 -1 1 2 false>",
         "gemm_tn_f16_pair_N256": "gemm_tn_f16_kernel", "segment_pool_F256": "segment_pool_fwd_kernel",
     },
     "arxiv-khop-sage5": {
