@@ -723,8 +723,8 @@ def main():
 OTHER_WORKLOADS = ("arxiv-khop-sage5", "products-ppr-sage5", "products-khop3-gat5")     # BASELINE.json configs[1], [2], [3] (per-GPU share)
 
 
-def other_workloads(budget_s, steps=10, warmup=3):
-    """`python bench.py --workload W --steps 10 --warmup 3` for the BASELINE configurations the main line is not quoted on,
+def other_workloads(budget_s, steps=24, warmup=8):
+    """`python bench.py --workload W --steps 24 --warmup 8` for the BASELINE configurations the main line is not quoted on,
     one sub-process each (fresh allocator / sampler state; the parent's graph stays resident -- 1.5 GB of 288), summarised to
     {ms_per_step, value, roofline_step.frac, dominant kernel + frac, host_busy}.  Sub-lines go to stderr as they finish."""
     import subprocess
