@@ -1,6 +1,7 @@
 #!/bin/bash
+# GPU box: the whole -m gpu suite, smoke(), then the default bench command timed (what the driver runs at round end)
 R="${GRAFT_REPO_ROOT:-$PWD}"
-O=$R/gpurun_out/r06full; mkdir -p $O
+O=$R/gpurun_out/suite; mkdir -p $O
 export PYTHONPATH=$R HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $R
 timeout 2400 python -m pytest tests -q -m gpu -x > $O/tests.log 2>&1; tail -4 $O/tests.log; grep -n "^E " $O/tests.log | head
