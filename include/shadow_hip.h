@@ -461,14 +461,16 @@ int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64_t *ldz, co
  * for an IDENTITY branch without a bias (vector layout only: sl_act_norm_vector_layout) -- for the GAT layer, whose aggregate N is
  * such a branch, the attention backward's t_i = dN_i . N_i per head (sl_gat_bwd's d_t).  The normalisation is invariant under
  * scaling of its input row, so this dot is S eps rstd^2 m2 (m2 = the segment mean of dy scale xhat the backward pass forms
- * anyway): written from that closed form, no extra reduction.  d_t_out NULL: as without.                                    */
+ * anyway): written from that closed form, no extra reduction.  d_t_out NULL: as without.  amax_branch (ABI 24): the branch whose
+ * dZ row maxima d_dz0_amax receives (0 in every other entry) -- the GAT tail asks for its second branch's (dz_self) without
+ * re-ordering the [nb, F] scale / offset rows.                                                                                  */
 int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
                            const int *act, const float *d_scale, const float *d_offset, uint32_t n, uint32_t F,
                            uint32_t seg, float out_scale, const float *d_dout, int64_t lddo,
                            float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                            float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                            const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
-                           int dz_compact, int t_branch, float *d_t_out, void *stream);
+                           int dz_compact, int t_branch, float *d_t_out, int amax_branch, void *stream);
 /* (ABI 24) sl_act_norm_bwd with the output gradient given as a TABLE: row i's gradient is d_dout[d_dout_map[i], :] -- the gradient of
  * a mean / sum pooling read-out (shaDow/layers.py:166-183) has one row per subgraph (+ one per root), sl_pool_grad_table builds that
  * table and the map; the [n, F] expansion is never written.  Same arithmetic on the same values: bit-identical to sl_act_norm_bwd

@@ -252,7 +252,7 @@ SIGNATURES = {
     "sl_act_norm_bwd_rows_t": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64,
                                    C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P, C.c_int,
-                                   C.c_int, _P, _P]),
+                                   C.c_int, _P, C.c_int, _P]),
     "sl_act_norm_bwd_map": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(C.c_int), _P, _P,
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, _P, C.c_int64, _P,
                                       C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P, _P, C.c_float, C.c_uint64, _P, C.c_int64, _P, _P]),

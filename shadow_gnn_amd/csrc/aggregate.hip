@@ -775,6 +775,7 @@ struct ActNormParams {
   const float *dout2; int64_t lddo2;
   // backward, optional: max_k |dZ[0][r, k]| per row (the fp16 operand scale of the GEMM that reads dZ[0] next, sl_row_amax)
   float *dz0_amax;
+  int amax_branch;               // the branch whose dZ row maxima dz0_amax receives (0 unless the caller says otherwise)
   // forward, optional: the same for the output the next layer reads (out2 in dual mode, out otherwise)
   float *out_amax;
   // backward, optional: the output gradient is given for `n` SELECTED rows only (dout / dout2 are [n, F] compact, row i of
@@ -917,7 +918,7 @@ __global__ void __launch_bounds__(kBlock, (BWD && NB == 2) ? 5 : 1) act_norm_ker
           // of 1e-7 |dh| |z|; the plain backward kernel sits exactly on its register cap, the direct sum spilled nine dwords: + 28 %)
           if (lane_on && (l % LS) == 0) p.t_out[(p.dz_compact ? r : rr) * (p.F / p.seg) + f / p.seg] = (float)p.seg * p.eps * rstd * rstd * m2;
         }
-        if (b == 0 && p.dz0_amax) {        // (the LPR lanes of a row group share r: the reduction is uniform over the group)
+        if (b == p.amax_branch && p.dz0_amax) {        // (the LPR lanes of a row group share r: the reduction is uniform over the group)
           zmax = group_max<LPR>(zmax);
           if (l == 0) p.dz0_amax[p.dz_compact ? r : rr] = zmax;
         }
@@ -1673,7 +1674,7 @@ extern "C" int sl_act_norm_bwd_rows(int nb, const float *const *d_Z, const int64
                                     int dz_compact, void *stream_) {
   return sl_act_norm_bwd_rows_t(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale,
                                 d_doffset, d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, d_row_idx,
-                                dz_compact, -1, nullptr, stream_);
+                                dz_compact, -1, nullptr, 0, stream_);
 }
 
 static int act_norm_bwd_impl(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
@@ -1682,7 +1683,8 @@ static int act_norm_bwd_impl(int nb, const float *const *d_Z, const int64_t *ldz
                              float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                              float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                              const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
-                             int dz_compact, int t_branch, float *d_t_out, const uint32_t *d_dout_map, void *stream_) {
+                             int dz_compact, int t_branch, float *d_t_out, const uint32_t *d_dout_map, int amax_branch, void *stream_) {
+  if (amax_branch < 0 || amax_branch >= nb) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of branch %d of %d", amax_branch, nb);
   if (d_dout_map && (!d_dout || d_row_idx)) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_map: a gradient table needs d_dout and no row selection");
   if (d_t_out && (t_branch < 0 || t_branch >= nb || act[t_branch] != 0 || (d_bias && d_bias[t_branch])))
     return set_error(SG_ERR_INVALID, "sl_act_norm_bwd_rows_t: the segment dots are provided for an identity branch without a bias");
@@ -1716,8 +1718,8 @@ static int act_norm_bwd_impl(int nb, const float *const *d_Z, const int64_t *ldz
       return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: the dropped-output gradient must be 16-byte aligned, ld %% 4 == 0");
     p.dout2 = d_dout_dropped; p.lddo2 = lddo_dropped;
   }
-  if (d_dz0_amax && !d_dZ[0]) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of a gradient that is not written");
-  p.dz0_amax = d_dz0_amax;
+  if (d_dz0_amax && !d_dZ[amax_branch]) return set_error(SG_ERR_INVALID, "sl_act_norm_bwd: row maxima of a gradient that is not written");
+  p.dz0_amax = d_dz0_amax; p.amax_branch = amax_branch;
   p.row_idx = d_row_idx;
   p.dout_map = d_dout_map;
   p.dz_compact = dz_compact ? 1 : 0;
@@ -1725,7 +1727,7 @@ static int act_norm_bwd_impl(int nb, const float *const *d_Z, const int64_t *ldz
   bool vec = false;
   if ((rc = act_norm_launch(p, true, st, &vec, d_row_idx != nullptr || d_t_out != nullptr)) != SG_OK) return rc;
   // (the general kernel does not write the row maxima: one more pass)
-  return (d_dz0_amax && !vec) ? sl_row_amax(d_dZ[0], lddz[0], n, F, d_dz0_amax, st) : SG_OK;
+  return (d_dz0_amax && !vec) ? sl_row_amax(d_dZ[amax_branch], lddz[amax_branch], n, F, d_dz0_amax, st) : SG_OK;
 }
 
 extern "C" int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int64_t *ldz, const float *const *d_bias,
@@ -1734,10 +1736,10 @@ extern "C" int sl_act_norm_bwd_rows_t(int nb, const float *const *d_Z, const int
                                       float *const *d_dZ, const int64_t *lddz, float *d_dscale,
                                       float *d_doffset, float *d_dbias, float *d_partial, float drop_p, uint64_t drop_seed,
                                       const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, const uint32_t *d_row_idx,
-                                      int dz_compact, int t_branch, float *d_t_out, void *stream_) {
+                                      int dz_compact, int t_branch, float *d_t_out, int amax_branch, void *stream_) {
   return act_norm_bwd_impl(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale, d_doffset,
                            d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, d_row_idx, dz_compact, t_branch,
-                           d_t_out, nullptr, stream_);
+                           d_t_out, nullptr, amax_branch, stream_);
 }
 
 // ... with the output gradient given as a table: row i's gradient is d_dout[d_dout_map[i], :] (sl_pool_grad_table)
@@ -1749,5 +1751,5 @@ extern "C" int sl_act_norm_bwd_map(int nb, const float *const *d_Z, const int64_
                                    const float *d_dout_dropped, int64_t lddo_dropped, float *d_dz0_amax, void *stream_) {
   return act_norm_bwd_impl(nb, d_Z, ldz, d_bias, act, d_scale, d_offset, n, F, seg, out_scale, d_dout, lddo, d_dZ, lddz, d_dscale, d_doffset,
                            d_dbias, d_partial, drop_p, drop_seed, d_dout_dropped, lddo_dropped, d_dz0_amax, nullptr, 0, -1, nullptr,
-                           d_dout_map, stream_);
+                           d_dout_map, 0, stream_);
 }

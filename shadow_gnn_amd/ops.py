@@ -565,7 +565,7 @@ def _an_fwd(Zs, biases, codes, sc, of, seg, out_scale, drop=(0.0, 0)):
 
 
 def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbias, drop=(0.0, 0), dz_out=None, row_idx=None,
-            dz0_amax=None, dz_compact=False, t_out=None):
+            dz0_amax=None, dz_compact=False, t_out=None, amax_branch=0):
     """``douts``: the gradient(s) autograd handed over -- (dout,) or, in dual mode, (dout_plain, dout_dropped) with
     None for an output nothing consumed.  ``dz_out``: optional preallocated dZ destinations (column slices of a
     wider buffer are fine).  ``row_idx`` (int32 [m]): the gradients are compact [m, F] and belong to those rows (a read-out
@@ -613,7 +613,7 @@ def _an_bwd(Zs, biases, codes, sc, of, seg, out_scale, douts, need_dz, want_dbia
                                                  dz0_amax.data_ptr() if dz0_amax is not None else None,
                                                  row_idx.data_ptr() if row_idx is not None else None, 1 if dz_compact else 0,
                                                  t_out[0] if t_out is not None else -1, t_out[1].data_ptr() if t_out is not None else None,
-                                                 _stream(Zs[0])))
+                                                 int(amax_branch), _stream(Zs[0])))
     return dZs, dsc, dof, dbi
 
 

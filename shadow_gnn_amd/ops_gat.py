@@ -232,8 +232,9 @@ class _GatTail(torch.autograd.Function):
                     and lv.r == int(lr.rows32.numel()) and lv.in_ids_full is not None):
                 return _GatTail._rows_backward(ctx, lr, lv, lr.levels[1:])
             rows, dout = lr.rows32, (lr.grad,)
-        # (branches passed self-first: the kernel's row maxima are those of its first gradient -- dz_self's, which the attention
-        #  backward below no longer reads on the rows it leaves alone; per-branch arithmetic does not depend on the order)
+        # (the row maxima asked for are those of the SECOND branch's gradient -- dz_self's, which the attention backward below no
+        #  longer reads on the rows it leaves alone; rounds 5 - 6a passed the branches self-first instead and flipped the [2, F]
+        #  scale / offset rows and their gradients: four small kernels per layer)
         amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
         if amax is not None and rows is not None:
             amax.zero_()                 # (rows the read-out gradient does not reach: dz_self = 0)
@@ -243,10 +244,9 @@ class _GatTail(torch.autograd.Function):
         tdot = None
         if _lib.load().sl_act_norm_vector_layout(F, int(seg)) and int(seg) * heads == F:
             tdot = (torch.zeros if rows is not None else torch.empty)(n, heads, device=dev)
-        (dzs, dnagg), dsc, dof, _ = ops._an_bwd([z_self, nagg], [None, None], (act_code, 0), sc.flip(0).contiguous(), of.flip(0).contiguous(), seg,
-                                                out_scale, dout, [True, True], False, drop, row_idx=rows, dz0_amax=amax,
-                                                t_out=(1, tdot) if tdot is not None else None)
-        dsc, dof = dsc.flip(0), dof.flip(0)
+        (dnagg, dzs), dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg,
+                                                out_scale, dout, [True, True], False, drop, row_idx=rows, dz0_amax=amax, amax_branch=1,
+                                                t_out=(0, tdot) if tdot is not None else None)
         if rows is not None:
             lr.release()
         ti, tx, tp = c.transposed
