@@ -218,6 +218,20 @@ int sg_set_profiling(sg_sampler *s, int enable);
  * sites of shaDow/layers.py and frontend/graph_utils.py listed per function.  */
 
 /* out[i,:] = table[idx[i],:]      (feat_full[subgs.node], shaDow/minibatch.py:469) */
+/* (ABI 24) Up to SL_ROWS_MAX_JOBS row copies under one int64 row index in ONE launch, for i < rows:
+ *   mode 0 (gather)   dst[i, :] = src[idx[i], :]       mode 1 (clear)   dst[i, :] = 0       mode 2 (scatter)   dst[idx[i], :] = src[i, :]
+ * (scatter: distinct idx; a clear of the same dst belongs in an EARLIER call).  Pure copies: what `x.index_select(0, idx)`,
+ * `torch.zeros` and `index_copy_` do around the row-sparse backward passes (ops_gat._GatTail._rows_backward), in two launches
+ * instead of fifteen. */
+#define SL_ROWS_MAX_JOBS 12
+typedef struct {
+  const float *src; int64_t lds;   /* source rows and their pitch in floats (unused for mode 1) */
+  float *dst; int64_t ldd;
+  uint32_t width;                  /* floats per row */
+  int mode;
+} sl_rows_job;
+int sl_rows_multi(const sl_rows_job *jobs, int njobs, const int64_t *d_idx, uint32_t rows, void *stream);
+
 int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const uint32_t *d_idx, uint32_t n,
                        uint32_t F, float *d_out, int64_t ld_out, void *stream);
 /* The same gather with layer 0's input dropout in the same pass (nn.Dropout at layers.py:430,471; the counter-hash

@@ -62,6 +62,11 @@ class SlSageBelow(C.Structure):
     ]
 
 
+class SlRowsJob(C.Structure):
+    """sl_rows_job: one row copy of sl_rows_multi (mode 0 gather, 1 clear, 2 scatter)."""
+    _fields_ = [("src", C.c_void_p), ("lds", C.c_int64), ("dst", C.c_void_p), ("ldd", C.c_int64), ("width", C.c_uint32), ("mode", C.c_int)]
+
+
 class SlSageStackLayer(C.Structure):
     """sl_sage_stack_layer: one GraphSAGE layer of a stack run by sl_sage_stack_fwd / sl_sage_stack_bwd."""
     _fields_ = [
@@ -128,6 +133,7 @@ SIGNATURES = {
     "sg_debug_scan_phases": (C.c_int, [_P, _P]),
     "sg_debug_stream_rows": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_int, C.c_int, _P]),
     "sl_gather_rows_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
+    "sl_rows_multi": (C.c_int, [C.POINTER(SlRowsJob), C.c_int, _P, C.c_uint32, _P]),
     "sl_gather_rows_drop_f32": (C.c_int, [_P, C.c_int64, _P, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, _P, C.c_int64,
                                            C.c_uint32, _P, _P]),
     "sl_csr_edge_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),

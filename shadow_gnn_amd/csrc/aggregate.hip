@@ -1122,6 +1122,46 @@ extern "C" int sl_gather_rows_f32(const float *d_table, int64_t ld_table, const 
   return SG_OK;
 }
 
+// Several row copies under ONE index in one launch (sl_rows_multi): a wavefront per row walks the jobs.  What a row-sparse backward
+// pass does before its kernels run -- seven saved tensors gathered on the rows' input set, two gradients scattered into zeroed
+// tensors over it -- was fifteen torch launches of ~5 us each around ~1 us of copying.
+struct RowsJobs { sl_rows_job j[SL_ROWS_MAX_JOBS]; int n; };
+
+__global__ void __launch_bounds__(kBlock) rows_multi_kernel(RowsJobs J, const int64_t *__restrict__ idx, uint32_t rows) {
+  const uint32_t lane = lane_id();
+  for (uint32_t i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); i < rows; i += gridDim.x * (kBlock / 64)) {   // (grid_for caps the grid)
+  const int64_t k = idx ? idx[i] : (int64_t)i;
+  for (int q = 0; q < J.n; q++) {
+    const sl_rows_job jb = J.j[q];
+    const float *s = jb.mode == 0 ? jb.src + k * jb.lds : (jb.mode == 2 ? jb.src + (int64_t)i * jb.lds : nullptr);
+    float *d = jb.mode == 2 ? jb.dst + k * jb.ldd : jb.dst + (int64_t)i * jb.ldd;
+    const bool vec = !(jb.width & 3u) && !(jb.lds & 3) && !(jb.ldd & 3) && !((uintptr_t)jb.dst & 15u) && (jb.mode == 1 || !((uintptr_t)jb.src & 15u));
+    if (vec) {
+      for (uint32_t c = lane * 4; c < jb.width; c += 256)
+        *reinterpret_cast<float4 *>(d + c) = s ? *reinterpret_cast<const float4 *>(s + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (uint32_t c = lane; c < jb.width; c += 64) d[c] = s ? s[c] : 0.f;
+    }
+  }
+  }
+}
+
+extern "C" int sl_rows_multi(const sl_rows_job *jobs, int njobs, const int64_t *d_idx, uint32_t rows, void *stream_) {
+  if (njobs < 0 || njobs > SL_ROWS_MAX_JOBS || (njobs && !jobs)) return set_error(SG_ERR_INVALID, "sl_rows_multi: %d jobs (at most %d)", njobs, SL_ROWS_MAX_JOBS);
+  if (rows == 0 || njobs == 0) return SG_OK;
+  RowsJobs J;
+  J.n = njobs;
+  for (int q = 0; q < njobs; q++) {
+    J.j[q] = jobs[q];
+    if (jobs[q].mode < 0 || jobs[q].mode > 2 || !jobs[q].dst || (jobs[q].mode != 1 && !jobs[q].src))
+      return set_error(SG_ERR_INVALID, "sl_rows_multi: job %d (mode %d) incomplete", q, jobs[q].mode);
+    if (jobs[q].mode != 1 && !d_idx) return set_error(SG_ERR_INVALID, "sl_rows_multi: job %d needs the row index", q);
+  }
+  hipLaunchKernelGGL(rows_multi_kernel, dim3(grid_for(rows, kBlock / 64)), dim3(kBlock), 0, (hipStream_t)stream_, J, d_idx, rows);
+  SHD_HIP(hipGetLastError());
+  return SG_OK;
+}
+
 extern "C" int sl_csr_edge_rows(const uint32_t *d_indptr, uint32_t n, uint32_t e, uint32_t *d_edge_row,
                                 void *stream_) {
   if (!d_indptr || (e && !d_edge_row)) return set_error(SG_ERR_INVALID, "sl_csr_edge_rows: null argument");

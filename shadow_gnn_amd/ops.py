@@ -247,6 +247,22 @@ class NormAdj:
         return d
 
 
+def rows_multi(jobs, idx: Optional[torch.Tensor], rows: int):
+    """Several row copies under one int64 row index in ONE launch (sl_rows_multi).  ``jobs``: (mode, src, dst) with mode
+    'gather' (dst[i] = src[idx[i]]), 'clear' (dst[i] = 0, src None) or 'scatter' (dst[idx[i]] = src[i]); fp32, unit column stride."""
+    if rows == 0 or not jobs:
+        return
+    arr = (_lib.SlRowsJob * len(jobs))()
+    for q, (mode, src, dst) in enumerate(jobs):
+        assert dst.dtype == torch.float32 and dst.dim() == 2 and dst.stride(1) == 1
+        assert src is None or (src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and src.shape[1] == dst.shape[1])
+        arr[q].mode = {"gather": 0, "clear": 1, "scatter": 2}[mode]
+        arr[q].src, arr[q].lds = (src.data_ptr(), src.stride(0)) if src is not None else (None, 0)
+        arr[q].dst, arr[q].ldd, arr[q].width = dst.data_ptr(), dst.stride(0), dst.shape[1]
+    assert idx is None or (idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() >= rows)
+    check(_lib.load().sl_rows_multi(arr, len(jobs), idx.data_ptr() if idx is not None else None, int(rows), _stream(jobs[0][2])))
+
+
 def degree_scales(csr: DeviceCSR, edge_w: Optional[torch.Tensor], mode: str) -> torch.Tensor:
     out = torch.empty(max(1, csr.n), dtype=torch.float32, device=csr.device)[:csr.n]
     check(_lib.load().sl_degree_scales(csr.indptr.data_ptr(), edge_w.data_ptr() if edge_w is not None else None,

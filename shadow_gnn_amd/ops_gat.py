@@ -188,12 +188,17 @@ class _GatTail(torch.autograd.Function):
         E = csr_c.e
         ti, tx, tp = csr_c.transposed
         w = adj.edge_w.index_select(0, level.edge_pos.index_select(0, order)) if adj.edge_w is not None else None
-        g = lambda x: x.index_select(0, Tl)
-        zs_c, us_c, un_c, mx_c, den_c, na_c = g(z_self), g(u_s), g(u_n), g(mx), g(den), g(nagg)
-        zn_c = g(z_neigh) if z_neigh.numel() else None          # (no pre-activation kept: hn carries the derivative, ops.GatPre)
-        hn_c = g(hn) if hn.numel() else None
-        dn_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dn_r)
-        dzs_c = torch.zeros(t, F, **f32).index_copy_(0, sidx, dzs_r)
+        # the saved tensors on the input set, the two gradients scattered into zeroed tensors over it: two launches (ops.rows_multi;
+        # rounds 5 - 6a: eight index_select, two zeros, two index_copy_)
+        like = lambda x: torch.empty(t, x.shape[1], **f32)
+        src = [z_self, u_s, u_n, mx, den, nagg] + ([z_neigh] if z_neigh.numel() else []) + ([hn] if hn.numel() else [])
+        out = [like(x) for x in src]
+        dn_c, dzs_c = torch.empty(t, F, **f32), torch.empty(t, F, **f32)
+        ops.rows_multi([("gather", x, y) for x, y in zip(src, out)] + [("clear", None, dn_c), ("clear", None, dzs_c)], Tl, t)
+        ops.rows_multi([("scatter", dn_r, dn_c), ("scatter", dzs_r, dzs_c)], sidx, r)
+        zs_c, us_c, un_c, mx_c, den_c, na_c = out[:6]
+        zn_c = out[6] if z_neigh.numel() else None              # (no pre-activation kept: hn carries the derivative, ops.GatPre)
+        hn_c = out[-1] if hn.numel() else None
         dzn_c = torch.empty(t, F, **f32)
         datt = torch.empty(2, F, **f32)
         work = torch.empty(t * heads + 4096 * F + 4, **f32)

@@ -2111,6 +2111,37 @@ def test_dual_output_layers_chain_their_backward_passes(n_layers, act, residue, 
 
 
 @pytest.mark.gpu
+def test_rows_multi_copies_like_index_select_zeros_and_index_copy():
+    """Round 6: ops.rows_multi (sl_rows_multi) -- several gathers / clears under one row index in one launch, several scatters in
+    another -- is what index_select, torch.zeros and index_copy_ produce, bit for bit: widths 1 .. 256 (vector and scalar paths),
+    padded source pitches, a one-row problem, the job-count limit refused."""
+    from shadow_gnn_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    n, t, r = 60000, 30011, 91            # (more rows than one grid holds: the kernel strides)
+    idx = torch.randperm(n, generator=g)[:t].to(dev)
+    srcs = [torch.randn(n, w, generator=g).to(dev) for w in (256, 4, 4, 1, 100, 7)]
+    wide = torch.randn(n, 300, generator=g).to(dev)[:, 20:276]          # (pitch 300, offset 20 floats: the scalar path)
+    srcs.append(wide)
+    outs = [torch.full((t, x.shape[1]), float("nan"), device=dev) for x in srcs]
+    z0, z1 = torch.full((t, 256), float("nan"), device=dev), torch.full((t, 12), float("nan"), device=dev)
+    ops.rows_multi([("gather", x, y) for x, y in zip(srcs, outs)] + [("clear", None, z0), ("clear", None, z1)], idx, t)
+    sidx = torch.randperm(t, generator=g)[:r].to(dev)
+    a, b = torch.randn(r, 256, generator=g).to(dev), torch.randn(r, 12, generator=g).to(dev)
+    ops.rows_multi([("scatter", a, z0), ("scatter", b, z1)], sidx, r)
+    torch.cuda.synchronize()
+    for x, y in zip(srcs, outs):
+        assert torch.equal(y, x.index_select(0, idx))
+    assert torch.equal(z0, torch.zeros(t, 256, device=dev).index_copy_(0, sidx, a))
+    assert torch.equal(z1, torch.zeros(t, 12, device=dev).index_copy_(0, sidx, b))
+    one = torch.empty(1, 4, device=dev)
+    ops.rows_multi([("gather", srcs[1], one)], idx[5:6].contiguous(), 1)
+    assert torch.equal(one, srcs[1][idx[5]].reshape(1, 4))
+    arr = (_lib.SlRowsJob * 13)()
+    assert _lib.load().sl_rows_multi(arr, 13, idx.data_ptr(), t, None) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,F,with_dout,with_droots", [("mean", 256, True, True), ("sum", 192, True, True), ("mean", 256, False, True),
                                                           ("mean", 132, True, False)])
 def test_pool_gradient_table_is_the_dense_pooling_backward_row_for_row(mode, F, with_dout, with_droots):
