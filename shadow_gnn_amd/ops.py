@@ -1995,10 +1995,12 @@ class _SageStack(torch.autograd.Function):
         # ---- top layer on the roots (ops._SageDense._sparse_top_backward)
         Ws, bs, Wn, bn, sc, of = prm(top)
         R = plan.rows64
-        (dZsR, dZnR), tsc, tof, tbi = _an_bwd([Zs(top).index_select(0, R), Zn(top).index_select(0, R)], [bs, bn], (meta[top][0],) * 2, sc, of, F, 1.0,
+        P = int(R.numel())
+        onR = [torch.empty(P, F, **f32) for _ in range(4)]           # (the four saved tensors on the roots' rows: one launch)
+        rows_multi([("gather", x, y) for x, y in zip((Zs(top), Zn(top), out(mid), AX(top)), onR)], R, P)
+        (dZsR, dZnR), tsc, tof, tbi = _an_bwd(onR[:2], [bs, bn], (meta[top][0],) * 2, sc, of, F, 1.0,
                                               (d,), [True, True], bs is not None or bn is not None, (0.0, 0))
-        g_top = (weight_grad(dZsR, out(mid).index_select(0, R), min_rows=ROOT_GEMM_MIN_ROWS),
-                 weight_grad(dZnR, AX(top).index_select(0, R), min_rows=ROOT_GEMM_MIN_ROWS), tbi, tsc, tof)
+        g_top = (weight_grad(dZsR, onR[2], min_rows=ROOT_GEMM_MIN_ROWS), weight_grad(dZnR, onR[3], min_rows=ROOT_GEMM_MIN_ROWS), tbi, tsc, tof)
         GS = (mm_nt(dZnR, Wn.t(), min_rows=ROOT_GEMM_MIN_ROWS), mm_nt(dZsR, Ws.t(), min_rows=ROOT_GEMM_MIN_ROWS))
         dXT = torch.empty(plan.t, F, **f32)
         check(lib.sl_top_dx(GS[0].data_ptr(), GS[1].data_ptr(), F, plan.T32.data_ptr(), plan.slot.data_ptr(), plan.epos.data_ptr(),
@@ -2015,7 +2017,9 @@ class _SageStack(torch.autograd.Function):
                                      dz_out=[dZsT, dZnT[:t]], row_idx=plan.T32, dz_compact=True)
         Tl = plan.T32.long()
         Xm = out(low) if mid >= 1 else X0
-        g_mid = (weight_grad(dZsT, Xm.index_select(0, Tl)), weight_grad(dZnT[:t], AX(mid).index_select(0, Tl)), mbi, msc, mof)
+        onT = [torch.empty(t, Xm.shape[1], **f32), torch.empty(t, F, **f32)]
+        rows_multi([("gather", Xm, onT[0]), ("gather", AX(mid), onT[1])], Tl, t)
+        g_mid = (weight_grad(dZsT, onT[0]), weight_grad(dZnT[:t], onT[1]), mbi, msc, mof)
         # ---- its input gradient = the output gradient of layer L - 3: (A^T dZn) Wn + scatter_T(dZs[T] Ws), with that layer's act +
         #      norm backward in the product's epilogue (ops._SageDense._compact_dz_backward)
         AtdZn, amx = _at_dzn_on_rows(adj, plan, dZnT, n, F)
