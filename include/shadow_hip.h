@@ -911,6 +911,18 @@ int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32
                const float *d_u_n, const float *d_mx, const float *d_den, const float *d_nagg,
                const float *d_dnagg, const float *d_t, float *d_work, float *d_dz_self, float *d_dz_neigh, float *d_datt,
                int accumulate_dz_self, float *d_row_amax, void *stream);
+/* (ABI 25) sl_gat_bwd for an incoming gradient that lives on a FEW rows -- the layer below a row-sparse backward pass
+ * (tail.build_backward_levels): d_dnagg_rows [t, F] and d_t_rows [t, heads] are compact, row i's at d_dn_map[i] (uint32 [n],
+ * 0xFFFFFFFF: dN_i = 0).  The column walk passes over the edges of such rows -- their terms are alpha_ij * 0 and 0, exactly what
+ * sl_gat_bwd adds for a zero row: bit-identical to sl_gat_bwd on the expanded [n, F] / [n, heads] tensors -- and the expansion is
+ * never written.  d_t_rows is required (sl_act_norm_bwd_rows_t with dz_compact leaves it).                                   */
+int sl_gat_bwd_map(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
+                   const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
+                   const float *d_z_self, const float *d_z_neigh, const float *d_att, int act, uint32_t n,
+                   uint32_t e, uint32_t F, uint32_t heads, const float *d_hn, const float *d_u_s,
+                   const float *d_u_n, const float *d_mx, const float *d_den, const float *d_nagg,
+                   const float *d_dnagg_rows, const float *d_t_rows, const uint32_t *d_dn_map, float *d_work, float *d_dz_self,
+                   float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream);
 
 /* Development aid: per-subgraph result words of the last sg_sample call,
  * 16 uint32 per subgraph: {nodes, edges, flags, stream slots, frontier nodes,

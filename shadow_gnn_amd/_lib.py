@@ -243,6 +243,8 @@ SIGNATURES = {
                                    C.c_uint64, _P, _P, _P, _P, _P, _P]),
     "sl_gat_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                               C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "sl_gat_bwd_map": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "sl_top_plan": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_plan_filter": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "sl_top_dx": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P]),
@@ -268,7 +270,7 @@ _lib = None
 
 
 MAX_BATCHES_PER_CALL = 16      # SG_MAX_BATCHES_PER_CALL of include/shadow_hip.h
-ABI_VERSION = 24      # sg_abi_version() of the library these signatures describe
+ABI_VERSION = 25      # sg_abi_version() of the library these signatures describe
 
 
 def load():

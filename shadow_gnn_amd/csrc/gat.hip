@@ -80,6 +80,7 @@ struct GatParams {
   // backward
   const float *dnagg;                     // [n, F]
   const float *tdot;                      // [n, H]  t_i = dN_i . N_i per head
+  const uint32_t *dn_map;                 // sl_gat_bwd_map: dnagg / tdot are compact, row i's live at dn_map[i] (0xFFFFFFFF: a zero row)
   float *dz_self, *dz_neigh;              // [n, F]
   int acc_self;                           // dz_self already holds the act_norm branch's share of the gradient: add to it
   float *row_amax;                        // optional [n]: max |.| over the final dz_self and dz_neigh rows (sl_row_amax)
@@ -180,23 +181,31 @@ __device__ __forceinline__ void gat_fwd_group_online(const GatParams &p, uint32_
 // Column walk (transposed CSR): the edges (i -> j) into column j.  alpha_ij = exp(lrelu(u_s[i]) + lrelu(u_n[j]) - mx_i) w_ij / den_i
 // is formed again from row i's three scalars -- the expression of the forward pass, same bits -- and de_ij = alpha_ij (dN_i.hn_j - t_i)
 // with the gathered dN_i against the column's own hn_j (in registers).
-template <int G, class C>
+// MAP (sl_gat_bwd_map): the incoming gradient lives on a few rows -- dnagg / tdot compact, row i's at dn_map[i] -- and an edge whose
+// row has none (0xFFFFFFFF) is passed over: its terms are alpha_ij * 0 and 0, what the dense form adds for a zero row (with a whole
+// wavefront per row -- 256 columns -- the test is wave-uniform and the five loads of such an edge are not issued).
+template <int G, bool MAP, class C>
 __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q, uint32_t h, uint32_t f, bool on, uint32_t ls, float lun,
                                                   const float4 &hn, float &dan, float4 &acc) {
-  uint32_t s_[G];
+  uint32_t s_[G], m_[G];
   float us[G], mx[G], dn[G], t[G], w[G];
   float4 v[G];
   const bool hw = cfg_w<C>(p);
 #pragma unroll
   for (int j = 0; j < G; j++) { s_[j] = p.t_indices[q + j]; w[j] = hw ? p.edge_w[p.t_perm[q + j]] : 1.0f; }
 #pragma unroll
+  for (int j = 0; j < G; j++) m_[j] = MAP ? p.dn_map[s_[j]] : s_[j];
+#pragma unroll
   for (int j = 0; j < G; j++) {
+    us[j] = 0.f; mx[j] = 0.f; dn[j] = 1.f; t[j] = 0.f; v[j] = make_float4(0, 0, 0, 0);
+    if (MAP && m_[j] == 0xFFFFFFFFu) continue;
     const uint64_t o = (uint64_t)s_[j] * cfg_H<C>(p) + h;
-    us[j] = p.u_s[o]; mx[j] = p.mx[o]; dn[j] = p.den[o]; t[j] = p.tdot[o];
-    v[j] = on ? gld4(p.dnagg + (uint64_t)s_[j] * cfg_F<C>(p) + f) : make_float4(0, 0, 0, 0);
+    us[j] = p.u_s[o]; mx[j] = p.mx[o]; dn[j] = p.den[o]; t[j] = p.tdot[(uint64_t)m_[j] * cfg_H<C>(p) + h];
+    v[j] = on ? gld4(p.dnagg + (uint64_t)m_[j] * cfg_F<C>(p) + f) : make_float4(0, 0, 0, 0);
   }
 #pragma unroll
   for (int j = 0; j < G; j++) {
+    if (MAP && m_[j] == 0xFFFFFFFFu) continue;
     const float ev = lrelu02(us[j]) + lun;        // e_ij, the forward pass's expression: == mx_i exactly on row i's maximum edge
     float pe = gat_exp(ev - mx[j]);
     if (hw) pe *= w[j];
@@ -330,7 +339,7 @@ __global__ void gat_t_kernel(GatParams p) {
 // the clamped rows' edges row-wise and kept a sum there that the reference's graph does not have).
 // backward, column side (transposed CSR): alpha, de, d hn, du_n, dz_neigh, datt[1]
 // (register caps -- amdgpu_waves_per_eu(6 / 7) -- measured and dropped: 578 us against 503 at the 87 VGPRs / 5 wavefronts hipcc picks)
-template <int LPR, class C>
+template <int LPR, bool MAP, class C>
 __global__ void gat_col_bwd_kernel(GatParams p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const uint32_t f = l * 4, ls = C::LS > 0 ? (uint32_t)C::LS : p.D / 4;
@@ -356,7 +365,7 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
     float4 acc = make_float4(0, 0, 0, 0);
     float dan = 0.f, rmax = 0.f;
     uint32_t q = a;
-#define SHD_CALL(G) gat_bwd_col_group<G, C>(p, q, h, f, on, ls, lun, hn, dan, acc)
+#define SHD_CALL(G) gat_bwd_col_group<G, MAP, C>(p, q, h, f, on, ls, lun, hn, dan, acc)
     SHD_GAT_EDGES(SHADOW_GAT_GROUPS_COL, q, b, SHD_CALL);
 #undef SHD_CALL
     if (on) {
@@ -568,13 +577,13 @@ extern "C" int sl_gat_fwd_tail(const uint32_t *d_indptr, const uint32_t *d_indic
   return SG_OK;
 }
 
-extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
-                          const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
-                          const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
-                          uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
-                          const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
-                          const float *d_nagg, const float *d_dnagg, const float *d_t, float *d_work, float *d_dz_self,
-                          float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
+static int gat_bwd_impl(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
+                        const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
+                        const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
+                        uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
+                        const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
+                        const float *d_nagg, const float *d_dnagg, const float *d_t, const uint32_t *d_dn_map, float *d_work, float *d_dz_self,
+                        float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
   (void)e;
   if (!d_indptr || !d_t_indptr || !(d_z_neigh || d_hn) || !d_att || !d_u_s || !d_u_n || !d_mx ||
       !d_den || !d_nagg || !d_dnagg || !d_work || !d_dz_self || !d_dz_neigh || !d_datt)
@@ -591,7 +600,7 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
   p.n = n; p.F = F; p.H = heads; p.D = F / heads;
   p.hn = const_cast<float *>(d_hn); p.u_s = const_cast<float *>(d_u_s); p.u_n = const_cast<float *>(d_u_n);
   p.mx = const_cast<float *>(d_mx); p.den = const_cast<float *>(d_den); p.nagg = const_cast<float *>(d_nagg);
-  p.dnagg = d_dnagg;
+  p.dnagg = d_dnagg; p.dn_map = d_dn_map;
   // work: t[n*H] (when not given), datt_part[2048][2][F]
   p.datt_part = d_work + (size_t)n * heads;
   p.dz_self = d_dz_self; p.dz_neigh = d_dz_neigh; p.datt = d_datt; p.acc_self = accumulate_dz_self; p.row_amax = d_row_amax;
@@ -602,9 +611,36 @@ extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, c
     SHD_GAT_LAUNCH(gat_t_kernel, lpr, g, st, p);
   }
   if (!accumulate_dz_self) SHD_HIP(hipMemsetAsync(d_dz_self, 0, (size_t)n * F * 4, st));     // (the attention's share of dz_self: zero)
-  SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p);
+  if (d_dn_map) SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p, true);
+  else SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p, false);
   hipLaunchKernelGGL(gat_datt_finish_kernel, dim3((2 * F + kDattCols - 1) / kDattCols), dim3(kDattCols * kDattSlices), 0, st,
                      p.datt_part, g, 2 * F, d_datt);
   SHD_HIP(hipGetLastError());
   return SG_OK;
+}
+
+extern "C" int sl_gat_bwd(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
+                          const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
+                          const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
+                          uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
+                          const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
+                          const float *d_nagg, const float *d_dnagg, const float *d_t, float *d_work, float *d_dz_self,
+                          float *d_dz_neigh, float *d_datt, int accumulate_dz_self, float *d_row_amax, void *stream_) {
+  return gat_bwd_impl(d_indptr, d_indices, d_t_indptr, d_t_indices, d_t_perm, d_edge_w, d_z_self, d_z_neigh, d_att, act, n, e, F, heads, d_hn,
+                      d_u_s, d_u_n, d_mx, d_den, d_nagg, d_dnagg, d_t, nullptr, d_work, d_dz_self, d_dz_neigh, d_datt, accumulate_dz_self,
+                      d_row_amax, stream_);
+}
+
+extern "C" int sl_gat_bwd_map(const uint32_t *d_indptr, const uint32_t *d_indices, const uint32_t *d_t_indptr,
+                              const uint32_t *d_t_indices, const uint32_t *d_t_perm, const float *d_edge_w,
+                              const float *d_z_self, const float *d_z_neigh, const float *d_att, int act,
+                              uint32_t n, uint32_t e, uint32_t F, uint32_t heads, const float *d_hn,
+                              const float *d_u_s, const float *d_u_n, const float *d_mx, const float *d_den,
+                              const float *d_nagg, const float *d_dnagg_rows, const float *d_t_rows, const uint32_t *d_dn_map,
+                              float *d_work, float *d_dz_self, float *d_dz_neigh, float *d_datt, int accumulate_dz_self,
+                              float *d_row_amax, void *stream_) {
+  if (!d_dn_map || !d_t_rows) return set_error(SG_ERR_INVALID, "sl_gat_bwd_map: the row map and the rows' t are required");
+  return gat_bwd_impl(d_indptr, d_indices, d_t_indptr, d_t_indices, d_t_perm, d_edge_w, d_z_self, d_z_neigh, d_att, act, n, e, F, heads, d_hn,
+                      d_u_s, d_u_n, d_mx, d_den, d_nagg, d_dnagg_rows, d_t_rows, d_dn_map, d_work, d_dz_self, d_dz_neigh, d_datt,
+                      accumulate_dz_self, d_row_amax, stream_);
 }

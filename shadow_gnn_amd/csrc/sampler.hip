@@ -359,7 +359,7 @@ extern "C" const char *sg_last_error(void) { return last_error().c_str(); }
 // 2: sl_act_norm_* carry (drop_p, drop_seed); gemm / cache / pooling entries.  3: sl_act_norm_* dual (plain + dropped) output
 // 4: sg_ppr_push(mode).  5: sl_gat_bwd work buffer holds the datt partial sums.  6: sg_create_from_bin_ex
 // 7: sl_spmm_blockdiag_gather_f32, sampler debug entries.  8: sl_sage_fwd / sl_sage_bwd, sl_gemm_pack_b2, sl_gather_rows_drop_f32
-extern "C" int sg_abi_version(void) { return 24; }
+extern "C" int sg_abi_version(void) { return 25; }
 
 static int create_common(sg_sampler *s, int device_id, int64_t seed) {
   s->device = device_id;

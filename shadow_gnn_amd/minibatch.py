@@ -472,6 +472,10 @@ class MinibatchShallowExtractor:
         main.wait_stream(self._side)
         for t in ([x for lv in plan for x in lv.tensors()] if isinstance(plan, list) else plan.tensors()):
             t.record_stream(main)
+        if isinstance(plan, list):                                # (the batch CSR's transpose, built with the levels)
+            for t in (*(adj._t or ()), adj._edge_row):
+                if t is not None:
+                    t.record_stream(main)
         self.wait_s += getattr(plan, "sync_wait_s", 0.0)          # (the plan's size read-back: blocked on the prefetch stream, as _collect)
         return plan
 

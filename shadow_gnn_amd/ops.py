@@ -803,11 +803,11 @@ class PairLink:
     gradients on the rows T here -- (rows32 [t], dza [t, N], dzb [t, N]) -- and hands autograd storage-less placeholders."""
     def __init__(self):
         self.filled = False
-        self.rows32 = self.dza = self.dzb = self.dummy = self.levels = None
+        self.rows32 = self.dza = self.dzb = self.dummy = self.levels = self.row_map = None
 
     def release(self):
         self.filled = False
-        self.rows32 = self.dza = self.dzb = self.dummy = self.levels = None
+        self.rows32 = self.dza = self.dzb = self.dummy = self.levels = self.row_map = None
 
 
 class GatPre:
@@ -893,7 +893,7 @@ class _LinearPair(torch.autograd.Function):
             if g is None or g.data_ptr() != pair.dummy.data_ptr() or tuple(g.stride()) != (0, 0):
                 raise RuntimeError("row-sparse GAT backward: an output of the paired Linear has a consumer besides the attention node")
         M, K = X.shape
-        rows32, dza, dzb, levels = pair.rows32, pair.dza, pair.dzb, pair.levels
+        rows32, dza, dzb, levels, row_map = pair.rows32, pair.dza, pair.dzb, pair.levels, pair.row_map
         pair.release()
         Tl = rows32.long()
         XT = X.index_select(0, Tl)
@@ -926,6 +926,7 @@ class _LinearPair(torch.autograd.Function):
             link = ctx.in_link
             if link is not None:
                 link.rows32, link.grad, link.plan, link.levels = rows32, dXT, None, (levels or None)
+                link.row_map = row_map
                 link.dummy = placeholder(M, K, X.device)
                 link.filled = True
                 out[0] = link.dummy
@@ -1246,10 +1247,11 @@ class RootsLink:
         self.plan = None             # tail.TopBackwardPlan of the selected rows: the node's backward may then run row-sparse
         self.want_levels = False     # the publishing node works from tail.build_backward_levels instead (GAT)
         self.levels = None           # remaining levels of a row-sparse backward pass, the one for THIS node's rows first
+        self.row_map = None          # int32 [n] or None: position of every batch row in rows32, -1 = absent (RectLevel.in_map32)
 
     def release(self):
         self.filled = False
-        self.rows32 = self.grad = self.dummy = self.plan = self.levels = None
+        self.rows32 = self.grad = self.dummy = self.plan = self.levels = self.row_map = None
 
 
 ROOTS_SPARSE_GRAD = True

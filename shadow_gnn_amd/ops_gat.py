@@ -19,6 +19,13 @@ RECOMPUTE_HN = False
 FUSED_FWD_TAIL = True
 
 
+# The layer below a row-sparse backward pass receives its output gradient on a few rows (depth-3 products batches: 10 % of them).
+# True: its act + norm backward leaves the aggregate's gradient COMPACT and the attention backward reads it through the rows' map
+# (sl_gat_bwd_map: edges of rows without a gradient are passed over) -- no zero-filled [n, F] tensor, nine gathers in ten not
+# issued; bit-identical to the expanded form (False; tests compare the two).
+MAP_ROWS_GRADIENT = True
+
+
 def _hn_buffer(n, F, dev):
     return None if RECOMPUTE_HN else torch.empty(n, F, device=dev)
 
@@ -211,11 +218,60 @@ class _GatTail(torch.autograd.Function):
                                          work.data_ptr(), dzs_c.data_ptr(), dzn_c.data_ptr(), datt.data_ptr(), 1, None, ops._stream(dn_c)))
         pair = ctx.pair
         pair.rows32, pair.dza, pair.dzb, pair.levels = level.in32, dzs_c, dzn_c, list(rest)
+        pair.row_map = level.in_map32
         pair.dummy = ops.placeholder(n, F, dev)
         pair.filled = True
         _GatTail.sparse_top_calls += 1
         return (pair.dummy, pair.dummy, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None,
                 None, None, None)
+
+    mapped_calls = 0         # backward passes that read a row-sparse incoming gradient through its map (sl_gat_bwd_map)
+
+    @staticmethod
+    def _mapped_backward(ctx, lr):
+        """The dense backward of a layer whose output gradient lives on the rows ``lr.rows32`` (``lr.row_map``: their positions):
+        the act + norm backward runs on those rows and leaves d aggregate, the normalised branch's share of dz_self, their row
+        maxima and t COMPACT; dz_self is expanded (the paired Linear's products read it densely), the aggregate's gradient is not --
+        the column walk finds a row's through the map and passes over the edges of rows that have none."""
+        z_self, z_neigh, att, hn, u_s, u_n, mx, den, nagg, sc, of = ctx.saved_tensors
+        act_code, heads, att_shape, seg, out_scale, drop, sshape, oshape = ctx.meta
+        adj = ctx.adj
+        c = adj.csr
+        n, F = z_self.shape
+        dev = z_self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        rows32, row_map, grad = lr.rows32, lr.row_map, lr.grad
+        m = int(rows32.numel())
+        dn_c, dzs_c = torch.empty(m, F, **f32), torch.empty(m, F, **f32)
+        want_amax = n >= ops.AMAX_HANDOVER_ROWS
+        amax_c = torch.empty(m, 1, **f32) if want_amax else None
+        t_c = torch.empty(m, heads, **f32)
+        _dz, dsc, dof, _ = ops._an_bwd([nagg, z_self], [None, None], (0, act_code), sc, of, seg, out_scale, (grad,), [True, True], False, drop,
+                                       dz_out=[dn_c, dzs_c], row_idx=rows32, dz_compact=True, dz0_amax=amax_c, amax_branch=1, t_out=(0, t_c))
+        lr.release()
+        dzs = torch.zeros(n, F, **f32)
+        amax = torch.zeros(n, 1, **f32) if want_amax else None
+        ops.rows_multi([("scatter", dzs_c, dzs)] + ([("scatter", amax_c, amax)] if want_amax else []), rows32.long(), m)
+        ti, tx, tp = c.transposed
+        work = torch.empty(4096 * F + n * heads + 4, **f32)
+        dzn = torch.empty(n, F, **f32)
+        datt = torch.empty(2, F, **f32)
+        w = adj.edge_w
+        # the transposed structure (+ the mask through its permutation) and the rows' map; hn in, dz_neigh out; the [n, heads] scores /
+        # statistics; the gradient rows that exist
+        nbytes = 4 * (n + 1) + 8 * c.e + (4 * c.e if w is not None else 0) + 4 * n + 2 * 4 * n * F + 5 * 4 * n * heads + 4 * m * (F + heads)
+        with ops._timed(f"gat_bwd_map_F{F}_H{heads}", nbytes, dev):
+            check(_lib.load().sl_gat_bwd_map(c.indptr.data_ptr(), c.indices.data_ptr(), ti.data_ptr(), tx.data_ptr(), tp.data_ptr(),
+                                             w.data_ptr() if w is not None else None, z_self.data_ptr(), _p(z_neigh),
+                                             att.data_ptr(), act_code, n, c.e, F, heads, _p(hn), u_s.data_ptr(),
+                                             u_n.data_ptr(), mx.data_ptr(), den.data_ptr(), nagg.data_ptr(), dn_c.data_ptr(), t_c.data_ptr(),
+                                             row_map.data_ptr(), work.data_ptr(), dzs.data_ptr(), dzn.data_ptr(), datt.data_ptr(), 1,
+                                             amax.data_ptr() if amax is not None else None, ops._stream(dn_c)))
+        if amax is not None:
+            amax = amax.reshape(n)
+            ops.set_row_amax(dzs, amax); ops.set_row_amax(dzn, amax)
+        _GatTail.mapped_calls += 1
+        return (dzs, dzn, datt.reshape(att_shape), dsc.reshape(sshape), dof.reshape(oshape), None, None, None, None, None, None, None, None, None)
 
     @staticmethod
     def backward(ctx, *dout):
@@ -240,6 +296,9 @@ class _GatTail(torch.autograd.Function):
         # (the row maxima asked for are those of the SECOND branch's gradient -- dz_self's, which the attention backward below no
         #  longer reads on the rows it leaves alone; rounds 5 - 6a passed the branches self-first instead and flipped the [2, F]
         #  scale / offset rows and their gradients: four small kernels per layer)
+        vec = bool(_lib.load().sl_act_norm_vector_layout(F, int(seg)) and int(seg) * heads == F)
+        if rows is not None and MAP_ROWS_GRADIENT and vec and lr.row_map is not None and lr.row_map.numel() == n:
+            return _GatTail._mapped_backward(ctx, lr)
         amax = torch.empty(n, device=dev) if n >= ops.AMAX_HANDOVER_ROWS else None
         if amax is not None and rows is not None:
             amax.zero_()                 # (rows the read-out gradient does not reach: dz_self = 0)

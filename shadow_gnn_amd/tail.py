@@ -45,6 +45,7 @@ class RectLevel:
         self._t = None
         self._sq = None
         self.rows32 = self.in32 = None  # int32 copies of rows_full / in_ids_full (build_backward_levels)
+        self.in_map32 = None            # int32 [n]: position of every batch row in in_ids_full, -1 = not an input (build_backward_levels)
         self.rows_ascending = False     # rows_full ascending: the edges are already in the square form's order (no sort, no bincount)
 
     @property
@@ -64,7 +65,7 @@ class RectLevel:
         ts = [self.indptr, self.indices, self.edge_row, self.edge_pos, self.rows_full, self.self_idx]
         if self.in_ids_full is not None:
             ts.append(self.in_ids_full)
-        ts.extend(x for x in (self.rows32, self.in32) if x is not None)
+        ts.extend(x for x in (self.rows32, self.in32, self.in_map32) if x is not None)
         if self._t is not None:
             ts.extend(self._t)
         if self._sq is not None:
@@ -332,6 +333,11 @@ def build_backward_levels(csr: "ops.DeviceCSR", targets: torch.Tensor, max_level
         lv.square[0].transposed
         lv.rows32 = rows.to(torch.int32)
         lv.in32 = in_ids.to(torch.int32)
+        # (the layer BELOW the last level receives its output gradient on the rows in_ids: with this map its attention backward
+        #  reads the compact gradient in place, ops_gat.MAP_ROWS_GRADIENT)
+        lv.in_map32 = torch.where(mask, newid, newid.new_full((), -1)).to(torch.int32)
         levels.append(lv)
         rows = in_ids
+    if levels:
+        csr.transposed                                      # (the dense layers' column walk: built here, off the training stream)
     return levels

@@ -2429,6 +2429,30 @@ def test_sparse_top_gat_backward_equals_dense(n_layers, p_drop, dropedge, given)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_layers,p_drop,dropedge,given", [(3, 0.35, 0.1, True), (4, 0.2, 0.05, True), (2, 0.0, 0.0, False), (3, 0.3, 0.1, False)])
+def test_gat_layer_below_the_row_sparse_pass_reads_its_gradient_through_the_row_map(n_layers, p_drop, dropedge, given, monkeypatch):
+    """The GAT layer below a row-sparse backward pass receives its output gradient on a few rows.  ops_gat.MAP_ROWS_GRADIENT: the
+    act + norm backward leaves the aggregate's gradient compact and sl_gat_bwd_map's column walk reads it through the rows' map
+    (tail.RectLevel.in_map32), passing over the edges of rows that have none -- against the expanded form (zero-filled [n, F]
+    tensor, sl_gat_bwd): loss, predictions and every parameter gradient bit for bit, with dropout and drop-edge on, one or two
+    row-sparse levels above it."""
+    from shadow_gnn_amd import ops_gat
+    monkeypatch.setattr(ops_gat, "MAP_ROWS_GRADIENT", False)
+    m0 = ops_gat._GatTail.mapped_calls
+    l0, p0, g0, n0 = _gat_stack_step(n_layers, p_drop, dropedge, 29, sparse_top=True, given_plan=given)
+    assert ops_gat._GatTail.mapped_calls == m0
+    monkeypatch.setattr(ops_gat, "MAP_ROWS_GRADIENT", True)
+    l1, p1, g1, n1 = _gat_stack_step(n_layers, p_drop, dropedge, 29, sparse_top=True, given_plan=given)
+    levels = min(2, n_layers) if given else 1
+    assert n0 == n1 == levels
+    assert ops_gat._GatTail.mapped_calls == m0 + (1 if n_layers > levels else 0), "the mapped backward was not taken"
+    assert l0 == l1
+    torch.testing.assert_close(p1, p0, rtol=0, atol=0)
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
 def test_sparse_top_backward_fuzz():
     """40 seeded random ragged batches (subgraphs of 1 .. 60 nodes, roots with / without self edges or neighbours) x random
     GraphSAGE / GAT stacks: the row-sparse top-layer backward passes against the dense ones (scripts/fuzz_sparse_top.py)."""
