@@ -122,6 +122,26 @@ template <class C> __device__ __forceinline__ float4 cfg_hn_row(const GatParams 
   else return gat_hn_row(p, row, f);
 }
 
+// The built-in shape gives a row to a WHOLE wavefront (256 columns = 64 lanes x float4): row ids, edge positions, column ids and
+// mask values are the same in every lane.  hipcc cannot see that (they derive from threadIdx.x / 64), keeps them in vector registers
+// and spends 64-bit vector arithmetic on every gather address: two thirds of the group-of-four loop body of the forward walk was
+// address arithmetic.  uni*: the value from lane 0 (v_readfirstlane -> scalar registers, scalar address arithmetic, gathers in the
+// scalar-base + lane-offset form); uld*: a load every lane would issue from the same address of data this launch only READS
+// (structure, mask, per-node terms of an earlier launch) as ONE scalar load through the constant address space.
+typedef const __attribute__((address_space(4))) uint32_t *gat_cu32p;
+typedef const __attribute__((address_space(4))) float *gat_cf32p;
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni64(uint64_t x) { return ((uint64_t)uni32((uint32_t)(x >> 32)) << 32) | uni32((uint32_t)x); }
+template <class C> __device__ __forceinline__ uint32_t uld(const uint32_t *q, uint64_t i) {
+  if constexpr (C::FIX) return ((gat_cu32p)(uintptr_t)q)[i]; else return q[i];
+}
+template <class C> __device__ __forceinline__ float uldf(const float *q, uint64_t i) {
+  if constexpr (C::FIX) return ((gat_cf32p)(uintptr_t)q)[i]; else return q[i];
+}
+template <class C> __device__ __forceinline__ void uni_walk(RowWalk &w) {
+  if constexpr (C::FIX) { w.r = uni64(w.r); w.end = uni64(w.end); w.step = uni64(w.step); }
+}
+
 template <int LPR>
 __global__ void gat_node_fwd_kernel(GatParams p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
@@ -192,9 +212,9 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatParams &p, uint32_t q
   float4 v[G];
   const bool hw = cfg_w<C>(p);
 #pragma unroll
-  for (int j = 0; j < G; j++) { s_[j] = p.t_indices[q + j]; w[j] = hw ? p.edge_w[p.t_perm[q + j]] : 1.0f; }
+  for (int j = 0; j < G; j++) { s_[j] = uld<C>(p.t_indices, q + j); w[j] = hw ? uldf<C>(p.edge_w, uld<C>(p.t_perm, q + j)) : 1.0f; }
 #pragma unroll
-  for (int j = 0; j < G; j++) m_[j] = MAP ? p.dn_map[s_[j]] : s_[j];
+  for (int j = 0; j < G; j++) m_[j] = MAP ? uld<C>(p.dn_map, s_[j]) : s_[j];
 #pragma unroll
   for (int j = 0; j < G; j++) {
     us[j] = 0.f; mx[j] = 0.f; dn[j] = 1.f; t[j] = 0.f; v[j] = make_float4(0, 0, 0, 0);
@@ -242,15 +262,16 @@ __global__ void gat_row_fwd_kernel(GatParams p) {
   const uint32_t F = cfg_F<C>(p), H = cfg_H<C>(p);
   const bool on = f < F;
   const uint32_t h = on ? f / (C::FIX ? 64u : p.D) : 0;
-  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  uni_walk<C>(rw_);
   // (the next row's pointers and score are loaded while this row's edges are walked: one dependent stage less per row)
   uint32_t na = 0, nb = 0;
   float nus = 0.f;
-  if (rw_.r < rw_.end) { na = p.indptr[rw_.r]; nb = p.indptr[rw_.r + 1]; nus = p.u_s[rw_.r * H + h]; }
+  if (rw_.r < rw_.end) { na = uld<C>(p.indptr, rw_.r); nb = uld<C>(p.indptr, rw_.r + 1); nus = p.u_s[rw_.r * H + h]; }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     const uint32_t a = na, b = nb;
     const float as = lrelu02(nus);
-    if (r + rw_.step < rw_.end) { na = p.indptr[r + rw_.step]; nb = p.indptr[r + rw_.step + 1]; nus = p.u_s[(r + rw_.step) * H + h]; }
+    if (r + rw_.step < rw_.end) { na = uld<C>(p.indptr, r + rw_.step); nb = uld<C>(p.indptr, r + rw_.step + 1); nus = p.u_s[(r + rw_.step) * H + h]; }
     // (tail: the row's own z_self slice is asked for AFTER the edge walk: before it, it is four more registers live through the walk --
     //  75 VGPRs, six wavefronts per SIMD, 437 us per launch against 360 with 71 / seven; docs/measurements/r06.md)
     float4 zs = make_float4(0, 0, 0, 0);
@@ -338,9 +359,14 @@ __global__ void gat_t_kernel(GatParams p) {
 // So the attention's share of dz_self and datt[0] are zero and z_self is not read at all by the backward pass (rounds 5 / 6 walked
 // the clamped rows' edges row-wise and kept a sum there that the reference's graph does not have).
 // backward, column side (transposed CSR): alpha, de, d hn, du_n, dz_neigh, datt[1]
-// (register caps -- amdgpu_waves_per_eu(6 / 7) -- measured and dropped: 578 us against 503 at the 87 VGPRs / 5 wavefronts hipcc picks)
+// (round 6a: register caps -- amdgpu_waves_per_eu(6 / 7) -- measured and dropped: 578 us against 503 at the 87 VGPRs / 5 wavefronts hipcc
+//  picked for the kernel of that time)
+// (round 6b, same box: the row walk and the per-edge structure loads on the scalar side -- uni_walk / uld -- 446 -> 367 us per dense
+//  launch, 70 -> 65 VGPRs; held to 64 for the eighth wavefront per SIMD: 373 -> 301 us, no spills.  The forward walk keeps its per-edge
+//  loads in vector registers: with scalar ones it went from 359 to 397 us (one lgkmcnt(0) for all eight scalar loads of a group in
+//  front of its gathers); its row walk alone on the scalar side: 353 -> 340 us, 71 -> 56 VGPRs.)
 template <int LPR, bool MAP, class C>
-__global__ void gat_col_bwd_kernel(GatParams p) {
+__device__ __forceinline__ void gat_col_bwd_body(const GatParams &p) {
   const uint32_t rpb = kGatBlock / LPR, sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const uint32_t f = l * 4, ls = C::LS > 0 ? (uint32_t)C::LS : p.D / 4;
   const uint32_t F = cfg_F<C>(p), H = cfg_H<C>(p);
@@ -348,12 +374,13 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
   const uint32_t h = on ? f / (C::FIX ? 64u : p.D) : 0;
   float4 a1 = make_float4(0, 0, 0, 0), g1 = a1;
   if (on) a1 = gld4(p.att + F + f);
-  const RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  RowWalk rw_ = xcd_row_walk(p.n, rpb, sub);
+  uni_walk<C>(rw_);
   uint32_t na = 0, nb = 0;                              // (next row's pointers ahead: see gat_row_fwd_kernel)
-  if (rw_.r < rw_.end) { na = p.t_indptr[rw_.r]; nb = p.t_indptr[rw_.r + 1]; }
+  if (rw_.r < rw_.end) { na = uld<C>(p.t_indptr, rw_.r); nb = uld<C>(p.t_indptr, rw_.r + 1); }
   for (uint64_t r = rw_.r; r < rw_.end; r += rw_.step) {
     const uint32_t a = na, b = nb;
-    if (r + rw_.step < rw_.end) { na = p.t_indptr[r + rw_.step]; nb = p.t_indptr[r + rw_.step + 1]; }
+    if (r + rw_.step < rw_.end) { na = uld<C>(p.t_indptr, r + rw_.step); nb = uld<C>(p.t_indptr, r + rw_.step + 1); }
     // the column's own hn_j and score (every edge's dN_i . hn_j and alpha_ij need them)
     float4 z = make_float4(0, 0, 0, 0), hn = z;
     if (on) {
@@ -401,6 +428,13 @@ __global__ void gat_col_bwd_kernel(GatParams p) {
     }
   }
 }
+
+// the run-time shapes at the register count hipcc picks; the built-in shape held to 64 VGPRs (see above: the cap costs the
+// run-time forms 5 - 7 spilled dwords, the built-in one none)
+template <int LPR, bool MAP, class C>
+__global__ void gat_col_bwd_kernel(GatParams p) { gat_col_bwd_body<LPR, MAP, C>(p); }
+template <int LPR, bool MAP, class C>
+__global__ void __attribute__((amdgpu_waves_per_eu(8))) gat_col_bwd_w8_kernel(GatParams p) { gat_col_bwd_body<LPR, MAP, C>(p); }
 
 // (Round 3, measured and dropped: edge-parallel forms of the three edge kernels -- lane q owns edge q of a 64-edge chunk for
 //  the scores / softmax, the numerators parked in LDS, the feature-row gathers of a chunk issued four at a time.  Slower
@@ -611,7 +645,15 @@ static int gat_bwd_impl(const uint32_t *d_indptr, const uint32_t *d_indices, con
     SHD_GAT_LAUNCH(gat_t_kernel, lpr, g, st, p);
   }
   if (!accumulate_dz_self) SHD_HIP(hipMemsetAsync(d_dz_self, 0, (size_t)n * F * 4, st));     // (the attention's share of dz_self: zero)
-  if (d_dn_map) SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p, true);
+  if (p.F == 256 && p.H == 4 && p.hn) {            // (the built-in shape of SHD_GAT_LAUNCH_CFG, on its eight-wavefront instantiation)
+    if (d_dn_map) {
+      if (p.edge_w) hipLaunchKernelGGL((gat_col_bwd_w8_kernel<64, true, GatCfg<16, 1, 1, 1>>), dim3(g), dim3(kGatBlock), 0, st, p);
+      else hipLaunchKernelGGL((gat_col_bwd_w8_kernel<64, true, GatCfg<16, 0, 1, 1>>), dim3(g), dim3(kGatBlock), 0, st, p);
+    } else {
+      if (p.edge_w) hipLaunchKernelGGL((gat_col_bwd_w8_kernel<64, false, GatCfg<16, 1, 1, 1>>), dim3(g), dim3(kGatBlock), 0, st, p);
+      else hipLaunchKernelGGL((gat_col_bwd_w8_kernel<64, false, GatCfg<16, 0, 1, 1>>), dim3(g), dim3(kGatBlock), 0, st, p);
+    }
+  } else if (d_dn_map) SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p, true);
   else SHD_GAT_LAUNCH_CFG(gat_col_bwd_kernel, lpr, g, st, p, false);
   hipLaunchKernelGGL(gat_datt_finish_kernel, dim3((2 * F + kDattCols - 1) / kDattCols), dim3(kDattCols * kDattSlices), 0, st,
                      p.datt_part, g, 2 * F, d_datt);
