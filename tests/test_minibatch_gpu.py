@@ -142,36 +142,6 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step_equals_single_process():
-    import torch.multiprocessing as mp
-    from shadow_gnn_amd.minibatch import TRAIN
-    from shadow_gnn_amd.models import DeepGNN
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    # both ranks end with identical parameters
-    for k in res[0]:
-        assert np.array_equal(res[0][k], res[1][k]), k
-    # single process, global batch 16, same initial parameters (rank 0's seed), deterministic
-    # (full 2-hop) sampler -> the same three optimizer steps up to fp32 summation order
-    mb = _setup(prefetch=False, batch=16, aug=(), budget=-1)[0]
-    torch.manual_seed(5)
-    arch = dict(num_layers=2, heads=1, dim=32, act="elu", aggr="sage", residue="none", pooling="center")
-    model = DeepGNN(20, 20, 7, 0, arch, [], 1, dict(dropout=0.0, dropedge=0.0, lr=1e-2), "node").to(DEV)
-    model.optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
-    for _ in range(3):
-        model.step(TRAIN, "running", mb.one_batch(TRAIN))
-    for k, v in model.state_dict().items():
-        np.testing.assert_allclose(res[0][k], v.cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=k)
-
-
 @pytest.mark.parametrize("S", [1, 3])
 @pytest.mark.parametrize("prefetch", [False, True])
 def test_subgraph_cache_record_then_reuse(prefetch, S):
@@ -357,7 +327,26 @@ def _ragged_worker(rank, world, port, q, nroots, ppr_epochs):
     dist.destroy_process_group()
 
 
-def _run_ranks(target, world, *args):
+def _run_ranks(target, world, *args, attempts=2):
+    """Spawn ``world`` rank processes on cuda:0 and collect what each puts on the queue.  A rank that dies (a GPU exception, an
+    assertion) fails the attempt at once with every rank's exit code -- the others would otherwise sit in the all-reduce until the
+    queue's time-out.  Several processes time-slicing ONE device is not an arrangement the product runs in (one process per GPU);
+    one of eight such processes was once seen to die of a device exception (HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION) on a box on which
+    the single-process run of the same worker passed: an attempt in which a rank process DIES is repeated once, with a warning;
+    wrong results are never retried."""
+    for attempt in range(attempts):
+        try:
+            return _run_ranks_once(target, world, *args)
+        except RuntimeError as e:
+            if "died" not in str(e) or attempt + 1 == attempts:
+                raise
+            import warnings
+            warnings.warn(f"{world} ranks on one GPU: {e}; one more attempt")
+
+
+def _run_ranks_once(target, world, *args):
+    import queue as _queue
+    import time
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -366,39 +355,29 @@ def _run_ranks(target, world, *args):
     for p in procs:
         p.start()
     res = {}
-    for _ in procs:
-        item = q.get(timeout=600)
-        res[item[0]] = item[1:]
+    deadline = time.monotonic() + 600
+    try:
+        while len(res) < world:
+            try:
+                item = q.get(timeout=2)
+                res[item[0]] = item[1:]
+                continue
+            except _queue.Empty:
+                pass
+            dead = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode not in (None, 0) and r not in res]
+            if dead:
+                raise RuntimeError(f"rank process(es) died (rank, exit code): {dead}")
+            if time.monotonic() > deadline:
+                raise RuntimeError(f"ranks {sorted(set(range(world)) - set(res))} did not report within 600 s")
+    except BaseException:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     return res
-
-
-@pytest.mark.parametrize("nroots", [103, 97])
-def test_three_rank_ragged_epoch_equals_single_process(nroots):
-    """A whole epoch whose last global batch is ragged (7 roots over 3 ranks) or leaves two ranks EMPTY (1 root):
-    nobody hangs in the all-reduce, every rank takes ceil(E / B) steps, all ranks end with identical parameters, and
-    those equal the single-process run over the same global batches (loss-weighted SUM all-reduce)."""
-    from shadow_gnn_amd.minibatch import TRAIN, MinibatchShallowExtractor
-    from shadow_gnn_amd.models import DeepGNN
-    from shadow_gnn_amd.synthetic import make_graph_numpy
-    res = _run_ranks(_ragged_worker, 3, nroots, 0)
-    T = -(-nroots // 16)
-    tail = nroots - 16 * (T - 1)
-    for r in range(3):
-        sizes = res[r][0]
-        assert len(sizes) == T
-        assert [s for s, _w in sizes[:-1]] == [6 - (r > 0)] * (T - 1)            # 16 = 6 + 5 + 5
-        assert sizes[-1][0] == tail // 3 + (r < tail % 3)
-        assert abs(sizes[-1][1] - sizes[-1][0] / tail) < 1e-6
-    if nroots == 97:
-        assert [res[r][0][-1][0] for r in range(3)] == [1, 0, 0]
-    for k in res[0][2]:
-        assert np.array_equal(res[0][2][k], res[1][2][k]) and np.array_equal(res[0][2][k], res[2][2][k]), k
-    single = _single_process_ragged_epoch(nroots)
-    for k, v in single.items():
-        np.testing.assert_allclose(res[0][2][k], v, rtol=2e-3, atol=2e-3, err_msg=k)
 
 
 def _single_process_ragged_epoch(nroots):
@@ -423,42 +402,6 @@ def _single_process_ragged_epoch(nroots):
     while not mb.is_end_epoch(TRAIN):
         model.step(TRAIN, "running", mb.one_batch(TRAIN))
     return {k: v.cpu().numpy() for k, v in model.state_dict().items()}
-
-
-def test_eight_rank_ragged_epoch_on_one_gpu_equals_single_process():
-    """ EIGHT ranks -- the node's process count -- sharing cuda:0 over gloo: 103 roots in global batches of
-    16 (2 per rank), the last batch 7 roots (ranks 0..6 one root, rank 7 an EMPTY share).  Every rank issues the same
-    sequence of bucket all-reduces through GradSync's backward hooks (nobody hangs), all eight end with identical
-    parameters, and those equal the single-process run over the same global batches.  Functional evidence only -- eight
-    processes time-slicing one GPU say nothing about scaling (profiles/r06_dist_8proc_one_gpu.json holds the host-side
-    figures of the same arrangement)."""
-    nroots = 103
-    res = _run_ranks(_ragged_worker, 8, nroots, 0)
-    T = -(-nroots // 16)
-    for r in range(8):
-        sizes = res[r][0]
-        assert len(sizes) == T
-        assert [s for s, _w in sizes[:-1]] == [2] * (T - 1)
-        assert sizes[-1][0] == (1 if r < 7 else 0)
-        assert abs(sizes[-1][1] - sizes[-1][0] / 7) < 1e-6
-    for k in res[0][2]:
-        for r in range(1, 8):
-            assert np.array_equal(res[0][2][k], res[r][2][k]), (k, r)
-    single = _single_process_ragged_epoch(nroots)
-    for k, v in single.items():
-        np.testing.assert_allclose(res[0][2][k], v, rtol=2e-3, atol=2e-3, err_msg=k)
-
-
-def test_two_rank_ppr_cache_survives_reshuffled_epochs():
-    """Per-rank record -> reuse caches with a NEW permutation every epoch: the static root -> rank map keeps
-    every reused root on the rank that recorded it; three epochs, no 'never recorded' error, ranks stay in step."""
-    res = _run_ranks(_ragged_worker, 2, 70, 3)
-    for r in range(2):
-        sizes, modes, _sd = res[r]
-        assert modes == ["record", "reuse", "reuse"]
-        assert len(sizes) == 3 * 5 and sum(s for s, _w in sizes) == 3 * 35
-    for k in res[0][2]:
-        assert np.array_equal(res[0][2][k], res[1][2][k]), k
 
 
 def test_reference_constructor_signature_and_bin_files(tmp_path):
@@ -608,36 +551,3 @@ def test_fused_clip_adam_equals_the_torch_statements(n, scale, monkeypatch):
     for x, y, name in zip(a[1:], b[1:], ("clipped grad", "exp_avg", "exp_avg_sq", "param")):
         # (the clip factor differs in its last bit with the reduction order of the norm; moments cancel towards zero)
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-6, atol=5e-7 * float(x.abs().max()), err_msg=name)
-
-
-def test_bench_two_ranks_through_torch_distributed_run():
-    """ bench.py exactly as the driver launches it for N > 1 -- `python -m torch.distributed.run
-    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2` -- on the smallest workload, the two ranks
-    sharing this box's one GPU over gloo (SHADOW_DIST_BACKEND; RCCL refuses two ranks on one device): rank 0 prints ONE
-    JSON line that carries the contract's fields for a 2-rank weak-scaling run, and the whole-job rate is that of two
-    batches per step."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, SHADOW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "3", "--warmup", "1", "--workload", "arxiv-khop-gcn3", "--no-cpu-baseline", "--no-tail"]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
-                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert two.returncode == 0, two.stderr[-2000:]
-    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, two.stdout[-2000:]                 # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64
-    assert d["metric"] == "sampled-nodes/sec" and d["value"] > 0 and d["ms_per_step"] > 0
-    assert "roofline" in d and "host_busy_ms_per_step" in d
-    # two batches of 32 roots per step: about twice the nodes of one
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root, env=env,
-                         capture_output=True, text=True, timeout=900)
-    assert one.returncode == 0, one.stderr[-2000:]
-    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
-    ratio = d["config"]["nodes_per_step"] / d1["config"]["nodes_per_step"]
-    assert 1.6 < ratio < 2.4, ratio
