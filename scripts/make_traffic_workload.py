@@ -21,7 +21,8 @@ FILT = "shadow::"
 # bench.py label -> substring of the kernel name (largest launch cluster)
 LABELS = {
     "products-khop3-gat5": {
-        "gat_fwd_tail_F256_H4": "gat_row_fwd_kernel<64 true", "gat_bwd_F256_H4": "gat_col_bwd_kernel<64",
+        "gat_fwd_tail_F256_H4": "gat_row_fwd_kernel<64 true", "gat_bwd_F256_H4": "gat_col_bwd_w8_kernel<64 false",
+        "gat_bwd_map_F256_H4": "gat_col_bwd_w8_kernel<64 true",
         "gemm_nt2_gat_f16_N256": "gemm_nt_fused_kernel<8 5 2 1 false>", "gemm_nt2_gat_f16_N256_Ktail": "gemm_nt_fused_kernel<8 5 2 1 true>",
         "act_norm_bwd_nb2_F256": "act_norm_kernel<64 16 true 2>", "gemm_nt_f16_N256": "gemm_nt_fused_kernel<8 2 1 1 false>",
         "gemm_tn_f16_pair_N256": "gemm_tn_f16_kernel", "gemm_tn_split_N256_K128": "gemm_tn_coop_kernel<2 false>",

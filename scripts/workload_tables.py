@@ -16,7 +16,11 @@ for w in ORDER:
     p = os.path.join(ROOT, "profiles", f"{tag}_bench_{w}.json")
     if not os.path.exists(p):
         continue
-    d = json.loads(open(p).read().strip().splitlines()[-1])
+    raw = open(p).read().strip()
+    try:
+        d = json.loads(raw)                                   # (pretty-printed by scripts/run_campaign.sh)
+    except json.JSONDecodeError:
+        d = json.loads(raw.splitlines()[-1])                  # (bench.py's own output: the line is the last one)
     rs, sa = d["roofline_step"], d.get("sampler_alone") or {}
     steps = d.get("instrumented_steps") or 1
     out.append(f"### {TITLE.get(w, w)} — {d['ms_per_step']:.2f} ms/step, {d['value'] / 1e6:.1f} M sampled nodes/s\n")
