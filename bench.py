@@ -708,6 +708,11 @@ def main():
                      "kernels": ns_keys},
         "roofline_hbm": roofline_hbm, "roofline_mfma": roofline_mfma,
         "kernels": kernels,
+        #  why a small kernel reads longer here than in a rocprofv3 table or in its own loop
+        "kernels_note": ("avg_ms = HIP-event pairs around each launch ON its launch stream during the instrumented steps, in which the prefetch "
+                         "stream keeps working (every step the next batch's row sets, every fourth the four-step sampler call): latency-bound "
+                         "kernels that meet it -- head_*, sg_sample_pipeline, the small row-sparse launches -- read up to 2x their time alone "
+                         "(rocprofv3's per-kernel table of the same command, `sampler_alone`); the large kernels' figures agree with rocprofv3 to 1 - 3 %"),
         "cpu_baseline": cb,
         "dist": dist_info,
     }
